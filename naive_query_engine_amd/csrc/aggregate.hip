@@ -1,0 +1,793 @@
+// aggregate.hip — PhysicalAggregatePlan::execute (reference: src/physical_plan/aggregate/mod.rs:113-222,
+// group split :54-102, operators aggregate/{sum,avg,count,max,min}.rs) fused with the SelectionPlan
+// below it and the key expression group_expr[0].
+//
+// The reference concatenates the input, materialises the key column, builds
+// HashMap<key, Vec<row>> and then calls a virtual update(batch, idx) per row per aggregate.
+// Here ONE streaming kernel reads each referenced column exactly once (coalesced, all loads of
+// an iteration issued before first use), evaluates predicate and key in registers, and
+// accumulates {count, sum, min, max} per (group, value column) in a per-workgroup LDS hash
+// table (open addressing, Fibonacci hash, 64-bit CAS on the key, LDS atomics on the state).
+// Rows whose key does not fit the workgroup table go straight to the global table.  At the end
+// every workgroup merges its LDS table into the global open-addressing table with device-scope
+// atomics; a collect + sort-by-key + finalize tail emits one row per group.
+//
+// Algorithmic HBM bytes per row = 8 B per distinct referenced column (16 B/row for
+// `... from t where id < K group by id % 1024` with count/sum/avg/min/max over v).
+//
+// Semantics kept from the reference (quirk Q10): all accumulation in f64 (`val as f64`), count =
+// non-null values, max starts at f64::MIN, min at f64::MAX, OrderedFloat NaN ordering (max → NaN
+// if any NaN, min ignores NaN), NULL keys dropped, NULL-predicate rows contribute nothing.
+// Sum order differs from the reference's sequential row order (atomics): ≤1e-9 relative.
+#include <algorithm>
+#include <cfloat>
+
+#include "device_utils.hpp"
+#include "nqe_internal.hpp"
+
+namespace nqe {
+
+namespace {
+
+constexpr uint64_t EMPTY_KEY = 0x8000000000000000ull; // i64::MIN; that key uses the extra slot [cap]
+constexpr uint64_t GOLD = 0x9E3779B97F4A7C15ull;
+constexpr int NV = 2;      // value columns per kernel pass
+constexpr int AGG_U = 4;   // rows per thread per iteration
+constexpr int AGG_BLOCK = 1024;
+constexpr uint32_t NAN_BIT = 0x80000000u;
+
+// order-preserving map f64 -> u64 (non-NaN): integer min/max atomics give the f64 min/max
+__host__ __device__ __forceinline__ uint64_t f64_to_ord(double d) {
+    uint64_t b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b = (uint64_t)__double_as_longlong(d);
+#else
+    std::memcpy(&b, &d, 8);
+#endif
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord_to_f64(uint64_t u) {
+    uint64_t b = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+    return __longlong_as_double((long long)b);
+}
+
+struct ColSrc {
+    const void *values;
+    const uint8_t *valid;
+    int32_t dtype;
+    int32_t present;
+};
+
+// global group table: arrays are [V][cap+1]; slot `cap` belongs to EMPTY_KEY itself
+struct GroupTable {
+    uint64_t *keys;     // [cap+1]; keys[cap] != EMPTY_KEY ⇔ special slot in use
+    uint64_t *cnt;      // non-null values
+    double *sum;
+    uint64_t *mn;       // f64_to_ord
+    uint64_t *mx;
+    uint32_t *nan;      // any NaN seen
+    uint32_t cap;       // power of two
+    int32_t shift;      // 64 - log2(cap)
+    int32_t V;
+    int32_t pad;
+};
+
+struct AggArgs {
+    int64_t n;
+    int32_t pred_mode; // 0 none, 1 SimpleExpr over pred_src, 2 Boolean column (bits + validity) in pred_src
+    int32_t has_key;
+    int32_t pred_shares_key;
+    int32_t nv;
+    ColSrc pred_src;
+    ColSrc key_src;
+    SimpleExpr pred;
+    SimpleExpr key;
+    ColSrc val[NV];
+    int32_t val_shares_key[NV];
+    int32_t need_sum[NV];
+    int32_t need_minmax[NV];
+    int32_t v0; // first value slot of this pass in the global table
+    int32_t lds_cap;
+    int32_t lds_shift;
+    int32_t pad;
+};
+
+__device__ __forceinline__ int lds_find_or_insert(uint64_t *keys, uint64_t key, uint32_t cap, int shift) {
+    if (key == EMPTY_KEY) {
+        keys[cap] = 0; // mark special slot used (idempotent plain store)
+        return int(cap);
+    }
+    uint32_t slot = uint32_t((key * GOLD) >> shift);
+    for (int probe = 0; probe < 48; ++probe) {
+        uint64_t k = keys[slot];
+        if (k == key) return int(slot);
+        if (k == EMPTY_KEY) {
+            uint64_t old = atomicCAS((unsigned long long *)&keys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (old == EMPTY_KEY || old == key) return int(slot);
+        }
+        slot = (slot + 1) & (cap - 1);
+    }
+    return -1; // workgroup table full for this key: caller goes to the global table
+}
+
+__device__ __forceinline__ int64_t global_find_or_insert(const GroupTable &g, uint64_t key, int *flags) {
+    if (key == EMPTY_KEY) {
+        __hip_atomic_store(&g.keys[g.cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return int64_t(g.cap);
+    }
+    uint32_t slot = uint32_t((key * GOLD) >> g.shift);
+    for (uint32_t probe = 0; probe < g.cap; ++probe) {
+        uint64_t k = __hip_atomic_load(&g.keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == key) return int64_t(slot);
+        if (k == EMPTY_KEY) {
+            uint64_t old = atomicCAS((unsigned long long *)&g.keys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (old == EMPTY_KEY || old == key) return int64_t(slot);
+        }
+        slot = (slot + 1) & (g.cap - 1);
+    }
+    atomicOr(&flags[NQE_FLAG_TABLE_FULL], 1);
+    return -1;
+}
+
+__device__ __forceinline__ void global_update(const GroupTable &g, int64_t slot, int v, uint64_t cnt, double sum, bool has_sum,
+                                              uint64_t mn, uint64_t mx, bool has_minmax, bool nan) {
+    size_t o = size_t(v) * (size_t(g.cap) + 1) + size_t(slot);
+    if (cnt) atomicAdd((unsigned long long *)&g.cnt[o], (unsigned long long)cnt);
+    if (has_sum) unsafeAtomicAdd(&g.sum[o], sum);
+    if (has_minmax) {
+        atomicMin((unsigned long long *)&g.mn[o], (unsigned long long)mn);
+        atomicMax((unsigned long long *)&g.mx[o], (unsigned long long)mx);
+    }
+    if (nan) atomicOr(&g.nan[o], 1u);
+}
+
+__device__ __forceinline__ bool row_valid(const ColSrc &c, int64_t row) { return c.valid ? get_bit(c.valid, row) : true; }
+
+// ------------------------------------------------------------------ grouped kernel
+__global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, GroupTable g, int *flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t cap = uint32_t(a.lds_cap);
+    const uint32_t slots = cap + 1;
+    uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
+    const uint32_t nvl = a.nv > 0 ? uint32_t(a.nv) : 1u;                 // value columns of THIS pass
+    double *lsum = reinterpret_cast<double *>(lkeys + slots);            // [nvl][slots]
+    uint64_t *lmn = reinterpret_cast<uint64_t *>(lsum + nvl * slots);    // [nvl][slots]
+    uint64_t *lmx = lmn + nvl * slots;                                   // [nvl][slots]
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + nvl * slots);    // [nvl][slots]
+    const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
+
+    for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+        lkeys[s] = EMPTY_KEY;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (uint32_t(j) >= nvl) continue;
+            lsum[j * slots + s] = 0.0;
+            lmn[j * slots + s] = ORD_MAX;
+            lmx[j * slots + s] = ORD_MIN;
+            lcnt[j * slots + s] = 0;
+        }
+    }
+    __syncthreads();
+
+    const int64_t step = int64_t(blockDim.x) * AGG_U;
+    for (int64_t base = int64_t(blockIdx.x) * step; base < a.n; base += int64_t(gridDim.x) * step) {
+        uint64_t kw[AGG_U], pw[AGG_U], vw[NV][AGG_U];
+        // ---- load phase: every referenced word of this iteration is requested before any use
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * blockDim.x + threadIdx.x;
+            bool in = row < a.n;
+            kw[u] = (in && a.has_key) ? load_word(a.key_src.values, a.key_src.dtype, row) : 0;
+            pw[u] = (in && a.pred_mode == 1 && !a.pred_shares_key) ? load_word(a.pred_src.values, a.pred_src.dtype, row) : 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                vw[j][u] = (in && j < a.nv && a.val[j].values && !a.val_shares_key[j])
+                               ? static_cast<const uint64_t *>(a.val[j].values)[row]
+                               : 0;
+        }
+        // ---- compute phase
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * blockDim.x + threadIdx.x;
+            bool pass = row < a.n;
+            if (a.pred_mode == 1) {
+                bool ok = pass && row_valid(a.pred_src, row);
+                uint64_t w = a.pred_shares_key ? kw[u] : pw[u];
+                pass = ok && eval_simple(a.pred, w, ok, flags) != 0;
+            } else if (a.pred_mode == 2) {
+                pass = pass && get_bit(static_cast<const uint8_t *>(a.pred_src.values), row) && row_valid(a.pred_src, row);
+            }
+            uint64_t key = 0;
+            if (a.has_key) {
+                bool kok = pass && row_valid(a.key_src, row);
+                key = eval_simple(a.key, kw[u], kok, flags);
+                pass = kok;
+            }
+            if (!pass) continue;
+            int slot = lds_find_or_insert(lkeys, key, cap, a.lds_shift);
+            int64_t gslot = slot < 0 ? global_find_or_insert(g, key, flags) : 0;
+            if (slot < 0 && gslot < 0) continue;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                if (j >= a.nv) continue;
+                if (!row_valid(a.val[j], row)) continue;
+                bool num = a.need_sum[j] || a.need_minmax[j];
+                double x = num ? word_as_f64(a.val_shares_key[j] ? kw[u] : vw[j][u], a.val[j].dtype) : 0.0;
+                bool isn = num && x != x;
+                uint64_t xo = f64_to_ord(x);
+                if (slot >= 0) {
+                    uint32_t o = uint32_t(j) * slots + uint32_t(slot);
+                    atomicAdd(&lcnt[o], 1u); // < 2^31 rows per workgroup, bit 31 is the NaN flag
+                    if (isn) atomicOr(&lcnt[o], NAN_BIT);
+                    if (a.need_sum[j]) unsafeAtomicAdd(&lsum[o], x);
+                    if (a.need_minmax[j] && !isn) {
+                        atomicMin((unsigned long long *)&lmn[o], (unsigned long long)xo);
+                        atomicMax((unsigned long long *)&lmx[o], (unsigned long long)xo);
+                    }
+                } else {
+                    global_update(g, gslot, a.v0 + j, 1, x, a.need_sum[j] != 0, xo, xo, a.need_minmax[j] && !isn, isn);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- merge this workgroup's table into the global one
+    for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+        uint64_t k = lkeys[s];
+        bool used = (s == cap) ? (k != EMPTY_KEY) : (k != EMPTY_KEY);
+        if (!used) continue;
+        uint64_t key = (s == cap) ? EMPTY_KEY : k;
+        int64_t gslot = global_find_or_insert(g, key, flags);
+        if (gslot < 0) continue;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (j >= a.nv) continue;
+            uint32_t o = uint32_t(j) * slots + s;
+            uint32_t c = lcnt[o];
+            global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], a.need_sum[j] != 0, lmn[o], lmx[o],
+                          a.need_minmax[j] != 0, (c & NAN_BIT) != 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ un-grouped kernel
+struct Partial {
+    uint64_t cnt;
+    double sum;
+    double mn, mx;
+    uint32_t nan;
+    uint32_t pad;
+};
+
+__device__ __forceinline__ double shfl_down_f64(double v, int d) { return __shfl_down(v, d, 64); }
+
+__global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_kernel(AggArgs a, Partial *partials, int *flags) {
+    uint64_t cnt[NV];
+    double sum[NV], mn[NV], mx[NV];
+    uint32_t nanf[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        cnt[j] = 0; sum[j] = 0.0; mn[j] = DBL_MAX; mx[j] = -DBL_MAX; nanf[j] = 0;
+    }
+    const int64_t step = int64_t(blockDim.x) * AGG_U;
+    for (int64_t base = int64_t(blockIdx.x) * step; base < a.n; base += int64_t(gridDim.x) * step) {
+        uint64_t pw[AGG_U], vw[NV][AGG_U];
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * blockDim.x + threadIdx.x;
+            bool in = row < a.n;
+            pw[u] = (in && a.pred_mode == 1) ? load_word(a.pred_src.values, a.pred_src.dtype, row) : 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                vw[j][u] = (in && j < a.nv && a.val[j].values) ? static_cast<const uint64_t *>(a.val[j].values)[row] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * blockDim.x + threadIdx.x;
+            bool pass = row < a.n;
+            if (a.pred_mode == 1) {
+                bool ok = pass && row_valid(a.pred_src, row);
+                pass = ok && eval_simple(a.pred, pw[u], ok, flags) != 0;
+            } else if (a.pred_mode == 2) {
+                pass = pass && get_bit(static_cast<const uint8_t *>(a.pred_src.values), row) && row_valid(a.pred_src, row);
+            }
+            if (!pass) continue;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                if (j >= a.nv || !row_valid(a.val[j], row)) continue;
+                cnt[j] += 1;
+                if (a.need_sum[j] || a.need_minmax[j]) {
+                    double x = word_as_f64(vw[j][u], a.val[j].dtype);
+                    sum[j] += x;
+                    if (x != x) nanf[j] = 1;
+                    else {
+                        mn[j] = x < mn[j] ? x : mn[j];
+                        mx[j] = x > mx[j] ? x : mx[j];
+                    }
+                }
+            }
+        }
+    }
+    __shared__ Partial wave_part[AGG_BLOCK / 64][NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        for (int d = 32; d > 0; d >>= 1) {
+            cnt[j] += __shfl_down((unsigned long long)cnt[j], d, 64);
+            sum[j] += shfl_down_f64(sum[j], d);
+            double omn = shfl_down_f64(mn[j], d), omx = shfl_down_f64(mx[j], d);
+            mn[j] = omn < mn[j] ? omn : mn[j];
+            mx[j] = omx > mx[j] ? omx : mx[j];
+            nanf[j] |= __shfl_down(nanf[j], d, 64);
+        }
+        if (lane_id() == 0) {
+            Partial p{cnt[j], sum[j], mn[j], mx[j], nanf[j], 0};
+            wave_part[threadIdx.x / 64][j] = p;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        int j = threadIdx.x;
+        Partial t{0, 0.0, DBL_MAX, -DBL_MAX, 0, 0};
+        for (int w = 0; w < int(blockDim.x) / 64; ++w) { // fixed order: deterministic
+            const Partial &p = wave_part[w][j];
+            t.cnt += p.cnt; t.sum += p.sum;
+            t.mn = p.mn < t.mn ? p.mn : t.mn;
+            t.mx = p.mx > t.mx ? p.mx : t.mx;
+            t.nan |= p.nan;
+        }
+        partials[size_t(blockIdx.x) * NV + j] = t;
+    }
+}
+
+// folds the per-workgroup partials (in block order) into slot 0 of a cap=1 table
+__global__ void agg_ungrouped_fold_kernel(const Partial *partials, int nblocks, int nv, int v0, GroupTable g) {
+    int j = threadIdx.x;
+    if (j >= nv) return;
+    Partial t{0, 0.0, DBL_MAX, -DBL_MAX, 0, 0};
+    for (int b = 0; b < nblocks; ++b) {
+        const Partial &p = partials[size_t(b) * NV + j];
+        t.cnt += p.cnt; t.sum += p.sum;
+        t.mn = p.mn < t.mn ? p.mn : t.mn;
+        t.mx = p.mx > t.mx ? p.mx : t.mx;
+        t.nan |= p.nan;
+    }
+    size_t o = size_t(v0 + j) * (size_t(g.cap) + 1);
+    g.cnt[o] += t.cnt;
+    g.sum[o] += t.sum;
+    uint64_t omn = f64_to_ord(t.mn), omx = f64_to_ord(t.mx);
+    if (omn < g.mn[o]) g.mn[o] = omn;
+    if (omx > g.mx[o]) g.mx[o] = omx;
+    g.nan[o] |= t.nan;
+}
+
+// ------------------------------------------------------------------ table init / collect / finalize
+__global__ void table_init_kernel(GroupTable g, int mark_slot0) {
+    size_t slots = size_t(g.cap) + 1;
+    size_t total = slots * size_t(g.V);
+    size_t stride = size_t(gridDim.x) * blockDim.x;
+    const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+        if (i < slots) g.keys[i] = (mark_slot0 && i == 0) ? 0ull : EMPTY_KEY;
+        g.cnt[i] = 0;
+        g.sum[i] = 0.0;
+        g.mn[i] = ORD_MAX;
+        g.mx[i] = ORD_MIN;
+        g.nan[i] = 0;
+    }
+}
+
+__global__ void collect_kernel(GroupTable g, uint64_t *out_keys, uint32_t *out_slots, uint32_t *counter) {
+    size_t slots = size_t(g.cap) + 1;
+    size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (size_t s = size_t(blockIdx.x) * blockDim.x + threadIdx.x; s < slots; s += stride) {
+        uint64_t k = g.keys[s];
+        if (k == EMPTY_KEY) continue;
+        uint32_t idx = atomicAdd(counter, 1u);
+        out_keys[idx] = (s == g.cap) ? EMPTY_KEY : k;
+        out_slots[idx] = uint32_t(s);
+    }
+}
+
+struct FinalizeArgs {
+    int32_t naggs;
+    int32_t partial; // 1: emit raw state (4 columns per aggregate)
+    int32_t func[16];
+    int32_t vslot[16];
+    uint64_t *out[64];
+};
+
+__global__ void finalize_kernel(GroupTable g, const uint32_t *sorted_slots, int64_t G, FinalizeArgs f) {
+    size_t slots = size_t(g.cap) + 1;
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < G; r += stride) {
+        uint32_t s = sorted_slots ? sorted_slots[r] : 0;
+        for (int i = 0; i < f.naggs; ++i) {
+            size_t o = size_t(f.vslot[i]) * slots + s;
+            uint64_t cnt = g.cnt[o];
+            double sum = g.sum[o];
+            double mn = ord_to_f64(g.mn[o]);
+            double mx = g.nan[o] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(g.mx[o]);
+            if (f.partial) {
+                f.out[4 * i + 0][r] = cnt;
+                f.out[4 * i + 1][r] = d2u(sum);
+                f.out[4 * i + 2][r] = d2u(mn);
+                f.out[4 * i + 3][r] = d2u(mx);
+            } else {
+                uint64_t w;
+                switch (f.func[i]) {
+                case NQE_AGG_COUNT: w = cnt; break;                                   // count.rs:76
+                case NQE_AGG_SUM: w = d2u(sum); break;                                // sum.rs:115
+                case NQE_AGG_AVG: w = d2u(sum / double(uint32_t(cnt))); break;        // avg.rs:121 (cnt is u32)
+                case NQE_AGG_MIN: w = d2u(mn); break;
+                default: w = d2u(mx); break;
+                }
+                f.out[i][r] = w;
+            }
+        }
+    }
+}
+
+// merges partial-state rows (one row per (rank, group)) into the table; V = naggs
+__global__ void merge_states_kernel(GroupTable g, const uint64_t *keys, int64_t n, int naggs, const uint64_t *const *state_cols,
+                                    int *flags) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) {
+        int64_t slot = keys ? global_find_or_insert(g, keys[r], flags) : 0;
+        if (slot < 0) continue;
+        for (int i = 0; i < naggs; ++i) {
+            uint64_t cnt = state_cols[4 * i + 0][r];
+            double sum = u2d(state_cols[4 * i + 1][r]);
+            double mn = u2d(state_cols[4 * i + 2][r]);
+            double mx = u2d(state_cols[4 * i + 3][r]);
+            bool nan = mx != mx;
+            global_update(g, slot, i, cnt, sum, true, f64_to_ord(mn), nan ? f64_to_ord(-DBL_MAX) : f64_to_ord(mx), true, nan);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct TableBufs {
+    BufRef keys, cnt, sum, mn, mx, nan;
+    GroupTable g{};
+};
+
+TableBufs make_table(nqe_ctx *ctx, uint32_t cap, int V, bool mark_slot0) {
+    TableBufs t;
+    size_t slots = size_t(cap) + 1;
+    if (V < 1) V = 1;
+    t.keys = dev_alloc(ctx, slots * 8);
+    t.cnt = dev_alloc(ctx, slots * size_t(V) * 8);
+    t.sum = dev_alloc(ctx, slots * size_t(V) * 8);
+    t.mn = dev_alloc(ctx, slots * size_t(V) * 8);
+    t.mx = dev_alloc(ctx, slots * size_t(V) * 8);
+    t.nan = dev_alloc(ctx, slots * size_t(V) * 4);
+    t.g.keys = (uint64_t *)t.keys->ptr;
+    t.g.cnt = (uint64_t *)t.cnt->ptr;
+    t.g.sum = (double *)t.sum->ptr;
+    t.g.mn = (uint64_t *)t.mn->ptr;
+    t.g.mx = (uint64_t *)t.mx->ptr;
+    t.g.nan = (uint32_t *)t.nan->ptr;
+    t.g.cap = cap;
+    int lg = 0;
+    while ((1u << lg) < cap) ++lg;
+    t.g.shift = cap == 1 ? 63 : 64 - lg;
+    t.g.V = V;
+    launch(ctx, "agg_table_init", table_init_kernel, dim3(stream_grid(ctx, int64_t(slots) * V, 256)), dim3(256), 0, t.g,
+           mark_slot0 ? 1 : 0);
+    return t;
+}
+
+ColSrc src_of(const DevColumn &c) {
+    ColSrc s;
+    s.values = c.values ? c.values->ptr : nullptr;
+    s.valid = c.valid();
+    s.dtype = c.dtype;
+    s.present = 1;
+    return s;
+}
+
+SimpleExpr plain_column_expr(int dtype) {
+    SimpleExpr s;
+    std::memset(&s, 0, sizeof(s));
+    s.src_dtype = s.out_dtype = dtype;
+    s.aux[0].pow2_shift = s.aux[1].pow2_shift = -1;
+    return s;
+}
+
+struct AggPlan {
+    std::vector<int> val_cols;  // distinct value columns
+    std::vector<int> vslot;     // aggregate -> value slot
+    std::vector<int> need_sum, need_minmax;
+};
+
+AggPlan plan_aggs(const nqe_table *in, const nqe_aggregate *aggs, int naggs) {
+    if (naggs < 0 || naggs > 16) fail(NQE_ERR_NOT_SUPPORTED, "at most 16 aggregates per call");
+    AggPlan p;
+    for (int i = 0; i < naggs; ++i) {
+        const nqe_aggregate &a = aggs[i];
+        if (a.func < NQE_AGG_COUNT || a.func > NQE_AGG_AVG) fail(NQE_ERR_NO_MATCH_FUNCTION, "unknown aggregate function");
+        if (a.column < 0 || size_t(a.column) >= in->cols.size()) fail(NQE_ERR_NOT_SUPPORTED, "aggregate column index out of range");
+        int dt = in->cols[size_t(a.column)].dtype;
+        if (a.func != NQE_AGG_COUNT && !is_word_type(dt)) // sum.rs:93 / :109
+            fail(NQE_ERR_NOT_SUPPORTED, "aggregate func for this column type is not supported");
+        auto it = std::find(p.val_cols.begin(), p.val_cols.end(), a.column);
+        int j;
+        if (it == p.val_cols.end()) {
+            p.val_cols.push_back(a.column);
+            p.need_sum.push_back(0);
+            p.need_minmax.push_back(0);
+            j = int(p.val_cols.size()) - 1;
+        } else {
+            j = int(it - p.val_cols.begin());
+        }
+        p.vslot.push_back(j);
+        if (a.func == NQE_AGG_SUM || a.func == NQE_AGG_AVG) p.need_sum[size_t(j)] = 1;
+        if (a.func == NQE_AGG_MIN || a.func == NQE_AGG_MAX) p.need_minmax[size_t(j)] = 1;
+    }
+    return p;
+}
+
+struct AggResult {
+    std::unique_ptr<nqe_table> out, keys;
+};
+
+// collect → sort by key → finalize
+AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const nqe_aggregate *aggs, int naggs,
+               const std::vector<int> &vslot, bool partial) {
+    int64_t G = 1;
+    BufRef sorted_keys, sorted_slots;
+    if (grouped) {
+        size_t slots = size_t(tb.g.cap) + 1;
+        BufRef ck = dev_alloc(ctx, slots * 8), cs = dev_alloc(ctx, slots * 4), counter = dev_alloc_zero(ctx, 4);
+        launch(ctx, "agg_collect", collect_kernel, dim3(stream_grid(ctx, int64_t(slots), 256)), dim3(256), 0, tb.g,
+               (uint64_t *)ck->ptr, (uint32_t *)cs->ptr, (uint32_t *)counter->ptr);
+        G = int64_t(read_scalar(ctx, (const uint32_t *)counter->ptr));
+        sorted_keys = dev_alloc(ctx, size_t(G) * 8 + 8);
+        sorted_slots = dev_alloc(ctx, size_t(G) * 4 + 8);
+        radix_sort_pairs_u64(ctx, (const uint64_t *)ck->ptr, (const uint32_t *)cs->ptr, (uint64_t *)sorted_keys->ptr,
+                             (uint32_t *)sorted_slots->ptr, G, key_dtype == NQE_INT64);
+    }
+    AggResult r;
+    r.out = std::make_unique<nqe_table>();
+    r.out->ctx = ctx;
+    r.out->rows = G;
+    FinalizeArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.naggs = naggs;
+    f.partial = partial ? 1 : 0;
+    for (int i = 0; i < naggs; ++i) {
+        f.func[i] = aggs[i].func;
+        f.vslot[i] = vslot[size_t(i)];
+        if (partial) {
+            const int dts[4] = {NQE_UINT64, NQE_FLOAT64, NQE_FLOAT64, NQE_FLOAT64};
+            for (int k = 0; k < 4; ++k) {
+                r.out->cols.push_back(make_word_column(ctx, dts[k], G, false));
+                f.out[4 * i + k] = (uint64_t *)r.out->cols.back().values->ptr;
+            }
+        } else {
+            r.out->cols.push_back(make_word_column(ctx, aggs[i].func == NQE_AGG_COUNT ? NQE_UINT64 : NQE_FLOAT64, G, false));
+            f.out[i] = (uint64_t *)r.out->cols.back().values->ptr;
+        }
+    }
+    if (G > 0 && naggs > 0)
+        launch(ctx, "agg_finalize", finalize_kernel, dim3(stream_grid(ctx, G, 256)), dim3(256), 0, tb.g,
+               grouped ? (const uint32_t *)sorted_slots->ptr : (const uint32_t *)nullptr, G, f);
+    if (grouped) {
+        r.keys = std::make_unique<nqe_table>();
+        r.keys->ctx = ctx;
+        r.keys->rows = G;
+        DevColumn kc;
+        kc.dtype = key_dtype;
+        kc.length = G;
+        kc.values = sorted_keys;
+        r.keys->cols.push_back(kc);
+    }
+    return r;
+}
+
+AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes,
+                        const nqe_expr_node *group, int group_nodes, const nqe_aggregate *aggs, int naggs, bool partial) {
+    AggPlan plan = plan_aggs(in, aggs, naggs);
+    const bool grouped = group && group_nodes > 0;
+    const bool has_pred = pred && pred_nodes > 0;
+
+    AggArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n = in->rows;
+    a.pred.aux[0].pow2_shift = a.pred.aux[1].pow2_shift = -1;
+    a.key.aux[0].pow2_shift = a.key.aux[1].pow2_shift = -1;
+
+    // ---- key expression (group_expr[0] only, quirk Q8)
+    ExprInfo kinfo;
+    int key_col = -1;
+    if (grouped) {
+        kinfo = analyze_expr(in, group, group_nodes);
+        if (kinfo.out_dtype == NQE_UTF8)
+            fail(NQE_ERR_NOT_SUPPORTED, "group by Utf8 keys is not supported on the device path yet");
+        if (kinfo.out_dtype != NQE_INT64 && kinfo.out_dtype != NQE_UINT64) // aggregate/mod.rs:217
+            fail(NQE_ERR_NOT_SUPPORTED, "group by only support by `Int64`, `UInt64`, `String`");
+        if (!kinfo.simple && has_pred) {
+            // A general key expression must only see rows that survive the filter (it may divide by a
+            // value the filter excludes): run the selection first, then aggregate without a predicate.
+            nqe_table *sel = nullptr;
+            nqe_status st = nqe_selection_execute(ctx, in, pred, pred_nodes, &sel);
+            if (st != NQE_OK) fail(st, ctx->last_error);
+            std::unique_ptr<nqe_table> guard(sel);
+            return run_aggregate(ctx, sel, nullptr, 0, group, group_nodes, aggs, naggs, partial);
+        }
+    }
+    // ---- predicate
+    DevColumn pred_col; // keeps a materialised predicate alive
+    if (has_pred) {
+        ExprInfo pinfo = analyze_expr(in, pred, pred_nodes);
+        if (pinfo.out_dtype != NQE_BOOLEAN)
+            fail(NQE_ERR_NOT_SUPPORTED, "predicate is not a BooleanArray (selection.rs:61 unwrap panics)");
+        if (pinfo.simple) {
+            a.pred_mode = 1;
+            a.pred = pinfo.s;
+            a.pred_src = src_of(in->cols[size_t(pinfo.s.col)]);
+        } else {
+            pred_col = evaluate_expr(ctx, in, pred, pred_nodes);
+            a.pred_mode = 2;
+            a.pred_src = src_of(pred_col);
+        }
+    }
+    DevColumn key_colbuf;
+    if (grouped) {
+        a.has_key = 1;
+        if (kinfo.simple) {
+            a.key = kinfo.s;
+            key_col = kinfo.s.col;
+            a.key_src = src_of(in->cols[size_t(key_col)]);
+        } else {
+            key_colbuf = evaluate_expr(ctx, in, group, group_nodes);
+            a.key = plain_column_expr(kinfo.out_dtype);
+            a.key_src = src_of(key_colbuf);
+        }
+        a.pred_shares_key = (a.pred_mode == 1 && key_col >= 0 && a.pred.col == key_col) ? 1 : 0;
+    }
+
+    const int V = int(plan.val_cols.size());
+    uint32_t cap = 1;
+    if (grouped) {
+        int64_t guess = std::min<int64_t>(std::max<int64_t>(in->rows, 1), int64_t(1) << 20);
+        cap = 4096;
+        while (int64_t(cap) < 2 * guess) cap <<= 1;
+    }
+    for (int attempt = 0;; ++attempt) {
+        TableBufs tb = make_table(ctx, cap, V, !grouped);
+        for (int v0 = 0; v0 < std::max(V, 1); v0 += NV) {
+            a.nv = std::min(NV, V - v0);
+            if (a.nv < 0) a.nv = 0;
+            a.v0 = v0;
+            for (int j = 0; j < NV; ++j) {
+                std::memset(&a.val[j], 0, sizeof(ColSrc));
+                a.val_shares_key[j] = a.need_sum[j] = a.need_minmax[j] = 0;
+                if (j < a.nv) {
+                    int c = plan.val_cols[size_t(v0 + j)];
+                    const DevColumn &dc = in->cols[size_t(c)];
+                    a.val[j] = src_of(dc);
+                    if (!is_word_type(dc.dtype)) a.val[j].values = nullptr; // count-only over Boolean/Utf8: validity only
+                    a.need_sum[j] = plan.need_sum[size_t(v0 + j)];
+                    a.need_minmax[j] = plan.need_minmax[size_t(v0 + j)];
+                    a.val_shares_key[j] = (grouped && c == key_col && is_word_type(dc.dtype)) ? 1 : 0;
+                }
+            }
+            if (in->rows == 0) continue;
+            if (grouped) {
+                a.lds_cap = 2048; // 1 value column: 72 KB (2 WG/CU); 2: 128 KB (1 WG/CU)
+                int lg = 0;
+                while ((1 << lg) < a.lds_cap) ++lg;
+                a.lds_shift = 64 - lg;
+                size_t slots = size_t(a.lds_cap) + 1;
+                size_t shmem = slots * 8 + size_t(std::max(a.nv, 1)) * slots * (8 + 8 + 8 + 4);
+                shmem = (shmem + 15) / 16 * 16;
+                int blocks_per_cu = shmem <= 80 * 1024 ? 2 : 1;
+                int grid = int(std::min<int64_t>(int64_t(ctx->num_cus) * blocks_per_cu,
+                                                 (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
+                launch(ctx, "agg_grouped", agg_grouped_kernel, dim3(grid), dim3(AGG_BLOCK), shmem, a, tb.g, ctx->d_flags);
+            } else {
+                int grid = int(std::min<int64_t>(int64_t(ctx->num_cus) * 2,
+                                                 (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
+                BufRef partials = dev_alloc(ctx, size_t(grid) * NV * sizeof(Partial));
+                launch(ctx, "agg_ungrouped", agg_ungrouped_kernel, dim3(grid), dim3(AGG_BLOCK), 0, a, (Partial *)partials->ptr,
+                       ctx->d_flags);
+                launch(ctx, "agg_ungrouped_fold", agg_ungrouped_fold_kernel, dim3(1), dim3(64), 0,
+                       (const Partial *)partials->ptr, grid, a.nv, v0, tb.g);
+            }
+        }
+        int f[NQE_NUM_FLAGS];
+        flags_read(ctx, f);
+        if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
+        if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
+        if (f[NQE_FLAG_TABLE_FULL]) {
+            if (cap >= (1u << 31) || attempt > 8) fail(NQE_ERR_OUT_OF_MEMORY, "group table overflow");
+            cap <<= 2;
+            flags_reset(ctx);
+            continue;
+        }
+        return emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial);
+    }
+}
+
+} // namespace
+
+} // namespace nqe
+
+using namespace nqe;
+
+extern "C" {
+
+nqe_status nqe_aggregate_execute(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int32_t pred_nodes,
+                                 const nqe_expr_node *group, int32_t group_nodes, const nqe_aggregate *aggs,
+                                 int32_t num_aggs, nqe_table **out, nqe_table **keys_out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !in || !out || (num_aggs > 0 && !aggs)) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    flags_reset(ctx);
+    AggResult r = run_aggregate(ctx, in, pred, pred_nodes, group, group_nodes, aggs, num_aggs, false);
+    *out = r.out.release();
+    if (keys_out) *keys_out = r.keys.release();
+    NQE_API_END()
+}
+
+nqe_status nqe_aggregate_partial(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int32_t pred_nodes,
+                                 const nqe_expr_node *group, int32_t group_nodes, const nqe_aggregate *aggs,
+                                 int32_t num_aggs, nqe_table **state_out, nqe_table **keys_out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !in || !state_out || (num_aggs > 0 && !aggs)) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (group && group_nodes > 0 && !keys_out) fail(NQE_ERR_INVALID_ARGUMENT, "keys_out is required for grouped partials");
+    flags_reset(ctx);
+    AggResult r = run_aggregate(ctx, in, pred, pred_nodes, group, group_nodes, aggs, num_aggs, true);
+    *state_out = r.out.release();
+    if (keys_out) *keys_out = r.keys.release();
+    NQE_API_END()
+}
+
+nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, const nqe_table *const *keys, int32_t n,
+                               const nqe_aggregate *aggs, int32_t num_aggs, nqe_table **out, nqe_table **keys_out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !states || n <= 0 || !out || num_aggs < 0 || num_aggs > 16 || (num_aggs > 0 && !aggs))
+        fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    const bool grouped = keys != nullptr && keys[0] != nullptr;
+    int key_dtype = NQE_INT64;
+    int64_t total = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!states[k] || int(states[k]->cols.size()) != 4 * num_aggs) fail(NQE_ERR_INVALID_ARGUMENT, "state table shape mismatch");
+        if (grouped) {
+            if (!keys[k] || keys[k]->cols.size() != 1 || keys[k]->rows != states[k]->rows)
+                fail(NQE_ERR_INVALID_ARGUMENT, "keys table shape mismatch");
+            key_dtype = keys[k]->cols[0].dtype;
+        }
+        total += states[k]->rows;
+    }
+    flags_reset(ctx);
+    uint32_t cap = 1;
+    if (grouped) {
+        cap = 4096;
+        while (int64_t(cap) < 2 * total) cap <<= 1;
+    }
+    TableBufs tb = make_table(ctx, cap, num_aggs, !grouped);
+    std::vector<int> vslot;
+    for (int i = 0; i < num_aggs; ++i) vslot.push_back(i);
+    BufRef ptrs = dev_alloc(ctx, size_t(4 * std::max(num_aggs, 1)) * sizeof(void *));
+    for (int k = 0; k < n; ++k) {
+        int64_t rows = states[k]->rows;
+        if (rows == 0 || num_aggs == 0) {
+            if (rows && grouped) { /* keys still need inserting */ } else continue;
+        }
+        std::vector<const uint64_t *> h(size_t(4 * std::max(num_aggs, 1)), nullptr);
+        for (int c = 0; c < 4 * num_aggs; ++c) h[size_t(c)] = states[k]->cols[size_t(c)].words();
+        NQE_HIP_CHECK(hipMemcpyAsync(ptrs->ptr, h.data(), h.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+        launch(ctx, "agg_merge_states", merge_states_kernel, dim3(stream_grid(ctx, rows, 256)), dim3(256), 0, tb.g,
+               grouped ? keys[k]->cols[0].words() : (const uint64_t *)nullptr, rows, num_aggs,
+               (const uint64_t *const *)ptrs->ptr, ctx->d_flags);
+        sync(ctx); // `h` / ptrs are reused by the next partial
+    }
+    throw_on_flags(ctx);
+    AggResult r = emit(ctx, tb, grouped, key_dtype, aggs, num_aggs, vslot, false);
+    *out = r.out.release();
+    if (keys_out) *keys_out = r.keys.release();
+    NQE_API_END()
+}
+
+} // extern "C"

@@ -1,0 +1,321 @@
+// expr.hip — PhysicalExpr::evaluate on the device (reference: src/physical_plan/expression/
+// binary.rs:108-155, column.rs:39-57, literal.rs:32-34; arrow-rs 13 compare / kleene /
+// arithmetic kernels at the call sites binary.rs:127-153).
+//
+// Two evaluation forms:
+//   * general: one streaming kernel per binary node (what arrow does), except that literals
+//     stay scalars in registers instead of being materialised as n-row columns
+//     (logical_plan/expression.rs:210-222, the TODO at binary.rs:121);
+//   * fused:   `col [op lit]{0,2}` shapes (SimpleExpr) are evaluated inside the consumer
+//     kernel (compaction, aggregation) from the streamed word — no temporary at all.
+#include "device_utils.hpp"
+#include "nqe_internal.hpp"
+
+namespace nqe {
+
+namespace {
+
+struct Node {
+    int kind = 0, op = 0, column = 0, dtype = 0;
+    bool lit_null = false;
+    uint64_t lit = 0;
+    int left = -1, right = -1; // children (indices into the node vector)
+    int out_dtype = NQE_NULLTYPE;
+};
+
+bool is_compare(int op) { return op >= NQE_OP_EQ && op <= NQE_OP_GT_EQ; }
+bool is_logic(int op) { return op == NQE_OP_AND || op == NQE_OP_OR; }
+bool is_arith(int op) { return op >= NQE_OP_PLUS && op <= NQE_OP_MODULOS; }
+
+// builds the tree and type-checks it exactly where binary.rs does
+std::vector<Node> parse(const nqe_table *in, const nqe_expr_node *nodes, int n, int *root) {
+    if (!nodes || n <= 0) fail(NQE_ERR_INVALID_ARGUMENT, "empty expression");
+    std::vector<Node> t;
+    std::vector<int> st;
+    for (int i = 0; i < n; ++i) {
+        const nqe_expr_node &nd = nodes[i];
+        Node x;
+        x.kind = nd.kind;
+        if (nd.kind == NQE_EXPR_COLUMN) {
+            if (nd.column < 0 || size_t(nd.column) >= in->cols.size())
+                fail(NQE_ERR_NOT_SUPPORTED, "column index out of range (RecordBatch::column panics)");
+            x.column = nd.column;
+            x.out_dtype = in->cols[size_t(nd.column)].dtype;
+        } else if (nd.kind == NQE_EXPR_LITERAL) {
+            x.dtype = nd.dtype;
+            x.lit_null = nd.is_null != 0 || nd.dtype == NQE_NULLTYPE;
+            x.lit = nd.dtype == NQE_BOOLEAN ? uint64_t(nd.value.boolean != 0) : nd.value.u64;
+            x.out_dtype = nd.dtype;
+            if (nd.dtype == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 literals are not supported on the device path");
+        } else if (nd.kind == NQE_EXPR_BINARY) {
+            if (st.size() < 2) fail(NQE_ERR_INVALID_ARGUMENT, "malformed expression");
+            x.right = st.back(); st.pop_back();
+            x.left = st.back(); st.pop_back();
+            x.op = nd.op;
+            int ldt = t[size_t(x.left)].out_dtype, rdt = t[size_t(x.right)].out_dtype;
+            if (ldt != rdt) // binary.rs:114-119
+                fail(NQE_ERR_INTERVAL, "Cannot evaluate binary expression with types " + std::to_string(ldt) + " and " +
+                                           std::to_string(rdt));
+            if (is_compare(x.op)) {
+                if (ldt == NQE_NULLTYPE) fail(NQE_ERR_ARROW, "comparison on Null arrays is not supported");
+                if (ldt == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 comparison is not supported on the device path yet");
+                x.out_dtype = NQE_BOOLEAN;
+            } else if (is_logic(x.op)) {
+                if (ldt != NQE_BOOLEAN) // binary_op! (binary.rs:32-42)
+                    fail(NQE_ERR_INTERVAL, "Cannot evaluate binary expression And/Or with non-Boolean types");
+                x.out_dtype = NQE_BOOLEAN;
+            } else if (is_arith(x.op)) {
+                if (!is_word_type(ldt)) // arithemic_op! `_ => unimplemented!()` (binary.rs:85)
+                    fail(NQE_ERR_NOT_SUPPORTED, "arithmetic on this type is unimplemented!() (binary.rs:85)");
+                x.out_dtype = ldt;
+            } else {
+                fail(NQE_ERR_INVALID_ARGUMENT, "unknown operator");
+            }
+        } else {
+            fail(NQE_ERR_INVALID_ARGUMENT, "unknown expression node kind");
+        }
+        t.push_back(x);
+        st.push_back(int(t.size()) - 1);
+    }
+    if (st.size() != 1) fail(NQE_ERR_INVALID_ARGUMENT, "malformed expression");
+    *root = st[0];
+    return t;
+}
+
+OpAux make_aux(int op, int dt, uint64_t lit) {
+    OpAux a;
+    a.pow2_shift = -1;
+    a.pad = 0;
+    a.abs_lit = 0;
+    if ((op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS) && (dt == NQE_INT64 || dt == NQE_UINT64) && lit != 0) {
+        uint64_t ab = lit;
+        if (dt == NQE_INT64 && int64_t(lit) < 0) ab = 0ull - lit;
+        a.abs_lit = ab;
+        if ((ab & (ab - 1)) == 0) {
+            int s = 0;
+            while ((ab >> s) != 1) ++s;
+            a.pow2_shift = s;
+        }
+    }
+    return a;
+}
+
+// col [op lit]{0,2}
+bool match_simple(const std::vector<Node> &t, int i, SimpleExpr *s) {
+    const Node &x = t[size_t(i)];
+    if (x.kind == NQE_EXPR_COLUMN) {
+        std::memset(s, 0, sizeof(*s));
+        s->col = x.column;
+        s->src_dtype = x.out_dtype;
+        s->out_dtype = x.out_dtype;
+        s->aux[0].pow2_shift = s->aux[1].pow2_shift = -1;
+        return x.out_dtype != NQE_UTF8;
+    }
+    if (x.kind != NQE_EXPR_BINARY || is_logic(x.op)) return false;
+    const Node &l = t[size_t(x.left)], &r = t[size_t(x.right)];
+    bool lit_left;
+    int sub;
+    const Node *litn;
+    if (r.kind == NQE_EXPR_LITERAL && !r.lit_null && l.kind != NQE_EXPR_LITERAL) {
+        lit_left = false; sub = x.left; litn = &r;
+    } else if (l.kind == NQE_EXPR_LITERAL && !l.lit_null && r.kind != NQE_EXPR_LITERAL) {
+        lit_left = true; sub = x.right; litn = &l;
+    } else {
+        return false;
+    }
+    if (!match_simple(t, sub, s) || s->nops >= 2) return false;
+    int k = s->nops++;
+    s->op[k] = x.op;
+    s->lit_left[k] = lit_left ? 1 : 0;
+    s->op_dtype[k] = litn->dtype;
+    s->lit[k] = litn->lit;
+    s->aux[k] = lit_left ? make_aux(0, 0, 0) : make_aux(x.op, litn->dtype, litn->lit);
+    s->out_dtype = x.out_dtype;
+    return true;
+}
+
+// ------------------------------------------------------------------ kernels
+struct Operand {
+    const void *values;   // words or packed bits
+    const uint8_t *valid; // or null
+    uint64_t lit;
+    int32_t is_lit;
+    int32_t lit_null;
+};
+
+// out = a op b, 64 consecutive rows per wave so that ballots form the packed result words.
+// bool_out: result is Boolean (compare / and / or) → packed into out_bits.
+__global__ void __launch_bounds__(256) binary_kernel(Operand a, Operand b, int op, int dt, OpAux aux, int64_t n,
+                                                     uint64_t *out_words, uint64_t *out_bits, uint64_t *out_valid,
+                                                     int *flags) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const int64_t n_pad = (n + 63) / 64 * 64;
+    const bool logic = op == NQE_OP_AND || op == NQE_OP_OR;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < n_pad; j += stride) {
+        const bool in = j < n;
+        bool av = in && (a.is_lit ? !a.lit_null : (a.valid ? get_bit(a.valid, j) : true));
+        bool bv = in && (b.is_lit ? !b.lit_null : (b.valid ? get_bit(b.valid, j) : true));
+        uint64_t x = a.is_lit ? a.lit : (in ? load_word(a.values, dt, j) : 0);
+        uint64_t y = b.is_lit ? b.lit : (in ? load_word(b.values, dt, j) : 0);
+        bool ok;
+        uint64_t r;
+        if (logic) {
+            // and_kleene / or_kleene
+            bool lb = av && x, rb = bv && y;
+            if (op == NQE_OP_AND) {
+                ok = (av && bv) || (av && !lb) || (bv && !rb);
+                r = ok && lb && rb;
+            } else {
+                ok = (av && bv) || lb || rb;
+                r = ok && (lb || rb);
+            }
+        } else {
+            ok = av && bv;
+            r = in ? apply_binary(op, dt, x, y, aux, ok, flags) : 0;
+        }
+        if (out_words) {
+            if (in) out_words[j] = ok ? r : 0;
+        } else {
+            uint64_t w = __ballot(ok && r);
+            if (lane_id() == 0) out_bits[j >> 6] = w;
+        }
+        if (out_valid) {
+            uint64_t v = __ballot(ok);
+            if (lane_id() == 0) out_valid[j >> 6] = v;
+        }
+    }
+}
+
+__global__ void fill_words_kernel(uint64_t *out, uint64_t v, int64_t n) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < n; j += stride) out[j] = v;
+}
+
+struct Value {
+    bool is_lit = false;
+    bool lit_null = false;
+    uint64_t lit = 0;
+    int dtype = NQE_NULLTYPE;
+    DevColumn col;
+};
+
+DevColumn materialise_literal(nqe_ctx *ctx, int dtype, uint64_t lit, bool lit_null, int64_t n) {
+    // ScalarValue::into_array (logical_plan/expression.rs:210-222)
+    if (dtype == NQE_NULLTYPE) fail(NQE_ERR_NOT_SUPPORTED, "Null-typed arrays are not supported on the device path");
+    DevColumn c;
+    if (dtype == NQE_BOOLEAN) {
+        c = make_bool_column(ctx, n, lit_null);
+        NQE_HIP_CHECK(hipMemsetAsync(c.values->ptr, (!lit_null && lit) ? 0xFF : 0x00, bitmap_alloc_bytes(n), ctx->stream));
+    } else {
+        c = make_word_column(ctx, dtype, n, lit_null);
+        if (n)
+            launch(ctx, "fill_words", fill_words_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0,
+                   (uint64_t *)c.values->ptr, lit_null ? 0ull : lit, n);
+    }
+    if (lit_null) {
+        NQE_HIP_CHECK(hipMemsetAsync(c.validity->ptr, 0, bitmap_alloc_bytes(n), ctx->stream));
+        c.null_count = n;
+    }
+    return c;
+}
+
+Operand operand_of(const Value &v) {
+    Operand o;
+    o.values = v.is_lit ? nullptr : v.col.values->ptr;
+    o.valid = v.is_lit ? nullptr : v.col.valid();
+    o.lit = v.lit;
+    o.is_lit = v.is_lit;
+    o.lit_null = v.lit_null;
+    return o;
+}
+
+Value eval_node(nqe_ctx *ctx, const nqe_table *in, const std::vector<Node> &t, int i) {
+    const Node &x = t[size_t(i)];
+    Value v;
+    v.dtype = x.out_dtype;
+    if (x.kind == NQE_EXPR_COLUMN) {
+        v.col = in->cols[size_t(x.column)]; // Arc clone (column.rs:41-43)
+        return v;
+    }
+    if (x.kind == NQE_EXPR_LITERAL) {
+        v.is_lit = true;
+        v.lit = x.lit;
+        v.lit_null = x.lit_null;
+        return v;
+    }
+    Value l = eval_node(ctx, in, t, x.left);
+    Value r = eval_node(ctx, in, t, x.right);
+    const int64_t n = in->rows;
+    if (l.is_lit && r.is_lit) { // lit op lit: materialise one side, as into_array would
+        l.col = materialise_literal(ctx, l.dtype, l.lit, l.lit_null, n);
+        l.is_lit = false;
+    }
+    const int dt = l.dtype;
+    bool need_valid = (l.is_lit ? l.lit_null : l.col.validity != nullptr) || (r.is_lit ? r.lit_null : r.col.validity != nullptr);
+    bool bool_out = x.out_dtype == NQE_BOOLEAN;
+    v.col = bool_out ? make_bool_column(ctx, n, need_valid) : make_word_column(ctx, x.out_dtype, n, need_valid);
+    OpAux aux = r.is_lit && !r.lit_null ? make_aux(x.op, dt, r.lit) : make_aux(0, 0, 0);
+    if (n)
+        launch(ctx, "expr_binary", binary_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, operand_of(l), operand_of(r),
+               x.op, dt, aux, n, bool_out ? nullptr : (uint64_t *)v.col.values->ptr,
+               bool_out ? (uint64_t *)v.col.values->ptr : nullptr, need_valid ? (uint64_t *)v.col.validity->ptr : nullptr,
+               ctx->d_flags);
+    return v;
+}
+
+} // namespace
+
+ExprInfo analyze_expr(const nqe_table *in, const nqe_expr_node *nodes, int n) {
+    int root;
+    std::vector<Node> t = parse(in, nodes, n, &root);
+    ExprInfo info;
+    info.out_dtype = t[size_t(root)].out_dtype;
+    info.simple = match_simple(t, root, &info.s);
+    return info;
+}
+
+DevColumn evaluate_expr(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, int n) {
+    int root;
+    std::vector<Node> t = parse(in, nodes, n, &root);
+    Value v = eval_node(ctx, in, t, root);
+    if (v.is_lit) return materialise_literal(ctx, v.dtype, v.lit, v.lit_null, in->rows);
+    return v.col;
+}
+
+} // namespace nqe
+
+using namespace nqe;
+
+extern "C" {
+
+nqe_status nqe_expr_evaluate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, int32_t num_nodes,
+                             nqe_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !in || !out) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    flags_reset(ctx);
+    auto t = std::make_unique<nqe_table>();
+    t->ctx = ctx;
+    t->rows = in->rows;
+    t->cols.push_back(evaluate_expr(ctx, in, nodes, num_nodes));
+    throw_on_flags(ctx);
+    *out = t.release();
+    NQE_API_END()
+}
+
+nqe_status nqe_projection_execute(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes,
+                                  const int32_t *expr_offsets, int32_t num_exprs, nqe_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !in || !out || num_exprs < 0 || (num_exprs > 0 && (!nodes || !expr_offsets)))
+        fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    flags_reset(ctx);
+    auto t = std::make_unique<nqe_table>();
+    t->ctx = ctx;
+    t->rows = in->rows;
+    for (int e = 0; e < num_exprs; ++e)
+        t->cols.push_back(evaluate_expr(ctx, in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e]));
+    throw_on_flags(ctx);
+    *out = t.release();
+    NQE_API_END()
+}
+
+} // extern "C"

@@ -1,0 +1,353 @@
+// hash_join.hip — HashJoin::execute = build() + probe() (reference: src/physical_plan/hash_join.rs:124-254).
+//
+// Reference: HashMap<XxHash64(key), Vec<build row>> chains, per probe row a chain walk with an
+// equality re-check (:86-101), then `take` of every left column by build index and every right
+// column by probe index (:237-246).  Output order: probe-row-major, duplicate build keys in
+// ascending build row.
+//
+// Device design
+//   build : stable radix sort of (key, build row) → equal keys adjacent, rows ascending;
+//           run heads → unique keys with (start, count) into the sorted row list `perm`;
+//           open-addressing table of 16-byte slots {key, start<<32|count} (Fibonacci hash, one
+//           128-bit load per probe step).  The XxHash64 value itself is unobservable in results
+//           (equality is re-checked), so any hash is parity-safe.  When every build key is
+//           unique the slot stores the build row directly (no `perm` indirection).
+//   probe : pass 1 looks every probe key up once and records its (start,count) word plus
+//           per-tile match counts; an exclusive scan gives each 4096-row tile its output base;
+//           pass 2 re-reads the recorded words, ranks rows inside the tile with wave scans and
+//           writes all output columns (gather of left columns by build row, copy of right
+//           columns) in probe order — exactly the order of the reference's outer_pos/inner_pos.
+// Key validity is ignored (quirk Q11): raw 8-byte slot values are compared.
+#include <algorithm>
+
+#include "device_utils.hpp"
+#include "nqe_internal.hpp"
+
+struct nqe_join_table {
+    nqe_ctx *ctx = nullptr;
+    std::vector<nqe::DevColumn> left_cols; // shared buffers of the build side ("self.data")
+    int64_t left_rows = 0;
+    int key_dtype = NQE_INT64;
+    nqe::BufRef slots; // ulonglong2[cap]
+    nqe::BufRef perm;  // uint32[left_rows], build rows sorted by (key, row)
+    uint32_t cap = 0;
+    int shift = 0;
+    bool direct = false; // all build keys unique: slot.y>>32 is the build row itself
+};
+
+namespace nqe {
+
+namespace {
+
+constexpr uint64_t GOLD = 0x9E3779B97F4A7C15ull;
+constexpr int JT_ROWS = 4096; // probe tile
+constexpr int JT_BLOCK = 256;
+constexpr int JT_ITERS = JT_ROWS / JT_BLOCK;
+constexpr int MAX_JOIN_COLS = 32;
+
+__global__ void iota_u32_kernel(uint32_t *out, int64_t n) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = uint32_t(i);
+}
+
+// flags[j] = 1 iff sorted key j starts a run; flags[n] = 0 (so the exclusive scan leaves the total there)
+__global__ void mark_heads_kernel(const uint64_t *skeys, int64_t n, uint32_t *flags) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j <= n; j += stride)
+        flags[j] = (j < n && (j == 0 || skeys[j] != skeys[j - 1])) ? 1u : 0u;
+}
+
+// ustart[u] = position of the u-th run head in the sorted order; ustart[U] = n
+__global__ void fill_ustart_kernel(const uint32_t *flags, const uint64_t *offs, int64_t n, uint32_t U, uint32_t *ustart) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j <= n; j += stride) {
+        if (j == n) ustart[U] = uint32_t(n);
+        else if (flags[j]) ustart[offs[j]] = uint32_t(j);
+    }
+}
+
+// inserts every unique key: claims a slot by CAS on the meta word (0 = empty), then stores the key
+__global__ void insert_unique_kernel(const uint64_t *skeys, const uint32_t *ustart, const uint32_t *perm, uint32_t U,
+                                     ulonglong2 *slots, uint32_t cap, int shift, int direct) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; u < int64_t(U); u += stride) {
+        uint32_t j = ustart[u];
+        uint64_t key = skeys[j];
+        uint64_t count = uint64_t(ustart[u + 1] - j);
+        uint64_t start = direct ? uint64_t(perm[j]) : uint64_t(j);
+        uint64_t meta = (start << 32) | count;
+        uint32_t slot = uint32_t((key * GOLD) >> shift);
+        for (;;) {
+            unsigned long long old = atomicCAS((unsigned long long *)&slots[slot].y, 0ull, (unsigned long long)meta);
+            if (old == 0ull) {
+                slots[slot].x = key;
+                break;
+            }
+            slot = (slot + 1) & (cap - 1);
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t probe_one(const ulonglong2 *__restrict__ slots, uint32_t cap, int shift, uint64_t key) {
+    uint32_t slot = uint32_t((key * GOLD) >> shift);
+    for (uint32_t p = 0; p < cap; ++p) {
+        ulonglong2 s = slots[slot];
+        if (s.y == 0ull) return 0ull;
+        if (s.x == key) return s.y;
+        slot = (slot + 1) & (cap - 1);
+    }
+    return 0ull;
+}
+
+// pass 1: one table lookup per probe row; records meta and per-tile totals
+__global__ void __launch_bounds__(JT_BLOCK) probe_count_kernel(const uint64_t *rkeys, int64_t n, const ulonglong2 *slots,
+                                                               uint32_t cap, int shift, uint64_t *pmeta, uint32_t *tile_counts,
+                                                               int *flags) {
+    __shared__ uint64_t wave_tot[JT_BLOCK / 64];
+    for (int64_t tile = blockIdx.x; tile * JT_ROWS < n; tile += gridDim.x) {
+        uint64_t keys[JT_ITERS];
+#pragma unroll
+        for (int it = 0; it < JT_ITERS; ++it) {
+            int64_t i = tile * JT_ROWS + int64_t(it) * JT_BLOCK + threadIdx.x;
+            keys[it] = i < n ? rkeys[i] : 0;
+        }
+        uint64_t local = 0;
+#pragma unroll
+        for (int it = 0; it < JT_ITERS; ++it) {
+            int64_t i = tile * JT_ROWS + int64_t(it) * JT_BLOCK + threadIdx.x;
+            if (i < n) {
+                uint64_t m = probe_one(slots, cap, shift, keys[it]);
+                pmeta[i] = m;
+                local += m & 0xFFFFFFFFull;
+            }
+        }
+        for (int d = 32; d > 0; d >>= 1) local += __shfl_down((unsigned long long)local, d, 64);
+        if (lane_id() == 0) wave_tot[threadIdx.x / 64] = local;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t t = 0;
+            for (int w = 0; w < JT_BLOCK / 64; ++w) t += wave_tot[w];
+            if (t > 0xFFFFFFFFull) {
+                atomicOr(&flags[NQE_FLAG_TABLE_FULL], 1);
+                t = 0;
+            }
+            tile_counts[tile] = uint32_t(t);
+        }
+        __syncthreads();
+    }
+}
+
+struct JoinCols {
+    int32_t n;
+    int32_t n_left;
+    const void *src[MAX_JOIN_COLS];
+    const uint8_t *src_valid[MAX_JOIN_COLS];
+    int32_t dtype[MAX_JOIN_COLS];
+    uint64_t *dst_words[MAX_JOIN_COLS];
+    uint8_t *dst_bool_bytes[MAX_JOIN_COLS];
+    uint8_t *dst_valid_bytes[MAX_JOIN_COLS];
+};
+
+// pass 2: ranks rows of the tile in probe order and writes every output column
+__global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *pmeta, int64_t n, const uint64_t *tile_offsets,
+                                                               const uint32_t *perm, int direct, JoinCols jc) {
+    __shared__ uint32_t wave_tot[JT_BLOCK / 64];
+    for (int64_t tile = blockIdx.x; tile * JT_ROWS < n; tile += gridDim.x) {
+        uint64_t run = tile_offsets[tile];
+        for (int it = 0; it < JT_ITERS; ++it) {
+            int64_t i = tile * JT_ROWS + int64_t(it) * JT_BLOCK + threadIdx.x;
+            uint64_t m = i < n ? pmeta[i] : 0ull;
+            uint32_t cnt = uint32_t(m & 0xFFFFFFFFull);
+            uint32_t start = uint32_t(m >> 32);
+            uint32_t wtot;
+            uint32_t ex = wave_exclusive_scan(cnt, wtot);
+            if (lane_id() == 63) wave_tot[threadIdx.x / 64] = wtot;
+            __syncthreads();
+            uint32_t pre = 0, all = 0;
+            for (int w = 0; w < JT_BLOCK / 64; ++w) {
+                if (w < int(threadIdx.x) / 64) pre += wave_tot[w];
+                all += wave_tot[w];
+            }
+            uint64_t pos = run + pre + ex;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                uint32_t b = direct ? start : perm[start + k];
+                for (int c = 0; c < jc.n; ++c) {
+                    int64_t srow = c < jc.n_left ? int64_t(b) : i;
+                    bool ok = jc.src_valid[c] ? get_bit(jc.src_valid[c], srow) : true;
+                    uint64_t v = load_word(jc.src[c], jc.dtype[c], srow);
+                    if (jc.dst_words[c]) jc.dst_words[c][pos + k] = ok ? v : 0;
+                    if (jc.dst_bool_bytes[c]) jc.dst_bool_bytes[c][pos + k] = (ok && v) ? 1 : 0;
+                    if (jc.dst_valid_bytes[c]) jc.dst_valid_bytes[c][pos + k] = ok ? 1 : 0;
+                }
+            }
+            run += all;
+            __syncthreads();
+        }
+    }
+}
+
+void check_key_types(int ldt, int rdt) {
+    auto joinable = [](int d) { return d == NQE_INT64 || d == NQE_UINT64 || d == NQE_UTF8; };
+    if (!joinable(ldt)) fail(NQE_ERR_NOT_IMPLEMENTED, "NotImplemented: join key type (hash_join.rs:161)");
+    if (ldt == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 join keys are not supported on the device path yet");
+    if (rdt < 0) return;
+    if (!joinable(rdt)) fail(NQE_ERR_NOT_IMPLEMENTED, "NotImplemented: join key type (hash_join.rs:232)");
+    if (rdt != ldt) fail(NQE_ERR_NOT_SUPPORTED, "join key types differ (downcast unwrap panics, hash_join.rs:83)");
+}
+
+std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left, int left_key) {
+    if (left_key < 0 || size_t(left_key) >= left->cols.size()) fail(NQE_ERR_LOGICAL, "ColumnExpr must has name or idx");
+    const DevColumn &kc = left->cols[size_t(left_key)];
+    check_key_types(kc.dtype, -1);
+    const int64_t n = left->rows;
+    if (n >= (int64_t(1) << 32)) fail(NQE_ERR_NOT_SUPPORTED, "build side with 2^32 or more rows is not supported");
+    auto jt = std::make_unique<nqe_join_table>();
+    jt->ctx = ctx;
+    jt->left_cols = left->cols;
+    jt->left_rows = n;
+    jt->key_dtype = kc.dtype;
+
+    BufRef idx = dev_alloc(ctx, size_t(n) * 4 + 8), skeys = dev_alloc(ctx, size_t(n) * 8 + 8);
+    jt->perm = dev_alloc(ctx, size_t(n) * 4 + 8);
+    uint32_t U = 0;
+    BufRef ustart;
+    if (n) {
+        launch(ctx, "join_iota", iota_u32_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, (uint32_t *)idx->ptr, n);
+        radix_sort_pairs_u64(ctx, kc.words(), (const uint32_t *)idx->ptr, (uint64_t *)skeys->ptr, (uint32_t *)jt->perm->ptr, n,
+                             false);
+        // run heads of the sorted keys → unique keys
+        BufRef flags = dev_alloc(ctx, size_t(n + 1) * 4);
+        launch(ctx, "join_mark_heads", mark_heads_kernel, dim3(stream_grid(ctx, n + 1, 256)), dim3(256), 0,
+               (const uint64_t *)skeys->ptr, n, (uint32_t *)flags->ptr);
+        BufRef offs = dev_alloc(ctx, size_t(n + 2) * 8);
+        exclusive_scan_u32_to_u64(ctx, (const uint32_t *)flags->ptr, (uint64_t *)offs->ptr, n + 1);
+        U = uint32_t(read_scalar(ctx, (const uint64_t *)offs->ptr + (n + 1)));
+        ustart = dev_alloc(ctx, size_t(U + 1) * 4);
+        launch(ctx, "join_fill_ustart", fill_ustart_kernel, dim3(stream_grid(ctx, n + 1, 256)), dim3(256), 0,
+               (const uint32_t *)flags->ptr, (const uint64_t *)offs->ptr, n, U, (uint32_t *)ustart->ptr);
+    }
+    jt->direct = (int64_t(U) == n);
+    uint32_t cap = 64;
+    while (uint64_t(cap) < 2ull * U) cap <<= 1;
+    int lg = 0;
+    while ((1u << lg) < cap) ++lg;
+    jt->cap = cap;
+    jt->shift = 64 - lg;
+    jt->slots = dev_alloc_zero(ctx, size_t(cap) * 16);
+    if (U)
+        launch(ctx, "join_insert", insert_unique_kernel, dim3(stream_grid(ctx, U, 256)), dim3(256), 0, (const uint64_t *)skeys->ptr,
+               (const uint32_t *)ustart->ptr, (const uint32_t *)jt->perm->ptr, U, (ulonglong2 *)jt->slots->ptr, cap, jt->shift,
+               jt->direct ? 1 : 0);
+    sync(ctx); // skeys/flags/ustart are released on return
+    return jt;
+}
+
+std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, const nqe_table *right, int right_key) {
+    if (right_key < 0 || size_t(right_key) >= right->cols.size()) fail(NQE_ERR_LOGICAL, "ColumnExpr must has name or idx");
+    const DevColumn &rk = right->cols[size_t(right_key)];
+    check_key_types(jt->key_dtype, rk.dtype);
+    const int64_t n = right->rows;
+    const size_t ncols = jt->left_cols.size() + right->cols.size();
+    if (ncols > size_t(MAX_JOIN_COLS)) fail(NQE_ERR_NOT_SUPPORTED, "join output wider than 32 columns");
+    for (auto &c : jt->left_cols)
+        if (c.dtype == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 payload columns are not supported by the device join yet");
+    for (auto &c : right->cols)
+        if (c.dtype == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 payload columns are not supported by the device join yet");
+
+    const int64_t ntiles = (n + JT_ROWS - 1) / JT_ROWS;
+    BufRef pmeta = dev_alloc(ctx, size_t(n) * 8 + 8);
+    BufRef counts = dev_alloc(ctx, size_t(ntiles + 1) * 4);
+    BufRef offs = dev_alloc(ctx, size_t(ntiles + 1) * 8);
+    int grid = int(std::max<int64_t>(1, std::min<int64_t>(ntiles, int64_t(ctx->num_cus) * 8)));
+    if (n)
+        launch(ctx, "join_probe_count", probe_count_kernel, dim3(grid), dim3(JT_BLOCK), 0, rk.words(), n,
+               (const ulonglong2 *)jt->slots->ptr, jt->cap, jt->shift, (uint64_t *)pmeta->ptr, (uint32_t *)counts->ptr, ctx->d_flags);
+    exclusive_scan_u32_to_u64(ctx, (const uint32_t *)counts->ptr, (uint64_t *)offs->ptr, ntiles);
+    const int64_t M = int64_t(read_scalar(ctx, (const uint64_t *)offs->ptr + ntiles));
+    {
+        int f[NQE_NUM_FLAGS];
+        flags_read(ctx, f);
+        if (f[NQE_FLAG_TABLE_FULL]) fail(NQE_ERR_OUT_OF_MEMORY, "join output of one probe tile exceeds 2^32 rows");
+    }
+
+    auto out = std::make_unique<nqe_table>();
+    out->ctx = ctx;
+    out->rows = M;
+    JoinCols jc;
+    std::memset(&jc, 0, sizeof(jc));
+    jc.n = int(ncols);
+    jc.n_left = int(jt->left_cols.size());
+    std::vector<BufRef> bool_bytes(ncols), valid_bytes(ncols);
+    for (size_t c = 0; c < ncols; ++c) {
+        const DevColumn &src = c < jt->left_cols.size() ? jt->left_cols[c] : right->cols[c - jt->left_cols.size()];
+        const bool v = src.validity != nullptr;
+        DevColumn dst = src.dtype == NQE_BOOLEAN ? make_bool_column(ctx, M, v) : make_word_column(ctx, src.dtype, M, v);
+        jc.src[c] = src.values ? src.values->ptr : nullptr;
+        jc.src_valid[c] = src.valid();
+        jc.dtype[c] = src.dtype;
+        if (src.dtype == NQE_BOOLEAN) {
+            bool_bytes[c] = dev_alloc(ctx, size_t(M) + 8);
+            jc.dst_bool_bytes[c] = (uint8_t *)bool_bytes[c]->ptr;
+        } else {
+            jc.dst_words[c] = (uint64_t *)dst.values->ptr;
+        }
+        if (v) {
+            valid_bytes[c] = dev_alloc(ctx, size_t(M) + 8);
+            jc.dst_valid_bytes[c] = (uint8_t *)valid_bytes[c]->ptr;
+        }
+        out->cols.push_back(std::move(dst));
+    }
+    if (n && M)
+        launch(ctx, "join_probe_write", probe_write_kernel, dim3(grid), dim3(JT_BLOCK), 0, (const uint64_t *)pmeta->ptr, n,
+               (const uint64_t *)offs->ptr, (const uint32_t *)jt->perm->ptr, jt->direct ? 1 : 0, jc);
+    for (size_t c = 0; c < ncols; ++c) {
+        if (bool_bytes[c]) pack_bytes_to_bits(ctx, (const uint8_t *)bool_bytes[c]->ptr, M, (uint64_t *)out->cols[c].values->ptr);
+        if (valid_bytes[c]) pack_bytes_to_bits(ctx, (const uint8_t *)valid_bytes[c]->ptr, M, (uint64_t *)out->cols[c].validity->ptr);
+    }
+    sync(ctx); // temporaries above are released on return; keep the stream drained for simplicity
+    return out;
+}
+
+} // namespace
+
+} // namespace nqe
+
+using namespace nqe;
+
+extern "C" {
+
+nqe_status nqe_hash_join_build(nqe_ctx *ctx, const nqe_table *left, int32_t left_key, nqe_join_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !left || !out) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    flags_reset(ctx);
+    *out = build_table(ctx, left, left_key).release();
+    NQE_API_END()
+}
+
+nqe_status nqe_hash_join_probe(nqe_ctx *ctx, const nqe_join_table *build, const nqe_table *right, int32_t right_key,
+                               nqe_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !build || !right || !out) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    flags_reset(ctx);
+    *out = probe_table(ctx, build, right, right_key).release();
+    NQE_API_END()
+}
+
+nqe_status nqe_join_table_release(nqe_join_table *jt) {
+    delete jt;
+    return NQE_OK;
+}
+
+nqe_status nqe_hash_join_execute(nqe_ctx *ctx, const nqe_table *left, const nqe_table *right, int32_t left_key,
+                                 int32_t right_key, nqe_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !left || !right || !out) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (left_key < 0 || right_key < 0) // empty `on` (hash_join.rs:125-129)
+        fail(NQE_ERR_PLAN, "Inner Join on Conditions can't not be empty");
+    flags_reset(ctx);
+    std::unique_ptr<nqe_join_table> jt = build_table(ctx, left, left_key);
+    *out = probe_table(ctx, jt.get(), right, right_key).release();
+    NQE_API_END()
+}
+
+} // extern "C"

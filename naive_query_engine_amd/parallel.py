@@ -1,0 +1,136 @@
+"""Row-range sharding of the hot operators across GPUs.
+
+One process per GPU; torch.distributed (backend "nccl" = RCCL over xGMI, "gloo" in the CPU tests)
+is used only as plumbing for the exchange steps the path really has:
+
+  * filter / projection / join probe: rows are independent → contiguous row ranges per rank keep the
+    reference's output order (rank order == row order); no collective unless one rank must
+    materialise the whole result, in which case the variable-length batches are all-gathered in rank
+    order (`all_gather_rows`).
+  * hash aggregate: every rank aggregates its row range into partial state {count,sum,min,max} per
+    group (nqe_aggregate_partial); the tiny partial tables are all-gathered and merged on every rank
+    (nqe_aggregate_merge).  avg is finalised after the merge (sum/count), never averaged per rank.
+  * hash join: the build side is replicated (every rank builds from its own copy), the probe side is
+    range-split; outputs are per-rank batches in probe order.
+
+The reference has no distributed code at all (single process, single thread); this module is the
+build's own design and has no reference analogue.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """contiguous row range [lo, hi) of rank `rank`: sizes differ by at most one row"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class DeviceArray:
+    """Zero-copy view of device memory for torch (`torch.as_tensor(DeviceArray(...), device='cuda')`)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str, owner=None):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr if n else 0, False), "version": 2}
+        self._owner = owner
+
+
+def table_columns_as_tensors(table, device) -> list:
+    """8-byte columns of an nqe table as int64 torch tensors (bit patterns), zero-copy."""
+    import torch
+
+    out = []
+    for i in range(table.num_columns):
+        info = table.column_info(i)
+        n = int(info.length)
+        if n == 0:
+            out.append(torch.empty(0, dtype=torch.int64, device=device))
+        else:
+            out.append(torch.as_tensor(DeviceArray(info.values, n, "<i8", owner=table), device=device))
+    return out
+
+
+def all_gather_rows(cols: Sequence, group=None) -> Tuple[List[list], List[int]]:
+    """Ordered variable-length all-gather.  `cols` = equally long 1-D tensors (one per column) on this
+    rank.  Returns (per_rank_columns, counts): per_rank_columns[r][c] is rank r's column c.  Counts are
+    exchanged first, then columns are padded to the maximum and gathered with one all_gather each."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    n_local = int(cols[0].numel()) if cols else 0
+    dev = cols[0].device if cols else torch.device("cpu")
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    counts_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts_t, cnt, group=group)
+    counts = [int(c.item()) for c in counts_t]
+    mx = max(counts) if counts else 0
+    per_rank: List[list] = [[] for _ in range(world)]
+    for c in cols:
+        padded = torch.zeros(mx, dtype=c.dtype, device=dev)
+        padded[:n_local] = c
+        bufs = [torch.empty(mx, dtype=c.dtype, device=dev) for _ in range(world)]
+        if mx:
+            dist.all_gather(bufs, padded, group=group)
+        for r in range(world):
+            per_rank[r].append(bufs[r][: counts[r]])
+    return per_rank, counts
+
+
+def sharded_aggregate(ctx, local_table, aggs, group_nodes=None, pred_nodes=None, group=None):
+    """Aggregate over the union of every rank's `local_table`; returns (result_table, keys_table)
+    on every rank (identical up to f64 summation order of the merge)."""
+    import torch
+    import torch.distributed as dist
+
+    from .arrow_host import DType
+
+    state, keys = ctx.aggregate_partial(local_table, aggs, group_nodes=group_nodes, pred_nodes=pred_nodes)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return ctx.aggregate_merge([state], [keys] if keys is not None else None, aggs)
+    dev = torch.device("cuda", ctx.device)
+    cols = table_columns_as_tensors(state, dev)
+    kdt = None
+    if keys is not None:
+        kdt = keys.dtypes()[0]
+        cols = table_columns_as_tensors(keys, dev) + cols
+    per_rank, counts = all_gather_rows(cols, group)
+    states, keyts, keep = [], [], []
+    sdt = state.dtypes()
+    for r, rc in enumerate(per_rank):
+        off = 0
+        if keys is not None:
+            kt = ctx.table_from_device([(kdt, counts[r], rc[0].data_ptr() if counts[r] else None, None)])
+            keyts.append(kt)
+            off = 1
+        st = ctx.table_from_device([(sdt[i], counts[r], rc[off + i].data_ptr() if counts[r] else None, None)
+                                    for i in range(len(sdt))])
+        states.append(st)
+        keep.append(rc)
+    out = ctx.aggregate_merge(states, keyts if keys is not None else None, aggs)
+    ctx.synchronize()
+    del keep
+    return out
+
+
+def merge_partials_numpy(keys_list: Sequence[Optional[np.ndarray]], states_list: Sequence[Sequence[np.ndarray]]):
+    """Host restatement of the partial merge rule (used by the CPU gloo tests to check the exchange;
+    the product path merges on the GPU with nqe_aggregate_merge).  states = per aggregate
+    (count u64, sum f64, min f64, max f64)."""
+    grouped = keys_list[0] is not None
+    acc = {}
+    for keys, st in zip(keys_list, states_list):
+        n = len(st[0])
+        for r in range(n):
+            k = int(keys[r]) if grouped else 0
+            row = acc.setdefault(k, [[0, 0.0, np.finfo(np.float64).max, -np.finfo(np.float64).max] for _ in range(len(st) // 4)])
+            for i in range(len(st) // 4):
+                c, s, mn, mx = st[4 * i][r], st[4 * i + 1][r], st[4 * i + 2][r], st[4 * i + 3][r]
+                row[i][0] += int(c)
+                row[i][1] += float(s)
+                row[i][2] = min(row[i][2], float(mn))
+                row[i][3] = float("nan") if (np.isnan(mx) or np.isnan(row[i][3])) else max(row[i][3], float(mx))
+    return acc

@@ -1,0 +1,59 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/nqe.h declares; the product
+fails loudly without a GPU instead of falling back."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from naive_query_engine_amd import ErrorCode, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "nqe.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nqe_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_match_binding_list():
+    assert header_symbols() == sorted(capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    for s in header_symbols():
+        assert hasattr(L, s), s
+    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (nqe_[a-z0-9_]+)", out))
+    assert set(header_symbols()) <= exported
+    assert L.nqe_abi_version() == 1
+
+
+def test_library_contains_gfx950_code_objects():
+    blob = open(capi.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ErrorCode) as e:
+        capi.Context(0)
+    assert "no HIP device" in str(e.value) or "Hip" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """the product path may not import, link, dlopen or call anything under oracle/"""
+    pkg = os.path.join(ROOT, "naive_query_engine_amd")
+    bad = re.compile(r"(^\s*(import|from)\s+oracle\b|libnqe_oracle|\borc_[a-z_]+\s*\(|oracle\.oracle|dlopen)", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not bad.search(text), f"{f} references the oracle"
+    out = subprocess.check_output(["ldd", capi.LIB_PATH], text=True)
+    assert "oracle" not in out

@@ -1,0 +1,438 @@
+"""GPU parity tests: every hot-path operator through the C ABI (libnqe_hip.so) against the CPU
+oracle on the same seeded inputs.  Bit-exact for integers/booleans/validity/row order; Float64
+sums/avgs within 1e-9 relative (north_star tolerance)."""
+import numpy as np
+import pytest
+
+from naive_query_engine_amd import AggregateFunc, Column, DType, ErrorCode, Operator, Status
+from naive_query_engine_amd.expression import binop, col, lit_bool, lit_f64, lit_i64, lit_u64
+from oracle import oracle as orc
+from tests.helpers import assert_batches_equal, assert_column_equal, assert_rows_multiset_equal, fields, random_batch
+
+pytestmark = pytest.mark.gpu
+
+FLD = fields("id", "k", "v", "u", "b")
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from naive_query_engine_amd import capi
+
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def flat(e):
+    return e.flatten(FLD)
+
+
+# --------------------------------------------------------------------------- expressions
+ARITH = [Operator.Plus, Operator.Minus, Operator.Multiply, Operator.Divide, Operator.Modulos]
+CMP = [Operator.Eq, Operator.NotEq, Operator.Lt, Operator.LtEq, Operator.Gt, Operator.GtEq]
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.2])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4097])
+def test_binary_ops_all_types(ctx, n, null_frac):
+    rng = np.random.default_rng(n * 7 + int(null_frac * 10))
+    cols = random_batch(rng, n, null_frac, with_bool=True)
+    t = ctx.table_from_host(cols)
+    lits = {1: lit_i64(-7), 2: lit_f64(3.25), 3: lit_u64(12)}
+    for c, lit in lits.items():
+        for op in ARITH + CMP:
+            for e in (binop(col(c), op, lit), binop(lit, op, col(c)), binop(col(c), op, col(c))):
+                try:
+                    exp = orc.expr_evaluate([cols], flat(e))
+                except ErrorCode as err:  # e.g. lit % col with a zero in col
+                    with pytest.raises(ErrorCode) as g:
+                        ctx.expr_evaluate(t, flat(e))
+                    assert g.value.status == err.status
+                    continue
+                got = ctx.expr_evaluate(t, flat(e)).to_host()[0]
+                assert_column_equal(got, exp, what=f"{e!r}")
+    # Boolean compares and Kleene logic
+    for op in CMP + [Operator.And, Operator.Or]:
+        for e in (binop(col(4), op, col(4)), binop(col(4), op, lit_bool(True)), binop(lit_bool(False), op, col(4)),
+                  binop(binop(col(1), Operator.Gt, lit_i64(0)), op, binop(col(2), Operator.Lt, lit_f64(10.0)))):
+            assert_column_equal(ctx.expr_evaluate(t, flat(e)).to_host()[0], orc.expr_evaluate([cols], flat(e)), what=f"{e!r}")
+
+
+def test_expression_edge_values(ctx):
+    i64 = np.array([np.iinfo(np.int64).min, -1, 0, 1, np.iinfo(np.int64).max, -1024, 1023, 5], dtype=np.int64)
+    f64 = np.array([np.nan, -0.0, 0.0, np.inf, -np.inf, 1e308, -1e-308, 2.5])
+    cols = [Column.from_numpy(i64), Column.from_numpy(f64)]
+    t = ctx.table_from_host(cols)
+    f = fields("a", "x")
+    cases = [binop(col(0), Operator.Plus, lit_i64(1)), binop(col(0), Operator.Minus, lit_i64(2)),
+             binop(col(0), Operator.Multiply, lit_i64(3)), binop(col(0), Operator.Modulos, lit_i64(1024)),
+             binop(col(0), Operator.Modulos, lit_i64(-1024)), binop(col(0), Operator.Divide, lit_i64(1024)),
+             binop(col(0), Operator.Divide, lit_i64(-8)), binop(col(0), Operator.Modulos, lit_i64(7)),
+             binop(col(0), Operator.Divide, lit_i64(7)), binop(col(0), Operator.Modulos, lit_i64(np.iinfo(np.int64).min)),
+             binop(lit_i64(100), Operator.Minus, col(0))]
+    cases += [binop(col(1), op, lit_f64(0.0)) for op in CMP] + [binop(col(1), op, col(1)) for op in CMP]
+    cases += [binop(col(1), Operator.Plus, lit_f64(1.0)), binop(col(1), Operator.Multiply, lit_f64(-2.0)),
+              binop(col(1), Operator.Divide, lit_f64(3.0)), binop(col(1), Operator.Modulos, lit_f64(2.0))]
+    for e in cases:
+        assert_column_equal(ctx.expr_evaluate(t, e.flatten(f)).to_host()[0], orc.expr_evaluate([cols], e.flatten(f)), what=f"{e!r}")
+    # i64::MIN / -1 overflows in Rust → error on both sides
+    for op in (Operator.Divide, Operator.Modulos):
+        e = binop(col(0), op, lit_i64(-1)).flatten(f)
+        with pytest.raises(ErrorCode) as a:
+            orc.expr_evaluate([cols], e)
+        with pytest.raises(ErrorCode) as b:
+            ctx.expr_evaluate(t, e)
+        assert a.value.status == b.value.status == Status.ArrowError
+
+
+def test_expression_errors(ctx):
+    cols = [Column.from_list([1, 0, 3], DType.INT64), Column.from_list([1.0, 0.0, None], DType.FLOAT64),
+            Column.from_list([True, None, False], DType.BOOLEAN)]
+    t = ctx.table_from_host(cols)
+    f = fields("a", "x", "b")
+    bad = [
+        (binop(col(0), Operator.Lt, lit_f64(4.5)), Status.IntervalError),       # Q6: no coercion
+        (binop(col(0), Operator.And, col(0)), Status.IntervalError),            # and/or need Boolean
+        (binop(col(2), Operator.Plus, col(2)), Status.NotSupported),            # arithmetic on Boolean panics
+        (binop(lit_i64(6), Operator.Divide, col(0)), Status.ArrowError),        # DivideByZero
+        (binop(col(1), Operator.Modulos, col(1)), Status.ArrowError),           # float zero divisor too
+        (binop(col(0), Operator.Modulos, lit_i64(0)), Status.ArrowError),
+    ]
+    for e, status in bad:
+        with pytest.raises(ErrorCode) as a:
+            orc.expr_evaluate([cols], e.flatten(f))
+        with pytest.raises(ErrorCode) as b:
+            ctx.expr_evaluate(t, e.flatten(f))
+        assert a.value.status == b.value.status == status, repr(e)
+    # a zero divisor under a NULL slot is fine
+    n = [Column.from_list([10, None], DType.INT64), Column.from_list([2, 0], DType.INT64)]
+    e = binop(col(0), Operator.Divide, col(1)).flatten(f)
+    assert_column_equal(ctx.expr_evaluate(ctx.table_from_host(n), e).to_host()[0], orc.expr_evaluate([n], e))
+    # NULL literal and literal-only expressions
+    for e in (binop(col(0), Operator.Plus, lit_i64(None)), binop(lit_i64(2), Operator.Multiply, lit_i64(21)), lit_f64(1.5), col(1)):
+        assert_column_equal(ctx.expr_evaluate(t, e.flatten(f)).to_host()[0], orc.expr_evaluate([cols], e.flatten(f)), what=repr(e))
+
+
+# --------------------------------------------------------------------------- filter / projection
+PREDS = [
+    binop(col(0), Operator.Lt, lit_i64(500)),                                                  # fused shape
+    binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Gt, lit_i64(5)),                  # reference test shape
+    binop(binop(col(1), Operator.Modulos, lit_i64(3)), Operator.Eq, lit_i64(0)),
+    binop(col(2), Operator.GtEq, lit_f64(0.0)),
+    binop(binop(col(0), Operator.Lt, lit_i64(700)), Operator.And, binop(col(2), Operator.Lt, lit_f64(50.0))),   # general
+    binop(binop(col(1), Operator.Gt, lit_i64(0)), Operator.Or, binop(col(3), Operator.Lt, lit_u64(1 << 39))),
+    binop(col(1), Operator.Gt, col(0)),
+]
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.15])
+@pytest.mark.parametrize("n", [0, 1, 64, 4095, 4096, 4097, 20000])
+def test_selection_matches_oracle(ctx, n, null_frac):
+    rng = np.random.default_rng(1000 + n)
+    cols = random_batch(rng, n, null_frac, with_bool=True)
+    t = ctx.table_from_host(cols)
+    for p in PREDS:
+        exp = orc.selection([cols], flat(p))[0]
+        got = ctx.selection(t, flat(p)).to_host()
+        assert_batches_equal(got, exp, what=f"selection {p!r} n={n}")
+
+
+def test_filter_zip_truncation_q3(ctx):
+    rng = np.random.default_rng(5)
+    b0 = random_batch(rng, 100)
+    b1 = random_batch(rng, 150)
+    p = binop(col(1), Operator.Gt, lit_i64(0))
+    exp = orc.selection([b0, b1], flat(p))
+    t0, t1 = ctx.table_from_host(b0), ctx.table_from_host(b1)
+    mask = ctx.expr_evaluate(t0, flat(p))                       # predicate from batch 0 only
+    assert_batches_equal(ctx.filter(t0, mask).to_host(), exp[0])
+    assert_batches_equal(ctx.filter(t1, mask).to_host(), exp[1])  # zipped against batch 1, truncated to 100 rows
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.15])
+def test_selection_projection_fused_equals_chained(ctx, null_frac):
+    rng = np.random.default_rng(77)
+    cols = random_batch(rng, 30000, null_frac, with_bool=True)
+    t = ctx.table_from_host(cols)
+    exprs = [binop(col(1), Operator.Plus, lit_i64(100)), col(0), binop(col(2), Operator.Multiply, lit_f64(0.5)),
+             binop(col(3), Operator.Modulos, lit_u64(1000)), binop(col(1), Operator.LtEq, lit_i64(3)), col(4)]
+    general = exprs + [binop(binop(col(0), Operator.Plus, col(1)), Operator.Multiply, lit_i64(2)),
+                       binop(lit_i64(100), Operator.Divide, col(0))]   # would divide by zero on the row id == 0
+    for p in PREDS[:4]:
+        sel = orc.selection([cols], flat(p))
+        exp = orc.projection(sel, [flat(e) for e in exprs])[0]
+        got = ctx.selection_projection(t, flat(p), [flat(e) for e in exprs]).to_host()
+        assert_batches_equal(got, exp, what=f"fused {p!r}")
+    # general expressions: evaluated after compaction, so the filter protects the divisor
+    p = binop(col(0), Operator.Gt, lit_i64(0))
+    if null_frac == 0.0:
+        sel = orc.selection([cols], flat(p))
+        exp = orc.projection(sel, [flat(e) for e in general])[0]
+        got = ctx.selection_projection(t, flat(p), [flat(e) for e in general]).to_host()
+        assert_batches_equal(got, exp, what="general projection")
+
+
+def test_projection_matches_oracle(ctx):
+    rng = np.random.default_rng(9)
+    cols = random_batch(rng, 5000, 0.1, with_bool=True)
+    t = ctx.table_from_host(cols)
+    exprs = [binop(col(0), Operator.Plus, lit_i64(1)), col(2), binop(binop(col(2), Operator.Multiply, col(2)), Operator.Minus, lit_f64(1.0)),
+             binop(col(4), Operator.Or, binop(col(1), Operator.Eq, lit_i64(0))), lit_i64(7)]
+    exp = orc.projection([cols], [flat(e) for e in exprs])[0]
+    assert_batches_equal(ctx.projection(t, [flat(e) for e in exprs]).to_host(), exp)
+
+
+# --------------------------------------------------------------------------- aggregate
+ALL_AGGS = lambda c: [(AggregateFunc.Count, c), (AggregateFunc.Sum, c), (AggregateFunc.Avg, c), (AggregateFunc.Min, c), (AggregateFunc.Max, c)]
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.2])
+@pytest.mark.parametrize("n", [1, 100, 5000, 70000])
+def test_group_by_matches_oracle(ctx, n, null_frac):
+    rng = np.random.default_rng(31 + n)
+    cols = random_batch(rng, n, null_frac, with_bool=True)
+    t = ctx.table_from_host(cols)
+    keys = [binop(col(0), Operator.Modulos, lit_i64(16)), col(1), binop(col(1), Operator.Multiply, lit_i64(1 << 40)),
+            binop(col(3), Operator.Modulos, lit_u64(37)), binop(binop(col(0), Operator.Plus, col(1)), Operator.Modulos, lit_i64(5))]
+    aggsets = [ALL_AGGS(2), ALL_AGGS(0) + ALL_AGGS(3), [(AggregateFunc.Count, 4), (AggregateFunc.Sum, 1), (AggregateFunc.Max, 2), (AggregateFunc.Min, 3), (AggregateFunc.Avg, 0)]]
+    for key in keys:
+        for aggs in aggsets:
+            exp = orc.aggregate([cols], aggs, group_nodes=flat(key))[0]
+            got, gk = ctx.aggregate(t, aggs, group_nodes=flat(key), with_keys=True)
+            counts = [i for i, (f, _) in enumerate(aggs) if f == AggregateFunc.Count]
+            assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=counts, what=f"key {key!r} aggs {aggs}")
+            kk = gk.to_host()[0].to_numpy()
+            assert (np.sort(kk) == kk).all() and len(np.unique(kk)) == len(kk)
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.2])
+def test_filter_then_group_by_matches_oracle(ctx, null_frac):
+    rng = np.random.default_rng(123)
+    n = 50000
+    cols = random_batch(rng, n, null_frac)
+    t = ctx.table_from_host(cols)
+    for p in PREDS[:6]:
+        for key in (binop(col(0), Operator.Modulos, lit_i64(1024)), col(1)):
+            exp = orc.aggregate([cols], ALL_AGGS(2), group_nodes=flat(key), pred_nodes=flat(p))[0]
+            got = ctx.aggregate(t, ALL_AGGS(2), group_nodes=flat(key), pred_nodes=flat(p)).to_host()
+            assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"{p!r} / {key!r}")
+    # general key under a filter that protects its divisor
+    p = binop(col(0), Operator.Gt, lit_i64(0))
+    key = binop(binop(lit_i64(1000000), Operator.Divide, col(0)), Operator.Modulos, lit_i64(7))
+    if null_frac == 0.0:
+        exp = orc.aggregate([cols], ALL_AGGS(2), group_nodes=flat(key), pred_nodes=flat(p))[0]
+        got = ctx.aggregate(t, ALL_AGGS(2), group_nodes=flat(key), pred_nodes=flat(p)).to_host()
+        assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0])
+
+
+def test_ungrouped_aggregate_matches_oracle(ctx):
+    rng = np.random.default_rng(8)
+    for n, nf in [(0, 0.0), (1, 0.0), (1000, 0.3), (300000, 0.0), (300000, 0.1)]:
+        cols = random_batch(rng, n, nf, with_bool=True)
+        t = ctx.table_from_host(cols)
+        aggs = ALL_AGGS(2) + ALL_AGGS(1) + [(AggregateFunc.Count, 4), (AggregateFunc.Sum, 3)]
+        for p in (None, PREDS[0], PREDS[4]):
+            pn = flat(p) if p is not None else None
+            exp = orc.aggregate([cols], aggs, pred_nodes=pn)[0] if not (n == 0 and p is not None) else None
+            if exp is None:
+                continue  # the reference panics on input[0] of an empty Vec; nothing to compare
+            got = ctx.aggregate(t, aggs, pred_nodes=pn).to_host()
+            assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0, 5, 10], what=f"n={n} p={p!r}")
+
+
+def test_aggregate_nan_null_and_sentinel_key(ctx):
+    nan = float("nan")
+    imin = np.iinfo(np.int64).min
+    k = Column.from_list([0, 0, 0, 1, 1, None, 2, imin, imin, -0], DType.INT64)
+    v = Column.from_list([1.0, nan, 3.0, None, None, 5.0, -0.5, 2.0, 4.0, -7.0], DType.FLOAT64)
+    cols = [k, v]
+    f = fields("k", "v")
+    aggs = ALL_AGGS(1)
+    exp = orc.aggregate([cols], aggs, group_nodes=col(0).flatten(f))[0]
+    got, gk = ctx.aggregate(ctx.table_from_host(cols), aggs, group_nodes=col(0).flatten(f), with_keys=True)
+    assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0])
+    assert gk.to_host()[0].to_list() == [imin, 0, 1, 2]
+    rows = {kk: r for kk, r in zip(gk.to_host()[0].to_list(), zip(*[c.to_list() for c in got.to_host()]))}
+    fmax = np.finfo(np.float64).max
+    assert rows[1][0] == 0 and rows[1][1] == 0.0 and np.isnan(rows[1][2]) and rows[1][3] == fmax and rows[1][4] == -fmax
+    assert np.isnan(rows[0][1]) and rows[0][3] == -7.0 and np.isnan(rows[0][4])
+    assert rows[imin] == (2, 6.0, 3.0, 2.0, 4.0)
+
+
+def test_aggregate_many_groups_overflows_workgroup_table(ctx):
+    # more distinct keys than a workgroup's LDS table holds → rows spill to the global table
+    rng = np.random.default_rng(4)
+    n = 200000
+    k = rng.integers(0, 60000, n).astype(np.int64) * 1024  # common low bits
+    v = rng.random(n)
+    cols = [Column.from_numpy(k), Column.from_numpy(v)]
+    f = fields("k", "v")
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=col(0).flatten(f))[0]
+    got = ctx.aggregate(ctx.table_from_host(cols), ALL_AGGS(1), group_nodes=col(0).flatten(f)).to_host()
+    assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0])
+
+
+def test_aggregate_partial_merge_equals_single_pass(ctx):
+    rng = np.random.default_rng(99)
+    n = 40000
+    cols = random_batch(rng, n, 0.1)
+    aggs = ALL_AGGS(2) + [(AggregateFunc.Count, 0)]
+    key = flat(binop(col(0), Operator.Modulos, lit_i64(100)))
+    pred = flat(PREDS[0])
+    full = ctx.aggregate(ctx.table_from_host(cols), aggs, group_nodes=key, pred_nodes=pred)
+    parts = []
+    for lo, hi in [(0, 13000), (13000, 13001), (13001, 40000)]:
+        sub = [Column.from_numpy(c.to_numpy()[lo:hi], c.valid_mask()[lo:hi]) for c in cols]
+        parts.append(ctx.aggregate_partial(ctx.table_from_host(sub), aggs, group_nodes=key, pred_nodes=pred))
+    merged, mk = ctx.aggregate_merge([p[0] for p in parts], [p[1] for p in parts], aggs)
+    assert_rows_multiset_equal(merged.to_host(), full.to_host(), RTOL, exact_cols=[0, 5])
+    # un-grouped partials
+    full_u = ctx.aggregate(ctx.table_from_host(cols), aggs)
+    parts_u = [ctx.aggregate_partial(ctx.table_from_host([Column.from_numpy(c.to_numpy()[lo:hi], c.valid_mask()[lo:hi]) for c in cols]), aggs)[0]
+               for lo, hi in [(0, 20000), (20000, 40000)]]
+    merged_u, _ = ctx.aggregate_merge(parts_u, None, aggs)
+    assert_rows_multiset_equal(merged_u.to_host(), full_u.to_host(), RTOL, exact_cols=[0, 5])
+
+
+def test_aggregate_errors(ctx):
+    cols = [Column.from_list([1.5, 2.5], DType.FLOAT64), Column.from_list([True, False], DType.BOOLEAN)]
+    t = ctx.table_from_host(cols)
+    f = fields("x", "b")
+    with pytest.raises(ErrorCode) as e:  # Float64 group key (aggregate/mod.rs:217)
+        ctx.aggregate(t, [(AggregateFunc.Sum, 0)], group_nodes=col(0).flatten(f))
+    assert e.value.status == Status.NotSupported
+    with pytest.raises(ErrorCode) as o:
+        orc.aggregate([cols], [(AggregateFunc.Sum, 0)], group_nodes=col(0).flatten(f))
+    assert o.value.status == Status.NotSupported
+    with pytest.raises(ErrorCode) as e:  # sum over Boolean
+        ctx.aggregate(t, [(AggregateFunc.Sum, 1)])
+    assert e.value.status == Status.NotSupported
+
+
+# --------------------------------------------------------------------------- hash join
+def join_inputs(rng, nb, npr, key_space, null_frac=0.0, unique=False):
+    lk = rng.permutation(key_space)[:nb].astype(np.int64) if unique else rng.integers(0, key_space, nb).astype(np.int64)
+    left = [Column.from_numpy(lk), Column.from_numpy(rng.integers(-1000, 1000, nb).astype(np.int64), None if null_frac == 0 else rng.random(nb) > null_frac),
+            Column.from_numpy(rng.random(nb) < 0.5)]
+    rkey = rng.integers(-3, key_space + 3, npr).astype(np.int64)
+    right = [Column.from_numpy(rng.random(npr), None if null_frac == 0 else rng.random(npr) > null_frac), Column.from_numpy(rkey)]
+    return left, right
+
+
+@pytest.mark.parametrize("unique", [True, False])
+@pytest.mark.parametrize("nb,npr,space", [(0, 10, 5), (5, 0, 5), (1, 1, 1), (50, 1000, 40), (5000, 20000, 5000), (6000, 9000, 100), (20000, 30000, 1 << 40)])
+def test_hash_join_matches_oracle(ctx, nb, npr, space, unique):
+    if unique and space < nb:
+        pytest.skip("cannot draw unique keys")
+    rng = np.random.default_rng(nb * 3 + npr)
+    left, right = join_inputs(rng, nb, npr, space, null_frac=0.1, unique=unique)
+    exp = orc.hash_join([left], [right], 0, 1)[0]
+    got = ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 0, 1).to_host()
+    assert_batches_equal(got, exp, what=f"join nb={nb} np={npr}")   # same rows in the SAME order
+
+
+def test_hash_join_heavy_duplicates_and_build_probe_reuse(ctx):
+    rng = np.random.default_rng(2)
+    lk = np.repeat(np.array([7, -1, 7, 3], dtype=np.int64), 1500)       # 6000 build rows, 3 distinct keys
+    left = [Column.from_numpy(lk), Column.from_numpy(np.arange(lk.size, dtype=np.int64))]
+    jt = ctx.hash_join_build(ctx.table_from_host(left), 0)
+    for seed in (1, 2):
+        rk = np.random.default_rng(seed).integers(-2, 9, 300).astype(np.int64)
+        right = [Column.from_numpy(rk)]
+        exp = orc.hash_join([left], [right], 0, 0)[0]
+        got = ctx.hash_join_probe(jt, ctx.table_from_host(right), 0).to_host()
+        assert_batches_equal(got, exp)
+
+
+def test_hash_join_ignores_key_validity_q11_and_uint64(ctx):
+    lk = Column.from_list([7, 3, 7, None, 7], DType.INT64)
+    left = [lk, Column.from_list([10, 11, 12, 13, 14], DType.INT64)]
+    right = [Column.from_list([3, 7, 0, 9], DType.INT64), Column.from_list([0.5, 1.5, 2.5, 3.5], DType.FLOAT64)]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    assert_batches_equal(ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 0, 0).to_host(), exp)
+    ul = [Column.from_numpy(np.array([1 << 63, 5, (1 << 64) - 1], dtype=np.uint64))]
+    ur = [Column.from_numpy(np.array([(1 << 64) - 1, 1 << 63, 6], dtype=np.uint64))]
+    assert_batches_equal(ctx.hash_join(ctx.table_from_host(ul), ctx.table_from_host(ur), 0, 0).to_host(), orc.hash_join([ul], [ur], 0, 0)[0])
+
+
+def test_hash_join_errors(ctx):
+    a = ctx.table_from_host([Column.from_list([1.0], DType.FLOAT64)])
+    i = ctx.table_from_host([Column.from_list([1], DType.INT64)])
+    u = ctx.table_from_host([Column.from_list([1], DType.UINT64)])
+    for l, r, lk, rk, st in [(a, a, 0, 0, Status.NotImplemented), (i, a, 0, 0, Status.NotImplemented), (i, u, 0, 0, Status.NotSupported),
+                             (i, i, -1, -1, Status.PlanError)]:
+        with pytest.raises(ErrorCode) as e:
+            ctx.hash_join(l, r, lk, rk)
+        assert e.value.status == st
+
+
+# --------------------------------------------------------------------------- table utilities
+def test_take_slice_concat_project(ctx):
+    rng = np.random.default_rng(3)
+    cols = random_batch(rng, 1000, 0.2, with_bool=True)
+    t = ctx.table_from_host(cols)
+    idx = rng.integers(0, 1000, 777).astype(np.int64)
+    got = ctx.take(t, ctx.table_from_host([Column.from_numpy(idx)])).to_host()
+    for g, c in zip(got, cols):
+        exp = Column.from_numpy(c.to_numpy()[idx], c.valid_mask()[idx])
+        assert_column_equal(g, exp)
+    with pytest.raises(ErrorCode):
+        ctx.take(t, ctx.table_from_host([Column.from_numpy(np.array([1000], dtype=np.int64))]))
+    for off, ln in [(0, 1000), (3, 100), (64, 65), (999, 1), (10, 0)]:
+        got = ctx.slice(t, off, ln).to_host()
+        assert_batches_equal(got, orc.limit(orc.offset([cols], off), ln)[0] if ln else [Column.from_numpy(c.to_numpy()[0:0]) for c in cols])
+    parts = [random_batch(rng, m, nf, with_bool=True) for m, nf in [(5, 0.0), (130, 0.3), (0, 0.0), (64, 0.0), (7, 0.5)]]
+    got = ctx.concat([ctx.table_from_host(p) for p in parts]).to_host()
+    for ci, g in enumerate(got):
+        vals = np.concatenate([p[ci].to_numpy() for p in parts])
+        mask = np.concatenate([p[ci].valid_mask() for p in parts])
+        assert_column_equal(g, Column.from_numpy(vals, mask))
+    pr = ctx.project(t, [2, 1]).to_host()
+    assert_batches_equal(pr, [cols[2], cols[1]])
+
+
+def test_synth_fill_matches_oracle_generator(ctx):
+    import ctypes
+
+    from naive_query_engine_amd import capi
+
+    n = 100003
+    for kind, seed, mod, base in [(0, 0, 1, 0), (1, 2, 60, 18), (1, 5, 1000000, 0), (2, 3, 1, 0)]:
+        ptr = ctx.device_alloc(n * 8)
+        ctx.synth_fill(kind, seed, 17, n, mod, base, ptr)
+        t = ctx.table_from_device([(DType.UINT64, n, ptr, None)])
+        got = t.download_column(0).to_numpy()
+        assert (got == orc.synth_fill(kind, seed, 17, n, mod, base)).all()
+        del t
+        ctx.device_free(ptr)
+
+
+# --------------------------------------------------------------------------- golden fixtures on the GPU
+def test_golden_fixture_queries_on_gpu(ctx, csv_tables, golden):
+    t1 = csv_tables["test_data"]
+    num = [t1.columns[0], t1.columns[2], t1.columns[3]]  # id, age, score (Utf8 `name` stays on the host for now)
+    f = fields("id", "age", "score")
+    t = ctx.table_from_host(num)
+    # test_selection: (id + 1) > 5
+    got = ctx.selection(t, binop(binop(col("id"), Operator.Plus, lit_i64(1)), Operator.Gt, lit_i64(5)).flatten(f)).to_host()
+    assert got[0].to_list() == golden["test_selection"]["id"]
+    # test_projection: id + 1
+    got = ctx.projection(t, [binop(col("id"), Operator.Plus, lit_i64(1)).flatten(f)]).to_host()
+    assert got[0].to_list() == golden["test_projection"]["id_plus_1"]
+    # select id, age from t1 where id > 1
+    got = ctx.selection_projection(t, binop(col(0), Operator.Gt, lit_i64(1)).flatten(f), [col(0).flatten(f), col(1).flatten(f)]).to_host()
+    assert got[0].to_list() == golden["sql_where_id_gt_1"]["id"] and got[1].to_list() == golden["sql_where_id_gt_1"]["age"]
+    # README aggregate: exact digits are sequential-order artefacts → 1e-9 relative, counts exact
+    aggs = [(AggregateFunc.Count, 0), (AggregateFunc.Sum, 1), (AggregateFunc.Sum, 2), (AggregateFunc.Avg, 2), (AggregateFunc.Max, 2), (AggregateFunc.Min, 2)]
+    got = ctx.aggregate(t, aggs, group_nodes=binop(col(0), Operator.Modulos, lit_i64(3)).flatten(f)).to_host()
+    rows = np.array(sorted(map(list, zip(*[c.to_list() for c in got]))), dtype=np.float64)
+    exp = np.array(sorted(golden["readme_group_by_id_mod_3"]["rows"]), dtype=np.float64)
+    assert (rows[:, 0] == exp[:, 0]).all() and np.allclose(rows, exp, rtol=RTOL, atol=0)
+    # README joins on the numeric columns: employee(id, department_id, rank) ⋈ rank(id) ⋈ department(id)
+    emp, rank, dep = csv_tables["employee"], csv_tables["rank"], csv_tables["department"]
+    e = ctx.table_from_host([emp.columns[0], emp.columns[2], emp.columns[3]])
+    r = ctx.table_from_host([rank.columns[0]])
+    d = ctx.table_from_host([dep.columns[0]])
+    j2 = ctx.hash_join(ctx.hash_join(e, r, 2, 0), d, 1, 0).to_host()
+    assert j2[0].to_list() == [row[0] for row in golden["readme_two_hash_joins"]["rows"]]  # employee ids in README order
