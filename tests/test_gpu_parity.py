@@ -312,7 +312,13 @@ def test_aggregate_errors(ctx):
 
 # --------------------------------------------------------------------------- hash join
 def join_inputs(rng, nb, npr, key_space, null_frac=0.0, unique=False):
-    lk = rng.permutation(key_space)[:nb].astype(np.int64) if unique else rng.integers(0, key_space, nb).astype(np.int64)
+    if unique:
+        # never materialise range(key_space): draw 2*nb candidates, de-duplicate, shuffle
+        cand = np.unique(rng.integers(0, key_space, 2 * nb + 16)) if key_space > 4 * nb else np.arange(key_space)
+        lk = rng.permutation(cand)[:nb].astype(np.int64)
+        assert lk.size == nb
+    else:
+        lk = rng.integers(0, key_space, nb).astype(np.int64)
     left = [Column.from_numpy(lk), Column.from_numpy(rng.integers(-1000, 1000, nb).astype(np.int64), None if null_frac == 0 else rng.random(nb) > null_frac),
             Column.from_numpy(rng.random(nb) < 0.5)]
     rkey = rng.integers(-3, key_space + 3, npr).astype(np.int64)
