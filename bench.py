@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--workload", default="headline", choices=["headline", "c2", "c3", "c4"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the BASELINE size of the workload)")
     ap.add_argument("--random-keys", action="store_true", help="c3/headline: group by a random id column instead of the row number")
+    ap.add_argument("--pass-frac", type=float, default=0.5, help="headline: fraction of rows passing `id < K` (diagnostics; the metric uses 0.5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=40_000_000)
     return ap.parse_args()
@@ -92,7 +93,7 @@ def main():
         table = ctx.table_from_device([(DType.INT64, n, ids.data_ptr(), None), (DType.FLOAT64, n, v.data_ptr(), None)])
         fields = [F("id"), F("v")]
         key = binop(col(0), Operator.Modulos, lit_i64(1024)).flatten(fields)
-        pred = binop(col(0), Operator.Lt, lit_i64(total // 2)).flatten(fields) if args.workload == "headline" else None
+        pred = binop(col(0), Operator.Lt, lit_i64(int(total * args.pass_frac))).flatten(fields) if args.workload == "headline" else None
         algo_bytes_per_row = 16.0
         kernel_name = "agg_grouped"
 

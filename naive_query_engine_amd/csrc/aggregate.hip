@@ -144,6 +144,27 @@ __device__ __forceinline__ void global_update(const GroupTable &g, int64_t slot,
 __device__ __forceinline__ bool row_valid(const ColSrc &c, int64_t row) { return c.valid ? get_bit(c.valid, row) : true; }
 
 // ------------------------------------------------------------------ grouped kernel
+// The general SimpleExpr evaluator (with its 64-bit software divides) is kept OUT of line: inlined
+// into the 4x-unrolled row loop for predicate and key it produced a 30k-instruction kernel that was
+// instruction-fetch bound (2.2 TB/s).  The shapes every BASELINE config uses are specialised instead:
+//   PRED: 0 none | 1 `col cmp lit` (literal on either side, normalised on the host) | 2 Boolean bitmap
+//         | 3 any other SimpleExpr (out-of-line)
+//   KEY : 0 plain column | 1 `col % ±2^k` | 2 any other SimpleExpr (out-of-line)
+//   PLAIN: every streamed source is an 8-byte column without a validity bitmap (no bitmap loads)
+__device__ __noinline__ uint64_t eval_simple_slow(const SimpleExpr &e, uint64_t v, bool valid, int *flags) {
+    return eval_simple(e, v, valid, flags);
+}
+
+__device__ __forceinline__ bool cmp_lit(int op, int dt, uint64_t a, uint64_t b) {
+    bool lt, eq;
+    if (dt == NQE_INT64) { lt = (long long)a < (long long)b; eq = a == b; }
+    else if (dt == NQE_FLOAT64) { double x = u2d(a), y = u2d(b); lt = x < y; eq = x == y; if (x != x || y != y) return op == NQE_OP_NOT_EQ; }
+    else { lt = a < b; eq = a == b; }
+    return op == NQE_OP_EQ ? eq : op == NQE_OP_NOT_EQ ? !eq : op == NQE_OP_LT ? lt : op == NQE_OP_LT_EQ ? (lt || eq)
+           : op == NQE_OP_GT ? !(lt || eq) : !lt;
+}
+
+template <int PRED, int KEY, bool PLAIN>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
@@ -169,6 +190,54 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
     }
     __syncthreads();
 
+    // Per-thread run cache.  All rows a thread visits are congruent modulo blockDim (row = base + u*blockDim +
+    // tid with base a multiple of blockDim*AGG_U), so for clustered keys — and for `id % m` over a row-number id
+    // whenever m divides blockDim — consecutive rows of a thread carry the SAME key.  They are accumulated in
+    // registers and written to the workgroup table only when the key changes (one flush per run instead of four
+    // LDS atomics per row).  Random keys flush every row.
+    bool run_live = false;
+    uint64_t run_key = 0;
+    uint32_t rcnt[NV];
+    double rsum[NV];
+    uint64_t rmn[NV], rmx[NV];
+    bool rnan[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = ORD_MAX; rmx[j] = ORD_MIN; rnan[j] = false;
+    }
+    auto flush_run = [&]() {
+        int slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+        int64_t gslot = slot < 0 ? global_find_or_insert(g, run_key, flags) : 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (j >= a.nv) continue;
+            if (slot >= 0) {
+                uint32_t o = uint32_t(j) * slots + uint32_t(slot);
+                if (rcnt[j]) atomicAdd(&lcnt[o], rcnt[j]); // < 2^31 rows per workgroup, bit 31 is the NaN flag
+                if (rnan[j]) atomicOr(&lcnt[o], NAN_BIT);
+                if (a.need_sum[j] && rcnt[j]) unsafeAtomicAdd(&lsum[o], rsum[j]);
+                if (a.need_minmax[j]) {
+                    // read-before-atomic: once a group holds a few rows almost no run improves its extremes, and
+                    // an LDS read costs a small fraction of a 64-bit LDS atomic.  A stale read only causes a
+                    // redundant (still correct) atomic.
+                    if (rmn[j] < lmn[o]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)rmn[j]);
+                    if (rmx[j] > lmx[o]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)rmx[j]);
+                }
+            } else if (gslot >= 0) {
+                global_update(g, gslot, a.v0 + j, rcnt[j], rsum[j], a.need_sum[j] != 0, rmn[j], rmx[j], a.need_minmax[j] != 0,
+                              rnan[j]);
+            }
+            rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = ORD_MAX; rmx[j] = ORD_MIN; rnan[j] = false;
+        }
+    };
+
+    const uint64_t *keyp = static_cast<const uint64_t *>(a.key_src.values);
+    const uint64_t *predp = static_cast<const uint64_t *>(a.pred_src.values);
+    const int pred_op = a.pred.op[0], pred_dt = a.pred.op_dtype[0];
+    const uint64_t pred_lit = a.pred.lit[0];
+    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
+    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
+
     const int64_t step = int64_t(blockDim.x) * AGG_U;
     for (int64_t base = int64_t(blockIdx.x) * step; base < a.n; base += int64_t(gridDim.x) * step) {
         uint64_t kw[AGG_U], pw[AGG_U], vw[NV][AGG_U];
@@ -177,8 +246,13 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * blockDim.x + threadIdx.x;
             bool in = row < a.n;
-            kw[u] = (in && a.has_key) ? load_word(a.key_src.values, a.key_src.dtype, row) : 0;
-            pw[u] = (in && a.pred_mode == 1 && !a.pred_shares_key) ? load_word(a.pred_src.values, a.pred_src.dtype, row) : 0;
+            if (PLAIN) {
+                kw[u] = in ? keyp[row] : 0;
+                pw[u] = ((PRED == 1 || PRED == 3) && in && !a.pred_shares_key) ? predp[row] : 0;
+            } else {
+                kw[u] = in ? load_word(a.key_src.values, a.key_src.dtype, row) : 0;
+                pw[u] = ((PRED == 1 || PRED == 3) && in && !a.pred_shares_key) ? load_word(a.pred_src.values, a.pred_src.dtype, row) : 0;
+            }
 #pragma unroll
             for (int j = 0; j < NV; ++j)
                 vw[j][u] = (in && j < a.nv && a.val[j].values && !a.val_shares_key[j])
@@ -190,52 +264,54 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * blockDim.x + threadIdx.x;
             bool pass = row < a.n;
-            if (a.pred_mode == 1) {
-                bool ok = pass && row_valid(a.pred_src, row);
+            if (PRED == 1 || PRED == 3) {
+                bool ok = pass && (PLAIN || row_valid(a.pred_src, row));
                 uint64_t w = a.pred_shares_key ? kw[u] : pw[u];
-                pass = ok && eval_simple(a.pred, w, ok, flags) != 0;
-            } else if (a.pred_mode == 2) {
+                if (PRED == 1) pass = ok && cmp_lit(pred_op, pred_dt, w, pred_lit);
+                else pass = ok && eval_simple_slow(a.pred, w, ok, flags) != 0;
+            } else if (PRED == 2) {
                 pass = pass && get_bit(static_cast<const uint8_t *>(a.pred_src.values), row) && row_valid(a.pred_src, row);
             }
-            uint64_t key = 0;
-            if (a.has_key) {
-                bool kok = pass && row_valid(a.key_src, row);
-                key = eval_simple(a.key, kw[u], kok, flags);
-                pass = kok;
-            }
+            bool kok = pass && (PLAIN || row_valid(a.key_src, row));
+            uint64_t key;
+            if (KEY == 0) key = kw[u];
+            else if (KEY == 1) {
+                uint64_t x = kw[u];
+                bool neg = key_signed && (long long)x < 0;
+                uint64_t ur = (neg ? 0ull - x : x) & key_mask;
+                key = neg ? 0ull - ur : ur;
+            } else key = eval_simple_slow(a.key, kw[u], kok, flags);
+            pass = kok;
             if (!pass) continue;
-            int slot = lds_find_or_insert(lkeys, key, cap, a.lds_shift);
-            int64_t gslot = slot < 0 ? global_find_or_insert(g, key, flags) : 0;
-            if (slot < 0 && gslot < 0) continue;
+            if (!run_live || key != run_key) {
+                if (run_live) flush_run();
+                run_key = key;
+                run_live = true;
+            }
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 if (j >= a.nv) continue;
-                if (!row_valid(a.val[j], row)) continue;
-                bool num = a.need_sum[j] || a.need_minmax[j];
-                double x = num ? word_as_f64(a.val_shares_key[j] ? kw[u] : vw[j][u], a.val[j].dtype) : 0.0;
-                bool isn = num && x != x;
-                uint64_t xo = f64_to_ord(x);
-                if (slot >= 0) {
-                    uint32_t o = uint32_t(j) * slots + uint32_t(slot);
-                    atomicAdd(&lcnt[o], 1u); // < 2^31 rows per workgroup, bit 31 is the NaN flag
-                    if (isn) atomicOr(&lcnt[o], NAN_BIT);
-                    if (a.need_sum[j]) unsafeAtomicAdd(&lsum[o], x);
-                    if (a.need_minmax[j] && !isn) {
-                        atomicMin((unsigned long long *)&lmn[o], (unsigned long long)xo);
-                        atomicMax((unsigned long long *)&lmx[o], (unsigned long long)xo);
+                if (!PLAIN && !row_valid(a.val[j], row)) continue;
+                rcnt[j] += 1;
+                if (a.need_sum[j] || a.need_minmax[j]) {
+                    double x = word_as_f64(a.val_shares_key[j] ? kw[u] : vw[j][u], a.val[j].dtype);
+                    rsum[j] += x;
+                    if (x != x) rnan[j] = true;
+                    else {
+                        uint64_t xo = f64_to_ord(x);
+                        rmn[j] = xo < rmn[j] ? xo : rmn[j];
+                        rmx[j] = xo > rmx[j] ? xo : rmx[j];
                     }
-                } else {
-                    global_update(g, gslot, a.v0 + j, 1, x, a.need_sum[j] != 0, xo, xo, a.need_minmax[j] && !isn, isn);
                 }
             }
         }
     }
+    if (run_live) flush_run();
     __syncthreads();
     // ---- merge this workgroup's table into the global one
     for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
         uint64_t k = lkeys[s];
-        bool used = (s == cap) ? (k != EMPTY_KEY) : (k != EMPTY_KEY);
-        if (!used) continue;
+        if (k == EMPTY_KEY) continue;
         uint64_t key = (s == cap) ? EMPTY_KEY : k;
         int64_t gslot = global_find_or_insert(g, key, flags);
         if (gslot < 0) continue;
@@ -247,6 +323,248 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
             global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], a.need_sum[j] != 0, lmn[o], lmx[o],
                           a.need_minmax[j] != 0, (c & NAN_BIT) != 0);
         }
+    }
+}
+
+// ------------------------------------------------------------------ grouped kernel, fast path
+// Sources are plain 8-byte columns without validity; predicate is none / integer `col cmp lit`;
+// key is a plain column / `col % ±2^k`.  Differences from the general kernel above:
+//   * NVT (value columns) and VF64 (all values Float64) are static, every statistic is always
+//     maintained → no flag or dtype branches in the row loop;
+//   * the integer predicate is a branch-free range test: the host rewrites `x op lit` into
+//     lo <= (x ^ flip) <= hi, optionally negated (flip = sign bit for UInt64 → signed compares);
+//   * min/max run on native v_min_f64/v_max_f64 (NaN operands are ignored by the instruction and
+//     tracked by a flag, which is exactly OrderedFloat's min rule and makes max NaN at the end);
+//   * loads are unconditional (row index clamped to n-1): no exec-mask branches around them;
+//   * PIPE: the NEXT tile's words are requested before the current tile is processed (two register
+//     tiles), so waits are counted `s_waitcnt vmcnt(k)` and a wave keeps a tile in flight while it
+//     computes.
+// PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column.
+struct FastPred {
+    int64_t lo, hi;
+    uint64_t flip;
+    int32_t negate;
+    int32_t pad;
+};
+
+template <int PRED, int KEY, int NVT, bool VF64, bool PIPE>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t cap = uint32_t(a.lds_cap);
+    const uint32_t slots = cap + 1;
+    uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
+    double *lsum = reinterpret_cast<double *>(lkeys + slots);            // [NVT][slots]
+    uint64_t *lmn = reinterpret_cast<uint64_t *>(lsum + NVT * slots);    // [NVT][slots]
+    uint64_t *lmx = lmn + NVT * slots;                                   // [NVT][slots]
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + NVT * slots);    // [NVT][slots]
+    const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
+    for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+        lkeys[s] = EMPTY_KEY;
+#pragma unroll
+        for (int j = 0; j < NVT; ++j) {
+            lsum[j * slots + s] = 0.0;
+            lmn[j * slots + s] = ORD_MAX;
+            lmx[j * slots + s] = ORD_MIN;
+            lcnt[j * slots + s] = 0;
+        }
+    }
+    __syncthreads();
+
+    bool run_live = false;
+    uint64_t run_key = 0;
+    uint32_t rcnt[NVT];
+    double rsum[NVT], rmn[NVT], rmx[NVT];
+    bool rnan[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) {
+        rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
+    }
+    auto flush_run = [&]() {
+        int slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+        int64_t gslot = slot < 0 ? global_find_or_insert(g, run_key, flags) : 0;
+#pragma unroll
+        for (int j = 0; j < NVT; ++j) {
+            const uint64_t omn = f64_to_ord(rmn[j]), omx = f64_to_ord(rmx[j]);
+            if (slot >= 0) {
+                uint32_t o = uint32_t(j) * slots + uint32_t(slot);
+                if (rcnt[j]) {
+                    atomicAdd(&lcnt[o], rcnt[j]);
+                    unsafeAtomicAdd(&lsum[o], rsum[j]);
+                }
+                if (rnan[j]) atomicOr(&lcnt[o], NAN_BIT);
+                // read-before-atomic (see the general kernel)
+                if (omn < lmn[o]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)omn);
+                if (omx > lmx[o]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)omx);
+            } else if (gslot >= 0) {
+                global_update(g, gslot, a.v0 + j, rcnt[j], rsum[j], true, omn, omx, true, rnan[j]);
+            }
+            rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
+        }
+    };
+
+    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ valp[NVT];
+    int vdt[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) {
+        valp[j] = static_cast<const uint64_t *>(a.val[j].values);
+        vdt[j] = a.val[j].dtype;
+    }
+    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
+    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
+    const int64_t n = a.n, last = a.n - 1;
+
+    struct Tile {
+        uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
+    };
+    auto load_tile = [&](Tile &t, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            row = row < last ? row : last; // clamp: unconditional, in-bounds
+            t.kw[u] = keyp[row];
+            if (PRED == 2) t.pw[u] = predp[row];
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) t.vw[j][u] = valp[j][row];
+        }
+    };
+    auto process_tile = [&](const Tile &t, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            bool pass = row < n;
+            if (PRED != 0) {
+                int64_t xs = int64_t((PRED == 1 ? t.kw[u] : t.pw[u]) ^ fp.flip);
+                pass = pass && (((xs >= fp.lo) && (xs <= fp.hi)) != (fp.negate != 0));
+            }
+            uint64_t key;
+            if (KEY == 0) key = t.kw[u];
+            else {
+                // truncated remainder by ±2^k: |x| & mask, sign of the dividend
+                uint64_t x = t.kw[u];
+                uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
+                uint64_t ur = ((x ^ sgn) - sgn) & key_mask;
+                key = (ur ^ sgn) - sgn;
+            }
+            if (!pass) continue;
+            if (!run_live || key != run_key) {
+                if (run_live) flush_run();
+                run_key = key;
+                run_live = true;
+            }
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+                double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+                rcnt[j] += 1;
+                rsum[j] += x;
+                rnan[j] = rnan[j] || (x != x);
+                rmn[j] = fmin(rmn[j], x); // NaN operand ignored
+                rmx[j] = fmax(rmx[j], x);
+            }
+        }
+    };
+
+    const int64_t step = int64_t(AGG_BLOCK) * AGG_U;
+    const int64_t stride = int64_t(gridDim.x) * step;
+    int64_t base = int64_t(blockIdx.x) * step;
+    if (PIPE) {
+        if (base < n) {
+            Tile A, B;
+            load_tile(A, base);
+            for (;;) {
+                load_tile(B, base + stride); // prefetch (clamped, always issued)
+                process_tile(A, base);
+                base += stride;
+                if (base >= n) break;
+                load_tile(A, base + stride);
+                process_tile(B, base);
+                base += stride;
+                if (base >= n) break;
+            }
+        }
+    } else {
+        for (; base < n; base += stride) {
+            Tile A;
+            load_tile(A, base);
+            process_tile(A, base);
+        }
+    }
+    if (run_live) flush_run();
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+        uint64_t k = lkeys[s];
+        if (k == EMPTY_KEY) continue;
+        uint64_t key = (s == cap) ? EMPTY_KEY : k;
+        int64_t gslot = global_find_or_insert(g, key, flags);
+        if (gslot < 0) continue;
+#pragma unroll
+        for (int j = 0; j < NVT; ++j) {
+            uint32_t o = uint32_t(j) * slots + s;
+            uint32_t c = lcnt[o];
+            global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
+        }
+    }
+}
+
+// host: `x op lit` (x Int64/UInt64) → range test. Returns false if the shape is not covered.
+bool make_fast_pred(const SimpleExpr &pe, FastPred *fp) {
+    if (pe.nops != 1 || pe.op[0] > NQE_OP_GT_EQ) return false;
+    if (pe.src_dtype != NQE_INT64 && pe.src_dtype != NQE_UINT64) return false;
+    static const int flip_op[6] = {NQE_OP_EQ, NQE_OP_NOT_EQ, NQE_OP_GT, NQE_OP_GT_EQ, NQE_OP_LT, NQE_OP_LT_EQ};
+    int op = pe.lit_left[0] ? flip_op[pe.op[0]] : pe.op[0]; // lit op x  ≡  x op' lit
+    fp->flip = pe.src_dtype == NQE_UINT64 ? 0x8000000000000000ull : 0ull;
+    const int64_t L = int64_t(pe.lit[0] ^ fp->flip);
+    const int64_t MIN = INT64_MIN, MAX = INT64_MAX;
+    fp->negate = 0;
+    fp->pad = 0;
+    switch (op) {
+    case NQE_OP_EQ: fp->lo = L; fp->hi = L; break;
+    case NQE_OP_NOT_EQ: fp->lo = L; fp->hi = L; fp->negate = 1; break;
+    case NQE_OP_LT: fp->lo = MIN; fp->hi = L - 1; if (L == MIN) { fp->lo = 1; fp->hi = 0; } break; // empty
+    case NQE_OP_LT_EQ: fp->lo = MIN; fp->hi = L; break;
+    case NQE_OP_GT: fp->lo = L + 1; fp->hi = MAX; if (L == MAX) { fp->lo = 1; fp->hi = 0; } break;
+    default: fp->lo = L; fp->hi = MAX; break;
+    }
+    return true;
+}
+
+using GroupedKernel = void (*)(AggArgs, GroupTable, int *);
+template <int PRED, int KEY> GroupedKernel pick_plain(bool plain) {
+    return plain ? agg_grouped_kernel<PRED, KEY, true> : agg_grouped_kernel<PRED, KEY, false>;
+}
+template <int PRED> GroupedKernel pick_key(int key, bool plain) {
+    switch (key) {
+    case 0: return pick_plain<PRED, 0>(plain);
+    case 1: return pick_plain<PRED, 1>(plain);
+    default: return pick_plain<PRED, 2>(plain);
+    }
+}
+GroupedKernel pick_grouped_kernel(int pred, int key, bool plain) {
+    switch (pred) {
+    case 0: return pick_key<0>(key, plain);
+    case 1: return pick_key<1>(key, plain);
+    case 2: return pick_key<2>(key, plain);
+    default: return pick_key<3>(key, plain);
+    }
+}
+
+using FastKernel = void (*)(AggArgs, FastPred, GroupTable, int *);
+template <int PRED, int KEY, int NVT, bool VF64> FastKernel pick_fast_pipe(bool pipe) {
+    return pipe ? agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, true> : agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, false>;
+}
+template <int PRED, int KEY> FastKernel pick_fast_nv(int nv, bool vf64, bool pipe) {
+    if (nv == 1) return vf64 ? pick_fast_pipe<PRED, KEY, 1, true>(pipe) : pick_fast_pipe<PRED, KEY, 1, false>(pipe);
+    return vf64 ? pick_fast_pipe<PRED, KEY, 2, true>(pipe) : pick_fast_pipe<PRED, KEY, 2, false>(pipe);
+}
+FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool pipe) {
+    switch (pred * 2 + key) {
+    case 0: return pick_fast_nv<0, 0>(nv, vf64, pipe);
+    case 1: return pick_fast_nv<0, 1>(nv, vf64, pipe);
+    case 2: return pick_fast_nv<1, 0>(nv, vf64, pipe);
+    case 3: return pick_fast_nv<1, 1>(nv, vf64, pipe);
+    case 4: return pick_fast_nv<2, 0>(nv, vf64, pipe);
+    default: return pick_fast_nv<2, 1>(nv, vf64, pipe);
     }
 }
 
@@ -685,7 +1003,43 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 int blocks_per_cu = shmem <= 80 * 1024 ? 2 : 1;
                 int grid = int(std::min<int64_t>(int64_t(ctx->num_cus) * blocks_per_cu,
                                                  (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
-                launch(ctx, "agg_grouped", agg_grouped_kernel, dim3(grid), dim3(AGG_BLOCK), shmem, a, tb.g, ctx->d_flags);
+                // ---- kernel variant (see the template comment)
+                int pk = 0;
+                AggArgs ka = a;
+                if (a.pred_mode == 2) pk = 2;
+                else if (a.pred_mode == 1) {
+                    const SimpleExpr &pe = a.pred;
+                    pk = 3;
+                    if (pe.nops == 1 && pe.op[0] <= NQE_OP_GT_EQ && is_word_type(pe.src_dtype)) {
+                        pk = 1;
+                        if (pe.lit_left[0]) { // lit op x  ≡  x op' lit
+                            static const int flip[6] = {NQE_OP_EQ, NQE_OP_NOT_EQ, NQE_OP_GT, NQE_OP_GT_EQ, NQE_OP_LT, NQE_OP_LT_EQ};
+                            ka.pred.op[0] = flip[pe.op[0]];
+                            ka.pred.lit_left[0] = 0;
+                        }
+                    }
+                }
+                int kk = 2;
+                if (a.key.nops == 0) kk = 0;
+                else if (a.key.nops == 1 && a.key.op[0] == NQE_OP_MODULOS && !a.key.lit_left[0] && a.key.aux[0].pow2_shift >= 0 &&
+                         (a.key.op_dtype[0] == NQE_INT64 || a.key.op_dtype[0] == NQE_UINT64))
+                    kk = 1;
+                bool plain = is_word_type(a.key_src.dtype) && !a.key_src.valid;
+                if (a.pred_mode == 1) plain = plain && is_word_type(a.pred_src.dtype) && !a.pred_src.valid;
+                for (int j = 0; j < a.nv; ++j) plain = plain && a.val[j].values && !a.val[j].valid;
+                FastPred fpred{};
+                bool fast = plain && a.nv >= 1 && (kk == 0 || kk == 1) && (pk == 0 || (pk == 1 && make_fast_pred(a.pred, &fpred)));
+                if (fast) {
+                    int fp = pk == 0 ? 0 : (a.pred_shares_key ? 1 : 2);
+                    bool vf64 = true;
+                    for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
+                    static const bool pipe = [] { const char *e = getenv("NQE_AGG_PIPE"); return e ? atoi(e) != 0 : true; }();
+                    launch(ctx, "agg_grouped_fast", pick_fast_kernel(fp, kk, a.nv, vf64, pipe), dim3(grid), dim3(AGG_BLOCK), shmem, ka,
+                           fpred, tb.g, ctx->d_flags);
+                } else {
+                    launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain), dim3(grid), dim3(AGG_BLOCK), shmem, ka, tb.g,
+                           ctx->d_flags);
+                }
             } else {
                 int grid = int(std::min<int64_t>(int64_t(ctx->num_cus) * 2,
                                                  (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
