@@ -132,7 +132,7 @@ def main():
         fact = ctx.table_from_device([(DType.INT64, n, fkey.data_ptr(), None), (DType.FLOAT64, n, val.data_ptr(), None)])
         jt = ctx.hash_join_build(dim, 0)  # build replicated on every rank, outside the timed probe
         algo_bytes_per_row = 16.0 + 32.0
-        kernel_name = "join_probe"
+        kernel_name = "join_probe+compact_gather+compact_column"
 
         def step():
             return ctx.hash_join_probe(jt, fact, 0)
@@ -164,6 +164,12 @@ def main():
         a_ms, a_n = ctx.timing_query(kn)
         kern_ms += a_ms
         launches += a_n
+    breakdown = {}
+    for kn in ("agg_grouped", "agg_table_init", "agg_collect", "agg_finalize", "bitonic_small", "keep_from_simple", "compact_expr",
+               "compact_column", "compact_gather", "join_probe_unique", "join_probe_count", "join_probe_write", "scan_chunk", "scan_add"):
+        b_ms, b_n = ctx.timing_query(kn)
+        if b_n:
+            breakdown[kn] = {"ms_per_step": b_ms / args.steps, "launches_per_step": b_n / args.steps}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -180,8 +186,15 @@ def main():
             "data": "synthetic", "config": {"workload": desc, "rows_per_gpu": n, "total_rows": total, "parallelism": f"row-range x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": kernel_name, "kernel_ms_per_step": kavg_ms,
-                         "algorithmic_bytes_per_step": algo_bytes_per_row * n},
+                         "algorithmic_bytes_per_step": algo_bytes_per_row * n, "kernels": breakdown},
         }
+        # HBM bytes per launch from the committed PMC passes of this workload (rocprofv3 cannot be run from inside
+        # the timed process; see profiles/): only reported for the exact configuration that was profiled.
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_headline.json")
+        if args.workload == "headline" and n == 10**9 and not args.random_keys and args.pass_frac == 0.5 and os.path.exists(pmc):
+            with open(pmc) as f:
+                out["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch_corrected"]
+            out["roofline"]["traffic_source"] = "profiles/r01/pmc_traffic_headline.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)"
         if world == 1 and not args.no_cpu_baseline and args.workload in ("headline", "c3", "c2"):
             out["cpu_baseline"] = cpu_baseline(args, n)
         print(json.dumps(out), flush=True)

@@ -340,13 +340,6 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
 //     tiles), so waits are counted `s_waitcnt vmcnt(k)` and a wave keeps a tile in flight while it
 //     computes.
 // PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column.
-struct FastPred {
-    int64_t lo, hi;
-    uint64_t flip;
-    int32_t negate;
-    int32_t pad;
-};
-
 template <int PRED, int KEY, int NVT, bool VF64, bool PIPE>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -435,8 +428,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = row < n;
             if (PRED != 0) {
-                int64_t xs = int64_t((PRED == 1 ? t.kw[u] : t.pw[u]) ^ fp.flip);
-                pass = pass && (((xs >= fp.lo) && (xs <= fp.hi)) != (fp.negate != 0));
+                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : t.pw[u]);
             }
             uint64_t key;
             if (KEY == 0) key = t.kw[u];
@@ -505,28 +497,6 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
         }
     }
-}
-
-// host: `x op lit` (x Int64/UInt64) → range test. Returns false if the shape is not covered.
-bool make_fast_pred(const SimpleExpr &pe, FastPred *fp) {
-    if (pe.nops != 1 || pe.op[0] > NQE_OP_GT_EQ) return false;
-    if (pe.src_dtype != NQE_INT64 && pe.src_dtype != NQE_UINT64) return false;
-    static const int flip_op[6] = {NQE_OP_EQ, NQE_OP_NOT_EQ, NQE_OP_GT, NQE_OP_GT_EQ, NQE_OP_LT, NQE_OP_LT_EQ};
-    int op = pe.lit_left[0] ? flip_op[pe.op[0]] : pe.op[0]; // lit op x  ≡  x op' lit
-    fp->flip = pe.src_dtype == NQE_UINT64 ? 0x8000000000000000ull : 0ull;
-    const int64_t L = int64_t(pe.lit[0] ^ fp->flip);
-    const int64_t MIN = INT64_MIN, MAX = INT64_MAX;
-    fp->negate = 0;
-    fp->pad = 0;
-    switch (op) {
-    case NQE_OP_EQ: fp->lo = L; fp->hi = L; break;
-    case NQE_OP_NOT_EQ: fp->lo = L; fp->hi = L; fp->negate = 1; break;
-    case NQE_OP_LT: fp->lo = MIN; fp->hi = L - 1; if (L == MIN) { fp->lo = 1; fp->hi = 0; } break; // empty
-    case NQE_OP_LT_EQ: fp->lo = MIN; fp->hi = L; break;
-    case NQE_OP_GT: fp->lo = L + 1; fp->hi = MAX; if (L == MAX) { fp->lo = 1; fp->hi = 0; } break;
-    default: fp->lo = L; fp->hi = MAX; break;
-    }
-    return true;
 }
 
 using GroupedKernel = void (*)(AggArgs, GroupTable, int *);

@@ -30,6 +30,20 @@ __device__ __forceinline__ double word_as_f64(uint64_t w, int dtype) {
     return u2d(w);
 }
 
+// The 64-bit software divide (and fmod) are ~200 instructions each; kept out of line so that kernels
+// inlining apply_binary stay small (an inlined copy per unrolled row made the first aggregate kernel
+// 30k instructions long and instruction-fetch bound).
+static __device__ __noinline__ uint64_t divmod_general(int op, int dt, uint64_t a, uint64_t b) {
+    if (dt == NQE_UINT64) return op == NQE_OP_DIVIDE ? a / b : a % b;
+    if (dt == NQE_FLOAT64) {
+        double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
+        double z = op == NQE_OP_DIVIDE ? x / y : fmod(x, y);
+        return (uint64_t)__double_as_longlong(z);
+    }
+    long long x = (long long)a, y = (long long)b;
+    return (uint64_t)(op == NQE_OP_DIVIDE ? x / y : x % y);
+}
+
 // One binary step on raw 64-bit words. `dt` is the OPERAND dtype (result dtype is Boolean for
 // compares). Semantics follow arrow-rs 13 (see oracle/nqe_oracle.cpp): wrapping integer
 // arithmetic, truncated remainder, IEEE float compares; zero divisor / MIN÷-1 raise device
@@ -64,7 +78,7 @@ __device__ __forceinline__ uint64_t apply_binary(int op, int dt, uint64_t a, uin
                 if (valid) atomicOr(&flags[NQE_FLAG_DIV_ZERO], 1);
                 return 0;
             }
-            z = op == NQE_OP_DIVIDE ? x / y : fmod(x, y);
+            return divmod_general(op, dt, a, b);
         }
         return d2u(z);
     }
@@ -79,17 +93,14 @@ __device__ __forceinline__ uint64_t apply_binary(int op, int dt, uint64_t a, uin
         if (valid) atomicOr(&flags[NQE_FLAG_DIV_ZERO], 1);
         return 0;
     }
-    if (dt == NQE_UINT64) {
-        if (aux.pow2_shift >= 0) return op == NQE_OP_DIVIDE ? a >> aux.pow2_shift : a & (aux.abs_lit - 1);
-        return op == NQE_OP_DIVIDE ? a / b : a % b;
-    }
-    long long x = (long long)a, y = (long long)b;
-    if (x == INT64_MIN && y == -1) {
+    if (dt == NQE_INT64 && (long long)a == INT64_MIN && (long long)b == -1) {
         if (valid) atomicOr(&flags[NQE_FLAG_OVERFLOW], 1);
         return 0;
     }
     if (aux.pow2_shift >= 0) {
         // divisor is a literal ±2^k: truncated division/remainder without the 64-bit divide
+        if (dt == NQE_UINT64) return op == NQE_OP_DIVIDE ? a >> aux.pow2_shift : a & (aux.abs_lit - 1);
+        long long x = (long long)a, y = (long long)b;
         uint64_t ux = x < 0 ? 0ull - a : a;
         if (op == NQE_OP_MODULOS) {
             uint64_t ur = ux & (aux.abs_lit - 1);
@@ -99,7 +110,7 @@ __device__ __forceinline__ uint64_t apply_binary(int op, int dt, uint64_t a, uin
         bool neg = (x < 0) != (y < 0);
         return neg ? 0ull - uq : uq;
     }
-    return (uint64_t)(op == NQE_OP_DIVIDE ? x / y : x % y);
+    return divmod_general(op, dt, a, b);
 }
 
 __device__ __forceinline__ OpAux no_aux() {
@@ -145,6 +156,21 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x *= 0xc4ceb9fe1a85ec53ULL;
     x ^= x >> 33;
     return x;
+}
+
+// broadcast lane `lane` (wave-uniform) of a 64-bit value through the scalar unit (v_readlane_b32),
+// instead of an LDS-routed ds_bpermute
+__device__ __forceinline__ uint64_t bcast64(uint64_t x, int lane) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane);
+    return (uint64_t(hi) << 32) | lo;
+}
+__device__ __forceinline__ uint32_t bcast32(uint32_t x, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x, lane); }
+
+// integer `x op lit` as a branch-free range test (host-prepared, see make_fast_pred)
+__device__ __forceinline__ bool range_pass(const FastPred &fp, uint64_t x) {
+    int64_t xs = int64_t(x ^ fp.flip);
+    return ((xs >= fp.lo) && (xs <= fp.hi)) != (fp.negate != 0);
 }
 
 // wave-level exclusive prefix sum of a 32-bit value (wave64, DPP-free shuffle version)

@@ -265,6 +265,28 @@ Value eval_node(nqe_ctx *ctx, const nqe_table *in, const std::vector<Node> &t, i
 
 } // namespace
 
+// `x op lit` (x Int64/UInt64) → range test. Returns false if the shape is not covered.
+bool make_fast_pred(const SimpleExpr &pe, FastPred *fp) {
+    if (pe.nops != 1 || pe.op[0] > NQE_OP_GT_EQ) return false;
+    if (pe.src_dtype != NQE_INT64 && pe.src_dtype != NQE_UINT64) return false;
+    static const int flip_op[6] = {NQE_OP_EQ, NQE_OP_NOT_EQ, NQE_OP_GT, NQE_OP_GT_EQ, NQE_OP_LT, NQE_OP_LT_EQ};
+    int op = pe.lit_left[0] ? flip_op[pe.op[0]] : pe.op[0]; // lit op x  ≡  x op' lit
+    fp->flip = pe.src_dtype == NQE_UINT64 ? 0x8000000000000000ull : 0ull;
+    const int64_t L = int64_t(pe.lit[0] ^ fp->flip);
+    const int64_t MIN = INT64_MIN, MAX = INT64_MAX;
+    fp->negate = 0;
+    fp->pad = 0;
+    switch (op) {
+    case NQE_OP_EQ: fp->lo = L; fp->hi = L; break;
+    case NQE_OP_NOT_EQ: fp->lo = L; fp->hi = L; fp->negate = 1; break;
+    case NQE_OP_LT: fp->lo = MIN; fp->hi = L - 1; if (L == MIN) { fp->lo = 1; fp->hi = 0; } break; // empty
+    case NQE_OP_LT_EQ: fp->lo = MIN; fp->hi = L; break;
+    case NQE_OP_GT: fp->lo = L + 1; fp->hi = MAX; if (L == MAX) { fp->lo = 1; fp->hi = 0; } break;
+    default: fp->lo = L; fp->hi = MAX; break;
+    }
+    return true;
+}
+
 ExprInfo analyze_expr(const nqe_table *in, const nqe_expr_node *nodes, int n) {
     int root;
     std::vector<Node> t = parse(in, nodes, n, &root);

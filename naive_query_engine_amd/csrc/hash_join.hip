@@ -33,6 +33,13 @@ struct nqe_join_table {
     uint32_t cap = 0;
     int shift = 0;
     bool direct = false; // all build keys unique: slot.y>>32 is the build row itself
+    // dense build keys (max-min+1 <= 4n): direct-address table instead of hashing.
+    //   unique keys:   dense[key-min] = build row + 1
+    //   duplicate keys: dense[key-min] = unique-key index + 1 → (ustart[u], ustart[u+1]-ustart[u])
+    int left_key = 0;
+    nqe::BufRef dense;   // uint32[span]
+    nqe::BufRef ustart;  // uint32[U+1]
+    uint64_t dense_min = 0, dense_span = 0; // span = number of entries (0: not dense)
 };
 
 namespace nqe {
@@ -99,10 +106,77 @@ __device__ __forceinline__ uint64_t probe_one(const ulonglong2 *__restrict__ slo
     return 0ull;
 }
 
+struct Lookup {
+    const ulonglong2 *slots; // hash table (16-byte slots)
+    uint32_t cap;
+    int32_t shift;
+    const uint32_t *dense;   // direct-address table or null
+    const uint32_t *ustart;
+    uint64_t dense_min, dense_span;
+    int32_t direct;
+    int32_t pad;
+};
+
+// (start<<32 | count) of `key`, 0 when absent. direct ⇒ start is the build row itself.
+__device__ __forceinline__ uint64_t lookup_meta(const Lookup &L, uint64_t key) {
+    if (L.dense) {
+        uint64_t d = key - L.dense_min;
+        if (d >= L.dense_span) return 0ull;
+        uint32_t e = L.dense[d];
+        if (e == 0) return 0ull;
+        if (L.direct) return (uint64_t(e - 1) << 32) | 1ull;
+        uint32_t st = L.ustart[e - 1];
+        return (uint64_t(st) << 32) | uint64_t(L.ustart[e] - st);
+    }
+    return probe_one(L.slots, L.cap, L.shift, key);
+}
+
+__global__ void fill_dense_kernel(const uint64_t *skeys, const uint32_t *ustart, const uint32_t *perm, uint32_t U, uint64_t dmin,
+                                  uint32_t *dense, int direct) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; u < int64_t(U); u += stride) {
+        uint32_t j = ustart[u];
+        dense[skeys[j] - dmin] = direct ? perm[j] + 1u : uint32_t(u) + 1u;
+    }
+}
+
+// Unique build keys: one lookup per probe row → match bitmap (the KEEP mask of the compaction
+// kernels), 4-byte build row per probe row, per-tile match counts.  Wave per 4096-row tile.
+__global__ void __launch_bounds__(256) probe_unique_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, Lookup L, uint64_t *keep,
+                                                           uint32_t *bidx, uint32_t *tile_counts) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t last = n - 1;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t row0 = tile * TILE_ROWS;
+        uint32_t total = 0;
+#pragma unroll 2
+        for (int k0 = 0; k0 < TILE_WORDS; k0 += 8) {
+            uint64_t key[8], meta[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                key[k] = rkeys[row < last ? row : last];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) meta[k] = lookup_meta(L, key[k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                bool hit = row < n && meta[k] != 0ull;
+                uint64_t kw = __ballot(hit);
+                if (row < n) bidx[row] = uint32_t(meta[k] >> 32);
+                if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
+                total += __popcll(kw);
+            }
+        }
+        if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
 // pass 1: one table lookup per probe row; records meta and per-tile totals
-__global__ void __launch_bounds__(JT_BLOCK) probe_count_kernel(const uint64_t *rkeys, int64_t n, const ulonglong2 *slots,
-                                                               uint32_t cap, int shift, uint64_t *pmeta, uint32_t *tile_counts,
-                                                               int *flags) {
+__global__ void __launch_bounds__(JT_BLOCK) probe_count_kernel(const uint64_t *rkeys, int64_t n, Lookup L, uint64_t *pmeta,
+                                                               uint32_t *tile_counts, int *flags) {
     __shared__ uint64_t wave_tot[JT_BLOCK / 64];
     for (int64_t tile = blockIdx.x; tile * JT_ROWS < n; tile += gridDim.x) {
         uint64_t keys[JT_ITERS];
@@ -116,7 +190,7 @@ __global__ void __launch_bounds__(JT_BLOCK) probe_count_kernel(const uint64_t *r
         for (int it = 0; it < JT_ITERS; ++it) {
             int64_t i = tile * JT_ROWS + int64_t(it) * JT_BLOCK + threadIdx.x;
             if (i < n) {
-                uint64_t m = probe_one(slots, cap, shift, keys[it]);
+                uint64_t m = lookup_meta(L, keys[it]);
                 pmeta[i] = m;
                 local += m & 0xFFFFFFFFull;
             }
@@ -206,6 +280,7 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
     jt->left_cols = left->cols;
     jt->left_rows = n;
     jt->key_dtype = kc.dtype;
+    jt->left_key = left_key;
 
     BufRef idx = dev_alloc(ctx, size_t(n) * 4 + 8), skeys = dev_alloc(ctx, size_t(n) * 8 + 8);
     jt->perm = dev_alloc(ctx, size_t(n) * 4 + 8);
@@ -238,6 +313,20 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
         launch(ctx, "join_insert", insert_unique_kernel, dim3(stream_grid(ctx, U, 256)), dim3(256), 0, (const uint64_t *)skeys->ptr,
                (const uint32_t *)ustart->ptr, (const uint32_t *)jt->perm->ptr, U, (ulonglong2 *)jt->slots->ptr, cap, jt->shift,
                jt->direct ? 1 : 0);
+    // dense key range → direct-address table (keys are sorted unsigned: first/last are min/max)
+    if (n > 0 && U > 0) {
+        uint64_t kmin = read_scalar(ctx, (const uint64_t *)skeys->ptr);
+        uint64_t kmax = read_scalar(ctx, (const uint64_t *)skeys->ptr + (n - 1));
+        uint64_t span = kmax - kmin + 1; // 0 on wrap-around: not dense
+        if (span != 0 && span <= std::max<uint64_t>(4ull * uint64_t(n), 1024ull) && span < (1ull << 31)) {
+            jt->dense = dev_alloc_zero(ctx, size_t(span) * 4);
+            jt->dense_min = kmin;
+            jt->dense_span = span;
+            launch(ctx, "join_fill_dense", fill_dense_kernel, dim3(stream_grid(ctx, U, 256)), dim3(256), 0, (const uint64_t *)skeys->ptr,
+                   (const uint32_t *)ustart->ptr, (const uint32_t *)jt->perm->ptr, U, kmin, (uint32_t *)jt->dense->ptr, jt->direct ? 1 : 0);
+            if (!jt->direct) jt->ustart = ustart;
+        }
+    }
     sync(ctx); // skeys/flags/ustart are released on return
     return jt;
 }
@@ -254,14 +343,60 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
     for (auto &c : right->cols)
         if (c.dtype == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 payload columns are not supported by the device join yet");
 
+    Lookup L;
+    std::memset(&L, 0, sizeof(L));
+    L.slots = (const ulonglong2 *)jt->slots->ptr;
+    L.cap = jt->cap;
+    L.shift = jt->shift;
+    L.dense = jt->dense ? (const uint32_t *)jt->dense->ptr : nullptr;
+    L.ustart = jt->ustart ? (const uint32_t *)jt->ustart->ptr : nullptr;
+    L.dense_min = jt->dense_min;
+    L.dense_span = jt->dense_span;
+    L.direct = jt->direct ? 1 : 0;
+
+    if (jt->direct) {
+        // unique build keys: every probe row yields 0/1 rows → stream compaction with a gather
+        KeepMask km;
+        km.n = n;
+        km.ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+        int64_t nwords = (n + 63) / 64;
+        km.keep = dev_alloc(ctx, size_t(nwords) * 8 + 8);
+        BufRef bidx = dev_alloc(ctx, size_t(n) * 4 + 8);
+        BufRef counts = dev_alloc(ctx, size_t(km.ntiles + 1) * 4);
+        if (km.ntiles)
+            launch(ctx, "join_probe_unique", probe_unique_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n,
+                   km.ntiles, L, (uint64_t *)km.keep->ptr, (uint32_t *)bidx->ptr, (uint32_t *)counts->ptr);
+        km = finish_mask(ctx, km, counts);
+        auto out = std::make_unique<nqe_table>();
+        out->ctx = ctx;
+        out->rows = km.total;
+        for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
+            const DevColumn &c = jt->left_cols[ci];
+            if (int(ci) == jt->left_key && !c.validity) {
+                // the build key of a matched row is bit-identical to the probe key: produce the column by the
+                // coalesced compaction of the probe keys instead of a random gather (validity comes from the
+                // LEFT column, which has none here)
+                DevColumn as_left = rk;
+                as_left.validity = nullptr;
+                as_left.null_count = 0;
+                out->cols.push_back(compact_column(ctx, as_left, km));
+            } else {
+                out->cols.push_back(compact_gather_column(ctx, c, (const uint32_t *)bidx->ptr, km));
+            }
+        }
+        for (auto &c : right->cols) out->cols.push_back(compact_column(ctx, c, km));
+        sync(ctx); // bidx / mask are released on return
+        return out;
+    }
+
     const int64_t ntiles = (n + JT_ROWS - 1) / JT_ROWS;
     BufRef pmeta = dev_alloc(ctx, size_t(n) * 8 + 8);
     BufRef counts = dev_alloc(ctx, size_t(ntiles + 1) * 4);
     BufRef offs = dev_alloc(ctx, size_t(ntiles + 1) * 8);
     int grid = int(std::max<int64_t>(1, std::min<int64_t>(ntiles, int64_t(ctx->num_cus) * 8)));
     if (n)
-        launch(ctx, "join_probe_count", probe_count_kernel, dim3(grid), dim3(JT_BLOCK), 0, rk.words(), n,
-               (const ulonglong2 *)jt->slots->ptr, jt->cap, jt->shift, (uint64_t *)pmeta->ptr, (uint32_t *)counts->ptr, ctx->d_flags);
+        launch(ctx, "join_probe_count", probe_count_kernel, dim3(grid), dim3(JT_BLOCK), 0, rk.words(), n, L, (uint64_t *)pmeta->ptr,
+               (uint32_t *)counts->ptr, ctx->d_flags);
     exclusive_scan_u32_to_u64(ctx, (const uint32_t *)counts->ptr, (uint64_t *)offs->ptr, ntiles);
     const int64_t M = int64_t(read_scalar(ctx, (const uint64_t *)offs->ptr + ntiles));
     {

@@ -192,6 +192,16 @@ struct SimpleExpr {
     OpAux aux[2];
 };
 
+// `x op lit` over an Int64/UInt64 column rewritten as  lo <= (x ^ flip) <= hi  (xor negate)
+struct FastPred {
+    int64_t lo, hi;
+    uint64_t flip;
+    int32_t negate;
+    int32_t pad;
+};
+// returns false when the SimpleExpr is not a single integer compare against a literal
+bool make_fast_pred(const SimpleExpr &pe, FastPred *fp);
+
 struct ExprInfo {
     int out_dtype = NQE_NULLTYPE;
     bool simple = false;
@@ -216,6 +226,10 @@ KeepMask build_keep_mask(nqe_ctx *ctx, const DevColumn &pred, int64_t n_rows);
 // predicate given as a fused SimpleExpr over `in`
 KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &pred);
 DevColumn compact_column(nqe_ctx *ctx, const DevColumn &src, const KeepMask &km);
+// out row r (r-th kept row i) = src[gidx[i]]
+DevColumn compact_gather_column(nqe_ctx *ctx, const DevColumn &src, const uint32_t *gidx, const KeepMask &km);
+// scans the per-tile counts into km.tile_offsets and reads back km.total
+KeepMask finish_mask(nqe_ctx *ctx, KeepMask km, BufRef tile_counts);
 // evaluates `e` over `in` and compacts the result in the same pass
 DevColumn compact_simple_expr(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &e, const KeepMask &km);
 

@@ -53,71 +53,139 @@ __global__ void __launch_bounds__(256) keep_from_pred_kernel(const uint8_t *pbit
     }
 }
 
-// predicate = SimpleExpr over one streamed column; wave per tile, 64 rows per step
-__global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *values, const uint8_t *valid, SimpleExpr e,
-                                                               int64_t n, int64_t ntiles, uint64_t *keep,
-                                                               uint64_t *pvalid_out, uint32_t *tile_counts, int *flags) {
+// predicate = SimpleExpr over one streamed column; wave per tile, 64 rows per step.
+// RANGE: the predicate is an integer `col cmp lit` over a plain 8-byte column without validity →
+// branch-free range test, clamped unconditional loads, 8 loads in flight per wave.
+template <bool RANGE>
+__global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *values, const uint8_t *valid, SimpleExpr e, FastPred fp,
+                                                               int64_t n, int64_t ntiles, uint64_t *keep, uint64_t *pvalid_out,
+                                                               uint32_t *tile_counts, int *flags) {
     const int waves_per_block = blockDim.x / 64;
+    const uint64_t *__restrict__ words = static_cast<const uint64_t *>(values);
+    const int64_t last = n - 1;
     for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
          tile += int64_t(gridDim.x) * waves_per_block) {
         const int64_t row0 = tile * TILE_ROWS;
         uint32_t total = 0;
-#pragma unroll 4
-        for (int k = 0; k < TILE_WORDS; ++k) {
-            int64_t row = row0 + int64_t(k) * 64 + lane_id();
-            bool in = row < n;
-            uint64_t v = in ? load_word(values, e.src_dtype, row) : 0;
-            bool ok = in && (valid ? get_bit(valid, row) : true);
-            bool r = eval_simple(e, v, ok, flags) != 0;
-            uint64_t kw = __ballot(in && (!ok || r));
-            uint64_t vw = __ballot(ok);
-            if (row0 + int64_t(k) * 64 < n && lane_id() == 0) {
-                keep[tile * TILE_WORDS + k] = kw;
-                if (pvalid_out) pvalid_out[tile * TILE_WORDS + k] = vw;
+        if (RANGE) {
+#pragma unroll 2
+            for (int k0 = 0; k0 < TILE_WORDS; k0 += 8) {
+                uint64_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                    v[k] = words[row < last ? row : last];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                    uint64_t kw = __ballot(row < n && range_pass(fp, v[k]));
+                    if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
+                    total += __popcll(kw);
+                }
             }
-            total += __popcll(kw);
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < TILE_WORDS; ++k) {
+                int64_t row = row0 + int64_t(k) * 64 + lane_id();
+                bool in = row < n;
+                uint64_t v = in ? load_word(values, e.src_dtype, row) : 0;
+                bool ok = in && (valid ? get_bit(valid, row) : true);
+                bool r = eval_simple(e, v, ok, flags) != 0;
+                uint64_t kw = __ballot(in && (!ok || r));
+                uint64_t vw = __ballot(ok);
+                if (row0 + int64_t(k) * 64 < n && lane_id() == 0) {
+                    keep[tile * TILE_WORDS + k] = kw;
+                    if (pvalid_out) pvalid_out[tile * TILE_WORDS + k] = vw;
+                }
+                total += __popcll(kw);
+            }
         }
         if (lane_id() == 0) tile_counts[tile] = total;
     }
 }
 
 // Stable compaction of one column (or of a SimpleExpr evaluated on it) by the keep bitmap.
-template <bool EXPR>
+// Word k of the tile lives in lane k; it is broadcast through the scalar unit (readlane).
+// PLAINW: 8-byte source without validity and a predicate without nulls → values only.
+// GATHER: the source row of output row is gidx[row] (join: build row of the matching probe row).
+template <bool EXPR, bool PLAINW, bool GATHER>
 __global__ void __launch_bounds__(256) compact_kernel(const void *src_values, int src_dtype, const uint8_t *src_valid,
-                                                      SimpleExpr e, const uint64_t *keep, const uint64_t *pvalid,
+                                                      const uint32_t *gidx, SimpleExpr e, const uint64_t *keep, const uint64_t *pvalid,
                                                       const uint64_t *tile_offsets, int64_t n, int64_t ntiles,
                                                       uint64_t *out_words, uint8_t *out_bool_bytes,
                                                       uint8_t *out_valid_bytes, int *flags) {
     const int waves_per_block = blockDim.x / 64;
     const int64_t nwords = (n + 63) / 64;
+    const int64_t last = n - 1;
+    const uint64_t *__restrict__ words = static_cast<const uint64_t *>(src_values);
     for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
          tile += int64_t(gridDim.x) * waves_per_block) {
         int64_t w = tile * TILE_WORDS + lane_id();
         uint64_t my_word = w < nwords ? keep[w] : 0;
-        uint64_t my_pv = (pvalid && w < nwords) ? pvalid[w] : ~0ull;
+        uint64_t my_pv = (!PLAINW && pvalid && w < nwords) ? pvalid[w] : ~0ull;
         uint32_t tot;
         uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
         const uint64_t base = tile_offsets[tile];
+        if (PLAINW) {
+#pragma unroll 2
+            for (int k0 = 0; k0 < TILE_WORDS; k0 += 8) {
+                uint64_t v[8];
+                if (GATHER) {
+                    uint32_t gi[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                        gi[k] = gidx[row < last ? row : last];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        bool kept = (bcast64(my_word, k0 + k) >> lane_id()) & 1;
+                        v[k] = words[kept ? gi[k] : 0u]; // gather (build side is cache resident)
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                        v[k] = words[row < last ? row : last]; // unconditional, coalesced
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    uint64_t word = bcast64(my_word, k0 + k);
+                    uint32_t off = bcast32(my_off, k0 + k);
+                    if ((word >> lane_id()) & 1) {
+                        uint64_t x = EXPR ? eval_simple(e, v[k], true, flags) : v[k];
+                        out_words[base + off + __popcll(word & lanemask_lt())] = x;
+                    }
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int k = 0; k < TILE_WORDS; ++k) {
-            uint64_t word = __shfl(my_word, k, 64);
-            uint64_t pvw = __shfl(my_pv, k, 64);
-            uint32_t off = __shfl(my_off, k, 64);
-            int64_t row = (tile * TILE_WORDS + k) * 64 + lane_id();
-            bool in = row < n;
-            uint64_t v = in ? load_word(src_values, src_dtype, row) : 0; // unconditional, coalesced
-            bool kept = (word >> lane_id()) & 1;
-            if (kept) {
-                bool ok = ((pvw >> lane_id()) & 1) && (src_valid ? get_bit(src_valid, row) : true);
-                if (EXPR) v = eval_simple(e, v, ok, flags);
-                uint64_t pos = base + off + __popcll(word & lanemask_lt());
-                if (out_words) out_words[pos] = ok ? v : 0;
-                if (out_bool_bytes) out_bool_bytes[pos] = (ok && v) ? 1 : 0;
-                if (out_valid_bytes) out_valid_bytes[pos] = ok ? 1 : 0;
+            for (int k = 0; k < TILE_WORDS; ++k) {
+                uint64_t word = bcast64(my_word, k);
+                uint64_t pvw = bcast64(my_pv, k);
+                uint32_t off = bcast32(my_off, k);
+                int64_t row = (tile * TILE_WORDS + k) * 64 + lane_id();
+                bool in = row < n;
+                bool kept = (word >> lane_id()) & 1;
+                int64_t srow = row;
+                if (GATHER) srow = (in && kept) ? int64_t(gidx[row]) : 0;
+                uint64_t v = (in && (!GATHER || kept)) ? load_word(src_values, src_dtype, srow) : 0;
+                if (kept) {
+                    bool ok = ((pvw >> lane_id()) & 1) && (src_valid ? get_bit(src_valid, srow) : true);
+                    if (EXPR) v = eval_simple(e, v, ok, flags);
+                    uint64_t pos = base + off + __popcll(word & lanemask_lt());
+                    if (out_words) out_words[pos] = ok ? v : 0;
+                    if (out_bool_bytes) out_bool_bytes[pos] = (ok && v) ? 1 : 0;
+                    if (out_valid_bytes) out_valid_bytes[pos] = ok ? 1 : 0;
+                }
             }
         }
     }
 }
+
+} // namespace
 
 KeepMask finish_mask(nqe_ctx *ctx, KeepMask km, BufRef tile_counts) {
     km.tile_offsets = dev_alloc(ctx, size_t(km.ntiles + 1) * 8);
@@ -125,8 +193,6 @@ KeepMask finish_mask(nqe_ctx *ctx, KeepMask km, BufRef tile_counts) {
     km.total = int64_t(read_scalar(ctx, (const uint64_t *)km.tile_offsets->ptr + km.ntiles));
     return km;
 }
-
-} // namespace
 
 KeepMask build_keep_mask(nqe_ctx *ctx, const DevColumn &pred, int64_t n_rows) {
     KeepMask km;
@@ -152,14 +218,23 @@ KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleE
     km.keep = dev_alloc(ctx, size_t(nwords) * 8 + 8);
     if (c.validity) km.pvalid = dev_alloc(ctx, size_t(nwords) * 8 + 8);
     BufRef counts = dev_alloc(ctx, size_t(km.ntiles + 1) * 4);
-    if (km.ntiles)
-        launch(ctx, "keep_from_simple", keep_from_simple_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0,
-               (const void *)c.values->ptr, c.valid(), pred, km.n, km.ntiles, (uint64_t *)km.keep->ptr,
-               km.pvalid ? (uint64_t *)km.pvalid->ptr : nullptr, (uint32_t *)counts->ptr, ctx->d_flags);
+    FastPred fp{};
+    const bool range = is_word_type(c.dtype) && !c.validity && make_fast_pred(pred, &fp);
+    if (km.ntiles) {
+        dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
+        if (range)
+            launch(ctx, "keep_from_simple", keep_from_simple_kernel<true>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred, fp,
+                   km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint64_t *)nullptr, (uint32_t *)counts->ptr, ctx->d_flags);
+        else
+            launch(ctx, "keep_from_simple", keep_from_simple_kernel<false>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred,
+                   fp, km.n, km.ntiles, (uint64_t *)km.keep->ptr, km.pvalid ? (uint64_t *)km.pvalid->ptr : nullptr,
+                   (uint32_t *)counts->ptr, ctx->d_flags);
+    }
     return finish_mask(ctx, km, counts);
 }
 
-static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExpr *e, int out_dtype, const KeepMask &km) {
+static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExpr *e, int out_dtype, const KeepMask &km,
+                             const uint32_t *gidx = nullptr) {
     if (!(is_word_type(src.dtype) || src.dtype == NQE_BOOLEAN))
         fail(NQE_ERR_NOT_SUPPORTED, src.dtype == NQE_UTF8 ? "Utf8 columns are not supported by the device filter yet"
                                                            : "unimplemented!() column type in selection (selection.rs:98)");
@@ -172,20 +247,28 @@ static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExp
     if (need_valid) valid_bytes = dev_alloc(ctx, size_t(m) + 8);
     SimpleExpr dummy;
     std::memset(&dummy, 0, sizeof(dummy));
-    if (km.ntiles) {
+    if (km.ntiles && km.total > 0) { // nothing kept: nothing to read or write (and a gather source may be empty)
         dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
-        if (e)
-            launch(ctx, "compact_expr", compact_kernel<true>, grid, block, 0, (const void *)src.values->ptr, src.dtype,
-                   src.valid(), *e, (const uint64_t *)km.keep->ptr, km.pvalid ? (const uint64_t *)km.pvalid->ptr : nullptr,
-                   (const uint64_t *)km.tile_offsets->ptr, km.n, km.ntiles, bool_out ? nullptr : (uint64_t *)out.values->ptr,
-                   bool_out ? (uint8_t *)bool_bytes->ptr : nullptr, need_valid ? (uint8_t *)valid_bytes->ptr : nullptr,
-                   ctx->d_flags);
-        else
-            launch(ctx, "compact_column", compact_kernel<false>, grid, block, 0, (const void *)src.values->ptr, src.dtype,
-                   src.valid(), dummy, (const uint64_t *)km.keep->ptr, km.pvalid ? (const uint64_t *)km.pvalid->ptr : nullptr,
-                   (const uint64_t *)km.tile_offsets->ptr, km.n, km.ntiles, bool_out ? nullptr : (uint64_t *)out.values->ptr,
-                   bool_out ? (uint8_t *)bool_bytes->ptr : nullptr, need_valid ? (uint8_t *)valid_bytes->ptr : nullptr,
-                   ctx->d_flags);
+        const void *sv = (const void *)src.values->ptr;
+        const uint64_t *kp = (const uint64_t *)km.keep->ptr;
+        const uint64_t *pv = km.pvalid ? (const uint64_t *)km.pvalid->ptr : nullptr;
+        const uint64_t *to = (const uint64_t *)km.tile_offsets->ptr;
+        uint64_t *ow = bool_out ? nullptr : (uint64_t *)out.values->ptr;
+        uint8_t *ob = bool_out ? (uint8_t *)bool_bytes->ptr : nullptr;
+        uint8_t *ov = need_valid ? (uint8_t *)valid_bytes->ptr : nullptr;
+        const bool plainw = is_word_type(src.dtype) && !need_valid && !bool_out;
+        const SimpleExpr &ex = e ? *e : dummy;
+#define NQE_COMPACT(NAME, E, P, G)                                                                                     \
+    launch(ctx, NAME, compact_kernel<E, P, G>, grid, block, 0, sv, src.dtype, src.valid(), gidx, ex, kp, pv, to, km.n,  \
+           km.ntiles, ow, ob, ov, ctx->d_flags)
+        if (gidx) {
+            if (plainw) NQE_COMPACT("compact_gather", false, true, true);
+            else NQE_COMPACT("compact_gather", false, false, true);
+        } else if (e && plainw) NQE_COMPACT("compact_expr", true, true, false);
+        else if (e) NQE_COMPACT("compact_expr", true, false, false);
+        else if (plainw) NQE_COMPACT("compact_column", false, true, false);
+        else NQE_COMPACT("compact_column", false, false, false);
+#undef NQE_COMPACT
     }
     if (bool_out) pack_bytes_to_bits(ctx, (const uint8_t *)bool_bytes->ptr, m, (uint64_t *)out.values->ptr);
     if (need_valid) pack_bytes_to_bits(ctx, (const uint8_t *)valid_bytes->ptr, m, (uint64_t *)out.validity->ptr);
@@ -194,6 +277,10 @@ static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExp
 
 DevColumn compact_column(nqe_ctx *ctx, const DevColumn &src, const KeepMask &km) {
     return run_compact(ctx, src, nullptr, src.dtype, km);
+}
+
+DevColumn compact_gather_column(nqe_ctx *ctx, const DevColumn &src, const uint32_t *gidx, const KeepMask &km) {
+    return run_compact(ctx, src, nullptr, src.dtype, km, gidx);
 }
 
 DevColumn compact_simple_expr(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &e, const KeepMask &km) {

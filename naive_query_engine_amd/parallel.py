@@ -63,6 +63,11 @@ def all_gather_rows(cols: Sequence, group=None) -> Tuple[List[list], List[int]]:
     world = dist.get_world_size(group)
     n_local = int(cols[0].numel()) if cols else 0
     dev = cols[0].device if cols else torch.device("cpu")
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        # gloo has no device all_gather: stage the (tiny) partial tables through the host. RCCL ("nccl")
+        # gathers device buffers directly.
+        per_rank, counts = all_gather_rows([c.cpu() for c in cols], group)
+        return [[t.to(dev) for t in rc] for rc in per_rank], counts
     cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
     counts_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts_t, cnt, group=group)
