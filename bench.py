@@ -132,7 +132,7 @@ def main():
         fact = ctx.table_from_device([(DType.INT64, n, fkey.data_ptr(), None), (DType.FLOAT64, n, val.data_ptr(), None)])
         jt = ctx.hash_join_build(dim, 0)  # build replicated on every rank, outside the timed probe
         algo_bytes_per_row = 16.0 + 32.0
-        kernel_name = "join_probe+compact_gather+compact_column"
+        kernel_name = "join_probe+join_fused+compact_gather+compact_column"
 
         def step():
             return ctx.hash_join_probe(jt, fact, 0)
@@ -166,7 +166,7 @@ def main():
         launches += a_n
     breakdown = {}
     for kn in ("agg_grouped", "agg_table_init", "agg_collect", "agg_finalize", "bitonic_small", "keep_from_simple", "compact_expr",
-               "compact_column", "compact_gather", "join_probe_unique", "join_probe_count", "join_probe_write", "scan_chunk", "scan_add"):
+               "compact_column", "compact_gather", "join_probe_unique", "join_probe_presence", "join_fused_write", "join_probe_count", "join_probe_write", "scan_chunk", "scan_add"):
         b_ms, b_n = ctx.timing_query(kn)
         if b_n:
             breakdown[kn] = {"ms_per_step": b_ms / args.steps, "launches_per_step": b_n / args.steps}

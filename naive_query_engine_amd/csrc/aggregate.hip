@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
 //     tiles), so waits are counted `s_waitcnt vmcnt(k)` and a wave keeps a tile in flight while it
 //     computes.
 // PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column.
-template <int PRED, int KEY, int NVT, bool VF64, bool PIPE>
+template <int PRED, int KEY, int NVT, bool VF64, bool PIPE, bool NT>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
@@ -416,10 +416,17 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             row = row < last ? row : last; // clamp: unconditional, in-bounds
-            t.kw[u] = keyp[row];
-            if (PRED == 2) t.pw[u] = predp[row];
+            if (NT) {
+                t.kw[u] = __builtin_nontemporal_load(&keyp[row]);
+                if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row]);
 #pragma unroll
-            for (int j = 0; j < NVT; ++j) t.vw[j][u] = valp[j][row];
+                for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
+            } else {
+                t.kw[u] = keyp[row];
+                if (PRED == 2) t.pw[u] = predp[row];
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) t.vw[j][u] = valp[j][row];
+            }
         }
     };
     auto process_tile = [&](const Tile &t, int64_t base) {
@@ -521,7 +528,9 @@ GroupedKernel pick_grouped_kernel(int pred, int key, bool plain) {
 
 using FastKernel = void (*)(AggArgs, FastPred, GroupTable, int *);
 template <int PRED, int KEY, int NVT, bool VF64> FastKernel pick_fast_pipe(bool pipe) {
-    return pipe ? agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, true> : agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, false>;
+    static const bool nt = [] { const char *e = getenv("NQE_AGG_NT"); return e ? atoi(e) != 0 : true; }(); // streamed once: +2-3 % measured
+    if (nt) return pipe ? agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, true, true> : agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, false, true>;
+    return pipe ? agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, true, false> : agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, false, false>;
 }
 template <int PRED, int KEY> FastKernel pick_fast_nv(int nv, bool vf64, bool pipe) {
     if (nv == 1) return vf64 ? pick_fast_pipe<PRED, KEY, 1, true>(pipe) : pick_fast_pipe<PRED, KEY, 1, false>(pipe);

@@ -40,6 +40,12 @@ struct nqe_join_table {
     nqe::BufRef dense;   // uint32[span]
     nqe::BufRef ustart;  // uint32[U+1]
     uint64_t dense_min = 0, dense_span = 0; // span = number of entries (0: not dense)
+    // unique + dense keys + plain 8-byte payload: payload columns re-laid out by (key - min) so that a probe
+    // needs ONE random access per gathered value and no build-row lookup at all
+    nqe::BufRef presence;                 // uint32 bitmap over [0, span)
+    std::vector<nqe::BufRef> dense_cols;  // per left column (null for the key column)
+    bool dense_payload = false;
+    bool dense_full = false; // every key of the dense range occurs
 };
 
 namespace nqe {
@@ -171,6 +177,123 @@ __global__ void __launch_bounds__(256) probe_unique_kernel(const uint64_t *rkeys
             }
         }
         if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
+// ---- unique + dense + plain payload: fused probe
+__global__ void scatter_dense_payload_kernel(const uint64_t *keys, int64_t n, uint64_t dmin, const uint64_t *src, uint64_t *dst,
+                                             uint32_t *presence) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) {
+        uint64_t d = keys[r] - dmin;
+        if (dst) dst[d] = src[r];
+        if (presence) atomicOr(&presence[d >> 5], 1u << (d & 31));
+    }
+}
+
+// pass 1: match bitmap + per-tile counts (no build-row output).
+// MODE 0: every key of [min, min+span) is present → a range check, no memory access at all;
+// MODE 1: presence bitmap staged in LDS (span/8 bytes ≤ 128 KB: random LDS reads instead of one L2
+//         request per probe row); MODE 2: presence bitmap read from global memory.
+template <int MODE>
+__global__ void __launch_bounds__(1024) probe_presence_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, const uint32_t *presence,
+                                                              uint64_t dmin, uint64_t span, uint64_t *keep, uint32_t *tile_counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lp = reinterpret_cast<uint32_t *>(smem);
+    if (MODE == 1) {
+        const uint32_t words = uint32_t((span + 31) / 32);
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) lp[i] = presence[i];
+        __syncthreads();
+    }
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t last = n - 1;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t row0 = tile * TILE_ROWS;
+        uint32_t total = 0;
+#pragma unroll 2
+        for (int k0 = 0; k0 < TILE_WORDS; k0 += 8) {
+            uint64_t key[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                key[k] = __builtin_nontemporal_load(&rkeys[row < last ? row : last]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                uint64_t d = key[k] - dmin;
+                bool hit = row < n && d < span;
+                if (MODE == 1) hit = hit && ((lp[d >> 5] >> (d & 31)) & 1u);
+                if (MODE == 2) hit = hit && ((presence[d >> 5] >> (d & 31)) & 1u);
+                uint64_t kw = __ballot(hit);
+                if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
+                total += __popcll(kw);
+            }
+        }
+        if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
+struct FusedCols {
+    int32_t n;
+    int32_t pad;
+    int32_t kind[MAX_JOIN_COLS];        // 0: probe-side column (coalesced copy), 1: build key (= probe key), 2: build payload (gather)
+    const uint64_t *src[MAX_JOIN_COLS]; // kind 0: probe column; kind 2: key-ordered build column
+    uint64_t *dst[MAX_JOIN_COLS];
+};
+
+// pass 2: one read of the probe keys, every output column written in probe order
+__global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, const uint64_t *keep,
+                                                               const uint64_t *tile_offsets, uint64_t dmin, FusedCols fc) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t nwords = (n + 63) / 64;
+    const int64_t last = n - 1;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        int64_t w = tile * TILE_WORDS + lane_id();
+        uint64_t my_word = w < nwords ? keep[w] : 0;
+        uint32_t tot;
+        uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+        const uint64_t base = tile_offsets[tile];
+        for (int k0 = 0; k0 < TILE_WORDS; k0 += 8) {
+            uint64_t key[8];
+            uint32_t pos[8]; // position inside the tile's output range
+            uint32_t kept = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                key[k] = __builtin_nontemporal_load(&rkeys[row < last ? row : last]); // streamed once: keep L2 for the gather
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint64_t word = bcast64(my_word, k0 + k);
+                pos[k] = bcast32(my_off, k0 + k) + __popcll(word & lanemask_lt());
+                kept |= uint32_t((word >> lane_id()) & 1) << k;
+            }
+            for (int c = 0; c < fc.n; ++c) {
+                const uint64_t *__restrict__ src = fc.src[c];
+                uint64_t *__restrict__ dst = fc.dst[c] + base;
+                const int kind = fc.kind[c];
+                uint64_t v[8];
+                if (kind == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                        v[k] = __builtin_nontemporal_load(&src[row < last ? row : last]);
+                    }
+                } else if (kind == 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = key[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = src[(kept >> k) & 1 ? key[k] - dmin : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((kept >> k) & 1) __builtin_nontemporal_store(v[k], &dst[pos[k]]);
+            }
+        }
     }
 }
 
@@ -325,6 +448,28 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
             launch(ctx, "join_fill_dense", fill_dense_kernel, dim3(stream_grid(ctx, U, 256)), dim3(256), 0, (const uint64_t *)skeys->ptr,
                    (const uint32_t *)ustart->ptr, (const uint32_t *)jt->perm->ptr, U, kmin, (uint32_t *)jt->dense->ptr, jt->direct ? 1 : 0);
             if (!jt->direct) jt->ustart = ustart;
+            // unique keys and plain payload: key-ordered copies of the payload columns + presence bitmap
+            bool plain = jt->direct && !kc.validity;
+            for (size_t ci = 0; ci < left->cols.size(); ++ci)
+                if (int(ci) != left_key) plain = plain && is_word_type(left->cols[ci].dtype) && !left->cols[ci].validity;
+            if (plain && span * 8 * left->cols.size() <= (size_t(8) << 30)) {
+                jt->presence = dev_alloc_zero(ctx, size_t((span + 31) / 32) * 4);
+                jt->dense_cols.resize(left->cols.size());
+                bool first = true;
+                for (size_t ci = 0; ci < left->cols.size(); ++ci) {
+                    if (int(ci) == left_key) continue;
+                    jt->dense_cols[ci] = dev_alloc(ctx, size_t(span) * 8);
+                    launch(ctx, "join_scatter_payload", scatter_dense_payload_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0,
+                           kc.words(), n, kmin, left->cols[ci].words(), (uint64_t *)jt->dense_cols[ci]->ptr,
+                           first ? (uint32_t *)jt->presence->ptr : (uint32_t *)nullptr);
+                    first = false;
+                }
+                if (first) // key-only build side: presence bitmap only
+                    launch(ctx, "join_scatter_payload", scatter_dense_payload_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0,
+                           kc.words(), n, kmin, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)jt->presence->ptr);
+                jt->dense_payload = true;
+                jt->dense_full = (span == uint64_t(U));
+            }
         }
     }
     sync(ctx); // skeys/flags/ustart are released on return
@@ -354,6 +499,60 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
     L.dense_span = jt->dense_span;
     L.direct = jt->direct ? 1 : 0;
 
+    bool right_plain = true;
+    for (auto &c : right->cols) right_plain = right_plain && is_word_type(c.dtype) && !c.validity;
+    if (jt->dense_payload && right_plain) {
+        // PK–FK fast path: presence test + counts, scan, then one fused write of every output column
+        KeepMask km;
+        km.n = n;
+        km.ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+        int64_t nwords = (n + 63) / 64;
+        km.keep = dev_alloc(ctx, size_t(nwords) * 8 + 8);
+        BufRef counts = dev_alloc(ctx, size_t(km.ntiles + 1) * 4);
+        dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
+        if (km.ntiles) {
+            const size_t pbytes = size_t((jt->dense_span + 31) / 32) * 4;
+            dim3 pgrid(stream_grid(ctx, km.ntiles, 16, 1)), pblock(1024);
+            const uint32_t *pp = (const uint32_t *)jt->presence->ptr;
+            uint64_t *kp = (uint64_t *)km.keep->ptr;
+            uint32_t *cp = (uint32_t *)counts->ptr;
+            if (jt->dense_full)
+                launch(ctx, "join_probe_presence", probe_presence_kernel<0>, dim3(stream_grid(ctx, km.ntiles, 16, 2)), pblock, 0, rk.words(),
+                       n, km.ntiles, pp, jt->dense_min, jt->dense_span, kp, cp);
+            else if (pbytes <= 128 * 1024)
+                launch(ctx, "join_probe_presence", probe_presence_kernel<1>, pgrid, pblock, pbytes, rk.words(), n, km.ntiles, pp,
+                       jt->dense_min, jt->dense_span, kp, cp);
+            else
+                launch(ctx, "join_probe_presence", probe_presence_kernel<2>, dim3(stream_grid(ctx, km.ntiles, 16, 2)), pblock, 0, rk.words(),
+                       n, km.ntiles, pp, jt->dense_min, jt->dense_span, kp, cp);
+        }
+        km = finish_mask(ctx, km, counts);
+        auto out = std::make_unique<nqe_table>();
+        out->ctx = ctx;
+        out->rows = km.total;
+        FusedCols fc;
+        std::memset(&fc, 0, sizeof(fc));
+        for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
+            const DevColumn &c = jt->left_cols[ci];
+            out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
+            fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : 2;
+            fc.src[fc.n] = int(ci) == jt->left_key ? nullptr : (const uint64_t *)jt->dense_cols[ci]->ptr;
+            fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
+            fc.n++;
+        }
+        for (auto &c : right->cols) {
+            out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
+            fc.kind[fc.n] = 0;
+            fc.src[fc.n] = c.words();
+            fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
+            fc.n++;
+        }
+        if (km.ntiles && km.total > 0)
+            launch(ctx, "join_fused_write", join_fused_write_kernel, grid, block, 0, rk.words(), n, km.ntiles, (const uint64_t *)km.keep->ptr,
+                   (const uint64_t *)km.tile_offsets->ptr, jt->dense_min, fc);
+        sync(ctx);
+        return out;
+    }
     if (jt->direct) {
         // unique build keys: every probe row yields 0/1 rows → stream compaction with a gather
         KeepMask km;

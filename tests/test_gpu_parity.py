@@ -338,6 +338,25 @@ def test_hash_join_matches_oracle(ctx, nb, npr, space, unique):
     assert_batches_equal(got, exp, what=f"join nb={nb} np={npr}")   # same rows in the SAME order
 
 
+@pytest.mark.parametrize("nb,npr,holes", [(1, 5, False), (4096, 4096, False), (10000, 50000, True), (30000, 70001, False)])
+def test_hash_join_pk_fk_fused_path(ctx, nb, npr, holes):
+    """unique + dense build keys with plain payload on both sides → presence bitmap + fused write path"""
+    rng = np.random.default_rng(nb + npr)
+    space = nb * 2 if holes else nb            # holes: only half of the key range is present
+    lk = (rng.permutation(space)[:nb] - 7).astype(np.int64)   # negative keys too
+    left = [Column.from_numpy(rng.integers(-9, 9, nb).astype(np.int64)), Column.from_numpy(lk), Column.from_numpy(rng.random(nb)),
+            Column.from_numpy(rng.integers(0, 1 << 60, nb).astype(np.uint64))]
+    rk = (rng.integers(-3, space + 3, npr) - 7).astype(np.int64)
+    right = [Column.from_numpy(rk), Column.from_numpy(rng.random(npr)), Column.from_numpy(np.arange(npr, dtype=np.int64))]
+    exp = orc.hash_join([left], [right], 1, 0)[0]
+    got = ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 1, 0).to_host()
+    assert_batches_equal(got, exp, what="pk-fk fused join")
+    # same build table reused for a second probe batch
+    jt = ctx.hash_join_build(ctx.table_from_host(left), 1)
+    right2 = [Column.from_numpy(rk[::-1].copy()), Column.from_numpy(rng.random(npr)), Column.from_numpy(np.arange(npr, dtype=np.int64))]
+    assert_batches_equal(ctx.hash_join_probe(jt, ctx.table_from_host(right2), 0).to_host(), orc.hash_join([left], [right2], 1, 0)[0])
+
+
 def test_hash_join_heavy_duplicates_and_build_probe_reuse(ctx):
     rng = np.random.default_rng(2)
     lk = np.repeat(np.array([7, -1, 7, 3], dtype=np.int64), 1500)       # 6000 build rows, 3 distinct keys
