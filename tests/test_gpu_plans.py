@@ -1,0 +1,127 @@
+"""The reference's own plan-level tests, written against the Python host mirror
+(naive_query_engine_amd/physical_plan.py) exactly as the reference writes them
+(selection.rs:126-178, projection.rs:88-121, sql/planner.rs:645-713, README.md:69-112), plus checks that the
+fused execute() paths equal the unfused operator chain."""
+import os
+
+import numpy as np
+import pytest
+
+from naive_query_engine_amd import (AggregateFunc, Column, ColumnExpr, DType, ErrorCode, Field, Operator, PhysicalBinaryExpr,
+                                    PhysicalLiteralExpr, RecordBatch, ScalarValue, Status)
+from tests.helpers import assert_batches_equal
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def pp():
+    from naive_query_engine_amd import physical_plan
+
+    return physical_plan
+
+
+def numeric_table(pp, batch, names):
+    idx = {f.name: i for i, f in enumerate(batch.fields)}
+    fields = [batch.fields[idx[n]] for n in names]
+    return pp.MemTable.try_create(fields, [RecordBatch(fields, [batch.columns[idx[n]] for n in names])])
+
+
+@pytest.fixture(scope="module")
+def t1(pp, csv_tables):
+    return numeric_table(pp, csv_tables["test_data"], ["id", "age", "score"])
+
+
+def lit(v):
+    return PhysicalLiteralExpr.create(ScalarValue.Int64(v))
+
+
+def test_selection_like_the_reference(pp, t1, golden):
+    schema = [t1.schema()[0], t1.schema()[1]]
+    scan = pp.ScanPlan.create(t1, None)
+    proj = pp.ProjectionPlan.create(scan, schema, [ColumnExpr.try_create(None, 0), ColumnExpr.try_create("age", None)])
+    add_expr = PhysicalBinaryExpr.create(ColumnExpr.try_create("id", None), Operator.Plus, lit(1))
+    expr = PhysicalBinaryExpr.create(add_expr, Operator.Gt, lit(5))
+    res = pp.SelectionPlan.create(proj, expr).execute()
+    assert len(res) == 1
+    assert res[0].column(0).to_list() == golden["test_selection"]["id"]
+
+
+def test_projection_like_the_reference(pp, t1, golden):
+    schema = [t1.schema()[0], t1.schema()[2]]
+    add_expr = PhysicalBinaryExpr.create(ColumnExpr.try_create("id", None), Operator.Plus, lit(1))
+    res = pp.ProjectionPlan.create(pp.ScanPlan.create(t1, None), schema, [add_expr, ColumnExpr.try_create("score", None)]).execute()
+    assert res[0].column(0).to_list() == golden["test_projection"]["id_plus_1"]
+    assert res[0].to_host().fields[0].name == "id"
+
+
+def test_readme_query1_fused_equals_unfused(pp, t1, golden):
+    scan = pp.ScanPlan.create(t1, None)
+    pred = PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 0), Operator.Lt, lit(9))
+    exprs = [ColumnExpr.try_create(None, 0), PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 1), Operator.Plus, lit(100))]
+    schema = [t1.schema()[0], Field("age + 100", DType.INT64, True)]
+    fused = pp.ProjectionPlan.create(pp.SelectionPlan.create(scan, pred), schema, exprs)
+    plan = pp.PhysicalLimitPlan.create(pp.PhysicalOffsetPlan.create(fused, 2), 3)
+    out = plan.execute()
+    rows = list(zip(out[0].column(0).to_list(), out[0].column(1).to_list()))
+    assert rows == [(r[0], r[2]) for r in golden["readme_filter_project_offset_limit"]["rows"]]
+    # unfused chain: selection materialised first
+    sel = pp.SelectionPlan.create(scan, pred).execute()
+    unfused = pp.ProjectionPlan.create(pp._Materialized(sel, t1.schema()), schema, exprs).execute()
+    assert_batches_equal(fused.execute()[0].table.to_host(), unfused[0].table.to_host())
+
+
+def test_readme_aggregate_and_q9(pp, t1, golden):
+    ops = [pp.Count.create(ColumnExpr.try_create(None, 0)), pp.Sum.create(ColumnExpr.try_create("age", None)), pp.Sum.create(ColumnExpr.try_create(None, 2)),
+           pp.Avg.create(ColumnExpr.try_create(None, 2)), pp.Max.create(ColumnExpr.try_create(None, 2)), pp.Min.create(ColumnExpr.try_create(None, 2))]
+    key = PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 0), Operator.Modulos, lit(3))
+    agg = pp.PhysicalAggregatePlan.create([key], ops, pp.ScanPlan.create(t1, None))
+    res = pp.ProjectionPlan.create(agg, [], []).execute()  # empty schema → pass-through (projection.rs:47-48)
+    host = res[0].to_host()
+    assert [f.name for f in host.fields] == ["count(id)", "sum(age)", "sum(score)", "avg(score)", "max(score)", "min(score)"]
+    rows = np.array(sorted(map(list, zip(*[c.to_list() for c in host.columns]))), dtype=np.float64)
+    exp = np.array(sorted(golden["readme_group_by_id_mod_3"]["rows"]), dtype=np.float64)
+    assert (rows[:, 0] == exp[:, 0]).all() and np.allclose(rows, exp, rtol=1e-9, atol=0)
+    assert agg.schema() == t1.schema()  # quirk Q8: schema() is the INPUT schema
+    # filter fused into the aggregate == aggregate over a materialised selection
+    pred = PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 0), Operator.Gt, lit(2))
+    mk = lambda: [pp.Count.create(ColumnExpr.try_create(None, 2)), pp.Sum.create(ColumnExpr.try_create(None, 2))]
+    a = pp.PhysicalAggregatePlan.create([key], mk(), pp.SelectionPlan.create(pp.ScanPlan.create(t1, None), pred)).execute()
+    sel = pp.SelectionPlan.create(pp.ScanPlan.create(t1, None), pred).execute()
+    b = pp.PhysicalAggregatePlan.create([key], mk(), pp._Materialized(sel, t1.schema())).execute()
+    assert_batches_equal(a[0].table.to_host(), b[0].table.to_host(), rtol=1e-12)
+    # quirk Q9: the un-grouped state is never cleared between execute() calls
+    un = pp.PhysicalAggregatePlan.create([], [pp.Count.create(ColumnExpr.try_create(None, 0)), pp.Sum.create(ColumnExpr.try_create(None, 0))], pp.ScanPlan.create(t1, None))
+    assert [c.to_list() for c in un.execute()[0].table.to_host()] == [[8], [42.0]]
+    assert [c.to_list() for c in un.execute()[0].table.to_host()] == [[16], [84.0]]
+
+
+def test_readme_joins_row_order(pp, csv_tables, golden):
+    emp = numeric_table(pp, csv_tables["employee"], ["id", "department_id", "rank"])
+    rank_b = csv_tables["rank"]
+    rank = pp.MemTable.try_create([Field("rank_id", DType.INT64)], [RecordBatch([Field("rank_id", DType.INT64)], [rank_b.columns[0]])])
+    dep_b = csv_tables["department"]
+    dep = pp.MemTable.try_create([Field("dep_id", DType.INT64)], [RecordBatch([Field("dep_id", DType.INT64)], [dep_b.columns[0]])])
+    j1 = pp.HashJoin.create(pp.ScanPlan.create(emp, None), pp.ScanPlan.create(rank, None), [(pp.ColumnRef("employee", "rank"), pp.ColumnRef("rank", "rank_id"))],
+                            pp.JoinType.Inner, [])
+    j2 = pp.HashJoin.create(j1, pp.ScanPlan.create(dep, None), [(pp.ColumnRef(None, "department_id"), pp.ColumnRef(None, "dep_id"))], pp.JoinType.Inner, [])
+    out = j2.execute()
+    assert len(out) == 1
+    assert out[0].column(0).to_list() == [r[0] for r in golden["readme_two_hash_joins"]["rows"]]
+    with pytest.raises(ErrorCode) as e:
+        pp.HashJoin.create(j1, j1, [], pp.JoinType.Inner, []).execute()
+    assert e.value.status == Status.PlanError
+
+
+def test_multi_batch_selection_q3_and_scan_projection(pp):
+    f = [Field("x", DType.INT64, True)]
+    b0 = RecordBatch(f, [Column.from_list([1, None, 9], DType.INT64)])
+    b1 = RecordBatch(f, [Column.from_list([7, 0, 8, 100], DType.INT64)])
+    t = pp.MemTable.try_create(f, [b0, b1])
+    res = pp.SelectionPlan.create(pp.ScanPlan.create(t, None), PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 0), Operator.Gt, lit(4))).execute()
+    assert [r.column(0).to_list() for r in res] == [[None, 9], [None, 8]]
+    f3 = [Field("a", DType.INT64), Field("b", DType.INT64), Field("c", DType.INT64)]
+    m = pp.MemTable.try_create(f3, [RecordBatch(f3, [Column.from_list([1, 2, 3], DType.INT64), Column.from_list([4, 5, 6], DType.INT64), Column.from_list([7, 8, 9], DType.INT64)])])
+    b = pp.ScanPlan.create(m, [2, 1]).execute()[0]
+    assert [x.name for x in b.fields] == ["c", "b"] and b.column(0).to_list() == [7, 8, 9]
