@@ -193,6 +193,59 @@ __global__ void take_bits_kernel(const uint8_t *src, const uint8_t *src_valid, i
     }
 }
 
+// ---- Utf8 take: lengths → exclusive scan (= int32 offsets) → byte copy.  idx < 0 emits NULL when allowed
+// (rows a NULL predicate emits, quirk Q4), otherwise it is out of bounds like any idx >= src_len.
+__global__ void utf8_take_lengths_kernel(const int32_t *src_off, const uint8_t *src_valid, int64_t src_len, const int64_t *idx, int64_t m,
+                                         int allow_null_idx, uint32_t *lens, uint64_t *out_valid, int *flags) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    int64_t m_pad = (m + 63) / 64 * 64;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < m_pad; j += stride) {
+        bool ok = false;
+        uint32_t len = 0;
+        if (j < m) {
+            int64_t i = idx[j];
+            if (i < 0 && allow_null_idx) ok = false;
+            else if (i < 0 || i >= src_len) atomicOr(&flags[NQE_FLAG_OOB], 1);
+            else {
+                ok = src_valid ? get_bit(src_valid, i) : true;
+                len = ok ? uint32_t(src_off[i + 1] - src_off[i]) : 0u;
+            }
+            lens[j] = len;
+        }
+        if (j == m) lens[m] = 0; // the scan leaves the total here
+        if (out_valid) {
+            uint64_t w = __ballot(ok);
+            if (lane_id() == 0) out_valid[j >> 6] = w;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (m & 63) == 0) lens[m] = 0;
+}
+
+__global__ void utf8_take_copy_kernel(const int32_t *src_off, const uint8_t *src_data, const uint8_t *src_valid, int64_t src_len,
+                                      const int64_t *idx, int64_t m, const uint32_t *out_off, uint8_t *out_data) {
+    // one wave per output string: lanes stride over its bytes (coalesced for long strings, cheap for short ones)
+    const int waves_per_block = blockDim.x / 64;
+    for (int64_t j = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; j < m; j += int64_t(gridDim.x) * waves_per_block) {
+        int64_t i = idx[j];
+        if (i < 0 || i >= src_len) continue;
+        if (src_valid && !get_bit(src_valid, i)) continue;
+        int32_t so = src_off[i];
+        uint32_t len = out_off[j + 1] - out_off[j];
+        uint32_t d = out_off[j];
+        for (uint32_t b = lane_id(); b < len; b += 64) out_data[d + b] = src_data[so + b];
+    }
+}
+
+__global__ void iota_i64_kernel(int64_t *out, int64_t first, int64_t n) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = first + i;
+}
+
+__global__ void rebase_offsets_kernel(const int32_t *src_off, int64_t n, int32_t delta, int32_t *dst_off) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i <= n; i += stride) dst_off[i] = src_off[i] - src_off[0] + delta;
+}
+
 __global__ void pack_bytes_kernel(const uint8_t *bytes, int64_t n, uint64_t *words) {
     int64_t stride = int64_t(gridDim.x) * blockDim.x;
     int64_t n_pad = (n + 63) / 64 * 64;
@@ -232,6 +285,37 @@ DevColumn make_bool_column(nqe_ctx *ctx, int64_t n, bool with_validity) {
     return c;
 }
 
+DevColumn take_utf8(nqe_ctx *ctx, const DevColumn &src, const int64_t *idx, int64_t m, bool allow_null_idx) {
+    DevColumn out;
+    out.dtype = NQE_UTF8;
+    out.length = m;
+    const bool need_valid = src.validity != nullptr || allow_null_idx;
+    out.values = dev_alloc(ctx, size_t(m + 1) * 4 + 8); // lengths, then (after the scan) int32 offsets
+    if (need_valid) {
+        out.validity = dev_alloc(ctx, bitmap_alloc_bytes(m));
+        out.null_count = -1;
+    }
+    launch(ctx, "utf8_take_lengths", utf8_take_lengths_kernel, dim3(stream_grid(ctx, m + 1, 256)), dim3(256), 0,
+           (const int32_t *)src.values->ptr, src.valid(), src.length, idx, m, allow_null_idx ? 1 : 0, (uint32_t *)out.values->ptr,
+           need_valid ? (uint64_t *)out.validity->ptr : nullptr, ctx->d_flags);
+    exclusive_scan_u32_inplace(ctx, (uint32_t *)out.values->ptr, m + 1);
+    uint32_t total = read_scalar(ctx, (const uint32_t *)out.values->ptr + m);
+    if (total >= 0x80000000u) fail(NQE_ERR_ARROW, "Utf8 take: offsets overflow int32");
+    out.data_length = total;
+    out.data = dev_alloc(ctx, size_t(total) + 8);
+    if (m && total)
+        launch(ctx, "utf8_take_copy", utf8_take_copy_kernel, dim3(stream_grid(ctx, m, 4)), dim3(256), 0, (const int32_t *)src.values->ptr,
+               src.data ? (const uint8_t *)src.data->ptr : nullptr, src.valid(), src.length, idx, m, (const uint32_t *)out.values->ptr,
+               (uint8_t *)out.data->ptr);
+    return out;
+}
+
+BufRef iota_i64(nqe_ctx *ctx, int64_t first, int64_t n) {
+    BufRef b = dev_alloc(ctx, size_t(n) * 8 + 8);
+    if (n) launch(ctx, "iota_i64", iota_i64_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, (int64_t *)b->ptr, first, n);
+    return b;
+}
+
 DevColumn take_column(nqe_ctx *ctx, const DevColumn &src, const int64_t *idx, int64_t m) {
     bool v = src.validity != nullptr;
     if (is_word_type(src.dtype)) {
@@ -250,7 +334,8 @@ DevColumn take_column(nqe_ctx *ctx, const DevColumn &src, const int64_t *idx, in
                    v ? (uint64_t *)out.validity->ptr : nullptr, ctx->d_flags);
         return out;
     }
-    fail(NQE_ERR_NOT_SUPPORTED, "take: Utf8 columns are not supported on the device path yet");
+    if (src.dtype == NQE_UTF8) return take_utf8(ctx, src, idx, m, false);
+    fail(NQE_ERR_NOT_SUPPORTED, "take: unsupported column type");
 }
 
 static BufRef slice_bitmap(nqe_ctx *ctx, const uint8_t *src, int64_t off, int64_t len) {
@@ -273,7 +358,9 @@ DevColumn slice_column(nqe_ctx *ctx, const DevColumn &src, int64_t off, int64_t 
     } else if (src.dtype == NQE_BOOLEAN) {
         out.values = slice_bitmap(ctx, src.bits(), off, len);
     } else {
-        fail(NQE_ERR_NOT_SUPPORTED, "slice: Utf8 columns are not supported on the device path yet");
+        if (src.dtype != NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "slice: unsupported column type");
+        BufRef idx = iota_i64(ctx, off, len);
+        return take_utf8(ctx, src, (const int64_t *)idx->ptr, len, false);
     }
     if (src.validity) {
         out.validity = slice_bitmap(ctx, src.valid(), off, len);
@@ -312,7 +399,35 @@ DevColumn concat_columns(nqe_ctx *ctx, const std::vector<const DevColumn *> &par
             off += p->length;
         }
     } else {
-        fail(NQE_ERR_NOT_SUPPORTED, "concat: Utf8 columns are not supported on the device path yet");
+        if (out.dtype != NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "concat: unsupported column type");
+        // offsets are rebased part by part; the byte ranges are copied back to back
+        std::vector<int32_t> first(parts.size()), lastv(parts.size());
+        for (size_t k = 0; k < parts.size(); ++k) {
+            first[k] = lastv[k] = 0;
+            if (parts[k]->length) {
+                first[k] = read_scalar(ctx, (const int32_t *)parts[k]->values->ptr);
+                lastv[k] = read_scalar(ctx, (const int32_t *)parts[k]->values->ptr + parts[k]->length);
+            }
+        }
+        int64_t bytes = 0;
+        for (size_t k = 0; k < parts.size(); ++k) bytes += lastv[k] - first[k];
+        if (bytes >= (int64_t(1) << 31)) fail(NQE_ERR_ARROW, "Utf8 concat: offsets overflow int32");
+        out.values = dev_alloc_zero(ctx, size_t(total + 1) * 4 + 8);
+        out.data = dev_alloc(ctx, size_t(bytes) + 8);
+        out.data_length = bytes;
+        int64_t row = 0, pos = 0;
+        for (size_t k = 0; k < parts.size(); ++k) {
+            const DevColumn *p = parts[k];
+            if (p->length == 0) continue;
+            launch(ctx, "utf8_rebase", rebase_offsets_kernel, dim3(stream_grid(ctx, p->length + 1, 256)), dim3(256), 0,
+                   (const int32_t *)p->values->ptr, p->length, int32_t(pos), (int32_t *)out.values->ptr + row);
+            int64_t nb = lastv[k] - first[k];
+            if (nb)
+                NQE_HIP_CHECK(hipMemcpyAsync((uint8_t *)out.data->ptr + pos, (const uint8_t *)p->data->ptr + first[k], size_t(nb),
+                                             hipMemcpyDeviceToDevice, ctx->stream));
+            row += p->length;
+            pos += nb;
+        }
     }
     if (any_valid) {
         out.validity = dev_alloc_zero(ctx, bitmap_alloc_bytes(total) + 8);

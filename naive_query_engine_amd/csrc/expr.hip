@@ -109,7 +109,7 @@ bool match_simple(const std::vector<Node> &t, int i, SimpleExpr *s) {
         s->src_dtype = x.out_dtype;
         s->out_dtype = x.out_dtype;
         s->aux[0].pow2_shift = s->aux[1].pow2_shift = -1;
-        return x.out_dtype != NQE_UTF8;
+        return true; // a bare column of any type (Utf8 included) passes through
     }
     if (x.kind != NQE_EXPR_BINARY || is_logic(x.op)) return false;
     const Node &l = t[size_t(x.left)], &r = t[size_t(x.right)];

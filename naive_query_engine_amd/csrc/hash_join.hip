@@ -483,10 +483,9 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
     const int64_t n = right->rows;
     const size_t ncols = jt->left_cols.size() + right->cols.size();
     if (ncols > size_t(MAX_JOIN_COLS)) fail(NQE_ERR_NOT_SUPPORTED, "join output wider than 32 columns");
-    for (auto &c : jt->left_cols)
-        if (c.dtype == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 payload columns are not supported by the device join yet");
-    for (auto &c : right->cols)
-        if (c.dtype == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 payload columns are not supported by the device join yet");
+    bool utf8_left = false, utf8_right = false;
+    for (auto &c : jt->left_cols) utf8_left |= c.dtype == NQE_UTF8;
+    for (auto &c : right->cols) utf8_right |= c.dtype == NQE_UTF8;
 
     Lookup L;
     std::memset(&L, 0, sizeof(L));
@@ -569,6 +568,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         auto out = std::make_unique<nqe_table>();
         out->ctx = ctx;
         out->rows = km.total;
+        DevColumn outer_pos;
         for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
             const DevColumn &c = jt->left_cols[ci];
             if (int(ci) == jt->left_key && !c.validity) {
@@ -579,6 +579,17 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
                 as_left.validity = nullptr;
                 as_left.null_count = 0;
                 out->cols.push_back(compact_column(ctx, as_left, km));
+            } else if (c.dtype == NQE_UTF8) {
+                // outer_pos (the reference's Int64 index array, hash_join.rs:230-231) = build rows of the matches,
+                // obtained by gathering a row-number column; then the Utf8 `take`
+                if (!outer_pos.values) {
+                    DevColumn rowid;
+                    rowid.dtype = NQE_INT64;
+                    rowid.length = jt->left_rows;
+                    rowid.values = iota_i64(ctx, 0, jt->left_rows);
+                    outer_pos = compact_gather_column(ctx, rowid, (const uint32_t *)bidx->ptr, km);
+                }
+                out->cols.push_back(take_utf8(ctx, c, (const int64_t *)outer_pos.words(), km.total, false));
             } else {
                 out->cols.push_back(compact_gather_column(ctx, c, (const uint32_t *)bidx->ptr, km));
             }
@@ -609,35 +620,63 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
     out->rows = M;
     JoinCols jc;
     std::memset(&jc, 0, sizeof(jc));
-    jc.n = int(ncols);
-    jc.n_left = int(jt->left_cols.size());
-    std::vector<BufRef> bool_bytes(ncols), valid_bytes(ncols);
-    for (size_t c = 0; c < ncols; ++c) {
-        const DevColumn &src = c < jt->left_cols.size() ? jt->left_cols[c] : right->cols[c - jt->left_cols.size()];
+    // Utf8 payload: the kernel emits outer_pos / inner_pos (gathers of row-number columns), then Utf8 `take`
+    DevColumn left_rowid, right_rowid, outer_pos, inner_pos;
+    std::vector<const DevColumn *> srcs;
+    std::vector<int> out_slot; // output column index of each kernel column, -1 outer_pos, -2 inner_pos
+    for (size_t c = 0; c < jt->left_cols.size(); ++c)
+        if (jt->left_cols[c].dtype != NQE_UTF8) { srcs.push_back(&jt->left_cols[c]); out_slot.push_back(int(c)); }
+    if (utf8_left) {
+        left_rowid.dtype = NQE_INT64; left_rowid.length = jt->left_rows; left_rowid.values = iota_i64(ctx, 0, jt->left_rows);
+        srcs.push_back(&left_rowid); out_slot.push_back(-1);
+    }
+    jc.n_left = int(srcs.size());
+    for (size_t c = 0; c < right->cols.size(); ++c)
+        if (right->cols[c].dtype != NQE_UTF8) { srcs.push_back(&right->cols[c]); out_slot.push_back(int(jt->left_cols.size() + c)); }
+    if (utf8_right) {
+        right_rowid.dtype = NQE_INT64; right_rowid.length = n; right_rowid.values = iota_i64(ctx, 0, n);
+        srcs.push_back(&right_rowid); out_slot.push_back(-2);
+    }
+    jc.n = int(srcs.size());
+    if (jc.n > MAX_JOIN_COLS) fail(NQE_ERR_NOT_SUPPORTED, "join output wider than 32 columns");
+    out->cols.resize(ncols);
+    std::vector<BufRef> bool_bytes(srcs.size()), valid_bytes(srcs.size());
+    std::vector<DevColumn> dsts(srcs.size());
+    for (size_t k = 0; k < srcs.size(); ++k) {
+        const DevColumn &src = *srcs[k];
         const bool v = src.validity != nullptr;
         DevColumn dst = src.dtype == NQE_BOOLEAN ? make_bool_column(ctx, M, v) : make_word_column(ctx, src.dtype, M, v);
-        jc.src[c] = src.values ? src.values->ptr : nullptr;
-        jc.src_valid[c] = src.valid();
-        jc.dtype[c] = src.dtype;
+        jc.src[k] = src.values ? src.values->ptr : nullptr;
+        jc.src_valid[k] = src.valid();
+        jc.dtype[k] = src.dtype;
         if (src.dtype == NQE_BOOLEAN) {
-            bool_bytes[c] = dev_alloc(ctx, size_t(M) + 8);
-            jc.dst_bool_bytes[c] = (uint8_t *)bool_bytes[c]->ptr;
+            bool_bytes[k] = dev_alloc(ctx, size_t(M) + 8);
+            jc.dst_bool_bytes[k] = (uint8_t *)bool_bytes[k]->ptr;
         } else {
-            jc.dst_words[c] = (uint64_t *)dst.values->ptr;
+            jc.dst_words[k] = (uint64_t *)dst.values->ptr;
         }
         if (v) {
-            valid_bytes[c] = dev_alloc(ctx, size_t(M) + 8);
-            jc.dst_valid_bytes[c] = (uint8_t *)valid_bytes[c]->ptr;
+            valid_bytes[k] = dev_alloc(ctx, size_t(M) + 8);
+            jc.dst_valid_bytes[k] = (uint8_t *)valid_bytes[k]->ptr;
         }
-        out->cols.push_back(std::move(dst));
+        dsts[k] = std::move(dst);
     }
     if (n && M)
         launch(ctx, "join_probe_write", probe_write_kernel, dim3(grid), dim3(JT_BLOCK), 0, (const uint64_t *)pmeta->ptr, n,
                (const uint64_t *)offs->ptr, (const uint32_t *)jt->perm->ptr, jt->direct ? 1 : 0, jc);
-    for (size_t c = 0; c < ncols; ++c) {
-        if (bool_bytes[c]) pack_bytes_to_bits(ctx, (const uint8_t *)bool_bytes[c]->ptr, M, (uint64_t *)out->cols[c].values->ptr);
-        if (valid_bytes[c]) pack_bytes_to_bits(ctx, (const uint8_t *)valid_bytes[c]->ptr, M, (uint64_t *)out->cols[c].validity->ptr);
+    for (size_t k = 0; k < srcs.size(); ++k) {
+        if (bool_bytes[k]) pack_bytes_to_bits(ctx, (const uint8_t *)bool_bytes[k]->ptr, M, (uint64_t *)dsts[k].values->ptr);
+        if (valid_bytes[k]) pack_bytes_to_bits(ctx, (const uint8_t *)valid_bytes[k]->ptr, M, (uint64_t *)dsts[k].validity->ptr);
+        if (out_slot[k] >= 0) out->cols[size_t(out_slot[k])] = dsts[k];
+        else if (out_slot[k] == -1) outer_pos = dsts[k];
+        else inner_pos = dsts[k];
     }
+    for (size_t c = 0; c < jt->left_cols.size(); ++c)
+        if (jt->left_cols[c].dtype == NQE_UTF8)
+            out->cols[c] = take_utf8(ctx, jt->left_cols[c], (const int64_t *)outer_pos.words(), M, false);
+    for (size_t c = 0; c < right->cols.size(); ++c)
+        if (right->cols[c].dtype == NQE_UTF8)
+            out->cols[jt->left_cols.size() + c] = take_utf8(ctx, right->cols[c], (const int64_t *)inner_pos.words(), M, false);
     sync(ctx); // temporaries above are released on return; keep the stream drained for simplicity
     return out;
 }

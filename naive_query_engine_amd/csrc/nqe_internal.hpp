@@ -160,6 +160,9 @@ DevColumn make_word_column(nqe_ctx *ctx, int dtype, int64_t n, bool with_validit
 DevColumn make_bool_column(nqe_ctx *ctx, int64_t n, bool with_validity);
 // out[j] = in[idx[j]] for every column (arrow take); idx are int64 row numbers on the device
 DevColumn take_column(nqe_ctx *ctx, const DevColumn &src, const int64_t *idx, int64_t m);
+// Utf8 gather; idx < 0 emits NULL when allow_null_idx (else out of bounds)
+DevColumn take_utf8(nqe_ctx *ctx, const DevColumn &src, const int64_t *idx, int64_t m, bool allow_null_idx);
+BufRef iota_i64(nqe_ctx *ctx, int64_t first, int64_t n);
 DevColumn slice_column(nqe_ctx *ctx, const DevColumn &src, int64_t off, int64_t len);
 DevColumn concat_columns(nqe_ctx *ctx, const std::vector<const DevColumn *> &parts);
 // exclusive prefix sum of n uint32 counts into uint64 offsets (offsets[n] = total); device arrays
@@ -221,7 +224,10 @@ struct KeepMask {
     int64_t n = 0;        // rows covered
     int64_t ntiles = 0;
     int64_t total = 0;    // emitted rows
+    mutable BufRef kept_idx; // int64 source row per emitted row (-1: NULL row from a NULL predicate); built on demand for Utf8
 };
+// source-row list of the emitted rows (cached in the mask)
+const int64_t *kept_rows(nqe_ctx *ctx, const KeepMask &km);
 KeepMask build_keep_mask(nqe_ctx *ctx, const DevColumn &pred, int64_t n_rows);
 // predicate given as a fused SimpleExpr over `in`
 KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &pred);

@@ -185,6 +185,31 @@ __global__ void __launch_bounds__(256) compact_kernel(const void *src_values, in
     }
 }
 
+// emitted-row list: out[pos] = source row (or -1 when the predicate was NULL there → NULL row, quirk Q4)
+__global__ void __launch_bounds__(256) kept_rows_kernel(const uint64_t *keep, const uint64_t *pvalid, const uint64_t *tile_offsets, int64_t n,
+                                                        int64_t ntiles, int64_t *out) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t nwords = (n + 63) / 64;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        int64_t w = tile * TILE_WORDS + lane_id();
+        uint64_t my_word = w < nwords ? keep[w] : 0;
+        uint64_t my_pv = (pvalid && w < nwords) ? pvalid[w] : ~0ull;
+        uint32_t tot;
+        uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+        const uint64_t base = tile_offsets[tile];
+        for (int k = 0; k < TILE_WORDS; ++k) {
+            uint64_t word = bcast64(my_word, k);
+            uint64_t pvw = bcast64(my_pv, k);
+            uint32_t off = bcast32(my_off, k);
+            if ((word >> lane_id()) & 1) {
+                int64_t row = (tile * TILE_WORDS + k) * 64 + lane_id();
+                out[base + off + __popcll(word & lanemask_lt())] = ((pvw >> lane_id()) & 1) ? row : -1;
+            }
+        }
+    }
+}
+
 } // namespace
 
 KeepMask finish_mask(nqe_ctx *ctx, KeepMask km, BufRef tile_counts) {
@@ -233,11 +258,23 @@ KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleE
     return finish_mask(ctx, km, counts);
 }
 
+const int64_t *kept_rows(nqe_ctx *ctx, const KeepMask &km) {
+    if (!km.kept_idx) {
+        km.kept_idx = dev_alloc(ctx, size_t(km.total) * 8 + 8);
+        if (km.ntiles && km.total > 0)
+            launch(ctx, "kept_rows", kept_rows_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, (const uint64_t *)km.keep->ptr,
+                   km.pvalid ? (const uint64_t *)km.pvalid->ptr : nullptr, (const uint64_t *)km.tile_offsets->ptr, km.n, km.ntiles,
+                   (int64_t *)km.kept_idx->ptr);
+    }
+    return (const int64_t *)km.kept_idx->ptr;
+}
+
 static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExpr *e, int out_dtype, const KeepMask &km,
                              const uint32_t *gidx = nullptr) {
+    if (src.dtype == NQE_UTF8 && !e && !gidx) // StringBuilder path of selection.rs:82-97: gather by the emitted-row list
+        return take_utf8(ctx, src, kept_rows(ctx, km), km.total, km.pvalid != nullptr);
     if (!(is_word_type(src.dtype) || src.dtype == NQE_BOOLEAN))
-        fail(NQE_ERR_NOT_SUPPORTED, src.dtype == NQE_UTF8 ? "Utf8 columns are not supported by the device filter yet"
-                                                           : "unimplemented!() column type in selection (selection.rs:98)");
+        fail(NQE_ERR_NOT_SUPPORTED, "unimplemented!() column type in selection (selection.rs:98)");
     const int64_t m = km.total;
     const bool need_valid = src.validity != nullptr || km.pvalid != nullptr;
     const bool bool_out = out_dtype == NQE_BOOLEAN;
@@ -362,14 +399,7 @@ nqe_status nqe_selection_projection_execute(nqe_ctx *ctx, const nqe_table *in, c
         sel.ctx = ctx;
         sel.rows = km.total;
         for (auto &c : in->cols) {
-            if (c.dtype == NQE_UTF8) { // unreferenced Utf8 columns: keep a placeholder so indices stay aligned
-                DevColumn ph;
-                ph.dtype = NQE_UTF8;
-                ph.length = km.total;
-                sel.cols.push_back(ph);
-            } else {
-                sel.cols.push_back(compact_column(ctx, c, km));
-            }
+            sel.cols.push_back(compact_column(ctx, c, km));
         }
         for (int e = 0; e < num_exprs; ++e)
             t->cols.push_back(evaluate_expr(ctx, &sel, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e]));

@@ -71,3 +71,12 @@ def random_batch(rng, n, null_frac=0.0, key_mod=None, with_bool=False):
     if with_bool:
         cols.append(Column.from_numpy(rng.random(n) < 0.5, mask()))
     return cols
+
+
+def random_utf8(rng, n, null_frac=0.0):
+    """strings of mixed lengths (empty, ascii, multi-byte), optional nulls"""
+    alphabet = ["", "a", "bob", "alice", "véé", "日本語", "x" * 70, "lynne", "grandmaster"]
+    items = [alphabet[int(i)] + (str(int(k)) if k % 3 else "") for i, k in zip(rng.integers(0, len(alphabet), n), rng.integers(0, 1000, n))]
+    if null_frac:
+        items = [None if rng.random() < null_frac else s for s in items]
+    return Column.from_list(items, DType.UTF8)

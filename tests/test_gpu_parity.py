@@ -7,7 +7,7 @@ import pytest
 from naive_query_engine_amd import AggregateFunc, Column, DType, ErrorCode, Operator, Status
 from naive_query_engine_amd.expression import binop, col, lit_bool, lit_f64, lit_i64, lit_u64
 from oracle import oracle as orc
-from tests.helpers import assert_batches_equal, assert_column_equal, assert_rows_multiset_equal, fields, random_batch
+from tests.helpers import assert_batches_equal, assert_column_equal, assert_rows_multiset_equal, fields, random_batch, random_utf8
 
 pytestmark = pytest.mark.gpu
 
@@ -461,3 +461,65 @@ def test_golden_fixture_queries_on_gpu(ctx, csv_tables, golden):
     d = ctx.table_from_host([dep.columns[0]])
     j2 = ctx.hash_join(ctx.hash_join(e, r, 2, 0), d, 1, 0).to_host()
     assert j2[0].to_list() == [row[0] for row in golden["readme_two_hash_joins"]["rows"]]  # employee ids in README order
+
+
+# --------------------------------------------------------------------------- Utf8 payload columns
+@pytest.mark.parametrize("null_frac", [0.0, 0.2])
+@pytest.mark.parametrize("n", [0, 1, 65, 5000])
+def test_utf8_columns_through_filter_take_slice_concat(ctx, n, null_frac):
+    rng = np.random.default_rng(500 + n)
+    cols = random_batch(rng, n, null_frac) + [random_utf8(rng, n, null_frac)]
+    t = ctx.table_from_host(cols)
+    for p in PREDS[:5]:
+        assert_batches_equal(ctx.selection(t, flat(p)).to_host(), orc.selection([cols], flat(p))[0], what=f"utf8 selection {p!r}")
+    # projection of a bare Utf8 column, plain and fused with a filter
+    exprs = [col(4), binop(col(1), Operator.Plus, lit_i64(1))]
+    f5 = fields("id", "k", "v", "u", "name")
+    assert_batches_equal(ctx.projection(t, [e.flatten(f5) for e in exprs]).to_host(), orc.projection([cols], [e.flatten(f5) for e in exprs])[0])
+    sel = orc.selection([cols], flat(PREDS[0]))
+    assert_batches_equal(ctx.selection_projection(t, flat(PREDS[0]), [e.flatten(f5) for e in exprs]).to_host(),
+                         orc.projection(sel, [e.flatten(f5) for e in exprs])[0])
+    if n:
+        idx = rng.integers(0, n, 33).astype(np.int64)
+        got = ctx.take(t, ctx.table_from_host([Column.from_numpy(idx)])).to_host()[4]
+        src = cols[4].to_list()
+        assert got.to_list() == [src[i] for i in idx]
+        for off, ln in [(0, n), (n // 3, n // 2), (n - 1, 1)]:
+            assert ctx.slice(t, off, ln).to_host()[4].to_list() == src[off:off + ln]
+    parts = [cols, random_batch(rng, 7, null_frac) + [random_utf8(rng, 7, null_frac)], random_batch(rng, 0) + [random_utf8(rng, 0)]]
+    got = ctx.concat([ctx.table_from_host(p) for p in parts]).to_host()[4]
+    assert got.to_list() == sum([p[4].to_list() for p in parts], [])
+    # count(name) counts the non-null strings
+    got = ctx.aggregate(t, [(AggregateFunc.Count, 4)]).to_host()[0].to_list()
+    assert got == [sum(x is not None for x in cols[4].to_list())]
+
+
+@pytest.mark.parametrize("unique", [True, False])
+def test_hash_join_with_utf8_payload(ctx, unique):
+    rng = np.random.default_rng(77 + unique)
+    nb, npr = 3000, 8000
+    lk = rng.permutation(nb).astype(np.int64) if unique else rng.integers(0, 400, nb).astype(np.int64)
+    left = [random_utf8(rng, nb, 0.1), Column.from_numpy(lk), Column.from_numpy(rng.random(nb))]
+    right = [Column.from_numpy(rng.integers(-5, nb + 5 if unique else 405, npr).astype(np.int64)), random_utf8(rng, npr, 0.1)]
+    exp = orc.hash_join([left], [right], 1, 0)[0]
+    got = ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 1, 0).to_host()
+    assert_batches_equal(got, exp, what="utf8 join")
+
+
+def test_readme_queries_end_to_end_with_names(ctx, csv_tables, golden):
+    t1 = csv_tables["test_data"]
+    f = fields("id", "name", "age", "score")
+    t = ctx.table_from_host(t1.columns)
+    # test_selection (selection.rs:166-172): ids AND names
+    got = ctx.selection(t, binop(binop(col("id"), Operator.Plus, lit_i64(1)), Operator.Gt, lit_i64(5)).flatten(f)).to_host()
+    assert got[0].to_list() == golden["test_selection"]["id"] and got[1].to_list() == golden["test_selection"]["name"]
+    # README query 1: select id, name, age + 100 from t1 where id < 9 limit 3 offset 2
+    proj = ctx.selection_projection(t, binop(col(0), Operator.Lt, lit_i64(9)).flatten(f),
+                                    [col(0).flatten(f), col(1).flatten(f), binop(col(2), Operator.Plus, lit_i64(100)).flatten(f)])
+    out = ctx.slice(proj, 2, 3).to_host()
+    assert list(map(list, zip(*[c.to_list() for c in out]))) == golden["readme_filter_project_offset_limit"]["rows"]
+    # README query 2: employee ⋈ rank ⋈ department with the Utf8 payloads, row order pinned
+    emp, rank, dep = (ctx.table_from_host(csv_tables[k].columns) for k in ("employee", "rank", "department"))
+    j2 = ctx.hash_join(ctx.hash_join(emp, rank, 3, 0), dep, 2, 0).to_host()
+    rows = list(map(list, zip(j2[0].to_list(), j2[1].to_list(), j2[5].to_list(), j2[7].to_list())))
+    assert rows == golden["readme_two_hash_joins"]["rows"]
