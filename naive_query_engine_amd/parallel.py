@@ -74,14 +74,23 @@ def all_gather_rows(cols: Sequence, group=None) -> Tuple[List[list], List[int]]:
     counts = [int(c.item()) for c in counts_t]
     mx = max(counts) if counts else 0
     per_rank: List[list] = [[] for _ in range(world)]
-    for c in cols:
-        padded = torch.zeros(mx, dtype=c.dtype, device=dev)
-        padded[:n_local] = c
-        bufs = [torch.empty(mx, dtype=c.dtype, device=dev) for _ in range(world)]
-        if mx:
-            dist.all_gather(bufs, padded, group=group)
-        for r in range(world):
-            per_rank[r].append(bufs[r][: counts[r]])
+    if not cols:
+        return per_rank, counts
+    # all columns are 8-byte words: pack them into ONE [ncols, mx] buffer → a single collective per exchange
+    ncols = len(cols)
+    packed = torch.zeros((ncols, mx), dtype=torch.int64, device=dev)
+    for i, c in enumerate(cols):
+        packed[i, :n_local] = c.view(torch.int64) if c.dtype != torch.int64 else c
+    bufs = [torch.empty((ncols, mx), dtype=torch.int64, device=dev) for _ in range(world)]
+    if mx:
+        dist.all_gather(bufs, packed, group=group)
+    if dev.type == "cuda":
+        # collectives run on torch's stream; the consumers (nqe kernels) run on the context's own stream
+        torch.cuda.synchronize(dev)
+    for r in range(world):
+        for i, c in enumerate(cols):
+            col = bufs[r][i, : counts[r]].contiguous()
+            per_rank[r].append(col if c.dtype == torch.int64 else col.view(c.dtype))
     return per_rank, counts
 
 

@@ -125,3 +125,30 @@ def test_multi_batch_selection_q3_and_scan_projection(pp):
     m = pp.MemTable.try_create(f3, [RecordBatch(f3, [Column.from_list([1, 2, 3], DType.INT64), Column.from_list([4, 5, 6], DType.INT64), Column.from_list([7, 8, 9], DType.INT64)])])
     b = pp.ScanPlan.create(m, [2, 1]).execute()[0]
     assert [x.name for x in b.fields] == ["c", "b"] and b.column(0).to_list() == [7, 8, 9]
+
+
+def test_reference_tests_with_utf8_names(pp, csv_tables, golden):
+    """the same reference tests with the Utf8 `name` column kept (selection.rs:166-172, projection.rs:113-118,
+    README.md:70-85)"""
+    b = csv_tables["test_data"]
+    t = pp.MemTable.try_create(b.fields, [b])
+    scan = pp.ScanPlan.create(t, None)
+    schema = [b.fields[0], b.fields[1], b.fields[2]]
+    proj = pp.ProjectionPlan.create(scan, schema, [ColumnExpr.try_create(None, 0), ColumnExpr.try_create("name", None), ColumnExpr.try_create(None, 2)])
+    expr = PhysicalBinaryExpr.create(PhysicalBinaryExpr.create(ColumnExpr.try_create("id", None), Operator.Plus, lit(1)), Operator.Gt, lit(5))
+    res = pp.SelectionPlan.create(proj, expr).execute()
+    assert res[0].column(0).to_list() == golden["test_selection"]["id"]
+    assert res[0].column(1).to_list() == golden["test_selection"]["name"]
+    # README query 1 with names
+    pred = PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 0), Operator.Lt, lit(9))
+    exprs = [ColumnExpr.try_create(None, 0), ColumnExpr.try_create(None, 1), PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 2), Operator.Plus, lit(100))]
+    q1 = pp.PhysicalLimitPlan.create(pp.PhysicalOffsetPlan.create(pp.ProjectionPlan.create(pp.SelectionPlan.create(scan, pred), schema, exprs), 2), 3).execute()
+    assert list(map(list, zip(*[q1[0].column(i).to_list() for i in range(3)]))) == golden["readme_filter_project_offset_limit"]["rows"]
+    # README query 2: joins resolved by NAME; `id` is ambiguous and resolves to the first match (quirk Q12)
+    emp, rank, dep = (pp.MemTable.try_create(csv_tables[k].fields, [csv_tables[k]]) for k in ("employee", "rank", "department"))
+    j1 = pp.HashJoin.create(pp.ScanPlan.create(emp, None), pp.ScanPlan.create(rank, None), [(pp.ColumnRef("employee", "rank"), pp.ColumnRef("rank", "id"))], pp.JoinType.Inner, [])
+    j2 = pp.HashJoin.create(j1, pp.ScanPlan.create(dep, None), [(pp.ColumnRef("employee", "department_id"), pp.ColumnRef("department", "id"))], pp.JoinType.Inner, [])
+    out = j2.execute()[0]
+    names = [f.name for f in out.fields]
+    pick = [names.index("id"), names.index("name"), names.index("rank_name"), names.index("department_name")]
+    assert list(map(list, zip(*[out.column(i).to_list() for i in pick]))) == golden["readme_two_hash_joins"]["rows"]
