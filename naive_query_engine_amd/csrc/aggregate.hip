@@ -116,7 +116,10 @@ __device__ __forceinline__ int64_t global_find_or_insert(const GroupTable &g, ui
         return int64_t(g.cap);
     }
     uint32_t slot = uint32_t((key * GOLD) >> g.shift);
-    for (uint32_t probe = 0; probe < g.cap; ++probe) {
+    // bounded probe sequence: a table that needs more than this is treated as full (the host retries with a
+    // larger one) — an unbounded walk over a nearly full table is O(rows x capacity)
+    const uint32_t max_probe = g.cap < 512u ? g.cap : 512u;
+    for (uint32_t probe = 0; probe < max_probe; ++probe) {
         uint64_t k = __hip_atomic_load(&g.keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == key) return int64_t(slot);
         if (k == EMPTY_KEY) {
@@ -144,17 +147,14 @@ __device__ __forceinline__ void global_update(const GroupTable &g, int64_t slot,
 __device__ __forceinline__ bool row_valid(const ColSrc &c, int64_t row) { return c.valid ? get_bit(c.valid, row) : true; }
 
 // ------------------------------------------------------------------ grouped kernel
-// The general SimpleExpr evaluator (with its 64-bit software divides) is kept OUT of line: inlined
-// into the 4x-unrolled row loop for predicate and key it produced a 30k-instruction kernel that was
-// instruction-fetch bound (2.2 TB/s).  The shapes every BASELINE config uses are specialised instead:
+// History: with the 64-bit software divide inlined for predicate and key in each of the 4 unrolled rows the first
+// version of this kernel was 30k instructions long and instruction-fetch bound (2.2 TB/s).  Now literal divisors use
+// shift/mask or a magic multiply and only column÷column reaches the out-of-line divmod_general, so the general
+// SimpleExpr evaluator is inlined again; the common shapes are still specialised:
 //   PRED: 0 none | 1 `col cmp lit` (literal on either side, normalised on the host) | 2 Boolean bitmap
-//         | 3 any other SimpleExpr (out-of-line)
-//   KEY : 0 plain column | 1 `col % ±2^k` | 2 any other SimpleExpr (out-of-line)
+//         | 3 any other SimpleExpr
+//   KEY : 0 plain column | 1 `col % ±2^k` | 2 any other SimpleExpr
 //   PLAIN: every streamed source is an 8-byte column without a validity bitmap (no bitmap loads)
-__device__ __noinline__ uint64_t eval_simple_slow(const SimpleExpr &e, uint64_t v, bool valid, int *flags) {
-    return eval_simple(e, v, valid, flags);
-}
-
 __device__ __forceinline__ bool cmp_lit(int op, int dt, uint64_t a, uint64_t b) {
     bool lt, eq;
     if (dt == NQE_INT64) { lt = (long long)a < (long long)b; eq = a == b; }
@@ -176,6 +176,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
     uint64_t *lmx = lmn + nvl * slots;                                   // [nvl][slots]
     uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + nvl * slots);    // [nvl][slots]
     const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
+    __shared__ int lds_full_flag;
+    volatile int *lds_full = &lds_full_flag;
+    if (threadIdx.x == 0) lds_full_flag = 0;
 
     for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
         lkeys[s] = EMPTY_KEY;
@@ -206,7 +209,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
         rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = ORD_MAX; rmx[j] = ORD_MIN; rnan[j] = false;
     }
     auto flush_run = [&]() {
-        int slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+        // once this workgroup's table has rejected a key, later keys skip it: any split of the updates between
+        // the LDS table and the global table is correct (the merge is additive), and a full table costs 48 probes
+        int slot = *lds_full ? -1 : lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+        if (slot < 0 && !*lds_full) *lds_full = 1;
         int64_t gslot = slot < 0 ? global_find_or_insert(g, run_key, flags) : 0;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -240,6 +246,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
 
     const int64_t step = int64_t(blockDim.x) * AGG_U;
     for (int64_t base = int64_t(blockIdx.x) * step; base < a.n; base += int64_t(gridDim.x) * step) {
+        if (__hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break; // host retries
         uint64_t kw[AGG_U], pw[AGG_U], vw[NV][AGG_U];
         // ---- load phase: every referenced word of this iteration is requested before any use
 #pragma unroll
@@ -268,7 +275,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
                 bool ok = pass && (PLAIN || row_valid(a.pred_src, row));
                 uint64_t w = a.pred_shares_key ? kw[u] : pw[u];
                 if (PRED == 1) pass = ok && cmp_lit(pred_op, pred_dt, w, pred_lit);
-                else pass = ok && eval_simple_slow(a.pred, w, ok, flags) != 0;
+                else pass = ok && eval_simple(a.pred, w, ok, flags) != 0;
             } else if (PRED == 2) {
                 pass = pass && get_bit(static_cast<const uint8_t *>(a.pred_src.values), row) && row_valid(a.pred_src, row);
             }
@@ -280,7 +287,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
                 bool neg = key_signed && (long long)x < 0;
                 uint64_t ur = (neg ? 0ull - x : x) & key_mask;
                 key = neg ? 0ull - ur : ur;
-            } else key = eval_simple_slow(a.key, kw[u], kok, flags);
+            } else key = eval_simple(a.key, kw[u], kok, flags);
             pass = kok;
             if (!pass) continue;
             if (!run_live || key != run_key) {
@@ -340,7 +347,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
 //     tiles), so waits are counted `s_waitcnt vmcnt(k)` and a wave keeps a tile in flight while it
 //     computes.
 // PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column.
-template <int PRED, int KEY, int NVT, bool VF64, bool PIPE, bool NT>
+template <int PRED, int KEY, int NVT, bool VF64>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
@@ -351,6 +358,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     uint64_t *lmx = lmn + NVT * slots;                                   // [NVT][slots]
     uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + NVT * slots);    // [NVT][slots]
     const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
+    __shared__ int lds_full_flag;
+    volatile int *lds_full = &lds_full_flag;
+    if (threadIdx.x == 0) lds_full_flag = 0;
     for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
         lkeys[s] = EMPTY_KEY;
 #pragma unroll
@@ -373,7 +383,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
     }
     auto flush_run = [&]() {
-        int slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+        // once this workgroup's table has rejected a key, later keys skip it: any split of the updates between
+        // the LDS table and the global table is correct (the merge is additive), and a full table costs 48 probes
+        int slot = *lds_full ? -1 : lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+        if (slot < 0 && !*lds_full) *lds_full = 1;
         int64_t gslot = slot < 0 ? global_find_or_insert(g, run_key, flags) : 0;
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
@@ -405,9 +418,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         vdt[j] = a.val[j].dtype;
     }
     const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
+    const OpAux key_aux = a.key.aux[0];
     const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
     const int64_t n = a.n, last = a.n - 1;
 
+    constexpr bool PIPE = true, NT = true; // both measured wins (prefetched second tile: 3.24 -> 2.69 ms with the lean loop; nt loads: -2..3 %)
     struct Tile {
         uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
     };
@@ -440,10 +455,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             uint64_t key;
             if (KEY == 0) key = t.kw[u];
             else {
-                // truncated remainder by ±2^k: |x| & mask, sign of the dividend
+                // truncated remainder by a literal: |x| mod |d| (mask for ±2^k, magic multiply otherwise), sign of
+                // the dividend
                 uint64_t x = t.kw[u];
                 uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
-                uint64_t ur = ((x ^ sgn) - sgn) & key_mask;
+                uint64_t ux = (x ^ sgn) - sgn;
+                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
                 key = (ur ^ sgn) - sgn;
             }
             if (!pass) continue;
@@ -480,6 +497,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 process_tile(B, base);
                 base += stride;
                 if (base >= n) break;
+                if (*lds_full && __hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
             }
         }
     } else {
@@ -527,23 +545,22 @@ GroupedKernel pick_grouped_kernel(int pred, int key, bool plain) {
 }
 
 using FastKernel = void (*)(AggArgs, FastPred, GroupTable, int *);
-template <int PRED, int KEY, int NVT, bool VF64> FastKernel pick_fast_pipe(bool pipe) {
-    static const bool nt = [] { const char *e = getenv("NQE_AGG_NT"); return e ? atoi(e) != 0 : true; }(); // streamed once: +2-3 % measured
-    if (nt) return pipe ? agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, true, true> : agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, false, true>;
-    return pipe ? agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, true, false> : agg_grouped_fast_kernel<PRED, KEY, NVT, VF64, false, false>;
+template <int PRED, int KEY> FastKernel pick_fast_nv(int nv, bool vf64) {
+    if (nv == 1) return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true> : agg_grouped_fast_kernel<PRED, KEY, 1, false>;
+    return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true> : agg_grouped_fast_kernel<PRED, KEY, 2, false>;
 }
-template <int PRED, int KEY> FastKernel pick_fast_nv(int nv, bool vf64, bool pipe) {
-    if (nv == 1) return vf64 ? pick_fast_pipe<PRED, KEY, 1, true>(pipe) : pick_fast_pipe<PRED, KEY, 1, false>(pipe);
-    return vf64 ? pick_fast_pipe<PRED, KEY, 2, true>(pipe) : pick_fast_pipe<PRED, KEY, 2, false>(pipe);
+template <int PRED> FastKernel pick_fast_key(int key, int nv, bool vf64) {
+    switch (key) {
+    case 0: return pick_fast_nv<PRED, 0>(nv, vf64);
+    case 1: return pick_fast_nv<PRED, 1>(nv, vf64);
+    default: return pick_fast_nv<PRED, 2>(nv, vf64);
+    }
 }
-FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool pipe) {
-    switch (pred * 2 + key) {
-    case 0: return pick_fast_nv<0, 0>(nv, vf64, pipe);
-    case 1: return pick_fast_nv<0, 1>(nv, vf64, pipe);
-    case 2: return pick_fast_nv<1, 0>(nv, vf64, pipe);
-    case 3: return pick_fast_nv<1, 1>(nv, vf64, pipe);
-    case 4: return pick_fast_nv<2, 0>(nv, vf64, pipe);
-    default: return pick_fast_nv<2, 1>(nv, vf64, pipe);
+FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64) {
+    switch (pred) {
+    case 0: return pick_fast_key<0>(key, nv, vf64);
+    case 1: return pick_fast_key<1>(key, nv, vf64);
+    default: return pick_fast_key<2>(key, nv, vf64);
     }
 }
 
@@ -788,6 +805,7 @@ SimpleExpr plain_column_expr(int dtype) {
     std::memset(&s, 0, sizeof(s));
     s.src_dtype = s.out_dtype = dtype;
     s.aux[0].pow2_shift = s.aux[1].pow2_shift = -1;
+    s.aux[0].more = s.aux[1].more = -1;
     return s;
 }
 
@@ -893,6 +911,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     a.n = in->rows;
     a.pred.aux[0].pow2_shift = a.pred.aux[1].pow2_shift = -1;
     a.key.aux[0].pow2_shift = a.key.aux[1].pow2_shift = -1;
+    a.pred.aux[0].more = a.pred.aux[1].more = -1;
+    a.key.aux[0].more = a.key.aux[1].more = -1;
 
     // ---- key expression (group_expr[0] only, quirk Q8)
     ExprInfo kinfo;
@@ -998,22 +1018,23 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         }
                     }
                 }
-                int kk = 2;
-                if (a.key.nops == 0) kk = 0;
-                else if (a.key.nops == 1 && a.key.op[0] == NQE_OP_MODULOS && !a.key.lit_left[0] && a.key.aux[0].pow2_shift >= 0 &&
-                         (a.key.op_dtype[0] == NQE_INT64 || a.key.op_dtype[0] == NQE_UINT64))
-                    kk = 1;
+                int kk = 2, fast_key = -1; // kk: general-kernel key kind; fast_key: fast-kernel key kind (-1 = not covered)
+                if (a.key.nops == 0) kk = 0, fast_key = 0;
+                else if (a.key.nops == 1 && a.key.op[0] == NQE_OP_MODULOS && !a.key.lit_left[0] &&
+                         (a.key.op_dtype[0] == NQE_INT64 || a.key.op_dtype[0] == NQE_UINT64)) {
+                    if (a.key.aux[0].pow2_shift >= 0) kk = 1, fast_key = 1;
+                    else if (a.key.aux[0].more >= 0) fast_key = 2; // `col % d`, d not a power of two: magic multiply
+                }
                 bool plain = is_word_type(a.key_src.dtype) && !a.key_src.valid;
                 if (a.pred_mode == 1) plain = plain && is_word_type(a.pred_src.dtype) && !a.pred_src.valid;
                 for (int j = 0; j < a.nv; ++j) plain = plain && a.val[j].values && !a.val[j].valid;
                 FastPred fpred{};
-                bool fast = plain && a.nv >= 1 && (kk == 0 || kk == 1) && (pk == 0 || (pk == 1 && make_fast_pred(a.pred, &fpred)));
+                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || (pk == 1 && make_fast_pred(a.pred, &fpred)));
                 if (fast) {
                     int fp = pk == 0 ? 0 : (a.pred_shares_key ? 1 : 2);
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
-                    static const bool pipe = [] { const char *e = getenv("NQE_AGG_PIPE"); return e ? atoi(e) != 0 : true; }();
-                    launch(ctx, "agg_grouped_fast", pick_fast_kernel(fp, kk, a.nv, vf64, pipe), dim3(grid), dim3(AGG_BLOCK), shmem, ka,
+                    launch(ctx, "agg_grouped_fast", pick_fast_kernel(fp, fast_key, a.nv, vf64), dim3(grid), dim3(AGG_BLOCK), shmem, ka,
                            fpred, tb.g, ctx->d_flags);
                 } else {
                     launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain), dim3(grid), dim3(AGG_BLOCK), shmem, ka, tb.g,
@@ -1035,7 +1056,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
         if (f[NQE_FLAG_TABLE_FULL]) {
             if (cap >= (1u << 31) || attempt > 8) fail(NQE_ERR_OUT_OF_MEMORY, "group table overflow");
-            cap <<= 2;
+            cap <<= 3;
             flags_reset(ctx);
             continue;
         }

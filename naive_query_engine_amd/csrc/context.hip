@@ -104,6 +104,7 @@ void throw_on_flags(nqe_ctx *ctx) {
     if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
     if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
     if (f[NQE_FLAG_OOB]) fail(NQE_ERR_ARROW, "take index out of bounds");
+    if (f[NQE_FLAG_TABLE_FULL]) fail(NQE_ERR_OUT_OF_MEMORY, "device hash table overflow");
 }
 
 // ---------------------------------------------------------------- small kernels

@@ -44,6 +44,13 @@ static __device__ __noinline__ uint64_t divmod_general(int op, int dt, uint64_t 
     return (uint64_t)(op == NQE_OP_DIVIDE ? x / y : x % y);
 }
 
+// n / d for the host-prepared (magic, more) of a non-power-of-two d
+__device__ __forceinline__ uint64_t udiv_magic(uint64_t n, const OpAux &aux) {
+    uint64_t q = __umul64hi(aux.magic, n);
+    uint64_t t = ((n - q) >> 1) + q;
+    return t >> aux.more;
+}
+
 // One binary step on raw 64-bit words. `dt` is the OPERAND dtype (result dtype is Boolean for
 // compares). Semantics follow arrow-rs 13 (see oracle/nqe_oracle.cpp): wrapping integer
 // arithmetic, truncated remainder, IEEE float compares; zero divisor / MIN÷-1 raise device
@@ -110,14 +117,28 @@ __device__ __forceinline__ uint64_t apply_binary(int op, int dt, uint64_t a, uin
         bool neg = (x < 0) != (y < 0);
         return neg ? 0ull - uq : uq;
     }
+    if (aux.more >= 0) {
+        // literal divisor that is not a power of two: magic multiply instead of the 64-bit divide
+        const bool sgn = dt == NQE_INT64;
+        const bool xneg = sgn && (long long)a < 0;
+        uint64_t ux = xneg ? 0ull - a : a;
+        uint64_t uq = udiv_magic(ux, aux);
+        if (op == NQE_OP_MODULOS) {
+            uint64_t ur = ux - uq * aux.abs_lit;
+            return xneg ? 0ull - ur : ur;
+        }
+        bool neg = sgn && (xneg != ((long long)b < 0));
+        return neg ? 0ull - uq : uq;
+    }
     return divmod_general(op, dt, a, b);
 }
 
 __device__ __forceinline__ OpAux no_aux() {
     OpAux a;
     a.pow2_shift = -1;
-    a.pad = 0;
+    a.more = -1;
     a.abs_lit = 0;
+    a.magic = 0;
     return a;
 }
 

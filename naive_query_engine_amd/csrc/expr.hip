@@ -85,8 +85,9 @@ std::vector<Node> parse(const nqe_table *in, const nqe_expr_node *nodes, int n, 
 OpAux make_aux(int op, int dt, uint64_t lit) {
     OpAux a;
     a.pow2_shift = -1;
-    a.pad = 0;
+    a.more = -1;
     a.abs_lit = 0;
+    a.magic = 0;
     if ((op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS) && (dt == NQE_INT64 || dt == NQE_UINT64) && lit != 0) {
         uint64_t ab = lit;
         if (dt == NQE_INT64 && int64_t(lit) < 0) ab = 0ull - lit;
@@ -95,6 +96,19 @@ OpAux make_aux(int op, int dt, uint64_t lit) {
             int s = 0;
             while ((ab >> s) != 1) ++s;
             a.pow2_shift = s;
+        } else {
+            // unsigned 64-bit division by an invariant divisor (Granlund–Montgomery, the branch-free "add"
+            // form): magic = floor(2^(64+L) / d) * 2 + adjustment + 1 with L = floor(log2 d)
+            int L = 63;
+            while (!((ab >> L) & 1)) --L;
+            unsigned __int128 num = (unsigned __int128)1 << (64 + L);
+            uint64_t pm = uint64_t(num / ab);
+            uint64_t rem = uint64_t(num % ab);
+            pm += pm;
+            uint64_t twice = rem + rem;
+            if (twice >= ab || twice < rem) pm += 1;
+            a.magic = pm + 1;
+            a.more = L;
         }
     }
     return a;
@@ -109,6 +123,7 @@ bool match_simple(const std::vector<Node> &t, int i, SimpleExpr *s) {
         s->src_dtype = x.out_dtype;
         s->out_dtype = x.out_dtype;
         s->aux[0].pow2_shift = s->aux[1].pow2_shift = -1;
+        s->aux[0].more = s->aux[1].more = -1;
         return true; // a bare column of any type (Utf8 included) passes through
     }
     if (x.kind != NQE_EXPR_BINARY || is_logic(x.op)) return false;

@@ -177,8 +177,9 @@ void radix_sort_pairs_u64(nqe_ctx *ctx, const uint64_t *keys_in, const uint32_t 
 // ---- expressions (expr.hip) -------------------------------------------------------------
 struct OpAux {          // host-precomputed helpers for `x / lit`, `x % lit`
     int32_t pow2_shift; // >= 0: |lit| is 2^shift
-    int32_t pad;
+    int32_t more;       // >= 0: |lit| is not a power of two: q = (((n - mulhi(magic,n)) >> 1) + mulhi(magic,n)) >> more
     uint64_t abs_lit;
+    uint64_t magic;
 };
 
 // col [op lit]{0,2}: the expression shapes fused into the consumer kernels

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 FLD = fields("id", "k", "v", "u", "b")
 RTOL = 1e-9
+ALL_AGGS = lambda c: [(AggregateFunc.Count, c), (AggregateFunc.Sum, c), (AggregateFunc.Avg, c), (AggregateFunc.Min, c), (AggregateFunc.Max, c)]
 
 
 @pytest.fixture(scope="module")
@@ -84,6 +85,35 @@ def test_expression_edge_values(ctx):
         with pytest.raises(ErrorCode) as b:
             ctx.expr_evaluate(t, e)
         assert a.value.status == b.value.status == Status.ArrowError
+
+
+def test_divide_and_modulo_by_literal_divisors(ctx):
+    """literal divisors take the magic-multiply path (non powers of two) or the shift/mask path (±2^k)"""
+    rng = np.random.default_rng(2024)
+    i64 = np.concatenate([rng.integers(np.iinfo(np.int64).min, np.iinfo(np.int64).max, 4000, dtype=np.int64),
+                          np.array([np.iinfo(np.int64).min, np.iinfo(np.int64).min + 1, -1, 0, 1, np.iinfo(np.int64).max], dtype=np.int64),
+                          rng.integers(-5000, 5000, 2000).astype(np.int64)])
+    u64 = np.concatenate([rng.integers(0, np.iinfo(np.uint64).max, 4000, dtype=np.uint64), np.array([0, 1, (1 << 64) - 1, 1 << 63], dtype=np.uint64)])
+    f = fields("a")
+    ti, tu = ctx.table_from_host([Column.from_numpy(i64)]), ctx.table_from_host([Column.from_numpy(u64)])
+    for d in [3, 5, 7, 10, 1000, 1023, 1025, (1 << 31) + 1, (1 << 62) + 3, np.iinfo(np.int64).max, -3, -1000, -((1 << 40) + 7), 2, -2, 1 << 20, 1]:
+        for op in (Operator.Divide, Operator.Modulos):
+            e = binop(col(0), op, lit_i64(int(d))).flatten(f)
+            assert_column_equal(ctx.expr_evaluate(ti, e).to_host()[0], orc.expr_evaluate([[Column.from_numpy(i64)]], e), what=f"i64 {op.name} {d}")
+    for d in [3, 7, 1000, (1 << 63) + 5, (1 << 64) - 1, (1 << 33) - 1, 1 << 63, 6]:
+        for op in (Operator.Divide, Operator.Modulos):
+            e = binop(col(0), op, lit_u64(int(d))).flatten(f)
+            assert_column_equal(ctx.expr_evaluate(tu, e).to_host()[0], orc.expr_evaluate([[Column.from_numpy(u64)]], e), what=f"u64 {op.name} {d}")
+    # as group keys (fast aggregate kernel, magic modulo) incl. negative dividends
+    v = Column.from_numpy(rng.random(i64.size))
+    t2 = ctx.table_from_host([Column.from_numpy(i64), v])
+    f2 = fields("a", "v")
+    for d in (3, 1000, -7):
+        key = binop(col(0), Operator.Modulos, lit_i64(d)).flatten(f2)
+        exp = orc.aggregate([[Column.from_numpy(i64), v]], ALL_AGGS(1), group_nodes=key)[0]
+        got, gk = ctx.aggregate(t2, ALL_AGGS(1), group_nodes=key, with_keys=True)
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"group by a % {d}")
+        assert gk.to_host()[0].to_list() == sorted(set(int(np.fmod(float(0), 1)) if False else int(abs(int(x)) % abs(d) * (1 if x >= 0 else -1)) for x in i64.tolist()))
 
 
 def test_expression_errors(ctx):

@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""Diagnostics on the GPU box: PCIe-inclusive ingest, nullable aggregate path, high-cardinality group-by."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from naive_query_engine_amd import AggregateFunc, Column, DType, Operator, capi
+from naive_query_engine_amd.expression import binop, col, lit_i64
+
+
+class F:
+    def __init__(self, n):
+        self.name = n
+
+
+SECTION = sys.argv[1] if len(sys.argv) > 1 else "all"
+ctx = capi.Context(0)
+dev = torch.device("cuda", 0)
+f = [F("id"), F("v")]
+aggs = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1), (AggregateFunc.Min, 1), (AggregateFunc.Max, 1)]
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        r = fn(); del r
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn(); del r
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+# ---- 1. PCIe-inclusive: host numpy columns → nqe_table_create → aggregate
+if SECTION not in ('all', 'pcie'):
+    pass
+n = 100_000_000 if SECTION in ('all', 'pcie') else 1000
+ids = np.arange(n, dtype=np.int64)
+v = np.random.default_rng(0).random(n) * 100
+t0 = time.perf_counter()
+t = ctx.table_from_host([Column.from_numpy(ids), Column.from_numpy(v)])
+up = time.perf_counter() - t0
+key = binop(col(0), Operator.Modulos, lit_i64(1024)).flatten(f)
+pred = binop(col(0), Operator.Lt, lit_i64(n // 2)).flatten(f)
+q = timeit(lambda: ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred))
+print(f"upload {n} rows x 2 cols ({1.6:.1f} GB, pageable numpy): {up*1e3:.1f} ms = {1.6/up:.1f} GB/s; query {q*1e3:.3f} ms; "
+      f"PCIe-inclusive {n/(up+q):.3e} rows/s vs resident {n/q:.3e} rows/s")
+del t
+
+# ---- 2. nullable columns (1% nulls) → general kernel
+n = 200_000_000 if SECTION in ('all', 'paths', 'keys') else 100_000_000
+idt = torch.empty(n, dtype=torch.int64, device=dev); ctx.synchronize()
+ctx.synth_fill(0, 0, 0, n, 1, 0, idt.data_ptr())
+vt = torch.empty(n, dtype=torch.float64, device=dev)
+ctx.synth_fill(2, 3, 0, n, 1, 0, vt.data_ptr())
+valid = (torch.rand(n, device=dev) > 0.01)
+# pack LSB-first validity bitmap on the device
+pad = (-n) % 64
+bits = torch.cat([valid, torch.zeros(pad, dtype=torch.bool, device=dev)]).view(-1, 8).to(torch.uint8)
+w = (bits * torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=dev)).sum(dim=1).to(torch.uint8).contiguous()
+torch.cuda.synchronize()
+plain = ctx.table_from_device([(DType.INT64, n, idt.data_ptr(), None), (DType.FLOAT64, n, vt.data_ptr(), None)])
+nullable = ctx.table_from_device([(DType.INT64, n, idt.data_ptr(), None), (DType.FLOAT64, n, vt.data_ptr(), w.data_ptr())])
+pred = binop(col(0), Operator.Lt, lit_i64(n // 2)).flatten(f)
+for name, tab in ((("plain", plain), ("1% null values", nullable)) if SECTION in ("all", "paths") else ()):
+    q = timeit(lambda: ctx.aggregate(tab, aggs, group_nodes=key, pred_nodes=pred))
+    print(f"aggregate {n} rows [{name}]: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
+if SECTION in ("all", "keys"):
+    for name, kexpr in (("id % 1024", binop(col(0), Operator.Modulos, lit_i64(1024))), ("id % 3", binop(col(0), Operator.Modulos, lit_i64(3))),
+                        ("id % 16", binop(col(0), Operator.Modulos, lit_i64(16))), ("id % 64", binop(col(0), Operator.Modulos, lit_i64(64))),
+                        ("id % 1000", binop(col(0), Operator.Modulos, lit_i64(1000))), ("id % 2000", binop(col(0), Operator.Modulos, lit_i64(2000))),
+                        ("(id + 1) % 1000", binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(1000)))):
+        q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=kexpr.flatten(f), pred_nodes=pred))
+        print(f"aggregate {n} rows key {name}: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
+if SECTION in ("all", "paths"):
+    gen = binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(1000)).flatten(f)   # non-pow2 modulus: general key
+    q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=gen, pred_nodes=pred))
+    print(f"aggregate {n} rows [key (id+1) % 1000, out-of-line divide]: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
+    q = timeit(lambda: ctx.aggregate(plain, aggs, pred_nodes=pred))
+    print(f"un-grouped aggregate {n} rows: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
+
+# ---- 3. high-cardinality group-by
+for groups in ((1 << 10, 1 << 12, 1 << 14, 1 << 17, 1 << 20, 1 << 24) if SECTION in ('all', 'groups') else ()):
+    kt = torch.empty(n, dtype=torch.int64, device=dev)
+    ctx.synth_fill(1, 7, 0, n, groups, 0, kt.data_ptr())
+    tab = ctx.table_from_device([(DType.INT64, n, kt.data_ptr(), None), (DType.FLOAT64, n, vt.data_ptr(), None)])
+    q = timeit(lambda: ctx.aggregate(tab, aggs, group_nodes=col(0).flatten(f)), reps=3, warm=1)
+    print(f"group by random key, {groups} groups, {n} rows: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
+    del tab, kt
