@@ -246,7 +246,8 @@ nqe_status nqe_selection_projection_execute(nqe_ctx *ctx, const nqe_table *in, c
  * predicate emits a NULL row from the selection, which then has a NULL key/value (Q4).
  * Accumulation is f64 for every input type (`val as f64`, quirk Q10); max starts at
  * f64::MIN, min at f64::MAX, NaN ordering follows OrderedFloat (max.rs:30,48).
- * Key dtype must be Int64/UInt64 (Utf8: NQE_ERR_NOT_SUPPORTED on this build). */
+ * Key dtype must be Int64, UInt64 or Utf8 (a bare Utf8 column; keys_out then holds the strings); anything else is
+ * NQE_ERR_NOT_SUPPORTED (aggregate/mod.rs:217). */
 nqe_status nqe_aggregate_execute(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred,
                                  int32_t pred_nodes, const nqe_expr_node *group, int32_t group_nodes,
                                  const nqe_aggregate *aggs, int32_t num_aggs, nqe_table **out,
@@ -274,7 +275,8 @@ nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, con
  * followed by all right columns gathered by probe index (`take`, :237-246); row order is
  * probe-row-major and, for duplicate build keys, ascending build row index (:86-101).
  * Key validity is ignored (quirk Q11): the raw 8-byte slot value is compared.
- * Key dtypes: both Int64 or both UInt64 (else NQE_ERR_NOT_IMPLEMENTED, :161). */
+ * Key dtypes: both Int64, both UInt64 or both Utf8 (other types NQE_ERR_NOT_IMPLEMENTED, :161; differing types
+ * NQE_ERR_NOT_SUPPORTED — the reference's downcast unwrap panics). */
 nqe_status nqe_hash_join_execute(nqe_ctx *ctx, const nqe_table *left, const nqe_table *right,
                                  int32_t left_key, int32_t right_key, nqe_table **out);
 /* Two-phase form: build once (replicated per GPU), probe many right batches / shards. */

@@ -917,10 +917,20 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     // ---- key expression (group_expr[0] only, quirk Q8)
     ExprInfo kinfo;
     int key_col = -1;
+    bool utf8_key = false;
+    DevColumn utf8_codes, utf8_src;
     if (grouped) {
         kinfo = analyze_expr(in, group, group_nodes);
-        if (kinfo.out_dtype == NQE_UTF8)
-            fail(NQE_ERR_NOT_SUPPORTED, "group by Utf8 keys is not supported on the device path yet");
+        if (kinfo.out_dtype == NQE_UTF8) {
+            // group by a String column (aggregate/mod.rs:170-216): encode strings to representative-row codes,
+            // then the Int64 path; keys_out returns the strings of the representatives
+            utf8_key = true;
+            Utf8Dict dict;
+            utf8_src = in->cols[size_t(kinfo.s.col)];
+            utf8_codes = utf8_encode_build(ctx, utf8_src, &dict);
+            kinfo.out_dtype = NQE_INT64;
+            kinfo.simple = true;
+        }
         if (kinfo.out_dtype != NQE_INT64 && kinfo.out_dtype != NQE_UINT64) // aggregate/mod.rs:217
             fail(NQE_ERR_NOT_SUPPORTED, "group by only support by `Int64`, `UInt64`, `String`");
         if (!kinfo.simple && has_pred) {
@@ -952,7 +962,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     DevColumn key_colbuf;
     if (grouped) {
         a.has_key = 1;
-        if (kinfo.simple) {
+        if (utf8_key) {
+            a.key = plain_column_expr(NQE_INT64);
+            a.key_src = src_of(utf8_codes);
+        } else if (kinfo.simple) {
             a.key = kinfo.s;
             key_col = kinfo.s.col;
             a.key_src = src_of(in->cols[size_t(key_col)]);
@@ -1060,7 +1073,13 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             flags_reset(ctx);
             continue;
         }
-        return emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial);
+        AggResult res = emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial);
+        if (utf8_key && res.keys) { // keys_out: the strings of the representative rows
+            DevColumn codes = res.keys->cols[0];
+            res.keys->cols[0] = take_utf8(ctx, utf8_src, (const int64_t *)codes.words(), codes.length, false);
+            sync(ctx);
+        }
+        return res;
     }
 }
 

@@ -46,6 +46,8 @@ struct nqe_join_table {
     std::vector<nqe::BufRef> dense_cols;  // per left column (null for the key column)
     bool dense_payload = false;
     bool dense_full = false; // every key of the dense range occurs
+    // Utf8 join keys: the build strings are encoded to representative-row codes (strings.hip)
+    nqe::Utf8Dict dict;
 };
 
 namespace nqe {
@@ -386,7 +388,6 @@ __global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *p
 void check_key_types(int ldt, int rdt) {
     auto joinable = [](int d) { return d == NQE_INT64 || d == NQE_UINT64 || d == NQE_UTF8; };
     if (!joinable(ldt)) fail(NQE_ERR_NOT_IMPLEMENTED, "NotImplemented: join key type (hash_join.rs:161)");
-    if (ldt == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 join keys are not supported on the device path yet");
     if (rdt < 0) return;
     if (!joinable(rdt)) fail(NQE_ERR_NOT_IMPLEMENTED, "NotImplemented: join key type (hash_join.rs:232)");
     if (rdt != ldt) fail(NQE_ERR_NOT_SUPPORTED, "join key types differ (downcast unwrap panics, hash_join.rs:83)");
@@ -394,16 +395,21 @@ void check_key_types(int ldt, int rdt) {
 
 std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left, int left_key) {
     if (left_key < 0 || size_t(left_key) >= left->cols.size()) fail(NQE_ERR_LOGICAL, "ColumnExpr must has name or idx");
-    const DevColumn &kc = left->cols[size_t(left_key)];
-    check_key_types(kc.dtype, -1);
+    const DevColumn &kc_orig = left->cols[size_t(left_key)];
+    check_key_types(kc_orig.dtype, -1);
     const int64_t n = left->rows;
+    Utf8Dict dict;
+    DevColumn kc_codes;
+    if (kc_orig.dtype == NQE_UTF8) kc_codes = utf8_encode_build(ctx, kc_orig, &dict);
+    const DevColumn &kc = kc_orig.dtype == NQE_UTF8 ? kc_codes : kc_orig;
     if (n >= (int64_t(1) << 32)) fail(NQE_ERR_NOT_SUPPORTED, "build side with 2^32 or more rows is not supported");
     auto jt = std::make_unique<nqe_join_table>();
     jt->ctx = ctx;
     jt->left_cols = left->cols;
     jt->left_rows = n;
-    jt->key_dtype = kc.dtype;
+    jt->key_dtype = kc_orig.dtype;
     jt->left_key = left_key;
+    jt->dict = dict;
 
     BufRef idx = dev_alloc(ctx, size_t(n) * 4 + 8), skeys = dev_alloc(ctx, size_t(n) * 8 + 8);
     jt->perm = dev_alloc(ctx, size_t(n) * 4 + 8);
@@ -449,7 +455,7 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
                    (const uint32_t *)ustart->ptr, (const uint32_t *)jt->perm->ptr, U, kmin, (uint32_t *)jt->dense->ptr, jt->direct ? 1 : 0);
             if (!jt->direct) jt->ustart = ustart;
             // unique keys and plain payload: key-ordered copies of the payload columns + presence bitmap
-            bool plain = jt->direct && !kc.validity;
+            bool plain = jt->direct && !kc.validity && kc_orig.dtype != NQE_UTF8;
             for (size_t ci = 0; ci < left->cols.size(); ++ci)
                 if (int(ci) != left_key) plain = plain && is_word_type(left->cols[ci].dtype) && !left->cols[ci].validity;
             if (plain && span * 8 * left->cols.size() <= (size_t(8) << 30)) {
@@ -478,8 +484,11 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
 
 std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, const nqe_table *right, int right_key) {
     if (right_key < 0 || size_t(right_key) >= right->cols.size()) fail(NQE_ERR_LOGICAL, "ColumnExpr must has name or idx");
-    const DevColumn &rk = right->cols[size_t(right_key)];
-    check_key_types(jt->key_dtype, rk.dtype);
+    const DevColumn &rk_orig = right->cols[size_t(right_key)];
+    check_key_types(jt->key_dtype, rk_orig.dtype);
+    DevColumn rk_codes;
+    if (rk_orig.dtype == NQE_UTF8) rk_codes = utf8_encode_probe(ctx, rk_orig, jt->dict);
+    const DevColumn &rk = rk_orig.dtype == NQE_UTF8 ? rk_codes : rk_orig;
     const int64_t n = right->rows;
     const size_t ncols = jt->left_cols.size() + right->cols.size();
     if (ncols > size_t(MAX_JOIN_COLS)) fail(NQE_ERR_NOT_SUPPORTED, "join output wider than 32 columns");
@@ -571,7 +580,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         DevColumn outer_pos;
         for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
             const DevColumn &c = jt->left_cols[ci];
-            if (int(ci) == jt->left_key && !c.validity) {
+            if (int(ci) == jt->left_key && !c.validity && c.dtype != NQE_UTF8) {
                 // the build key of a matched row is bit-identical to the probe key: produce the column by the
                 // coalesced compaction of the probe keys instead of a random gather (validity comes from the
                 // LEFT column, which has none here)

@@ -174,6 +174,18 @@ void pack_bytes_to_bits(nqe_ctx *ctx, const uint8_t *bytes, int64_t n, uint64_t 
 void radix_sort_pairs_u64(nqe_ctx *ctx, const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
                           uint32_t *vals_out, int64_t n, bool signed_order);
 
+// ---- Utf8 keys (strings.hip): exact string → representative-row encoding
+struct Utf8Dict {
+    BufRef slots;      // int64 representative build row per slot, -1 = empty
+    uint32_t cap = 0;
+    int shift = 0;
+    DevColumn build;   // the encoded (build) column: its strings back the table
+};
+// codes[i] = representative row of string i (Int64 column sharing the strings' validity)
+DevColumn utf8_encode_build(nqe_ctx *ctx, const DevColumn &col, Utf8Dict *dict);
+// codes[i] = representative BUILD row of the equal build string, or a negative value that matches nothing
+DevColumn utf8_encode_probe(nqe_ctx *ctx, const DevColumn &col, const Utf8Dict &dict);
+
 // ---- expressions (expr.hip) -------------------------------------------------------------
 struct OpAux {          // host-precomputed helpers for `x / lit`, `x % lit`
     int32_t pow2_shift; // >= 0: |lit| is 2^shift

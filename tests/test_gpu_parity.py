@@ -553,3 +553,38 @@ def test_readme_queries_end_to_end_with_names(ctx, csv_tables, golden):
     j2 = ctx.hash_join(ctx.hash_join(emp, rank, 3, 0), dep, 2, 0).to_host()
     rows = list(map(list, zip(j2[0].to_list(), j2[1].to_list(), j2[5].to_list(), j2[7].to_list())))
     assert rows == golden["readme_two_hash_joins"]["rows"]
+
+
+def test_group_by_utf8_key(ctx):
+    rng = np.random.default_rng(321)
+    for n, nf in [(1, 0.0), (500, 0.0), (40000, 0.15)]:
+        cols = random_batch(rng, n, nf) + [random_utf8(rng, n, nf)]
+        t = ctx.table_from_host(cols)
+        f5 = fields("id", "k", "v", "u", "name")
+        aggs = ALL_AGGS(2) + [(AggregateFunc.Count, 4), (AggregateFunc.Sum, 0)]
+        for pred in (None, PREDS[0], PREDS[4]):
+            pn = pred.flatten(f5) if pred is not None else None
+            exp = orc.aggregate([cols], aggs, group_nodes=col(4).flatten(f5), pred_nodes=pn)[0]
+            got, gk = ctx.aggregate(t, aggs, group_nodes=col(4).flatten(f5), pred_nodes=pn, with_keys=True)
+            assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0, 5], what=f"group by name n={n}")
+            keys = gk.to_host()[0]
+            assert keys.dtype == DType.UTF8 and len(set(keys.to_list())) == keys.length == got.num_rows
+
+
+@pytest.mark.parametrize("unique", [True, False])
+def test_hash_join_on_utf8_keys(ctx, unique):
+    rng = np.random.default_rng(99 + unique)
+    nb, npr = 2000, 6000
+    if unique:
+        lk = Column.from_list([f"key-{i:05d}" + ("é" if i % 7 == 0 else "") for i in rng.permutation(nb)], DType.UTF8)
+    else:
+        lk = random_utf8(rng, nb, 0.1)   # few distinct strings, duplicates, NULL slots (validity is ignored, quirk Q11)
+    left = [lk, Column.from_numpy(rng.integers(0, 100, nb).astype(np.int64))]
+    rk = Column.from_list([f"key-{i:05d}" + ("é" if i % 7 == 0 else "") for i in rng.integers(-5, nb + 5, npr)], DType.UTF8) if unique else random_utf8(rng, npr, 0.1)
+    right = [Column.from_numpy(rng.random(npr)), rk]
+    exp = orc.hash_join([left], [right], 0, 1)[0]
+    got = ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 0, 1).to_host()
+    assert_batches_equal(got, exp, what="utf8-key join")
+    with pytest.raises(ErrorCode) as e:
+        ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 0, 0)  # Utf8 vs Float64 key
+    assert e.value.status in (Status.NotImplemented, Status.NotSupported)
