@@ -361,6 +361,56 @@ class RecordBatch:
     def to_pydict(self) -> dict:
         return {f.name: c.to_list() for f, c in zip(self.fields, self.columns)}
 
+    # -- Arrow interchange (pyarrow is optional plumbing; the C ABI takes the same buffers directly)
+    @staticmethod
+    def from_arrow(batch) -> "RecordBatch":
+        """pyarrow.RecordBatch / Table (single chunk) → host RecordBatch, zero interpretation: the Arrow buffers
+        (validity bitmap, values / offsets+data) are exactly the layout of include/nqe.h."""
+        import pyarrow as pa
+
+        if isinstance(batch, pa.Table):
+            batch = batch.combine_chunks().to_batches()[0] if batch.num_rows else pa.RecordBatch.from_pylist([], schema=batch.schema)
+        amap = {pa.int64(): DType.INT64, pa.uint64(): DType.UINT64, pa.float64(): DType.FLOAT64, pa.bool_(): DType.BOOLEAN, pa.string(): DType.UTF8}
+        fields, cols = [], []
+        for name, arr in zip(batch.schema.names, batch.columns):
+            if arr.type not in amap:
+                raise ErrorCode(Status.NotSupported, f"Arrow type {arr.type} is not on the hot path")
+            dt = amap[arr.type]
+            n = len(arr)
+            if arr.offset != 0:  # the ABI takes offset-free arrays
+                arr = pa.concat_arrays([arr])
+            bufs = arr.buffers()
+            validity = None
+            if arr.null_count and bufs[0] is not None:
+                validity = np.frombuffer(bufs[0], dtype=np.uint8)[: bitmap_bytes(n)].copy()
+            if dt == DType.BOOLEAN:
+                col = Column(dt, n, np.frombuffer(bufs[1], dtype=np.uint8)[: bitmap_bytes(n)].copy() if n else np.zeros(0, np.uint8), validity)
+            elif dt == DType.UTF8:
+                offs = np.frombuffer(bufs[1], dtype=np.int32)[: n + 1].copy() if bufs[1] is not None else np.zeros(1, np.int32)
+                data = np.frombuffer(bufs[2], dtype=np.uint8).copy() if bufs[2] is not None else np.zeros(0, np.uint8)
+                col = Column(dt, n, offs, validity, data)
+            else:
+                col = Column(dt, n, np.frombuffer(bufs[1], dtype=_WORD_NP[dt])[:n].copy() if n else np.zeros(0, _WORD_NP[dt]), validity)
+            fields.append(Field(name, dt, arr.null_count > 0))
+            cols.append(col)
+        return RecordBatch(fields, cols)
+
+    def to_arrow(self):
+        """host RecordBatch → pyarrow.RecordBatch built from the same buffers."""
+        import pyarrow as pa
+
+        tmap = {DType.INT64: pa.int64(), DType.UINT64: pa.uint64(), DType.FLOAT64: pa.float64(), DType.BOOLEAN: pa.bool_(), DType.UTF8: pa.string()}
+        arrays = []
+        for c in self.columns:
+            vb = pa.py_buffer(np.ascontiguousarray(c.validity).tobytes()) if c.validity is not None else None
+            if c.dtype == DType.UTF8:
+                data = c.data if c.data is not None else np.zeros(0, np.uint8)
+                bufs = [vb, pa.py_buffer(np.ascontiguousarray(c.values).tobytes()), pa.py_buffer(np.ascontiguousarray(data).tobytes())]
+            else:
+                bufs = [vb, pa.py_buffer(np.ascontiguousarray(c.values).tobytes())]
+            arrays.append(pa.Array.from_buffers(tmap[c.dtype], c.length, bufs, null_count=c.null_count if c.validity is not None else 0))
+        return pa.RecordBatch.from_arrays(arrays, names=[f.name for f in self.fields])
+
 
 # ----------------------------------------------------------------------------- expression encoding
 def node_column(idx: int) -> NqeExprNode:

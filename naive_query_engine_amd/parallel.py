@@ -130,6 +130,50 @@ def sharded_aggregate(ctx, local_table, aggs, group_nodes=None, pred_nodes=None,
     return out
 
 
+def _gather_table(ctx, table, group=None):
+    """All-gathers a per-rank result table (8-byte columns) in rank order = row order; returns one table."""
+    import torch
+    import torch.distributed as dist
+
+    dev = torch.device("cuda", ctx.device)
+    dts = table.dtypes()
+    per_rank, counts = all_gather_rows(table_columns_as_tensors(table, dev), group)
+    parts, keep = [], []
+    for r, rc in enumerate(per_rank):
+        parts.append(ctx.table_from_device([(dts[i], counts[r], rc[i].data_ptr() if counts[r] else None, None) for i in range(len(dts))]))
+        keep.append(rc)
+    out = ctx.concat(parts)  # copies into library-owned memory
+    ctx.synchronize()
+    del keep
+    return out
+
+
+def sharded_hash_join(ctx, left_table, right_local_table, left_key: int, right_key: int, gather: bool = False, group=None, join_table=None):
+    """Inner hash join with the build side replicated (every rank holds `left_table` and builds its own table)
+    and the probe side range-split (`right_local_table` = this rank's contiguous row range).  The local output is
+    already in probe order; concatenating the ranks' outputs in rank order reproduces the single-GPU row order.
+    `gather=True` materialises that concatenation on every rank (variable-length all-gather over RCCL; for large
+    outputs this dominates — SURVEY §8e); validity bitmaps / Utf8 columns are not gathered by this helper."""
+    import torch.distributed as dist
+
+    jt = join_table or ctx.hash_join_build(left_table, left_key)
+    local = ctx.hash_join_probe(jt, right_local_table, right_key)
+    if not gather or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    return _gather_table(ctx, local, group)
+
+
+def sharded_selection_projection(ctx, local_table, pred_nodes, exprs, gather: bool = False, group=None):
+    """Filter + projection over a row-range shard; rows are independent, so there is no exchange unless one rank
+    wants the whole result (`gather=True`: ordered variable-length all-gather, rank order == row order)."""
+    import torch.distributed as dist
+
+    local = ctx.selection_projection(local_table, pred_nodes, exprs)
+    if not gather or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    return _gather_table(ctx, local, group)
+
+
 def merge_partials_numpy(keys_list: Sequence[Optional[np.ndarray]], states_list: Sequence[Sequence[np.ndarray]]):
     """Host restatement of the partial merge rule (used by the CPU gloo tests to check the exchange;
     the product path merges on the GPU with nqe_aggregate_merge).  states = per aggregate

@@ -96,3 +96,58 @@ def test_sharded_aggregate_two_ranks_one_gpu():
         g = got[np.lexsort(got.T[::-1])]
         assert (g[:, 0] == exp_m[:, 0]).all() and np.allclose(g, exp_m, rtol=1e-9, atol=0)
     ctx.close()
+
+
+def join_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    from naive_query_engine_amd import Column, capi
+    from naive_query_engine_amd.parallel import shard_range, sharded_hash_join
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ctx = capi.Context(0)
+        left, right = join_data()
+        lo, hi = shard_range(right[0].length, rank, world)
+        sub = [Column.from_numpy(c.to_numpy()[lo:hi]) for c in right]
+        out = sharded_hash_join(ctx, ctx.table_from_host(left), ctx.table_from_host(sub), 0, 0, gather=True)
+        q.put((rank, [c.to_numpy().view(np.int64).tolist() for c in out.to_host()]))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def join_data():
+    from naive_query_engine_amd import Column
+
+    rng = np.random.default_rng(3)
+    nb, npr = 3000, 10001
+    left = [Column.from_numpy(rng.permutation(nb).astype(np.int64)), Column.from_numpy(rng.integers(0, 99, nb).astype(np.int64))]
+    right = [Column.from_numpy(rng.integers(-3, nb + 3, npr).astype(np.int64)), Column.from_numpy(rng.random(npr))]
+    return left, right
+
+
+@pytest.mark.timeout(300)
+def test_sharded_hash_join_two_ranks_keeps_probe_order():
+    import torch.multiprocessing as mp
+
+    from oracle import oracle as orc
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = free_port()
+    procs = [mpc.Process(target=join_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    left, right = join_data()
+    exp = [c.to_numpy().view(np.int64).tolist() for c in orc.hash_join([left], [right], 0, 0)[0]]
+    for rank, got in results:
+        assert got == exp  # build replicated, probe range-split, rank order == probe order
