@@ -89,7 +89,7 @@ struct AggArgs {
     int32_t v0; // first value slot of this pass in the global table
     int32_t lds_cap;
     int32_t lds_shift;
-    int32_t pad;
+    int32_t allow_partition; // an LDS-table overflow asks the host for the partitioned path instead of falling back to global atomics
 };
 
 __device__ __forceinline__ int lds_find_or_insert(uint64_t *keys, uint64_t key, uint32_t cap, int shift) {
@@ -386,8 +386,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         // once this workgroup's table has rejected a key, later keys skip it: any split of the updates between
         // the LDS table and the global table is correct (the merge is additive), and a full table costs 48 probes
         int slot = *lds_full ? -1 : lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
-        if (slot < 0 && !*lds_full) *lds_full = 1;
-        int64_t gslot = slot < 0 ? global_find_or_insert(g, run_key, flags) : 0;
+        if (slot < 0 && !*lds_full) {
+            *lds_full = 1;
+            if (a.allow_partition) atomicOr(&flags[NQE_FLAG_NEED_PARTITION], 1); // more distinct keys than a workgroup table holds
+        }
+        int64_t gslot = (slot < 0 && !a.allow_partition) ? global_find_or_insert(g, run_key, flags) : (slot < 0 ? -1 : 0);
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
             const uint64_t omn = f64_to_ord(rmn[j]), omx = f64_to_ord(rmx[j]);
@@ -497,7 +500,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 process_tile(B, base);
                 base += stride;
                 if (base >= n) break;
-                if (*lds_full && __hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (*lds_full && (a.allow_partition || __hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+                    break; // the host redoes the query (partitioned path / larger table)
             }
         }
     } else {
@@ -521,6 +525,329 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             uint32_t c = lcnt[o];
             global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
         }
+    }
+}
+
+// ------------------------------------------------------------------ partitioned aggregation
+// More distinct keys than a workgroup's LDS table holds would turn every row into device-scope atomics, and
+// those run at a flat ≈2.4e10 ops/s on MI355X whatever the scope, table size or layout (tools/atomics_bench.hip):
+// 100 M rows took 17-20 ms at 4 K…1 M groups versus 0.6 ms at 1 K.  Instead the passing rows are hash-partitioned
+// (count → scan → scatter of (key, values) tuples, PARTS partitions so that a workgroup's open write lines stay L2
+// resident) and each partition — whose distinct keys now fit an LDS table — is aggregated by one workgroup.
+constexpr int PARTS_LOG2 = 9;
+constexpr int PARTS = 1 << PARTS_LOG2;
+
+struct PartArgs {
+    uint32_t *counts;        // [PARTS][nblocks] (count pass out)
+    const uint64_t *offsets; // [PARTS][nblocks] exclusive scan of counts (scatter pass in)
+    uint64_t *out_key;
+    uint64_t *out_val[NV];
+    int64_t chunk;           // rows per workgroup (multiple of AGG_BLOCK*AGG_U)
+};
+
+template <int PRED, int KEY, int NVT, bool SCATTER>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_partition_kernel(AggArgs a, FastPred fp, PartArgs pa) {
+    __shared__ uint32_t cnt[PARTS];
+    __shared__ uint64_t basep[PARTS];
+    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) {
+        cnt[p] = 0;
+        if (SCATTER) basep[p] = pa.offsets[size_t(p) * gridDim.x + blockIdx.x];
+    }
+    __syncthreads();
+    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ valp[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) valp[j] = static_cast<const uint64_t *>(a.val[j].values);
+    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
+    const OpAux key_aux = a.key.aux[0];
+    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
+    const int64_t lo = int64_t(blockIdx.x) * pa.chunk;
+    const int64_t hi = lo + pa.chunk < a.n ? lo + pa.chunk : a.n;
+    const int64_t last = a.n - 1;
+    for (int64_t base = lo; base < hi; base += int64_t(AGG_BLOCK) * AGG_U) {
+        uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            row = row < last ? row : last;
+            kw[u] = __builtin_nontemporal_load(&keyp[row]);
+            if (PRED == 2) pw[u] = __builtin_nontemporal_load(&predp[row]);
+            if (SCATTER) {
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            bool pass = row < hi;
+            if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? kw[u] : pw[u]);
+            uint64_t key;
+            if (KEY == 0) key = kw[u];
+            else {
+                uint64_t x = kw[u];
+                uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
+                uint64_t ux = (x ^ sgn) - sgn;
+                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
+                key = (ur ^ sgn) - sgn;
+            }
+            if (!pass) continue;
+            uint32_t p = uint32_t((key * GOLD) >> (64 - PARTS_LOG2));
+            uint32_t r = atomicAdd(&cnt[p], 1u);
+            if (SCATTER) {
+                uint64_t pos = basep[p] + r;
+                pa.out_key[pos] = key;
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) pa.out_val[j][pos] = vw[j][u];
+            }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (int p = threadIdx.x; p < PARTS; p += blockDim.x) pa.counts[size_t(p) * gridDim.x + blockIdx.x] = cnt[p];
+    }
+}
+
+// Scatter pass with LDS write-combining: a tile of SC_ROWS rows is counting-sorted by partition inside LDS
+// (rank = LDS atomic on a per-tile counter, tile-local exclusive scan), then copied out so that consecutive lanes
+// write consecutive tuples of the same partition (runs of SC_ROWS/PARTS tuples → full 128-B lines instead of
+// 8-byte stores sprayed over 512 streams: 2.4 ms → see DESIGN.md for the measured effect).
+template <int PRED, int KEY, int NVT>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_partition_scatter_kernel(AggArgs a, FastPred fp, PartArgs pa) {
+    constexpr int RPT = NVT == 1 ? 8 : 4;            // rows per thread per tile
+    constexpr int SC_ROWS = AGG_BLOCK * RPT;         // 8192 (one value column) / 4096 (two)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *skey = reinterpret_cast<uint64_t *>(smem);     // [SC_ROWS]
+    uint64_t *sval = skey + SC_ROWS;                          // [NVT][SC_ROWS]
+    uint64_t *gcur = sval + NVT * SC_ROWS;                    // [PARTS] global write cursor of this workgroup
+    uint32_t *tcnt = reinterpret_cast<uint32_t *>(gcur + PARTS); // [PARTS] tuples of this tile per partition
+    uint32_t *tstart = tcnt + PARTS;                          // [PARTS] tile-local exclusive scan
+    __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
+    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) {
+        gcur[p] = pa.offsets[size_t(p) * gridDim.x + blockIdx.x];
+        tcnt[p] = 0;
+    }
+    __syncthreads();
+    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ valp[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) valp[j] = static_cast<const uint64_t *>(a.val[j].values);
+    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
+    const OpAux key_aux = a.key.aux[0];
+    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
+    const int64_t lo = int64_t(blockIdx.x) * pa.chunk;
+    const int64_t hi = lo + pa.chunk < a.n ? lo + pa.chunk : a.n;
+    const int64_t last = a.n - 1;
+    for (int64_t base = lo; base < hi; base += SC_ROWS) {
+        uint64_t key[RPT], vw[NVT][RPT];
+        uint32_t part[RPT], rank[RPT];
+        bool pass[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            int64_t rc = row < last ? row : last;
+            uint64_t kw = __builtin_nontemporal_load(&keyp[rc]);
+            uint64_t pw = PRED == 2 ? __builtin_nontemporal_load(&predp[rc]) : kw;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][rc]);
+            bool ok = row < hi;
+            if (PRED != 0) ok = ok && range_pass(fp, pw);
+            if (KEY == 0) key[u] = kw;
+            else {
+                uint64_t sgn = key_signed ? uint64_t((long long)kw >> 63) : 0ull;
+                uint64_t ux = (kw ^ sgn) - sgn;
+                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
+                key[u] = (ur ^ sgn) - sgn;
+            }
+            pass[u] = ok;
+            part[u] = uint32_t((key[u] * GOLD) >> (64 - PARTS_LOG2));
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
+        __syncthreads();
+        // tile-local exclusive scan of the PARTS counters (threads 0..PARTS-1)
+        uint32_t c = threadIdx.x < PARTS ? tcnt[threadIdx.x] : 0u, wt;
+        uint32_t ex = wave_exclusive_scan(c, wt);
+        if (lane_id() == 63) wave_tot[threadIdx.x / 64] = wt;
+        __syncthreads();
+        if (threadIdx.x < PARTS) {
+            uint32_t pre = 0;
+            for (int w = 0; w < int(threadIdx.x) / 64; ++w) pre += wave_tot[w];
+            tstart[threadIdx.x] = pre + ex;
+        }
+        uint32_t tile_total = 0;
+        for (int w = 0; w < PARTS / 64; ++w) tile_total += wave_tot[w];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            if (!pass[u]) continue;
+            uint32_t i = tstart[part[u]] + rank[u];
+            skey[i] = key[u];
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) sval[j * SC_ROWS + i] = vw[j][u];
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < tile_total; i += blockDim.x) {
+            uint64_t k = skey[i];
+            uint32_t p = uint32_t((k * GOLD) >> (64 - PARTS_LOG2));
+            uint64_t dest = gcur[p] + (i - tstart[p]);
+            pa.out_key[dest] = k;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) pa.out_val[j][dest] = sval[j * SC_ROWS + i];
+        }
+        __syncthreads();
+        if (threadIdx.x < PARTS) {
+            gcur[threadIdx.x] += tcnt[threadIdx.x];
+            tcnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// one workgroup per partition (grid-stride over partitions): plain (key, values) tuples → LDS table → global table.
+// The LDS slot uses the hash bits BELOW the partition bits (all keys of a partition share the top PARTS_LOG2 bits).
+template <int NVT, bool VF64>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, const uint64_t *seg_offsets, int64_t seg_stride, int nsegs, const uint64_t *keys,
+                                                                 const uint64_t *v0, const uint64_t *v1, GroupTable g, int *flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t cap = uint32_t(a.lds_cap);
+    const uint32_t slots = cap + 1;
+    uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
+    double *lsum = reinterpret_cast<double *>(lkeys + slots);
+    uint64_t *lmn = reinterpret_cast<uint64_t *>(lsum + NVT * slots);
+    uint64_t *lmx = lmn + NVT * slots;
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + NVT * slots);
+    const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
+    const uint64_t *__restrict__ valp[2] = {v0, v1};
+    int vdt[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) vdt[j] = a.val[j].dtype;
+    __shared__ int seg_full_flag;
+    volatile int *seg_full = &seg_full_flag;
+    for (int seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) seg_full_flag = 0;
+        for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+            lkeys[s] = EMPTY_KEY;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+                lsum[j * slots + s] = 0.0;
+                lmn[j * slots + s] = ORD_MAX;
+                lmx[j * slots + s] = ORD_MIN;
+                lcnt[j * slots + s] = 0;
+            }
+        }
+        __syncthreads();
+        const int64_t lo = int64_t(seg_offsets[int64_t(seg) * seg_stride]), hi = int64_t(seg_offsets[int64_t(seg + 1) * seg_stride]);
+        for (int64_t base = lo; base < hi; base += int64_t(AGG_BLOCK) * AGG_U) {
+            uint64_t kw[AGG_U], vw[NVT][AGG_U];
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) {
+                int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+                row = row < hi - 1 ? row : hi - 1;
+                kw[u] = keys[row];
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) vw[j][u] = valp[j][row];
+            }
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) {
+                int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+                if (row >= hi) continue;
+                const uint64_t key = kw[u];
+                // tuples of a partition arrive in no particular order: no run cache, one table update per row
+                int slot;
+                if (key == EMPTY_KEY) { lkeys[cap] = 0; slot = int(cap); }
+                else if (*seg_full) slot = -1; // this partition has more distinct keys than the table: spill the rest
+                else {
+                    uint32_t sl = uint32_t(((key * GOLD) << PARTS_LOG2) >> a.lds_shift);
+                    slot = -1;
+                    for (int probe = 0; probe < 32; ++probe) {
+                        uint64_t k = lkeys[sl];
+                        if (k == key) { slot = int(sl); break; }
+                        if (k == EMPTY_KEY) {
+                            uint64_t old = atomicCAS((unsigned long long *)&lkeys[sl], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                            if (old == EMPTY_KEY || old == key) { slot = int(sl); break; }
+                        }
+                        sl = (sl + 1) & (cap - 1);
+                    }
+                }
+                if (slot < 0 && !*seg_full) *seg_full = 1;
+                int64_t gslot = slot < 0 ? global_find_or_insert(g, key, flags) : 0; // partition larger than the table: spill
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) {
+                    double x = VF64 ? u2d(vw[j][u]) : word_as_f64(vw[j][u], vdt[j]);
+                    bool isn = x != x;
+                    uint64_t xo = f64_to_ord(x);
+                    if (slot >= 0) {
+                        uint32_t o = uint32_t(j) * slots + uint32_t(slot);
+                        atomicAdd(&lcnt[o], 1u);
+                        if (isn) atomicOr(&lcnt[o], NAN_BIT);
+                        unsafeAtomicAdd(&lsum[o], x);
+                        if (!isn) {
+                            if (xo < lmn[o]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)xo);
+                            if (xo > lmx[o]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)xo);
+                        }
+                    } else if (gslot >= 0) {
+                        global_update(g, gslot, a.v0 + j, 1, x, true, xo, xo, !isn, isn);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+            uint64_t k = lkeys[s];
+            if (k == EMPTY_KEY) continue;
+            uint64_t key = (s == cap) ? EMPTY_KEY : k;
+            int64_t gslot = global_find_or_insert(g, key, flags);
+            if (gslot < 0) continue;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+                uint32_t o = uint32_t(j) * slots + s;
+                uint32_t c = lcnt[o];
+                global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
+            }
+        }
+    }
+}
+
+using PartKernel = void (*)(AggArgs, FastPred, PartArgs);
+template <int PRED, int KEY> PartKernel pick_scatter_nv(int nv) {
+    return nv == 1 ? agg_partition_scatter_kernel<PRED, KEY, 1> : agg_partition_scatter_kernel<PRED, KEY, 2>;
+}
+template <int PRED> PartKernel pick_scatter_key(int key, int nv) {
+    switch (key) {
+    case 0: return pick_scatter_nv<PRED, 0>(nv);
+    case 1: return pick_scatter_nv<PRED, 1>(nv);
+    default: return pick_scatter_nv<PRED, 2>(nv);
+    }
+}
+PartKernel pick_scatter_kernel(int pred, int key, int nv) {
+    switch (pred) {
+    case 0: return pick_scatter_key<0>(key, nv);
+    case 1: return pick_scatter_key<1>(key, nv);
+    default: return pick_scatter_key<2>(key, nv);
+    }
+}
+template <int PRED, int KEY, int NVT> PartKernel pick_part_sc(bool scatter) {
+    return scatter ? agg_partition_kernel<PRED, KEY, NVT, true> : agg_partition_kernel<PRED, KEY, NVT, false>;
+}
+template <int PRED, int KEY> PartKernel pick_part_nv(int nv, bool scatter) {
+    return nv == 1 ? pick_part_sc<PRED, KEY, 1>(scatter) : pick_part_sc<PRED, KEY, 2>(scatter);
+}
+template <int PRED> PartKernel pick_part_key(int key, int nv, bool scatter) {
+    switch (key) {
+    case 0: return pick_part_nv<PRED, 0>(nv, scatter);
+    case 1: return pick_part_nv<PRED, 1>(nv, scatter);
+    default: return pick_part_nv<PRED, 2>(nv, scatter);
+    }
+}
+PartKernel pick_part_kernel(int pred, int key, int nv, bool scatter) {
+    switch (pred) {
+    case 0: return pick_part_key<0>(key, nv, scatter);
+    case 1: return pick_part_key<1>(key, nv, scatter);
+    default: return pick_part_key<2>(key, nv, scatter);
     }
 }
 
@@ -984,6 +1311,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         cap = 4096;
         while (int64_t(cap) < 2 * guess) cap <<= 1;
     }
+    bool partition_mode = false;
     for (int attempt = 0;; ++attempt) {
         TableBufs tb = make_table(ctx, cap, V, !grouped);
         for (int v0 = 0; v0 < std::max(V, 1); v0 += NV) {
@@ -1047,8 +1375,55 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     int fp = pk == 0 ? 0 : (a.pred_shares_key ? 1 : 2);
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
-                    launch(ctx, "agg_grouped_fast", pick_fast_kernel(fp, fast_key, a.nv, vf64), dim3(grid), dim3(AGG_BLOCK), shmem, ka,
-                           fpred, tb.g, ctx->d_flags);
+                    if (partition_mode) {
+                        // ---- partitioned path: count → scan → scatter → one workgroup per partition
+                        const int64_t stepr = int64_t(AGG_BLOCK) * 8; // multiple of the count tile (4096) and the scatter tile (8192/4096)
+                        int nblk = int(std::min<int64_t>(512, (in->rows + stepr - 1) / stepr));
+                        int64_t chunk = ((in->rows + nblk - 1) / nblk + stepr - 1) / stepr * stepr;
+                        nblk = int((in->rows + chunk - 1) / chunk);
+                        const int64_t ncnt = int64_t(PARTS) * nblk;
+                        BufRef counts = dev_alloc(ctx, size_t(ncnt) * 4), offs = dev_alloc(ctx, size_t(ncnt + 1) * 8);
+                        PartArgs pa;
+                        std::memset(&pa, 0, sizeof(pa));
+                        pa.counts = (uint32_t *)counts->ptr;
+                        pa.offsets = (const uint64_t *)offs->ptr;
+                        pa.chunk = chunk;
+                        launch(ctx, "agg_partition_count", pick_part_kernel(fp, fast_key, a.nv, false), dim3(nblk), dim3(AGG_BLOCK), 0, ka, fpred, pa);
+                        exclusive_scan_u32_to_u64(ctx, (const uint32_t *)counts->ptr, (uint64_t *)offs->ptr, ncnt);
+                        const int64_t R = int64_t(read_scalar(ctx, (const uint64_t *)offs->ptr + ncnt));
+                        if (R > 0) {
+                            BufRef okey = dev_alloc(ctx, size_t(R) * 8 + 8), ov0 = dev_alloc(ctx, size_t(R) * 8 + 8), ov1;
+                            if (a.nv > 1) ov1 = dev_alloc(ctx, size_t(R) * 8 + 8);
+                            pa.out_key = (uint64_t *)okey->ptr;
+                            pa.out_val[0] = (uint64_t *)ov0->ptr;
+                            pa.out_val[1] = ov1 ? (uint64_t *)ov1->ptr : nullptr;
+                            const size_t sc_rows = size_t(AGG_BLOCK) * (a.nv == 1 ? 8 : 4);
+                            const size_t sc_shmem = sc_rows * 8 * size_t(1 + a.nv) + size_t(PARTS) * (8 + 4 + 4);
+                            launch(ctx, "agg_partition_scatter", pick_scatter_kernel(fp, fast_key, a.nv), dim3(nblk), dim3(AGG_BLOCK), sc_shmem, ka, fpred,
+                                   pa);
+                            // one value column: a 4096-slot table (147 KB, one workgroup per CU) doubles the distinct keys a partition may hold
+                            AggArgs sa = ka;
+                            size_t sshmem = shmem;
+                            int sblocks = blocks_per_cu;
+                            if (a.nv == 1) {
+                                sa.lds_cap = 4096;
+                                sa.lds_shift = 64 - 12;
+                                sshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
+                                sblocks = 1;
+                            }
+                            int sgrid = std::min(PARTS, ctx->num_cus * sblocks);
+                            auto segk = a.nv == 1 ? (vf64 ? agg_segments_kernel<1, true> : agg_segments_kernel<1, false>)
+                                                  : (vf64 ? agg_segments_kernel<2, true> : agg_segments_kernel<2, false>);
+                            launch(ctx, "agg_segments", segk, dim3(sgrid), dim3(AGG_BLOCK), sshmem, sa, (const uint64_t *)offs->ptr, int64_t(nblk), PARTS,
+                                   (const uint64_t *)okey->ptr, (const uint64_t *)ov0->ptr, ov1 ? (const uint64_t *)ov1->ptr : (const uint64_t *)nullptr,
+                                   tb.g, ctx->d_flags);
+                            sync(ctx); // the partition buffers are released at the end of this scope
+                        }
+                    } else {
+                        ka.allow_partition = in->rows >= (int64_t(1) << 18) ? 1 : 0;
+                        launch(ctx, "agg_grouped_fast", pick_fast_kernel(fp, fast_key, a.nv, vf64), dim3(grid), dim3(AGG_BLOCK), shmem, ka,
+                               fpred, tb.g, ctx->d_flags);
+                    }
                 } else {
                     launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain), dim3(grid), dim3(AGG_BLOCK), shmem, ka, tb.g,
                            ctx->d_flags);
@@ -1067,6 +1442,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         flags_read(ctx, f);
         if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
+        if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode) {
+            partition_mode = true; // a workgroup table overflowed: redo with hash-partitioned rows
+            flags_reset(ctx);
+            continue;
+        }
         if (f[NQE_FLAG_TABLE_FULL]) {
             if (cap >= (1u << 31) || attempt > 8) fail(NQE_ERR_OUT_OF_MEMORY, "group table overflow");
             cap <<= 3;

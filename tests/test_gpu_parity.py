@@ -588,3 +588,26 @@ def test_hash_join_on_utf8_keys(ctx, unique):
     with pytest.raises(ErrorCode) as e:
         ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 0, 0)  # Utf8 vs Float64 key
     assert e.value.status in (Status.NotImplemented, Status.NotSupported)
+
+
+@pytest.mark.parametrize("groups", [3000, 60000, 400000])
+def test_aggregate_partitioned_path_many_groups(ctx, groups):
+    """more distinct keys than a workgroup table holds (and >= 2^18 rows): hash-partitioned aggregation"""
+    rng = np.random.default_rng(groups)
+    n = 600_000
+    k = (rng.integers(0, groups, n).astype(np.int64) - groups // 2) * 7      # negative keys, common factor
+    k[:3] = np.iinfo(np.int64).min                                            # the table's EMPTY sentinel as a real key
+    v = rng.random(n) * 100 - 50
+    v[5] = np.nan
+    w = rng.integers(-1000, 1000, n).astype(np.int64)
+    cols = [Column.from_numpy(k), Column.from_numpy(v), Column.from_numpy(w)]
+    f3 = fields("k", "v", "w")
+    t = ctx.table_from_host(cols)
+    for aggs in (ALL_AGGS(1), ALL_AGGS(1) + ALL_AGGS(2)):
+        for key in (col(0), binop(col(0), Operator.Modulos, lit_i64(100003))):
+            for pred in (None, binop(col(2), Operator.GtEq, lit_i64(-200))):
+                pn = pred.flatten(f3) if pred is not None else None
+                exp = orc.aggregate([cols], aggs, group_nodes=key.flatten(f3), pred_nodes=pn)[0]
+                got = ctx.aggregate(t, aggs, group_nodes=key.flatten(f3), pred_nodes=pn).to_host()
+                counts = [i for i, (fn, _) in enumerate(aggs) if fn == AggregateFunc.Count]
+                assert_rows_multiset_equal(got, exp, RTOL, exact_cols=counts, what=f"partitioned groups={groups} key={key!r}")

@@ -90,5 +90,9 @@ for groups in ((1 << 10, 1 << 12, 1 << 14, 1 << 17, 1 << 20, 1 << 24) if SECTION
     ctx.synth_fill(1, 7, 0, n, groups, 0, kt.data_ptr())
     tab = ctx.table_from_device([(DType.INT64, n, kt.data_ptr(), None), (DType.FLOAT64, n, vt.data_ptr(), None)])
     q = timeit(lambda: ctx.aggregate(tab, aggs, group_nodes=col(0).flatten(f)), reps=3, warm=1)
-    print(f"group by random key, {groups} groups, {n} rows: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
+    ctx.timing_enable(True); ctx.timing_reset()
+    r = ctx.aggregate(tab, aggs, group_nodes=col(0).flatten(f)); del r
+    ctx.timing_enable(False)
+    br = {k: round(ctx.timing_query(k)[0], 3) for k in ("agg_grouped_fast", "agg_partition_count", "agg_partition_scatter", "agg_segments", "scan_", "agg_table_init", "agg_collect", "radix", "agg_finalize")}
+    print(f"group by random key, {groups} groups, {n} rows: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s  kernels(ms) {br}")
     del tab, kt
