@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *value
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
-                    v[k] = words[row < last ? row : last];
+                    v[k] = __builtin_nontemporal_load(&words[row < last ? row : last]);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) compact_kernel(const void *src_values, in
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
-                        v[k] = words[row < last ? row : last]; // unconditional, coalesced
+                        v[k] = __builtin_nontemporal_load(&words[row < last ? row : last]); // unconditional, coalesced, streamed once
                     }
                 }
 #pragma unroll
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) compact_kernel(const void *src_values, in
                     uint32_t off = bcast32(my_off, k0 + k);
                     if ((word >> lane_id()) & 1) {
                         uint64_t x = EXPR ? eval_simple(e, v[k], true, flags) : v[k];
-                        out_words[base + off + __popcll(word & lanemask_lt())] = x;
+                        __builtin_nontemporal_store(x, &out_words[base + off + __popcll(word & lanemask_lt())]);
                     }
                 }
             }

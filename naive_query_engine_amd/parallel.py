@@ -112,21 +112,21 @@ def sharded_aggregate(ctx, local_table, aggs, group_nodes=None, pred_nodes=None,
         kdt = keys.dtypes()[0]
         cols = table_columns_as_tensors(keys, dev) + cols
     per_rank, counts = all_gather_rows(cols, group)
-    states, keyts, keep = [], [], []
+    # one concatenated (keys, state) table instead of 2 x world small ones: the merge is associative
+    ncols = len(cols)
+    cat = [torch.cat([per_rank[r][i] for r in range(len(per_rank))]).contiguous() for i in range(ncols)]
+    total = int(sum(counts))
+    torch.cuda.synchronize(dev)
     sdt = state.dtypes()
-    for r, rc in enumerate(per_rank):
-        off = 0
-        if keys is not None:
-            kt = ctx.table_from_device([(kdt, counts[r], rc[0].data_ptr() if counts[r] else None, None)])
-            keyts.append(kt)
-            off = 1
-        st = ctx.table_from_device([(sdt[i], counts[r], rc[off + i].data_ptr() if counts[r] else None, None)
-                                    for i in range(len(sdt))])
-        states.append(st)
-        keep.append(rc)
-    out = ctx.aggregate_merge(states, keyts if keys is not None else None, aggs)
+    off = 0
+    keyt = None
+    if keys is not None:
+        keyt = ctx.table_from_device([(kdt, total, cat[0].data_ptr() if total else None, None)])
+        off = 1
+    st = ctx.table_from_device([(sdt[i], total, cat[off + i].data_ptr() if total else None, None) for i in range(len(sdt))])
+    out = ctx.aggregate_merge([st], [keyt] if keyt is not None else None, aggs)
     ctx.synchronize()
-    del keep
+    del cat
     return out
 
 
