@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the BASELINE size of the workload)")
     ap.add_argument("--random-keys", action="store_true", help="c3/headline: group by a random id column instead of the row number")
     ap.add_argument("--pass-frac", type=float, default=0.5, help="headline: fraction of rows passing `id < K` (diagnostics; the metric uses 0.5)")
+    ap.add_argument("--gather", action="store_true", help="c4 with --gpus N: also all-gather every rank's output batch in rank order (BASELINE config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=40_000_000)
     return ap.parse_args()
@@ -55,7 +56,7 @@ def main():
 
     from naive_query_engine_amd import AggregateFunc, DType, Operator, capi
     from naive_query_engine_amd.expression import binop, col, lit_i64
-    from naive_query_engine_amd.parallel import sharded_aggregate
+    from naive_query_engine_amd.parallel import sharded_aggregate, sharded_hash_join
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +136,8 @@ def main():
         kernel_name = "join_probe+join_fused+compact_gather+compact_column"
 
         def step():
+            if world > 1 and args.gather:  # C5: ordered variable-length all-gather of the per-rank outputs over RCCL
+                return sharded_hash_join(ctx, dim, fact, 0, 0, gather=True, join_table=jt)
             return ctx.hash_join_probe(jt, fact, 0)
 
         metric = "hash_join_probe_rows_per_s"

@@ -980,6 +980,115 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_kernel(AggArgs a, Par
     }
 }
 
+// un-grouped fast path: plain 8-byte columns, optional integer range predicate on one column.
+// PRED: 0 none, 1 predicate column is value column 0 (one load serves both), 2 a separate column.
+template <int PRED, int NVT, bool VF64>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_fast_kernel(AggArgs a, FastPred fp, Partial *partials) {
+    uint64_t cnt[NVT];
+    double sum[NVT], mn[NVT], mx[NVT];
+    bool nanf[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) {
+        cnt[j] = 0; sum[j] = 0.0; mn[j] = DBL_MAX; mx[j] = -DBL_MAX; nanf[j] = false;
+    }
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(a.pred_src.values);
+    const uint64_t *__restrict__ valp[NVT];
+    int vdt[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) {
+        valp[j] = static_cast<const uint64_t *>(a.val[j].values);
+        vdt[j] = a.val[j].dtype;
+    }
+    const int64_t n = a.n, last = a.n - 1;
+    struct Tile {
+        uint64_t pw[AGG_U], vw[NVT][AGG_U];
+    };
+    auto load_tile = [&](Tile &t, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            row = row < last ? row : last;
+            if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row]);
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
+        }
+    };
+    auto process_tile = [&](const Tile &t, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            bool pass = row < n;
+            if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? t.vw[0][u] : t.pw[u]);
+            if (!pass) continue;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+                double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+                cnt[j] += 1;
+                sum[j] += x;
+                nanf[j] = nanf[j] || (x != x);
+                mn[j] = fmin(mn[j], x);
+                mx[j] = fmax(mx[j], x);
+            }
+        }
+    };
+    const int64_t step = int64_t(AGG_BLOCK) * AGG_U;
+    const int64_t stride = int64_t(gridDim.x) * step;
+    int64_t base = int64_t(blockIdx.x) * step;
+    if (base < n) {
+        Tile A, B;
+        load_tile(A, base);
+        for (;;) {
+            load_tile(B, base + stride);
+            process_tile(A, base);
+            base += stride;
+            if (base >= n) break;
+            load_tile(A, base + stride);
+            process_tile(B, base);
+            base += stride;
+            if (base >= n) break;
+        }
+    }
+    __shared__ Partial wave_part[AGG_BLOCK / 64][NV];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) {
+        uint32_t nf = nanf[j] ? 1u : 0u;
+        for (int d = 32; d > 0; d >>= 1) {
+            cnt[j] += __shfl_down((unsigned long long)cnt[j], d, 64);
+            sum[j] += shfl_down_f64(sum[j], d);
+            double omn = shfl_down_f64(mn[j], d), omx = shfl_down_f64(mx[j], d);
+            mn[j] = omn < mn[j] ? omn : mn[j];
+            mx[j] = omx > mx[j] ? omx : mx[j];
+            nf |= __shfl_down(nf, d, 64);
+        }
+        if (lane_id() == 0) {
+            Partial p{cnt[j], sum[j], mn[j], mx[j], nf, 0};
+            wave_part[threadIdx.x / 64][j] = p;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NVT) {
+        int j = threadIdx.x;
+        Partial t{0, 0.0, DBL_MAX, -DBL_MAX, 0, 0};
+        for (int w = 0; w < AGG_BLOCK / 64; ++w) {
+            const Partial &p = wave_part[w][j];
+            t.cnt += p.cnt; t.sum += p.sum;
+            t.mn = p.mn < t.mn ? p.mn : t.mn;
+            t.mx = p.mx > t.mx ? p.mx : t.mx;
+            t.nan |= p.nan;
+        }
+        partials[size_t(blockIdx.x) * NV + j] = t;
+    }
+}
+
+using UngroupedFastKernel = void (*)(AggArgs, FastPred, Partial *);
+template <int PRED> UngroupedFastKernel pick_ungrouped_fast_nv(int nv, bool vf64) {
+    if (nv == 1) return vf64 ? agg_ungrouped_fast_kernel<PRED, 1, true> : agg_ungrouped_fast_kernel<PRED, 1, false>;
+    return vf64 ? agg_ungrouped_fast_kernel<PRED, 2, true> : agg_ungrouped_fast_kernel<PRED, 2, false>;
+}
+UngroupedFastKernel pick_ungrouped_fast(int pred, int nv, bool vf64) {
+    return pred == 0 ? pick_ungrouped_fast_nv<0>(nv, vf64) : pred == 1 ? pick_ungrouped_fast_nv<1>(nv, vf64) : pick_ungrouped_fast_nv<2>(nv, vf64);
+}
+
 // folds the per-workgroup partials (in block order) into slot 0 of a cap=1 table
 __global__ void agg_ungrouped_fold_kernel(const Partial *partials, int nblocks, int nv, int v0, GroupTable g) {
     int j = threadIdx.x;
@@ -1432,6 +1541,19 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 int grid = int(std::min<int64_t>(int64_t(ctx->num_cus) * 2,
                                                  (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
                 BufRef partials = dev_alloc(ctx, size_t(grid) * NV * sizeof(Partial));
+                // fast path: plain 8-byte value columns, predicate none or an integer `col cmp lit`
+                FastPred ufp{};
+                bool uplain = a.nv >= 1;
+                for (int j = 0; j < a.nv; ++j) uplain = uplain && a.val[j].values && !a.val[j].valid;
+                bool upred_ok = a.pred_mode == 0 ||
+                                (a.pred_mode == 1 && is_word_type(a.pred_src.dtype) && !a.pred_src.valid && make_fast_pred(a.pred, &ufp));
+                if (uplain && upred_ok) {
+                    int up = a.pred_mode == 0 ? 0 : (a.pred_src.values == a.val[0].values ? 1 : 2);
+                    bool vf64 = true;
+                    for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
+                    launch(ctx, "agg_ungrouped_fast", pick_ungrouped_fast(up, a.nv, vf64), dim3(grid), dim3(AGG_BLOCK), 0, a, ufp,
+                           (Partial *)partials->ptr);
+                } else
                 launch(ctx, "agg_ungrouped", agg_ungrouped_kernel, dim3(grid), dim3(AGG_BLOCK), 0, a, (Partial *)partials->ptr,
                        ctx->d_flags);
                 launch(ctx, "agg_ungrouped_fold", agg_ungrouped_fold_kernel, dim3(1), dim3(64), 0,
