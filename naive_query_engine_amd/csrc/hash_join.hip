@@ -347,39 +347,90 @@ struct JoinCols {
     uint8_t *dst_valid_bytes[MAX_JOIN_COLS];
 };
 
-// pass 2: ranks rows of the tile in probe order and writes every output column
+// pass 2, output-driven ("load-balanced expansion"): a tile of probe rows is scanned in LDS; lane j of the
+// workgroup then produces OUTPUT row base+j: its probe row is found by binary search in the tile's offsets,
+// its match number m = j - offset[row], its build row = perm[start + m].  Consecutive lanes write consecutive
+// output rows of every column (coalesced), probe-row-major with ascending build row inside a probe row —
+// exactly the order of the reference's outer_pos/inner_pos (hash_join.rs:86-101).
+constexpr int PW_TILE = 1024; // probe rows per tile (= JT_ROWS / 4); tile_offsets are per JT_ROWS, so 4 sub-tiles share one base
 __global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *pmeta, int64_t n, const uint64_t *tile_offsets,
                                                                const uint32_t *perm, int direct, JoinCols jc) {
+    __shared__ uint32_t off[PW_TILE + 1];
+    __shared__ uint32_t startv[PW_TILE];
     __shared__ uint32_t wave_tot[JT_BLOCK / 64];
+    constexpr int RPT = PW_TILE / JT_BLOCK; // probe rows per thread
     for (int64_t tile = blockIdx.x; tile * JT_ROWS < n; tile += gridDim.x) {
-        uint64_t run = tile_offsets[tile];
-        for (int it = 0; it < JT_ITERS; ++it) {
-            int64_t i = tile * JT_ROWS + int64_t(it) * JT_BLOCK + threadIdx.x;
-            uint64_t m = i < n ? pmeta[i] : 0ull;
-            uint32_t cnt = uint32_t(m & 0xFFFFFFFFull);
-            uint32_t start = uint32_t(m >> 32);
+        uint64_t out_base = tile_offsets[tile];
+        for (int sub = 0; sub < JT_ROWS / PW_TILE; ++sub) {
+            const int64_t row0 = tile * JT_ROWS + int64_t(sub) * PW_TILE;
+            if (row0 >= n) break;
+            // ---- exclusive scan of the match counts of this sub-tile (thread t owns RPT consecutive probe rows)
+            uint32_t cnt[RPT], local = 0;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                int64_t i = row0 + int64_t(threadIdx.x) * RPT + r;
+                uint64_t m = i < n ? pmeta[i] : 0ull;
+                cnt[r] = uint32_t(m & 0xFFFFFFFFull);
+                startv[threadIdx.x * RPT + r] = uint32_t(m >> 32);
+                local += cnt[r];
+            }
             uint32_t wtot;
-            uint32_t ex = wave_exclusive_scan(cnt, wtot);
+            uint32_t ex = wave_exclusive_scan(local, wtot);
             if (lane_id() == 63) wave_tot[threadIdx.x / 64] = wtot;
             __syncthreads();
-            uint32_t pre = 0, all = 0;
+            uint32_t pre = 0, total = 0;
             for (int w = 0; w < JT_BLOCK / 64; ++w) {
                 if (w < int(threadIdx.x) / 64) pre += wave_tot[w];
-                all += wave_tot[w];
+                total += wave_tot[w];
             }
-            uint64_t pos = run + pre + ex;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                uint32_t b = direct ? start : perm[start + k];
+            uint32_t run = pre + ex;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                off[threadIdx.x * RPT + r] = run;
+                run += cnt[r];
+            }
+            if (threadIdx.x == 0) off[PW_TILE] = total;
+            __syncthreads();
+            // ---- one lane per output row
+            for (uint32_t j0 = 0; j0 < total; j0 += JT_BLOCK * 4) {
+                uint32_t prow[4], brow[4];
+                bool live[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t j = j0 + q * JT_BLOCK + threadIdx.x;
+                    live[q] = j < total;
+                    uint32_t lo = 0, hi = PW_TILE; // largest lo with off[lo] <= j
+                    uint32_t jj = live[q] ? j : 0;
+#pragma unroll
+                    for (int step = 0; step < 10; ++step) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        bool go = off[mid] <= jj;
+                        lo = go ? mid : lo;
+                        hi = go ? hi : mid;
+                    }
+                    prow[q] = lo;
+                    uint32_t mth = jj - off[lo];
+                    brow[q] = live[q] ? (direct ? startv[lo] : perm[startv[lo] + mth]) : 0u;
+                }
                 for (int c = 0; c < jc.n; ++c) {
-                    int64_t srow = c < jc.n_left ? int64_t(b) : i;
-                    bool ok = jc.src_valid[c] ? get_bit(jc.src_valid[c], srow) : true;
-                    uint64_t v = load_word(jc.src[c], jc.dtype[c], srow);
-                    if (jc.dst_words[c]) jc.dst_words[c][pos + k] = ok ? v : 0;
-                    if (jc.dst_bool_bytes[c]) jc.dst_bool_bytes[c][pos + k] = (ok && v) ? 1 : 0;
-                    if (jc.dst_valid_bytes[c]) jc.dst_valid_bytes[c][pos + k] = ok ? 1 : 0;
+                    const bool left = c < jc.n_left;
+                    const void *src = jc.src[c];
+                    const uint8_t *sv = jc.src_valid[c];
+                    const int dt = jc.dtype[c];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (!live[q]) continue;
+                        int64_t srow = left ? int64_t(brow[q]) : row0 + prow[q];
+                        bool ok = sv ? get_bit(sv, srow) : true;
+                        uint64_t v = load_word(src, dt, srow);
+                        uint64_t pos = out_base + j0 + q * JT_BLOCK + threadIdx.x;
+                        if (jc.dst_words[c]) jc.dst_words[c][pos] = ok ? v : 0;
+                        if (jc.dst_bool_bytes[c]) jc.dst_bool_bytes[c][pos] = (ok && v) ? 1 : 0;
+                        if (jc.dst_valid_bytes[c]) jc.dst_valid_bytes[c][pos] = ok ? 1 : 0;
+                    }
                 }
             }
-            run += all;
+            out_base += total;
             __syncthreads();
         }
     }
@@ -633,13 +684,22 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
     DevColumn left_rowid, right_rowid, outer_pos, inner_pos;
     std::vector<const DevColumn *> srcs;
     std::vector<int> out_slot; // output column index of each kernel column, -1 outer_pos, -2 inner_pos
+    // the build key of a match is bit-identical to the probe key: emit that column from the probe side (coalesced)
+    DevColumn key_from_probe;
+    const bool key_shortcut = jt->key_dtype != NQE_UTF8 && !jt->left_cols[size_t(jt->left_key)].validity;
     for (size_t c = 0; c < jt->left_cols.size(); ++c)
-        if (jt->left_cols[c].dtype != NQE_UTF8) { srcs.push_back(&jt->left_cols[c]); out_slot.push_back(int(c)); }
+        if (jt->left_cols[c].dtype != NQE_UTF8 && !(key_shortcut && int(c) == jt->left_key)) { srcs.push_back(&jt->left_cols[c]); out_slot.push_back(int(c)); }
     if (utf8_left) {
         left_rowid.dtype = NQE_INT64; left_rowid.length = jt->left_rows; left_rowid.values = iota_i64(ctx, 0, jt->left_rows);
         srcs.push_back(&left_rowid); out_slot.push_back(-1);
     }
     jc.n_left = int(srcs.size());
+    if (key_shortcut) {
+        key_from_probe = rk;
+        key_from_probe.validity = nullptr;
+        key_from_probe.null_count = 0;
+        srcs.push_back(&key_from_probe); out_slot.push_back(jt->left_key);
+    }
     for (size_t c = 0; c < right->cols.size(); ++c)
         if (right->cols[c].dtype != NQE_UTF8) { srcs.push_back(&right->cols[c]); out_slot.push_back(int(jt->left_cols.size() + c)); }
     if (utf8_right) {

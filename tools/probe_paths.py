@@ -96,3 +96,22 @@ for groups in ((1 << 10, 1 << 12, 1 << 14, 1 << 17, 1 << 20, 1 << 24) if SECTION
     br = {k: round(ctx.timing_query(k)[0], 3) for k in ("agg_grouped_fast", "agg_partition_count", "agg_partition_scatter", "agg_segments", "scan_", "agg_table_init", "agg_collect", "radix", "agg_finalize")}
     print(f"group by random key, {groups} groups, {n} rows: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s  kernels(ms) {br}")
     del tab, kt
+
+# ---- 4. join with duplicate build keys (general two-pass path)
+if SECTION in ("all", "dupjoin"):
+    nb, npr = 1_000_000, 50_000_000
+    for dup in (1, 2, 4):
+        bk = torch.arange(nb, device=dev, dtype=torch.int64) // dup          # every key `dup` times
+        ba = torch.arange(nb, device=dev, dtype=torch.int64) * 3
+        pk = torch.empty(npr, dtype=torch.int64, device=dev); torch.cuda.synchronize()
+        ctx.synth_fill(1, 5, 0, npr, nb // dup, 0, pk.data_ptr())
+        pv = torch.empty(npr, dtype=torch.float64, device=dev); ctx.synth_fill(2, 3, 0, npr, 1, 0, pv.data_ptr())
+        dim = ctx.table_from_device([(DType.INT64, nb, bk.data_ptr(), None), (DType.INT64, nb, ba.data_ptr(), None)])
+        fact = ctx.table_from_device([(DType.INT64, npr, pk.data_ptr(), None), (DType.FLOAT64, npr, pv.data_ptr(), None)])
+        jt = ctx.hash_join_build(dim, 0)
+        q = timeit(lambda: ctx.hash_join_probe(jt, fact, 0), reps=3, warm=1)
+        ctx.timing_enable(True); ctx.timing_reset()
+        r = ctx.hash_join_probe(jt, fact, 0); rows = r.num_rows; del r
+        ctx.timing_enable(False)
+        br = {k: round(ctx.timing_query(k)[0], 3) for k in ("join_probe_count", "join_probe_write", "join_probe_presence", "join_fused_write", "join_probe_unique", "compact", "scan_")}
+        print(f"join dup={dup}: {npr} probe rows -> {rows} rows: {q*1e3:.3f} ms  ({(npr*16+rows*32)/q/1e9:.0f} GB/s algorithmic)  kernels(ms) {br}")
