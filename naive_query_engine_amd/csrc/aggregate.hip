@@ -706,10 +706,101 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_scatter_kernel(AggArg
     }
 }
 
+// Second partitioning level: workgroup p splits parent partition p (a contiguous tuple range) into SUB sub-partitions
+// by the next SUB_LOG2 hash bits — count, tile-local scan, then the same LDS-sorted scatter as level 1.  The output
+// occupies the same global range as the input partition, so no cross-workgroup scan is needed.
+constexpr int SUB_LOG2 = 6;
+constexpr int SUB = 1 << SUB_LOG2;
+template <int NVT>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_subpartition_kernel(const uint64_t *offsets, int64_t off_stride, const uint64_t *in_key,
+                                                                     const uint64_t *in_v0, const uint64_t *in_v1, uint64_t *out_key,
+                                                                     uint64_t *out_v0, uint64_t *out_v1, uint64_t *sub_offsets) {
+    constexpr int RPT = NVT == 1 ? 8 : 4;
+    constexpr int SC_ROWS = AGG_BLOCK * RPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *skey = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *sval = skey + SC_ROWS;
+    __shared__ uint64_t gcur[SUB];
+    __shared__ uint32_t tcnt[SUB], tstart[SUB], total_cnt[SUB];
+    const uint64_t *__restrict__ inv[2] = {in_v0, in_v1};
+    uint64_t *outv[2] = {out_v0, out_v1};
+    for (int p = blockIdx.x; p < PARTS; p += gridDim.x) {
+        const int64_t lo = int64_t(offsets[int64_t(p) * off_stride]), hi = int64_t(offsets[int64_t(p + 1) * off_stride]);
+        __syncthreads();
+        if (threadIdx.x < SUB) total_cnt[threadIdx.x] = 0, tcnt[threadIdx.x] = 0;
+        __syncthreads();
+        // ---- count
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            uint32_t sp = uint32_t(((in_key[i] * GOLD) << PARTS_LOG2) >> (64 - SUB_LOG2));
+            atomicAdd(&total_cnt[sp], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t run = uint64_t(lo);
+            for (int sp = 0; sp < SUB; ++sp) {
+                gcur[sp] = run;
+                sub_offsets[int64_t(p) * SUB + sp] = run;
+                run += total_cnt[sp];
+            }
+            if (p == PARTS - 1) sub_offsets[int64_t(PARTS) * SUB] = run;
+        }
+        __syncthreads();
+        // ---- scatter, tile by tile, sorted in LDS first
+        for (int64_t base = lo; base < hi; base += SC_ROWS) {
+            uint64_t key[RPT], vw[NVT][RPT];
+            uint32_t part[RPT], rank[RPT];
+            bool pass[RPT];
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+                pass[u] = row < hi;
+                int64_t rc = pass[u] ? row : hi - 1;
+                key[u] = in_key[rc];
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) vw[j][u] = inv[j][rc];
+                part[u] = uint32_t(((key[u] * GOLD) << PARTS_LOG2) >> (64 - SUB_LOG2));
+            }
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
+            __syncthreads();
+            if (threadIdx.x < 64) { // SUB == 64: one wave scans the tile counters
+                uint32_t c = tcnt[threadIdx.x], wt;
+                tstart[threadIdx.x] = wave_exclusive_scan(c, wt);
+            }
+            __syncthreads();
+            uint32_t tile_total = tstart[SUB - 1] + tcnt[SUB - 1];
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                if (!pass[u]) continue;
+                uint32_t i = tstart[part[u]] + rank[u];
+                skey[i] = key[u];
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) sval[j * SC_ROWS + i] = vw[j][u];
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < tile_total; i += blockDim.x) {
+                uint64_t k = skey[i];
+                uint32_t sp = uint32_t(((k * GOLD) << PARTS_LOG2) >> (64 - SUB_LOG2));
+                uint64_t dest = gcur[sp] + (i - tstart[sp]);
+                out_key[dest] = k;
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) outv[j][dest] = sval[j * SC_ROWS + i];
+            }
+            __syncthreads();
+            if (threadIdx.x < SUB) {
+                gcur[threadIdx.x] += tcnt[threadIdx.x];
+                tcnt[threadIdx.x] = 0;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // one workgroup per partition (grid-stride over partitions): plain (key, values) tuples → LDS table → global table.
 // The LDS slot uses the hash bits BELOW the partition bits (all keys of a partition share the top PARTS_LOG2 bits).
 template <int NVT, bool VF64>
-__global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, const uint64_t *seg_offsets, int64_t seg_stride, int nsegs, const uint64_t *keys,
+__global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, const uint64_t *seg_offsets, int64_t seg_stride, int nsegs, int part_bits,
+                                                                 int signal_level2, const uint64_t *keys,
                                                                  const uint64_t *v0, const uint64_t *v1, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
@@ -728,6 +819,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
     volatile int *seg_full = &seg_full_flag;
     for (int seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
         __syncthreads();
+        if (signal_level2 && __hip_atomic_load(&flags[NQE_FLAG_NEED_LEVEL2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         if (threadIdx.x == 0) seg_full_flag = 0;
         for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
             lkeys[s] = EMPTY_KEY;
@@ -761,7 +853,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
                 if (key == EMPTY_KEY) { lkeys[cap] = 0; slot = int(cap); }
                 else if (*seg_full) slot = -1; // this partition has more distinct keys than the table: spill the rest
                 else {
-                    uint32_t sl = uint32_t(((key * GOLD) << PARTS_LOG2) >> a.lds_shift);
+                    uint32_t sl = uint32_t(((key * GOLD) << part_bits) >> a.lds_shift);
                     slot = -1;
                     for (int probe = 0; probe < 32; ++probe) {
                         uint64_t k = lkeys[sl];
@@ -773,7 +865,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
                         sl = (sl + 1) & (cap - 1);
                     }
                 }
-                if (slot < 0 && !*seg_full) *seg_full = 1;
+                if (slot < 0 && !*seg_full) {
+                    *seg_full = 1;
+                    if (signal_level2) atomicOr(&flags[NQE_FLAG_NEED_LEVEL2], 1); // the host re-partitions one level deeper
+                }
+                if (slot < 0 && signal_level2) continue;                              // result will be discarded
                 int64_t gslot = slot < 0 ? global_find_or_insert(g, key, flags) : 0; // partition larger than the table: spill
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) {
@@ -1126,15 +1222,43 @@ __global__ void table_init_kernel(GroupTable g, int mark_slot0) {
     }
 }
 
-__global__ void collect_kernel(GroupTable g, uint64_t *out_keys, uint32_t *out_slots, uint32_t *counter) {
-    size_t slots = size_t(g.cap) + 1;
-    size_t stride = size_t(gridDim.x) * blockDim.x;
-    for (size_t s = size_t(blockIdx.x) * blockDim.x + threadIdx.x; s < slots; s += stride) {
-        uint64_t k = g.keys[s];
-        if (k == EMPTY_KEY) continue;
-        uint32_t idx = atomicAdd(counter, 1u);
-        out_keys[idx] = (s == g.cap) ? EMPTY_KEY : k;
-        out_slots[idx] = uint32_t(s);
+__global__ void __launch_bounds__(256) collect_kernel(GroupTable g, uint64_t *out_keys, uint32_t *out_slots, uint32_t *counter) {
+    // One returning atomic per WORKGROUP: a single hot word sustains only ≈88 M returning atomics/s on MI355X
+    // (one per wave-iteration cost 23.8 ms for a 2^27-slot table).  Pass 1 counts the occupied slots of the
+    // workgroup's contiguous chunk, one atomicAdd reserves its output range, pass 2 writes (order is irrelevant:
+    // the entries are sorted by key afterwards).
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ uint32_t block_base;
+    const size_t slots = size_t(g.cap) + 1;
+    const size_t chunk = ((slots + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
+    const size_t lo = size_t(blockIdx.x) * chunk, hi = lo + chunk < slots ? lo + chunk : slots;
+    const int wv = threadIdx.x / 64;
+    uint32_t mine = 0;
+    for (size_t s0 = lo + size_t(wv) * 64; s0 < hi; s0 += 256) {
+        size_t s = s0 + lane_id();
+        bool used = s < hi && g.keys[s] != EMPTY_KEY;
+        mine += uint32_t(__popcll(__ballot(used))); // wave-uniform
+    }
+    if (lane_id() == 0) wave_cnt[wv] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        block_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t run = block_base;
+    for (int w = 0; w < wv; ++w) run += wave_cnt[w];
+    for (size_t s0 = lo + size_t(wv) * 64; s0 < hi; s0 += 256) {
+        size_t s = s0 + lane_id();
+        uint64_t k = s < hi ? g.keys[s] : EMPTY_KEY;
+        bool used = k != EMPTY_KEY;
+        uint64_t m = __ballot(used);
+        if (used) {
+            uint32_t idx = run + uint32_t(__popcll(m & lanemask_lt()));
+            out_keys[idx] = (s == g.cap) ? EMPTY_KEY : k;
+            out_slots[idx] = uint32_t(s);
+        }
+        run += uint32_t(__popcll(m));
     }
 }
 
@@ -1420,7 +1544,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         cap = 4096;
         while (int64_t(cap) < 2 * guess) cap <<= 1;
     }
-    bool partition_mode = false;
+    bool partition_mode = false, level2 = false;
     for (int attempt = 0;; ++attempt) {
         TableBufs tb = make_table(ctx, cap, V, !grouped);
         for (int v0 = 0; v0 < std::max(V, 1); v0 += NV) {
@@ -1523,9 +1647,25 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             int sgrid = std::min(PARTS, ctx->num_cus * sblocks);
                             auto segk = a.nv == 1 ? (vf64 ? agg_segments_kernel<1, true> : agg_segments_kernel<1, false>)
                                                   : (vf64 ? agg_segments_kernel<2, true> : agg_segments_kernel<2, false>);
-                            launch(ctx, "agg_segments", segk, dim3(sgrid), dim3(AGG_BLOCK), sshmem, sa, (const uint64_t *)offs->ptr, int64_t(nblk), PARTS,
-                                   (const uint64_t *)okey->ptr, (const uint64_t *)ov0->ptr, ov1 ? (const uint64_t *)ov1->ptr : (const uint64_t *)nullptr,
-                                   tb.g, ctx->d_flags);
+                            if (!level2) {
+                                launch(ctx, "agg_segments", segk, dim3(sgrid), dim3(AGG_BLOCK), sshmem, sa, (const uint64_t *)offs->ptr, int64_t(nblk), PARTS,
+                                       PARTS_LOG2, 1, (const uint64_t *)okey->ptr, (const uint64_t *)ov0->ptr,
+                                       ov1 ? (const uint64_t *)ov1->ptr : (const uint64_t *)nullptr, tb.g, ctx->d_flags);
+                            } else {
+                                // partitions were overfull: split each into 64 sub-partitions, then one workgroup per sub-partition
+                                BufRef k2 = dev_alloc(ctx, size_t(R) * 8 + 8), v02 = dev_alloc(ctx, size_t(R) * 8 + 8), v12;
+                                if (a.nv > 1) v12 = dev_alloc(ctx, size_t(R) * 8 + 8);
+                                BufRef suboff = dev_alloc(ctx, size_t(PARTS) * SUB * 8 + 16);
+                                auto subk = a.nv == 1 ? agg_subpartition_kernel<1> : agg_subpartition_kernel<2>;
+                                launch(ctx, "agg_subpartition", subk, dim3(std::min(PARTS, ctx->num_cus)), dim3(AGG_BLOCK), sc_rows * 8 * size_t(1 + a.nv),
+                                       (const uint64_t *)offs->ptr, int64_t(nblk), (const uint64_t *)okey->ptr, (const uint64_t *)ov0->ptr,
+                                       ov1 ? (const uint64_t *)ov1->ptr : (const uint64_t *)nullptr, (uint64_t *)k2->ptr, (uint64_t *)v02->ptr,
+                                       v12 ? (uint64_t *)v12->ptr : (uint64_t *)nullptr, (uint64_t *)suboff->ptr);
+                                launch(ctx, "agg_segments", segk, dim3(std::min(PARTS * SUB, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem, sa,
+                                       (const uint64_t *)suboff->ptr, int64_t(1), PARTS * SUB, PARTS_LOG2 + SUB_LOG2, 0, (const uint64_t *)k2->ptr,
+                                       (const uint64_t *)v02->ptr, v12 ? (const uint64_t *)v12->ptr : (const uint64_t *)nullptr, tb.g, ctx->d_flags);
+                                sync(ctx);
+                            }
                             sync(ctx); // the partition buffers are released at the end of this scope
                         }
                     } else {
@@ -1564,6 +1704,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         flags_read(ctx, f);
         if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
+        if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2) {
+            level2 = true; // partitions hold more distinct keys than a workgroup table: one more partitioning level
+            cap = std::max<uint32_t>(cap, 1u << 24);
+            flags_reset(ctx);
+            continue;
+        }
         if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode) {
             partition_mode = true; // a workgroup table overflowed: redo with hash-partitioned rows
             flags_reset(ctx);

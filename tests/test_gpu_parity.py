@@ -611,3 +611,18 @@ def test_aggregate_partitioned_path_many_groups(ctx, groups):
                 got = ctx.aggregate(t, aggs, group_nodes=key.flatten(f3), pred_nodes=pn).to_host()
                 counts = [i for i, (fn, _) in enumerate(aggs) if fn == AggregateFunc.Count]
                 assert_rows_multiset_equal(got, exp, RTOL, exact_cols=counts, what=f"partitioned groups={groups} key={key!r}")
+
+
+def test_aggregate_two_level_partitioning_millions_of_groups(ctx):
+    """more distinct keys per partition than a workgroup table holds → second partitioning level (512 x 64)"""
+    rng = np.random.default_rng(5)
+    n, groups = 3_000_000, 2_600_000
+    k = rng.integers(0, groups, n).astype(np.int64) * 3 - groups
+    v = rng.random(n)
+    cols = [Column.from_numpy(k), Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=col(0).flatten(f2))[0]
+    got, gk = ctx.aggregate(ctx.table_from_host(cols), ALL_AGGS(1), group_nodes=col(0).flatten(f2), with_keys=True)
+    assert got.num_rows == len(np.unique(k))
+    assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what="two-level partitioned aggregate")
+    assert (gk.to_host()[0].to_numpy() == np.unique(k)).all()
