@@ -206,6 +206,301 @@ __global__ void fill_words_kernel(uint64_t *out, uint64_t v, int64_t n) {
     for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < n; j += stride) out[j] = v;
 }
 
+// ------------------------------------------------------------------ fused whole-tree evaluation
+// A tree of binary nodes is evaluated in ONE pass by a small stack machine: one instruction per BINARY node
+// (post-order), whose operands are a literal (SGPR broadcast), a pre-loaded column word, or the top of a register-
+// resident stack of intermediate results.  Control flow is wave-uniform (the program lives in the kernel arguments).
+// Reads each referenced column once and writes the result once — no temporaries (the reference / arrow materialise one
+// full column per node plus one per literal).
+//
+// Each wave walks 256-row chunks; a lane owns EX_ROWS rows (chunk + r*64 + lane: every access is a coalesced 512-byte
+// wave access and a ballot is one bitmap word).  All column loads of a chunk are issued back to back before anything is
+// consumed; the interpretive overhead (scalar instruction fetch, op/dtype branch chain) is paid once per EX_ROWS rows and
+// the next instruction is fetched while the current one executes.  The stack keeps its top at level 0 by register moves:
+// `stack op x` (the common left-deep shape) moves nothing.
+constexpr int EX_MAX_INSTR = 16, EX_MAX_COLS = 4, EX_MAX_DEPTH = 3, EX_ROWS = 4;
+enum ExSrc : int32_t { EX_STACK = 0, EX_LIT = 1, EX_LIT_NULL = 2, EX_COL = 4 /* + slot */ };
+struct ExInstr {
+    int32_t op, dt;       // operator, operand dtype
+    int32_t a_src, b_src; // ExSrc
+    uint64_t lit_a, lit_b;
+    OpAux aux;            // host-prepared divisor constants when b is a literal
+};
+struct ExProgram {
+    int32_t n, ncols;
+    ExInstr ins[EX_MAX_INSTR];
+    const void *col_values[EX_MAX_COLS];
+    const uint8_t *col_valid[EX_MAX_COLS];
+    int32_t col_dtype[EX_MAX_COLS];
+};
+
+template <int OP, int DT> struct OpTag { static constexpr int op = OP, dt = DT; };
+// wave-uniform (op, dtype) → compile-time constants.  Boolean operands compare like UInt64 words (0/1).
+template <class F> __device__ __forceinline__ void dispatch_binary(int op, int dt, F &&f) {
+#define NQE_DISPATCH_OP(O)                                                                                                       \
+    case O:                                                                                                                      \
+        if (dt == NQE_INT64) f(OpTag<O, NQE_INT64>{});                                                                           \
+        else if (dt == NQE_FLOAT64) f(OpTag<O, NQE_FLOAT64>{});                                                                  \
+        else f(OpTag<O, NQE_UINT64>{});                                                                                          \
+        break;
+    switch (op) {
+        NQE_DISPATCH_OP(NQE_OP_EQ) NQE_DISPATCH_OP(NQE_OP_NOT_EQ) NQE_DISPATCH_OP(NQE_OP_LT) NQE_DISPATCH_OP(NQE_OP_LT_EQ)
+        NQE_DISPATCH_OP(NQE_OP_GT) NQE_DISPATCH_OP(NQE_OP_GT_EQ) NQE_DISPATCH_OP(NQE_OP_PLUS) NQE_DISPATCH_OP(NQE_OP_MINUS)
+        NQE_DISPATCH_OP(NQE_OP_MULTIPLY) NQE_DISPATCH_OP(NQE_OP_DIVIDE)
+    default: // NQE_OP_MODULOS
+        if (dt == NQE_INT64) f(OpTag<NQE_OP_MODULOS, NQE_INT64>{});
+        else if (dt == NQE_FLOAT64) f(OpTag<NQE_OP_MODULOS, NQE_FLOAT64>{});
+        else f(OpTag<NQE_OP_MODULOS, NQE_UINT64>{});
+        break;
+    }
+#undef NQE_DISPATCH_OP
+}
+
+__device__ __forceinline__ void ex_combine(const ExInstr &in, uint64_t &a, bool &av, uint64_t b, bool bv, int *flags) {
+    if (in.op == NQE_OP_AND || in.op == NQE_OP_OR) { // and_kleene / or_kleene
+        bool lb = av && a, rb = bv && b, ok, r;
+        if (in.op == NQE_OP_AND) { ok = (av && bv) || (av && !lb) || (bv && !rb); r = ok && lb && rb; }
+        else { ok = (av && bv) || lb || rb; r = ok && (lb || rb); }
+        a = r ? 1ull : 0ull;
+        av = ok;
+    } else {
+        bool ok = av && bv;
+        a = apply_binary(in.op, in.dt, a, b, in.aux, ok, flags);
+        av = ok;
+    }
+}
+
+__global__ void __launch_bounds__(256) expr_tree_kernel(ExProgram P, int64_t n, uint64_t *out_words, uint64_t *out_bits, uint64_t *out_valid,
+                                                        int *flags) {
+    constexpr int R = EX_ROWS;
+    const int lane = lane_id();
+    const int64_t n_chunks = (n + 64 * R - 1) / (64 * R);
+    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, n_waves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        const int64_t row0 = chunk * (64 * R) + lane;
+        // ---- issue every load of the chunk (rows clamped to n-1 so that no load is predicated), then consume
+        uint64_t cw[EX_MAX_COLS][R];
+        uint32_t vbyte[EX_MAX_COLS][R];
+#pragma unroll
+        for (int c = 0; c < EX_MAX_COLS; ++c) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { cw[c][r] = 0; vbyte[c][r] = 0xffu; }
+            if (c < P.ncols) {
+                if (P.col_dtype[c] == NQE_BOOLEAN) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) cw[c][r] = static_cast<const uint8_t *>(P.col_values[c])[min(row0 + r * 64, n - 1) >> 3];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        cw[c][r] = __builtin_nontemporal_load(static_cast<const uint64_t *>(P.col_values[c]) + min(row0 + r * 64, n - 1));
+                }
+                if (P.col_valid[c]) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) vbyte[c][r] = P.col_valid[c][min(row0 + r * 64, n - 1) >> 3];
+                }
+            }
+        }
+        uint32_t inm = 0, cvm[EX_MAX_COLS]; // one bit per owned row
+#pragma unroll
+        for (int r = 0; r < R; ++r) inm |= (row0 + r * 64 < n ? 1u : 0u) << r;
+#pragma unroll
+        for (int c = 0; c < EX_MAX_COLS; ++c) {
+            cvm[c] = 0;
+            const bool isb = c < P.ncols && P.col_dtype[c] == NQE_BOOLEAN;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int sh = int(min(row0 + r * 64, n - 1) & 7);
+                if (isb) cw[c][r] = (cw[c][r] >> sh) & 1ull;
+                cvm[c] |= ((vbyte[c][r] >> sh) & 1u) << r;
+            }
+            cvm[c] &= inm;
+        }
+        // ---- run the program
+        uint64_t s[EX_MAX_DEPTH][R];
+        uint32_t vm[EX_MAX_DEPTH];
+#pragma unroll
+        for (int d = 0; d < EX_MAX_DEPTH; ++d) {
+            vm[d] = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[d][r] = 0;
+        }
+        ExInstr cur = P.ins[0];
+        for (int pc = 0; pc < P.n; ++pc) {
+            const ExInstr nxt = P.ins[pc + 1 < P.n ? pc + 1 : pc]; // in flight while `cur` executes
+            const bool a_st = cur.a_src == EX_STACK, b_st = cur.b_src == EX_STACK;
+            const int ac = cur.a_src - EX_COL, bc = cur.b_src - EX_COL;
+            // Operand fetch and stack update are wave-uniform BRANCHES around plain register moves: a select costs VALU
+            // issue slots per row, a scalar branch does not, and the budget to stay HBM-bound is ~130 VALU instructions per
+            // 64 rows for the whole program.  Everything is copied by value with constant indices (a conditional over array
+            // lvalues would turn the stack into a dynamically indexed private array, i.e. scratch memory).
+            uint64_t a[R], b[R];
+            uint32_t am, bm;
+            if (a_st) {
+                if (b_st) {
+                    am = vm[1];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) a[r] = s[1][r];
+                } else {
+                    am = vm[0];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) a[r] = s[0][r];
+                }
+            } else if (ac < 0) {
+                am = cur.a_src == EX_LIT ? inm : 0u;
+#pragma unroll
+                for (int r = 0; r < R; ++r) a[r] = cur.lit_a;
+            } else if (ac == 0) {
+                am = cvm[0];
+#pragma unroll
+                for (int r = 0; r < R; ++r) a[r] = cw[0][r];
+            } else if (ac == 1) {
+                am = cvm[1];
+#pragma unroll
+                for (int r = 0; r < R; ++r) a[r] = cw[1][r];
+            } else if (ac == 2) {
+                am = cvm[2];
+#pragma unroll
+                for (int r = 0; r < R; ++r) a[r] = cw[2][r];
+            } else {
+                am = cvm[3];
+#pragma unroll
+                for (int r = 0; r < R; ++r) a[r] = cw[3][r];
+            }
+            if (b_st) {
+                bm = vm[0];
+#pragma unroll
+                for (int r = 0; r < R; ++r) b[r] = s[0][r];
+            } else if (bc < 0) {
+                bm = cur.b_src == EX_LIT ? inm : 0u;
+#pragma unroll
+                for (int r = 0; r < R; ++r) b[r] = cur.lit_b;
+            } else if (bc == 0) {
+                bm = cvm[0];
+#pragma unroll
+                for (int r = 0; r < R; ++r) b[r] = cw[0][r];
+            } else if (bc == 1) {
+                bm = cvm[1];
+#pragma unroll
+                for (int r = 0; r < R; ++r) b[r] = cw[1][r];
+            } else if (bc == 2) {
+                bm = cvm[2];
+#pragma unroll
+                for (int r = 0; r < R; ++r) b[r] = cw[2][r];
+            } else {
+                bm = cvm[3];
+#pragma unroll
+                for (int r = 0; r < R; ++r) b[r] = cw[3][r];
+            }
+            uint32_t m;
+            if (cur.op == NQE_OP_AND || cur.op == NQE_OP_OR) { // and_kleene / or_kleene
+                m = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    bool av = (am >> r) & 1u;
+                    ex_combine(cur, a[r], av, b[r], (bm >> r) & 1u, flags);
+                    m |= (av ? 1u : 0u) << r;
+                }
+            } else {
+                m = am & bm;
+                // one uniform op/dtype decision per instruction (not per row): the body is instantiated with constants
+                dispatch_binary(cur.op, cur.dt, [&](auto tag) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) a[r] = apply_binary(tag.op, tag.dt, a[r], b[r], cur.aux, (m >> r) & 1u, flags);
+                });
+            }
+            if (a_st && b_st) { // pop 2, push 1
+                vm[1] = vm[2];
+#pragma unroll
+                for (int r = 0; r < R; ++r) s[1][r] = s[2][r];
+            } else if (!a_st && !b_st) { // push
+                vm[2] = vm[1];
+                vm[1] = vm[0];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { s[2][r] = s[1][r]; s[1][r] = s[0][r]; }
+            }
+            vm[0] = m;
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[0][r] = a[r];
+            cur = nxt;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row0 + r * 64;
+            const bool ok = (vm[0] >> r) & 1u;
+            if (row - lane >= n) break; // wave-uniform: this 64-row word is past the end
+            if (out_words) {
+                if (row < n) __builtin_nontemporal_store(ok ? s[0][r] : 0ull, out_words + row);
+            } else {
+                uint64_t w = __ballot(ok && s[0][r]);
+                if (lane == 0) out_bits[row >> 6] = w;
+            }
+            if (out_valid) {
+                uint64_t w = __ballot(ok);
+                if (lane == 0) out_valid[row >> 6] = w;
+            }
+        }
+    }
+}
+
+// builds the stack program; false when the tree does not fit the machine (then: node-at-a-time)
+bool build_program(const nqe_table *in, const std::vector<Node> &t, int root, ExProgram *P, bool *needs_valid) {
+    std::memset(P, 0, sizeof(*P));
+    std::vector<int> order; // BINARY nodes, post-order
+    std::vector<std::pair<int, bool>> st = {{root, false}};
+    while (!st.empty()) {
+        auto [i, done] = st.back();
+        st.pop_back();
+        const Node &x = t[size_t(i)];
+        if (x.kind != NQE_EXPR_BINARY) continue;
+        if (done) { order.push_back(i); continue; }
+        st.push_back({i, true});
+        st.push_back({x.right, false});
+        st.push_back({x.left, false});
+    }
+    if (int(order.size()) > EX_MAX_INSTR || order.empty()) return false;
+    *needs_valid = false;
+    bool fits = true;
+    auto operand = [&](int idx, int32_t *src, uint64_t *lit) {
+        const Node &x = t[size_t(idx)];
+        if (x.kind == NQE_EXPR_BINARY) { *src = EX_STACK; return; }
+        if (x.kind == NQE_EXPR_LITERAL) {
+            *src = x.lit_null ? EX_LIT_NULL : EX_LIT;
+            *lit = x.lit;
+            *needs_valid |= x.lit_null;
+            return;
+        }
+        const DevColumn &c = in->cols[size_t(x.column)];
+        if (!(is_word_type(c.dtype) || c.dtype == NQE_BOOLEAN)) { fits = false; return; }
+        int slot = -1;
+        for (int k = 0; k < P->ncols; ++k)
+            if (P->col_values[k] == c.values->ptr && P->col_dtype[k] == c.dtype && P->col_valid[k] == c.valid()) slot = k;
+        if (slot < 0) {
+            if (P->ncols == EX_MAX_COLS) { fits = false; return; }
+            slot = P->ncols++;
+            P->col_values[slot] = c.values->ptr;
+            P->col_valid[slot] = c.valid();
+            P->col_dtype[slot] = c.dtype;
+        }
+        *src = EX_COL + slot;
+        *needs_valid |= c.validity != nullptr;
+    };
+    int depth = 0;
+    for (int i : order) {
+        const Node &x = t[size_t(i)];
+        ExInstr &I = P->ins[P->n++];
+        I.op = x.op;
+        I.dt = t[size_t(x.left)].out_dtype;
+        I.aux.pow2_shift = I.aux.more = -1;
+        operand(x.left, &I.a_src, &I.lit_a);
+        operand(x.right, &I.b_src, &I.lit_b);
+        if (!fits) return false;
+        if (I.b_src == EX_LIT) I.aux = make_aux(x.op, I.dt, I.lit_b);
+        depth += 1 - int(I.a_src == EX_STACK) - int(I.b_src == EX_STACK);
+        if (depth > EX_MAX_DEPTH) return false;
+    }
+    return true;
+}
+
 struct Value {
     bool is_lit = false;
     bool lit_null = false;
@@ -314,6 +609,19 @@ ExprInfo analyze_expr(const nqe_table *in, const nqe_expr_node *nodes, int n) {
 DevColumn evaluate_expr(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, int n) {
     int root;
     std::vector<Node> t = parse(in, nodes, n, &root);
+    ExProgram P;
+    bool needs_valid = false;
+    if (t[size_t(root)].kind == NQE_EXPR_BINARY && build_program(in, t, root, &P, &needs_valid)) {
+        const int64_t rows = in->rows;
+        const int odt = t[size_t(root)].out_dtype;
+        const bool bool_out = odt == NQE_BOOLEAN;
+        DevColumn out = bool_out ? make_bool_column(ctx, rows, needs_valid) : make_word_column(ctx, odt, rows, needs_valid);
+        if (rows)
+            launch(ctx, "expr_tree", expr_tree_kernel, dim3(stream_grid(ctx, (rows + EX_ROWS - 1) / EX_ROWS, 256)), dim3(256), 0, P, rows,
+                   bool_out ? nullptr : (uint64_t *)out.values->ptr, bool_out ? (uint64_t *)out.values->ptr : nullptr,
+                   needs_valid ? (uint64_t *)out.validity->ptr : nullptr, ctx->d_flags);
+        return out;
+    }
     Value v = eval_node(ctx, in, t, root);
     if (v.is_lit) return materialise_literal(ctx, v.dtype, v.lit, v.lit_null, in->rows);
     return v.col;

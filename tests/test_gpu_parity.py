@@ -116,6 +116,66 @@ def test_divide_and_modulo_by_literal_divisors(ctx):
         assert gk.to_host()[0].to_list() == sorted(set(int(np.fmod(float(0), 1)) if False else int(abs(int(x)) % abs(d) * (1 if x >= 0 else -1)) for x in i64.tolist()))
 
 
+def _random_tree(rng, depth, want):
+    """random well-typed tree over FLD: want in {'i','f','u','b'}; leaves are columns or non-zero literals"""
+    leaf_col = {"i": [0, 1], "f": [2], "u": [3], "b": [4]}[want]
+    def leaf():
+        if rng.random() < 0.6:
+            return col(int(rng.choice(leaf_col)))
+        if want == "i":
+            return lit_i64(int(rng.choice([-9, -2, 1, 3, 8, 1000])))
+        if want == "f":
+            return lit_f64(float(rng.choice([-2.5, 0.5, 3.0, 10.0])))
+        if want == "u":
+            return lit_u64(int(rng.choice([1, 2, 7, 1 << 20])))
+        return lit_bool(bool(rng.random() < 0.5))
+    if depth == 0:
+        return leaf()
+    if want == "b":
+        if rng.random() < 0.5:
+            return binop(_random_tree(rng, depth - 1, "b"), Operator.And if rng.random() < 0.5 else Operator.Or, _random_tree(rng, depth - 1, "b"))
+        t = str(rng.choice(["i", "f", "u", "b"]))
+        return binop(_random_tree(rng, depth - 1, t), CMP[int(rng.integers(0, len(CMP)))], _random_tree(rng, depth - 1, t))
+    # keep Divide/Modulos to literal divisors so that DivideByZero cannot fire on random data
+    op = ARITH[int(rng.integers(0, 3))]
+    if rng.random() < 0.3:
+        div = {"i": lit_i64(int(rng.choice([-7, 3, 16, 1000]))), "f": lit_f64(2.5), "u": lit_u64(int(rng.choice([3, 64, 1000])))}[want]
+        return binop(_random_tree(rng, depth - 1, want), Operator.Divide if rng.random() < 0.5 else Operator.Modulos, div)
+    return binop(_random_tree(rng, depth - 1, want), op, _random_tree(rng, depth - 1, want))
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.25])
+def test_random_expression_trees_fused_and_deep(ctx, null_frac):
+    """trees with >= 2 binary nodes run in the single-pass stack machine (depth <= 4, <= 24 nodes); deeper ones node-at-a-time"""
+    rng = np.random.default_rng(77 + int(null_frac * 100))
+    cols = random_batch(rng, 3000, null_frac, with_bool=True)
+    t = ctx.table_from_host(cols)
+    n_checked = 0
+    for trial in range(120):
+        e = _random_tree(rng, int(rng.integers(1, 6)), str(rng.choice(["i", "f", "u", "b"])))
+        nodes = flat(e)
+        try:
+            exp = orc.expr_evaluate([cols], nodes)
+        except ErrorCode as err:
+            with pytest.raises(ErrorCode) as g:
+                ctx.expr_evaluate(t, nodes)
+            assert g.value.status == err.status, repr(e)
+            continue
+        assert_column_equal(ctx.expr_evaluate(t, nodes).to_host()[0], exp, what=repr(e))
+        n_checked += 1
+    assert n_checked > 60
+    # the same trees as predicates / projections inside the fused operators
+    pred = binop(binop(binop(col(1), Operator.Plus, col(0)), Operator.Modulos, lit_i64(5)), Operator.Lt, binop(col(1), Operator.Multiply, lit_i64(2)))
+    proj = [binop(binop(col(2), Operator.Multiply, col(2)), Operator.Plus, binop(col(2), Operator.Divide, lit_f64(4.0))), col(3)]
+    sel = orc.selection([cols], flat(pred))
+    exp = orc.projection(sel, [flat(x) for x in proj])[0]
+    assert_batches_equal(ctx.selection_projection(t, flat(pred), [flat(x) for x in proj]).to_host(), exp, what="tree predicate + tree projection")
+    aggs = ALL_AGGS(2)
+    expa = orc.aggregate([cols], aggs, group_nodes=flat(binop(binop(col(1), Operator.Plus, lit_i64(3)), Operator.Multiply, binop(col(1), Operator.Minus, lit_i64(1)))), pred_nodes=flat(pred))[0]
+    gota = ctx.aggregate(t, aggs, group_nodes=flat(binop(binop(col(1), Operator.Plus, lit_i64(3)), Operator.Multiply, binop(col(1), Operator.Minus, lit_i64(1)))), pred_nodes=flat(pred))
+    assert_rows_multiset_equal(gota.to_host(), expa, RTOL, exact_cols=[0], what="tree key + tree predicate aggregate")
+
+
 def test_expression_errors(ctx):
     cols = [Column.from_list([1, 0, 3], DType.INT64), Column.from_list([1.0, 0.0, None], DType.FLOAT64),
             Column.from_list([True, None, False], DType.BOOLEAN)]

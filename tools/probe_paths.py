@@ -53,7 +53,7 @@ print(f"upload {n} rows x 2 cols ({1.6:.1f} GB, pageable numpy): {up*1e3:.1f} ms
 del t
 
 # ---- 2. nullable columns (1% nulls) → general kernel
-n = 200_000_000 if SECTION in ('all', 'paths', 'keys') else 100_000_000
+n = 200_000_000 if SECTION in ('all', 'paths', 'keys', 'exprs') else 100_000_000
 idt = torch.empty(n, dtype=torch.int64, device=dev); ctx.synchronize()
 ctx.synth_fill(0, 0, 0, n, 1, 0, idt.data_ptr())
 vt = torch.empty(n, dtype=torch.float64, device=dev)
@@ -83,6 +83,27 @@ if SECTION in ("all", "paths"):
     print(f"aggregate {n} rows [key (id+1) % 1000, out-of-line divide]: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
     q = timeit(lambda: ctx.aggregate(plain, aggs, pred_nodes=pred))
     print(f"un-grouped aggregate {n} rows: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
+
+# ---- 2b. expression trees: single-pass stack machine vs algorithmic bytes
+if SECTION in ("all", "exprs"):
+    from naive_query_engine_amd.expression import lit_f64
+    cases = [("v*v + v/4 (2 reads? no: 1 col, 1 write)", binop(binop(col(1), Operator.Multiply, col(1)), Operator.Plus, binop(col(1), Operator.Divide, lit_f64(4.0))), 16),
+             ("(id + 1) * (id - 1)", binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Multiply, binop(col(0), Operator.Minus, lit_i64(1))), 16),
+             ("(id % 1000) * 3 + id / 7", binop(binop(binop(col(0), Operator.Modulos, lit_i64(1000)), Operator.Multiply, lit_i64(3)), Operator.Plus, binop(col(0), Operator.Divide, lit_i64(7))), 16),
+             ("v > 50 and id % 3 == 0 (bool out)", binop(binop(col(1), Operator.Gt, lit_f64(50.0)), Operator.And, binop(binop(col(0), Operator.Modulos, lit_i64(3)), Operator.Eq, lit_i64(0))), 16.125),
+             ("id + 1 (single node)", binop(col(0), Operator.Plus, lit_i64(1)), 16),
+             ("id+1+1 (2 ops)", binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Plus, lit_i64(1)), 16),
+             ("id+1+1+1+1 (4 ops)", binop(binop(binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Plus, lit_i64(1)), Operator.Plus, lit_i64(1)), Operator.Plus, lit_i64(1)), 16),
+             ("8 ops chain", __import__("functools").reduce(lambda a, _: binop(a, Operator.Plus, lit_i64(1)), range(8), col(0)), 16),
+             ("id + v? no: id + id (2 pushes col)", binop(binop(col(0), Operator.Plus, col(0)), Operator.Plus, col(0)), 16)]
+    for name, e, bpr in cases:
+        q = timeit(lambda: ctx.expr_evaluate(plain, e.flatten(f)))
+        print(f"expr {name}: {n} rows {q*1e3:.3f} ms = {bpr*n/q/1e9:.0f} GB/s algorithmic")
+    tp = binop(binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(10)), Operator.Lt, lit_i64(5))
+    q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=key, pred_nodes=tp.flatten(f)))
+    print(f"aggregate with tree predicate ((id+1)%10 < 5): {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
+    q = timeit(lambda: ctx.selection_projection(plain, tp.flatten(f), [cases[0][1].flatten(f), col(0).flatten(f)]))
+    print(f"selection(tree pred)+projection(tree, id): {q*1e3:.3f} ms = {(16*n + 8*n)/q/1e9:.0f} GB/s algorithmic (50% pass)")
 
 # ---- 3. high-cardinality group-by
 for groups in ((1 << 10, 1 << 12, 1 << 14, 1 << 17, 1 << 20, 1 << 24) if SECTION in ('all', 'groups') else ()):
