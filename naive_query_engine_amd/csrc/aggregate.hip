@@ -436,12 +436,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             row = row < last ? row : last; // clamp: unconditional, in-bounds
             if (NT) {
                 t.kw[u] = __builtin_nontemporal_load(&keyp[row]);
-                if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row]);
+                if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
             } else {
                 t.kw[u] = keyp[row];
-                if (PRED == 2) t.pw[u] = predp[row];
+                if (PRED == 2) t.pw[u] = predp[row >> fp.row_shift];
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = valp[j][row];
             }
@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = row < n;
             if (PRED != 0) {
-                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : t.pw[u]);
+                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             }
             uint64_t key;
             if (KEY == 0) key = t.kw[u];
@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_kernel(AggArgs a, Fas
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             row = row < last ? row : last;
             kw[u] = __builtin_nontemporal_load(&keyp[row]);
-            if (PRED == 2) pw[u] = __builtin_nontemporal_load(&predp[row]);
+            if (PRED == 2) pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
             if (SCATTER) {
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_kernel(AggArgs a, Fas
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = row < hi;
-            if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? kw[u] : pw[u]);
+            if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? kw[u] : pred_extract(fp, pw[u], row));
             uint64_t key;
             if (KEY == 0) key = kw[u];
             else {
@@ -649,7 +649,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_scatter_kernel(AggArg
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             int64_t rc = row < last ? row : last;
             uint64_t kw = __builtin_nontemporal_load(&keyp[rc]);
-            uint64_t pw = PRED == 2 ? __builtin_nontemporal_load(&predp[rc]) : kw;
+            uint64_t pw = PRED == 2 ? pred_extract(fp, __builtin_nontemporal_load(&predp[rc >> fp.row_shift]), rc) : kw;
 #pragma unroll
             for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][rc]);
             bool ok = row < hi;
@@ -1104,7 +1104,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_fast_kernel(AggArgs a
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             row = row < last ? row : last;
-            if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row]);
+            if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
 #pragma unroll
             for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
         }
@@ -1114,7 +1114,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_fast_kernel(AggArgs a
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = row < n;
-            if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? t.vw[0][u] : t.pw[u]);
+            if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? t.vw[0][u] : pred_extract(fp, t.pw[u], row));
             if (!pass) continue;
 #pragma unroll
             for (int j = 0; j < NVT; ++j) {
@@ -1600,12 +1600,18 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     else if (a.key.aux[0].more >= 0) fast_key = 2; // `col % d`, d not a power of two: magic multiply
                 }
                 bool plain = is_word_type(a.key_src.dtype) && !a.key_src.valid;
-                if (a.pred_mode == 1) plain = plain && is_word_type(a.pred_src.dtype) && !a.pred_src.valid;
+                // a Boolean predicate column without nulls (a Boolean input column, or any predicate tree evaluated by the
+                // expression machine) is tested by the same variants as a separate integer predicate column: the word of a
+                // row is its bit
+                const bool bitmap_pred = a.pred_src.dtype == NQE_BOOLEAN && !a.pred_src.valid &&
+                                         (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
+                if (a.pred_mode == 1 && !bitmap_pred) plain = plain && is_word_type(a.pred_src.dtype) && !a.pred_src.valid;
                 for (int j = 0; j < a.nv; ++j) plain = plain && a.val[j].values && !a.val[j].valid;
                 FastPred fpred{};
-                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || (pk == 1 && make_fast_pred(a.pred, &fpred)));
+                if (bitmap_pred) fpred = bitmap_fast_pred();
+                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || bitmap_pred || (pk == 1 && make_fast_pred(a.pred, &fpred)));
                 if (fast) {
-                    int fp = pk == 0 ? 0 : (a.pred_shares_key ? 1 : 2);
+                    int fp = pk == 0 ? 0 : ((a.pred_shares_key && !bitmap_pred) ? 1 : 2);
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
                     if (partition_mode) {
@@ -1685,10 +1691,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 FastPred ufp{};
                 bool uplain = a.nv >= 1;
                 for (int j = 0; j < a.nv; ++j) uplain = uplain && a.val[j].values && !a.val[j].valid;
-                bool upred_ok = a.pred_mode == 0 ||
+                const bool ubitmap = a.pred_src.dtype == NQE_BOOLEAN && !a.pred_src.valid && (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
+                if (ubitmap) ufp = bitmap_fast_pred();
+                bool upred_ok = a.pred_mode == 0 || ubitmap ||
                                 (a.pred_mode == 1 && is_word_type(a.pred_src.dtype) && !a.pred_src.valid && make_fast_pred(a.pred, &ufp));
                 if (uplain && upred_ok) {
-                    int up = a.pred_mode == 0 ? 0 : (a.pred_src.values == a.val[0].values ? 1 : 2);
+                    int up = a.pred_mode == 0 ? 0 : ((a.pred_src.values == a.val[0].values && !ubitmap) ? 1 : 2);
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
                     launch(ctx, "agg_ungrouped_fast", pick_ungrouped_fast(up, a.nv, vf64), dim3(grid), dim3(AGG_BLOCK), 0, a, ufp,

@@ -194,6 +194,11 @@ __device__ __forceinline__ bool range_pass(const FastPred &fp, uint64_t x) {
     return ((xs >= fp.lo) && (xs <= fp.hi)) != (fp.negate != 0);
 }
 
+// the word a FastPred tests for row `row`, from the loaded source word (a word column's element or a bitmap word)
+__device__ __forceinline__ uint64_t pred_extract(const FastPred &fp, uint64_t w, int64_t row) {
+    return (w >> (int(row) & fp.bit_mask)) & fp.val_mask;
+}
+
 // wave-level exclusive prefix sum of a 32-bit value (wave64, DPP-free shuffle version)
 __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t &total) {
     uint32_t x = v;

@@ -270,129 +270,137 @@ __device__ __forceinline__ void ex_combine(const ExInstr &in, uint64_t &a, bool 
     }
 }
 
-__global__ void __launch_bounds__(256) expr_tree_kernel(ExProgram P, int64_t n, uint64_t *out_words, uint64_t *out_bits, uint64_t *out_valid,
-                                                        int *flags) {
+// Loads the EX_ROWS rows a lane owns (row0 + r*64) of every program column; `inm` = rows that exist / are wanted.
+// NULLS = false: no column has a validity bitmap and no literal is NULL, so every mask equals `inm` and none is computed
+// (the kernel is VALU-issue bound once the program has a few instructions; mask bookkeeping is ~40% of it).
+template <bool NULLS, int NC>
+__device__ __forceinline__ void ex_load(const ExProgram &P, int64_t row0, int64_t n, uint32_t inm, uint64_t (&cw)[NC][EX_ROWS], uint32_t (&cvm)[NC]) {
     constexpr int R = EX_ROWS;
-    const int lane = lane_id();
-    const int64_t n_chunks = (n + 64 * R - 1) / (64 * R);
-    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, n_waves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
-        const int64_t row0 = chunk * (64 * R) + lane;
-        // ---- issue every load of the chunk (rows clamped to n-1 so that no load is predicated), then consume
-        uint64_t cw[EX_MAX_COLS][R];
-        uint32_t vbyte[EX_MAX_COLS][R];
+    // issue every load of the chunk (rows clamped to n-1 so that no load is predicated), then consume
+    int64_t rc[R];
 #pragma unroll
-        for (int c = 0; c < EX_MAX_COLS; ++c) {
+    for (int r = 0; r < R; ++r) rc[r] = min(row0 + r * 64, n - 1);
+    uint32_t vbyte[NC][R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) { cw[c][r] = 0; vbyte[c][r] = 0xffu; }
-            if (c < P.ncols) {
-                if (P.col_dtype[c] == NQE_BOOLEAN) {
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) cw[c][r] = static_cast<const uint8_t *>(P.col_values[c])[min(row0 + r * 64, n - 1) >> 3];
-                } else {
+        for (int r = 0; r < R; ++r) { cw[c][r] = 0; vbyte[c][r] = 0xffu; }
+        if (c < P.ncols) {
+            if (P.col_dtype[c] == NQE_BOOLEAN) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        cw[c][r] = __builtin_nontemporal_load(static_cast<const uint64_t *>(P.col_values[c]) + min(row0 + r * 64, n - 1));
-                }
-                if (P.col_valid[c]) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) vbyte[c][r] = P.col_valid[c][min(row0 + r * 64, n - 1) >> 3];
-                }
-            }
-        }
-        uint32_t inm = 0, cvm[EX_MAX_COLS]; // one bit per owned row
-#pragma unroll
-        for (int r = 0; r < R; ++r) inm |= (row0 + r * 64 < n ? 1u : 0u) << r;
-#pragma unroll
-        for (int c = 0; c < EX_MAX_COLS; ++c) {
-            cvm[c] = 0;
-            const bool isb = c < P.ncols && P.col_dtype[c] == NQE_BOOLEAN;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int sh = int(min(row0 + r * 64, n - 1) & 7);
-                if (isb) cw[c][r] = (cw[c][r] >> sh) & 1ull;
-                cvm[c] |= ((vbyte[c][r] >> sh) & 1u) << r;
-            }
-            cvm[c] &= inm;
-        }
-        // ---- run the program
-        uint64_t s[EX_MAX_DEPTH][R];
-        uint32_t vm[EX_MAX_DEPTH];
-#pragma unroll
-        for (int d = 0; d < EX_MAX_DEPTH; ++d) {
-            vm[d] = 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) s[d][r] = 0;
-        }
-        ExInstr cur = P.ins[0];
-        for (int pc = 0; pc < P.n; ++pc) {
-            const ExInstr nxt = P.ins[pc + 1 < P.n ? pc + 1 : pc]; // in flight while `cur` executes
-            const bool a_st = cur.a_src == EX_STACK, b_st = cur.b_src == EX_STACK;
-            const int ac = cur.a_src - EX_COL, bc = cur.b_src - EX_COL;
-            // Operand fetch and stack update are wave-uniform BRANCHES around plain register moves: a select costs VALU
-            // issue slots per row, a scalar branch does not, and the budget to stay HBM-bound is ~130 VALU instructions per
-            // 64 rows for the whole program.  Everything is copied by value with constant indices (a conditional over array
-            // lvalues would turn the stack into a dynamically indexed private array, i.e. scratch memory).
-            uint64_t a[R], b[R];
-            uint32_t am, bm;
-            if (a_st) {
-                if (b_st) {
-                    am = vm[1];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) a[r] = s[1][r];
-                } else {
-                    am = vm[0];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) a[r] = s[0][r];
-                }
-            } else if (ac < 0) {
-                am = cur.a_src == EX_LIT ? inm : 0u;
-#pragma unroll
-                for (int r = 0; r < R; ++r) a[r] = cur.lit_a;
-            } else if (ac == 0) {
-                am = cvm[0];
-#pragma unroll
-                for (int r = 0; r < R; ++r) a[r] = cw[0][r];
-            } else if (ac == 1) {
-                am = cvm[1];
-#pragma unroll
-                for (int r = 0; r < R; ++r) a[r] = cw[1][r];
-            } else if (ac == 2) {
-                am = cvm[2];
-#pragma unroll
-                for (int r = 0; r < R; ++r) a[r] = cw[2][r];
+                for (int r = 0; r < R; ++r) cw[c][r] = static_cast<const uint8_t *>(P.col_values[c])[rc[r] >> 3];
             } else {
-                am = cvm[3];
 #pragma unroll
-                for (int r = 0; r < R; ++r) a[r] = cw[3][r];
+                for (int r = 0; r < R; ++r) cw[c][r] = __builtin_nontemporal_load(static_cast<const uint64_t *>(P.col_values[c]) + rc[r]);
             }
+            if (NULLS && P.col_valid[c]) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) vbyte[c][r] = P.col_valid[c][rc[r] >> 3];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        cvm[c] = inm;
+        if (c < P.ncols) {
+            if (P.col_dtype[c] == NQE_BOOLEAN) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) cw[c][r] = (cw[c][r] >> (int(rc[r]) & 7)) & 1ull;
+            }
+            if (NULLS && P.col_valid[c]) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) m |= ((vbyte[c][r] >> (int(rc[r]) & 7)) & 1u) << r;
+                cvm[c] = m & inm;
+            }
+        }
+    }
+}
+
+// Runs the program on the loaded rows; the result words are left in res[], the returned mask holds their validity.
+template <bool NULLS, int NC>
+__device__ __forceinline__ uint32_t ex_run(const ExProgram &P, const uint64_t (&cw)[NC][EX_ROWS], const uint32_t (&cvm)[NC],
+                                           uint32_t inm, uint64_t (&res)[EX_ROWS], int *flags) {
+    constexpr int R = EX_ROWS;
+    // ---- run the program
+    uint64_t s[EX_MAX_DEPTH][R];
+    uint32_t vm[EX_MAX_DEPTH];
+#pragma unroll
+    for (int d = 0; d < EX_MAX_DEPTH; ++d) {
+        vm[d] = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[d][r] = 0;
+    }
+    ExInstr cur = P.ins[0];
+    for (int pc = 0; pc < P.n; ++pc) {
+        const ExInstr nxt = P.ins[pc + 1 < P.n ? pc + 1 : pc]; // in flight while `cur` executes
+        const bool a_st = cur.a_src == EX_STACK, b_st = cur.b_src == EX_STACK;
+        const int ac = cur.a_src - EX_COL, bc = cur.b_src - EX_COL;
+        // Operand fetch and stack update are wave-uniform BRANCHES around plain register moves: a select costs VALU
+        // issue slots per row, a scalar branch does not, and the budget to stay HBM-bound is ~130 VALU instructions per
+        // 64 rows for the whole program.  Everything is copied by value with constant indices (a conditional over array
+        // lvalues would turn the stack into a dynamically indexed private array, i.e. scratch memory).
+        uint64_t a[R], b[R];
+        uint32_t am, bm;
+        if (a_st) {
             if (b_st) {
-                bm = vm[0];
+                am = vm[1];
 #pragma unroll
-                for (int r = 0; r < R; ++r) b[r] = s[0][r];
-            } else if (bc < 0) {
-                bm = cur.b_src == EX_LIT ? inm : 0u;
-#pragma unroll
-                for (int r = 0; r < R; ++r) b[r] = cur.lit_b;
-            } else if (bc == 0) {
-                bm = cvm[0];
-#pragma unroll
-                for (int r = 0; r < R; ++r) b[r] = cw[0][r];
-            } else if (bc == 1) {
-                bm = cvm[1];
-#pragma unroll
-                for (int r = 0; r < R; ++r) b[r] = cw[1][r];
-            } else if (bc == 2) {
-                bm = cvm[2];
-#pragma unroll
-                for (int r = 0; r < R; ++r) b[r] = cw[2][r];
+                for (int r = 0; r < R; ++r) a[r] = s[1][r];
             } else {
-                bm = cvm[3];
+                am = vm[0];
 #pragma unroll
-                for (int r = 0; r < R; ++r) b[r] = cw[3][r];
+                for (int r = 0; r < R; ++r) a[r] = s[0][r];
             }
-            uint32_t m;
-            if (cur.op == NQE_OP_AND || cur.op == NQE_OP_OR) { // and_kleene / or_kleene
+        } else if (ac < 0) {
+            am = cur.a_src == EX_LIT ? inm : 0u;
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = cur.lit_a;
+        } else if (ac == 0) {
+            am = cvm[0];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = cw[0][r];
+        } else if (NC <= 2 || ac == 1) {
+            am = cvm[1];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = cw[1][r];
+        } else if (ac == 2) {
+            am = cvm[NC > 2 ? 2 : 0];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = cw[NC > 2 ? 2 : 0][r];
+        } else {
+            am = cvm[NC > 2 ? 3 : 0];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = cw[NC > 2 ? 3 : 0][r];
+        }
+        if (b_st) {
+            bm = vm[0];
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r] = s[0][r];
+        } else if (bc < 0) {
+            bm = cur.b_src == EX_LIT ? inm : 0u;
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r] = cur.lit_b;
+        } else if (bc == 0) {
+            bm = cvm[0];
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r] = cw[0][r];
+        } else if (NC <= 2 || bc == 1) {
+            bm = cvm[1];
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r] = cw[1][r];
+        } else if (bc == 2) {
+            bm = cvm[NC > 2 ? 2 : 0];
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r] = cw[NC > 2 ? 2 : 0][r];
+        } else {
+            bm = cvm[NC > 2 ? 3 : 0];
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r] = cw[NC > 2 ? 3 : 0][r];
+        }
+        uint32_t m;
+        if (cur.op == NQE_OP_AND || cur.op == NQE_OP_OR) {
+            if (NULLS) { // and_kleene / or_kleene
                 m = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -401,42 +409,122 @@ __global__ void __launch_bounds__(256) expr_tree_kernel(ExProgram P, int64_t n, 
                     m |= (av ? 1u : 0u) << r;
                 }
             } else {
-                m = am & bm;
-                // one uniform op/dtype decision per instruction (not per row): the body is instantiated with constants
-                dispatch_binary(cur.op, cur.dt, [&](auto tag) {
+                m = inm;
+                if (cur.op == NQE_OP_AND) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) a[r] = apply_binary(tag.op, tag.dt, a[r], b[r], cur.aux, (m >> r) & 1u, flags);
-                });
+                    for (int r = 0; r < R; ++r) a[r] &= b[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) a[r] |= b[r];
+                }
             }
-            if (a_st && b_st) { // pop 2, push 1
-                vm[1] = vm[2];
+        } else {
+            m = NULLS ? (am & bm) : inm;
+            // one uniform op/dtype decision per instruction (not per row): the body is instantiated with constants
+            dispatch_binary(cur.op, cur.dt, [&](auto tag) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) s[1][r] = s[2][r];
-            } else if (!a_st && !b_st) { // push
-                vm[2] = vm[1];
-                vm[1] = vm[0];
-#pragma unroll
-                for (int r = 0; r < R; ++r) { s[2][r] = s[1][r]; s[1][r] = s[0][r]; }
-            }
-            vm[0] = m;
-#pragma unroll
-            for (int r = 0; r < R; ++r) s[0][r] = a[r];
-            cur = nxt;
+                for (int r = 0; r < R; ++r) a[r] = apply_binary(tag.op, tag.dt, a[r], b[r], cur.aux, (m >> r) & 1u, flags);
+            });
         }
+        if (a_st && b_st) { // pop 2, push 1
+            vm[1] = vm[2];
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[1][r] = s[2][r];
+        } else if (!a_st && !b_st) { // push
+            vm[2] = vm[1];
+            vm[1] = vm[0];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { s[2][r] = s[1][r]; s[1][r] = s[0][r]; }
+        }
+        vm[0] = m;
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[0][r] = a[r];
+        cur = nxt;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) res[r] = s[0][r];
+    return vm[0];
+}
+
+template <bool NULLS, int NC>
+__global__ void __launch_bounds__(256) expr_tree_kernel(ExProgram P, int64_t n, uint64_t *out_words, uint64_t *out_bits, uint64_t *out_valid,
+                                                        int *flags) {
+    constexpr int R = EX_ROWS;
+    const int lane = lane_id();
+    const int64_t n_chunks = (n + 64 * R - 1) / (64 * R);
+    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, n_waves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        const int64_t row0 = chunk * (64 * R) + lane;
+        uint32_t inm = 0; // one bit per owned row
+#pragma unroll
+        for (int r = 0; r < R; ++r) inm |= (row0 + r * 64 < n ? 1u : 0u) << r;
+        uint64_t cw[NC][R], res[R];
+        uint32_t cvm[NC];
+        ex_load<NULLS, NC>(P, row0, n, inm, cw, cvm);
+        const uint32_t vm = ex_run<NULLS, NC>(P, cw, cvm, inm, res, flags);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t row = row0 + r * 64;
-            const bool ok = (vm[0] >> r) & 1u;
+            const bool ok = (vm >> r) & 1u;
             if (row - lane >= n) break; // wave-uniform: this 64-row word is past the end
             if (out_words) {
-                if (row < n) __builtin_nontemporal_store(ok ? s[0][r] : 0ull, out_words + row);
+                if (row < n) __builtin_nontemporal_store(ok ? res[r] : 0ull, out_words + row);
             } else {
-                uint64_t w = __ballot(ok && s[0][r]);
+                uint64_t w = __ballot(ok && res[r]);
                 if (lane == 0) out_bits[row >> 6] = w;
             }
             if (out_valid) {
                 uint64_t w = __ballot(ok);
                 if (lane == 0) out_valid[row >> 6] = w;
+            }
+        }
+    }
+}
+
+// The same machine behind a selection: one wave per 4096-row tile of the keep bitmap (word k of the tile in lane k, as in
+// compact_kernel); only the rows the filter emits are evaluated as valid (a dropped row can never raise DivideByZero,
+// as in the reference where the projection runs on the filtered batch), 256-row chunks without any kept row are not even
+// loaded, and results go straight to their compacted position.  A NULL predicate emits a NULL row (quirk Q4).
+template <bool NULLS, int NC>
+__global__ void __launch_bounds__(256) expr_tree_compact_kernel(ExProgram P, const uint64_t *keep, const uint64_t *pvalid,
+                                                                const uint64_t *tile_offsets, int64_t n, int64_t ntiles, uint64_t *out_words,
+                                                                uint8_t *out_bool_bytes, uint8_t *out_valid_bytes, int *flags) {
+    constexpr int R = EX_ROWS;
+    const int lane = lane_id();
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t nwords = (n + 63) / 64;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles; tile += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t w = tile * TILE_WORDS + lane;
+        const uint64_t my_word = w < nwords ? keep[w] : 0;
+        const uint64_t my_pv = (pvalid && w < nwords) ? pvalid[w] : ~0ull;
+        uint32_t tot;
+        const uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+        if (tot == 0) continue;
+        const uint64_t base = tile_offsets[tile];
+        for (int k0 = 0; k0 < TILE_WORDS; k0 += R) {
+            uint64_t kw[R];
+            uint32_t inm = 0, anyk = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                kw[r] = bcast64(my_word, k0 + r);
+                anyk |= kw[r] != 0 ? 1u : 0u;
+                inm |= uint32_t(((kw[r] & bcast64(my_pv, k0 + r)) >> lane) & 1ull) << r;
+            }
+            if (!anyk) continue; // wave-uniform
+            const int64_t row0 = (tile * TILE_WORDS + k0) * 64 + lane;
+            uint64_t cw[NC][R], res[R];
+            uint32_t cvm[NC];
+            ex_load<NULLS, NC>(P, row0, n, inm, cw, cvm);
+            const uint32_t vm = ex_run<NULLS, NC>(P, cw, cvm, inm, res, flags);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if ((kw[r] >> lane) & 1ull) {
+                    const bool ok = (vm >> r) & 1u;
+                    const uint64_t pos = base + bcast32(my_off, k0 + r) + __popcll(kw[r] & lanemask_lt());
+                    if (out_words) __builtin_nontemporal_store(ok ? res[r] : 0ull, out_words + pos);
+                    if (out_bool_bytes) out_bool_bytes[pos] = (ok && res[r]) ? 1 : 0;
+                    if (out_valid_bytes) out_valid_bytes[pos] = ok ? 1 : 0;
+                }
             }
         }
     }
@@ -586,6 +674,9 @@ bool make_fast_pred(const SimpleExpr &pe, FastPred *fp) {
     const int64_t MIN = INT64_MIN, MAX = INT64_MAX;
     fp->negate = 0;
     fp->pad = 0;
+    fp->row_shift = 0;
+    fp->bit_mask = 0;
+    fp->val_mask = ~0ull;
     switch (op) {
     case NQE_OP_EQ: fp->lo = L; fp->hi = L; break;
     case NQE_OP_NOT_EQ: fp->lo = L; fp->hi = L; fp->negate = 1; break;
@@ -595,6 +686,15 @@ bool make_fast_pred(const SimpleExpr &pe, FastPred *fp) {
     default: fp->lo = L; fp->hi = MAX; break;
     }
     return true;
+}
+
+FastPred bitmap_fast_pred() {
+    FastPred fp{};
+    fp.lo = fp.hi = 1;
+    fp.row_shift = 6;
+    fp.bit_mask = 63;
+    fp.val_mask = 1;
+    return fp;
 }
 
 ExprInfo analyze_expr(const nqe_table *in, const nqe_expr_node *nodes, int n) {
@@ -616,15 +716,54 @@ DevColumn evaluate_expr(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         const int odt = t[size_t(root)].out_dtype;
         const bool bool_out = odt == NQE_BOOLEAN;
         DevColumn out = bool_out ? make_bool_column(ctx, rows, needs_valid) : make_word_column(ctx, odt, rows, needs_valid);
-        if (rows)
-            launch(ctx, "expr_tree", expr_tree_kernel, dim3(stream_grid(ctx, (rows + EX_ROWS - 1) / EX_ROWS, 256)), dim3(256), 0, P, rows,
-                   bool_out ? nullptr : (uint64_t *)out.values->ptr, bool_out ? (uint64_t *)out.values->ptr : nullptr,
-                   needs_valid ? (uint64_t *)out.validity->ptr : nullptr, ctx->d_flags);
+        if (rows) {
+            dim3 grid(stream_grid(ctx, (rows + EX_ROWS - 1) / EX_ROWS, 256));
+            uint64_t *ow = bool_out ? nullptr : (uint64_t *)out.values->ptr, *ob = bool_out ? (uint64_t *)out.values->ptr : nullptr;
+            uint64_t *ov = needs_valid ? (uint64_t *)out.validity->ptr : nullptr;
+            // instantiated per (nullable, <=2 / <=4 columns): the column registers of a lane are the largest block of VGPRs
+#define NQE_TREE(NU, NC) launch(ctx, "expr_tree", expr_tree_kernel<NU, NC>, grid, dim3(256), 0, P, rows, ow, ob, ov, ctx->d_flags)
+            if (needs_valid) { if (P.ncols <= 2) NQE_TREE(true, 2); else NQE_TREE(true, 4); }
+            else { if (P.ncols <= 2) NQE_TREE(false, 2); else NQE_TREE(false, 4); }
+#undef NQE_TREE
+        }
         return out;
     }
     Value v = eval_node(ctx, in, t, root);
     if (v.is_lit) return materialise_literal(ctx, v.dtype, v.lit, v.lit_null, in->rows);
     return v.col;
+}
+
+// `e` over the rows a selection emits, written compacted (one pass over the referenced columns).  Returns false when the
+// tree does not fit the stack machine (caller: compact the inputs, then evaluate_expr).
+bool evaluate_expr_compacted(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, int n, const KeepMask &km, DevColumn *result) {
+    int root;
+    std::vector<Node> t = parse(in, nodes, n, &root);
+    ExProgram P;
+    bool needs_valid = false;
+    if (t[size_t(root)].kind != NQE_EXPR_BINARY || !build_program(in, t, root, &P, &needs_valid)) return false;
+    needs_valid |= km.pvalid != nullptr;
+    const int64_t m = km.total;
+    const int odt = t[size_t(root)].out_dtype;
+    const bool bool_out = odt == NQE_BOOLEAN;
+    DevColumn out = bool_out ? make_bool_column(ctx, m, needs_valid) : make_word_column(ctx, odt, m, needs_valid);
+    BufRef bool_bytes, valid_bytes;
+    if (bool_out) bool_bytes = dev_alloc(ctx, size_t(m) + 8);
+    if (needs_valid) valid_bytes = dev_alloc(ctx, size_t(m) + 8);
+    if (km.ntiles && m > 0) {
+        dim3 grid(stream_grid(ctx, km.ntiles, 4));
+        const uint64_t *kp = (const uint64_t *)km.keep->ptr, *pv = km.pvalid ? (const uint64_t *)km.pvalid->ptr : nullptr;
+        const uint64_t *to = (const uint64_t *)km.tile_offsets->ptr;
+        uint64_t *ow = bool_out ? nullptr : (uint64_t *)out.values->ptr;
+        uint8_t *ob = bool_out ? (uint8_t *)bool_bytes->ptr : nullptr, *ov = needs_valid ? (uint8_t *)valid_bytes->ptr : nullptr;
+#define NQE_TREE(NU, NC) launch(ctx, "expr_tree_compact", expr_tree_compact_kernel<NU, NC>, grid, dim3(256), 0, P, kp, pv, to, km.n, km.ntiles, ow, ob, ov, ctx->d_flags)
+        if (needs_valid) { if (P.ncols <= 2) NQE_TREE(true, 2); else NQE_TREE(true, 4); }
+        else { if (P.ncols <= 2) NQE_TREE(false, 2); else NQE_TREE(false, 4); }
+#undef NQE_TREE
+    }
+    if (bool_out) pack_bytes_to_bits(ctx, (const uint8_t *)bool_bytes->ptr, m, (uint64_t *)out.values->ptr);
+    if (needs_valid) pack_bytes_to_bits(ctx, (const uint8_t *)valid_bytes->ptr, m, (uint64_t *)out.validity->ptr);
+    *result = out;
+    return true;
 }
 
 } // namespace nqe

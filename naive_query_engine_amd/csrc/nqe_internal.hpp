@@ -213,8 +213,14 @@ struct FastPred {
     int64_t lo, hi;
     uint64_t flip;
     int32_t negate;
+    // where the tested word of row r comes from: word column → src[r]; Boolean bitmap → (src[r >> 6] >> (r & 63)) & 1
+    int32_t row_shift; // 0 | 6
+    int32_t bit_mask;  // 0 | 63
     int32_t pad;
+    uint64_t val_mask; // ~0 | 1
 };
+// FastPred "bit r of a non-null Boolean bitmap is set"
+FastPred bitmap_fast_pred();
 // returns false when the SimpleExpr is not a single integer compare against a literal
 bool make_fast_pred(const SimpleExpr &pe, FastPred *fp);
 
@@ -249,6 +255,8 @@ DevColumn compact_column(nqe_ctx *ctx, const DevColumn &src, const KeepMask &km)
 DevColumn compact_gather_column(nqe_ctx *ctx, const DevColumn &src, const uint32_t *gidx, const KeepMask &km);
 // scans the per-tile counts into km.tile_offsets and reads back km.total
 KeepMask finish_mask(nqe_ctx *ctx, KeepMask km, BufRef tile_counts);
+// general tree `nodes` over the rows of `km`, compacted in the same pass; false = does not fit the stack machine
+bool evaluate_expr_compacted(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, int n, const KeepMask &km, DevColumn *result);
 // evaluates `e` over `in` and compacts the result in the same pass
 DevColumn compact_simple_expr(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &e, const KeepMask &km);
 

@@ -381,28 +381,30 @@ nqe_status nqe_selection_projection_execute(nqe_ctx *ctx, const nqe_table *in, c
     flags_reset(ctx);
     // type errors of the projection surface before any work, as they would at evaluate()
     std::vector<ExprInfo> infos;
-    bool all_simple = true;
-    for (int e = 0; e < num_exprs; ++e) {
-        infos.push_back(analyze_expr(in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e]));
-        all_simple &= infos.back().simple;
-    }
+    for (int e = 0; e < num_exprs; ++e) infos.push_back(analyze_expr(in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e]));
     KeepMask km = mask_for_predicate(ctx, in, pred, pred_nodes);
     auto t = std::make_unique<nqe_table>();
     t->ctx = ctx;
     t->rows = km.total;
-    if (all_simple) {
-        for (int e = 0; e < num_exprs; ++e) t->cols.push_back(compact_simple_expr(ctx, in, infos[size_t(e)].s, km));
-    } else {
-        // general shapes: compact every column, then evaluate on the compacted batch (so that
-        // rows the filter dropped can never raise DivideByZero, as in the reference)
-        nqe_table sel;
-        sel.ctx = ctx;
-        sel.rows = km.total;
-        for (auto &c : in->cols) {
-            sel.cols.push_back(compact_column(ctx, c, km));
+    // per expression: fused single-column shape → compact_expr; any tree that fits the stack machine → evaluated and
+    // compacted in one pass over the columns it references; otherwise compact the inputs once, then evaluate on the
+    // compacted batch.  In every case rows the filter dropped can never raise DivideByZero, as in the reference.
+    std::unique_ptr<nqe_table> sel;
+    for (int e = 0; e < num_exprs; ++e) {
+        const nqe_expr_node *en = nodes + expr_offsets[e];
+        const int nn = expr_offsets[e + 1] - expr_offsets[e];
+        DevColumn c;
+        if (infos[size_t(e)].simple) c = compact_simple_expr(ctx, in, infos[size_t(e)].s, km);
+        else if (!evaluate_expr_compacted(ctx, in, en, nn, km, &c)) {
+            if (!sel) {
+                sel = std::make_unique<nqe_table>();
+                sel->ctx = ctx;
+                sel->rows = km.total;
+                for (auto &ic : in->cols) sel->cols.push_back(compact_column(ctx, ic, km));
+            }
+            c = evaluate_expr(ctx, sel.get(), en, nn);
         }
-        for (int e = 0; e < num_exprs; ++e)
-            t->cols.push_back(evaluate_expr(ctx, &sel, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e]));
+        t->cols.push_back(std::move(c));
     }
     throw_on_flags(ctx);
     *out = t.release();

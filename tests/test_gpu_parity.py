@@ -263,6 +263,48 @@ def test_selection_projection_fused_equals_chained(ctx, null_frac):
         assert_batches_equal(got, exp, what="general projection")
 
 
+def test_tree_projection_under_selection_errors_only_on_kept_rows(ctx):
+    """two-column trees run fused with the compaction; a zero divisor in a dropped row must not raise (reference: projection sees the filtered batch)"""
+    rng = np.random.default_rng(31)
+    n = 20000
+    cols = random_batch(rng, n, 0.1, key_mod=5, with_bool=True)   # k in 0..4 with nulls
+    t = ctx.table_from_host(cols)
+    proj = [binop(binop(col(0), Operator.Divide, col(1)), Operator.Plus, col(0)), binop(col(0), Operator.Modulos, col(1)),
+            binop(binop(col(2), Operator.Lt, lit_f64(0.0)), Operator.Or, binop(col(0), Operator.Gt, col(1))), col(3)]
+    ok_pred = binop(col(1), Operator.NotEq, lit_i64(0))
+    sel = orc.selection([cols], flat(ok_pred))
+    exp = orc.projection(sel, [flat(e) for e in proj])[0]
+    assert_batches_equal(ctx.selection_projection(t, flat(ok_pred), [flat(e) for e in proj]).to_host(), exp, what="kept rows only")
+    bad_pred = binop(col(1), Operator.LtEq, lit_i64(2))   # keeps k == 0 rows
+    with pytest.raises(ErrorCode) as a:
+        orc.projection(orc.selection([cols], flat(bad_pred)), [flat(e) for e in proj])
+    with pytest.raises(ErrorCode) as b:
+        ctx.selection_projection(t, flat(bad_pred), [flat(e) for e in proj])
+    assert a.value.status == b.value.status
+    # nothing kept / everything kept
+    for pred in (binop(col(1), Operator.Gt, lit_i64(100)), binop(col(1), Operator.Gt, lit_i64(0))):
+        sel = orc.selection([cols], flat(pred))
+        exp = orc.projection(sel, [flat(e) for e in proj])[0]
+        assert_batches_equal(ctx.selection_projection(t, flat(pred), [flat(e) for e in proj]).to_host(), exp, what="edge selectivity")
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.15])
+def test_aggregate_with_boolean_and_tree_predicates(ctx, null_frac):
+    """non-null Boolean predicates (a Boolean column, or a tree evaluated to a bitmap) feed the fast kernels bit-wise"""
+    rng = np.random.default_rng(5 + int(null_frac * 100))
+    n = 300_000
+    cols = random_batch(rng, n, null_frac, key_mod=300, with_bool=True)
+    t = ctx.table_from_host(cols)
+    tree = binop(binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(10)), Operator.Lt, lit_i64(5))
+    both = binop(col(4), Operator.And, binop(col(2), Operator.Gt, lit_f64(-20.0)))
+    for pred in (col(4), tree, both):
+        for key in (col(1), binop(col(0), Operator.Modulos, lit_i64(64)), binop(col(0), Operator.Modulos, lit_i64(1000)), None):
+            aggs = ALL_AGGS(2) if key is not None else ALL_AGGS(2) + ALL_AGGS(3)
+            exp = orc.aggregate([cols], aggs, group_nodes=flat(key) if key is not None else None, pred_nodes=flat(pred))[0]
+            got = ctx.aggregate(t, aggs, group_nodes=flat(key) if key is not None else None, pred_nodes=flat(pred))
+            assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"pred {pred!r} key {key!r}")
+
+
 def test_projection_matches_oracle(ctx):
     rng = np.random.default_rng(9)
     cols = random_batch(rng, 5000, 0.1, with_bool=True)

@@ -104,6 +104,14 @@ if SECTION in ("all", "exprs"):
     print(f"aggregate with tree predicate ((id+1)%10 < 5): {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
     q = timeit(lambda: ctx.selection_projection(plain, tp.flatten(f), [cases[0][1].flatten(f), col(0).flatten(f)]))
     print(f"selection(tree pred)+projection(tree, id): {q*1e3:.3f} ms = {(16*n + 8*n)/q/1e9:.0f} GB/s algorithmic (50% pass)")
+    ctx.timing_enable(True); ctx.timing_reset()
+    r = ctx.selection_projection(plain, tp.flatten(f), [cases[0][1].flatten(f), col(0).flatten(f)]); del r
+    ctx.timing_enable(False)
+    print("   kernels(ms):", {k: round(ctx.timing_query(k)[0], 3) for k in ("expr_tree", "expr_tree_compact", "keep_from_pred", "scan_", "compact_column", "compact_expr", "pack_bytes")})
+    ctx.timing_enable(True); ctx.timing_reset()
+    r = ctx.aggregate(plain, aggs, group_nodes=key, pred_nodes=tp.flatten(f)); del r
+    ctx.timing_enable(False)
+    print("   agg kernels(ms):", {k: round(ctx.timing_query(k)[0], 3) for k in ("expr_tree", "agg_grouped_fast", "agg_grouped", "agg_table_init", "agg_collect", "agg_finalize")})
 
 # ---- 3. high-cardinality group-by
 for groups in ((1 << 10, 1 << 12, 1 << 14, 1 << 17, 1 << 20, 1 << 24) if SECTION in ('all', 'groups') else ()):
