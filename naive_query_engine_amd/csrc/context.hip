@@ -552,6 +552,31 @@ nqe_status nqe_ctx_timing_query(nqe_ctx *ctx, const char *name_substr, double *t
 }
 
 // ---------------------------------------------------------------- tables
+namespace {
+__global__ void __launch_bounds__(256) count_valid_kernel(const uint64_t *words, int64_t n_rows, unsigned long long *out) {
+    const int64_t nfull = n_rows / 64; // whole words; the tail is read byte-wise (a borrowed bitmap ends at ceil(n/8) bytes)
+    unsigned long long c = 0;
+    for (int64_t w = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; w < nfull; w += int64_t(gridDim.x) * blockDim.x)
+        c += (unsigned long long)__popcll(words[w]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint8_t *bytes = reinterpret_cast<const uint8_t *>(words + nfull);
+        for (int64_t r = 0; r < (n_rows & 63); ++r) c += (bytes[r >> 3] >> (r & 7)) & 1;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if (nqe::lane_id() == 0 && c) atomicAdd(out, c);
+}
+} // namespace
+
+// number of set bits among the first n_rows bits of a (word-padded) device bitmap
+static int64_t count_valid(nqe_ctx *ctx, const void *bitmap, int64_t n_rows) {
+    if (n_rows == 0) return 0;
+    BufRef cnt = dev_alloc_zero(ctx, 8);
+    launch(ctx, "count_valid", count_valid_kernel, dim3(stream_grid(ctx, n_rows / 64 + 1, 256)), dim3(256), 0, (const uint64_t *)bitmap, n_rows,
+           (unsigned long long *)cnt->ptr);
+    return int64_t(read_scalar(ctx, (const unsigned long long *)cnt->ptr));
+}
+
 nqe_status nqe_table_create(nqe_ctx *ctx, const nqe_column *columns, int32_t num_columns, nqe_table **out) {
     NQE_API_BEGIN(ctx)
     if (!ctx || !out || num_columns < 0 || (num_columns > 0 && !columns)) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
@@ -593,6 +618,13 @@ nqe_status nqe_table_create(nqe_ctx *ctx, const nqe_column *columns, int32_t num
                 if (c.data_length)
                     NQE_HIP_CHECK(hipMemcpyAsync(d.data->ptr, c.data, size_t(c.data_length), hipMemcpyHostToDevice, ctx->stream));
             }
+        }
+        // A bitmap that marks every row valid is dropped (null_count 0 from the caller, or counted here when unknown): such
+        // columns then take the kernels specialised for non-null inputs.  Arrow semantics are unchanged (an absent bitmap
+        // == all valid).
+        if (d.validity) {
+            if (d.null_count < 0) d.null_count = c.length - count_valid(ctx, d.validity->ptr, c.length);
+            if (d.null_count == 0) d.validity = nullptr;
         }
         t->cols.push_back(std::move(d));
     }

@@ -525,6 +525,27 @@ def test_hash_join_errors(ctx):
 
 
 # --------------------------------------------------------------------------- table utilities
+def test_all_valid_bitmaps_are_dropped_at_table_creation(ctx):
+    """a validity bitmap without a single null is dropped (counted on the device when null_count is unknown), so that
+    schema-nullable data still takes the kernels specialised for non-null columns; results are unchanged"""
+    rng = np.random.default_rng(12)
+    for n in (1, 63, 64, 1000, 70001):
+        allv = np.ones(n, dtype=bool)
+        last_null = allv.copy(); last_null[-1] = False
+        first_null = allv.copy(); first_null[0] = False
+        ids = rng.integers(0, 50, n).astype(np.int64)
+        v = rng.random(n)
+        cols = [Column.from_numpy(ids, allv), Column.from_numpy(v, last_null), Column.from_numpy(v, first_null), Column.from_numpy(v, allv)]
+        t = ctx.table_from_host(cols)
+        infos = [t.column_info(i) for i in range(4)]
+        assert not infos[0].validity and not infos[3].validity, n
+        assert infos[1].validity and infos[2].validity, n
+        assert [int(i.null_count) for i in infos] == [0, 1, 1, 0]
+        got = ctx.aggregate(t, ALL_AGGS(1) + ALL_AGGS(3), group_nodes=col(0).flatten(fields("k", "a", "b", "c")))
+        exp = orc.aggregate([cols], ALL_AGGS(1) + ALL_AGGS(3), group_nodes=col(0).flatten(fields("k", "a", "b", "c")))[0]
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0, 5], what=f"n={n}")
+
+
 def test_take_slice_concat_project(ctx):
     rng = np.random.default_rng(3)
     cols = random_batch(rng, 1000, 0.2, with_bool=True)
