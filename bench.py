@@ -61,8 +61,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = bool(os.environ.get("NQE_FORCE_EXCHANGE"))  # one rank, but through RCCL and the exchange path (diagnostics)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -99,7 +103,7 @@ def main():
         kernel_name = "agg_grouped"
 
         def step():
-            if world > 1:
+            if world > 1 or force_dist:
                 return sharded_aggregate(ctx, table, aggs, group_nodes=key, pred_nodes=pred)
             return ctx.aggregate(table, aggs, group_nodes=key, pred_nodes=pred)
 
@@ -136,7 +140,7 @@ def main():
         kernel_name = "join_probe+join_fused+compact_gather+compact_column"
 
         def step():
-            if world > 1 and args.gather:  # C5: ordered variable-length all-gather of the per-rank outputs over RCCL
+            if (world > 1 or force_dist) and args.gather:  # C5: ordered variable-length all-gather of the per-rank outputs over RCCL
                 return sharded_hash_join(ctx, dim, fact, 0, 0, gather=True, join_table=jt)
             return ctx.hash_join_probe(jt, fact, 0)
 
@@ -144,7 +148,7 @@ def main():
         desc = f"dim(id,attr) 10^6 rows (LEFT/build) join fact(key,val) {n} rows per GPU (RIGHT/probe), 1 match per probe row"
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
@@ -173,7 +177,7 @@ def main():
         b_ms, b_n = ctx.timing_query(kn)
         if b_n:
             breakdown[kn] = {"ms_per_step": b_ms / args.steps, "launches_per_step": b_n / args.steps}
-    if world > 1:
+    if world > 1 or force_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -201,7 +205,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload in ("headline", "c3", "c2"):
             out["cpu_baseline"] = cpu_baseline(args, n)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -196,6 +196,21 @@ nqe_status nqe_table_slice(nqe_ctx *ctx, const nqe_table *in, int64_t offset, in
  * NQE_ERR_INVALID_ARGUMENT here (the host mirror builds the empty batch itself). */
 nqe_status nqe_table_concat(nqe_ctx *ctx, const nqe_table *const *tables, int32_t n, nqe_table **out);
 
+/* ------------------------------------------------------------------ exchange plumbing (multi-GPU)
+ * No reference analogue (the reference is single-process).  A rank's partial aggregate (keys + state tables: 8-byte
+ * columns without validity) is packed into ONE device buffer so that the exchange is a single RCCL all-gather, and the
+ * gathered buffer is unpacked into one concatenated table for nqe_aggregate_merge.
+ *
+ * pack:   dst[c * stride_rows + r] = word r of column c (columns of `tables` in order, c over all tables);
+ *         dst[num_columns * stride_rows] = number of rows (the tables must agree) — the header the peers read.
+ *         Every table must have rows <= stride_rows; dst holds num_columns * stride_rows + 1 words.
+ * unpack: src = num_parts such buffers back to back; out column c = for p in 0..num_parts: src_p[c][0 .. counts[p]).
+ *         counts[p] is what the caller read from the headers (host memory). */
+nqe_status nqe_table_pack_words(nqe_ctx *ctx, const nqe_table *const *tables, int32_t num_tables, int64_t stride_rows,
+                                void *dst_device);
+nqe_status nqe_table_unpack_words(nqe_ctx *ctx, const void *src_device, int32_t num_parts, int32_t num_columns,
+                                  int64_t stride_rows, const int64_t *counts, const int32_t *dtypes, nqe_table **out);
+
 /* ------------------------------------------------------------------ expressions
  * PhysicalExpr::evaluate(batch).into_array() (expression/mod.rs:25-29, binary.rs:108-155,
  * datatype.rs:27-34): evaluates one expression over `in`, returns a 1-column table.

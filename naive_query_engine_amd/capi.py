@@ -23,7 +23,8 @@ SYMBOLS = [
     "nqe_abi_version", "nqe_ctx_create", "nqe_ctx_destroy", "nqe_ctx_synchronize", "nqe_last_error",
     "nqe_last_global_error", "nqe_ctx_timing_enable", "nqe_ctx_timing_query", "nqe_ctx_timing_reset",
     "nqe_table_create", "nqe_table_release", "nqe_table_num_rows", "nqe_table_num_columns", "nqe_table_column",
-    "nqe_table_download_column", "nqe_table_project", "nqe_table_slice", "nqe_table_concat", "nqe_expr_evaluate",
+    "nqe_table_download_column", "nqe_table_project", "nqe_table_slice", "nqe_table_concat", "nqe_table_pack_words",
+    "nqe_table_unpack_words", "nqe_expr_evaluate",
     "nqe_filter", "nqe_selection_execute", "nqe_projection_execute", "nqe_selection_projection_execute",
     "nqe_aggregate_execute", "nqe_aggregate_partial", "nqe_aggregate_merge", "nqe_hash_join_execute",
     "nqe_hash_join_build", "nqe_hash_join_probe", "nqe_join_table_release", "nqe_take", "nqe_synth_fill",
@@ -65,6 +66,8 @@ def lib():
         "nqe_table_project": (i32, [vp, vp, C.POINTER(i32), i32, pvp]),
         "nqe_table_slice": (i32, [vp, vp, i64, i64, pvp]),
         "nqe_table_concat": (i32, [vp, pvp, i32, pvp]),
+        "nqe_table_pack_words": (i32, [vp, pvp, i32, i64, vp]),
+        "nqe_table_unpack_words": (i32, [vp, vp, i32, i32, i64, C.POINTER(i64), C.POINTER(i32), pvp]),
         "nqe_expr_evaluate": (i32, [vp, vp, nodes, i32, pvp]),
         "nqe_filter": (i32, [vp, vp, vp, i32, pvp]),
         "nqe_selection_execute": (i32, [vp, vp, nodes, i32, pvp]),
@@ -273,6 +276,20 @@ class Context:
         arr = (C.c_void_p * max(1, len(tables)))(*[t.handle for t in tables])
         h = C.c_void_p()
         self.check(lib().nqe_table_concat(self.handle, arr, len(tables), C.byref(h)))
+        return Table(self, h)
+
+    # ---- exchange plumbing (multi-GPU)
+    def pack_words(self, tables: Sequence["Table"], stride_rows: int, dst_ptr: int) -> None:
+        """columns of `tables` → dst[c*stride + r]; dst[ncols*stride] = row count (header)"""
+        arr = (C.c_void_p * max(1, len(tables)))(*[t.handle for t in tables])
+        self.check(lib().nqe_table_pack_words(self.handle, arr, len(tables), stride_rows, C.c_void_p(dst_ptr)))
+
+    def unpack_words(self, src_ptr: int, counts: Sequence[int], dtypes: Sequence[DType], stride_rows: int) -> "Table":
+        """len(counts) packed buffers back to back → one table, parts concatenated per column"""
+        ca = (C.c_int64 * max(1, len(counts)))(*[int(c) for c in counts])
+        da = (C.c_int32 * max(1, len(dtypes)))(*[int(d) for d in dtypes])
+        h = C.c_void_p()
+        self.check(lib().nqe_table_unpack_words(self.handle, C.c_void_p(src_ptr), len(counts), len(dtypes), stride_rows, ca, da, C.byref(h)))
         return Table(self, h)
 
 

@@ -81,6 +81,16 @@ BufRef dev_borrow(nqe_ctx *ctx, const void *ptr, size_t bytes) {
     return b;
 }
 
+BufRef dev_view(const BufRef &parent, size_t offset, size_t bytes) {
+    DevBuf *v = new DevBuf();
+    v->ctx = parent->ctx;
+    v->ptr = static_cast<char *>(parent->ptr) + offset;
+    v->bytes = bytes;
+    v->capacity = bytes;
+    v->owned = false;
+    return BufRef(v, [parent](DevBuf *p) { delete p; });
+}
+
 DevBuf::~DevBuf() {
     if (owned && ptr && ctx) {
         // stream-ordered reuse: every consumer of this block was enqueued on ctx->stream before
@@ -553,6 +563,37 @@ nqe_status nqe_ctx_timing_query(nqe_ctx *ctx, const char *name_substr, double *t
 
 // ---------------------------------------------------------------- tables
 namespace {
+constexpr int PACK_MAX_COLS = 48, UNPACK_MAX_PARTS = 64;
+struct PackArgs {
+    const uint64_t *src[PACK_MAX_COLS];
+    int64_t rows, stride;
+    int32_t ncols, pad;
+};
+__global__ void __launch_bounds__(256) pack_words_kernel(PackArgs pa, uint64_t *dst) {
+    const int64_t total = pa.rows * pa.ncols;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int c = int(i / pa.rows);
+        const int64_t r = i - int64_t(c) * pa.rows;
+        dst[int64_t(c) * pa.stride + r] = pa.src[c][r];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) dst[int64_t(pa.ncols) * pa.stride] = uint64_t(pa.rows);
+}
+struct UnpackArgs {
+    int64_t offset[UNPACK_MAX_PARTS + 1]; // output row of part p's first row; [nparts] = total
+    int64_t stride;
+    int32_t nparts, ncols;
+};
+__global__ void __launch_bounds__(256) unpack_words_kernel(UnpackArgs ua, const uint64_t *src, uint64_t *dst) {
+    const int64_t total = ua.offset[ua.nparts];
+    const int64_t part_words = int64_t(ua.ncols) * ua.stride + 1;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total * ua.ncols; i += int64_t(gridDim.x) * blockDim.x) {
+        const int c = int(i / total);
+        const int64_t r = i - int64_t(c) * total;
+        int p = 0;
+        while (r >= ua.offset[p + 1]) ++p;
+        dst[i] = src[int64_t(p) * part_words + int64_t(c) * ua.stride + (r - ua.offset[p])];
+    }
+}
 __global__ void __launch_bounds__(256) count_valid_kernel(const uint64_t *words, int64_t n_rows, unsigned long long *out) {
     const int64_t nfull = n_rows / 64; // whole words; the tail is read byte-wise (a borrowed bitmap ends at ceil(n/8) bytes)
     unsigned long long c = 0;
@@ -718,6 +759,65 @@ nqe_status nqe_table_concat(nqe_ctx *ctx, const nqe_table *const *tables, int32_
             t->cols.push_back(concat_columns(ctx, parts));
         }
     }
+    *out = t.release();
+    NQE_API_END()
+}
+
+nqe_status nqe_table_pack_words(nqe_ctx *ctx, const nqe_table *const *tables, int32_t num_tables, int64_t stride_rows, void *dst_device) {
+    NQE_API_BEGIN(ctx)
+    if (!tables || num_tables <= 0 || stride_rows < 0 || !dst_device) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    PackArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    const int64_t rows = tables[0]->rows;
+    for (int k = 0; k < num_tables; ++k) {
+        if (tables[k]->rows != rows) fail(NQE_ERR_INVALID_ARGUMENT, "pack: tables differ in rows");
+        for (auto &c : tables[k]->cols) {
+            if (!is_word_type(c.dtype) || c.validity) fail(NQE_ERR_NOT_SUPPORTED, "pack: only 8-byte columns without validity");
+            if (pa.ncols == PACK_MAX_COLS) fail(NQE_ERR_NOT_SUPPORTED, "pack: too many columns");
+            pa.src[pa.ncols++] = (const uint64_t *)c.words();
+        }
+    }
+    if (rows > stride_rows) fail(NQE_ERR_INVALID_ARGUMENT, "pack: rows exceed the stride");
+    pa.rows = rows;
+    pa.stride = stride_rows;
+    launch(ctx, "pack_words", pack_words_kernel, dim3(unsigned(std::max<int64_t>(1, std::min<int64_t>(1024, (rows * pa.ncols + 255) / 256)))), dim3(256), 0, pa,
+           (uint64_t *)dst_device);
+    NQE_API_END()
+}
+
+nqe_status nqe_table_unpack_words(nqe_ctx *ctx, const void *src_device, int32_t num_parts, int32_t num_columns, int64_t stride_rows,
+                                  const int64_t *counts, const int32_t *dtypes, nqe_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!out || num_parts <= 0 || num_parts > UNPACK_MAX_PARTS || num_columns <= 0 || stride_rows < 0 || !counts || !dtypes || (stride_rows && !src_device))
+        fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    UnpackArgs ua;
+    std::memset(&ua, 0, sizeof(ua));
+    int64_t total = 0;
+    for (int p = 0; p < num_parts; ++p) {
+        if (counts[p] < 0 || counts[p] > stride_rows) fail(NQE_ERR_INVALID_ARGUMENT, "unpack: count exceeds the stride");
+        ua.offset[p] = total;
+        total += counts[p];
+    }
+    ua.offset[num_parts] = total;
+    ua.nparts = num_parts;
+    ua.ncols = num_columns;
+    ua.stride = stride_rows;
+    auto t = std::make_unique<nqe_table>();
+    t->ctx = ctx;
+    t->rows = total;
+    BufRef all = dev_alloc(ctx, size_t(total) * size_t(num_columns) * 8 + 8); // one allocation, columns are views
+    for (int c = 0; c < num_columns; ++c) {
+        if (!is_word_type(dtypes[c])) fail(NQE_ERR_NOT_SUPPORTED, "unpack: only 8-byte columns");
+        DevColumn d;
+        d.dtype = dtypes[c];
+        d.length = total;
+        d.null_count = 0;
+        d.values = dev_view(all, size_t(c) * size_t(total) * 8, size_t(total) * 8);
+        t->cols.push_back(std::move(d));
+    }
+    if (total)
+        launch(ctx, "unpack_words", unpack_words_kernel, dim3(unsigned(std::min<int64_t>(1024, (total * num_columns + 255) / 256))), dim3(256), 0, ua,
+               (const uint64_t *)src_device, (uint64_t *)all->ptr);
     *out = t.release();
     NQE_API_END()
 }

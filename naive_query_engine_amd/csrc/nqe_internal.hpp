@@ -79,6 +79,8 @@ using BufRef = std::shared_ptr<DevBuf>;
 BufRef dev_alloc(nqe_ctx *ctx, size_t bytes);
 BufRef dev_alloc_zero(nqe_ctx *ctx, size_t bytes);
 BufRef dev_borrow(nqe_ctx *ctx, const void *ptr, size_t bytes);
+// a sub-range of `parent` (keeps the parent alive)
+BufRef dev_view(const BufRef &parent, size_t offset, size_t bytes);
 void pool_trim(nqe_ctx *ctx);
 
 // One Arrow array resident in HBM.

@@ -23,6 +23,18 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 
+def _single(group=None) -> bool:
+    """True when there is nothing to exchange.  NQE_FORCE_EXCHANGE=1 keeps the exchange path even for one rank (used to
+    exercise the RCCL collectives on a single-GPU box)."""
+    import os
+
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size(group) == 1 and not os.environ.get("NQE_FORCE_EXCHANGE")
+
+
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """contiguous row range [lo, hi) of rank `rank`: sizes differ by at most one row"""
     base, rem = divmod(n, world)
@@ -94,36 +106,75 @@ def all_gather_rows(cols: Sequence, group=None) -> Tuple[List[list], List[int]]:
     return per_rank, counts
 
 
-def sharded_aggregate(ctx, local_table, aggs, group_nodes=None, pred_nodes=None, group=None):
-    """Aggregate over the union of every rank's `local_table`; returns (result_table, keys_table)
-    on every rank (identical up to f64 summation order of the merge)."""
+# rows of the fixed-size exchange buffer: partial states up to this many groups travel in ONE collective (header
+# included); larger ones take the exact-size two-collective path
+EXCHANGE_ROWS = 4096
+
+
+def _all_gather_packed(buf, group=None):
+    """all-gather of equally sized 1-D int64 buffers → [world, len] tensor (gloo + CUDA stages through the host)"""
     import torch
     import torch.distributed as dist
 
-    from .arrow_host import DType
+    world = dist.get_world_size(group)
+    if buf.device.type == "cuda" and dist.get_backend(group) == "gloo":
+        host = buf.cpu()
+        outs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(outs, host, group=group)
+        return torch.stack(outs).to(buf.device)
+    out = torch.empty(world * buf.numel(), dtype=buf.dtype, device=buf.device)  # flat: gloo accepts only the concatenated form
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return out.view(world, buf.numel())
+
+
+def sharded_aggregate(ctx, local_table, aggs, group_nodes=None, pred_nodes=None, group=None):
+    """Aggregate over the union of every rank's `local_table`; returns (result_table, keys_table)
+    on every rank (identical up to f64 summation order of the merge).
+
+    Exchange: the partial (keys + {count,sum,min,max} per value column) is packed into one fixed-size device buffer whose
+    last word is the group count, all-gathered with ONE collective, the counts are read from the headers (one D2H sync),
+    and the gathered buffer is unpacked into a single concatenated table for the merge.  Partials with more than
+    EXCHANGE_ROWS groups on any rank fall back to the exact-size path (counts first, then data)."""
+    import torch
+    import torch.distributed as dist
 
     state, keys = ctx.aggregate_partial(local_table, aggs, group_nodes=group_nodes, pred_nodes=pred_nodes)
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _single(group):
         return ctx.aggregate_merge([state], [keys] if keys is not None else None, aggs)
     dev = torch.device("cuda", ctx.device)
-    cols = table_columns_as_tensors(state, dev)
-    kdt = None
-    if keys is not None:
-        kdt = keys.dtypes()[0]
-        cols = table_columns_as_tensors(keys, dev) + cols
+    tables = ([keys] if keys is not None else []) + [state]
+    dts = [d for t in tables for d in t.dtypes()]
+    ncols = len(dts)
+    nk = 1 if keys is not None else 0
+    rows = state.num_rows
+    stride = EXCHANGE_ROWS
+    words = ncols * stride + 1
+    buf = torch.empty(words, dtype=torch.int64, device=dev)
+    fits = rows <= stride
+    if fits:
+        ctx.pack_words(tables, stride, buf.data_ptr())
+    else:
+        buf[-1] = rows  # header only: tells the peers to take the exact-size path
+    ctx.synchronize()  # the pack ran on the context's stream, the collective runs on torch's
+    gathered = _all_gather_packed(buf, group)
+    counts = [int(c) for c in gathered[:, -1].cpu().tolist()]  # D2H: also orders the collective before the unpack
+    if max(counts) <= stride:
+        cat = ctx.unpack_words(gathered.data_ptr(), counts, dts, stride)
+        ctx.synchronize()
+        del gathered
+        keyt = ctx.project(cat, [0]) if nk else None
+        st = ctx.project(cat, list(range(nk, ncols)))
+        return ctx.aggregate_merge([st], [keyt] if keyt is not None else None, aggs)
+    # ---- exact-size path
+    cols = []
+    for t in tables:
+        cols += table_columns_as_tensors(t, dev)
     per_rank, counts = all_gather_rows(cols, group)
-    # one concatenated (keys, state) table instead of 2 x world small ones: the merge is associative
-    ncols = len(cols)
     cat = [torch.cat([per_rank[r][i] for r in range(len(per_rank))]).contiguous() for i in range(ncols)]
     total = int(sum(counts))
     torch.cuda.synchronize(dev)
-    sdt = state.dtypes()
-    off = 0
-    keyt = None
-    if keys is not None:
-        keyt = ctx.table_from_device([(kdt, total, cat[0].data_ptr() if total else None, None)])
-        off = 1
-    st = ctx.table_from_device([(sdt[i], total, cat[off + i].data_ptr() if total else None, None) for i in range(len(sdt))])
+    keyt = ctx.table_from_device([(dts[0], total, cat[0].data_ptr() if total else None, None)]) if nk else None
+    st = ctx.table_from_device([(dts[nk + i], total, cat[nk + i].data_ptr() if total else None, None) for i in range(ncols - nk)])
     out = ctx.aggregate_merge([st], [keyt] if keyt is not None else None, aggs)
     ctx.synchronize()
     del cat
@@ -158,7 +209,7 @@ def sharded_hash_join(ctx, left_table, right_local_table, left_key: int, right_k
 
     jt = join_table or ctx.hash_join_build(left_table, left_key)
     local = ctx.hash_join_probe(jt, right_local_table, right_key)
-    if not gather or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not gather or _single(group):
         return local
     return _gather_table(ctx, local, group)
 
@@ -169,9 +220,26 @@ def sharded_selection_projection(ctx, local_table, pred_nodes, exprs, gather: bo
     import torch.distributed as dist
 
     local = ctx.selection_projection(local_table, pred_nodes, exprs)
-    if not gather or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not gather or _single(group):
         return local
     return _gather_table(ctx, local, group)
+
+
+def pack_words_numpy(cols: Sequence[np.ndarray], stride: int) -> np.ndarray:
+    """Host restatement of nqe_table_pack_words' layout (CPU gloo tests): [ncols*stride] words + the row count."""
+    rows = len(cols[0]) if cols else 0
+    assert rows <= stride
+    buf = np.zeros(len(cols) * stride + 1, dtype=np.int64)
+    for c, a in enumerate(cols):
+        buf[c * stride : c * stride + rows] = np.ascontiguousarray(a).view(np.int64)
+    buf[-1] = rows
+    return buf
+
+
+def unpack_words_numpy(gathered: np.ndarray, ncols: int, stride: int) -> Tuple[List[np.ndarray], List[int]]:
+    """Host restatement of nqe_table_unpack_words: [world, ncols*stride+1] → per column the parts concatenated."""
+    counts = [int(c) for c in gathered[:, -1]]
+    return [np.concatenate([gathered[p, c * stride : c * stride + counts[p]] for p in range(gathered.shape[0])]) for c in range(ncols)], counts
 
 
 def merge_partials_numpy(keys_list: Sequence[Optional[np.ndarray]], states_list: Sequence[Sequence[np.ndarray]]):

@@ -30,17 +30,18 @@ def make_cols():
     return [Column.from_numpy(ids), Column.from_numpy(v, mask)]
 
 
-def plan():
+def plan(mod=128):
     from naive_query_engine_amd import AggregateFunc, Operator
     from naive_query_engine_amd.expression import binop, col, lit_i64
     from tests.helpers import fields
 
     f = fields("id", "v")
     aggs = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1), (AggregateFunc.Min, 1), (AggregateFunc.Max, 1)]
-    return aggs, binop(col(0), Operator.Modulos, lit_i64(128)).flatten(f), binop(col(0), Operator.Lt, lit_i64(N // 2)).flatten(f)
+    key = binop(col(0), Operator.Modulos, lit_i64(mod)).flatten(f) if mod else None
+    return aggs, key, binop(col(0), Operator.Lt, lit_i64(N // 2)).flatten(f)
 
 
-def worker(rank, world, port, q):
+def worker(rank, world, port, q, mod):
     import torch
     import torch.distributed as dist
 
@@ -56,17 +57,18 @@ def worker(rank, world, port, q):
         cols = make_cols()
         lo, hi = shard_range(N, rank, world)
         sub = [Column.from_numpy(c.to_numpy()[lo:hi], c.valid_mask()[lo:hi]) for c in cols]
-        aggs, key, pred = plan()
+        aggs, key, pred = plan(mod)
         out, keys = sharded_aggregate(ctx, ctx.table_from_host(sub), aggs, group_nodes=key, pred_nodes=pred)
         res = np.stack([c.to_numpy().astype(np.float64) for c in out.to_host()], axis=1)
-        q.put((rank, keys.to_host()[0].to_numpy().tolist(), res.tolist()))
+        q.put((rank, keys.to_host()[0].to_numpy().tolist() if keys is not None else None, res.tolist()))
         ctx.close()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_sharded_aggregate_two_ranks_one_gpu():
+@pytest.mark.parametrize("mod", [128, 6000, None])  # one-collective exchange / more groups than the exchange buffer / un-grouped
+def test_sharded_aggregate_two_ranks_one_gpu(mod):
     import torch.multiprocessing as mp
 
     from naive_query_engine_amd import capi
@@ -75,7 +77,7 @@ def test_sharded_aggregate_two_ranks_one_gpu():
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = free_port()
-    procs = [mpc.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [mpc.Process(target=worker, args=(r, 2, port, q, mod)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(2)]
@@ -83,14 +85,14 @@ def test_sharded_aggregate_two_ranks_one_gpu():
         p.join(60)
         assert p.exitcode == 0
     cols = make_cols()
-    aggs, key, pred = plan()
+    aggs, key, pred = plan(mod)
     exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=pred)[0]
     exp_m = np.stack([c.to_numpy().astype(np.float64) for c in exp], axis=1)
     exp_m = exp_m[np.lexsort(exp_m.T[::-1])]
     ctx = capi.Context(0)
     single = np.stack([c.to_numpy().astype(np.float64) for c in ctx.aggregate(ctx.table_from_host(cols), aggs, group_nodes=key, pred_nodes=pred).to_host()], axis=1)
     for rank, keys, res in results:
-        assert keys == list(range(128))
+        assert keys == (list(range(mod)) if mod else None)
         got = np.array(res)
         assert np.allclose(got, single, rtol=1e-9, atol=0)          # rows are key-sorted on both sides
         g = got[np.lexsort(got.T[::-1])]

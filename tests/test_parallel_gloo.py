@@ -12,7 +12,8 @@ import torch.multiprocessing as mp
 
 from naive_query_engine_amd import AggregateFunc, Column, Operator
 from naive_query_engine_amd.expression import binop, col, lit_i64
-from naive_query_engine_amd.parallel import all_gather_rows, merge_partials_numpy, shard_range
+from naive_query_engine_amd.parallel import (_all_gather_packed, all_gather_rows, merge_partials_numpy, pack_words_numpy, shard_range,
+                                               unpack_words_numpy)
 from tests.helpers import fields
 
 
@@ -118,6 +119,51 @@ def test_sharded_aggregate_exchange_world2():
         for g, e in zip(got_rows, exp_rows):
             assert g[0] == e[0] and g[2] == e[2] and g[3] == e[3]
             assert abs(g[1] - e[1]) <= 1e-9 * abs(e[1])
+
+
+def packed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the one-collective exchange of sharded_aggregate: fixed-size packed buffer with the row count as header
+        lo, hi = shard_range(N, rank, world)
+        keys, state = shard_partial(lo, hi, N)
+        stride = 100
+        buf = pack_words_numpy([keys] + [s_.view(np.int64) for s_ in state], stride)
+        gathered = _all_gather_packed(torch.from_numpy(buf)).numpy()
+        cols, counts = unpack_words_numpy(gathered, 5, stride)
+        merged = merge_partials_numpy([cols[0]], [[cols[1].view(np.uint64), cols[2].view(np.float64), cols[3].view(np.float64), cols[4].view(np.float64)]])
+        q.put((rank, counts, {int(k): v[0] for k, v in merged.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_packed_single_collective_exchange_world2():
+    from oracle import oracle as orc
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=packed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=150) for _ in range(2)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    ids, v = make_data()
+    cols = [Column.from_numpy(ids), Column.from_numpy(v)]
+    pred = binop(col(0), Operator.Lt, lit_i64(N // 2)).flatten(FLD)
+    key = binop(col(0), Operator.Modulos, lit_i64(64)).flatten(FLD)
+    exp_rows = sorted(zip(*[c.to_list() for c in orc.aggregate([cols], AGGS, group_nodes=key, pred_nodes=pred)[0]]))
+    for rank, counts, merged in results:
+        assert counts == [64, 0]
+        got_rows = sorted((m[0], m[1], m[2], m[3]) for m in merged.values())
+        assert len(got_rows) == 64
+        for g, e in zip(got_rows, exp_rows):
+            assert g[0] == e[0] and g[2] == e[2] and g[3] == e[3] and abs(g[1] - e[1]) <= 1e-9 * abs(e[1])
 
 
 def gather_worker(rank, world, port, q):
