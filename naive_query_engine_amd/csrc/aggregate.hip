@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
     // whenever m divides blockDim — consecutive rows of a thread carry the SAME key.  They are accumulated in
     // registers and written to the workgroup table only when the key changes (one flush per run instead of four
     // LDS atomics per row).  Random keys flush every row.
+    bool full = false; // register copy of lds_full_flag (set by own failures, refreshed per tile)
     bool run_live = false;
     uint64_t run_key = 0;
     uint32_t rcnt[NV];
@@ -211,8 +212,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
     auto flush_run = [&]() {
         // once this workgroup's table has rejected a key, later keys skip it: any split of the updates between
         // the LDS table and the global table is correct (the merge is additive), and a full table costs 48 probes
-        int slot = *lds_full ? -1 : lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
-        if (slot < 0 && !*lds_full) *lds_full = 1;
+        int slot = full ? -1 : lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+        if (slot < 0 && !full) {
+            full = true;
+            *lds_full = 1;
+        }
         int64_t gslot = slot < 0 ? global_find_or_insert(g, run_key, flags) : 0;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -247,6 +251,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
     const int64_t step = int64_t(blockDim.x) * AGG_U;
     for (int64_t base = int64_t(blockIdx.x) * step; base < a.n; base += int64_t(gridDim.x) * step) {
         if (__hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break; // host retries
+        full = full || *lds_full != 0;
         uint64_t kw[AGG_U], pw[AGG_U], vw[NV][AGG_U];
         // ---- load phase: every referenced word of this iteration is requested before any use
 #pragma unroll
@@ -383,14 +388,18 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
     }
     auto flush_run = [&]() {
-        // once this workgroup's table has rejected a key, later keys skip it: any split of the updates between
-        // the LDS table and the global table is correct (the merge is additive), and a full table costs 48 probes
-        int slot = *lds_full ? -1 : lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
-        if (slot < 0 && !*lds_full) {
-            *lds_full = 1;
-            if (a.allow_partition) atomicOr(&flags[NQE_FLAG_NEED_PARTITION], 1); // more distinct keys than a workgroup table holds
+        // The hit path must stay minimal: random-key inputs flush once per row (guarding the lookup with a "table is full"
+        // test cost them 14 %).  A rejected key is the cold path: it raises the workgroup flag (the tile loop then leaves
+        // early and the host redoes the query partitioned) or, for small inputs, goes to the global table.
+        int slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+        int64_t gslot = 0;
+        if (slot < 0) {
+            if (!*lds_full) {
+                *lds_full = 1;
+                if (a.allow_partition) atomicOr(&flags[NQE_FLAG_NEED_PARTITION], 1); // more distinct keys than a workgroup table holds
+            }
+            gslot = a.allow_partition ? -1 : global_find_or_insert(g, run_key, flags);
         }
-        int64_t gslot = (slot < 0 && !a.allow_partition) ? global_find_or_insert(g, run_key, flags) : (slot < 0 ? -1 : 0);
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
             const uint64_t omn = f64_to_ord(rmn[j]), omx = f64_to_ord(rmx[j]);
