@@ -196,6 +196,31 @@ nqe_status nqe_table_slice(nqe_ctx *ctx, const nqe_table *in, int64_t offset, in
  * NQE_ERR_INVALID_ARGUMENT here (the host mirror builds the empty batch itself). */
 nqe_status nqe_table_concat(nqe_ctx *ctx, const nqe_table *const *tables, int32_t n, nqe_table **out);
 
+/* ------------------------------------------------------------------ CSV ingest
+ * CsvTable::try_create (datasource/csv.rs:53-86) = infer_schema_from_csv (csv.rs:76-85, arrow-rs 13
+ * csv::reader::infer_reader_schema over the first max_read_records records) + csv::Reader::next() — only the FIRST
+ * batch of batch_size rows is kept (quirk Q1, csv.rs:71-73).  CsvConfig (csv.rs:23-43): has_header = true,
+ * delimiter = ',', max_read_records = Some(3), batch_size = 1_000_000; file_projection / datetime_format are not mirrored. */
+typedef struct nqe_csv_options {
+    int32_t has_header;       /* first record = column names; otherwise "column_1", "column_2", ... */
+    int32_t delimiter;        /* one byte */
+    int64_t max_read_records; /* records sampled by the inference; < 0 = all */
+    int64_t batch_size;       /* rows kept; < 0 = all */
+} nqe_csv_options;
+/* Schema inference (host side, a handful of records): per column Boolean / Int64 / Float64 / Utf8 (Int64+Float64 →
+ * Float64, any other mix → Utf8; Date-like columns → NQE_ERR_NOT_SUPPORTED), nullable[c] = an empty field was seen.
+ * names: the column names joined with '\0' terminators (names_bytes = bytes needed). */
+nqe_status nqe_csv_infer_schema(nqe_ctx *ctx, const void *bytes_host, int64_t nbytes, const nqe_csv_options *opt,
+                                int32_t max_columns, int32_t *num_columns, int32_t *dtypes, int32_t *nullable,
+                                char *names, int64_t names_capacity, int64_t *names_bytes);
+/* Parses the file image (host or device memory, `location` = nqe_location) into one device table with the given column
+ * types: records split on the GPU (quotes with "" escapes, \r / \n / \r\n, empty lines skipped), fields converted on
+ * the GPU (lexical-core semantics: Int64 overflow and malformed numbers are NQE_ERR_ARROW, Float64 correctly rounded,
+ * empty numeric/Boolean fields are NULL, Utf8 fields are never NULL); a record with a different number of fields is
+ * NQE_ERR_ARROW. */
+nqe_status nqe_csv_read(nqe_ctx *ctx, const void *bytes, int32_t location, int64_t nbytes, const nqe_csv_options *opt,
+                        const int32_t *dtypes, int32_t num_columns, nqe_table **out);
+
 /* ------------------------------------------------------------------ exchange plumbing (multi-GPU)
  * No reference analogue (the reference is single-process).  A rank's partial aggregate (keys + state tables: 8-byte
  * columns without validity) is packed into ONE device buffer so that the exchange is a single RCCL all-gather, and the

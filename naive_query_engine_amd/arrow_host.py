@@ -124,6 +124,12 @@ class NqeAggregate(C.Structure):
     _fields_ = [("func", C.c_int32), ("column", C.c_int32)]
 
 
+class NqeCsvOptions(C.Structure):
+    """nqe_csv_options (CsvConfig, src/datasource/csv.rs:23-43)"""
+
+    _fields_ = [("has_header", C.c_int32), ("delimiter", C.c_int32), ("max_read_records", C.c_int64), ("batch_size", C.c_int64)]
+
+
 EXPR_COLUMN, EXPR_LITERAL, EXPR_BINARY = 0, 1, 2
 HOST, DEVICE = 0, 1
 

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-from .arrow_host import (DEVICE, Column, DType, ErrorCode, NqeAggregate, NqeColumn, NqeExprNode, Status, bitmap_bytes,
+from .arrow_host import (DEVICE, Column, DType, ErrorCode, NqeAggregate, NqeColumn, NqeCsvOptions, NqeExprNode, Status, bitmap_bytes,
                          nodes_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,7 +24,7 @@ SYMBOLS = [
     "nqe_last_global_error", "nqe_ctx_timing_enable", "nqe_ctx_timing_query", "nqe_ctx_timing_reset",
     "nqe_table_create", "nqe_table_release", "nqe_table_num_rows", "nqe_table_num_columns", "nqe_table_column",
     "nqe_table_download_column", "nqe_table_project", "nqe_table_slice", "nqe_table_concat", "nqe_table_pack_words",
-    "nqe_table_unpack_words", "nqe_expr_evaluate",
+    "nqe_table_unpack_words", "nqe_csv_infer_schema", "nqe_csv_read", "nqe_expr_evaluate",
     "nqe_filter", "nqe_selection_execute", "nqe_projection_execute", "nqe_selection_projection_execute",
     "nqe_aggregate_execute", "nqe_aggregate_partial", "nqe_aggregate_merge", "nqe_hash_join_execute",
     "nqe_hash_join_build", "nqe_hash_join_probe", "nqe_join_table_release", "nqe_take", "nqe_synth_fill",
@@ -68,6 +68,9 @@ def lib():
         "nqe_table_concat": (i32, [vp, pvp, i32, pvp]),
         "nqe_table_pack_words": (i32, [vp, pvp, i32, i64, vp]),
         "nqe_table_unpack_words": (i32, [vp, vp, i32, i32, i64, C.POINTER(i64), C.POINTER(i32), pvp]),
+        "nqe_csv_infer_schema": (i32, [vp, C.c_char_p, i64, C.POINTER(NqeCsvOptions), i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, i64,
+                                       C.POINTER(i64)]),
+        "nqe_csv_read": (i32, [vp, vp, i32, i64, C.POINTER(NqeCsvOptions), C.POINTER(i32), i32, pvp]),
         "nqe_expr_evaluate": (i32, [vp, vp, nodes, i32, pvp]),
         "nqe_filter": (i32, [vp, vp, vp, i32, pvp]),
         "nqe_selection_execute": (i32, [vp, vp, nodes, i32, pvp]),
@@ -276,6 +279,32 @@ class Context:
         arr = (C.c_void_p * max(1, len(tables)))(*[t.handle for t in tables])
         h = C.c_void_p()
         self.check(lib().nqe_table_concat(self.handle, arr, len(tables), C.byref(h)))
+        return Table(self, h)
+
+    # ---- CSV ingest (datasource/csv.rs)
+    def csv_infer_schema(self, data: bytes, has_header: bool = True, delimiter: str = ",", max_read_records: int = 3, batch_size: int = 1_000_000):
+        """→ (names, dtypes, nullable) from the first `max_read_records` records (host side)"""
+        opt = NqeCsvOptions(int(has_header), ord(delimiter), max_read_records, batch_size)
+        cap = 256
+        nc, need = C.c_int32(), C.c_int64()
+        dts, nul = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+        names = C.create_string_buffer(1 << 16)
+        self.check(lib().nqe_csv_infer_schema(self.handle, data, len(data), C.byref(opt), cap, C.byref(nc), dts, nul, names, len(names), C.byref(need)))
+        n = nc.value
+        nm = names.raw[: need.value].split(b"\0")[:n]
+        return [x.decode() for x in nm], [DType(dts[i]) for i in range(n)], [bool(nul[i]) for i in range(n)]
+
+    def csv_read(self, data, dtypes: Sequence[DType], has_header: bool = True, delimiter: str = ",", batch_size: int = 1_000_000,
+                 device_ptr: Optional[int] = None, nbytes: Optional[int] = None) -> "Table":
+        """parses a file image (host `bytes`, or device memory via device_ptr/nbytes) into a device table"""
+        opt = NqeCsvOptions(int(has_header), ord(delimiter), 3, batch_size)
+        da = (C.c_int32 * max(1, len(dtypes)))(*[int(d) for d in dtypes])
+        h = C.c_void_p()
+        if device_ptr is not None:
+            self.check(lib().nqe_csv_read(self.handle, C.c_void_p(device_ptr), 1, nbytes, C.byref(opt), da, len(dtypes), C.byref(h)))
+        else:
+            buf = C.c_char_p(data)
+            self.check(lib().nqe_csv_read(self.handle, C.cast(buf, C.c_void_p), 0, len(data), C.byref(opt), da, len(dtypes), C.byref(h)))
         return Table(self, h)
 
     # ---- exchange plumbing (multi-GPU)

@@ -17,6 +17,8 @@
 #pragma once
 
 #include <cstring>
+#include <fstream>
+#include <iterator>
 #include <memory>
 #include <optional>
 #include <string>
@@ -124,6 +126,8 @@ struct Array {
     std::vector<uint64_t> words;   // Int64/UInt64/Float64 raw 64-bit words
     std::vector<uint8_t> bits;     // Boolean values (LSB-first)
     std::vector<uint8_t> validity; // empty = no nulls
+    std::vector<int32_t> offsets;  // Utf8: length + 1 offsets into `data`
+    std::string data;              // Utf8 bytes
 
     static Array from_i64(const std::vector<int64_t> &v) { Array a; a.dtype = DataType::Int64; a.length = int64_t(v.size()); a.words.resize(v.size()); if (!v.empty()) std::memcpy(a.words.data(), v.data(), v.size() * 8); return a; }
     static Array from_u64(const std::vector<uint64_t> &v) { Array a; a.dtype = DataType::UInt64; a.length = int64_t(v.size()); a.words = v; return a; }
@@ -138,6 +142,7 @@ struct Array {
     uint64_t u64(int64_t i) const { return words[size_t(i)]; }
     double f64(int64_t i) const { double d; std::memcpy(&d, &words[size_t(i)], 8); return d; }
     bool boolean(int64_t i) const { return (bits[size_t(i) >> 3] >> (i & 7)) & 1; }
+    std::string str(int64_t i) const { return data.substr(size_t(offsets[size_t(i)]), size_t(offsets[size_t(i) + 1] - offsets[size_t(i)])); }
     std::vector<int64_t> to_i64() const { std::vector<int64_t> o(static_cast<size_t>(length)); for (int64_t i = 0; i < length; ++i) o[size_t(i)] = i64(i); return o; }
     std::vector<double> to_f64() const { std::vector<double> o(static_cast<size_t>(length)); for (int64_t i = 0; i < length; ++i) o[size_t(i)] = f64(i); return o; }
 };
@@ -174,9 +179,15 @@ class RecordBatch {
         Array a;
         a.dtype = DataType(info.dtype);
         a.length = info.length;
+        if (info.validity) a.validity.assign(size_t((info.length + 7) / 8), 0);
+        if (a.dtype == DataType::Utf8) {
+            a.offsets.assign(size_t(info.length) + 1, 0);
+            a.data.assign(size_t(info.data_length), '\0');
+            ctx_->check(nqe_table_download_column(table_.get(), i, a.offsets.data(), a.validity.empty() ? nullptr : a.validity.data(), a.data.data()));
+            return a;
+        }
         if (a.dtype == DataType::Boolean) a.bits.assign(size_t((info.length + 7) / 8), 0);
         else a.words.assign(size_t(info.length), 0);
-        if (info.validity) a.validity.assign(size_t((info.length + 7) / 8), 0);
         ctx_->check(nqe_table_download_column(table_.get(), i, a.dtype == DataType::Boolean ? static_cast<void *>(a.bits.data()) : static_cast<void *>(a.words.data()),
                                               a.validity.empty() ? nullptr : a.validity.data(), nullptr));
         return a;
@@ -280,6 +291,51 @@ struct MemTable : TableSource { // memory.rs:14-46
         return out;
     }
     std::string source_name() const override { return "MemTable"; }
+};
+
+// ---------------------------------------------------------------- datasource/csv.rs
+struct CsvConfig { // csv.rs:23-43 (file_projection / datetime_format are not mirrored)
+    bool has_header = true;
+    uint8_t delimiter = ',';
+    std::optional<size_t> max_read_records = 3;
+    size_t batch_size = 1000000;
+};
+
+struct CsvTable : TableSource { // csv.rs:46-103: schema inferred from the first records, FIRST batch only (Q1), scan ignores projection (Q2)
+    NaiveSchema schema_;
+    std::vector<RecordBatch> batches;
+    static TableRef try_create(const std::string &filename, const CsvConfig &config = CsvConfig(), ContextRef ctx = Context::default_context()) {
+        std::ifstream f(filename, std::ios::binary);
+        if (!f) throw ErrorCode(ErrorCode::IoError, "cannot open " + filename);
+        std::string bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        nqe_csv_options opt;
+        opt.has_header = config.has_header ? 1 : 0;
+        opt.delimiter = config.delimiter;
+        opt.max_read_records = config.max_read_records ? int64_t(*config.max_read_records) : -1;
+        opt.batch_size = int64_t(config.batch_size);
+        int32_t nc = 0;
+        std::vector<int32_t> dtypes(256), nullable(256);
+        std::vector<char> names(1 << 16);
+        int64_t names_bytes = 0;
+        ctx->check(nqe_csv_infer_schema(ctx->raw(), bytes.data(), int64_t(bytes.size()), &opt, 256, &nc, dtypes.data(), nullable.data(), names.data(),
+                                        int64_t(names.size()), &names_bytes));
+        std::vector<NaiveField> fields;
+        const char *p = names.data();
+        for (int32_t c = 0; c < nc; ++c) {
+            std::string nm(p);
+            p += nm.size() + 1;
+            fields.emplace_back(std::nullopt, nm, DataType(dtypes[size_t(c)]), nullable[size_t(c)] != 0);
+        }
+        nqe_table *t = nullptr;
+        ctx->check(nqe_csv_read(ctx->raw(), bytes.data(), NQE_HOST, int64_t(bytes.size()), &opt, dtypes.data(), nc, &t));
+        auto tab = std::make_shared<CsvTable>();
+        tab->schema_ = NaiveSchema(fields);
+        tab->batches.push_back(RecordBatch(ctx, tab->schema_, t));
+        return tab;
+    }
+    const NaiveSchema &schema() const override { return schema_; }
+    std::vector<RecordBatch> scan(const std::optional<std::vector<size_t>> &) const override { return batches; }
+    std::string source_name() const override { return "CsvTable"; }
 };
 
 // ---------------------------------------------------------------- physical_plan/plan.rs:14-23

@@ -91,16 +91,28 @@ class MemTable:
         return "MemTable"
 
 
+class CsvConfig:
+    """src/datasource/csv.rs:23-43 (file_projection / datetime_format are not mirrored)"""
+
+    def __init__(self, has_header: bool = True, delimiter: str = ",", max_read_records: Optional[int] = 3, batch_size: int = 1_000_000):
+        self.has_header, self.delimiter, self.max_read_records, self.batch_size = has_header, delimiter, max_read_records, batch_size
+
+
 class CsvTable(MemTable):
-    """src/datasource/csv.rs:46-103 — only the first batch is loaded (Q1); scan ignores projection (Q2)."""
+    """src/datasource/csv.rs:46-103 — schema inferred from the first max_read_records records, only the first batch is
+    loaded (Q1); scan ignores projection (Q2).  The file image is parsed on the GPU (nqe_csv_read)."""
 
     @staticmethod
-    def try_create(filename: str, ctx: Optional["capi.Context"] = None) -> "CsvTable":
-        from .arrow_host import read_csv
-
-        batch = read_csv(filename)
-        m = MemTable.try_create(batch.fields, [batch], ctx)
-        return CsvTable(m._schema, m.batches)
+    def try_create(filename: str, csv_config: Optional[CsvConfig] = None, ctx: Optional["capi.Context"] = None) -> "CsvTable":
+        cfg = csv_config or CsvConfig()
+        ctx = ctx or capi.default_context()
+        with open(filename, "rb") as f:
+            data = f.read()
+        mrr = -1 if cfg.max_read_records is None else cfg.max_read_records
+        names, dtypes, nullable = ctx.csv_infer_schema(data, cfg.has_header, cfg.delimiter, mrr, cfg.batch_size)
+        table = ctx.csv_read(data, dtypes, cfg.has_header, cfg.delimiter, cfg.batch_size)
+        fields = [Field(n, d, nl) for n, d, nl in zip(names, dtypes, nullable)]
+        return CsvTable(fields, [DeviceRecordBatch(fields, table)])
 
     def scan(self, projection):
         return list(self.batches)

@@ -27,6 +27,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cerrno>
+#include <cctype>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -1128,6 +1130,193 @@ static inline uint64_t splitmix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
     return x ^ (x >> 31);
 }
+// ------------------------------------------------------------------ CsvTable::try_create (datasource/csv.rs:53-86)
+// Sequential restatement of what the reference gets from arrow-rs 13 + the csv crate (neither is under /root/reference:
+// arrow 13.0.0 / csv 1.1 / lexical-core 0.8 per Cargo.lock), written independently of the device code:
+//   * records: '"'-quoted fields with "" escapes (a quote is special only at the start of a field; text after a closing
+//     quote is appended literally), terminators \r, \n, \r\n, empty lines skipped, a last record without terminator is kept;
+//   * schema: infer_reader_schema over the first max_read_records records (non-empty fields only): leading '"' → Utf8,
+//     true/false → Boolean, ^-?\d+\.\d+$ → Float64, ^-?\d+$ → Int64, ISO date(-time) → Date (unsupported here), else
+//     Utf8; {Int64, Float64} → Float64, other mixes → Utf8; nullable = an empty field was seen;
+//   * values: only the first batch of batch_size rows (quirk Q1); empty numeric/Boolean → NULL; Int64/Float64 via the
+//     C library after a lexical-core grammar check (strtod is correctly rounded); Utf8 never NULL.
+namespace {
+struct CsvReaderState {
+    const uint8_t *p;
+    int64_t n, i = 0;
+    uint8_t delim;
+    // next record; false at end of input
+    bool next(std::vector<std::string> &fields) {
+        fields.clear();
+        while (i < n && (p[i] == '\n' || p[i] == '\r')) ++i; // empty lines
+        if (i >= n) return false;
+        std::string cur;
+        for (;;) {
+            // one field
+            cur.clear();
+            if (i < n && p[i] == '"') {
+                ++i;
+                for (;;) {
+                    if (i >= n) break;
+                    if (p[i] == '"') {
+                        if (i + 1 < n && p[i + 1] == '"') { cur.push_back('"'); i += 2; continue; }
+                        ++i; // closing quote
+                        break;
+                    }
+                    cur.push_back(char(p[i++]));
+                }
+                // csv-core: after the closing quote the field continues as an unquoted one (quotes are then literal)
+                while (i < n && p[i] != delim && p[i] != '\n' && p[i] != '\r') cur.push_back(char(p[i++]));
+            } else {
+                while (i < n && p[i] != delim && p[i] != '\n' && p[i] != '\r') cur.push_back(char(p[i++]));
+            }
+            fields.push_back(cur);
+            if (i < n && p[i] == delim) { ++i; continue; }
+            break;
+        }
+        if (i < n) ++i; // one terminator byte (\r\n leaves an empty line, skipped above)
+        return true;
+    }
+};
+
+bool csv_all_digits(const std::string &s, size_t a, size_t b) {
+    if (a >= b) return false;
+    for (size_t k = a; k < b; ++k)
+        if (!isdigit((unsigned char)s[k])) return false;
+    return true;
+}
+bool csv_ieq(const std::string &s, const char *w) {
+    if (s.size() != strlen(w)) return false;
+    for (size_t k = 0; k < s.size(); ++k)
+        if (tolower((unsigned char)s[k]) != w[k]) return false;
+    return true;
+}
+enum { CI_UTF8 = 1, CI_BOOL = 2, CI_F64 = 4, CI_I64 = 8, CI_DATE = 16 };
+int csv_infer(const std::string &s) {
+    if (s[0] == '"') return CI_UTF8;
+    if (csv_ieq(s, "true") || csv_ieq(s, "false")) return CI_BOOL;
+    size_t b = s[0] == '-' ? 1 : 0, dot = s.find('.');
+    if (dot != std::string::npos && csv_all_digits(s, b, dot) && csv_all_digits(s, dot + 1, s.size())) return CI_F64;
+    if (csv_all_digits(s, b, s.size())) return CI_I64;
+    auto shape = [&](const char *pat) {
+        if (s.size() != strlen(pat)) return false;
+        for (size_t k = 0; k < s.size(); ++k)
+            if (pat[k] == 'd' ? !isdigit((unsigned char)s[k]) : s[k] != pat[k]) return false;
+        return true;
+    };
+    if (shape("dddd-dd-ddTdd:dd:dd") || shape("dddd-dd-dd")) return CI_DATE;
+    return CI_UTF8;
+}
+// lexical-core float grammar (no whitespace, no hex, digits required, exponent digits required)
+bool csv_float_grammar(const std::string &s) {
+    size_t k = 0;
+    if (k < s.size() && (s[k] == '+' || s[k] == '-')) ++k;
+    std::string rest = s.substr(k);
+    if (csv_ieq(rest, "nan") || csv_ieq(rest, "inf") || csv_ieq(rest, "infinity")) return true;
+    size_t digits = 0;
+    while (k < s.size() && isdigit((unsigned char)s[k])) { ++k; ++digits; }
+    if (k < s.size() && s[k] == '.') {
+        ++k;
+        while (k < s.size() && isdigit((unsigned char)s[k])) { ++k; ++digits; }
+    }
+    if (!digits) return false;
+    if (k < s.size() && (s[k] == 'e' || s[k] == 'E')) {
+        ++k;
+        if (k < s.size() && (s[k] == '+' || s[k] == '-')) ++k;
+        size_t ed = 0;
+        while (k < s.size() && isdigit((unsigned char)s[k])) { ++k; ++ed; }
+        if (!ed) return false;
+    }
+    return k == s.size();
+}
+} // namespace
+
+// names_out: '\0'-joined column names (caller buffer)
+int orc_csv_read(const uint8_t *bytes, int64_t nbytes, int32_t has_header, int32_t delimiter, int64_t max_read_records, int64_t batch_size,
+                 orc_batches **out, char *names_out, int64_t names_cap, int32_t *nullable_out, int32_t nullable_cap) {
+    return guarded([&] {
+        // ---- schema
+        CsvReaderState rd{bytes, nbytes, 0, uint8_t(delimiter)};
+        std::vector<std::string> rec, names;
+        if (!rd.next(rec)) fail(NQE_ERR_ARROW, "csv: empty file");
+        const size_t nc = rec.size();
+        if (has_header) names = rec;
+        else {
+            for (size_t c = 0; c < nc; ++c) names.push_back("column_" + std::to_string(c + 1));
+            rd.i = 0;
+        }
+        std::vector<int> poss(nc, 0), nul(nc, 0);
+        for (int64_t r = 0; max_read_records < 0 || r < max_read_records; ++r) {
+            if (!rd.next(rec)) break;
+            if (rec.size() != nc) fail(NQE_ERR_ARROW, "csv: record with a different number of fields");
+            for (size_t c = 0; c < nc; ++c) {
+                if (rec[c].empty()) nul[c] = 1;
+                else poss[c] |= csv_infer(rec[c]);
+            }
+        }
+        std::vector<int> dts(nc);
+        for (size_t c = 0; c < nc; ++c) {
+            const int p = poss[c];
+            if (p == CI_BOOL) dts[c] = NQE_BOOLEAN;
+            else if (p == CI_I64) dts[c] = NQE_INT64;
+            else if (p == CI_F64 || p == (CI_F64 | CI_I64)) dts[c] = NQE_FLOAT64;
+            else if (p == CI_DATE) fail(NQE_ERR_NOT_SUPPORTED, "csv: Date32/Date64 columns are outside the hot path's types");
+            else dts[c] = NQE_UTF8;
+        }
+        // ---- first batch
+        CsvReaderState rd2{bytes, nbytes, 0, uint8_t(delimiter)};
+        if (has_header) rd2.next(rec);
+        std::vector<Builder> bs;
+        for (size_t c = 0; c < nc; ++c) bs.emplace_back(dts[c]);
+        int64_t rows = 0;
+        while ((batch_size < 0 || rows < batch_size) && rd2.next(rec)) {
+            if (rec.size() != nc) fail(NQE_ERR_ARROW, "csv: record with a different number of fields than the schema");
+            for (size_t c = 0; c < nc; ++c) {
+                const std::string &f = rec[c];
+                if (dts[c] == NQE_UTF8) {
+                    Arr tmp;
+                    tmp.dtype = NQE_UTF8;
+                    tmp.offs = {0, int32_t(f.size())};
+                    tmp.data = f;
+                    bs[c].append_str(true, tmp, 0);
+                } else if (f.empty()) {
+                    if (dts[c] == NQE_BOOLEAN) bs[c].append_bool(false, false);
+                    else bs[c].append_word(false, 0);
+                } else if (dts[c] == NQE_BOOLEAN) {
+                    if (csv_ieq(f, "true")) bs[c].append_bool(true, true);
+                    else if (csv_ieq(f, "false")) bs[c].append_bool(true, false);
+                    else fail(NQE_ERR_ARROW, "csv: error while parsing a Boolean value");
+                } else if (dts[c] == NQE_INT64) {
+                    size_t k = (f[0] == '+' || f[0] == '-') ? 1 : 0;
+                    if (!csv_all_digits(f, k, f.size())) fail(NQE_ERR_ARROW, "csv: error while parsing an Int64 value");
+                    errno = 0;
+                    long long v = strtoll(f.c_str(), nullptr, 10);
+                    if (errno) fail(NQE_ERR_ARROW, "csv: Int64 overflow");
+                    bs[c].append_word(true, uint64_t(v));
+                } else {
+                    if (!csv_float_grammar(f)) fail(NQE_ERR_ARROW, "csv: error while parsing a Float64 value");
+                    bs[c].append_word(true, f64_bits(strtod(f.c_str(), nullptr)));
+                }
+            }
+            ++rows;
+        }
+        auto *ob = new orc_batches;
+        Batch bt;
+        bt.rows = rows;
+        for (size_t c = 0; c < nc; ++c) {
+            ob->dtypes.push_back(dts[c]);
+            bt.cols.push_back(bs[c].a);
+        }
+        ob->batches.push_back(std::move(bt));
+        *out = ob;
+        std::string joined;
+        for (auto &nm : names) { joined += nm; joined.push_back('\0'); }
+        if (int64_t(joined.size()) > names_cap || int32_t(nc) > nullable_cap) { delete ob; fail(NQE_ERR_INVALID_ARGUMENT, "csv: output buffers too small"); }
+        std::memcpy(names_out, joined.data(), joined.size());
+        for (size_t c = 0; c < nc; ++c) nullable_out[c] = nul[c];
+    });
+}
+
 int orc_synth_fill(int32_t kind, uint64_t seed, int64_t first_row, int64_t n, uint64_t modulus, int64_t base, void *out) {
     return guarded([&] {
         uint64_t *o = static_cast<uint64_t *>(out);

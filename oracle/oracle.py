@@ -64,6 +64,8 @@ def lib():
         L.orc_xxhash64.restype = C.c_uint64
         L.orc_xxhash64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
         L.orc_synth_fill.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, vp]
+        L.orc_csv_read.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(vp), C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.c_int32]
+        L.orc_csv_read.restype = C.c_int
         _lib = L
     return _lib
 
@@ -211,6 +213,19 @@ def xxhash64_word(w: int) -> int:
 
 def xxhash64(data: bytes, seed: int = 0) -> int:
     return int(lib().orc_xxhash64(data, len(data), seed))
+
+
+def csv_read(data: bytes, has_header: bool = True, delimiter: str = ",", max_read_records: int = 3, batch_size: int = 1_000_000):
+    """CsvTable::try_create on a file image → (names, nullable flags, columns of the first batch)"""
+    out = C.c_void_p()
+    names = C.create_string_buffer(1 << 16)
+    nullable = (C.c_int32 * 256)()
+    _check(lib().orc_csv_read(data, len(data), int(has_header), ord(delimiter), max_read_records, batch_size, C.byref(out), names, len(names), nullable, 256))
+    h = _Handle(out.value)
+    cols = h.to_python()[0]
+    raw = names.raw
+    nm = raw.split(b"\0")[: len(cols)]
+    return [x.decode() for x in nm], [bool(nullable[i]) for i in range(len(cols))], cols
 
 
 def synth_fill(kind: int, seed: int, first_row: int, n: int, modulus: int = 1, base: int = 0):

@@ -71,6 +71,27 @@ int main(int argc, char **argv) {
     Csv t1 = read_csv_numeric(dir + "/test_data.csv", {{"id", DataType::Int64}, {"age", DataType::Int64}, {"score", DataType::Float64}});
     TableRef source = table_of(ctx, t1);
 
+    run("test_infer_schema (csv.rs:113-137)", [&] {
+        TableRef table = CsvTable::try_create(dir + "/test_data.csv", CsvConfig());
+        const NaiveSchema &s = table->schema();
+        const char *names[] = {"id", "name", "age", "score"};
+        const DataType types[] = {DataType::Int64, DataType::Utf8, DataType::Int64, DataType::Float64};
+        CHECK(s.fields().size() == 4);
+        for (size_t i = 0; i < 4; ++i) CHECK(s.field(i).name() == names[i] && s.field(i).data_type == types[i] && !s.field(i).nullable);
+    });
+
+    run("test_read_from_csv (csv.rs:139-170)", [&] {
+        TableRef table = CsvTable::try_create(dir + "/test_data.csv", CsvConfig());
+        auto batches = table->scan(std::nullopt);
+        CHECK(batches.size() == 1 && batches[0].num_columns() == 4 && batches[0].num_rows() == 8);
+        CHECK((batches[0].column(0).to_i64() == std::vector<int64_t>{1, 2, 4, 5, 6, 7, 8, 9}));
+        Array name = batches[0].column(1);
+        const char *exp[] = {"veeupup", "alex", "lynne", "alice", "bob", "jack", "cock", "primer"};
+        for (int i = 0; i < 8; ++i) CHECK(name.str(i) == exp[i]);
+        CHECK((batches[0].column(2).to_i64() == std::vector<int64_t>{23, 20, 18, 19, 20, 21, 22, 23}));
+        CHECK((batches[0].column(3).to_f64() == std::vector<double>{60.0, 90.1, 99.99, 81.1, 82.2, 83.3, 84.4, 85.5}));
+    });
+
     run("test_physical_scan (scan.rs:51-78)", [&] {
         auto res = ScanPlan::create(source, std::nullopt)->execute();
         CHECK(res.size() == 1 && res[0].num_columns() == 3);

@@ -113,6 +113,32 @@ if SECTION in ("all", "exprs"):
     ctx.timing_enable(False)
     print("   agg kernels(ms):", {k: round(ctx.timing_query(k)[0], 3) for k in ("expr_tree", "agg_grouped_fast", "agg_grouped", "agg_table_init", "agg_collect", "agg_finalize")})
 
+# ---- 2c. CSV ingest: 1M rows (the reference keeps only the first 1M-row batch, quirk Q1)
+if SECTION in ("all", "csv"):
+    from oracle import oracle as orc
+    rng = np.random.default_rng(0)
+    m = 1_000_000
+    ids = np.arange(m)
+    price = rng.random(m) * 1000
+    qty = rng.integers(-10**9, 10**9, m)
+    names = np.array(["alice", "bob", "carol", "dave", "eve", "mallory, \"the\" quoted"])[rng.integers(0, 6, m)]
+    lines = ["id,price,qty,name"] + [f'{i},{p!r},{q},"{nm.replace(chr(34), chr(34) * 2)}"' if "," in nm else f"{i},{p!r},{q},{nm}" for i, p, q, nm in zip(ids, price, qty, names)]
+    data = ("\n".join(lines) + "\n").encode()
+    t0 = time.perf_counter(); nm_, dts, _ = ctx.csv_infer_schema(data); t_inf = time.perf_counter() - t0
+    q_host = timeit(lambda: ctx.csv_read(data, dts), reps=5, warm=2)
+    padded = data + b"\0" * ((-len(data)) % 8)
+    holder = ctx.table_from_host([Column.from_numpy(np.frombuffer(padded, dtype=np.uint64).copy())])
+    dptr = int(holder.column_info(0).values)
+    q_dev = timeit(lambda: ctx.csv_read(None, dts, device_ptr=dptr, nbytes=len(data)), reps=5, warm=2)
+    ctx.timing_enable(True); ctx.timing_reset()
+    r = ctx.csv_read(None, dts, device_ptr=dptr, nbytes=len(data)); del r
+    ctx.timing_enable(False)
+    br = {k: round(ctx.timing_query(k)[0], 3) for k in ("csv_vec", "csv_block_scan", "csv_mark_count", "csv_mark_write", "csv_fields", "csv_fields_copy", "scan_", "pack_bytes")}
+    t0 = time.perf_counter(); o = orc.csv_read(data); t_cpu = time.perf_counter() - t0
+    print(f"csv {m} rows, {len(data)/1e6:.1f} MB: infer {t_inf*1e3:.2f} ms (host); read from host bytes {q_host*1e3:.2f} ms ({len(data)/q_host/1e9:.2f} GB/s), "
+          f"HBM-resident image {q_dev*1e3:.2f} ms ({len(data)/q_dev/1e9:.2f} GB/s = {m/q_dev:.3e} rows/s); oracle (1 thread) {t_cpu*1e3:.0f} ms ({len(data)/t_cpu/1e9:.3f} GB/s)")
+    print("   kernels(ms):", br)
+
 # ---- 3. high-cardinality group-by
 for groups in ((1 << 10, 1 << 12, 1 << 14, 1 << 17, 1 << 20, 1 << 24) if SECTION in ('all', 'groups') else ()):
     kt = torch.empty(n, dtype=torch.int64, device=dev)
