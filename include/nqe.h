@@ -123,12 +123,14 @@ typedef struct nqe_expr_node {
     int32_t column;  /* COLUMN: index into the input batch */
     int32_t dtype;   /* LITERAL: nqe_dtype of the ScalarValue */
     int32_t is_null; /* LITERAL: 1 = ScalarValue::X(None) */
-    int32_t reserved;
+    int32_t utf8_length; /* LITERAL of dtype NQE_UTF8: byte length of value.utf8 (the field was `reserved` before Utf8
+                            literals existed; the struct layout is unchanged) */
     union {
         int64_t i64;
         uint64_t u64;
         double f64;
-        int64_t boolean; /* 0 / 1 */
+        int64_t boolean;  /* 0 / 1 */
+        const char *utf8; /* ScalarValue::Utf8(Some(s)): borrowed for the duration of the call, not NUL-terminated */
     } value;
 } nqe_expr_node;
 

@@ -105,7 +105,7 @@ class NqeColumn(C.Structure):
 
 
 class _NodeValue(C.Union):
-    _fields_ = [("i64", C.c_int64), ("u64", C.c_uint64), ("f64", C.c_double), ("boolean", C.c_int64)]
+    _fields_ = [("i64", C.c_int64), ("u64", C.c_uint64), ("f64", C.c_double), ("boolean", C.c_int64), ("utf8", C.c_void_p)]
 
 
 class NqeExprNode(C.Structure):
@@ -115,7 +115,7 @@ class NqeExprNode(C.Structure):
         ("column", C.c_int32),
         ("dtype", C.c_int32),
         ("is_null", C.c_int32),
-        ("reserved", C.c_int32),
+        ("utf8_length", C.c_int32),
         ("value", _NodeValue),
     ]
 
@@ -178,6 +178,10 @@ class ScalarValue:
     @staticmethod
     def UInt64(v: Optional[int]) -> "ScalarValue":
         return ScalarValue(DType.UINT64, v)
+
+    @staticmethod
+    def Utf8(v: Optional[str]) -> "ScalarValue":
+        return ScalarValue(DType.UTF8, v)
 
 
 # ----------------------------------------------------------------------------- Array
@@ -440,8 +444,14 @@ def node_literal(s: ScalarValue) -> NqeExprNode:
             n.value.f64 = float(s.value)
         elif s.dtype == DType.BOOLEAN:
             n.value.boolean = 1 if s.value else 0
+        elif s.dtype == DType.UTF8:
+            raw = s.value.encode() if isinstance(s.value, str) else bytes(s.value)
+            buf = C.create_string_buffer(raw, len(raw) + 1)
+            n._keep = buf  # borrowed by the callee for the duration of the call
+            n.value.utf8 = C.cast(buf, C.c_void_p).value
+            n.utf8_length = len(raw)
         else:
-            raise ErrorCode(Status.NotSupported, "Utf8 literals are not supported on this path")
+            raise ErrorCode(Status.NotSupported, "literal type")
     return n
 
 
@@ -454,6 +464,7 @@ def node_binary(op: Operator) -> NqeExprNode:
 
 def nodes_array(nodes: Sequence[NqeExprNode]):
     arr = (NqeExprNode * max(1, len(nodes)))()
+    arr._keep = [getattr(nd, "_keep", None) for nd in nodes]  # Utf8 literal bytes referenced by the copied structs
     for i, nd in enumerate(nodes):
         arr[i] = nd
     return arr

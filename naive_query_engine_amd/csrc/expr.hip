@@ -19,6 +19,7 @@ struct Node {
     int kind = 0, op = 0, column = 0, dtype = 0;
     bool lit_null = false;
     uint64_t lit = 0;
+    std::string lit_str;       // Utf8 literal
     int left = -1, right = -1; // children (indices into the node vector)
     int out_dtype = NQE_NULLTYPE;
 };
@@ -46,7 +47,13 @@ std::vector<Node> parse(const nqe_table *in, const nqe_expr_node *nodes, int n, 
             x.lit_null = nd.is_null != 0 || nd.dtype == NQE_NULLTYPE;
             x.lit = nd.dtype == NQE_BOOLEAN ? uint64_t(nd.value.boolean != 0) : nd.value.u64;
             x.out_dtype = nd.dtype;
-            if (nd.dtype == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 literals are not supported on the device path");
+            if (nd.dtype == NQE_UTF8) {
+                x.lit = 0;
+                if (!x.lit_null) {
+                    if (nd.utf8_length < 0 || (nd.utf8_length > 0 && !nd.value.utf8)) fail(NQE_ERR_INVALID_ARGUMENT, "Utf8 literal without bytes");
+                    x.lit_str.assign(nd.value.utf8 ? nd.value.utf8 : "", size_t(nd.utf8_length));
+                }
+            }
         } else if (nd.kind == NQE_EXPR_BINARY) {
             if (st.size() < 2) fail(NQE_ERR_INVALID_ARGUMENT, "malformed expression");
             x.right = st.back(); st.pop_back();
@@ -58,7 +65,6 @@ std::vector<Node> parse(const nqe_table *in, const nqe_expr_node *nodes, int n, 
                                            std::to_string(rdt));
             if (is_compare(x.op)) {
                 if (ldt == NQE_NULLTYPE) fail(NQE_ERR_ARROW, "comparison on Null arrays is not supported");
-                if (ldt == NQE_UTF8) fail(NQE_ERR_NOT_SUPPORTED, "Utf8 comparison is not supported on the device path yet");
                 x.out_dtype = NQE_BOOLEAN;
             } else if (is_logic(x.op)) {
                 if (ldt != NQE_BOOLEAN) // binary_op! (binary.rs:32-42)
@@ -138,6 +144,7 @@ bool match_simple(const std::vector<Node> &t, int i, SimpleExpr *s) {
     } else {
         return false;
     }
+    if (litn->dtype == NQE_UTF8) return false; // string compares have their own kernel
     if (!match_simple(t, sub, s) || s->nops >= 2) return false;
     int k = s->nops++;
     s->op[k] = x.op;
@@ -552,6 +559,7 @@ bool build_program(const nqe_table *in, const std::vector<Node> &t, int root, Ex
         const Node &x = t[size_t(idx)];
         if (x.kind == NQE_EXPR_BINARY) { *src = EX_STACK; return; }
         if (x.kind == NQE_EXPR_LITERAL) {
+            if (x.dtype == NQE_UTF8) { fits = false; return; }
             *src = x.lit_null ? EX_LIT_NULL : EX_LIT;
             *lit = x.lit;
             *needs_valid |= x.lit_null;
@@ -593,6 +601,7 @@ struct Value {
     bool is_lit = false;
     bool lit_null = false;
     uint64_t lit = 0;
+    std::string lit_str;
     int dtype = NQE_NULLTYPE;
     DevColumn col;
 };
@@ -638,12 +647,17 @@ Value eval_node(nqe_ctx *ctx, const nqe_table *in, const std::vector<Node> &t, i
     if (x.kind == NQE_EXPR_LITERAL) {
         v.is_lit = true;
         v.lit = x.lit;
+        v.lit_str = x.lit_str;
         v.lit_null = x.lit_null;
         return v;
     }
     Value l = eval_node(ctx, in, t, x.left);
     Value r = eval_node(ctx, in, t, x.right);
     const int64_t n = in->rows;
+    if (l.dtype == NQE_UTF8) { // only compares reach here (parse)
+        v.col = utf8_compare(ctx, x.op, l.is_lit ? nullptr : &l.col, l.lit_str, l.lit_null, r.is_lit ? nullptr : &r.col, r.lit_str, r.lit_null, n);
+        return v;
+    }
     if (l.is_lit && r.is_lit) { // lit op lit: materialise one side, as into_array would
         l.col = materialise_literal(ctx, l.dtype, l.lit, l.lit_null, n);
         l.is_lit = false;
@@ -729,6 +743,7 @@ DevColumn evaluate_expr(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         return out;
     }
     Value v = eval_node(ctx, in, t, root);
+    if (v.is_lit && v.dtype == NQE_UTF8) return utf8_literal_column(ctx, v.lit_str, v.lit_null, in->rows);
     if (v.is_lit) return materialise_literal(ctx, v.dtype, v.lit, v.lit_null, in->rows);
     return v.col;
 }

@@ -257,6 +257,10 @@ DevColumn compact_column(nqe_ctx *ctx, const DevColumn &src, const KeepMask &km)
 DevColumn compact_gather_column(nqe_ctx *ctx, const DevColumn &src, const uint32_t *gidx, const KeepMask &km);
 // scans the per-tile counts into km.tile_offsets and reads back km.total
 KeepMask finish_mask(nqe_ctx *ctx, KeepMask km, BufRef tile_counts);
+// Utf8 comparison; a null column pointer means that side is the literal (lit, lit_null)
+DevColumn utf8_compare(nqe_ctx *ctx, int op, const DevColumn *lcol, const std::string &llit, bool llit_null, const DevColumn *rcol,
+                       const std::string &rlit, bool rlit_null, int64_t n);
+DevColumn utf8_literal_column(nqe_ctx *ctx, const std::string &lit, bool lit_null, int64_t n);
 // general tree `nodes` over the rows of `km`, compacted in the same pass; false = does not fit the stack machine
 bool evaluate_expr_compacted(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, int n, const KeepMask &km, DevColumn *result);
 // evaluates `e` over `in` and compacts the result in the same pass

@@ -115,5 +115,9 @@ def lit_bool(v) -> PhysicalLiteralExpr:
     return PhysicalLiteralExpr.create(ScalarValue.Boolean(v))
 
 
+def lit_utf8(v) -> PhysicalLiteralExpr:
+    return PhysicalLiteralExpr.create(ScalarValue.Utf8(v))
+
+
 def binop(l, op, r) -> PhysicalBinaryExpr:
     return PhysicalBinaryExpr.create(l, op, r)

@@ -52,6 +52,7 @@ struct ScalarValue { // :174-187
     DataType dtype = DataType::Null;
     bool is_null = true;
     nqe_expr_node node{};
+    std::string str; // Utf8 payload (the node's pointer is bound when the expression is flattened)
     static ScalarValue make(DataType dt, bool null) {
         ScalarValue s;
         s.dtype = dt;
@@ -66,6 +67,7 @@ struct ScalarValue { // :174-187
     static ScalarValue UInt64(std::optional<uint64_t> v) { auto s = make(DataType::UInt64, !v); if (v) s.node.value.u64 = *v; return s; }
     static ScalarValue Float64(std::optional<double> v) { auto s = make(DataType::Float64, !v); if (v) s.node.value.f64 = *v; return s; }
     static ScalarValue Boolean(std::optional<bool> v) { auto s = make(DataType::Boolean, !v); if (v) s.node.value.boolean = *v ? 1 : 0; return s; }
+    static ScalarValue Utf8(std::optional<std::string> v) { auto s = make(DataType::Utf8, !v); if (v) s.str = *v; return s; }
 };
 
 struct Column { // logical_plan/expression.rs:167-170
@@ -237,7 +239,14 @@ struct ColumnExpr : PhysicalExpr { // column.rs:18-58
 struct PhysicalLiteralExpr : PhysicalExpr { // literal.rs:17-35
     ScalarValue literal;
     static PhysicalExprRef create(ScalarValue v) { auto e = std::make_shared<PhysicalLiteralExpr>(); e->literal = v; return e; }
-    void flatten(const NaiveSchema &, std::vector<nqe_expr_node> &out) const override { out.push_back(literal.node); }
+    void flatten(const NaiveSchema &, std::vector<nqe_expr_node> &out) const override {
+        nqe_expr_node n = literal.node;
+        if (literal.dtype == DataType::Utf8 && !literal.is_null) { // borrowed: this expression outlives the call
+            n.value.utf8 = literal.str.data();
+            n.utf8_length = int32_t(literal.str.size());
+        }
+        out.push_back(n);
+    }
 };
 
 struct PhysicalBinaryExpr : PhysicalExpr { // binary.rs:91-156

@@ -152,6 +152,7 @@ struct Scalar {
     int dtype = NQE_NULLTYPE;
     bool is_null = true;
     uint64_t word = 0; // i64/u64/f64 bits, or 0/1 for Boolean
+    std::string str;   // Utf8
 };
 
 ArrRef new_null_array(int dtype, int64_t n) {
@@ -177,8 +178,14 @@ ArrRef scalar_into_array(const Scalar &s, int64_t n) {
         a->bits.assign(bm_bytes(n), s.word ? 0xFF : 0x00);
     } else if (is_word_type(s.dtype)) {
         a->v.assign(size_t(n), s.word);
+    } else if (s.dtype == NQE_UTF8) { // StringArray::from_iter_values(repeat(value).take(size))
+        a->offs.push_back(0);
+        for (int64_t i = 0; i < n; ++i) {
+            a->data += s.str;
+            a->offs.push_back(int32_t(a->data.size()));
+        }
     } else {
-        fail(NQE_ERR_NOT_SUPPORTED, "Utf8 literals are not restated in the oracle");
+        fail(NQE_ERR_NOT_SUPPORTED, "literal type");
     }
     return a;
 }
@@ -419,7 +426,9 @@ ExprRef build_expr(const nqe_expr_node *nodes, int n) {
             Scalar s;
             s.dtype = nd.dtype;
             s.is_null = nd.is_null != 0;
-            s.word = nd.dtype == NQE_BOOLEAN ? uint64_t(nd.value.boolean != 0) : nd.value.u64;
+            if (nd.dtype == NQE_UTF8) {
+                if (!s.is_null && nd.value.utf8) s.str.assign(nd.value.utf8, size_t(nd.utf8_length));
+            } else s.word = nd.dtype == NQE_BOOLEAN ? uint64_t(nd.value.boolean != 0) : nd.value.u64;
             st.push_back(std::make_shared<LiteralExpr>(s));
         } else if (nd.kind == NQE_EXPR_BINARY) {
             if (st.size() < 2) fail(NQE_ERR_INVALID_ARGUMENT, "malformed expression");

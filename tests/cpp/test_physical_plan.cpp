@@ -92,6 +92,16 @@ int main(int argc, char **argv) {
         CHECK((batches[0].column(3).to_f64() == std::vector<double>{60.0, 90.1, 99.99, 81.1, 82.2, 83.3, 84.4, 85.5}));
     });
 
+    run("Utf8 predicate on a CsvTable: select id from t1 where name >= 'bob' (binary.rs:127-132 on StringArrays)", [&] {
+        TableRef table = CsvTable::try_create(dir + "/test_data.csv", CsvConfig());
+        auto pred = PhysicalBinaryExpr::create(col("name"), Operator::GtEq, PhysicalLiteralExpr::create(ScalarValue::Utf8(std::string("bob"))));
+        auto sel = SelectionPlan::create(ScanPlan::create(table, std::nullopt), pred);
+        NaiveSchema schema({table->schema().field(0)});
+        auto res = ProjectionPlan::create(sel, schema, {coli(0)})->execute();
+        // names: veeupup alex lynne alice bob jack cock primer -> >= "bob": veeupup lynne bob jack cock primer
+        CHECK((res[0].column(0).to_i64() == std::vector<int64_t>{1, 4, 6, 7, 8, 9}));
+    });
+
     run("test_physical_scan (scan.rs:51-78)", [&] {
         auto res = ScanPlan::create(source, std::nullopt)->execute();
         CHECK(res.size() == 1 && res[0].num_columns() == 3);
