@@ -511,6 +511,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 if (base >= n) break;
                 if (*lds_full && (a.allow_partition || __hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
                     break; // the host redoes the query (partitioned path / larger table)
+                if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    break; // another workgroup's table overflowed: this attempt is abandoned anyway
             }
         }
     } else {
@@ -522,6 +524,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     }
     if (run_live) flush_run();
     __syncthreads();
+    // an abandoned attempt (the host re-runs the query partitioned) does not merge: 2048 slots x 512 workgroups of
+    // device-scope atomics were two thirds of what the abandoned attempt cost
+    if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
         uint64_t k = lkeys[s];
         if (k == EMPTY_KEY) continue;
