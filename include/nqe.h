@@ -160,6 +160,11 @@ uint32_t nqe_abi_version(void);
 nqe_status nqe_ctx_create(int32_t device, void *stream, nqe_ctx **out);
 nqe_status nqe_ctx_destroy(nqe_ctx *ctx);
 nqe_status nqe_ctx_synchronize(nqe_ctx *ctx);
+/* Device memory of the context: bytes held by live tables/handles, and bytes cached in the context's block pool
+ * (released blocks are reused stream-ordered; a failed hipMalloc trims the pool and retries).  nqe_ctx_trim returns
+ * the cached blocks to the driver (after a stream synchronisation). */
+nqe_status nqe_ctx_memory_stats(nqe_ctx *ctx, int64_t *live_bytes, int64_t *pooled_bytes);
+nqe_status nqe_ctx_trim(nqe_ctx *ctx);
 const char *nqe_last_error(const nqe_ctx *ctx);
 /* global message for failures with no ctx (nqe_ctx_create itself) */
 const char *nqe_last_global_error(void);

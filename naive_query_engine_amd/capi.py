@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libnqe_hip.so")
 
 # every symbol include/nqe.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
-    "nqe_abi_version", "nqe_ctx_create", "nqe_ctx_destroy", "nqe_ctx_synchronize", "nqe_last_error",
+    "nqe_abi_version", "nqe_ctx_create", "nqe_ctx_destroy", "nqe_ctx_synchronize", "nqe_ctx_memory_stats", "nqe_ctx_trim", "nqe_last_error",
     "nqe_last_global_error", "nqe_ctx_timing_enable", "nqe_ctx_timing_query", "nqe_ctx_timing_reset",
     "nqe_table_create", "nqe_table_release", "nqe_table_num_rows", "nqe_table_num_columns", "nqe_table_column",
     "nqe_table_download_column", "nqe_table_project", "nqe_table_slice", "nqe_table_concat", "nqe_table_pack_words",
@@ -54,6 +54,8 @@ def lib():
         "nqe_ctx_synchronize": (i32, [vp]),
         "nqe_last_error": (C.c_char_p, [vp]),
         "nqe_last_global_error": (C.c_char_p, []),
+        "nqe_ctx_memory_stats": (i32, [vp, C.POINTER(i64), C.POINTER(i64)]),
+        "nqe_ctx_trim": (i32, [vp]),
         "nqe_ctx_timing_enable": (i32, [vp, i32]),
         "nqe_ctx_timing_query": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
         "nqe_ctx_timing_reset": (i32, [vp]),
@@ -126,6 +128,15 @@ class Context:
 
     def timing_reset(self):
         self.check(lib().nqe_ctx_timing_reset(self.handle))
+
+    def memory_stats(self):
+        """(bytes held by live handles, bytes cached in the block pool)"""
+        live, pooled = C.c_int64(), C.c_int64()
+        self.check(lib().nqe_ctx_memory_stats(self.handle, C.byref(live), C.byref(pooled)))
+        return live.value, pooled.value
+
+    def trim(self) -> None:
+        self.check(lib().nqe_ctx_trim(self.handle))
 
     def timing_query(self, name_substr: str = ""):
         ms, cnt = C.c_double(), C.c_int64()

@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
 //     tiles), so waits are counted `s_waitcnt vmcnt(k)` and a wave keeps a tile in flight while it
 //     computes.
 // PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column.
-template <int PRED, int KEY, int NVT, bool VF64>
+template <int PRED, int KEY, int NVT, bool VF64, bool VNULL>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
@@ -423,10 +423,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
     const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
     const uint64_t *__restrict__ valp[NVT];
+    const uint64_t *__restrict__ vvalid[NVT]; // VNULL: validity bitmaps of the value columns (word-padded), null = all valid
     int vdt[NVT];
 #pragma unroll
     for (int j = 0; j < NVT; ++j) {
         valp[j] = static_cast<const uint64_t *>(a.val[j].values);
+        vvalid[j] = reinterpret_cast<const uint64_t *>(a.val[j].valid);
         vdt[j] = a.val[j].dtype;
     }
     const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
@@ -437,6 +439,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     constexpr bool PIPE = true, NT = true; // both measured wins (prefetched second tile: 3.24 -> 2.69 ms with the lean loop; nt loads: -2..3 %)
     struct Tile {
         uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
+        uint64_t vv[VNULL ? NVT : 1][AGG_U]; // validity word of the wave's 64 rows
     };
     auto load_tile = [&](Tile &t, int64_t base) {
 #pragma unroll
@@ -448,6 +451,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
+                if (VNULL) {
+#pragma unroll
+                    for (int j = 0; j < NVT; ++j) t.vv[j][u] = vvalid[j] ? vvalid[j][row >> 6] : ~0ull;
+                }
             } else {
                 t.kw[u] = keyp[row];
                 if (PRED == 2) t.pw[u] = predp[row >> fp.row_shift];
@@ -484,11 +491,23 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 #pragma unroll
             for (int j = 0; j < NVT; ++j) {
                 double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
-                rcnt[j] += 1;
-                rsum[j] += x;
-                rnan[j] = rnan[j] || (x != x);
-                rmn[j] = fmin(rmn[j], x); // NaN operand ignored
-                rmx[j] = fmax(rmx[j], x);
+                if (VNULL) {
+                    // a NULL value contributes nothing (count of non-null, Q10) but its row still creates the group:
+                    // branch-free — count += bit, sum += 0, and a NaN operand that min/max ignore and the flag skips
+                    const bool vb = (t.vv[j][u] >> (row & 63)) & 1ull;
+                    rcnt[j] += vb ? 1u : 0u;
+                    rsum[j] += vb ? x : 0.0;
+                    rnan[j] = rnan[j] || (vb && x != x);
+                    const double xm = vb ? x : __builtin_nan("");
+                    rmn[j] = fmin(rmn[j], xm);
+                    rmx[j] = fmax(rmx[j], xm);
+                } else {
+                    rcnt[j] += 1;
+                    rsum[j] += x;
+                    rnan[j] = rnan[j] || (x != x);
+                    rmn[j] = fmin(rmn[j], x); // NaN operand ignored
+                    rmx[j] = fmax(rmx[j], x);
+                }
             }
         }
     };
@@ -982,22 +1001,22 @@ GroupedKernel pick_grouped_kernel(int pred, int key, bool plain) {
 }
 
 using FastKernel = void (*)(AggArgs, FastPred, GroupTable, int *);
-template <int PRED, int KEY> FastKernel pick_fast_nv(int nv, bool vf64) {
-    if (nv == 1) return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true> : agg_grouped_fast_kernel<PRED, KEY, 1, false>;
-    return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true> : agg_grouped_fast_kernel<PRED, KEY, 2, false>;
+template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64) {
+    if (nv == 1) return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 1, false, VNULL>;
+    return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 2, false, VNULL>;
 }
-template <int PRED> FastKernel pick_fast_key(int key, int nv, bool vf64) {
+template <int PRED> FastKernel pick_fast_key(int key, int nv, bool vf64, bool vnull) {
     switch (key) {
-    case 0: return pick_fast_nv<PRED, 0>(nv, vf64);
-    case 1: return pick_fast_nv<PRED, 1>(nv, vf64);
-    default: return pick_fast_nv<PRED, 2>(nv, vf64);
+    case 0: return vnull ? pick_fast_nv<PRED, 0, true>(nv, vf64) : pick_fast_nv<PRED, 0, false>(nv, vf64);
+    case 1: return vnull ? pick_fast_nv<PRED, 1, true>(nv, vf64) : pick_fast_nv<PRED, 1, false>(nv, vf64);
+    default: return vnull ? pick_fast_nv<PRED, 2, true>(nv, vf64) : pick_fast_nv<PRED, 2, false>(nv, vf64);
     }
 }
-FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64) {
+FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull) {
     switch (pred) {
-    case 0: return pick_fast_key<0>(key, nv, vf64);
-    case 1: return pick_fast_key<1>(key, nv, vf64);
-    default: return pick_fast_key<2>(key, nv, vf64);
+    case 0: return pick_fast_key<0>(key, nv, vf64, vnull);
+    case 1: return pick_fast_key<1>(key, nv, vf64, vnull);
+    default: return pick_fast_key<2>(key, nv, vf64, vnull);
     }
 }
 
@@ -1565,12 +1584,14 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             a.nv = std::min(NV, V - v0);
             if (a.nv < 0) a.nv = 0;
             a.v0 = v0;
+            bool valid_words_ok = true; // validity bitmaps readable as whole 64-bit words (owned buffers are padded)
             for (int j = 0; j < NV; ++j) {
                 std::memset(&a.val[j], 0, sizeof(ColSrc));
                 a.val_shares_key[j] = a.need_sum[j] = a.need_minmax[j] = 0;
                 if (j < a.nv) {
                     int c = plan.val_cols[size_t(v0 + j)];
                     const DevColumn &dc = in->cols[size_t(c)];
+                    if (dc.validity && !dc.validity->owned && (dc.length % 64) != 0) valid_words_ok = false;
                     a.val[j] = src_of(dc);
                     if (!is_word_type(dc.dtype)) a.val[j].values = nullptr; // count-only over Boolean/Utf8: validity only
                     a.need_sum[j] = plan.need_sum[size_t(v0 + j)];
@@ -1620,7 +1641,14 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 const bool bitmap_pred = a.pred_src.dtype == NQE_BOOLEAN && !a.pred_src.valid &&
                                          (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
                 if (a.pred_mode == 1 && !bitmap_pred) plain = plain && is_word_type(a.pred_src.dtype) && !a.pred_src.valid;
-                for (int j = 0; j < a.nv; ++j) plain = plain && a.val[j].values && !a.val[j].valid;
+                // value columns may carry validity bitmaps (VNULL variants of the fast kernel); the partitioned path and
+                // everything else nullable stays with the general kernel
+                bool vnull = false;
+                for (int j = 0; j < a.nv; ++j) {
+                    plain = plain && a.val[j].values;
+                    vnull = vnull || a.val[j].valid != nullptr;
+                }
+                if (vnull && (partition_mode || !valid_words_ok)) plain = false;
                 FastPred fpred{};
                 if (bitmap_pred) fpred = bitmap_fast_pred();
                 bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || bitmap_pred || (pk == 1 && make_fast_pred(a.pred, &fpred)));
@@ -1690,11 +1718,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         }
                     } else {
                         ka.allow_partition = in->rows >= (int64_t(1) << 18) ? 1 : 0;
-                        launch(ctx, "agg_grouped_fast", pick_fast_kernel(fp, fast_key, a.nv, vf64), dim3(grid), dim3(AGG_BLOCK), shmem, ka,
+                        launch(ctx, "agg_grouped_fast", pick_fast_kernel(fp, fast_key, a.nv, vf64, vnull), dim3(grid), dim3(AGG_BLOCK), shmem, ka,
                                fpred, tb.g, ctx->d_flags);
                     }
                 } else {
-                    launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain), dim3(grid), dim3(AGG_BLOCK), shmem, ka, tb.g,
+                    launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain && !vnull), dim3(grid), dim3(AGG_BLOCK), shmem, ka, tb.g,
                            ctx->d_flags);
                 }
             } else {

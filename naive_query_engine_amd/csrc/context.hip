@@ -527,6 +527,22 @@ nqe_status nqe_ctx_synchronize(nqe_ctx *ctx) {
     NQE_API_END()
 }
 
+nqe_status nqe_ctx_memory_stats(nqe_ctx *ctx, int64_t *live_bytes, int64_t *pooled_bytes) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx) fail(NQE_ERR_INVALID_ARGUMENT, "null context");
+    if (live_bytes) *live_bytes = int64_t(ctx->live_bytes);
+    if (pooled_bytes) *pooled_bytes = int64_t(ctx->pool_bytes);
+    NQE_API_END()
+}
+
+nqe_status nqe_ctx_trim(nqe_ctx *ctx) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx) fail(NQE_ERR_INVALID_ARGUMENT, "null context");
+    sync(ctx);
+    pool_trim(ctx);
+    NQE_API_END()
+}
+
 const char *nqe_last_error(const nqe_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 nqe_status nqe_ctx_timing_enable(nqe_ctx *ctx, int32_t enable) {

@@ -546,6 +546,19 @@ def test_all_valid_bitmaps_are_dropped_at_table_creation(ctx):
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0, 5], what=f"n={n}")
 
 
+def test_memory_stats_and_trim(ctx):
+    ctx.synchronize()
+    live0, _ = ctx.memory_stats()
+    t = ctx.table_from_host([Column.from_numpy(np.arange(1 << 20, dtype=np.int64))])
+    live1, _ = ctx.memory_stats()
+    assert live1 - live0 >= 8 << 20
+    del t
+    live2, pooled2 = ctx.memory_stats()
+    assert live2 <= live0 and pooled2 >= 8 << 20          # the block went back to the pool
+    ctx.trim()
+    assert ctx.memory_stats()[1] == 0
+
+
 def test_take_slice_concat_project(ctx):
     rng = np.random.default_rng(3)
     cols = random_batch(rng, 1000, 0.2, with_bool=True)
