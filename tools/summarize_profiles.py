@@ -20,6 +20,10 @@ for f in sorted(os.listdir(src)):
                                "cpu_baseline_rows_per_s": d.get("cpu_baseline", {}).get("value")}
         except Exception as e:  # noqa: BLE001
             summary[f[:-5]] = {"error": str(e)}
+for f in sorted(os.listdir(src)):
+    if f.startswith("probe_") and f.endswith(".txt"):  # tools/probe_paths.py / probe_exchange.py diagnostics quoted in DESIGN.md
+        lines = [l for l in open(os.path.join(src, f), errors="replace").read().splitlines() if "amdgpu.ids" not in l and not l.startswith("Hostname") and "Librccl" not in l]
+        open(os.path.join(dst, f), "w").write("\n".join(lines) + "\n")
 for w in ("headline", "c2", "c3", "c4"):
     p = os.path.join(src, f"prof_{w}", f"{w}_kernel_stats.csv")
     if os.path.exists(p):
