@@ -1653,7 +1653,9 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 if (bitmap_pred) fpred = bitmap_fast_pred();
                 bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || bitmap_pred || (pk == 1 && make_fast_pred(a.pred, &fpred)));
                 if (fast) {
-                    int fp = pk == 0 ? 0 : ((a.pred_shares_key && !bitmap_pred) ? 1 : 2);
+                    // variant 1 tests the key word with the integer range test alone; Float64 predicates and bitmaps use the
+                    // "other column" variant, whose extraction step applies the order mapping
+                    int fp = pk == 0 ? 0 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2);
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
                     if (partition_mode) {
@@ -1738,7 +1740,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 bool upred_ok = a.pred_mode == 0 || ubitmap ||
                                 (a.pred_mode == 1 && is_word_type(a.pred_src.dtype) && !a.pred_src.valid && make_fast_pred(a.pred, &ufp));
                 if (uplain && upred_ok) {
-                    int up = a.pred_mode == 0 ? 0 : ((a.pred_src.values == a.val[0].values && !ubitmap) ? 1 : 2);
+                    int up = a.pred_mode == 0 ? 0 : ((a.pred_src.values == a.val[0].values && !ubitmap && !ufp.fmask) ? 1 : 2);
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
                     launch(ctx, "agg_ungrouped_fast", pick_ungrouped_fast(up, a.nv, vf64), dim3(grid), dim3(AGG_BLOCK), 0, a, ufp,

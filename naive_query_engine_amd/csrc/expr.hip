@@ -8,6 +8,9 @@
 //     (logical_plan/expression.rs:210-222, the TODO at binary.rs:121);
 //   * fused:   `col [op lit]{0,2}` shapes (SimpleExpr) are evaluated inside the consumer
 //     kernel (compaction, aggregation) from the streamed word — no temporary at all.
+#include <cmath>
+#include <cstring>
+
 #include "device_utils.hpp"
 #include "nqe_internal.hpp"
 
@@ -680,17 +683,49 @@ Value eval_node(nqe_ctx *ctx, const nqe_table *in, const std::vector<Node> &t, i
 // `x op lit` (x Int64/UInt64) → range test. Returns false if the shape is not covered.
 bool make_fast_pred(const SimpleExpr &pe, FastPred *fp) {
     if (pe.nops != 1 || pe.op[0] > NQE_OP_GT_EQ) return false;
-    if (pe.src_dtype != NQE_INT64 && pe.src_dtype != NQE_UINT64) return false;
+    if (pe.src_dtype != NQE_INT64 && pe.src_dtype != NQE_UINT64 && pe.src_dtype != NQE_FLOAT64) return false;
     static const int flip_op[6] = {NQE_OP_EQ, NQE_OP_NOT_EQ, NQE_OP_GT, NQE_OP_GT_EQ, NQE_OP_LT, NQE_OP_LT_EQ};
     int op = pe.lit_left[0] ? flip_op[pe.op[0]] : pe.op[0]; // lit op x  ≡  x op' lit
-    fp->flip = pe.src_dtype == NQE_UINT64 ? 0x8000000000000000ull : 0ull;
-    const int64_t L = int64_t(pe.lit[0] ^ fp->flip);
     const int64_t MIN = INT64_MIN, MAX = INT64_MAX;
     fp->negate = 0;
     fp->pad = 0;
     fp->row_shift = 0;
     fp->bit_mask = 0;
     fp->val_mask = ~0ull;
+    fp->fmask = 0;
+    if (pe.src_dtype == NQE_FLOAT64) {
+        // IEEE compares as an integer range over the order-preserving image ord(x) = x ^ ((x >> 63) & 0x7fff…f) (signed):
+        // every NaN maps beyond ord(±inf), so a range inside [ord(-inf), ord(+inf)] is false for NaN, and the negated
+        // range (!=) is true for NaN — exactly arrow's lt/gt/eq/neq on Float64.  ±0 compare equal: the bound uses
+        // whichever zero makes the range include / exclude both.
+        fp->flip = 0;
+        fp->fmask = 0x7fffffffffffffffull;
+        auto ord = [](double d) {
+            uint64_t b;
+            std::memcpy(&b, &d, 8);
+            return int64_t(b ^ (uint64_t(int64_t(b) >> 63) & 0x7fffffffffffffffull));
+        };
+        double c;
+        std::memcpy(&c, &pe.lit[0], 8);
+        const int64_t NINF = ord(-HUGE_VAL), PINF = ord(HUGE_VAL);
+        if (c != c) { // NaN literal: every compare is false, != is true
+            fp->lo = 1; fp->hi = 0;
+            fp->negate = op == NQE_OP_NOT_EQ ? 1 : 0;
+            return true;
+        }
+        const int64_t c_lo = ord(c == 0.0 ? -0.0 : c), c_hi = ord(c == 0.0 ? 0.0 : c); // image of {x : x == c}
+        switch (op) {
+        case NQE_OP_EQ: fp->lo = c_lo; fp->hi = c_hi; break;
+        case NQE_OP_NOT_EQ: fp->lo = c_lo; fp->hi = c_hi; fp->negate = 1; break;
+        case NQE_OP_LT: fp->lo = NINF; fp->hi = c_lo - 1; break;   // c = -inf: empty (hi < lo)
+        case NQE_OP_LT_EQ: fp->lo = NINF; fp->hi = c_hi; break;
+        case NQE_OP_GT: fp->lo = c_hi + 1; fp->hi = PINF; break;   // c = +inf: empty
+        default: fp->lo = c_lo; fp->hi = PINF; break;
+        }
+        return true;
+    }
+    fp->flip = pe.src_dtype == NQE_UINT64 ? 0x8000000000000000ull : 0ull;
+    const int64_t L = int64_t(pe.lit[0] ^ fp->flip);
     switch (op) {
     case NQE_OP_EQ: fp->lo = L; fp->hi = L; break;
     case NQE_OP_NOT_EQ: fp->lo = L; fp->hi = L; fp->negate = 1; break;
@@ -708,6 +743,7 @@ FastPred bitmap_fast_pred() {
     fp.row_shift = 6;
     fp.bit_mask = 63;
     fp.val_mask = 1;
+    fp.fmask = 0;
     return fp;
 }
 

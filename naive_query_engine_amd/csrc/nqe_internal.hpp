@@ -220,10 +220,13 @@ struct FastPred {
     int32_t bit_mask;  // 0 | 63
     int32_t pad;
     uint64_t val_mask; // ~0 | 1
+    // Float64 operands: x ^= (x >> 63 arithmetic) & fmask with fmask = 0x7fff…f maps IEEE doubles to signed integers in
+    // the same order (negative values reversed); NaNs land beyond ±inf and are excluded by [lo, hi].  0 for integers.
+    uint64_t fmask;
 };
 // FastPred "bit r of a non-null Boolean bitmap is set"
 FastPred bitmap_fast_pred();
-// returns false when the SimpleExpr is not a single integer compare against a literal
+// returns false when the SimpleExpr is not a single Int64/UInt64/Float64 compare against a literal
 bool make_fast_pred(const SimpleExpr &pe, FastPred *fp);
 
 struct ExprInfo {

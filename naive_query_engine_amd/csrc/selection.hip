@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) keep_from_pred_kernel(const uint8_t *pbit
 // predicate = SimpleExpr over one streamed column; wave per tile, 64 rows per step.
 // RANGE: the predicate is an integer `col cmp lit` over a plain 8-byte column without validity →
 // branch-free range test, clamped unconditional loads, 8 loads in flight per wave.
-template <bool RANGE>
+template <int RANGE> // 0: any SimpleExpr; 1: integer range test; 2: Float64 range test (order-mapped)
 __global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *values, const uint8_t *valid, SimpleExpr e, FastPred fp,
                                                                int64_t n, int64_t ntiles, uint64_t *keep, uint64_t *pvalid_out,
                                                                uint32_t *tile_counts, int *flags) {
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *value
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
-                    uint64_t kw = __ballot(row < n && range_pass(fp, v[k]));
+                    uint64_t kw = __ballot(row < n && range_pass(fp, RANGE == 2 ? f64_order_map(fp, v[k]) : v[k]));
                     if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
                     total += __popcll(kw);
                 }
@@ -247,11 +247,14 @@ KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleE
     const bool range = is_word_type(c.dtype) && !c.validity && make_fast_pred(pred, &fp);
     if (km.ntiles) {
         dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
-        if (range)
-            launch(ctx, "keep_from_simple", keep_from_simple_kernel<true>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred, fp,
+        if (range && fp.fmask)
+            launch(ctx, "keep_from_simple", keep_from_simple_kernel<2>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred, fp,
+                   km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint64_t *)nullptr, (uint32_t *)counts->ptr, ctx->d_flags);
+        else if (range)
+            launch(ctx, "keep_from_simple", keep_from_simple_kernel<1>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred, fp,
                    km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint64_t *)nullptr, (uint32_t *)counts->ptr, ctx->d_flags);
         else
-            launch(ctx, "keep_from_simple", keep_from_simple_kernel<false>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred,
+            launch(ctx, "keep_from_simple", keep_from_simple_kernel<0>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred,
                    fp, km.n, km.ntiles, (uint64_t *)km.keep->ptr, km.pvalid ? (uint64_t *)km.pvalid->ptr : nullptr,
                    (uint32_t *)counts->ptr, ctx->d_flags);
     }

@@ -305,6 +305,33 @@ def test_aggregate_with_boolean_and_tree_predicates(ctx, null_frac):
             assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"pred {pred!r} key {key!r}")
 
 
+def test_float_predicates_take_the_range_paths(ctx):
+    """`x op c` on Float64 runs as an integer range test over the order-preserving image of the double (selection keep
+    mask, fast aggregate kernels): NaN, ±0, ±inf, subnormals on both sides, all six operators, literal on either side"""
+    special = np.array([np.nan, -np.nan, 0.0, -0.0, np.inf, -np.inf, 5e-324, -5e-324, 1.0, -1.0, 2.5, -2.5, 1e308, -1e308, 50.0, 49.99999999999999])
+    rng = np.random.default_rng(8)
+    x = np.concatenate([special, rng.random(20000) * 100.0 - 50.0, rng.choice(special, 2000)])
+    n = x.size
+    cols = [Column.from_numpy(x), Column.from_numpy(rng.integers(0, 50, n).astype(np.int64)), Column.from_numpy(rng.random(n))]
+    f = fields("x", "k", "v")
+    t = ctx.table_from_host(cols)
+    lits = [0.0, -0.0, 50.0, -1.0, 2.5, float("inf"), float("-inf"), float("nan"), 5e-324, 1e308]
+    for c in lits:
+        for op in CMP:
+            for pred in (binop(col(0), op, lit_f64(c)), binop(lit_f64(c), op, col(0))):
+                exp = orc.selection([cols], pred.flatten(f))[0]
+                assert_batches_equal(ctx.selection(t, pred.flatten(f)).to_host(), exp, what=f"selection {pred!r}")
+                expa = orc.aggregate([cols], ALL_AGGS(2), group_nodes=col(1).flatten(f), pred_nodes=pred.flatten(f))[0]
+                gota = ctx.aggregate(t, ALL_AGGS(2), group_nodes=col(1).flatten(f), pred_nodes=pred.flatten(f))
+                assert_rows_multiset_equal(gota.to_host(), expa, RTOL, exact_cols=[0], what=f"aggregate {pred!r}")
+    # predicate on the aggregated column itself, and un-grouped
+    pred = binop(col(2), Operator.Gt, lit_f64(0.25))
+    for key in (col(1), None):
+        expa = orc.aggregate([cols], ALL_AGGS(2), group_nodes=key.flatten(f) if key else None, pred_nodes=pred.flatten(f))[0]
+        gota = ctx.aggregate(t, ALL_AGGS(2), group_nodes=key.flatten(f) if key else None, pred_nodes=pred.flatten(f))
+        assert_rows_multiset_equal(gota.to_host(), expa, RTOL, exact_cols=[0], what="pred on the value column")
+
+
 def test_projection_matches_oracle(ctx):
     rng = np.random.default_rng(9)
     cols = random_batch(rng, 5000, 0.1, with_bool=True)

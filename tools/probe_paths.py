@@ -170,3 +170,38 @@ if SECTION in ("all", "dupjoin"):
         ctx.timing_enable(False)
         br = {k: round(ctx.timing_query(k)[0], 3) for k in ("join_probe_count", "join_probe_write", "join_probe_presence", "join_fused_write", "join_probe_unique", "compact", "scan_")}
         print(f"join dup={dup}: {npr} probe rows -> {rows} rows: {q*1e3:.3f} ms  ({(npr*16+rows*32)/q/1e9:.0f} GB/s algorithmic)  kernels(ms) {br}")
+
+# ---- 5. join shapes beyond C4 (dense unique 1e6-row build): sparse keys, larger builds, partial match
+if SECTION in ("all", "joinshapes"):
+    npr = 100_000_000
+    pv = torch.empty(npr, dtype=torch.float64, device=dev); ctx.synth_fill(2, 3, 0, npr, 1, 0, pv.data_ptr())
+    def run(name, bk, pk):
+        nb = bk.numel()
+        ba = torch.arange(nb, device=dev, dtype=torch.int64) * 3
+        torch.cuda.synchronize()
+        dim = ctx.table_from_device([(DType.INT64, nb, bk.data_ptr(), None), (DType.INT64, nb, ba.data_ptr(), None)])
+        fact = ctx.table_from_device([(DType.INT64, npr, pk.data_ptr(), None), (DType.FLOAT64, npr, pv.data_ptr(), None)])
+        t0 = time.perf_counter(); jt = ctx.hash_join_build(dim, 0); ctx.synchronize(); tb = time.perf_counter() - t0
+        q = timeit(lambda: ctx.hash_join_probe(jt, fact, 0), reps=3, warm=1)
+        ctx.timing_enable(True); ctx.timing_reset()
+        r = ctx.hash_join_probe(jt, fact, 0); rows = r.num_rows; del r
+        ctx.timing_enable(False)
+        br = {k: round(ctx.timing_query(k)[0], 3) for k in ("join_probe_count", "join_probe_write", "join_probe_presence", "join_fused_write", "join_probe_unique", "compact", "scan_")}
+        br = {k: v for k, v in br.items() if v}
+        print(f"join [{name}] build {nb} rows {tb*1e3:.2f} ms; probe {npr} rows -> {rows}: {q*1e3:.3f} ms = {npr/q:.3e} probe rows/s ({(npr*16+rows*32)/q/1e9:.0f} GB/s algorithmic)  {br}")
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    for nb in (1_000_000, 10_000_000, 100_000_000):
+        bk = torch.randperm(nb, device=dev, generator=g)
+        pk = torch.randint(0, nb, (npr,), device=dev, generator=g)
+        run(f"dense unique, every probe row matches, build {nb:.0e}", bk, pk)
+        del bk, pk
+    nb = 1_000_000
+    sparse = torch.unique(torch.randint(0, 1 << 40, (nb + nb // 8,), device=dev, generator=g))[:nb]
+    sparse = sparse[torch.randperm(sparse.numel(), device=dev, generator=g)]
+    pk = sparse[torch.randint(0, sparse.numel(), (npr,), device=dev, generator=g)]
+    run("sparse unique keys (2^40 domain), all match", sparse, pk)
+    pk2 = torch.where(torch.rand(npr, device=dev, generator=g) < 0.1, pk, pk + 1)
+    run("sparse unique keys, ~10% match", sparse, pk2)
+    bk = torch.randperm(nb, device=dev, generator=g)
+    pk3 = torch.randint(0, nb * 10, (npr,), device=dev, generator=g)
+    run("dense unique, ~10% match", bk, pk3)
