@@ -66,10 +66,14 @@ struct GroupTable {
     uint64_t *mn;       // f64_to_ord
     uint64_t *mx;
     uint32_t *nan;      // any NaN seen
-    uint32_t cap;       // power of two
+    uint32_t cap;       // power of two (hashed mode) / number of dense slots
     int32_t shift;      // 64 - log2(cap)
     int32_t V;
     int32_t pad;
+    // Dense mode (partitioned aggregation, one pass over the value columns): partitions hold disjoint key sets, so a
+    // workgroup writes the groups of its partition straight to slots [base, base + n) reserved with ONE atomic on this
+    // counter — no global hash table, no initialisation, no collect pass.  null = hashed mode.
+    uint32_t *dense_count;
 };
 
 struct AggArgs {
@@ -903,6 +907,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
                     if (signal_level2) atomicOr(&flags[NQE_FLAG_NEED_LEVEL2], 1); // the host re-partitions one level deeper
                 }
                 if (slot < 0 && signal_level2) continue;                              // result will be discarded
+                if (slot < 0 && g.dense_count) {                                      // no hash table to spill to: the host falls back
+                    atomicOr(&flags[NQE_FLAG_DENSE_OVERFLOW], 1);
+                    continue;
+                }
                 int64_t gslot = slot < 0 ? global_find_or_insert(g, key, flags) : 0; // partition larger than the table: spill
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) {
@@ -925,6 +933,45 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
             }
         }
         __syncthreads();
+        if (g.dense_count) {
+            // ---- dense output: count this partition's groups, reserve [base, base + n) with one atomic, write them there
+            __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
+            __shared__ uint32_t dense_base;
+            uint32_t mine = 0;
+            for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) mine += lkeys[s] != EMPTY_KEY ? 1u : 0u;
+            uint32_t wtot;
+            const uint32_t wexcl = wave_exclusive_scan(mine, wtot);
+            if (lane_id() == 0) wave_tot[threadIdx.x / 64] = wtot;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t tot = 0;
+                for (int w = 0; w < AGG_BLOCK / 64; ++w) { uint32_t c = wave_tot[w]; wave_tot[w] = tot; tot += c; }
+                dense_base = tot ? atomicAdd(g.dense_count, tot) : 0u;
+            }
+            __syncthreads();
+            uint32_t pos = dense_base + wave_tot[threadIdx.x / 64] + wexcl;
+            const size_t gstride = size_t(g.cap) + 1;
+            for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+                uint64_t k = lkeys[s];
+                if (k == EMPTY_KEY) continue;
+                if (pos < g.cap) {
+                    g.keys[pos] = (s == cap) ? EMPTY_KEY : k;
+#pragma unroll
+                    for (int j = 0; j < NVT; ++j) {
+                        const uint32_t o = uint32_t(j) * slots + s;
+                        const uint32_t c = lcnt[o];
+                        const size_t go = size_t(a.v0 + j) * gstride + pos;
+                        g.cnt[go] = uint64_t(c & ~NAN_BIT);
+                        g.sum[go] = lsum[o];
+                        g.mn[go] = lmn[o];
+                        g.mx[go] = lmx[o];
+                        g.nan[go] = (c & NAN_BIT) ? 1u : 0u;
+                    }
+                } else atomicOr(&flags[NQE_FLAG_DENSE_OVERFLOW], 1);
+                ++pos;
+            }
+            continue;
+        }
         for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
             uint64_t k = lkeys[s];
             if (k == EMPTY_KEY) continue;
@@ -1308,12 +1355,20 @@ __global__ void finalize_kernel(GroupTable g, const uint32_t *sorted_slots, int6
     int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < G; r += stride) {
         uint32_t s = sorted_slots ? sorted_slots[r] : 0;
+        // the state of a value column is gathered once for all aggregates over it (count, sum, avg, min, max of one column
+        // are five outputs of ONE random access per array, not of five)
+        int cached = -1;
+        uint64_t cnt = 0;
+        double sum = 0, mn = 0, mx = 0;
         for (int i = 0; i < f.naggs; ++i) {
-            size_t o = size_t(f.vslot[i]) * slots + s;
-            uint64_t cnt = g.cnt[o];
-            double sum = g.sum[o];
-            double mn = ord_to_f64(g.mn[o]);
-            double mx = g.nan[o] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(g.mx[o]);
+            if (f.vslot[i] != cached) {
+                cached = f.vslot[i];
+                size_t o = size_t(cached) * slots + s;
+                cnt = g.cnt[o];
+                sum = g.sum[o];
+                mn = ord_to_f64(g.mn[o]);
+                mx = g.nan[o] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(g.mx[o]);
+            }
             if (f.partial) {
                 f.out[4 * i + 0][r] = cnt;
                 f.out[4 * i + 1][r] = d2u(sum);
@@ -1352,13 +1407,17 @@ __global__ void merge_states_kernel(GroupTable g, const uint64_t *keys, int64_t 
     }
 }
 
+__global__ void iota_slots_kernel(uint32_t *out, int64_t n) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) out[i] = uint32_t(i);
+}
+
 // ------------------------------------------------------------------ host side
 struct TableBufs {
-    BufRef keys, cnt, sum, mn, mx, nan;
+    BufRef keys, cnt, sum, mn, mx, nan, dense_counter;
     GroupTable g{};
 };
 
-TableBufs make_table(nqe_ctx *ctx, uint32_t cap, int V, bool mark_slot0) {
+TableBufs make_table(nqe_ctx *ctx, uint32_t cap, int V, bool mark_slot0, bool dense = false) {
     TableBufs t;
     size_t slots = size_t(cap) + 1;
     if (V < 1) V = 1;
@@ -1379,6 +1438,12 @@ TableBufs make_table(nqe_ctx *ctx, uint32_t cap, int V, bool mark_slot0) {
     while ((1u << lg) < cap) ++lg;
     t.g.shift = cap == 1 ? 63 : 64 - lg;
     t.g.V = V;
+    t.g.dense_count = nullptr;
+    if (dense) { // every used slot is written in full by the producer: nothing to initialise but the counter
+        t.dense_counter = dev_alloc_zero(ctx, 8);
+        t.g.dense_count = (uint32_t *)t.dense_counter->ptr;
+        return t;
+    }
     launch(ctx, "agg_table_init", table_init_kernel, dim3(stream_grid(ctx, int64_t(slots) * V, 256)), dim3(256), 0, t.g,
            mark_slot0 ? 1 : 0);
     return t;
@@ -1446,10 +1511,20 @@ AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const n
     BufRef sorted_keys, sorted_slots;
     if (grouped) {
         size_t slots = size_t(tb.g.cap) + 1;
-        BufRef ck = dev_alloc(ctx, slots * 8), cs = dev_alloc(ctx, slots * 4), counter = dev_alloc_zero(ctx, 4);
-        launch(ctx, "agg_collect", collect_kernel, dim3(stream_grid(ctx, int64_t(slots), 256)), dim3(256), 0, tb.g,
-               (uint64_t *)ck->ptr, (uint32_t *)cs->ptr, (uint32_t *)counter->ptr);
-        G = int64_t(read_scalar(ctx, (const uint32_t *)counter->ptr));
+        BufRef ck, cs;
+        if (tb.g.dense_count) { // groups already occupy slots [0, G)
+            G = int64_t(read_scalar(ctx, (const uint32_t *)tb.g.dense_count));
+            ck = tb.keys;
+            cs = dev_alloc(ctx, size_t(G) * 4 + 8);
+            if (G) launch(ctx, "iota_u32", iota_slots_kernel, dim3(stream_grid(ctx, G, 256)), dim3(256), 0, (uint32_t *)cs->ptr, G);
+        } else {
+            BufRef counter = dev_alloc_zero(ctx, 4);
+            ck = dev_alloc(ctx, slots * 8);
+            cs = dev_alloc(ctx, slots * 4);
+            launch(ctx, "agg_collect", collect_kernel, dim3(stream_grid(ctx, int64_t(slots), 256)), dim3(256), 0, tb.g, (uint64_t *)ck->ptr,
+                   (uint32_t *)cs->ptr, (uint32_t *)counter->ptr);
+            G = int64_t(read_scalar(ctx, (const uint32_t *)counter->ptr));
+        }
         sorted_keys = dev_alloc(ctx, size_t(G) * 8 + 8);
         sorted_slots = dev_alloc(ctx, size_t(G) * 4 + 8);
         radix_sort_pairs_u64(ctx, (const uint64_t *)ck->ptr, (const uint32_t *)cs->ptr, (uint64_t *)sorted_keys->ptr,
@@ -1577,9 +1652,16 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         cap = 4096;
         while (int64_t(cap) < 2 * guess) cap <<= 1;
     }
-    bool partition_mode = false, level2 = false;
+    bool partition_mode = false, level2 = false, dense_ok = true;
+    bool any_val_nullable = false;
+    for (int c : plan.val_cols) any_val_nullable = any_val_nullable || in->cols[size_t(c)].validity != nullptr;
     for (int attempt = 0;; ++attempt) {
-        TableBufs tb = make_table(ctx, cap, V, !grouped);
+        // The partitioned path (entered after the fast kernel asked for it) with a single pass over the value columns writes
+        // its groups densely: at most one LDS table's worth per (sub-)partition, never more than the input rows.
+        const bool dense = grouped && partition_mode && dense_ok && V <= NV && !any_val_nullable;
+        uint32_t tcap = cap;
+        if (dense) tcap = uint32_t(std::min<int64_t>(int64_t(PARTS) * (level2 ? SUB : 1) * 4097, std::max<int64_t>(in->rows, 1)));
+        TableBufs tb = make_table(ctx, tcap, V, !grouped, dense);
         for (int v0 = 0; v0 < std::max(V, 1); v0 += NV) {
             a.nv = std::min(NV, V - v0);
             if (a.nv < 0) a.nv = 0;
@@ -1764,6 +1846,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
         if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode) {
             partition_mode = true; // a workgroup table overflowed: redo with hash-partitioned rows
+            flags_reset(ctx);
+            continue;
+        }
+        if (f[NQE_FLAG_DENSE_OVERFLOW]) { // a sub-partition with more distinct keys than an LDS table: hashed global table instead
+            dense_ok = false;
             flags_reset(ctx);
             continue;
         }
