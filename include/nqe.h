@@ -1,8 +1,8 @@
 /*
  * nqe.h — C ABI of the MI355X-native physical execution layer for
  * naive-query-engine's hot operators (filter, projection, hash group-by
- * aggregate, inner hash join over Arrow-layout Int64/UInt64/Float64/Boolean
- * columns).
+ * aggregate, inner hash join over Arrow-layout Int64/UInt64/Float64/Boolean/Utf8
+ * columns) and of the CSV ingest that feeds them.
  *
  * The reference (Veeupup/naive-query-engine, Rust) has NO FFI; its operator
  * boundary is the in-crate trait
@@ -248,6 +248,9 @@ nqe_status nqe_table_unpack_words(nqe_ctx *ctx, const void *src_device, int32_t 
  * datatype.rs:27-34): evaluates one expression over `in`, returns a 1-column table.
  * Literals are kept as scalars in registers (never materialised, cf. binary.rs:121 TODO),
  * except a root literal, which is expanded to `in.num_rows` rows as into_array does.
+ * Compares (= != < <= > >=) work on every type incl. Utf8 (byte-wise lexicographic, as arrow's
+ * *_dyn kernels); and/or are Kleene; arithmetic is wrapping on Int64/UInt64, IEEE on Float64.
+ * A tree of binary nodes is evaluated in one pass over the columns it references.
  * Errors: operand dtype mismatch → NQE_ERR_INTERVAL; divide/modulus with a valid zero
  * divisor → NQE_ERR_ARROW; arithmetic on Boolean/Utf8 → NQE_ERR_NOT_SUPPORTED. */
 nqe_status nqe_expr_evaluate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes,
