@@ -330,7 +330,7 @@ __device__ __forceinline__ void ex_load(const ExProgram &P, int64_t row0, int64_
 // Runs the program on the loaded rows; the result words are left in res[], the returned mask holds their validity.
 template <bool NULLS, int NC>
 __device__ __forceinline__ uint32_t ex_run(const ExProgram &P, const uint64_t (&cw)[NC][EX_ROWS], const uint32_t (&cvm)[NC],
-                                           uint32_t inm, uint64_t (&res)[EX_ROWS], int *flags) {
+                                           uint32_t inm, uint32_t litm, uint64_t (&res)[EX_ROWS], int *flags) {
     constexpr int R = EX_ROWS;
     // ---- run the program
     uint64_t s[EX_MAX_DEPTH][R];
@@ -363,7 +363,7 @@ __device__ __forceinline__ uint32_t ex_run(const ExProgram &P, const uint64_t (&
                 for (int r = 0; r < R; ++r) a[r] = s[0][r];
             }
         } else if (ac < 0) {
-            am = cur.a_src == EX_LIT ? inm : 0u;
+            am = cur.a_src == EX_LIT ? litm : 0u;
 #pragma unroll
             for (int r = 0; r < R; ++r) a[r] = cur.lit_a;
         } else if (ac == 0) {
@@ -388,7 +388,7 @@ __device__ __forceinline__ uint32_t ex_run(const ExProgram &P, const uint64_t (&
 #pragma unroll
             for (int r = 0; r < R; ++r) b[r] = s[0][r];
         } else if (bc < 0) {
-            bm = cur.b_src == EX_LIT ? inm : 0u;
+            bm = cur.b_src == EX_LIT ? litm : 0u;
 #pragma unroll
             for (int r = 0; r < R; ++r) b[r] = cur.lit_b;
         } else if (bc == 0) {
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(256) expr_tree_kernel(ExProgram P, int64_t n, 
         uint64_t cw[NC][R], res[R];
         uint32_t cvm[NC];
         ex_load<NULLS, NC>(P, row0, n, inm, cw, cvm);
-        const uint32_t vm = ex_run<NULLS, NC>(P, cw, cvm, inm, res, flags);
+        const uint32_t vm = ex_run<NULLS, NC>(P, cw, cvm, inm, inm, res, flags);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t row = row0 + r * 64;
@@ -513,11 +513,15 @@ __global__ void __launch_bounds__(256) expr_tree_compact_kernel(ExProgram P, con
         const uint64_t base = tile_offsets[tile];
         for (int k0 = 0; k0 < TILE_WORDS; k0 += R) {
             uint64_t kw[R];
-            uint32_t inm = 0, anyk = 0;
+            // inm: emitted rows whose predicate was valid (column values count); litm: every emitted row — a row emitted for
+            // a NULL predicate is all-NULL in the reference's filtered batch, but literals are still valid there
+            // (NULL OR true = true), found by the differential fuzzer
+            uint32_t inm = 0, litm = 0, anyk = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 kw[r] = bcast64(my_word, k0 + r);
                 anyk |= kw[r] != 0 ? 1u : 0u;
+                litm |= uint32_t((kw[r] >> lane) & 1ull) << r;
                 inm |= uint32_t(((kw[r] & bcast64(my_pv, k0 + r)) >> lane) & 1ull) << r;
             }
             if (!anyk) continue; // wave-uniform
@@ -525,7 +529,7 @@ __global__ void __launch_bounds__(256) expr_tree_compact_kernel(ExProgram P, con
             uint64_t cw[NC][R], res[R];
             uint32_t cvm[NC];
             ex_load<NULLS, NC>(P, row0, n, inm, cw, cvm);
-            const uint32_t vm = ex_run<NULLS, NC>(P, cw, cvm, inm, res, flags);
+            const uint32_t vm = ex_run<NULLS, NC>(P, cw, cvm, inm, litm, res, flags);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if ((kw[r] >> lane) & 1ull) {
