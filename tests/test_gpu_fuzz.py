@@ -131,3 +131,115 @@ def test_fuzz_hash_join(ctx, seed):
                         lambda: orc.hash_join([left], [right], 0, 1)[0], what)
         if exp is not None:
             assert_batches_equal(got, exp, what=what)
+
+
+@pytest.mark.parametrize("seed", range(4 + EXTRA // 4))
+def test_fuzz_many_groups_partitioned_paths(ctx, seed):
+    """enough rows and distinct keys to leave the single LDS table: partitioned (dense and hashed) and two-level paths,
+    one and several value-column passes, nullable values"""
+    rng = np.random.default_rng(3000 + seed)
+    n = int(rng.choice([300_000, 700_001, 1_500_000]))
+    groups = int(rng.choice([3000, 40_000, 900_000]))
+    null_frac = float(rng.choice([0.0, 0.0, 0.1]))
+    ids = rng.integers(-groups // 2, groups // 2, n).astype(np.int64) if rng.random() < 0.5 else (rng.integers(0, 1 << 50, groups)[rng.integers(0, groups, n)]).astype(np.int64)
+    mask = (lambda: None if null_frac == 0 else rng.random(n) >= null_frac)
+    cols = [Column.from_numpy(ids), Column.from_numpy(rng.integers(-1000, 1000, n).astype(np.int64), mask()), Column.from_numpy(rng.random(n) * 10, mask()),
+            Column.from_numpy(rng.integers(0, 1 << 30, n).astype(np.uint64)), Column.from_numpy(rng.random(n) < 0.5)]
+    t = ctx.table_from_host(cols)
+    for case in range(3):
+        pred = random_pred(rng) if case else None
+        vcols = [1, 2, 3][: int(rng.integers(1, 4))]
+        aggs = [(f, c) for c in vcols for f in (AggregateFunc.Count, AggregateFunc.Sum, AggregateFunc.Min, AggregateFunc.Max, AggregateFunc.Avg)]
+        what = f"seed {seed} case {case}: n={n} groups={groups} nulls={null_frac} pred={pred!r} vcols={vcols}"
+        got, exp = both(lambda: ctx.aggregate(t, aggs, group_nodes=flat(col(0)), pred_nodes=flat(pred)).to_host(),
+                        lambda: orc.aggregate([cols], aggs, group_nodes=flat(col(0)), pred_nodes=flat(pred))[0], what)
+        if exp is not None:
+            exact = [i for i, (f, _) in enumerate(aggs) if f == AggregateFunc.Count]
+            assert_rows_multiset_equal(got, exp, RTOL, exact_cols=exact, what=what)
+
+
+@pytest.mark.parametrize("seed", range(4 + EXTRA // 4))
+def test_fuzz_utf8_everywhere(ctx, seed):
+    """Utf8 as payload through selection / join, as group key, as join key, in comparisons; partial + merge of aggregates"""
+    from naive_query_engine_amd.expression import lit_utf8
+    from tests.helpers import random_utf8
+
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.choice([1, 64, 1000, 4097, 30000]))
+    null_frac = float(rng.choice([0.0, 0.2]))
+    s1, s2 = random_utf8(rng, n, null_frac), random_utf8(rng, n, 0.0)
+    ids = Column.from_numpy(rng.integers(0, 60, n).astype(np.int64))
+    v = Column.from_numpy(rng.random(n), None if null_frac == 0 else rng.random(n) > null_frac)
+    cols = [s1, s2, ids, v]
+    f = fields("s1", "s2", "id", "v")
+    t = ctx.table_from_host(cols)
+    op = [Operator.Eq, Operator.NotEq, Operator.Lt, Operator.GtEq][int(rng.integers(0, 4))]
+    pred = binop(binop(col(0), op, lit_utf8(str(rng.choice(["bob", "", "lynne", "x"])))), Operator.Or, binop(col(2), Operator.Lt, lit_i64(int(rng.integers(0, 60)))))
+    what = f"seed {seed}: n={n} nulls={null_frac} pred={pred!r}"
+    assert_batches_equal(ctx.selection(t, pred.flatten(f)).to_host(), orc.selection([cols], pred.flatten(f))[0], what=what + " [selection]")
+    aggs = [(AggregateFunc.Count, 3), (AggregateFunc.Sum, 3), (AggregateFunc.Max, 3), (AggregateFunc.Count, 0)]
+    for key in (col(1), col(0)):
+        exp = orc.aggregate([cols], aggs, group_nodes=key.flatten(f), pred_nodes=pred.flatten(f))[0]
+        got = ctx.aggregate(t, aggs, group_nodes=key.flatten(f), pred_nodes=pred.flatten(f))
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0, 3], what=what + f" [group by {key!r}]")
+    # partial + merge over two halves == single pass
+    if n >= 2:
+        h = n // 2
+        halves = [[Column.from_list(c.to_list()[a:b], c.dtype) if c.dtype == DType.UTF8 else Column.from_numpy(c.to_numpy()[a:b], c.valid_mask()[a:b]) for c in cols] for a, b in ((0, h), (h, n))]
+        parts = [ctx.aggregate_partial(ctx.table_from_host(hc), aggs[:3], group_nodes=col(2).flatten(f), pred_nodes=None) for hc in halves]
+        merged, _ = ctx.aggregate_merge([p[0] for p in parts], [p[1] for p in parts], aggs[:3])
+        exp = orc.aggregate([cols], aggs[:3], group_nodes=col(2).flatten(f))[0]
+        assert_rows_multiset_equal(merged.to_host(), exp, RTOL, exact_cols=[0], what=what + " [partial+merge]")
+    # join on a Utf8 key with Utf8 payload on both sides
+    nb = int(rng.choice([1, 50, 2000]))
+    left = [random_utf8(rng, nb, 0.0), Column.from_numpy(rng.integers(0, 9, nb).astype(np.int64)), random_utf8(rng, nb, null_frac)]
+    exp = orc.hash_join([left], [cols], 0, 1)[0]
+    got = ctx.hash_join(ctx.table_from_host(left), t, 0, 1).to_host()
+    assert_batches_equal(got, exp, what=what + f" [utf8 join nb={nb}]")
+
+
+@pytest.mark.parametrize("seed", range(4 + EXTRA // 4))
+def test_fuzz_csv(ctx, seed):
+    """random CSV images (quotes, escapes, embedded terminators, empty fields and lines, CR/LF/CRLF, odd delimiters)"""
+    rng = np.random.default_rng(5000 + seed)
+    for case in range(12):
+        nrows, ncols = int(rng.choice([0, 1, 3, 4, 50, 700])), int(rng.integers(1, 6))
+        delim = str(rng.choice([",", ";", "|", "\t"]))
+        kinds = [str(rng.choice(["int", "float", "str", "bool", "mixed"])) for _ in range(ncols)]
+        def field(kind):
+            r = rng.random()
+            if r < 0.06:
+                return ""
+            if kind == "int":
+                return str(int(rng.integers(-10**15, 10**15)))
+            if kind == "float":
+                return str(rng.choice([repr(float(rng.normal() * 1e3)), f"{rng.integers(-999, 999)}.{rng.integers(0, 99999)}", "0.0", "-12.5"]))
+            if kind == "bool":
+                return str(rng.choice(["true", "false", "TRUE", "False"]))
+            if kind == "mixed":
+                return str(rng.choice(["1", "2.5", "x", "true", "2020-01-01x"]))
+            raw = str(rng.choice(["a", "bob", 'say "hi"', "x" + delim + "y", "line\nbreak", "cr\rhere", "日本", ' lead', 'q"mid', ""]))
+            if any(ch in raw for ch in (delim, '"', "\n", "\r")) and not raw.startswith('q"'):
+                return '"' + raw.replace('"', '""') + '"'
+            return raw if raw != "" or rng.random() < 0.5 else '""'
+        lines = [delim.join(f"c{j}" for j in range(ncols))] if rng.random() < 0.8 else []
+        has_header = bool(lines)
+        for _ in range(nrows):
+            lines.append(delim.join(field(k) for k in kinds))
+            if rng.random() < 0.05:
+                lines.append("")
+        term = str(rng.choice(["\n", "\r\n", "\r"]))
+        data = term.join(lines).encode() + (term.encode() if rng.random() < 0.7 else b"")
+        kw = dict(has_header=has_header, delimiter=delim, max_read_records=int(rng.choice([-1, 1, 3, 1000])), batch_size=int(rng.choice([1_000_000, 5, 0])))
+        what = f"seed {seed} case {case}: rows={nrows} kinds={kinds} kw={kw} data={data[:120]!r}"
+        try:
+            names, nullable, exp = orc.csv_read(data, **kw)
+        except ErrorCode as e:
+            with pytest.raises(ErrorCode) as g:
+                gn, gd, _ = ctx.csv_infer_schema(data, kw["has_header"], delim, kw["max_read_records"], kw["batch_size"])
+                ctx.csv_read(data, gd, kw["has_header"], delim, kw["batch_size"])
+            assert g.value.status == e.status, what
+            continue
+        gn, gd, gnull = ctx.csv_infer_schema(data, kw["has_header"], delim, kw["max_read_records"], kw["batch_size"])
+        assert (gn, gnull, gd) == (names, nullable, [c.dtype for c in exp]), what
+        assert_batches_equal(ctx.csv_read(data, gd, kw["has_header"], delim, kw["batch_size"]).to_host(), exp, what=what)
