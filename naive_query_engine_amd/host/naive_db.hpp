@@ -581,6 +581,7 @@ struct HashJoin : PhysicalPlan {
     std::vector<std::pair<Column, Column>> on;
     JoinType join_type = JoinType::Inner; // stored, never read (:48-49)
     NaiveSchema schema_;
+    int executions_ = 0;
     static PhysicalPlanRef create(PhysicalPlanRef left, PhysicalPlanRef right, std::vector<std::pair<Column, Column>> on, JoinType jt, NaiveSchema schema) {
         auto p = std::make_shared<HashJoin>();
         p->left = std::move(left); p->right = std::move(right); p->on = std::move(on); p->join_type = jt; p->schema_ = std::move(schema);
@@ -604,6 +605,16 @@ struct HashJoin : PhysicalPlan {
             ltab = c;
         }
         size_t lkey = ColumnExpr::try_create(on[0].first.name, std::nullopt)->resolve(lb[0].schema()); // by NAME (:134-136)
+        // Q11: the reference never clears its hash table, so the k-th execute() of one plan object emits every match k
+        // times ([matches of the first build..., of the second...]); a build side of k copies has exactly that order
+        std::shared_ptr<nqe_table> repeated;
+        if (++executions_ > 1) {
+            std::vector<const nqe_table *> copies(size_t(executions_), ltab);
+            nqe_table *c = nullptr;
+            ctx->check(nqe_table_concat(ctx->raw(), copies.data(), int32_t(copies.size()), &c));
+            repeated.reset(c, [](nqe_table *p) { nqe_table_release(p); });
+            ltab = c;
+        }
         nqe_join_table *jt = nullptr;
         ctx->check(nqe_hash_join_build(ctx->raw(), ltab, int32_t(lkey), &jt));
         std::shared_ptr<nqe_join_table> jguard(jt, [](nqe_join_table *p) { nqe_join_table_release(p); });

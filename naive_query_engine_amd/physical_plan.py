@@ -441,6 +441,7 @@ class HashJoin(PhysicalPlan):
 
     def __init__(self, left, right, on, join_type, schema):
         self.left, self.right, self.on, self.join_type, self._schema = left, right, list(on), join_type, list(schema)
+        self._executions = 0  # the reference never clears its hash table between execute() calls (quirk Q11)
 
     @staticmethod
     def create(left: PhysicalPlan, right: PhysicalPlan, on: Sequence[Tuple[ColumnRef, ColumnRef]], join_type, schema: NaiveSchema):
@@ -462,6 +463,12 @@ class HashJoin(PhysicalPlan):
             raise ErrorCode(Status.NotSupported, "join with an empty left batch list is not supported on the device path")
         ltab = lb[0].table if len(lb) == 1 else ctx.concat([b.table for b in lb])  # concat_batches (:132)
         lkey = ColumnExpr.try_create(self.on[0][0].name, None).resolve(lb[0].fields)  # by NAME, first match (:134-136)
+        # Q11: build() pushes the row indices into the SAME map again on every execute(), so the k-th execute() emits each
+        # match k times, in the order [matches of the first build..., of the second...].  A build side of k copies of the
+        # left batch has exactly that match order (row i + c*n carries the payload of row i).
+        self._executions += 1
+        if self._executions > 1:
+            ltab = ctx.concat([ltab] * self._executions)
         jt = ctx.hash_join_build(ltab, lkey)
         out = []
         for b in rb:  # one output batch per probe batch (:177-250)

@@ -1129,6 +1129,24 @@ int orc_hash_join(const orc_batches *left, const orc_batches *right, int32_t lef
     });
 }
 
+// the same plan object executed `executions` times: the hash table is never cleared (quirk Q11), so the k-th execute()
+// emits every match k times (Vec<idx> = [first build..., second build..., ...], hash_join.rs:58-78)
+int orc_hash_join_n(const orc_batches *left, const orc_batches *right, int32_t left_key, int32_t right_key, int32_t executions,
+                    orc_batches **out) {
+    return guarded([&] {
+        HashJoin j;
+        j.left = scan_of(left);
+        j.right = scan_of(right);
+        j.has_on = left_key >= 0 && right_key >= 0;
+        j.left_key = left_key;
+        j.right_key = right_key;
+        std::vector<int> sch = j.schema();
+        Batches last;
+        for (int e = 0; e < std::max(1, executions); ++e) last = j.execute();
+        *out = wrap(last, sch);
+    });
+}
+
 uint64_t orc_xxhash64_word(uint64_t w) { return hash_word(w); }
 uint64_t orc_xxhash64(const uint8_t *p, size_t n, uint64_t seed) { return xxh64(p, n, seed); }
 

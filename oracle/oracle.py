@@ -59,6 +59,7 @@ def lib():
         L.orc_aggregate.argtypes = [vp, C.POINTER(NqeExprNode), C.c_int32, C.POINTER(NqeExprNode), C.c_int32,
                                     C.POINTER(NqeAggregate), C.c_int32, C.c_int32, C.POINTER(vp)]
         L.orc_hash_join.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.orc_hash_join_n.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
         L.orc_xxhash64_word.restype = C.c_uint64
         L.orc_xxhash64_word.argtypes = [C.c_uint64]
         L.orc_xxhash64.restype = C.c_uint64
@@ -199,10 +200,11 @@ def aggregate(table, aggs: Sequence[tuple], group_nodes=None, pred_nodes=None, e
     return r if raw else r.to_python()
 
 
-def hash_join(left, right, left_key: int, right_key: int, raw: bool = False):
+def hash_join(left, right, left_key: int, right_key: int, raw: bool = False, executions: int = 1):
+    """executions > 1: the same HashJoin object executed that many times (its hash table is never cleared, quirk Q11)"""
     hl, hr = _as_handle(left), _as_handle(right)
     out = C.c_void_p()
-    _check(lib().orc_hash_join(hl.ptr, hr.ptr, left_key, right_key, C.byref(out)))
+    _check(lib().orc_hash_join_n(hl.ptr, hr.ptr, left_key, right_key, executions, C.byref(out)))
     r = _Handle(out.value)
     return r if raw else r.to_python()
 

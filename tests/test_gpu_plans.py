@@ -114,6 +114,26 @@ def test_readme_joins_row_order(pp, csv_tables, golden):
     assert e.value.status == Status.PlanError
 
 
+def test_hash_join_reexecution_duplicates_matches_q11(pp):
+    """the reference never clears HashJoin's hash table: executing the same plan object again emits every match twice,
+    then three times (hash_join.rs:58-78, :138-156); the oracle keeps the table across executes the same way"""
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(17)
+    nb, npr = 300, 2000
+    left = [Column.from_numpy(rng.integers(0, 120, nb).astype(np.int64)), Column.from_numpy(rng.random(nb))]      # duplicate build keys
+    right = [Column.from_numpy(rng.integers(-5, 130, npr).astype(np.int64)), Column.from_numpy(rng.integers(0, 9, npr).astype(np.int64))]
+    lf, rf = [Field("id", DType.INT64, False), Field("x", DType.FLOAT64, False)], [Field("key", DType.INT64, False), Field("y", DType.INT64, False)]
+    lt = pp.MemTable.try_create(lf, [RecordBatch(lf, left)])
+    rt = pp.MemTable.try_create(rf, [RecordBatch(rf, right)])
+    join = pp.HashJoin.create(pp.ScanPlan.create(lt, None), pp.ScanPlan.create(rt, None), [(pp.ColumnRef(None, "id"), pp.ColumnRef(None, "key"))], pp.JoinType.Inner, lf + rf)
+    for k in (1, 2, 3):
+        got = join.execute()[0].to_host().columns
+        exp = orc.hash_join([left], [right], 0, 0, executions=k)[0]
+        assert got[0].length == k * orc.hash_join([left], [right], 0, 0)[0][0].length
+        assert_batches_equal(got, exp, what=f"execute() #{k}")
+
+
 def test_multi_batch_selection_q3_and_scan_projection(pp):
     f = [Field("x", DType.INT64, True)]
     b0 = RecordBatch(f, [Column.from_list([1, None, 9], DType.INT64)])
