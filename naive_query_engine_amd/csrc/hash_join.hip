@@ -246,8 +246,10 @@ struct FusedCols {
 };
 
 // pass 2: one read of the probe keys, every output column written in probe order
+// `bidx` null: a build payload is addressed by key - dmin (key-ordered dense columns); non-null: by the build row recorded
+// per probe row by probe_unique_kernel (hashed unique keys), gathered from the build columns themselves.
 __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, const uint64_t *keep,
-                                                               const uint64_t *tile_offsets, uint64_t dmin, FusedCols fc) {
+                                                               const uint64_t *tile_offsets, uint64_t dmin, const uint32_t *bidx, FusedCols fc) {
     const int waves_per_block = blockDim.x / 64;
     const int64_t nwords = (n + 63) / 64;
     const int64_t last = n - 1;
@@ -273,6 +275,14 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
                 pos[k] = bcast32(my_off, k0 + k) + __popcll(word & lanemask_lt());
                 kept |= uint32_t((word >> lane_id()) & 1) << k;
             }
+            uint64_t gix[8]; // gather index of a build payload
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (bidx) {
+                    int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                    gix[k] = bidx[row < last ? row : last];
+                } else gix[k] = key[k] - dmin;
+            }
             for (int c = 0; c < fc.n; ++c) {
                 const uint64_t *__restrict__ src = fc.src[c];
                 uint64_t *__restrict__ dst = fc.dst[c] + base;
@@ -289,7 +299,7 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
                     for (int k = 0; k < 8; ++k) v[k] = key[k];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = src[(kept >> k) & 1 ? key[k] - dmin : 0];
+                    for (int k = 0; k < 8; ++k) v[k] = src[(kept >> k) & 1 ? gix[k] : 0];
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
@@ -608,7 +618,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         }
         if (km.ntiles && km.total > 0)
             launch(ctx, "join_fused_write", join_fused_write_kernel, grid, block, 0, rk.words(), n, km.ntiles, (const uint64_t *)km.keep->ptr,
-                   (const uint64_t *)km.tile_offsets->ptr, jt->dense_min, fc);
+                   (const uint64_t *)km.tile_offsets->ptr, jt->dense_min, (const uint32_t *)nullptr, fc);
         sync(ctx);
         return out;
     }
@@ -628,6 +638,34 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         auto out = std::make_unique<nqe_table>();
         out->ctx = ctx;
         out->rows = km.total;
+        bool left_plain = jt->left_cols.size() + right->cols.size() <= size_t(MAX_JOIN_COLS);
+        for (auto &c : jt->left_cols) left_plain = left_plain && is_word_type(c.dtype) && !c.validity;
+        if (left_plain && right_plain) {
+            // every column is a plain 8-byte column: ONE pass writes all of them (probe columns streamed, the build key taken
+            // from the probe key, build payloads gathered by the recorded build row) instead of one compaction per column
+            FusedCols fc;
+            std::memset(&fc, 0, sizeof(fc));
+            for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
+                const DevColumn &c = jt->left_cols[ci];
+                out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
+                fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : 2;
+                fc.src[fc.n] = c.words();
+                fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
+                fc.n++;
+            }
+            for (auto &c : right->cols) {
+                out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
+                fc.kind[fc.n] = 0;
+                fc.src[fc.n] = c.words();
+                fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
+                fc.n++;
+            }
+            if (km.ntiles && km.total > 0)
+                launch(ctx, "join_fused_write", join_fused_write_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,
+                       (const uint64_t *)km.keep->ptr, (const uint64_t *)km.tile_offsets->ptr, uint64_t(0), (const uint32_t *)bidx->ptr, fc);
+            sync(ctx);
+            return out;
+        }
         DevColumn outer_pos;
         for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
             const DevColumn &c = jt->left_cols[ci];
