@@ -44,6 +44,10 @@ struct nqe_join_table {
     // needs ONE random access per gathered value and no build-row lookup at all
     nqe::BufRef presence;                 // uint32 bitmap over [0, span)
     std::vector<nqe::BufRef> dense_cols;  // per left column (null for the key column)
+    // Int64/UInt64 payloads whose value range fits 32 bits are stored as uint32 offsets from their minimum (frame of
+    // reference): the gather target halves, so more of it stays in the 4 MB per-XCD L2 (the probe is gather-bound)
+    std::vector<int> dense_packed;        // 1: dense_cols[ci] holds uint32 (value - dense_base[ci])
+    std::vector<uint64_t> dense_base;
     bool dense_payload = false;
     bool dense_full = false; // every key of the dense range occurs
     // Utf8 join keys: the build strings are encoded to representative-row codes (strings.hip)
@@ -193,6 +197,35 @@ __global__ void scatter_dense_payload_kernel(const uint64_t *keys, int64_t n, ui
     }
 }
 
+// unsigned min / max of (value ^ flip) over a column (flip = sign bit for Int64 → order as signed)
+__global__ void __launch_bounds__(256) minmax_u64_kernel(const uint64_t *v, int64_t n, uint64_t flip, unsigned long long *out_min, unsigned long long *out_max) {
+    uint64_t mn = ~0ull, mx = 0;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        const uint64_t x = v[i] ^ flip;
+        mn = x < mn ? x : mn;
+        mx = x > mx ? x : mx;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint64_t a = __shfl_down(mn, d, 64), b = __shfl_down(mx, d, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (lane_id() == 0) {
+        atomicMin(out_min, (unsigned long long)mn);
+        atomicMax(out_max, (unsigned long long)mx);
+    }
+}
+__global__ void scatter_dense_payload32_kernel(const uint64_t *keys, int64_t n, uint64_t dmin, const uint64_t *src, uint64_t base, uint32_t *dst,
+                                               uint32_t *presence) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) {
+        uint64_t d = keys[r] - dmin;
+        dst[d] = uint32_t(src[r] - base);
+        if (presence) atomicOr(&presence[d >> 5], 1u << (d & 31));
+    }
+}
+
 // pass 1: match bitmap + per-tile counts (no build-row output).
 // MODE 0: every key of [min, min+span) is present → a range check, no memory access at all;
 // MODE 1: presence bitmap staged in LDS (span/8 bytes ≤ 128 KB: random LDS reads instead of one L2
@@ -240,9 +273,11 @@ __global__ void __launch_bounds__(1024) probe_presence_kernel(const uint64_t *rk
 struct FusedCols {
     int32_t n;
     int32_t pad;
-    int32_t kind[MAX_JOIN_COLS];        // 0: probe-side column (coalesced copy), 1: build key (= probe key), 2: build payload (gather)
-    const uint64_t *src[MAX_JOIN_COLS]; // kind 0: probe column; kind 2: key-ordered build column
+    int32_t kind[MAX_JOIN_COLS];        // 0: probe-side column (coalesced copy), 1: build key (= probe key), 2: build payload (gather),
+                                        // 3: build payload packed as uint32 offsets from base[] (gather)
+    const uint64_t *src[MAX_JOIN_COLS]; // kind 0: probe column; kind 2/3: key-ordered build column
     uint64_t *dst[MAX_JOIN_COLS];
+    uint64_t base[MAX_JOIN_COLS];
 };
 
 // pass 2: one read of the probe keys, every output column written in probe order
@@ -297,9 +332,14 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
                 } else if (kind == 1) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = key[k];
-                } else {
+                } else if (kind == 2) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = src[(kept >> k) & 1 ? gix[k] : 0];
+                } else {
+                    const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(src);
+                    const uint64_t b0 = fc.base[c];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = b0 + src32[(kept >> k) & 1 ? gix[k] : 0];
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
@@ -522,9 +562,31 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
             if (plain && span * 8 * left->cols.size() <= (size_t(8) << 30)) {
                 jt->presence = dev_alloc_zero(ctx, size_t((span + 31) / 32) * 4);
                 jt->dense_cols.resize(left->cols.size());
+                jt->dense_packed.assign(left->cols.size(), 0);
+                jt->dense_base.assign(left->cols.size(), 0);
                 bool first = true;
                 for (size_t ci = 0; ci < left->cols.size(); ++ci) {
                     if (int(ci) == left_key) continue;
+                    const DevColumn &pc = left->cols[ci];
+                    if (pc.dtype == NQE_INT64 || pc.dtype == NQE_UINT64) { // value range within 32 bits → uint32 offsets
+                        const uint64_t flip = pc.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
+                        BufRef mm = dev_alloc(ctx, 16);
+                        const uint64_t init[2] = {~0ull, 0ull};
+                        NQE_HIP_CHECK(hipMemcpyAsync(mm->ptr, init, 16, hipMemcpyHostToDevice, ctx->stream));
+                        launch(ctx, "join_payload_minmax", minmax_u64_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, pc.words(), n, flip,
+                               (unsigned long long *)mm->ptr, (unsigned long long *)mm->ptr + 1);
+                        const uint64_t mn = read_scalar(ctx, (const uint64_t *)mm->ptr), mx = read_scalar(ctx, (const uint64_t *)mm->ptr + 1);
+                        if (mx - mn <= 0xffffffffull) {
+                            jt->dense_packed[ci] = 1;
+                            jt->dense_base[ci] = mn ^ flip;
+                            jt->dense_cols[ci] = dev_alloc_zero(ctx, size_t(span) * 4 + 8);
+                            launch(ctx, "join_scatter_payload", scatter_dense_payload32_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n,
+                                   kmin, pc.words(), jt->dense_base[ci], (uint32_t *)jt->dense_cols[ci]->ptr,
+                                   first ? (uint32_t *)jt->presence->ptr : (uint32_t *)nullptr);
+                            first = false;
+                            continue;
+                        }
+                    }
                     jt->dense_cols[ci] = dev_alloc(ctx, size_t(span) * 8);
                     launch(ctx, "join_scatter_payload", scatter_dense_payload_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0,
                            kc.words(), n, kmin, left->cols[ci].words(), (uint64_t *)jt->dense_cols[ci]->ptr,
@@ -604,7 +666,8 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
             const DevColumn &c = jt->left_cols[ci];
             out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
-            fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : 2;
+            fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : (jt->dense_packed[ci] ? 3 : 2);
+            fc.base[fc.n] = int(ci) == jt->left_key ? 0 : jt->dense_base[ci];
             fc.src[fc.n] = int(ci) == jt->left_key ? nullptr : (const uint64_t *)jt->dense_cols[ci]->ptr;
             fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
             fc.n++;

@@ -503,8 +503,13 @@ def test_hash_join_pk_fk_fused_path(ctx, nb, npr, holes):
     rng = np.random.default_rng(nb + npr)
     space = nb * 2 if holes else nb            # holes: only half of the key range is present
     lk = (rng.permutation(space)[:nb] - 7).astype(np.int64)   # negative keys too
+    # payloads: small signed range (packed as 32-bit offsets), Float64 and wide UInt64 (not packable), Int64 around i64::MIN
+    # (packable, wrapping base), UInt64 with a range of exactly 2^32 - 1 and 2^32 (boundary of the packing rule)
     left = [Column.from_numpy(rng.integers(-9, 9, nb).astype(np.int64)), Column.from_numpy(lk), Column.from_numpy(rng.random(nb)),
-            Column.from_numpy(rng.integers(0, 1 << 60, nb).astype(np.uint64))]
+            Column.from_numpy(rng.integers(0, 1 << 60, nb).astype(np.uint64)),
+            Column.from_numpy((np.iinfo(np.int64).min + rng.integers(0, 1 << 31, nb)).astype(np.int64)),
+            Column.from_numpy((np.uint64(1 << 63) + np.concatenate([[0, (1 << 32) - 1], rng.integers(0, 1 << 32, nb)])[:nb].astype(np.uint64))),
+            Column.from_numpy((np.uint64(5) + np.concatenate([[0, 1 << 32], rng.integers(0, 1 << 32, nb)])[:nb].astype(np.uint64)))]
     rk = (rng.integers(-3, space + 3, npr) - 7).astype(np.int64)
     right = [Column.from_numpy(rk), Column.from_numpy(rng.random(npr)), Column.from_numpy(np.arange(npr, dtype=np.int64))]
     exp = orc.hash_join([left], [right], 1, 0)[0]
