@@ -162,6 +162,8 @@ __global__ void __launch_bounds__(256) probe_unique_kernel(const uint64_t *rkeys
          tile += int64_t(gridDim.x) * waves_per_block) {
         const int64_t row0 = tile * TILE_ROWS;
         uint32_t total = 0;
+        // (issuing the first probe of 16 keys before examining any was measured slower, 2.41 -> 2.63 ms: the hashed probe is
+        // bound by line fetches — 10^8 x 128 B at ≈5 TB/s — not by latency, and the extra registers cost occupancy)
 #pragma unroll 2
         for (int k0 = 0; k0 < TILE_WORDS; k0 += 8) {
             uint64_t key[8], meta[8];
@@ -283,6 +285,7 @@ struct FusedCols {
 // pass 2: one read of the probe keys, every output column written in probe order
 // `bidx` null: a build payload is addressed by key - dmin (key-ordered dense columns); non-null: by the build row recorded
 // per probe row by probe_unique_kernel (hashed unique keys), gathered from the build columns themselves.
+template <int FW_B> // rows per lane in flight
 __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, const uint64_t *keep,
                                                                const uint64_t *tile_offsets, uint64_t dmin, const uint32_t *bidx, FusedCols fc) {
     const int waves_per_block = blockDim.x / 64;
@@ -295,24 +298,24 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
         uint32_t tot;
         uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
         const uint64_t base = tile_offsets[tile];
-        for (int k0 = 0; k0 < TILE_WORDS; k0 += 8) {
-            uint64_t key[8];
-            uint32_t pos[8]; // position inside the tile's output range
+        for (int k0 = 0; k0 < TILE_WORDS; k0 += FW_B) {
+            uint64_t key[FW_B];
+            uint32_t pos[FW_B]; // position inside the tile's output range
             uint32_t kept = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < FW_B; ++k) {
                 int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
                 key[k] = __builtin_nontemporal_load(&rkeys[row < last ? row : last]); // streamed once: keep L2 for the gather
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < FW_B; ++k) {
                 uint64_t word = bcast64(my_word, k0 + k);
                 pos[k] = bcast32(my_off, k0 + k) + __popcll(word & lanemask_lt());
                 kept |= uint32_t((word >> lane_id()) & 1) << k;
             }
-            uint64_t gix[8]; // gather index of a build payload
+            uint64_t gix[FW_B]; // gather index of a build payload
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < FW_B; ++k) {
                 if (bidx) {
                     int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
                     gix[k] = bidx[row < last ? row : last];
@@ -322,32 +325,37 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
                 const uint64_t *__restrict__ src = fc.src[c];
                 uint64_t *__restrict__ dst = fc.dst[c] + base;
                 const int kind = fc.kind[c];
-                uint64_t v[8];
+                uint64_t v[FW_B];
                 if (kind == 0) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
+                    for (int k = 0; k < FW_B; ++k) {
                         int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
                         v[k] = __builtin_nontemporal_load(&src[row < last ? row : last]);
                     }
                 } else if (kind == 1) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = key[k];
+                    for (int k = 0; k < FW_B; ++k) v[k] = key[k];
                 } else if (kind == 2) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = src[(kept >> k) & 1 ? gix[k] : 0];
+                    for (int k = 0; k < FW_B; ++k) v[k] = src[(kept >> k) & 1 ? gix[k] : 0];
                 } else {
                     const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(src);
                     const uint64_t b0 = fc.base[c];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = b0 + src32[(kept >> k) & 1 ? gix[k] : 0];
+                    for (int k = 0; k < FW_B; ++k) v[k] = b0 + src32[(kept >> k) & 1 ? gix[k] : 0];
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
+                for (int k = 0; k < FW_B; ++k)
                     if ((kept >> k) & 1) __builtin_nontemporal_store(v[k], &dst[pos[k]]);
             }
         }
     }
 }
+
+// 16 rows per lane in flight: the kernel is bound by the latency of its gathers, and memory-level parallelism per wave
+// beats occupancy (A/B on one box, C4: 4 rows/lane (70 VGPRs, 7 waves/SIMD) 1.53 ms, 8 (116, 4) 1.33 ms, 16 (210, 2)
+// 1.24 ms, 32 (256, 1) 1.31 ms)
+constexpr int FUSED_WRITE_ROWS = 16;
 
 // pass 1: one table lookup per probe row; records meta and per-tile totals
 __global__ void __launch_bounds__(JT_BLOCK) probe_count_kernel(const uint64_t *rkeys, int64_t n, Lookup L, uint64_t *pmeta,
@@ -680,7 +688,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
             fc.n++;
         }
         if (km.ntiles && km.total > 0)
-            launch(ctx, "join_fused_write", join_fused_write_kernel, grid, block, 0, rk.words(), n, km.ntiles, (const uint64_t *)km.keep->ptr,
+            launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS>, grid, block, 0, rk.words(), n, km.ntiles, (const uint64_t *)km.keep->ptr,
                    (const uint64_t *)km.tile_offsets->ptr, jt->dense_min, (const uint32_t *)nullptr, fc);
         sync(ctx);
         return out;
@@ -724,7 +732,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
                 fc.n++;
             }
             if (km.ntiles && km.total > 0)
-                launch(ctx, "join_fused_write", join_fused_write_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,
+                launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS>, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,
                        (const uint64_t *)km.keep->ptr, (const uint64_t *)km.tile_offsets->ptr, uint64_t(0), (const uint32_t *)bidx->ptr, fc);
             sync(ctx);
             return out;
