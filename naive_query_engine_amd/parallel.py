@@ -182,20 +182,47 @@ def sharded_aggregate(ctx, local_table, aggs, group_nodes=None, pred_nodes=None,
 
 
 def _gather_table(ctx, table, group=None):
-    """All-gathers a per-rank result table (8-byte columns) in rank order = row order; returns one table."""
+    """All-gathers a per-rank result table (8-byte columns without validity) in rank order = row order; returns one table.
+    Counts are exchanged first (the per-rank outputs differ in length), then every rank packs its table into one buffer of
+    the common stride (nqe_table_pack_words), ONE all-gather moves the data, and nqe_table_unpack_words writes the
+    concatenation: two device copies around the collective instead of per-column pads, slices and a concat."""
     import torch
     import torch.distributed as dist
 
     dev = torch.device("cuda", ctx.device)
     dts = table.dtypes()
-    per_rank, counts = all_gather_rows(table_columns_as_tensors(table, dev), group)
-    parts, keep = [], []
-    for r, rc in enumerate(per_rank):
-        parts.append(ctx.table_from_device([(dts[i], counts[r], rc[i].data_ptr() if counts[r] else None, None) for i in range(len(dts))]))
-        keep.append(rc)
-    out = ctx.concat(parts)  # copies into library-owned memory
+    ncols = len(dts)
+    world = dist.get_world_size(group)
+    n_local = table.num_rows
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    if dist.get_backend(group) == "gloo":
+        cl = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(cl, cnt.cpu(), group=group)
+    else:
+        cl = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(cl, cnt, group=group)
+    counts = [int(c.item()) for c in cl]
+    if min(counts) == max(counts) and counts[0] > 0 and dist.get_backend(group) != "gloo":
+        # equal-length outputs (e.g. a PK-FK join over equal shards): gather every column straight from the table's memory
+        # into its place in the result — the collective's output IS the concatenated column, no staging copies at all
+        outs = []
+        for t_in in table_columns_as_tensors(table, dev):
+            o = torch.empty(world * n_local, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(o, t_in, group=group)
+            outs.append(o)
+        torch.cuda.synchronize(dev)
+        res = ctx.table_from_device([(dts[i], world * n_local, outs[i].data_ptr(), None) for i in range(ncols)])
+        res._keep = outs  # the table borrows the gathered tensors
+        return res
+    stride = max(max(counts), 1)
+    buf = torch.empty(ncols * stride + 1, dtype=torch.int64, device=dev)
+    ctx.pack_words([table], stride, buf.data_ptr())
+    ctx.synchronize()  # the pack ran on the context's stream, the collective runs on torch's
+    gathered = _all_gather_packed(buf, group)
+    torch.cuda.synchronize(dev)
+    out = ctx.unpack_words(gathered.data_ptr(), counts, dts, stride)
     ctx.synchronize()
-    del keep
+    del gathered, buf
     return out
 
 

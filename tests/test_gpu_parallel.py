@@ -153,3 +153,18 @@ def test_sharded_hash_join_two_ranks_keeps_probe_order():
     exp = [c.to_numpy().view(np.int64).tolist() for c in orc.hash_join([left], [right], 0, 0)[0]]
     for rank, got in results:
         assert got == exp  # build replicated, probe range-split, rank order == probe order
+
+
+@pytest.mark.timeout(300)
+def test_single_rank_rccl_exchange_paths():
+    """real RCCL (backend "nccl") needs one device per rank, so on a 1-GPU box the collectives are exercised with ONE rank
+    and NQE_FORCE_EXCHANGE=1: the packed one-collective aggregate exchange and the equal-count zero-copy table gather must
+    reproduce the local results (tools/check_gather_nccl.py runs in its own process: torch initialises the device first)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(free_port()))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_gather_nccl.py")], capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "nccl single-rank exchange checks passed" in out.stdout
