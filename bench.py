@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--pass-frac", type=float, default=0.5, help="headline: fraction of rows passing `id < K` (diagnostics; the metric uses 0.5)")
     ap.add_argument("--gather", action="store_true", help="c4 with --gpus N: also all-gather every rank's output batch in rank order (BASELINE config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=40_000_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=150_000_000, help="rows of the CPU baseline sample (about 10 s of single-thread work for the headline)")
     return ap.parse_args()
 
 
