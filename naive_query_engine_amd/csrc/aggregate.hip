@@ -427,6 +427,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
     const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
     const uint64_t *__restrict__ valp[NVT];
+    const uint64_t *__restrict__ kvalid = reinterpret_cast<const uint64_t *>(a.key_src.valid);
+    const uint64_t *__restrict__ pvalid = reinterpret_cast<const uint64_t *>(PRED != 0 ? a.pred_src.valid : nullptr);
     const uint64_t *__restrict__ vvalid[NVT]; // VNULL: validity bitmaps of the value columns (word-padded), null = all valid
     int vdt[NVT];
 #pragma unroll
@@ -444,6 +446,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     struct Tile {
         uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
         uint64_t vv[VNULL ? NVT : 1][AGG_U]; // validity word of the wave's 64 rows
+        uint64_t kpv[VNULL ? AGG_U : 1];     // key validity AND predicate validity
     };
     auto load_tile = [&](Tile &t, int64_t base) {
 #pragma unroll
@@ -458,6 +461,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 if (VNULL) {
 #pragma unroll
                     for (int j = 0; j < NVT; ++j) t.vv[j][u] = vvalid[j] ? vvalid[j][row >> 6] : ~0ull;
+                    t.kpv[u] = (kvalid ? kvalid[row >> 6] : ~0ull) & (pvalid ? pvalid[row >> 6] : ~0ull);
                 }
             } else {
                 t.kw[u] = keyp[row];
@@ -475,6 +479,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             if (PRED != 0) {
                 pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             }
+            if (VNULL) pass = pass && ((t.kpv[u] >> (row & 63)) & 1ull);
             uint64_t key;
             if (KEY == 0) key = t.kw[u];
             else {
@@ -1644,6 +1649,13 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
         a.pred_shares_key = (a.pred_mode == 1 && key_col >= 0 && a.pred.col == key_col) ? 1 : 0;
     }
+    // validity bitmaps the fast kernels read as whole 64-bit words: library-owned buffers are padded, a borrowed one only
+    // if its length is a multiple of 64
+    auto words_ok = [](const DevColumn &c) { return !c.validity || c.validity->owned || (c.length % 64) == 0; };
+    bool kp_valid_words_ok = true;
+    if (grouped && key_col >= 0 && !utf8_key) kp_valid_words_ok = kp_valid_words_ok && words_ok(in->cols[size_t(key_col)]);
+    if (grouped && utf8_key) kp_valid_words_ok = kp_valid_words_ok && words_ok(utf8_src); // the codes share the strings' validity buffer
+    if (a.pred_mode == 1) kp_valid_words_ok = kp_valid_words_ok && words_ok(in->cols[size_t(a.pred.col)]);
 
     const int V = int(plan.val_cols.size());
     uint32_t cap = 1;
@@ -1658,7 +1670,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     for (int attempt = 0;; ++attempt) {
         // The partitioned path (entered after the fast kernel asked for it) with a single pass over the value columns writes
         // its groups densely: at most one LDS table's worth per (sub-)partition, never more than the input rows.
-        const bool dense = grouped && partition_mode && dense_ok && V <= NV && !any_val_nullable;
+        const bool dense = grouped && partition_mode && dense_ok && V <= NV && !any_val_nullable && !a.key_src.valid &&
+                           !(a.pred_mode != 0 && a.pred_src.valid);
         uint32_t tcap = cap;
         if (dense) tcap = uint32_t(std::min<int64_t>(int64_t(PARTS) * (level2 ? SUB : 1) * 4097, std::max<int64_t>(in->rows, 1)));
         TableBufs tb = make_table(ctx, tcap, V, !grouped, dense);
@@ -1716,21 +1729,23 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     if (a.key.aux[0].pow2_shift >= 0) kk = 1, fast_key = 1;
                     else if (a.key.aux[0].more >= 0) fast_key = 2; // `col % d`, d not a power of two: magic multiply
                 }
-                bool plain = is_word_type(a.key_src.dtype) && !a.key_src.valid;
+                bool plain = is_word_type(a.key_src.dtype);
                 // a Boolean predicate column without nulls (a Boolean input column, or any predicate tree evaluated by the
                 // expression machine) is tested by the same variants as a separate integer predicate column: the word of a
                 // row is its bit
-                const bool bitmap_pred = a.pred_src.dtype == NQE_BOOLEAN && !a.pred_src.valid &&
-                                         (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
-                if (a.pred_mode == 1 && !bitmap_pred) plain = plain && is_word_type(a.pred_src.dtype) && !a.pred_src.valid;
+                // NULL keys are dropped and a NULL predicate filters the row out (the NULL row a selection would emit has a NULL
+                // key / NULL values, Q4 + Q8): the VNULL variants AND both validity bits into the row's pass flag
+                const bool kp_nullable = a.key_src.valid != nullptr || (a.pred_mode != 0 && a.pred_src.valid != nullptr);
+                const bool bitmap_pred = a.pred_src.dtype == NQE_BOOLEAN && (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
+                if (a.pred_mode == 1 && !bitmap_pred) plain = plain && is_word_type(a.pred_src.dtype);
                 // value columns may carry validity bitmaps (VNULL variants of the fast kernel); the partitioned path and
                 // everything else nullable stays with the general kernel
-                bool vnull = false;
+                bool vnull = kp_nullable;
                 for (int j = 0; j < a.nv; ++j) {
                     plain = plain && a.val[j].values;
                     vnull = vnull || a.val[j].valid != nullptr;
                 }
-                if (vnull && (partition_mode || !valid_words_ok)) plain = false;
+                if (vnull && (partition_mode || !valid_words_ok || !kp_valid_words_ok)) plain = false;
                 FastPred fpred{};
                 if (bitmap_pred) fpred = bitmap_fast_pred();
                 bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || bitmap_pred || (pk == 1 && make_fast_pred(a.pred, &fpred)));
