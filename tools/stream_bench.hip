@@ -1,0 +1,78 @@
+// Read-bandwidth ceiling of one MI355X for the access pattern of the headline kernel: two 8 GB columns streamed once with
+// non-temporal 8-byte loads per lane, a trivial reduction as the only compute.  hipcc -O3 --offload-arch=gfx950 -o stream_bench
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+template <int U, int WIDE>
+__global__ void __launch_bounds__(1024) read2(const uint64_t *a, const uint64_t *b, int64_t n, uint64_t *out) {
+    uint64_t acc = 0;
+    const int64_t step = int64_t(blockDim.x) * U * (WIDE ? 2 : 1);
+    for (int64_t base = int64_t(blockIdx.x) * step; base < n; base += int64_t(gridDim.x) * step) {
+        if (WIDE) {
+            typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+            v2u64 x[U], y[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int64_t i = base / 2 + int64_t(u) * blockDim.x + threadIdx.x;
+                i = i < n / 2 - 1 ? i : n / 2 - 1;
+                x[u] = __builtin_nontemporal_load(reinterpret_cast<const v2u64 *>(a) + i);
+                y[u] = __builtin_nontemporal_load(reinterpret_cast<const v2u64 *>(b) + i);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc ^= x[u].x + x[u].y + y[u].x + y[u].y;
+        } else {
+            uint64_t x[U], y[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int64_t i = base + int64_t(u) * blockDim.x + threadIdx.x;
+                i = i < n - 1 ? i : n - 1;
+                x[u] = __builtin_nontemporal_load(a + i);
+                y[u] = __builtin_nontemporal_load(b + i);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc ^= x[u] + y[u];
+        }
+    }
+    if (acc == 0x123456789abcdefull) out[0] = acc; // keep the loads alive
+}
+
+template <int U, int WIDE>
+int run(const uint64_t *a, const uint64_t *b, int64_t n, uint64_t *out, int blocks_per_cu, int threads) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int grid = 256 * blocks_per_cu;
+    for (int w = 0; w < 2; ++w) read2<U, WIDE><<<grid, threads>>>(a, b, n, out);
+    CK(hipEventRecord(e0));
+    const int reps = 10;
+    for (int r = 0; r < reps; ++r) read2<U, WIDE><<<grid, threads>>>(a, b, n, out);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    printf("U=%d wide=%d blocks/CU=%d threads=%d: %.3f ms = %.0f GB/s\n", U, WIDE, blocks_per_cu, threads, ms, 16.0 * n / ms / 1e6);
+    return 0;
+}
+
+int main() {
+    const int64_t n = 1000000000;
+    uint64_t *a, *b, *out;
+    CK(hipMalloc(&a, n * 8));
+    CK(hipMalloc(&b, n * 8));
+    CK(hipMalloc(&out, 8));
+    CK(hipMemset(a, 1, n * 8));
+    CK(hipMemset(b, 2, n * 8));
+    for (int bpc : {1, 2, 4, 8}) {
+        for (int th : {256, 1024}) {
+            if (run<4, 0>(a, b, n, out, bpc, th)) return 1;
+            if (run<8, 0>(a, b, n, out, bpc, th)) return 1;
+            if (run<4, 1>(a, b, n, out, bpc, th)) return 1;
+        }
+    }
+    return 0;
+}
