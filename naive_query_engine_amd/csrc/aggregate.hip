@@ -22,133 +22,13 @@
 #include <algorithm>
 #include <cfloat>
 
-#include "device_utils.hpp"
-#include "nqe_internal.hpp"
+#include "aggregate_common.hpp"
 
 namespace nqe {
 
 namespace {
 
-constexpr uint64_t EMPTY_KEY = 0x8000000000000000ull; // i64::MIN; that key uses the extra slot [cap]
-constexpr uint64_t GOLD = 0x9E3779B97F4A7C15ull;
-constexpr int NV = 2;      // value columns per kernel pass
-constexpr int AGG_U = 4;   // rows per thread per iteration
-constexpr int AGG_BLOCK = 1024;
-constexpr uint32_t NAN_BIT = 0x80000000u;
-
-// order-preserving map f64 -> u64 (non-NaN): integer min/max atomics give the f64 min/max
-__host__ __device__ __forceinline__ uint64_t f64_to_ord(double d) {
-    uint64_t b;
-#if defined(__HIP_DEVICE_COMPILE__)
-    b = (uint64_t)__double_as_longlong(d);
-#else
-    std::memcpy(&b, &d, 8);
-#endif
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double ord_to_f64(uint64_t u) {
-    uint64_t b = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
-    return __longlong_as_double((long long)b);
-}
-
-struct ColSrc {
-    const void *values;
-    const uint8_t *valid;
-    int32_t dtype;
-    int32_t present;
-};
-
-// global group table: arrays are [V][cap+1]; slot `cap` belongs to EMPTY_KEY itself
-struct GroupTable {
-    uint64_t *keys;     // [cap+1]; keys[cap] != EMPTY_KEY ⇔ special slot in use
-    uint64_t *cnt;      // non-null values
-    double *sum;
-    uint64_t *mn;       // f64_to_ord
-    uint64_t *mx;
-    uint32_t *nan;      // any NaN seen
-    uint32_t cap;       // power of two (hashed mode) / number of dense slots
-    int32_t shift;      // 64 - log2(cap)
-    int32_t V;
-    int32_t pad;
-    // Dense mode (partitioned aggregation, one pass over the value columns): partitions hold disjoint key sets, so a
-    // workgroup writes the groups of its partition straight to slots [base, base + n) reserved with ONE atomic on this
-    // counter — no global hash table, no initialisation, no collect pass.  null = hashed mode.
-    uint32_t *dense_count;
-};
-
-struct AggArgs {
-    int64_t n;
-    int32_t pred_mode; // 0 none, 1 SimpleExpr over pred_src, 2 Boolean column (bits + validity) in pred_src
-    int32_t has_key;
-    int32_t pred_shares_key;
-    int32_t nv;
-    ColSrc pred_src;
-    ColSrc key_src;
-    SimpleExpr pred;
-    SimpleExpr key;
-    ColSrc val[NV];
-    int32_t val_shares_key[NV];
-    int32_t need_sum[NV];
-    int32_t need_minmax[NV];
-    int32_t v0; // first value slot of this pass in the global table
-    int32_t lds_cap;
-    int32_t lds_shift;
-    int32_t allow_partition; // an LDS-table overflow asks the host for the partitioned path instead of falling back to global atomics
-};
-
-__device__ __forceinline__ int lds_find_or_insert(uint64_t *keys, uint64_t key, uint32_t cap, int shift) {
-    if (key == EMPTY_KEY) {
-        keys[cap] = 0; // mark special slot used (idempotent plain store)
-        return int(cap);
-    }
-    uint32_t slot = uint32_t((key * GOLD) >> shift);
-    for (int probe = 0; probe < 48; ++probe) {
-        uint64_t k = keys[slot];
-        if (k == key) return int(slot);
-        if (k == EMPTY_KEY) {
-            uint64_t old = atomicCAS((unsigned long long *)&keys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-            if (old == EMPTY_KEY || old == key) return int(slot);
-        }
-        slot = (slot + 1) & (cap - 1);
-    }
-    return -1; // workgroup table full for this key: caller goes to the global table
-}
-
-__device__ __forceinline__ int64_t global_find_or_insert(const GroupTable &g, uint64_t key, int *flags) {
-    if (key == EMPTY_KEY) {
-        __hip_atomic_store(&g.keys[g.cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return int64_t(g.cap);
-    }
-    uint32_t slot = uint32_t((key * GOLD) >> g.shift);
-    // bounded probe sequence: a table that needs more than this is treated as full (the host retries with a
-    // larger one) — an unbounded walk over a nearly full table is O(rows x capacity)
-    const uint32_t max_probe = g.cap < 512u ? g.cap : 512u;
-    for (uint32_t probe = 0; probe < max_probe; ++probe) {
-        uint64_t k = __hip_atomic_load(&g.keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k == key) return int64_t(slot);
-        if (k == EMPTY_KEY) {
-            uint64_t old = atomicCAS((unsigned long long *)&g.keys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-            if (old == EMPTY_KEY || old == key) return int64_t(slot);
-        }
-        slot = (slot + 1) & (g.cap - 1);
-    }
-    atomicOr(&flags[NQE_FLAG_TABLE_FULL], 1);
-    return -1;
-}
-
-__device__ __forceinline__ void global_update(const GroupTable &g, int64_t slot, int v, uint64_t cnt, double sum, bool has_sum,
-                                              uint64_t mn, uint64_t mx, bool has_minmax, bool nan) {
-    size_t o = size_t(v) * (size_t(g.cap) + 1) + size_t(slot);
-    if (cnt) atomicAdd((unsigned long long *)&g.cnt[o], (unsigned long long)cnt);
-    if (has_sum) unsafeAtomicAdd(&g.sum[o], sum);
-    if (has_minmax) {
-        atomicMin((unsigned long long *)&g.mn[o], (unsigned long long)mn);
-        atomicMax((unsigned long long *)&g.mx[o], (unsigned long long)mx);
-    }
-    if (nan) atomicOr(&g.nan[o], 1u);
-}
-
-__device__ __forceinline__ bool row_valid(const ColSrc &c, int64_t row) { return c.valid ? get_bit(c.valid, row) : true; }
+using namespace agg;
 
 // ------------------------------------------------------------------ grouped kernel
 // History: with the 64-bit software divide inlined for predicate and key in each of the 4 unrolled rows the first
@@ -342,696 +222,6 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_kernel(AggArgs a, Group
     }
 }
 
-// ------------------------------------------------------------------ grouped kernel, fast path
-// Sources are plain 8-byte columns without validity; predicate is none / integer `col cmp lit`;
-// key is a plain column / `col % ±2^k`.  Differences from the general kernel above:
-//   * NVT (value columns) and VF64 (all values Float64) are static, every statistic is always
-//     maintained → no flag or dtype branches in the row loop;
-//   * the integer predicate is a branch-free range test: the host rewrites `x op lit` into
-//     lo <= (x ^ flip) <= hi, optionally negated (flip = sign bit for UInt64 → signed compares);
-//   * min/max run on native v_min_f64/v_max_f64 (NaN operands are ignored by the instruction and
-//     tracked by a flag, which is exactly OrderedFloat's min rule and makes max NaN at the end);
-//   * loads are unconditional (row index clamped to n-1): no exec-mask branches around them;
-//   * PIPE: the NEXT tile's words are requested before the current tile is processed (two register
-//     tiles), so waits are counted `s_waitcnt vmcnt(k)` and a wave keeps a tile in flight while it
-//     computes.
-// PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column.
-template <int PRED, int KEY, int NVT, bool VF64, bool VNULL>
-__global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t cap = uint32_t(a.lds_cap);
-    const uint32_t slots = cap + 1;
-    uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
-    double *lsum = reinterpret_cast<double *>(lkeys + slots);            // [NVT][slots]
-    uint64_t *lmn = reinterpret_cast<uint64_t *>(lsum + NVT * slots);    // [NVT][slots]
-    uint64_t *lmx = lmn + NVT * slots;                                   // [NVT][slots]
-    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + NVT * slots);    // [NVT][slots]
-    const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
-    __shared__ int lds_full_flag;
-    volatile int *lds_full = &lds_full_flag;
-    if (threadIdx.x == 0) lds_full_flag = 0;
-    for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
-        lkeys[s] = EMPTY_KEY;
-#pragma unroll
-        for (int j = 0; j < NVT; ++j) {
-            lsum[j * slots + s] = 0.0;
-            lmn[j * slots + s] = ORD_MAX;
-            lmx[j * slots + s] = ORD_MIN;
-            lcnt[j * slots + s] = 0;
-        }
-    }
-    __syncthreads();
-
-    bool run_live = false;
-    uint64_t run_key = 0;
-    uint32_t rcnt[NVT];
-    double rsum[NVT], rmn[NVT], rmx[NVT];
-    bool rnan[NVT];
-#pragma unroll
-    for (int j = 0; j < NVT; ++j) {
-        rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
-    }
-    auto flush_run = [&]() {
-        // The hit path must stay minimal: random-key inputs flush once per row (guarding the lookup with a "table is full"
-        // test cost them 14 %).  A rejected key is the cold path: it raises the workgroup flag (the tile loop then leaves
-        // early and the host redoes the query partitioned) or, for small inputs, goes to the global table.
-        int slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
-        int64_t gslot = 0;
-        if (slot < 0) {
-            if (!*lds_full) {
-                *lds_full = 1;
-                if (a.allow_partition) atomicOr(&flags[NQE_FLAG_NEED_PARTITION], 1); // more distinct keys than a workgroup table holds
-            }
-            gslot = a.allow_partition ? -1 : global_find_or_insert(g, run_key, flags);
-        }
-#pragma unroll
-        for (int j = 0; j < NVT; ++j) {
-            const uint64_t omn = f64_to_ord(rmn[j]), omx = f64_to_ord(rmx[j]);
-            if (slot >= 0) {
-                uint32_t o = uint32_t(j) * slots + uint32_t(slot);
-                if (rcnt[j]) {
-                    atomicAdd(&lcnt[o], rcnt[j]);
-                    unsafeAtomicAdd(&lsum[o], rsum[j]);
-                }
-                if (rnan[j]) atomicOr(&lcnt[o], NAN_BIT);
-                // read-before-atomic (see the general kernel)
-                if (omn < lmn[o]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)omn);
-                if (omx > lmx[o]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)omx);
-            } else if (gslot >= 0) {
-                global_update(g, gslot, a.v0 + j, rcnt[j], rsum[j], true, omn, omx, true, rnan[j]);
-            }
-            rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
-        }
-    };
-
-    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
-    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
-    const uint64_t *__restrict__ valp[NVT];
-    const uint64_t *__restrict__ kvalid = reinterpret_cast<const uint64_t *>(a.key_src.valid);
-    const uint64_t *__restrict__ pvalid = reinterpret_cast<const uint64_t *>(PRED != 0 ? a.pred_src.valid : nullptr);
-    const uint64_t *__restrict__ vvalid[NVT]; // VNULL: validity bitmaps of the value columns (word-padded), null = all valid
-    int vdt[NVT];
-#pragma unroll
-    for (int j = 0; j < NVT; ++j) {
-        valp[j] = static_cast<const uint64_t *>(a.val[j].values);
-        vvalid[j] = reinterpret_cast<const uint64_t *>(a.val[j].valid);
-        vdt[j] = a.val[j].dtype;
-    }
-    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
-    const OpAux key_aux = a.key.aux[0];
-    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
-    const int64_t n = a.n, last = a.n - 1;
-
-    constexpr bool PIPE = true, NT = true; // both measured wins (prefetched second tile: 3.24 -> 2.69 ms with the lean loop; nt loads: -2..3 %)
-    struct Tile {
-        uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
-        uint64_t vv[VNULL ? NVT : 1][AGG_U]; // validity word of the wave's 64 rows
-        uint64_t kpv[VNULL ? AGG_U : 1];     // key validity AND predicate validity
-    };
-    auto load_tile = [&](Tile &t, int64_t base) {
-#pragma unroll
-        for (int u = 0; u < AGG_U; ++u) {
-            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-            row = row < last ? row : last; // clamp: unconditional, in-bounds
-            if (NT) {
-                t.kw[u] = __builtin_nontemporal_load(&keyp[row]);
-                if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
-#pragma unroll
-                for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
-                if (VNULL) {
-#pragma unroll
-                    for (int j = 0; j < NVT; ++j) t.vv[j][u] = vvalid[j] ? vvalid[j][row >> 6] : ~0ull;
-                    t.kpv[u] = (kvalid ? kvalid[row >> 6] : ~0ull) & (pvalid ? pvalid[row >> 6] : ~0ull);
-                }
-            } else {
-                t.kw[u] = keyp[row];
-                if (PRED == 2) t.pw[u] = predp[row >> fp.row_shift];
-#pragma unroll
-                for (int j = 0; j < NVT; ++j) t.vw[j][u] = valp[j][row];
-            }
-        }
-    };
-    auto process_tile = [&](const Tile &t, int64_t base) {
-#pragma unroll
-        for (int u = 0; u < AGG_U; ++u) {
-            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-            bool pass = row < n;
-            if (PRED != 0) {
-                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
-            }
-            if (VNULL) pass = pass && ((t.kpv[u] >> (row & 63)) & 1ull);
-            uint64_t key;
-            if (KEY == 0) key = t.kw[u];
-            else {
-                // truncated remainder by a literal: |x| mod |d| (mask for ±2^k, magic multiply otherwise), sign of
-                // the dividend
-                uint64_t x = t.kw[u];
-                uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
-                uint64_t ux = (x ^ sgn) - sgn;
-                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
-                key = (ur ^ sgn) - sgn;
-            }
-            if (!pass) continue;
-            if (!run_live || key != run_key) {
-                if (run_live) flush_run();
-                run_key = key;
-                run_live = true;
-            }
-#pragma unroll
-            for (int j = 0; j < NVT; ++j) {
-                double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
-                if (VNULL) {
-                    // a NULL value contributes nothing (count of non-null, Q10) but its row still creates the group:
-                    // branch-free — count += bit, sum += 0, and a NaN operand that min/max ignore and the flag skips
-                    const bool vb = (t.vv[j][u] >> (row & 63)) & 1ull;
-                    rcnt[j] += vb ? 1u : 0u;
-                    rsum[j] += vb ? x : 0.0;
-                    rnan[j] = rnan[j] || (vb && x != x);
-                    const double xm = vb ? x : __builtin_nan("");
-                    rmn[j] = fmin(rmn[j], xm);
-                    rmx[j] = fmax(rmx[j], xm);
-                } else {
-                    rcnt[j] += 1;
-                    rsum[j] += x;
-                    rnan[j] = rnan[j] || (x != x);
-                    rmn[j] = fmin(rmn[j], x); // NaN operand ignored
-                    rmx[j] = fmax(rmx[j], x);
-                }
-            }
-        }
-    };
-
-    const int64_t step = int64_t(AGG_BLOCK) * AGG_U;
-    const int64_t stride = int64_t(gridDim.x) * step;
-    int64_t base = int64_t(blockIdx.x) * step;
-    if (PIPE) {
-        if (base < n) {
-            Tile A, B;
-            load_tile(A, base);
-            for (;;) {
-                load_tile(B, base + stride); // prefetch (clamped, always issued)
-                process_tile(A, base);
-                base += stride;
-                if (base >= n) break;
-                load_tile(A, base + stride);
-                process_tile(B, base);
-                base += stride;
-                if (base >= n) break;
-                if (*lds_full && (a.allow_partition || __hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
-                    break; // the host redoes the query (partitioned path / larger table)
-                if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                    break; // another workgroup's table overflowed: this attempt is abandoned anyway
-            }
-        }
-    } else {
-        for (; base < n; base += stride) {
-            Tile A;
-            load_tile(A, base);
-            process_tile(A, base);
-        }
-    }
-    if (run_live) flush_run();
-    __syncthreads();
-    // an abandoned attempt (the host re-runs the query partitioned) does not merge: 2048 slots x 512 workgroups of
-    // device-scope atomics were two thirds of what the abandoned attempt cost
-    if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
-        uint64_t k = lkeys[s];
-        if (k == EMPTY_KEY) continue;
-        uint64_t key = (s == cap) ? EMPTY_KEY : k;
-        int64_t gslot = global_find_or_insert(g, key, flags);
-        if (gslot < 0) continue;
-#pragma unroll
-        for (int j = 0; j < NVT; ++j) {
-            uint32_t o = uint32_t(j) * slots + s;
-            uint32_t c = lcnt[o];
-            global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
-        }
-    }
-}
-
-// ------------------------------------------------------------------ partitioned aggregation
-// More distinct keys than a workgroup's LDS table holds would turn every row into device-scope atomics, and
-// those run at a flat ≈2.4e10 ops/s on MI355X whatever the scope, table size or layout (tools/atomics_bench.hip):
-// 100 M rows took 17-20 ms at 4 K…1 M groups versus 0.6 ms at 1 K.  Instead the passing rows are hash-partitioned
-// (count → scan → scatter of (key, values) tuples, PARTS partitions so that a workgroup's open write lines stay L2
-// resident) and each partition — whose distinct keys now fit an LDS table — is aggregated by one workgroup.
-constexpr int PARTS_LOG2 = 9;
-constexpr int PARTS = 1 << PARTS_LOG2;
-
-struct PartArgs {
-    uint32_t *counts;        // [PARTS][nblocks] (count pass out)
-    const uint64_t *offsets; // [PARTS][nblocks] exclusive scan of counts (scatter pass in)
-    uint64_t *out_key;
-    uint64_t *out_val[NV];
-    int64_t chunk;           // rows per workgroup (multiple of AGG_BLOCK*AGG_U)
-};
-
-template <int PRED, int KEY, int NVT, bool SCATTER>
-__global__ void __launch_bounds__(AGG_BLOCK) agg_partition_kernel(AggArgs a, FastPred fp, PartArgs pa) {
-    __shared__ uint32_t cnt[PARTS];
-    __shared__ uint64_t basep[PARTS];
-    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) {
-        cnt[p] = 0;
-        if (SCATTER) basep[p] = pa.offsets[size_t(p) * gridDim.x + blockIdx.x];
-    }
-    __syncthreads();
-    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
-    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
-    const uint64_t *__restrict__ valp[NVT];
-#pragma unroll
-    for (int j = 0; j < NVT; ++j) valp[j] = static_cast<const uint64_t *>(a.val[j].values);
-    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
-    const OpAux key_aux = a.key.aux[0];
-    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
-    const int64_t lo = int64_t(blockIdx.x) * pa.chunk;
-    const int64_t hi = lo + pa.chunk < a.n ? lo + pa.chunk : a.n;
-    const int64_t last = a.n - 1;
-    for (int64_t base = lo; base < hi; base += int64_t(AGG_BLOCK) * AGG_U) {
-        uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
-#pragma unroll
-        for (int u = 0; u < AGG_U; ++u) {
-            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-            row = row < last ? row : last;
-            kw[u] = __builtin_nontemporal_load(&keyp[row]);
-            if (PRED == 2) pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
-            if (SCATTER) {
-#pragma unroll
-                for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < AGG_U; ++u) {
-            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-            bool pass = row < hi;
-            if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? kw[u] : pred_extract(fp, pw[u], row));
-            uint64_t key;
-            if (KEY == 0) key = kw[u];
-            else {
-                uint64_t x = kw[u];
-                uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
-                uint64_t ux = (x ^ sgn) - sgn;
-                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
-                key = (ur ^ sgn) - sgn;
-            }
-            if (!pass) continue;
-            uint32_t p = uint32_t((key * GOLD) >> (64 - PARTS_LOG2));
-            uint32_t r = atomicAdd(&cnt[p], 1u);
-            if (SCATTER) {
-                uint64_t pos = basep[p] + r;
-                pa.out_key[pos] = key;
-#pragma unroll
-                for (int j = 0; j < NVT; ++j) pa.out_val[j][pos] = vw[j][u];
-            }
-        }
-    }
-    if (!SCATTER) {
-        __syncthreads();
-        for (int p = threadIdx.x; p < PARTS; p += blockDim.x) pa.counts[size_t(p) * gridDim.x + blockIdx.x] = cnt[p];
-    }
-}
-
-// Scatter pass with LDS write-combining: a tile of SC_ROWS rows is counting-sorted by partition inside LDS
-// (rank = LDS atomic on a per-tile counter, tile-local exclusive scan), then copied out so that consecutive lanes
-// write consecutive tuples of the same partition (runs of SC_ROWS/PARTS tuples → full 128-B lines instead of
-// 8-byte stores sprayed over 512 streams: 2.4 ms → see DESIGN.md for the measured effect).
-template <int PRED, int KEY, int NVT>
-__global__ void __launch_bounds__(AGG_BLOCK) agg_partition_scatter_kernel(AggArgs a, FastPred fp, PartArgs pa) {
-    constexpr int RPT = NVT == 1 ? 8 : 4;            // rows per thread per tile
-    constexpr int SC_ROWS = AGG_BLOCK * RPT;         // 8192 (one value column) / 4096 (two)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *skey = reinterpret_cast<uint64_t *>(smem);     // [SC_ROWS]
-    uint64_t *sval = skey + SC_ROWS;                          // [NVT][SC_ROWS]
-    uint64_t *gcur = sval + NVT * SC_ROWS;                    // [PARTS] global write cursor of this workgroup
-    uint32_t *tcnt = reinterpret_cast<uint32_t *>(gcur + PARTS); // [PARTS] tuples of this tile per partition
-    uint32_t *tstart = tcnt + PARTS;                          // [PARTS] tile-local exclusive scan
-    __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
-    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) {
-        gcur[p] = pa.offsets[size_t(p) * gridDim.x + blockIdx.x];
-        tcnt[p] = 0;
-    }
-    __syncthreads();
-    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
-    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
-    const uint64_t *__restrict__ valp[NVT];
-#pragma unroll
-    for (int j = 0; j < NVT; ++j) valp[j] = static_cast<const uint64_t *>(a.val[j].values);
-    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
-    const OpAux key_aux = a.key.aux[0];
-    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
-    const int64_t lo = int64_t(blockIdx.x) * pa.chunk;
-    const int64_t hi = lo + pa.chunk < a.n ? lo + pa.chunk : a.n;
-    const int64_t last = a.n - 1;
-    for (int64_t base = lo; base < hi; base += SC_ROWS) {
-        uint64_t key[RPT], vw[NVT][RPT];
-        uint32_t part[RPT], rank[RPT];
-        bool pass[RPT];
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-            int64_t rc = row < last ? row : last;
-            uint64_t kw = __builtin_nontemporal_load(&keyp[rc]);
-            uint64_t pw = PRED == 2 ? pred_extract(fp, __builtin_nontemporal_load(&predp[rc >> fp.row_shift]), rc) : kw;
-#pragma unroll
-            for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][rc]);
-            bool ok = row < hi;
-            if (PRED != 0) ok = ok && range_pass(fp, pw);
-            if (KEY == 0) key[u] = kw;
-            else {
-                uint64_t sgn = key_signed ? uint64_t((long long)kw >> 63) : 0ull;
-                uint64_t ux = (kw ^ sgn) - sgn;
-                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
-                key[u] = (ur ^ sgn) - sgn;
-            }
-            pass[u] = ok;
-            part[u] = uint32_t((key[u] * GOLD) >> (64 - PARTS_LOG2));
-        }
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
-        __syncthreads();
-        // tile-local exclusive scan of the PARTS counters (threads 0..PARTS-1)
-        uint32_t c = threadIdx.x < PARTS ? tcnt[threadIdx.x] : 0u, wt;
-        uint32_t ex = wave_exclusive_scan(c, wt);
-        if (lane_id() == 63) wave_tot[threadIdx.x / 64] = wt;
-        __syncthreads();
-        if (threadIdx.x < PARTS) {
-            uint32_t pre = 0;
-            for (int w = 0; w < int(threadIdx.x) / 64; ++w) pre += wave_tot[w];
-            tstart[threadIdx.x] = pre + ex;
-        }
-        uint32_t tile_total = 0;
-        for (int w = 0; w < PARTS / 64; ++w) tile_total += wave_tot[w];
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            if (!pass[u]) continue;
-            uint32_t i = tstart[part[u]] + rank[u];
-            skey[i] = key[u];
-#pragma unroll
-            for (int j = 0; j < NVT; ++j) sval[j * SC_ROWS + i] = vw[j][u];
-        }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < tile_total; i += blockDim.x) {
-            uint64_t k = skey[i];
-            uint32_t p = uint32_t((k * GOLD) >> (64 - PARTS_LOG2));
-            uint64_t dest = gcur[p] + (i - tstart[p]);
-            pa.out_key[dest] = k;
-#pragma unroll
-            for (int j = 0; j < NVT; ++j) pa.out_val[j][dest] = sval[j * SC_ROWS + i];
-        }
-        __syncthreads();
-        if (threadIdx.x < PARTS) {
-            gcur[threadIdx.x] += tcnt[threadIdx.x];
-            tcnt[threadIdx.x] = 0;
-        }
-        __syncthreads();
-    }
-}
-
-// Second partitioning level: workgroup p splits parent partition p (a contiguous tuple range) into SUB sub-partitions
-// by the next SUB_LOG2 hash bits — count, tile-local scan, then the same LDS-sorted scatter as level 1.  The output
-// occupies the same global range as the input partition, so no cross-workgroup scan is needed.
-constexpr int SUB_LOG2 = 6;
-constexpr int SUB = 1 << SUB_LOG2;
-template <int NVT>
-__global__ void __launch_bounds__(AGG_BLOCK) agg_subpartition_kernel(const uint64_t *offsets, int64_t off_stride, const uint64_t *in_key,
-                                                                     const uint64_t *in_v0, const uint64_t *in_v1, uint64_t *out_key,
-                                                                     uint64_t *out_v0, uint64_t *out_v1, uint64_t *sub_offsets) {
-    constexpr int RPT = NVT == 1 ? 8 : 4;
-    constexpr int SC_ROWS = AGG_BLOCK * RPT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *skey = reinterpret_cast<uint64_t *>(smem);
-    uint64_t *sval = skey + SC_ROWS;
-    __shared__ uint64_t gcur[SUB];
-    __shared__ uint32_t tcnt[SUB], tstart[SUB], total_cnt[SUB];
-    const uint64_t *__restrict__ inv[2] = {in_v0, in_v1};
-    uint64_t *outv[2] = {out_v0, out_v1};
-    for (int p = blockIdx.x; p < PARTS; p += gridDim.x) {
-        const int64_t lo = int64_t(offsets[int64_t(p) * off_stride]), hi = int64_t(offsets[int64_t(p + 1) * off_stride]);
-        __syncthreads();
-        if (threadIdx.x < SUB) total_cnt[threadIdx.x] = 0, tcnt[threadIdx.x] = 0;
-        __syncthreads();
-        // ---- count
-        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-            uint32_t sp = uint32_t(((in_key[i] * GOLD) << PARTS_LOG2) >> (64 - SUB_LOG2));
-            atomicAdd(&total_cnt[sp], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t run = uint64_t(lo);
-            for (int sp = 0; sp < SUB; ++sp) {
-                gcur[sp] = run;
-                sub_offsets[int64_t(p) * SUB + sp] = run;
-                run += total_cnt[sp];
-            }
-            if (p == PARTS - 1) sub_offsets[int64_t(PARTS) * SUB] = run;
-        }
-        __syncthreads();
-        // ---- scatter, tile by tile, sorted in LDS first
-        for (int64_t base = lo; base < hi; base += SC_ROWS) {
-            uint64_t key[RPT], vw[NVT][RPT];
-            uint32_t part[RPT], rank[RPT];
-            bool pass[RPT];
-#pragma unroll
-            for (int u = 0; u < RPT; ++u) {
-                int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-                pass[u] = row < hi;
-                int64_t rc = pass[u] ? row : hi - 1;
-                key[u] = in_key[rc];
-#pragma unroll
-                for (int j = 0; j < NVT; ++j) vw[j][u] = inv[j][rc];
-                part[u] = uint32_t(((key[u] * GOLD) << PARTS_LOG2) >> (64 - SUB_LOG2));
-            }
-#pragma unroll
-            for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
-            __syncthreads();
-            if (threadIdx.x < 64) { // SUB == 64: one wave scans the tile counters
-                uint32_t c = tcnt[threadIdx.x], wt;
-                tstart[threadIdx.x] = wave_exclusive_scan(c, wt);
-            }
-            __syncthreads();
-            uint32_t tile_total = tstart[SUB - 1] + tcnt[SUB - 1];
-#pragma unroll
-            for (int u = 0; u < RPT; ++u) {
-                if (!pass[u]) continue;
-                uint32_t i = tstart[part[u]] + rank[u];
-                skey[i] = key[u];
-#pragma unroll
-                for (int j = 0; j < NVT; ++j) sval[j * SC_ROWS + i] = vw[j][u];
-            }
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < tile_total; i += blockDim.x) {
-                uint64_t k = skey[i];
-                uint32_t sp = uint32_t(((k * GOLD) << PARTS_LOG2) >> (64 - SUB_LOG2));
-                uint64_t dest = gcur[sp] + (i - tstart[sp]);
-                out_key[dest] = k;
-#pragma unroll
-                for (int j = 0; j < NVT; ++j) outv[j][dest] = sval[j * SC_ROWS + i];
-            }
-            __syncthreads();
-            if (threadIdx.x < SUB) {
-                gcur[threadIdx.x] += tcnt[threadIdx.x];
-                tcnt[threadIdx.x] = 0;
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// one workgroup per partition (grid-stride over partitions): plain (key, values) tuples → LDS table → global table.
-// The LDS slot uses the hash bits BELOW the partition bits (all keys of a partition share the top PARTS_LOG2 bits).
-template <int NVT, bool VF64>
-__global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, const uint64_t *seg_offsets, int64_t seg_stride, int nsegs, int part_bits,
-                                                                 int signal_level2, const uint64_t *keys,
-                                                                 const uint64_t *v0, const uint64_t *v1, GroupTable g, int *flags) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t cap = uint32_t(a.lds_cap);
-    const uint32_t slots = cap + 1;
-    uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
-    double *lsum = reinterpret_cast<double *>(lkeys + slots);
-    uint64_t *lmn = reinterpret_cast<uint64_t *>(lsum + NVT * slots);
-    uint64_t *lmx = lmn + NVT * slots;
-    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + NVT * slots);
-    const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
-    const uint64_t *__restrict__ valp[2] = {v0, v1};
-    int vdt[NVT];
-#pragma unroll
-    for (int j = 0; j < NVT; ++j) vdt[j] = a.val[j].dtype;
-    __shared__ int seg_full_flag;
-    volatile int *seg_full = &seg_full_flag;
-    for (int seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
-        __syncthreads();
-        if (signal_level2 && __hip_atomic_load(&flags[NQE_FLAG_NEED_LEVEL2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        if (threadIdx.x == 0) seg_full_flag = 0;
-        for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
-            lkeys[s] = EMPTY_KEY;
-#pragma unroll
-            for (int j = 0; j < NVT; ++j) {
-                lsum[j * slots + s] = 0.0;
-                lmn[j * slots + s] = ORD_MAX;
-                lmx[j * slots + s] = ORD_MIN;
-                lcnt[j * slots + s] = 0;
-            }
-        }
-        __syncthreads();
-        const int64_t lo = int64_t(seg_offsets[int64_t(seg) * seg_stride]), hi = int64_t(seg_offsets[int64_t(seg + 1) * seg_stride]);
-        for (int64_t base = lo; base < hi; base += int64_t(AGG_BLOCK) * AGG_U) {
-            uint64_t kw[AGG_U], vw[NVT][AGG_U];
-#pragma unroll
-            for (int u = 0; u < AGG_U; ++u) {
-                int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-                row = row < hi - 1 ? row : hi - 1;
-                kw[u] = keys[row];
-#pragma unroll
-                for (int j = 0; j < NVT; ++j) vw[j][u] = valp[j][row];
-            }
-#pragma unroll
-            for (int u = 0; u < AGG_U; ++u) {
-                int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-                if (row >= hi) continue;
-                const uint64_t key = kw[u];
-                // tuples of a partition arrive in no particular order: no run cache, one table update per row
-                int slot;
-                if (key == EMPTY_KEY) { lkeys[cap] = 0; slot = int(cap); }
-                else if (*seg_full) slot = -1; // this partition has more distinct keys than the table: spill the rest
-                else {
-                    uint32_t sl = uint32_t(((key * GOLD) << part_bits) >> a.lds_shift);
-                    slot = -1;
-                    for (int probe = 0; probe < 32; ++probe) {
-                        uint64_t k = lkeys[sl];
-                        if (k == key) { slot = int(sl); break; }
-                        if (k == EMPTY_KEY) {
-                            uint64_t old = atomicCAS((unsigned long long *)&lkeys[sl], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-                            if (old == EMPTY_KEY || old == key) { slot = int(sl); break; }
-                        }
-                        sl = (sl + 1) & (cap - 1);
-                    }
-                }
-                if (slot < 0 && !*seg_full) {
-                    *seg_full = 1;
-                    if (signal_level2) atomicOr(&flags[NQE_FLAG_NEED_LEVEL2], 1); // the host re-partitions one level deeper
-                }
-                if (slot < 0 && signal_level2) continue;                              // result will be discarded
-                if (slot < 0 && g.dense_count) {                                      // no hash table to spill to: the host falls back
-                    atomicOr(&flags[NQE_FLAG_DENSE_OVERFLOW], 1);
-                    continue;
-                }
-                int64_t gslot = slot < 0 ? global_find_or_insert(g, key, flags) : 0; // partition larger than the table: spill
-#pragma unroll
-                for (int j = 0; j < NVT; ++j) {
-                    double x = VF64 ? u2d(vw[j][u]) : word_as_f64(vw[j][u], vdt[j]);
-                    bool isn = x != x;
-                    uint64_t xo = f64_to_ord(x);
-                    if (slot >= 0) {
-                        uint32_t o = uint32_t(j) * slots + uint32_t(slot);
-                        atomicAdd(&lcnt[o], 1u);
-                        if (isn) atomicOr(&lcnt[o], NAN_BIT);
-                        unsafeAtomicAdd(&lsum[o], x);
-                        if (!isn) {
-                            if (xo < lmn[o]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)xo);
-                            if (xo > lmx[o]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)xo);
-                        }
-                    } else if (gslot >= 0) {
-                        global_update(g, gslot, a.v0 + j, 1, x, true, xo, xo, !isn, isn);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (g.dense_count) {
-            // ---- dense output: count this partition's groups, reserve [base, base + n) with one atomic, write them there
-            __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
-            __shared__ uint32_t dense_base;
-            uint32_t mine = 0;
-            for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) mine += lkeys[s] != EMPTY_KEY ? 1u : 0u;
-            uint32_t wtot;
-            const uint32_t wexcl = wave_exclusive_scan(mine, wtot);
-            if (lane_id() == 0) wave_tot[threadIdx.x / 64] = wtot;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t tot = 0;
-                for (int w = 0; w < AGG_BLOCK / 64; ++w) { uint32_t c = wave_tot[w]; wave_tot[w] = tot; tot += c; }
-                dense_base = tot ? atomicAdd(g.dense_count, tot) : 0u;
-            }
-            __syncthreads();
-            uint32_t pos = dense_base + wave_tot[threadIdx.x / 64] + wexcl;
-            const size_t gstride = size_t(g.cap) + 1;
-            for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
-                uint64_t k = lkeys[s];
-                if (k == EMPTY_KEY) continue;
-                if (pos < g.cap) {
-                    g.keys[pos] = (s == cap) ? EMPTY_KEY : k;
-#pragma unroll
-                    for (int j = 0; j < NVT; ++j) {
-                        const uint32_t o = uint32_t(j) * slots + s;
-                        const uint32_t c = lcnt[o];
-                        const size_t go = size_t(a.v0 + j) * gstride + pos;
-                        g.cnt[go] = uint64_t(c & ~NAN_BIT);
-                        g.sum[go] = lsum[o];
-                        g.mn[go] = lmn[o];
-                        g.mx[go] = lmx[o];
-                        g.nan[go] = (c & NAN_BIT) ? 1u : 0u;
-                    }
-                } else atomicOr(&flags[NQE_FLAG_DENSE_OVERFLOW], 1);
-                ++pos;
-            }
-            continue;
-        }
-        for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
-            uint64_t k = lkeys[s];
-            if (k == EMPTY_KEY) continue;
-            uint64_t key = (s == cap) ? EMPTY_KEY : k;
-            int64_t gslot = global_find_or_insert(g, key, flags);
-            if (gslot < 0) continue;
-#pragma unroll
-            for (int j = 0; j < NVT; ++j) {
-                uint32_t o = uint32_t(j) * slots + s;
-                uint32_t c = lcnt[o];
-                global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
-            }
-        }
-    }
-}
-
-using PartKernel = void (*)(AggArgs, FastPred, PartArgs);
-template <int PRED, int KEY> PartKernel pick_scatter_nv(int nv) {
-    return nv == 1 ? agg_partition_scatter_kernel<PRED, KEY, 1> : agg_partition_scatter_kernel<PRED, KEY, 2>;
-}
-template <int PRED> PartKernel pick_scatter_key(int key, int nv) {
-    switch (key) {
-    case 0: return pick_scatter_nv<PRED, 0>(nv);
-    case 1: return pick_scatter_nv<PRED, 1>(nv);
-    default: return pick_scatter_nv<PRED, 2>(nv);
-    }
-}
-PartKernel pick_scatter_kernel(int pred, int key, int nv) {
-    switch (pred) {
-    case 0: return pick_scatter_key<0>(key, nv);
-    case 1: return pick_scatter_key<1>(key, nv);
-    default: return pick_scatter_key<2>(key, nv);
-    }
-}
-template <int PRED, int KEY, int NVT> PartKernel pick_part_sc(bool scatter) {
-    return scatter ? agg_partition_kernel<PRED, KEY, NVT, true> : agg_partition_kernel<PRED, KEY, NVT, false>;
-}
-template <int PRED, int KEY> PartKernel pick_part_nv(int nv, bool scatter) {
-    return nv == 1 ? pick_part_sc<PRED, KEY, 1>(scatter) : pick_part_sc<PRED, KEY, 2>(scatter);
-}
-template <int PRED> PartKernel pick_part_key(int key, int nv, bool scatter) {
-    switch (key) {
-    case 0: return pick_part_nv<PRED, 0>(nv, scatter);
-    case 1: return pick_part_nv<PRED, 1>(nv, scatter);
-    default: return pick_part_nv<PRED, 2>(nv, scatter);
-    }
-}
-PartKernel pick_part_kernel(int pred, int key, int nv, bool scatter) {
-    switch (pred) {
-    case 0: return pick_part_key<0>(key, nv, scatter);
-    case 1: return pick_part_key<1>(key, nv, scatter);
-    default: return pick_part_key<2>(key, nv, scatter);
-    }
-}
-
 using GroupedKernel = void (*)(AggArgs, GroupTable, int *);
 template <int PRED, int KEY> GroupedKernel pick_plain(bool plain) {
     return plain ? agg_grouped_kernel<PRED, KEY, true> : agg_grouped_kernel<PRED, KEY, false>;
@@ -1049,26 +239,6 @@ GroupedKernel pick_grouped_kernel(int pred, int key, bool plain) {
     case 1: return pick_key<1>(key, plain);
     case 2: return pick_key<2>(key, plain);
     default: return pick_key<3>(key, plain);
-    }
-}
-
-using FastKernel = void (*)(AggArgs, FastPred, GroupTable, int *);
-template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64) {
-    if (nv == 1) return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 1, false, VNULL>;
-    return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 2, false, VNULL>;
-}
-template <int PRED> FastKernel pick_fast_key(int key, int nv, bool vf64, bool vnull) {
-    switch (key) {
-    case 0: return vnull ? pick_fast_nv<PRED, 0, true>(nv, vf64) : pick_fast_nv<PRED, 0, false>(nv, vf64);
-    case 1: return vnull ? pick_fast_nv<PRED, 1, true>(nv, vf64) : pick_fast_nv<PRED, 1, false>(nv, vf64);
-    default: return vnull ? pick_fast_nv<PRED, 2, true>(nv, vf64) : pick_fast_nv<PRED, 2, false>(nv, vf64);
-    }
-}
-FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull) {
-    switch (pred) {
-    case 0: return pick_fast_key<0>(key, nv, vf64, vnull);
-    case 1: return pick_fast_key<1>(key, nv, vf64, vnull);
-    default: return pick_fast_key<2>(key, nv, vf64, vnull);
     }
 }
 
@@ -1792,8 +962,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                                 sblocks = 1;
                             }
                             int sgrid = std::min(PARTS, ctx->num_cus * sblocks);
-                            auto segk = a.nv == 1 ? (vf64 ? agg_segments_kernel<1, true> : agg_segments_kernel<1, false>)
-                                                  : (vf64 ? agg_segments_kernel<2, true> : agg_segments_kernel<2, false>);
+                            auto segk = pick_segments_kernel(a.nv, vf64);
                             if (!level2) {
                                 launch(ctx, "agg_segments", segk, dim3(sgrid), dim3(AGG_BLOCK), sshmem, sa, (const uint64_t *)offs->ptr, int64_t(nblk), PARTS,
                                        PARTS_LOG2, 1, (const uint64_t *)okey->ptr, (const uint64_t *)ov0->ptr,
@@ -1803,7 +972,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                                 BufRef k2 = dev_alloc(ctx, size_t(R) * 8 + 8), v02 = dev_alloc(ctx, size_t(R) * 8 + 8), v12;
                                 if (a.nv > 1) v12 = dev_alloc(ctx, size_t(R) * 8 + 8);
                                 BufRef suboff = dev_alloc(ctx, size_t(PARTS) * SUB * 8 + 16);
-                                auto subk = a.nv == 1 ? agg_subpartition_kernel<1> : agg_subpartition_kernel<2>;
+                                auto subk = pick_subpartition_kernel(a.nv);
                                 launch(ctx, "agg_subpartition", subk, dim3(std::min(PARTS, ctx->num_cus)), dim3(AGG_BLOCK), sc_rows * 8 * size_t(1 + a.nv),
                                        (const uint64_t *)offs->ptr, int64_t(nblk), (const uint64_t *)okey->ptr, (const uint64_t *)ov0->ptr,
                                        ov1 ? (const uint64_t *)ov1->ptr : (const uint64_t *)nullptr, (uint64_t *)k2->ptr, (uint64_t *)v02->ptr,
