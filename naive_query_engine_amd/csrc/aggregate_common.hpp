@@ -14,7 +14,10 @@ namespace agg {
 constexpr uint64_t EMPTY_KEY = 0x8000000000000000ull; // i64::MIN; that key uses the extra slot [cap]
 constexpr uint64_t GOLD = 0x9E3779B97F4A7C15ull;
 constexpr int NV = 2;      // value columns per kernel pass
-constexpr int AGG_U = 4;   // rows per thread per iteration
+#ifndef NQE_AGG_U
+#define NQE_AGG_U 4
+#endif
+constexpr int AGG_U = NQE_AGG_U;   // rows per thread per iteration
 constexpr int AGG_BLOCK = 1024;
 constexpr uint32_t NAN_BIT = 0x80000000u;
 
