@@ -990,7 +990,13 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         // 2.44 -> 2.39 ms, C3 2.56 -> 2.41 ms, random keys 3.63 -> 3.54 ms, 1 % nulls 0.81 -> 0.69 ms per 2e8 rows;
                         // tools/stream_bench.hip shows the same for a bare read kernel)
                         const int fgrid = std::min(grid, ctx->num_cus);
-                        launch(ctx, "agg_grouped_fast", pick_fast_kernel(fp, fast_key, a.nv, vf64, vnull), dim3(fgrid), dim3(AGG_BLOCK), shmem, ka,
+                        size_t fshmem = shmem;
+                        if (a.nv == 1) { // the CU's LDS is this workgroup's alone: a 4096-slot table (147 KB) keeps up to ~3500 groups on this path
+                            ka.lds_cap = 4096;
+                            ka.lds_shift = 64 - 12;
+                            fshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
+                        }
+                        launch(ctx, "agg_grouped_fast", pick_fast_kernel(fp, fast_key, a.nv, vf64, vnull), dim3(fgrid), dim3(AGG_BLOCK), fshmem, ka,
                                fpred, tb.g, ctx->d_flags);
                     }
                 } else {

@@ -140,7 +140,7 @@ if SECTION in ("all", "csv"):
     print("   kernels(ms):", br)
 
 # ---- 3. high-cardinality group-by
-for groups in ((1 << 10, 1 << 12, 1 << 14, 1 << 17, 1 << 20, 1 << 24) if SECTION in ('all', 'groups') else ()):
+for groups in ((1 << 10, 2000, 3000, 1 << 12, 1 << 14, 1 << 17, 1 << 20, 1 << 24) if SECTION in ('all', 'groups') else ()):
     kt = torch.empty(n, dtype=torch.int64, device=dev)
     ctx.synth_fill(1, 7, 0, n, groups, 0, kt.data_ptr())
     tab = ctx.table_from_device([(DType.INT64, n, kt.data_ptr(), None), (DType.FLOAT64, n, vt.data_ptr(), None)])
