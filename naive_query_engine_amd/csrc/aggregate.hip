@@ -1003,7 +1003,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     // the general kernel's PLAIN variant reads predicate and values as bare 8-byte words: not for a Boolean
                     // predicate column (bits) nor nullable values (found by the differential fuzzer: a bitmap predicate with
                     // a key shape the fast kernel does not cover was read as words)
-                    launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain && !vnull && !bitmap_pred), dim3(grid), dim3(AGG_BLOCK), shmem, ka, tb.g,
+                    launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain && !vnull && !bitmap_pred), dim3(std::min(grid, ctx->num_cus)), dim3(AGG_BLOCK), shmem, ka, tb.g,
                            ctx->d_flags);
                 }
             } else {
