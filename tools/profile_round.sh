@@ -16,7 +16,7 @@ python bench.py --workload c2 2>&1 | tail -1 > $OUT/bench_c2.json
 python bench.py --workload c4 --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_c4.json
 cd /tmp
 for w in headline c2 c3 c4; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python $R/bench.py --workload $w --no-cpu-baseline --steps 5 --warmup 2 > $OUT/prof_$w.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python $R/bench.py --workload $w --no-cpu-baseline --steps 20 --warmup 3 > $OUT/prof_$w.log 2>&1
 done
 # PMC passes: counters in their own runs, kernel-trace only (never combined with other trace domains)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o headline -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
