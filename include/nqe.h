@@ -30,6 +30,14 @@
  *     outputs are nqe_table handles owned by the caller (nqe_table_release).
  *   - a context owns one HIP stream on one device and is used by one host
  *     thread at a time (the reference is single-threaded).
+ *   - calls are stream-ordered: an operator may return while its last kernels
+ *     still run on the context's stream; every later call on the same context,
+ *     every download and nqe_ctx_synchronize order after them.  Errors that
+ *     depend on device data (DivideByZero, overflow) are still reported by the
+ *     call that causes them: a call whose expressions can raise one reads the
+ *     device flags back (and thereby synchronises) before returning.  Device
+ *     pointers from nqe_table_column may be handed to another stream only after
+ *     nqe_ctx_synchronize.
  */
 #ifndef NQE_H
 #define NQE_H

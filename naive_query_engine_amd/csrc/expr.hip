@@ -757,6 +757,13 @@ ExprInfo analyze_expr(const nqe_table *in, const nqe_expr_node *nodes, int n) {
     ExprInfo info;
     info.out_dtype = t[size_t(root)].out_dtype;
     info.simple = match_simple(t, root, &info.s);
+    for (const Node &x : t) {
+        if (x.kind != NQE_EXPR_BINARY || (x.op != NQE_OP_DIVIDE && x.op != NQE_OP_MODULOS)) continue;
+        const Node &r = t[size_t(x.right)];
+        const bool safe_literal = r.kind == NQE_EXPR_LITERAL && !r.lit_null &&
+                                  (r.dtype == NQE_FLOAT64 ? r.lit != 0 && r.lit != 0x8000000000000000ull : r.lit != 0 && r.lit != ~0ull);
+        if (!safe_literal) info.may_fault = true;
+    }
     return info;
 }
 
@@ -831,12 +838,14 @@ nqe_status nqe_expr_evaluate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_n
                              nqe_table **out) {
     NQE_API_BEGIN(ctx)
     if (!ctx || !in || !out) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
-    flags_reset(ctx);
+    // the error flags are reset and read back (a stream synchronisation) only when the expression can raise one
+    const bool fault = analyze_expr(in, nodes, num_nodes).may_fault;
+    if (fault) flags_reset(ctx);
     auto t = std::make_unique<nqe_table>();
     t->ctx = ctx;
     t->rows = in->rows;
     t->cols.push_back(evaluate_expr(ctx, in, nodes, num_nodes));
-    throw_on_flags(ctx);
+    if (fault) throw_on_flags(ctx);
     *out = t.release();
     NQE_API_END()
 }
@@ -846,13 +855,15 @@ nqe_status nqe_projection_execute(nqe_ctx *ctx, const nqe_table *in, const nqe_e
     NQE_API_BEGIN(ctx)
     if (!ctx || !in || !out || num_exprs < 0 || (num_exprs > 0 && (!nodes || !expr_offsets)))
         fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
-    flags_reset(ctx);
+    bool fault = false;
+    for (int e = 0; e < num_exprs; ++e) fault = fault || analyze_expr(in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e]).may_fault;
+    if (fault) flags_reset(ctx);
     auto t = std::make_unique<nqe_table>();
     t->ctx = ctx;
     t->rows = in->rows;
     for (int e = 0; e < num_exprs; ++e)
         t->cols.push_back(evaluate_expr(ctx, in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e]));
-    throw_on_flags(ctx);
+    if (fault) throw_on_flags(ctx);
     *out = t.release();
     NQE_API_END()
 }

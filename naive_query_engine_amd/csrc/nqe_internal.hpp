@@ -233,6 +233,9 @@ struct ExprInfo {
     int out_dtype = NQE_NULLTYPE;
     bool simple = false;
     SimpleExpr s{};
+    // true when evaluating it can raise a device error flag (a divide/modulus whose divisor is not a literal other than
+    // 0 and -1): only then does an operator need the flag read-back, which is a stream synchronisation
+    bool may_fault = false;
 };
 // type-checks (IntervalError / NotSupported exactly where the reference raises them) and
 // recognises the fusable shape

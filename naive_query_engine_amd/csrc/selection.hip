@@ -367,13 +367,15 @@ nqe_status nqe_selection_execute(nqe_ctx *ctx, const nqe_table *in, const nqe_ex
                                  nqe_table **out) {
     NQE_API_BEGIN(ctx)
     if (!ctx || !in || !out) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
-    flags_reset(ctx);
+    // the error flags are reset and read back (a stream synchronisation) only when the predicate can raise one
+    const bool fault = analyze_expr(in, pred, pred_nodes).may_fault;
+    if (fault) flags_reset(ctx);
     KeepMask km = mask_for_predicate(ctx, in, pred, pred_nodes);
     auto t = std::make_unique<nqe_table>();
     t->ctx = ctx;
     t->rows = km.total;
     for (auto &c : in->cols) t->cols.push_back(compact_column(ctx, c, km));
-    throw_on_flags(ctx);
+    if (fault) throw_on_flags(ctx);
     *out = t.release();
     NQE_API_END()
 }
@@ -384,10 +386,13 @@ nqe_status nqe_selection_projection_execute(nqe_ctx *ctx, const nqe_table *in, c
     NQE_API_BEGIN(ctx)
     if (!ctx || !in || !out || num_exprs < 0 || (num_exprs > 0 && (!nodes || !expr_offsets)))
         fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
-    flags_reset(ctx);
     // type errors of the projection surface before any work, as they would at evaluate()
     std::vector<ExprInfo> infos;
     for (int e = 0; e < num_exprs; ++e) infos.push_back(analyze_expr(in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e]));
+    // the error flags are reset and read back (a stream synchronisation) only when some expression can raise one
+    bool fault = analyze_expr(in, pred, pred_nodes).may_fault;
+    for (auto &inf : infos) fault = fault || inf.may_fault;
+    if (fault) flags_reset(ctx);
     KeepMask km = mask_for_predicate(ctx, in, pred, pred_nodes);
     auto t = std::make_unique<nqe_table>();
     t->ctx = ctx;
@@ -412,7 +417,7 @@ nqe_status nqe_selection_projection_execute(nqe_ctx *ctx, const nqe_table *in, c
         }
         t->cols.push_back(std::move(c));
     }
-    throw_on_flags(ctx);
+    if (fault) throw_on_flags(ctx);
     *out = t.release();
     NQE_API_END()
 }
