@@ -1,9 +1,10 @@
 """naive_query_engine_amd — MI355X-native physical execution layer for naive-query-engine's hot
-operators (filter, projection, hash group-by aggregate, inner hash join), hand-written HIP for
-gfx950 behind the C ABI in include/nqe.h.
+operators (filter, projection, hash group-by aggregate, inner hash join) and its CSV ingest,
+hand-written HIP for gfx950 behind the C ABI in include/nqe.h.
 
 Layout:
   csrc/            HIP kernels + the C-ABI implementation (libnqe_hip.so, built in-tree)
+  host/naive_db.hpp C++ mirror of the reference's operator classes over the C ABI
   capi.py          ctypes binding of include/nqe.h (fails loudly if the library is missing)
   arrow_host.py    numpy-backed Arrow-layout host containers (plumbing)
   expression.py    host mirror of ColumnExpr / PhysicalLiteralExpr / PhysicalBinaryExpr

@@ -680,14 +680,25 @@ struct AggResult {
 };
 
 // collect → sort by key → finalize
+// occupied slots of a hashed table, collected ahead of the flag read-back so that the group count travels with the flags
+// (one stream synchronisation per aggregate step instead of two)
+struct Collected {
+    BufRef keys, slots;
+    int64_t G = -1; // -1: not collected yet
+};
+
 AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const nqe_aggregate *aggs, int naggs,
-               const std::vector<int> &vslot, bool partial) {
+               const std::vector<int> &vslot, bool partial, const Collected *pre = nullptr) {
     int64_t G = 1;
     BufRef sorted_keys, sorted_slots;
     if (grouped) {
         size_t slots = size_t(tb.g.cap) + 1;
         BufRef ck, cs;
-        if (tb.g.dense_count) { // groups already occupy slots [0, G)
+        if (pre && pre->G >= 0) {
+            G = pre->G;
+            ck = pre->keys;
+            cs = pre->slots;
+        } else if (tb.g.dense_count) { // groups already occupy slots [0, G)
             G = int64_t(read_scalar(ctx, (const uint32_t *)tb.g.dense_count));
             ck = tb.keys;
             cs = dev_alloc(ctx, size_t(G) * 4 + 8);
@@ -1031,8 +1042,18 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                        (const Partial *)partials->ptr, grid, a.nv, v0, tb.g);
             }
         }
+        Collected pre;
+        if (grouped && !tb.g.dense_count && tb.g.cap <= (1u << 16)) {
+            // small table: collect speculatively; the count lands in the spare flag slot and is read with the flags
+            const size_t slots = size_t(tb.g.cap) + 1;
+            pre.keys = dev_alloc(ctx, slots * 8);
+            pre.slots = dev_alloc(ctx, slots * 4);
+            launch(ctx, "agg_collect", collect_kernel, dim3(stream_grid(ctx, int64_t(slots), 256)), dim3(256), 0, tb.g, (uint64_t *)pre.keys->ptr,
+                   (uint32_t *)pre.slots->ptr, reinterpret_cast<uint32_t *>(ctx->d_flags + NQE_FLAG_GROUP_COUNT));
+        }
         int f[NQE_NUM_FLAGS];
         flags_read(ctx, f);
+        if (pre.keys) pre.G = int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT]));
         if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
         if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2) {
@@ -1057,7 +1078,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             flags_reset(ctx);
             continue;
         }
-        AggResult res = emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial);
+        AggResult res = emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial, &pre);
         if (utf8_key && res.keys) { // keys_out: the strings of the representative rows
             DevColumn codes = res.keys->cols[0];
             res.keys->cols[0] = take_utf8(ctx, utf8_src, (const int64_t *)codes.words(), codes.length, false);
