@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_kernel(AggArgs a, Par
 
 // un-grouped fast path: plain 8-byte columns, optional integer range predicate on one column.
 // PRED: 0 none, 1 predicate column is value column 0 (one load serves both), 2 a separate column.
-template <int PRED, int NVT, bool VF64>
+template <int PRED, int NVT, bool VF64, bool VNULL>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_fast_kernel(AggArgs a, FastPred fp, Partial *partials) {
     uint64_t cnt[NVT];
     double sum[NVT], mn[NVT], mx[NVT];
@@ -344,15 +344,19 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_fast_kernel(AggArgs a
     }
     const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(a.pred_src.values);
     const uint64_t *__restrict__ valp[NVT];
+    const uint64_t *__restrict__ vvalid[NVT]; // VNULL: word-readable validity bitmaps, null = all valid
+    const uint64_t *__restrict__ pvalid = reinterpret_cast<const uint64_t *>(PRED != 0 ? a.pred_src.valid : nullptr);
     int vdt[NVT];
 #pragma unroll
     for (int j = 0; j < NVT; ++j) {
         valp[j] = static_cast<const uint64_t *>(a.val[j].values);
+        vvalid[j] = reinterpret_cast<const uint64_t *>(a.val[j].valid);
         vdt[j] = a.val[j].dtype;
     }
     const int64_t n = a.n, last = a.n - 1;
     struct Tile {
         uint64_t pw[AGG_U], vw[NVT][AGG_U];
+        uint64_t vv[VNULL ? NVT : 1][AGG_U], pv[VNULL ? AGG_U : 1];
     };
     auto load_tile = [&](Tile &t, int64_t base) {
 #pragma unroll
@@ -362,6 +366,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_fast_kernel(AggArgs a
             if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
 #pragma unroll
             for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
+            if (VNULL) {
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) t.vv[j][u] = vvalid[j] ? vvalid[j][row >> 6] : ~0ull;
+                t.pv[u] = pvalid ? pvalid[row >> 6] : ~0ull;
+            }
         }
     };
     auto process_tile = [&](const Tile &t, int64_t base) {
@@ -370,10 +379,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_fast_kernel(AggArgs a
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = row < n;
             if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? t.vw[0][u] : pred_extract(fp, t.pw[u], row));
+            if (VNULL) pass = pass && ((t.pv[u] >> (row & 63)) & 1ull); // a NULL predicate's row is all-NULL: contributes nothing
             if (!pass) continue;
 #pragma unroll
             for (int j = 0; j < NVT; ++j) {
                 double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+                if (VNULL && !((t.vv[j][u] >> (row & 63)) & 1ull)) continue; // NULL value: not counted (Q10)
                 cnt[j] += 1;
                 sum[j] += x;
                 nanf[j] = nanf[j] || (x != x);
@@ -432,15 +443,17 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_ungrouped_fast_kernel(AggArgs a
 }
 
 using UngroupedFastKernel = void (*)(AggArgs, FastPred, Partial *);
-template <int PRED> UngroupedFastKernel pick_ungrouped_fast_nv(int nv, bool vf64) {
-    if (nv == 1) return vf64 ? agg_ungrouped_fast_kernel<PRED, 1, true> : agg_ungrouped_fast_kernel<PRED, 1, false>;
-    return vf64 ? agg_ungrouped_fast_kernel<PRED, 2, true> : agg_ungrouped_fast_kernel<PRED, 2, false>;
+template <int PRED, bool VNULL> UngroupedFastKernel pick_ungrouped_fast_nv(int nv, bool vf64) {
+    if (nv == 1) return vf64 ? agg_ungrouped_fast_kernel<PRED, 1, true, VNULL> : agg_ungrouped_fast_kernel<PRED, 1, false, VNULL>;
+    return vf64 ? agg_ungrouped_fast_kernel<PRED, 2, true, VNULL> : agg_ungrouped_fast_kernel<PRED, 2, false, VNULL>;
 }
-UngroupedFastKernel pick_ungrouped_fast(int pred, int nv, bool vf64) {
-    return pred == 0 ? pick_ungrouped_fast_nv<0>(nv, vf64) : pred == 1 ? pick_ungrouped_fast_nv<1>(nv, vf64) : pick_ungrouped_fast_nv<2>(nv, vf64);
+template <bool VNULL> UngroupedFastKernel pick_ungrouped_fast_pred(int pred, int nv, bool vf64) {
+    return pred == 0 ? pick_ungrouped_fast_nv<0, VNULL>(nv, vf64) : pred == 1 ? pick_ungrouped_fast_nv<1, VNULL>(nv, vf64) : pick_ungrouped_fast_nv<2, VNULL>(nv, vf64);
+}
+UngroupedFastKernel pick_ungrouped_fast(int pred, int nv, bool vf64, bool vnull) {
+    return vnull ? pick_ungrouped_fast_pred<true>(pred, nv, vf64) : pick_ungrouped_fast_pred<false>(pred, nv, vf64);
 }
 
-// folds the per-workgroup partials (in block order) into slot 0 of a cap=1 table
 __global__ void agg_ungrouped_fold_kernel(const Partial *partials, int nblocks, int nv, int v0, GroupTable g) {
     int j = threadIdx.x;
     if (j >= nv) return;
@@ -1024,16 +1037,21 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 // fast path: plain 8-byte value columns, predicate none or an integer `col cmp lit`
                 FastPred ufp{};
                 bool uplain = a.nv >= 1;
-                for (int j = 0; j < a.nv; ++j) uplain = uplain && a.val[j].values && !a.val[j].valid;
-                const bool ubitmap = a.pred_src.dtype == NQE_BOOLEAN && !a.pred_src.valid && (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
+                bool uvnull = a.pred_mode != 0 && a.pred_src.valid != nullptr;
+                for (int j = 0; j < a.nv; ++j) {
+                    uplain = uplain && a.val[j].values;
+                    uvnull = uvnull || a.val[j].valid != nullptr;
+                }
+                if (uvnull && (!valid_words_ok || !kp_valid_words_ok)) uplain = false; // bitmaps must be readable as whole words
+                const bool ubitmap = a.pred_src.dtype == NQE_BOOLEAN && (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
                 if (ubitmap) ufp = bitmap_fast_pred();
                 bool upred_ok = a.pred_mode == 0 || ubitmap ||
-                                (a.pred_mode == 1 && is_word_type(a.pred_src.dtype) && !a.pred_src.valid && make_fast_pred(a.pred, &ufp));
+                                (a.pred_mode == 1 && is_word_type(a.pred_src.dtype) && make_fast_pred(a.pred, &ufp));
                 if (uplain && upred_ok) {
                     int up = a.pred_mode == 0 ? 0 : ((a.pred_src.values == a.val[0].values && !ubitmap && !ufp.fmask) ? 1 : 2);
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
-                    launch(ctx, "agg_ungrouped_fast", pick_ungrouped_fast(up, a.nv, vf64), dim3(grid), dim3(AGG_BLOCK), 0, a, ufp,
+                    launch(ctx, "agg_ungrouped_fast", pick_ungrouped_fast(up, a.nv, vf64, uvnull), dim3(grid), dim3(AGG_BLOCK), 0, a, ufp,
                            (Partial *)partials->ptr);
                 } else
                 launch(ctx, "agg_ungrouped", agg_ungrouped_kernel, dim3(grid), dim3(AGG_BLOCK), 0, a, (Partial *)partials->ptr,
