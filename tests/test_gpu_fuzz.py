@@ -15,6 +15,7 @@ import os
 
 pytestmark = pytest.mark.gpu
 EXTRA = int(os.environ.get("NQE_FUZZ_EXTRA_SEEDS", "0"))  # a longer hunt: NQE_FUZZ_EXTRA_SEEDS=200 pytest tests/test_gpu_fuzz.py
+BASE = int(os.environ.get("NQE_FUZZ_SEED_BASE", "0"))      # ... and NQE_FUZZ_SEED_BASE=100000 for fresh cases
 FLD = fields("id", "k", "v", "u", "b")
 SIZES = [0, 1, 2, 63, 64, 65, 127, 1000, 4095, 4096, 4097, 8193, 20000, 70001]
 RTOL = 1e-9
@@ -77,7 +78,7 @@ def both(fn_gpu, fn_orc, what):
 
 @pytest.mark.parametrize("seed", range(12 + EXTRA))
 def test_fuzz_selection_projection_aggregate(ctx, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + BASE + seed)
     for case in range(14):
         n = int(rng.choice(SIZES))
         null_frac = float(rng.choice([0.0, 0.0, 0.05, 0.5]))
@@ -110,7 +111,7 @@ def test_fuzz_selection_projection_aggregate(ctx, seed):
 
 @pytest.mark.parametrize("seed", range(6 + EXTRA))
 def test_fuzz_hash_join(ctx, seed):
-    rng = np.random.default_rng(2000 + seed)
+    rng = np.random.default_rng(2000 + BASE + seed)
     for case in range(10):
         nb, npr = int(rng.choice([0, 1, 5, 64, 1000, 4097, 30000])), int(rng.choice([0, 1, 63, 65, 4096, 50001]))
         domain = int(rng.choice([4, 100, 5000, 1 << 20, 1 << 40]))
@@ -137,7 +138,7 @@ def test_fuzz_hash_join(ctx, seed):
 def test_fuzz_many_groups_partitioned_paths(ctx, seed):
     """enough rows and distinct keys to leave the single LDS table: partitioned (dense and hashed) and two-level paths,
     one and several value-column passes, nullable values"""
-    rng = np.random.default_rng(3000 + seed)
+    rng = np.random.default_rng(3000 + BASE + seed)
     n = int(rng.choice([300_000, 700_001, 1_500_000]))
     groups = int(rng.choice([3000, 40_000, 900_000]))
     null_frac = float(rng.choice([0.0, 0.0, 0.1]))
@@ -164,7 +165,7 @@ def test_fuzz_utf8_everywhere(ctx, seed):
     from naive_query_engine_amd.expression import lit_utf8
     from tests.helpers import random_utf8
 
-    rng = np.random.default_rng(4000 + seed)
+    rng = np.random.default_rng(4000 + BASE + seed)
     n = int(rng.choice([1, 64, 1000, 4097, 30000]))
     null_frac = float(rng.choice([0.0, 0.2]))
     s1, s2 = random_utf8(rng, n, null_frac), random_utf8(rng, n, 0.0)
@@ -201,7 +202,7 @@ def test_fuzz_utf8_everywhere(ctx, seed):
 @pytest.mark.parametrize("seed", range(4 + EXTRA // 4))
 def test_fuzz_csv(ctx, seed):
     """random CSV images (quotes, escapes, embedded terminators, empty fields and lines, CR/LF/CRLF, odd delimiters)"""
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + BASE + seed)
     for case in range(12):
         nrows, ncols = int(rng.choice([0, 1, 3, 4, 50, 700])), int(rng.integers(1, 6))
         delim = str(rng.choice([",", ";", "|", "\t"]))
