@@ -40,6 +40,56 @@ __global__ void __launch_bounds__(1024) read2(const uint64_t *a, const uint64_t 
     if (acc == 0x123456789abcdefull) out[0] = acc; // keep the loads alive
 }
 
+// Write-side ceilings for the kernels that emit as much as they read (compaction, the join's fused write): RD input columns
+// streamed once, WR output columns written once (WR = 0: the read2 case above; RD = 0: a pure fill), NT picks non-temporal
+// stores.  One 8-byte element per lane per column per unrolled step, like the product kernels.
+template <int U, int RD, int WR, int NT>
+__global__ void __launch_bounds__(1024) copy_rw(const uint64_t *in, uint64_t *outp, int64_t n) {
+    const int64_t step = int64_t(blockDim.x) * U;
+    for (int64_t base = int64_t(blockIdx.x) * step; base < n; base += int64_t(gridDim.x) * step) {
+        uint64_t x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t i = base + int64_t(u) * blockDim.x + threadIdx.x;
+            i = i < n - 1 ? i : n - 1;
+            x[u] = uint64_t(i);
+#pragma unroll
+            for (int r = 0; r < RD; ++r) x[u] += __builtin_nontemporal_load(in + r * n + i);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + int64_t(u) * blockDim.x + threadIdx.x;
+            if (i < n) {
+#pragma unroll
+                for (int w = 0; w < WR; ++w) {
+                    if (NT) __builtin_nontemporal_store(x[u] + w, outp + w * n + i);
+                    else outp[w * n + i] = x[u] + w;
+                }
+            }
+        }
+    }
+}
+
+template <int U, int RD, int WR, int NT>
+int run_rw(const uint64_t *in, uint64_t *outp, int64_t n, int blocks_per_cu, int threads) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int grid = 256 * blocks_per_cu;
+    for (int w = 0; w < 2; ++w) copy_rw<U, RD, WR, NT><<<grid, threads>>>(in, outp, n);
+    CK(hipEventRecord(e0));
+    const int reps = 10;
+    for (int r = 0; r < reps; ++r) copy_rw<U, RD, WR, NT><<<grid, threads>>>(in, outp, n);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    printf("copy U=%d read=%d write=%d nt=%d blocks/CU=%d threads=%d: %.3f ms = %.0f GB/s\n", U, RD, WR, NT, blocks_per_cu, threads, ms,
+           8.0 * (RD + WR) * n / ms / 1e6);
+    return 0;
+}
+
 template <int U, int WIDE>
 int run(const uint64_t *a, const uint64_t *b, int64_t n, uint64_t *out, int blocks_per_cu, int threads) {
     hipEvent_t e0, e1;
@@ -72,6 +122,21 @@ int main() {
             if (run<4, 0>(a, b, n, out, bpc, th)) return 1;
             if (run<8, 0>(a, b, n, out, bpc, th)) return 1;
             if (run<4, 1>(a, b, n, out, bpc, th)) return 1;
+        }
+    }
+    // read:write mixes at 2e8 rows per column (1.6 GB each): fill, 1:1 copy, the join's 2:4, the selection's 2:2
+    const int64_t m = 200000000;
+    uint64_t *wout = a; // a holds up to 5 columns of m rows (8 GB); b supplies the inputs
+    for (int bpc : {1, 2, 8}) {
+        for (int th : {256, 1024}) {
+            if (run_rw<4, 0, 4, 0>(b, wout, m, bpc, th)) return 1;
+            if (run_rw<4, 0, 4, 1>(b, wout, m, bpc, th)) return 1;
+            if (run_rw<4, 1, 1, 0>(b, wout, m, bpc, th)) return 1;
+            if (run_rw<4, 1, 1, 1>(b, wout, m, bpc, th)) return 1;
+            if (run_rw<4, 2, 4, 0>(b, wout, m, bpc, th)) return 1;
+            if (run_rw<4, 2, 4, 1>(b, wout, m, bpc, th)) return 1;
+            if (run_rw<16, 2, 4, 1>(b, wout, m, bpc, th)) return 1;
+            if (run_rw<4, 2, 2, 1>(b, wout, m, bpc, th)) return 1;
         }
     }
     return 0;
