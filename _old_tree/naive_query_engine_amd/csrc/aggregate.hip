@@ -538,131 +538,42 @@ struct FinalizeArgs {
     uint64_t *out[64];
 };
 
-// output row r ← the state of table slot s.  The state of a value column is gathered once for all aggregates over it (count,
-// sum, avg, min, max of one column are five outputs of ONE random access per array, not of five).
-__device__ __forceinline__ void finalize_row(const GroupTable &g, uint32_t s, int64_t r, const FinalizeArgs &f) {
-    const size_t slots = size_t(g.cap) + 1;
-    int cached = -1;
-    uint64_t cnt = 0;
-    double sum = 0, mn = 0, mx = 0;
-    for (int i = 0; i < f.naggs; ++i) {
-        if (f.vslot[i] != cached) {
-            cached = f.vslot[i];
-            size_t o = size_t(cached) * slots + s;
-            cnt = g.cnt[o];
-            sum = g.sum[o];
-            mn = ord_to_f64(g.mn[o]);
-            mx = g.nan[o] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(g.mx[o]);
-        }
-        if (f.partial) {
-            f.out[4 * i + 0][r] = cnt;
-            f.out[4 * i + 1][r] = d2u(sum);
-            f.out[4 * i + 2][r] = d2u(mn);
-            f.out[4 * i + 3][r] = d2u(mx);
-        } else {
-            uint64_t w;
-            switch (f.func[i]) {
-            case NQE_AGG_COUNT: w = cnt; break;                                   // count.rs:76
-            case NQE_AGG_SUM: w = d2u(sum); break;                                // sum.rs:115
-            case NQE_AGG_AVG: w = d2u(sum / double(uint32_t(cnt))); break;        // avg.rs:121 (cnt is u32)
-            case NQE_AGG_MIN: w = d2u(mn); break;
-            default: w = d2u(mx); break;
-            }
-            f.out[i][r] = w;
-        }
-    }
-}
-
 __global__ void finalize_kernel(GroupTable g, const uint32_t *sorted_slots, int64_t G, FinalizeArgs f) {
+    size_t slots = size_t(g.cap) + 1;
     int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < G; r += stride)
-        finalize_row(g, sorted_slots ? sorted_slots[r] : 0, r, f);
-}
-
-// Tail of a SMALL hashed table (the first-attempt 8192-slot table: the headline's 1024 groups): collect + sort + finalize in one
-// launch, enqueued ahead of the flag read-back.  Every workgroup compacts the occupied slots into LDS (keys in sort order + slot
-// numbers; the same deterministic order in every workgroup), owns 64 of the G entries, and ranks each by counting the keys below
-// it — keys in the table are distinct, so the ranks are exactly the permutation 0..G-1 of the sorted output.  Wave w of 16 scans
-// one sixteenth of the entries with broadcast LDS reads (lane = entry), the partial counts meet in LDS, wave 0 writes key and
-// aggregates of its entries at their ranks.  Work is G²/64 broadcast reads spread over G/64 workgroups (workgroups past the last
-// entry leave after the compaction); it replaces collect (20 µs) + single-workgroup bitonic sort (21 µs) + finalize (7.5 µs)
-// and the host round trip between them.
-constexpr uint32_t RANK_MAX_CAP = 8192;
-constexpr int RANK_SLOTS = 64;
-constexpr int RANK_WAVES = 16;
-constexpr int RANK_PASSES = (RANK_MAX_CAP + 1 + RANK_WAVES * 64 - 1) / (RANK_WAVES * 64);
-
-__global__ void __launch_bounds__(RANK_WAVES * 64) rank_finalize_kernel(GroupTable g, int signed_order, FinalizeArgs f, uint64_t *out_keys,
-                                                                        uint32_t *count_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rank_smem[];
-    const uint32_t slots = g.cap + 1;
-    uint64_t *ok = reinterpret_cast<uint64_t *>(rank_smem);        // [slots] ordered keys of the occupied slots, compacted
-    uint32_t *oslot = reinterpret_cast<uint32_t *>(ok + slots);    // [slots] their slot numbers
-    __shared__ uint32_t part[RANK_WAVES][RANK_SLOTS];
-    __shared__ uint32_t wbase[RANK_PASSES * RANK_WAVES + 1];
-    const uint64_t flip = signed_order ? 0x8000000000000000ull : 0ull;
-    const int wv = threadIdx.x / 64;
-    const int passes = int((slots + blockDim.x - 1) / blockDim.x);
-    // ---- compaction, pass 1: occupied slots per (pass, wave)
-    for (int p = 0; p < passes; ++p) {
-        const uint32_t s = uint32_t(p) * blockDim.x + threadIdx.x;
-        const bool used = s < slots && g.keys[s] != EMPTY_KEY;
-        const uint64_t m = __ballot(used);
-        if (lane_id() == 0) wbase[p * RANK_WAVES + wv] = uint32_t(__popcll(m));
-    }
-    __syncthreads();
-    if (wv == 0) { // exclusive scan of the ≤ 144 counts
-        uint32_t run = 0;
-        const int n = passes * RANK_WAVES;
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane_id();
-            const uint32_t c = i < n ? wbase[i] : 0u;
-            uint32_t tot;
-            const uint32_t ex = wave_exclusive_scan(c, tot);
-            if (i < n) wbase[i] = run + ex;
-            run += tot;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < G; r += stride) {
+        uint32_t s = sorted_slots ? sorted_slots[r] : 0;
+        // the state of a value column is gathered once for all aggregates over it (count, sum, avg, min, max of one column
+        // are five outputs of ONE random access per array, not of five)
+        int cached = -1;
+        uint64_t cnt = 0;
+        double sum = 0, mn = 0, mx = 0;
+        for (int i = 0; i < f.naggs; ++i) {
+            if (f.vslot[i] != cached) {
+                cached = f.vslot[i];
+                size_t o = size_t(cached) * slots + s;
+                cnt = g.cnt[o];
+                sum = g.sum[o];
+                mn = ord_to_f64(g.mn[o]);
+                mx = g.nan[o] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(g.mx[o]);
+            }
+            if (f.partial) {
+                f.out[4 * i + 0][r] = cnt;
+                f.out[4 * i + 1][r] = d2u(sum);
+                f.out[4 * i + 2][r] = d2u(mn);
+                f.out[4 * i + 3][r] = d2u(mx);
+            } else {
+                uint64_t w;
+                switch (f.func[i]) {
+                case NQE_AGG_COUNT: w = cnt; break;                                   // count.rs:76
+                case NQE_AGG_SUM: w = d2u(sum); break;                                // sum.rs:115
+                case NQE_AGG_AVG: w = d2u(sum / double(uint32_t(cnt))); break;        // avg.rs:121 (cnt is u32)
+                case NQE_AGG_MIN: w = d2u(mn); break;
+                default: w = d2u(mx); break;
+                }
+                f.out[i][r] = w;
+            }
         }
-        if (lane_id() == 0) wbase[n] = run;
-    }
-    __syncthreads();
-    const uint32_t G = wbase[passes * RANK_WAVES];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = G;
-    if (blockIdx.x * RANK_SLOTS >= G) return; // no entries for this workgroup
-    // ---- compaction, pass 2
-    for (int p = 0; p < passes; ++p) {
-        const uint32_t s = uint32_t(p) * blockDim.x + threadIdx.x;
-        const uint64_t k = s < slots ? g.keys[s] : EMPTY_KEY;
-        const bool used = k != EMPTY_KEY;
-        const uint64_t m = __ballot(used);
-        if (used) {
-            const uint32_t pos = wbase[p * RANK_WAVES + wv] + uint32_t(__popcll(m & lanemask_lt()));
-            ok[pos] = (s == g.cap ? EMPTY_KEY : k) ^ flip;
-            oslot[pos] = s;
-        }
-    }
-    __syncthreads();
-    // ---- rank
-    const uint32_t e = blockIdx.x * RANK_SLOTS + lane_id();
-    const uint64_t mine = e < G ? ok[e] : ~0ull;
-    const uint32_t seg = (G + RANK_WAVES - 1) / RANK_WAVES;
-    const uint32_t lo = uint32_t(wv) * seg < G ? uint32_t(wv) * seg : G, hi = lo + seg < G ? lo + seg : G;
-    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    uint32_t j = lo;
-    for (; j + 4 <= hi; j += 4) {
-        c0 += ok[j] < mine;
-        c1 += ok[j + 1] < mine;
-        c2 += ok[j + 2] < mine;
-        c3 += ok[j + 3] < mine;
-    }
-    for (; j < hi; ++j) c0 += ok[j] < mine;
-    part[wv][lane_id()] = c0 + c1 + c2 + c3;
-    __syncthreads();
-    if (wv == 0 && e < G) {
-        uint32_t rank = 0;
-#pragma unroll
-        for (int w = 0; w < RANK_WAVES; ++w) rank += part[w][lane_id()];
-        out_keys[rank] = mine ^ flip;
-        finalize_row(g, oslot[e], int64_t(rank), f);
     }
 }
 
@@ -789,57 +700,6 @@ struct Collected {
     int64_t G = -1; // -1: not collected yet
 };
 
-// output columns of an aggregate (or its partial state) with room for `rows` rows, and the kernel arguments that fill them
-FinalizeArgs alloc_outputs(nqe_ctx *ctx, AggResult &r, int64_t rows, const nqe_aggregate *aggs, int naggs, const std::vector<int> &vslot,
-                           bool partial) {
-    r.out = std::make_unique<nqe_table>();
-    r.out->ctx = ctx;
-    r.out->rows = rows;
-    FinalizeArgs f;
-    std::memset(&f, 0, sizeof(f));
-    f.naggs = naggs;
-    f.partial = partial ? 1 : 0;
-    for (int i = 0; i < naggs; ++i) {
-        f.func[i] = aggs[i].func;
-        f.vslot[i] = vslot[size_t(i)];
-        if (partial) {
-            const int dts[4] = {NQE_UINT64, NQE_FLOAT64, NQE_FLOAT64, NQE_FLOAT64};
-            for (int k = 0; k < 4; ++k) {
-                r.out->cols.push_back(make_word_column(ctx, dts[k], rows, false));
-                f.out[4 * i + k] = (uint64_t *)r.out->cols.back().values->ptr;
-            }
-        } else {
-            r.out->cols.push_back(make_word_column(ctx, aggs[i].func == NQE_AGG_COUNT ? NQE_UINT64 : NQE_FLOAT64, rows, false));
-            f.out[i] = (uint64_t *)r.out->cols.back().values->ptr;
-        }
-    }
-    return f;
-}
-
-// small hashed table: one launch ranks the keys and writes the sorted outputs (rank_finalize_kernel); the columns are allocated
-// for a full table and cut to the group count once it has travelled back with the flags (set_group_count)
-AggResult emit_ranked(nqe_ctx *ctx, TableBufs &tb, int key_dtype, const nqe_aggregate *aggs, int naggs, const std::vector<int> &vslot,
-                      bool partial) {
-    const int64_t slots = int64_t(tb.g.cap) + 1;
-    AggResult r;
-    FinalizeArgs f = alloc_outputs(ctx, r, slots, aggs, naggs, vslot, partial);
-    r.keys = std::make_unique<nqe_table>();
-    r.keys->ctx = ctx;
-    r.keys->rows = slots;
-    r.keys->cols.push_back(make_word_column(ctx, key_dtype, slots, false));
-    launch(ctx, "agg_rank_finalize", rank_finalize_kernel, dim3(unsigned((slots + RANK_SLOTS - 1) / RANK_SLOTS)), dim3(RANK_WAVES * 64), size_t(slots) * 12, tb.g,
-           key_dtype == NQE_INT64 ? 1 : 0, f, (uint64_t *)r.keys->cols[0].values->ptr,
-           reinterpret_cast<uint32_t *>(ctx->d_flags + NQE_FLAG_GROUP_COUNT));
-    return r;
-}
-
-void set_group_count(AggResult &r, int64_t G) {
-    r.out->rows = G;
-    for (auto &c : r.out->cols) c.length = G;
-    r.keys->rows = G;
-    for (auto &c : r.keys->cols) c.length = G;
-}
-
 AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const nqe_aggregate *aggs, int naggs,
                const std::vector<int> &vslot, bool partial, const Collected *pre = nullptr) {
     int64_t G = 1;
@@ -870,7 +730,27 @@ AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const n
                              (uint32_t *)sorted_slots->ptr, G, key_dtype == NQE_INT64);
     }
     AggResult r;
-    FinalizeArgs f = alloc_outputs(ctx, r, G, aggs, naggs, vslot, partial);
+    r.out = std::make_unique<nqe_table>();
+    r.out->ctx = ctx;
+    r.out->rows = G;
+    FinalizeArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.naggs = naggs;
+    f.partial = partial ? 1 : 0;
+    for (int i = 0; i < naggs; ++i) {
+        f.func[i] = aggs[i].func;
+        f.vslot[i] = vslot[size_t(i)];
+        if (partial) {
+            const int dts[4] = {NQE_UINT64, NQE_FLOAT64, NQE_FLOAT64, NQE_FLOAT64};
+            for (int k = 0; k < 4; ++k) {
+                r.out->cols.push_back(make_word_column(ctx, dts[k], G, false));
+                f.out[4 * i + k] = (uint64_t *)r.out->cols.back().values->ptr;
+            }
+        } else {
+            r.out->cols.push_back(make_word_column(ctx, aggs[i].func == NQE_AGG_COUNT ? NQE_UINT64 : NQE_FLOAT64, G, false));
+            f.out[i] = (uint64_t *)r.out->cols.back().values->ptr;
+        }
+    }
     if (G > 0 && naggs > 0)
         launch(ctx, "agg_finalize", finalize_kernel, dim3(stream_grid(ctx, G, 256)), dim3(256), 0, tb.g,
                grouped ? (const uint32_t *)sorted_slots->ptr : (const uint32_t *)nullptr, G, f);
@@ -972,17 +852,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     if (a.pred_mode == 1) kp_valid_words_ok = kp_valid_words_ok && words_ok(in->cols[size_t(a.pred.col)]);
 
     const int V = int(plan.val_cols.size());
-    // Global table: the first attempt is SMALL (8192 slots) whatever the input size — every workgroup merges at most one LDS
-    // table's worth of groups, and unless the workgroups see different key sets their union fits, so that initialisation is
-    // 0.4 MB instead of 92 MB and the whole tail is one launch (rank_finalize_kernel).  When the union does not fit (TABLE_FULL:
-    // keys correlated with the tile→workgroup assignment, or a small input of mostly distinct keys) the retry is sized for the
-    // worst case (every workgroup inserting its own ≤4096 groups, at most one per row), as is the partitioned path.
-    uint32_t cap = 1, sized_cap = 1;
+    uint32_t cap = 1;
     if (grouped) {
         int64_t guess = std::min<int64_t>(std::max<int64_t>(in->rows, 1), int64_t(1) << 20);
-        sized_cap = 4096;
-        while (int64_t(sized_cap) < 2 * guess) sized_cap <<= 1;
-        cap = std::min(sized_cap, RANK_MAX_CAP);
+        cap = 4096;
+        while (int64_t(cap) < 2 * guess) cap <<= 1;
     }
     bool partition_mode = false, level2 = false, dense_ok = true;
     bool any_val_nullable = false;
@@ -1187,11 +1061,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             }
         }
         Collected pre;
-        AggResult ranked;
-        if (grouped && !tb.g.dense_count && tb.g.cap <= RANK_MAX_CAP) {
-            // first-attempt table: the whole tail (collect, sort, finalize) runs ahead of the read-back
-            ranked = emit_ranked(ctx, tb, kinfo.out_dtype, aggs, naggs, plan.vslot, partial);
-        } else if (grouped && !tb.g.dense_count && tb.g.cap <= (1u << 16)) {
+        if (grouped && !tb.g.dense_count && tb.g.cap <= (1u << 16)) {
             // small table: collect speculatively; the count lands in the spare flag slot and is read with the flags
             const size_t slots = size_t(tb.g.cap) + 1;
             pre.keys = dev_alloc(ctx, slots * 8);
@@ -1212,7 +1082,6 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
         if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode) {
             partition_mode = true; // a workgroup table overflowed: redo with hash-partitioned rows
-            cap = std::max(cap, sized_cap);
             flags_reset(ctx);
             continue;
         }
@@ -1223,16 +1092,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
         if (f[NQE_FLAG_TABLE_FULL]) {
             if (cap >= (1u << 31) || attempt > 8) fail(NQE_ERR_OUT_OF_MEMORY, "group table overflow");
-            cap = cap < sized_cap ? sized_cap : cap << 3;
+            cap <<= 3;
             flags_reset(ctx);
             continue;
         }
-        AggResult res;
-        if (ranked.out) {
-            set_group_count(ranked, int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT])));
-            res = std::move(ranked);
-        } else
-            res = emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial, &pre);
+        AggResult res = emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial, &pre);
         if (utf8_key && res.keys) { // keys_out: the strings of the representative rows
             DevColumn codes = res.keys->cols[0];
             res.keys->cols[0] = take_utf8(ctx, utf8_src, (const int64_t *)codes.words(), codes.length, false);
@@ -1315,16 +1179,8 @@ nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, con
                (const uint64_t *const *)ptrs->ptr, ctx->d_flags);
         sync(ctx); // `h` / ptrs are reused by the next partial
     }
-    AggResult r;
-    if (grouped && cap <= RANK_MAX_CAP) {
-        // the exchanged states of a small group set (the sharded headline: world x 1024 rows): tail ahead of the read-back
-        r = emit_ranked(ctx, tb, key_dtype, aggs, num_aggs, vslot, false);
-        throw_on_flags(ctx);
-        set_group_count(r, int64_t(uint32_t(ctx->h_flags[NQE_FLAG_GROUP_COUNT])));
-    } else {
-        throw_on_flags(ctx);
-        r = emit(ctx, tb, grouped, key_dtype, aggs, num_aggs, vslot, false);
-    }
+    throw_on_flags(ctx);
+    AggResult r = emit(ctx, tb, grouped, key_dtype, aggs, num_aggs, vslot, false);
     *out = r.out.release();
     if (keys_out) *keys_out = r.keys.release();
     NQE_API_END()

@@ -1,0 +1,165 @@
+// aggregate_common.hpp — types, constants and device helpers shared by the aggregate translation units
+// (aggregate.hip: general / un-grouped kernels, table kernels, host logic; aggregate_fast.hip: the specialised streaming
+// kernel and its instantiations; aggregate_partition.hip: the partitioned path).  Split so that the ~100 kernel
+// instantiations compile in parallel.
+#pragma once
+#include <cfloat>
+
+#include "device_utils.hpp"
+#include "nqe_internal.hpp"
+
+namespace nqe {
+namespace agg {
+
+constexpr uint64_t EMPTY_KEY = 0x8000000000000000ull; // i64::MIN; that key uses the extra slot [cap]
+constexpr uint64_t GOLD = 0x9E3779B97F4A7C15ull;
+constexpr int NV = 2;      // value columns per kernel pass
+#ifndef NQE_AGG_U
+#define NQE_AGG_U 4
+#endif
+constexpr int AGG_U = NQE_AGG_U;   // rows per thread per iteration
+constexpr int AGG_BLOCK = 1024;
+constexpr uint32_t NAN_BIT = 0x80000000u;
+
+// order-preserving map f64 -> u64 (non-NaN): integer min/max atomics give the f64 min/max
+__host__ __device__ __forceinline__ uint64_t f64_to_ord(double d) {
+    uint64_t b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b = (uint64_t)__double_as_longlong(d);
+#else
+    std::memcpy(&b, &d, 8);
+#endif
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord_to_f64(uint64_t u) {
+    uint64_t b = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+    return __longlong_as_double((long long)b);
+}
+
+struct ColSrc {
+    const void *values;
+    const uint8_t *valid;
+    int32_t dtype;
+    int32_t present;
+};
+
+// global group table: arrays are [V][cap+1]; slot `cap` belongs to EMPTY_KEY itself
+struct GroupTable {
+    uint64_t *keys;     // [cap+1]; keys[cap] != EMPTY_KEY ⇔ special slot in use
+    uint64_t *cnt;      // non-null values
+    double *sum;
+    uint64_t *mn;       // f64_to_ord
+    uint64_t *mx;
+    uint32_t *nan;      // any NaN seen
+    uint32_t cap;       // power of two (hashed mode) / number of dense slots
+    int32_t shift;      // 64 - log2(cap)
+    int32_t V;
+    int32_t pad;
+    // Dense mode (partitioned aggregation, one pass over the value columns): partitions hold disjoint key sets, so a
+    // workgroup writes the groups of its partition straight to slots [base, base + n) reserved with ONE atomic on this
+    // counter — no global hash table, no initialisation, no collect pass.  null = hashed mode.
+    uint32_t *dense_count;
+};
+
+struct AggArgs {
+    int64_t n;
+    int32_t pred_mode; // 0 none, 1 SimpleExpr over pred_src, 2 Boolean column (bits + validity) in pred_src
+    int32_t has_key;
+    int32_t pred_shares_key;
+    int32_t nv;
+    ColSrc pred_src;
+    ColSrc key_src;
+    SimpleExpr pred;
+    SimpleExpr key;
+    ColSrc val[NV];
+    int32_t val_shares_key[NV];
+    int32_t need_sum[NV];
+    int32_t need_minmax[NV];
+    int32_t v0; // first value slot of this pass in the global table
+    int32_t lds_cap;
+    int32_t lds_shift;
+    int32_t allow_partition; // an LDS-table overflow asks the host for the partitioned path instead of falling back to global atomics
+};
+
+__device__ __forceinline__ int lds_find_or_insert(uint64_t *keys, uint64_t key, uint32_t cap, int shift) {
+    if (key == EMPTY_KEY) {
+        keys[cap] = 0; // mark special slot used (idempotent plain store)
+        return int(cap);
+    }
+    uint32_t slot = uint32_t((key * GOLD) >> shift);
+    for (int probe = 0; probe < 48; ++probe) {
+        uint64_t k = keys[slot];
+        if (k == key) return int(slot);
+        if (k == EMPTY_KEY) {
+            uint64_t old = atomicCAS((unsigned long long *)&keys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (old == EMPTY_KEY || old == key) return int(slot);
+        }
+        slot = (slot + 1) & (cap - 1);
+    }
+    return -1; // workgroup table full for this key: caller goes to the global table
+}
+
+__device__ __forceinline__ int64_t global_find_or_insert(const GroupTable &g, uint64_t key, int *flags) {
+    if (key == EMPTY_KEY) {
+        __hip_atomic_store(&g.keys[g.cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return int64_t(g.cap);
+    }
+    uint32_t slot = uint32_t((key * GOLD) >> g.shift);
+    // bounded probe sequence: a table that needs more than this is treated as full (the host retries with a
+    // larger one) — an unbounded walk over a nearly full table is O(rows x capacity)
+    const uint32_t max_probe = g.cap < 512u ? g.cap : 512u;
+    for (uint32_t probe = 0; probe < max_probe; ++probe) {
+        uint64_t k = __hip_atomic_load(&g.keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == key) return int64_t(slot);
+        if (k == EMPTY_KEY) {
+            uint64_t old = atomicCAS((unsigned long long *)&g.keys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (old == EMPTY_KEY || old == key) return int64_t(slot);
+        }
+        slot = (slot + 1) & (g.cap - 1);
+    }
+    atomicOr(&flags[NQE_FLAG_TABLE_FULL], 1);
+    return -1;
+}
+
+__device__ __forceinline__ void global_update(const GroupTable &g, int64_t slot, int v, uint64_t cnt, double sum, bool has_sum,
+                                              uint64_t mn, uint64_t mx, bool has_minmax, bool nan) {
+    size_t o = size_t(v) * (size_t(g.cap) + 1) + size_t(slot);
+    if (cnt) atomicAdd((unsigned long long *)&g.cnt[o], (unsigned long long)cnt);
+    if (has_sum) unsafeAtomicAdd(&g.sum[o], sum);
+    if (has_minmax) {
+        atomicMin((unsigned long long *)&g.mn[o], (unsigned long long)mn);
+        atomicMax((unsigned long long *)&g.mx[o], (unsigned long long)mx);
+    }
+    if (nan) atomicOr(&g.nan[o], 1u);
+}
+
+__device__ __forceinline__ bool row_valid(const ColSrc &c, int64_t row) { return c.valid ? get_bit(c.valid, row) : true; }
+
+// partitioned aggregation (aggregate_partition.hip)
+constexpr int PARTS_LOG2 = 9;
+constexpr int PARTS = 1 << PARTS_LOG2;
+
+struct PartArgs {
+    uint32_t *counts;        // [PARTS][nblocks] (count pass out)
+    const uint64_t *offsets; // [PARTS][nblocks] exclusive scan of counts (scatter pass in)
+    uint64_t *out_key;
+    uint64_t *out_val[NV];
+    int64_t chunk;           // rows per workgroup (multiple of AGG_BLOCK*AGG_U)
+};
+
+constexpr int SUB_LOG2 = 6;
+constexpr int SUB = 1 << SUB_LOG2;
+
+// kernel entry points of the other translation units
+using FastKernel = void (*)(AggArgs, FastPred, GroupTable, int *);
+FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull);
+using PartKernel = void (*)(AggArgs, FastPred, PartArgs);
+PartKernel pick_scatter_kernel(int pred, int key, int nv);
+PartKernel pick_part_kernel(int pred, int key, int nv, bool scatter);
+using SubpartitionKernel = void (*)(const uint64_t *, int64_t, const uint64_t *, const uint64_t *, const uint64_t *, uint64_t *, uint64_t *, uint64_t *, uint64_t *);
+SubpartitionKernel pick_subpartition_kernel(int nv);
+using SegmentsKernel = void (*)(AggArgs, const uint64_t *, int64_t, int, int, int, const uint64_t *, const uint64_t *, const uint64_t *, GroupTable, int *);
+SegmentsKernel pick_segments_kernel(int nv, bool vf64);
+
+} // namespace agg
+} // namespace nqe

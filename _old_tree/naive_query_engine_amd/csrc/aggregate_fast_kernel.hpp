@@ -1,0 +1,260 @@
+// aggregate_fast_kernel.hpp — the specialised streaming kernel of the hash aggregate (see aggregate.hip for the operator
+// and its semantics).  Included by aggregate_fast.hip (VNULL = false instantiations) and aggregate_fast_null.hip
+// (VNULL = true), so that the two halves of the ~70 instantiations compile in parallel.
+#pragma once
+#include "aggregate_common.hpp"
+
+namespace nqe {
+namespace agg {
+namespace {
+
+// ------------------------------------------------------------------ grouped kernel, fast path
+// Sources are plain 8-byte columns without validity; predicate is none / integer `col cmp lit`;
+// key is a plain column / `col % ±2^k`.  Differences from the general kernel above:
+//   * NVT (value columns) and VF64 (all values Float64) are static, every statistic is always
+//     maintained → no flag or dtype branches in the row loop;
+//   * the integer predicate is a branch-free range test: the host rewrites `x op lit` into
+//     lo <= (x ^ flip) <= hi, optionally negated (flip = sign bit for UInt64 → signed compares);
+//   * min/max run on native v_min_f64/v_max_f64 (NaN operands are ignored by the instruction and
+//     tracked by a flag, which is exactly OrderedFloat's min rule and makes max NaN at the end);
+//   * loads are unconditional (row index clamped to n-1): no exec-mask branches around them;
+//   * PIPE: the NEXT tile's words are requested before the current tile is processed (two register
+//     tiles), so waits are counted `s_waitcnt vmcnt(k)` and a wave keeps a tile in flight while it
+//     computes.
+// PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column.
+template <int PRED, int KEY, int NVT, bool VF64, bool VNULL>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t cap = uint32_t(a.lds_cap);
+    const uint32_t slots = cap + 1;
+    uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
+    double *lsum = reinterpret_cast<double *>(lkeys + slots);            // [NVT][slots]
+    uint64_t *lmn = reinterpret_cast<uint64_t *>(lsum + NVT * slots);    // [NVT][slots]
+    uint64_t *lmx = lmn + NVT * slots;                                   // [NVT][slots]
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + NVT * slots);    // [NVT][slots]
+    const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
+    __shared__ int lds_full_flag;
+    volatile int *lds_full = &lds_full_flag;
+    if (threadIdx.x == 0) lds_full_flag = 0;
+    for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+        lkeys[s] = EMPTY_KEY;
+#pragma unroll
+        for (int j = 0; j < NVT; ++j) {
+            lsum[j * slots + s] = 0.0;
+            lmn[j * slots + s] = ORD_MAX;
+            lmx[j * slots + s] = ORD_MIN;
+            lcnt[j * slots + s] = 0;
+        }
+    }
+    __syncthreads();
+
+    bool run_live = false;
+    uint64_t run_key = 0;
+    uint32_t rcnt[NVT];
+    double rsum[NVT], rmn[NVT], rmx[NVT];
+    bool rnan[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) {
+        rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
+    }
+    auto flush_run = [&]() {
+        // The hit path must stay minimal: random-key inputs flush once per row (guarding the lookup with a "table is full"
+        // test cost them 14 %).  A rejected key is the cold path: it raises the workgroup flag (the tile loop then leaves
+        // early and the host redoes the query partitioned) or, for small inputs, goes to the global table.
+        int slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+        int64_t gslot = 0;
+        if (slot < 0) {
+            if (!*lds_full) {
+                *lds_full = 1;
+                if (a.allow_partition) atomicOr(&flags[NQE_FLAG_NEED_PARTITION], 1); // more distinct keys than a workgroup table holds
+            }
+            gslot = a.allow_partition ? -1 : global_find_or_insert(g, run_key, flags);
+        }
+#pragma unroll
+        for (int j = 0; j < NVT; ++j) {
+            const uint64_t omn = f64_to_ord(rmn[j]), omx = f64_to_ord(rmx[j]);
+            if (slot >= 0) {
+                uint32_t o = uint32_t(j) * slots + uint32_t(slot);
+                if (rcnt[j]) {
+                    atomicAdd(&lcnt[o], rcnt[j]);
+                    unsafeAtomicAdd(&lsum[o], rsum[j]);
+                }
+                if (rnan[j]) atomicOr(&lcnt[o], NAN_BIT);
+                // read-before-atomic (see the general kernel)
+                if (omn < lmn[o]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)omn);
+                if (omx > lmx[o]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)omx);
+            } else if (gslot >= 0) {
+                global_update(g, gslot, a.v0 + j, rcnt[j], rsum[j], true, omn, omx, true, rnan[j]);
+            }
+            rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
+        }
+    };
+
+    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ valp[NVT];
+    const uint64_t *__restrict__ kvalid = reinterpret_cast<const uint64_t *>(a.key_src.valid);
+    const uint64_t *__restrict__ pvalid = reinterpret_cast<const uint64_t *>(PRED != 0 ? a.pred_src.valid : nullptr);
+    const uint64_t *__restrict__ vvalid[NVT]; // VNULL: validity bitmaps of the value columns (word-padded), null = all valid
+    int vdt[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) {
+        valp[j] = static_cast<const uint64_t *>(a.val[j].values);
+        vvalid[j] = reinterpret_cast<const uint64_t *>(a.val[j].valid);
+        vdt[j] = a.val[j].dtype;
+    }
+    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
+    const OpAux key_aux = a.key.aux[0];
+    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
+    const int64_t n = a.n, last = a.n - 1;
+
+    constexpr bool PIPE = true, NT = true; // both measured wins (prefetched second tile: 3.24 -> 2.69 ms with the lean loop; nt loads: -2..3 %)
+    struct Tile {
+        uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
+        uint64_t vv[VNULL ? NVT : 1][AGG_U]; // validity word of the wave's 64 rows
+        uint64_t kpv[VNULL ? AGG_U : 1];     // key validity AND predicate validity
+    };
+    auto load_tile = [&](Tile &t, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            row = row < last ? row : last; // clamp: unconditional, in-bounds
+            if (NT) {
+                t.kw[u] = __builtin_nontemporal_load(&keyp[row]);
+                if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
+                if (VNULL) {
+#pragma unroll
+                    for (int j = 0; j < NVT; ++j) t.vv[j][u] = vvalid[j] ? vvalid[j][row >> 6] : ~0ull;
+                    t.kpv[u] = (kvalid ? kvalid[row >> 6] : ~0ull) & (pvalid ? pvalid[row >> 6] : ~0ull);
+                }
+            } else {
+                t.kw[u] = keyp[row];
+                if (PRED == 2) t.pw[u] = predp[row >> fp.row_shift];
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) t.vw[j][u] = valp[j][row];
+            }
+        }
+    };
+    auto process_tile = [&](const Tile &t, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            bool pass = row < n;
+            if (PRED != 0) {
+                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
+            }
+            if (VNULL) pass = pass && ((t.kpv[u] >> (row & 63)) & 1ull);
+            uint64_t key;
+            if (KEY == 0) key = t.kw[u];
+            else {
+                // truncated remainder by a literal: |x| mod |d| (mask for ±2^k, magic multiply otherwise), sign of
+                // the dividend
+                uint64_t x = t.kw[u];
+                uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
+                uint64_t ux = (x ^ sgn) - sgn;
+                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
+                key = (ur ^ sgn) - sgn;
+            }
+            if (!pass) continue;
+            if (!run_live || key != run_key) {
+                if (run_live) flush_run();
+                run_key = key;
+                run_live = true;
+            }
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+                double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+                if (VNULL) {
+                    // a NULL value contributes nothing (count of non-null, Q10) but its row still creates the group:
+                    // branch-free — count += bit, sum += 0, and a NaN operand that min/max ignore and the flag skips
+                    const bool vb = (t.vv[j][u] >> (row & 63)) & 1ull;
+                    rcnt[j] += vb ? 1u : 0u;
+                    rsum[j] += vb ? x : 0.0;
+                    rnan[j] = rnan[j] || (vb && x != x);
+                    const double xm = vb ? x : __builtin_nan("");
+                    rmn[j] = fmin(rmn[j], xm);
+                    rmx[j] = fmax(rmx[j], xm);
+                } else {
+                    rcnt[j] += 1;
+                    rsum[j] += x;
+                    rnan[j] = rnan[j] || (x != x);
+                    rmn[j] = fmin(rmn[j], x); // NaN operand ignored
+                    rmx[j] = fmax(rmx[j], x);
+                }
+            }
+        }
+    };
+
+    const int64_t step = int64_t(AGG_BLOCK) * AGG_U;
+    const int64_t stride = int64_t(gridDim.x) * step;
+    int64_t base = int64_t(blockIdx.x) * step;
+    if (PIPE) {
+        if (base < n) {
+            Tile A, B;
+            load_tile(A, base);
+            for (;;) {
+                load_tile(B, base + stride); // prefetch (clamped, always issued)
+                process_tile(A, base);
+                base += stride;
+                if (base >= n) break;
+                load_tile(A, base + stride);
+                process_tile(B, base);
+                base += stride;
+                if (base >= n) break;
+                if (*lds_full && (a.allow_partition || __hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+                    break; // the host redoes the query (partitioned path / larger table)
+                if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    break; // another workgroup's table overflowed: this attempt is abandoned anyway
+            }
+        }
+    } else {
+        for (; base < n; base += stride) {
+            Tile A;
+            load_tile(A, base);
+            process_tile(A, base);
+        }
+    }
+    if (run_live) flush_run();
+    __syncthreads();
+    // an abandoned attempt (the host re-runs the query partitioned) does not merge: 2048 slots x 512 workgroups of
+    // device-scope atomics were two thirds of what the abandoned attempt cost
+    if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+        uint64_t k = lkeys[s];
+        if (k == EMPTY_KEY) continue;
+        uint64_t key = (s == cap) ? EMPTY_KEY : k;
+        int64_t gslot = global_find_or_insert(g, key, flags);
+        if (gslot < 0) continue;
+#pragma unroll
+        for (int j = 0; j < NVT; ++j) {
+            uint32_t o = uint32_t(j) * slots + s;
+            uint32_t c = lcnt[o];
+            global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
+        }
+    }
+}
+
+template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64) {
+    if (nv == 1) return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 1, false, VNULL>;
+    return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 2, false, VNULL>;
+}
+template <int PRED, bool VNULL> FastKernel pick_fast_key(int key, int nv, bool vf64) {
+    switch (key) {
+    case 0: return pick_fast_nv<PRED, 0, VNULL>(nv, vf64);
+    case 1: return pick_fast_nv<PRED, 1, VNULL>(nv, vf64);
+    default: return pick_fast_nv<PRED, 2, VNULL>(nv, vf64);
+    }
+}
+template <bool VNULL> FastKernel pick_fast_pred(int pred, int key, int nv, bool vf64) {
+    switch (pred) {
+    case 0: return pick_fast_key<0, VNULL>(key, nv, vf64);
+    case 1: return pick_fast_key<1, VNULL>(key, nv, vf64);
+    default: return pick_fast_key<2, VNULL>(key, nv, vf64);
+    }
+}
+
+} // namespace
+} // namespace agg
+} // namespace nqe

@@ -1,0 +1,463 @@
+// aggregate_partition.hip — partitioned aggregation for more distinct keys than a workgroup's LDS table holds.
+// More distinct keys than a workgroup's LDS table holds would turn every row into device-scope atomics, and
+// those run at a flat ≈2.4e10 ops/s on MI355X whatever the scope, table size or layout (tools/atomics_bench.hip):
+// 100 M rows took 17-20 ms at 4 K…1 M groups versus 0.6 ms at 1 K.  Instead the passing rows are hash-partitioned
+// (count → scan → scatter of (key, values) tuples, PARTS partitions so that a workgroup's open write lines stay L2
+// resident) and each partition — whose distinct keys now fit an LDS table — is aggregated by one workgroup.
+#include "aggregate_common.hpp"
+
+namespace nqe {
+namespace agg {
+namespace {
+
+template <int PRED, int KEY, int NVT, bool SCATTER>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_partition_kernel(AggArgs a, FastPred fp, PartArgs pa) {
+    __shared__ uint32_t cnt[PARTS];
+    __shared__ uint64_t basep[PARTS];
+    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) {
+        cnt[p] = 0;
+        if (SCATTER) basep[p] = pa.offsets[size_t(p) * gridDim.x + blockIdx.x];
+    }
+    __syncthreads();
+    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ valp[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) valp[j] = static_cast<const uint64_t *>(a.val[j].values);
+    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
+    const OpAux key_aux = a.key.aux[0];
+    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
+    const int64_t lo = int64_t(blockIdx.x) * pa.chunk;
+    const int64_t hi = lo + pa.chunk < a.n ? lo + pa.chunk : a.n;
+    const int64_t last = a.n - 1;
+    for (int64_t base = lo; base < hi; base += int64_t(AGG_BLOCK) * AGG_U) {
+        uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            row = row < last ? row : last;
+            kw[u] = __builtin_nontemporal_load(&keyp[row]);
+            if (PRED == 2) pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
+            if (SCATTER) {
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            bool pass = row < hi;
+            if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? kw[u] : pred_extract(fp, pw[u], row));
+            uint64_t key;
+            if (KEY == 0) key = kw[u];
+            else {
+                uint64_t x = kw[u];
+                uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
+                uint64_t ux = (x ^ sgn) - sgn;
+                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
+                key = (ur ^ sgn) - sgn;
+            }
+            if (!pass) continue;
+            uint32_t p = uint32_t((key * GOLD) >> (64 - PARTS_LOG2));
+            uint32_t r = atomicAdd(&cnt[p], 1u);
+            if (SCATTER) {
+                uint64_t pos = basep[p] + r;
+                pa.out_key[pos] = key;
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) pa.out_val[j][pos] = vw[j][u];
+            }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (int p = threadIdx.x; p < PARTS; p += blockDim.x) pa.counts[size_t(p) * gridDim.x + blockIdx.x] = cnt[p];
+    }
+}
+
+// Scatter pass with LDS write-combining: a tile of SC_ROWS rows is counting-sorted by partition inside LDS
+// (rank = LDS atomic on a per-tile counter, tile-local exclusive scan), then copied out so that consecutive lanes
+// write consecutive tuples of the same partition (runs of SC_ROWS/PARTS tuples → full 128-B lines instead of
+// 8-byte stores sprayed over 512 streams: 2.4 ms → see DESIGN.md for the measured effect).
+template <int PRED, int KEY, int NVT>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_partition_scatter_kernel(AggArgs a, FastPred fp, PartArgs pa) {
+    constexpr int RPT = NVT == 1 ? 8 : 4;            // rows per thread per tile
+    constexpr int SC_ROWS = AGG_BLOCK * RPT;         // 8192 (one value column) / 4096 (two)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *skey = reinterpret_cast<uint64_t *>(smem);     // [SC_ROWS]
+    uint64_t *sval = skey + SC_ROWS;                          // [NVT][SC_ROWS]
+    uint64_t *gcur = sval + NVT * SC_ROWS;                    // [PARTS] global write cursor of this workgroup
+    uint32_t *tcnt = reinterpret_cast<uint32_t *>(gcur + PARTS); // [PARTS] tuples of this tile per partition
+    uint32_t *tstart = tcnt + PARTS;                          // [PARTS] tile-local exclusive scan
+    __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
+    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) {
+        gcur[p] = pa.offsets[size_t(p) * gridDim.x + blockIdx.x];
+        tcnt[p] = 0;
+    }
+    __syncthreads();
+    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ valp[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) valp[j] = static_cast<const uint64_t *>(a.val[j].values);
+    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
+    const OpAux key_aux = a.key.aux[0];
+    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
+    const int64_t lo = int64_t(blockIdx.x) * pa.chunk;
+    const int64_t hi = lo + pa.chunk < a.n ? lo + pa.chunk : a.n;
+    const int64_t last = a.n - 1;
+    for (int64_t base = lo; base < hi; base += SC_ROWS) {
+        uint64_t key[RPT], vw[NVT][RPT];
+        uint32_t part[RPT], rank[RPT];
+        bool pass[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            int64_t rc = row < last ? row : last;
+            uint64_t kw = __builtin_nontemporal_load(&keyp[rc]);
+            uint64_t pw = PRED == 2 ? pred_extract(fp, __builtin_nontemporal_load(&predp[rc >> fp.row_shift]), rc) : kw;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][rc]);
+            bool ok = row < hi;
+            if (PRED != 0) ok = ok && range_pass(fp, pw);
+            if (KEY == 0) key[u] = kw;
+            else {
+                uint64_t sgn = key_signed ? uint64_t((long long)kw >> 63) : 0ull;
+                uint64_t ux = (kw ^ sgn) - sgn;
+                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
+                key[u] = (ur ^ sgn) - sgn;
+            }
+            pass[u] = ok;
+            part[u] = uint32_t((key[u] * GOLD) >> (64 - PARTS_LOG2));
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
+        __syncthreads();
+        // tile-local exclusive scan of the PARTS counters (threads 0..PARTS-1)
+        uint32_t c = threadIdx.x < PARTS ? tcnt[threadIdx.x] : 0u, wt;
+        uint32_t ex = wave_exclusive_scan(c, wt);
+        if (lane_id() == 63) wave_tot[threadIdx.x / 64] = wt;
+        __syncthreads();
+        if (threadIdx.x < PARTS) {
+            uint32_t pre = 0;
+            for (int w = 0; w < int(threadIdx.x) / 64; ++w) pre += wave_tot[w];
+            tstart[threadIdx.x] = pre + ex;
+        }
+        uint32_t tile_total = 0;
+        for (int w = 0; w < PARTS / 64; ++w) tile_total += wave_tot[w];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            if (!pass[u]) continue;
+            uint32_t i = tstart[part[u]] + rank[u];
+            skey[i] = key[u];
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) sval[j * SC_ROWS + i] = vw[j][u];
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < tile_total; i += blockDim.x) {
+            uint64_t k = skey[i];
+            uint32_t p = uint32_t((k * GOLD) >> (64 - PARTS_LOG2));
+            uint64_t dest = gcur[p] + (i - tstart[p]);
+            pa.out_key[dest] = k;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) pa.out_val[j][dest] = sval[j * SC_ROWS + i];
+        }
+        __syncthreads();
+        if (threadIdx.x < PARTS) {
+            gcur[threadIdx.x] += tcnt[threadIdx.x];
+            tcnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// Second partitioning level: workgroup p splits parent partition p (a contiguous tuple range) into SUB sub-partitions
+// by the next SUB_LOG2 hash bits — count, tile-local scan, then the same LDS-sorted scatter as level 1.  The output
+// occupies the same global range as the input partition, so no cross-workgroup scan is needed.
+template <int NVT>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_subpartition_kernel(const uint64_t *offsets, int64_t off_stride, const uint64_t *in_key,
+                                                                     const uint64_t *in_v0, const uint64_t *in_v1, uint64_t *out_key,
+                                                                     uint64_t *out_v0, uint64_t *out_v1, uint64_t *sub_offsets) {
+    constexpr int RPT = NVT == 1 ? 8 : 4;
+    constexpr int SC_ROWS = AGG_BLOCK * RPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *skey = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *sval = skey + SC_ROWS;
+    __shared__ uint64_t gcur[SUB];
+    __shared__ uint32_t tcnt[SUB], tstart[SUB], total_cnt[SUB];
+    const uint64_t *__restrict__ inv[2] = {in_v0, in_v1};
+    uint64_t *outv[2] = {out_v0, out_v1};
+    for (int p = blockIdx.x; p < PARTS; p += gridDim.x) {
+        const int64_t lo = int64_t(offsets[int64_t(p) * off_stride]), hi = int64_t(offsets[int64_t(p + 1) * off_stride]);
+        __syncthreads();
+        if (threadIdx.x < SUB) total_cnt[threadIdx.x] = 0, tcnt[threadIdx.x] = 0;
+        __syncthreads();
+        // ---- count
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            uint32_t sp = uint32_t(((in_key[i] * GOLD) << PARTS_LOG2) >> (64 - SUB_LOG2));
+            atomicAdd(&total_cnt[sp], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t run = uint64_t(lo);
+            for (int sp = 0; sp < SUB; ++sp) {
+                gcur[sp] = run;
+                sub_offsets[int64_t(p) * SUB + sp] = run;
+                run += total_cnt[sp];
+            }
+            if (p == PARTS - 1) sub_offsets[int64_t(PARTS) * SUB] = run;
+        }
+        __syncthreads();
+        // ---- scatter, tile by tile, sorted in LDS first
+        for (int64_t base = lo; base < hi; base += SC_ROWS) {
+            uint64_t key[RPT], vw[NVT][RPT];
+            uint32_t part[RPT], rank[RPT];
+            bool pass[RPT];
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+                pass[u] = row < hi;
+                int64_t rc = pass[u] ? row : hi - 1;
+                key[u] = in_key[rc];
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) vw[j][u] = inv[j][rc];
+                part[u] = uint32_t(((key[u] * GOLD) << PARTS_LOG2) >> (64 - SUB_LOG2));
+            }
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
+            __syncthreads();
+            if (threadIdx.x < 64) { // SUB == 64: one wave scans the tile counters
+                uint32_t c = tcnt[threadIdx.x], wt;
+                tstart[threadIdx.x] = wave_exclusive_scan(c, wt);
+            }
+            __syncthreads();
+            uint32_t tile_total = tstart[SUB - 1] + tcnt[SUB - 1];
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                if (!pass[u]) continue;
+                uint32_t i = tstart[part[u]] + rank[u];
+                skey[i] = key[u];
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) sval[j * SC_ROWS + i] = vw[j][u];
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < tile_total; i += blockDim.x) {
+                uint64_t k = skey[i];
+                uint32_t sp = uint32_t(((k * GOLD) << PARTS_LOG2) >> (64 - SUB_LOG2));
+                uint64_t dest = gcur[sp] + (i - tstart[sp]);
+                out_key[dest] = k;
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) outv[j][dest] = sval[j * SC_ROWS + i];
+            }
+            __syncthreads();
+            if (threadIdx.x < SUB) {
+                gcur[threadIdx.x] += tcnt[threadIdx.x];
+                tcnt[threadIdx.x] = 0;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// one workgroup per partition (grid-stride over partitions): plain (key, values) tuples → LDS table → global table.
+// The LDS slot uses the hash bits BELOW the partition bits (all keys of a partition share the top PARTS_LOG2 bits).
+template <int NVT, bool VF64>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, const uint64_t *seg_offsets, int64_t seg_stride, int nsegs, int part_bits,
+                                                                 int signal_level2, const uint64_t *keys,
+                                                                 const uint64_t *v0, const uint64_t *v1, GroupTable g, int *flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t cap = uint32_t(a.lds_cap);
+    const uint32_t slots = cap + 1;
+    uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
+    double *lsum = reinterpret_cast<double *>(lkeys + slots);
+    uint64_t *lmn = reinterpret_cast<uint64_t *>(lsum + NVT * slots);
+    uint64_t *lmx = lmn + NVT * slots;
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + NVT * slots);
+    const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
+    const uint64_t *__restrict__ valp[2] = {v0, v1};
+    int vdt[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) vdt[j] = a.val[j].dtype;
+    __shared__ int seg_full_flag;
+    volatile int *seg_full = &seg_full_flag;
+    for (int seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
+        __syncthreads();
+        if (signal_level2 && __hip_atomic_load(&flags[NQE_FLAG_NEED_LEVEL2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        if (threadIdx.x == 0) seg_full_flag = 0;
+        for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+            lkeys[s] = EMPTY_KEY;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+                lsum[j * slots + s] = 0.0;
+                lmn[j * slots + s] = ORD_MAX;
+                lmx[j * slots + s] = ORD_MIN;
+                lcnt[j * slots + s] = 0;
+            }
+        }
+        __syncthreads();
+        const int64_t lo = int64_t(seg_offsets[int64_t(seg) * seg_stride]), hi = int64_t(seg_offsets[int64_t(seg + 1) * seg_stride]);
+        for (int64_t base = lo; base < hi; base += int64_t(AGG_BLOCK) * AGG_U) {
+            uint64_t kw[AGG_U], vw[NVT][AGG_U];
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) {
+                int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+                row = row < hi - 1 ? row : hi - 1;
+                kw[u] = keys[row];
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) vw[j][u] = valp[j][row];
+            }
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) {
+                int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+                if (row >= hi) continue;
+                const uint64_t key = kw[u];
+                // tuples of a partition arrive in no particular order: no run cache, one table update per row
+                int slot;
+                if (key == EMPTY_KEY) { lkeys[cap] = 0; slot = int(cap); }
+                else if (*seg_full) slot = -1; // this partition has more distinct keys than the table: spill the rest
+                else {
+                    uint32_t sl = uint32_t(((key * GOLD) << part_bits) >> a.lds_shift);
+                    slot = -1;
+                    for (int probe = 0; probe < 32; ++probe) {
+                        uint64_t k = lkeys[sl];
+                        if (k == key) { slot = int(sl); break; }
+                        if (k == EMPTY_KEY) {
+                            uint64_t old = atomicCAS((unsigned long long *)&lkeys[sl], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                            if (old == EMPTY_KEY || old == key) { slot = int(sl); break; }
+                        }
+                        sl = (sl + 1) & (cap - 1);
+                    }
+                }
+                if (slot < 0 && !*seg_full) {
+                    *seg_full = 1;
+                    if (signal_level2) atomicOr(&flags[NQE_FLAG_NEED_LEVEL2], 1); // the host re-partitions one level deeper
+                }
+                if (slot < 0 && signal_level2) continue;                              // result will be discarded
+                if (slot < 0 && g.dense_count) {                                      // no hash table to spill to: the host falls back
+                    atomicOr(&flags[NQE_FLAG_DENSE_OVERFLOW], 1);
+                    continue;
+                }
+                int64_t gslot = slot < 0 ? global_find_or_insert(g, key, flags) : 0; // partition larger than the table: spill
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) {
+                    double x = VF64 ? u2d(vw[j][u]) : word_as_f64(vw[j][u], vdt[j]);
+                    bool isn = x != x;
+                    uint64_t xo = f64_to_ord(x);
+                    if (slot >= 0) {
+                        uint32_t o = uint32_t(j) * slots + uint32_t(slot);
+                        atomicAdd(&lcnt[o], 1u);
+                        if (isn) atomicOr(&lcnt[o], NAN_BIT);
+                        unsafeAtomicAdd(&lsum[o], x);
+                        if (!isn) {
+                            if (xo < lmn[o]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)xo);
+                            if (xo > lmx[o]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)xo);
+                        }
+                    } else if (gslot >= 0) {
+                        global_update(g, gslot, a.v0 + j, 1, x, true, xo, xo, !isn, isn);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (g.dense_count) {
+            // ---- dense output: count this partition's groups, reserve [base, base + n) with one atomic, write them there
+            __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
+            __shared__ uint32_t dense_base;
+            uint32_t mine = 0;
+            for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) mine += lkeys[s] != EMPTY_KEY ? 1u : 0u;
+            uint32_t wtot;
+            const uint32_t wexcl = wave_exclusive_scan(mine, wtot);
+            if (lane_id() == 0) wave_tot[threadIdx.x / 64] = wtot;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t tot = 0;
+                for (int w = 0; w < AGG_BLOCK / 64; ++w) { uint32_t c = wave_tot[w]; wave_tot[w] = tot; tot += c; }
+                dense_base = tot ? atomicAdd(g.dense_count, tot) : 0u;
+            }
+            __syncthreads();
+            uint32_t pos = dense_base + wave_tot[threadIdx.x / 64] + wexcl;
+            const size_t gstride = size_t(g.cap) + 1;
+            for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+                uint64_t k = lkeys[s];
+                if (k == EMPTY_KEY) continue;
+                if (pos < g.cap) {
+                    g.keys[pos] = (s == cap) ? EMPTY_KEY : k;
+#pragma unroll
+                    for (int j = 0; j < NVT; ++j) {
+                        const uint32_t o = uint32_t(j) * slots + s;
+                        const uint32_t c = lcnt[o];
+                        const size_t go = size_t(a.v0 + j) * gstride + pos;
+                        g.cnt[go] = uint64_t(c & ~NAN_BIT);
+                        g.sum[go] = lsum[o];
+                        g.mn[go] = lmn[o];
+                        g.mx[go] = lmx[o];
+                        g.nan[go] = (c & NAN_BIT) ? 1u : 0u;
+                    }
+                } else atomicOr(&flags[NQE_FLAG_DENSE_OVERFLOW], 1);
+                ++pos;
+            }
+            continue;
+        }
+        for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+            uint64_t k = lkeys[s];
+            if (k == EMPTY_KEY) continue;
+            uint64_t key = (s == cap) ? EMPTY_KEY : k;
+            int64_t gslot = global_find_or_insert(g, key, flags);
+            if (gslot < 0) continue;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+                uint32_t o = uint32_t(j) * slots + s;
+                uint32_t c = lcnt[o];
+                global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
+            }
+        }
+    }
+}
+
+template <int PRED, int KEY> PartKernel pick_scatter_nv(int nv) {
+    return nv == 1 ? agg_partition_scatter_kernel<PRED, KEY, 1> : agg_partition_scatter_kernel<PRED, KEY, 2>;
+}
+template <int PRED> PartKernel pick_scatter_key(int key, int nv) {
+    switch (key) {
+    case 0: return pick_scatter_nv<PRED, 0>(nv);
+    case 1: return pick_scatter_nv<PRED, 1>(nv);
+    default: return pick_scatter_nv<PRED, 2>(nv);
+    }
+}
+template <int PRED, int KEY, int NVT> PartKernel pick_part_sc(bool scatter) {
+    return scatter ? agg_partition_kernel<PRED, KEY, NVT, true> : agg_partition_kernel<PRED, KEY, NVT, false>;
+}
+template <int PRED, int KEY> PartKernel pick_part_nv(int nv, bool scatter) {
+    return nv == 1 ? pick_part_sc<PRED, KEY, 1>(scatter) : pick_part_sc<PRED, KEY, 2>(scatter);
+}
+template <int PRED> PartKernel pick_part_key(int key, int nv, bool scatter) {
+    switch (key) {
+    case 0: return pick_part_nv<PRED, 0>(nv, scatter);
+    case 1: return pick_part_nv<PRED, 1>(nv, scatter);
+    default: return pick_part_nv<PRED, 2>(nv, scatter);
+    }
+}
+
+} // namespace
+
+PartKernel pick_scatter_kernel(int pred, int key, int nv) {
+    switch (pred) {
+    case 0: return pick_scatter_key<0>(key, nv);
+    case 1: return pick_scatter_key<1>(key, nv);
+    default: return pick_scatter_key<2>(key, nv);
+    }
+}
+PartKernel pick_part_kernel(int pred, int key, int nv, bool scatter) {
+    switch (pred) {
+    case 0: return pick_part_key<0>(key, nv, scatter);
+    case 1: return pick_part_key<1>(key, nv, scatter);
+    default: return pick_part_key<2>(key, nv, scatter);
+    }
+}
+SubpartitionKernel pick_subpartition_kernel(int nv) { return nv == 1 ? agg_subpartition_kernel<1> : agg_subpartition_kernel<2>; }
+SegmentsKernel pick_segments_kernel(int nv, bool vf64) {
+    return nv == 1 ? (vf64 ? agg_segments_kernel<1, true> : agg_segments_kernel<1, false>) : (vf64 ? agg_segments_kernel<2, true> : agg_segments_kernel<2, false>);
+}
+
+} // namespace agg
+} // namespace nqe

@@ -1,0 +1,904 @@
+// hash_join.hip — HashJoin::execute = build() + probe() (reference: src/physical_plan/hash_join.rs:124-254).
+//
+// Reference: HashMap<XxHash64(key), Vec<build row>> chains, per probe row a chain walk with an
+// equality re-check (:86-101), then `take` of every left column by build index and every right
+// column by probe index (:237-246).  Output order: probe-row-major, duplicate build keys in
+// ascending build row.
+//
+// Device design
+//   build : stable radix sort of (key, build row) → equal keys adjacent, rows ascending;
+//           run heads → unique keys with (start, count) into the sorted row list `perm`;
+//           open-addressing table of 16-byte slots {key, start<<32|count} (Fibonacci hash, one
+//           128-bit load per probe step).  The XxHash64 value itself is unobservable in results
+//           (equality is re-checked), so any hash is parity-safe.  When every build key is
+//           unique the slot stores the build row directly (no `perm` indirection).
+//   probe : pass 1 looks every probe key up once and records its (start,count) word plus
+//           per-tile match counts; an exclusive scan gives each 4096-row tile its output base;
+//           pass 2 re-reads the recorded words, ranks rows inside the tile with wave scans and
+//           writes all output columns (gather of left columns by build row, copy of right
+//           columns) in probe order — exactly the order of the reference's outer_pos/inner_pos.
+// Key validity is ignored (quirk Q11): raw 8-byte slot values are compared.
+#include <algorithm>
+
+#include "device_utils.hpp"
+#include "nqe_internal.hpp"
+
+struct nqe_join_table {
+    nqe_ctx *ctx = nullptr;
+    std::vector<nqe::DevColumn> left_cols; // shared buffers of the build side ("self.data")
+    int64_t left_rows = 0;
+    int key_dtype = NQE_INT64;
+    nqe::BufRef slots; // ulonglong2[cap]
+    nqe::BufRef perm;  // uint32[left_rows], build rows sorted by (key, row)
+    uint32_t cap = 0;
+    int shift = 0;
+    bool direct = false; // all build keys unique: slot.y>>32 is the build row itself
+    // dense build keys (max-min+1 <= 4n): direct-address table instead of hashing.
+    //   unique keys:   dense[key-min] = build row + 1
+    //   duplicate keys: dense[key-min] = unique-key index + 1 → (ustart[u], ustart[u+1]-ustart[u])
+    int left_key = 0;
+    nqe::BufRef dense;   // uint32[span]
+    nqe::BufRef ustart;  // uint32[U+1]
+    uint64_t dense_min = 0, dense_span = 0; // span = number of entries (0: not dense)
+    // unique + dense keys + plain 8-byte payload: payload columns re-laid out by (key - min) so that a probe
+    // needs ONE random access per gathered value and no build-row lookup at all
+    nqe::BufRef presence;                 // uint32 bitmap over [0, span)
+    std::vector<nqe::BufRef> dense_cols;  // per left column (null for the key column)
+    // Int64/UInt64 payloads whose value range fits 32 bits are stored as uint32 offsets from their minimum (frame of
+    // reference): the gather target halves, so more of it stays in the 4 MB per-XCD L2 (the probe is gather-bound)
+    std::vector<int> dense_packed;        // 1: dense_cols[ci] holds uint32 (value - dense_base[ci])
+    std::vector<uint64_t> dense_base;
+    bool dense_payload = false;
+    bool dense_full = false; // every key of the dense range occurs
+    // Utf8 join keys: the build strings are encoded to representative-row codes (strings.hip)
+    nqe::Utf8Dict dict;
+};
+
+namespace nqe {
+
+namespace {
+
+constexpr uint64_t GOLD = 0x9E3779B97F4A7C15ull;
+constexpr int JT_ROWS = 4096; // probe tile
+constexpr int JT_BLOCK = 256;
+constexpr int JT_ITERS = JT_ROWS / JT_BLOCK;
+constexpr int MAX_JOIN_COLS = 32;
+
+__global__ void iota_u32_kernel(uint32_t *out, int64_t n) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = uint32_t(i);
+}
+
+// flags[j] = 1 iff sorted key j starts a run; flags[n] = 0 (so the exclusive scan leaves the total there)
+__global__ void mark_heads_kernel(const uint64_t *skeys, int64_t n, uint32_t *flags) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j <= n; j += stride)
+        flags[j] = (j < n && (j == 0 || skeys[j] != skeys[j - 1])) ? 1u : 0u;
+}
+
+// ustart[u] = position of the u-th run head in the sorted order; ustart[U] = n
+__global__ void fill_ustart_kernel(const uint32_t *flags, const uint64_t *offs, int64_t n, uint32_t U, uint32_t *ustart) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j <= n; j += stride) {
+        if (j == n) ustart[U] = uint32_t(n);
+        else if (flags[j]) ustart[offs[j]] = uint32_t(j);
+    }
+}
+
+// inserts every unique key: claims a slot by CAS on the meta word (0 = empty), then stores the key
+__global__ void insert_unique_kernel(const uint64_t *skeys, const uint32_t *ustart, const uint32_t *perm, uint32_t U,
+                                     ulonglong2 *slots, uint32_t cap, int shift, int direct) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; u < int64_t(U); u += stride) {
+        uint32_t j = ustart[u];
+        uint64_t key = skeys[j];
+        uint64_t count = uint64_t(ustart[u + 1] - j);
+        uint64_t start = direct ? uint64_t(perm[j]) : uint64_t(j);
+        uint64_t meta = (start << 32) | count;
+        uint32_t slot = uint32_t((key * GOLD) >> shift);
+        for (;;) {
+            unsigned long long old = atomicCAS((unsigned long long *)&slots[slot].y, 0ull, (unsigned long long)meta);
+            if (old == 0ull) {
+                slots[slot].x = key;
+                break;
+            }
+            slot = (slot + 1) & (cap - 1);
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t probe_one(const ulonglong2 *__restrict__ slots, uint32_t cap, int shift, uint64_t key) {
+    uint32_t slot = uint32_t((key * GOLD) >> shift);
+    for (uint32_t p = 0; p < cap; ++p) {
+        ulonglong2 s = slots[slot];
+        if (s.y == 0ull) return 0ull;
+        if (s.x == key) return s.y;
+        slot = (slot + 1) & (cap - 1);
+    }
+    return 0ull;
+}
+
+struct Lookup {
+    const ulonglong2 *slots; // hash table (16-byte slots)
+    uint32_t cap;
+    int32_t shift;
+    const uint32_t *dense;   // direct-address table or null
+    const uint32_t *ustart;
+    uint64_t dense_min, dense_span;
+    int32_t direct;
+    int32_t pad;
+};
+
+// (start<<32 | count) of `key`, 0 when absent. direct ⇒ start is the build row itself.
+__device__ __forceinline__ uint64_t lookup_meta(const Lookup &L, uint64_t key) {
+    if (L.dense) {
+        uint64_t d = key - L.dense_min;
+        if (d >= L.dense_span) return 0ull;
+        uint32_t e = L.dense[d];
+        if (e == 0) return 0ull;
+        if (L.direct) return (uint64_t(e - 1) << 32) | 1ull;
+        uint32_t st = L.ustart[e - 1];
+        return (uint64_t(st) << 32) | uint64_t(L.ustart[e] - st);
+    }
+    return probe_one(L.slots, L.cap, L.shift, key);
+}
+
+__global__ void fill_dense_kernel(const uint64_t *skeys, const uint32_t *ustart, const uint32_t *perm, uint32_t U, uint64_t dmin,
+                                  uint32_t *dense, int direct) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; u < int64_t(U); u += stride) {
+        uint32_t j = ustart[u];
+        dense[skeys[j] - dmin] = direct ? perm[j] + 1u : uint32_t(u) + 1u;
+    }
+}
+
+// Unique build keys: one lookup per probe row → match bitmap (the KEEP mask of the compaction
+// kernels), 4-byte build row per probe row, per-tile match counts.  Wave per 4096-row tile.
+__global__ void __launch_bounds__(256) probe_unique_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, Lookup L, uint64_t *keep,
+                                                           uint32_t *bidx, uint32_t *tile_counts) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t last = n - 1;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t row0 = tile * TILE_ROWS;
+        uint32_t total = 0;
+        // (issuing the first probe of 16 keys before examining any was measured slower, 2.41 -> 2.63 ms: the hashed probe is
+        // bound by line fetches — 10^8 x 128 B at ≈5 TB/s — not by latency, and the extra registers cost occupancy)
+#pragma unroll 2
+        for (int k0 = 0; k0 < TILE_WORDS; k0 += 8) {
+            uint64_t key[8], meta[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                key[k] = rkeys[row < last ? row : last];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) meta[k] = lookup_meta(L, key[k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                bool hit = row < n && meta[k] != 0ull;
+                uint64_t kw = __ballot(hit);
+                if (row < n) bidx[row] = uint32_t(meta[k] >> 32);
+                if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
+                total += __popcll(kw);
+            }
+        }
+        if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
+// ---- unique + dense + plain payload: fused probe
+__global__ void scatter_dense_payload_kernel(const uint64_t *keys, int64_t n, uint64_t dmin, const uint64_t *src, uint64_t *dst,
+                                             uint32_t *presence) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) {
+        uint64_t d = keys[r] - dmin;
+        if (dst) dst[d] = src[r];
+        if (presence) atomicOr(&presence[d >> 5], 1u << (d & 31));
+    }
+}
+
+// unsigned min / max of (value ^ flip) over a column (flip = sign bit for Int64 → order as signed)
+__global__ void __launch_bounds__(256) minmax_u64_kernel(const uint64_t *v, int64_t n, uint64_t flip, unsigned long long *out_min, unsigned long long *out_max) {
+    uint64_t mn = ~0ull, mx = 0;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        const uint64_t x = v[i] ^ flip;
+        mn = x < mn ? x : mn;
+        mx = x > mx ? x : mx;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint64_t a = __shfl_down(mn, d, 64), b = __shfl_down(mx, d, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (lane_id() == 0) {
+        atomicMin(out_min, (unsigned long long)mn);
+        atomicMax(out_max, (unsigned long long)mx);
+    }
+}
+__global__ void scatter_dense_payload32_kernel(const uint64_t *keys, int64_t n, uint64_t dmin, const uint64_t *src, uint64_t base, uint32_t *dst,
+                                               uint32_t *presence) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) {
+        uint64_t d = keys[r] - dmin;
+        dst[d] = uint32_t(src[r] - base);
+        if (presence) atomicOr(&presence[d >> 5], 1u << (d & 31));
+    }
+}
+
+// pass 1: match bitmap + per-tile counts (no build-row output).
+// MODE 0: every key of [min, min+span) is present → a range check, no memory access at all;
+// MODE 1: presence bitmap staged in LDS (span/8 bytes ≤ 128 KB: random LDS reads instead of one L2
+//         request per probe row); MODE 2: presence bitmap read from global memory.
+template <int MODE>
+__global__ void __launch_bounds__(1024) probe_presence_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, const uint32_t *presence,
+                                                              uint64_t dmin, uint64_t span, uint64_t *keep, uint32_t *tile_counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lp = reinterpret_cast<uint32_t *>(smem);
+    if (MODE == 1) {
+        const uint32_t words = uint32_t((span + 31) / 32);
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) lp[i] = presence[i];
+        __syncthreads();
+    }
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t last = n - 1;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t row0 = tile * TILE_ROWS;
+        uint32_t total = 0;
+#pragma unroll 2
+        for (int k0 = 0; k0 < TILE_WORDS; k0 += 8) {
+            uint64_t key[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                key[k] = __builtin_nontemporal_load(&rkeys[row < last ? row : last]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                uint64_t d = key[k] - dmin;
+                bool hit = row < n && d < span;
+                if (MODE == 1) hit = hit && ((lp[d >> 5] >> (d & 31)) & 1u);
+                if (MODE == 2) hit = hit && ((presence[d >> 5] >> (d & 31)) & 1u);
+                uint64_t kw = __ballot(hit);
+                if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
+                total += __popcll(kw);
+            }
+        }
+        if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
+struct FusedCols {
+    int32_t n;
+    int32_t pad;
+    int32_t kind[MAX_JOIN_COLS];        // 0: probe-side column (coalesced copy), 1: build key (= probe key), 2: build payload (gather),
+                                        // 3: build payload packed as uint32 offsets from base[] (gather)
+    const uint64_t *src[MAX_JOIN_COLS]; // kind 0: probe column; kind 2/3: key-ordered build column
+    uint64_t *dst[MAX_JOIN_COLS];
+    uint64_t base[MAX_JOIN_COLS];
+};
+
+// pass 2: one read of the probe keys, every output column written in probe order
+// `bidx` null: a build payload is addressed by key - dmin (key-ordered dense columns); non-null: by the build row recorded
+// per probe row by probe_unique_kernel (hashed unique keys), gathered from the build columns themselves.
+template <int FW_B> // rows per lane in flight
+__global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, const uint64_t *keep,
+                                                               const uint64_t *tile_offsets, uint64_t dmin, const uint32_t *bidx, FusedCols fc) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t nwords = (n + 63) / 64;
+    const int64_t last = n - 1;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        int64_t w = tile * TILE_WORDS + lane_id();
+        uint64_t my_word = w < nwords ? keep[w] : 0;
+        uint32_t tot;
+        uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+        const uint64_t base = tile_offsets[tile];
+        for (int k0 = 0; k0 < TILE_WORDS; k0 += FW_B) {
+            uint64_t key[FW_B];
+            uint32_t pos[FW_B]; // position inside the tile's output range
+            uint32_t kept = 0;
+#pragma unroll
+            for (int k = 0; k < FW_B; ++k) {
+                int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                key[k] = __builtin_nontemporal_load(&rkeys[row < last ? row : last]); // streamed once: keep L2 for the gather
+            }
+#pragma unroll
+            for (int k = 0; k < FW_B; ++k) {
+                uint64_t word = bcast64(my_word, k0 + k);
+                pos[k] = bcast32(my_off, k0 + k) + __popcll(word & lanemask_lt());
+                kept |= uint32_t((word >> lane_id()) & 1) << k;
+            }
+            uint64_t gix[FW_B]; // gather index of a build payload
+#pragma unroll
+            for (int k = 0; k < FW_B; ++k) {
+                if (bidx) {
+                    int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                    gix[k] = bidx[row < last ? row : last];
+                } else gix[k] = key[k] - dmin;
+            }
+            for (int c = 0; c < fc.n; ++c) {
+                const uint64_t *__restrict__ src = fc.src[c];
+                uint64_t *__restrict__ dst = fc.dst[c] + base;
+                const int kind = fc.kind[c];
+                uint64_t v[FW_B];
+                if (kind == 0) {
+#pragma unroll
+                    for (int k = 0; k < FW_B; ++k) {
+                        int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                        v[k] = __builtin_nontemporal_load(&src[row < last ? row : last]);
+                    }
+                } else if (kind == 1) {
+#pragma unroll
+                    for (int k = 0; k < FW_B; ++k) v[k] = key[k];
+                } else if (kind == 2) {
+#pragma unroll
+                    for (int k = 0; k < FW_B; ++k) v[k] = src[(kept >> k) & 1 ? gix[k] : 0];
+                } else {
+                    const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(src);
+                    const uint64_t b0 = fc.base[c];
+#pragma unroll
+                    for (int k = 0; k < FW_B; ++k) v[k] = b0 + src32[(kept >> k) & 1 ? gix[k] : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < FW_B; ++k)
+                    if ((kept >> k) & 1) __builtin_nontemporal_store(v[k], &dst[pos[k]]);
+            }
+        }
+    }
+}
+
+// 16 rows per lane in flight: the kernel is bound by the latency of its gathers, and memory-level parallelism per wave
+// beats occupancy (A/B on one box, C4: 4 rows/lane (70 VGPRs, 7 waves/SIMD) 1.53 ms, 8 (116, 4) 1.33 ms, 16 (210, 2)
+// 1.24 ms, 32 (256, 1) 1.31 ms)
+constexpr int FUSED_WRITE_ROWS = 16;
+
+// pass 1: one table lookup per probe row; records meta and per-tile totals
+__global__ void __launch_bounds__(JT_BLOCK) probe_count_kernel(const uint64_t *rkeys, int64_t n, Lookup L, uint64_t *pmeta,
+                                                               uint32_t *tile_counts, int *flags) {
+    __shared__ uint64_t wave_tot[JT_BLOCK / 64];
+    for (int64_t tile = blockIdx.x; tile * JT_ROWS < n; tile += gridDim.x) {
+        uint64_t keys[JT_ITERS];
+#pragma unroll
+        for (int it = 0; it < JT_ITERS; ++it) {
+            int64_t i = tile * JT_ROWS + int64_t(it) * JT_BLOCK + threadIdx.x;
+            keys[it] = i < n ? rkeys[i] : 0;
+        }
+        uint64_t local = 0;
+#pragma unroll
+        for (int it = 0; it < JT_ITERS; ++it) {
+            int64_t i = tile * JT_ROWS + int64_t(it) * JT_BLOCK + threadIdx.x;
+            if (i < n) {
+                uint64_t m = lookup_meta(L, keys[it]);
+                pmeta[i] = m;
+                local += m & 0xFFFFFFFFull;
+            }
+        }
+        for (int d = 32; d > 0; d >>= 1) local += __shfl_down((unsigned long long)local, d, 64);
+        if (lane_id() == 0) wave_tot[threadIdx.x / 64] = local;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t t = 0;
+            for (int w = 0; w < JT_BLOCK / 64; ++w) t += wave_tot[w];
+            if (t > 0xFFFFFFFFull) {
+                atomicOr(&flags[NQE_FLAG_TABLE_FULL], 1);
+                t = 0;
+            }
+            tile_counts[tile] = uint32_t(t);
+        }
+        __syncthreads();
+    }
+}
+
+struct JoinCols {
+    int32_t n;
+    int32_t n_left;
+    const void *src[MAX_JOIN_COLS];
+    const uint8_t *src_valid[MAX_JOIN_COLS];
+    int32_t dtype[MAX_JOIN_COLS];
+    uint64_t *dst_words[MAX_JOIN_COLS];
+    uint8_t *dst_bool_bytes[MAX_JOIN_COLS];
+    uint8_t *dst_valid_bytes[MAX_JOIN_COLS];
+};
+
+// pass 2, output-driven ("load-balanced expansion"): a tile of probe rows is scanned in LDS; lane j of the
+// workgroup then produces OUTPUT row base+j: its probe row is found by binary search in the tile's offsets,
+// its match number m = j - offset[row], its build row = perm[start + m].  Consecutive lanes write consecutive
+// output rows of every column (coalesced), probe-row-major with ascending build row inside a probe row —
+// exactly the order of the reference's outer_pos/inner_pos (hash_join.rs:86-101).
+constexpr int PW_TILE = 1024; // probe rows per tile (= JT_ROWS / 4); tile_offsets are per JT_ROWS, so 4 sub-tiles share one base
+__global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *pmeta, int64_t n, const uint64_t *tile_offsets,
+                                                               const uint32_t *perm, int direct, JoinCols jc) {
+    __shared__ uint32_t off[PW_TILE + 1];
+    __shared__ uint32_t startv[PW_TILE];
+    __shared__ uint32_t wave_tot[JT_BLOCK / 64];
+    constexpr int RPT = PW_TILE / JT_BLOCK; // probe rows per thread
+    for (int64_t tile = blockIdx.x; tile * JT_ROWS < n; tile += gridDim.x) {
+        uint64_t out_base = tile_offsets[tile];
+        for (int sub = 0; sub < JT_ROWS / PW_TILE; ++sub) {
+            const int64_t row0 = tile * JT_ROWS + int64_t(sub) * PW_TILE;
+            if (row0 >= n) break;
+            // ---- exclusive scan of the match counts of this sub-tile (thread t owns RPT consecutive probe rows)
+            uint32_t cnt[RPT], local = 0;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                int64_t i = row0 + int64_t(threadIdx.x) * RPT + r;
+                uint64_t m = i < n ? pmeta[i] : 0ull;
+                cnt[r] = uint32_t(m & 0xFFFFFFFFull);
+                startv[threadIdx.x * RPT + r] = uint32_t(m >> 32);
+                local += cnt[r];
+            }
+            uint32_t wtot;
+            uint32_t ex = wave_exclusive_scan(local, wtot);
+            if (lane_id() == 63) wave_tot[threadIdx.x / 64] = wtot;
+            __syncthreads();
+            uint32_t pre = 0, total = 0;
+            for (int w = 0; w < JT_BLOCK / 64; ++w) {
+                if (w < int(threadIdx.x) / 64) pre += wave_tot[w];
+                total += wave_tot[w];
+            }
+            uint32_t run = pre + ex;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                off[threadIdx.x * RPT + r] = run;
+                run += cnt[r];
+            }
+            if (threadIdx.x == 0) off[PW_TILE] = total;
+            __syncthreads();
+            // ---- one lane per output row
+            for (uint32_t j0 = 0; j0 < total; j0 += JT_BLOCK * 4) {
+                uint32_t prow[4], brow[4];
+                bool live[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t j = j0 + q * JT_BLOCK + threadIdx.x;
+                    live[q] = j < total;
+                    uint32_t lo = 0, hi = PW_TILE; // largest lo with off[lo] <= j
+                    uint32_t jj = live[q] ? j : 0;
+#pragma unroll
+                    for (int step = 0; step < 10; ++step) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        bool go = off[mid] <= jj;
+                        lo = go ? mid : lo;
+                        hi = go ? hi : mid;
+                    }
+                    prow[q] = lo;
+                    uint32_t mth = jj - off[lo];
+                    brow[q] = live[q] ? (direct ? startv[lo] : perm[startv[lo] + mth]) : 0u;
+                }
+                for (int c = 0; c < jc.n; ++c) {
+                    const bool left = c < jc.n_left;
+                    const void *src = jc.src[c];
+                    const uint8_t *sv = jc.src_valid[c];
+                    const int dt = jc.dtype[c];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (!live[q]) continue;
+                        int64_t srow = left ? int64_t(brow[q]) : row0 + prow[q];
+                        bool ok = sv ? get_bit(sv, srow) : true;
+                        uint64_t v = load_word(src, dt, srow);
+                        uint64_t pos = out_base + j0 + q * JT_BLOCK + threadIdx.x;
+                        if (jc.dst_words[c]) jc.dst_words[c][pos] = ok ? v : 0;
+                        if (jc.dst_bool_bytes[c]) jc.dst_bool_bytes[c][pos] = (ok && v) ? 1 : 0;
+                        if (jc.dst_valid_bytes[c]) jc.dst_valid_bytes[c][pos] = ok ? 1 : 0;
+                    }
+                }
+            }
+            out_base += total;
+            __syncthreads();
+        }
+    }
+}
+
+void check_key_types(int ldt, int rdt) {
+    auto joinable = [](int d) { return d == NQE_INT64 || d == NQE_UINT64 || d == NQE_UTF8; };
+    if (!joinable(ldt)) fail(NQE_ERR_NOT_IMPLEMENTED, "NotImplemented: join key type (hash_join.rs:161)");
+    if (rdt < 0) return;
+    if (!joinable(rdt)) fail(NQE_ERR_NOT_IMPLEMENTED, "NotImplemented: join key type (hash_join.rs:232)");
+    if (rdt != ldt) fail(NQE_ERR_NOT_SUPPORTED, "join key types differ (downcast unwrap panics, hash_join.rs:83)");
+}
+
+std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left, int left_key) {
+    if (left_key < 0 || size_t(left_key) >= left->cols.size()) fail(NQE_ERR_LOGICAL, "ColumnExpr must has name or idx");
+    const DevColumn &kc_orig = left->cols[size_t(left_key)];
+    check_key_types(kc_orig.dtype, -1);
+    const int64_t n = left->rows;
+    Utf8Dict dict;
+    DevColumn kc_codes;
+    if (kc_orig.dtype == NQE_UTF8) kc_codes = utf8_encode_build(ctx, kc_orig, &dict);
+    const DevColumn &kc = kc_orig.dtype == NQE_UTF8 ? kc_codes : kc_orig;
+    if (n >= (int64_t(1) << 32)) fail(NQE_ERR_NOT_SUPPORTED, "build side with 2^32 or more rows is not supported");
+    auto jt = std::make_unique<nqe_join_table>();
+    jt->ctx = ctx;
+    jt->left_cols = left->cols;
+    jt->left_rows = n;
+    jt->key_dtype = kc_orig.dtype;
+    jt->left_key = left_key;
+    jt->dict = dict;
+
+    BufRef idx = dev_alloc(ctx, size_t(n) * 4 + 8), skeys = dev_alloc(ctx, size_t(n) * 8 + 8);
+    jt->perm = dev_alloc(ctx, size_t(n) * 4 + 8);
+    uint32_t U = 0;
+    BufRef ustart;
+    if (n) {
+        launch(ctx, "join_iota", iota_u32_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, (uint32_t *)idx->ptr, n);
+        radix_sort_pairs_u64(ctx, kc.words(), (const uint32_t *)idx->ptr, (uint64_t *)skeys->ptr, (uint32_t *)jt->perm->ptr, n,
+                             false);
+        // run heads of the sorted keys → unique keys
+        BufRef flags = dev_alloc(ctx, size_t(n + 1) * 4);
+        launch(ctx, "join_mark_heads", mark_heads_kernel, dim3(stream_grid(ctx, n + 1, 256)), dim3(256), 0,
+               (const uint64_t *)skeys->ptr, n, (uint32_t *)flags->ptr);
+        BufRef offs = dev_alloc(ctx, size_t(n + 2) * 8);
+        exclusive_scan_u32_to_u64(ctx, (const uint32_t *)flags->ptr, (uint64_t *)offs->ptr, n + 1);
+        U = uint32_t(read_scalar(ctx, (const uint64_t *)offs->ptr + (n + 1)));
+        ustart = dev_alloc(ctx, size_t(U + 1) * 4);
+        launch(ctx, "join_fill_ustart", fill_ustart_kernel, dim3(stream_grid(ctx, n + 1, 256)), dim3(256), 0,
+               (const uint32_t *)flags->ptr, (const uint64_t *)offs->ptr, n, U, (uint32_t *)ustart->ptr);
+    }
+    jt->direct = (int64_t(U) == n);
+    uint32_t cap = 64;
+    while (uint64_t(cap) < 2ull * U) cap <<= 1;
+    int lg = 0;
+    while ((1u << lg) < cap) ++lg;
+    jt->cap = cap;
+    jt->shift = 64 - lg;
+    jt->slots = dev_alloc_zero(ctx, size_t(cap) * 16);
+    if (U)
+        launch(ctx, "join_insert", insert_unique_kernel, dim3(stream_grid(ctx, U, 256)), dim3(256), 0, (const uint64_t *)skeys->ptr,
+               (const uint32_t *)ustart->ptr, (const uint32_t *)jt->perm->ptr, U, (ulonglong2 *)jt->slots->ptr, cap, jt->shift,
+               jt->direct ? 1 : 0);
+    // dense key range → direct-address table (keys are sorted unsigned: first/last are min/max)
+    if (n > 0 && U > 0) {
+        uint64_t kmin = read_scalar(ctx, (const uint64_t *)skeys->ptr);
+        uint64_t kmax = read_scalar(ctx, (const uint64_t *)skeys->ptr + (n - 1));
+        uint64_t span = kmax - kmin + 1; // 0 on wrap-around: not dense
+        if (span != 0 && span <= std::max<uint64_t>(4ull * uint64_t(n), 1024ull) && span < (1ull << 31)) {
+            jt->dense = dev_alloc_zero(ctx, size_t(span) * 4);
+            jt->dense_min = kmin;
+            jt->dense_span = span;
+            launch(ctx, "join_fill_dense", fill_dense_kernel, dim3(stream_grid(ctx, U, 256)), dim3(256), 0, (const uint64_t *)skeys->ptr,
+                   (const uint32_t *)ustart->ptr, (const uint32_t *)jt->perm->ptr, U, kmin, (uint32_t *)jt->dense->ptr, jt->direct ? 1 : 0);
+            if (!jt->direct) jt->ustart = ustart;
+            // unique keys and plain payload: key-ordered copies of the payload columns + presence bitmap
+            bool plain = jt->direct && !kc.validity && kc_orig.dtype != NQE_UTF8;
+            for (size_t ci = 0; ci < left->cols.size(); ++ci)
+                if (int(ci) != left_key) plain = plain && is_word_type(left->cols[ci].dtype) && !left->cols[ci].validity;
+            if (plain && span * 8 * left->cols.size() <= (size_t(8) << 30)) {
+                jt->presence = dev_alloc_zero(ctx, size_t((span + 31) / 32) * 4);
+                jt->dense_cols.resize(left->cols.size());
+                jt->dense_packed.assign(left->cols.size(), 0);
+                jt->dense_base.assign(left->cols.size(), 0);
+                bool first = true;
+                for (size_t ci = 0; ci < left->cols.size(); ++ci) {
+                    if (int(ci) == left_key) continue;
+                    const DevColumn &pc = left->cols[ci];
+                    if (pc.dtype == NQE_INT64 || pc.dtype == NQE_UINT64) { // value range within 32 bits → uint32 offsets
+                        const uint64_t flip = pc.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
+                        BufRef mm = dev_alloc(ctx, 16);
+                        const uint64_t init[2] = {~0ull, 0ull};
+                        NQE_HIP_CHECK(hipMemcpyAsync(mm->ptr, init, 16, hipMemcpyHostToDevice, ctx->stream));
+                        launch(ctx, "join_payload_minmax", minmax_u64_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, pc.words(), n, flip,
+                               (unsigned long long *)mm->ptr, (unsigned long long *)mm->ptr + 1);
+                        const uint64_t mn = read_scalar(ctx, (const uint64_t *)mm->ptr), mx = read_scalar(ctx, (const uint64_t *)mm->ptr + 1);
+                        if (mx - mn <= 0xffffffffull) {
+                            jt->dense_packed[ci] = 1;
+                            jt->dense_base[ci] = mn ^ flip;
+                            jt->dense_cols[ci] = dev_alloc_zero(ctx, size_t(span) * 4 + 8);
+                            launch(ctx, "join_scatter_payload", scatter_dense_payload32_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n,
+                                   kmin, pc.words(), jt->dense_base[ci], (uint32_t *)jt->dense_cols[ci]->ptr,
+                                   first ? (uint32_t *)jt->presence->ptr : (uint32_t *)nullptr);
+                            first = false;
+                            continue;
+                        }
+                    }
+                    jt->dense_cols[ci] = dev_alloc(ctx, size_t(span) * 8);
+                    launch(ctx, "join_scatter_payload", scatter_dense_payload_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0,
+                           kc.words(), n, kmin, left->cols[ci].words(), (uint64_t *)jt->dense_cols[ci]->ptr,
+                           first ? (uint32_t *)jt->presence->ptr : (uint32_t *)nullptr);
+                    first = false;
+                }
+                if (first) // key-only build side: presence bitmap only
+                    launch(ctx, "join_scatter_payload", scatter_dense_payload_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0,
+                           kc.words(), n, kmin, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)jt->presence->ptr);
+                jt->dense_payload = true;
+                jt->dense_full = (span == uint64_t(U));
+            }
+        }
+    }
+    sync(ctx); // skeys/flags/ustart are released on return
+    return jt;
+}
+
+std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, const nqe_table *right, int right_key) {
+    if (right_key < 0 || size_t(right_key) >= right->cols.size()) fail(NQE_ERR_LOGICAL, "ColumnExpr must has name or idx");
+    const DevColumn &rk_orig = right->cols[size_t(right_key)];
+    check_key_types(jt->key_dtype, rk_orig.dtype);
+    DevColumn rk_codes;
+    if (rk_orig.dtype == NQE_UTF8) rk_codes = utf8_encode_probe(ctx, rk_orig, jt->dict);
+    const DevColumn &rk = rk_orig.dtype == NQE_UTF8 ? rk_codes : rk_orig;
+    const int64_t n = right->rows;
+    const size_t ncols = jt->left_cols.size() + right->cols.size();
+    if (ncols > size_t(MAX_JOIN_COLS)) fail(NQE_ERR_NOT_SUPPORTED, "join output wider than 32 columns");
+    bool utf8_left = false, utf8_right = false;
+    for (auto &c : jt->left_cols) utf8_left |= c.dtype == NQE_UTF8;
+    for (auto &c : right->cols) utf8_right |= c.dtype == NQE_UTF8;
+
+    Lookup L;
+    std::memset(&L, 0, sizeof(L));
+    L.slots = (const ulonglong2 *)jt->slots->ptr;
+    L.cap = jt->cap;
+    L.shift = jt->shift;
+    L.dense = jt->dense ? (const uint32_t *)jt->dense->ptr : nullptr;
+    L.ustart = jt->ustart ? (const uint32_t *)jt->ustart->ptr : nullptr;
+    L.dense_min = jt->dense_min;
+    L.dense_span = jt->dense_span;
+    L.direct = jt->direct ? 1 : 0;
+
+    bool right_plain = true;
+    for (auto &c : right->cols) right_plain = right_plain && is_word_type(c.dtype) && !c.validity;
+    if (jt->dense_payload && right_plain) {
+        // PK–FK fast path: presence test + counts, scan, then one fused write of every output column
+        KeepMask km;
+        km.n = n;
+        km.ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+        int64_t nwords = (n + 63) / 64;
+        km.keep = dev_alloc(ctx, size_t(nwords) * 8 + 8);
+        BufRef counts = dev_alloc(ctx, size_t(km.ntiles + 1) * 4);
+        dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
+        if (km.ntiles) {
+            const size_t pbytes = size_t((jt->dense_span + 31) / 32) * 4;
+            dim3 pgrid(stream_grid(ctx, km.ntiles, 16, 1)), pblock(1024);
+            const uint32_t *pp = (const uint32_t *)jt->presence->ptr;
+            uint64_t *kp = (uint64_t *)km.keep->ptr;
+            uint32_t *cp = (uint32_t *)counts->ptr;
+            if (jt->dense_full)
+                launch(ctx, "join_probe_presence", probe_presence_kernel<0>, dim3(stream_grid(ctx, km.ntiles, 16, 2)), pblock, 0, rk.words(),
+                       n, km.ntiles, pp, jt->dense_min, jt->dense_span, kp, cp);
+            else if (pbytes <= 128 * 1024)
+                launch(ctx, "join_probe_presence", probe_presence_kernel<1>, pgrid, pblock, pbytes, rk.words(), n, km.ntiles, pp,
+                       jt->dense_min, jt->dense_span, kp, cp);
+            else
+                launch(ctx, "join_probe_presence", probe_presence_kernel<2>, dim3(stream_grid(ctx, km.ntiles, 16, 2)), pblock, 0, rk.words(),
+                       n, km.ntiles, pp, jt->dense_min, jt->dense_span, kp, cp);
+        }
+        km = finish_mask(ctx, km, counts);
+        auto out = std::make_unique<nqe_table>();
+        out->ctx = ctx;
+        out->rows = km.total;
+        FusedCols fc;
+        std::memset(&fc, 0, sizeof(fc));
+        for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
+            const DevColumn &c = jt->left_cols[ci];
+            out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
+            fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : (jt->dense_packed[ci] ? 3 : 2);
+            fc.base[fc.n] = int(ci) == jt->left_key ? 0 : jt->dense_base[ci];
+            fc.src[fc.n] = int(ci) == jt->left_key ? nullptr : (const uint64_t *)jt->dense_cols[ci]->ptr;
+            fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
+            fc.n++;
+        }
+        for (auto &c : right->cols) {
+            out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
+            fc.kind[fc.n] = 0;
+            fc.src[fc.n] = c.words();
+            fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
+            fc.n++;
+        }
+        if (km.ntiles && km.total > 0)
+            launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS>, grid, block, 0, rk.words(), n, km.ntiles, (const uint64_t *)km.keep->ptr,
+                   (const uint64_t *)km.tile_offsets->ptr, jt->dense_min, (const uint32_t *)nullptr, fc);
+        sync(ctx);
+        return out;
+    }
+    if (jt->direct) {
+        // unique build keys: every probe row yields 0/1 rows → stream compaction with a gather
+        KeepMask km;
+        km.n = n;
+        km.ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+        int64_t nwords = (n + 63) / 64;
+        km.keep = dev_alloc(ctx, size_t(nwords) * 8 + 8);
+        BufRef bidx = dev_alloc(ctx, size_t(n) * 4 + 8);
+        BufRef counts = dev_alloc(ctx, size_t(km.ntiles + 1) * 4);
+        if (km.ntiles)
+            launch(ctx, "join_probe_unique", probe_unique_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n,
+                   km.ntiles, L, (uint64_t *)km.keep->ptr, (uint32_t *)bidx->ptr, (uint32_t *)counts->ptr);
+        km = finish_mask(ctx, km, counts);
+        auto out = std::make_unique<nqe_table>();
+        out->ctx = ctx;
+        out->rows = km.total;
+        bool left_plain = jt->left_cols.size() + right->cols.size() <= size_t(MAX_JOIN_COLS);
+        for (auto &c : jt->left_cols) left_plain = left_plain && is_word_type(c.dtype) && !c.validity;
+        if (left_plain && right_plain) {
+            // every column is a plain 8-byte column: ONE pass writes all of them (probe columns streamed, the build key taken
+            // from the probe key, build payloads gathered by the recorded build row) instead of one compaction per column
+            FusedCols fc;
+            std::memset(&fc, 0, sizeof(fc));
+            for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
+                const DevColumn &c = jt->left_cols[ci];
+                out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
+                fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : 2;
+                fc.src[fc.n] = c.words();
+                fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
+                fc.n++;
+            }
+            for (auto &c : right->cols) {
+                out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
+                fc.kind[fc.n] = 0;
+                fc.src[fc.n] = c.words();
+                fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
+                fc.n++;
+            }
+            if (km.ntiles && km.total > 0)
+                launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS>, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,
+                       (const uint64_t *)km.keep->ptr, (const uint64_t *)km.tile_offsets->ptr, uint64_t(0), (const uint32_t *)bidx->ptr, fc);
+            sync(ctx);
+            return out;
+        }
+        DevColumn outer_pos;
+        for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
+            const DevColumn &c = jt->left_cols[ci];
+            if (int(ci) == jt->left_key && !c.validity && c.dtype != NQE_UTF8) {
+                // the build key of a matched row is bit-identical to the probe key: produce the column by the
+                // coalesced compaction of the probe keys instead of a random gather (validity comes from the
+                // LEFT column, which has none here)
+                DevColumn as_left = rk;
+                as_left.validity = nullptr;
+                as_left.null_count = 0;
+                out->cols.push_back(compact_column(ctx, as_left, km));
+            } else if (c.dtype == NQE_UTF8) {
+                // outer_pos (the reference's Int64 index array, hash_join.rs:230-231) = build rows of the matches,
+                // obtained by gathering a row-number column; then the Utf8 `take`
+                if (!outer_pos.values) {
+                    DevColumn rowid;
+                    rowid.dtype = NQE_INT64;
+                    rowid.length = jt->left_rows;
+                    rowid.values = iota_i64(ctx, 0, jt->left_rows);
+                    outer_pos = compact_gather_column(ctx, rowid, (const uint32_t *)bidx->ptr, km);
+                }
+                out->cols.push_back(take_utf8(ctx, c, (const int64_t *)outer_pos.words(), km.total, false));
+            } else {
+                out->cols.push_back(compact_gather_column(ctx, c, (const uint32_t *)bidx->ptr, km));
+            }
+        }
+        for (auto &c : right->cols) out->cols.push_back(compact_column(ctx, c, km));
+        sync(ctx); // bidx / mask are released on return
+        return out;
+    }
+
+    const int64_t ntiles = (n + JT_ROWS - 1) / JT_ROWS;
+    BufRef pmeta = dev_alloc(ctx, size_t(n) * 8 + 8);
+    BufRef counts = dev_alloc(ctx, size_t(ntiles + 1) * 4);
+    BufRef offs = dev_alloc(ctx, size_t(ntiles + 1) * 8);
+    int grid = int(std::max<int64_t>(1, std::min<int64_t>(ntiles, int64_t(ctx->num_cus) * 8)));
+    if (n)
+        launch(ctx, "join_probe_count", probe_count_kernel, dim3(grid), dim3(JT_BLOCK), 0, rk.words(), n, L, (uint64_t *)pmeta->ptr,
+               (uint32_t *)counts->ptr, ctx->d_flags);
+    exclusive_scan_u32_to_u64(ctx, (const uint32_t *)counts->ptr, (uint64_t *)offs->ptr, ntiles);
+    const int64_t M = int64_t(read_scalar(ctx, (const uint64_t *)offs->ptr + ntiles));
+    {
+        int f[NQE_NUM_FLAGS];
+        flags_read(ctx, f);
+        if (f[NQE_FLAG_TABLE_FULL]) fail(NQE_ERR_OUT_OF_MEMORY, "join output of one probe tile exceeds 2^32 rows");
+    }
+
+    auto out = std::make_unique<nqe_table>();
+    out->ctx = ctx;
+    out->rows = M;
+    JoinCols jc;
+    std::memset(&jc, 0, sizeof(jc));
+    // Utf8 payload: the kernel emits outer_pos / inner_pos (gathers of row-number columns), then Utf8 `take`
+    DevColumn left_rowid, right_rowid, outer_pos, inner_pos;
+    std::vector<const DevColumn *> srcs;
+    std::vector<int> out_slot; // output column index of each kernel column, -1 outer_pos, -2 inner_pos
+    // the build key of a match is bit-identical to the probe key: emit that column from the probe side (coalesced)
+    DevColumn key_from_probe;
+    const bool key_shortcut = jt->key_dtype != NQE_UTF8 && !jt->left_cols[size_t(jt->left_key)].validity;
+    for (size_t c = 0; c < jt->left_cols.size(); ++c)
+        if (jt->left_cols[c].dtype != NQE_UTF8 && !(key_shortcut && int(c) == jt->left_key)) { srcs.push_back(&jt->left_cols[c]); out_slot.push_back(int(c)); }
+    if (utf8_left) {
+        left_rowid.dtype = NQE_INT64; left_rowid.length = jt->left_rows; left_rowid.values = iota_i64(ctx, 0, jt->left_rows);
+        srcs.push_back(&left_rowid); out_slot.push_back(-1);
+    }
+    jc.n_left = int(srcs.size());
+    if (key_shortcut) {
+        key_from_probe = rk;
+        key_from_probe.validity = nullptr;
+        key_from_probe.null_count = 0;
+        srcs.push_back(&key_from_probe); out_slot.push_back(jt->left_key);
+    }
+    for (size_t c = 0; c < right->cols.size(); ++c)
+        if (right->cols[c].dtype != NQE_UTF8) { srcs.push_back(&right->cols[c]); out_slot.push_back(int(jt->left_cols.size() + c)); }
+    if (utf8_right) {
+        right_rowid.dtype = NQE_INT64; right_rowid.length = n; right_rowid.values = iota_i64(ctx, 0, n);
+        srcs.push_back(&right_rowid); out_slot.push_back(-2);
+    }
+    jc.n = int(srcs.size());
+    if (jc.n > MAX_JOIN_COLS) fail(NQE_ERR_NOT_SUPPORTED, "join output wider than 32 columns");
+    out->cols.resize(ncols);
+    std::vector<BufRef> bool_bytes(srcs.size()), valid_bytes(srcs.size());
+    std::vector<DevColumn> dsts(srcs.size());
+    for (size_t k = 0; k < srcs.size(); ++k) {
+        const DevColumn &src = *srcs[k];
+        const bool v = src.validity != nullptr;
+        DevColumn dst = src.dtype == NQE_BOOLEAN ? make_bool_column(ctx, M, v) : make_word_column(ctx, src.dtype, M, v);
+        jc.src[k] = src.values ? src.values->ptr : nullptr;
+        jc.src_valid[k] = src.valid();
+        jc.dtype[k] = src.dtype;
+        if (src.dtype == NQE_BOOLEAN) {
+            bool_bytes[k] = dev_alloc(ctx, size_t(M) + 8);
+            jc.dst_bool_bytes[k] = (uint8_t *)bool_bytes[k]->ptr;
+        } else {
+            jc.dst_words[k] = (uint64_t *)dst.values->ptr;
+        }
+        if (v) {
+            valid_bytes[k] = dev_alloc(ctx, size_t(M) + 8);
+            jc.dst_valid_bytes[k] = (uint8_t *)valid_bytes[k]->ptr;
+        }
+        dsts[k] = std::move(dst);
+    }
+    if (n && M)
+        launch(ctx, "join_probe_write", probe_write_kernel, dim3(grid), dim3(JT_BLOCK), 0, (const uint64_t *)pmeta->ptr, n,
+               (const uint64_t *)offs->ptr, (const uint32_t *)jt->perm->ptr, jt->direct ? 1 : 0, jc);
+    for (size_t k = 0; k < srcs.size(); ++k) {
+        if (bool_bytes[k]) pack_bytes_to_bits(ctx, (const uint8_t *)bool_bytes[k]->ptr, M, (uint64_t *)dsts[k].values->ptr);
+        if (valid_bytes[k]) pack_bytes_to_bits(ctx, (const uint8_t *)valid_bytes[k]->ptr, M, (uint64_t *)dsts[k].validity->ptr);
+        if (out_slot[k] >= 0) out->cols[size_t(out_slot[k])] = dsts[k];
+        else if (out_slot[k] == -1) outer_pos = dsts[k];
+        else inner_pos = dsts[k];
+    }
+    for (size_t c = 0; c < jt->left_cols.size(); ++c)
+        if (jt->left_cols[c].dtype == NQE_UTF8)
+            out->cols[c] = take_utf8(ctx, jt->left_cols[c], (const int64_t *)outer_pos.words(), M, false);
+    for (size_t c = 0; c < right->cols.size(); ++c)
+        if (right->cols[c].dtype == NQE_UTF8)
+            out->cols[jt->left_cols.size() + c] = take_utf8(ctx, right->cols[c], (const int64_t *)inner_pos.words(), M, false);
+    sync(ctx); // temporaries above are released on return; keep the stream drained for simplicity
+    return out;
+}
+
+} // namespace
+
+} // namespace nqe
+
+using namespace nqe;
+
+extern "C" {
+
+nqe_status nqe_hash_join_build(nqe_ctx *ctx, const nqe_table *left, int32_t left_key, nqe_join_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !left || !out) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    flags_reset(ctx);
+    *out = build_table(ctx, left, left_key).release();
+    NQE_API_END()
+}
+
+nqe_status nqe_hash_join_probe(nqe_ctx *ctx, const nqe_join_table *build, const nqe_table *right, int32_t right_key,
+                               nqe_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !build || !right || !out) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    flags_reset(ctx);
+    *out = probe_table(ctx, build, right, right_key).release();
+    NQE_API_END()
+}
+
+nqe_status nqe_join_table_release(nqe_join_table *jt) {
+    delete jt;
+    return NQE_OK;
+}
+
+nqe_status nqe_hash_join_execute(nqe_ctx *ctx, const nqe_table *left, const nqe_table *right, int32_t left_key,
+                                 int32_t right_key, nqe_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !left || !right || !out) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (left_key < 0 || right_key < 0) // empty `on` (hash_join.rs:125-129)
+        fail(NQE_ERR_PLAN, "Inner Join on Conditions can't not be empty");
+    flags_reset(ctx);
+    std::unique_ptr<nqe_join_table> jt = build_table(ctx, left, left_key);
+    *out = probe_table(ctx, jt.get(), right, right_key).release();
+    NQE_API_END()
+}
+
+} // extern "C"

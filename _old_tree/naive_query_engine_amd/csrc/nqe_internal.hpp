@@ -1,0 +1,302 @@
+// nqe_internal.hpp — host-side internals of libnqe_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/nqe.h"
+
+namespace nqe {
+
+struct Error {
+    int code;
+    std::string msg;
+};
+
+[[noreturn]] inline void fail(int code, const std::string &msg) { throw Error{code, msg}; }
+
+#define NQE_HIP_CHECK(expr)                                                                                  \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            ::nqe::fail(_e == hipErrorOutOfMemory ? NQE_ERR_OUT_OF_MEMORY : NQE_ERR_HIP,                     \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                                  \
+    } while (0)
+
+inline size_t bitmap_bytes(int64_t n) { return size_t((n + 7) / 8); }
+// bitmaps we allocate are padded to whole 64-bit words so kernels may store u64 words
+inline size_t bitmap_alloc_bytes(int64_t n) { return size_t((n + 63) / 64) * 8; }
+inline bool is_word_type(int dt) { return dt == NQE_INT64 || dt == NQE_UINT64 || dt == NQE_FLOAT64; }
+
+} // namespace nqe
+
+// Device error flag slots (ctx->d_flags[i])
+enum { NQE_FLAG_DIV_ZERO = 0, NQE_FLAG_OVERFLOW = 1, NQE_FLAG_TABLE_FULL = 2, NQE_FLAG_OOB = 3, NQE_FLAG_NEED_PARTITION = 4, NQE_FLAG_NEED_LEVEL2 = 5, NQE_FLAG_DENSE_OVERFLOW = 6,
+       NQE_FLAG_GROUP_COUNT = 7 /* not an error: the aggregate's group count rides along with the flag read-back */, NQE_NUM_FLAGS = 8 };
+
+struct nqe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    std::string last_error;
+
+    // caching device allocator: freed blocks are reused by later (stream-ordered) work
+    std::multimap<size_t, void *> pool;
+    size_t pool_bytes = 0;
+    size_t live_bytes = 0;
+
+    // per-kernel timing (bench.py roofline leg)
+    bool timing = false;
+    struct TimingRec {
+        std::string name;
+        hipEvent_t start, stop;
+    };
+    std::vector<TimingRec> timings;
+
+    int *d_flags = nullptr; // NQE_NUM_FLAGS ints on the device
+    int *h_flags = nullptr; // pinned host mirror
+};
+
+namespace nqe {
+
+// A device allocation (owned → returned to the ctx pool) or a borrowed device pointer.
+struct DevBuf {
+    nqe_ctx *ctx = nullptr;
+    void *ptr = nullptr;
+    size_t bytes = 0;    // usable size requested
+    size_t capacity = 0; // pooled block size
+    bool owned = false;
+    ~DevBuf();
+};
+using BufRef = std::shared_ptr<DevBuf>;
+
+BufRef dev_alloc(nqe_ctx *ctx, size_t bytes);
+BufRef dev_alloc_zero(nqe_ctx *ctx, size_t bytes);
+BufRef dev_borrow(nqe_ctx *ctx, const void *ptr, size_t bytes);
+// a sub-range of `parent` (keeps the parent alive)
+BufRef dev_view(const BufRef &parent, size_t offset, size_t bytes);
+void pool_trim(nqe_ctx *ctx);
+
+// One Arrow array resident in HBM.
+struct DevColumn {
+    int dtype = NQE_NULLTYPE;
+    int64_t length = 0;
+    int64_t null_count = 0; // -1 unknown; 0 ⇒ validity may still be present (all ones)
+    BufRef values;          // 8 B/row words, packed bits (Boolean), or int32 offsets (Utf8)
+    BufRef validity;        // packed bits or null
+    BufRef data;            // Utf8 bytes
+    int64_t data_length = 0;
+
+    const uint64_t *words() const { return values ? static_cast<const uint64_t *>(values->ptr) : nullptr; }
+    const uint8_t *bits() const { return values ? static_cast<const uint8_t *>(values->ptr) : nullptr; }
+    const uint8_t *valid() const { return validity ? static_cast<const uint8_t *>(validity->ptr) : nullptr; }
+};
+
+} // namespace nqe
+
+struct nqe_table {
+    nqe_ctx *ctx = nullptr;
+    std::vector<nqe::DevColumn> cols;
+    int64_t rows = 0;
+};
+
+namespace nqe {
+
+// ---- launch helpers ---------------------------------------------------------------------
+struct TimerScope {
+    nqe_ctx *ctx;
+    size_t idx = size_t(-1);
+    TimerScope(nqe_ctx *c, const char *name) : ctx(c) {
+        if (ctx->timing) {
+            nqe_ctx::TimingRec r;
+            r.name = name;
+            NQE_HIP_CHECK(hipEventCreate(&r.start));
+            NQE_HIP_CHECK(hipEventCreate(&r.stop));
+            NQE_HIP_CHECK(hipEventRecord(r.start, ctx->stream));
+            ctx->timings.push_back(r);
+            idx = ctx->timings.size() - 1;
+        }
+    }
+    ~TimerScope() {
+        if (idx != size_t(-1)) (void)hipEventRecord(ctx->timings[idx].stop, ctx->stream);
+    }
+};
+
+template <typename K, typename... Args>
+inline void launch(nqe_ctx *ctx, const char *name, K kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
+    TimerScope t(ctx, name);
+    hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, args...);
+    NQE_HIP_CHECK(hipGetLastError());
+}
+
+// grid for a streaming kernel: enough blocks to fill the chip, grid-stride the rest
+inline int stream_grid(nqe_ctx *ctx, int64_t work_items, int per_block, int blocks_per_cu = 8) {
+    int64_t need = (work_items + per_block - 1) / per_block;
+    int64_t cap = int64_t(ctx->num_cus) * blocks_per_cu;
+    if (need < 1) need = 1;
+    return int(need < cap ? need : cap);
+}
+
+void flags_reset(nqe_ctx *ctx);
+// synchronises the stream, returns flag values
+void flags_read(nqe_ctx *ctx, int out[NQE_NUM_FLAGS]);
+void throw_on_flags(nqe_ctx *ctx);
+
+inline void sync(nqe_ctx *ctx) { NQE_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }
+
+template <typename T> inline T read_scalar(nqe_ctx *ctx, const T *dptr) {
+    T v;
+    NQE_HIP_CHECK(hipMemcpyAsync(&v, dptr, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    sync(ctx);
+    return v;
+}
+
+// ---- column utilities (columns.hip) -----------------------------------------------------
+DevColumn make_word_column(nqe_ctx *ctx, int dtype, int64_t n, bool with_validity);
+DevColumn make_bool_column(nqe_ctx *ctx, int64_t n, bool with_validity);
+// out[j] = in[idx[j]] for every column (arrow take); idx are int64 row numbers on the device
+DevColumn take_column(nqe_ctx *ctx, const DevColumn &src, const int64_t *idx, int64_t m);
+// Utf8 gather; idx < 0 emits NULL when allow_null_idx (else out of bounds)
+DevColumn take_utf8(nqe_ctx *ctx, const DevColumn &src, const int64_t *idx, int64_t m, bool allow_null_idx);
+BufRef iota_i64(nqe_ctx *ctx, int64_t first, int64_t n);
+DevColumn slice_column(nqe_ctx *ctx, const DevColumn &src, int64_t off, int64_t len);
+DevColumn concat_columns(nqe_ctx *ctx, const std::vector<const DevColumn *> &parts);
+// exclusive prefix sum of n uint32 counts into uint64 offsets (offsets[n] = total); device arrays
+void exclusive_scan_u32_to_u64(nqe_ctx *ctx, const uint32_t *counts, uint64_t *offsets, int64_t n);
+void exclusive_scan_u32_inplace(nqe_ctx *ctx, uint32_t *data, int64_t n);
+// packs one byte per row (0/1) into an LSB-first bitmap
+void pack_bytes_to_bits(nqe_ctx *ctx, const uint8_t *bytes, int64_t n, uint64_t *bitmap_words);
+// stable LSD radix sort of (key, value) pairs by 64-bit key; keys_out/vals_out are device arrays of n
+void radix_sort_pairs_u64(nqe_ctx *ctx, const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
+                          uint32_t *vals_out, int64_t n, bool signed_order);
+
+// ---- Utf8 keys (strings.hip): exact string → representative-row encoding
+struct Utf8Dict {
+    BufRef slots;      // int64 representative build row per slot, -1 = empty
+    uint32_t cap = 0;
+    int shift = 0;
+    DevColumn build;   // the encoded (build) column: its strings back the table
+};
+// codes[i] = representative row of string i (Int64 column sharing the strings' validity)
+DevColumn utf8_encode_build(nqe_ctx *ctx, const DevColumn &col, Utf8Dict *dict);
+// codes[i] = representative BUILD row of the equal build string, or a negative value that matches nothing
+DevColumn utf8_encode_probe(nqe_ctx *ctx, const DevColumn &col, const Utf8Dict &dict);
+
+// ---- expressions (expr.hip) -------------------------------------------------------------
+struct OpAux {          // host-precomputed helpers for `x / lit`, `x % lit`
+    int32_t pow2_shift; // >= 0: |lit| is 2^shift
+    int32_t more;       // >= 0: |lit| is not a power of two: q = (((n - mulhi(magic,n)) >> 1) + mulhi(magic,n)) >> more
+    uint64_t abs_lit;
+    uint64_t magic;
+};
+
+// col [op lit]{0,2}: the expression shapes fused into the consumer kernels
+struct SimpleExpr {
+    int32_t col;       // index into the INPUT table
+    int32_t src_dtype; // dtype of the column
+    int32_t out_dtype;
+    int32_t nops;
+    int32_t op[2];
+    int32_t lit_left[2]; // 1: lit op v
+    int32_t op_dtype[2]; // operand dtype of step k
+    int32_t pad;
+    uint64_t lit[2];
+    OpAux aux[2];
+};
+
+// `x op lit` over an Int64/UInt64 column rewritten as  lo <= (x ^ flip) <= hi  (xor negate)
+struct FastPred {
+    int64_t lo, hi;
+    uint64_t flip;
+    int32_t negate;
+    // where the tested word of row r comes from: word column → src[r]; Boolean bitmap → (src[r >> 6] >> (r & 63)) & 1
+    int32_t row_shift; // 0 | 6
+    int32_t bit_mask;  // 0 | 63
+    int32_t pad;
+    uint64_t val_mask; // ~0 | 1
+    // Float64 operands: x ^= (x >> 63 arithmetic) & fmask with fmask = 0x7fff…f maps IEEE doubles to signed integers in
+    // the same order (negative values reversed); NaNs land beyond ±inf and are excluded by [lo, hi].  0 for integers.
+    uint64_t fmask;
+};
+// FastPred "bit r of a non-null Boolean bitmap is set"
+FastPred bitmap_fast_pred();
+// returns false when the SimpleExpr is not a single Int64/UInt64/Float64 compare against a literal
+bool make_fast_pred(const SimpleExpr &pe, FastPred *fp);
+
+struct ExprInfo {
+    int out_dtype = NQE_NULLTYPE;
+    bool simple = false;
+    SimpleExpr s{};
+    // true when evaluating it can raise a device error flag (a divide/modulus whose divisor is not a literal other than
+    // 0 and -1): only then does an operator need the flag read-back, which is a stream synchronisation
+    bool may_fault = false;
+};
+// type-checks (IntervalError / NotSupported exactly where the reference raises them) and
+// recognises the fusable shape
+ExprInfo analyze_expr(const nqe_table *in, const nqe_expr_node *nodes, int n);
+// general evaluator: one streaming kernel per binary node, literals kept scalar
+DevColumn evaluate_expr(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, int n);
+
+// ---- filter (selection.hip) ---------------------------------------------------------------
+struct KeepMask {
+    BufRef keep;          // bit i = row i is emitted (pred true OR pred NULL)
+    BufRef pvalid;        // predicate validity (null if predicate has no nulls)
+    BufRef tile_offsets;  // uint64 per 4096-row tile (exclusive), [ntiles] = total
+    int64_t n = 0;        // rows covered
+    int64_t ntiles = 0;
+    int64_t total = 0;    // emitted rows
+    mutable BufRef kept_idx; // int64 source row per emitted row (-1: NULL row from a NULL predicate); built on demand for Utf8
+};
+// source-row list of the emitted rows (cached in the mask)
+const int64_t *kept_rows(nqe_ctx *ctx, const KeepMask &km);
+KeepMask build_keep_mask(nqe_ctx *ctx, const DevColumn &pred, int64_t n_rows);
+// predicate given as a fused SimpleExpr over `in`
+KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &pred);
+DevColumn compact_column(nqe_ctx *ctx, const DevColumn &src, const KeepMask &km);
+// out row r (r-th kept row i) = src[gidx[i]]
+DevColumn compact_gather_column(nqe_ctx *ctx, const DevColumn &src, const uint32_t *gidx, const KeepMask &km);
+// scans the per-tile counts into km.tile_offsets and reads back km.total
+KeepMask finish_mask(nqe_ctx *ctx, KeepMask km, BufRef tile_counts);
+// Utf8 comparison; a null column pointer means that side is the literal (lit, lit_null)
+DevColumn utf8_compare(nqe_ctx *ctx, int op, const DevColumn *lcol, const std::string &llit, bool llit_null, const DevColumn *rcol,
+                       const std::string &rlit, bool rlit_null, int64_t n);
+DevColumn utf8_literal_column(nqe_ctx *ctx, const std::string &lit, bool lit_null, int64_t n);
+// general tree `nodes` over the rows of `km`, compacted in the same pass; false = does not fit the stack machine
+bool evaluate_expr_compacted(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, int n, const KeepMask &km, DevColumn *result);
+// evaluates `e` over `in` and compacts the result in the same pass
+DevColumn compact_simple_expr(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &e, const KeepMask &km);
+
+} // namespace nqe
+
+// wraps a C entry point: exceptions → status + ctx->last_error
+#define NQE_API_BEGIN(ctxptr)                                                                                \
+    nqe_ctx *_api_ctx = (ctxptr);                                                                            \
+    try {                                                                                                    \
+        if (_api_ctx) (void)hipSetDevice(_api_ctx->device);
+#define NQE_API_END()                                                                                        \
+    }                                                                                                        \
+    catch (const ::nqe::Error &e) {                                                                          \
+        if (_api_ctx) _api_ctx->last_error = e.msg;                                                          \
+        ::nqe::set_global_error(e.msg);                                                                      \
+        return (nqe_status)e.code;                                                                           \
+    }                                                                                                        \
+    catch (const std::bad_alloc &) {                                                                         \
+        if (_api_ctx) _api_ctx->last_error = "host out of memory";                                           \
+        return NQE_ERR_OUT_OF_MEMORY;                                                                        \
+    }                                                                                                        \
+    catch (const std::exception &e) {                                                                        \
+        if (_api_ctx) _api_ctx->last_error = e.what();                                                       \
+        return NQE_ERR_OTHERS;                                                                               \
+    }                                                                                                        \
+    return NQE_OK;
+
+namespace nqe {
+void set_global_error(const std::string &msg);
+}

@@ -1,0 +1,425 @@
+// selection.hip — SelectionPlan::execute (reference: src/physical_plan/selection.rs:58-107 and
+// the row-at-a-time `build_array_by_predicate!` :34-51) as stable stream compaction.
+//
+// Layout: the predicate becomes a KEEP bitmap (1 bit/row: pred true OR pred NULL — a NULL
+// predicate emits a NULL row, quirk Q4) and a per-tile popcount (tile = 4096 rows = 64 bitmap
+// words).  An exclusive scan of the tile counts gives each tile its output base; inside a tile a
+// wave turns the 64 word popcounts into word offsets with one wave scan, and each lane's rank
+// within its word is popc(word & lanemask_lt).  Output order is therefore exactly input order
+// (the reference's builder appends in row order).
+//
+// HBM traffic per payload column: 8 B/row read (coalesced, unconditional) + 8 B per kept row
+// written + 1/8 B/row of bitmap — i.e. the algorithmic minimum of SURVEY §8d C2.
+#include "device_utils.hpp"
+#include "nqe_internal.hpp"
+
+namespace nqe {
+
+namespace {
+
+constexpr int SEL_B = 8; // 8-byte loads per lane per step of the streaming selection kernels (two steps are unrolled together: 16 in
+                         // flight; an explicit 16 without the unroll measured slower for the compaction, faster for the mask kernel)
+
+__device__ __forceinline__ uint64_t load_bitmap_word(const uint8_t *bm, int64_t w, int64_t nbits) {
+    // reads word w of an LSB-first bitmap holding nbits bits; never reads past ceil(nbits/8) bytes
+    int64_t nbytes = (nbits + 7) >> 3;
+    int64_t b0 = w * 8;
+    if (b0 + 8 <= nbytes) return *reinterpret_cast<const uint64_t *>(bm + b0);
+    uint64_t v = 0;
+    for (int k = 0; k < 8; ++k)
+        if (b0 + k < nbytes) v |= uint64_t(bm[b0 + k]) << (8 * k);
+    return v;
+}
+
+// keep = (~pvalid | pbits) & in-range ; one wave per tile, one word per lane
+__global__ void __launch_bounds__(256) keep_from_pred_kernel(const uint8_t *pbits, const uint8_t *pvalid, int64_t pred_len,
+                                                             int64_t n, int64_t ntiles, uint64_t *keep,
+                                                             uint64_t *pvalid_out, uint32_t *tile_counts) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t nwords = (n + 63) / 64;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        int64_t w = tile * TILE_WORDS + lane_id();
+        uint64_t k = 0, pv = ~0ull;
+        if (w < nwords) {
+            uint64_t pb = load_bitmap_word(pbits, w, pred_len);
+            if (pvalid) pv = load_bitmap_word(pvalid, w, pred_len);
+            int64_t rem = n - w * 64;
+            uint64_t range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+            k = (~pv | pb) & range;
+            keep[w] = k;
+            if (pvalid_out) pvalid_out[w] = pv;
+        }
+        uint32_t c = __popcll(k), tot;
+        (void)wave_exclusive_scan(c, tot);
+        if (lane_id() == 0) tile_counts[tile] = tot;
+    }
+}
+
+// predicate = SimpleExpr over one streamed column; wave per tile, 64 rows per step.
+// RANGE: the predicate is an integer `col cmp lit` over a plain 8-byte column without validity →
+// branch-free range test, clamped unconditional loads, 8 loads in flight per wave.
+template <int RANGE> // 0: any SimpleExpr; 1: integer range test; 2: Float64 range test (order-mapped)
+__global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *values, const uint8_t *valid, SimpleExpr e, FastPred fp,
+                                                               int64_t n, int64_t ntiles, uint64_t *keep, uint64_t *pvalid_out,
+                                                               uint32_t *tile_counts, int *flags) {
+    const int waves_per_block = blockDim.x / 64;
+    const uint64_t *__restrict__ words = static_cast<const uint64_t *>(values);
+    const int64_t last = n - 1;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t row0 = tile * TILE_ROWS;
+        uint32_t total = 0;
+        if (RANGE) {
+#pragma unroll 2
+            for (int k0 = 0; k0 < TILE_WORDS; k0 += SEL_B) {
+                uint64_t v[SEL_B];
+#pragma unroll
+                for (int k = 0; k < SEL_B; ++k) {
+                    int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                    v[k] = __builtin_nontemporal_load(&words[row < last ? row : last]);
+                }
+#pragma unroll
+                for (int k = 0; k < SEL_B; ++k) {
+                    int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                    uint64_t kw = __ballot(row < n && range_pass(fp, RANGE == 2 ? f64_order_map(fp, v[k]) : v[k]));
+                    if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
+                    total += __popcll(kw);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < TILE_WORDS; ++k) {
+                int64_t row = row0 + int64_t(k) * 64 + lane_id();
+                bool in = row < n;
+                uint64_t v = in ? load_word(values, e.src_dtype, row) : 0;
+                bool ok = in && (valid ? get_bit(valid, row) : true);
+                bool r = eval_simple(e, v, ok, flags) != 0;
+                uint64_t kw = __ballot(in && (!ok || r));
+                uint64_t vw = __ballot(ok);
+                if (row0 + int64_t(k) * 64 < n && lane_id() == 0) {
+                    keep[tile * TILE_WORDS + k] = kw;
+                    if (pvalid_out) pvalid_out[tile * TILE_WORDS + k] = vw;
+                }
+                total += __popcll(kw);
+            }
+        }
+        if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
+// Stable compaction of one column (or of a SimpleExpr evaluated on it) by the keep bitmap.
+// Word k of the tile lives in lane k; it is broadcast through the scalar unit (readlane).
+// PLAINW: 8-byte source without validity and a predicate without nulls → values only.
+// GATHER: the source row of output row is gidx[row] (join: build row of the matching probe row).
+template <bool EXPR, bool PLAINW, bool GATHER>
+__global__ void __launch_bounds__(256) compact_kernel(const void *src_values, int src_dtype, const uint8_t *src_valid,
+                                                      const uint32_t *gidx, SimpleExpr e, const uint64_t *keep, const uint64_t *pvalid,
+                                                      const uint64_t *tile_offsets, int64_t n, int64_t ntiles,
+                                                      uint64_t *out_words, uint8_t *out_bool_bytes,
+                                                      uint8_t *out_valid_bytes, int *flags) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t nwords = (n + 63) / 64;
+    const int64_t last = n - 1;
+    const uint64_t *__restrict__ words = static_cast<const uint64_t *>(src_values);
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        int64_t w = tile * TILE_WORDS + lane_id();
+        uint64_t my_word = w < nwords ? keep[w] : 0;
+        uint64_t my_pv = (!PLAINW && pvalid && w < nwords) ? pvalid[w] : ~0ull;
+        uint32_t tot;
+        uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+        const uint64_t base = tile_offsets[tile];
+        if (PLAINW) {
+#pragma unroll 2
+            for (int k0 = 0; k0 < TILE_WORDS; k0 += SEL_B) {
+                uint64_t v[SEL_B];
+                if (GATHER) {
+                    uint32_t gi[SEL_B];
+#pragma unroll
+                    for (int k = 0; k < SEL_B; ++k) {
+                        int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                        gi[k] = gidx[row < last ? row : last];
+                    }
+#pragma unroll
+                    for (int k = 0; k < SEL_B; ++k) {
+                        bool kept = (bcast64(my_word, k0 + k) >> lane_id()) & 1;
+                        v[k] = words[kept ? gi[k] : 0u]; // gather (build side is cache resident)
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < SEL_B; ++k) {
+                        int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                        v[k] = __builtin_nontemporal_load(&words[row < last ? row : last]); // unconditional, coalesced, streamed once
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < SEL_B; ++k) {
+                    uint64_t word = bcast64(my_word, k0 + k);
+                    uint32_t off = bcast32(my_off, k0 + k);
+                    if ((word >> lane_id()) & 1) {
+                        uint64_t x = EXPR ? eval_simple(e, v[k], true, flags) : v[k];
+                        __builtin_nontemporal_store(x, &out_words[base + off + __popcll(word & lanemask_lt())]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < TILE_WORDS; ++k) {
+                uint64_t word = bcast64(my_word, k);
+                uint64_t pvw = bcast64(my_pv, k);
+                uint32_t off = bcast32(my_off, k);
+                int64_t row = (tile * TILE_WORDS + k) * 64 + lane_id();
+                bool in = row < n;
+                bool kept = (word >> lane_id()) & 1;
+                int64_t srow = row;
+                if (GATHER) srow = (in && kept) ? int64_t(gidx[row]) : 0;
+                uint64_t v = (in && (!GATHER || kept)) ? load_word(src_values, src_dtype, srow) : 0;
+                if (kept) {
+                    bool ok = ((pvw >> lane_id()) & 1) && (src_valid ? get_bit(src_valid, srow) : true);
+                    if (EXPR) v = eval_simple(e, v, ok, flags);
+                    uint64_t pos = base + off + __popcll(word & lanemask_lt());
+                    if (out_words) out_words[pos] = ok ? v : 0;
+                    if (out_bool_bytes) out_bool_bytes[pos] = (ok && v) ? 1 : 0;
+                    if (out_valid_bytes) out_valid_bytes[pos] = ok ? 1 : 0;
+                }
+            }
+        }
+    }
+}
+
+// emitted-row list: out[pos] = source row (or -1 when the predicate was NULL there → NULL row, quirk Q4)
+__global__ void __launch_bounds__(256) kept_rows_kernel(const uint64_t *keep, const uint64_t *pvalid, const uint64_t *tile_offsets, int64_t n,
+                                                        int64_t ntiles, int64_t *out) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t nwords = (n + 63) / 64;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        int64_t w = tile * TILE_WORDS + lane_id();
+        uint64_t my_word = w < nwords ? keep[w] : 0;
+        uint64_t my_pv = (pvalid && w < nwords) ? pvalid[w] : ~0ull;
+        uint32_t tot;
+        uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+        const uint64_t base = tile_offsets[tile];
+        for (int k = 0; k < TILE_WORDS; ++k) {
+            uint64_t word = bcast64(my_word, k);
+            uint64_t pvw = bcast64(my_pv, k);
+            uint32_t off = bcast32(my_off, k);
+            if ((word >> lane_id()) & 1) {
+                int64_t row = (tile * TILE_WORDS + k) * 64 + lane_id();
+                out[base + off + __popcll(word & lanemask_lt())] = ((pvw >> lane_id()) & 1) ? row : -1;
+            }
+        }
+    }
+}
+
+} // namespace
+
+KeepMask finish_mask(nqe_ctx *ctx, KeepMask km, BufRef tile_counts) {
+    km.tile_offsets = dev_alloc(ctx, size_t(km.ntiles + 1) * 8);
+    exclusive_scan_u32_to_u64(ctx, (const uint32_t *)tile_counts->ptr, (uint64_t *)km.tile_offsets->ptr, km.ntiles);
+    km.total = int64_t(read_scalar(ctx, (const uint64_t *)km.tile_offsets->ptr + km.ntiles));
+    return km;
+}
+
+KeepMask build_keep_mask(nqe_ctx *ctx, const DevColumn &pred, int64_t n_rows) {
+    KeepMask km;
+    km.n = std::min<int64_t>(pred.length, n_rows); // iterator zip truncates (quirk Q3)
+    km.ntiles = (km.n + TILE_ROWS - 1) / TILE_ROWS;
+    int64_t nwords = (km.n + 63) / 64;
+    km.keep = dev_alloc(ctx, size_t(nwords) * 8 + 8);
+    if (pred.validity) km.pvalid = dev_alloc(ctx, size_t(nwords) * 8 + 8);
+    BufRef counts = dev_alloc(ctx, size_t(km.ntiles + 1) * 4);
+    if (km.ntiles)
+        launch(ctx, "keep_from_pred", keep_from_pred_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, pred.bits(),
+               pred.valid(), pred.length, km.n, km.ntiles, (uint64_t *)km.keep->ptr,
+               km.pvalid ? (uint64_t *)km.pvalid->ptr : nullptr, (uint32_t *)counts->ptr);
+    return finish_mask(ctx, km, counts);
+}
+
+KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &pred) {
+    const DevColumn &c = in->cols[size_t(pred.col)];
+    KeepMask km;
+    km.n = in->rows;
+    km.ntiles = (km.n + TILE_ROWS - 1) / TILE_ROWS;
+    int64_t nwords = (km.n + 63) / 64;
+    km.keep = dev_alloc(ctx, size_t(nwords) * 8 + 8);
+    if (c.validity) km.pvalid = dev_alloc(ctx, size_t(nwords) * 8 + 8);
+    BufRef counts = dev_alloc(ctx, size_t(km.ntiles + 1) * 4);
+    FastPred fp{};
+    const bool range = is_word_type(c.dtype) && !c.validity && make_fast_pred(pred, &fp);
+    if (km.ntiles) {
+        dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
+        if (range && fp.fmask)
+            launch(ctx, "keep_from_simple", keep_from_simple_kernel<2>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred, fp,
+                   km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint64_t *)nullptr, (uint32_t *)counts->ptr, ctx->d_flags);
+        else if (range)
+            launch(ctx, "keep_from_simple", keep_from_simple_kernel<1>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred, fp,
+                   km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint64_t *)nullptr, (uint32_t *)counts->ptr, ctx->d_flags);
+        else
+            launch(ctx, "keep_from_simple", keep_from_simple_kernel<0>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred,
+                   fp, km.n, km.ntiles, (uint64_t *)km.keep->ptr, km.pvalid ? (uint64_t *)km.pvalid->ptr : nullptr,
+                   (uint32_t *)counts->ptr, ctx->d_flags);
+    }
+    return finish_mask(ctx, km, counts);
+}
+
+const int64_t *kept_rows(nqe_ctx *ctx, const KeepMask &km) {
+    if (!km.kept_idx) {
+        km.kept_idx = dev_alloc(ctx, size_t(km.total) * 8 + 8);
+        if (km.ntiles && km.total > 0)
+            launch(ctx, "kept_rows", kept_rows_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, (const uint64_t *)km.keep->ptr,
+                   km.pvalid ? (const uint64_t *)km.pvalid->ptr : nullptr, (const uint64_t *)km.tile_offsets->ptr, km.n, km.ntiles,
+                   (int64_t *)km.kept_idx->ptr);
+    }
+    return (const int64_t *)km.kept_idx->ptr;
+}
+
+static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExpr *e, int out_dtype, const KeepMask &km,
+                             const uint32_t *gidx = nullptr) {
+    if (src.dtype == NQE_UTF8 && !e && !gidx) // StringBuilder path of selection.rs:82-97: gather by the emitted-row list
+        return take_utf8(ctx, src, kept_rows(ctx, km), km.total, km.pvalid != nullptr);
+    if (!(is_word_type(src.dtype) || src.dtype == NQE_BOOLEAN))
+        fail(NQE_ERR_NOT_SUPPORTED, "unimplemented!() column type in selection (selection.rs:98)");
+    const int64_t m = km.total;
+    const bool need_valid = src.validity != nullptr || km.pvalid != nullptr;
+    const bool bool_out = out_dtype == NQE_BOOLEAN;
+    DevColumn out = bool_out ? make_bool_column(ctx, m, need_valid) : make_word_column(ctx, out_dtype, m, need_valid);
+    BufRef bool_bytes, valid_bytes;
+    if (bool_out) bool_bytes = dev_alloc(ctx, size_t(m) + 8);
+    if (need_valid) valid_bytes = dev_alloc(ctx, size_t(m) + 8);
+    SimpleExpr dummy;
+    std::memset(&dummy, 0, sizeof(dummy));
+    if (km.ntiles && km.total > 0) { // nothing kept: nothing to read or write (and a gather source may be empty)
+        dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
+        const void *sv = (const void *)src.values->ptr;
+        const uint64_t *kp = (const uint64_t *)km.keep->ptr;
+        const uint64_t *pv = km.pvalid ? (const uint64_t *)km.pvalid->ptr : nullptr;
+        const uint64_t *to = (const uint64_t *)km.tile_offsets->ptr;
+        uint64_t *ow = bool_out ? nullptr : (uint64_t *)out.values->ptr;
+        uint8_t *ob = bool_out ? (uint8_t *)bool_bytes->ptr : nullptr;
+        uint8_t *ov = need_valid ? (uint8_t *)valid_bytes->ptr : nullptr;
+        const bool plainw = is_word_type(src.dtype) && !need_valid && !bool_out;
+        const SimpleExpr &ex = e ? *e : dummy;
+#define NQE_COMPACT(NAME, E, P, G)                                                                                     \
+    launch(ctx, NAME, compact_kernel<E, P, G>, grid, block, 0, sv, src.dtype, src.valid(), gidx, ex, kp, pv, to, km.n,  \
+           km.ntiles, ow, ob, ov, ctx->d_flags)
+        if (gidx) {
+            if (plainw) NQE_COMPACT("compact_gather", false, true, true);
+            else NQE_COMPACT("compact_gather", false, false, true);
+        } else if (e && plainw) NQE_COMPACT("compact_expr", true, true, false);
+        else if (e) NQE_COMPACT("compact_expr", true, false, false);
+        else if (plainw) NQE_COMPACT("compact_column", false, true, false);
+        else NQE_COMPACT("compact_column", false, false, false);
+#undef NQE_COMPACT
+    }
+    if (bool_out) pack_bytes_to_bits(ctx, (const uint8_t *)bool_bytes->ptr, m, (uint64_t *)out.values->ptr);
+    if (need_valid) pack_bytes_to_bits(ctx, (const uint8_t *)valid_bytes->ptr, m, (uint64_t *)out.validity->ptr);
+    return out;
+}
+
+DevColumn compact_column(nqe_ctx *ctx, const DevColumn &src, const KeepMask &km) {
+    return run_compact(ctx, src, nullptr, src.dtype, km);
+}
+
+DevColumn compact_gather_column(nqe_ctx *ctx, const DevColumn &src, const uint32_t *gidx, const KeepMask &km) {
+    return run_compact(ctx, src, nullptr, src.dtype, km, gidx);
+}
+
+DevColumn compact_simple_expr(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &e, const KeepMask &km) {
+    return run_compact(ctx, in->cols[size_t(e.col)], e.nops ? &e : nullptr, e.out_dtype, km);
+}
+
+static KeepMask mask_for_predicate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes) {
+    ExprInfo info = analyze_expr(in, pred, pred_nodes);
+    if (info.out_dtype != NQE_BOOLEAN)
+        fail(NQE_ERR_NOT_SUPPORTED, "predicate is not a BooleanArray (selection.rs:61 unwrap panics)");
+    if (info.simple) return build_keep_mask_simple(ctx, in, info.s);
+    DevColumn p = evaluate_expr(ctx, in, pred, pred_nodes);
+    return build_keep_mask(ctx, p, in->rows);
+}
+
+} // namespace nqe
+
+using namespace nqe;
+
+extern "C" {
+
+nqe_status nqe_filter(nqe_ctx *ctx, const nqe_table *in, const nqe_table *pred_table, int32_t pred_column,
+                      nqe_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !in || !pred_table || !out || pred_column < 0 || size_t(pred_column) >= pred_table->cols.size())
+        fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    const DevColumn &p = pred_table->cols[size_t(pred_column)];
+    if (p.dtype != NQE_BOOLEAN) fail(NQE_ERR_NOT_SUPPORTED, "predicate is not a BooleanArray (selection.rs:61 unwrap panics)");
+    flags_reset(ctx);
+    KeepMask km = build_keep_mask(ctx, p, in->rows);
+    auto t = std::make_unique<nqe_table>();
+    t->ctx = ctx;
+    t->rows = km.total;
+    for (auto &c : in->cols) t->cols.push_back(compact_column(ctx, c, km));
+    throw_on_flags(ctx);
+    *out = t.release();
+    NQE_API_END()
+}
+
+nqe_status nqe_selection_execute(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int32_t pred_nodes,
+                                 nqe_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !in || !out) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    // the error flags are reset and read back (a stream synchronisation) only when the predicate can raise one
+    const bool fault = analyze_expr(in, pred, pred_nodes).may_fault;
+    if (fault) flags_reset(ctx);
+    KeepMask km = mask_for_predicate(ctx, in, pred, pred_nodes);
+    auto t = std::make_unique<nqe_table>();
+    t->ctx = ctx;
+    t->rows = km.total;
+    for (auto &c : in->cols) t->cols.push_back(compact_column(ctx, c, km));
+    if (fault) throw_on_flags(ctx);
+    *out = t.release();
+    NQE_API_END()
+}
+
+nqe_status nqe_selection_projection_execute(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred,
+                                            int32_t pred_nodes, const nqe_expr_node *nodes,
+                                            const int32_t *expr_offsets, int32_t num_exprs, nqe_table **out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !in || !out || num_exprs < 0 || (num_exprs > 0 && (!nodes || !expr_offsets)))
+        fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    // type errors of the projection surface before any work, as they would at evaluate()
+    std::vector<ExprInfo> infos;
+    for (int e = 0; e < num_exprs; ++e) infos.push_back(analyze_expr(in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e]));
+    // the error flags are reset and read back (a stream synchronisation) only when some expression can raise one
+    bool fault = analyze_expr(in, pred, pred_nodes).may_fault;
+    for (auto &inf : infos) fault = fault || inf.may_fault;
+    if (fault) flags_reset(ctx);
+    KeepMask km = mask_for_predicate(ctx, in, pred, pred_nodes);
+    auto t = std::make_unique<nqe_table>();
+    t->ctx = ctx;
+    t->rows = km.total;
+    // per expression: fused single-column shape → compact_expr; any tree that fits the stack machine → evaluated and
+    // compacted in one pass over the columns it references; otherwise compact the inputs once, then evaluate on the
+    // compacted batch.  In every case rows the filter dropped can never raise DivideByZero, as in the reference.
+    std::unique_ptr<nqe_table> sel;
+    for (int e = 0; e < num_exprs; ++e) {
+        const nqe_expr_node *en = nodes + expr_offsets[e];
+        const int nn = expr_offsets[e + 1] - expr_offsets[e];
+        DevColumn c;
+        if (infos[size_t(e)].simple) c = compact_simple_expr(ctx, in, infos[size_t(e)].s, km);
+        else if (!evaluate_expr_compacted(ctx, in, en, nn, km, &c)) {
+            if (!sel) {
+                sel = std::make_unique<nqe_table>();
+                sel->ctx = ctx;
+                sel->rows = km.total;
+                for (auto &ic : in->cols) sel->cols.push_back(compact_column(ctx, ic, km));
+            }
+            c = evaluate_expr(ctx, sel.get(), en, nn);
+        }
+        t->cols.push_back(std::move(c));
+    }
+    if (fault) throw_on_flags(ctx);
+    *out = t.release();
+    NQE_API_END()
+}
+
+} // extern "C"

@@ -1,0 +1,241 @@
+// sort.hip — device sorting/scan primitives used by the join build (stable order of duplicate
+// build keys = ascending build row, hash_join.rs:66-76) and by the aggregate output ordering.
+//
+//   radix_sort_pairs_u64: stable LSD radix sort of (u64 key, u32 payload), 8-bit digits; digit
+//   passes whose histogram is a single bucket are skipped (keys < 2^24 need 3 passes).  Small
+//   inputs (≤ 4096) use one single-block bitonic sort on the composite (key, payload) order,
+//   which equals the stable order when payloads are the original positions.
+#include "device_utils.hpp"
+#include "nqe_internal.hpp"
+
+namespace nqe {
+
+namespace {
+
+constexpr int SORT_ITEMS = 64;                 // keys per lane per wave-block
+constexpr int SORT_CHUNK = 64 * SORT_ITEMS;    // 4096 keys per wave-block
+constexpr int SCAN_CHUNK = 4096;               // entries per scan block (1024 threads x 4)
+
+__device__ __forceinline__ uint64_t flip_key(uint64_t k, bool signed_order) { return signed_order ? k ^ 0x8000000000000000ull : k; }
+
+// ---- all eight digit histograms in one pass
+__global__ void __launch_bounds__(256) radix_hist_kernel(const uint64_t *keys, int64_t n, bool signed_order, uint32_t *ghist) {
+    __shared__ uint32_t h[8 * 256];
+    for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t k = flip_key(keys[i], signed_order);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) atomicAdd(&h[d * 256 + int((k >> (8 * d)) & 255)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x)
+        if (h[i]) atomicAdd(&ghist[i], h[i]);
+}
+
+// ---- per wave-block digit counts, digit-major layout: counts[digit * nblocks + block]
+__global__ void __launch_bounds__(64) radix_count_kernel(const uint64_t *keys, int64_t n, int shift, bool signed_order,
+                                                         uint32_t *counts, int64_t nblocks) {
+    __shared__ uint32_t h[256];
+    for (int i = threadIdx.x; i < 256; i += 64) h[i] = 0;
+    __syncthreads();
+    int64_t base = int64_t(blockIdx.x) * SORT_CHUNK;
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        int64_t i = base + int64_t(it) * 64 + threadIdx.x;
+        if (i < n) atomicAdd(&h[int((flip_key(keys[i], signed_order) >> shift) & 255)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += 64) counts[int64_t(i) * nblocks + blockIdx.x] = h[i];
+}
+
+// ---- stable scatter: one wave per chunk, keys visited in chunk order
+__global__ void __launch_bounds__(64) radix_scatter_kernel(const uint64_t *keys_in, const uint32_t *vals_in, int64_t n,
+                                                           int shift, bool signed_order, const uint32_t *offsets,
+                                                           int64_t nblocks, uint64_t *keys_out, uint32_t *vals_out) {
+    __shared__ uint32_t base_of[256];
+    for (int i = threadIdx.x; i < 256; i += 64) base_of[i] = offsets[int64_t(i) * nblocks + blockIdx.x];
+    __syncthreads();
+    int64_t base = int64_t(blockIdx.x) * SORT_CHUNK;
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        int64_t i = base + int64_t(it) * 64 + threadIdx.x;
+        bool in = i < n;
+        uint64_t k = in ? keys_in[i] : 0;
+        uint32_t v = in ? vals_in[i] : 0;
+        int digit = int((flip_key(k, signed_order) >> shift) & 255);
+        // lanes with the same digit (wave multi-split by 8 ballots)
+        uint64_t peers = __ballot(in);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            uint64_t m = __ballot((digit >> b) & 1);
+            peers &= ((digit >> b) & 1) ? m : ~m;
+        }
+        uint32_t rank = __popcll(peers & lanemask_lt());
+        uint32_t cnt = __popcll(peers);
+        uint32_t start = 0;
+        if (in && rank == 0) { // leader of its digit group
+            start = base_of[digit];
+            base_of[digit] = start + cnt;
+        }
+        int leader = in ? __ffsll((long long)peers) - 1 : 0;
+        start = __shfl(start, leader, 64);
+        if (in) {
+            keys_out[start + rank] = k;
+            vals_out[start + rank] = v;
+        }
+        __syncthreads(); // base_of updates visible to the next iteration
+    }
+}
+
+// ---- multi-block exclusive scan, recursive on the chunk sums.  out may alias in when the types match.
+// Writes entries [0, n_out): entries at or beyond n_in read as 0 (so n_out = n_in + 1 yields the total).
+template <typename Tin, typename Tout>
+__global__ void __launch_bounds__(1024) scan_chunk_kernel(const Tin *in, int64_t n_in, Tout *out, int64_t n_out, Tout *chunk_sums) {
+    __shared__ Tout wave_tot[16];
+    int64_t base = int64_t(blockIdx.x) * SCAN_CHUNK + int64_t(threadIdx.x) * 4;
+    Tout v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = base + k < n_in ? Tout(in[base + k]) : Tout(0);
+        s += v[k];
+    }
+    // wave inclusive scan of s
+    Tout x = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Tout y = __shfl_up(x, d, 64);
+        if (lane_id() >= d) x += y;
+    }
+    int wv = threadIdx.x / 64;
+    if (lane_id() == 63) wave_tot[wv] = x;
+    __syncthreads();
+    Tout pre = 0, all = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wv) pre += wave_tot[w];
+        all += wave_tot[w];
+    }
+    Tout run = pre + (x - s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n_out) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = all;
+}
+template <typename T> __global__ void __launch_bounds__(1024) scan_add_kernel(T *data, int64_t n, const T *chunk_offsets) {
+    int64_t base = int64_t(blockIdx.x) * SCAN_CHUNK + int64_t(threadIdx.x) * 4;
+    T o = chunk_offsets[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k < n) data[base + k] += o;
+}
+
+template <typename Tin, typename Tout> void scan_impl(nqe_ctx *ctx, const Tin *in, int64_t n_in, Tout *out, int64_t n_out) {
+    if (n_out <= 0) return;
+    int64_t nchunks = (n_out + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    BufRef sums = dev_alloc(ctx, size_t(nchunks) * sizeof(Tout));
+    launch(ctx, "scan_chunk", scan_chunk_kernel<Tin, Tout>, dim3((unsigned)nchunks), dim3(1024), 0, in, n_in, out, n_out,
+           (Tout *)sums->ptr);
+    if (nchunks > 1) {
+        scan_impl<Tout, Tout>(ctx, (const Tout *)sums->ptr, nchunks, (Tout *)sums->ptr, nchunks);
+        launch(ctx, "scan_add", scan_add_kernel<Tout>, dim3((unsigned)nchunks), dim3(1024), 0, out, n_out, (const Tout *)sums->ptr);
+    }
+}
+
+// ---- single-block bitonic sort of up to 4096 (key, payload) pairs, composite order
+__global__ void __launch_bounds__(1024) bitonic_small_kernel(const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
+                                                             uint32_t *vals_out, int n, int np2, bool signed_order) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *k = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *v = reinterpret_cast<uint32_t *>(smem + size_t(np2) * 8);
+    for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+        k[i] = i < n ? flip_key(keys_in[i], signed_order) : ~0ull;
+        v[i] = i < n ? vals_in[i] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < np2 / 2; t += blockDim.x) {
+                int lo = 2 * t - (t & (stride - 1));
+                int hi = lo + stride;
+                bool up = (lo & size) == 0;
+                uint64_t ka = k[lo], kb = k[hi];
+                uint32_t va = v[lo], vb = v[hi];
+                bool gt = ka > kb || (ka == kb && va > vb);
+                if (gt == up) {
+                    k[lo] = kb; k[hi] = ka;
+                    v[lo] = vb; v[hi] = va;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        keys_out[i] = flip_key(k[i], signed_order);
+        vals_out[i] = v[i];
+    }
+}
+
+} // namespace
+
+void exclusive_scan_u32_inplace(nqe_ctx *ctx, uint32_t *data, int64_t n) { scan_impl<uint32_t, uint32_t>(ctx, data, n, data, n); }
+
+void exclusive_scan_u32_to_u64(nqe_ctx *ctx, const uint32_t *counts, uint64_t *offsets, int64_t n) {
+    scan_impl<uint32_t, uint64_t>(ctx, counts, n, offsets, n + 1);
+}
+
+void radix_sort_pairs_u64(nqe_ctx *ctx, const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
+                          uint32_t *vals_out, int64_t n, bool signed_order) {
+    if (n <= 0) return;
+    if (n <= 4096) {
+        int np2 = 2;
+        while (np2 < n) np2 <<= 1;
+        launch(ctx, "bitonic_small", bitonic_small_kernel, dim3(1), dim3(1024), size_t(np2) * 12, keys_in, vals_in, keys_out,
+               vals_out, int(n), np2, signed_order);
+        return;
+    }
+    if (n >= (int64_t(1) << 32)) fail(NQE_ERR_NOT_SUPPORTED, "sort of more than 2^32 rows is not supported");
+    BufRef ghist = dev_alloc_zero(ctx, 8 * 256 * 4);
+    launch(ctx, "radix_hist", radix_hist_kernel, dim3(stream_grid(ctx, n, 256, 4)), dim3(256), 0, keys_in, n, signed_order,
+           (uint32_t *)ghist->ptr);
+    std::vector<uint32_t> h(8 * 256);
+    NQE_HIP_CHECK(hipMemcpyAsync(h.data(), ghist->ptr, 8 * 256 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    sync(ctx);
+    std::vector<int> passes;
+    for (int d = 0; d < 8; ++d) {
+        bool trivial = false;
+        for (int b = 0; b < 256; ++b)
+            if (h[size_t(d * 256 + b)] == uint32_t(n)) trivial = true;
+        if (!trivial) passes.push_back(d);
+    }
+    const int64_t nblocks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
+    BufRef counts = dev_alloc(ctx, size_t(nblocks) * 256 * 4);
+    BufRef tmp_k, tmp_v;
+    if (passes.size() > 1 || passes.empty()) {
+        tmp_k = dev_alloc(ctx, size_t(n) * 8);
+        tmp_v = dev_alloc(ctx, size_t(n) * 4);
+    }
+    if (passes.empty()) { // all keys equal: already sorted
+        NQE_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, size_t(n) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        NQE_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, size_t(n) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return;
+    }
+    // ping-pong so that the LAST pass writes keys_out/vals_out
+    const uint64_t *src_k = keys_in;
+    const uint32_t *src_v = vals_in;
+    for (size_t p = 0; p < passes.size(); ++p) {
+        bool to_out = ((passes.size() - 1 - p) % 2) == 0;
+        uint64_t *dst_k = to_out ? keys_out : (uint64_t *)tmp_k->ptr;
+        uint32_t *dst_v = to_out ? vals_out : (uint32_t *)tmp_v->ptr;
+        int shift = passes[p] * 8;
+        launch(ctx, "radix_count", radix_count_kernel, dim3((unsigned)nblocks), dim3(64), 0, src_k, n, shift, signed_order,
+               (uint32_t *)counts->ptr, nblocks);
+        exclusive_scan_u32_inplace(ctx, (uint32_t *)counts->ptr, nblocks * 256);
+        launch(ctx, "radix_scatter", radix_scatter_kernel, dim3((unsigned)nblocks), dim3(64), 0, src_k, src_v, n, shift,
+               signed_order, (const uint32_t *)counts->ptr, nblocks, dst_k, dst_v);
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+}
+
+} // namespace nqe

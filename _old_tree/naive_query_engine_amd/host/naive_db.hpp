@@ -1,0 +1,638 @@
+// naive_db.hpp — C++ host mirror of the reference's physical-plan surface over the C ABI (include/nqe.h).
+//
+// The reference is a Rust crate (naive-db); no Rust toolchain exists in this image, so the host side above
+// the C ABI is written in C++ (and, for the pytest suites, in Python: naive_query_engine_amd/physical_plan.py).
+// Names, constructor arguments, schema()/execute()/children() and error variants follow the reference so
+// that plans read like its tests:
+//
+//   auto scan = ScanPlan::create(MemTable::try_create(schema, {batch}), std::nullopt);
+//   auto add  = PhysicalBinaryExpr::create(ColumnExpr::try_create("id", std::nullopt), Operator::Plus,
+//                                          PhysicalLiteralExpr::create(ScalarValue::Int64(1)));
+//   auto sel  = SelectionPlan::create(scan, PhysicalBinaryExpr::create(add, Operator::Gt,
+//                                          PhysicalLiteralExpr::create(ScalarValue::Int64(5))));
+//   std::vector<RecordBatch> out = sel->execute();        // selection.rs:126-178
+//
+// Nothing here computes: expressions are flattened to the post-order encoding and every execute() calls
+// libnqe_hip.so.  `Result<T>` of the reference is a thrown `ErrorCode` here.
+#pragma once
+
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <memory>
+#include <optional>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/nqe.h"
+
+namespace naive_db {
+
+// ---------------------------------------------------------------- error.rs:13-40
+struct ErrorCode : std::exception {
+    enum Kind {
+        ArrowError = 1, IoError, NoSuchField, ColumnNotExists, LogicalError, NoSuchTable, ParserError, IntervalError,
+        PlanError, NoMatchFunction, NotSupported, NotImplemented, Others,
+    };
+    int status;
+    std::string message;
+    ErrorCode(int s, std::string m) : status(s), message(std::move(m)) {}
+    Kind kind() const { return status >= 1 && status <= 13 ? Kind(status) : Others; }
+    const char *what() const noexcept override { return message.c_str(); }
+};
+
+// ---------------------------------------------------------------- logical_plan/expression.rs
+enum class Operator { Eq, NotEq, Lt, LtEq, Gt, GtEq, Plus, Minus, Multiply, Divide, Modulos, And, Or }; // :335-362
+enum class AggregateFunc { Count, Sum, Min, Max, Avg };                                                // :491-502
+enum class DataType { Null = NQE_NULLTYPE, Boolean = NQE_BOOLEAN, Int64 = NQE_INT64, UInt64 = NQE_UINT64, Float64 = NQE_FLOAT64, Utf8 = NQE_UTF8 };
+enum class JoinType { Inner, Left, Right, Cross }; // logical_plan/plan.rs:134-139
+
+struct ScalarValue { // :174-187
+    DataType dtype = DataType::Null;
+    bool is_null = true;
+    nqe_expr_node node{};
+    std::string str; // Utf8 payload (the node's pointer is bound when the expression is flattened)
+    static ScalarValue make(DataType dt, bool null) {
+        ScalarValue s;
+        s.dtype = dt;
+        s.is_null = null;
+        s.node.kind = NQE_EXPR_LITERAL;
+        s.node.dtype = int(dt);
+        s.node.is_null = null ? 1 : 0;
+        return s;
+    }
+    static ScalarValue Null() { return make(DataType::Null, true); }
+    static ScalarValue Int64(std::optional<int64_t> v) { auto s = make(DataType::Int64, !v); if (v) s.node.value.i64 = *v; return s; }
+    static ScalarValue UInt64(std::optional<uint64_t> v) { auto s = make(DataType::UInt64, !v); if (v) s.node.value.u64 = *v; return s; }
+    static ScalarValue Float64(std::optional<double> v) { auto s = make(DataType::Float64, !v); if (v) s.node.value.f64 = *v; return s; }
+    static ScalarValue Boolean(std::optional<bool> v) { auto s = make(DataType::Boolean, !v); if (v) s.node.value.boolean = *v ? 1 : 0; return s; }
+    static ScalarValue Utf8(std::optional<std::string> v) { auto s = make(DataType::Utf8, !v); if (v) s.str = *v; return s; }
+};
+
+struct Column { // logical_plan/expression.rs:167-170
+    std::optional<std::string> table;
+    std::string name;
+};
+
+// ---------------------------------------------------------------- logical_plan/schema.rs
+struct NaiveField {
+    std::optional<std::string> qualifier;
+    std::string name_;
+    DataType data_type;
+    bool nullable = false;
+    NaiveField(std::optional<std::string> q, std::string n, DataType dt, bool nl) : qualifier(std::move(q)), name_(std::move(n)), data_type(dt), nullable(nl) {}
+    const std::string &name() const { return name_; }
+};
+
+struct NaiveSchema {
+    std::vector<NaiveField> fields_;
+    NaiveSchema() = default;
+    explicit NaiveSchema(std::vector<NaiveField> f) : fields_(std::move(f)) {}
+    const std::vector<NaiveField> &fields() const { return fields_; }
+    const NaiveField &field(size_t i) const { return fields_.at(i); }
+    // schema.rs:116-125: the FIRST field with that name (quirk Q12)
+    const NaiveField &field_with_unqualified_name(const std::string &name) const {
+        for (auto &f : fields_)
+            if (f.name() == name) return f;
+        throw ErrorCode(ErrorCode::PlanError, "No field named '" + name + "'");
+    }
+};
+
+// ---------------------------------------------------------------- the GPU context (no reference analogue)
+class Context {
+  public:
+    explicit Context(int device = 0) {
+        if (nqe_ctx_create(device, nullptr, &ctx_) != NQE_OK) throw ErrorCode(NQE_ERR_HIP, nqe_last_global_error());
+    }
+    ~Context() { nqe_ctx_destroy(ctx_); }
+    Context(const Context &) = delete;
+    nqe_ctx *raw() const { return ctx_; }
+    void check(nqe_status st) const {
+        if (st != NQE_OK) throw ErrorCode(int(st), nqe_last_error(ctx_));
+    }
+    static std::shared_ptr<Context> &default_context() {
+        static std::shared_ptr<Context> c = std::make_shared<Context>(0);
+        return c;
+    }
+
+  private:
+    nqe_ctx *ctx_ = nullptr;
+};
+using ContextRef = std::shared_ptr<Context>;
+
+// ---------------------------------------------------------------- host Arrow array / RecordBatch
+struct Array {
+    DataType dtype = DataType::Null;
+    int64_t length = 0;
+    std::vector<uint64_t> words;   // Int64/UInt64/Float64 raw 64-bit words
+    std::vector<uint8_t> bits;     // Boolean values (LSB-first)
+    std::vector<uint8_t> validity; // empty = no nulls
+    std::vector<int32_t> offsets;  // Utf8: length + 1 offsets into `data`
+    std::string data;              // Utf8 bytes
+
+    static Array from_i64(const std::vector<int64_t> &v) { Array a; a.dtype = DataType::Int64; a.length = int64_t(v.size()); a.words.resize(v.size()); if (!v.empty()) std::memcpy(a.words.data(), v.data(), v.size() * 8); return a; }
+    static Array from_u64(const std::vector<uint64_t> &v) { Array a; a.dtype = DataType::UInt64; a.length = int64_t(v.size()); a.words = v; return a; }
+    static Array from_f64(const std::vector<double> &v) { Array a; a.dtype = DataType::Float64; a.length = int64_t(v.size()); a.words.resize(v.size()); if (!v.empty()) std::memcpy(a.words.data(), v.data(), v.size() * 8); return a; }
+    static Array from_opt_i64(const std::vector<std::optional<int64_t>> &v) {
+        Array a; a.dtype = DataType::Int64; a.length = int64_t(v.size()); a.words.assign(v.size(), 0); a.validity.assign((v.size() + 7) / 8, 0);
+        for (size_t i = 0; i < v.size(); ++i) if (v[i]) { a.words[i] = uint64_t(*v[i]); a.validity[i >> 3] |= uint8_t(1u << (i & 7)); }
+        return a;
+    }
+    bool is_valid(int64_t i) const { return validity.empty() || ((validity[size_t(i) >> 3] >> (i & 7)) & 1); }
+    int64_t i64(int64_t i) const { return int64_t(words[size_t(i)]); }
+    uint64_t u64(int64_t i) const { return words[size_t(i)]; }
+    double f64(int64_t i) const { double d; std::memcpy(&d, &words[size_t(i)], 8); return d; }
+    bool boolean(int64_t i) const { return (bits[size_t(i) >> 3] >> (i & 7)) & 1; }
+    std::string str(int64_t i) const { return data.substr(size_t(offsets[size_t(i)]), size_t(offsets[size_t(i) + 1] - offsets[size_t(i)])); }
+    std::vector<int64_t> to_i64() const { std::vector<int64_t> o(static_cast<size_t>(length)); for (int64_t i = 0; i < length; ++i) o[size_t(i)] = i64(i); return o; }
+    std::vector<double> to_f64() const { std::vector<double> o(static_cast<size_t>(length)); for (int64_t i = 0; i < length; ++i) o[size_t(i)] = f64(i); return o; }
+};
+
+// A RecordBatch whose columns live in HBM; column(i) downloads.
+class RecordBatch {
+  public:
+    RecordBatch(ContextRef ctx, NaiveSchema schema, nqe_table *t) : ctx_(std::move(ctx)), schema_(std::move(schema)), table_(t, [](nqe_table *p) { nqe_table_release(p); }) {}
+    static RecordBatch try_new(const ContextRef &ctx, const NaiveSchema &schema, const std::vector<Array> &columns) {
+        std::vector<nqe_column> cols(columns.size());
+        for (size_t i = 0; i < columns.size(); ++i) {
+            const Array &a = columns[i];
+            nqe_column &c = cols[i];
+            std::memset(&c, 0, sizeof(c));
+            c.dtype = int(a.dtype);
+            c.location = NQE_HOST;
+            c.length = a.length;
+            c.null_count = a.validity.empty() ? 0 : -1;
+            c.values = a.dtype == DataType::Boolean ? static_cast<const void *>(a.bits.data()) : static_cast<const void *>(a.words.data());
+            c.validity = a.validity.empty() ? nullptr : a.validity.data();
+        }
+        nqe_table *t = nullptr;
+        ctx->check(nqe_table_create(ctx->raw(), cols.data(), int32_t(cols.size()), &t));
+        return RecordBatch(ctx, schema, t);
+    }
+    int64_t num_rows() const { return nqe_table_num_rows(table_.get()); }
+    int32_t num_columns() const { return nqe_table_num_columns(table_.get()); }
+    const NaiveSchema &schema() const { return schema_; }
+    nqe_table *raw() const { return table_.get(); }
+    const ContextRef &ctx() const { return ctx_; }
+    Array column(int32_t i) const {
+        nqe_column info;
+        ctx_->check(nqe_table_column(table_.get(), i, &info));
+        Array a;
+        a.dtype = DataType(info.dtype);
+        a.length = info.length;
+        if (info.validity) a.validity.assign(size_t((info.length + 7) / 8), 0);
+        if (a.dtype == DataType::Utf8) {
+            a.offsets.assign(size_t(info.length) + 1, 0);
+            a.data.assign(size_t(info.data_length), '\0');
+            ctx_->check(nqe_table_download_column(table_.get(), i, a.offsets.data(), a.validity.empty() ? nullptr : a.validity.data(), a.data.data()));
+            return a;
+        }
+        if (a.dtype == DataType::Boolean) a.bits.assign(size_t((info.length + 7) / 8), 0);
+        else a.words.assign(size_t(info.length), 0);
+        ctx_->check(nqe_table_download_column(table_.get(), i, a.dtype == DataType::Boolean ? static_cast<void *>(a.bits.data()) : static_cast<void *>(a.words.data()),
+                                              a.validity.empty() ? nullptr : a.validity.data(), nullptr));
+        return a;
+    }
+    RecordBatch with_table(NaiveSchema schema, nqe_table *t) const { return RecordBatch(ctx_, std::move(schema), t); }
+
+  private:
+    ContextRef ctx_;
+    NaiveSchema schema_;
+    std::shared_ptr<nqe_table> table_;
+};
+
+// ---------------------------------------------------------------- physical_plan/expression/*.rs
+struct PhysicalExpr { // mod.rs:25-29
+    virtual ~PhysicalExpr() = default;
+    // post-order encoding against the schema of the batch it will be evaluated on
+    virtual void flatten(const NaiveSchema &schema, std::vector<nqe_expr_node> &out) const = 0;
+    virtual const struct ColumnExpr *as_column() const { return nullptr; }
+};
+using PhysicalExprRef = std::shared_ptr<PhysicalExpr>;
+
+struct ColumnExpr : PhysicalExpr { // column.rs:18-58
+    std::optional<std::string> name;
+    std::optional<size_t> idx;
+    static std::shared_ptr<ColumnExpr> try_create(std::optional<std::string> name, std::optional<size_t> idx) {
+        if (!name && !idx) throw ErrorCode(ErrorCode::LogicalError, "ColumnExpr must has name or idx");
+        auto c = std::make_shared<ColumnExpr>();
+        c->name = std::move(name);
+        c->idx = idx;
+        return c;
+    }
+    size_t resolve(const NaiveSchema &schema) const { // prefer idx, then the first matching name (:41-53)
+        if (idx) return *idx;
+        for (size_t i = 0; i < schema.fields().size(); ++i)
+            if (schema.field(i).name() == *name) return i;
+        throw ErrorCode(ErrorCode::LogicalError, "ColumnExpr must has name or idx");
+    }
+    void flatten(const NaiveSchema &schema, std::vector<nqe_expr_node> &out) const override {
+        nqe_expr_node n{};
+        n.kind = NQE_EXPR_COLUMN;
+        n.column = int32_t(resolve(schema));
+        out.push_back(n);
+    }
+    const ColumnExpr *as_column() const override { return this; }
+};
+
+struct PhysicalLiteralExpr : PhysicalExpr { // literal.rs:17-35
+    ScalarValue literal;
+    static PhysicalExprRef create(ScalarValue v) { auto e = std::make_shared<PhysicalLiteralExpr>(); e->literal = v; return e; }
+    void flatten(const NaiveSchema &, std::vector<nqe_expr_node> &out) const override {
+        nqe_expr_node n = literal.node;
+        if (literal.dtype == DataType::Utf8 && !literal.is_null) { // borrowed: this expression outlives the call
+            n.value.utf8 = literal.str.data();
+            n.utf8_length = int32_t(literal.str.size());
+        }
+        out.push_back(n);
+    }
+};
+
+struct PhysicalBinaryExpr : PhysicalExpr { // binary.rs:91-156
+    PhysicalExprRef left, right;
+    Operator op;
+    static PhysicalExprRef create(PhysicalExprRef l, Operator op, PhysicalExprRef r) {
+        auto e = std::make_shared<PhysicalBinaryExpr>();
+        e->left = std::move(l); e->op = op; e->right = std::move(r);
+        return e;
+    }
+    void flatten(const NaiveSchema &schema, std::vector<nqe_expr_node> &out) const override {
+        left->flatten(schema, out);
+        right->flatten(schema, out);
+        nqe_expr_node n{};
+        n.kind = NQE_EXPR_BINARY;
+        n.op = int32_t(op);
+        out.push_back(n);
+    }
+};
+
+// ---------------------------------------------------------------- datasource/memory.rs
+struct TableSource {
+    virtual ~TableSource() = default;
+    virtual const NaiveSchema &schema() const = 0;
+    virtual std::vector<RecordBatch> scan(const std::optional<std::vector<size_t>> &projection) const = 0;
+    virtual std::string source_name() const = 0;
+};
+using TableRef = std::shared_ptr<TableSource>;
+
+struct MemTable : TableSource { // memory.rs:14-46
+    NaiveSchema schema_;
+    std::vector<RecordBatch> batches;
+    static TableRef try_create(NaiveSchema schema, std::vector<RecordBatch> batches) {
+        auto m = std::make_shared<MemTable>();
+        m->schema_ = std::move(schema);
+        m->batches = std::move(batches);
+        return m;
+    }
+    const NaiveSchema &schema() const override { return schema_; }
+    std::vector<RecordBatch> scan(const std::optional<std::vector<size_t>> &projection) const override {
+        if (!projection) return batches;
+        std::vector<RecordBatch> out;
+        for (auto &b : batches) { // RecordBatch::project
+            std::vector<int32_t> idx(projection->begin(), projection->end());
+            std::vector<NaiveField> f;
+            for (size_t i : *projection) f.push_back(b.schema().field(i));
+            nqe_table *t = nullptr;
+            b.ctx()->check(nqe_table_project(b.ctx()->raw(), b.raw(), idx.data(), int32_t(idx.size()), &t));
+            out.push_back(b.with_table(NaiveSchema(f), t));
+        }
+        return out;
+    }
+    std::string source_name() const override { return "MemTable"; }
+};
+
+// ---------------------------------------------------------------- datasource/csv.rs
+struct CsvConfig { // csv.rs:23-43 (file_projection / datetime_format are not mirrored)
+    bool has_header = true;
+    uint8_t delimiter = ',';
+    std::optional<size_t> max_read_records = 3;
+    size_t batch_size = 1000000;
+};
+
+struct CsvTable : TableSource { // csv.rs:46-103: schema inferred from the first records, FIRST batch only (Q1), scan ignores projection (Q2)
+    NaiveSchema schema_;
+    std::vector<RecordBatch> batches;
+    static TableRef try_create(const std::string &filename, const CsvConfig &config = CsvConfig(), ContextRef ctx = Context::default_context()) {
+        std::ifstream f(filename, std::ios::binary);
+        if (!f) throw ErrorCode(ErrorCode::IoError, "cannot open " + filename);
+        std::string bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        nqe_csv_options opt;
+        opt.has_header = config.has_header ? 1 : 0;
+        opt.delimiter = config.delimiter;
+        opt.max_read_records = config.max_read_records ? int64_t(*config.max_read_records) : -1;
+        opt.batch_size = int64_t(config.batch_size);
+        int32_t nc = 0;
+        std::vector<int32_t> dtypes(256), nullable(256);
+        std::vector<char> names(1 << 16);
+        int64_t names_bytes = 0;
+        ctx->check(nqe_csv_infer_schema(ctx->raw(), bytes.data(), int64_t(bytes.size()), &opt, 256, &nc, dtypes.data(), nullable.data(), names.data(),
+                                        int64_t(names.size()), &names_bytes));
+        std::vector<NaiveField> fields;
+        const char *p = names.data();
+        for (int32_t c = 0; c < nc; ++c) {
+            std::string nm(p);
+            p += nm.size() + 1;
+            fields.emplace_back(std::nullopt, nm, DataType(dtypes[size_t(c)]), nullable[size_t(c)] != 0);
+        }
+        nqe_table *t = nullptr;
+        ctx->check(nqe_csv_read(ctx->raw(), bytes.data(), NQE_HOST, int64_t(bytes.size()), &opt, dtypes.data(), nc, &t));
+        auto tab = std::make_shared<CsvTable>();
+        tab->schema_ = NaiveSchema(fields);
+        tab->batches.push_back(RecordBatch(ctx, tab->schema_, t));
+        return tab;
+    }
+    const NaiveSchema &schema() const override { return schema_; }
+    std::vector<RecordBatch> scan(const std::optional<std::vector<size_t>> &) const override { return batches; }
+    std::string source_name() const override { return "CsvTable"; }
+};
+
+// ---------------------------------------------------------------- physical_plan/plan.rs:14-23
+struct PhysicalPlan {
+    virtual ~PhysicalPlan() = default;
+    virtual const NaiveSchema &schema() const = 0;
+    virtual std::vector<RecordBatch> execute() = 0;
+    virtual std::vector<std::shared_ptr<PhysicalPlan>> children() const = 0;
+};
+using PhysicalPlanRef = std::shared_ptr<PhysicalPlan>;
+
+struct ScanPlan : PhysicalPlan { // scan.rs:18-41
+    TableRef source;
+    std::optional<std::vector<size_t>> projection;
+    static PhysicalPlanRef create(TableRef source, std::optional<std::vector<size_t>> projection) {
+        auto p = std::make_shared<ScanPlan>();
+        p->source = std::move(source);
+        p->projection = std::move(projection);
+        return p;
+    }
+    const NaiveSchema &schema() const override { return source->schema(); }
+    std::vector<RecordBatch> execute() override { return source->scan(projection); }
+    std::vector<PhysicalPlanRef> children() const override { return {}; }
+};
+
+struct SelectionPlan : PhysicalPlan { // selection.rs:23-112
+    PhysicalPlanRef input;
+    PhysicalExprRef expr;
+    static PhysicalPlanRef create(PhysicalPlanRef input, PhysicalExprRef expr) {
+        auto p = std::make_shared<SelectionPlan>();
+        p->input = std::move(input);
+        p->expr = std::move(expr);
+        return p;
+    }
+    const NaiveSchema &schema() const override { return input->schema(); }
+    std::vector<RecordBatch> execute() override {
+        std::vector<RecordBatch> in = input->execute();
+        if (in.empty()) throw ErrorCode(ErrorCode::NotSupported, "index out of bounds: input[0] (selection.rs:60 panics)");
+        std::vector<nqe_expr_node> pred;
+        expr->flatten(in[0].schema(), pred);
+        std::vector<RecordBatch> out;
+        if (in.size() == 1) {
+            nqe_table *t = nullptr;
+            in[0].ctx()->check(nqe_selection_execute(in[0].ctx()->raw(), in[0].raw(), pred.data(), int32_t(pred.size()), &t));
+            out.push_back(in[0].with_table(in[0].schema(), t));
+            return out;
+        }
+        // quirk Q3: predicate from batch 0 only, zipped (truncating) against every batch
+        nqe_table *mask = nullptr;
+        in[0].ctx()->check(nqe_expr_evaluate(in[0].ctx()->raw(), in[0].raw(), pred.data(), int32_t(pred.size()), &mask));
+        std::shared_ptr<nqe_table> guard(mask, [](nqe_table *p) { nqe_table_release(p); });
+        for (auto &b : in) {
+            nqe_table *t = nullptr;
+            b.ctx()->check(nqe_filter(b.ctx()->raw(), b.raw(), mask, 0, &t));
+            out.push_back(b.with_table(b.schema(), t));
+        }
+        return out;
+    }
+    std::vector<PhysicalPlanRef> children() const override { return {input}; }
+};
+
+struct ProjectionPlan : PhysicalPlan { // projection.rs:18-75
+    PhysicalPlanRef input;
+    NaiveSchema schema_;
+    std::vector<PhysicalExprRef> expr;
+    static PhysicalPlanRef create(PhysicalPlanRef input, NaiveSchema schema, std::vector<PhysicalExprRef> expr) {
+        auto p = std::make_shared<ProjectionPlan>();
+        p->input = std::move(input);
+        p->schema_ = std::move(schema);
+        p->expr = std::move(expr);
+        return p;
+    }
+    const NaiveSchema &schema() const override { return schema_; }
+    std::vector<RecordBatch> execute() override {
+        if (schema_.fields().empty()) return input->execute(); // :47-48 pass-through above an aggregate
+        auto flatten_all = [&](const NaiveSchema &s, std::vector<nqe_expr_node> &nodes, std::vector<int32_t> &offs) {
+            offs.push_back(0);
+            for (auto &e : expr) { e->flatten(s, nodes); offs.push_back(int32_t(nodes.size())); }
+        };
+        // fused Projection∘Selection over a single batch (identical result, one pass per output column)
+        if (auto sel = std::dynamic_pointer_cast<SelectionPlan>(input)) {
+            std::vector<RecordBatch> below = sel->input->execute();
+            if (below.size() == 1) {
+                std::vector<nqe_expr_node> pred, nodes;
+                std::vector<int32_t> offs;
+                sel->expr->flatten(below[0].schema(), pred);
+                flatten_all(below[0].schema(), nodes, offs);
+                nqe_table *t = nullptr;
+                below[0].ctx()->check(nqe_selection_projection_execute(below[0].ctx()->raw(), below[0].raw(), pred.data(), int32_t(pred.size()),
+                                                                       nodes.data(), offs.data(), int32_t(expr.size()), &t));
+                return {below[0].with_table(schema_, t)};
+            }
+        }
+        std::vector<RecordBatch> out;
+        for (auto &b : input->execute()) {
+            std::vector<nqe_expr_node> nodes;
+            std::vector<int32_t> offs;
+            flatten_all(b.schema(), nodes, offs);
+            nqe_table *t = nullptr;
+            b.ctx()->check(nqe_projection_execute(b.ctx()->raw(), b.raw(), nodes.data(), offs.data(), int32_t(expr.size()), &t));
+            out.push_back(b.with_table(schema_, t));
+        }
+        return out;
+    }
+    std::vector<PhysicalPlanRef> children() const override { return {input}; }
+};
+
+// limit.rs:32-49 / offset.rs:30-51
+struct PhysicalLimitPlan : PhysicalPlan {
+    PhysicalPlanRef input;
+    size_t n = 0;
+    static PhysicalPlanRef create(PhysicalPlanRef input, size_t n) { auto p = std::make_shared<PhysicalLimitPlan>(); p->input = std::move(input); p->n = n; return p; }
+    const NaiveSchema &schema() const override { return input->schema(); }
+    std::vector<RecordBatch> execute() override {
+        size_t k = n;
+        std::vector<RecordBatch> ret;
+        for (auto &b : input->execute()) {
+            if (k == 0) break;
+            if (size_t(b.num_rows()) <= k) { ret.push_back(b); k -= size_t(b.num_rows()); }
+            else {
+                nqe_table *t = nullptr;
+                b.ctx()->check(nqe_table_slice(b.ctx()->raw(), b.raw(), 0, int64_t(k), &t));
+                ret.push_back(b.with_table(b.schema(), t));
+                k = 0;
+            }
+        }
+        return ret;
+    }
+    std::vector<PhysicalPlanRef> children() const override { return {input}; }
+};
+struct PhysicalOffsetPlan : PhysicalPlan {
+    PhysicalPlanRef input;
+    size_t n = 0;
+    static PhysicalPlanRef create(PhysicalPlanRef input, size_t n) { auto p = std::make_shared<PhysicalOffsetPlan>(); p->input = std::move(input); p->n = n; return p; }
+    const NaiveSchema &schema() const override { return input->schema(); }
+    std::vector<RecordBatch> execute() override {
+        size_t k = n;
+        std::vector<RecordBatch> ret;
+        for (auto &b : input->execute()) {
+            if (k == 0) { ret.push_back(b); continue; }
+            if (k >= size_t(b.num_rows())) { k -= size_t(b.num_rows()); continue; }
+            nqe_table *t = nullptr;
+            b.ctx()->check(nqe_table_slice(b.ctx()->raw(), b.raw(), int64_t(k), b.num_rows() - int64_t(k), &t));
+            ret.push_back(b.with_table(b.schema(), t));
+            k = 0;
+        }
+        return ret;
+    }
+    std::vector<PhysicalPlanRef> children() const override { return {input}; }
+};
+
+// ---------------------------------------------------------------- physical_plan/aggregate/*.rs
+struct AggregateOperator { // mod.rs:225-235 — the update loops run on the device
+    std::shared_ptr<ColumnExpr> col_expr;
+    virtual ~AggregateOperator() = default;
+    virtual AggregateFunc func() const = 0;
+    virtual const char *label() const = 0;
+    virtual DataType out_type() const { return DataType::Float64; }
+    NaiveField data_field(const NaiveSchema &schema) const {
+        if (col_expr->name) return NaiveField(std::nullopt, std::string(label()) + "(" + schema.field_with_unqualified_name(*col_expr->name).name() + ")", out_type(), false);
+        if (col_expr->idx) return NaiveField(std::nullopt, std::string(label()) + "(" + schema.field(*col_expr->idx).name() + ")", out_type(), false);
+        throw ErrorCode(ErrorCode::LogicalError, "ColumnExpr must has name or idx");
+    }
+};
+#define NAIVE_DB_AGG(NAME, FUNC, LABEL, OUT)                                                                            \
+    struct NAME : AggregateOperator {                                                                                  \
+        static std::unique_ptr<AggregateOperator> create(std::shared_ptr<ColumnExpr> c) { auto a = std::make_unique<NAME>(); a->col_expr = std::move(c); return a; } \
+        AggregateFunc func() const override { return AggregateFunc::FUNC; }                                            \
+        const char *label() const override { return LABEL; }                                                           \
+        DataType out_type() const override { return DataType::OUT; }                                                   \
+    };
+NAIVE_DB_AGG(Sum, Sum, "sum", Float64)     // sum.rs
+NAIVE_DB_AGG(Avg, Avg, "avg", Float64)     // avg.rs
+NAIVE_DB_AGG(Count, Count, "count", UInt64) // count.rs
+NAIVE_DB_AGG(Max, Max, "max", Float64)     // max.rs
+NAIVE_DB_AGG(Min, Min, "min", Float64)     // min.rs
+#undef NAIVE_DB_AGG
+
+struct PhysicalAggregatePlan : PhysicalPlan { // aggregate/mod.rs:31-223
+    std::vector<PhysicalExprRef> group_expr;
+    std::vector<std::unique_ptr<AggregateOperator>> aggr_ops;
+    PhysicalPlanRef input;
+    NaiveSchema schema_;
+    static PhysicalPlanRef create(std::vector<PhysicalExprRef> group_expr, std::vector<std::unique_ptr<AggregateOperator>> aggr_ops, PhysicalPlanRef input) {
+        auto p = std::make_shared<PhysicalAggregatePlan>();
+        p->schema_ = input->schema(); // the INPUT schema (quirk Q8/Q13)
+        p->group_expr = std::move(group_expr);
+        p->aggr_ops = std::move(aggr_ops);
+        p->input = std::move(input);
+        return p;
+    }
+    const NaiveSchema &schema() const override { return schema_; }
+    std::vector<PhysicalPlanRef> children() const override { return {input}; }
+    std::vector<RecordBatch> execute() override {
+        std::vector<NaiveField> fields;
+        for (auto &op : aggr_ops) fields.push_back(op->data_field(schema_));
+        // fuse a SelectionPlan below into the aggregation kernel when it sees one batch
+        PhysicalExprRef pred_expr;
+        std::vector<RecordBatch> batches;
+        if (auto sel = std::dynamic_pointer_cast<SelectionPlan>(input)) {
+            batches = sel->input->execute();
+            if (batches.size() == 1) pred_expr = sel->expr;
+            else batches = input->execute();
+        } else {
+            batches = input->execute();
+        }
+        if (batches.empty()) throw ErrorCode(ErrorCode::NotSupported, "aggregate over an empty batch list is not supported on the device path");
+        const ContextRef &ctx = batches[0].ctx();
+        std::vector<nqe_aggregate> aggs;
+        for (auto &op : aggr_ops) aggs.push_back(nqe_aggregate{int32_t(op->func()), int32_t(op->col_expr->resolve(batches[0].schema()))});
+        std::vector<nqe_expr_node> pred, key;
+        if (pred_expr) pred_expr->flatten(batches[0].schema(), pred);
+        if (!group_expr.empty()) group_expr[0]->flatten(batches[0].schema(), key); // only group_expr[0] (Q8)
+        std::shared_ptr<nqe_table> single;
+        nqe_table *in = batches[0].raw();
+        if (batches.size() > 1) { // concat_batches (:143-144)
+            std::vector<const nqe_table *> parts;
+            for (auto &b : batches) parts.push_back(b.raw());
+            nqe_table *c = nullptr;
+            ctx->check(nqe_table_concat(ctx->raw(), parts.data(), int32_t(parts.size()), &c));
+            single.reset(c, [](nqe_table *p) { nqe_table_release(p); });
+            in = c;
+        }
+        nqe_table *out = nullptr;
+        ctx->check(nqe_aggregate_execute(ctx->raw(), in, pred.empty() ? nullptr : pred.data(), int32_t(pred.size()), key.empty() ? nullptr : key.data(),
+                                         int32_t(key.size()), aggs.data(), int32_t(aggs.size()), &out, nullptr));
+        return {batches[0].with_table(NaiveSchema(fields), out)};
+    }
+};
+
+// ---------------------------------------------------------------- physical_plan/hash_join.rs:44-289
+struct HashJoin : PhysicalPlan {
+    PhysicalPlanRef left, right; // LEFT = build side, RIGHT = probe side (quirk Q11)
+    std::vector<std::pair<Column, Column>> on;
+    JoinType join_type = JoinType::Inner; // stored, never read (:48-49)
+    NaiveSchema schema_;
+    int executions_ = 0;
+    static PhysicalPlanRef create(PhysicalPlanRef left, PhysicalPlanRef right, std::vector<std::pair<Column, Column>> on, JoinType jt, NaiveSchema schema) {
+        auto p = std::make_shared<HashJoin>();
+        p->left = std::move(left); p->right = std::move(right); p->on = std::move(on); p->join_type = jt; p->schema_ = std::move(schema);
+        return p;
+    }
+    const NaiveSchema &schema() const override { return schema_; }
+    std::vector<PhysicalPlanRef> children() const override { return {left, right}; }
+    std::vector<RecordBatch> execute() override {
+        if (on.empty()) throw ErrorCode(ErrorCode::PlanError, "Inner Join on Conditions can't not be empty"); // :125-129
+        std::vector<RecordBatch> lb = left->execute(), rb = right->execute();
+        if (lb.empty()) throw ErrorCode(ErrorCode::NotSupported, "join with an empty left batch list is not supported on the device path");
+        const ContextRef &ctx = lb[0].ctx();
+        std::shared_ptr<nqe_table> single;
+        nqe_table *ltab = lb[0].raw();
+        if (lb.size() > 1) {
+            std::vector<const nqe_table *> parts;
+            for (auto &b : lb) parts.push_back(b.raw());
+            nqe_table *c = nullptr;
+            ctx->check(nqe_table_concat(ctx->raw(), parts.data(), int32_t(parts.size()), &c));
+            single.reset(c, [](nqe_table *p) { nqe_table_release(p); });
+            ltab = c;
+        }
+        size_t lkey = ColumnExpr::try_create(on[0].first.name, std::nullopt)->resolve(lb[0].schema()); // by NAME (:134-136)
+        // Q11: the reference never clears its hash table, so the k-th execute() of one plan object emits every match k
+        // times ([matches of the first build..., of the second...]); a build side of k copies has exactly that order
+        std::shared_ptr<nqe_table> repeated;
+        if (++executions_ > 1) {
+            std::vector<const nqe_table *> copies(size_t(executions_), ltab);
+            nqe_table *c = nullptr;
+            ctx->check(nqe_table_concat(ctx->raw(), copies.data(), int32_t(copies.size()), &c));
+            repeated.reset(c, [](nqe_table *p) { nqe_table_release(p); });
+            ltab = c;
+        }
+        nqe_join_table *jt = nullptr;
+        ctx->check(nqe_hash_join_build(ctx->raw(), ltab, int32_t(lkey), &jt));
+        std::shared_ptr<nqe_join_table> jguard(jt, [](nqe_join_table *p) { nqe_join_table_release(p); });
+        std::vector<RecordBatch> out;
+        for (auto &b : rb) { // one output batch per probe batch (:177-250)
+            size_t rkey = ColumnExpr::try_create(on[0].second.name, std::nullopt)->resolve(b.schema());
+            nqe_table *t = nullptr;
+            ctx->check(nqe_hash_join_probe(ctx->raw(), jt, b.raw(), int32_t(rkey), &t));
+            NaiveSchema s = schema_;
+            if (int32_t(s.fields().size()) != nqe_table_num_columns(t)) {
+                std::vector<NaiveField> f = lb[0].schema().fields();
+                for (auto &x : b.schema().fields()) f.push_back(x);
+                s = NaiveSchema(f);
+            }
+            out.push_back(b.with_table(s, t));
+        }
+        return out;
+    }
+};
+
+} // namespace naive_db
