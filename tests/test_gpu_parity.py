@@ -432,6 +432,37 @@ def test_aggregate_many_groups_overflows_workgroup_table(ctx):
     assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0])
 
 
+@pytest.mark.parametrize("groups", [1, 63, 64, 65, 1024, 4095, 4097, 8000, 8192, 8193, 9000])
+@pytest.mark.parametrize("unsigned", [False, True])
+def test_aggregate_small_table_tail_boundaries(ctx, groups, unsigned):
+    """group counts around the entry/slot boundaries of the single-launch tail (rank_finalize_kernel: 64 entries per workgroup,
+    8192-slot first-attempt table) and past it (TABLE_FULL → retry with the worst-case table): rows in key order (signed /
+    unsigned), keys_out aligned with the rows, the table's EMPTY sentinel (i64::MIN) as a real key"""
+    rng = np.random.default_rng(groups * 2 + int(unsigned))
+    n = max(3 * groups, 50)
+    if unsigned:
+        base = rng.permutation(groups).astype(np.uint64) * np.uint64(0x0004000000000001)   # keys on both sides of 2^63
+        base[0] = np.uint64(1) << np.uint64(63)
+    else:
+        base = (rng.permutation(groups).astype(np.int64) - groups // 2) * 0x0000100000000003
+        base[0] = np.iinfo(np.int64).min
+    k = base[rng.integers(0, groups, n)]
+    k[:groups] = base                                                         # every group present
+    v = k.astype(np.float64)
+    cols = [Column.from_numpy(k), Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    aggs = [(AggregateFunc.Min, 1), (AggregateFunc.Count, 0), (AggregateFunc.Max, 1)]
+    exp = orc.aggregate([cols], aggs, group_nodes=col(0).flatten(f2))[0]
+    got, gk = ctx.aggregate(ctx.table_from_host(cols), aggs, group_nodes=col(0).flatten(f2), with_keys=True)
+    kk = gk.to_host()[0].to_numpy()
+    assert got.num_rows == groups and (kk == np.unique(k)).all()
+    g = got.to_host()
+    assert (g[0].to_numpy() == kk.astype(np.float64)).all() and (g[2].to_numpy() == kk.astype(np.float64)).all()
+    cnt = {int(a): int(b) for a, b in zip(*np.unique(k, return_counts=True))}
+    assert [cnt[int(x)] for x in kk] == g[1].to_list()
+    assert_rows_multiset_equal(g, exp, RTOL, exact_cols=[1])
+
+
 def test_aggregate_partial_merge_equals_single_pass(ctx):
     rng = np.random.default_rng(99)
     n = 40000
