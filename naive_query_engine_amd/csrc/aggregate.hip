@@ -593,7 +593,7 @@ constexpr int RANK_WAVES = 16;
 constexpr int RANK_PASSES = (RANK_MAX_CAP + 1 + RANK_WAVES * 64 - 1) / (RANK_WAVES * 64);
 
 __global__ void __launch_bounds__(RANK_WAVES * 64) rank_finalize_kernel(GroupTable g, int signed_order, FinalizeArgs f, uint64_t *out_keys,
-                                                                        uint32_t *count_out) {
+                                                                        const int *flags, int *mirror) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rank_smem[];
     const uint32_t slots = g.cap + 1;
     uint64_t *ok = reinterpret_cast<uint64_t *>(rank_smem);        // [slots] ordered keys of the occupied slots, compacted
@@ -626,7 +626,12 @@ __global__ void __launch_bounds__(RANK_WAVES * 64) rank_finalize_kernel(GroupTab
     }
     __syncthreads();
     const uint32_t G = wbase[passes * RANK_WAVES];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = G;
+    if (blockIdx.x == 0 && threadIdx.x < NQE_NUM_FLAGS) {
+        // this is the last kernel before the read-back: the flags of the kernels before it and the group count go straight into
+        // the pinned host mirror (no device-to-host copy command between the kernel and the host's wait)
+        mirror[threadIdx.x] = threadIdx.x == NQE_FLAG_GROUP_COUNT ? int(G) : flags[threadIdx.x];
+        __threadfence_system();
+    }
     if (blockIdx.x * RANK_SLOTS >= G) return; // no entries for this workgroup
     // ---- compaction, pass 2
     for (int p = 0; p < passes; ++p) {
@@ -828,8 +833,7 @@ AggResult emit_ranked(nqe_ctx *ctx, TableBufs &tb, int key_dtype, const nqe_aggr
     r.keys->rows = slots;
     r.keys->cols.push_back(make_word_column(ctx, key_dtype, slots, false));
     launch(ctx, "agg_rank_finalize", rank_finalize_kernel, dim3(unsigned((slots + RANK_SLOTS - 1) / RANK_SLOTS)), dim3(RANK_WAVES * 64), size_t(slots) * 12, tb.g,
-           key_dtype == NQE_INT64 ? 1 : 0, f, (uint64_t *)r.keys->cols[0].values->ptr,
-           reinterpret_cast<uint32_t *>(ctx->d_flags + NQE_FLAG_GROUP_COUNT));
+           key_dtype == NQE_INT64 ? 1 : 0, f, (uint64_t *)r.keys->cols[0].values->ptr, (const int *)ctx->d_flags, ctx->h_flags_dev);
     return r;
 }
 
@@ -1200,7 +1204,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                    (uint32_t *)pre.slots->ptr, reinterpret_cast<uint32_t *>(ctx->d_flags + NQE_FLAG_GROUP_COUNT));
         }
         int f[NQE_NUM_FLAGS];
-        flags_read(ctx, f);
+        if (ranked.out) flags_read_mirrored(ctx, f);
+        else flags_read(ctx, f);
         if (pre.keys) pre.G = int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT]));
         if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
@@ -1319,8 +1324,10 @@ nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, con
     if (grouped && cap <= RANK_MAX_CAP) {
         // the exchanged states of a small group set (the sharded headline: world x 1024 rows): tail ahead of the read-back
         r = emit_ranked(ctx, tb, key_dtype, aggs, num_aggs, vslot, false);
-        throw_on_flags(ctx);
-        set_group_count(r, int64_t(uint32_t(ctx->h_flags[NQE_FLAG_GROUP_COUNT])));
+        int f[NQE_NUM_FLAGS];
+        flags_read_mirrored(ctx, f);
+        if (f[NQE_FLAG_TABLE_FULL]) fail(NQE_ERR_OUT_OF_MEMORY, "device hash table overflow");
+        set_group_count(r, int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT])));
     } else {
         throw_on_flags(ctx);
         r = emit(ctx, tb, grouped, key_dtype, aggs, num_aggs, vslot, false);
