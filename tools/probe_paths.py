@@ -73,10 +73,17 @@ for name, tab in ((("plain", plain), ("1% null values", nullable)) if SECTION in
 if SECTION in ("all", "keys"):
     for name, kexpr in (("id % 1024", binop(col(0), Operator.Modulos, lit_i64(1024))), ("id % 3", binop(col(0), Operator.Modulos, lit_i64(3))),
                         ("id % 16", binop(col(0), Operator.Modulos, lit_i64(16))), ("id % 64", binop(col(0), Operator.Modulos, lit_i64(64))),
+                        ("id % 256", binop(col(0), Operator.Modulos, lit_i64(256))), ("id % 512", binop(col(0), Operator.Modulos, lit_i64(512))),
+                        ("id % 2048", binop(col(0), Operator.Modulos, lit_i64(2048))),
                         ("id % 1000", binop(col(0), Operator.Modulos, lit_i64(1000))), ("id % 2000", binop(col(0), Operator.Modulos, lit_i64(2000))),
                         ("(id + 1) % 1000", binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(1000)))):
-        q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=kexpr.flatten(f), pred_nodes=pred))
-        print(f"aggregate {n} rows key {name}: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
+        q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=kexpr.flatten(f), pred_nodes=pred), reps=20)
+        ctx.timing_enable(True); ctx.timing_reset()
+        for _ in range(5):
+            r = ctx.aggregate(plain, aggs, group_nodes=kexpr.flatten(f), pred_nodes=pred); del r
+        ctx.timing_enable(False)
+        br = {k: round(ctx.timing_query(k)[0] / 5, 4) for k in ("agg_grouped", "agg_table_init", "agg_rank_finalize", "agg_collect", "bitonic", "agg_finalize")}
+        print(f"aggregate {n} rows key {name}: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s  kernels(ms) {br}")
 if SECTION in ("all", "paths"):
     gen = binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(1000)).flatten(f)   # non-pow2 modulus: general key
     q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=gen, pred_nodes=pred))
