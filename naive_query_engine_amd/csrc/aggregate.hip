@@ -1053,6 +1053,18 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     if (a.key.aux[0].pow2_shift >= 0) kk = 1, fast_key = 1;
                     else if (a.key.aux[0].more >= 0) fast_key = 2; // `col % d`, d not a power of two: magic multiply
                 }
+                if (fast_key < 0 && a.key.nops >= 1) {
+                    // any other chain of integer arithmetic with literals that cannot fault (divisors: literals other than 0
+                    // and -1): the fast kernels evaluate it with the generic interpreter (KEY = 3)
+                    bool ok = true;
+                    for (int k = 0; k < a.key.nops; ++k) {
+                        const int op = a.key.op[k];
+                        ok = ok && op >= NQE_OP_PLUS && op <= NQE_OP_MODULOS && (a.key.op_dtype[k] == NQE_INT64 || a.key.op_dtype[k] == NQE_UINT64);
+                        if (op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS)
+                            ok = ok && !a.key.lit_left[k] && a.key.lit[k] != 0 && a.key.lit[k] != ~0ull;
+                    }
+                    if (ok) fast_key = 3;
+                }
                 bool plain = is_word_type(a.key_src.dtype);
                 // a Boolean predicate column without nulls (a Boolean input column, or any predicate tree evaluated by the
                 // expression machine) is tested by the same variants as a separate integer predicate column: the word of a

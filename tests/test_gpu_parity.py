@@ -463,6 +463,40 @@ def test_aggregate_small_table_tail_boundaries(ctx, groups, unsigned):
     assert_rows_multiset_equal(g, exp, RTOL, exact_cols=[1])
 
 
+@pytest.mark.parametrize("m", [700, 150_001])
+def test_aggregate_two_step_integer_keys(ctx, m):
+    """chains of one or two integer operations with literals as group keys (`(id + 1) % m`, `id / 7 * 3`, `(100 - id) % m`, …): the
+    fast kernels' interpreted key variant, on the single-pass path (m = 700) and the hash-partitioned one (m = 150001: more
+    groups than a workgroup table, >= 2^18 rows); signed and unsigned sources, negative dividends, a predicate on another column"""
+    rng = np.random.default_rng(m)
+    n = 400_000
+    a = rng.integers(-3 * m, 3 * m, n).astype(np.int64)
+    u = rng.integers(0, 6 * m, n).astype(np.uint64)
+    v = rng.random(n) * 10 - 5
+    w = rng.integers(-50, 50, n).astype(np.int64)
+    cols = [Column.from_numpy(a), Column.from_numpy(u), Column.from_numpy(v), Column.from_numpy(w)]
+    f4 = fields("a", "u", "v", "w")
+    t = ctx.table_from_host(cols)
+    A, U = col(0), col(1)
+    keys = [binop(binop(A, Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(m)),
+            binop(binop(A, Operator.Divide, lit_i64(7)), Operator.Multiply, lit_i64(3)),
+            binop(binop(lit_i64(100), Operator.Minus, A), Operator.Modulos, lit_i64(m)),
+            binop(binop(A, Operator.Multiply, lit_i64(3)), Operator.Plus, lit_i64(1)),
+            binop(binop(A, Operator.Modulos, lit_i64(-m)), Operator.Divide, lit_i64(2)),
+            binop(A, Operator.Minus, lit_i64(-5)),
+            binop(binop(U, Operator.Plus, lit_u64(3)), Operator.Modulos, lit_u64(m)),
+            binop(binop(U, Operator.Divide, lit_u64(5)), Operator.Minus, lit_u64(7))]       # wraps below zero: huge UInt64 keys
+    aggs = ALL_AGGS(2)
+    for key in keys:
+        for pred in (None, binop(col(3), Operator.GtEq, lit_i64(-20))):
+            pn = pred.flatten(f4) if pred is not None else None
+            exp = orc.aggregate([cols], aggs, group_nodes=key.flatten(f4), pred_nodes=pn)[0]
+            got, gk = ctx.aggregate(t, aggs, group_nodes=key.flatten(f4), pred_nodes=pn, with_keys=True)
+            assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"key {key!r} pred {pred!r}")
+            kk = gk.to_host()[0].to_numpy()
+            assert (np.sort(kk) == kk).all() and len(np.unique(kk)) == len(kk) == got.num_rows
+
+
 def test_aggregate_partial_merge_equals_single_pass(ctx):
     rng = np.random.default_rng(99)
     n = 40000
