@@ -173,7 +173,7 @@ def main():
         launches += a_n
     breakdown = {}
     for kn in ("agg_grouped", "agg_table_init", "agg_collect", "agg_finalize", "agg_rank_finalize", "bitonic_small", "keep_from_simple", "compact_expr",
-               "compact_column", "compact_gather", "join_probe_unique", "join_probe_presence", "join_fused_write", "join_probe_count", "join_probe_write", "scan_chunk", "scan_add"):
+               "compact_column", "compact_gather", "join_probe_unique", "join_probe_presence", "join_fused_write", "join_probe_count", "join_probe_write", "scan_chunk", "scan_add", "scan_single"):
         b_ms, b_n = ctx.timing_query(kn)
         if b_n:
             breakdown[kn] = {"ms_per_step": b_ms / args.steps, "launches_per_step": b_n / args.steps}

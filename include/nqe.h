@@ -38,6 +38,10 @@
  *     device flags back (and thereby synchronises) before returning.  Device
  *     pointers from nqe_table_column may be handed to another stream only after
  *     nqe_ctx_synchronize.
+ *   - when a call has to wait for the device (a row count, the flags) the host
+ *     thread polls the stream for up to 5 ms before it blocks: the waits sit
+ *     behind kernels of microseconds to a few milliseconds, and an
+ *     interrupt-driven wake-up would add its latency to every operator.
  */
 #ifndef NQE_H
 #define NQE_H
