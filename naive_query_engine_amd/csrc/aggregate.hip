@@ -603,12 +603,18 @@ __global__ void __launch_bounds__(RANK_WAVES * 64) rank_finalize_kernel(GroupTab
     const uint64_t flip = signed_order ? 0x8000000000000000ull : 0ull;
     const int wv = threadIdx.x / 64;
     const int passes = int((slots + blockDim.x - 1) / blockDim.x);
-    // ---- compaction, pass 1: occupied slots per (pass, wave)
-    for (int p = 0; p < passes; ++p) {
-        const uint32_t s = uint32_t(p) * blockDim.x + threadIdx.x;
-        const bool used = s < slots && g.keys[s] != EMPTY_KEY;
-        const uint64_t m = __ballot(used);
-        if (lane_id() == 0) wbase[p * RANK_WAVES + wv] = uint32_t(__popcll(m));
+    // ---- compaction, pass 1: occupied slots per (pass, wave).  The ≤ 9 key words of a thread are requested back to back and
+    // kept in registers for pass 2 (one memory round trip for the whole table instead of one per pass)
+    uint64_t kreg[RANK_PASSES];
+#pragma unroll
+    for (int p = 0; p < RANK_PASSES; ++p) {
+        const uint32_t s = uint32_t(p) * (RANK_WAVES * 64) + threadIdx.x;
+        kreg[p] = s < slots ? g.keys[s] : EMPTY_KEY;
+    }
+#pragma unroll
+    for (int p = 0; p < RANK_PASSES; ++p) {
+        const uint64_t m = __ballot(kreg[p] != EMPTY_KEY);
+        if (lane_id() == 0 && p < passes) wbase[p * RANK_WAVES + wv] = uint32_t(__popcll(m));
     }
     __syncthreads();
     if (wv == 0) { // exclusive scan of the ≤ 144 counts
@@ -634,14 +640,14 @@ __global__ void __launch_bounds__(RANK_WAVES * 64) rank_finalize_kernel(GroupTab
     }
     if (blockIdx.x * RANK_SLOTS >= G) return; // no entries for this workgroup
     // ---- compaction, pass 2
-    for (int p = 0; p < passes; ++p) {
-        const uint32_t s = uint32_t(p) * blockDim.x + threadIdx.x;
-        const uint64_t k = s < slots ? g.keys[s] : EMPTY_KEY;
-        const bool used = k != EMPTY_KEY;
+#pragma unroll
+    for (int p = 0; p < RANK_PASSES; ++p) {
+        const uint32_t s = uint32_t(p) * (RANK_WAVES * 64) + threadIdx.x;
+        const bool used = kreg[p] != EMPTY_KEY;
         const uint64_t m = __ballot(used);
         if (used) {
             const uint32_t pos = wbase[p * RANK_WAVES + wv] + uint32_t(__popcll(m & lanemask_lt()));
-            ok[pos] = (s == g.cap ? EMPTY_KEY : k) ^ flip;
+            ok[pos] = (s == g.cap ? EMPTY_KEY : kreg[p]) ^ flip;
             oslot[pos] = s;
         }
     }
