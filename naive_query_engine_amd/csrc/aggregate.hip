@@ -942,8 +942,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     }
     // ---- predicate
     DevColumn pred_col; // keeps a materialised predicate alive
+    bool pred_may_fault = false;
     if (has_pred) {
         ExprInfo pinfo = analyze_expr(in, pred, pred_nodes);
+        pred_may_fault = pinfo.may_fault;
         if (pinfo.out_dtype != NQE_BOOLEAN)
             fail(NQE_ERR_NOT_SUPPORTED, "predicate is not a BooleanArray (selection.rs:61 unwrap panics)");
         if (pinfo.simple) {
@@ -1005,6 +1007,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         uint32_t tcap = cap;
         if (dense) tcap = uint32_t(std::min<int64_t>(int64_t(PARTS) * (level2 ? SUB : 1) * 4097, std::max<int64_t>(in->rows, 1)));
         TableBufs tb = make_table(ctx, tcap, V, !grouped, dense);
+        // an un-grouped aggregate whose passes all took the fast kernel (no flag argument) under a predicate that cannot fault
+        bool flagless = !grouped && !pred_may_fault;
         for (int v0 = 0; v0 < std::max(V, 1); v0 += NV) {
             a.nv = std::min(NV, V - v0);
             if (a.nv < 0) a.nv = 0;
@@ -1201,9 +1205,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
                     launch(ctx, "agg_ungrouped_fast", pick_ungrouped_fast(up, a.nv, vf64, uvnull), dim3(grid), dim3(AGG_BLOCK), 0, a, ufp,
                            (Partial *)partials->ptr);
-                } else
-                launch(ctx, "agg_ungrouped", agg_ungrouped_kernel, dim3(grid), dim3(AGG_BLOCK), 0, a, (Partial *)partials->ptr,
-                       ctx->d_flags);
+                } else {
+                    flagless = false;
+                    launch(ctx, "agg_ungrouped", agg_ungrouped_kernel, dim3(grid), dim3(AGG_BLOCK), 0, a, (Partial *)partials->ptr,
+                           ctx->d_flags);
+                }
                 launch(ctx, "agg_ungrouped_fold", agg_ungrouped_fold_kernel, dim3(1), dim3(64), 0,
                        (const Partial *)partials->ptr, grid, a.nv, v0, tb.g);
             }
@@ -1222,7 +1228,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                    (uint32_t *)pre.slots->ptr, reinterpret_cast<uint32_t *>(ctx->d_flags + NQE_FLAG_GROUP_COUNT));
         }
         int f[NQE_NUM_FLAGS];
-        if (ranked.out) flags_read_mirrored(ctx, f);
+        if (flagless) std::memset(f, 0, sizeof(f)); // nothing on this path raises a flag and the result has exactly one row: no read-back
+        else if (ranked.out) flags_read_mirrored(ctx, f);
         else flags_read(ctx, f);
         if (pre.keys) pre.G = int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT]));
         if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
