@@ -73,7 +73,14 @@ def main():
         torch.cuda.set_device(local_rank)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
-    ctx = capi.Context(local_rank)
+    if world > 1 or force_dist:
+        # one stream for the kernels and for torch's collectives' dependencies: the exchange needs no host synchronisation
+        # between pack, all-gather and merge
+        ts = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(ts)
+        ctx = capi.Context(local_rank, stream=ts.cuda_stream)
+    else:
+        ctx = capi.Context(local_rank)
 
     default_rows = {"headline": 10**9, "c3": 10**9, "c2": 10**8, "c4": 10**8}[args.workload]
     n = args.rows or default_rows

@@ -329,6 +329,14 @@ nqe_status nqe_aggregate_partial(nqe_ctx *ctx, const nqe_table *in, const nqe_ex
 nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, const nqe_table *const *keys,
                                int32_t n, const nqe_aggregate *aggs, int32_t num_aggs, nqe_table **out,
                                nqe_table **keys_out);
+/* The same merge straight from an all-gathered buffer of nqe_table_pack_words parts (part p = [key column when `grouped`] +
+ * {count,sum,min,max} per aggregate, `stride_rows` words per column, + 1 header word = the part's row count): the counts
+ * are read on the device, so the whole exchange + merge costs the host one wait.  When some part's header exceeds
+ * `stride_rows` (its sender shipped the header only) the call returns NQE_OK with *out = NULL and the caller exchanges
+ * exact-size tables instead (nqe_aggregate_merge).  Replaces the same merge loop as nqe_aggregate_merge. */
+nqe_status nqe_aggregate_merge_packed(nqe_ctx *ctx, const void *gathered_device, int32_t num_parts, int64_t stride_rows,
+                                      int32_t grouped, int32_t key_dtype, const nqe_aggregate *aggs, int32_t num_aggs,
+                                      nqe_table **out, nqe_table **keys_out);
 
 /* ------------------------------------------------------------------ hash join
  * HashJoin::execute = build() + probe() (hash_join.rs:124-254, :280-284) for one left

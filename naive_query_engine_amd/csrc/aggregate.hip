@@ -695,6 +695,37 @@ __global__ void merge_states_kernel(GroupTable g, const uint64_t *keys, int64_t 
     }
 }
 
+// the same merge straight from an all-gathered nqe_table_pack_words buffer: part p = `ncols` column segments of `stride` words
+// (key first when nk = 1, then {count, sum, min, max} per aggregate) + one header word = its row count, which is read HERE — the
+// host never needs the counts, so the exchange costs no read-back of its own.  A header beyond the stride (the sender took the
+// exact-size path) raises NQE_FLAG_OOB.
+__global__ void merge_packed_kernel(GroupTable g, const uint64_t *src, int nparts, int64_t stride, int nk, int naggs, int *flags) {
+    const int ncols = nk + 4 * naggs;
+    const int64_t part_words = int64_t(ncols) * stride + 1;
+    const int64_t nthreads = int64_t(gridDim.x) * blockDim.x;
+    for (int p = 0; p < nparts; ++p) {
+        const uint64_t *base = src + int64_t(p) * part_words;
+        const uint64_t rows = base[int64_t(ncols) * stride];
+        if (rows > uint64_t(stride)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&flags[NQE_FLAG_OOB], 1);
+            continue;
+        }
+        for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < int64_t(rows); r += nthreads) {
+            int64_t slot = nk ? global_find_or_insert(g, base[r], flags) : 0;
+            if (slot < 0) continue;
+            for (int i = 0; i < naggs; ++i) {
+                const uint64_t *st = base + int64_t(nk + 4 * i) * stride + r;
+                uint64_t cnt = st[0];
+                double sum = u2d(st[stride]);
+                double mn = u2d(st[2 * stride]);
+                double mx = u2d(st[3 * stride]);
+                bool nan = mx != mx;
+                global_update(g, slot, i, cnt, sum, true, f64_to_ord(mn), nan ? f64_to_ord(-DBL_MAX) : f64_to_ord(mx), true, nan);
+            }
+        }
+    }
+}
+
 __global__ void iota_slots_kernel(uint32_t *out, int64_t n) {
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) out[i] = uint32_t(i);
 }
@@ -1359,6 +1390,52 @@ nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, con
     }
     *out = r.out.release();
     if (keys_out) *keys_out = r.keys.release();
+    NQE_API_END()
+}
+
+nqe_status nqe_aggregate_merge_packed(nqe_ctx *ctx, const void *gathered_device, int32_t num_parts, int64_t stride_rows, int32_t grouped,
+                                      int32_t key_dtype, const nqe_aggregate *aggs, int32_t num_aggs, nqe_table **out, nqe_table **keys_out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !gathered_device || num_parts <= 0 || stride_rows <= 0 || !out || num_aggs < 0 || num_aggs > 16 || (num_aggs > 0 && !aggs) ||
+        (grouped && !keys_out))
+        fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    *out = nullptr;
+    if (keys_out) *keys_out = nullptr;
+    std::vector<int> vslot;
+    for (int i = 0; i < num_aggs; ++i) vslot.push_back(i);
+    const int64_t bound = int64_t(num_parts) * stride_rows;
+    uint32_t sized_cap = 1;
+    if (grouped) {
+        sized_cap = 4096;
+        while (int64_t(sized_cap) < 2 * bound) sized_cap <<= 1;
+    }
+    // small table first (the sharded headline merges world x 1024 rows of the same 1024 keys): single-launch tail, one read-back
+    uint32_t cap = grouped ? std::min(sized_cap, RANK_MAX_CAP) : 1u;
+    for (;;) {
+        flags_reset(ctx);
+        TableBufs tb = make_table(ctx, cap, num_aggs, !grouped);
+        launch(ctx, "agg_merge_packed", merge_packed_kernel, dim3(stream_grid(ctx, std::min<int64_t>(bound, int64_t(1) << 16), 256)), dim3(256), 0, tb.g,
+               (const uint64_t *)gathered_device, int(num_parts), stride_rows, grouped ? 1 : 0, int(num_aggs), ctx->d_flags);
+        AggResult r;
+        int f[NQE_NUM_FLAGS];
+        const bool ranked = grouped && cap <= RANK_MAX_CAP;
+        if (ranked) {
+            r = emit_ranked(ctx, tb, key_dtype, aggs, num_aggs, vslot, false);
+            flags_read_mirrored(ctx, f);
+        } else
+            flags_read(ctx, f);
+        if (f[NQE_FLAG_OOB]) break; // some part was sent header-only: the caller takes the exact-size path (*out stays NULL)
+        if (f[NQE_FLAG_TABLE_FULL]) {
+            if (cap >= sized_cap) fail(NQE_ERR_OUT_OF_MEMORY, "device hash table overflow");
+            cap = sized_cap;
+            continue;
+        }
+        if (ranked) set_group_count(r, int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT])));
+        else r = emit(ctx, tb, grouped != 0, key_dtype, aggs, num_aggs, vslot, false);
+        *out = r.out.release();
+        if (keys_out) *keys_out = r.keys.release();
+        break;
+    }
     NQE_API_END()
 }
 
