@@ -532,7 +532,8 @@ __global__ void __launch_bounds__(256) collect_kernel(GroupTable g, uint64_t *ou
 
 struct FinalizeArgs {
     int32_t naggs;
-    int32_t partial; // 1: emit raw state (4 columns per aggregate)
+    int32_t partial; // 1: emit raw state (4 columns per DISTINCT value column = table slot: count, sum, min, max)
+    int32_t nslots;  // distinct value columns (partial mode)
     int32_t func[16];
     int32_t vslot[16];
     uint64_t *out[64];
@@ -542,6 +543,16 @@ struct FinalizeArgs {
 // sum, avg, min, max of one column are five outputs of ONE random access per array, not of five).
 __device__ __forceinline__ void finalize_row(const GroupTable &g, uint32_t s, int64_t r, const FinalizeArgs &f) {
     const size_t slots = size_t(g.cap) + 1;
+    if (f.partial) { // the raw state of every value column, once (five aggregates over one column exchange 4 words, not 20)
+        for (int v = 0; v < f.nslots; ++v) {
+            const size_t o = size_t(v) * slots + s;
+            f.out[4 * v + 0][r] = g.cnt[o];
+            f.out[4 * v + 1][r] = d2u(g.sum[o]);
+            f.out[4 * v + 2][r] = d2u(ord_to_f64(g.mn[o]));
+            f.out[4 * v + 3][r] = d2u(g.nan[o] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(g.mx[o]));
+        }
+        return;
+    }
     int cached = -1;
     uint64_t cnt = 0;
     double sum = 0, mn = 0, mx = 0;
@@ -554,12 +565,7 @@ __device__ __forceinline__ void finalize_row(const GroupTable &g, uint32_t s, in
             mn = ord_to_f64(g.mn[o]);
             mx = g.nan[o] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(g.mx[o]);
         }
-        if (f.partial) {
-            f.out[4 * i + 0][r] = cnt;
-            f.out[4 * i + 1][r] = d2u(sum);
-            f.out[4 * i + 2][r] = d2u(mn);
-            f.out[4 * i + 3][r] = d2u(mx);
-        } else {
+        {
             uint64_t w;
             switch (f.func[i]) {
             case NQE_AGG_COUNT: w = cnt; break;                                   // count.rs:76
@@ -819,6 +825,22 @@ AggPlan plan_aggs(const nqe_table *in, const nqe_aggregate *aggs, int naggs) {
     return p;
 }
 
+// aggregate -> value slot from the aggregate list alone (distinct columns in order of first appearance: what plan_aggs assigns):
+// the layout of the partial state, shared by the producer and the merges
+std::vector<int> slots_of_aggs(const nqe_aggregate *aggs, int naggs, int *nslots) {
+    std::vector<int> cols, vslot;
+    for (int i = 0; i < naggs; ++i) {
+        auto it = std::find(cols.begin(), cols.end(), aggs[i].column);
+        if (it == cols.end()) {
+            cols.push_back(aggs[i].column);
+            vslot.push_back(int(cols.size()) - 1);
+        } else
+            vslot.push_back(int(it - cols.begin()));
+    }
+    *nslots = int(cols.size());
+    return vslot;
+}
+
 struct AggResult {
     std::unique_ptr<nqe_table> out, keys;
 };
@@ -844,16 +866,19 @@ FinalizeArgs alloc_outputs(nqe_ctx *ctx, AggResult &r, int64_t rows, const nqe_a
     for (int i = 0; i < naggs; ++i) {
         f.func[i] = aggs[i].func;
         f.vslot[i] = vslot[size_t(i)];
-        if (partial) {
-            const int dts[4] = {NQE_UINT64, NQE_FLOAT64, NQE_FLOAT64, NQE_FLOAT64};
-            for (int k = 0; k < 4; ++k) {
-                r.out->cols.push_back(make_word_column(ctx, dts[k], rows, false));
-                f.out[4 * i + k] = (uint64_t *)r.out->cols.back().values->ptr;
-            }
-        } else {
+        f.nslots = std::max(f.nslots, f.vslot[i] + 1);
+        if (!partial) {
             r.out->cols.push_back(make_word_column(ctx, aggs[i].func == NQE_AGG_COUNT ? NQE_UINT64 : NQE_FLOAT64, rows, false));
             f.out[i] = (uint64_t *)r.out->cols.back().values->ptr;
         }
+    }
+    if (partial) {
+        const int dts[4] = {NQE_UINT64, NQE_FLOAT64, NQE_FLOAT64, NQE_FLOAT64};
+        for (int v = 0; v < f.nslots; ++v)
+            for (int k = 0; k < 4; ++k) {
+                r.out->cols.push_back(make_word_column(ctx, dts[k], rows, false));
+                f.out[4 * v + k] = (uint64_t *)r.out->cols.back().values->ptr;
+            }
     }
     return f;
 }
@@ -1344,8 +1369,10 @@ nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, con
     const bool grouped = keys != nullptr && keys[0] != nullptr;
     int key_dtype = NQE_INT64;
     int64_t total = 0;
+    int V = 0;
+    const std::vector<int> vslot = slots_of_aggs(aggs, num_aggs, &V);
     for (int k = 0; k < n; ++k) {
-        if (!states[k] || int(states[k]->cols.size()) != 4 * num_aggs) fail(NQE_ERR_INVALID_ARGUMENT, "state table shape mismatch");
+        if (!states[k] || int(states[k]->cols.size()) != 4 * V) fail(NQE_ERR_INVALID_ARGUMENT, "state table shape mismatch");
         if (grouped) {
             if (!keys[k] || keys[k]->cols.size() != 1 || keys[k]->rows != states[k]->rows)
                 fail(NQE_ERR_INVALID_ARGUMENT, "keys table shape mismatch");
@@ -1359,20 +1386,18 @@ nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, con
         cap = 4096;
         while (int64_t(cap) < 2 * total) cap <<= 1;
     }
-    TableBufs tb = make_table(ctx, cap, num_aggs, !grouped);
-    std::vector<int> vslot;
-    for (int i = 0; i < num_aggs; ++i) vslot.push_back(i);
-    BufRef ptrs = dev_alloc(ctx, size_t(4 * std::max(num_aggs, 1)) * sizeof(void *));
+    TableBufs tb = make_table(ctx, cap, V, !grouped);
+    BufRef ptrs = dev_alloc(ctx, size_t(4 * std::max(V, 1)) * sizeof(void *));
     for (int k = 0; k < n; ++k) {
         int64_t rows = states[k]->rows;
-        if (rows == 0 || num_aggs == 0) {
+        if (rows == 0 || V == 0) {
             if (rows && grouped) { /* keys still need inserting */ } else continue;
         }
-        std::vector<const uint64_t *> h(size_t(4 * std::max(num_aggs, 1)), nullptr);
-        for (int c = 0; c < 4 * num_aggs; ++c) h[size_t(c)] = states[k]->cols[size_t(c)].words();
+        std::vector<const uint64_t *> h(size_t(4 * std::max(V, 1)), nullptr);
+        for (int c = 0; c < 4 * V; ++c) h[size_t(c)] = states[k]->cols[size_t(c)].words();
         NQE_HIP_CHECK(hipMemcpyAsync(ptrs->ptr, h.data(), h.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
         launch(ctx, "agg_merge_states", merge_states_kernel, dim3(stream_grid(ctx, rows, 256)), dim3(256), 0, tb.g,
-               grouped ? keys[k]->cols[0].words() : (const uint64_t *)nullptr, rows, num_aggs,
+               grouped ? keys[k]->cols[0].words() : (const uint64_t *)nullptr, rows, V,
                (const uint64_t *const *)ptrs->ptr, ctx->d_flags);
         sync(ctx); // `h` / ptrs are reused by the next partial
     }
@@ -1401,8 +1426,8 @@ nqe_status nqe_aggregate_merge_packed(nqe_ctx *ctx, const void *gathered_device,
         fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
     *out = nullptr;
     if (keys_out) *keys_out = nullptr;
-    std::vector<int> vslot;
-    for (int i = 0; i < num_aggs; ++i) vslot.push_back(i);
+    int V = 0;
+    const std::vector<int> vslot = slots_of_aggs(aggs, num_aggs, &V);
     const int64_t bound = int64_t(num_parts) * stride_rows;
     uint32_t sized_cap = 1;
     if (grouped) {
@@ -1413,9 +1438,9 @@ nqe_status nqe_aggregate_merge_packed(nqe_ctx *ctx, const void *gathered_device,
     uint32_t cap = grouped ? std::min(sized_cap, RANK_MAX_CAP) : 1u;
     for (;;) {
         flags_reset(ctx);
-        TableBufs tb = make_table(ctx, cap, num_aggs, !grouped);
+        TableBufs tb = make_table(ctx, cap, V, !grouped);
         launch(ctx, "agg_merge_packed", merge_packed_kernel, dim3(stream_grid(ctx, std::min<int64_t>(bound, int64_t(1) << 16), 256)), dim3(256), 0, tb.g,
-               (const uint64_t *)gathered_device, int(num_parts), stride_rows, grouped ? 1 : 0, int(num_aggs), ctx->d_flags);
+               (const uint64_t *)gathered_device, int(num_parts), stride_rows, grouped ? 1 : 0, V, ctx->d_flags);
         AggResult r;
         int f[NQE_NUM_FLAGS];
         const bool ranked = grouped && cap <= RANK_MAX_CAP;

@@ -284,7 +284,7 @@ def unpack_words_numpy(gathered: np.ndarray, ncols: int, stride: int) -> Tuple[L
 
 def merge_partials_numpy(keys_list: Sequence[Optional[np.ndarray]], states_list: Sequence[Sequence[np.ndarray]]):
     """Host restatement of the partial merge rule (used by the CPU gloo tests to check the exchange;
-    the product path merges on the GPU with nqe_aggregate_merge).  states = per aggregate
+    the product path merges on the GPU with nqe_aggregate_merge).  states = per distinct aggregate column
     (count u64, sum f64, min f64, max f64)."""
     grouped = keys_list[0] is not None
     acc = {}
