@@ -49,8 +49,27 @@ def random_pred(rng):
     return _random_tree(rng, int(rng.integers(1, 4)), "b")
 
 
+def random_chain_key(rng, c=0, unsigned=False):
+    """one or two integer operations with literals over one column (the fast kernels' interpreted key variant when it cannot fault,
+    the general kernel when it can: zero / -1 divisors, literal-on-the-left divisions)"""
+    lit = lit_u64 if unsigned else lit_i64
+    lo = 0 if unsigned else -9
+    e = col(c)
+    for _ in range(int(rng.integers(1, 3))):
+        op = [Operator.Plus, Operator.Minus, Operator.Multiply, Operator.Divide, Operator.Modulos][int(rng.integers(0, 5))]
+        v = int(rng.choice([lo, 0, 1, 2, 3, 7, 16, 1000, 4097])) if op in (Operator.Divide, Operator.Modulos) else int(rng.integers(lo, 50))
+        if op in (Operator.Divide, Operator.Modulos) and v == 0 and rng.random() < 0.8:
+            v = 5
+        e = binop(lit(abs(v) if unsigned else v), op, e) if rng.random() < 0.15 else binop(e, op, lit(abs(v) if unsigned else v))
+    return e
+
+
 def random_key(rng):
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 8))
+    if kind == 6:
+        return random_chain_key(rng, 0)
+    if kind == 7:
+        return random_chain_key(rng, 3, unsigned=True)
     if kind == 0:
         return col(1)
     if kind == 1:
@@ -151,9 +170,12 @@ def test_fuzz_many_groups_partitioned_paths(ctx, seed):
         pred = random_pred(rng) if case else None
         vcols = [1, 2, 3][: int(rng.integers(1, 4))]
         aggs = [(f, c) for c in vcols for f in (AggregateFunc.Count, AggregateFunc.Sum, AggregateFunc.Min, AggregateFunc.Max, AggregateFunc.Avg)]
-        what = f"seed {seed} case {case}: n={n} groups={groups} nulls={null_frac} pred={pred!r} vcols={vcols}"
-        got, exp = both(lambda: ctx.aggregate(t, aggs, group_nodes=flat(col(0)), pred_nodes=flat(pred)).to_host(),
-                        lambda: orc.aggregate([cols], aggs, group_nodes=flat(col(0)), pred_nodes=flat(pred))[0], what)
+        key = col(0) if case < 2 else [binop(binop(col(0), Operator.Multiply, lit_i64(3)), Operator.Plus, lit_i64(1)),
+                                       binop(binop(col(0), Operator.Plus, lit_i64(7)), Operator.Modulos, lit_i64(max(groups // 2, 1) + 1)),
+                                       binop(col(0), Operator.Divide, lit_i64(2))][int(rng.integers(0, 3))]
+        what = f"seed {seed} case {case}: n={n} groups={groups} nulls={null_frac} pred={pred!r} vcols={vcols} key={key!r}"
+        got, exp = both(lambda: ctx.aggregate(t, aggs, group_nodes=flat(key), pred_nodes=flat(pred)).to_host(),
+                        lambda: orc.aggregate([cols], aggs, group_nodes=flat(key), pred_nodes=flat(pred))[0], what)
         if exp is not None:
             exact = [i for i, (f, _) in enumerate(aggs) if f == AggregateFunc.Count]
             assert_rows_multiset_equal(got, exp, RTOL, exact_cols=exact, what=what)
