@@ -152,7 +152,8 @@ def main():
             return ctx.hash_join_probe(jt, fact, 0)
 
         metric = "hash_join_probe_rows_per_s"
-        desc = f"dim(id,attr) 10^6 rows (LEFT/build) join fact(key,val) {n} rows per GPU (RIGHT/probe), 1 match per probe row"
+        desc = (f"dim(id,attr) 10^6 rows (LEFT/build) join fact(key,val) {n} rows per GPU (RIGHT/probe), 1 match per probe row; 4 output columns "
+                "(SURVEY 8d: 16 B read + 32 B written per probe row; the output's two key columns are one shared buffer, so 24 B are physically written)")
 
     def barrier():
         if world > 1 or force_dist:
