@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(1024) copy_rw(const uint64_t *in, uint64_t *ou
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = base + int64_t(u) * blockDim.x + threadIdx.x;
+            if (WR == 0 && x[u] == 0x123456789abcdefull) outp[0] = x[u]; // read-only variant: keep the loads alive
             if (i < n) {
 #pragma unroll
                 for (int w = 0; w < WR; ++w) {
@@ -122,6 +123,13 @@ int main() {
             if (run<4, 0>(a, b, n, out, bpc, th)) return 1;
             if (run<8, 0>(a, b, n, out, bpc, th)) return 1;
             if (run<4, 1>(a, b, n, out, bpc, th)) return 1;
+        }
+    }
+    // one 0.8 GB column (the predicate pass of a 10^8-row selection): how much of the ceiling a 0.1 ms launch can reach at all
+    for (int bpc : {1, 2, 8}) {
+        for (int th : {256, 1024}) {
+            if (run_rw<8, 1, 0, 0>(b, a, 100000000, bpc, th)) return 1;
+            if (run_rw<16, 1, 0, 0>(b, a, 100000000, bpc, th)) return 1;
         }
     }
     // read:write mixes at 2e8 rows per column (1.6 GB each): fill, 1:1 copy, the join's 2:4, the selection's 2:2
