@@ -126,6 +126,7 @@ int main() {
         }
     }
     // one 0.8 GB column (the predicate pass of a 10^8-row selection): how much of the ceiling a 0.1 ms launch can reach at all
+    // (back-to-back repetitions: up to a third of the column may still sit in the 256 MB Infinity Cache, so this is an upper bound)
     for (int bpc : {1, 2, 8}) {
         for (int th : {256, 1024}) {
             if (run_rw<8, 1, 0, 0>(b, a, 100000000, bpc, th)) return 1;
