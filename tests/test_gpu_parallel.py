@@ -37,6 +37,10 @@ def plan(mod=128):
 
     f = fields("id", "v")
     aggs = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1), (AggregateFunc.Min, 1), (AggregateFunc.Max, 1)]
+    if mod == "disjoint":
+        # 8192 groups, the two ranks hold 4096 each and none in common: every partial fits the exchange buffer, their union
+        # does not fit the merge's small first-attempt table (TABLE_FULL → retry with the worst-case table)
+        return aggs, binop(col(0), Operator.Divide, lit_i64(N // 8192 + 1)).flatten(f), binop(col(0), Operator.GtEq, lit_i64(0)).flatten(f)
     key = binop(col(0), Operator.Modulos, lit_i64(mod)).flatten(f) if mod else None
     return aggs, key, binop(col(0), Operator.Lt, lit_i64(N // 2)).flatten(f)
 
@@ -67,7 +71,7 @@ def worker(rank, world, port, q, mod):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mod", [128, 6000, None])  # one-collective exchange / more groups than the exchange buffer / un-grouped
+@pytest.mark.parametrize("mod", [128, 6000, None, "disjoint"])  # one-collective exchange / more groups than the exchange buffer / un-grouped / union overflows the small merge table
 def test_sharded_aggregate_two_ranks_one_gpu(mod):
     import torch.multiprocessing as mp
 
@@ -92,7 +96,8 @@ def test_sharded_aggregate_two_ranks_one_gpu(mod):
     ctx = capi.Context(0)
     single = np.stack([c.to_numpy().astype(np.float64) for c in ctx.aggregate(ctx.table_from_host(cols), aggs, group_nodes=key, pred_nodes=pred).to_host()], axis=1)
     for rank, keys, res in results:
-        assert keys == (list(range(mod)) if mod else None)
+        nkeys = (N - 1) // (N // 8192 + 1) + 1 if mod == "disjoint" else mod
+        assert keys == (list(range(nkeys)) if mod else None)
         got = np.array(res)
         assert np.allclose(got, single, rtol=1e-9, atol=0)          # rows are key-sorted on both sides
         g = got[np.lexsort(got.T[::-1])]
