@@ -73,7 +73,14 @@ def main():
         torch.cuda.set_device(local_rank)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
-    ctx = capi.Context(local_rank)
+    if world > 1 or force_dist:
+        # one stream for the kernels and for torch's collectives' dependencies: the exchange needs no host synchronisation
+        # between pack, all-gather and merge
+        ts = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(ts)
+        ctx = capi.Context(local_rank, stream=ts.cuda_stream)
+    else:
+        ctx = capi.Context(local_rank)
 
     default_rows = {"headline": 10**9, "c3": 10**9, "c2": 10**8, "c4": 10**8}[args.workload]
     n = args.rows or default_rows
@@ -145,7 +152,8 @@ def main():
             return ctx.hash_join_probe(jt, fact, 0)
 
         metric = "hash_join_probe_rows_per_s"
-        desc = f"dim(id,attr) 10^6 rows (LEFT/build) join fact(key,val) {n} rows per GPU (RIGHT/probe), 1 match per probe row"
+        desc = (f"dim(id,attr) 10^6 rows (LEFT/build) join fact(key,val) {n} rows per GPU (RIGHT/probe), 1 match per probe row; 4 output columns "
+                "(SURVEY 8d: 16 B read + 32 B written per probe row; the output's two key columns are one shared buffer, so 24 B are physically written)")
 
     def barrier():
         if world > 1 or force_dist:
@@ -172,8 +180,8 @@ def main():
         kern_ms += a_ms
         launches += a_n
     breakdown = {}
-    for kn in ("agg_grouped", "agg_table_init", "agg_collect", "agg_finalize", "bitonic_small", "keep_from_simple", "compact_expr",
-               "compact_column", "compact_gather", "join_probe_unique", "join_probe_presence", "join_fused_write", "join_probe_count", "join_probe_write", "scan_chunk", "scan_add"):
+    for kn in ("agg_grouped", "agg_table_init", "agg_collect", "agg_finalize", "agg_rank_finalize", "bitonic_small", "keep_from_simple", "compact_expr",
+               "compact_column", "compact_gather", "join_probe_unique", "join_probe_presence", "join_fused_write", "join_probe_count", "join_probe_write", "scan_chunk", "scan_add", "scan_single"):
         b_ms, b_n = ctx.timing_query(kn)
         if b_n:
             breakdown[kn] = {"ms_per_step": b_ms / args.steps, "launches_per_step": b_n / args.steps}

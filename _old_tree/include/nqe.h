@@ -38,6 +38,10 @@
  *     device flags back (and thereby synchronises) before returning.  Device
  *     pointers from nqe_table_column may be handed to another stream only after
  *     nqe_ctx_synchronize.
+ *   - when a call has to wait for the device (a row count, the flags) the host
+ *     thread polls the stream for up to 5 ms before it blocks: the waits sit
+ *     behind kernels of microseconds to a few milliseconds, and an
+ *     interrupt-driven wake-up would add its latency to every operator.
  */
 #ifndef NQE_H
 #define NQE_H
@@ -311,10 +315,12 @@ nqe_status nqe_aggregate_execute(nqe_ctx *ctx, const nqe_table *in, const nqe_ex
                                  const nqe_aggregate *aggs, int32_t num_aggs, nqe_table **out,
                                  nqe_table **keys_out);
 /* Partial-state form used to merge per-GPU / per-batch partials:
- * output columns per aggregate are the raw state, in this order for EVERY aggregate i:
- *   4*i+0 count (UInt64, non-null values), 4*i+1 sum (Float64), 4*i+2 min (Float64),
- *   4*i+3 max (Float64; NaN if any NaN was seen),
- * plus keys in `keys_out` (required when grouped). */
+ * the output columns are the raw state of every DISTINCT aggregate column (slot v = the v-th
+ * distinct `column` of `aggs` in order of first appearance; count,sum,avg,min,max over one
+ * column exchange four words per group, not twenty), in this order for every slot v:
+ *   4*v+0 count (UInt64, non-null values), 4*v+1 sum (Float64), 4*v+2 min (Float64),
+ *   4*v+3 max (Float64; NaN if any NaN was seen),
+ * plus keys in `keys_out` (required when grouped).  The merges take the same `aggs`. */
 nqe_status nqe_aggregate_partial(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred,
                                  int32_t pred_nodes, const nqe_expr_node *group, int32_t group_nodes,
                                  const nqe_aggregate *aggs, int32_t num_aggs, nqe_table **state_out,
@@ -325,6 +331,14 @@ nqe_status nqe_aggregate_partial(nqe_ctx *ctx, const nqe_table *in, const nqe_ex
 nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, const nqe_table *const *keys,
                                int32_t n, const nqe_aggregate *aggs, int32_t num_aggs, nqe_table **out,
                                nqe_table **keys_out);
+/* The same merge straight from an all-gathered buffer of nqe_table_pack_words parts (part p = [key column when `grouped`] +
+ * {count,sum,min,max} per distinct aggregate column, `stride_rows` words per column, + 1 header word = the part's row count): the counts
+ * are read on the device, so the whole exchange + merge costs the host one wait.  When some part's header exceeds
+ * `stride_rows` (its sender shipped the header only) the call returns NQE_OK with *out = NULL and the caller exchanges
+ * exact-size tables instead (nqe_aggregate_merge).  Replaces the same merge loop as nqe_aggregate_merge. */
+nqe_status nqe_aggregate_merge_packed(nqe_ctx *ctx, const void *gathered_device, int32_t num_parts, int64_t stride_rows,
+                                      int32_t grouped, int32_t key_dtype, const nqe_aggregate *aggs, int32_t num_aggs,
+                                      nqe_table **out, nqe_table **keys_out);
 
 /* ------------------------------------------------------------------ hash join
  * HashJoin::execute = build() + probe() (hash_join.rs:124-254, :280-284) for one left

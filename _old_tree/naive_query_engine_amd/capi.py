@@ -26,7 +26,7 @@ SYMBOLS = [
     "nqe_table_download_column", "nqe_table_project", "nqe_table_slice", "nqe_table_concat", "nqe_table_pack_words",
     "nqe_table_unpack_words", "nqe_csv_infer_schema", "nqe_csv_read", "nqe_expr_evaluate",
     "nqe_filter", "nqe_selection_execute", "nqe_projection_execute", "nqe_selection_projection_execute",
-    "nqe_aggregate_execute", "nqe_aggregate_partial", "nqe_aggregate_merge", "nqe_hash_join_execute",
+    "nqe_aggregate_execute", "nqe_aggregate_partial", "nqe_aggregate_merge", "nqe_aggregate_merge_packed", "nqe_hash_join_execute",
     "nqe_hash_join_build", "nqe_hash_join_probe", "nqe_join_table_release", "nqe_take", "nqe_synth_fill",
     "nqe_device_alloc", "nqe_device_free",
 ]
@@ -81,6 +81,7 @@ def lib():
         "nqe_aggregate_execute": (i32, [vp, vp, nodes, i32, nodes, i32, C.POINTER(NqeAggregate), i32, pvp, pvp]),
         "nqe_aggregate_partial": (i32, [vp, vp, nodes, i32, nodes, i32, C.POINTER(NqeAggregate), i32, pvp, pvp]),
         "nqe_aggregate_merge": (i32, [vp, pvp, pvp, i32, C.POINTER(NqeAggregate), i32, pvp, pvp]),
+        "nqe_aggregate_merge_packed": (i32, [vp, vp, i32, i64, i32, i32, C.POINTER(NqeAggregate), i32, pvp, pvp]),
         "nqe_hash_join_execute": (i32, [vp, vp, vp, i32, i32, pvp]),
         "nqe_hash_join_build": (i32, [vp, vp, i32, pvp]),
         "nqe_hash_join_probe": (i32, [vp, vp, vp, i32, pvp]),
@@ -109,6 +110,7 @@ class Context:
             raise ErrorCode(st, L.nqe_last_global_error().decode())
         self.handle = h
         self.device = device
+        self.stream = stream  # the hipStream_t the context launches on when it was given one (None: a private stream)
 
     def check(self, st: int):
         if st != 0:
@@ -253,6 +255,16 @@ class Context:
         karr = (C.c_void_p * n)(*[k.handle for k in keys]) if keys else None
         h, k = C.c_void_p(), C.c_void_p()
         self.check(lib().nqe_aggregate_merge(self.handle, sarr, karr, n, self._aggs(aggs), len(aggs), C.byref(h), C.byref(k)))
+        return Table(self, h), (Table(self, k) if k.value else None)
+
+    def aggregate_merge_packed(self, gathered_ptr: int, num_parts: int, stride_rows: int, grouped: bool, key_dtype: int, aggs):
+        """merge straight from an all-gathered pack_words buffer (row counts read on the device); None when some part was sent
+        header-only (its row count exceeds the stride) and the exact-size exchange has to be used"""
+        h, k = C.c_void_p(), C.c_void_p()
+        self.check(lib().nqe_aggregate_merge_packed(self.handle, C.c_void_p(gathered_ptr), num_parts, stride_rows, 1 if grouped else 0,
+                                                    int(key_dtype), self._aggs(aggs), len(aggs), C.byref(h), C.byref(k)))
+        if not h.value:
+            return None
         return Table(self, h), (Table(self, k) if k.value else None)
 
     def hash_join(self, left: "Table", right: "Table", left_key: int, right_key: int) -> "Table":

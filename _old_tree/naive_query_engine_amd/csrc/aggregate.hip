@@ -532,48 +532,154 @@ __global__ void __launch_bounds__(256) collect_kernel(GroupTable g, uint64_t *ou
 
 struct FinalizeArgs {
     int32_t naggs;
-    int32_t partial; // 1: emit raw state (4 columns per aggregate)
+    int32_t partial; // 1: emit raw state (4 columns per DISTINCT value column = table slot: count, sum, min, max)
+    int32_t nslots;  // distinct value columns (partial mode)
     int32_t func[16];
     int32_t vslot[16];
     uint64_t *out[64];
 };
 
-__global__ void finalize_kernel(GroupTable g, const uint32_t *sorted_slots, int64_t G, FinalizeArgs f) {
-    size_t slots = size_t(g.cap) + 1;
-    int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < G; r += stride) {
-        uint32_t s = sorted_slots ? sorted_slots[r] : 0;
-        // the state of a value column is gathered once for all aggregates over it (count, sum, avg, min, max of one column
-        // are five outputs of ONE random access per array, not of five)
-        int cached = -1;
-        uint64_t cnt = 0;
-        double sum = 0, mn = 0, mx = 0;
-        for (int i = 0; i < f.naggs; ++i) {
-            if (f.vslot[i] != cached) {
-                cached = f.vslot[i];
-                size_t o = size_t(cached) * slots + s;
-                cnt = g.cnt[o];
-                sum = g.sum[o];
-                mn = ord_to_f64(g.mn[o]);
-                mx = g.nan[o] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(g.mx[o]);
-            }
-            if (f.partial) {
-                f.out[4 * i + 0][r] = cnt;
-                f.out[4 * i + 1][r] = d2u(sum);
-                f.out[4 * i + 2][r] = d2u(mn);
-                f.out[4 * i + 3][r] = d2u(mx);
-            } else {
-                uint64_t w;
-                switch (f.func[i]) {
-                case NQE_AGG_COUNT: w = cnt; break;                                   // count.rs:76
-                case NQE_AGG_SUM: w = d2u(sum); break;                                // sum.rs:115
-                case NQE_AGG_AVG: w = d2u(sum / double(uint32_t(cnt))); break;        // avg.rs:121 (cnt is u32)
-                case NQE_AGG_MIN: w = d2u(mn); break;
-                default: w = d2u(mx); break;
-                }
-                f.out[i][r] = w;
-            }
+// output row r ← the state of table slot s.  The state of a value column is gathered once for all aggregates over it (count,
+// sum, avg, min, max of one column are five outputs of ONE random access per array, not of five).
+__device__ __forceinline__ void finalize_row(const GroupTable &g, uint32_t s, int64_t r, const FinalizeArgs &f) {
+    const size_t slots = size_t(g.cap) + 1;
+    if (f.partial) { // the raw state of every value column, once (five aggregates over one column exchange 4 words, not 20)
+        for (int v = 0; v < f.nslots; ++v) {
+            const size_t o = size_t(v) * slots + s;
+            f.out[4 * v + 0][r] = g.cnt[o];
+            f.out[4 * v + 1][r] = d2u(g.sum[o]);
+            f.out[4 * v + 2][r] = d2u(ord_to_f64(g.mn[o]));
+            f.out[4 * v + 3][r] = d2u(g.nan[o] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(g.mx[o]));
         }
+        return;
+    }
+    int cached = -1;
+    uint64_t cnt = 0;
+    double sum = 0, mn = 0, mx = 0;
+    for (int i = 0; i < f.naggs; ++i) {
+        if (f.vslot[i] != cached) {
+            cached = f.vslot[i];
+            size_t o = size_t(cached) * slots + s;
+            cnt = g.cnt[o];
+            sum = g.sum[o];
+            mn = ord_to_f64(g.mn[o]);
+            mx = g.nan[o] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(g.mx[o]);
+        }
+        {
+            uint64_t w;
+            switch (f.func[i]) {
+            case NQE_AGG_COUNT: w = cnt; break;                                   // count.rs:76
+            case NQE_AGG_SUM: w = d2u(sum); break;                                // sum.rs:115
+            case NQE_AGG_AVG: w = d2u(sum / double(uint32_t(cnt))); break;        // avg.rs:121 (cnt is u32)
+            case NQE_AGG_MIN: w = d2u(mn); break;
+            default: w = d2u(mx); break;
+            }
+            f.out[i][r] = w;
+        }
+    }
+}
+
+__global__ void finalize_kernel(GroupTable g, const uint32_t *sorted_slots, int64_t G, FinalizeArgs f) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < G; r += stride)
+        finalize_row(g, sorted_slots ? sorted_slots[r] : 0, r, f);
+}
+
+// Tail of a SMALL hashed table (the first-attempt 8192-slot table: the headline's 1024 groups): collect + sort + finalize in one
+// launch, enqueued ahead of the flag read-back.  Every workgroup compacts the occupied slots into LDS (keys in sort order + slot
+// numbers; the same deterministic order in every workgroup), owns 64 of the G entries, and ranks each by counting the keys below
+// it — keys in the table are distinct, so the ranks are exactly the permutation 0..G-1 of the sorted output.  Wave w of 16 scans
+// one sixteenth of the entries with broadcast LDS reads (lane = entry), the partial counts meet in LDS, wave 0 writes key and
+// aggregates of its entries at their ranks.  Work is G²/64 broadcast reads spread over G/64 workgroups (workgroups past the last
+// entry leave after the compaction); it replaces collect (20 µs) + single-workgroup bitonic sort (21 µs) + finalize (7.5 µs)
+// and the host round trip between them.
+constexpr uint32_t RANK_MAX_CAP = 8192;
+constexpr int RANK_SLOTS = 64;
+constexpr int RANK_WAVES = 16;
+constexpr int RANK_PASSES = (RANK_MAX_CAP + 1 + RANK_WAVES * 64 - 1) / (RANK_WAVES * 64);
+
+__global__ void __launch_bounds__(RANK_WAVES * 64) rank_finalize_kernel(GroupTable g, int signed_order, FinalizeArgs f, uint64_t *out_keys,
+                                                                        const int *flags, int *mirror) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rank_smem[];
+    const uint32_t slots = g.cap + 1;
+    uint64_t *ok = reinterpret_cast<uint64_t *>(rank_smem);        // [slots] ordered keys of the occupied slots, compacted
+    uint32_t *oslot = reinterpret_cast<uint32_t *>(ok + slots);    // [slots] their slot numbers
+    __shared__ uint32_t part[RANK_WAVES][RANK_SLOTS];
+    __shared__ uint32_t wbase[RANK_PASSES * RANK_WAVES + 1];
+    const uint64_t flip = signed_order ? 0x8000000000000000ull : 0ull;
+    const int wv = threadIdx.x / 64;
+    const int passes = int((slots + blockDim.x - 1) / blockDim.x);
+    // ---- compaction, pass 1: occupied slots per (pass, wave).  The ≤ 9 key words of a thread are requested back to back and
+    // kept in registers for pass 2 (one memory round trip for the whole table instead of one per pass)
+    uint64_t kreg[RANK_PASSES];
+#pragma unroll
+    for (int p = 0; p < RANK_PASSES; ++p) {
+        const uint32_t s = uint32_t(p) * (RANK_WAVES * 64) + threadIdx.x;
+        kreg[p] = s < slots ? g.keys[s] : EMPTY_KEY;
+    }
+#pragma unroll
+    for (int p = 0; p < RANK_PASSES; ++p) {
+        const uint64_t m = __ballot(kreg[p] != EMPTY_KEY);
+        if (lane_id() == 0 && p < passes) wbase[p * RANK_WAVES + wv] = uint32_t(__popcll(m));
+    }
+    __syncthreads();
+    if (wv == 0) { // exclusive scan of the ≤ 144 counts
+        uint32_t run = 0;
+        const int n = passes * RANK_WAVES;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane_id();
+            const uint32_t c = i < n ? wbase[i] : 0u;
+            uint32_t tot;
+            const uint32_t ex = wave_exclusive_scan(c, tot);
+            if (i < n) wbase[i] = run + ex;
+            run += tot;
+        }
+        if (lane_id() == 0) wbase[n] = run;
+    }
+    __syncthreads();
+    const uint32_t G = wbase[passes * RANK_WAVES];
+    if (blockIdx.x == 0 && threadIdx.x < NQE_NUM_FLAGS) {
+        // this is the last kernel before the read-back: the flags of the kernels before it and the group count go straight into
+        // the pinned host mirror (no device-to-host copy command between the kernel and the host's wait)
+        mirror[threadIdx.x] = threadIdx.x == NQE_FLAG_GROUP_COUNT ? int(G) : flags[threadIdx.x];
+        __threadfence_system();
+    }
+    if (blockIdx.x * RANK_SLOTS >= G) return; // no entries for this workgroup
+    // ---- compaction, pass 2
+#pragma unroll
+    for (int p = 0; p < RANK_PASSES; ++p) {
+        const uint32_t s = uint32_t(p) * (RANK_WAVES * 64) + threadIdx.x;
+        const bool used = kreg[p] != EMPTY_KEY;
+        const uint64_t m = __ballot(used);
+        if (used) {
+            const uint32_t pos = wbase[p * RANK_WAVES + wv] + uint32_t(__popcll(m & lanemask_lt()));
+            ok[pos] = (s == g.cap ? EMPTY_KEY : kreg[p]) ^ flip;
+            oslot[pos] = s;
+        }
+    }
+    __syncthreads();
+    // ---- rank
+    const uint32_t e = blockIdx.x * RANK_SLOTS + lane_id();
+    const uint64_t mine = e < G ? ok[e] : ~0ull;
+    const uint32_t seg = (G + RANK_WAVES - 1) / RANK_WAVES;
+    const uint32_t lo = uint32_t(wv) * seg < G ? uint32_t(wv) * seg : G, hi = lo + seg < G ? lo + seg : G;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    uint32_t j = lo;
+    for (; j + 4 <= hi; j += 4) {
+        c0 += ok[j] < mine;
+        c1 += ok[j + 1] < mine;
+        c2 += ok[j + 2] < mine;
+        c3 += ok[j + 3] < mine;
+    }
+    for (; j < hi; ++j) c0 += ok[j] < mine;
+    part[wv][lane_id()] = c0 + c1 + c2 + c3;
+    __syncthreads();
+    if (wv == 0 && e < G) {
+        uint32_t rank = 0;
+#pragma unroll
+        for (int w = 0; w < RANK_WAVES; ++w) rank += part[w][lane_id()];
+        out_keys[rank] = mine ^ flip;
+        finalize_row(g, oslot[e], int64_t(rank), f);
     }
 }
 
@@ -591,6 +697,37 @@ __global__ void merge_states_kernel(GroupTable g, const uint64_t *keys, int64_t 
             double mx = u2d(state_cols[4 * i + 3][r]);
             bool nan = mx != mx;
             global_update(g, slot, i, cnt, sum, true, f64_to_ord(mn), nan ? f64_to_ord(-DBL_MAX) : f64_to_ord(mx), true, nan);
+        }
+    }
+}
+
+// the same merge straight from an all-gathered nqe_table_pack_words buffer: part p = `ncols` column segments of `stride` words
+// (key first when nk = 1, then {count, sum, min, max} per aggregate) + one header word = its row count, which is read HERE — the
+// host never needs the counts, so the exchange costs no read-back of its own.  A header beyond the stride (the sender took the
+// exact-size path) raises NQE_FLAG_OOB.
+__global__ void merge_packed_kernel(GroupTable g, const uint64_t *src, int nparts, int64_t stride, int nk, int naggs, int *flags) {
+    const int ncols = nk + 4 * naggs;
+    const int64_t part_words = int64_t(ncols) * stride + 1;
+    const int64_t nthreads = int64_t(gridDim.x) * blockDim.x;
+    for (int p = 0; p < nparts; ++p) {
+        const uint64_t *base = src + int64_t(p) * part_words;
+        const uint64_t rows = base[int64_t(ncols) * stride];
+        if (rows > uint64_t(stride)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&flags[NQE_FLAG_OOB], 1);
+            continue;
+        }
+        for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < int64_t(rows); r += nthreads) {
+            int64_t slot = nk ? global_find_or_insert(g, base[r], flags) : 0;
+            if (slot < 0) continue;
+            for (int i = 0; i < naggs; ++i) {
+                const uint64_t *st = base + int64_t(nk + 4 * i) * stride + r;
+                uint64_t cnt = st[0];
+                double sum = u2d(st[stride]);
+                double mn = u2d(st[2 * stride]);
+                double mx = u2d(st[3 * stride]);
+                bool nan = mx != mx;
+                global_update(g, slot, i, cnt, sum, true, f64_to_ord(mn), nan ? f64_to_ord(-DBL_MAX) : f64_to_ord(mx), true, nan);
+            }
         }
     }
 }
@@ -688,6 +825,22 @@ AggPlan plan_aggs(const nqe_table *in, const nqe_aggregate *aggs, int naggs) {
     return p;
 }
 
+// aggregate -> value slot from the aggregate list alone (distinct columns in order of first appearance: what plan_aggs assigns):
+// the layout of the partial state, shared by the producer and the merges
+std::vector<int> slots_of_aggs(const nqe_aggregate *aggs, int naggs, int *nslots) {
+    std::vector<int> cols, vslot;
+    for (int i = 0; i < naggs; ++i) {
+        auto it = std::find(cols.begin(), cols.end(), aggs[i].column);
+        if (it == cols.end()) {
+            cols.push_back(aggs[i].column);
+            vslot.push_back(int(cols.size()) - 1);
+        } else
+            vslot.push_back(int(it - cols.begin()));
+    }
+    *nslots = int(cols.size());
+    return vslot;
+}
+
 struct AggResult {
     std::unique_ptr<nqe_table> out, keys;
 };
@@ -699,6 +852,59 @@ struct Collected {
     BufRef keys, slots;
     int64_t G = -1; // -1: not collected yet
 };
+
+// output columns of an aggregate (or its partial state) with room for `rows` rows, and the kernel arguments that fill them
+FinalizeArgs alloc_outputs(nqe_ctx *ctx, AggResult &r, int64_t rows, const nqe_aggregate *aggs, int naggs, const std::vector<int> &vslot,
+                           bool partial) {
+    r.out = std::make_unique<nqe_table>();
+    r.out->ctx = ctx;
+    r.out->rows = rows;
+    FinalizeArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.naggs = naggs;
+    f.partial = partial ? 1 : 0;
+    for (int i = 0; i < naggs; ++i) {
+        f.func[i] = aggs[i].func;
+        f.vslot[i] = vslot[size_t(i)];
+        f.nslots = std::max(f.nslots, f.vslot[i] + 1);
+        if (!partial) {
+            r.out->cols.push_back(make_word_column(ctx, aggs[i].func == NQE_AGG_COUNT ? NQE_UINT64 : NQE_FLOAT64, rows, false));
+            f.out[i] = (uint64_t *)r.out->cols.back().values->ptr;
+        }
+    }
+    if (partial) {
+        const int dts[4] = {NQE_UINT64, NQE_FLOAT64, NQE_FLOAT64, NQE_FLOAT64};
+        for (int v = 0; v < f.nslots; ++v)
+            for (int k = 0; k < 4; ++k) {
+                r.out->cols.push_back(make_word_column(ctx, dts[k], rows, false));
+                f.out[4 * v + k] = (uint64_t *)r.out->cols.back().values->ptr;
+            }
+    }
+    return f;
+}
+
+// small hashed table: one launch ranks the keys and writes the sorted outputs (rank_finalize_kernel); the columns are allocated
+// for a full table and cut to the group count once it has travelled back with the flags (set_group_count)
+AggResult emit_ranked(nqe_ctx *ctx, TableBufs &tb, int key_dtype, const nqe_aggregate *aggs, int naggs, const std::vector<int> &vslot,
+                      bool partial) {
+    const int64_t slots = int64_t(tb.g.cap) + 1;
+    AggResult r;
+    FinalizeArgs f = alloc_outputs(ctx, r, slots, aggs, naggs, vslot, partial);
+    r.keys = std::make_unique<nqe_table>();
+    r.keys->ctx = ctx;
+    r.keys->rows = slots;
+    r.keys->cols.push_back(make_word_column(ctx, key_dtype, slots, false));
+    launch(ctx, "agg_rank_finalize", rank_finalize_kernel, dim3(unsigned((slots + RANK_SLOTS - 1) / RANK_SLOTS)), dim3(RANK_WAVES * 64), size_t(slots) * 12, tb.g,
+           key_dtype == NQE_INT64 ? 1 : 0, f, (uint64_t *)r.keys->cols[0].values->ptr, (const int *)ctx->d_flags, ctx->h_flags_dev);
+    return r;
+}
+
+void set_group_count(AggResult &r, int64_t G) {
+    r.out->rows = G;
+    for (auto &c : r.out->cols) c.length = G;
+    r.keys->rows = G;
+    for (auto &c : r.keys->cols) c.length = G;
+}
 
 AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const nqe_aggregate *aggs, int naggs,
                const std::vector<int> &vslot, bool partial, const Collected *pre = nullptr) {
@@ -730,27 +936,7 @@ AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const n
                              (uint32_t *)sorted_slots->ptr, G, key_dtype == NQE_INT64);
     }
     AggResult r;
-    r.out = std::make_unique<nqe_table>();
-    r.out->ctx = ctx;
-    r.out->rows = G;
-    FinalizeArgs f;
-    std::memset(&f, 0, sizeof(f));
-    f.naggs = naggs;
-    f.partial = partial ? 1 : 0;
-    for (int i = 0; i < naggs; ++i) {
-        f.func[i] = aggs[i].func;
-        f.vslot[i] = vslot[size_t(i)];
-        if (partial) {
-            const int dts[4] = {NQE_UINT64, NQE_FLOAT64, NQE_FLOAT64, NQE_FLOAT64};
-            for (int k = 0; k < 4; ++k) {
-                r.out->cols.push_back(make_word_column(ctx, dts[k], G, false));
-                f.out[4 * i + k] = (uint64_t *)r.out->cols.back().values->ptr;
-            }
-        } else {
-            r.out->cols.push_back(make_word_column(ctx, aggs[i].func == NQE_AGG_COUNT ? NQE_UINT64 : NQE_FLOAT64, G, false));
-            f.out[i] = (uint64_t *)r.out->cols.back().values->ptr;
-        }
-    }
+    FinalizeArgs f = alloc_outputs(ctx, r, G, aggs, naggs, vslot, partial);
     if (G > 0 && naggs > 0)
         launch(ctx, "agg_finalize", finalize_kernel, dim3(stream_grid(ctx, G, 256)), dim3(256), 0, tb.g,
                grouped ? (const uint32_t *)sorted_slots->ptr : (const uint32_t *)nullptr, G, f);
@@ -812,8 +998,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     }
     // ---- predicate
     DevColumn pred_col; // keeps a materialised predicate alive
+    bool pred_may_fault = false;
     if (has_pred) {
         ExprInfo pinfo = analyze_expr(in, pred, pred_nodes);
+        pred_may_fault = pinfo.may_fault;
         if (pinfo.out_dtype != NQE_BOOLEAN)
             fail(NQE_ERR_NOT_SUPPORTED, "predicate is not a BooleanArray (selection.rs:61 unwrap panics)");
         if (pinfo.simple) {
@@ -852,11 +1040,17 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     if (a.pred_mode == 1) kp_valid_words_ok = kp_valid_words_ok && words_ok(in->cols[size_t(a.pred.col)]);
 
     const int V = int(plan.val_cols.size());
-    uint32_t cap = 1;
+    // Global table: the first attempt is SMALL (8192 slots) whatever the input size — every workgroup merges at most one LDS
+    // table's worth of groups, and unless the workgroups see different key sets their union fits, so that initialisation is
+    // 0.4 MB instead of 92 MB and the whole tail is one launch (rank_finalize_kernel).  When the union does not fit (TABLE_FULL:
+    // keys correlated with the tile→workgroup assignment, or a small input of mostly distinct keys) the retry is sized for the
+    // worst case (every workgroup inserting its own ≤4096 groups, at most one per row), as is the partitioned path.
+    uint32_t cap = 1, sized_cap = 1;
     if (grouped) {
         int64_t guess = std::min<int64_t>(std::max<int64_t>(in->rows, 1), int64_t(1) << 20);
-        cap = 4096;
-        while (int64_t(cap) < 2 * guess) cap <<= 1;
+        sized_cap = 4096;
+        while (int64_t(sized_cap) < 2 * guess) sized_cap <<= 1;
+        cap = std::min(sized_cap, RANK_MAX_CAP);
     }
     bool partition_mode = false, level2 = false, dense_ok = true;
     bool any_val_nullable = false;
@@ -869,6 +1063,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         uint32_t tcap = cap;
         if (dense) tcap = uint32_t(std::min<int64_t>(int64_t(PARTS) * (level2 ? SUB : 1) * 4097, std::max<int64_t>(in->rows, 1)));
         TableBufs tb = make_table(ctx, tcap, V, !grouped, dense);
+        // an un-grouped aggregate whose passes all took the fast kernel (no flag argument) under a predicate that cannot fault
+        bool flagless = !grouped && !pred_may_fault;
         for (int v0 = 0; v0 < std::max(V, 1); v0 += NV) {
             a.nv = std::min(NV, V - v0);
             if (a.nv < 0) a.nv = 0;
@@ -922,6 +1118,18 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                          (a.key.op_dtype[0] == NQE_INT64 || a.key.op_dtype[0] == NQE_UINT64)) {
                     if (a.key.aux[0].pow2_shift >= 0) kk = 1, fast_key = 1;
                     else if (a.key.aux[0].more >= 0) fast_key = 2; // `col % d`, d not a power of two: magic multiply
+                }
+                if (fast_key < 0 && a.key.nops >= 1) {
+                    // any other chain of integer arithmetic with literals that cannot fault (divisors: literals other than 0
+                    // and -1): the fast kernels evaluate it with the generic interpreter (KEY = 3)
+                    bool ok = true;
+                    for (int k = 0; k < a.key.nops; ++k) {
+                        const int op = a.key.op[k];
+                        ok = ok && op >= NQE_OP_PLUS && op <= NQE_OP_MODULOS && (a.key.op_dtype[k] == NQE_INT64 || a.key.op_dtype[k] == NQE_UINT64);
+                        if (op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS)
+                            ok = ok && !a.key.lit_left[k] && a.key.lit[k] != 0 && a.key.lit[k] != ~0ull;
+                    }
+                    if (ok) fast_key = 3;
                 }
                 bool plain = is_word_type(a.key_src.dtype);
                 // a Boolean predicate column without nulls (a Boolean input column, or any predicate tree evaluated by the
@@ -1053,15 +1261,21 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
                     launch(ctx, "agg_ungrouped_fast", pick_ungrouped_fast(up, a.nv, vf64, uvnull), dim3(grid), dim3(AGG_BLOCK), 0, a, ufp,
                            (Partial *)partials->ptr);
-                } else
-                launch(ctx, "agg_ungrouped", agg_ungrouped_kernel, dim3(grid), dim3(AGG_BLOCK), 0, a, (Partial *)partials->ptr,
-                       ctx->d_flags);
+                } else {
+                    flagless = false;
+                    launch(ctx, "agg_ungrouped", agg_ungrouped_kernel, dim3(grid), dim3(AGG_BLOCK), 0, a, (Partial *)partials->ptr,
+                           ctx->d_flags);
+                }
                 launch(ctx, "agg_ungrouped_fold", agg_ungrouped_fold_kernel, dim3(1), dim3(64), 0,
                        (const Partial *)partials->ptr, grid, a.nv, v0, tb.g);
             }
         }
         Collected pre;
-        if (grouped && !tb.g.dense_count && tb.g.cap <= (1u << 16)) {
+        AggResult ranked;
+        if (grouped && !tb.g.dense_count && tb.g.cap <= RANK_MAX_CAP) {
+            // first-attempt table: the whole tail (collect, sort, finalize) runs ahead of the read-back
+            ranked = emit_ranked(ctx, tb, kinfo.out_dtype, aggs, naggs, plan.vslot, partial);
+        } else if (grouped && !tb.g.dense_count && tb.g.cap <= (1u << 16)) {
             // small table: collect speculatively; the count lands in the spare flag slot and is read with the flags
             const size_t slots = size_t(tb.g.cap) + 1;
             pre.keys = dev_alloc(ctx, slots * 8);
@@ -1070,7 +1284,9 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                    (uint32_t *)pre.slots->ptr, reinterpret_cast<uint32_t *>(ctx->d_flags + NQE_FLAG_GROUP_COUNT));
         }
         int f[NQE_NUM_FLAGS];
-        flags_read(ctx, f);
+        if (flagless) std::memset(f, 0, sizeof(f)); // nothing on this path raises a flag and the result has exactly one row: no read-back
+        else if (ranked.out) flags_read_mirrored(ctx, f);
+        else flags_read(ctx, f);
         if (pre.keys) pre.G = int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT]));
         if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
@@ -1082,6 +1298,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
         if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode) {
             partition_mode = true; // a workgroup table overflowed: redo with hash-partitioned rows
+            cap = std::max(cap, sized_cap);
             flags_reset(ctx);
             continue;
         }
@@ -1092,11 +1309,16 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
         if (f[NQE_FLAG_TABLE_FULL]) {
             if (cap >= (1u << 31) || attempt > 8) fail(NQE_ERR_OUT_OF_MEMORY, "group table overflow");
-            cap <<= 3;
+            cap = cap < sized_cap ? sized_cap : cap << 3;
             flags_reset(ctx);
             continue;
         }
-        AggResult res = emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial, &pre);
+        AggResult res;
+        if (ranked.out) {
+            set_group_count(ranked, int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT])));
+            res = std::move(ranked);
+        } else
+            res = emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial, &pre);
         if (utf8_key && res.keys) { // keys_out: the strings of the representative rows
             DevColumn codes = res.keys->cols[0];
             res.keys->cols[0] = take_utf8(ctx, utf8_src, (const int64_t *)codes.words(), codes.length, false);
@@ -1147,8 +1369,10 @@ nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, con
     const bool grouped = keys != nullptr && keys[0] != nullptr;
     int key_dtype = NQE_INT64;
     int64_t total = 0;
+    int V = 0;
+    const std::vector<int> vslot = slots_of_aggs(aggs, num_aggs, &V);
     for (int k = 0; k < n; ++k) {
-        if (!states[k] || int(states[k]->cols.size()) != 4 * num_aggs) fail(NQE_ERR_INVALID_ARGUMENT, "state table shape mismatch");
+        if (!states[k] || int(states[k]->cols.size()) != 4 * V) fail(NQE_ERR_INVALID_ARGUMENT, "state table shape mismatch");
         if (grouped) {
             if (!keys[k] || keys[k]->cols.size() != 1 || keys[k]->rows != states[k]->rows)
                 fail(NQE_ERR_INVALID_ARGUMENT, "keys table shape mismatch");
@@ -1162,27 +1386,81 @@ nqe_status nqe_aggregate_merge(nqe_ctx *ctx, const nqe_table *const *states, con
         cap = 4096;
         while (int64_t(cap) < 2 * total) cap <<= 1;
     }
-    TableBufs tb = make_table(ctx, cap, num_aggs, !grouped);
-    std::vector<int> vslot;
-    for (int i = 0; i < num_aggs; ++i) vslot.push_back(i);
-    BufRef ptrs = dev_alloc(ctx, size_t(4 * std::max(num_aggs, 1)) * sizeof(void *));
+    TableBufs tb = make_table(ctx, cap, V, !grouped);
+    BufRef ptrs = dev_alloc(ctx, size_t(4 * std::max(V, 1)) * sizeof(void *));
     for (int k = 0; k < n; ++k) {
         int64_t rows = states[k]->rows;
-        if (rows == 0 || num_aggs == 0) {
+        if (rows == 0 || V == 0) {
             if (rows && grouped) { /* keys still need inserting */ } else continue;
         }
-        std::vector<const uint64_t *> h(size_t(4 * std::max(num_aggs, 1)), nullptr);
-        for (int c = 0; c < 4 * num_aggs; ++c) h[size_t(c)] = states[k]->cols[size_t(c)].words();
+        std::vector<const uint64_t *> h(size_t(4 * std::max(V, 1)), nullptr);
+        for (int c = 0; c < 4 * V; ++c) h[size_t(c)] = states[k]->cols[size_t(c)].words();
         NQE_HIP_CHECK(hipMemcpyAsync(ptrs->ptr, h.data(), h.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
         launch(ctx, "agg_merge_states", merge_states_kernel, dim3(stream_grid(ctx, rows, 256)), dim3(256), 0, tb.g,
-               grouped ? keys[k]->cols[0].words() : (const uint64_t *)nullptr, rows, num_aggs,
+               grouped ? keys[k]->cols[0].words() : (const uint64_t *)nullptr, rows, V,
                (const uint64_t *const *)ptrs->ptr, ctx->d_flags);
         sync(ctx); // `h` / ptrs are reused by the next partial
     }
-    throw_on_flags(ctx);
-    AggResult r = emit(ctx, tb, grouped, key_dtype, aggs, num_aggs, vslot, false);
+    AggResult r;
+    if (grouped && cap <= RANK_MAX_CAP) {
+        // the exchanged states of a small group set (the sharded headline: world x 1024 rows): tail ahead of the read-back
+        r = emit_ranked(ctx, tb, key_dtype, aggs, num_aggs, vslot, false);
+        int f[NQE_NUM_FLAGS];
+        flags_read_mirrored(ctx, f);
+        if (f[NQE_FLAG_TABLE_FULL]) fail(NQE_ERR_OUT_OF_MEMORY, "device hash table overflow");
+        set_group_count(r, int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT])));
+    } else {
+        throw_on_flags(ctx);
+        r = emit(ctx, tb, grouped, key_dtype, aggs, num_aggs, vslot, false);
+    }
     *out = r.out.release();
     if (keys_out) *keys_out = r.keys.release();
+    NQE_API_END()
+}
+
+nqe_status nqe_aggregate_merge_packed(nqe_ctx *ctx, const void *gathered_device, int32_t num_parts, int64_t stride_rows, int32_t grouped,
+                                      int32_t key_dtype, const nqe_aggregate *aggs, int32_t num_aggs, nqe_table **out, nqe_table **keys_out) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !gathered_device || num_parts <= 0 || stride_rows <= 0 || !out || num_aggs < 0 || num_aggs > 16 || (num_aggs > 0 && !aggs) ||
+        (grouped && !keys_out))
+        fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    *out = nullptr;
+    if (keys_out) *keys_out = nullptr;
+    int V = 0;
+    const std::vector<int> vslot = slots_of_aggs(aggs, num_aggs, &V);
+    const int64_t bound = int64_t(num_parts) * stride_rows;
+    uint32_t sized_cap = 1;
+    if (grouped) {
+        sized_cap = 4096;
+        while (int64_t(sized_cap) < 2 * bound) sized_cap <<= 1;
+    }
+    // small table first (the sharded headline merges world x 1024 rows of the same 1024 keys): single-launch tail, one read-back
+    uint32_t cap = grouped ? std::min(sized_cap, RANK_MAX_CAP) : 1u;
+    for (;;) {
+        flags_reset(ctx);
+        TableBufs tb = make_table(ctx, cap, V, !grouped);
+        launch(ctx, "agg_merge_packed", merge_packed_kernel, dim3(stream_grid(ctx, std::min<int64_t>(bound, int64_t(1) << 16), 256)), dim3(256), 0, tb.g,
+               (const uint64_t *)gathered_device, int(num_parts), stride_rows, grouped ? 1 : 0, V, ctx->d_flags);
+        AggResult r;
+        int f[NQE_NUM_FLAGS];
+        const bool ranked = grouped && cap <= RANK_MAX_CAP;
+        if (ranked) {
+            r = emit_ranked(ctx, tb, key_dtype, aggs, num_aggs, vslot, false);
+            flags_read_mirrored(ctx, f);
+        } else
+            flags_read(ctx, f);
+        if (f[NQE_FLAG_OOB]) break; // some part was sent header-only: the caller takes the exact-size path (*out stays NULL)
+        if (f[NQE_FLAG_TABLE_FULL]) {
+            if (cap >= sized_cap) fail(NQE_ERR_OUT_OF_MEMORY, "device hash table overflow");
+            cap = sized_cap;
+            continue;
+        }
+        if (ranked) set_group_count(r, int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT])));
+        else r = emit(ctx, tb, grouped != 0, key_dtype, aggs, num_aggs, vslot, false);
+        *out = r.out.release();
+        if (keys_out) *keys_out = r.keys.release();
+        break;
+    }
     NQE_API_END()
 }
 

@@ -133,6 +133,21 @@ __device__ __forceinline__ void global_update(const GroupTable &g, int64_t slot,
     if (nan) atomicOr(&g.nan[o], 1u);
 }
 
+// group key of a row for the kernels that compute it inline.  KEY: 0 = the column itself, 1 = `col % ±2^k` (mask), 2 = `col % d`
+// (magic multiply), 3 = any fault-free chain of one or two integer operations with literals (`(id + 1) % 1000`, `id / 7 * 3`, …)
+// through the generic SimpleExpr interpreter — wave-uniform branches on the operator, no flags (the host admits only chains
+// whose divisors are literals other than 0 and -1)
+template <int KEY>
+__device__ __forceinline__ uint64_t inline_key(const SimpleExpr &ke, uint64_t x, uint64_t key_mask, const OpAux &key_aux, bool key_signed) {
+    if (KEY == 0) return x;
+    if (KEY == 3) return eval_simple(ke, x, false, nullptr);
+    // truncated remainder by a literal: |x| mod |d|, sign of the dividend
+    uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
+    uint64_t ux = (x ^ sgn) - sgn;
+    uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
+    return (ur ^ sgn) - sgn;
+}
+
 __device__ __forceinline__ bool row_valid(const ColSrc &c, int64_t row) { return c.valid ? get_bit(c.valid, row) : true; }
 
 // partitioned aggregation (aggregate_partition.hip)

@@ -146,17 +146,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             }
             if (VNULL) pass = pass && ((t.kpv[u] >> (row & 63)) & 1ull);
-            uint64_t key;
-            if (KEY == 0) key = t.kw[u];
-            else {
-                // truncated remainder by a literal: |x| mod |d| (mask for ±2^k, magic multiply otherwise), sign of
-                // the dividend
-                uint64_t x = t.kw[u];
-                uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
-                uint64_t ux = (x ^ sgn) - sgn;
-                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
-                key = (ur ^ sgn) - sgn;
-            }
+            const uint64_t key = inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
             if (!pass) continue;
             if (!run_live || key != run_key) {
                 if (run_live) flush_run();
@@ -244,7 +234,8 @@ template <int PRED, bool VNULL> FastKernel pick_fast_key(int key, int nv, bool v
     switch (key) {
     case 0: return pick_fast_nv<PRED, 0, VNULL>(nv, vf64);
     case 1: return pick_fast_nv<PRED, 1, VNULL>(nv, vf64);
-    default: return pick_fast_nv<PRED, 2, VNULL>(nv, vf64);
+    case 2: return pick_fast_nv<PRED, 2, VNULL>(nv, vf64);
+    default: return pick_fast_nv<PRED, 3, VNULL>(nv, vf64);
     }
 }
 template <bool VNULL> FastKernel pick_fast_pred(int pred, int key, int nv, bool vf64) {

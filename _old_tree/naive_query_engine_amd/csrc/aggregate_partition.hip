@@ -48,15 +48,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_kernel(AggArgs a, Fas
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = row < hi;
             if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? kw[u] : pred_extract(fp, pw[u], row));
-            uint64_t key;
-            if (KEY == 0) key = kw[u];
-            else {
-                uint64_t x = kw[u];
-                uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
-                uint64_t ux = (x ^ sgn) - sgn;
-                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
-                key = (ur ^ sgn) - sgn;
-            }
+            const uint64_t key = inline_key<KEY>(a.key, kw[u], key_mask, key_aux, key_signed);
             if (!pass) continue;
             uint32_t p = uint32_t((key * GOLD) >> (64 - PARTS_LOG2));
             uint32_t r = atomicAdd(&cnt[p], 1u);
@@ -119,13 +111,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_scatter_kernel(AggArg
             for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][rc]);
             bool ok = row < hi;
             if (PRED != 0) ok = ok && range_pass(fp, pw);
-            if (KEY == 0) key[u] = kw;
-            else {
-                uint64_t sgn = key_signed ? uint64_t((long long)kw >> 63) : 0ull;
-                uint64_t ux = (kw ^ sgn) - sgn;
-                uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
-                key[u] = (ur ^ sgn) - sgn;
-            }
+            key[u] = inline_key<KEY>(a.key, kw, key_mask, key_aux, key_signed);
             pass[u] = ok;
             part[u] = uint32_t((key[u] * GOLD) >> (64 - PARTS_LOG2));
         }
@@ -421,7 +407,8 @@ template <int PRED> PartKernel pick_scatter_key(int key, int nv) {
     switch (key) {
     case 0: return pick_scatter_nv<PRED, 0>(nv);
     case 1: return pick_scatter_nv<PRED, 1>(nv);
-    default: return pick_scatter_nv<PRED, 2>(nv);
+    case 2: return pick_scatter_nv<PRED, 2>(nv);
+    default: return pick_scatter_nv<PRED, 3>(nv);
     }
 }
 template <int PRED, int KEY, int NVT> PartKernel pick_part_sc(bool scatter) {
@@ -434,7 +421,8 @@ template <int PRED> PartKernel pick_part_key(int key, int nv, bool scatter) {
     switch (key) {
     case 0: return pick_part_nv<PRED, 0>(nv, scatter);
     case 1: return pick_part_nv<PRED, 1>(nv, scatter);
-    default: return pick_part_nv<PRED, 2>(nv, scatter);
+    case 2: return pick_part_nv<PRED, 2>(nv, scatter);
+    default: return pick_part_nv<PRED, 3>(nv, scatter);
     }
 }
 

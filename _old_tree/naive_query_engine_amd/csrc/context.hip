@@ -102,11 +102,26 @@ DevBuf::~DevBuf() {
 }
 
 // ---------------------------------------------------------------- flags
-void flags_reset(nqe_ctx *ctx) { NQE_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NQE_NUM_FLAGS, ctx->stream)); }
+void flags_reset(nqe_ctx *ctx) {
+    if (ctx->flags_clean) return;
+    NQE_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NQE_NUM_FLAGS, ctx->stream));
+    ctx->flags_clean = true;
+}
+static void flags_note(nqe_ctx *ctx, const int *f, bool count_on_device) {
+    bool zero = true;
+    for (int i = 0; i < NQE_NUM_FLAGS; ++i) zero = zero && (f[i] == 0 || (!count_on_device && i == NQE_FLAG_GROUP_COUNT));
+    ctx->flags_clean = zero; // every kernel launched so far has completed
+}
 void flags_read(nqe_ctx *ctx, int out[NQE_NUM_FLAGS]) {
     NQE_HIP_CHECK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, sizeof(int) * NQE_NUM_FLAGS, hipMemcpyDeviceToHost, ctx->stream));
     sync(ctx);
     for (int i = 0; i < NQE_NUM_FLAGS; ++i) out[i] = ctx->h_flags[i];
+    flags_note(ctx, out, true);
+}
+void flags_read_mirrored(nqe_ctx *ctx, int out[NQE_NUM_FLAGS]) {
+    sync(ctx);
+    for (int i = 0; i < NQE_NUM_FLAGS; ++i) out[i] = ctx->h_flags[i];
+    flags_note(ctx, out, false); // the group count went to the mirror only; its device slot is still zero
 }
 void throw_on_flags(nqe_ctx *ctx) {
     int f[NQE_NUM_FLAGS];
@@ -499,7 +514,8 @@ nqe_status nqe_ctx_create(int32_t device, void *stream, nqe_ctx **out) {
     NQE_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     NQE_HIP_CHECK(hipMalloc(&ctx->d_flags, sizeof(int) * NQE_NUM_FLAGS));
-    NQE_HIP_CHECK(hipHostMalloc(&ctx->h_flags, sizeof(int) * NQE_NUM_FLAGS));
+    NQE_HIP_CHECK(hipHostMalloc(&ctx->h_flags, sizeof(int) * NQE_NUM_FLAGS, hipHostMallocMapped | hipHostMallocCoherent));
+    NQE_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_flags_dev), ctx->h_flags, 0));
     NQE_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NQE_NUM_FLAGS, ctx->stream));
     *out = ctx.release();
     NQE_API_END()

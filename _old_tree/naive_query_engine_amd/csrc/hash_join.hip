@@ -613,6 +613,13 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
     return jt;
 }
 
+// the build-side key column of an equi-join's output can alias the probe-side one: plain integer keys of one type, where equal
+// means identical bits (Float64 keys compare -0.0 == 0.0 with different bits; Utf8 keys are not 8-byte words)
+static bool share_key_column(const DevColumn &left_key, const DevColumn &right_key) {
+    return left_key.dtype == right_key.dtype && (left_key.dtype == NQE_INT64 || left_key.dtype == NQE_UINT64) && !left_key.validity &&
+           !right_key.validity;
+}
+
 std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, const nqe_table *right, int right_key) {
     if (right_key < 0 || size_t(right_key) >= right->cols.size()) fail(NQE_ERR_LOGICAL, "ColumnExpr must has name or idx");
     const DevColumn &rk_orig = right->cols[size_t(right_key)];
@@ -671,8 +678,18 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         out->rows = km.total;
         FusedCols fc;
         std::memset(&fc, 0, sizeof(fc));
+        // In an equi-join on an integer key the build key column of the output IS the probe key column of the output, bit for
+        // bit: it is written once and the two output columns share the buffer (tables are immutable; 8 of the 32 output bytes
+        // per row of C4 are never written)
+        const bool share_key = share_key_column(jt->left_cols[size_t(jt->left_key)], rk);
+        int share_pos = -1, right_key_pos = -1;
         for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
             const DevColumn &c = jt->left_cols[ci];
+            if (int(ci) == jt->left_key && share_key) {
+                share_pos = int(out->cols.size());
+                out->cols.push_back(DevColumn{});
+                continue;
+            }
             out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
             fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : (jt->dense_packed[ci] ? 3 : 2);
             fc.base[fc.n] = int(ci) == jt->left_key ? 0 : jt->dense_base[ci];
@@ -680,12 +697,18 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
             fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
             fc.n++;
         }
-        for (auto &c : right->cols) {
+        for (size_t cj = 0; cj < right->cols.size(); ++cj) {
+            const DevColumn &c = right->cols[cj];
             out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
+            if (int(cj) == right_key) right_key_pos = int(out->cols.size()) - 1;
             fc.kind[fc.n] = 0;
             fc.src[fc.n] = c.words();
             fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
             fc.n++;
+        }
+        if (share_pos >= 0) {
+            out->cols[size_t(share_pos)] = out->cols[size_t(right_key_pos)];
+            out->cols[size_t(share_pos)].dtype = jt->left_cols[size_t(jt->left_key)].dtype;
         }
         if (km.ntiles && km.total > 0)
             launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS>, grid, block, 0, rk.words(), n, km.ntiles, (const uint64_t *)km.keep->ptr,
@@ -716,20 +739,33 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
             // from the probe key, build payloads gathered by the recorded build row) instead of one compaction per column
             FusedCols fc;
             std::memset(&fc, 0, sizeof(fc));
+            const bool share_key = share_key_column(jt->left_cols[size_t(jt->left_key)], rk); // as in the dense path
+            int share_pos = -1, right_key_pos = -1;
             for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
                 const DevColumn &c = jt->left_cols[ci];
+                if (int(ci) == jt->left_key && share_key) {
+                    share_pos = int(out->cols.size());
+                    out->cols.push_back(DevColumn{});
+                    continue;
+                }
                 out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
                 fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : 2;
                 fc.src[fc.n] = c.words();
                 fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
                 fc.n++;
             }
-            for (auto &c : right->cols) {
+            for (size_t cj = 0; cj < right->cols.size(); ++cj) {
+                const DevColumn &c = right->cols[cj];
                 out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
+                if (int(cj) == right_key) right_key_pos = int(out->cols.size()) - 1;
                 fc.kind[fc.n] = 0;
                 fc.src[fc.n] = c.words();
                 fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
                 fc.n++;
+            }
+            if (share_pos >= 0) {
+                out->cols[size_t(share_pos)] = out->cols[size_t(right_key_pos)];
+                out->cols[size_t(share_pos)].dtype = jt->left_cols[size_t(jt->left_key)].dtype;
             }
             if (km.ntiles && km.total > 0)
                 launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS>, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,

@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -62,6 +64,10 @@ struct nqe_ctx {
 
     int *d_flags = nullptr; // NQE_NUM_FLAGS ints on the device
     int *h_flags = nullptr; // pinned host mirror
+    int *h_flags_dev = nullptr; // the mirror's address as seen by kernels (a tail kernel may write it directly)
+    // d_flags known to be all zero at the current stream position: set by a read-back that saw only zeros (or a reset), cleared
+    // by every kernel launch — lets the next operator skip its reset (one fill launch per operator)
+    bool flags_clean = false;
 };
 
 namespace nqe {
@@ -132,6 +138,7 @@ struct TimerScope {
 template <typename K, typename... Args>
 inline void launch(nqe_ctx *ctx, const char *name, K kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
     TimerScope t(ctx, name);
+    ctx->flags_clean = false;
     hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, args...);
     NQE_HIP_CHECK(hipGetLastError());
 }
@@ -147,9 +154,23 @@ inline int stream_grid(nqe_ctx *ctx, int64_t work_items, int per_block, int bloc
 void flags_reset(nqe_ctx *ctx);
 // synchronises the stream, returns flag values
 void flags_read(nqe_ctx *ctx, int out[NQE_NUM_FLAGS]);
+// the same when the last kernel of the stream copied the flags into the pinned mirror itself (no device-to-host copy)
+void flags_read_mirrored(nqe_ctx *ctx, int out[NQE_NUM_FLAGS]);
 void throw_on_flags(nqe_ctx *ctx);
 
-inline void sync(nqe_ctx *ctx) { NQE_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }
+// Host wait for the stream.  The operators wait for a handful of bytes (flags, a row count) right behind kernels that run for
+// microseconds to a few milliseconds, and an interrupt-driven hipStreamSynchronize adds its wake-up latency to every such step:
+// poll the stream for the first milliseconds, then block.
+inline void sync(nqe_ctx *ctx) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) NQE_HIP_CHECK(e);
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+    }
+    NQE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+}
 
 template <typename T> inline T read_scalar(nqe_ctx *ctx, const T *dptr) {
     T v;

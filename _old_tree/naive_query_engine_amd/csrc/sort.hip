@@ -130,9 +130,69 @@ template <typename T> __global__ void __launch_bounds__(1024) scan_add_kernel(T 
         if (base + k < n) data[base + k] += o;
 }
 
+// the same scan by ONE workgroup: for the few-thousand tile counts of a selection or a join probe (10^8 rows = 24 K tiles = 6
+// chunks) one launch replaces three dependent launches and their gaps.  Every chunk's words are requested before the first is
+// used (one memory round trip instead of one per chunk), the per-chunk wave scans run back to back, and a single barrier
+// publishes all wave totals.
+// (the chunk words stay in registers in their input width: 8 chunks of 4-byte counts, 6 when they scan into 8-byte offsets, 4 chunks of
+// 8-byte words: no scratch)
+template <typename Tin, typename Tout> constexpr int scan_single_max_chunks() { return sizeof(Tout) == 4 ? 8 : (sizeof(Tin) == 4 ? 6 : 4); }
+template <typename Tin, typename Tout>
+__global__ void __launch_bounds__(1024) scan_single_kernel(const Tin *in, int64_t n_in, Tout *out, int64_t n_out) {
+    constexpr int MAXC = scan_single_max_chunks<Tin, Tout>();
+    __shared__ Tout wave_tot[MAXC][16];
+    const int wv = threadIdx.x / 64;
+    Tin v[MAXC][4];
+    Tout s[MAXC], x[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int64_t base = int64_t(c) * SCAN_CHUNK + int64_t(threadIdx.x) * 4;
+        s[c] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[c][k] = base + k < n_in ? in[base + k] : Tin(0);
+            s[c] += Tout(v[c][k]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        x[c] = s[c];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            Tout y = __shfl_up(x[c], d, 64);
+            if (lane_id() >= d) x[c] += y;
+        }
+        if (lane_id() == 63) wave_tot[c][wv] = x[c];
+    }
+    __syncthreads();
+    Tout carry = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int64_t base = int64_t(c) * SCAN_CHUNK + int64_t(threadIdx.x) * 4;
+        if (int64_t(c) * SCAN_CHUNK >= n_out) break; // uniform
+        Tout pre = 0, all = 0;
+        for (int w = 0; w < 16; ++w) {
+            const Tout t = wave_tot[c][w];
+            if (w < wv) pre += t;
+            all += t;
+        }
+        Tout run = carry + pre + (x[c] - s[c]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (base + k < n_out) out[base + k] = run;
+            run += Tout(v[c][k]);
+        }
+        carry += all;
+    }
+}
+
 template <typename Tin, typename Tout> void scan_impl(nqe_ctx *ctx, const Tin *in, int64_t n_in, Tout *out, int64_t n_out) {
     if (n_out <= 0) return;
     int64_t nchunks = (n_out + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (nchunks > 1 && nchunks <= scan_single_max_chunks<Tin, Tout>()) {
+        launch(ctx, "scan_single", scan_single_kernel<Tin, Tout>, dim3(1), dim3(1024), 0, in, n_in, out, n_out);
+        return;
+    }
     BufRef sums = dev_alloc(ctx, size_t(nchunks) * sizeof(Tout));
     launch(ctx, "scan_chunk", scan_chunk_kernel<Tin, Tout>, dim3((unsigned)nchunks), dim3(1024), 0, in, n_in, out, n_out,
            (Tout *)sums->ptr);

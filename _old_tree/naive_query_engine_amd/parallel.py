@@ -111,6 +111,15 @@ def all_gather_rows(cols: Sequence, group=None) -> Tuple[List[list], List[int]]:
 EXCHANGE_ROWS = 4096
 
 
+def _shares_stream(ctx, dev) -> bool:
+    """the context launches on torch's current stream (Context(device, stream=torch_stream.cuda_stream) under
+    `torch.cuda.stream(torch_stream)`): kernels and collectives are ordered by the stream itself, no host synchronisation
+    between them"""
+    import torch
+
+    return ctx.stream is not None and int(ctx.stream) == int(torch.cuda.current_stream(dev).cuda_stream)
+
+
 def _all_gather_packed(buf, group=None):
     """all-gather of equally sized 1-D int64 buffers → [world, len] tensor (gloo + CUDA stages through the host)"""
     import torch
@@ -132,9 +141,11 @@ def sharded_aggregate(ctx, local_table, aggs, group_nodes=None, pred_nodes=None,
     on every rank (identical up to f64 summation order of the merge).
 
     Exchange: the partial (keys + {count,sum,min,max} per value column) is packed into one fixed-size device buffer whose
-    last word is the group count, all-gathered with ONE collective, the counts are read from the headers (one D2H sync),
-    and the gathered buffer is unpacked into a single concatenated table for the merge.  Partials with more than
-    EXCHANGE_ROWS groups on any rank fall back to the exact-size path (counts first, then data)."""
+    last word is the group count, all-gathered with ONE collective, and merged straight from the gathered buffer
+    (nqe_aggregate_merge_packed reads the counts from the headers on the device).  When the context launches on torch's
+    current stream the whole exchange + merge costs the host ONE wait (the merged group count); with a private context
+    stream the two streams are ordered by host synchronisations.  Partials with more than EXCHANGE_ROWS groups on any rank
+    fall back to the exact-size path (counts first, then data)."""
     import torch
     import torch.distributed as dist
 
@@ -155,16 +166,18 @@ def sharded_aggregate(ctx, local_table, aggs, group_nodes=None, pred_nodes=None,
         ctx.pack_words(tables, stride, buf.data_ptr())
     else:
         buf[-1] = rows  # header only: tells the peers to take the exact-size path
-    ctx.synchronize()  # the pack ran on the context's stream, the collective runs on torch's
+    shared = _shares_stream(ctx, dev)
+    if not shared:
+        ctx.synchronize()  # the pack ran on the context's stream, the collective is ordered after torch's current stream
     gathered = _all_gather_packed(buf, group)
-    counts = [int(c) for c in gathered[:, -1].cpu().tolist()]  # D2H: also orders the collective before the unpack
-    if max(counts) <= stride:
-        cat = ctx.unpack_words(gathered.data_ptr(), counts, dts, stride)
-        ctx.synchronize()
-        del gathered
-        keyt = ctx.project(cat, [0]) if nk else None
-        st = ctx.project(cat, list(range(nk, ncols)))
-        return ctx.aggregate_merge([st], [keyt] if keyt is not None else None, aggs)
+    if not shared:
+        torch.cuda.current_stream(dev).synchronize()  # ... and the merge runs on the context's stream again
+    # the merge reads the row counts from the headers on the device: no count read-back, no unpack, one host wait in all
+    merged = ctx.aggregate_merge_packed(gathered.data_ptr(), gathered.shape[0], stride, nk == 1, dts[0] if nk else 0, aggs)
+    if merged is not None:
+        if not shared:
+            ctx.synchronize()  # `gathered` goes back to torch's allocator
+        return merged
     # ---- exact-size path
     cols = []
     for t in tables:
@@ -271,7 +284,7 @@ def unpack_words_numpy(gathered: np.ndarray, ncols: int, stride: int) -> Tuple[L
 
 def merge_partials_numpy(keys_list: Sequence[Optional[np.ndarray]], states_list: Sequence[Sequence[np.ndarray]]):
     """Host restatement of the partial merge rule (used by the CPU gloo tests to check the exchange;
-    the product path merges on the GPU with nqe_aggregate_merge).  states = per aggregate
+    the product path merges on the GPU with nqe_aggregate_merge).  states = per distinct aggregate column
     (count u64, sum f64, min f64, max f64)."""
     grouped = keys_list[0] is not None
     acc = {}

@@ -79,6 +79,10 @@ struct AggArgs {
     int32_t lds_cap;
     int32_t lds_shift;
     int32_t allow_partition; // an LDS-table overflow asks the host for the partitioned path instead of falling back to global atomics
+    // fast kernel, key = `col % m` with a small m: the key's value range (-m, m) fits the LDS table, so slot = key + direct_bias —
+    // no hash, no probe, no compare on the per-row path of inputs whose key changes every row
+    int32_t direct;
+    int64_t direct_bias;
 };
 
 __device__ __forceinline__ int lds_find_or_insert(uint64_t *keys, uint64_t key, uint32_t cap, int shift) {

@@ -61,7 +61,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         // The hit path must stay minimal: random-key inputs flush once per row (guarding the lookup with a "table is full"
         // test cost them 14 %).  A rejected key is the cold path: it raises the workgroup flag (the tile loop then leaves
         // early and the host redoes the query partitioned) or, for small inputs, goes to the global table.
-        int slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+        int slot;
+        if (a.direct) { // wave-uniform
+            slot = int(int64_t(run_key) + a.direct_bias);
+            lkeys[slot] = run_key; // marks the slot for the final merge (every writer stores the same word)
+        } else
+            slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
         int64_t gslot = 0;
         if (slot < 0) {
             if (!*lds_full) {
