@@ -64,7 +64,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         int slot;
         if (a.direct) { // wave-uniform
             slot = int(int64_t(run_key) + a.direct_bias);
-            lkeys[slot] = run_key; // marks the slot for the final merge (every writer stores the same word)
+            // the final merge recognises a used slot by its count; only NULL-able values (a group of NULLs has count 0) need the
+            // key word as the mark (every writer stores the same word)
+            if (VNULL) lkeys[slot] = run_key;
         } else
             slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
         int64_t gslot = 0;
@@ -217,8 +219,14 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // device-scope atomics were two thirds of what the abandoned attempt cost
     if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
-        uint64_t k = lkeys[s];
-        if (k == EMPTY_KEY) continue;
+        uint64_t k;
+        if (a.direct && !VNULL) {
+            if (lcnt[s] == 0) continue;
+            k = uint64_t(int64_t(s) - a.direct_bias);
+        } else {
+            k = lkeys[s];
+            if (k == EMPTY_KEY) continue;
+        }
         uint64_t key = (s == cap) ? EMPTY_KEY : k;
         int64_t gslot = global_find_or_insert(g, key, flags);
         if (gslot < 0) continue;
