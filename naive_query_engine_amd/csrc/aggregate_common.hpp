@@ -144,7 +144,7 @@ __device__ __forceinline__ void global_update(const GroupTable &g, int64_t slot,
 template <int KEY>
 __device__ __forceinline__ uint64_t inline_key(const SimpleExpr &ke, uint64_t x, uint64_t key_mask, const OpAux &key_aux, bool key_signed) {
     if (KEY == 0) return x;
-    if (KEY == 3) return eval_simple(ke, x, false, nullptr);
+    if (KEY == 3) return eval_simple<false>(ke, x, false, nullptr);
     // truncated remainder by a literal: |x| mod |d|, sign of the dividend
     uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
     uint64_t ux = (x ^ sgn) - sgn;

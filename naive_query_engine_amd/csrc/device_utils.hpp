@@ -56,6 +56,9 @@ __device__ __forceinline__ uint64_t udiv_magic(uint64_t n, const OpAux &aux) {
 // arithmetic, truncated remainder, IEEE float compares; zero divisor / MIN÷-1 raise device
 // flags which the host turns into NQE_ERR_ARROW. Control flow is wave-uniform (op, dt come
 // from kernel arguments).
+// CHECKED = false: the caller guarantees an integer divisor other than 0 and -1 (literals vetted by the host), so the fault
+// tests are compiled out.
+template <bool CHECKED = true>
 __device__ __forceinline__ uint64_t apply_binary(int op, int dt, uint64_t a, uint64_t b, const OpAux &aux,
                                                  bool valid, int *flags) {
     if (op <= NQE_OP_GT_EQ) {
@@ -96,13 +99,15 @@ __device__ __forceinline__ uint64_t apply_binary(int op, int dt, uint64_t a, uin
     default: break;
     }
     // divide / modulus on integers
-    if (b == 0) {
-        if (valid) atomicOr(&flags[NQE_FLAG_DIV_ZERO], 1);
-        return 0;
-    }
-    if (dt == NQE_INT64 && (long long)a == INT64_MIN && (long long)b == -1) {
-        if (valid) atomicOr(&flags[NQE_FLAG_OVERFLOW], 1);
-        return 0;
+    if (CHECKED) {
+        if (b == 0) {
+            if (valid) atomicOr(&flags[NQE_FLAG_DIV_ZERO], 1);
+            return 0;
+        }
+        if (dt == NQE_INT64 && (long long)a == INT64_MIN && (long long)b == -1) {
+            if (valid) atomicOr(&flags[NQE_FLAG_OVERFLOW], 1);
+            return 0;
+        }
     }
     if (aux.pow2_shift >= 0) {
         // divisor is a literal ±2^k: truncated division/remainder without the 64-bit divide
@@ -143,13 +148,14 @@ __device__ __forceinline__ OpAux no_aux() {
 }
 
 // Evaluates a SimpleExpr on a source word that is already in a register.
+template <bool CHECKED = true>
 __device__ __forceinline__ uint64_t eval_simple(const SimpleExpr &e, uint64_t v, bool valid, int *flags) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (k < e.nops) {
             uint64_t a = e.lit_left[k] ? e.lit[k] : v;
             uint64_t b = e.lit_left[k] ? v : e.lit[k];
-            v = apply_binary(e.op[k], e.op_dtype[k], a, b, e.lit_left[k] ? no_aux() : e.aux[k], valid, flags);
+            v = apply_binary<CHECKED>(e.op[k], e.op_dtype[k], a, b, e.lit_left[k] ? no_aux() : e.aux[k], valid, flags);
         }
     }
     return v;
