@@ -1228,10 +1228,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             ka.lds_shift = 64 - 12;
                             fshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
                         }
-                        if (fast_key == 1 || fast_key == 2) {
-                            // `col % m`: keys lie in (-m, m) (signed) or [0, m) — direct-mapped LDS table when that span fits
-                            const bool sgn = a.key.op_dtype[0] == NQE_INT64;
-                            const uint64_t m = a.key.aux[0].abs_lit;
+                        const int lastop = a.key.nops - 1;
+                        if (fast_key == 1 || fast_key == 2 ||
+                            (fast_key == 3 && a.key.op[lastop] == NQE_OP_MODULOS && !a.key.lit_left[lastop])) {
+                            // `… % m`: keys lie in (-m, m) (signed) or [0, m) — direct-mapped LDS table when that span fits
+                            const bool sgn = a.key.op_dtype[lastop] == NQE_INT64;
+                            const uint64_t m = a.key.aux[lastop].abs_lit;
                             const uint64_t span = sgn ? 2 * m - 1 : m;
                             if (m > 0 && span <= uint64_t(ka.lds_cap)) {
                                 ka.direct = 1;
