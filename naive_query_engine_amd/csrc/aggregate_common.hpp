@@ -152,6 +152,71 @@ __device__ __forceinline__ uint64_t inline_key(const SimpleExpr &ke, uint64_t x,
     return (ur ^ sgn) - sgn;
 }
 
+// truncated division / remainder by a vetted literal (not 0, not -1) with everything that does not depend on the row fixed at
+// compile time; same results as apply_binary
+template <bool MOD, bool SGN, bool POW2>
+__device__ __forceinline__ uint64_t divmod_by_literal(uint64_t a, uint64_t lit, const OpAux &aux) {
+    const bool xneg = SGN && (long long)a < 0;
+    const uint64_t ux = xneg ? 0ull - a : a;
+    const uint64_t uq = POW2 ? ux >> aux.pow2_shift : udiv_magic(ux, aux);
+    if (MOD) {
+        const uint64_t ur = POW2 ? ux & (aux.abs_lit - 1) : ux - uq * aux.abs_lit;
+        return xneg ? 0ull - ur : ur;
+    }
+    const bool neg = SGN && (xneg != ((long long)lit < 0));
+    return neg ? 0ull - uq : uq;
+}
+
+// keys of a register tile of U rows.  The interpreted variant (KEY = 3) runs operator-major: the (wave-uniform) dispatch on the
+// operator, its type and the divisor's shape happens once per operator per tile, the U rows are straight-line code under it —
+// per-row interpretation cost `(id + 1) % 1000` 0.90 ms per 2x10^8 rows against 0.56 ms for the built-in `id % 1000`.
+template <int KEY, int U>
+__device__ __forceinline__ void inline_keys(const SimpleExpr &ke, const uint64_t (&kw)[U], uint64_t (&key)[U], uint64_t key_mask,
+                                            const OpAux &key_aux, bool key_signed) {
+    if (KEY != 3) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) key[u] = inline_key<KEY>(ke, kw[u], key_mask, key_aux, key_signed);
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) key[u] = kw[u];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k >= ke.nops) break;
+        const int op = ke.op[k];
+        const bool ll = ke.lit_left[k] != 0;
+        const uint64_t lit = ke.lit[k];
+        if (op == NQE_OP_PLUS) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) key[u] += lit;
+        } else if (op == NQE_OP_MULTIPLY) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) key[u] *= lit;
+        } else if (op == NQE_OP_MINUS) {
+            if (ll) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) key[u] = lit - key[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) key[u] -= lit;
+            }
+        } else { // DIVIDE / MODULOS by a literal on the right (the host admits nothing else here)
+            const OpAux aux = ke.aux[k];
+            const bool mod = op == NQE_OP_MODULOS, sgn = ke.op_dtype[k] == NQE_INT64, pow2 = aux.pow2_shift >= 0;
+#define NQE_DM(M, S, P)                                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) key[u] = divmod_by_literal<M, S, P>(key[u], lit, aux)
+            if (mod) {
+                if (sgn) { if (pow2) { NQE_DM(true, true, true); } else { NQE_DM(true, true, false); } }
+                else { if (pow2) { NQE_DM(true, false, true); } else { NQE_DM(true, false, false); } }
+            } else {
+                if (sgn) { if (pow2) { NQE_DM(false, true, true); } else { NQE_DM(false, true, false); } }
+                else { if (pow2) { NQE_DM(false, false, true); } else { NQE_DM(false, false, false); } }
+            }
+#undef NQE_DM
+        }
+    }
+}
+
 __device__ __forceinline__ bool row_valid(const ColSrc &c, int64_t row) { return c.valid ? get_bit(c.valid, row) : true; }
 
 // partitioned aggregation (aggregate_partition.hip)

@@ -145,6 +145,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         }
     };
     auto process_tile = [&](const Tile &t, int64_t base) {
+        // interpreted keys are computed for the whole tile up front (operator-major); the built-in shapes stay inside the row loop,
+        // where the compiler sinks them below the predicate (hoisting them cost the headline 1.5 %)
+        uint64_t keys[KEY == 3 ? AGG_U : 1];
+        if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, reinterpret_cast<uint64_t (&)[AGG_U]>(keys), key_mask, key_aux, key_signed);
 #pragma unroll
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             }
             if (VNULL) pass = pass && ((t.kpv[u] >> (row & 63)) & 1ull);
-            const uint64_t key = inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
+            const uint64_t key = KEY == 3 ? keys[KEY == 3 ? u : 0] : inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
             if (!pass) continue;
             if (!run_live || key != run_key) {
                 if (run_live) flush_run();
