@@ -1150,11 +1150,25 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 if (vnull && (partition_mode || !valid_words_ok || !kp_valid_words_ok)) plain = false;
                 FastPred fpred{};
                 if (bitmap_pred) fpred = bitmap_fast_pred();
-                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || bitmap_pred || (pk == 1 && make_fast_pred(a.pred, &fpred)));
+                bool range_pred = pk == 1 && make_fast_pred(a.pred, &fpred);
+                // any other fault-free integer chain `col op lit [op lit]` ending in a comparison: interpreted inside the fast kernel
+                bool chain_pred = false;
+                if (a.pred_mode == 1 && !bitmap_pred && !range_pred && !partition_mode && a.pred.nops >= 1 &&
+                    a.pred.op[a.pred.nops - 1] <= NQE_OP_GT_EQ) {
+                    chain_pred = true;
+                    for (int k = 0; k < a.pred.nops; ++k) {
+                        const int op = a.pred.op[k];
+                        chain_pred = chain_pred && op <= NQE_OP_MODULOS && (a.pred.op_dtype[k] == NQE_INT64 || a.pred.op_dtype[k] == NQE_UINT64);
+                        if (op <= NQE_OP_GT_EQ && k != a.pred.nops - 1) chain_pred = false; // a comparison feeds nothing but the result
+                        if (op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS)
+                            chain_pred = chain_pred && !a.pred.lit_left[k] && a.pred.lit[k] != 0 && a.pred.lit[k] != ~0ull;
+                    }
+                }
+                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || bitmap_pred || range_pred || chain_pred);
                 if (fast) {
                     // variant 1 tests the key word with the integer range test alone; Float64 predicates and bitmaps use the
                     // "other column" variant, whose extraction step applies the order mapping
-                    int fp = pk == 0 ? 0 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2);
+                    int fp = pk == 0 ? 0 : (chain_pred ? 3 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2));
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
                     if (partition_mode) {
@@ -1217,7 +1231,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             sync(ctx); // the partition buffers are released at the end of this scope
                         }
                     } else {
-                        ka.allow_partition = in->rows >= (int64_t(1) << 18) ? 1 : 0;
+                        // (the partition kernels have no interpreted-predicate variant: such a query keeps its rows on this kernel and
+                        // spills to the global table, as it did on the general kernel — found by the fuzzer: asking for the partitioned
+                        // path here handed a densely laid out table to the hashed general kernel)
+                        ka.allow_partition = (in->rows >= (int64_t(1) << 18) && !chain_pred) ? 1 : 0;
                         // ONE 1024-thread workgroup per CU: fewer concurrent streams read HBM faster (A/B on one box: headline
                         // 2.44 -> 2.39 ms, C3 2.56 -> 2.41 ms, random keys 3.63 -> 3.54 ms, 1 % nulls 0.81 -> 0.69 ms per 2e8 rows;
                         // tools/stream_bench.hip shows the same for a bare read kernel)
@@ -1247,6 +1264,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     // the general kernel's PLAIN variant reads predicate and values as bare 8-byte words: not for a Boolean
                     // predicate column (bits) nor nullable values (found by the differential fuzzer: a bitmap predicate with
                     // a key shape the fast kernel does not cover was read as words)
+                    if (dense) fail(NQE_ERR_NOT_SUPPORTED, "internal: the hashed aggregate kernel was handed a densely laid out group table");
                     launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain && !vnull && !bitmap_pred), dim3(std::min(grid, ctx->num_cus)), dim3(AGG_BLOCK), shmem, ka, tb.g,
                            ctx->d_flags);
                 }

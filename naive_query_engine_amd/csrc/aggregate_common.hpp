@@ -200,6 +200,32 @@ __device__ __forceinline__ void inline_keys(const SimpleExpr &ke, const uint64_t
 #pragma unroll
                 for (int u = 0; u < U; ++u) key[u] -= lit;
             }
+        } else if (op <= NQE_OP_GT_EQ) { // comparison with the literal (a predicate chain's last step): 1 / 0
+            // lit op x  ==  x op' lit
+            const int o = !ll ? op : op == NQE_OP_LT ? NQE_OP_GT : op == NQE_OP_LT_EQ ? NQE_OP_GT_EQ : op == NQE_OP_GT ? NQE_OP_LT : op == NQE_OP_GT_EQ ? NQE_OP_LT_EQ : op;
+            const bool sgn = ke.op_dtype[k] == NQE_INT64;
+#define NQE_CMP(T, OP)                                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) key[u] = (T(key[u]) OP T(lit)) ? 1ull : 0ull
+            if (sgn) {
+                switch (o) {
+                case NQE_OP_EQ: NQE_CMP(int64_t, ==); break;
+                case NQE_OP_NOT_EQ: NQE_CMP(int64_t, !=); break;
+                case NQE_OP_LT: NQE_CMP(int64_t, <); break;
+                case NQE_OP_LT_EQ: NQE_CMP(int64_t, <=); break;
+                case NQE_OP_GT: NQE_CMP(int64_t, >); break;
+                default: NQE_CMP(int64_t, >=); break;
+                }
+            } else {
+                switch (o) {
+                case NQE_OP_EQ: NQE_CMP(uint64_t, ==); break;
+                case NQE_OP_NOT_EQ: NQE_CMP(uint64_t, !=); break;
+                case NQE_OP_LT: NQE_CMP(uint64_t, <); break;
+                case NQE_OP_LT_EQ: NQE_CMP(uint64_t, <=); break;
+                case NQE_OP_GT: NQE_CMP(uint64_t, >); break;
+                default: NQE_CMP(uint64_t, >=); break;
+                }
+            }
+#undef NQE_CMP
         } else { // DIVIDE / MODULOS by a literal on the right (the host admits nothing else here)
             const OpAux aux = ke.aux[k];
             const bool mod = op == NQE_OP_MODULOS, sgn = ke.op_dtype[k] == NQE_INT64, pow2 = aux.pow2_shift >= 0;

@@ -21,7 +21,8 @@ namespace {
 //   * PIPE: the NEXT tile's words are requested before the current tile is processed (two register
 //     tiles), so waits are counted `s_waitcnt vmcnt(k)` and a wave keeps a tile in flight while it
 //     computes.
-// PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column.
+// PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column, 3 a fault-free integer chain
+// `col op lit … cmp lit` over any column, interpreted operator-major like the KEY = 3 keys.
 template <int PRED, int KEY, int NVT, bool VF64, bool VNULL>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     };
 
     const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
-    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED >= 2 ? a.pred_src.values : a.key_src.values);
     const uint64_t *__restrict__ valp[NVT];
     const uint64_t *__restrict__ kvalid = reinterpret_cast<const uint64_t *>(a.key_src.valid);
     const uint64_t *__restrict__ pvalid = reinterpret_cast<const uint64_t *>(PRED != 0 ? a.pred_src.valid : nullptr);
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             if (NT) {
                 t.kw[u] = __builtin_nontemporal_load(&keyp[row]);
                 if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
+                if (PRED == 3) t.pw[u] = __builtin_nontemporal_load(&predp[row]);
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
                 if (VNULL) {
@@ -139,6 +141,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             } else {
                 t.kw[u] = keyp[row];
                 if (PRED == 2) t.pw[u] = predp[row >> fp.row_shift];
+                if (PRED == 3) t.pw[u] = predp[row];
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = valp[j][row];
             }
@@ -147,13 +150,16 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     auto process_tile = [&](const Tile &t, int64_t base) {
         // interpreted keys are computed for the whole tile up front (operator-major); the built-in shapes stay inside the row loop,
         // where the compiler sinks them below the predicate (hoisting them cost the headline 1.5 %)
+        uint64_t pvals[PRED == 3 ? AGG_U : 1];
+        if (PRED == 3) inline_keys<3, AGG_U>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
         uint64_t keys[KEY == 3 ? AGG_U : 1];
         if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, reinterpret_cast<uint64_t (&)[AGG_U]>(keys), key_mask, key_aux, key_signed);
 #pragma unroll
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = row < n;
-            if (PRED != 0) {
+            if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
+            else if (PRED != 0) {
                 pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             }
             if (VNULL) pass = pass && ((t.kpv[u] >> (row & 63)) & 1ull);
@@ -259,7 +265,8 @@ template <bool VNULL> FastKernel pick_fast_pred(int pred, int key, int nv, bool 
     switch (pred) {
     case 0: return pick_fast_key<0, VNULL>(key, nv, vf64);
     case 1: return pick_fast_key<1, VNULL>(key, nv, vf64);
-    default: return pick_fast_key<2, VNULL>(key, nv, vf64);
+    case 2: return pick_fast_key<2, VNULL>(key, nv, vf64);
+    default: return pick_fast_key<3, VNULL>(key, nv, vf64);
     }
 }
 

@@ -34,21 +34,6 @@ def flat(e):
     return e.flatten(FLD) if e is not None else None
 
 
-def random_pred(rng):
-    kind = int(rng.integers(0, 7))
-    if kind == 0:
-        return None
-    if kind == 1:
-        return binop(col(0), [Operator.Lt, Operator.GtEq, Operator.NotEq, Operator.Eq][int(rng.integers(0, 4))], lit_i64(int(rng.integers(-5, 3000))))
-    if kind == 2:
-        return binop(col(2), [Operator.Gt, Operator.LtEq, Operator.NotEq][int(rng.integers(0, 3))], lit_f64(float(rng.choice([0.0, -0.0, 25.5, -60.0, float("nan"), float("inf")]))))
-    if kind == 3:
-        return col(4)
-    if kind == 4:
-        return binop(lit_u64(int(rng.integers(0, 1 << 39))), Operator.Lt, col(3))
-    return _random_tree(rng, int(rng.integers(1, 4)), "b")
-
-
 def random_chain_key(rng, c=0, unsigned=False):
     """one or two integer operations with literals over one column (the fast kernels' interpreted key variant when it cannot fault,
     the general kernel when it can: zero / -1 divisors, literal-on-the-left divisions)"""
@@ -62,6 +47,27 @@ def random_chain_key(rng, c=0, unsigned=False):
             v = 5
         e = binop(lit(abs(v) if unsigned else v), op, e) if rng.random() < 0.15 else binop(e, op, lit(abs(v) if unsigned else v))
     return e
+
+
+def random_pred(rng):
+    kind = int(rng.integers(0, 9))
+    if kind >= 7:  # integer chain ending in a comparison (the fast kernels' interpreted predicate when it cannot fault)
+        unsigned = kind == 8
+        e = random_chain_key(rng, 3 if unsigned else 0, unsigned=unsigned)
+        cmp_op = [Operator.Lt, Operator.LtEq, Operator.Gt, Operator.GtEq, Operator.Eq, Operator.NotEq][int(rng.integers(0, 6))]
+        lit = (lit_u64(int(rng.integers(0, 2000))) if unsigned else lit_i64(int(rng.integers(-50, 2000))))
+        return binop(lit, cmp_op, e) if rng.random() < 0.2 else binop(e, cmp_op, lit)
+    if kind == 0:
+        return None
+    if kind == 1:
+        return binop(col(0), [Operator.Lt, Operator.GtEq, Operator.NotEq, Operator.Eq][int(rng.integers(0, 4))], lit_i64(int(rng.integers(-5, 3000))))
+    if kind == 2:
+        return binop(col(2), [Operator.Gt, Operator.LtEq, Operator.NotEq][int(rng.integers(0, 3))], lit_f64(float(rng.choice([0.0, -0.0, 25.5, -60.0, float("nan"), float("inf")]))))
+    if kind == 3:
+        return col(4)
+    if kind == 4:
+        return binop(lit_u64(int(rng.integers(0, 1 << 39))), Operator.Lt, col(3))
+    return _random_tree(rng, int(rng.integers(1, 4)), "b")
 
 
 def random_key(rng):

@@ -84,6 +84,12 @@ if SECTION in ("all", "keys"):
         ctx.timing_enable(False)
         br = {k: round(ctx.timing_query(k)[0] / 5, 4) for k in ("agg_grouped", "agg_table_init", "agg_rank_finalize", "agg_collect", "bitonic", "agg_finalize")}
         print(f"aggregate {n} rows key {name}: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s  kernels(ms) {br}")
+if SECTION in ("all", "keys"):
+    from naive_query_engine_amd.expression import lit_i64 as _li
+    for name, pe in (("id % 10 < 5", binop(binop(col(0), Operator.Modulos, _li(10)), Operator.Lt, _li(5))),
+                     ("id * 3 >= 300000000", binop(binop(col(0), Operator.Multiply, _li(3)), Operator.GtEq, _li(300000000)))):
+        q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=key, pred_nodes=pe.flatten(f)), reps=20)
+        print(f"aggregate {n} rows, chain predicate {name}, key id % 1024: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
 if SECTION in ("all", "paths"):
     gen = binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(1000)).flatten(f)   # non-pow2 modulus: general key
     q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=gen, pred_nodes=pred))
