@@ -28,6 +28,9 @@
  *     bit-packed LSB-first, Utf8 = int32 offsets[length+1] + bytes.
  *   - inputs are borrowed for the duration of the call and never mutated;
  *     outputs are nqe_table handles owned by the caller (nqe_table_release).
+ *     Tables are immutable and their columns may share device buffers (a
+ *     projection of a column, a slice, the two key columns of an equi-join on
+ *     an integer key are one buffer): never write through nqe_table_column.
  *   - a context owns one HIP stream on one device and is used by one host
  *     thread at a time (the reference is single-threaded).
  *   - calls are stream-ordered: an operator may return while its last kernels
