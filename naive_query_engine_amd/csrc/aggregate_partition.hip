@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_kernel(AggArgs a, Fas
     }
     __syncthreads();
     const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
-    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED >= 2 ? a.pred_src.values : a.key_src.values);
     const uint64_t *__restrict__ valp[NVT];
 #pragma unroll
     for (int j = 0; j < NVT; ++j) valp[j] = static_cast<const uint64_t *>(a.val[j].values);
@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_kernel(AggArgs a, Fas
             row = row < last ? row : last;
             kw[u] = __builtin_nontemporal_load(&keyp[row]);
             if (PRED == 2) pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
+            if (PRED == 3) pw[u] = __builtin_nontemporal_load(&predp[row]);
             if (SCATTER) {
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
@@ -47,7 +48,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_kernel(AggArgs a, Fas
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = row < hi;
-            if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? kw[u] : pred_extract(fp, pw[u], row));
+            if (PRED == 3) pass = pass && eval_simple<false>(a.pred, pw[u], false, nullptr) != 0; // interpreted chain (host-vetted: cannot fault)
+            else if (PRED != 0) pass = pass && range_pass(fp, PRED == 1 ? kw[u] : pred_extract(fp, pw[u], row));
             const uint64_t key = inline_key<KEY>(a.key, kw[u], key_mask, key_aux, key_signed);
             if (!pass) continue;
             uint32_t p = uint32_t((key * GOLD) >> (64 - PARTS_LOG2));
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_scatter_kernel(AggArg
     }
     __syncthreads();
     const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
-    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED == 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED >= 2 ? a.pred_src.values : a.key_src.values);
     const uint64_t *__restrict__ valp[NVT];
 #pragma unroll
     for (int j = 0; j < NVT; ++j) valp[j] = static_cast<const uint64_t *>(a.val[j].values);
@@ -106,11 +108,13 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_partition_scatter_kernel(AggArg
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             int64_t rc = row < last ? row : last;
             uint64_t kw = __builtin_nontemporal_load(&keyp[rc]);
-            uint64_t pw = PRED == 2 ? pred_extract(fp, __builtin_nontemporal_load(&predp[rc >> fp.row_shift]), rc) : kw;
+            uint64_t pw = PRED == 2 ? pred_extract(fp, __builtin_nontemporal_load(&predp[rc >> fp.row_shift]), rc)
+                                    : (PRED == 3 ? __builtin_nontemporal_load(&predp[rc]) : kw);
 #pragma unroll
             for (int j = 0; j < NVT; ++j) vw[j][u] = __builtin_nontemporal_load(&valp[j][rc]);
             bool ok = row < hi;
-            if (PRED != 0) ok = ok && range_pass(fp, pw);
+            if (PRED == 3) ok = ok && eval_simple<false>(a.pred, pw, false, nullptr) != 0;
+            else if (PRED != 0) ok = ok && range_pass(fp, pw);
             key[u] = inline_key<KEY>(a.key, kw, key_mask, key_aux, key_signed);
             pass[u] = ok;
             part[u] = uint32_t((key[u] * GOLD) >> (64 - PARTS_LOG2));
@@ -432,14 +436,16 @@ PartKernel pick_scatter_kernel(int pred, int key, int nv) {
     switch (pred) {
     case 0: return pick_scatter_key<0>(key, nv);
     case 1: return pick_scatter_key<1>(key, nv);
-    default: return pick_scatter_key<2>(key, nv);
+    case 2: return pick_scatter_key<2>(key, nv);
+    default: return pick_scatter_key<3>(key, nv);
     }
 }
 PartKernel pick_part_kernel(int pred, int key, int nv, bool scatter) {
     switch (pred) {
     case 0: return pick_part_key<0>(key, nv, scatter);
     case 1: return pick_part_key<1>(key, nv, scatter);
-    default: return pick_part_key<2>(key, nv, scatter);
+    case 2: return pick_part_key<2>(key, nv, scatter);
+    default: return pick_part_key<3>(key, nv, scatter);
     }
 }
 SubpartitionKernel pick_subpartition_kernel(int nv) { return nv == 1 ? agg_subpartition_kernel<1> : agg_subpartition_kernel<2>; }

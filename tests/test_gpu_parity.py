@@ -497,6 +497,37 @@ def test_aggregate_two_step_integer_keys(ctx, m):
             assert (np.sort(kk) == kk).all() and len(np.unique(kk)) == len(kk) == got.num_rows
 
 
+@pytest.mark.parametrize("groups", [900, 120_000])
+def test_aggregate_chain_predicates(ctx, groups):
+    """integer chains ending in a comparison as predicates (`w % 7 >= 2`, `3 * k > -1000`, `100 - u / 3 != 67`, …): the fast kernels'
+    interpreted predicate variant on the single-pass path (900 groups) and on the hash-partitioned path (120000 groups, >= 2^18
+    rows), over the key column and over other columns, with plain and interpreted keys"""
+    rng = np.random.default_rng(groups)
+    n = 420_000
+    k = rng.integers(-groups // 2, groups // 2, n).astype(np.int64)
+    u = rng.integers(0, 1000, n).astype(np.uint64)
+    v = rng.random(n) * 10 - 5
+    w = rng.integers(-50, 50, n).astype(np.int64)
+    cols = [Column.from_numpy(k), Column.from_numpy(u), Column.from_numpy(v), Column.from_numpy(w)]
+    f4 = fields("k", "u", "v", "w")
+    t = ctx.table_from_host(cols)
+    K, U, W = col(0), col(1), col(3)
+    preds = [binop(binop(W, Operator.Modulos, lit_i64(7)), Operator.GtEq, lit_i64(2)),
+             binop(binop(lit_i64(3), Operator.Multiply, K), Operator.Gt, lit_i64(-1000)),
+             binop(binop(U, Operator.Divide, lit_u64(3)), Operator.NotEq, lit_u64(67)),
+             binop(lit_i64(5), Operator.LtEq, binop(K, Operator.Modulos, lit_i64(-16))),
+             binop(binop(W, Operator.Plus, lit_i64(50)), Operator.Eq, lit_i64(50))]
+    keys = [K, binop(binop(K, Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(groups + 1))]
+    aggs = ALL_AGGS(2)
+    for pred in preds:
+        for key in keys:
+            exp = orc.aggregate([cols], aggs, group_nodes=key.flatten(f4), pred_nodes=pred.flatten(f4))[0]
+            got, gk = ctx.aggregate(t, aggs, group_nodes=key.flatten(f4), pred_nodes=pred.flatten(f4), with_keys=True)
+            assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"pred {pred!r} key {key!r}")
+            kk = gk.to_host()[0].to_numpy()
+            assert (np.sort(kk) == kk).all() and len(np.unique(kk)) == len(kk) == got.num_rows
+
+
 def test_aggregate_partial_merge_equals_single_pass(ctx):
     rng = np.random.default_rng(99)
     n = 40000
