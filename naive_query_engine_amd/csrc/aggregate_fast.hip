@@ -1,14 +1,26 @@
-// aggregate_fast.hip — instantiations of the fast aggregate kernel for inputs without validity bitmaps, and the entry point
-// the host logic (aggregate.hip) uses to pick a variant.
+// aggregate_fast.hip — the entry point the host logic (aggregate.hip) uses to pick a variant of the fast aggregate kernel; the
+// instances live in eight slices (aggregate_fast_inst.hip compiled per predicate variant, with and without validity bitmaps).
 #include "aggregate_fast_kernel.hpp"
 
 namespace nqe {
 namespace agg {
 
-FastKernel pick_fast_kernel_nullable(int pred, int key, int nv, bool vf64); // aggregate_fast_null.hip
+#define NQE_FAST_DECL(p)                                   \
+    FastKernel pick_fast_p##p##_v0(int key, int nv, bool vf64); \
+    FastKernel pick_fast_p##p##_v1(int key, int nv, bool vf64);
+NQE_FAST_DECL(0)
+NQE_FAST_DECL(1)
+NQE_FAST_DECL(2)
+NQE_FAST_DECL(3)
+#undef NQE_FAST_DECL
 
 FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull) {
-    return vnull ? pick_fast_kernel_nullable(pred, key, nv, vf64) : pick_fast_pred<false>(pred, key, nv, vf64);
+    switch (pred) {
+    case 0: return vnull ? pick_fast_p0_v1(key, nv, vf64) : pick_fast_p0_v0(key, nv, vf64);
+    case 1: return vnull ? pick_fast_p1_v1(key, nv, vf64) : pick_fast_p1_v0(key, nv, vf64);
+    case 2: return vnull ? pick_fast_p2_v1(key, nv, vf64) : pick_fast_p2_v0(key, nv, vf64);
+    default: return vnull ? pick_fast_p3_v1(key, nv, vf64) : pick_fast_p3_v0(key, nv, vf64);
+    }
 }
 
 } // namespace agg

@@ -261,14 +261,6 @@ template <int PRED, bool VNULL> FastKernel pick_fast_key(int key, int nv, bool v
     default: return pick_fast_nv<PRED, 3, VNULL>(nv, vf64);
     }
 }
-template <bool VNULL> FastKernel pick_fast_pred(int pred, int key, int nv, bool vf64) {
-    switch (pred) {
-    case 0: return pick_fast_key<0, VNULL>(key, nv, vf64);
-    case 1: return pick_fast_key<1, VNULL>(key, nv, vf64);
-    case 2: return pick_fast_key<2, VNULL>(key, nv, vf64);
-    default: return pick_fast_key<3, VNULL>(key, nv, vf64);
-    }
-}
 
 } // namespace
 } // namespace agg
