@@ -1,6 +1,6 @@
 // aggregate_common.hpp — types, constants and device helpers shared by the aggregate translation units
-// (aggregate.hip: general / un-grouped kernels, table kernels, host logic; aggregate_fast.hip: the specialised streaming
-// kernel and its instantiations; aggregate_partition.hip: the partitioned path).  Split so that the ~100 kernel
+// (aggregate.hip: general / un-grouped kernels, table kernels, host logic; aggregate_fast*.hip: the specialised streaming
+// kernel and its instantiations; aggregate_partition.hip: the partitioned path).  Split so that the ~200 kernel
 // instantiations compile in parallel.
 #pragma once
 #include <cfloat>

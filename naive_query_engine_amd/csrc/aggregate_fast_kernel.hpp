@@ -1,6 +1,6 @@
 // aggregate_fast_kernel.hpp — the specialised streaming kernel of the hash aggregate (see aggregate.hip for the operator
-// and its semantics).  Included by aggregate_fast.hip (VNULL = false instantiations) and aggregate_fast_null.hip
-// (VNULL = true), so that the two halves of the ~70 instantiations compile in parallel.
+// and its semantics).  Instantiated by aggregate_fast_inst.hip, which the Makefile compiles once per predicate variant and
+// validity mode, so that the eight slices of the 128 instantiations compile in parallel; aggregate_fast.hip picks among them.
 #pragma once
 #include "aggregate_common.hpp"
 
