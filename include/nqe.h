@@ -76,7 +76,7 @@ typedef enum nqe_status {
     NQE_ERR_OTHERS = 13,          /* ErrorCode::Others */
     /* codes with no reference analogue */
     NQE_ERR_HIP = 100,            /* a HIP runtime call failed */
-    NQE_ERR_RCCL = 101,           /* reserved for collective failures */
+    NQE_ERR_RCCL = 101,           /* a collective / the exchange transport failed (nqe_comm_*, nqe_sharded_*) */
     NQE_ERR_INVALID_ARGUMENT = 102,
     NQE_ERR_OUT_OF_MEMORY = 103
 } nqe_status;
@@ -191,6 +191,9 @@ nqe_status nqe_ctx_timing_enable(nqe_ctx *ctx, int32_t enable);
  * contains `name_substr`; resets nothing. */
 nqe_status nqe_ctx_timing_query(nqe_ctx *ctx, const char *name_substr, double *total_ms, int64_t *launches);
 nqe_status nqe_ctx_timing_reset(nqe_ctx *ctx);
+/* every kernel family launched since the last reset by exact name, one "name\tms\tlaunches\n" line each, NUL-terminated;
+ * *needed = bytes required (call with capacity 0 to size the buffer). */
+nqe_status nqe_ctx_timing_report(nqe_ctx *ctx, char *buf, int64_t capacity, int64_t *needed);
 
 /* ------------------------------------------------------------------ tables
  * MemTable::try_create + ScanPlan::execute (datasource/memory.rs:21-41, scan.rs:34-36):
@@ -257,6 +260,64 @@ nqe_status nqe_table_pack_words(nqe_ctx *ctx, const nqe_table *const *tables, in
                                 void *dst_device);
 nqe_status nqe_table_unpack_words(nqe_ctx *ctx, const void *src_device, int32_t num_parts, int32_t num_columns,
                                   int64_t stride_rows, const int64_t *counts, const int32_t *dtypes, nqe_table **out);
+
+/* ------------------------------------------------------------------ sharded operators (multi-GPU)
+ * No reference analogue.  One process (or thread) per GPU, each with its own context and a communicator over it; every rank
+ * calls the same sharded entry point with ITS row range.  Collectives are enqueued on the context's stream (no host
+ * synchronisation between an operator's kernels and its exchange); failures of the transport are NQE_ERR_RCCL.
+ *
+ * The default transport is RCCL over xGMI, bound at run time (librccl.so.1 is dlopen'ed by the first nqe_comm_* call, never
+ * by single-GPU use): rank 0 calls nqe_comm_get_unique_id, the host distributes the 128 bytes by whatever it has (MPI, a
+ * store, torch.distributed), every rank calls nqe_comm_create.  nqe_comm_create_custom plugs in the host's own transport. */
+#define NQE_COMM_ID_BYTES 128
+/* rows of the fixed-size buffer a partial aggregate travels in (one collective, counts read on the device); larger partials take
+ * an exact-size two-step exchange */
+#define NQE_EXCHANGE_ROWS 4096
+typedef struct nqe_comm nqe_comm;
+typedef struct nqe_transport {
+    void *user;
+    /* every rank contributes `bytes` device bytes; recv (device) receives world*bytes ordered by rank.  Enqueue on `stream`
+     * (a hipStream_t) or complete before returning.  0 = success. */
+    int32_t (*all_gather)(void *user, const void *send, void *recv, size_t bytes, void *stream);
+    /* variable-length form: rank r's contribution (recv_bytes[r] bytes) lands at recv + recv_offsets[r]; send_bytes ==
+     * recv_bytes[own rank].  Arrays are host memory, valid for the duration of the call. */
+    int32_t (*all_gather_v)(void *user, const void *send, size_t send_bytes, void *recv, const size_t *recv_offsets,
+                            const size_t *recv_bytes, void *stream);
+    /* optional (may be NULL): brackets around the all_gather_v calls of one table (RCCL: ncclGroupStart / ncclGroupEnd) */
+    int32_t (*group_begin)(void *user);
+    int32_t (*group_end)(void *user);
+    /* optional: called by nqe_comm_destroy */
+    void (*destroy)(void *user);
+} nqe_transport;
+nqe_status nqe_comm_get_unique_id(void *id_out /* NQE_COMM_ID_BYTES */);
+nqe_status nqe_comm_rccl_version(int32_t *version_out);
+nqe_status nqe_comm_create(nqe_ctx *ctx, const void *unique_id, int32_t rank, int32_t world, nqe_comm **out);
+nqe_status nqe_comm_create_custom(nqe_ctx *ctx, const nqe_transport *transport, int32_t rank, int32_t world, nqe_comm **out);
+nqe_status nqe_comm_destroy(nqe_comm *comm);
+int32_t nqe_comm_rank(const nqe_comm *comm);
+int32_t nqe_comm_world(const nqe_comm *comm);
+/* Ordered variable-length all-gather of a per-rank result table: out = the ranks' tables concatenated in rank order (= row
+ * order for row-range shards), on every rank.  8-byte columns without validity only (NQE_ERR_NOT_SUPPORTED otherwise).  Counts
+ * travel first (one host wait), then each column moves peer to peer straight from the local table into its place in `out`;
+ * columns that share a buffer locally are moved once and share it in `out`. */
+nqe_status nqe_table_all_gather(nqe_comm *comm, const nqe_table *local, nqe_table **out);
+/* PhysicalAggregatePlan::execute (aggregate/mod.rs:113-222) over the union of every rank's `in`: per-rank partial state
+ * {count,sum,min,max} → ONE all-gather → merge on every rank; avg is finalised after the merge.  Same output contract as
+ * nqe_aggregate_execute on the concatenated input (f64 sums in a different order: 1e-9 relative).  Utf8 group keys are
+ * NQE_ERR_NOT_SUPPORTED here. */
+nqe_status nqe_sharded_aggregate_execute(nqe_comm *comm, const nqe_table *in, const nqe_expr_node *pred, int32_t pred_nodes,
+                                         const nqe_expr_node *group, int32_t group_nodes, const nqe_aggregate *aggs,
+                                         int32_t num_aggs, nqe_table **out, nqe_table **keys_out);
+/* HashJoin::probe (hash_join.rs:168-254) with the build side replicated (every rank built `build` from the whole left table)
+ * and the probe side range-split: `right_local` is this rank's contiguous row range.  gather = 0: out = this rank's output
+ * rows (rank order == probe row order); gather = 1: out = nqe_table_all_gather of them (the single-GPU result on every rank). */
+typedef struct nqe_join_table nqe_join_table;
+nqe_status nqe_sharded_hash_join_probe(nqe_comm *comm, const nqe_join_table *build, const nqe_table *right_local,
+                                       int32_t right_key, int32_t gather, nqe_table **out);
+/* Fused ProjectionPlan(SelectionPlan(input)) over a row-range shard, optionally gathered like the join. */
+nqe_status nqe_sharded_selection_projection_execute(nqe_comm *comm, const nqe_table *in_local, const nqe_expr_node *pred,
+                                                    int32_t pred_nodes, const nqe_expr_node *nodes, const int32_t *expr_offsets,
+                                                    int32_t num_exprs, int32_t gather, nqe_table **out);
 
 /* ------------------------------------------------------------------ expressions
  * PhysicalExpr::evaluate(batch).into_array() (expression/mod.rs:25-29, binary.rs:108-155,
@@ -354,8 +415,8 @@ nqe_status nqe_aggregate_merge_packed(nqe_ctx *ctx, const void *gathered_device,
  * NQE_ERR_NOT_SUPPORTED — the reference's downcast unwrap panics). */
 nqe_status nqe_hash_join_execute(nqe_ctx *ctx, const nqe_table *left, const nqe_table *right,
                                  int32_t left_key, int32_t right_key, nqe_table **out);
-/* Two-phase form: build once (replicated per GPU), probe many right batches / shards. */
-typedef struct nqe_join_table nqe_join_table;
+/* Two-phase form: build once (replicated per GPU), probe many right batches / shards (nqe_join_table is declared with the
+ * sharded operators above). */
 nqe_status nqe_hash_join_build(nqe_ctx *ctx, const nqe_table *left, int32_t left_key, nqe_join_table **out);
 nqe_status nqe_hash_join_probe(nqe_ctx *ctx, const nqe_join_table *build, const nqe_table *right,
                                int32_t right_key, nqe_table **out);

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libnqe_hip.so")
 # every symbol include/nqe.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
     "nqe_abi_version", "nqe_ctx_create", "nqe_ctx_destroy", "nqe_ctx_synchronize", "nqe_ctx_memory_stats", "nqe_ctx_trim", "nqe_last_error",
-    "nqe_last_global_error", "nqe_ctx_timing_enable", "nqe_ctx_timing_query", "nqe_ctx_timing_reset",
+    "nqe_last_global_error", "nqe_ctx_timing_enable", "nqe_ctx_timing_query", "nqe_ctx_timing_reset", "nqe_ctx_timing_report",
     "nqe_table_create", "nqe_table_release", "nqe_table_num_rows", "nqe_table_num_columns", "nqe_table_column",
     "nqe_table_download_column", "nqe_table_project", "nqe_table_slice", "nqe_table_concat", "nqe_table_pack_words",
     "nqe_table_unpack_words", "nqe_csv_infer_schema", "nqe_csv_read", "nqe_expr_evaluate",
@@ -29,7 +29,25 @@ SYMBOLS = [
     "nqe_aggregate_execute", "nqe_aggregate_partial", "nqe_aggregate_merge", "nqe_aggregate_merge_packed", "nqe_hash_join_execute",
     "nqe_hash_join_build", "nqe_hash_join_probe", "nqe_join_table_release", "nqe_take", "nqe_synth_fill",
     "nqe_device_alloc", "nqe_device_free",
+    "nqe_comm_get_unique_id", "nqe_comm_rccl_version", "nqe_comm_create", "nqe_comm_create_custom", "nqe_comm_destroy", "nqe_comm_rank",
+    "nqe_comm_world", "nqe_table_all_gather", "nqe_sharded_aggregate_execute", "nqe_sharded_hash_join_probe",
+    "nqe_sharded_selection_projection_execute",
 ]
+
+COMM_ID_BYTES = 128    # NQE_COMM_ID_BYTES
+EXCHANGE_ROWS = 4096   # NQE_EXCHANGE_ROWS
+
+# nqe_transport (include/nqe.h): the exchange's vtable
+_AG_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_AGV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p)
+_GRP_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p)
+_DESTROY_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class NqeTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", _AG_FN), ("all_gather_v", _AGV_FN), ("group_begin", _GRP_FN), ("group_end", _GRP_FN),
+                ("destroy", _DESTROY_FN)]
+
 
 _lib = None
 
@@ -59,6 +77,7 @@ def lib():
         "nqe_ctx_timing_enable": (i32, [vp, i32]),
         "nqe_ctx_timing_query": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
         "nqe_ctx_timing_reset": (i32, [vp]),
+        "nqe_ctx_timing_report": (i32, [vp, C.c_char_p, i64, C.POINTER(i64)]),
         "nqe_table_create": (i32, [vp, C.POINTER(NqeColumn), i32, pvp]),
         "nqe_table_release": (i32, [vp]),
         "nqe_table_num_rows": (i64, [vp]),
@@ -90,6 +109,17 @@ def lib():
         "nqe_synth_fill": (i32, [vp, i32, u64, i64, i64, u64, i64, vp]),
         "nqe_device_alloc": (i32, [vp, C.c_size_t, pvp]),
         "nqe_device_free": (i32, [vp, vp]),
+        "nqe_comm_get_unique_id": (i32, [vp]),
+        "nqe_comm_rccl_version": (i32, [C.POINTER(i32)]),
+        "nqe_comm_create": (i32, [vp, vp, i32, i32, pvp]),
+        "nqe_comm_create_custom": (i32, [vp, C.POINTER(NqeTransport), i32, i32, pvp]),
+        "nqe_comm_destroy": (i32, [vp]),
+        "nqe_comm_rank": (i32, [vp]),
+        "nqe_comm_world": (i32, [vp]),
+        "nqe_table_all_gather": (i32, [vp, vp, pvp]),
+        "nqe_sharded_aggregate_execute": (i32, [vp, vp, nodes, i32, nodes, i32, C.POINTER(NqeAggregate), i32, pvp, pvp]),
+        "nqe_sharded_hash_join_probe": (i32, [vp, vp, vp, i32, i32, pvp]),
+        "nqe_sharded_selection_projection_execute": (i32, [vp, vp, nodes, i32, nodes, C.POINTER(i32), i32, i32, pvp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -144,6 +174,18 @@ class Context:
         ms, cnt = C.c_double(), C.c_int64()
         self.check(lib().nqe_ctx_timing_query(self.handle, name_substr.encode(), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def timing_report(self) -> dict:
+        """{kernel name: (total ms, launches)} since the last reset, by exact name"""
+        need = C.c_int64()
+        self.check(lib().nqe_ctx_timing_report(self.handle, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(max(1, need.value))
+        self.check(lib().nqe_ctx_timing_report(self.handle, buf, len(buf), C.byref(need)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, cnt = line.split("\t")
+            out[name] = (float(ms), int(cnt))
+        return out
 
     # ---- tables
     def table_from_host(self, columns: Sequence[Column]) -> "Table":
@@ -343,6 +385,117 @@ class Context:
         h = C.c_void_p()
         self.check(lib().nqe_table_unpack_words(self.handle, C.c_void_p(src_ptr), len(counts), len(dtypes), stride_rows, ca, da, C.byref(h)))
         return Table(self, h)
+
+
+class Comm:
+    """nqe_comm: the exchange of the sharded operators over one context (include/nqe.h, "sharded operators").
+
+    Comm.rccl(ctx, unique_id, rank, world): RCCL over xGMI, one device per rank; rank 0 draws the id with Comm.unique_id() and the
+    host distributes the 128 bytes.  Comm.custom(ctx, transport, rank, world): the host's own transport — an object with
+    all_gather(send_ptr, recv_ptr, nbytes) and all_gather_v(send_ptr, send_bytes, recv_ptr, offsets, sizes) over device pointers.
+    The callbacks run on the calling thread while the context's stream may still be producing `send`: they must order themselves
+    against it (parallel.HostStagedTransport synchronises the context first)."""
+
+    def __init__(self, ctx: Context, handle, keep=None):
+        self.ctx = ctx
+        self.handle = handle
+        self._keep = keep
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        st = lib().nqe_comm_get_unique_id(buf)
+        if st != 0:
+            raise ErrorCode(st, lib().nqe_last_global_error().decode())
+        return buf.raw
+
+    @staticmethod
+    def rccl_version() -> int:
+        v = C.c_int32()
+        st = lib().nqe_comm_rccl_version(C.byref(v))
+        if st != 0:
+            raise ErrorCode(st, lib().nqe_last_global_error().decode())
+        return v.value
+
+    @classmethod
+    def rccl(cls, ctx: Context, unique_id: bytes, rank: int, world: int) -> "Comm":
+        assert len(unique_id) == COMM_ID_BYTES
+        h = C.c_void_p()
+        ctx.check(lib().nqe_comm_create(ctx.handle, C.c_char_p(unique_id), rank, world, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def custom(cls, ctx: Context, transport, rank: int, world: int) -> "Comm":
+        def ag(user, send, recv, nbytes, stream):
+            try:
+                transport.all_gather(send or 0, recv or 0, int(nbytes))
+                return 0
+            except Exception:  # noqa: BLE001 - the status code is all that crosses the ABI
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def agv(user, send, send_bytes, recv, offs, sizes, stream):
+            try:
+                transport.all_gather_v(send or 0, int(send_bytes), recv or 0, [int(offs[r]) for r in range(world)], [int(sizes[r]) for r in range(world)])
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        tr = NqeTransport()
+        tr.user = None
+        tr.all_gather = _AG_FN(ag)
+        tr.all_gather_v = _AGV_FN(agv)
+        tr.group_begin = _GRP_FN(0)
+        tr.group_end = _GRP_FN(0)
+        tr.destroy = _DESTROY_FN(0)
+        h = C.c_void_p()
+        ctx.check(lib().nqe_comm_create_custom(ctx.handle, C.byref(tr), rank, world, C.byref(h)))
+        return cls(ctx, h, keep=(tr, transport))
+
+    @property
+    def rank(self) -> int:
+        return int(lib().nqe_comm_rank(self.handle))
+
+    @property
+    def world(self) -> int:
+        return int(lib().nqe_comm_world(self.handle))
+
+    def close(self):
+        if self.handle and self.ctx.handle:
+            lib().nqe_comm_destroy(self.handle)
+        self.handle = None
+
+    # ---- sharded operators
+    def all_gather_table(self, table: "Table") -> "Table":
+        h = C.c_void_p()
+        self.ctx.check(lib().nqe_table_all_gather(self.handle, table.handle, C.byref(h)))
+        return Table(self.ctx, h)
+
+    def sharded_aggregate(self, table: "Table", aggs, group_nodes=None, pred_nodes=None):
+        c = self.ctx
+        parr, pn = c._nodes(pred_nodes)
+        garr, gn = c._nodes(group_nodes)
+        h, k = C.c_void_p(), C.c_void_p()
+        c.check(lib().nqe_sharded_aggregate_execute(self.handle, table.handle, parr, pn, garr, gn, c._aggs(aggs), len(aggs), C.byref(h), C.byref(k)))
+        return Table(c, h), (Table(c, k) if k.value else None)
+
+    def sharded_hash_join_probe(self, jt: "JoinTable", right_local: "Table", right_key: int, gather: bool = False) -> "Table":
+        h = C.c_void_p()
+        self.ctx.check(lib().nqe_sharded_hash_join_probe(self.handle, jt.handle, right_local.handle, right_key, 1 if gather else 0, C.byref(h)))
+        return Table(self.ctx, h)
+
+    def sharded_selection_projection(self, table: "Table", pred_nodes, exprs, gather: bool = False) -> "Table":
+        c = self.ctx
+        parr, pn = c._nodes(pred_nodes)
+        arr, offs, ne = c._flat(exprs)
+        h = C.c_void_p()
+        c.check(lib().nqe_sharded_selection_projection_execute(self.handle, table.handle, parr, pn, arr, offs, ne, 1 if gather else 0, C.byref(h)))
+        return Table(c, h)
 
 
 class Table:

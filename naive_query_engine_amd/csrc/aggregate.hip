@@ -1038,6 +1038,13 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     if (grouped && key_col >= 0 && !utf8_key) kp_valid_words_ok = kp_valid_words_ok && words_ok(in->cols[size_t(key_col)]);
     if (grouped && utf8_key) kp_valid_words_ok = kp_valid_words_ok && words_ok(utf8_src); // the codes share the strings' validity buffer
     if (a.pred_mode == 1) kp_valid_words_ok = kp_valid_words_ok && words_ok(in->cols[size_t(a.pred.col)]);
+    // a Boolean INPUT column used as the predicate is read by the fast kernels as whole 64-bit words of its VALUES bitmap too: a
+    // borrowed one ends at ceil(n/8) bytes, so unless n is a multiple of 64 (and the pointer 8-byte aligned) take the general kernel
+    bool pred_bits_words_ok = true;
+    if (a.pred_mode == 1 && a.pred.nops == 0 && a.pred_src.dtype == NQE_BOOLEAN) {
+        const DevColumn &pc = in->cols[size_t(a.pred.col)];
+        if (pc.values && !pc.values->owned && ((pc.length % 64) != 0 || (reinterpret_cast<uintptr_t>(pc.values->ptr) & 7) != 0)) pred_bits_words_ok = false;
+    }
 
     const int V = int(plan.val_cols.size());
     // Global table: the first attempt is SMALL (8192 slots) whatever the input size — every workgroup merges at most one LDS
@@ -1148,6 +1155,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     vnull = vnull || a.val[j].valid != nullptr;
                 }
                 if (vnull && (partition_mode || !valid_words_ok || !kp_valid_words_ok)) plain = false;
+                if (bitmap_pred && !pred_bits_words_ok) plain = false;
                 FastPred fpred{};
                 if (bitmap_pred) fpred = bitmap_fast_pred();
                 bool range_pred = pk == 1 && make_fast_pred(a.pred, &fpred);
@@ -1280,6 +1288,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     uvnull = uvnull || a.val[j].valid != nullptr;
                 }
                 if (uvnull && (!valid_words_ok || !kp_valid_words_ok)) uplain = false; // bitmaps must be readable as whole words
+                if (a.pred_src.dtype == NQE_BOOLEAN && a.pred_mode == 1 && a.pred.nops == 0 && !pred_bits_words_ok) uplain = false;
                 const bool ubitmap = a.pred_src.dtype == NQE_BOOLEAN && (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
                 if (ubitmap) ufp = bitmap_fast_pred();
                 bool upred_ok = a.pred_mode == 0 || ubitmap ||
@@ -1337,8 +1346,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             continue;
         }
         if (f[NQE_FLAG_TABLE_FULL]) {
+            // grow in 64 bits: 2^30 << 3 wraps a uint32_t to 0 (a zero-capacity table, then a spurious overflow error)
+            const uint64_t next = cap < sized_cap ? uint64_t(sized_cap) : uint64_t(cap) << 3;
             if (cap >= (1u << 31) || attempt > 8) fail(NQE_ERR_OUT_OF_MEMORY, "group table overflow");
-            cap = cap < sized_cap ? sized_cap : cap << 3;
+            cap = uint32_t(std::min<uint64_t>(next, uint64_t(1) << 31));
             flags_reset(ctx);
             continue;
         }

@@ -4,6 +4,10 @@
 #pragma once
 #include "aggregate_common.hpp"
 
+#ifndef NQE_AGG_BATCH
+#define NQE_AGG_BATCH 1 // 0: the round-1 row loop (A/B runs)
+#endif
+
 namespace nqe {
 namespace agg {
 namespace {
@@ -147,6 +151,76 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             }
         }
     };
+    // Rows of a thread whose keys differ inside one register tile (random keys): the run cache would flush once per row, each
+    // flush a dependent LDS round trip (slot → read min/max → compare → atomics); the kernel was bound by those waits, not by
+    // LDS-atomic throughput (tools/micro_bench.hip: the same update stream issued back to back runs 3x faster).  Such a tile
+    // goes to the table directly, all its rows at once: AGG_U slots, one batch of min/max reads, one wait, then the atomics.
+    auto direct_rows = [&](const Tile &t, int64_t base, const bool (&pass)[AGG_U], const uint64_t (&key)[AGG_U]) {
+        int slot[AGG_U];
+        int64_t gslot[AGG_U];
+        uint64_t k0[AGG_U];
+        if (!a.direct) {
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) k0[u] = lkeys[uint32_t((key[u] * GOLD) >> a.lds_shift)]; // first probe of every row, issued together
+        }
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            slot[u] = -1;
+            gslot[u] = -1;
+            if (!pass[u]) continue;
+            if (a.direct) {
+                slot[u] = int(int64_t(key[u]) + a.direct_bias);
+                if (VNULL) lkeys[slot[u]] = key[u];
+            } else if (k0[u] == key[u] && key[u] != EMPTY_KEY) {
+                slot[u] = int(uint32_t((key[u] * GOLD) >> a.lds_shift));
+            } else {
+                slot[u] = lds_find_or_insert(lkeys, key[u], cap, a.lds_shift);
+            }
+            if (slot[u] < 0) { // cold: the table rejected the key (see flush_run)
+                if (!*lds_full) {
+                    *lds_full = 1;
+                    if (a.allow_partition) atomicOr(&flags[NQE_FLAG_NEED_PARTITION], 1);
+                }
+                gslot[u] = a.allow_partition ? -1 : global_find_or_insert(g, key[u], flags);
+            }
+        }
+        uint64_t cmn[NVT][AGG_U], cmx[NVT][AGG_U];
+#pragma unroll
+        for (int j = 0; j < NVT; ++j) {
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) {
+                const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u] < 0 ? 0 : slot[u]);
+                cmn[j][u] = lmn[o]; // read-before-atomic, all rows of the tile in flight together
+                cmx[j][u] = lmx[o];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NVT; ++j) {
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) {
+                if (!pass[u]) continue;
+                const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+                const double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+                const bool vb = VNULL ? bool((t.vv[VNULL ? j : 0][u] >> (row & 63)) & 1ull) : true;
+                if (!vb) continue; // a NULL value contributes nothing; its row has created the group above
+                const bool isn = x != x;
+                const uint64_t xo = f64_to_ord(x);
+                if (slot[u] >= 0) {
+                    const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
+                    atomicAdd(&lcnt[o], 1u);
+                    unsafeAtomicAdd(&lsum[o], x);
+                    if (isn) atomicOr(&lcnt[o], NAN_BIT);
+                    else {
+                        if (xo < cmn[j][u]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)xo);
+                        if (xo > cmx[j][u]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)xo);
+                    }
+                } else if (gslot[u] >= 0) {
+                    global_update(g, gslot[u], a.v0 + j, 1, x, true, isn ? ORD_MAX : xo, isn ? ORD_MIN : xo, true, isn);
+                }
+            }
+        }
+    };
+
     auto process_tile = [&](const Tile &t, int64_t base) {
         // interpreted keys are computed for the whole tile up front (operator-major); the built-in shapes stay inside the row loop,
         // where the compiler sinks them below the predicate (hoisting them cost the headline 1.5 %)
@@ -154,20 +228,39 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         if (PRED == 3) inline_keys<3, AGG_U>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
         uint64_t keys[KEY == 3 ? AGG_U : 1];
         if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, reinterpret_cast<uint64_t (&)[AGG_U]>(keys), key_mask, key_aux, key_signed);
+        bool pass[AGG_U];
+        uint64_t key[AGG_U];
 #pragma unroll
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-            bool pass = row < n;
-            if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
+            pass[u] = row < n;
+            if (PRED == 3) pass[u] = pass[u] && pvals[PRED == 3 ? u : 0] != 0;
             else if (PRED != 0) {
-                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
+                pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             }
-            if (VNULL) pass = pass && ((t.kpv[u] >> (row & 63)) & 1ull);
-            const uint64_t key = KEY == 3 ? keys[KEY == 3 ? u : 0] : inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
-            if (!pass) continue;
-            if (!run_live || key != run_key) {
+            if (VNULL) pass[u] = pass[u] && ((t.kpv[u] >> (row & 63)) & 1ull);
+            key[u] = KEY == 3 ? keys[KEY == 3 ? u : 0] : inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
+        }
+#if NQE_AGG_BATCH
+        bool mixed = false; // keys of rows that fail the predicate take part: a false "mixed" costs nothing but the batch path
+#pragma unroll
+        for (int u = 1; u < AGG_U; ++u) mixed = mixed || key[u] != key[0];
+        if (mixed) {
+            if (run_live) {
+                flush_run();
+                run_live = false;
+            }
+            direct_rows(t, base, pass, key);
+            return;
+        }
+#endif
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            if (!pass[u]) continue;
+            if (!run_live || key[u] != run_key) {
                 if (run_live) flush_run();
-                run_key = key;
+                run_key = key[u];
                 run_live = true;
             }
 #pragma unroll

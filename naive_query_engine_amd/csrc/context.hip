@@ -593,6 +593,30 @@ nqe_status nqe_ctx_timing_query(nqe_ctx *ctx, const char *name_substr, double *t
     NQE_API_END()
 }
 
+// every kernel family launched since the last reset, by exact name: "name\tms\tlaunches\n" per line (sorted by name)
+nqe_status nqe_ctx_timing_report(nqe_ctx *ctx, char *buf, int64_t capacity, int64_t *needed) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx || !needed || capacity < 0 || (capacity > 0 && !buf)) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    sync(ctx);
+    std::map<std::string, std::pair<double, int64_t>> acc;
+    for (auto &t : ctx->timings) {
+        float ms = 0;
+        NQE_HIP_CHECK(hipEventElapsedTime(&ms, t.start, t.stop));
+        auto &a = acc[t.name];
+        a.first += ms;
+        a.second += 1;
+    }
+    std::string out;
+    char line[256];
+    for (auto &kv : acc) {
+        snprintf(line, sizeof(line), "%s\t%.6f\t%lld\n", kv.first.c_str(), kv.second.first, (long long)kv.second.second);
+        out += line;
+    }
+    *needed = int64_t(out.size()) + 1;
+    if (capacity >= *needed) std::memcpy(buf, out.c_str(), out.size() + 1);
+    NQE_API_END()
+}
+
 // ---------------------------------------------------------------- tables
 namespace {
 constexpr int PACK_MAX_COLS = 48, UNPACK_MAX_PARTS = 64;

@@ -19,6 +19,8 @@
 //           columns) in probe order — exactly the order of the reference's outer_pos/inner_pos.
 // Key validity is ignored (quirk Q11): raw 8-byte slot values are compared.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "device_utils.hpp"
 #include "nqe_internal.hpp"
@@ -610,6 +612,9 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
         }
     }
     sync(ctx); // skeys/flags/ustart are released on return
+    if (getenv("NQE_DEBUG"))
+        fprintf(stderr, "[nqe] join build: n=%lld U=%u direct=%d dense_span=%llu dense_payload=%d dense_full=%d cap=%u\n", (long long)n, U, int(jt->direct),
+                (unsigned long long)jt->dense_span, int(jt->dense_payload), int(jt->dense_full), jt->cap);
     return jt;
 }
 

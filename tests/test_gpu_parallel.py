@@ -1,6 +1,10 @@
-"""GPU, 2 ranks sharing cuda:0 (gloo rendezvous; RCCL needs one device per rank, the driver's 8-GPU
-run covers that): the sharded aggregate = per-rank nqe_aggregate_partial → ordered all-gather →
-nqe_aggregate_merge on every rank must equal the single-GPU result and the oracle."""
+"""GPU: the sharded operators of the C ABI (nqe_sharded_*, csrc/exchange.hip).
+
+* 2 ranks sharing cuda:0: RCCL needs one device per rank, so the two ranks drive the SAME C++ sharding code through the host-staged
+  transport (parallel.HostStagedTransport over gloo, plugged in with nqe_comm_create_custom) — sharded aggregate / join /
+  filter+projection must equal the single-GPU result and the oracle;
+* real RCCL (backend "nccl"): tools/check_exchange.py with one rank on a 1-GPU box, and with one rank per device under
+  torch.distributed.run whenever the box has two or more devices."""
 import os
 import socket
 
@@ -50,7 +54,7 @@ def worker(rank, world, port, q, mod):
     import torch.distributed as dist
 
     from naive_query_engine_amd import Column, capi
-    from naive_query_engine_amd.parallel import shard_range, sharded_aggregate
+    from naive_query_engine_amd.parallel import make_staged_comm, shard_range, sharded_aggregate
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -62,7 +66,8 @@ def worker(rank, world, port, q, mod):
         lo, hi = shard_range(N, rank, world)
         sub = [Column.from_numpy(c.to_numpy()[lo:hi], c.valid_mask()[lo:hi]) for c in cols]
         aggs, key, pred = plan(mod)
-        out, keys = sharded_aggregate(ctx, ctx.table_from_host(sub), aggs, group_nodes=key, pred_nodes=pred)
+        comm = make_staged_comm(ctx)
+        out, keys = sharded_aggregate(comm, ctx.table_from_host(sub), aggs, group_nodes=key, pred_nodes=pred)
         res = np.stack([c.to_numpy().astype(np.float64) for c in out.to_host()], axis=1)
         q.put((rank, keys.to_host()[0].to_numpy().tolist() if keys is not None else None, res.tolist()))
         ctx.close()
@@ -110,7 +115,7 @@ def join_worker(rank, world, port, q):
     import torch.distributed as dist
 
     from naive_query_engine_amd import Column, capi
-    from naive_query_engine_amd.parallel import shard_range, sharded_hash_join
+    from naive_query_engine_amd.parallel import make_staged_comm, shard_range, sharded_hash_join, sharded_selection_projection
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -121,8 +126,17 @@ def join_worker(rank, world, port, q):
         left, right = join_data()
         lo, hi = shard_range(right[0].length, rank, world)
         sub = [Column.from_numpy(c.to_numpy()[lo:hi]) for c in right]
-        out = sharded_hash_join(ctx, ctx.table_from_host(left), ctx.table_from_host(sub), 0, 0, gather=True)
-        q.put((rank, [c.to_numpy().view(np.int64).tolist() for c in out.to_host()]))
+        comm = make_staged_comm(ctx)
+        out = sharded_hash_join(comm, ctx.table_from_host(left), ctx.table_from_host(sub), 0, 0, gather=True)
+        # filter + projection over the same shard, gathered (ragged counts)
+        from naive_query_engine_amd import Operator
+        from naive_query_engine_amd.expression import binop, col, lit_i64
+        from tests.helpers import fields
+
+        f = fields("k", "v")
+        sp = sharded_selection_projection(comm, ctx.table_from_host(sub), binop(col(0), Operator.Lt, lit_i64(700)).flatten(f),
+                                          [binop(col(0), Operator.Plus, lit_i64(100)).flatten(f)], gather=True)
+        q.put((rank, [c.to_numpy().view(np.int64).tolist() for c in out.to_host()], sp.to_host()[0].to_numpy().tolist()))
         ctx.close()
     finally:
         dist.destroy_process_group()
@@ -156,20 +170,63 @@ def test_sharded_hash_join_two_ranks_keeps_probe_order():
         assert p.exitcode == 0
     left, right = join_data()
     exp = [c.to_numpy().view(np.int64).tolist() for c in orc.hash_join([left], [right], 0, 0)[0]]
-    for rank, got in results:
+    k = right[0].to_numpy()
+    exp_sp = (k[k < 700] + 100).tolist()
+    for rank, got, sp in results:
         assert got == exp  # build replicated, probe range-split, rank order == probe order
+        assert sp == exp_sp
 
 
-@pytest.mark.timeout(300)
-def test_single_rank_rccl_exchange_paths():
-    """real RCCL (backend "nccl") needs one device per rank, so on a 1-GPU box the collectives are exercised with ONE rank
-    and NQE_FORCE_EXCHANGE=1: the packed one-collective aggregate exchange and the equal-count zero-copy table gather must
-    reproduce the local results (tools/check_gather_nccl.py runs in its own process: torch initialises the device first)"""
+def _run_check_exchange(nranks):
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "check_exchange.py")
     env = dict(os.environ, MASTER_PORT=str(free_port()))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_gather_nccl.py")], capture_output=True, text=True, timeout=280, env=env)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "nccl single-rank exchange checks passed" in out.stdout
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if nranks == 1:
+        cmd = [sys.executable, tool]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
+               "--master-port", env["MASTER_PORT"], tool]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=560, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("exchange checks passed") == nranks, out.stdout[-2000:]
+
+
+@pytest.mark.timeout(600)
+def test_single_rank_rccl_exchange_paths():
+    """real RCCL needs one device per rank, so a 1-GPU box exercises nqe_comm_create / ncclAllGather / the sharded entry points
+    with ONE rank (tools/check_exchange.py runs in its own process: torch initialises the device first)"""
+    _run_check_exchange(1)
+
+
+@pytest.mark.timeout(600)
+def test_multi_device_rccl_exchange():
+    """one rank per device over RCCL (the peer-to-peer all_gather_v included) whenever the box has at least two devices"""
+    import torch
+
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs two or more GPUs (the driver's multi-GPU run)")
+    _run_check_exchange(min(n, 8))
+
+
+@pytest.mark.timeout(300)
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` launches N ranks itself and must fail loudly — never fall back to one GPU — when the box has
+    fewer devices"""
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=280, env=env)
+    assert out.returncode != 0
+    assert "n_gpus" not in out.stdout

@@ -925,3 +925,23 @@ def test_aggregate_two_level_partitioning_millions_of_groups(ctx):
     assert got.num_rows == len(np.unique(k))
     assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what="two-level partitioned aggregate")
     assert (gk.to_host()[0].to_numpy() == np.unique(k)).all()
+
+
+@pytest.mark.parametrize("n", [1000, 4097, 70001])  # none a multiple of 64: a borrowed bitmap ends at ceil(n/8) bytes
+def test_borrowed_boolean_predicate_column_is_not_read_past_its_end(ctx, n):
+    """a caller-owned (NQE_DEVICE) Boolean column used directly as the aggregate predicate: the fast kernels read predicate
+    bits as whole 64-bit words, which is only legal for padded (library-owned) bitmaps — a borrowed one whose length is not a
+    multiple of 64 must take the general kernel."""
+    rng = np.random.default_rng(n)
+    ids = rng.integers(0, 50, n).astype(np.int64)
+    v = rng.random(n) * 10.0
+    b = rng.random(n) < 0.5
+    cols = [Column.from_numpy(ids), Column.from_numpy(v), Column.from_numpy(b)]
+    owner = ctx.table_from_host(cols)  # device memory the "caller" owns; the table below only borrows it
+    tab = ctx.table_from_device([(DType(owner.column_info(i).dtype), n, owner.column_info(i).values, None) for i in range(3)])
+    f = fields("id", "v", "b")
+    aggs = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Min, 1), (AggregateFunc.Max, 1)]
+    for key in (col(0).flatten(f), None):
+        got = ctx.aggregate(tab, aggs, group_nodes=key, pred_nodes=col(2).flatten(f)).to_host()
+        exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=col(2).flatten(f))[0]
+        assert_rows_multiset_equal(got, exp, exact_cols=(0,))
