@@ -16,7 +16,8 @@ from .arrow_host import (DEVICE, Column, DType, ErrorCode, NqeAggregate, NqeColu
                          nodes_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnqe_hip.so")
+# NQE_LIB_PATH: another build of the same library (tools/build_variant.sh) for A/B runs on one GPU box
+LIB_PATH = os.environ.get("NQE_LIB_PATH") or os.path.join(_HERE, "libnqe_hip.so")
 
 # every symbol include/nqe.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [

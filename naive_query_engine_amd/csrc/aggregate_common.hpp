@@ -257,6 +257,18 @@ struct PartArgs {
     int64_t chunk;           // rows per workgroup (multiple of AGG_BLOCK*AGG_U)
 };
 
+// Slab form of the partitioned path (no count pass): scatter workgroup w appends the tuples of partition p to ITS OWN slab
+// (p, w) of fixed capacity — hash partitions of a chunk are near-uniform, so mean + 25 % + 64 tuples holds unless the keys are
+// heavily skewed (then NQE_FLAG_SLAB_OVERFLOW sends the query to the exact count → scan → scatter form).  A tuple is
+// (key, value...) in ONE stream: a 16-tuple run of a tile is 256 contiguous bytes instead of 128 B in each of two arrays.
+struct SlabArgs {
+    uint64_t *slabs;   // [PARTS][W][cap] tuples of (1 + nv) words
+    uint32_t *fill;    // [PARTS][W] tuples written
+    int64_t chunk;     // rows per scatter workgroup (multiple of the scatter tile)
+    int32_t W;         // scatter workgroups
+    int32_t cap;       // tuples per slab
+};
+
 constexpr int SUB_LOG2 = 6;
 constexpr int SUB = 1 << SUB_LOG2;
 
@@ -270,6 +282,11 @@ using SubpartitionKernel = void (*)(const uint64_t *, int64_t, const uint64_t *,
 SubpartitionKernel pick_subpartition_kernel(int nv);
 using SegmentsKernel = void (*)(AggArgs, const uint64_t *, int64_t, int, int, int, const uint64_t *, const uint64_t *, const uint64_t *, GroupTable, int *);
 SegmentsKernel pick_segments_kernel(int nv, bool vf64);
+using SlabScatterKernel = void (*)(AggArgs, FastPred, SlabArgs, int *);
+SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv);
+int slab_scatter_rows_per_thread(int pred, int nv);
+using SlabSegmentsKernel = void (*)(AggArgs, SlabArgs, GroupTable, int *);
+SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64);
 
 } // namespace agg
 } // namespace nqe

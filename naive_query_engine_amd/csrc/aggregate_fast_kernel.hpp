@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
     const int64_t n = a.n, last = a.n - 1;
 
-    constexpr bool PIPE = true, NT = true; // both measured wins (prefetched second tile: 3.24 -> 2.69 ms with the lean loop; nt loads: -2..3 %)
+    constexpr bool NT = true; // non-temporal loads: -2..3 % (and the loop below keeps a prefetched second tile in flight: 3.24 -> 2.69 ms with the lean loop)
     struct Tile {
         uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
         uint64_t vv[VNULL ? NVT : 1][AGG_U]; // validity word of the wave's 64 rows
@@ -221,27 +221,82 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         }
     };
 
-    auto process_tile = [&](const Tile &t, int64_t base) {
+    // Two row loops.  RUN: register accumulation while a thread's key repeats (sorted ids, `id % m` with m | 1024), where nothing
+    // but a changed key touches LDS.  BATCH: every key of the tile up front, tiles whose keys differ go through direct_rows.
+    // Hoisting the keys costs the run loop's best case 4-5 % (the headline kernel sits at the HBM/VALU knee; A/B on one box:
+    // 2.36 -> 2.47 ms with the test on every tile, still +2-3 % with a per-tile mode branch inside one loop), so they are two
+    // separate streaming loops and a wave re-picks between them every 64 tiles from the keys of the tile in hand: batch when a
+    // quarter of its lanes see mixed keys (random keys: 2.90 -> 2.57 ms).
+    auto accumulate_row = [&](const Tile &t, int u, int64_t row, uint64_t key) {
+        if (!run_live || key != run_key) {
+            if (run_live) flush_run();
+            run_key = key;
+            run_live = true;
+        }
+#pragma unroll
+        for (int j = 0; j < NVT; ++j) {
+            double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+            if (VNULL) {
+                // a NULL value contributes nothing (count of non-null, Q10) but its row still creates the group:
+                // branch-free — count += bit, sum += 0, and a NaN operand that min/max ignore and the flag skips
+                const bool vb = (t.vv[VNULL ? j : 0][u] >> (row & 63)) & 1ull;
+                rcnt[j] += vb ? 1u : 0u;
+                rsum[j] += vb ? x : 0.0;
+                rnan[j] = rnan[j] || (vb && x != x);
+                const double xm = vb ? x : __builtin_nan("");
+                rmn[j] = fmin(rmn[j], xm);
+                rmx[j] = fmax(rmx[j], xm);
+            } else {
+                rcnt[j] += 1;
+                rsum[j] += x;
+                rnan[j] = rnan[j] || (x != x);
+                rmn[j] = fmin(rmn[j], x); // NaN operand ignored
+                rmx[j] = fmax(rmx[j], x);
+            }
+        }
+    };
+    auto process_run = [&](const Tile &t, int64_t base) {
         // interpreted keys are computed for the whole tile up front (operator-major); the built-in shapes stay inside the row loop,
         // where the compiler sinks them below the predicate (hoisting them cost the headline 1.5 %)
         uint64_t pvals[PRED == 3 ? AGG_U : 1];
         if (PRED == 3) inline_keys<3, AGG_U>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
         uint64_t keys[KEY == 3 ? AGG_U : 1];
         if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, reinterpret_cast<uint64_t (&)[AGG_U]>(keys), key_mask, key_aux, key_signed);
+#pragma unroll
+        for (int u = 0; u < AGG_U; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            bool pass = row < n;
+            if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
+            else if (PRED != 0) {
+                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
+            }
+            if (VNULL) pass = pass && ((t.kpv[u] >> (row & 63)) & 1ull);
+            const uint64_t key = KEY == 3 ? keys[KEY == 3 ? u : 0] : inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
+            if (!pass) continue;
+            accumulate_row(t, u, row, key);
+        }
+    };
+    auto tile_keys = [&](const Tile &t, uint64_t (&key)[AGG_U]) {
+        if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, key, key_mask, key_aux, key_signed);
+        else {
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) key[u] = inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
+        }
+    };
+    auto process_batch = [&](const Tile &t, int64_t base) {
+        uint64_t pvals[PRED == 3 ? AGG_U : 1];
+        if (PRED == 3) inline_keys<3, AGG_U>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
         bool pass[AGG_U];
         uint64_t key[AGG_U];
+        tile_keys(t, key);
 #pragma unroll
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             pass[u] = row < n;
             if (PRED == 3) pass[u] = pass[u] && pvals[PRED == 3 ? u : 0] != 0;
-            else if (PRED != 0) {
-                pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
-            }
+            else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             if (VNULL) pass[u] = pass[u] && ((t.kpv[u] >> (row & 63)) & 1ull);
-            key[u] = KEY == 3 ? keys[KEY == 3 ? u : 0] : inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
         }
-#if NQE_AGG_BATCH
         bool mixed = false; // keys of rows that fail the predicate take part: a false "mixed" costs nothing but the batch path
 #pragma unroll
         for (int u = 1; u < AGG_U; ++u) mixed = mixed || key[u] != key[0];
@@ -251,69 +306,55 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 run_live = false;
             }
             direct_rows(t, base, pass, key);
-            return;
-        }
-#endif
+        } else {
 #pragma unroll
-        for (int u = 0; u < AGG_U; ++u) {
-            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-            if (!pass[u]) continue;
-            if (!run_live || key[u] != run_key) {
-                if (run_live) flush_run();
-                run_key = key[u];
-                run_live = true;
-            }
-#pragma unroll
-            for (int j = 0; j < NVT; ++j) {
-                double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
-                if (VNULL) {
-                    // a NULL value contributes nothing (count of non-null, Q10) but its row still creates the group:
-                    // branch-free — count += bit, sum += 0, and a NaN operand that min/max ignore and the flag skips
-                    const bool vb = (t.vv[j][u] >> (row & 63)) & 1ull;
-                    rcnt[j] += vb ? 1u : 0u;
-                    rsum[j] += vb ? x : 0.0;
-                    rnan[j] = rnan[j] || (vb && x != x);
-                    const double xm = vb ? x : __builtin_nan("");
-                    rmn[j] = fmin(rmn[j], xm);
-                    rmx[j] = fmax(rmx[j], xm);
-                } else {
-                    rcnt[j] += 1;
-                    rsum[j] += x;
-                    rnan[j] = rnan[j] || (x != x);
-                    rmn[j] = fmin(rmn[j], x); // NaN operand ignored
-                    rmx[j] = fmax(rmx[j], x);
-                }
-            }
+            for (int u = 0; u < AGG_U; ++u)
+                if (pass[u]) accumulate_row(t, u, base + int64_t(u) * AGG_BLOCK + threadIdx.x, key[u]);
         }
     };
 
     const int64_t step = int64_t(AGG_BLOCK) * AGG_U;
     const int64_t stride = int64_t(gridDim.x) * step;
     int64_t base = int64_t(blockIdx.x) * step;
-    if (PIPE) {
-        if (base < n) {
-            Tile A, B;
-            load_tile(A, base);
-            for (;;) {
-                load_tile(B, base + stride); // prefetch (clamped, always issued)
-                process_tile(A, base);
-                base += stride;
-                if (base >= n) break;
-                load_tile(A, base + stride);
-                process_tile(B, base);
-                base += stride;
-                if (base >= n) break;
-                if (*lds_full && (a.allow_partition || __hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
-                    break; // the host redoes the query (partitioned path / larger table)
-                if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                    break; // another workgroup's table overflowed: this attempt is abandoned anyway
+    // up to 2 x `budget` tiles.  In: A holds tile `base` (< n).  Out: base >= n (done or abandoned), or A holds tile `base`.
+    auto stream = [&](auto &&process, Tile &A, int budget) {
+        Tile B;
+        for (int it = 0; it < budget; ++it) {
+            load_tile(B, base + stride); // prefetch (clamped, always issued)
+            process(A, base);
+            base += stride;
+            if (base >= n) return;
+            load_tile(A, base + stride);
+            process(B, base);
+            base += stride;
+            if (base >= n) return;
+            if (*lds_full && (a.allow_partition || __hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                base = n; // the host redoes the query (partitioned path / larger table)
+                return;
+            }
+            if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                base = n; // another workgroup's table overflowed: this attempt is abandoned anyway
+                return;
             }
         }
-    } else {
-        for (; base < n; base += stride) {
-            Tile A;
-            load_tile(A, base);
-            process_tile(A, base);
+    };
+    if (base < n) {
+        Tile A;
+        load_tile(A, base);
+        // not where registers are short: the VNULL variants (37 VGPRs spilled: 2.2x slower), two value columns, interpreted predicates
+        constexpr bool CAN_BATCH = NQE_AGG_BATCH && !VNULL && NVT == 1 && PRED != 3 && !(PRED == 2 && KEY == 3);
+        while (base < n) {
+            bool batch = false; // wave-uniform
+            if (CAN_BATCH) {
+                uint64_t key[AGG_U];
+                tile_keys(A, key);
+                bool mixed = false;
+#pragma unroll
+                for (int u = 1; u < AGG_U; ++u) mixed = mixed || key[u] != key[0];
+                batch = __popcll(__ballot(mixed)) >= 16;
+            }
+            if (CAN_BATCH && batch) stream(process_batch, A, 32);
+            else stream(process_run, A, CAN_BATCH ? 32 : (1 << 30));
         }
     }
     if (run_live) flush_run();

@@ -404,6 +404,344 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
     }
 }
 
+// ------------------------------------------------------------------ slab form: no count pass, software-pipelined scatter
+// Rows per thread per tile: 8 where the registers allow two tiles in flight (one value column, predicate on the key column or
+// none), else 4.
+template <int PRED, int NVT> struct SlabShape {
+    static constexpr int RPT = (NVT == 1 && PRED <= 1) ? 8 : 4;
+};
+
+// One workgroup per chunk of rows.  Per tile: fused predicate + key → partition → rank (LDS atomic on the tile's counter) →
+// tile-local scan → tuples written to LDS at their sorted position → copied out so that consecutive lanes write consecutive
+// tuples of one partition into THIS workgroup's slab of it.  The next tile's words are requested before the copy-out, so the
+// loads overlap the LDS phases and the stores (one workgroup per CU fits — 136 KB of LDS — and the unpipelined form spent
+// 22 µs per 8192-row tile where the CU's share of HBM needs 13).
+template <int PRED, int KEY, int NVT>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, FastPred fp, SlabArgs sa, int *flags) {
+    constexpr int RPT = SlabShape<PRED, NVT>::RPT;
+    constexpr int SC_ROWS = AGG_BLOCK * RPT;
+    constexpr int TW = 1 + NVT; // words per tuple
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *stup = reinterpret_cast<uint64_t *>(smem);                    // [SC_ROWS][TW]
+    uint32_t *gcur = reinterpret_cast<uint32_t *>(stup + size_t(SC_ROWS) * TW); // [PARTS] tuples this workgroup has written per partition
+    uint32_t *tcnt = gcur + PARTS;                                          // [PARTS] tuples of this tile per partition
+    uint32_t *tstart = tcnt + PARTS;                                        // [PARTS] tile-local exclusive scan
+    __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
+    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) {
+        gcur[p] = 0;
+        tcnt[p] = 0;
+    }
+    __syncthreads();
+    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED >= 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ valp[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) valp[j] = static_cast<const uint64_t *>(a.val[j].values);
+    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
+    const OpAux key_aux = a.key.aux[0];
+    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
+    const int64_t lo = int64_t(blockIdx.x) * sa.chunk;
+    const int64_t hi = lo + sa.chunk < a.n ? lo + sa.chunk : a.n;
+    const int64_t last = a.n - 1;
+    const uint32_t cap = uint32_t(sa.cap);
+    struct Regs {
+        uint64_t kw[RPT], pw[PRED >= 2 ? RPT : 1], vw[NVT][RPT];
+    };
+    auto load = [&](Regs &r, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            row = row < last ? row : last; // clamp: unconditional, in-bounds
+            r.kw[u] = __builtin_nontemporal_load(&keyp[row]);
+            if (PRED == 2) r.pw[PRED >= 2 ? u : 0] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
+            if (PRED == 3) r.pw[PRED >= 2 ? u : 0] = __builtin_nontemporal_load(&predp[row]);
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) r.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
+        }
+    };
+    auto tile = [&](const Regs &r, Regs &next, int64_t base) {
+        uint64_t key[RPT];
+        uint32_t part[RPT], rank[RPT];
+        bool pass[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            bool ok = row < hi;
+            if (PRED == 3) ok = ok && eval_simple<false>(a.pred, r.pw[PRED >= 2 ? u : 0], false, nullptr) != 0; // host-vetted chain: cannot fault
+            else if (PRED == 2) ok = ok && range_pass(fp, pred_extract(fp, r.pw[PRED >= 2 ? u : 0], row < last ? row : last));
+            else if (PRED == 1) ok = ok && range_pass(fp, r.kw[u]);
+            key[u] = inline_key<KEY>(a.key, r.kw[u], key_mask, key_aux, key_signed);
+            pass[u] = ok;
+            part[u] = uint32_t((key[u] * GOLD) >> (64 - PARTS_LOG2));
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
+        __syncthreads();
+        // tile-local exclusive scan of the PARTS counters (threads 0..PARTS-1)
+        uint32_t c = threadIdx.x < PARTS ? tcnt[threadIdx.x] : 0u, wt;
+        uint32_t ex = wave_exclusive_scan(c, wt);
+        if (lane_id() == 63) wave_tot[threadIdx.x / 64] = wt;
+        __syncthreads();
+        if (threadIdx.x < PARTS) {
+            uint32_t pre = 0;
+            for (int w = 0; w < int(threadIdx.x) / 64; ++w) pre += wave_tot[w];
+            tstart[threadIdx.x] = pre + ex;
+        }
+        uint32_t tile_total = 0;
+        for (int w = 0; w < PARTS / 64; ++w) tile_total += wave_tot[w];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            if (!pass[u]) continue;
+            const uint32_t i = tstart[part[u]] + rank[u];
+            if (TW == 2) {
+                *reinterpret_cast<ulonglong2 *>(&stup[size_t(i) * 2]) = make_ulonglong2(key[u], r.vw[0][u]);
+            } else {
+                stup[size_t(i) * TW] = key[u];
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) stup[size_t(i) * TW + 1 + j] = r.vw[j][u];
+            }
+        }
+        if (base + SC_ROWS < hi) load(next, base + SC_ROWS); // workgroup-uniform: the next tile's words fly during the copy-out
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < tile_total; i += blockDim.x) {
+            uint64_t k, v0 = 0, v1 = 0;
+            if (TW == 2) {
+                const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(&stup[size_t(i) * 2]);
+                k = t.x;
+                v0 = t.y;
+            } else {
+                k = stup[size_t(i) * TW];
+                v0 = stup[size_t(i) * TW + 1];
+                if (NVT > 1) v1 = stup[size_t(i) * TW + 2];
+            }
+            const uint32_t p = uint32_t((k * GOLD) >> (64 - PARTS_LOG2));
+            const uint32_t at = gcur[p] + (i - tstart[p]);
+            if (at < cap) {
+                uint64_t *dst = sa.slabs + ((size_t(p) * size_t(sa.W) + blockIdx.x) * size_t(cap) + at) * TW;
+                if (TW == 2) {
+                    *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(k, v0);
+                } else {
+                    dst[0] = k;
+                    dst[1] = v0;
+                    if (NVT > 1) dst[2] = v1;
+                }
+            } else {
+                atomicOr(&flags[NQE_FLAG_SLAB_OVERFLOW], 1); // skewed keys: the host redoes the query with exact partition sizes
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < PARTS) {
+            gcur[threadIdx.x] += tcnt[threadIdx.x];
+            tcnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+    };
+    if (lo < hi) {
+        Regs A, B;
+        load(A, lo);
+        for (int64_t base = lo; base < hi; base += 2 * int64_t(SC_ROWS)) {
+            tile(A, B, base);
+            if (base + SC_ROWS >= hi) break;
+            tile(B, A, base + SC_ROWS);
+        }
+    }
+    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) sa.fill[size_t(p) * size_t(sa.W) + blockIdx.x] = gcur[p] < cap ? gcur[p] : cap;
+}
+
+// one workgroup per partition (grid-stride); its waves take the partition's slabs round-robin and stream their tuples, four
+// per lane per step, into the workgroup's LDS table with the batched update of the fast kernel (all first probes, then all
+// min/max reads of the step in flight together — tuples of a partition arrive in no particular order, every row is an update).
+template <int NVT, bool VF64>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a, SlabArgs sa, GroupTable g, int *flags) {
+    constexpr int TW = 1 + NVT;
+    constexpr int SU = 4; // tuples per lane per step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t cap = uint32_t(a.lds_cap);
+    const uint32_t slots = cap + 1;
+    uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
+    double *lsum = reinterpret_cast<double *>(lkeys + slots);
+    uint64_t *lmn = reinterpret_cast<uint64_t *>(lsum + NVT * slots);
+    uint64_t *lmx = lmn + NVT * slots;
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + NVT * slots);
+    const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
+    int vdt[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) vdt[j] = a.val[j].dtype;
+    __shared__ int seg_full_flag;
+    volatile int *seg_full = &seg_full_flag;
+    const int wave = int(threadIdx.x) / 64, nwaves = AGG_BLOCK / 64;
+    for (int p = blockIdx.x; p < PARTS; p += gridDim.x) {
+        __syncthreads();
+        if (__hip_atomic_load(&flags[NQE_FLAG_NEED_LEVEL2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        if (threadIdx.x == 0) seg_full_flag = 0;
+        for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+            lkeys[s] = EMPTY_KEY;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+                lsum[j * slots + s] = 0.0;
+                lmn[j * slots + s] = ORD_MAX;
+                lmx[j * slots + s] = ORD_MIN;
+                lcnt[j * slots + s] = 0;
+            }
+        }
+        __syncthreads();
+        for (int w = wave; w < sa.W; w += nwaves) {
+            const uint32_t f = sa.fill[size_t(p) * size_t(sa.W) + w];
+            const uint64_t *__restrict__ slab = sa.slabs + (size_t(p) * size_t(sa.W) + w) * size_t(sa.cap) * TW;
+            for (uint32_t i0 = 0; i0 < f; i0 += 64 * SU) {
+                uint64_t key[SU], vw[NVT][SU];
+                bool live[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
+                    live[u] = i < f;
+                    const uint32_t ic = live[u] ? i : f - 1;
+                    if (TW == 2) {
+                        const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(&slab[size_t(ic) * 2]);
+                        key[u] = t.x;
+                        vw[0][u] = t.y;
+                    } else {
+                        key[u] = slab[size_t(ic) * TW];
+#pragma unroll
+                        for (int j = 0; j < NVT; ++j) vw[j][u] = slab[size_t(ic) * TW + 1 + j];
+                    }
+                }
+                // ---- slots: every first probe issued before any is examined
+                uint32_t s0[SU];
+                uint64_t k0[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    s0[u] = uint32_t(((key[u] * GOLD) << PARTS_LOG2) >> a.lds_shift);
+                    k0[u] = lkeys[s0[u]];
+                }
+                int slot[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    slot[u] = -1;
+                    if (!live[u]) continue;
+                    if (key[u] == EMPTY_KEY) {
+                        lkeys[cap] = 0;
+                        slot[u] = int(cap);
+                    } else if (k0[u] == key[u]) {
+                        slot[u] = int(s0[u]);
+                    } else if (!*seg_full) {
+                        uint32_t sl = s0[u];
+                        for (int probe = 0; probe < 32; ++probe) {
+                            uint64_t k = lkeys[sl];
+                            if (k == key[u]) { slot[u] = int(sl); break; }
+                            if (k == EMPTY_KEY) {
+                                uint64_t old = atomicCAS((unsigned long long *)&lkeys[sl], (unsigned long long)EMPTY_KEY, (unsigned long long)key[u]);
+                                if (old == EMPTY_KEY || old == key[u]) { slot[u] = int(sl); break; }
+                            }
+                            sl = (sl + 1) & (cap - 1);
+                        }
+                    }
+                    if (slot[u] < 0 && !*seg_full) { // more distinct keys than the table: the host partitions one level deeper (exact form)
+                        *seg_full = 1;
+                        atomicOr(&flags[NQE_FLAG_NEED_LEVEL2], 1);
+                    }
+                }
+                // ---- read-before-atomic, the step's rows in flight together
+                uint64_t cmn[NVT][SU], cmx[NVT][SU];
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) {
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u] < 0 ? 0 : slot[u]);
+                        cmn[j][u] = lmn[o];
+                        cmx[j][u] = lmx[o];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) {
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        if (slot[u] < 0) continue;
+                        const double x = VF64 ? u2d(vw[j][u]) : word_as_f64(vw[j][u], vdt[j]);
+                        const bool isn = x != x;
+                        const uint64_t xo = f64_to_ord(x);
+                        const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
+                        atomicAdd(&lcnt[o], 1u);
+                        unsafeAtomicAdd(&lsum[o], x);
+                        if (isn) atomicOr(&lcnt[o], NAN_BIT);
+                        else {
+                            if (xo < cmn[j][u]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)xo);
+                            if (xo > cmx[j][u]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)xo);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (*seg_full) break; // result discarded
+        if (g.dense_count) {
+            // ---- dense output: count this partition's groups, reserve [base, base + n) with one atomic, write them there
+            __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
+            __shared__ uint32_t dense_base;
+            uint32_t mine = 0;
+            for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) mine += lkeys[s] != EMPTY_KEY ? 1u : 0u;
+            uint32_t wtot;
+            const uint32_t wexcl = wave_exclusive_scan(mine, wtot);
+            if (lane_id() == 0) wave_tot[threadIdx.x / 64] = wtot;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t tot = 0;
+                for (int w = 0; w < AGG_BLOCK / 64; ++w) { uint32_t c = wave_tot[w]; wave_tot[w] = tot; tot += c; }
+                dense_base = tot ? atomicAdd(g.dense_count, tot) : 0u;
+            }
+            __syncthreads();
+            uint32_t pos = dense_base + wave_tot[threadIdx.x / 64] + wexcl;
+            const size_t gstride = size_t(g.cap) + 1;
+            for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+                uint64_t k = lkeys[s];
+                if (k == EMPTY_KEY) continue;
+                if (pos < g.cap) {
+                    g.keys[pos] = (s == cap) ? EMPTY_KEY : k;
+#pragma unroll
+                    for (int j = 0; j < NVT; ++j) {
+                        const uint32_t o = uint32_t(j) * slots + s;
+                        const uint32_t c = lcnt[o];
+                        const size_t go = size_t(a.v0 + j) * gstride + pos;
+                        g.cnt[go] = uint64_t(c & ~NAN_BIT);
+                        g.sum[go] = lsum[o];
+                        g.mn[go] = lmn[o];
+                        g.mx[go] = lmx[o];
+                        g.nan[go] = (c & NAN_BIT) ? 1u : 0u;
+                    }
+                } else atomicOr(&flags[NQE_FLAG_DENSE_OVERFLOW], 1);
+                ++pos;
+            }
+            continue;
+        }
+        for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+            uint64_t k = lkeys[s];
+            if (k == EMPTY_KEY) continue;
+            uint64_t key = (s == cap) ? EMPTY_KEY : k;
+            int64_t gslot = global_find_or_insert(g, key, flags);
+            if (gslot < 0) continue;
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+                uint32_t o = uint32_t(j) * slots + s;
+                uint32_t c = lcnt[o];
+                global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
+            }
+        }
+    }
+}
+
+template <int PRED, int KEY> SlabScatterKernel pick_slab_scatter_nv(int nv) {
+    return nv == 1 ? agg_slab_scatter_kernel<PRED, KEY, 1> : agg_slab_scatter_kernel<PRED, KEY, 2>;
+}
+template <int PRED> SlabScatterKernel pick_slab_scatter_key(int key, int nv) {
+    switch (key) {
+    case 0: return pick_slab_scatter_nv<PRED, 0>(nv);
+    case 1: return pick_slab_scatter_nv<PRED, 1>(nv);
+    case 2: return pick_slab_scatter_nv<PRED, 2>(nv);
+    default: return pick_slab_scatter_nv<PRED, 3>(nv);
+    }
+}
+
 template <int PRED, int KEY> PartKernel pick_scatter_nv(int nv) {
     return nv == 1 ? agg_partition_scatter_kernel<PRED, KEY, 1> : agg_partition_scatter_kernel<PRED, KEY, 2>;
 }
@@ -447,6 +785,19 @@ PartKernel pick_part_kernel(int pred, int key, int nv, bool scatter) {
     case 2: return pick_part_key<2>(key, nv, scatter);
     default: return pick_part_key<3>(key, nv, scatter);
     }
+}
+SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv) {
+    switch (pred) {
+    case 0: return pick_slab_scatter_key<0>(key, nv);
+    case 1: return pick_slab_scatter_key<1>(key, nv);
+    case 2: return pick_slab_scatter_key<2>(key, nv);
+    default: return pick_slab_scatter_key<3>(key, nv);
+    }
+}
+int slab_scatter_rows_per_thread(int pred, int nv) { return (nv == 1 && pred <= 1) ? 8 : 4; }
+SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64) {
+    return nv == 1 ? (vf64 ? agg_slab_segments_kernel<1, true> : agg_slab_segments_kernel<1, false>)
+                   : (vf64 ? agg_slab_segments_kernel<2, true> : agg_slab_segments_kernel<2, false>);
 }
 SubpartitionKernel pick_subpartition_kernel(int nv) { return nv == 1 ? agg_subpartition_kernel<1> : agg_subpartition_kernel<2>; }
 SegmentsKernel pick_segments_kernel(int nv, bool vf64) {
