@@ -1059,7 +1059,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         while (int64_t(sized_cap) < 2 * guess) sized_cap <<= 1;
         cap = std::min(sized_cap, RANK_MAX_CAP);
     }
-    bool partition_mode = false, level2 = false, dense_ok = true;
+    bool partition_mode = false, level2 = false, dense_ok = true, slab_failed = false;
     bool any_val_nullable = false;
     for (int c : plan.val_cols) any_val_nullable = any_val_nullable || in->cols[size_t(c)].validity != nullptr;
     for (int attempt = 0;; ++attempt) {
@@ -1179,8 +1179,43 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     int fp = pk == 0 ? 0 : (chain_pred ? 3 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2));
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
-                    if (partition_mode) {
-                        // ---- partitioned path: count → scan → scatter → one workgroup per partition
+                    if (partition_mode && !level2 && !slab_failed) {
+                        // ---- partitioned path, slab form: ONE pass scatters (key, values) tuples into per-workgroup slabs of fixed
+                        // capacity (no count pass, no scan, no read-back), then one workgroup per partition aggregates its slabs
+                        const int rpt = slab_scatter_rows_per_thread(fp, fast_key, a.nv);
+                        const int64_t tile_rows = int64_t(AGG_BLOCK) * rpt;
+                        int W = int(std::min<int64_t>(ctx->num_cus, (in->rows + tile_rows - 1) / tile_rows));
+                        int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
+                        W = int((in->rows + chunk - 1) / chunk);
+                        const int64_t mean = chunk / PARTS;
+                        const int64_t capt = (mean + mean / 4 + 64 + 15) / 16 * 16;
+                        const size_t tw = size_t(1 + a.nv);
+                        BufRef slabs = dev_alloc(ctx, size_t(PARTS) * size_t(W) * size_t(capt) * tw * 8 + 16);
+                        BufRef fill = dev_alloc(ctx, size_t(PARTS) * size_t(W) * 4);
+                        SlabArgs sl;
+                        sl.slabs = (uint64_t *)slabs->ptr;
+                        sl.fill = (uint32_t *)fill->ptr;
+                        sl.chunk = chunk;
+                        sl.W = W;
+                        sl.cap = int32_t(capt);
+                        const size_t sc_shmem = size_t(tile_rows) * 8 * tw + size_t(PARTS) * 12;
+                        launch(ctx, "agg_partition_scatter", pick_slab_scatter_kernel(fp, fast_key, a.nv), dim3(W), dim3(AGG_BLOCK), sc_shmem, ka, fpred, sl,
+                               ctx->d_flags);
+                        AggArgs sa = ka;
+                        size_t sshmem = shmem;
+                        int sblocks = blocks_per_cu;
+                        if (a.nv == 1) { // one value column: a 4096-slot table (147 KB, one workgroup per CU) doubles the distinct keys a partition may hold
+                            sa.lds_cap = 4096;
+                            sa.lds_shift = 64 - 12;
+                            sshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
+                            sblocks = 1;
+                        }
+                        launch(ctx, "agg_segments", pick_slab_segments_kernel(a.nv, vf64), dim3(std::min(PARTS, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem,
+                               sa, sl, tb.g, ctx->d_flags);
+                        sync(ctx); // the slabs are released at the end of this scope
+                    } else if (partition_mode) {
+                        // ---- partitioned path, exact form: count → scan → scatter → one workgroup per partition (skewed keys whose
+                        // partitions overflow a slab, and the two-level form for more distinct keys than PARTS tables hold)
                         const int64_t stepr = int64_t(AGG_BLOCK) * 8; // multiple of the count tile (4096) and the scatter tile (8192/4096)
                         int nblk = int(std::min<int64_t>(512, (in->rows + stepr - 1) / stepr));
                         int64_t chunk = ((in->rows + nblk - 1) / nblk + stepr - 1) / stepr * stepr;
@@ -1328,6 +1363,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         if (pre.keys) pre.G = int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT]));
         if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
+        if (f[NQE_FLAG_SLAB_OVERFLOW] && partition_mode && !slab_failed) {
+            slab_failed = true; // a partition outgrew its slab (skewed keys): exact partition sizes instead
+            flags_reset(ctx);
+            continue;
+        }
         if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2) {
             level2 = true; // partitions hold more distinct keys than a workgroup table: one more partitioning level
             cap = std::max<uint32_t>(cap, 1u << 24);

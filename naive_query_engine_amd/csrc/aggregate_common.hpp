@@ -284,7 +284,7 @@ using SegmentsKernel = void (*)(AggArgs, const uint64_t *, int64_t, int, int, in
 SegmentsKernel pick_segments_kernel(int nv, bool vf64);
 using SlabScatterKernel = void (*)(AggArgs, FastPred, SlabArgs, int *);
 SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv);
-int slab_scatter_rows_per_thread(int pred, int nv);
+int slab_scatter_rows_per_thread(int pred, int key, int nv);
 using SlabSegmentsKernel = void (*)(AggArgs, SlabArgs, GroupTable, int *);
 SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64);
 

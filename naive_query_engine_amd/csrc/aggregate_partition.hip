@@ -407,8 +407,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
 // ------------------------------------------------------------------ slab form: no count pass, software-pipelined scatter
 // Rows per thread per tile: 8 where the registers allow two tiles in flight (one value column, predicate on the key column or
 // none), else 4.
-template <int PRED, int NVT> struct SlabShape {
-    static constexpr int RPT = (NVT == 1 && PRED <= 1) ? 8 : 4;
+template <int PRED, int KEY, int NVT> struct SlabShape {
+    static constexpr int RPT = (NVT == 1 && PRED <= 1 && KEY != 3) ? 8 : 4;
 };
 
 // One workgroup per chunk of rows.  Per tile: fused predicate + key → partition → rank (LDS atomic on the tile's counter) →
@@ -418,7 +418,7 @@ template <int PRED, int NVT> struct SlabShape {
 // 22 µs per 8192-row tile where the CU's share of HBM needs 13).
 template <int PRED, int KEY, int NVT>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, FastPred fp, SlabArgs sa, int *flags) {
-    constexpr int RPT = SlabShape<PRED, NVT>::RPT;
+    constexpr int RPT = SlabShape<PRED, KEY, NVT>::RPT;
     constexpr int SC_ROWS = AGG_BLOCK * RPT;
     constexpr int TW = 1 + NVT; // words per tuple
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -586,91 +586,128 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
             }
         }
         __syncthreads();
-        for (int w = wave; w < sa.W; w += nwaves) {
-            const uint32_t f = sa.fill[size_t(p) * size_t(sa.W) + w];
-            const uint64_t *__restrict__ slab = sa.slabs + (size_t(p) * size_t(sa.W) + w) * size_t(sa.cap) * TW;
-            for (uint32_t i0 = 0; i0 < f; i0 += 64 * SU) {
-                uint64_t key[SU], vw[NVT][SU];
-                bool live[SU];
+        // The wave's slabs w = wave, wave + 16, ... as ONE flat sequence of 256-tuple steps, the next step's tuples requested
+        // before the current step is processed (a slab is ~750 tuples = 3 steps; walking the slabs one at a time exposed the
+        // fill-count load and the first tuple load of every slab: 16 dependent round trips per wave per partition).
+        const int nl = (sa.W - wave + nwaves - 1) / nwaves; // slabs of this wave (<= 64: W <= 1024)
+        const uint32_t myfill = lane_id() < nl ? sa.fill[size_t(p) * size_t(sa.W) + size_t(wave + lane_id() * nwaves)] : 0u;
+        const uint64_t *__restrict__ pbase = sa.slabs + size_t(p) * size_t(sa.W) * size_t(sa.cap) * TW;
+        struct Step {
+            uint64_t key[SU], vw[NVT][SU];
+            bool live[SU];
+        };
+        int cl = 0;          // current slab (index into the wave's list), wave-uniform
+        uint32_t ci0 = 0;    // first tuple of the current step
+        auto seek = [&](int &l, uint32_t &i0) { // first position at or after (l, i0) that holds tuples; l == nl: none
+            while (l < nl && i0 >= uint32_t(__builtin_amdgcn_readlane(int(myfill), l))) {
+                ++l;
+                i0 = 0;
+            }
+        };
+        auto fetch = [&](Step &st, int l, uint32_t i0) {
+            const uint32_t f = uint32_t(__builtin_amdgcn_readlane(int(myfill), l));
+            const uint64_t *__restrict__ slab = pbase + size_t(wave + l * nwaves) * size_t(sa.cap) * TW;
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
-                    live[u] = i < f;
-                    const uint32_t ic = live[u] ? i : f - 1;
-                    if (TW == 2) {
-                        const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(&slab[size_t(ic) * 2]);
-                        key[u] = t.x;
-                        vw[0][u] = t.y;
-                    } else {
-                        key[u] = slab[size_t(ic) * TW];
+            for (int u = 0; u < SU; ++u) {
+                const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
+                st.live[u] = i < f;
+                const uint32_t ic = st.live[u] ? i : f - 1;
+                if (TW == 2) {
+                    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+                    const v2u64 t = __builtin_nontemporal_load(reinterpret_cast<const v2u64 *>(&slab[size_t(ic) * 2]));
+                    st.key[u] = t.x;
+                    st.vw[0][u] = t.y;
+                } else {
+                    st.key[u] = slab[size_t(ic) * TW];
 #pragma unroll
-                        for (int j = 0; j < NVT; ++j) vw[j][u] = slab[size_t(ic) * TW + 1 + j];
-                    }
+                    for (int j = 0; j < NVT; ++j) st.vw[j][u] = slab[size_t(ic) * TW + 1 + j];
                 }
-                // ---- slots: every first probe issued before any is examined
-                uint32_t s0[SU];
-                uint64_t k0[SU];
+            }
+        };
+        auto update = [&](const Step &st) {
+            // ---- slots: every first probe issued before any is examined
+            uint32_t s0[SU];
+            uint64_t k0[SU];
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    s0[u] = uint32_t(((key[u] * GOLD) << PARTS_LOG2) >> a.lds_shift);
-                    k0[u] = lkeys[s0[u]];
-                }
-                int slot[SU];
+            for (int u = 0; u < SU; ++u) {
+                s0[u] = uint32_t(((st.key[u] * GOLD) << PARTS_LOG2) >> a.lds_shift);
+                k0[u] = lkeys[s0[u]];
+            }
+            int slot[SU];
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    slot[u] = -1;
-                    if (!live[u]) continue;
-                    if (key[u] == EMPTY_KEY) {
-                        lkeys[cap] = 0;
-                        slot[u] = int(cap);
-                    } else if (k0[u] == key[u]) {
-                        slot[u] = int(s0[u]);
-                    } else if (!*seg_full) {
-                        uint32_t sl = s0[u];
-                        for (int probe = 0; probe < 32; ++probe) {
-                            uint64_t k = lkeys[sl];
-                            if (k == key[u]) { slot[u] = int(sl); break; }
-                            if (k == EMPTY_KEY) {
-                                uint64_t old = atomicCAS((unsigned long long *)&lkeys[sl], (unsigned long long)EMPTY_KEY, (unsigned long long)key[u]);
-                                if (old == EMPTY_KEY || old == key[u]) { slot[u] = int(sl); break; }
-                            }
-                            sl = (sl + 1) & (cap - 1);
+            for (int u = 0; u < SU; ++u) {
+                slot[u] = -1;
+                if (!st.live[u]) continue;
+                const uint64_t key = st.key[u];
+                if (key == EMPTY_KEY) {
+                    lkeys[cap] = 0;
+                    slot[u] = int(cap);
+                } else if (k0[u] == key) {
+                    slot[u] = int(s0[u]);
+                } else if (!*seg_full) {
+                    uint32_t sl = s0[u];
+                    for (int probe = 0; probe < 32; ++probe) {
+                        uint64_t k = lkeys[sl];
+                        if (k == key) { slot[u] = int(sl); break; }
+                        if (k == EMPTY_KEY) {
+                            uint64_t old = atomicCAS((unsigned long long *)&lkeys[sl], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                            if (old == EMPTY_KEY || old == key) { slot[u] = int(sl); break; }
                         }
-                    }
-                    if (slot[u] < 0 && !*seg_full) { // more distinct keys than the table: the host partitions one level deeper (exact form)
-                        *seg_full = 1;
-                        atomicOr(&flags[NQE_FLAG_NEED_LEVEL2], 1);
+                        sl = (sl + 1) & (cap - 1);
                     }
                 }
-                // ---- read-before-atomic, the step's rows in flight together
-                uint64_t cmn[NVT][SU], cmx[NVT][SU];
+                if (slot[u] < 0 && !*seg_full) { // more distinct keys than the table: the host partitions one level deeper (exact form)
+                    *seg_full = 1;
+                    atomicOr(&flags[NQE_FLAG_NEED_LEVEL2], 1);
+                }
+            }
+            // ---- read-before-atomic, the step's rows in flight together
+            uint64_t cmn[NVT][SU], cmx[NVT][SU];
 #pragma unroll
-                for (int j = 0; j < NVT; ++j) {
+            for (int j = 0; j < NVT; ++j) {
 #pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u] < 0 ? 0 : slot[u]);
-                        cmn[j][u] = lmn[o];
-                        cmx[j][u] = lmx[o];
+                for (int u = 0; u < SU; ++u) {
+                    const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u] < 0 ? 0 : slot[u]);
+                    cmn[j][u] = lmn[o];
+                    cmx[j][u] = lmx[o];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    if (slot[u] < 0) continue;
+                    const double x = VF64 ? u2d(st.vw[j][u]) : word_as_f64(st.vw[j][u], vdt[j]);
+                    const bool isn = x != x;
+                    const uint64_t xo = f64_to_ord(x);
+                    const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
+                    atomicAdd(&lcnt[o], 1u);
+                    unsafeAtomicAdd(&lsum[o], x);
+                    if (isn) atomicOr(&lcnt[o], NAN_BIT);
+                    else {
+                        if (xo < cmn[j][u]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)xo);
+                        if (xo > cmx[j][u]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)xo);
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < NVT; ++j) {
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        if (slot[u] < 0) continue;
-                        const double x = VF64 ? u2d(vw[j][u]) : word_as_f64(vw[j][u], vdt[j]);
-                        const bool isn = x != x;
-                        const uint64_t xo = f64_to_ord(x);
-                        const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
-                        atomicAdd(&lcnt[o], 1u);
-                        unsafeAtomicAdd(&lsum[o], x);
-                        if (isn) atomicOr(&lcnt[o], NAN_BIT);
-                        else {
-                            if (xo < cmn[j][u]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)xo);
-                            if (xo > cmx[j][u]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)xo);
-                        }
-                    }
-                }
+            }
+        };
+        seek(cl, ci0);
+        if (cl < nl) {
+            Step A, B;
+            fetch(A, cl, ci0);
+            for (;;) {
+                int nlx = cl;
+                uint32_t ni0 = ci0 + 64 * SU;
+                seek(nlx, ni0);
+                if (nlx < nl) fetch(B, nlx, ni0);
+                update(A);
+                if (nlx >= nl) break;
+                cl = nlx;
+                ci0 = ni0 + 64 * SU;
+                seek(cl, ci0);
+                if (cl < nl) fetch(A, cl, ci0);
+                update(B);
+                if (cl >= nl) break;
             }
         }
         __syncthreads();
@@ -794,7 +831,7 @@ SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv) {
     default: return pick_slab_scatter_key<3>(key, nv);
     }
 }
-int slab_scatter_rows_per_thread(int pred, int nv) { return (nv == 1 && pred <= 1) ? 8 : 4; }
+int slab_scatter_rows_per_thread(int pred, int key, int nv) { return (nv == 1 && pred <= 1 && key != 3) ? 8 : 4; }
 SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64) {
     return nv == 1 ? (vf64 ? agg_slab_segments_kernel<1, true> : agg_slab_segments_kernel<1, false>)
                    : (vf64 ? agg_slab_segments_kernel<2, true> : agg_slab_segments_kernel<2, false>);
