@@ -52,6 +52,12 @@ struct nqe_join_table {
     std::vector<uint64_t> dense_base;
     bool dense_payload = false;
     bool dense_full = false; // every key of the dense range occurs
+    // unique hashed keys whose build side has exactly one plain payload column: a second table of 16-byte slots {key, payload} — a
+    // probe gets key check and payload with ONE random access (beyond the 4 MB per-XCD L2 that access IS the cost: 5.3e10/s
+    // whatever the element size — tools/micro_bench.hip).  Empty slots hold `filler`, a value that is not a build key.
+    nqe::BufRef slotsp;
+    uint64_t filler = 0;
+    int pis_col = -1; // the left column carried in the slot
     // Utf8 join keys: the build strings are encoded to representative-row codes (strings.hip)
     nqe::Utf8Dict dict;
 };
@@ -65,6 +71,10 @@ constexpr int JT_ROWS = 4096; // probe tile
 constexpr int JT_BLOCK = 256;
 constexpr int JT_ITERS = JT_ROWS / JT_BLOCK;
 constexpr int MAX_JOIN_COLS = 32;
+
+// Every probe sequence starts at the first slot of the key's 8-slot bucket = one 128-byte line (capacities are multiples of 64):
+// inserts fill a bucket from its start, a lookup that reads the whole line has seen every candidate unless the bucket is full.
+__device__ __forceinline__ uint32_t home_slot(uint64_t key, int shift) { return uint32_t((key * GOLD) >> shift) & ~7u; }
 
 __global__ void iota_u32_kernel(uint32_t *out, int64_t n) {
     int64_t stride = int64_t(gridDim.x) * blockDim.x;
@@ -97,7 +107,7 @@ __global__ void insert_unique_kernel(const uint64_t *skeys, const uint32_t *usta
         uint64_t count = uint64_t(ustart[u + 1] - j);
         uint64_t start = direct ? uint64_t(perm[j]) : uint64_t(j);
         uint64_t meta = (start << 32) | count;
-        uint32_t slot = uint32_t((key * GOLD) >> shift);
+        uint32_t slot = home_slot(key, shift);
         for (;;) {
             unsigned long long old = atomicCAS((unsigned long long *)&slots[slot].y, 0ull, (unsigned long long)meta);
             if (old == 0ull) {
@@ -110,7 +120,7 @@ __global__ void insert_unique_kernel(const uint64_t *skeys, const uint32_t *usta
 }
 
 __device__ __forceinline__ uint64_t probe_one(const ulonglong2 *__restrict__ slots, uint32_t cap, int shift, uint64_t key) {
-    uint32_t slot = uint32_t((key * GOLD) >> shift);
+    uint32_t slot = home_slot(key, shift);
     for (uint32_t p = 0; p < cap; ++p) {
         ulonglong2 s = slots[slot];
         if (s.y == 0ull) return 0ull;
@@ -118,6 +128,139 @@ __device__ __forceinline__ uint64_t probe_one(const ulonglong2 *__restrict__ slo
         slot = (slot + 1) & (cap - 1);
     }
     return 0ull;
+}
+
+// ---- sort-free build for unique keys (the common case: a dimension table's primary key).  Uniqueness is established by the
+// build itself: a second occupant of a dense slot / a second slot with the same key raises *dup and the host falls back to the
+// sort-based build below, which handles duplicates (and their ascending-build-row order).
+// unsigned min / max of (value ^ flip) over up to MAX_JOIN_COLS columns in one launch: blockIdx.y = column; one atomic pair per
+// workgroup (per wave it was 16 K same-address atomics at ~12 ns each = 0.2 ms of a 1e6-row build)
+struct MinMaxCols {
+    const uint64_t *src[MAX_JOIN_COLS];
+    uint64_t flip[MAX_JOIN_COLS];
+};
+__global__ void __launch_bounds__(256) minmax_cols_kernel(MinMaxCols mc, int64_t n, unsigned long long *mins, unsigned long long *maxs) {
+    __shared__ uint64_t smn[4], smx[4];
+    const int c = blockIdx.y;
+    const uint64_t *__restrict__ v = mc.src[c];
+    const uint64_t flip = mc.flip[c];
+    uint64_t mn = ~0ull, mx = 0;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        const uint64_t x = v[i] ^ flip;
+        mn = x < mn ? x : mn;
+        mx = x > mx ? x : mx;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint64_t a = __shfl_down((unsigned long long)mn, d, 64), b = __shfl_down((unsigned long long)mx, d, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (lane_id() == 0) smn[threadIdx.x / 64] = mn, smx[threadIdx.x / 64] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            mn = smn[w] < mn ? smn[w] : mn;
+            mx = smx[w] > mx ? smx[w] : mx;
+        }
+        atomicMin(&mins[c], (unsigned long long)mn);
+        atomicMax(&maxs[c], (unsigned long long)mx);
+    }
+}
+constexpr int UNIQUE_MAX_PROBE = 128;
+struct DensePayload {
+    int32_t n;
+    int32_t pad;
+    const uint64_t *src[MAX_JOIN_COLS];
+    void *dst[MAX_JOIN_COLS];
+    uint64_t base[MAX_JOIN_COLS];
+    int32_t packed[MAX_JOIN_COLS]; // 1: dst holds uint32 (value - base)
+};
+__global__ void __launch_bounds__(256) dense_unique_build_kernel(const uint64_t *keys, int64_t n, uint64_t dmin, uint32_t *dense, uint32_t *presence,
+                                                                 DensePayload dp, int *dup) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const uint64_t d = keys[r] - dmin;
+        const uint32_t bit = 1u << (d & 31);
+        const uint32_t old = atomicOr(&presence[d >> 5], bit);
+        if (old & bit) {
+            *dup = 1; // plain store of a constant: every writer agrees
+            continue;
+        }
+        dense[d] = uint32_t(r) + 1u;
+        for (int c = 0; c < dp.n; ++c) {
+            const uint64_t v = dp.src[c][r];
+            if (dp.packed[c]) static_cast<uint32_t *>(dp.dst[c])[d] = uint32_t(v - dp.base[c]);
+            else static_cast<uint64_t *>(dp.dst[c])[d] = v;
+        }
+    }
+}
+// claims the first free slot of the probe sequence for every row (no key comparison: equal keys simply occupy several slots),
+// then writes the key (and the 32-byte companion slot at the same index)
+__global__ void __launch_bounds__(256) hashed_insert_rows_kernel(const uint64_t *keys, int64_t n, ulonglong2 *slots, uint32_t cap, int shift, int *dup) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const uint64_t key = keys[r];
+        const unsigned long long meta = ((unsigned long long)r << 32) | 1ull;
+        uint32_t slot = home_slot(key, shift);
+        // bounded walk: with unique keys at load <= 1/2 a sequence this long does not occur; many equal keys (which the sort-based
+        // build handles) would otherwise turn the insert into O(n^2)
+        bool placed = false;
+        for (int p = 0; p < UNIQUE_MAX_PROBE; ++p) {
+            if (atomicCAS((unsigned long long *)&slots[slot].y, 0ull, meta) == 0ull) {
+                placed = true;
+                break;
+            }
+            slot = (slot + 1) & (cap - 1);
+        }
+        if (!placed) {
+            *dup = 1;
+            continue;
+        }
+        slots[slot].x = key;
+    }
+}
+// the {key, payload} table: empty slots hold `filler` (not a build key), so the key word itself is claimed by CAS — and an equal
+// key already in place IS a duplicate
+__global__ void __launch_bounds__(256) fill_pairs_kernel(ulonglong2 *t, uint32_t cap, uint64_t filler) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) t[i] = make_ulonglong2(filler, 0ull);
+}
+__global__ void __launch_bounds__(256) hashed_insert_pairs_kernel(const uint64_t *keys, const uint64_t *payload, int64_t n, ulonglong2 *t, uint32_t cap, int shift,
+                                                                  uint64_t filler, int *dup) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const uint64_t key = keys[r];
+        uint32_t slot = home_slot(key, shift);
+        bool placed = false;
+        for (int p = 0; p < UNIQUE_MAX_PROBE; ++p) {
+            const unsigned long long old = atomicCAS((unsigned long long *)&t[slot].x, (unsigned long long)filler, (unsigned long long)key);
+            if (old == filler) {
+                t[slot].y = payload[r];
+                placed = true;
+                break;
+            }
+            if (old == key) break; // the same key twice
+            slot = (slot + 1) & (cap - 1);
+        }
+        if (!placed) *dup = 1;
+    }
+}
+// after the insert kernel has completed: does any row's probe sequence hold its key twice?
+__global__ void __launch_bounds__(256) hashed_check_unique_kernel(const uint64_t *keys, int64_t n, const ulonglong2 *slots, uint32_t cap, int shift, int *dup) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const uint64_t key = keys[r];
+        uint32_t slot = home_slot(key, shift);
+        for (int p = 0; p < 2 * UNIQUE_MAX_PROBE; ++p) {
+            const ulonglong2 s = slots[slot];
+            if (s.y == 0ull) break;
+            if (s.x == key && uint32_t(s.y >> 32) != uint32_t(r)) {
+                *dup = 1;
+                break;
+            }
+            slot = (slot + 1) & (cap - 1);
+        }
+    }
 }
 
 struct Lookup {
@@ -185,6 +328,59 @@ __global__ void __launch_bounds__(256) probe_unique_kernel(const uint64_t *rkeys
                 if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
                 total += __popcll(kw);
             }
+        }
+        if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
+// the same for hashed tables, wave-cooperatively (see probe_pairs_kernel): 8 lanes read the 8 slots of a key's bucket — one
+// coalesced line per key, the loads of 8 sub-steps in flight together — and a ballot finds the match
+__global__ void __launch_bounds__(256) probe_unique_coop_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, const ulonglong2 *tab, uint32_t cap, int shift,
+                                                                uint64_t *keep, uint32_t *bidx, uint32_t *tile_counts) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t last = n - 1;
+    const int my_t = lane_id() >> 3, my_g = lane_id() & 7;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t row0 = tile * TILE_ROWS;
+        uint32_t total = 0;
+        for (int k0 = 0; k0 < TILE_WORDS; ++k0) {
+            const int64_t row = row0 + int64_t(k0) * 64 + lane_id();
+            const uint64_t key = __builtin_nontemporal_load(&rkeys[row < last ? row : last]);
+            uint64_t kg[8];
+            ulonglong2 s[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                kg[t] = (uint64_t)__shfl((unsigned long long)key, t * 8 + (lane_id() >> 3), 64);
+                s[t] = tab[home_slot(kg[t], shift) + uint32_t(lane_id() & 7)];
+            }
+            uint64_t meta = 0;
+            bool settled = false;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint64_t m = __ballot(s[t].y != 0ull && s[t].x == kg[t]), f = __ballot(s[t].y == 0ull);
+                const uint32_t mb = uint32_t(m >> (8 * my_g)) & 0xFFu, fb = uint32_t(f >> (8 * my_g)) & 0xFFu;
+                const int src = 8 * my_g + (mb ? __ffs(int(mb)) - 1 : 0);
+                const uint64_t mt = (uint64_t)__shfl((unsigned long long)s[t].y, src, 64);
+                if (t == my_t) {
+                    meta = mb ? mt : 0ull;
+                    settled = mb != 0 || fb != 0;
+                }
+            }
+            if (!settled) { // rare: a full bucket without the key
+                uint32_t sl = (home_slot(key, shift) + 8u) & (cap - 1);
+                for (uint32_t p = 8; p < cap; ++p) {
+                    const ulonglong2 c = tab[sl];
+                    if (c.y == 0ull) break;
+                    if (c.x == key) { meta = c.y; break; }
+                    sl = (sl + 1) & (cap - 1);
+                }
+            }
+            const bool hit = row < n && meta != 0ull;
+            const uint64_t kw = __ballot(hit);
+            if (row < n) bidx[row] = uint32_t(meta >> 32);
+            if (row0 + int64_t(k0) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0] = kw;
+            total += __popcll(kw);
         }
         if (lane_id() == 0) tile_counts[tile] = total;
     }
@@ -354,6 +550,71 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
     }
 }
 
+// ---- unique hashed keys with ONE plain payload column: the lookup IS the gather.  Pass 1 of the two-pass probe looks every
+// probe key up in the {key, payload} table (one random 16-byte access) and writes the payload word per probe row next to the
+// match bitmap; the payload is then just another probe-side column that pass 2 (join_fused_write_kernel) streams and compacts —
+// no build-row list, no second random access per row (the {key, row} form gathers every payload column by build row in pass 2).
+// (A single-pass probe — decoupled look-back over per-tile counts, flat or hierarchical, publish-early / consume-a-tile-later —
+// was built and measured: the fused kernel runs C4 in 1.00-1.08 ms with the placement given, 1.4-1.6 ms with any of the
+// look-back variants: with 8 XCDs every publish / poll is a 2-5 µs fabric round trip per 512-1024-row tile and pollers eat the
+// bandwidth the gathers need.  Two passes without inter-workgroup traffic are faster here.)
+// Wave-cooperative probing: the table is read in 8-slot buckets = one 128-byte line.  A wave looks up its 64 keys in 8 sub-steps
+// of 8 keys: lane (g, i) loads slot i of the bucket of sub-step key g — one coalesced line per key, all 8 sub-steps' loads in
+// flight together — and a ballot finds the slot that matches.  Per-lane probing fetches the same one line per key but then walks
+// collisions with dependent, divergent loads (2.4-3.0 ms per 1e8 keys against 1.6 ms for the bare random reads).
+__global__ void __launch_bounds__(256) probe_pairs_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, const ulonglong2 *tab, uint32_t cap, int shift,
+                                                          uint64_t filler, uint64_t *keep, uint64_t *payload, uint32_t *tile_counts) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t last = n - 1;
+    const int my_t = lane_id() >> 3, my_g = lane_id() & 7; // this lane owns key my_g of sub-step my_t; as a loader it reads slot my_g... of group lane>>3
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t row0 = tile * TILE_ROWS;
+        uint32_t total = 0;
+        for (int k0 = 0; k0 < TILE_WORDS; ++k0) {
+            const int64_t row = row0 + int64_t(k0) * 64 + lane_id();
+            const uint64_t key = __builtin_nontemporal_load(&rkeys[row < last ? row : last]);
+            uint64_t kg[8];
+            ulonglong2 s[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { // sub-step t serves the keys of lanes 8t .. 8t+7; this lane loads for key group lane >> 3
+                kg[t] = (uint64_t)__shfl((unsigned long long)key, t * 8 + (lane_id() >> 3), 64);
+                const uint32_t bucket = home_slot(kg[t], shift);
+                s[t] = tab[bucket + uint32_t(lane_id() & 7)];
+            }
+            uint64_t pay = 0;
+            bool hit = false, settled = false;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint64_t m = __ballot(s[t].x == kg[t]), f = __ballot(s[t].x == filler);
+                const uint32_t mb = uint32_t(m >> (8 * my_g)) & 0xFFu, fb = uint32_t(f >> (8 * my_g)) & 0xFFu; // the bucket of this lane's own key, if t is its sub-step
+                const int src = 8 * my_g + (mb ? __ffs(int(mb)) - 1 : 0);
+                const uint64_t pl = (uint64_t)__shfl((unsigned long long)s[t].y, src, 64);
+                if (t == my_t) {
+                    hit = mb != 0;
+                    pay = pl;
+                    settled = hit || fb != 0; // found, or the bucket has a free slot: the key is not in the table
+                }
+            }
+            if (!settled) { // rare: a full bucket without the key — walk the following slots alone
+                uint32_t sl = (home_slot(key, shift) + 8u) & (cap - 1);
+                for (int p = 0; p < 2 * UNIQUE_MAX_PROBE; ++p) {
+                    const ulonglong2 c = tab[sl];
+                    if (c.x == key) { hit = true; pay = c.y; break; }
+                    if (c.x == filler) break;
+                    sl = (sl + 1) & (cap - 1);
+                }
+            }
+            hit = hit && row < n && key != filler;
+            const uint64_t kw = __ballot(hit);
+            if (row < n) __builtin_nontemporal_store(hit ? pay : 0ull, &payload[row]);
+            if (row0 + int64_t(k0) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0] = kw;
+            total += __popcll(kw);
+        }
+        if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
 // 16 rows per lane in flight: the kernel is bound by the latency of its gathers, and memory-level parallelism per wave
 // beats occupancy (A/B on one box, C4: 4 rows/lane (70 VGPRs, 7 waves/SIMD) 1.53 ms, 8 (116, 4) 1.33 ms, 16 (210, 2)
 // 1.24 ms, 32 (256, 1) 1.31 ms)
@@ -504,6 +765,125 @@ void check_key_types(int ldt, int rdt) {
     if (rdt != ldt) fail(NQE_ERR_NOT_SUPPORTED, "join key types differ (downcast unwrap panics, hash_join.rs:83)");
 }
 
+// Sort-free build (see the kernels above).  Returns false — with `jt` untouched apart from buffers it will overwrite — when the
+// keys turn out not to be unique; the caller then runs the sort-based build.  `plain_key`: the key column is a plain 8-byte
+// column without validity (Utf8 keys arrive as codes and keep the generic probe).
+bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, const DevColumn &kc, bool plain_key) {
+    const int64_t n = left->rows;
+    const size_t ncols = left->cols.size();
+    // ---- one round trip: min / max of the key and of every integer payload column (frame-of-reference packing)
+    bool payload_plain = plain_key;
+    for (size_t ci = 0; ci < ncols; ++ci)
+        if (int(ci) != jt->left_key) payload_plain = payload_plain && is_word_type(left->cols[ci].dtype) && !left->cols[ci].validity;
+    std::vector<int> mm_cols; // columns whose range is measured: [0] = the key
+    mm_cols.push_back(-1);
+    if (payload_plain)
+        for (size_t ci = 0; ci < ncols; ++ci)
+            if (int(ci) != jt->left_key && (left->cols[ci].dtype == NQE_INT64 || left->cols[ci].dtype == NQE_UINT64)) mm_cols.push_back(int(ci));
+    const size_t K = mm_cols.size();
+    BufRef mm = dev_alloc(ctx, K * 16); // [K mins][K maxs]
+    NQE_HIP_CHECK(hipMemsetAsync(mm->ptr, 0xFF, K * 8, ctx->stream));
+    NQE_HIP_CHECK(hipMemsetAsync(static_cast<char *>(mm->ptr) + K * 8, 0, K * 8, ctx->stream));
+    MinMaxCols mc;
+    std::memset(&mc, 0, sizeof(mc));
+    for (size_t k = 0; k < K; ++k) {
+        const DevColumn &c = mm_cols[k] < 0 ? kc : left->cols[size_t(mm_cols[k])];
+        mc.src[k] = c.words();
+        mc.flip[k] = (mm_cols[k] >= 0 && c.dtype == NQE_INT64) ? 0x8000000000000000ull : 0ull; // the key range is taken unsigned
+    }
+    launch(ctx, "join_build_minmax", minmax_cols_kernel, dim3(unsigned(std::min<int64_t>(256, (n + 255) / 256)), unsigned(K)), dim3(256), 0, mc, n,
+           (unsigned long long *)mm->ptr, (unsigned long long *)mm->ptr + K);
+    std::vector<uint64_t> mmraw(K * 2), mmh(K * 2);
+    NQE_HIP_CHECK(hipMemcpyAsync(mmraw.data(), mm->ptr, K * 16, hipMemcpyDeviceToHost, ctx->stream));
+    sync(ctx);
+    for (size_t k = 0; k < K; ++k) mmh[2 * k] = mmraw[k], mmh[2 * k + 1] = mmraw[K + k];
+    const uint64_t kmin = mmh[0], kmax = mmh[1];
+    const uint64_t span = kmax - kmin + 1; // 0 on wrap-around: not dense
+    BufRef dupflag = dev_alloc_zero(ctx, 4);
+    int dup = 0;
+    if (span != 0 && span <= std::max<uint64_t>(4ull * uint64_t(n), 1024ull) && span < (1ull << 31)) {
+        // ---- dense keys: direct-address table (+ key-ordered payload columns and the presence bitmap when everything is plain)
+        BufRef dense = dev_alloc_zero(ctx, size_t(span) * 4);
+        BufRef presence = dev_alloc_zero(ctx, size_t((span + 31) / 32) * 4);
+        DensePayload dp;
+        std::memset(&dp, 0, sizeof(dp));
+        std::vector<BufRef> dense_cols(ncols);
+        std::vector<int> dense_packed(ncols, 0);
+        std::vector<uint64_t> dense_base(ncols, 0);
+        const bool with_payload = payload_plain && span * 8 * ncols <= (size_t(8) << 30) && ncols <= size_t(MAX_JOIN_COLS);
+        if (with_payload) {
+            for (size_t ci = 0; ci < ncols; ++ci) {
+                if (int(ci) == jt->left_key) continue;
+                const DevColumn &pc = left->cols[ci];
+                bool packed = false;
+                for (size_t k = 1; k < mm_cols.size(); ++k)
+                    if (mm_cols[k] == int(ci) && mmh[2 * k + 1] - mmh[2 * k] <= 0xffffffffull) { // value range within 32 bits → uint32 offsets
+                        packed = true;
+                        dense_base[ci] = mmh[2 * k] ^ (pc.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull);
+                    }
+                dense_packed[ci] = packed ? 1 : 0;
+                dense_cols[ci] = packed ? dev_alloc_zero(ctx, size_t(span) * 4 + 8) : dev_alloc(ctx, size_t(span) * 8);
+                dp.src[dp.n] = pc.words();
+                dp.dst[dp.n] = dense_cols[ci]->ptr;
+                dp.base[dp.n] = dense_base[ci];
+                dp.packed[dp.n] = dense_packed[ci];
+                dp.n++;
+            }
+        }
+        launch(ctx, "join_build_dense", dense_unique_build_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, kmin, (uint32_t *)dense->ptr,
+               (uint32_t *)presence->ptr, dp, (int *)dupflag->ptr);
+        dup = read_scalar(ctx, (const int *)dupflag->ptr);
+        if (dup) return false;
+        jt->direct = true;
+        jt->dense = dense;
+        jt->dense_min = kmin;
+        jt->dense_span = span;
+        jt->cap = 0; // no hash table: every lookup goes through the direct-address table
+        if (with_payload) {
+            jt->presence = presence;
+            jt->dense_cols = dense_cols;
+            jt->dense_packed = dense_packed;
+            jt->dense_base = dense_base;
+            jt->dense_payload = true;
+            jt->dense_full = (span == uint64_t(n));
+        }
+        return true;
+    }
+    // ---- sparse keys: open addressing, one slot per row
+    uint32_t cap = 64;
+    while (uint64_t(cap) < 2ull * uint64_t(n)) cap <<= 1;
+    int lg = 0;
+    while ((1u << lg) < cap) ++lg;
+    BufRef slots = dev_alloc_zero(ctx, size_t(cap) * 16);
+    launch(ctx, "join_build_insert", hashed_insert_rows_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, (ulonglong2 *)slots->ptr, cap, 64 - lg,
+           (int *)dupflag->ptr);
+    BufRef slotsp;
+    uint64_t filler = 0;
+    int pis_col = -1;
+    const bool have_filler = kmax != ~0ull || kmin != 0ull; // a value outside [kmin, kmax] (unsigned) is not a build key
+    if (payload_plain && ncols == 2 && have_filler) { // exactly one payload column: it rides in the slot
+        filler = kmax != ~0ull ? kmax + 1 : kmin - 1;
+        pis_col = jt->left_key == 0 ? 1 : 0;
+        slotsp = dev_alloc(ctx, size_t(cap) * 16);
+        launch(ctx, "join_build_fill", fill_pairs_kernel, dim3(stream_grid(ctx, cap, 256)), dim3(256), 0, (ulonglong2 *)slotsp->ptr, cap, filler);
+        launch(ctx, "join_build_insert", hashed_insert_pairs_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), left->cols[size_t(pis_col)].words(), n,
+               (ulonglong2 *)slotsp->ptr, cap, 64 - lg, filler, (int *)dupflag->ptr);
+    } else {
+        launch(ctx, "join_build_check", hashed_check_unique_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, (const ulonglong2 *)slots->ptr,
+               cap, 64 - lg, (int *)dupflag->ptr);
+    }
+    dup = read_scalar(ctx, (const int *)dupflag->ptr);
+    if (dup) return false;
+    jt->direct = true;
+    jt->slots = slots;
+    jt->cap = cap;
+    jt->shift = 64 - lg;
+    jt->slotsp = slotsp;
+    jt->filler = filler;
+    jt->pis_col = pis_col;
+    return true;
+}
+
 std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left, int left_key) {
     if (left_key < 0 || size_t(left_key) >= left->cols.size()) fail(NQE_ERR_LOGICAL, "ColumnExpr must has name or idx");
     const DevColumn &kc_orig = left->cols[size_t(left_key)];
@@ -522,6 +902,13 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
     jt->left_key = left_key;
     jt->dict = dict;
 
+    if (n > 0 && build_unique_fast(ctx, jt.get(), left, kc, kc_orig.dtype != NQE_UTF8 && !kc.validity)) {
+        if (getenv("NQE_DEBUG"))
+            fprintf(stderr, "[nqe] join build (sort-free): n=%lld dense_span=%llu dense_payload=%d dense_full=%d cap=%u pis=%d\n", (long long)n,
+                    (unsigned long long)jt->dense_span, int(jt->dense_payload), int(jt->dense_full), jt->cap, jt->pis_col);
+        return jt;
+    }
+    // ---- sort-based build: duplicate keys (their matches must come out in ascending build row), or an empty build side
     BufRef idx = dev_alloc(ctx, size_t(n) * 4 + 8), skeys = dev_alloc(ctx, size_t(n) * 8 + 8);
     jt->perm = dev_alloc(ctx, size_t(n) * 4 + 8);
     uint32_t U = 0;
@@ -641,7 +1028,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
 
     Lookup L;
     std::memset(&L, 0, sizeof(L));
-    L.slots = (const ulonglong2 *)jt->slots->ptr;
+    L.slots = jt->slots ? (const ulonglong2 *)jt->slots->ptr : nullptr;
     L.cap = jt->cap;
     L.shift = jt->shift;
     L.dense = jt->dense ? (const uint32_t *)jt->dense->ptr : nullptr;
@@ -652,6 +1039,8 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
 
     bool right_plain = true;
     for (auto &c : right->cols) right_plain = right_plain && is_word_type(c.dtype) && !c.validity;
+    bool left_all_plain = ncols <= size_t(MAX_JOIN_COLS);
+    for (auto &c : jt->left_cols) left_all_plain = left_all_plain && is_word_type(c.dtype) && !c.validity;
     if (jt->dense_payload && right_plain) {
         // PK–FK fast path: presence test + counts, scan, then one fused write of every output column
         KeepMask km;
@@ -728,17 +1117,31 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         km.ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
         int64_t nwords = (n + 63) / 64;
         km.keep = dev_alloc(ctx, size_t(nwords) * 8 + 8);
-        BufRef bidx = dev_alloc(ctx, size_t(n) * 4 + 8);
         BufRef counts = dev_alloc(ctx, size_t(km.ntiles + 1) * 4);
-        if (km.ntiles)
-            launch(ctx, "join_probe_unique", probe_unique_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n,
-                   km.ntiles, L, (uint64_t *)km.keep->ptr, (uint32_t *)bidx->ptr, (uint32_t *)counts->ptr);
+        bool left_plain = jt->left_cols.size() + right->cols.size() <= size_t(MAX_JOIN_COLS);
+        for (auto &c : jt->left_cols) left_plain = left_plain && is_word_type(c.dtype) && !c.validity;
+        // one plain payload column riding in the table's slots: its values arrive with the lookup, per probe row
+        const bool pairs = jt->slotsp != nullptr && left_plain && right_plain && !jt->dense;
+        BufRef bidx, payload;
+        if (pairs) {
+            payload = dev_alloc(ctx, size_t(n) * 8 + 8);
+            if (km.ntiles)
+                launch(ctx, "join_probe_pairs", probe_pairs_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,
+                       (const ulonglong2 *)jt->slotsp->ptr, jt->cap, jt->shift, jt->filler, (uint64_t *)km.keep->ptr, (uint64_t *)payload->ptr,
+                       (uint32_t *)counts->ptr);
+        } else {
+            bidx = dev_alloc(ctx, size_t(n) * 4 + 8);
+            if (km.ntiles && !jt->dense)
+                launch(ctx, "join_probe_unique", probe_unique_coop_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,
+                       (const ulonglong2 *)jt->slots->ptr, jt->cap, jt->shift, (uint64_t *)km.keep->ptr, (uint32_t *)bidx->ptr, (uint32_t *)counts->ptr);
+            else if (km.ntiles)
+                launch(ctx, "join_probe_unique", probe_unique_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n,
+                       km.ntiles, L, (uint64_t *)km.keep->ptr, (uint32_t *)bidx->ptr, (uint32_t *)counts->ptr);
+        }
         km = finish_mask(ctx, km, counts);
         auto out = std::make_unique<nqe_table>();
         out->ctx = ctx;
         out->rows = km.total;
-        bool left_plain = jt->left_cols.size() + right->cols.size() <= size_t(MAX_JOIN_COLS);
-        for (auto &c : jt->left_cols) left_plain = left_plain && is_word_type(c.dtype) && !c.validity;
         if (left_plain && right_plain) {
             // every column is a plain 8-byte column: ONE pass writes all of them (probe columns streamed, the build key taken
             // from the probe key, build payloads gathered by the recorded build row) instead of one compaction per column
@@ -754,8 +1157,8 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
                     continue;
                 }
                 out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
-                fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : 2;
-                fc.src[fc.n] = c.words();
+                fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : (pairs ? 0 : 2);
+                fc.src[fc.n] = pairs && int(ci) != jt->left_key ? (const uint64_t *)payload->ptr : c.words();
                 fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
                 fc.n++;
             }
@@ -774,7 +1177,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
             }
             if (km.ntiles && km.total > 0)
                 launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS>, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,
-                       (const uint64_t *)km.keep->ptr, (const uint64_t *)km.tile_offsets->ptr, uint64_t(0), (const uint32_t *)bidx->ptr, fc);
+                       (const uint64_t *)km.keep->ptr, (const uint64_t *)km.tile_offsets->ptr, uint64_t(0), pairs ? (const uint32_t *)nullptr : (const uint32_t *)bidx->ptr, fc);
             sync(ctx);
             return out;
         }
