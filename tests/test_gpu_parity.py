@@ -945,3 +945,62 @@ def test_borrowed_boolean_predicate_column_is_not_read_past_its_end(ctx, n):
         got = ctx.aggregate(tab, aggs, group_nodes=key, pred_nodes=col(2).flatten(f)).to_host()
         exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=col(2).flatten(f))[0]
         assert_rows_multiset_equal(got, exp, exact_cols=(0,))
+
+
+# --------------------------------------------------------------------------- hashed unique builds: buckets, filler, fall-backs
+GOLD = 0x9E3779B97F4A7C15
+GOLD_INV = pow(GOLD, -1, 1 << 64)
+
+
+def _join_both_ways(ctx, left, right):
+    got = ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 0, 0).to_host()
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    assert_batches_equal(got, exp, what="hash join")
+    return got
+
+
+@pytest.mark.parametrize("payload_cols", [1, 2])
+@pytest.mark.parametrize("colliding", [5, 9, 60, 100, 300])
+def test_hash_join_keys_that_all_land_in_one_bucket(ctx, colliding, payload_cols):
+    """keys j * GOLD^-1 (mod 2^64) hash to slot 0 whatever the table size: a full 8-slot bucket (the wave-cooperative probe's slow
+    path), probe sequences of up to `colliding` slots, and — beyond the insert's bound — the fall-back to the sort-based build"""
+    rng = np.random.default_rng(colliding)
+    bad = np.array([(j * GOLD_INV) % (1 << 64) for j in range(1, colliding + 1)], dtype=np.uint64)
+    other = rng.integers(1 << 40, 1 << 62, 5000).astype(np.uint64)
+    keys = np.unique(np.concatenate([bad, other]))
+    rng.shuffle(keys)
+    left = [Column.from_numpy(keys)] + [Column.from_numpy(rng.integers(0, 1 << 50, len(keys)).astype(np.int64)) for _ in range(payload_cols)]
+    probe = np.concatenate([rng.choice(keys, 20000), bad, rng.integers(1 << 40, 1 << 62, 3000).astype(np.uint64),
+                            np.array([(j * GOLD_INV) % (1 << 64) for j in range(colliding + 1, colliding + 40)], dtype=np.uint64)])  # misses that walk the same bucket
+    rng.shuffle(probe)
+    right = [Column.from_numpy(probe), Column.from_numpy(rng.random(len(probe)))]
+    _join_both_ways(ctx, left, right)
+
+
+@pytest.mark.parametrize("build_has", ["max_key", "zero_and_max", "zero"])
+def test_hash_join_filler_value_of_the_payload_table(ctx, build_has):
+    """the {key, payload} table marks empty slots with a value outside the build keys' range (max + 1, else min - 1; none when the
+    keys span 0 .. 2^64-1): probing exactly that value must not match, and keys 0 / 2^64-1 must work"""
+    rng = np.random.default_rng(1)
+    keys = np.unique(rng.integers(1 << 45, 1 << 62, 3000).astype(np.uint64))
+    extra = {"max_key": [(1 << 64) - 1], "zero_and_max": [0, (1 << 64) - 1], "zero": [0]}[build_has]
+    keys = np.concatenate([keys, np.array(extra, dtype=np.uint64)])
+    rng.shuffle(keys)
+    left = [Column.from_numpy(keys), Column.from_numpy(rng.integers(-5, 5, len(keys)).astype(np.int64))]
+    kmax, kmin = int(keys.max()), int(keys.min())
+    specials = [0, 1, (1 << 64) - 1, (1 << 64) - 2, (kmax + 1) % (1 << 64), (kmin - 1) % (1 << 64)]
+    probe = np.concatenate([rng.choice(keys, 10000), np.array(specials * 50, dtype=np.uint64), rng.integers(0, 1 << 63, 2000).astype(np.uint64)])
+    rng.shuffle(probe)
+    right = [Column.from_numpy(probe), Column.from_numpy(rng.random(len(probe)))]
+    _join_both_ways(ctx, left, right)
+
+
+@pytest.mark.parametrize("nb", [1, 7, 8, 9, 64, 65, 1000])
+def test_hash_join_sort_free_build_small_and_signed_keys(ctx, nb):
+    """unique Int64 keys incl. negatives (raw 8-byte slots compare; a mixed-sign key set is never 'dense'), tiny builds"""
+    rng = np.random.default_rng(nb)
+    keys = rng.permutation(np.arange(-(nb // 2), nb - nb // 2, dtype=np.int64) * 3)
+    left = [Column.from_numpy(keys), Column.from_numpy(rng.random(nb)), Column.from_numpy(rng.integers(0, 9, nb).astype(np.int64))]
+    probe = rng.integers(-3 * nb - 3, 3 * nb + 3, 5000).astype(np.int64)
+    right = [Column.from_numpy(probe), Column.from_numpy(np.arange(5000, dtype=np.int64))]
+    _join_both_ways(ctx, left, right)
