@@ -221,6 +221,47 @@ nqe_status nqe_table_slice(nqe_ctx *ctx, const nqe_table *in, int64_t offset, in
  * NQE_ERR_INVALID_ARGUMENT here (the host mirror builds the empty batch itself). */
 nqe_status nqe_table_concat(nqe_ctx *ctx, const nqe_table *const *tables, int32_t n, nqe_table **out);
 
+/* ------------------------------------------------------------------ Arrow C Data Interface
+ * MemTable::try_create(schema, batches) (datasource/memory.rs:21-29; Catalog::add_memory_table, catalog.rs:40-49) for hosts that hold
+ * real Arrow data, and the way back for results (the Vec<RecordBatch> of plan.rs:18).  The structs are the standard ones of the
+ * Arrow C Data Interface (arrow-rs `arrow::ffi`, pyarrow `_export_to_c` / `_import_from_c`); include Arrow's own header first if
+ * you have it. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+    const char *format;
+    const char *name;
+    const char *metadata;
+    int64_t flags;
+    int64_t n_children;
+    struct ArrowSchema **children;
+    struct ArrowSchema *dictionary;
+    void (*release)(struct ArrowSchema *);
+    void *private_data;
+};
+struct ArrowArray {
+    int64_t length;
+    int64_t null_count;
+    int64_t offset;
+    int64_t n_buffers;
+    int64_t n_children;
+    const void **buffers;
+    struct ArrowArray **children;
+    struct ArrowArray *dictionary;
+    void (*release)(struct ArrowArray *);
+    void *private_data;
+};
+#endif
+/* One RecordBatch = one struct array (format "+s") whose children are the columns: "l" Int64, "L" UInt64, "g" Float64, "b" Boolean,
+ * "u" Utf8; anything else is NQE_ERR_NOT_SUPPORTED (selection.rs:98).  Sliced arrays (offset != 0) are honoured.  The buffers are
+ * host memory; they are copied to HBM and `array` is then RELEASED by this call (the interface's move semantics — on failure it is
+ * left untouched); `schema` is only read. */
+nqe_status nqe_table_import_arrow(nqe_ctx *ctx, struct ArrowArray *array, const struct ArrowSchema *schema, nqe_table **out);
+/* The table as one struct array with host copies of its buffers, owned by the returned structs until their `release` callbacks
+ * run.  names: one per column, or NULL ("c0", "c1", ...).  Blocking. */
+nqe_status nqe_table_export_arrow(const nqe_table *table, const char *const *names, struct ArrowArray *out_array,
+                                  struct ArrowSchema *out_schema);
+
 /* ------------------------------------------------------------------ CSV ingest
  * CsvTable::try_create (datasource/csv.rs:53-86) = infer_schema_from_csv (csv.rs:76-85, arrow-rs 13
  * csv::reader::infer_reader_schema over the first max_read_records records) + csv::Reader::next() — only the FIRST

@@ -32,7 +32,7 @@ SYMBOLS = [
     "nqe_device_alloc", "nqe_device_free",
     "nqe_comm_get_unique_id", "nqe_comm_rccl_version", "nqe_comm_create", "nqe_comm_create_custom", "nqe_comm_destroy", "nqe_comm_rank",
     "nqe_comm_world", "nqe_table_all_gather", "nqe_sharded_aggregate_execute", "nqe_sharded_hash_join_probe",
-    "nqe_sharded_selection_projection_execute",
+    "nqe_sharded_selection_projection_execute", "nqe_table_import_arrow", "nqe_table_export_arrow",
 ]
 
 COMM_ID_BYTES = 128    # NQE_COMM_ID_BYTES
@@ -43,6 +43,18 @@ _AG_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, 
 _AGV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p)
 _GRP_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p)
 _DESTROY_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class ArrowSchemaStruct(C.Structure):
+    """struct ArrowSchema of the Arrow C Data Interface (72 bytes)"""
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64), ("n_children", C.c_int64),
+                ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class ArrowArrayStruct(C.Structure):
+    """struct ArrowArray of the Arrow C Data Interface (80 bytes)"""
+    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64), ("n_children", C.c_int64),
+                ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
 
 
 class NqeTransport(C.Structure):
@@ -121,6 +133,8 @@ def lib():
         "nqe_sharded_aggregate_execute": (i32, [vp, vp, nodes, i32, nodes, i32, C.POINTER(NqeAggregate), i32, pvp, pvp]),
         "nqe_sharded_hash_join_probe": (i32, [vp, vp, vp, i32, i32, pvp]),
         "nqe_sharded_selection_projection_execute": (i32, [vp, vp, nodes, i32, nodes, C.POINTER(i32), i32, i32, pvp]),
+        "nqe_table_import_arrow": (i32, [vp, vp, vp, pvp]),
+        "nqe_table_export_arrow": (i32, [vp, C.POINTER(C.c_char_p), vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -211,6 +225,21 @@ class Context:
             arr[i].validity = valid
         h = C.c_void_p()
         self.check(lib().nqe_table_create(self.handle, arr, len(cols), C.byref(h)))
+        return Table(self, h)
+
+    def table_from_arrow(self, record_batch) -> "Table":
+        """a pyarrow.RecordBatch through the Arrow C Data Interface (nqe_table_import_arrow): the batch is exported as a struct array
+        whose children are the columns; the library copies the buffers to HBM and releases the exported array"""
+        arr, sch = ArrowArrayStruct(), ArrowSchemaStruct()
+        record_batch._export_to_c(C.addressof(arr), C.addressof(sch))
+        h = C.c_void_p()
+        try:
+            self.check(lib().nqe_table_import_arrow(self.handle, C.addressof(arr), C.addressof(sch), C.byref(h)))
+        finally:
+            # the schema is only borrowed by the import; the array is released by a successful import (and by us otherwise)
+            for st in (arr, sch):
+                if st.release:
+                    C.CFUNCTYPE(None, C.c_void_p)(st.release)(C.addressof(st))
         return Table(self, h)
 
     def device_alloc(self, nbytes: int) -> int:
@@ -549,6 +578,20 @@ class Table:
 
     def to_host(self) -> List[Column]:
         return [self.download_column(i) for i in range(self.num_columns)]
+
+    def to_arrow(self, names: Optional[Sequence[str]] = None):
+        """the table as a pyarrow.RecordBatch through the Arrow C Data Interface (nqe_table_export_arrow): pyarrow takes over the
+        exported structs and calls their release callbacks when the batch is garbage-collected"""
+        import pyarrow as pa
+
+        arr, sch = ArrowArrayStruct(), ArrowSchemaStruct()
+        n = self.num_columns
+        na = None
+        if names is not None:
+            assert len(names) == n
+            na = (C.c_char_p * max(1, n))(*[s.encode() for s in names])
+        self.ctx.check(lib().nqe_table_export_arrow(self.handle, na, C.addressof(arr), C.addressof(sch)))
+        return pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
 
 
 class JoinTable:

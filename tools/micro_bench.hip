@@ -147,6 +147,19 @@ int main(int argc, char **argv) {
             if (run_lds<5>(slots, out, "add_u32 + add_f64 + read-before min/max")) return 1;
         }
     }
+    if (!strcmp(what, "gather1")) { // one shape for the PMC passes: how many bytes does a random 8-byte read beyond the L2 move?
+        const int64_t n = 100000000;
+        uint64_t *keys;
+        CK(hipMalloc(&keys, size_t(n) * 8));
+        fill_keys<<<2048, 256>>>(keys, n);
+        void *table;
+        CK(hipMalloc(&table, size_t(1) << 30));
+        CK(hipMemset(table, 1, size_t(1) << 30));
+        CK(hipDeviceSynchronize());
+        if (run_gather<uint64_t, 0, 8>(keys, n, table, size_t(1) << 30, out, "u64 plain 1 GB")) return 1;
+        if (run_gather<uint64_t, 0, 8>(keys, n, table, size_t(32) << 20, out, "u64 plain 32 MB")) return 1;
+        return 0;
+    }
     if (!strcmp(what, "all") || !strcmp(what, "gather")) {
         const int64_t n = 100000000;
         uint64_t *keys;

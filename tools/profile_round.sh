@@ -1,27 +1,33 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): every bench workload + rocprofv3 kernel stats + PMC traffic passes for the
-# headline.  Output under gpurun_out/$1/ ; tools/summarize_profiles.py turns it into profiles/$1/.
-#   usage: tools/profile_round.sh r01
+# Runs on the GPU box (via gpurun): the default bench line, rocprofv3 kernel stats per config, and the PMC traffic passes
+# (counters in their own runs, --kernel-trace only, one counter per pass) for every config plus the calibration kernels.
+# Output under gpurun_out/$1/ ; tools/summarize_profiles.py turns it into profiles/$1/ (tracked).
+#   usage: tools/profile_round.sh r02
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py 2>&1 | tail -1 > $OUT/bench_headline.json
-# the profiled run of the headline right behind the plain one (the kernel slows by a few per cent as the box warms up)
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_headline -o headline -- python $R/bench.py --workload headline --no-cpu-baseline --steps 20 --warmup 3 > $OUT/prof_headline.log 2>&1)
-python bench.py --random-keys --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_headline_random_keys.json
-python bench.py --workload c3 --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_c3.json
-python bench.py --workload c3 --random-keys --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_c3_random_keys.json
-python bench.py --workload c2 2>&1 | tail -1 > $OUT/bench_c2.json
-python bench.py --workload c4 --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_c4.json
+python tools/csrc_rev.py > $OUT/csrc_rev.txt
+python bench.py 2>&1 | tail -1 > $OUT/bench_default.json
+declare -A WL=( [headline]="--workload headline" [headline_random_keys]="--workload headline --random-keys" [c2]="--workload c2" [c4]="--workload c4" \
+                [c4_sparse_keys]="--workload c4_sparse" [agg_65536_groups]="--workload agg_groups --groups 65536" )
 cd /tmp
-for w in c2 c3 c4; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python $R/bench.py --workload $w --no-cpu-baseline --steps 20 --warmup 3 > $OUT/prof_$w.log 2>&1
+for name in headline headline_random_keys c2 c4 c4_sparse_keys agg_65536_groups; do
+  args="${WL[$name]} --no-configs --no-cpu-baseline"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o $name -- python $R/bench.py $args --steps 20 --warmup 3 > $OUT/prof_$name.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$name -o $name -- python $R/bench.py $args --steps 3 --warmup 1 > $OUT/pmc_fetch_$name.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$name -o $name -- python $R/bench.py $args --steps 3 --warmup 1 > $OUT/pmc_write_$name.log 2>&1
 done
-# PMC passes: counters in their own runs, kernel-trace only (never combined with other trace domains)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o headline -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o headline -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
+# calibration: known byte counts in the product kernels' access pattern (8-byte non-temporal loads / stores), and random reads
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_calib -o calib -- $R/tools/stream_bench calib > $OUT/pmc_fetch_calib.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_calib -o calib -- $R/tools/stream_bench calib > $OUT/pmc_write_calib.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_gather -o gather -- $R/tools/micro_bench gather1 > $OUT/pmc_fetch_gather.log 2>&1
 cd $R
+python tools/probe_paths.py groups 2>&1 | grep -v amdgpu.ids > $OUT/probe_groups.txt
+python tools/probe_paths.py joinshapes 2>&1 | grep -v amdgpu.ids > $OUT/probe_joinshapes.txt
+python tools/probe_paths.py keys 2>&1 | grep -v amdgpu.ids > $OUT/probe_keys.txt
+python tools/probe_paths.py exprs 2>&1 | grep -v amdgpu.ids > $OUT/probe_exprs.txt
+./tools/micro_bench all > $OUT/micro_bench.txt 2>&1
 ls $OUT

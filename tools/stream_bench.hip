@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <string>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -110,8 +111,24 @@ int run(const uint64_t *a, const uint64_t *b, int64_t n, uint64_t *out, int bloc
     return 0;
 }
 
-int main() {
+int main(int argc, char **argv) {
     const int64_t n = 1000000000;
+    if (argc > 1 && std::string(argv[1]) == "calib") {
+        // known byte counts for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE on THIS access pattern (8-byte non-temporal loads
+        // and stores, like the product kernels): read2 streams 2 x 8e9 B, the fill writes 4 x 1.6e9 B, the copy reads and writes 1.6e9 B
+        uint64_t *a, *b, *out;
+        CK(hipMalloc(&a, n * 8));
+        CK(hipMalloc(&b, n * 8));
+        CK(hipMalloc(&out, 8));
+        CK(hipMemset(a, 1, n * 8));
+        CK(hipMemset(b, 2, n * 8));
+        for (int r = 0; r < 3; ++r) read2<4, 0><<<256, 1024>>>(a, b, n, out);
+        for (int r = 0; r < 3; ++r) copy_rw<4, 0, 4, 1><<<256 * 2, 1024>>>(b, a, 200000000);
+        for (int r = 0; r < 3; ++r) copy_rw<4, 1, 1, 1><<<256 * 2, 1024>>>(b, a, 200000000);
+        CK(hipDeviceSynchronize());
+        printf("calib: read2<4,0> 16e9 B read; copy_rw<4,0,4,1> 6.4e9 B written; copy_rw<4,1,1,1> 1.6e9 B read + 1.6e9 B written\n");
+        return 0;
+    }
     uint64_t *a, *b, *out;
     CK(hipMalloc(&a, n * 8));
     CK(hipMalloc(&b, n * 8));
