@@ -9,7 +9,8 @@ Layout:
   arrow_host.py    numpy-backed Arrow-layout host containers (plumbing)
   expression.py    host mirror of ColumnExpr / PhysicalLiteralExpr / PhysicalBinaryExpr
   physical_plan.py host mirror of the PhysicalPlan operators (ScanPlan, SelectionPlan, ...)
-  parallel.py      row-range sharding across GPUs (torch.distributed / RCCL)
+  rewrite.py       plan rewrite pass (unfused reference-shaped tree → fused device operators), Catalog / NaiveDB surface
+  parallel.py      row-range sharding across GPUs: thin caller of the C ABI's sharded entry points (RCCL)
 """
 from .arrow_host import (AggregateFunc, Column, DType, ErrorCode, Field, Operator, RecordBatch, ScalarValue, Status,
                          read_csv)
@@ -24,7 +25,7 @@ __all__ = [
 def __getattr__(name):
     # capi / physical_plan load libnqe_hip.so; keep `import naive_query_engine_amd` usable by tools
     # that only need the host containers, but never fall back to anything else.
-    if name in ("capi", "physical_plan", "parallel"):
+    if name in ("capi", "physical_plan", "parallel", "rewrite"):
         import importlib
 
         return importlib.import_module(f".{name}", __name__)

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <fstream>
 #include <iterator>
+#include <map>
 #include <memory>
 #include <optional>
 #include <string>
@@ -424,20 +425,6 @@ struct ProjectionPlan : PhysicalPlan { // projection.rs:18-75
             offs.push_back(0);
             for (auto &e : expr) { e->flatten(s, nodes); offs.push_back(int32_t(nodes.size())); }
         };
-        // fused Projection∘Selection over a single batch (identical result, one pass per output column)
-        if (auto sel = std::dynamic_pointer_cast<SelectionPlan>(input)) {
-            std::vector<RecordBatch> below = sel->input->execute();
-            if (below.size() == 1) {
-                std::vector<nqe_expr_node> pred, nodes;
-                std::vector<int32_t> offs;
-                sel->expr->flatten(below[0].schema(), pred);
-                flatten_all(below[0].schema(), nodes, offs);
-                nqe_table *t = nullptr;
-                below[0].ctx()->check(nqe_selection_projection_execute(below[0].ctx()->raw(), below[0].raw(), pred.data(), int32_t(pred.size()),
-                                                                       nodes.data(), offs.data(), int32_t(expr.size()), &t));
-                return {below[0].with_table(schema_, t)};
-            }
-        }
         std::vector<RecordBatch> out;
         for (auto &b : input->execute()) {
             std::vector<nqe_expr_node> nodes;
@@ -525,32 +512,29 @@ NAIVE_DB_AGG(Min, Min, "min", Float64)     // min.rs
 
 struct PhysicalAggregatePlan : PhysicalPlan { // aggregate/mod.rs:31-223
     std::vector<PhysicalExprRef> group_expr;
-    std::vector<std::unique_ptr<AggregateOperator>> aggr_ops;
+    std::vector<std::shared_ptr<AggregateOperator>> aggr_ops; // Vec<Box<dyn AggregateOperator>>; shared so that the rewrite pass can re-parent them
     PhysicalPlanRef input;
     NaiveSchema schema_;
     static PhysicalPlanRef create(std::vector<PhysicalExprRef> group_expr, std::vector<std::unique_ptr<AggregateOperator>> aggr_ops, PhysicalPlanRef input) {
         auto p = std::make_shared<PhysicalAggregatePlan>();
         p->schema_ = input->schema(); // the INPUT schema (quirk Q8/Q13)
         p->group_expr = std::move(group_expr);
-        p->aggr_ops = std::move(aggr_ops);
+        for (auto &op : aggr_ops) p->aggr_ops.push_back(std::move(op));
         p->input = std::move(input);
         return p;
+    }
+    // (input batches, predicate the aggregation kernel applies itself): the plain operator has no predicate
+    virtual std::vector<RecordBatch> input_batches(PhysicalExprRef &pred_expr) {
+        pred_expr = nullptr;
+        return input->execute();
     }
     const NaiveSchema &schema() const override { return schema_; }
     std::vector<PhysicalPlanRef> children() const override { return {input}; }
     std::vector<RecordBatch> execute() override {
         std::vector<NaiveField> fields;
         for (auto &op : aggr_ops) fields.push_back(op->data_field(schema_));
-        // fuse a SelectionPlan below into the aggregation kernel when it sees one batch
         PhysicalExprRef pred_expr;
-        std::vector<RecordBatch> batches;
-        if (auto sel = std::dynamic_pointer_cast<SelectionPlan>(input)) {
-            batches = sel->input->execute();
-            if (batches.size() == 1) pred_expr = sel->expr;
-            else batches = input->execute();
-        } else {
-            batches = input->execute();
-        }
+        std::vector<RecordBatch> batches = input_batches(pred_expr);
         if (batches.empty()) throw ErrorCode(ErrorCode::NotSupported, "aggregate over an empty batch list is not supported on the device path");
         const ContextRef &ctx = batches[0].ctx();
         std::vector<nqe_aggregate> aggs;
@@ -633,6 +617,144 @@ struct HashJoin : PhysicalPlan {
         }
         return out;
     }
+};
+
+// ---------------------------------------------------------------- physical_plan/visitor.rs:4-24
+struct PhysicalPlanVisitor { // trait PhysicalPlanVistor
+    virtual ~PhysicalPlanVisitor() = default;
+    virtual void pre_visit(const PhysicalPlan &) {}
+    virtual void post_visit(const PhysicalPlan &) {}
+};
+// _visit_physical_plan (:12-24): children() first, then pre_visit, the children in order, post_visit
+inline void visit_physical_plan(const PhysicalPlan &plan, PhysicalPlanVisitor &visitor) {
+    auto children = plan.children();
+    visitor.pre_visit(plan);
+    for (auto &c : children) visit_physical_plan(*c, visitor);
+    visitor.post_visit(plan);
+}
+
+// ---------------------------------------------------------------- the rewrite pass
+// Takes the UNFUSED tree the reference's planner builds (QueryPlanner::create_physical_plan, planner/mod.rs:42-182) and substitutes
+// the subtrees the device executes in one go; `rewrite(tree)->execute()` returns what `tree->execute()` returns.
+//   ProjectionPlan(SelectionPlan(x))         → FusedSelectionProjectionPlan(x)   nqe_selection_projection_execute
+//   PhysicalAggregatePlan(SelectionPlan(x))  → FusedSelectionAggregatePlan(x)    nqe_aggregate_execute with its predicate argument
+struct Materialized : PhysicalPlan { // an already-executed child (a fused operator falling back to the plain chain)
+    std::vector<RecordBatch> batches;
+    NaiveSchema schema_;
+    static PhysicalPlanRef create(std::vector<RecordBatch> b, NaiveSchema s) {
+        auto p = std::make_shared<Materialized>();
+        p->batches = std::move(b);
+        p->schema_ = std::move(s);
+        return p;
+    }
+    const NaiveSchema &schema() const override { return schema_; }
+    std::vector<RecordBatch> execute() override { return batches; }
+    std::vector<PhysicalPlanRef> children() const override { return {}; }
+};
+
+struct FusedSelectionProjectionPlan : PhysicalPlan {
+    PhysicalPlanRef input;
+    PhysicalExprRef predicate;
+    NaiveSchema schema_;
+    std::vector<PhysicalExprRef> expr;
+    static PhysicalPlanRef create(PhysicalPlanRef input, PhysicalExprRef predicate, NaiveSchema schema, std::vector<PhysicalExprRef> expr) {
+        auto p = std::make_shared<FusedSelectionProjectionPlan>();
+        p->input = std::move(input);
+        p->predicate = std::move(predicate);
+        p->schema_ = std::move(schema);
+        p->expr = std::move(expr);
+        return p;
+    }
+    const NaiveSchema &schema() const override { return schema_; }
+    std::vector<PhysicalPlanRef> children() const override { return {input}; }
+    std::vector<RecordBatch> execute() override {
+        std::vector<RecordBatch> below = input->execute();
+        if (below.size() != 1 || schema_.fields().empty()) // several batches: predicate from batch 0 (Q3) — the plain operators do that
+            return ProjectionPlan::create(SelectionPlan::create(Materialized::create(below, input->schema()), predicate), schema_, expr)->execute();
+        std::vector<nqe_expr_node> pred, nodes;
+        std::vector<int32_t> offs{0};
+        predicate->flatten(below[0].schema(), pred);
+        for (auto &e : expr) { e->flatten(below[0].schema(), nodes); offs.push_back(int32_t(nodes.size())); }
+        nqe_table *t = nullptr;
+        below[0].ctx()->check(nqe_selection_projection_execute(below[0].ctx()->raw(), below[0].raw(), pred.data(), int32_t(pred.size()), nodes.data(),
+                                                               offs.data(), int32_t(expr.size()), &t));
+        return {below[0].with_table(schema_, t)};
+    }
+};
+
+struct FusedSelectionAggregatePlan : PhysicalAggregatePlan { // state and quirks (Q8, Q10) inherited unchanged
+    PhysicalExprRef predicate;
+    std::vector<RecordBatch> input_batches(PhysicalExprRef &pred_expr) override {
+        std::vector<RecordBatch> below = input->execute();
+        if (below.size() == 1) {
+            pred_expr = predicate;
+            return below;
+        }
+        pred_expr = nullptr; // several batches (Q3) or none (the selection's own error): the plain selection over what was produced
+        return SelectionPlan::create(Materialized::create(below, input->schema()), predicate)->execute();
+    }
+};
+
+// returns a NEW tree; nodes of the input tree are shared where they are kept (scans) and left as they were otherwise
+inline PhysicalPlanRef rewrite(const PhysicalPlanRef &plan) {
+    if (auto p = std::dynamic_pointer_cast<ProjectionPlan>(plan)) {
+        auto sel = std::dynamic_pointer_cast<SelectionPlan>(p->input);
+        if (sel && !p->schema_.fields().empty()) return FusedSelectionProjectionPlan::create(rewrite(sel->input), sel->expr, p->schema_, p->expr);
+        return ProjectionPlan::create(rewrite(p->input), p->schema_, p->expr);
+    }
+    if (std::dynamic_pointer_cast<FusedSelectionAggregatePlan>(plan)) return plan;
+    if (auto a = std::dynamic_pointer_cast<PhysicalAggregatePlan>(plan)) {
+        auto sel = std::dynamic_pointer_cast<SelectionPlan>(a->input);
+        std::shared_ptr<PhysicalAggregatePlan> out;
+        if (sel) {
+            auto f = std::make_shared<FusedSelectionAggregatePlan>();
+            f->predicate = sel->expr;
+            f->input = rewrite(sel->input);
+            out = f;
+        } else {
+            out = std::make_shared<PhysicalAggregatePlan>();
+            out->input = rewrite(a->input);
+        }
+        out->schema_ = a->schema_;
+        out->group_expr = a->group_expr;
+        out->aggr_ops = a->aggr_ops;
+        return out;
+    }
+    if (auto s = std::dynamic_pointer_cast<SelectionPlan>(plan)) return SelectionPlan::create(rewrite(s->input), s->expr);
+    if (auto l = std::dynamic_pointer_cast<PhysicalLimitPlan>(plan)) return PhysicalLimitPlan::create(rewrite(l->input), l->n);
+    if (auto o = std::dynamic_pointer_cast<PhysicalOffsetPlan>(plan)) return PhysicalOffsetPlan::create(rewrite(o->input), o->n);
+    if (auto j = std::dynamic_pointer_cast<HashJoin>(plan)) return HashJoin::create(rewrite(j->left), rewrite(j->right), j->on, j->join_type, j->schema_);
+    return plan; // scans, fused operators, operators this pass does not know
+}
+
+// ---------------------------------------------------------------- catalog.rs:21-62 / db.rs:19-47 (without the SQL front end)
+struct Catalog {
+    std::map<std::string, TableRef> tables;
+    void add_csv_table(const std::string &table, const std::string &csv_file, const CsvConfig &conf = CsvConfig()) {
+        tables[table] = CsvTable::try_create(csv_file, conf);
+    }
+    void add_memory_table(const std::string &table, NaiveSchema schema, std::vector<RecordBatch> batches) {
+        tables[table] = MemTable::try_create(std::move(schema), std::move(batches));
+    }
+    TableRef get_table(const std::string &table) const {
+        auto it = tables.find(table);
+        if (it == tables.end()) throw ErrorCode(ErrorCode::NoSuchTable, "Unable to get table named: " + table);
+        return it->second;
+    }
+};
+struct NaiveDB {
+    Catalog catalog;
+    void create_csv_table(const std::string &table, const std::string &csv_file, const CsvConfig &conf = CsvConfig()) {
+        catalog.add_csv_table(table, csv_file, conf);
+    }
+    void create_memory_table(const std::string &table, NaiveSchema schema, std::vector<RecordBatch> batches) {
+        catalog.add_memory_table(table, std::move(schema), std::move(batches));
+    }
+    PhysicalPlanRef scan(const std::string &table, std::optional<std::vector<size_t>> projection = std::nullopt) const {
+        return ScanPlan::create(catalog.get_table(table), std::move(projection));
+    }
+    // what run_sql does after planning (db.rs:34-36): the physical tree → (rewrite) → execute()
+    std::vector<RecordBatch> run_plan(const PhysicalPlanRef &physical_plan) const { return rewrite(physical_plan)->execute(); }
 };
 
 } // namespace naive_db

@@ -10,9 +10,10 @@ behaviour as the reference, so plans are written as in its tests:
 
 `execute()` returns `DeviceRecordBatch`es (columns stay in HBM between operators; `.to_host()`
 downloads).  All computation goes through the C ABI (capi → libnqe_hip.so); there is no host
-fallback.  Where the reference's tree shape allows it, `execute()` calls the fused entry points
-(Projection∘Selection, Aggregate∘Selection) — results are identical to the unfused chain, which
-tests/test_gpu_plans.py checks.
+fallback.  Every operator here does exactly what its reference namesake does, one operator at a
+time; the fused device entry points (Projection∘Selection, Aggregate∘Selection) are introduced
+by a separate pass over the tree, `rewrite()` in rewrite.py — `rewrite(tree).execute()` equals
+`tree.execute()`, which tests/test_gpu_plans.py checks.
 """
 from __future__ import annotations
 
@@ -207,18 +208,7 @@ class ProjectionPlan(PhysicalPlan):
     def execute(self):
         if not self._schema:  # projection.rs:47-48: pass-through above an aggregate
             return self.input.execute()
-        # fused Projection∘Selection when the selection sees exactly one batch
-        if isinstance(self.input, SelectionPlan):
-            below = self.input.input.execute()
-            if len(below) == 1:
-                ctx = _ctx_of(below)
-                pred = self.input.expr.flatten(below[0].fields)
-                exprs = [e.flatten(below[0].fields) for e in self.expr]
-                t = ctx.selection_projection(below[0].table, pred, exprs)
-                return [DeviceRecordBatch(self._out_fields(t.dtypes()), t)]
-            batches = self.input.execute() if not below else SelectionPlan(_Materialized(below, self.input.input.schema()), self.input.expr).execute()
-        else:
-            batches = self.input.execute()
+        batches = self.input.execute()
         out = []
         for b in batches:
             ctx = b.table.ctx
@@ -375,18 +365,13 @@ class PhysicalAggregatePlan(PhysicalPlan):
     def children(self):
         return [self.input]
 
+    def _input_batches(self):
+        """(input batches, predicate expression the aggregation kernel applies itself): the plain operator has no predicate"""
+        return self.input.execute(), None
+
     def execute(self):
         out_fields = [op.data_field(self._schema) for op in self.aggr_ops]
-        pred_expr = None
-        src = self.input
-        if isinstance(src, SelectionPlan):
-            below = src.input.execute()
-            if len(below) == 1:  # fuse the filter into the aggregation kernel
-                pred_expr, batches = src.expr, below
-            else:
-                batches = SelectionPlan(_Materialized(below, src.input.schema()), src.expr).execute() if below else src.execute()
-        else:
-            batches = src.execute()
+        batches, pred_expr = self._input_batches()
         ctx = _ctx_of(batches)
         if not batches:
             if self.group_expr:

@@ -7,6 +7,7 @@
 #include <fstream>
 #include <functional>
 #include <sstream>
+#include <typeinfo>
 
 #include "../../naive_query_engine_amd/host/naive_db.hpp"
 
@@ -131,12 +132,59 @@ int main(int argc, char **argv) {
         CHECK((res[0].column(1).to_f64() == t1.cols[2].to_f64()));
     });
 
-    run("select id, age from t1 where id > 1 (sql/planner.rs:670-679): fused Projection(Selection(Scan))", [&] {
+    run("select id, age from t1 where id > 1 (sql/planner.rs:670-679): Projection(Selection(Scan))", [&] {
         NaiveSchema schema({source->schema().field(0), source->schema().field(1)});
         auto sel = SelectionPlan::create(ScanPlan::create(source, std::nullopt), PhysicalBinaryExpr::create(coli(0), Operator::Gt, lit(1)));
         auto res = ProjectionPlan::create(sel, schema, {coli(0), coli(1)})->execute();
         CHECK((res[0].column(0).to_i64() == std::vector<int64_t>{2, 4, 5, 6, 7, 8, 9}));
         CHECK((res[0].column(1).to_i64() == std::vector<int64_t>{20, 18, 19, 20, 21, 22, 23}));
+    });
+
+    run("rewrite pass: unfused planner-shaped trees -> fused device operators, same results (planner/mod.rs:42-182, visitor.rs:12-24)", [&] {
+        struct Shape : PhysicalPlanVisitor {
+            std::vector<std::string> names;
+            void pre_visit(const PhysicalPlan &p) override { names.push_back(typeid(p).name()); }
+        };
+        auto shape = [](const PhysicalPlanRef &p) { Shape s; visit_physical_plan(*p, s); return s.names.size(); };
+        NaiveSchema schema({source->schema().field(0), NaiveField(std::nullopt, "age + 100", DataType::Int64, true)});
+        auto mk = [&] {
+            auto sel = SelectionPlan::create(ScanPlan::create(source, std::nullopt), PhysicalBinaryExpr::create(coli(0), Operator::Lt, lit(9)));
+            auto proj = ProjectionPlan::create(sel, schema, {coli(0), PhysicalBinaryExpr::create(coli(1), Operator::Plus, lit(100))});
+            return PhysicalLimitPlan::create(PhysicalOffsetPlan::create(proj, 2), 3);
+        };
+        auto plain = mk();
+        auto fused = rewrite(plain);
+        CHECK(shape(plain) == 5 && shape(fused) == 4); // Limit, Offset, [Projection, Selection | FusedSelectionProjection], Scan
+        CHECK(std::dynamic_pointer_cast<FusedSelectionProjectionPlan>(fused->children()[0]->children()[0]) != nullptr);
+        auto a = plain->execute(), b = fused->execute();
+        CHECK(a.size() == 1 && b.size() == 1);
+        CHECK((a[0].column(0).to_i64() == b[0].column(0).to_i64()) && (a[0].column(1).to_i64() == b[0].column(1).to_i64()));
+        CHECK((b[0].column(1).to_i64() == std::vector<int64_t>{118, 119, 120}));
+        // aggregate over a selection: the filter becomes the aggregation kernel's predicate
+        auto mkagg = [&] {
+            std::vector<std::unique_ptr<AggregateOperator>> ops;
+            ops.push_back(Count::create(ColumnExpr::try_create(std::nullopt, 0)));
+            ops.push_back(Sum::create(ColumnExpr::try_create(std::nullopt, 2)));
+            auto sel = SelectionPlan::create(ScanPlan::create(source, std::nullopt), PhysicalBinaryExpr::create(coli(0), Operator::Gt, lit(2)));
+            return PhysicalAggregatePlan::create({PhysicalBinaryExpr::create(coli(0), Operator::Modulos, lit(3))}, std::move(ops), sel);
+        };
+        auto pa = mkagg();
+        auto fa = rewrite(pa);
+        CHECK(std::dynamic_pointer_cast<FusedSelectionAggregatePlan>(fa) != nullptr && shape(fa) == 2 && shape(pa) == 3);
+        auto ra = pa->execute(), rb = fa->execute();
+        CHECK((ra[0].column(0).to_i64() == rb[0].column(0).to_i64()));
+        auto sa = ra[0].column(1).to_f64(), sb = rb[0].column(1).to_f64();
+        CHECK(sa.size() == sb.size());
+        for (size_t i = 0; i < sa.size(); ++i) CHECK(std::fabs(sa[i] - sb[i]) <= 1e-12 * std::fabs(sa[i]));
+        // the catalog surface (catalog.rs:40-62, db.rs:39-46)
+        NaiveDB db;
+        db.create_memory_table("t1", source->schema(), source->scan(std::nullopt));
+        auto viadb = db.run_plan(ProjectionPlan::create(SelectionPlan::create(db.scan("t1"), PhysicalBinaryExpr::create(coli(0), Operator::Lt, lit(9))), schema,
+                                                        {coli(0), PhysicalBinaryExpr::create(coli(1), Operator::Plus, lit(100))}));
+        CHECK(viadb.size() == 1 && viadb[0].num_rows() == 7);
+        bool threw = false;
+        try { db.scan("nope"); } catch (const ErrorCode &e) { threw = e.kind() == ErrorCode::NoSuchTable; }
+        CHECK(threw);
     });
 
     run("README query 1 (README.md:70-76): select id, age + 100 from t1 where id < 9 limit 3 offset 2", [&] {

@@ -29,4 +29,4 @@ def test_reference_tests_through_cpp_host_mirror():
     out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "14/14 tests passed" in out.stdout
+    assert "15/15 tests passed" in out.stdout

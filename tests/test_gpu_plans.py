@@ -1,7 +1,7 @@
 """The reference's own plan-level tests, written against the Python host mirror
 (naive_query_engine_amd/physical_plan.py) exactly as the reference writes them
 (selection.rs:126-178, projection.rs:88-121, sql/planner.rs:645-713, README.md:69-112), plus checks that the
-fused execute() paths equal the unfused operator chain."""
+rewrite pass (rewrite.py: unfused reference-shaped tree → fused device operators) leaves every result as it was."""
 import os
 
 import numpy as np
@@ -56,20 +56,23 @@ def test_projection_like_the_reference(pp, t1, golden):
     assert res[0].to_host().fields[0].name == "id"
 
 
-def test_readme_query1_fused_equals_unfused(pp, t1, golden):
+def test_readme_query1_rewritten_equals_unfused(pp, t1, golden):
     scan = pp.ScanPlan.create(t1, None)
     pred = PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 0), Operator.Lt, lit(9))
     exprs = [ColumnExpr.try_create(None, 0), PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 1), Operator.Plus, lit(100))]
     schema = [t1.schema()[0], Field("age + 100", DType.INT64, True)]
-    fused = pp.ProjectionPlan.create(pp.SelectionPlan.create(scan, pred), schema, exprs)
-    plan = pp.PhysicalLimitPlan.create(pp.PhysicalOffsetPlan.create(fused, 2), 3)
-    out = plan.execute()
-    rows = list(zip(out[0].column(0).to_list(), out[0].column(1).to_list()))
-    assert rows == [(r[0], r[2]) for r in golden["readme_filter_project_offset_limit"]["rows"]]
-    # unfused chain: selection materialised first
-    sel = pp.SelectionPlan.create(scan, pred).execute()
-    unfused = pp.ProjectionPlan.create(pp._Materialized(sel, t1.schema()), schema, exprs).execute()
-    assert_batches_equal(fused.execute()[0].table.to_host(), unfused[0].table.to_host())
+    from naive_query_engine_amd.rewrite import plan_shape, rewrite
+
+    chain = pp.ProjectionPlan.create(pp.SelectionPlan.create(scan, pred), schema, exprs)
+    plan = pp.PhysicalLimitPlan.create(pp.PhysicalOffsetPlan.create(chain, 2), 3)
+    assert plan_shape(plan) == ["PhysicalLimitPlan", "PhysicalOffsetPlan", "ProjectionPlan", "SelectionPlan", "ScanPlan"]
+    fused = rewrite(plan)
+    assert plan_shape(fused) == ["PhysicalLimitPlan", "PhysicalOffsetPlan", "FusedSelectionProjectionPlan", "ScanPlan"]
+    for p in (plan, fused):
+        out = p.execute()
+        rows = list(zip(out[0].column(0).to_list(), out[0].column(1).to_list()))
+        assert rows == [(r[0], r[2]) for r in golden["readme_filter_project_offset_limit"]["rows"]]
+    assert_batches_equal(rewrite(chain).execute()[0].table.to_host(), chain.execute()[0].table.to_host())
 
 
 def test_readme_aggregate_and_q9(pp, t1, golden):
@@ -84,13 +87,15 @@ def test_readme_aggregate_and_q9(pp, t1, golden):
     exp = np.array(sorted(golden["readme_group_by_id_mod_3"]["rows"]), dtype=np.float64)
     assert (rows[:, 0] == exp[:, 0]).all() and np.allclose(rows, exp, rtol=1e-9, atol=0)
     assert agg.schema() == t1.schema()  # quirk Q8: schema() is the INPUT schema
-    # filter fused into the aggregate == aggregate over a materialised selection
+    # the rewrite pass folds the filter into the aggregate: same result as the plain chain
+    from naive_query_engine_amd.rewrite import plan_shape, rewrite
+
     pred = PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 0), Operator.Gt, lit(2))
     mk = lambda: [pp.Count.create(ColumnExpr.try_create(None, 2)), pp.Sum.create(ColumnExpr.try_create(None, 2))]
-    a = pp.PhysicalAggregatePlan.create([key], mk(), pp.SelectionPlan.create(pp.ScanPlan.create(t1, None), pred)).execute()
-    sel = pp.SelectionPlan.create(pp.ScanPlan.create(t1, None), pred).execute()
-    b = pp.PhysicalAggregatePlan.create([key], mk(), pp._Materialized(sel, t1.schema())).execute()
-    assert_batches_equal(a[0].table.to_host(), b[0].table.to_host(), rtol=1e-12)
+    chain = pp.PhysicalAggregatePlan.create([key], mk(), pp.SelectionPlan.create(pp.ScanPlan.create(t1, None), pred))
+    fused = rewrite(pp.ProjectionPlan.create(chain, [], []))
+    assert plan_shape(fused) == ["ProjectionPlan", "FusedSelectionAggregatePlan", "ScanPlan"]
+    assert_batches_equal(fused.execute()[0].table.to_host(), chain.execute()[0].table.to_host(), rtol=1e-12)
     # quirk Q9: the un-grouped state is never cleared between execute() calls
     un = pp.PhysicalAggregatePlan.create([], [pp.Count.create(ColumnExpr.try_create(None, 0)), pp.Sum.create(ColumnExpr.try_create(None, 0))], pp.ScanPlan.create(t1, None))
     assert [c.to_list() for c in un.execute()[0].table.to_host()] == [[8], [42.0]]
@@ -172,3 +177,51 @@ def test_reference_tests_with_utf8_names(pp, csv_tables, golden):
     names = [f.name for f in out.fields]
     pick = [names.index("id"), names.index("name"), names.index("rank_name"), names.index("department_name")]
     assert list(map(list, zip(*[out.column(i).to_list() for i in pick]))) == golden["readme_two_hash_joins"]["rows"]
+
+
+def test_rewrite_keeps_quirks_q3_q9_q11(pp):
+    """the fused operators fall back to the plain chain where the reference's behaviour depends on the tree being unfused
+    (several input batches: the predicate comes from batch 0, Q3) and keep the per-operator state (Q9, Q11)"""
+    from naive_query_engine_amd.rewrite import NaiveDB, plan_shape, rewrite
+
+    f = [Field("x", DType.INT64, True), Field("y", DType.INT64, True)]
+    b0 = RecordBatch(f, [Column.from_list([1, None, 9], DType.INT64), Column.from_list([10, 20, 30], DType.INT64)])
+    b1 = RecordBatch(f, [Column.from_list([7, 0, 8, 100], DType.INT64), Column.from_list([1, 2, 3, 4], DType.INT64)])
+    db = NaiveDB()
+    db.create_memory_table("t", f, [b0, b1])
+    pred = PhysicalBinaryExpr.create(ColumnExpr.try_create(None, 0), Operator.Gt, lit(4))
+    proj = lambda: pp.ProjectionPlan.create(pp.SelectionPlan.create(db.scan("t"), pred), [f[1]],
+                                            [PhysicalBinaryExpr.create(ColumnExpr.try_create("y", None), Operator.Plus, lit(1))])
+    plain = [r.column(0).to_list() for r in proj().execute()]
+    assert plain == [[None, 31], [None, 4]]                                   # Q3: batch 0's mask zipped against batch 1
+    assert [r.column(0).to_list() for r in db.run_plan(proj())] == plain      # run_plan = rewrite + execute
+    assert plan_shape(rewrite(proj())) == ["FusedSelectionProjectionPlan", "ScanPlan"]
+    # grouped aggregate over the filtered two-batch table
+    agg = lambda: pp.PhysicalAggregatePlan.create([ColumnExpr.try_create("x", None)], [pp.Sum.create(ColumnExpr.try_create("y", None))],
+                                                  pp.SelectionPlan.create(db.scan("t"), pred))
+    a, b = agg().execute()[0].table.to_host(), db.run_plan(agg())[0].table.to_host()
+    assert_batches_equal(a, b)
+    # Q9 on a rewritten tree: the un-grouped state survives between execute() calls of the same (rewritten) plan object
+    un = rewrite(pp.PhysicalAggregatePlan.create([], [pp.Count.create(ColumnExpr.try_create("y", None))],
+                                                 pp.SelectionPlan.create(db.scan("t"), PhysicalBinaryExpr.create(ColumnExpr.try_create("y", None), Operator.Gt, lit(0)))))
+    first = un.execute()[0].column(0).to_list()
+    assert un.execute()[0].column(0).to_list() == [2 * first[0]]
+    with pytest.raises(ErrorCode) as e:
+        db.scan("nope")
+    assert e.value.status == Status.NoSuchTable
+    with pytest.raises(ErrorCode):
+        db.run_sql("select 1")
+
+
+def test_arrow_tables_enter_through_the_catalog(pp):
+    pa = pytest.importorskip("pyarrow")
+    from naive_query_engine_amd.rewrite import NaiveDB
+
+    rb = pa.RecordBatch.from_arrays([pa.array([1, 2, 3, 4, 5], pa.int64()), pa.array([1.5, None, 3.5, 4.5, 5.5], pa.float64()), pa.array(["a", "b", None, "d", "e"])],
+                                    names=["id", "v", "s"])
+    db = NaiveDB()
+    db.create_arrow_table("t", [rb])
+    plan = pp.ProjectionPlan.create(pp.SelectionPlan.create(db.scan("t"), PhysicalBinaryExpr.create(ColumnExpr.try_create("id", None), Operator.Gt, lit(2))),
+                                    [Field("v", DType.FLOAT64, True), Field("s", DType.UTF8, True)], [ColumnExpr.try_create("v", None), ColumnExpr.try_create("s", None)])
+    out = db.run_plan(plan)[0].table.to_arrow(names=["v", "s"])
+    assert out.to_pydict() == {"v": [3.5, 4.5, 5.5], "s": [None, "d", "e"]}
