@@ -787,8 +787,7 @@ SimpleExpr plain_column_expr(int dtype) {
     SimpleExpr s;
     std::memset(&s, 0, sizeof(s));
     s.src_dtype = s.out_dtype = dtype;
-    s.aux[0].pow2_shift = s.aux[1].pow2_shift = -1;
-    s.aux[0].more = s.aux[1].more = -1;
+    for (int k = 0; k < SIMPLE_MAX_OPS; ++k) s.aux[k].pow2_shift = s.aux[k].more = -1;
     return s;
 }
 
@@ -962,10 +961,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     AggArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n = in->rows;
-    a.pred.aux[0].pow2_shift = a.pred.aux[1].pow2_shift = -1;
-    a.key.aux[0].pow2_shift = a.key.aux[1].pow2_shift = -1;
-    a.pred.aux[0].more = a.pred.aux[1].more = -1;
-    a.key.aux[0].more = a.key.aux[1].more = -1;
+    for (int k = 0; k < SIMPLE_MAX_OPS; ++k) a.pred.aux[k].pow2_shift = a.pred.aux[k].more = a.key.aux[k].pow2_shift = a.key.aux[k].more = -1;
 
     // ---- key expression (group_expr[0] only, quirk Q8)
     ExprInfo kinfo;

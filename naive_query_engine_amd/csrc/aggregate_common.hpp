@@ -138,7 +138,7 @@ __device__ __forceinline__ void global_update(const GroupTable &g, int64_t slot,
 }
 
 // group key of a row for the kernels that compute it inline.  KEY: 0 = the column itself, 1 = `col % ±2^k` (mask), 2 = `col % d`
-// (magic multiply), 3 = any fault-free chain of one or two integer operations with literals (`(id + 1) % 1000`, `id / 7 * 3`, …)
+// (magic multiply), 3 = any fault-free chain of up to four integer operations with literals (`(id + 1) % 1000`, `id / 7 * 3`, …)
 // through the generic SimpleExpr interpreter — wave-uniform branches on the operator, no flags (the host admits only chains
 // whose divisors are literals other than 0 and -1)
 template <int KEY>
@@ -181,7 +181,7 @@ __device__ __forceinline__ void inline_keys(const SimpleExpr &ke, const uint64_t
 #pragma unroll
     for (int u = 0; u < U; ++u) key[u] = kw[u];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < SIMPLE_MAX_OPS; ++k) {
         if (k >= ke.nops) break;
         const int op = ke.op[k];
         const bool ll = ke.lit_left[k] != 0;

@@ -151,7 +151,7 @@ __device__ __forceinline__ OpAux no_aux() {
 template <bool CHECKED = true>
 __device__ __forceinline__ uint64_t eval_simple(const SimpleExpr &e, uint64_t v, bool valid, int *flags) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < SIMPLE_MAX_OPS; ++k) {
         if (k < e.nops) {
             uint64_t a = e.lit_left[k] ? e.lit[k] : v;
             uint64_t b = e.lit_left[k] ? v : e.lit[k];

@@ -123,7 +123,7 @@ OpAux make_aux(int op, int dt, uint64_t lit) {
     return a;
 }
 
-// col [op lit]{0,2}
+// col [op lit]{0,SIMPLE_MAX_OPS}
 bool match_simple(const std::vector<Node> &t, int i, SimpleExpr *s) {
     const Node &x = t[size_t(i)];
     if (x.kind == NQE_EXPR_COLUMN) {
@@ -131,8 +131,7 @@ bool match_simple(const std::vector<Node> &t, int i, SimpleExpr *s) {
         s->col = x.column;
         s->src_dtype = x.out_dtype;
         s->out_dtype = x.out_dtype;
-        s->aux[0].pow2_shift = s->aux[1].pow2_shift = -1;
-        s->aux[0].more = s->aux[1].more = -1;
+        for (int k = 0; k < SIMPLE_MAX_OPS; ++k) s->aux[k].pow2_shift = s->aux[k].more = -1;
         return true; // a bare column of any type (Utf8 included) passes through
     }
     if (x.kind != NQE_EXPR_BINARY || is_logic(x.op)) return false;
@@ -148,7 +147,7 @@ bool match_simple(const std::vector<Node> &t, int i, SimpleExpr *s) {
         return false;
     }
     if (litn->dtype == NQE_UTF8) return false; // string compares have their own kernel
-    if (!match_simple(t, sub, s) || s->nops >= 2) return false;
+    if (!match_simple(t, sub, s) || s->nops >= SIMPLE_MAX_OPS) return false;
     int k = s->nops++;
     s->op[k] = x.op;
     s->lit_left[k] = lit_left ? 1 : 0;

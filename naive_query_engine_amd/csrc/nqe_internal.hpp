@@ -219,18 +219,18 @@ struct OpAux {          // host-precomputed helpers for `x / lit`, `x % lit`
     uint64_t magic;
 };
 
-// col [op lit]{0,2}: the expression shapes fused into the consumer kernels
+// col [op lit]{0,4}: the expression shapes fused into the consumer kernels (literal on either side of every step)
+constexpr int SIMPLE_MAX_OPS = 4;
 struct SimpleExpr {
     int32_t col;       // index into the INPUT table
     int32_t src_dtype; // dtype of the column
     int32_t out_dtype;
     int32_t nops;
-    int32_t op[2];
-    int32_t lit_left[2]; // 1: lit op v
-    int32_t op_dtype[2]; // operand dtype of step k
-    int32_t pad;
-    uint64_t lit[2];
-    OpAux aux[2];
+    int32_t op[SIMPLE_MAX_OPS];
+    int32_t lit_left[SIMPLE_MAX_OPS]; // 1: lit op v
+    int32_t op_dtype[SIMPLE_MAX_OPS]; // operand dtype of step k
+    uint64_t lit[SIMPLE_MAX_OPS];
+    OpAux aux[SIMPLE_MAX_OPS];
 };
 
 // `x op lit` over an Int64/UInt64 column rewritten as  lo <= (x ^ flip) <= hi  (xor negate)

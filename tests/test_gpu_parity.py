@@ -485,7 +485,11 @@ def test_aggregate_two_step_integer_keys(ctx, m):
             binop(binop(A, Operator.Modulos, lit_i64(-m)), Operator.Divide, lit_i64(2)),
             binop(A, Operator.Minus, lit_i64(-5)),
             binop(binop(U, Operator.Plus, lit_u64(3)), Operator.Modulos, lit_u64(m)),
-            binop(binop(U, Operator.Divide, lit_u64(5)), Operator.Minus, lit_u64(7))]       # wraps below zero: huge UInt64 keys
+            binop(binop(U, Operator.Divide, lit_u64(5)), Operator.Minus, lit_u64(7)),       # wraps below zero: huge UInt64 keys
+            # three- and four-step chains (SIMPLE_MAX_OPS = 4)
+            binop(binop(binop(A, Operator.Plus, lit_i64(1)), Operator.Multiply, lit_i64(3)), Operator.Modulos, lit_i64(m)),
+            binop(binop(binop(binop(A, Operator.Divide, lit_i64(3)), Operator.Plus, lit_i64(7)), Operator.Multiply, lit_i64(-2)), Operator.Modulos, lit_i64(m)),
+            binop(lit_u64(5), Operator.Plus, binop(binop(binop(U, Operator.Modulos, lit_u64(m)), Operator.Multiply, lit_u64(2)), Operator.Divide, lit_u64(3)))]
     aggs = ALL_AGGS(2)
     for key in keys:
         for pred in (None, binop(col(3), Operator.GtEq, lit_i64(-20))):
@@ -516,7 +520,10 @@ def test_aggregate_chain_predicates(ctx, groups):
              binop(binop(lit_i64(3), Operator.Multiply, K), Operator.Gt, lit_i64(-1000)),
              binop(binop(U, Operator.Divide, lit_u64(3)), Operator.NotEq, lit_u64(67)),
              binop(lit_i64(5), Operator.LtEq, binop(K, Operator.Modulos, lit_i64(-16))),
-             binop(binop(W, Operator.Plus, lit_i64(50)), Operator.Eq, lit_i64(50))]
+             binop(binop(W, Operator.Plus, lit_i64(50)), Operator.Eq, lit_i64(50)),
+             # three- and four-step chains: the probe's `(id + 1) % 10 < 5` shape and a longer one
+             binop(binop(binop(K, Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(10)), Operator.Lt, lit_i64(5)),
+             binop(binop(binop(binop(W, Operator.Multiply, lit_i64(3)), Operator.Minus, lit_i64(7)), Operator.Divide, lit_i64(4)), Operator.GtEq, lit_i64(-3))]
     keys = [K, binop(binop(K, Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(groups + 1))]
     aggs = ALL_AGGS(2)
     for pred in preds:
