@@ -1056,6 +1056,40 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         cap = std::min(sized_cap, RANK_MAX_CAP);
     }
     bool partition_mode = false, level2 = false, dense_ok = true, slab_failed = false;
+    // plan hint (see nqe_ctx::agg_hints): FNV-1a over everything that decides which kernels the query takes — the key column's
+    // buffer and expression, the predicate and its column, the value columns (buffers, validity, types) and the row count — so
+    // that a hint is only ever applied to the very query shape that recorded it
+    uint64_t hint_key = 0;
+    if (grouped && a.key_src.values && in->rows >= (int64_t(1) << 18)) {
+        hint_key = 1469598103934665603ull;
+        auto mix = [&](const void *p, size_t nbytes) {
+            const unsigned char *b = static_cast<const unsigned char *>(p);
+            for (size_t i = 0; i < nbytes; ++i) hint_key = (hint_key ^ b[i]) * 1099511628211ull;
+        };
+        const void *kp = a.key_src.values;
+        mix(&kp, sizeof(kp));
+        mix(&in->rows, sizeof(in->rows));
+        mix(&a.key, sizeof(a.key));
+        mix(&a.key_src, sizeof(a.key_src));
+        mix(&a.pred_mode, sizeof(a.pred_mode));
+        if (a.pred_mode) {
+            mix(&a.pred, sizeof(a.pred));
+            mix(&a.pred_src, sizeof(a.pred_src));
+        }
+        for (int c : plan.val_cols) {
+            const DevColumn &dc = in->cols[size_t(c)];
+            const void *vp = dc.values ? dc.values->ptr : nullptr, *vv = dc.valid();
+            mix(&vp, sizeof(vp));
+            mix(&vv, sizeof(vv));
+            mix(&dc.dtype, sizeof(dc.dtype));
+        }
+        if (hint_key == 0) hint_key = 1;
+        auto it = ctx->agg_hints.find(hint_key);
+        if (it != ctx->agg_hints.end() && it->second == 1) {
+            partition_mode = true;
+            cap = std::max(cap, sized_cap);
+        }
+    }
     bool any_val_nullable = false;
     for (int c : plan.val_cols) any_val_nullable = any_val_nullable || in->cols[size_t(c)].validity != nullptr;
     for (int attempt = 0;; ++attempt) {
@@ -1372,6 +1406,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
         if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode) {
             partition_mode = true; // a workgroup table overflowed: redo with hash-partitioned rows
+            if (hint_key) {
+                if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
+                ctx->agg_hints[hint_key] = 1;
+            }
             cap = std::max(cap, sized_cap);
             flags_reset(ctx);
             continue;

@@ -63,6 +63,12 @@ struct nqe_ctx {
     };
     std::vector<TimingRec> timings;
 
+    // Grouped aggregates that had to be redone hash-partitioned (more distinct keys than a workgroup's LDS table), remembered by
+    // (key column buffer, rows, key expression): the next execution of the same query over the same table starts partitioned
+    // instead of paying for an abandoned single-pass attempt and its read-back first.  Only a starting point — a partitioned run
+    // is correct for any number of groups, and a single-pass run still falls back when its tables overflow.
+    std::map<uint64_t, uint8_t> agg_hints;
+
     int *d_flags = nullptr; // NQE_NUM_FLAGS ints on the device
     int *h_flags = nullptr; // pinned host mirror
     int *h_flags_dev = nullptr; // the mirror's address as seen by kernels (a tail kernel may write it directly)

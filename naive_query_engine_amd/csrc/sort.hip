@@ -12,8 +12,11 @@ namespace nqe {
 
 namespace {
 
-constexpr int SORT_ITEMS = 64;                 // keys per lane per wave-block
-constexpr int SORT_CHUNK = 64 * SORT_ITEMS;    // 4096 keys per wave-block
+// keys per lane per wave-block: 64 (4096-key chunks) for large inputs, 16 (1024-key chunks) up to 4M keys — a chunk is walked
+// by ONE wave in `items` dependent steps, so the sorts that sit in an operator's tail (10^4..10^6 group keys, a 10^6-row build
+// side) were a handful of waves doing 64 serial steps per pass
+constexpr int SORT_ITEMS_LARGE = 64, SORT_ITEMS_SMALL = 16;
+constexpr int64_t SORT_SMALL_LIMIT = int64_t(1) << 22;
 constexpr int SCAN_CHUNK = 4096;               // entries per scan block (1024 threads x 4)
 
 __device__ __forceinline__ uint64_t flip_key(uint64_t k, bool signed_order) { return signed_order ? k ^ 0x8000000000000000ull : k; }
@@ -36,12 +39,12 @@ __global__ void __launch_bounds__(256) radix_hist_kernel(const uint64_t *keys, i
 
 // ---- per wave-block digit counts, digit-major layout: counts[digit * nblocks + block]
 __global__ void __launch_bounds__(64) radix_count_kernel(const uint64_t *keys, int64_t n, int shift, bool signed_order,
-                                                         uint32_t *counts, int64_t nblocks) {
+                                                         uint32_t *counts, int64_t nblocks, int items) {
     __shared__ uint32_t h[256];
     for (int i = threadIdx.x; i < 256; i += 64) h[i] = 0;
     __syncthreads();
-    int64_t base = int64_t(blockIdx.x) * SORT_CHUNK;
-    for (int it = 0; it < SORT_ITEMS; ++it) {
+    int64_t base = int64_t(blockIdx.x) * 64 * items;
+    for (int it = 0; it < items; ++it) {
         int64_t i = base + int64_t(it) * 64 + threadIdx.x;
         if (i < n) atomicAdd(&h[int((flip_key(keys[i], signed_order) >> shift) & 255)], 1u);
     }
@@ -52,12 +55,12 @@ __global__ void __launch_bounds__(64) radix_count_kernel(const uint64_t *keys, i
 // ---- stable scatter: one wave per chunk, keys visited in chunk order
 __global__ void __launch_bounds__(64) radix_scatter_kernel(const uint64_t *keys_in, const uint32_t *vals_in, int64_t n,
                                                            int shift, bool signed_order, const uint32_t *offsets,
-                                                           int64_t nblocks, uint64_t *keys_out, uint32_t *vals_out) {
+                                                           int64_t nblocks, uint64_t *keys_out, uint32_t *vals_out, int items) {
     __shared__ uint32_t base_of[256];
     for (int i = threadIdx.x; i < 256; i += 64) base_of[i] = offsets[int64_t(i) * nblocks + blockIdx.x];
     __syncthreads();
-    int64_t base = int64_t(blockIdx.x) * SORT_CHUNK;
-    for (int it = 0; it < SORT_ITEMS; ++it) {
+    int64_t base = int64_t(blockIdx.x) * 64 * items;
+    for (int it = 0; it < items; ++it) {
         int64_t i = base + int64_t(it) * 64 + threadIdx.x;
         bool in = i < n;
         uint64_t k = in ? keys_in[i] : 0;
@@ -268,7 +271,9 @@ void radix_sort_pairs_u64(nqe_ctx *ctx, const uint64_t *keys_in, const uint32_t 
             if (h[size_t(d * 256 + b)] == uint32_t(n)) trivial = true;
         if (!trivial) passes.push_back(d);
     }
-    const int64_t nblocks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
+    const int items = n <= SORT_SMALL_LIMIT ? SORT_ITEMS_SMALL : SORT_ITEMS_LARGE;
+    const int64_t chunk = int64_t(64) * items;
+    const int64_t nblocks = (n + chunk - 1) / chunk;
     BufRef counts = dev_alloc(ctx, size_t(nblocks) * 256 * 4);
     BufRef tmp_k, tmp_v;
     if (passes.size() > 1 || passes.empty()) {
@@ -289,10 +294,10 @@ void radix_sort_pairs_u64(nqe_ctx *ctx, const uint64_t *keys_in, const uint32_t 
         uint32_t *dst_v = to_out ? vals_out : (uint32_t *)tmp_v->ptr;
         int shift = passes[p] * 8;
         launch(ctx, "radix_count", radix_count_kernel, dim3((unsigned)nblocks), dim3(64), 0, src_k, n, shift, signed_order,
-               (uint32_t *)counts->ptr, nblocks);
+               (uint32_t *)counts->ptr, nblocks, items);
         exclusive_scan_u32_inplace(ctx, (uint32_t *)counts->ptr, nblocks * 256);
         launch(ctx, "radix_scatter", radix_scatter_kernel, dim3((unsigned)nblocks), dim3(64), 0, src_k, src_v, n, shift,
-               signed_order, (const uint32_t *)counts->ptr, nblocks, dst_k, dst_v);
+               signed_order, (const uint32_t *)counts->ptr, nblocks, dst_k, dst_v, items);
         src_k = dst_k;
         src_v = dst_v;
     }
