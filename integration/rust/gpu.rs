@@ -289,6 +289,92 @@ impl PhysicalPlan for GpuHashJoin {
     }
 }
 
+// ------------------------------------------------------------------ Arrow C Data Interface (nqe.h "Arrow C Data Interface")
+// arrow-rs speaks the same interface (arrow::ffi): a RecordBatch goes over as ONE struct array, no per-buffer marshalling.
+extern "C" {
+    fn nqe_table_import_arrow(ctx: *mut NqeCtx, array: *mut arrow::ffi::FFI_ArrowArray, schema: *const arrow::ffi::FFI_ArrowSchema, out: *mut *mut NqeTable) -> i32;
+    fn nqe_table_export_arrow(t: *const NqeTable, names: *const *const c_char, out_array: *mut arrow::ffi::FFI_ArrowArray,
+                              out_schema: *mut arrow::ffi::FFI_ArrowSchema) -> i32;
+}
+impl GpuCtx {
+    /// RecordBatch → device table through the C Data Interface (the library copies the buffers to HBM and releases the array)
+    pub fn upload_arrow(&self, batch: &RecordBatch) -> Result<GpuTable> {
+        let sa: arrow::array::StructArray = batch.clone().into();
+        let (mut array, schema) = (arrow::ffi::FFI_ArrowArray::new(sa.data()), arrow::ffi::FFI_ArrowSchema::try_from(sa.data_type())?);
+        let mut t = std::ptr::null_mut();
+        self.check(unsafe { nqe_table_import_arrow(self.0, &mut array, &schema, &mut t) })?;
+        Ok(GpuTable(t))
+    }
+    /// device table → RecordBatch: the exported structs own host copies; arrow-rs calls their release callbacks on drop
+    pub fn download_arrow(&self, t: &GpuTable) -> Result<RecordBatch> {
+        let (mut array, mut schema) = (arrow::ffi::FFI_ArrowArray::empty(), arrow::ffi::FFI_ArrowSchema::empty());
+        self.check(unsafe { nqe_table_export_arrow(t.0, std::ptr::null(), &mut array, &mut schema) })?;
+        let data = arrow::ffi::ArrowArray::new(array, schema).to_data()?;
+        Ok(RecordBatch::from(&arrow::array::StructArray::from(data)))
+    }
+}
+
+// ------------------------------------------------------------------ the rewrite pass (what rewrite.py / naive_db.hpp `rewrite` do)
+// The planner keeps building the plain tree (planner/mod.rs:42-182); this pass substitutes the subtrees the device runs in one
+// go.  It needs `pub(crate)` on SelectionPlan / ProjectionPlan / PhysicalAggregatePlan's fields and an `as_any` on PhysicalPlan
+// (the trait has none today; the expression trait does: expression/mod.rs:25-29).
+pub fn rewrite(ctx: &Arc<GpuCtx>, plan: PhysicalPlanRef) -> Result<PhysicalPlanRef> {
+    use crate::physical_plan::{PhysicalAggregatePlan, ProjectionPlan, SelectionPlan};
+    if let Some(p) = plan.as_any().downcast_ref::<ProjectionPlan>() {
+        if let Some(sel) = p.input.as_any().downcast_ref::<SelectionPlan>() {
+            if !p.schema.fields().is_empty() {
+                return Ok(GpuSelectionPlan::create_fused(ctx.clone(), rewrite(ctx, sel.input.clone())?, sel.expr.clone(), p.schema.clone(), p.expr.clone()));
+            }
+        }
+        return Ok(GpuProjectionPlan::create(ctx.clone(), rewrite(ctx, p.input.clone())?, p.schema.clone(), p.expr.clone()));
+    }
+    if let Some(a) = plan.as_any().downcast_ref::<PhysicalAggregatePlan>() {
+        let (input, filter) = match a.input.as_any().downcast_ref::<SelectionPlan>() {
+            Some(sel) => (rewrite(ctx, sel.input.clone())?, Some(sel.expr.clone())),
+            None => (rewrite(ctx, a.input.clone())?, None),
+        };
+        return Ok(GpuAggregatePlan::from_reference(ctx.clone(), a, input, filter)); // copies group_expr / (func, column) pairs / data_field()s
+    }
+    if let Some(sel) = plan.as_any().downcast_ref::<SelectionPlan>() {
+        return Ok(GpuSelectionPlan::create(ctx.clone(), rewrite(ctx, sel.input.clone())?, sel.expr.clone()));
+    }
+    // HashJoin → GpuHashJoin with rewritten children; Limit / Offset / Scan keep their operators (children rewritten)
+    Ok(plan)
+}
+
+// ------------------------------------------------------------------ multi-GPU: one process per GPU, each holding its row range
+// (nqe.h "sharded operators"; RCCL over xGMI inside the library, collectives on the context's stream)
+pub enum NqeComm {}
+pub enum NqeJoinTable {}
+extern "C" {
+    fn nqe_comm_get_unique_id(id_out: *mut u8 /* 128 bytes */) -> i32;
+    fn nqe_comm_create(ctx: *mut NqeCtx, unique_id: *const u8, rank: i32, world: i32, out: *mut *mut NqeComm) -> i32;
+    fn nqe_comm_destroy(comm: *mut NqeComm) -> i32;
+    fn nqe_sharded_aggregate_execute(comm: *mut NqeComm, t: *const NqeTable, pred: *const NqeExprNode, pn: i32, group: *const NqeExprNode, gn: i32,
+                                     aggs: *const NqeAggregate, na: i32, out: *mut *mut NqeTable, keys_out: *mut *mut NqeTable) -> i32;
+    fn nqe_hash_join_build(ctx: *mut NqeCtx, left: *const NqeTable, left_key: i32, out: *mut *mut NqeJoinTable) -> i32;
+    fn nqe_join_table_release(jt: *mut NqeJoinTable) -> i32;
+    fn nqe_sharded_hash_join_probe(comm: *mut NqeComm, build: *const NqeJoinTable, right_local: *const NqeTable, right_key: i32, gather: i32,
+                                   out: *mut *mut NqeTable) -> i32;
+    fn nqe_sharded_selection_projection_execute(comm: *mut NqeComm, t: *const NqeTable, pred: *const NqeExprNode, pn: i32, nodes: *const NqeExprNode,
+                                                offs: *const i32, ne: i32, gather: i32, out: *mut *mut NqeTable) -> i32;
+    fn nqe_table_all_gather(comm: *mut NqeComm, local: *const NqeTable, out: *mut *mut NqeTable) -> i32;
+}
+/// The host distributes the 128-byte id however it talks to its peers (MPI, a TCP store, a file): rank 0 draws it.
+pub struct GpuComm { raw: *mut NqeComm, pub rank: i32, pub world: i32 }
+impl GpuComm {
+    pub fn unique_id() -> Result<[u8; 128]> { let mut id = [0u8; 128]; if unsafe { nqe_comm_get_unique_id(id.as_mut_ptr()) } != 0 { return Err(ErrorCode::Others); } Ok(id) }
+    pub fn create(ctx: &GpuCtx, id: &[u8; 128], rank: i32, world: i32) -> Result<Self> {
+        let mut c = std::ptr::null_mut();
+        ctx.check(unsafe { nqe_comm_create(ctx.0, id.as_ptr(), rank, world, &mut c) })?;
+        Ok(Self { raw: c, rank, world })
+    }
+}
+impl Drop for GpuComm { fn drop(&mut self) { unsafe { nqe_comm_destroy(self.raw); } } }
+// GpuAggregatePlan / GpuHashJoin / GpuSelectionPlan take an Option<Arc<GpuComm>>: with one, `execute()` calls the sharded entry
+// point on this process's shard of the input (rows [rank*n/world, (rank+1)*n/world) of every table) and gets the WHOLE result
+// (aggregate; join / filter with gather = 1) or its own rows in rank order (gather = 0).
+
 // ------------------------------------------------------------------ the planner edit (planner/mod.rs:42-182)
 //
 //     LogicalPlan::Filter(filter) => {
@@ -297,7 +383,7 @@ impl PhysicalPlan for GpuHashJoin {
 //         match gpu::context() { Some(ctx) => Ok(GpuSelectionPlan::create(ctx, input, predicate)), None => Ok(SelectionPlan::create(input, predicate)) }
 //     }
 //
-// and likewise for Projection (:48-62, fusing with a GpuSelectionPlan child via create_fused), Join (:71-89) and
-// Aggregate (:95-170, passing a child filter's predicate as `filter`).  To keep intermediates in HBM between operators,
+// and likewise for Projection (:48-62), Join (:71-89) and Aggregate (:95-170) — or, leaving the planner alone, run `gpu::rewrite`
+// over the tree it returns (db.rs:34-36: between create_physical_plan and execute).  To keep intermediates in HBM between operators,
 // carry `GpuTable` handles in a `GpuBatch` next to `RecordBatch` instead of downloading after every operator — what
 // `naive_query_engine_amd/physical_plan.py` (`DeviceRecordBatch`) and `host/naive_db.hpp` do.

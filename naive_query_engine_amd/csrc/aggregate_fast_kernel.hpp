@@ -7,6 +7,9 @@
 #ifndef NQE_AGG_BATCH
 #define NQE_AGG_BATCH 1 // 0: the round-1 row loop (A/B runs)
 #endif
+#ifndef NQE_AGG_RUN_BUDGET
+#define NQE_AGG_RUN_BUDGET 32 // tile pairs between two looks at the keys while in the run loop
+#endif
 
 namespace nqe {
 namespace agg {
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 batch = __popcll(__ballot(mixed)) >= 16;
             }
             if (CAN_BATCH && batch) stream(process_batch, A, 32);
-            else stream(process_run, A, CAN_BATCH ? 32 : (1 << 30));
+            else stream(process_run, A, CAN_BATCH ? NQE_AGG_RUN_BUDGET : (1 << 30));
         }
     }
     if (run_live) flush_run();

@@ -1011,3 +1011,44 @@ def test_hash_join_sort_free_build_small_and_signed_keys(ctx, nb):
     probe = rng.integers(-3 * nb - 3, 3 * nb + 3, 5000).astype(np.int64)
     right = [Column.from_numpy(probe), Column.from_numpy(np.arange(5000, dtype=np.int64))]
     _join_both_ways(ctx, left, right)
+
+
+@pytest.mark.parametrize("heavy_frac", [0.5, 0.9])
+def test_aggregate_partitioned_path_with_a_heavy_key(ctx, heavy_frac):
+    """skewed keys on the partitioned path: one key holds most rows, so its hash partition outgrows the fixed-capacity slabs of the
+    count-free scatter (NQE_FLAG_SLAB_OVERFLOW) and the query is redone with exact partition sizes; the other 20000 keys keep the
+    query off the single-pass path.  Executed twice: the second run starts from the recorded plan hint."""
+    rng = np.random.default_rng(int(heavy_frac * 10))
+    n = 600_000
+    k = rng.integers(0, 20000, n).astype(np.int64)
+    k[rng.random(n) < heavy_frac] = 777
+    v = rng.random(n) * 100 - 50
+    cols = [Column.from_numpy(k), Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    t = ctx.table_from_host(cols)
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=col(0).flatten(f2))[0]
+    for _ in range(2):
+        got, gk = ctx.aggregate(t, ALL_AGGS(1), group_nodes=col(0).flatten(f2), with_keys=True)
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what="heavy-key partitioned aggregate")
+        assert (gk.to_host()[0].to_numpy() == np.unique(k)).all()
+
+
+def test_aggregate_plan_hint_is_per_query_shape(ctx):
+    """a query that had to be partitioned leaves a hint keyed by its whole shape; the same key column under a different predicate /
+    with nullable values must not inherit it blindly (it takes kernels that have no partitioned form)"""
+    rng = np.random.default_rng(3)
+    n = 500_000
+    k = rng.integers(0, 30000, n).astype(np.int64)
+    v = rng.random(n)
+    vn = Column.from_numpy(rng.random(n), rng.random(n) > 0.1)
+    b = Column.from_numpy(rng.random(n) < 0.5)
+    cols = [Column.from_numpy(k), Column.from_numpy(v), vn, b]
+    f4 = fields("k", "v", "vn", "b")
+    t = ctx.table_from_host(cols)
+    key = col(0).flatten(f4)
+    shapes = [(ALL_AGGS(1), None), (ALL_AGGS(1), None), (ALL_AGGS(2), None), (ALL_AGGS(1), col(3).flatten(f4)),
+              (ALL_AGGS(1), binop(col(1), Operator.Gt, lit_f64(0.25)).flatten(f4)), (ALL_AGGS(1) + ALL_AGGS(2), None), (ALL_AGGS(1), None)]
+    for aggs, pred in shapes:
+        exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=pred)[0]
+        got = ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred)
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{aggs} {pred is not None}")
