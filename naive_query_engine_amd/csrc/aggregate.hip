@@ -1102,8 +1102,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         TableBufs tb = make_table(ctx, tcap, V, !grouped, dense);
         // an un-grouped aggregate whose passes all took the fast kernel (no flag argument) under a predicate that cannot fault
         bool flagless = !grouped && !pred_may_fault;
-        for (int v0 = 0; v0 < std::max(V, 1); v0 += NV) {
-            a.nv = std::min(NV, V - v0);
+        // nullable sources: one value column per pass — the two-column VNULL variants of the fast kernel spill 60-135 VGPRs
+        // (3.1-3.4 TB/s); two passes of the one-column variant (5.3 TB/s each over key + one value column) are faster
+        const int nv_step = (any_val_nullable || a.key_src.valid || (a.pred_mode != 0 && a.pred_src.valid)) ? 1 : NV;
+        for (int v0 = 0; v0 < std::max(V, 1); v0 += nv_step) {
+            a.nv = std::min(nv_step, V - v0);
             if (a.nv < 0) a.nv = 0;
             a.v0 = v0;
             bool valid_words_ok = true; // validity bitmaps readable as whole 64-bit words (owned buffers are padded)

@@ -388,7 +388,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 
 template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64) {
     if (nv == 1) return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 1, false, VNULL>;
-    return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 2, false, VNULL>;
+    if constexpr (VNULL) {
+        return nullptr; // nullable sources take one value column per pass (aggregate.hip): the two-column variants spilled 60-135 VGPRs
+    } else {
+        return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 2, false, VNULL>;
+    }
 }
 template <int PRED, bool VNULL> FastKernel pick_fast_key(int key, int nv, bool vf64) {
     switch (key) {
