@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <cfloat>
 
+#include <cstdlib>
+
 #include "aggregate_common.hpp"
 
 namespace nqe {
@@ -1084,8 +1086,9 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             mix(&dc.dtype, sizeof(dc.dtype));
         }
         if (hint_key == 0) hint_key = 1;
+        static const bool no_hints = getenv("NQE_NO_PLAN_HINTS") != nullptr; // diagnostics (A/B runs)
         auto it = ctx->agg_hints.find(hint_key);
-        if (it != ctx->agg_hints.end() && it->second == 1) {
+        if (!no_hints && it != ctx->agg_hints.end() && it->second == 1) {
             partition_mode = true;
             cap = std::max(cap, sized_cap);
         }
@@ -1221,7 +1224,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
                         W = int((in->rows + chunk - 1) / chunk);
                         const int64_t mean = chunk / PARTS;
-                        const int64_t capt = (mean + mean / 4 + 64 + 15) / 16 * 16;
+                        // an ODD number of 256-byte units per slab: with a power-of-two slab stride (16 KB at 10^8 rows) the 512 write
+                        // streams of a workgroup — and those of every other workgroup — start on the same HBM channel and move in
+                        // step (the scatter took 0.78 or 0.97 ms depending on where the buffer happened to land)
+                        const int64_t capt = ((mean + mean / 4 + 64 + 15) / 16 | 1) * 16;
                         const size_t tw = size_t(1 + a.nv);
                         BufRef slabs = dev_alloc(ctx, size_t(PARTS) * size_t(W) * size_t(capt) * tw * 8 + 16);
                         BufRef fill = dev_alloc(ctx, size_t(PARTS) * size_t(W) * 4);

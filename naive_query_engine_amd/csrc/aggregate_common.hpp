@@ -262,7 +262,8 @@ struct PartArgs {
 // heavily skewed (then NQE_FLAG_SLAB_OVERFLOW sends the query to the exact count → scan → scatter form).  A tuple is
 // (key, value...) in ONE stream: a 16-tuple run of a tile is 256 contiguous bytes instead of 128 B in each of two arrays.
 struct SlabArgs {
-    uint64_t *slabs;   // [PARTS][W][cap] tuples of (1 + nv) words
+    uint64_t *slabs;   // [W][PARTS][cap] tuples of (1 + nv) words: a scatter workgroup's 512 slabs are one contiguous region (with
+                       // [PARTS][W] they lay 4 MB apart — 512 write streams over as many pages per workgroup)
     uint32_t *fill;    // [PARTS][W] tuples written
     int64_t chunk;     // rows per scatter workgroup (multiple of the scatter tile)
     int32_t W;         // scatter workgroups

@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
             const uint32_t p = uint32_t((k * GOLD) >> (64 - PARTS_LOG2));
             const uint32_t at = gcur[p] + (i - tstart[p]);
             if (at < cap) {
-                uint64_t *dst = sa.slabs + ((size_t(p) * size_t(sa.W) + blockIdx.x) * size_t(cap) + at) * TW;
+                uint64_t *dst = sa.slabs + ((size_t(blockIdx.x) * PARTS + p) * size_t(cap) + at) * TW;
                 if (TW == 2) {
                     *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(k, v0);
                 } else {
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
         // fill-count load and the first tuple load of every slab: 16 dependent round trips per wave per partition).
         const int nl = (sa.W - wave + nwaves - 1) / nwaves; // slabs of this wave (<= 64: W <= 1024)
         const uint32_t myfill = lane_id() < nl ? sa.fill[size_t(p) * size_t(sa.W) + size_t(wave + lane_id() * nwaves)] : 0u;
-        const uint64_t *__restrict__ pbase = sa.slabs + size_t(p) * size_t(sa.W) * size_t(sa.cap) * TW;
+        const uint64_t *__restrict__ pbase = sa.slabs + size_t(p) * size_t(sa.cap) * TW; // slab (w, p) = pbase + w * PARTS * cap tuples
         struct Step {
             uint64_t key[SU], vw[NVT][SU];
             bool live[SU];
@@ -606,7 +606,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
         };
         auto fetch = [&](Step &st, int l, uint32_t i0) {
             const uint32_t f = uint32_t(__builtin_amdgcn_readlane(int(myfill), l));
-            const uint64_t *__restrict__ slab = pbase + size_t(wave + l * nwaves) * size_t(sa.cap) * TW;
+            const uint64_t *__restrict__ slab = pbase + size_t(wave + l * nwaves) * size_t(PARTS) * size_t(sa.cap) * TW;
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
