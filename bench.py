@@ -447,6 +447,25 @@ def main():
         out["exchange"] = "nqe_sharded_* (C ABI) on RCCL, collectives on the context's stream"
     if par:
         out["parity_checked"], out["cpu_baseline"] = par
+    if B.comm is not None and args.workload == "headline" and not args.random_keys and args.pass_frac == 0.5:
+        # no oracle at this size: a size-independent check of the SHARDED result on every rank — ids are row numbers, so group g of
+        # `id % 1024` holds exactly the ids g, g + 1024, ... below total/2, and every value lies in [0, 100)
+        import numpy as np
+
+        from naive_query_engine_amd import Operator
+        from naive_query_engine_amd.expression import binop, col, lit_i64
+
+        pred = binop(col(0), Operator.Lt, lit_i64(st["total"] // 2)).flatten([F("id"), F("v")])
+        res, keys = B.comm.sharded_aggregate(st["table"], AGGS5, group_nodes=st["key"], pred_nodes=pred)
+        cols = [c.to_numpy() for c in res.to_host()]
+        kk = keys.to_host()[0].to_numpy()
+        half = st["total"] // 2
+        exp_cnt = np.array([(half - g + 1023) // 1024 if g < half else 0 for g in range(1024)], dtype=np.uint64)
+        ok = bool(len(kk) == 1024 and (kk == np.arange(1024)).all() and (cols[0] == exp_cnt).all() and (cols[3] >= 0).all() and (cols[4] < 100).all()
+                  and np.allclose(cols[2], cols[1] / cols[0].astype(np.float64), rtol=1e-12))
+        okt = B.torch.tensor([1 if ok else 0], dtype=B.torch.int64, device=B.dev)
+        B.dist.all_reduce(okt, op=B.dist.ReduceOp.MIN)
+        out["result_check"] = {"ok": bool(int(okt.item())), "what": "sharded headline on every rank: 1024 keys, analytic counts, avg = sum / count, min/max in [0, 100)"}
     del st
 
     # ---- every other config, in the same line
@@ -492,10 +511,21 @@ def main():
                          "probe_rows_per_s_all_gpus": 10**8 / (p["ms_per_step"] * 1e-3)}
         out["configs"] = cfg
 
+    # RCCL writes a version banner through C stdio, which (redirected) is flushed at process exit — after Python's own output.
+    # Everything buffered so far goes out on every rank first, so that rank 0's JSON line is the LAST line of the job's stdout.
+    import ctypes
+
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if B.distributed:
+        B.dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if par and not par[0]["ok"]:
         sys.stderr.write("bench.py: PARITY FAILURE against the oracle on the sample\n")
+        sys.exit(3)
+    if "result_check" in out and not out["result_check"]["ok"]:
+        sys.stderr.write("bench.py: the sharded result failed its analytic check\n")
         sys.exit(3)
     if "configs" in out and any(not c.get("parity_checked", {"ok": True})["ok"] for c in out["configs"].values()):
         sys.stderr.write("bench.py: PARITY FAILURE against the oracle in a side config\n")
