@@ -1052,3 +1052,25 @@ def test_aggregate_plan_hint_is_per_query_shape(ctx):
         exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=pred)[0]
         got = ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred)
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{aggs} {pred is not None}")
+
+
+@pytest.mark.parametrize("pred_kind", ["none", "key_range", "other_column", "chain"])
+def test_aggregate_partitioned_path_two_value_columns(ctx, pred_kind):
+    """the slab form with two value columns in one pass (24-byte tuples, 4 rows per thread per tile) under every predicate variant
+    of the scatter kernel; Int64 and Float64 values (`val as f64`)"""
+    rng = np.random.default_rng(len(pred_kind))
+    n, groups = 330_000, 45_000
+    k = rng.integers(-groups // 2, groups // 2, n).astype(np.int64)
+    v = rng.random(n) * 200 - 100
+    w = rng.integers(-1000, 1000, n).astype(np.int64)
+    cols = [Column.from_numpy(k), Column.from_numpy(v), Column.from_numpy(w)]
+    f3 = fields("k", "v", "w")
+    t = ctx.table_from_host(cols)
+    pred = {"none": None, "key_range": binop(col(0), Operator.GtEq, lit_i64(-groups // 4)), "other_column": binop(col(2), Operator.Lt, lit_i64(500)),
+            "chain": binop(binop(col(2), Operator.Modulos, lit_i64(7)), Operator.NotEq, lit_i64(3))}[pred_kind]
+    pn = pred.flatten(f3) if pred is not None else None
+    aggs = ALL_AGGS(1) + ALL_AGGS(2)
+    exp = orc.aggregate([cols], aggs, group_nodes=col(0).flatten(f3), pred_nodes=pn)[0]
+    for _ in range(2):  # second run: from the plan hint
+        got = ctx.aggregate(t, aggs, group_nodes=col(0).flatten(f3), pred_nodes=pn)
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0, 5], what=f"two value columns, predicate {pred_kind}")
