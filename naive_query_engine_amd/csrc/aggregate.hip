@@ -1058,6 +1058,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         cap = std::min(sized_cap, RANK_MAX_CAP);
     }
     bool partition_mode = false, level2 = false, dense_ok = true, slab_failed = false;
+    // Between one LDS table's worth of groups and the partitioned path: the fast kernel with two key subsets (see
+    // AggArgs::subsets_log2) — every row is read by two workgroups, each of which keeps its half of the keys.  Rows of the other
+    // half cost a wave as many issue slots as its own (lanes are masked, instructions are not skipped), so the kernel time doubles:
+    // per 10^8 rows 0.80-0.91 ms at 4096-6000 groups against 1.29 ms partitioned; with four subsets (1.5-1.7 ms) partitioning wins.
+    static const int subsets_max = getenv("NQE_AGG_SUBSETS_MAX") ? atoi(getenv("NQE_AGG_SUBSETS_MAX")) : 1; // log2; diagnostics
+    int subsets_log2 = 0;
     // plan hint (see nqe_ctx::agg_hints): FNV-1a over everything that decides which kernels the query takes — the key column's
     // buffer and expression, the predicate and its column, the value columns (buffers, validity, types) and the row count — so
     // that a hint is only ever applied to the very query shape that recorded it
@@ -1088,13 +1094,21 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         if (hint_key == 0) hint_key = 1;
         static const bool no_hints = getenv("NQE_NO_PLAN_HINTS") != nullptr; // diagnostics (A/B runs)
         auto it = ctx->agg_hints.find(hint_key);
-        if (!no_hints && it != ctx->agg_hints.end() && it->second == 1) {
-            partition_mode = true;
-            cap = std::max(cap, sized_cap);
+        if (!no_hints && it != ctx->agg_hints.end()) {
+            if (it->second == 1) {
+                partition_mode = true;
+                cap = std::max(cap, sized_cap);
+            } else if (it->second >= 2 && it->second - 1 <= subsets_max) {
+                subsets_log2 = it->second - 1;
+                cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
+            }
         }
     }
     bool any_val_nullable = false;
     for (int c : plan.val_cols) any_val_nullable = any_val_nullable || in->cols[size_t(c)].validity != nullptr;
+    // the two-subset instances exist for one value column and sources without validity bitmaps
+    const bool subsets_ok = V == 1 && !any_val_nullable && !a.key_src.valid && !(a.pred_mode != 0 && a.pred_src.valid);
+    if (!subsets_ok) subsets_log2 = 0;
     for (int attempt = 0;; ++attempt) {
         // The partitioned path (entered after the fast kernel asked for it) with a single pass over the value columns writes
         // its groups densely: at most one LDS table's worth per (sub-)partition, never more than the input rows.
@@ -1319,7 +1333,9 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         // ONE 1024-thread workgroup per CU: fewer concurrent streams read HBM faster (A/B on one box: headline
                         // 2.44 -> 2.39 ms, C3 2.56 -> 2.41 ms, random keys 3.63 -> 3.54 ms, 1 % nulls 0.81 -> 0.69 ms per 2e8 rows;
                         // tools/stream_bench.hip shows the same for a bare read kernel)
-                        const int fgrid = std::min(grid, ctx->num_cus);
+                        int fgrid = std::min(grid, ctx->num_cus);
+                        ka.subsets_log2 = subsets_log2;
+                        if (subsets_log2) fgrid = std::max(1, ctx->num_cus / (8 << subsets_log2)) * (8 << subsets_log2);
                         size_t fshmem = shmem;
                         if (a.nv == 1) { // the CU's LDS is this workgroup's alone: a 4096-slot table (147 KB) keeps up to ~3500 groups on this path
                             ka.lds_cap = 4096;
@@ -1338,8 +1354,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                                 ka.direct_bias = sgn ? int64_t(m) - 1 : 0;
                             }
                         }
-                        launch(ctx, "agg_grouped_fast", pick_fast_kernel(fp, fast_key, a.nv, vf64, vnull), dim3(fgrid), dim3(AGG_BLOCK), fshmem, ka,
-                               fpred, tb.g, ctx->d_flags);
+                        ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
+                        FastKernel fk = pick_fast_kernel(fp, fast_key, a.nv, vf64, vnull, subsets_log2 != 0);
+                        if (!fk) fail(NQE_ERR_NOT_SUPPORTED, "internal: no such variant of the streaming aggregate kernel");
+                        launch(ctx, "agg_grouped_fast", fk, dim3(fgrid), dim3(AGG_BLOCK), fshmem, ka, fpred, tb.g, ctx->d_flags);
                     }
                 } else {
                     // the general kernel's PLAIN variant reads predicate and values as bare 8-byte words: not for a Boolean
@@ -1400,6 +1418,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         else if (ranked.out) flags_read_mirrored(ctx, f);
         else flags_read(ctx, f);
         if (pre.keys) pre.G = int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT]));
+        if (getenv("NQE_DEBUG"))
+            fprintf(stderr, "[nqe] aggregate attempt %d: partition %d subsets_log2 %d cap %u flags need_partition %d slab_overflow %d level2 %d table_full %d dense_overflow %d\n",
+                    attempt, int(partition_mode), subsets_log2, cap, f[NQE_FLAG_NEED_PARTITION], f[NQE_FLAG_SLAB_OVERFLOW], f[NQE_FLAG_NEED_LEVEL2],
+                    f[NQE_FLAG_TABLE_FULL], f[NQE_FLAG_DENSE_OVERFLOW]);
         if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
         if (f[NQE_FLAG_SLAB_OVERFLOW] && partition_mode && !slab_failed) {
@@ -1414,12 +1436,19 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             continue;
         }
         if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode) {
-            partition_mode = true; // a workgroup table overflowed: redo with hash-partitioned rows
+            // a workgroup table overflowed: two key subsets, and beyond those hash-partitioned rows
+            if (subsets_ok && subsets_log2 < subsets_max) {
+                ++subsets_log2;
+                cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
+            } else {
+                subsets_log2 = 0;
+                partition_mode = true;
+                cap = std::max(cap, sized_cap);
+            }
             if (hint_key) {
                 if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
-                ctx->agg_hints[hint_key] = 1;
+                ctx->agg_hints[hint_key] = partition_mode ? 1 : 1 + subsets_log2;
             }
-            cap = std::max(cap, sized_cap);
             flags_reset(ctx);
             continue;
         }

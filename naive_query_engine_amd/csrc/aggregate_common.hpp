@@ -83,6 +83,10 @@ struct AggArgs {
     // no hash, no probe, no compare on the per-row path of inputs whose key changes every row
     int32_t direct;
     int64_t direct_bias;
+    // fast kernel, key subsets: 2^subsets_log2 workgroups share every row range and each keeps only the keys whose hash bits
+    // [subset_shift, subset_shift + subsets_log2) name it — 2^subsets_log2 LDS tables' worth of groups without partitioning the rows
+    int32_t subsets_log2;
+    int32_t subset_shift;
 };
 
 __device__ __forceinline__ int lds_find_or_insert(uint64_t *keys, uint64_t key, uint32_t cap, int shift) {
@@ -275,7 +279,8 @@ constexpr int SUB = 1 << SUB_LOG2;
 
 // kernel entry points of the other translation units
 using FastKernel = void (*)(AggArgs, FastPred, GroupTable, int *);
-FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull);
+// sub: the two-key-subset variant (AggArgs::subsets_log2 = 1), built for one value column without validity bitmaps — nullptr otherwise
+FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull, bool sub = false);
 using PartKernel = void (*)(AggArgs, FastPred, PartArgs);
 PartKernel pick_scatter_kernel(int pred, int key, int nv);
 PartKernel pick_part_kernel(int pred, int key, int nv, bool scatter);

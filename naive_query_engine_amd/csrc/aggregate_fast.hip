@@ -6,20 +6,20 @@ namespace nqe {
 namespace agg {
 
 #define NQE_FAST_DECL(p)                                   \
-    FastKernel pick_fast_p##p##_v0(int key, int nv, bool vf64); \
-    FastKernel pick_fast_p##p##_v1(int key, int nv, bool vf64);
+    FastKernel pick_fast_p##p##_v0(int key, int nv, bool vf64, bool sub); \
+    FastKernel pick_fast_p##p##_v1(int key, int nv, bool vf64, bool sub);
 NQE_FAST_DECL(0)
 NQE_FAST_DECL(1)
 NQE_FAST_DECL(2)
 NQE_FAST_DECL(3)
 #undef NQE_FAST_DECL
 
-FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull) {
+FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull, bool sub) {
     switch (pred) {
-    case 0: return vnull ? pick_fast_p0_v1(key, nv, vf64) : pick_fast_p0_v0(key, nv, vf64);
-    case 1: return vnull ? pick_fast_p1_v1(key, nv, vf64) : pick_fast_p1_v0(key, nv, vf64);
-    case 2: return vnull ? pick_fast_p2_v1(key, nv, vf64) : pick_fast_p2_v0(key, nv, vf64);
-    default: return vnull ? pick_fast_p3_v1(key, nv, vf64) : pick_fast_p3_v0(key, nv, vf64);
+    case 0: return vnull ? pick_fast_p0_v1(key, nv, vf64, sub) : pick_fast_p0_v0(key, nv, vf64, sub);
+    case 1: return vnull ? pick_fast_p1_v1(key, nv, vf64, sub) : pick_fast_p1_v0(key, nv, vf64, sub);
+    case 2: return vnull ? pick_fast_p2_v1(key, nv, vf64, sub) : pick_fast_p2_v0(key, nv, vf64, sub);
+    default: return vnull ? pick_fast_p3_v1(key, nv, vf64, sub) : pick_fast_p3_v0(key, nv, vf64, sub);
     }
 }
 

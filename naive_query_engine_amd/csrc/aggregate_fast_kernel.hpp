@@ -30,7 +30,7 @@ namespace {
 //     computes.
 // PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column, 3 a fault-free integer chain
 // `col op lit … cmp lit` over any column, interpreted operator-major like the KEY = 3 keys.
-template <int PRED, int KEY, int NVT, bool VF64, bool VNULL>
+template <int PRED, int KEY, int NVT, bool VF64, bool VNULL, bool SUB = false>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
@@ -65,7 +65,28 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     for (int j = 0; j < NVT; ++j) {
         rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
     }
+    // key subsets (AggArgs::subsets_log2): the workgroups of one XCD that share a row range are neighbours in time, so the second
+    // to 2^k-th reader of a tile is served by that XCD's L2 / the Infinity Cache
+    // SUB: a separate set of instances — the test inside the one-subset kernels cost the 1000-3000-group cases 4-10 %
+    const uint32_t sub_log2 = SUB ? uint32_t(a.subsets_log2) : 0u;
+    const uint32_t sub_mask = (1u << sub_log2) - 1u;
+    const uint32_t my_subset = (blockIdx.x >> 3) & sub_mask;
+    const uint32_t lane_id = SUB ? ((blockIdx.x & 7u) | ((blockIdx.x >> (3 + sub_log2)) << 3)) : blockIdx.x;
+    const uint32_t lanes = gridDim.x >> sub_log2;
+    // subset of a key: two bits of the slot hash's product below the slot bits, XORed (one bit alone — a rotation sequence for keys
+    // in arithmetic progression, like the slot bits — left each half of `5r - 77` clustered: probe sequences of 69 slots at load 0.6)
+    auto foreign = [&](uint64_t key) {
+        const uint64_t h = key * GOLD;
+        return ((uint32_t(h >> a.subset_shift) ^ uint32_t(h >> 23)) & sub_mask) != my_subset;
+    };
     auto flush_run = [&]() {
+        if (SUB && foreign(run_key)) { // another workgroup's key: drop the run
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+                rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
+            }
+            return;
+        }
         // The hit path must stay minimal: random-key inputs flush once per row (guarding the lookup with a "table is full"
         // test cost them 14 %).  A rejected key is the cold path: it raises the workgroup flag (the tile loop then leaves
         // early and the host redoes the query partitioned) or, for small inputs, goes to the global table.
@@ -163,8 +184,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         int64_t gslot[AGG_U];
         uint64_t k0[AGG_U];
         if (!a.direct) {
+            // first probe of every row, issued together.  (Advancing all four probe sequences in lockstep, one slot of every
+            // unresolved row per round, was slower: 0.34 -> 0.38 ms per 10^8 rows at 1000 groups, 0.43 -> 0.46 at 3000 — the
+            // kernel is bound by instruction issue, not by the probes' latency.)
 #pragma unroll
-            for (int u = 0; u < AGG_U; ++u) k0[u] = lkeys[uint32_t((key[u] * GOLD) >> a.lds_shift)]; // first probe of every row, issued together
+            for (int u = 0; u < AGG_U; ++u) k0[u] = lkeys[uint32_t((key[u] * GOLD) >> a.lds_shift)];
         }
 #pragma unroll
         for (int u = 0; u < AGG_U; ++u) {
@@ -303,6 +327,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         bool mixed = false; // keys of rows that fail the predicate take part: a false "mixed" costs nothing but the batch path
 #pragma unroll
         for (int u = 1; u < AGG_U; ++u) mixed = mixed || key[u] != key[0];
+        if (SUB) {
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) pass[u] = pass[u] && !foreign(key[u]);
+        }
         if (mixed) {
             if (run_live) {
                 flush_run();
@@ -317,8 +345,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     };
 
     const int64_t step = int64_t(AGG_BLOCK) * AGG_U;
-    const int64_t stride = int64_t(gridDim.x) * step;
-    int64_t base = int64_t(blockIdx.x) * step;
+    const int64_t stride = int64_t(lanes) * step;
+    int64_t base = int64_t(lane_id) * step;
     // up to 2 x `budget` tiles.  In: A holds tile `base` (< n).  Out: base >= n (done or abandoned), or A holds tile `base`.
     auto stream = [&](auto &&process, Tile &A, int budget) {
         Tile B;
@@ -386,7 +414,14 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     }
 }
 
-template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64) {
+template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64, bool sub) {
+    if (sub) {
+        if constexpr (VNULL) return nullptr;
+        else {
+            if (nv != 1) return nullptr;
+            return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, false, true> : agg_grouped_fast_kernel<PRED, KEY, 1, false, false, true>;
+        }
+    }
     if (nv == 1) return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 1, false, VNULL>;
     if constexpr (VNULL) {
         return nullptr; // nullable sources take one value column per pass (aggregate.hip): the two-column variants spilled 60-135 VGPRs
@@ -394,12 +429,12 @@ template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf
         return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 2, false, VNULL>;
     }
 }
-template <int PRED, bool VNULL> FastKernel pick_fast_key(int key, int nv, bool vf64) {
+template <int PRED, bool VNULL> FastKernel pick_fast_key(int key, int nv, bool vf64, bool sub) {
     switch (key) {
-    case 0: return pick_fast_nv<PRED, 0, VNULL>(nv, vf64);
-    case 1: return pick_fast_nv<PRED, 1, VNULL>(nv, vf64);
-    case 2: return pick_fast_nv<PRED, 2, VNULL>(nv, vf64);
-    default: return pick_fast_nv<PRED, 3, VNULL>(nv, vf64);
+    case 0: return pick_fast_nv<PRED, 0, VNULL>(nv, vf64, sub);
+    case 1: return pick_fast_nv<PRED, 1, VNULL>(nv, vf64, sub);
+    case 2: return pick_fast_nv<PRED, 2, VNULL>(nv, vf64, sub);
+    default: return pick_fast_nv<PRED, 3, VNULL>(nv, vf64, sub);
     }
 }
 

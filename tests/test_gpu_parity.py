@@ -896,9 +896,10 @@ def test_hash_join_on_utf8_keys(ctx, unique):
     assert e.value.status in (Status.NotImplemented, Status.NotSupported)
 
 
-@pytest.mark.parametrize("groups", [3000, 60000, 400000])
+@pytest.mark.parametrize("groups", [3000, 5000, 6500, 60000, 400000])
 def test_aggregate_partitioned_path_many_groups(ctx, groups):
-    """more distinct keys than a workgroup table holds (and >= 2^18 rows): hash-partitioned aggregation"""
+    """more distinct keys than a workgroup table holds (and >= 2^18 rows): two key subsets (5000, 6500: each row range read by
+    two workgroups that keep half of the keys each), then hash-partitioned aggregation"""
     rng = np.random.default_rng(groups)
     n = 600_000
     k = (rng.integers(0, groups, n).astype(np.int64) - groups // 2) * 7      # negative keys, common factor
@@ -917,6 +918,26 @@ def test_aggregate_partitioned_path_many_groups(ctx, groups):
                 got = ctx.aggregate(t, aggs, group_nodes=key.flatten(f3), pred_nodes=pn).to_host()
                 counts = [i for i, (fn, _) in enumerate(aggs) if fn == AggregateFunc.Count]
                 assert_rows_multiset_equal(got, exp, RTOL, exact_cols=counts, what=f"partitioned groups={groups} key={key!r}")
+
+
+def test_aggregate_key_subset_tier_is_taken_between_one_table_and_partitioning(ctx):
+    """5000 groups: the second attempt runs the streaming kernel with two key subsets, not the partition kernels; 20000: partitioned"""
+    rng = np.random.default_rng(11)
+    n = 700_000
+    f2 = fields("k", "v")
+    v = rng.random(n)
+    for groups, want_partition in ((5000, False), (20000, True)):
+        k = rng.integers(0, groups, n).astype(np.int64) * 5 - 77
+        cols = [Column.from_numpy(k), Column.from_numpy(v)]
+        t = ctx.table_from_host(cols)
+        exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=col(0).flatten(f2))[0]
+        for _ in range(2):  # the second run starts from the plan hint
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            got = ctx.aggregate(t, ALL_AGGS(1), group_nodes=col(0).flatten(f2)).to_host()
+            ctx.timing_enable(False)
+            assert (ctx.timing_query("agg_partition_scatter")[1] > 0) == want_partition, f"groups={groups}"
+            assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"key subsets, groups={groups}")
 
 
 def test_aggregate_two_level_partitioning_millions_of_groups(ctx):
