@@ -938,6 +938,16 @@ def test_aggregate_key_subset_tier_is_taken_between_one_table_and_partitioning(c
             ctx.timing_enable(False)
             assert (ctx.timing_query("agg_partition_scatter")[1] > 0) == want_partition, f"groups={groups}"
             assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"key subsets, groups={groups}")
+        # Int64 values under an interpreted chain predicate, key `k % m` by magic multiply: the other instances of the tier
+        w = rng.integers(-1000, 1000, n).astype(np.int64)
+        cols3 = [Column.from_numpy(k), Column.from_numpy(v), Column.from_numpy(w)]
+        f3 = fields("k", "v", "w")
+        t3 = ctx.table_from_host(cols3)
+        pred = binop(binop(binop(col(2), Operator.Plus, lit_i64(7)), Operator.Modulos, lit_i64(10)), Operator.Lt, lit_i64(6)).flatten(f3)
+        key = binop(col(0), Operator.Modulos, lit_i64(1_000_003)).flatten(f3)
+        exp = orc.aggregate([cols3], ALL_AGGS(2), group_nodes=key, pred_nodes=pred)[0]
+        got = ctx.aggregate(t3, ALL_AGGS(2), group_nodes=key, pred_nodes=pred).to_host()
+        assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"key subsets (chain predicate, Int64 values), groups={groups}")
 
 
 def test_aggregate_two_level_partitioning_millions_of_groups(ctx):
