@@ -37,8 +37,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     const uint32_t slots = cap + 1;
     uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
     double *lsum = reinterpret_cast<double *>(lkeys + slots);            // [NVT][slots]
-    uint64_t *lmn = reinterpret_cast<uint64_t *>(lsum + NVT * slots);    // [NVT][slots]
-    uint64_t *lmx = lmn + NVT * slots;                                   // [NVT][slots]
+    // min / max live in LDS as plain doubles (ds_min_f64 / ds_max_f64; a NaN never reaches them: every update is guarded by an
+    // ordered compare, which a NaN fails) and take the order-preserving integer form only for the global table at the merge
+    double *lmn = lsum + NVT * slots;                                    // [NVT][slots]
+    double *lmx = lmn + NVT * slots;                                     // [NVT][slots]
     uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + NVT * slots);    // [NVT][slots]
     const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
     __shared__ int lds_full_flag;
@@ -49,8 +51,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
             lsum[j * slots + s] = 0.0;
-            lmn[j * slots + s] = ORD_MAX;
-            lmx[j * slots + s] = ORD_MIN;
+            lmn[j * slots + s] = DBL_MAX;
+            lmx[j * slots + s] = -DBL_MAX;
             lcnt[j * slots + s] = 0;
         }
     }
@@ -108,7 +110,6 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         }
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
-            const uint64_t omn = f64_to_ord(rmn[j]), omx = f64_to_ord(rmx[j]);
             if (slot >= 0) {
                 uint32_t o = uint32_t(j) * slots + uint32_t(slot);
                 if (rcnt[j]) {
@@ -117,10 +118,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 }
                 if (rnan[j]) atomicOr(&lcnt[o], NAN_BIT);
                 // read-before-atomic (see the general kernel)
-                if (omn < lmn[o]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)omn);
-                if (omx > lmx[o]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)omx);
+                if (rmn[j] < lmn[o]) unsafeAtomicMin(&lmn[o], rmn[j]);
+                if (rmx[j] > lmx[o]) unsafeAtomicMax(&lmx[o], rmx[j]);
             } else if (gslot >= 0) {
-                global_update(g, gslot, a.v0 + j, rcnt[j], rsum[j], true, omn, omx, true, rnan[j]);
+                global_update(g, gslot, a.v0 + j, rcnt[j], rsum[j], true, f64_to_ord(rmn[j]), f64_to_ord(rmx[j]), true, rnan[j]);
             }
             rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
         }
@@ -181,7 +182,6 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // goes to the table directly, all its rows at once: AGG_U slots, one batch of min/max reads, one wait, then the atomics.
     auto direct_rows = [&](const Tile &t, int64_t base, const bool (&pass)[AGG_U], const uint64_t (&key)[AGG_U]) {
         int slot[AGG_U];
-        int64_t gslot[AGG_U];
         uint64_t k0[AGG_U];
         if (!a.direct) {
             // first probe of every row, issued together.  (Advancing all four probe sequences in lockstep, one slot of every
@@ -190,10 +190,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 #pragma unroll
             for (int u = 0; u < AGG_U; ++u) k0[u] = lkeys[uint32_t((key[u] * GOLD) >> a.lds_shift)];
         }
+        bool cold = false;
 #pragma unroll
         for (int u = 0; u < AGG_U; ++u) {
             slot[u] = -1;
-            gslot[u] = -1;
             if (!pass[u]) continue;
             if (a.direct) {
                 slot[u] = int(int64_t(key[u]) + a.direct_bias);
@@ -203,15 +203,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             } else {
                 slot[u] = lds_find_or_insert(lkeys, key[u], cap, a.lds_shift);
             }
-            if (slot[u] < 0) { // cold: the table rejected the key (see flush_run)
-                if (!*lds_full) {
-                    *lds_full = 1;
-                    if (a.allow_partition) atomicOr(&flags[NQE_FLAG_NEED_PARTITION], 1);
-                }
-                gslot[u] = a.allow_partition ? -1 : global_find_or_insert(g, key[u], flags);
-            }
+            cold = cold || slot[u] < 0;
         }
-        uint64_t cmn[NVT][AGG_U], cmx[NVT][AGG_U];
+        double cmn[NVT][AGG_U], cmx[NVT][AGG_U];
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
 #pragma unroll
@@ -221,28 +215,44 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 cmx[j][u] = lmx[o];
             }
         }
+        // the per-row path: one branch (the row takes part), the updates themselves predicated by ordered compares — a NaN fails
+        // both and only raises the group's flag
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
 #pragma unroll
             for (int u = 0; u < AGG_U; ++u) {
-                if (!pass[u]) continue;
+                if (slot[u] < 0) continue;
                 const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
                 const double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
                 const bool vb = VNULL ? bool((t.vv[VNULL ? j : 0][u] >> (row & 63)) & 1ull) : true;
                 if (!vb) continue; // a NULL value contributes nothing; its row has created the group above
-                const bool isn = x != x;
-                const uint64_t xo = f64_to_ord(x);
-                if (slot[u] >= 0) {
-                    const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
-                    atomicAdd(&lcnt[o], 1u);
-                    unsafeAtomicAdd(&lsum[o], x);
-                    if (isn) atomicOr(&lcnt[o], NAN_BIT);
-                    else {
-                        if (xo < cmn[j][u]) atomicMin((unsigned long long *)&lmn[o], (unsigned long long)xo);
-                        if (xo > cmx[j][u]) atomicMax((unsigned long long *)&lmx[o], (unsigned long long)xo);
-                    }
-                } else if (gslot[u] >= 0) {
-                    global_update(g, gslot[u], a.v0 + j, 1, x, true, isn ? ORD_MAX : xo, isn ? ORD_MIN : xo, true, isn);
+                const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
+                atomicAdd(&lcnt[o], 1u);
+                unsafeAtomicAdd(&lsum[o], x);
+                if (x < cmn[j][u]) unsafeAtomicMin(&lmn[o], x);
+                if (x > cmx[j][u]) unsafeAtomicMax(&lmx[o], x);
+                if (x != x) atomicOr(&lcnt[o], NAN_BIT);
+            }
+        }
+        if (cold) { // the table rejected a key (see flush_run): off the per-row path
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) {
+                if (!pass[u] || slot[u] >= 0) continue;
+                if (!*lds_full) {
+                    *lds_full = 1;
+                    if (a.allow_partition) atomicOr(&flags[NQE_FLAG_NEED_PARTITION], 1);
+                }
+                const int64_t gslot = a.allow_partition ? -1 : global_find_or_insert(g, key[u], flags);
+                if (gslot < 0) continue;
+                const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) {
+                    const double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+                    const bool vb = VNULL ? bool((t.vv[VNULL ? j : 0][u] >> (row & 63)) & 1ull) : true;
+                    if (!vb) continue;
+                    const bool isn = x != x;
+                    const uint64_t xo = f64_to_ord(x);
+                    global_update(g, gslot, a.v0 + j, 1, x, true, isn ? ORD_MAX : xo, isn ? ORD_MIN : xo, true, isn);
                 }
             }
         }
@@ -409,7 +419,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         for (int j = 0; j < NVT; ++j) {
             uint32_t o = uint32_t(j) * slots + s;
             uint32_t c = lcnt[o];
-            global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
+            global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, f64_to_ord(lmn[o]), f64_to_ord(lmx[o]), true, (c & NAN_BIT) != 0);
         }
     }
 }
