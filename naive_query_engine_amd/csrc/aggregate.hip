@@ -1064,6 +1064,9 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     // per 10^8 rows 0.80-0.91 ms at 4096-6000 groups against 1.29 ms partitioned; with four subsets (1.5-1.7 ms) partitioning wins.
     static const int subsets_max = getenv("NQE_AGG_SUBSETS_MAX") ? atoi(getenv("NQE_AGG_SUBSETS_MAX")) : 1; // log2; diagnostics
     int subsets_log2 = 0;
+    // slab form of the partitioned path: 256 partitions first, PARTS when one of them holds more distinct keys than a workgroup table
+    static const int slab_parts_first = getenv("NQE_SLAB_PARTS_LOG2") ? atoi(getenv("NQE_SLAB_PARTS_LOG2")) : 8; // diagnostics
+    int slab_parts_log2 = std::min(std::max(slab_parts_first, 6), PARTS_LOG2);
     // plan hint (see nqe_ctx::agg_hints): FNV-1a over everything that decides which kernels the query takes — the key column's
     // buffer and expression, the predicate and its column, the value columns (buffers, validity, types) and the row count — so
     // that a hint is only ever applied to the very query shape that recorded it
@@ -1095,8 +1098,9 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         static const bool no_hints = getenv("NQE_NO_PLAN_HINTS") != nullptr; // diagnostics (A/B runs)
         auto it = ctx->agg_hints.find(hint_key);
         if (!no_hints && it != ctx->agg_hints.end()) {
-            if (it->second == 1) {
+            if (it->second == 1 || it->second == 16) { // 1: PARTS partitions, 16: the smaller first count was enough
                 partition_mode = true;
+                if (it->second == 1) slab_parts_log2 = PARTS_LOG2;
                 cap = std::max(cap, sized_cap);
             } else if (it->second >= 2 && it->second - 1 <= subsets_max) {
                 subsets_log2 = it->second - 1;
@@ -1237,20 +1241,22 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         int W = int(std::min<int64_t>(ctx->num_cus, (in->rows + tile_rows - 1) / tile_rows));
                         int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
                         W = int((in->rows + chunk - 1) / chunk);
-                        const int64_t mean = chunk / PARTS;
+                        const int sparts = 1 << slab_parts_log2;
+                        const int64_t mean = chunk / sparts;
                         // an ODD number of 256-byte units per slab: with a power-of-two slab stride (16 KB at 10^8 rows) the 512 write
                         // streams of a workgroup — and those of every other workgroup — start on the same HBM channel and move in
                         // step (the scatter took 0.78 or 0.97 ms depending on where the buffer happened to land)
                         const int64_t capt = ((mean + mean / 4 + 64 + 15) / 16 | 1) * 16;
                         const size_t tw = size_t(1 + a.nv);
-                        BufRef slabs = dev_alloc(ctx, size_t(PARTS) * size_t(W) * size_t(capt) * tw * 8 + 16);
-                        BufRef fill = dev_alloc(ctx, size_t(PARTS) * size_t(W) * 4);
+                        BufRef slabs = dev_alloc(ctx, size_t(sparts) * size_t(W) * size_t(capt) * tw * 8 + 16);
+                        BufRef fill = dev_alloc(ctx, size_t(sparts) * size_t(W) * 4);
                         SlabArgs sl;
                         sl.slabs = (uint64_t *)slabs->ptr;
                         sl.fill = (uint32_t *)fill->ptr;
                         sl.chunk = chunk;
                         sl.W = W;
                         sl.cap = int32_t(capt);
+                        sl.parts_log2 = slab_parts_log2;
                         const size_t sc_shmem = size_t(tile_rows) * 8 * tw + size_t(PARTS) * 12;
                         launch(ctx, "agg_partition_scatter", pick_slab_scatter_kernel(fp, fast_key, a.nv), dim3(W), dim3(AGG_BLOCK), sc_shmem, ka, fpred, sl,
                                ctx->d_flags);
@@ -1263,7 +1269,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             sshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
                             sblocks = 1;
                         }
-                        launch(ctx, "agg_segments", pick_slab_segments_kernel(a.nv, vf64), dim3(std::min(PARTS, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem,
+                        launch(ctx, "agg_segments", pick_slab_segments_kernel(a.nv, vf64), dim3(std::min(sparts, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem,
                                sa, sl, tb.g, ctx->d_flags);
                         sync(ctx); // the slabs are released at the end of this scope
                     } else if (partition_mode) {
@@ -1429,6 +1435,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             flags_reset(ctx);
             continue;
         }
+        if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2 && !slab_failed && slab_parts_log2 < PARTS_LOG2) {
+            slab_parts_log2 = PARTS_LOG2; // a partition outgrew a workgroup table: the full partition count, still in slab form
+            if (hint_key) ctx->agg_hints[hint_key] = 1;
+            flags_reset(ctx);
+            continue;
+        }
         if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2) {
             level2 = true; // partitions hold more distinct keys than a workgroup table: one more partitioning level
             cap = std::max<uint32_t>(cap, 1u << 24);
@@ -1447,7 +1459,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             }
             if (hint_key) {
                 if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
-                ctx->agg_hints[hint_key] = partition_mode ? 1 : 1 + subsets_log2;
+                ctx->agg_hints[hint_key] = partition_mode ? (slab_parts_log2 < PARTS_LOG2 ? 16 : 1) : 1 + subsets_log2;
             }
             flags_reset(ctx);
             continue;

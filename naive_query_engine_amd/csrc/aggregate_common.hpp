@@ -272,6 +272,9 @@ struct SlabArgs {
     int64_t chunk;     // rows per scatter workgroup (multiple of the scatter tile)
     int32_t W;         // scatter workgroups
     int32_t cap;       // tuples per slab
+    int32_t parts_log2; // partitions of this run: 8 (twice the run length per partition and tile: the scatter's stores are what bound
+                        // it — 0.72-0.82 ms per 10^8 rows against 0.88-0.93 with 512, while 128 leave the second kernel half the
+                        // chip) until a partition holds more distinct keys than a workgroup table, then PARTS_LOG2
 };
 
 constexpr int SUB_LOG2 = 6;

@@ -427,6 +427,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
     uint32_t *tcnt = gcur + PARTS;                                          // [PARTS] tuples of this tile per partition
     uint32_t *tstart = tcnt + PARTS;                                        // [PARTS] tile-local exclusive scan
     __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
+    const int parts_log2 = sa.parts_log2, parts = 1 << parts_log2; // <= PARTS (the LDS counters are sized for PARTS)
     for (int p = threadIdx.x; p < PARTS; p += blockDim.x) {
         gcur[p] = 0;
         tcnt[p] = 0;
@@ -472,17 +473,17 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
             else if (PRED == 1) ok = ok && range_pass(fp, r.kw[u]);
             key[u] = inline_key<KEY>(a.key, r.kw[u], key_mask, key_aux, key_signed);
             pass[u] = ok;
-            part[u] = uint32_t((key[u] * GOLD) >> (64 - PARTS_LOG2));
+            part[u] = uint32_t((key[u] * GOLD) >> (64 - parts_log2));
         }
 #pragma unroll
         for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
         __syncthreads();
         // tile-local exclusive scan of the PARTS counters (threads 0..PARTS-1)
-        uint32_t c = threadIdx.x < PARTS ? tcnt[threadIdx.x] : 0u, wt;
+        uint32_t c = int(threadIdx.x) < parts ? tcnt[threadIdx.x] : 0u, wt;
         uint32_t ex = wave_exclusive_scan(c, wt);
         if (lane_id() == 63) wave_tot[threadIdx.x / 64] = wt;
         __syncthreads();
-        if (threadIdx.x < PARTS) {
+        if (int(threadIdx.x) < parts) {
             uint32_t pre = 0;
             for (int w = 0; w < int(threadIdx.x) / 64; ++w) pre += wave_tot[w];
             tstart[threadIdx.x] = pre + ex;
@@ -515,10 +516,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
                 v0 = stup[size_t(i) * TW + 1];
                 if (NVT > 1) v1 = stup[size_t(i) * TW + 2];
             }
-            const uint32_t p = uint32_t((k * GOLD) >> (64 - PARTS_LOG2));
+            const uint32_t p = uint32_t((k * GOLD) >> (64 - parts_log2));
             const uint32_t at = gcur[p] + (i - tstart[p]);
             if (at < cap) {
-                uint64_t *dst = sa.slabs + ((size_t(blockIdx.x) * PARTS + p) * size_t(cap) + at) * TW;
+                uint64_t *dst = sa.slabs + ((size_t(blockIdx.x) * size_t(parts) + p) * size_t(cap) + at) * TW;
                 if (TW == 2) {
                     *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(k, v0);
                 } else {
@@ -531,7 +532,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
             }
         }
         __syncthreads();
-        if (threadIdx.x < PARTS) {
+        if (int(threadIdx.x) < parts) {
             gcur[threadIdx.x] += tcnt[threadIdx.x];
             tcnt[threadIdx.x] = 0;
         }
@@ -546,7 +547,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
             tile(B, A, base + SC_ROWS);
         }
     }
-    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) sa.fill[size_t(p) * size_t(sa.W) + blockIdx.x] = gcur[p] < cap ? gcur[p] : cap;
+    for (int p = threadIdx.x; p < parts; p += blockDim.x) sa.fill[size_t(p) * size_t(sa.W) + blockIdx.x] = gcur[p] < cap ? gcur[p] : cap;
 }
 
 // one workgroup per partition (grid-stride); its waves take the partition's slabs round-robin and stream their tuples, four
@@ -571,7 +572,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
     __shared__ int seg_full_flag;
     volatile int *seg_full = &seg_full_flag;
     const int wave = int(threadIdx.x) / 64, nwaves = AGG_BLOCK / 64;
-    for (int p = blockIdx.x; p < PARTS; p += gridDim.x) {
+    const int parts_log2 = sa.parts_log2, parts = 1 << parts_log2;
+    for (int p = blockIdx.x; p < parts; p += gridDim.x) {
         __syncthreads();
         if (__hip_atomic_load(&flags[NQE_FLAG_NEED_LEVEL2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         if (threadIdx.x == 0) seg_full_flag = 0;
@@ -606,7 +608,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
         };
         auto fetch = [&](Step &st, int l, uint32_t i0) {
             const uint32_t f = uint32_t(__builtin_amdgcn_readlane(int(myfill), l));
-            const uint64_t *__restrict__ slab = pbase + size_t(wave + l * nwaves) * size_t(PARTS) * size_t(sa.cap) * TW;
+            const uint64_t *__restrict__ slab = pbase + size_t(wave + l * nwaves) * size_t(parts) * size_t(sa.cap) * TW;
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
@@ -630,7 +632,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
             uint64_t k0[SU];
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
-                s0[u] = uint32_t(((st.key[u] * GOLD) << PARTS_LOG2) >> a.lds_shift);
+                s0[u] = uint32_t(((st.key[u] * GOLD) << parts_log2) >> a.lds_shift);
                 k0[u] = lkeys[s0[u]];
             }
             int slot[SU];
