@@ -45,8 +45,14 @@ def rows_sorted(cols):
     m = np.stack([c.to_numpy().astype(np.float64) for c in cols], axis=1) if cols else np.zeros((0, 0))
     if m.size == 0:
         return m
-    key = np.where(np.isnan(m), np.inf, m)
-    return m[np.lexsort(key.T[::-1])]
+    # NaN sorts behind +inf (a tie between the two would leave such rows in input order: found by a group whose max is NaN next
+    # to one whose max is +inf, everything else equal)
+    nan = np.isnan(m)
+    val = np.where(nan, np.inf, m)
+    keys = []
+    for c in range(m.shape[1]):
+        keys += [val[:, c], nan[:, c].astype(np.float64)]
+    return m[np.lexsort(keys[::-1])]
 
 
 def assert_rows_multiset_equal(got_cols, exp_cols, rtol=1e-9, exact_cols=(), what=""):

@@ -920,6 +920,29 @@ def test_aggregate_partitioned_path_many_groups(ctx, groups):
                 assert_rows_multiset_equal(got, exp, RTOL, exact_cols=counts, what=f"partitioned groups={groups} key={key!r}")
 
 
+@pytest.mark.parametrize("groups", [7, 1000, 3000])
+def test_aggregate_special_float_values_under_random_keys(ctx, groups):
+    """NaN, +-inf, +-0, subnormals as VALUES where every row's key differs from its neighbour's (the kernel's batch loop
+    keeps min/max in LDS as doubles behind ordered compares): NaN is ignored by min and makes max NaN (OrderedFloat, max.rs:38-50),
+    a group of nothing but +inf keeps the f64::MAX start of min (min.rs), counts are exact"""
+    rng = np.random.default_rng(groups)
+    n = 300_000
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 5e-324, -5e-324, 1.0, -1.0])  # (no +-DBL_MAX: their sum depends on the order)
+    v = rng.random(n) * 200 - 100
+    where = rng.random(n) < 0.02
+    v[where] = special[rng.integers(0, len(special), int(where.sum()))]
+    k = rng.integers(0, groups, n).astype(np.int64) * 3 - groups
+    v[k == k.min()] = np.inf          # one group of +inf only
+    v[k == k.max()] = np.nan          # one group of NaN only
+    cols = [Column.from_numpy(k), Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    t = ctx.table_from_host(cols)
+    for key in (col(0), binop(col(0), Operator.Modulos, lit_i64(512))):
+        exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=key.flatten(f2))[0]
+        got = ctx.aggregate(t, ALL_AGGS(1), group_nodes=key.flatten(f2)).to_host()
+        assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"special values, groups={groups}, key={key!r}")
+
+
 def test_aggregate_key_subset_tier_is_taken_between_one_table_and_partitioning(ctx):
     """5000 groups: the second attempt runs the streaming kernel with two key subsets, not the partition kernels; 20000: partitioned"""
     rng = np.random.default_rng(11)
