@@ -1219,11 +1219,17 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     a.pred.op[a.pred.nops - 1] <= NQE_OP_GT_EQ) {
                     chain_pred = true;
                     for (int k = 0; k < a.pred.nops; ++k) {
-                        const int op = a.pred.op[k];
-                        chain_pred = chain_pred && op <= NQE_OP_MODULOS && (a.pred.op_dtype[k] == NQE_INT64 || a.pred.op_dtype[k] == NQE_UINT64);
+                        const int op = a.pred.op[k], dt = a.pred.op_dtype[k];
+                        chain_pred = chain_pred && op <= NQE_OP_MODULOS && (dt == NQE_INT64 || dt == NQE_UINT64 || (dt == NQE_FLOAT64 && op != NQE_OP_MODULOS));
                         if (op <= NQE_OP_GT_EQ && k != a.pred.nops - 1) chain_pred = false; // a comparison feeds nothing but the result
-                        if (op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS)
-                            chain_pred = chain_pred && !a.pred.lit_left[k] && a.pred.lit[k] != 0 && a.pred.lit[k] != ~0ull;
+                        if (op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS) {
+                            if (dt == NQE_FLOAT64) { // x / lit, lit != +-0 (a zero divisor is arrow's DivideByZero)
+                                double dl;
+                                std::memcpy(&dl, &a.pred.lit[k], 8);
+                                chain_pred = chain_pred && !a.pred.lit_left[k] && dl != 0.0;
+                            } else
+                                chain_pred = chain_pred && !a.pred.lit_left[k] && a.pred.lit[k] != 0 && a.pred.lit[k] != ~0ull;
+                        }
                     }
                 }
                 bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || bitmap_pred || range_pred || chain_pred);

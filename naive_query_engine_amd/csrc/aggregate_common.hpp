@@ -190,6 +190,26 @@ __device__ __forceinline__ void inline_keys(const SimpleExpr &ke, const uint64_t
         const int op = ke.op[k];
         const bool ll = ke.lit_left[k] != 0;
         const uint64_t lit = ke.lit[k];
+        if (ke.op_dtype[k] == NQE_FLOAT64) {
+            // Float64 steps of a predicate chain (`v * 2.0 + 1.0 > 50.0`): IEEE arithmetic, ordered compares (a NaN fails all but !=);
+            // the host admits a division only by a non-zero literal on the right (arrow-rs 13 raises DivideByZero on a zero divisor)
+            const double dl = u2d(lit);
+#define NQE_F64(EXPR) _Pragma("unroll") for (int u = 0; u < U; ++u) { const double x = u2d(key[u]); key[u] = (EXPR); }
+            switch (op) {
+            case NQE_OP_PLUS: NQE_F64(d2u(x + dl)); break;
+            case NQE_OP_MULTIPLY: NQE_F64(d2u(x * dl)); break;
+            case NQE_OP_MINUS: if (ll) { NQE_F64(d2u(dl - x)); } else { NQE_F64(d2u(x - dl)); } break;
+            case NQE_OP_DIVIDE: NQE_F64(d2u(x / dl)); break;
+            case NQE_OP_EQ: NQE_F64(x == dl ? 1ull : 0ull); break;
+            case NQE_OP_NOT_EQ: NQE_F64(x != dl ? 1ull : 0ull); break;
+            case NQE_OP_LT: if (ll) { NQE_F64(dl < x ? 1ull : 0ull); } else { NQE_F64(x < dl ? 1ull : 0ull); } break;
+            case NQE_OP_LT_EQ: if (ll) { NQE_F64(dl <= x ? 1ull : 0ull); } else { NQE_F64(x <= dl ? 1ull : 0ull); } break;
+            case NQE_OP_GT: if (ll) { NQE_F64(dl > x ? 1ull : 0ull); } else { NQE_F64(x > dl ? 1ull : 0ull); } break;
+            default: if (ll) { NQE_F64(dl >= x ? 1ull : 0ull); } else { NQE_F64(x >= dl ? 1ull : 0ull); } break;
+            }
+#undef NQE_F64
+            continue;
+        }
         if (op == NQE_OP_PLUS) {
 #pragma unroll
             for (int u = 0; u < U; ++u) key[u] += lit;

@@ -524,6 +524,16 @@ def test_aggregate_chain_predicates(ctx, groups):
              # three- and four-step chains: the probe's `(id + 1) % 10 < 5` shape and a longer one
              binop(binop(binop(K, Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(10)), Operator.Lt, lit_i64(5)),
              binop(binop(binop(binop(W, Operator.Multiply, lit_i64(3)), Operator.Minus, lit_i64(7)), Operator.Divide, lit_i64(4)), Operator.GtEq, lit_i64(-3))]
+    # Float64 chains over the value column (with NaN / +-inf / -0.0 among the values): IEEE arithmetic, ordered compares,
+    # division by a non-zero literal; literal on either side
+    V = col(2)
+    v[:7] = [np.nan, np.inf, -np.inf, -0.0, 0.0, 5e-324, -2.5]
+    cols[2] = Column.from_numpy(v)
+    t = ctx.table_from_host(cols)
+    preds += [binop(binop(V, Operator.Multiply, lit_f64(2.0)), Operator.Gt, lit_f64(1.5)),
+              binop(binop(binop(V, Operator.Plus, lit_f64(5.0)), Operator.Divide, lit_f64(3.0)), Operator.LtEq, lit_f64(2.0)),
+              binop(lit_f64(0.0), Operator.Lt, binop(lit_f64(1.0), Operator.Minus, V)),
+              binop(binop(binop(binop(V, Operator.Multiply, lit_f64(-1.0)), Operator.Minus, lit_f64(0.25)), Operator.Divide, lit_f64(-0.5)), Operator.NotEq, lit_f64(0.5))]
     keys = [K, binop(binop(K, Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(groups + 1))]
     aggs = ALL_AGGS(2)
     for pred in preds:
