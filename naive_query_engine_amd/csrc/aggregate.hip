@@ -595,6 +595,38 @@ __global__ void finalize_kernel(GroupTable g, const uint32_t *sorted_slots, int6
 // aggregates of its entries at their ranks.  Work is G²/64 broadcast reads spread over G/64 workgroups (workgroups past the last
 // entry leave after the compaction); it replaces collect (20 µs) + single-workgroup bitonic sort (21 µs) + finalize (7.5 µs)
 // and the host round trip between them.
+// `A and B` / `A or B` where A and B are `col cmp lit` / `lit cmp col` over non-null Int64/UInt64/Float64 columns, at most one of
+// which is neither of … (which loaded word serves a test is decided per pass: key column, first value column, or the predicate
+// column).  Postfix layout: [a0 a1 cmpA b0 b1 cmpB and/or].
+bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred *out, int (&cols)[2]) {
+    if (n != 7 || nodes[6].kind != NQE_EXPR_BINARY || (nodes[6].op != NQE_OP_AND && nodes[6].op != NQE_OP_OR)) return false;
+    std::memset(out, 0, sizeof(*out));
+    for (int t = 0; t < 2; ++t) {
+        const nqe_expr_node *leaf = nodes + 3 * t;
+        if (leaf[2].kind != NQE_EXPR_BINARY || leaf[2].op > NQE_OP_GT_EQ) return false;
+        if (!((leaf[0].kind == NQE_EXPR_COLUMN && leaf[1].kind == NQE_EXPR_LITERAL) || (leaf[0].kind == NQE_EXPR_LITERAL && leaf[1].kind == NQE_EXPR_COLUMN)))
+            return false;
+        ExprInfo li;
+        try {
+            li = analyze_expr(in, leaf, 3);
+        } catch (...) {
+            return false; // whatever the leaf's problem is, the tree as a whole reports it
+        }
+        FastPred fp{};
+        if (!li.simple || li.out_dtype != NQE_BOOLEAN || !make_fast_pred(li.s, &fp)) return false;
+        const DevColumn &c = in->cols[size_t(li.s.col)];
+        if (!is_word_type(c.dtype) || c.validity || !c.values) return false;
+        cols[t] = li.s.col;
+        out->t[t].lo = fp.lo;
+        out->t[t].hi = fp.hi;
+        out->t[t].flip = fp.flip;
+        out->t[t].fmask = fp.fmask;
+        out->t[t].negate = fp.negate;
+    }
+    out->is_or = nodes[6].op == NQE_OP_OR ? 1 : 0;
+    return true;
+}
+
 constexpr uint32_t RANK_MAX_CAP = 8192;
 constexpr int RANK_SLOTS = 64;
 constexpr int RANK_WAVES = 16;
@@ -997,6 +1029,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     // ---- predicate
     DevColumn pred_col; // keeps a materialised predicate alive
     bool pred_may_fault = false;
+    int conj_col[2] = {-1, -1};
+    auto materialize_pred = [&]() { // the predicate tree as a Boolean column (expression machine), tested bit by bit
+        pred_col = evaluate_expr(ctx, in, pred, pred_nodes);
+        a.pred_mode = 2;
+        a.pred_src = src_of(pred_col);
+    };
     if (has_pred) {
         ExprInfo pinfo = analyze_expr(in, pred, pred_nodes);
         pred_may_fault = pinfo.may_fault;
@@ -1006,10 +1044,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             a.pred_mode = 1;
             a.pred = pinfo.s;
             a.pred_src = src_of(in->cols[size_t(pinfo.s.col)]);
+        } else if (grouped && match_conj(in, pred, pred_nodes, &a.conj, conj_col)) {
+            a.pred_mode = 3; // resolved (or materialised) per pass, see the launch section
         } else {
-            pred_col = evaluate_expr(ctx, in, pred, pred_nodes);
-            a.pred_mode = 2;
-            a.pred_src = src_of(pred_col);
+            materialize_pred();
         }
     }
     DevColumn key_colbuf;
@@ -1083,7 +1121,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         mix(&a.key, sizeof(a.key));
         mix(&a.key_src, sizeof(a.key_src));
         mix(&a.pred_mode, sizeof(a.pred_mode));
-        if (a.pred_mode) {
+        if (a.pred_mode == 3) {
+            mix(&a.conj, sizeof(a.conj));
+            mix(conj_col, sizeof(conj_col));
+        } else if (a.pred_mode) {
             mix(&a.pred, sizeof(a.pred));
             mix(&a.pred_src, sizeof(a.pred_src));
         }
@@ -1157,22 +1198,6 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 int blocks_per_cu = shmem <= 80 * 1024 ? 2 : 1;
                 int grid = int(std::min<int64_t>(int64_t(ctx->num_cus) * blocks_per_cu,
                                                  (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
-                // ---- kernel variant (see the template comment)
-                int pk = 0;
-                AggArgs ka = a;
-                if (a.pred_mode == 2) pk = 2;
-                else if (a.pred_mode == 1) {
-                    const SimpleExpr &pe = a.pred;
-                    pk = 3;
-                    if (pe.nops == 1 && pe.op[0] <= NQE_OP_GT_EQ && is_word_type(pe.src_dtype)) {
-                        pk = 1;
-                        if (pe.lit_left[0]) { // lit op x  ≡  x op' lit
-                            static const int flip[6] = {NQE_OP_EQ, NQE_OP_NOT_EQ, NQE_OP_GT, NQE_OP_GT_EQ, NQE_OP_LT, NQE_OP_LT_EQ};
-                            ka.pred.op[0] = flip[pe.op[0]];
-                            ka.pred.lit_left[0] = 0;
-                        }
-                    }
-                }
                 int kk = 2, fast_key = -1; // kk: general-kernel key kind; fast_key: fast-kernel key kind (-1 = not covered)
                 if (a.key.nops == 0) kk = 0, fast_key = 0;
                 else if (a.key.nops == 1 && a.key.op[0] == NQE_OP_MODULOS && !a.key.lit_left[0] &&
@@ -1191,6 +1216,54 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             ok = ok && !a.key.lit_left[k] && a.key.lit[k] != 0 && a.key.lit[k] != ~0ull;
                     }
                     if (ok) fast_key = 3;
+                }
+                // ---- `A and B` / `A or B` of two range tests (pred_mode 3): inside the single-pass streaming kernel when everything it
+                // reads is a plain 8-byte column; everywhere else (more groups than one workgroup table, validity bitmaps, a key the
+                // kernel does not compute) the predicate is materialised as a Boolean column first, as any other tree is
+                if (a.pred_mode == 1 && a.nv > 1 && a.pred.nops > 1) {
+                    // a chain with Float64 steps is interpreted by the one-value-column instances only
+                    bool f64_steps = false;
+                    for (int k = 0; k < a.pred.nops; ++k) f64_steps = f64_steps || a.pred.op_dtype[k] == NQE_FLOAT64;
+                    if (f64_steps) materialize_pred();
+                }
+                if (a.pred_mode == 3) {
+                    bool ok = !partition_mode && subsets_log2 == 0 && fast_key >= 0 && a.nv >= 1 && is_word_type(a.key_src.dtype) && !a.key_src.valid;
+                    for (int j = 0; j < a.nv; ++j) ok = ok && a.val[j].values && !a.val[j].valid;
+                    const void *other = nullptr; // the one column the kernel would load for the predicate alone
+                    if (ok) {
+                        a.conj.need_pw = 0;
+                        for (int t = 0; t < 2; ++t) {
+                            const DevColumn &lc = in->cols[size_t(conj_col[t])];
+                            const void *lp = lc.values->ptr;
+                            if (lp == a.key_src.values) a.conj.t[t].src = 0;
+                            else if (lp == a.val[0].values) a.conj.t[t].src = 1;
+                            else {
+                                if (other && other != lp) ok = false; // two such columns: not this kernel's shape
+                                other = lp;
+                                a.conj.t[t].src = 2;
+                                a.conj.need_pw = 1;
+                                a.pred_src = src_of(lc);
+                            }
+                        }
+                    }
+                    if (!ok) materialize_pred();
+                }
+                // ---- kernel variant (see the template comment)
+                int pk = 0;
+                AggArgs ka = a;
+                if (a.pred_mode == 2) pk = 2;
+                else if (a.pred_mode == 3) pk = 4;
+                else if (a.pred_mode == 1) {
+                    const SimpleExpr &pe = a.pred;
+                    pk = 3;
+                    if (pe.nops == 1 && pe.op[0] <= NQE_OP_GT_EQ && is_word_type(pe.src_dtype)) {
+                        pk = 1;
+                        if (pe.lit_left[0]) { // lit op x  ≡  x op' lit
+                            static const int flip[6] = {NQE_OP_EQ, NQE_OP_NOT_EQ, NQE_OP_GT, NQE_OP_GT_EQ, NQE_OP_LT, NQE_OP_LT_EQ};
+                            ka.pred.op[0] = flip[pe.op[0]];
+                            ka.pred.lit_left[0] = 0;
+                        }
+                    }
                 }
                 bool plain = is_word_type(a.key_src.dtype);
                 // a Boolean predicate column without nulls (a Boolean input column, or any predicate tree evaluated by the
@@ -1232,11 +1305,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         }
                     }
                 }
-                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || bitmap_pred || range_pred || chain_pred);
+                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || pk == 4 || bitmap_pred || range_pred || chain_pred);
+                if (pk == 4 && (!fast || vnull)) fail(NQE_ERR_NOT_SUPPORTED, "internal: a two-test predicate reached a kernel that cannot evaluate it");
                 if (fast) {
                     // variant 1 tests the key word with the integer range test alone; Float64 predicates and bitmaps use the
                     // "other column" variant, whose extraction step applies the order mapping
-                    int fp = pk == 0 ? 0 : (chain_pred ? 3 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2));
+                    int fp = pk == 0 ? 0 : pk == 4 ? 4 : (chain_pred ? 3 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2));
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
                     if (partition_mode && !level2 && !slab_failed) {

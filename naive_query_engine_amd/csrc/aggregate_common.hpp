@@ -63,7 +63,7 @@ struct GroupTable {
 
 struct AggArgs {
     int64_t n;
-    int32_t pred_mode; // 0 none, 1 SimpleExpr over pred_src, 2 Boolean column (bits + validity) in pred_src
+    int32_t pred_mode; // 0 none, 1 SimpleExpr over pred_src, 2 Boolean column (bits + validity) in pred_src, 3 `conj` (fast kernel only)
     int32_t has_key;
     int32_t pred_shares_key;
     int32_t nv;
@@ -87,6 +87,7 @@ struct AggArgs {
     // [subset_shift, subset_shift + subsets_log2) name it — 2^subsets_log2 LDS tables' worth of groups without partitioning the rows
     int32_t subsets_log2;
     int32_t subset_shift;
+    ConjPred conj; // pred_mode 3
 };
 
 __device__ __forceinline__ int lds_find_or_insert(uint64_t *keys, uint64_t key, uint32_t cap, int shift) {
@@ -174,7 +175,9 @@ __device__ __forceinline__ uint64_t divmod_by_literal(uint64_t a, uint64_t lit, 
 // keys of a register tile of U rows.  The interpreted variant (KEY = 3) runs operator-major: the (wave-uniform) dispatch on the
 // operator, its type and the divisor's shape happens once per operator per tile, the U rows are straight-line code under it —
 // per-row interpretation cost `(id + 1) % 1000` 0.90 ms per 2x10^8 rows against 0.56 ms for the built-in `id % 1000`.
-template <int KEY, int U>
+// F64: Float64 steps are compiled in (predicate chains of the one-value-column kernels only: with them in every instance the
+// interpreted-key and two-value-column variants spilled 10-120 more VGPRs)
+template <int KEY, int U, bool F64 = false>
 __device__ __forceinline__ void inline_keys(const SimpleExpr &ke, const uint64_t (&kw)[U], uint64_t (&key)[U], uint64_t key_mask,
                                             const OpAux &key_aux, bool key_signed) {
     if (KEY != 3) {
@@ -190,7 +193,7 @@ __device__ __forceinline__ void inline_keys(const SimpleExpr &ke, const uint64_t
         const int op = ke.op[k];
         const bool ll = ke.lit_left[k] != 0;
         const uint64_t lit = ke.lit[k];
-        if (ke.op_dtype[k] == NQE_FLOAT64) {
+        if (F64 && ke.op_dtype[k] == NQE_FLOAT64) {
             // Float64 steps of a predicate chain (`v * 2.0 + 1.0 > 50.0`): IEEE arithmetic, ordered compares (a NaN fails all but !=);
             // the host admits a division only by a non-zero literal on the right (arrow-rs 13 raises DivideByZero on a zero divisor)
             const double dl = u2d(lit);

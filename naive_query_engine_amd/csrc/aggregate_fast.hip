@@ -1,5 +1,5 @@
 // aggregate_fast.hip — the entry point the host logic (aggregate.hip) uses to pick a variant of the fast aggregate kernel; the
-// instances live in eight slices (aggregate_fast_inst.hip compiled per predicate variant, with and without validity bitmaps).
+// instances live in nine slices (aggregate_fast_inst.hip compiled per predicate variant, with and without validity bitmaps).
 #include "aggregate_fast_kernel.hpp"
 
 namespace nqe {
@@ -13,13 +13,15 @@ NQE_FAST_DECL(1)
 NQE_FAST_DECL(2)
 NQE_FAST_DECL(3)
 #undef NQE_FAST_DECL
+FastKernel pick_fast_p4_v0(int key, int nv, bool vf64, bool sub);
 
 FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull, bool sub) {
     switch (pred) {
     case 0: return vnull ? pick_fast_p0_v1(key, nv, vf64, sub) : pick_fast_p0_v0(key, nv, vf64, sub);
     case 1: return vnull ? pick_fast_p1_v1(key, nv, vf64, sub) : pick_fast_p1_v0(key, nv, vf64, sub);
     case 2: return vnull ? pick_fast_p2_v1(key, nv, vf64, sub) : pick_fast_p2_v0(key, nv, vf64, sub);
-    default: return vnull ? pick_fast_p3_v1(key, nv, vf64, sub) : pick_fast_p3_v0(key, nv, vf64, sub);
+    case 3: return vnull ? pick_fast_p3_v1(key, nv, vf64, sub) : pick_fast_p3_v0(key, nv, vf64, sub);
+    default: return vnull ? nullptr : pick_fast_p4_v0(key, nv, vf64, sub);
     }
 }
 

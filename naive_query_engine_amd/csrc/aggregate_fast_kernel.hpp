@@ -29,7 +29,8 @@ namespace {
 //     tiles), so waits are counted `s_waitcnt vmcnt(k)` and a wave keeps a tile in flight while it
 //     computes.
 // PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column, 3 a fault-free integer chain
-// `col op lit … cmp lit` over any column, interpreted operator-major like the KEY = 3 keys.
+// `col op lit … cmp lit` over any column, interpreted operator-major like the KEY = 3 keys, 4 `A and B` / `A or B` of two range
+// tests over the key column, the first value column and at most one more column (AggArgs::conj).
 template <int PRED, int KEY, int NVT, bool VF64, bool VNULL, bool SUB = false>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -160,6 +161,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 t.kw[u] = __builtin_nontemporal_load(&keyp[row]);
                 if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
                 if (PRED == 3) t.pw[u] = __builtin_nontemporal_load(&predp[row]);
+                if (PRED == 4) t.pw[u] = a.conj.need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull; // wave-uniform
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
                 if (VNULL) {
@@ -296,7 +298,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         // interpreted keys are computed for the whole tile up front (operator-major); the built-in shapes stay inside the row loop,
         // where the compiler sinks them below the predicate (hoisting them cost the headline 1.5 %)
         uint64_t pvals[PRED == 3 ? AGG_U : 1];
-        if (PRED == 3) inline_keys<3, AGG_U>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
+        if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
         uint64_t keys[KEY == 3 ? AGG_U : 1];
         if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, reinterpret_cast<uint64_t (&)[AGG_U]>(keys), key_mask, key_aux, key_signed);
 #pragma unroll
@@ -304,6 +306,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = row < n;
             if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
+            else if (PRED == 4) pass = pass && conj_pass(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) {
                 pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             }
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     };
     auto process_batch = [&](const Tile &t, int64_t base) {
         uint64_t pvals[PRED == 3 ? AGG_U : 1];
-        if (PRED == 3) inline_keys<3, AGG_U>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
+        if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
         bool pass[AGG_U];
         uint64_t key[AGG_U];
         tile_keys(t, key);
@@ -331,6 +334,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             pass[u] = row < n;
             if (PRED == 3) pass[u] = pass[u] && pvals[PRED == 3 ? u : 0] != 0;
+            else if (PRED == 4) pass[u] = pass[u] && conj_pass(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             if (VNULL) pass[u] = pass[u] && ((t.kpv[u] >> (row & 63)) & 1ull);
         }
@@ -383,7 +387,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         Tile A;
         load_tile(A, base);
         // not where registers are short: the VNULL variants (37 VGPRs spilled: 2.2x slower), two value columns, interpreted predicates
-        constexpr bool CAN_BATCH = NQE_AGG_BATCH && !VNULL && NVT == 1 && PRED != 3 && !(PRED == 2 && KEY == 3);
+        constexpr bool CAN_BATCH = NQE_AGG_BATCH && !VNULL && NVT == 1 && PRED != 3 && !(PRED == 2 && KEY == 3) && !(PRED == 4 && KEY == 3);
         while (base < n) {
             bool batch = false; // wave-uniform
             if (CAN_BATCH) {
@@ -426,7 +430,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 
 template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64, bool sub) {
     if (sub) {
-        if constexpr (VNULL) return nullptr;
+        // (PRED 4: a query that outgrows one table continues with a materialised predicate; its slice is built without validity only)
+        if constexpr (VNULL || PRED == 4) return nullptr;
         else {
             if (nv != 1) return nullptr;
             return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, false, true> : agg_grouped_fast_kernel<PRED, KEY, 1, false, false, true>;

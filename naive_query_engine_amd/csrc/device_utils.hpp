@@ -211,6 +211,19 @@ __device__ __forceinline__ uint64_t pred_extract(const FastPred &fp, uint64_t w,
     return f64_order_map(fp, (w >> (int(row) & fp.bit_mask)) & fp.val_mask);
 }
 
+// one leaf of a ConjPred on the row's word
+__device__ __forceinline__ bool conj_test(const ConjTest &t, uint64_t w) {
+    const uint64_t x = w ^ (uint64_t(int64_t(w) >> 63) & t.fmask);
+    const int64_t xs = int64_t(x ^ t.flip);
+    return ((xs >= t.lo) && (xs <= t.hi)) != (t.negate != 0);
+}
+__device__ __forceinline__ bool conj_pass(const ConjPred &c, uint64_t kw, uint64_t vw, uint64_t pw) {
+    const uint64_t w0 = c.t[0].src == 0 ? kw : c.t[0].src == 1 ? vw : pw;
+    const uint64_t w1 = c.t[1].src == 0 ? kw : c.t[1].src == 1 ? vw : pw;
+    const bool r0 = conj_test(c.t[0], w0), r1 = conj_test(c.t[1], w1);
+    return c.is_or ? (r0 || r1) : (r0 && r1);
+}
+
 // wave-level exclusive prefix sum of a 32-bit value (wave64, DPP-free shuffle version)
 __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t &total) {
     uint32_t x = v;

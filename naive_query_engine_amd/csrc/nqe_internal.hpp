@@ -253,6 +253,21 @@ struct FastPred {
     // the same order (negative values reversed); NaNs land beyond ±inf and are excluded by [lo, hi].  0 for integers.
     uint64_t fmask;
 };
+// `A and B` / `A or B` of two range tests `col cmp lit` over non-null 8-byte columns the consuming kernel reads anyway (its key
+// column, its first value column) plus at most one more column: a WHERE clause's usual shape, tested per row inside the
+// aggregate kernel instead of through a materialised Boolean column (one more pass over the predicate's columns)
+struct ConjTest {
+    int64_t lo, hi;
+    uint64_t flip;  // sign bit for UInt64 operands
+    uint64_t fmask; // Float64 operands: order map (see FastPred::fmask), 0 for integers
+    int32_t negate;
+    int32_t src;    // which loaded word of the row: 0 key column, 1 first value column, 2 the predicate column
+};
+struct ConjPred {
+    ConjTest t[2];
+    int32_t is_or;
+    int32_t need_pw; // some test reads the predicate column (src == 2)
+};
 // FastPred "bit r of a non-null Boolean bitmap is set"
 FastPred bitmap_fast_pred();
 // returns false when the SimpleExpr is not a single Int64/UInt64/Float64 compare against a literal

@@ -930,6 +930,63 @@ def test_aggregate_partitioned_path_many_groups(ctx, groups):
                 assert_rows_multiset_equal(got, exp, RTOL, exact_cols=counts, what=f"partitioned groups={groups} key={key!r}")
 
 
+@pytest.mark.parametrize("groups", [5, 900, 5000, 70000])
+def test_aggregate_two_test_predicates(ctx, groups):
+    """`A and B` / `A or B` of two compares with literals — the usual WHERE clause — run inside the streaming aggregate kernel
+    when the tested columns are the key column, the first value column or one more column (5, 900 groups), and as a materialised
+    Boolean column on the subset / partitioned tiers (5000, 70000 groups), for nullable columns and for two extra columns"""
+    rng = np.random.default_rng(groups + 1)
+    n = 400_000
+    k = rng.integers(-groups // 2, groups - groups // 2, n).astype(np.int64)
+    v = rng.random(n) * 100 - 50
+    v[:5] = [np.nan, np.inf, -np.inf, -0.0, 0.0]
+    w = rng.integers(-1000, 1000, n).astype(np.int64)
+    u = rng.integers(0, 1 << 40, n).astype(np.uint64)
+    z = rng.integers(0, 100, n).astype(np.int64)
+    zmask = rng.random(n) > 0.1
+    cols = [Column.from_numpy(k), Column.from_numpy(v), Column.from_numpy(w), Column.from_numpy(u), Column.from_numpy(z, zmask)]
+    f5 = fields("k", "v", "w", "u", "z")
+    t = ctx.table_from_host(cols)
+    K, V, W, U, Z = col(0), col(1), col(2), col(3), col(4)
+    A, O = Operator.And, Operator.Or
+    preds = [binop(binop(K, Operator.Lt, lit_i64(groups // 4)), A, binop(V, Operator.Gt, lit_f64(-10.0))),        # key column, value column
+             binop(binop(lit_f64(25.0), Operator.GtEq, V), O, binop(K, Operator.Eq, lit_i64(1))),                  # literal on the left, or
+             binop(binop(W, Operator.NotEq, lit_i64(0)), A, binop(K, Operator.GtEq, lit_i64(-3))),                 # another column + key
+             binop(binop(W, Operator.Gt, lit_i64(-500)), A, binop(W, Operator.LtEq, lit_i64(500))),                # a range on one other column
+             binop(binop(U, Operator.Lt, lit_u64(1 << 39)), O, binop(V, Operator.NotEq, lit_f64(0.0))),            # UInt64 + Float64 (!= is true for NaN)
+             binop(binop(W, Operator.Lt, lit_i64(0)), A, binop(U, Operator.Gt, lit_u64(1 << 38))),                 # two other columns: materialised
+             binop(binop(Z, Operator.Lt, lit_i64(50)), A, binop(K, Operator.Gt, lit_i64(-100)))]                   # nullable column: materialised (Kleene)
+    for pred in preds:
+        for aggs in (ALL_AGGS(1), ALL_AGGS(1) + ALL_AGGS(2)):
+            for key in (K, binop(K, Operator.Modulos, lit_i64(1 << 20))):
+                exp = orc.aggregate([cols], aggs, group_nodes=key.flatten(f5), pred_nodes=pred.flatten(f5))[0]
+                got = ctx.aggregate(t, aggs, group_nodes=key.flatten(f5), pred_nodes=pred.flatten(f5)).to_host()
+                counts = [i for i, (fn, _) in enumerate(aggs) if fn == AggregateFunc.Count]
+                assert_rows_multiset_equal(got, exp, RTOL, exact_cols=counts, what=f"groups={groups} pred={pred!r} key={key!r}")
+    # un-grouped: the materialised form
+    exp = orc.aggregate([cols], ALL_AGGS(1), pred_nodes=preds[0].flatten(f5))[0]
+    got = ctx.aggregate(t, ALL_AGGS(1), pred_nodes=preds[0].flatten(f5)).to_host()
+    assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what="un-grouped, two-test predicate")
+
+
+def test_two_test_predicate_runs_inside_the_streaming_kernel(ctx):
+    """no expression-machine pass and no second kernel for `k < c and v > d`"""
+    rng = np.random.default_rng(3)
+    n = 300_000
+    cols = [Column.from_numpy(rng.integers(0, 100, n).astype(np.int64)), Column.from_numpy(rng.random(n))]
+    f2 = fields("k", "v")
+    t = ctx.table_from_host(cols)
+    pred = binop(binop(col(0), Operator.Lt, lit_i64(50)), Operator.And, binop(col(1), Operator.Gt, lit_f64(0.25))).flatten(f2)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    got = ctx.aggregate(t, ALL_AGGS(1), group_nodes=col(0).flatten(f2), pred_nodes=pred).to_host()
+    ctx.timing_enable(False)
+    rep = ctx.timing_report()
+    assert rep["agg_grouped_fast"][1] == 1 and not any(name.startswith("expr") for name in rep), rep
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=col(0).flatten(f2), pred_nodes=pred)[0]
+    assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what="two-test predicate, in-kernel")
+
+
 @pytest.mark.parametrize("groups", [7, 1000, 3000])
 def test_aggregate_special_float_values_under_random_keys(ctx, groups):
     """NaN, +-inf, +-0, subnormals as VALUES where every row's key differs from its neighbour's (the kernel's batch loop
