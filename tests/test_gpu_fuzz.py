@@ -49,8 +49,32 @@ def random_chain_key(rng, c=0, unsigned=False):
     return e
 
 
+def _random_leaf(rng):
+    """`col cmp lit` / `lit cmp col` over the batch's Int64 / Float64 / UInt64 columns (ids, k, v, u)"""
+    c = int(rng.choice([0, 1, 2, 3]))
+    cmp_op = [Operator.Lt, Operator.LtEq, Operator.Gt, Operator.GtEq, Operator.Eq, Operator.NotEq][int(rng.integers(0, 6))]
+    if c == 2:
+        lit = lit_f64(float(rng.choice([0.0, -0.0, 25.5, -60.0, 99.0, float("nan"), float("inf"), float("-inf")])))
+    elif c == 3:
+        lit = lit_u64(int(rng.choice([0, 1, 1 << 20, 1 << 39, (1 << 40) - 1])))
+    else:
+        lit = lit_i64(int(rng.choice([-50, -1, 0, 1, 7, 49, 500, 3000])))
+    return binop(lit, cmp_op, col(c)) if rng.random() < 0.25 else binop(col(c), cmp_op, lit)
+
+
 def random_pred(rng):
-    kind = int(rng.integers(0, 9))
+    kind = int(rng.integers(0, 12))
+    if kind == 9 or kind == 10:  # two tests joined by and / or: inside the streaming aggregate kernel when its columns allow
+        return binop(_random_leaf(rng), Operator.And if kind == 9 else Operator.Or, _random_leaf(rng))
+    if kind == 11:  # Float64 chain ending in a comparison
+        e = col(2)
+        for _ in range(int(rng.integers(1, 4))):
+            op = [Operator.Plus, Operator.Minus, Operator.Multiply, Operator.Divide][int(rng.integers(0, 4))]
+            v = float(rng.choice([0.5, -2.0, 3.0, 100.0, 1e-3])) if op == Operator.Divide else float(rng.choice([0.0, -0.0, 0.5, -2.0, 3.0, 100.0, float("inf")]))
+            e = binop(lit_f64(v), op, e) if (rng.random() < 0.2 and op != Operator.Divide) else binop(e, op, lit_f64(v))
+        cmp_op = [Operator.Lt, Operator.LtEq, Operator.Gt, Operator.GtEq, Operator.Eq, Operator.NotEq][int(rng.integers(0, 6))]
+        lit = lit_f64(float(rng.choice([0.0, 10.0, -75.0, 250.0, float("nan")])))
+        return binop(lit, cmp_op, e) if rng.random() < 0.2 else binop(e, cmp_op, lit)
     if kind >= 7:  # integer chain ending in a comparison (the fast kernels' interpreted predicate when it cannot fault)
         unsigned = kind == 8
         e = random_chain_key(rng, 3 if unsigned else 0, unsigned=unsigned)

@@ -115,6 +115,12 @@ if SECTION in ("all", "exprs"):
     tp = binop(binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(10)), Operator.Lt, lit_i64(5))
     q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=key, pred_nodes=tp.flatten(f)))
     print(f"aggregate with tree predicate ((id+1)%10 < 5): {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
+    for name, tp2 in (("v * 2.0 > 100.0 (Float64 chain)", binop(binop(col(1), Operator.Multiply, lit_f64(2.0)), Operator.Gt, lit_f64(100.0))),
+                      ("(v + 5.0) / 3.0 <= 20.0 (Float64 chain)", binop(binop(binop(col(1), Operator.Plus, lit_f64(5.0)), Operator.Divide, lit_f64(3.0)), Operator.LtEq, lit_f64(20.0))),
+                      ("id < N/2 and v > 10 (two tests, in-kernel)", binop(binop(col(0), Operator.Lt, lit_i64(n // 2)), Operator.And, binop(col(1), Operator.Gt, lit_f64(10.0)))),
+                      ("v < 20 or id % 3 == 0 (general tree: materialised Boolean column)", binop(binop(col(1), Operator.Lt, lit_f64(20.0)), Operator.Or, binop(binop(col(0), Operator.Modulos, lit_i64(3)), Operator.Eq, lit_i64(0))))):
+        q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=key, pred_nodes=tp2.flatten(f)))
+        print(f"aggregate with predicate {name}: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s")
     q = timeit(lambda: ctx.selection_projection(plain, tp.flatten(f), [cases[0][1].flatten(f), col(0).flatten(f)]))
     print(f"selection(tree pred)+projection(tree, id): {q*1e3:.3f} ms = {(16*n + 8*n)/q/1e9:.0f} GB/s algorithmic (50% pass)")
     ctx.timing_enable(True); ctx.timing_reset()
@@ -153,7 +159,7 @@ if SECTION in ("all", "csv"):
     print("   kernels(ms):", br)
 
 # ---- 3. high-cardinality group-by
-for groups in ((1 << 10, 2000, 3000, 1 << 12, 1 << 14, 1 << 17, 1 << 20, 1 << 24) if SECTION in ('all', 'groups') else ()):
+for groups in ((1 << 10, 2000, 3000, 1 << 12, 6000, 1 << 14, 1 << 17, 500_000, 1 << 20, 1 << 24) if SECTION in ('all', 'groups') else ()):
     kt = torch.empty(n, dtype=torch.int64, device=dev)
     ctx.synth_fill(1, 7, 0, n, groups, 0, kt.data_ptr())
     tab = ctx.table_from_device([(DType.INT64, n, kt.data_ptr(), None), (DType.FLOAT64, n, vt.data_ptr(), None)])
