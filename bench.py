@@ -490,7 +490,8 @@ def main():
             del s
             cfg[cname] = r
 
-        if world == 1:
+        # (NQE_BENCH_MULTI_CONFIGS with NQE_FORCE_EXCHANGE: the multi-rank block on one rank through RCCL — a dry run of that code)
+        if world == 1 and not (B.distributed and os.environ.get("NQE_BENCH_MULTI_CONFIGS")):
             add("c3", lambda: wl_aggregate(B, n, False, False, csteps, cwarm), lambda s: parity_aggregate(B, s, 20_000_000))
             add("headline_random_keys", lambda: wl_aggregate(B, n, True, True, csteps, cwarm), lambda s: parity_aggregate(B, s, 20_000_000))
             add("c3_random_keys", lambda: wl_aggregate(B, n, False, True, csteps, cwarm))

@@ -230,3 +230,24 @@ def test_bench_refuses_more_ranks_than_devices():
                          timeout=280, env=env)
     assert out.returncode != 0
     assert "n_gpus" not in out.stdout
+
+
+def test_bench_multi_rank_block_dry_run_on_one_rank():
+    """the part of bench.py that only runs with more than one rank (headline with and without its exchange, C5 probe / gather /
+    end to end), driven on ONE rank through real RCCL: same code, same JSON keys as an N-GPU run of the driver"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(NQE_FORCE_EXCHANGE="1", NQE_BENCH_MULTI_CONFIGS="1", MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True,
+                         text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = out.stdout.strip().splitlines()[-1]
+    d = json.loads(line)  # the JSON line is the last line of stdout
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["rccl_version"] > 0 and d["result_check"]["ok"]
+    assert {"headline_local_only", "c5_probe_only", "c5_probe_and_gather", "c5"} <= set(d["configs"])
+    c5 = d["configs"]["c5"]
+    assert c5["end_to_end_ms"] >= c5["probe_only_ms"] > 0 and "exchange_ms_per_step" in d
