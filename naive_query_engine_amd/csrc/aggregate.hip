@@ -595,38 +595,6 @@ __global__ void finalize_kernel(GroupTable g, const uint32_t *sorted_slots, int6
 // aggregates of its entries at their ranks.  Work is G²/64 broadcast reads spread over G/64 workgroups (workgroups past the last
 // entry leave after the compaction); it replaces collect (20 µs) + single-workgroup bitonic sort (21 µs) + finalize (7.5 µs)
 // and the host round trip between them.
-// `A and B` / `A or B` where A and B are `col cmp lit` / `lit cmp col` over non-null Int64/UInt64/Float64 columns, at most one of
-// which is neither of … (which loaded word serves a test is decided per pass: key column, first value column, or the predicate
-// column).  Postfix layout: [a0 a1 cmpA b0 b1 cmpB and/or].
-bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred *out, int (&cols)[2]) {
-    if (n != 7 || nodes[6].kind != NQE_EXPR_BINARY || (nodes[6].op != NQE_OP_AND && nodes[6].op != NQE_OP_OR)) return false;
-    std::memset(out, 0, sizeof(*out));
-    for (int t = 0; t < 2; ++t) {
-        const nqe_expr_node *leaf = nodes + 3 * t;
-        if (leaf[2].kind != NQE_EXPR_BINARY || leaf[2].op > NQE_OP_GT_EQ) return false;
-        if (!((leaf[0].kind == NQE_EXPR_COLUMN && leaf[1].kind == NQE_EXPR_LITERAL) || (leaf[0].kind == NQE_EXPR_LITERAL && leaf[1].kind == NQE_EXPR_COLUMN)))
-            return false;
-        ExprInfo li;
-        try {
-            li = analyze_expr(in, leaf, 3);
-        } catch (...) {
-            return false; // whatever the leaf's problem is, the tree as a whole reports it
-        }
-        FastPred fp{};
-        if (!li.simple || li.out_dtype != NQE_BOOLEAN || !make_fast_pred(li.s, &fp)) return false;
-        const DevColumn &c = in->cols[size_t(li.s.col)];
-        if (!is_word_type(c.dtype) || c.validity || !c.values) return false;
-        cols[t] = li.s.col;
-        out->t[t].lo = fp.lo;
-        out->t[t].hi = fp.hi;
-        out->t[t].flip = fp.flip;
-        out->t[t].fmask = fp.fmask;
-        out->t[t].negate = fp.negate;
-    }
-    out->is_or = nodes[6].op == NQE_OP_OR ? 1 : 0;
-    return true;
-}
-
 constexpr uint32_t RANK_MAX_CAP = 8192;
 constexpr int RANK_SLOTS = 64;
 constexpr int RANK_WAVES = 16;

@@ -740,6 +740,38 @@ bool make_fast_pred(const SimpleExpr &pe, FastPred *fp) {
     return true;
 }
 
+// `A and B` / `A or B` where A and B are `col cmp lit` / `lit cmp col` over non-null Int64/UInt64/Float64 columns (cols[] names
+// them; which loaded word of a row serves a test — ConjTest::src — is the consumer's business).  Postfix layout:
+// [a0 a1 cmpA b0 b1 cmpB and/or].
+bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred *out, int *cols) {
+    if (n != 7 || nodes[6].kind != NQE_EXPR_BINARY || (nodes[6].op != NQE_OP_AND && nodes[6].op != NQE_OP_OR)) return false;
+    std::memset(out, 0, sizeof(*out));
+    for (int t = 0; t < 2; ++t) {
+        const nqe_expr_node *leaf = nodes + 3 * t;
+        if (leaf[2].kind != NQE_EXPR_BINARY || leaf[2].op > NQE_OP_GT_EQ) return false;
+        if (!((leaf[0].kind == NQE_EXPR_COLUMN && leaf[1].kind == NQE_EXPR_LITERAL) || (leaf[0].kind == NQE_EXPR_LITERAL && leaf[1].kind == NQE_EXPR_COLUMN)))
+            return false;
+        ExprInfo li;
+        try {
+            li = analyze_expr(in, leaf, 3);
+        } catch (...) {
+            return false; // whatever the leaf's problem is, the tree as a whole reports it
+        }
+        FastPred fp{};
+        if (!li.simple || li.out_dtype != NQE_BOOLEAN || !make_fast_pred(li.s, &fp)) return false;
+        const DevColumn &c = in->cols[size_t(li.s.col)];
+        if (!is_word_type(c.dtype) || c.validity || !c.values) return false;
+        cols[t] = li.s.col;
+        out->t[t].lo = fp.lo;
+        out->t[t].hi = fp.hi;
+        out->t[t].flip = fp.flip;
+        out->t[t].fmask = fp.fmask;
+        out->t[t].negate = fp.negate;
+    }
+    out->is_or = nodes[6].op == NQE_OP_OR ? 1 : 0;
+    return true;
+}
+
 FastPred bitmap_fast_pred() {
     FastPred fp{};
     fp.lo = fp.hi = 1;

@@ -268,6 +268,8 @@ struct ConjPred {
     int32_t is_or;
     int32_t need_pw; // some test reads the predicate column (src == 2)
 };
+// recognises the shape (see expr.hip); cols[2] receive the two tested columns
+bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred *out, int *cols);
 // FastPred "bit r of a non-null Boolean bitmap is set"
 FastPred bitmap_fast_pred();
 // returns false when the SimpleExpr is not a single Int64/UInt64/Float64 compare against a literal

@@ -108,6 +108,39 @@ __global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *value
     }
 }
 
+// keep mask of `A and B` / `A or B`, two range tests over one or two plain 8-byte columns (ConjTest::src 0: column a, 2: column b):
+// the WHERE clause's usual shape in one streaming pass over its column(s), without the expression machine's Boolean column
+template <bool TWO>
+__global__ void __launch_bounds__(256) keep_from_conj_kernel(const uint64_t *__restrict__ wa, const uint64_t *__restrict__ wb, ConjPred c, int64_t n,
+                                                             int64_t ntiles, uint64_t *keep, uint32_t *tile_counts) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t last = n - 1;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t row0 = tile * TILE_ROWS;
+        uint32_t total = 0;
+#pragma unroll 2
+        for (int k0 = 0; k0 < TILE_WORDS; k0 += SEL_B) {
+            uint64_t a[SEL_B], b[SEL_B];
+#pragma unroll
+            for (int k = 0; k < SEL_B; ++k) {
+                int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                row = row < last ? row : last;
+                a[k] = __builtin_nontemporal_load(&wa[row]);
+                b[k] = TWO ? __builtin_nontemporal_load(&wb[row]) : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < SEL_B; ++k) {
+                const int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
+                const uint64_t kw = __ballot(row < n && conj_pass(c, a[k], 0ull, b[k]));
+                if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
+                total += __popcll(kw);
+            }
+        }
+        if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
 // Stable compaction of one column (or of a SimpleExpr evaluated on it) by the keep bitmap.
 // Word k of the tile lives in lane k; it is broadcast through the scalar unit (readlane).
 // PLAINW: 8-byte source without validity and a predicate without nulls → values only.
@@ -264,6 +297,30 @@ KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleE
     return finish_mask(ctx, km, counts);
 }
 
+KeepMask build_keep_mask_conj(nqe_ctx *ctx, const nqe_table *in, ConjPred c, const int *cols) {
+    KeepMask km;
+    km.n = in->rows;
+    km.ntiles = (km.n + TILE_ROWS - 1) / TILE_ROWS;
+    const int64_t nwords = (km.n + 63) / 64;
+    km.keep = dev_alloc(ctx, size_t(nwords) * 8 + 8);
+    BufRef counts = dev_alloc(ctx, size_t(km.ntiles + 1) * 4);
+    const bool two = cols[0] != cols[1];
+    c.t[0].src = 0;
+    c.t[1].src = two ? 2 : 0;
+    c.need_pw = two ? 1 : 0;
+    if (km.ntiles) {
+        dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
+        const uint64_t *wa = in->cols[size_t(cols[0])].words(), *wb = in->cols[size_t(cols[1])].words();
+        if (two)
+            launch(ctx, "keep_from_conj", keep_from_conj_kernel<true>, grid, block, 0, wa, wb, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr,
+                   (uint32_t *)counts->ptr);
+        else
+            launch(ctx, "keep_from_conj", keep_from_conj_kernel<false>, grid, block, 0, wa, wb, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr,
+                   (uint32_t *)counts->ptr);
+    }
+    return finish_mask(ctx, km, counts);
+}
+
 const int64_t *kept_rows(nqe_ctx *ctx, const KeepMask &km) {
     if (!km.kept_idx) {
         km.kept_idx = dev_alloc(ctx, size_t(km.total) * 8 + 8);
@@ -335,6 +392,9 @@ static KeepMask mask_for_predicate(nqe_ctx *ctx, const nqe_table *in, const nqe_
     if (info.out_dtype != NQE_BOOLEAN)
         fail(NQE_ERR_NOT_SUPPORTED, "predicate is not a BooleanArray (selection.rs:61 unwrap panics)");
     if (info.simple) return build_keep_mask_simple(ctx, in, info.s);
+    ConjPred conj;
+    int conj_cols[2];
+    if (match_conj(in, pred, pred_nodes, &conj, conj_cols)) return build_keep_mask_conj(ctx, in, conj, conj_cols);
     DevColumn p = evaluate_expr(ctx, in, pred, pred_nodes);
     return build_keep_mask(ctx, p, in->rows);
 }

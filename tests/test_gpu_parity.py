@@ -930,6 +930,36 @@ def test_aggregate_partitioned_path_many_groups(ctx, groups):
                 assert_rows_multiset_equal(got, exp, RTOL, exact_cols=counts, what=f"partitioned groups={groups} key={key!r}")
 
 
+@pytest.mark.parametrize("n", [1, 63, 4096, 4097, 70001])
+def test_selection_two_test_predicates(ctx, n):
+    """`A and B` / `A or B` of two compares with literals as a selection's predicate: one streaming pass over the tested
+    column(s) builds the keep mask (no Boolean column); same rows, same order as the reference's filter"""
+    rng = np.random.default_rng(n)
+    k = rng.integers(-50, 50, n).astype(np.int64)
+    v = rng.random(n) * 100 - 50
+    v[: min(n, 5)] = [np.nan, np.inf, -np.inf, -0.0, 0.0][: min(n, 5)]
+    u = rng.integers(0, 1 << 40, n).astype(np.uint64)
+    z = rng.integers(0, 100, n).astype(np.int64)
+    cols = [Column.from_numpy(k), Column.from_numpy(v), Column.from_numpy(u), Column.from_numpy(z, rng.random(n) > 0.2)]
+    f4 = fields("k", "v", "u", "z")
+    t = ctx.table_from_host(cols)
+    K, V, U, Z = col(0), col(1), col(2), col(3)
+    A, O = Operator.And, Operator.Or
+    preds = [binop(binop(K, Operator.GtEq, lit_i64(-10)), A, binop(K, Operator.Lt, lit_i64(25))),                # a range on one column
+             binop(binop(K, Operator.Lt, lit_i64(0)), A, binop(V, Operator.Gt, lit_f64(-10.0))),
+             binop(binop(lit_f64(0.0), Operator.LtEq, V), O, binop(U, Operator.Lt, lit_u64(1 << 38))),           # literal on the left, -0.0 == 0.0
+             binop(binop(V, Operator.NotEq, lit_f64(float("nan"))), A, binop(V, Operator.Lt, lit_f64(float("inf")))),  # != NaN is true for every row
+             binop(binop(V, Operator.Eq, lit_f64(float("nan"))), O, binop(K, Operator.Eq, lit_i64(7))),
+             binop(binop(Z, Operator.Lt, lit_i64(50)), A, binop(K, Operator.Gt, lit_i64(-100)))]                  # nullable column: the general path (Kleene)
+    for pred in preds:
+        exp = orc.selection([cols], pred.flatten(f4))[0]
+        got = ctx.selection(t, pred.flatten(f4)).to_host()
+        assert_batches_equal(got, exp, what=f"n={n} pred={pred!r}")
+        expp = orc.projection(orc.selection([cols], pred.flatten(f4)), [binop(K, Operator.Plus, lit_i64(100)).flatten(f4), U.flatten(f4)])[0]
+        gotp = ctx.selection_projection(t, pred.flatten(f4), [binop(K, Operator.Plus, lit_i64(100)).flatten(f4), U.flatten(f4)]).to_host()
+        assert_batches_equal(gotp, expp, what=f"fused n={n} pred={pred!r}")
+
+
 @pytest.mark.parametrize("groups", [5, 900, 5000, 70000])
 def test_aggregate_two_test_predicates(ctx, groups):
     """`A and B` / `A or B` of two compares with literals — the usual WHERE clause — run inside the streaming aggregate kernel
