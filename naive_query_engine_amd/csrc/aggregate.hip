@@ -997,7 +997,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     // ---- predicate
     DevColumn pred_col; // keeps a materialised predicate alive
     bool pred_may_fault = false;
-    int conj_col[2] = {-1, -1};
+    int conj_col[CONJ_MAX] = {-1, -1, -1, -1};
     auto materialize_pred = [&]() { // the predicate tree as a Boolean column (expression machine), tested bit by bit
         pred_col = evaluate_expr(ctx, in, pred, pred_nodes);
         a.pred_mode = 2;
@@ -1185,7 +1185,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     }
                     if (ok) fast_key = 3;
                 }
-                // ---- `A and B` / `A or B` of two range tests (pred_mode 3): inside the single-pass streaming kernel when everything it
+                // ---- `A and B [and …]` / `A or B [or …]` of up to four range tests (pred_mode 3): inside the single-pass streaming kernel when everything it
                 // reads is a plain 8-byte column; everywhere else (more groups than one workgroup table, validity bitmaps, a key the
                 // kernel does not compute) the predicate is materialised as a Boolean column first, as any other tree is
                 if (a.pred_mode == 1 && a.nv > 1 && a.pred.nops > 1) {
@@ -1200,7 +1200,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     const void *other = nullptr; // the one column the kernel would load for the predicate alone
                     if (ok) {
                         a.conj.need_pw = 0;
-                        for (int t = 0; t < 2; ++t) {
+                        for (int t = 0; t < a.conj.n; ++t) {
                             const DevColumn &lc = in->cols[size_t(conj_col[t])];
                             const void *lp = lc.values->ptr;
                             if (lp == a.key_src.values) a.conj.t[t].src = 0;

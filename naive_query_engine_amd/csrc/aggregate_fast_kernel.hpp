@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = row < n;
             if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
-            else if (PRED == 4) pass = pass && conj_pass(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
+            else if (PRED == 4) pass = pass && conj_pass<3>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) {
                 pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             }
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             pass[u] = row < n;
             if (PRED == 3) pass[u] = pass[u] && pvals[PRED == 3 ? u : 0] != 0;
-            else if (PRED == 4) pass[u] = pass[u] && conj_pass(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
+            else if (PRED == 4) pass[u] = pass[u] && conj_pass<3>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             if (VNULL) pass[u] = pass[u] && ((t.kpv[u] >> (row & 63)) & 1ull);
         }

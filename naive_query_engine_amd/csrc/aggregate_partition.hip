@@ -407,8 +407,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
 // ------------------------------------------------------------------ slab form: no count pass, software-pipelined scatter
 // Rows per thread per tile: 8 where the registers allow two tiles in flight (one value column, predicate on the key column or
 // none), else 4.
+#ifndef NQE_SLAB_KEYMOD_RPT
+#define NQE_SLAB_KEYMOD_RPT 8 // rows per thread of the `col % m` key variants: 8 spill 14-16 VGPRs and are still faster than 4 without (scatter 0.85 vs 0.93 ms)
+#endif
 template <int PRED, int KEY, int NVT> struct SlabShape {
-    static constexpr int RPT = (NVT == 1 && PRED <= 1 && KEY != 3) ? 8 : 4;
+    static constexpr int RPT = (NVT == 1 && PRED <= 1 && (KEY == 0 || (NQE_SLAB_KEYMOD_RPT == 8 && KEY != 3))) ? 8 : 4;
 };
 
 // One workgroup per chunk of rows.  Per tile: fused predicate + key → partition → rank (LDS atomic on the tile's counter) →
@@ -833,7 +836,7 @@ SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv) {
     default: return pick_slab_scatter_key<3>(key, nv);
     }
 }
-int slab_scatter_rows_per_thread(int pred, int key, int nv) { return (nv == 1 && pred <= 1 && key != 3) ? 8 : 4; }
+int slab_scatter_rows_per_thread(int pred, int key, int nv) { return (nv == 1 && pred <= 1 && (key == 0 || (NQE_SLAB_KEYMOD_RPT == 8 && key != 3))) ? 8 : 4; }
 SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64) {
     return nv == 1 ? (vf64 ? agg_slab_segments_kernel<1, true> : agg_slab_segments_kernel<1, false>)
                    : (vf64 ? agg_slab_segments_kernel<2, true> : agg_slab_segments_kernel<2, false>);

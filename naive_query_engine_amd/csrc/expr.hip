@@ -740,14 +740,44 @@ bool make_fast_pred(const SimpleExpr &pe, FastPred *fp) {
     return true;
 }
 
-// `A and B` / `A or B` where A and B are `col cmp lit` / `lit cmp col` over non-null Int64/UInt64/Float64 columns (cols[] names
-// them; which loaded word of a row serves a test — ConjTest::src — is the consumer's business).  Postfix layout:
-// [a0 a1 cmpA b0 b1 cmpB and/or].
+// `A and B [and …]` / `A or B [or …]`, two to CONJ_MAX leaves `col cmp lit` / `lit cmp col` over non-null Int64/UInt64/Float64
+// columns, in any association of the one operator (cols[] names the tested column of every test; which loaded word of a row
+// serves a test — ConjTest::src — is the consumer's business).  Nodes are in postfix order.
 bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred *out, int *cols) {
-    if (n != 7 || nodes[6].kind != NQE_EXPR_BINARY || (nodes[6].op != NQE_OP_AND && nodes[6].op != NQE_OP_OR)) return false;
+    if (n < 7 || n > 4 * CONJ_MAX - 1 || nodes[n - 1].kind != NQE_EXPR_BINARY) return false;
+    const int root_op = nodes[n - 1].op;
+    if (root_op != NQE_OP_AND && root_op != NQE_OP_OR) return false;
+    // first node of the subtree that ends at node i
+    int start[4 * CONJ_MAX], stack[4 * CONJ_MAX], sp = 0;
+    for (int i = 0; i < n; ++i) {
+        if (nodes[i].kind == NQE_EXPR_BINARY) {
+            if (sp < 2) return false;
+            sp -= 2;
+            start[i] = stack[sp];
+        } else
+            start[i] = i;
+        stack[sp++] = start[i];
+    }
+    if (sp != 1) return false;
     std::memset(out, 0, sizeof(*out));
-    for (int t = 0; t < 2; ++t) {
-        const nqe_expr_node *leaf = nodes + 3 * t;
+    int todo[4 * CONJ_MAX], nt = 0;
+    todo[nt++] = n - 1;
+    int leaves[CONJ_MAX], nl = 0;
+    while (nt) {
+        const int i = todo[--nt];
+        if (nodes[i].kind == NQE_EXPR_BINARY && nodes[i].op == root_op) {
+            todo[nt++] = start[i - 1] - 1; // left operand's root (examined after the right one: leaves come out right to left)
+            todo[nt++] = i - 1;
+        } else {
+            if (nl == CONJ_MAX) return false;
+            leaves[nl++] = i;
+        }
+    }
+    if (nl < 2) return false;
+    for (int t = 0; t < nl; ++t) {
+        const int i = leaves[nl - 1 - t]; // left to right
+        if (i - start[i] != 2) return false;
+        const nqe_expr_node *leaf = nodes + start[i];
         if (leaf[2].kind != NQE_EXPR_BINARY || leaf[2].op > NQE_OP_GT_EQ) return false;
         if (!((leaf[0].kind == NQE_EXPR_COLUMN && leaf[1].kind == NQE_EXPR_LITERAL) || (leaf[0].kind == NQE_EXPR_LITERAL && leaf[1].kind == NQE_EXPR_COLUMN)))
             return false;
@@ -768,7 +798,8 @@ bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred
         out->t[t].fmask = fp.fmask;
         out->t[t].negate = fp.negate;
     }
-    out->is_or = nodes[6].op == NQE_OP_OR ? 1 : 0;
+    out->n = nl;
+    out->is_or = root_op == NQE_OP_OR ? 1 : 0;
     return true;
 }
 

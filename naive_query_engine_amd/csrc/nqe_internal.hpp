@@ -253,22 +253,27 @@ struct FastPred {
     // the same order (negative values reversed); NaNs land beyond ±inf and are excluded by [lo, hi].  0 for integers.
     uint64_t fmask;
 };
-// `A and B` / `A or B` of two range tests `col cmp lit` over non-null 8-byte columns the consuming kernel reads anyway (its key
-// column, its first value column) plus at most one more column: a WHERE clause's usual shape, tested per row inside the
-// aggregate kernel instead of through a materialised Boolean column (one more pass over the predicate's columns)
+// `A and B [and C [and D]]` / the same with `or`: up to four range tests `col cmp lit` over non-null 8-byte columns — a WHERE
+// clause's usual shape — tested per row inside the consuming kernel (the aggregate's streaming kernel when the columns are its key
+// column, its first value column and at most one more; the selection's keep-mask kernel over up to four columns) instead of
+// through a materialised Boolean column (one more pass over the predicate's columns)
+constexpr int CONJ_MAX = 4;
 struct ConjTest {
     int64_t lo, hi;
     uint64_t flip;  // sign bit for UInt64 operands
     uint64_t fmask; // Float64 operands: order map (see FastPred::fmask), 0 for integers
     int32_t negate;
-    int32_t src;    // which loaded word of the row: 0 key column, 1 first value column, 2 the predicate column
+    int32_t src;    // which loaded word of the row (aggregate: 0 key column, 1 first value column, 2 the predicate column;
+                    // selection: the column's slot among the distinct tested columns)
 };
 struct ConjPred {
-    ConjTest t[2];
+    ConjTest t[CONJ_MAX];
+    int32_t n;       // tests
     int32_t is_or;
-    int32_t need_pw; // some test reads the predicate column (src == 2)
+    int32_t need_pw; // aggregate: some test reads the predicate column (src == 2)
+    int32_t pad;
 };
-// recognises the shape (see expr.hip); cols[2] receive the two tested columns
+// recognises the shape (see expr.hip); cols[CONJ_MAX] receive the tested column of every test
 bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred *out, int *cols);
 // FastPred "bit r of a non-null Boolean bitmap is set"
 FastPred bitmap_fast_pred();

@@ -108,11 +108,15 @@ __global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *value
     }
 }
 
-// keep mask of `A and B` / `A or B`, two range tests over one or two plain 8-byte columns (ConjTest::src 0: column a, 2: column b):
-// the WHERE clause's usual shape in one streaming pass over its column(s), without the expression machine's Boolean column
-template <bool TWO>
-__global__ void __launch_bounds__(256) keep_from_conj_kernel(const uint64_t *__restrict__ wa, const uint64_t *__restrict__ wb, ConjPred c, int64_t n,
-                                                             int64_t ntiles, uint64_t *keep, uint32_t *tile_counts) {
+// keep mask of `A and B [and …]` / `A or B [or …]`, up to four range tests over NC <= 4 plain 8-byte columns (ConjTest::src = the
+// column's slot): the WHERE clause's usual shape in one streaming pass over its column(s), without the expression machine's
+// Boolean column
+struct ConjCols {
+    const uint64_t *w[CONJ_MAX];
+};
+template <int NC>
+__global__ void __launch_bounds__(256) keep_from_conj_kernel(ConjCols cols, ConjPred c, int64_t n, int64_t ntiles, uint64_t *keep, uint32_t *tile_counts) {
+    constexpr int B = NC <= 2 ? SEL_B : SEL_B / 2; // words in flight per lane stay at 8-16
     const int waves_per_block = blockDim.x / 64;
     const int64_t last = n - 1;
     for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
@@ -120,19 +124,19 @@ __global__ void __launch_bounds__(256) keep_from_conj_kernel(const uint64_t *__r
         const int64_t row0 = tile * TILE_ROWS;
         uint32_t total = 0;
 #pragma unroll 2
-        for (int k0 = 0; k0 < TILE_WORDS; k0 += SEL_B) {
-            uint64_t a[SEL_B], b[SEL_B];
+        for (int k0 = 0; k0 < TILE_WORDS; k0 += B) {
+            uint64_t w[CONJ_MAX][B];
 #pragma unroll
-            for (int k = 0; k < SEL_B; ++k) {
+            for (int k = 0; k < B; ++k) {
                 int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
                 row = row < last ? row : last;
-                a[k] = __builtin_nontemporal_load(&wa[row]);
-                b[k] = TWO ? __builtin_nontemporal_load(&wb[row]) : 0ull;
+#pragma unroll
+                for (int q = 0; q < CONJ_MAX; ++q) w[q][k] = q < NC ? __builtin_nontemporal_load(&cols.w[q][row]) : 0ull;
             }
 #pragma unroll
-            for (int k = 0; k < SEL_B; ++k) {
+            for (int k = 0; k < B; ++k) {
                 const int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
-                const uint64_t kw = __ballot(row < n && conj_pass(c, a[k], 0ull, b[k]));
+                const uint64_t kw = __ballot(row < n && conj_pass<NC>(c, w[0][k], w[1][k], w[2][k], w[3][k]));
                 if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
                 total += __popcll(kw);
             }
@@ -304,19 +308,22 @@ KeepMask build_keep_mask_conj(nqe_ctx *ctx, const nqe_table *in, ConjPred c, con
     const int64_t nwords = (km.n + 63) / 64;
     km.keep = dev_alloc(ctx, size_t(nwords) * 8 + 8);
     BufRef counts = dev_alloc(ctx, size_t(km.ntiles + 1) * 4);
-    const bool two = cols[0] != cols[1];
-    c.t[0].src = 0;
-    c.t[1].src = two ? 2 : 0;
-    c.need_pw = two ? 1 : 0;
+    // the distinct tested columns, each loaded once per row
+    ConjCols cc{};
+    int slot_col[CONJ_MAX], nc = 0;
+    for (int t = 0; t < c.n; ++t) {
+        int q = 0;
+        while (q < nc && slot_col[q] != cols[t]) ++q;
+        if (q == nc) {
+            slot_col[nc] = cols[t];
+            cc.w[nc++] = in->cols[size_t(cols[t])].words();
+        }
+        c.t[t].src = q;
+    }
     if (km.ntiles) {
         dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
-        const uint64_t *wa = in->cols[size_t(cols[0])].words(), *wb = in->cols[size_t(cols[1])].words();
-        if (two)
-            launch(ctx, "keep_from_conj", keep_from_conj_kernel<true>, grid, block, 0, wa, wb, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr,
-                   (uint32_t *)counts->ptr);
-        else
-            launch(ctx, "keep_from_conj", keep_from_conj_kernel<false>, grid, block, 0, wa, wb, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr,
-                   (uint32_t *)counts->ptr);
+        auto k = nc == 1 ? keep_from_conj_kernel<1> : nc == 2 ? keep_from_conj_kernel<2> : nc == 3 ? keep_from_conj_kernel<3> : keep_from_conj_kernel<4>;
+        launch(ctx, "keep_from_conj", k, grid, block, 0, cc, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
     }
     return finish_mask(ctx, km, counts);
 }
@@ -393,7 +400,7 @@ static KeepMask mask_for_predicate(nqe_ctx *ctx, const nqe_table *in, const nqe_
         fail(NQE_ERR_NOT_SUPPORTED, "predicate is not a BooleanArray (selection.rs:61 unwrap panics)");
     if (info.simple) return build_keep_mask_simple(ctx, in, info.s);
     ConjPred conj;
-    int conj_cols[2];
+    int conj_cols[CONJ_MAX];
     if (match_conj(in, pred, pred_nodes, &conj, conj_cols)) return build_keep_mask_conj(ctx, in, conj, conj_cols);
     DevColumn p = evaluate_expr(ctx, in, pred, pred_nodes);
     return build_keep_mask(ctx, p, in->rows);

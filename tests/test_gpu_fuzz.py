@@ -64,8 +64,13 @@ def _random_leaf(rng):
 
 def random_pred(rng):
     kind = int(rng.integers(0, 12))
-    if kind == 9 or kind == 10:  # two tests joined by and / or: inside the streaming aggregate kernel when its columns allow
-        return binop(_random_leaf(rng), Operator.And if kind == 9 else Operator.Or, _random_leaf(rng))
+    if kind == 9 or kind == 10:  # two to five tests joined by and / or (any association): in-kernel when the columns allow
+        op = Operator.And if kind == 9 else Operator.Or
+        parts = [_random_leaf(rng) for _ in range(int(rng.integers(2, 6)))]
+        while len(parts) > 1:
+            i = int(rng.integers(0, len(parts) - 1))
+            parts[i:i + 2] = [binop(parts[i], op, parts[i + 1])]
+        return parts[0]
     if kind == 11:  # Float64 chain ending in a comparison
         e = col(2)
         for _ in range(int(rng.integers(1, 4))):

@@ -951,6 +951,13 @@ def test_selection_two_test_predicates(ctx, n):
              binop(binop(V, Operator.NotEq, lit_f64(float("nan"))), A, binop(V, Operator.Lt, lit_f64(float("inf")))),  # != NaN is true for every row
              binop(binop(V, Operator.Eq, lit_f64(float("nan"))), O, binop(K, Operator.Eq, lit_i64(7))),
              binop(binop(Z, Operator.Lt, lit_i64(50)), A, binop(K, Operator.Gt, lit_i64(-100)))]                  # nullable column: the general path (Kleene)
+    l1, l2, l3 = binop(K, Operator.GtEq, lit_i64(-30)), binop(V, Operator.Lt, lit_f64(40.0)), binop(U, Operator.Gt, lit_u64(1 << 36))
+    l4, l5 = binop(K, Operator.NotEq, lit_i64(3)), binop(V, Operator.GtEq, lit_f64(-45.0))
+    preds += [binop(binop(l1, A, l2), A, l3),                       # three tests over three columns, left-deep
+              binop(l1, A, binop(l2, A, binop(l3, A, l4))),         # four tests, right-deep
+              binop(binop(l1, O, l2), O, binop(l3, O, l4)),         # four tests, balanced, or
+              binop(binop(binop(binop(l1, A, l2), A, l3), A, l4), A, l5),   # five tests: the general path
+              binop(binop(l1, A, l2), O, l3)]                       # mixed and / or: the general path
     for pred in preds:
         exp = orc.selection([cols], pred.flatten(f4))[0]
         got = ctx.selection(t, pred.flatten(f4)).to_host()
@@ -986,6 +993,12 @@ def test_aggregate_two_test_predicates(ctx, groups):
              binop(binop(U, Operator.Lt, lit_u64(1 << 39)), O, binop(V, Operator.NotEq, lit_f64(0.0))),            # UInt64 + Float64 (!= is true for NaN)
              binop(binop(W, Operator.Lt, lit_i64(0)), A, binop(U, Operator.Gt, lit_u64(1 << 38))),                 # two other columns: materialised
              binop(binop(Z, Operator.Lt, lit_i64(50)), A, binop(K, Operator.Gt, lit_i64(-100)))]                   # nullable column: materialised (Kleene)
+    l1, l2, l3, l4 = (binop(K, Operator.GtEq, lit_i64(-groups // 4)), binop(V, Operator.Lt, lit_f64(40.0)), binop(W, Operator.Gt, lit_i64(-900)),
+                      binop(W, Operator.NotEq, lit_i64(5)))
+    preds += [binop(binop(l1, A, l2), A, l3),                       # three tests: key, value, one more column
+              binop(l1, A, binop(l2, A, binop(l3, A, l4))),         # four tests, right-deep
+              binop(binop(l1, O, l2), O, binop(l3, O, l4)),         # four tests, or
+              binop(binop(l1, A, l2), O, l3)]                       # mixed and / or: materialised
     for pred in preds:
         for aggs in (ALL_AGGS(1), ALL_AGGS(1) + ALL_AGGS(2)):
             for key in (K, binop(K, Operator.Modulos, lit_i64(1 << 20))):
