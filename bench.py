@@ -25,6 +25,7 @@ as the main line; `--no-configs` skips the block (used under rocprofv3).
 """
 import argparse
 import json
+import math
 import os
 import socket
 import sys
@@ -141,11 +142,23 @@ class Bench:
         (self.min_warm_s > 0) additionally warm up for a minimum wall time: they start right behind seconds of CPU-only work (the
         oracle), from a GPU that has clocked down."""
         t_w = time.perf_counter()
-        done = 0
-        while done < warmup or (time.perf_counter() - t_w) < self.min_warm_s:
+        for _ in range(warmup):
             r = step()
             del r
-            done += 1
+        if self.min_warm_s > 0:
+            # the extra steps are a COUNT every rank agrees on (max over ranks): a step may hold a collective, and ranks that
+            # looped on their own clocks would issue different numbers of them
+            if warmup == 0:
+                r = step()
+                del r
+            self.ctx.synchronize()
+            elapsed = time.perf_counter() - t_w
+            per = max(elapsed / max(warmup, 1), 1e-4)
+            extra = min(2000, int(math.ceil(max(0.0, self.min_warm_s - elapsed) / per)))
+            extra = int(self.max_over_ranks(float(extra)))
+            for _ in range(extra):
+                r = step()
+                del r
         self.barrier()
         self.ctx.timing_enable(True)
         self.ctx.timing_reset()
