@@ -356,6 +356,8 @@ def make_join_data(B, rows, nb, sparse, first):
 def wl_c4(B, rows, nb, sparse, steps, warmup, gather=False):
     from naive_query_engine_amd import DType
 
+    torch = B.torch
+
     n, first = rows, B.rank * rows
     dkey, attr, fkey, val = make_join_data(B, n, nb, sparse, first)
     dim = B.ctx.table_from_device([(DType.INT64, nb, dkey.data_ptr(), None), (DType.INT64, nb, attr.data_ptr(), None)])
@@ -380,10 +382,40 @@ def wl_c4(B, rows, nb, sparse, steps, warmup, gather=False):
              "frac_end_to_end": algo / ((ms + build_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
              "note": "frac = SURVEY 8d's 48 B/probe row over the probe kernels; frac_physical = the 40 B/row that move (shared key column); "
                      "frac_end_to_end = 8d bytes over build + probe wall time (HashJoin::execute)"}
+    gather_check = None
+    if B.comm is not None and gather:
+        # no oracle at this size: size-independent properties of the GATHERED output on every rank — every probe row matches once,
+        # so the output has n x world rows in rank order: this rank's slice of the fact-key column is its own fact keys, the whole
+        # column sums to the sum of every rank's keys, and the dim key column equals the fact key column row by row
+        from naive_query_engine_amd.parallel import table_columns_as_tensors
+
+        out_t = probe()
+        B.ctx.synchronize()
+        ok = out_t.num_rows == n * B.world and out_t.num_columns == 4
+        if ok:
+            cols_t = table_columns_as_tensors(out_t, B.dev)
+            mine = cols_t[2][B.rank * n:(B.rank + 1) * n]
+            ok = bool(torch.equal(mine, fkey)) and bool(torch.equal(cols_t[0], cols_t[2]))
+            sums = torch.stack([fkey.sum(), val.view(torch.int64).sum()])
+            if B.distributed:
+                B.dist.all_reduce(sums)  # int64 sums wrap identically everywhere
+            ok = ok and int(cols_t[2].sum()) == int(sums[0]) and int(cols_t[3].sum()) == int(sums[1])
+            del cols_t, mine
+        okt = torch.tensor([1 if ok else 0], device=B.dev)
+        if B.distributed:
+            B.dist.all_reduce(okt, op=B.dist.ReduceOp.MIN)
+        gather_check = {"ok": bool(int(okt.item())), "rows": int(out_t.num_rows),
+                        "what": "gathered join output on every rank: n x world rows, own slice == own fact keys, dim key == fact key, column sums == all-rank sums"}
+        del out_t
+        if not gather_check["ok"]:
+            sys.stderr.write("bench.py: the gathered join output failed its check\n")
+            sys.exit(3)
     res = {"metric": "hash_join_probe_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms,
            "workload": f"dim(id,attr) {nb} rows ({'sparse 2^40-domain' if sparse else 'dense'} unique keys, LEFT/build) join fact(key,val) {n} rows per GPU "
                        f"(RIGHT/probe), 1 match per probe row; 4 output columns{'; outputs all-gathered in rank order' if gather else ''}",
            "rows_per_gpu": n, "build_rows": nb, "roofline": roofline(algo, kernels, names, extra)}
+    if gather_check:
+        res["gather_check"] = gather_check
     return res, dict(dim=dim, jt=jt, dkey=dkey, attr=attr, fkey=fkey, val=val, n=n, nb=nb, fact=fact)
 
 

@@ -249,5 +249,6 @@ def test_bench_multi_rank_block_dry_run_on_one_rank():
     d = json.loads(line)  # the JSON line is the last line of stdout
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["rccl_version"] > 0 and d["result_check"]["ok"]
     assert {"headline_local_only", "c5_probe_only", "c5_probe_and_gather", "c5"} <= set(d["configs"])
+    assert d["configs"]["c5_probe_and_gather"]["gather_check"]["ok"]
     c5 = d["configs"]["c5"]
     assert c5["end_to_end_ms"] >= c5["probe_only_ms"] > 0 and "exchange_ms_per_step" in d
