@@ -495,6 +495,7 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
         uint64_t my_word = w < nwords ? keep[w] : 0;
         uint32_t tot;
         uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+        if (tot == 0) continue; // no probe row of this tile matched (wave-uniform): nothing of it is read again
         const uint64_t base = tile_offsets[tile];
         for (int k0 = 0; k0 < TILE_WORDS; k0 += FW_B) {
             uint64_t key[FW_B];

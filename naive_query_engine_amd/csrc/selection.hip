@@ -166,6 +166,8 @@ __global__ void __launch_bounds__(256) compact_kernel(const void *src_values, in
         uint64_t my_pv = (!PLAINW && pvalid && w < nwords) ? pvalid[w] : ~0ull;
         uint32_t tot;
         uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+        if (tot == 0) continue; // nothing kept in these 4096 rows (wave-uniform): their source words are not read at all — a filter
+                                // on clustered data (sorted ids, time ranges) then moves only the kept part of every other column
         const uint64_t base = tile_offsets[tile];
         if (PLAINW) {
 #pragma unroll 2
