@@ -930,6 +930,39 @@ def test_aggregate_partitioned_path_many_groups(ctx, groups):
                 assert_rows_multiset_equal(got, exp, RTOL, exact_cols=counts, what=f"partitioned groups={groups} key={key!r}")
 
 
+def test_clustered_predicates_leave_whole_tiles_empty(ctx):
+    """a filter on sorted data keeps a contiguous range: the 4096-row tiles outside it hold no kept rows and the compaction / the
+    join's fused write skip them before their loads — the result is the reference's, empty tiles or not (first, last and inner
+    tiles empty; everything empty)"""
+    n = 9 * 4096 + 17
+    ids = np.arange(n, dtype=np.int64)
+    rng = np.random.default_rng(4)
+    v = rng.random(n) * 10
+    w = rng.integers(0, 50, n).astype(np.int64)
+    cols = [Column.from_numpy(ids), Column.from_numpy(v), Column.from_numpy(w), Column.from_numpy(w, rng.random(n) > 0.3)]
+    f4 = fields("id", "v", "w", "wn")
+    t = ctx.table_from_host(cols)
+    ID = col(0)
+    ranges = [(0, 5000), (3 * 4096, 5 * 4096), (n - 100, n), (20000, 20001), (n + 5, n + 9)]
+    for lo, hi in ranges:
+        pred = binop(binop(ID, Operator.GtEq, lit_i64(lo)), Operator.And, binop(ID, Operator.Lt, lit_i64(hi))).flatten(f4)
+        exp = orc.selection([cols], pred)[0]
+        assert_batches_equal(ctx.selection(t, pred).to_host(), exp, what=f"selection [{lo},{hi})")
+        proj = [binop(col(2), Operator.Plus, lit_i64(100)).flatten(f4), binop(binop(col(1), Operator.Multiply, col(1)), Operator.Plus, col(1)).flatten(f4),
+                col(3).flatten(f4)]
+        expp = orc.projection(orc.selection([cols], pred), proj)[0]
+        assert_batches_equal(ctx.selection_projection(t, pred, proj).to_host(), expp, what=f"selection + projection [{lo},{hi})")
+    # join: the dim covers one key range only (dense keys) / scattered keys inside one range (hashed), probe keys ascending
+    for lo, hi, stride in ((2 * 4096 + 5, 4 * 4096 + 9, 1), (5 * 4096, 7 * 4096, 97)):
+        dk = np.arange(lo, hi, stride, dtype=np.int64)
+        dk = dk[rng.permutation(len(dk))]
+        left = [Column.from_numpy(dk), Column.from_numpy(rng.integers(0, 1 << 20, len(dk)).astype(np.int64))]
+        right = [Column.from_numpy(ids), Column.from_numpy(v)]
+        exp = orc.hash_join([left], [right], 0, 0)[0]
+        got = ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 0, 0).to_host()
+        assert_batches_equal(got, exp, what=f"join, dim keys [{lo},{hi}) step {stride}")
+
+
 @pytest.mark.parametrize("n", [1, 63, 4096, 4097, 70001])
 def test_selection_two_test_predicates(ctx, n):
     """`A and B` / `A or B` of two compares with literals as a selection's predicate: one streaming pass over the tested
