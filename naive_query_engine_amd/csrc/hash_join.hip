@@ -48,7 +48,7 @@ struct nqe_join_table {
     std::vector<nqe::BufRef> dense_cols;  // per left column (null for the key column)
     // Int64/UInt64 payloads whose value range fits 32 bits are stored as uint32 offsets from their minimum (frame of
     // reference): the gather target halves, so more of it stays in the 4 MB per-XCD L2 (the probe is gather-bound)
-    std::vector<int> dense_packed;        // 1: dense_cols[ci] holds uint32 (value - dense_base[ci])
+    std::vector<int> dense_packed;        // dense_cols[ci] holds value - dense_base[ci] as 1: uint32, 2: three bytes, 3: uint16
     std::vector<uint64_t> dense_base;
     bool dense_payload = false;
     bool dense_full = false; // every key of the dense range occurs
@@ -174,7 +174,7 @@ struct DensePayload {
     const uint64_t *src[MAX_JOIN_COLS];
     void *dst[MAX_JOIN_COLS];
     uint64_t base[MAX_JOIN_COLS];
-    int32_t packed[MAX_JOIN_COLS]; // 1: dst holds uint32 (value - base)
+    int32_t packed[MAX_JOIN_COLS]; // 1: dst holds uint32 (value - base); 2: three bytes per entry (value - base < 2^24); 3: uint16
 };
 __global__ void __launch_bounds__(256) dense_unique_build_kernel(const uint64_t *keys, int64_t n, uint64_t dmin, uint32_t *dense, uint32_t *presence,
                                                                  DensePayload dp, int *dup) {
@@ -190,7 +190,14 @@ __global__ void __launch_bounds__(256) dense_unique_build_kernel(const uint64_t 
         dense[d] = uint32_t(r) + 1u;
         for (int c = 0; c < dp.n; ++c) {
             const uint64_t v = dp.src[c][r];
-            if (dp.packed[c]) static_cast<uint32_t *>(dp.dst[c])[d] = uint32_t(v - dp.base[c]);
+            if (dp.packed[c] == 3) static_cast<uint16_t *>(dp.dst[c])[d] = uint16_t(v - dp.base[c]);
+            else if (dp.packed[c] == 2) {
+                const uint32_t o = uint32_t(v - dp.base[c]);
+                uint8_t *b = static_cast<uint8_t *>(dp.dst[c]) + 3 * d;
+                b[0] = uint8_t(o);
+                b[1] = uint8_t(o >> 8);
+                b[2] = uint8_t(o >> 16);
+            } else if (dp.packed[c]) static_cast<uint32_t *>(dp.dst[c])[d] = uint32_t(v - dp.base[c]);
             else static_cast<uint64_t *>(dp.dst[c])[d] = v;
         }
     }
@@ -474,7 +481,7 @@ struct FusedCols {
     int32_t n;
     int32_t pad;
     int32_t kind[MAX_JOIN_COLS];        // 0: probe-side column (coalesced copy), 1: build key (= probe key), 2: build payload (gather),
-                                        // 3: build payload packed as uint32 offsets from base[] (gather)
+                                        // 3: build payload packed as uint32 offsets from base[] (gather), 4: as three-byte offsets, 5: as uint16 offsets
     const uint64_t *src[MAX_JOIN_COLS]; // kind 0: probe column; kind 2/3: key-ordered build column
     uint64_t *dst[MAX_JOIN_COLS];
     uint64_t base[MAX_JOIN_COLS];
@@ -537,11 +544,25 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
                 } else if (kind == 2) {
 #pragma unroll
                     for (int k = 0; k < FW_B; ++k) v[k] = src[(kept >> k) & 1 ? gix[k] : 0];
-                } else {
+                } else if (kind == 3) {
                     const uint32_t *__restrict__ src32 = reinterpret_cast<const uint32_t *>(src);
                     const uint64_t b0 = fc.base[c];
 #pragma unroll
                     for (int k = 0; k < FW_B; ++k) v[k] = b0 + src32[(kept >> k) & 1 ? gix[k] : 0];
+                } else if (kind == 5) {
+                    const uint16_t *__restrict__ src16 = reinterpret_cast<const uint16_t *>(src);
+                    const uint64_t b0 = fc.base[c];
+#pragma unroll
+                    for (int k = 0; k < FW_B; ++k) v[k] = b0 + src16[(kept >> k) & 1 ? gix[k] : 0];
+                } else { // three bytes per entry: one unaligned 4-byte load (the table is padded), the fourth byte masked off
+                    const uint8_t *__restrict__ src8 = reinterpret_cast<const uint8_t *>(src);
+                    const uint64_t b0 = fc.base[c];
+#pragma unroll
+                    for (int k = 0; k < FW_B; ++k) {
+                        uint32_t x;
+                        __builtin_memcpy(&x, src8 + 3 * ((kept >> k) & 1 ? gix[k] : 0), 4);
+                        v[k] = b0 + (x & 0xFFFFFFu);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < FW_B; ++k)
@@ -816,14 +837,20 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             for (size_t ci = 0; ci < ncols; ++ci) {
                 if (int(ci) == jt->left_key) continue;
                 const DevColumn &pc = left->cols[ci];
-                bool packed = false;
+                int packed = 0;
                 for (size_t k = 1; k < mm_cols.size(); ++k)
                     if (mm_cols[k] == int(ci) && mmh[2 * k + 1] - mmh[2 * k] <= 0xffffffffull) { // value range within 32 bits → uint32 offsets
-                        packed = true;
+                        // … within 24 bits → three bytes per entry: the smaller the key-ordered table, the more of the probe's gathers
+                        // hit the 4 MB L2 (10^6 keys: 3 MB instead of 4)
+                        static const bool no24 = getenv("NQE_JOIN_NO_PACK24") != nullptr; // diagnostics (A/B)
+                        const uint64_t range = mmh[2 * k + 1] - mmh[2 * k];
+                        packed = no24 ? 1 : (range <= 0xffffull ? 3 : (range <= 0xffffffull ? 2 : 1));
                         dense_base[ci] = mmh[2 * k] ^ (pc.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull);
                     }
-                dense_packed[ci] = packed ? 1 : 0;
-                dense_cols[ci] = packed ? dev_alloc_zero(ctx, size_t(span) * 4 + 8) : dev_alloc(ctx, size_t(span) * 8);
+                dense_packed[ci] = packed;
+                dense_cols[ci] = packed == 3 ? dev_alloc_zero(ctx, size_t(span) * 2 + 8)
+                                 : packed == 2 ? dev_alloc_zero(ctx, size_t(span) * 3 + 8)
+                                               : (packed ? dev_alloc_zero(ctx, size_t(span) * 4 + 8) : dev_alloc(ctx, size_t(span) * 8));
                 dp.src[dp.n] = pc.words();
                 dp.dst[dp.n] = dense_cols[ci]->ptr;
                 dp.base[dp.n] = dense_base[ci];
@@ -1086,7 +1113,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
                 continue;
             }
             out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
-            fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : (jt->dense_packed[ci] ? 3 : 2);
+            fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : (jt->dense_packed[ci] == 3 ? 5 : jt->dense_packed[ci] == 2 ? 4 : (jt->dense_packed[ci] ? 3 : 2));
             fc.base[fc.n] = int(ci) == jt->left_key ? 0 : jt->dense_base[ci];
             fc.src[fc.n] = int(ci) == jt->left_key ? nullptr : (const uint64_t *)jt->dense_cols[ci]->ptr;
             fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;

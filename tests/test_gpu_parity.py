@@ -930,6 +930,28 @@ def test_aggregate_partitioned_path_many_groups(ctx, groups):
                 assert_rows_multiset_equal(got, exp, RTOL, exact_cols=counts, what=f"partitioned groups={groups} key={key!r}")
 
 
+@pytest.mark.parametrize("span_bits", [7, 16, 17, 24, 25, 40])
+def test_join_payload_packing_widths(ctx, span_bits):
+    """dense unique build keys with plain payloads: the key-ordered payload table holds value - min in 2, 3 or 4 bytes when the
+    column's range allows (8 otherwise) — every width, at its boundary values, for Int64 (negative minimum), UInt64 and a
+    Float64 payload (never packed) in one build"""
+    rng = np.random.default_rng(span_bits)
+    nb, n = 5000, 60000
+    dk = rng.permutation(nb).astype(np.int64) + 1000
+    top = (1 << span_bits) - 1
+    a = rng.integers(0, top + 1, nb).astype(np.int64) - (1 << 20)       # range of exactly span_bits bits, negative minimum
+    a[:2] = [-(1 << 20), top - (1 << 20)]
+    b = rng.integers(0, top + 1, nb).astype(np.uint64) + np.uint64(1 << 62)
+    b[:2] = [np.uint64(1 << 62), np.uint64((1 << 62) + top)]
+    c = rng.random(nb)
+    left = [Column.from_numpy(dk), Column.from_numpy(a), Column.from_numpy(b), Column.from_numpy(c)]
+    rk = rng.integers(900, nb + 1100, n).astype(np.int64)           # some keys outside the build range
+    right = [Column.from_numpy(rk), Column.from_numpy(rng.random(n))]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    got = ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 0, 0).to_host()
+    assert_batches_equal(got, exp, what=f"payload range of {span_bits} bits")
+
+
 def test_clustered_predicates_leave_whole_tiles_empty(ctx):
     """a filter on sorted data keeps a contiguous range: the 4096-row tiles outside it hold no kept rows and the compaction / the
     join's fused write skip them before their loads — the result is the reference's, empty tiles or not (first, last and inner
