@@ -339,14 +339,15 @@ def parity_c2(B, st, sample_rows):
     return {"rows": m, "ok": ok, "tolerance": "bit-exact"}, cpu
 
 
-def make_join_data(B, rows, nb, sparse, first):
+def make_join_data(B, rows, nb, sparse, first, wide=False):
     """dim(id unique, attr) = LEFT/build, fact(key, val) = RIGHT/probe, every probe row matches once.
     dense: id = a permutation of 0..nb-1 (the direct-address PK-FK path); sparse: unique ids spread over a 2^20 x nb domain (the
     general hashed path)."""
     torch = B.torch
     g = torch.Generator(device=B.dev).manual_seed(7)
     perm = torch.randperm(nb, device=B.dev, generator=g).to(torch.int64)
-    attr = B.synth(1, 4, nb, 0, 1 << 20, 0)
+    # the dim attribute: 20 bits of range (stored bit-packed in the key-ordered payload table of the dense path), or — `wide` — 62 bits
+    attr = B.synth(1, 4, nb, 0, (1 << 62) if wide else (1 << 20), 0)
     fidx = B.synth(1, 5, rows, first, nb, 0)  # which dim row a fact row references
     if sparse:
         # unique by construction: key j = j * 2^20 + (u(j, 11) mod 2^20): span 2^20 x nb, far beyond the direct-address limit
@@ -361,13 +362,13 @@ def make_join_data(B, rows, nb, sparse, first):
     return dkey, attr, fkey, val
 
 
-def wl_c4(B, rows, nb, sparse, steps, warmup, gather=False):
+def wl_c4(B, rows, nb, sparse, steps, warmup, gather=False, wide=False):
     from naive_query_engine_amd import DType
 
     torch = B.torch
 
     n, first = rows, B.rank * rows
-    dkey, attr, fkey, val = make_join_data(B, n, nb, sparse, first)
+    dkey, attr, fkey, val = make_join_data(B, n, nb, sparse, first, wide)
     dim = B.ctx.table_from_device([(DType.INT64, nb, dkey.data_ptr(), None), (DType.INT64, nb, attr.data_ptr(), None)])
     fact = B.ctx.table_from_device([(DType.INT64, n, fkey.data_ptr(), None), (DType.FLOAT64, n, val.data_ptr(), None)])
     # build (HashJoin::build, hash_join.rs:124-166): timed on its own — replicated on every rank, once per query
@@ -419,7 +420,7 @@ def wl_c4(B, rows, nb, sparse, steps, warmup, gather=False):
             sys.stderr.write("bench.py: the gathered join output failed its check\n")
             sys.exit(3)
     res = {"metric": "hash_join_probe_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms,
-           "workload": f"dim(id,attr) {nb} rows ({'sparse 2^40-domain' if sparse else 'dense'} unique keys, LEFT/build) join fact(key,val) {n} rows per GPU "
+           "workload": f"dim(id,attr{' of 62-bit range' if wide else ' of 20-bit range'}) {nb} rows ({'sparse 2^40-domain' if sparse else 'dense'} unique keys, LEFT/build) join fact(key,val) {n} rows per GPU "
                        f"(RIGHT/probe), 1 match per probe row; 4 output columns{'; outputs all-gathered in rank order' if gather else ''}",
            "rows_per_gpu": n, "build_rows": nb, "roofline": roofline(algo, kernels, names, extra)}
     if gather_check:
@@ -550,6 +551,7 @@ def main():
             add("c3_random_keys", lambda: wl_aggregate(B, n, False, True, csteps, cwarm))
             add("c2", lambda: wl_c2(B, 10**8, csteps, cwarm), lambda s: parity_c2(B, s, 20_000_000))
             add("c4", lambda: wl_c4(B, 10**8, 10**6, False, csteps, cwarm), lambda s: parity_c4(B, s, 5_000_000))
+            add("c4_wide_payload", lambda: wl_c4(B, 10**8, 10**6, False, csteps, cwarm, wide=True))  # attr spans 2^62: an 8 MB payload table
             add("c4_dim_1e7", lambda: wl_c4(B, 10**8, 10**7, False, csteps, cwarm))
             add("c4_sparse_keys", lambda: wl_c4(B, 10**8, 10**6, True, csteps, cwarm), lambda s: parity_c4(B, s, 5_000_000))
             for G in (4096, 65536, 1 << 20):

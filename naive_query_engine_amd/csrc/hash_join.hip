@@ -48,7 +48,7 @@ struct nqe_join_table {
     std::vector<nqe::BufRef> dense_cols;  // per left column (null for the key column)
     // Int64/UInt64 payloads whose value range fits 32 bits are stored as uint32 offsets from their minimum (frame of
     // reference): the gather target halves, so more of it stays in the 4 MB per-XCD L2 (the probe is gather-bound)
-    std::vector<int> dense_packed;        // dense_cols[ci] holds value - dense_base[ci] as 1: uint32, 2: three bytes, 3: uint16
+    std::vector<int> dense_packed;        // dense_cols[ci] holds value - dense_base[ci] as 1: uint32, 2..25: that many bits per entry
     std::vector<uint64_t> dense_base;
     bool dense_payload = false;
     bool dense_full = false; // every key of the dense range occurs
@@ -174,7 +174,7 @@ struct DensePayload {
     const uint64_t *src[MAX_JOIN_COLS];
     void *dst[MAX_JOIN_COLS];
     uint64_t base[MAX_JOIN_COLS];
-    int32_t packed[MAX_JOIN_COLS]; // 1: dst holds uint32 (value - base); 2: three bytes per entry (value - base < 2^24); 3: uint16
+    int32_t packed[MAX_JOIN_COLS]; // 1: dst holds uint32 (value - base); 2..25: that many BITS per entry (value - base < 2^packed)
 };
 __global__ void __launch_bounds__(256) dense_unique_build_kernel(const uint64_t *keys, int64_t n, uint64_t dmin, uint32_t *dense, uint32_t *presence,
                                                                  DensePayload dp, int *dup) {
@@ -190,13 +190,14 @@ __global__ void __launch_bounds__(256) dense_unique_build_kernel(const uint64_t 
         dense[d] = uint32_t(r) + 1u;
         for (int c = 0; c < dp.n; ++c) {
             const uint64_t v = dp.src[c][r];
-            if (dp.packed[c] == 3) static_cast<uint16_t *>(dp.dst[c])[d] = uint16_t(v - dp.base[c]);
-            else if (dp.packed[c] == 2) {
-                const uint32_t o = uint32_t(v - dp.base[c]);
-                uint8_t *b = static_cast<uint8_t *>(dp.dst[c]) + 3 * d;
-                b[0] = uint8_t(o);
-                b[1] = uint8_t(o >> 8);
-                b[2] = uint8_t(o >> 16);
+            if (dp.packed[c] >= 2) {
+                // `packed` bits per entry (<= 25), entry d at bit d * packed of a zeroed table: neighbours share words, so the bits are
+                // OR-ed in (at most two aligned words per entry)
+                const uint64_t bit = d * uint64_t(dp.packed[c]);
+                const uint64_t o = uint64_t(uint32_t(v - dp.base[c])) << (bit & 31);
+                uint32_t *w = static_cast<uint32_t *>(dp.dst[c]) + (bit >> 5);
+                atomicOr(w, uint32_t(o));
+                if (o >> 32) atomicOr(w + 1, uint32_t(o >> 32));
             } else if (dp.packed[c]) static_cast<uint32_t *>(dp.dst[c])[d] = uint32_t(v - dp.base[c]);
             else static_cast<uint64_t *>(dp.dst[c])[d] = v;
         }
@@ -481,10 +482,11 @@ struct FusedCols {
     int32_t n;
     int32_t pad;
     int32_t kind[MAX_JOIN_COLS];        // 0: probe-side column (coalesced copy), 1: build key (= probe key), 2: build payload (gather),
-                                        // 3: build payload packed as uint32 offsets from base[] (gather), 4: as three-byte offsets, 5: as uint16 offsets
+                                        // 3: build payload packed as uint32 offsets from base[] (gather), 4: as bits[]-bit offsets
     const uint64_t *src[MAX_JOIN_COLS]; // kind 0: probe column; kind 2/3: key-ordered build column
     uint64_t *dst[MAX_JOIN_COLS];
     uint64_t base[MAX_JOIN_COLS];
+    int32_t bits[MAX_JOIN_COLS]; // kind 4: bits per entry
 };
 
 // pass 2: one read of the probe keys, every output column written in probe order
@@ -549,19 +551,16 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
                     const uint64_t b0 = fc.base[c];
 #pragma unroll
                     for (int k = 0; k < FW_B; ++k) v[k] = b0 + src32[(kept >> k) & 1 ? gix[k] : 0];
-                } else if (kind == 5) {
-                    const uint16_t *__restrict__ src16 = reinterpret_cast<const uint16_t *>(src);
-                    const uint64_t b0 = fc.base[c];
-#pragma unroll
-                    for (int k = 0; k < FW_B; ++k) v[k] = b0 + src16[(kept >> k) & 1 ? gix[k] : 0];
-                } else { // three bytes per entry: one unaligned 4-byte load (the table is padded), the fourth byte masked off
+                } else { // kind 4: `bits` per entry (<= 25): one unaligned 4-byte load holds the entry wherever it starts (the table is padded)
                     const uint8_t *__restrict__ src8 = reinterpret_cast<const uint8_t *>(src);
                     const uint64_t b0 = fc.base[c];
+                    const uint32_t nb = uint32_t(fc.bits[c]), mask = (1u << nb) - 1u;
 #pragma unroll
                     for (int k = 0; k < FW_B; ++k) {
+                        const uint64_t bit = ((kept >> k) & 1 ? gix[k] : 0) * nb;
                         uint32_t x;
-                        __builtin_memcpy(&x, src8 + 3 * ((kept >> k) & 1 ? gix[k] : 0), 4);
-                        v[k] = b0 + (x & 0xFFFFFFu);
+                        __builtin_memcpy(&x, src8 + (bit >> 3), 4);
+                        v[k] = b0 + ((x >> (uint32_t(bit) & 7u)) & mask);
                     }
                 }
 #pragma unroll
@@ -840,17 +839,18 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
                 int packed = 0;
                 for (size_t k = 1; k < mm_cols.size(); ++k)
                     if (mm_cols[k] == int(ci) && mmh[2 * k + 1] - mmh[2 * k] <= 0xffffffffull) { // value range within 32 bits → uint32 offsets
-                        // … within 24 bits → three bytes per entry: the smaller the key-ordered table, the more of the probe's gathers
-                        // hit the 4 MB L2 (10^6 keys: 3 MB instead of 4)
+                        // … within 25 bits → exactly as many bits per entry as the range needs: the smaller the key-ordered table, the more
+                        // of the probe's gathers hit the 4 MB L2 (10^6 keys of a 20-bit attribute: 2.5 MB instead of 4)
                         static const bool no24 = getenv("NQE_JOIN_NO_PACK24") != nullptr; // diagnostics (A/B)
                         const uint64_t range = mmh[2 * k + 1] - mmh[2 * k];
-                        packed = no24 ? 1 : (range <= 0xffffull ? 3 : (range <= 0xffffffull ? 2 : 1));
+                        int bits = 2;
+                        while (bits < 32 && (range >> bits) != 0) ++bits;
+                        packed = (no24 || bits > 25) ? 1 : bits; // <= 25 bits: any entry lies inside one unaligned 4-byte window
                         dense_base[ci] = mmh[2 * k] ^ (pc.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull);
                     }
                 dense_packed[ci] = packed;
-                dense_cols[ci] = packed == 3 ? dev_alloc_zero(ctx, size_t(span) * 2 + 8)
-                                 : packed == 2 ? dev_alloc_zero(ctx, size_t(span) * 3 + 8)
-                                               : (packed ? dev_alloc_zero(ctx, size_t(span) * 4 + 8) : dev_alloc(ctx, size_t(span) * 8));
+                dense_cols[ci] = packed >= 2 ? dev_alloc_zero(ctx, (size_t(span) * size_t(packed) + 7) / 8 + 16)
+                                             : (packed ? dev_alloc_zero(ctx, size_t(span) * 4 + 8) : dev_alloc(ctx, size_t(span) * 8));
                 dp.src[dp.n] = pc.words();
                 dp.dst[dp.n] = dense_cols[ci]->ptr;
                 dp.base[dp.n] = dense_base[ci];
@@ -1113,7 +1113,8 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
                 continue;
             }
             out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
-            fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : (jt->dense_packed[ci] == 3 ? 5 : jt->dense_packed[ci] == 2 ? 4 : (jt->dense_packed[ci] ? 3 : 2));
+            fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : (jt->dense_packed[ci] >= 2 ? 4 : (jt->dense_packed[ci] ? 3 : 2));
+            fc.bits[fc.n] = jt->dense_packed[ci];
             fc.base[fc.n] = int(ci) == jt->left_key ? 0 : jt->dense_base[ci];
             fc.src[fc.n] = int(ci) == jt->left_key ? nullptr : (const uint64_t *)jt->dense_cols[ci]->ptr;
             fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
