@@ -35,6 +35,8 @@ struct nqe_join_table {
     uint32_t cap = 0;
     int shift = 0;
     bool direct = false; // all build keys unique: slot.y>>32 is the build row itself
+    // a probe that found a key outside a gap-free build key range: later probes of this table take the two-pass form at once
+    mutable bool all_match_failed = false;
     // dense build keys (max-min+1 <= 4n): direct-address table instead of hashing.
     //   unique keys:   dense[key-min] = build row + 1
     //   duplicate keys: dense[key-min] = unique-key index + 1 → (ustart[u], ustart[u+1]-ustart[u])
@@ -492,20 +494,27 @@ struct FusedCols {
 // pass 2: one read of the probe keys, every output column written in probe order
 // `bidx` null: a build payload is addressed by key - dmin (key-ordered dense columns); non-null: by the build row recorded
 // per probe row by probe_unique_kernel (hashed unique keys), gathered from the build columns themselves.
-template <int FW_B> // rows per lane in flight
+// IDENT (the optimistic form of a PK-FK join, see probe): no keep bitmap and no offsets — every probe row is taken to match, output row =
+// probe row; a key outside [dmin, dmin + span) raises *miss and the host discards the output.
+template <int FW_B, bool IDENT = false> // FW_B: rows per lane in flight
 __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, const uint64_t *keep,
-                                                               const uint64_t *tile_offsets, uint64_t dmin, const uint32_t *bidx, FusedCols fc) {
+                                                               const uint64_t *tile_offsets, uint64_t dmin, const uint32_t *bidx, FusedCols fc,
+                                                               uint64_t span, int *miss) {
     const int waves_per_block = blockDim.x / 64;
     const int64_t nwords = (n + 63) / 64;
     const int64_t last = n - 1;
     for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
          tile += int64_t(gridDim.x) * waves_per_block) {
         int64_t w = tile * TILE_WORDS + lane_id();
-        uint64_t my_word = w < nwords ? keep[w] : 0;
-        uint32_t tot;
-        uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
-        if (tot == 0) continue; // no probe row of this tile matched (wave-uniform): nothing of it is read again
-        const uint64_t base = tile_offsets[tile];
+        uint64_t my_word = 0;
+        uint32_t tot = 0, my_off = 0;
+        uint64_t base = 0;
+        if (!IDENT) {
+            my_word = w < nwords ? keep[w] : 0;
+            my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+            if (tot == 0) continue; // no probe row of this tile matched (wave-uniform): nothing of it is read again
+            base = tile_offsets[tile];
+        }
         for (int k0 = 0; k0 < TILE_WORDS; k0 += FW_B) {
             uint64_t key[FW_B];
             uint32_t pos[FW_B]; // position inside the tile's output range
@@ -515,11 +524,26 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
                 int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
                 key[k] = __builtin_nontemporal_load(&rkeys[row < last ? row : last]); // streamed once: keep L2 for the gather
             }
+            if (IDENT) {
+                bool bad = false;
 #pragma unroll
-            for (int k = 0; k < FW_B; ++k) {
-                uint64_t word = bcast64(my_word, k0 + k);
-                pos[k] = bcast32(my_off, k0 + k) + __popcll(word & lanemask_lt());
-                kept |= uint32_t((word >> lane_id()) & 1) << k;
+                for (int k = 0; k < FW_B; ++k) {
+                    const int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                    const bool in = row < n;
+                    const bool ok = key[k] - dmin < span;
+                    bad = bad || (in && !ok);
+                    pos[k] = uint32_t(row - tile * TILE_ROWS);
+                    kept |= uint32_t(in && ok) << k;
+                }
+                if (bad) *miss = 1; // plain store of a constant
+                base = uint64_t(tile) * TILE_ROWS;
+            } else {
+#pragma unroll
+                for (int k = 0; k < FW_B; ++k) {
+                    uint64_t word = bcast64(my_word, k0 + k);
+                    pos[k] = bcast32(my_off, k0 + k) + __popcll(word & lanemask_lt());
+                    kept |= uint32_t((word >> lane_id()) & 1) << k;
+                }
             }
             uint64_t gix[FW_B]; // gather index of a build payload
 #pragma unroll
@@ -1070,6 +1094,64 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
     bool left_all_plain = ncols <= size_t(MAX_JOIN_COLS);
     for (auto &c : jt->left_cols) left_all_plain = left_all_plain && is_word_type(c.dtype) && !c.validity;
     if (jt->dense_payload && right_plain) {
+        auto build_out = [&](int64_t out_rows, FusedCols &fc) {
+        auto out = std::make_unique<nqe_table>();
+        out->ctx = ctx;
+        out->rows = out_rows;
+        std::memset(&fc, 0, sizeof(fc));
+        // In an equi-join on an integer key the build key column of the output IS the probe key column of the output, bit for
+        // bit: it is written once and the two output columns share the buffer (tables are immutable; 8 of the 32 output bytes
+        // per row of C4 are never written)
+        const bool share_key = share_key_column(jt->left_cols[size_t(jt->left_key)], rk);
+        int share_pos = -1, right_key_pos = -1;
+        for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
+            const DevColumn &c = jt->left_cols[ci];
+            if (int(ci) == jt->left_key && share_key) {
+                share_pos = int(out->cols.size());
+                out->cols.push_back(DevColumn{});
+                continue;
+            }
+            out->cols.push_back(make_word_column(ctx, c.dtype, out_rows, false));
+            fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : (jt->dense_packed[ci] >= 2 ? 4 : (jt->dense_packed[ci] ? 3 : 2));
+            fc.bits[fc.n] = jt->dense_packed[ci];
+            fc.base[fc.n] = int(ci) == jt->left_key ? 0 : jt->dense_base[ci];
+            fc.src[fc.n] = int(ci) == jt->left_key ? nullptr : (const uint64_t *)jt->dense_cols[ci]->ptr;
+            fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
+            fc.n++;
+        }
+        for (size_t cj = 0; cj < right->cols.size(); ++cj) {
+            const DevColumn &c = right->cols[cj];
+            out->cols.push_back(make_word_column(ctx, c.dtype, out_rows, false));
+            if (int(cj) == right_key) right_key_pos = int(out->cols.size()) - 1;
+            // the probe key column is in registers already (kind 1): loading it again as a probe-side column cost pass 2 8-15 %
+            // (C4 1.13 -> 1.04 ms, a 10 %-match join 0.70 -> 0.60 ms).  Requesting one more probe-side column together with the
+            // keys (33 more VGPRs) was neutral on top of that.
+            fc.kind[fc.n] = int(cj) == right_key ? 1 : 0;
+            fc.src[fc.n] = c.words();
+            fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
+            fc.n++;
+        }
+        if (share_pos >= 0) {
+            out->cols[size_t(share_pos)] = out->cols[size_t(right_key_pos)];
+            out->cols[size_t(share_pos)].dtype = jt->left_cols[size_t(jt->left_key)].dtype;
+        }
+        return out;
+        };
+        // Optimistic form: a build side whose keys fill their range without gaps is a primary key; a foreign key then matches on
+        // every row, the output row of a probe row is the probe row, and ONE pass (no presence pass, no scan, the probe keys read
+        // once) writes everything — while checking every key against the range.  A key outside it discards the output, and this
+        // join table takes the two-pass form from then on.
+        static const bool no_optimistic = getenv("NQE_JOIN_NO_OPTIMISTIC") != nullptr; // diagnostics (A/B)
+        if (jt->dense_full && !jt->all_match_failed && !no_optimistic && n > 0) {
+            FusedCols fc;
+            auto out = build_out(n, fc);
+            BufRef miss = dev_alloc_zero(ctx, 4);
+            const int64_t ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+            launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS, true>, dim3(stream_grid(ctx, ntiles, 4)), dim3(256), 0, rk.words(), n, ntiles,
+                   (const uint64_t *)nullptr, (const uint64_t *)nullptr, jt->dense_min, (const uint32_t *)nullptr, fc, jt->dense_span, (int *)miss->ptr);
+            if (!read_scalar(ctx, (const int *)miss->ptr)) return out;
+            jt->all_match_failed = true;
+        }
         // PK–FK fast path: presence test + counts, scan, then one fused write of every output column
         KeepMask km;
         km.n = n;
@@ -1095,50 +1177,11 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
                        n, km.ntiles, pp, jt->dense_min, jt->dense_span, kp, cp);
         }
         km = finish_mask(ctx, km, counts);
-        auto out = std::make_unique<nqe_table>();
-        out->ctx = ctx;
-        out->rows = km.total;
         FusedCols fc;
-        std::memset(&fc, 0, sizeof(fc));
-        // In an equi-join on an integer key the build key column of the output IS the probe key column of the output, bit for
-        // bit: it is written once and the two output columns share the buffer (tables are immutable; 8 of the 32 output bytes
-        // per row of C4 are never written)
-        const bool share_key = share_key_column(jt->left_cols[size_t(jt->left_key)], rk);
-        int share_pos = -1, right_key_pos = -1;
-        for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
-            const DevColumn &c = jt->left_cols[ci];
-            if (int(ci) == jt->left_key && share_key) {
-                share_pos = int(out->cols.size());
-                out->cols.push_back(DevColumn{});
-                continue;
-            }
-            out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
-            fc.kind[fc.n] = int(ci) == jt->left_key ? 1 : (jt->dense_packed[ci] >= 2 ? 4 : (jt->dense_packed[ci] ? 3 : 2));
-            fc.bits[fc.n] = jt->dense_packed[ci];
-            fc.base[fc.n] = int(ci) == jt->left_key ? 0 : jt->dense_base[ci];
-            fc.src[fc.n] = int(ci) == jt->left_key ? nullptr : (const uint64_t *)jt->dense_cols[ci]->ptr;
-            fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
-            fc.n++;
-        }
-        for (size_t cj = 0; cj < right->cols.size(); ++cj) {
-            const DevColumn &c = right->cols[cj];
-            out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
-            if (int(cj) == right_key) right_key_pos = int(out->cols.size()) - 1;
-            // the probe key column is in registers already (kind 1): loading it again as a probe-side column cost pass 2 8-15 %
-            // (C4 1.13 -> 1.04 ms, a 10 %-match join 0.70 -> 0.60 ms).  Requesting one more probe-side column together with the
-            // keys (33 more VGPRs) was neutral on top of that.
-            fc.kind[fc.n] = int(cj) == right_key ? 1 : 0;
-            fc.src[fc.n] = c.words();
-            fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
-            fc.n++;
-        }
-        if (share_pos >= 0) {
-            out->cols[size_t(share_pos)] = out->cols[size_t(right_key_pos)];
-            out->cols[size_t(share_pos)].dtype = jt->left_cols[size_t(jt->left_key)].dtype;
-        }
+        auto out = build_out(km.total, fc);
         if (km.ntiles && km.total > 0)
             launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS>, grid, block, 0, rk.words(), n, km.ntiles, (const uint64_t *)km.keep->ptr,
-                   (const uint64_t *)km.tile_offsets->ptr, jt->dense_min, (const uint32_t *)nullptr, fc);
+                   (const uint64_t *)km.tile_offsets->ptr, jt->dense_min, (const uint32_t *)nullptr, fc, uint64_t(0), (int *)nullptr);
         sync(ctx);
         return out;
     }
@@ -1209,7 +1252,8 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
             }
             if (km.ntiles && km.total > 0)
                 launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS>, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,
-                       (const uint64_t *)km.keep->ptr, (const uint64_t *)km.tile_offsets->ptr, uint64_t(0), pairs ? (const uint32_t *)nullptr : (const uint32_t *)bidx->ptr, fc);
+                       (const uint64_t *)km.keep->ptr, (const uint64_t *)km.tile_offsets->ptr, uint64_t(0), pairs ? (const uint32_t *)nullptr : (const uint32_t *)bidx->ptr, fc,
+                       uint64_t(0), (int *)nullptr);
             sync(ctx);
             return out;
         }

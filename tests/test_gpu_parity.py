@@ -952,6 +952,33 @@ def test_join_payload_packing_widths(ctx, span_bits):
     assert_batches_equal(got, exp, what=f"payload range of {span_bits} bits")
 
 
+def test_join_optimistic_all_match_form_and_its_fallback(ctx):
+    """a build side whose keys fill their range (a primary key): the probe first assumes every probe row matches and writes the
+    output in one pass; a probe key outside the range (first row, a middle tile, the very last row) must discard that output and
+    produce the reference's rows through the two-pass form — on this and on every later probe of the same join table"""
+    rng = np.random.default_rng(12)
+    nb, n = 3000, 5 * 4096 + 33
+    dk = rng.permutation(nb).astype(np.int64) + 50
+    left = [Column.from_numpy(dk), Column.from_numpy(rng.integers(0, 1000, nb).astype(np.int64)), Column.from_numpy(rng.random(nb))]
+    lt = ctx.table_from_host(left)
+    base = rng.integers(50, 50 + nb, n).astype(np.int64)
+    for bad_at in ([], [0], [2 * 4096 + 17], [n - 1], [5, 9000, n - 2]):
+        jt = ctx.hash_join_build(lt, 0)
+        rk = base.copy()
+        for j, i in enumerate(bad_at):
+            rk[i] = [49, 50 + nb, -7][j % 3]                      # just below, just above, far outside
+        right = [Column.from_numpy(rk), Column.from_numpy(rng.random(n))]
+        rt = ctx.table_from_host(right)
+        exp = orc.hash_join([left], [right], 0, 0)[0]
+        for _ in range(2):                                      # the second probe starts from what the first one learnt
+            got = ctx.hash_join_probe(jt, rt, 0).to_host()
+            assert_batches_equal(got, exp, what=f"optimistic join, misses at {bad_at}")
+        # the same join table, then an all-matching probe side
+        right2 = [Column.from_numpy(base), Column.from_numpy(rng.random(n))]
+        exp2 = orc.hash_join([left], [right2], 0, 0)[0]
+        assert_batches_equal(ctx.hash_join_probe(jt, ctx.table_from_host(right2), 0).to_host(), exp2, what="all-match probe after a miss")
+
+
 def test_clustered_predicates_leave_whole_tiles_empty(ctx):
     """a filter on sorted data keeps a contiguous range: the 4096-row tiles outside it hold no kept rows and the compaction / the
     join's fused write skip them before their loads — the result is the reference's, empty tiles or not (first, last and inner
