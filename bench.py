@@ -15,13 +15,22 @@ Launch: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run,
 set, and exits non-zero when the box has fewer than N devices or WORLD_SIZE disagrees with --gpus: there is no silent 1-GPU
 fallback.  Under the driver's own `python -m torch.distributed.run … bench.py --gpus N` it reads RANK/LOCAL_RANK/WORLD_SIZE.
 
-Rank 0 prints ONE JSON line: the contract's keys for the headline, `roofline` (dominant kernel timed with HIP events on the
-launch stream), `cpu_baseline` (the oracle — a C++ restatement of the reference's single-threaded algorithm — on a bounded
-sample, N=1 only), `parity_checked` (the GPU result on that sample compared with the oracle's: counts exact, f64 within 1e-9)
-and `configs`: the other BASELINE configs (C2, C3, C4 with build time, the random-key variants, a general hash join on sparse
-keys, a many-groups aggregate; N>1: the headline without its exchange and C5 = the join range-split over the ranks with its
-output all-gathered), each with its own timing, roofline block and oracle parity on a sample.  `--workload X` runs one config
-as the main line; `--no-configs` skips the block (used under rocprofv3).
+Rank 0 prints ONE JSON line (kept under 8 KB so that a record which keeps only the tail of stdout still holds all of it): the
+contract's keys for the headline, `roofline` (dominant kernel timed with HIP events on the launch stream), `cpu_baseline` (the
+oracle — a C++ restatement of the reference's single-threaded algorithm — on a bounded sample, N=1 only), `parity_checked` (the
+GPU result on that sample compared with the oracle's: counts exact, f64 within 1e-9) and `configs`: the other BASELINE configs
+(C2 in both id orders, C3, C4 with build time), the random-key variants, the Int64-value and single-column forms of the headline,
+C1's three-value-column query at scale, joins with a wide payload / a 10^7-row dim / sparse keys / duplicate build keys / a
+partially matching foreign key, many-groups aggregates and a general predicate tree (N>1: the headline without its exchange and
+C5 = the join range-split over the ranks with its output all-gathered).  EVERY side config is timed as the median of three
+blocks (`ms` with `ms_min`/`ms_max`) and checked against the oracle on a sample in the same run (`parity`).  A config record is
+compact: `frac` = SURVEY §8d's algorithmic bytes over the summed HIP-event time of the step's data kernels, as a fraction of the
+8 TB/s peak — EXCEPT where the data lets a kernel skip reads (C2 over sorted ids): there `frac` counts only the bytes that move
+and `frac_8d` is shown beside it; `frac_physical` = the bytes that physically move; `cold_ms` = the first execution of the query
+shape in the process (no plan hints, no remembered join form).  The LAST key, `summary`, repeats {config: [ms, frac,
+frac_physical, parity ok]}.  Per-kernel maps and full workload descriptions go to `--details PATH` (default:
+gpurun_out/bench_details.json when that directory exists).  `--workload X` runs one config as the main line; `--no-configs`
+skips the block (used under rocprofv3).
 """
 import argparse
 import json
@@ -36,16 +45,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable)
+PROFILE_TAG = "r03"    # profiles/<tag>/pmc_traffic_<config>.json are quoted as `roofline.traffic`
 # kernels that do not belong to an operator's step (data generation, diagnostics)
 NOT_STEP_KERNELS = ("synth_fill",)
+LINE_LIMIT = 8000      # bytes of the JSON line
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="headline", choices=["headline", "c2", "c3", "c4", "c4_sparse", "agg_groups"])
+    ap.add_argument("--workload", default="headline", choices=["headline", "headline_int64", "headline_single", "agg3", "tree_pred", "c2", "c2_random", "c3",
+                                                               "c4", "c4_sparse", "c4_wide", "c4_dup", "c4_partial", "agg_groups"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the BASELINE size of the workload)")
     ap.add_argument("--random-keys", action="store_true", help="c3/headline: group by a random id column instead of the row number")
     ap.add_argument("--groups", type=int, default=65536, help="agg_groups: distinct keys")
@@ -54,8 +66,10 @@ def parse():
     ap.add_argument("--gather", action="store_true", help="c4 with --gpus N: also all-gather every rank's output batch in rank order (BASELINE config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="only the main workload's line (no `configs` block)")
+    ap.add_argument("--only", default="", help="comma-separated side configs to run (default: all)")
     ap.add_argument("--cpu-sample-rows", type=int, default=150_000_000, help="rows of the CPU baseline sample (about 10 s of single-thread work for the headline)")
-    return ap.parse_args()
+    ap.add_argument("--details", default="", help="write the full per-config records (per-kernel times, workload text) to this file")
+    return ap.parse_args(argv)
 
 
 def free_port():
@@ -136,11 +150,9 @@ class Bench:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(self, step, steps, warmup):
-        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.  Kernel times come
-        from HIP events the library records around every launch on its stream while timing is enabled.  The side configs
-        (self.min_warm_s > 0) additionally warm up for a minimum wall time: they start right behind seconds of CPU-only work (the
-        oracle), from a GPU that has clocked down."""
+    def _warm(self, step, warmup):
+        """W untimed steps; the side configs (self.min_warm_s > 0) additionally warm up for a minimum wall time: they start right
+        behind seconds of CPU-only work (the oracle), from a GPU that has clocked down."""
         t_w = time.perf_counter()
         for _ in range(warmup):
             r = step()
@@ -159,6 +171,10 @@ class Bench:
             for _ in range(extra):
                 r = step()
                 del r
+
+    def _block(self, step, steps):
+        """exactly K steps between barrier + synchronize on both sides; max over ranks.  Kernel times come from HIP events the
+        library records around every launch on its stream while timing is enabled."""
         self.barrier()
         self.ctx.timing_enable(True)
         self.ctx.timing_reset()
@@ -173,6 +189,26 @@ class Bench:
                    if kn not in NOT_STEP_KERNELS}
         return self.max_over_ranks(dt) / steps * 1e3, kernels
 
+    def timed(self, step, steps, warmup, blocks=1):
+        """→ (ms per step, kernels, spread).  blocks = 1: the contract's W warm-up steps + exactly K timed steps.  blocks > 1 (the
+        side configs): that many timed blocks of K steps behind one warm-up; the MEDIAN block is reported (its ms and its kernel
+        times), with min/max over the blocks as `spread`."""
+        self._warm(step, warmup)
+        runs = [self._block(step, steps) for _ in range(blocks)]
+        runs.sort(key=lambda r: r[0])
+        ms, kernels = runs[len(runs) // 2]
+        return ms, kernels, {"ms_min": runs[0][0], "ms_max": runs[-1][0], "blocks": blocks, "steps_per_block": steps}
+
+    def cold(self, step):
+        """wall time of the FIRST execution of a query shape in this process (no plan hint, no remembered join form)"""
+        self.barrier()
+        t0 = time.perf_counter()
+        r = step()
+        self.ctx.synchronize()
+        dt = time.perf_counter() - t0
+        del r
+        return dt * 1e3
+
 
 def pick(kernels, prefixes):
     """the kernels of a step that stream the data (by name prefix), as opposed to its scans / table set-up / tails"""
@@ -183,22 +219,26 @@ def kernel_ms(kernels, prefixes):
     return sum(kernels[k]["ms_per_step"] for k in pick(kernels, prefixes))
 
 
-def roofline(algo_bytes, kernels, prefixes, extra=None):
+def roofline(algo_bytes, kernels, prefixes, phys_bytes=None, extra=None):
     """achieved = SURVEY §8d algorithmic bytes of one step ÷ the summed HIP-event time of the step's data kernels"""
     kms = kernel_ms(kernels, prefixes)
     achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
            "kernel": "+".join(pick(kernels, prefixes)), "kernel_ms_per_step": kms, "algorithmic_bytes_per_step": algo_bytes,
            "kernels": kernels}
+    if phys_bytes is not None:
+        out["physical_bytes_per_step"] = phys_bytes
+        out["frac_physical"] = (phys_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms > 0 else 0.0
     if extra:
         out.update(extra)
     return out
 
 
 def attach_traffic(roof, config_name):
-    """HBM bytes per launch from this round's PMC passes (tools/profile_round.sh → profiles/r02/pmc_traffic_<config>.json;
-    rocprofv3 cannot run inside the timed process).  Only when the file was made from the csrc/ tree that is running."""
-    path = os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_{config_name}.json")
+    """HBM bytes per launch QUOTED from this round's PMC passes (tools/profile_round.sh → profiles/<tag>/pmc_traffic_<config>.json;
+    rocprofv3 cannot run inside the timed process) — not a measurement of this run, hence `traffic_quoted_from`.  Only when the
+    file was made from the csrc/ tree that is running."""
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG, f"pmc_traffic_{config_name}.json")
     if not os.path.exists(path):
         return
     try:
@@ -207,113 +247,148 @@ def attach_traffic(roof, config_name):
         from tools.csrc_rev import csrc_rev
 
         if rec.get("csrc_rev") != csrc_rev():
-            roof["traffic_source"] = f"{os.path.relpath(path, ROOT)} is stale (made from csrc rev {rec.get('csrc_rev')}, running {csrc_rev()}): not reported"
+            roof["traffic_quoted_from"] = f"{os.path.relpath(path, ROOT)} is stale (csrc rev {rec.get('csrc_rev')}, running {csrc_rev()}): not quoted"
             return
         roof["traffic"] = rec["hbm_bytes_per_step_corrected"]
         roof["traffic_ratio"] = rec["hbm_bytes_per_step_corrected"] / roof["algorithmic_bytes_per_step"] if roof["algorithmic_bytes_per_step"] else None
-        roof["traffic_source"] = f"{os.path.relpath(path, ROOT)} ({rec.get('method', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE')})"
+        roof["traffic_quoted_from"] = f"{os.path.relpath(path, ROOT)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this csrc revision, calibrated)"
     except Exception as e:  # noqa: BLE001 - a missing/odd profile file must not fail the bench
-        roof["traffic_source"] = f"unreadable {path}: {e}"
+        roof["traffic_quoted_from"] = f"unreadable {path}: {e}"
 
 
-AGGS5 = None  # filled in main (needs the package)
+AGG = None  # naive_query_engine_amd.AggregateFunc, filled in main (needs the package)
 
 
-# ------------------------------------------------------------------------------------------------ workloads
-def wl_aggregate(B, rows, with_filter, random_keys, steps, warmup, groups=None, exchange=True):
-    """headline / C3 / many-groups aggregate.  groups=None: key `id % 1024`; else: key = a random Int64 column in [0, groups)."""
-    from naive_query_engine_amd import DType, Operator
-    from naive_query_engine_amd.expression import binop, col, lit_i64
+# ------------------------------------------------------------------------------------------------ aggregate workloads
+# column generators: (name, synth kind, seed, modulus, base, dtype)
+#   kind 0: row number; kind 1: base + splitmix64(seed + row) mod modulus; kind 2: Float64 in [0, 100)
+def agg_shape(name, total, random_keys=False, groups=None):
+    """→ dict(cols, aggs, key, pred(limit) builder, bytes per row, text) for one aggregate query shape"""
+    from naive_query_engine_amd import Operator
+    from naive_query_engine_amd.expression import binop, col, lit_f64, lit_i64
+
+    idc = ("id", 1, 1, total, 0, "i64") if random_keys else ("id", 0, 0, 1, 0, "i64")
+    five = lambda c: [(AGG.Count, c), (AGG.Sum, c), (AGG.Avg, c), (AGG.Min, c), (AGG.Max, c)]
+    key_mod = lambda m: binop(col(0), Operator.Modulos, lit_i64(m))
+    lt = lambda limit: binop(col(0), Operator.Lt, lit_i64(limit))
+    if groups is not None:      # many distinct keys: key = a random Int64 column in [0, groups)
+        return dict(cols=[("k", 1, 7, groups, 0, "i64"), ("v", 2, 3, 1, 0, "f64")], aggs=five(1), key=col(0), pred=None, bpr=16.0,
+                    text=f"select count(v),sum(v),avg(v),min(v),max(v) from t group by k; k random in [0, {groups})")
+    if name == "v":             # the headline / C3: Float64 values
+        return dict(cols=[idc, ("v", 2, 3, 1, 0, "f64")], aggs=five(1), key=key_mod(1024), pred=lt, bpr=16.0,
+                    text="select count(v),sum(v),avg(v),min(v),max(v) from t{w} group by id % 1024; t(id Int64, v Float64)")
+    if name == "age":           # north_star's literal "10^9 Int64 rows": Int64 values (`val as f64` per row, sum.rs:86-101)
+        return dict(cols=[idc, ("age", 1, 2, 60, 18, "i64")], aggs=five(1), key=key_mod(1024), pred=lt, bpr=16.0,
+                    text="select count(age),sum(age),avg(age),min(age),max(age) from t{w} group by id % 1024; t(id Int64, age Int64)")
+    if name == "id":            # SURVEY §8d's single-column variant: key, predicate and value are ONE Int64 column = 8 B/row
+        return dict(cols=[idc], aggs=five(0), key=key_mod(1024), pred=lt, bpr=8.0,
+                    text="select count(id),sum(id),avg(id),min(id),max(id) from t{w} group by id % 1024; t(id Int64)")
+    if name == "three":         # C1's query shape (src/main.rs:36-40) at scale: three DIFFERENT value columns
+        return dict(cols=[idc, ("age", 1, 2, 60, 18, "i64"), ("score", 2, 3, 1, 0, "f64")], aggs=[(AGG.Count, 0), (AGG.Sum, 1), (AGG.Avg, 2)],
+                    key=key_mod(3), pred=None, bpr=24.0, text="select count(id),sum(age),avg(score) from t group by id % 3; t(id Int64, age Int64, score Float64)")
+    if name == "tree":          # a predicate that is neither a chain nor a list of compares: `v < 20 or id % 3 == 0`
+        tree = lambda limit: binop(binop(col(1), Operator.Lt, lit_f64(20.0)), Operator.Or,
+                                   binop(binop(col(0), Operator.Modulos, lit_i64(3)), Operator.Eq, lit_i64(0)))
+        return dict(cols=[idc, ("v", 2, 3, 1, 0, "f64")], aggs=five(1), key=key_mod(1024), pred=tree, bpr=16.0,
+                    text="select count(v),sum(v),avg(v),min(v),max(v) from t where v < 20 or id % 3 = 0 group by id % 1024; t(id Int64, v Float64)")
+    raise ValueError(name)
+
+
+def wl_aggregate(B, rows, with_filter, random_keys, steps, warmup, groups=None, exchange=True, shape="v", blocks=1, cold=False):
+    """headline / C3 / their Int64-value, single-column, three-column and tree-predicate forms / many-groups aggregates"""
+    from naive_query_engine_amd import DType
 
     n, total, first = rows, rows * B.world, B.rank * rows
     torch = B.torch
-    if groups is None:
-        ids = B.synth(1, 1, n, first, total, 0) if random_keys else B.synth(0, 0, n, first)
-        key = binop(col(0), Operator.Modulos, lit_i64(1024)).flatten([F("id"), F("v")])
-        kdesc = "id % 1024"
-    else:
-        ids = B.synth(1, 7, n, first, groups, 0)
-        key = col(0).flatten([F("id"), F("v")])
-        kdesc = f"k (random in [0, {groups}))"
-    v = B.synth(2, 3, n, first, dtype=torch.float64)
-    table = B.ctx.table_from_device([(DType.INT64, n, ids.data_ptr(), None), (DType.FLOAT64, n, v.data_ptr(), None)])
-    pred = binop(col(0), Operator.Lt, lit_i64(int(total * B.args.pass_frac))).flatten([F("id"), F("v")]) if with_filter else None
+    sh = agg_shape(shape, total, random_keys, groups)
+    fields = [F(c[0]) for c in sh["cols"]]
+    tens = [B.synth(kind, seed, n, first, mod, base, dtype=torch.float64 if dt == "f64" else torch.int64) for (_, kind, seed, mod, base, dt) in sh["cols"]]
+    table = B.ctx.table_from_device([(DType.FLOAT64 if c[5] == "f64" else DType.INT64, n, t.data_ptr(), None) for c, t in zip(sh["cols"], tens)])
+    key = sh["key"].flatten(fields)
+    use_pred = with_filter and sh["pred"] is not None
+    pred = sh["pred"](int(total * B.args.pass_frac)).flatten(fields) if use_pred else None
 
     def step():
         if B.comm is not None and exchange:
-            return B.comm.sharded_aggregate(table, AGGS5, group_nodes=key, pred_nodes=pred)
-        return B.ctx.aggregate(table, AGGS5, group_nodes=key, pred_nodes=pred)
+            return B.comm.sharded_aggregate(table, sh["aggs"], group_nodes=key, pred_nodes=pred)
+        return B.ctx.aggregate(table, sh["aggs"], group_nodes=key, pred_nodes=pred)
 
-    ms, kernels = B.timed(step, steps, warmup)
-    desc = (f"select count(v),sum(v),avg(v),min(v),max(v) from t{' where id < N/2' if with_filter else ''} group by {kdesc}; "
-            f"t(id Int64 {'random' if (random_keys or groups) else 'row number'}, v Float64), {n} rows per GPU")
-    names = ["agg_grouped", "agg_partition", "agg_segments", "agg_subpartition", "agg_sample"]
-    res = {"metric": "filter_hash_aggregate_rows_per_s" if with_filter else "hash_aggregate_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s",
-           "ms_per_step": ms, "workload": desc, "rows_per_gpu": n, "roofline": roofline(16.0 * n, kernels, names)}
-    return res, dict(table=table, ids=ids, v=v, key=key, n=n, total=total, with_filter=with_filter, random_keys=random_keys, groups=groups)
+    cold_ms = B.cold(step) if cold else None
+    ms, kernels, spread = B.timed(step, steps, warmup, blocks)
+    where = " where id < N/2" if (use_pred and shape != "tree") else ""
+    desc = sh["text"].replace("{w}", where) + f"; id = {'random' if random_keys else 'row number'}; {n} rows per GPU"
+    names = ["agg_grouped", "agg_partition", "agg_slab", "agg_segments", "agg_subpartition", "agg_sample", "expr_tree", "keep_from"]
+    res = {"metric": "filter_hash_aggregate_rows_per_s" if use_pred else "hash_aggregate_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s",
+           "ms_per_step": ms, "spread": spread, "cold_ms": cold_ms, "workload": desc, "rows_per_gpu": n, "roofline": roofline(sh["bpr"] * n, kernels, names)}
+    return res, dict(table=table, tens=tens, sh=sh, key=key, fields=fields, n=n, total=total, use_pred=use_pred, random_keys=random_keys, groups=groups)
 
 
 def parity_aggregate(B, st, sample_rows):
     """the same query on the first `sample_rows` rows: GPU (the same tensors, a prefix table) vs the oracle; also the cpu_baseline"""
     import numpy as np
 
-    from naive_query_engine_amd import Column, DType, Operator
-    from naive_query_engine_amd.expression import binop, col, lit_i64
+    from naive_query_engine_amd import Column, DType
     from oracle import oracle as orc
 
     m = min(st["n"], sample_rows)
-    fields = [F("id"), F("v")]
-    if st["groups"] is not None:
-        ids = orc.synth_fill(1, 7, 0, m, st["groups"], 0).view(np.int64)
-    elif st["random_keys"]:
-        ids = orc.synth_fill(1, 1, 0, m, st["total"], 0).view(np.int64)
-    else:
-        ids = orc.synth_fill(0, 0, 0, m).view(np.int64)
-    x = orc.synth_fill(2, 3, 0, m).view(np.float64)
-    h = orc.upload([[Column.from_numpy(ids), Column.from_numpy(x)]])
+    sh = st["sh"]
+    host = []
+    for (_, kind, seed, mod, base, dt) in sh["cols"]:
+        a = orc.synth_fill(kind, seed, 0, m, mod, base)
+        host.append(a.view(np.float64) if dt == "f64" else a.view(np.int64))
+    h = orc.upload([[Column.from_numpy(a) for a in host]])
+    # `id < limit`: half of the id range of the SAMPLE (sorted ids: the prefix's own range; random ids: drawn from [0, total))
     plimit = st["total"] // 2 if st["random_keys"] else m // 2
-    pred = binop(col(0), Operator.Lt, lit_i64(plimit)).flatten(fields) if st["with_filter"] else None
+    pred = sh["pred"](plimit).flatten(st["fields"]) if st["use_pred"] else None
     t0 = time.perf_counter()
-    ref = orc.aggregate(h, AGGS5, group_nodes=st["key"], pred_nodes=pred)[0]
-    dt = time.perf_counter() - t0
-    prefix = B.ctx.table_from_device([(DType.INT64, m, st["ids"].data_ptr(), None), (DType.FLOAT64, m, st["v"].data_ptr(), None)])
-    got = B.ctx.aggregate(prefix, AGGS5, group_nodes=st["key"], pred_nodes=pred).to_host()
+    ref = orc.aggregate(h, sh["aggs"], group_nodes=st["key"], pred_nodes=pred)[0]
+    dt_s = time.perf_counter() - t0
+    prefix = B.ctx.table_from_device([(DType.FLOAT64 if c[5] == "f64" else DType.INT64, m, t.data_ptr(), None) for c, t in zip(sh["cols"], st["tens"])])
+    got = B.ctx.aggregate(prefix, sh["aggs"], group_nodes=st["key"], pred_nodes=pred).to_host()
     g = np.stack([c.to_numpy().astype(np.float64) for c in got], axis=1)
     e = np.stack([c.to_numpy().astype(np.float64) for c in ref], axis=1)
     ok = g.shape == e.shape
     if ok:
         g, e = g[np.lexsort(g.T[::-1])], e[np.lexsort(e.T[::-1])]
-        ok = bool((g[:, 0] == e[:, 0]).all() and np.allclose(g, e, rtol=1e-9, atol=0))
-    cpu = {"value": m / dt, "unit": "rows/s", "cores": 1, "kind": "port",
-           "sample": f"same query on the first {m} rows (single thread; the reference is single-threaded; host has {os.cpu_count()} cores)", "seconds": dt}
+        exact = [i for i, (f, _) in enumerate(sh["aggs"]) if f == AGG.Count]
+        ok = bool(all((g[:, i] == e[:, i]).all() for i in exact) and np.allclose(g, e, rtol=1e-9, atol=0))
+    cpu = {"value": m / dt_s, "unit": "rows/s", "cores": 1, "kind": "port",
+           "sample": f"same query on the first {m} rows (single thread; the reference is single-threaded; host has {os.cpu_count()} cores)", "seconds": dt_s}
     return {"rows": m, "ok": ok, "groups": int(e.shape[0]), "tolerance": "counts exact, f64 rtol 1e-9"}, cpu
 
 
-def wl_c2(B, rows, steps, warmup):
+# ------------------------------------------------------------------------------------------------ C2
+def wl_c2(B, rows, steps, warmup, random_ids=False, blocks=1, cold=False):
     from naive_query_engine_amd import DType, Operator
     from naive_query_engine_amd.expression import binop, col, lit_i64
 
     n, total, first = rows, rows * B.world, B.rank * rows
-    ids = B.synth(0, 0, n, first)
+    ids = B.synth(1, 1, n, first, total, 0) if random_ids else B.synth(0, 0, n, first)
     age = B.synth(1, 2, n, first, 60, 18)
     table = B.ctx.table_from_device([(DType.INT64, n, ids.data_ptr(), None), (DType.INT64, n, age.data_ptr(), None)])
     fields = [F("id"), F("age")]
     pred = binop(col(0), Operator.Lt, lit_i64(total // 2)).flatten(fields)
     proj = [binop(col(1), Operator.Plus, lit_i64(100)).flatten(fields)]
-    ms, kernels = B.timed(lambda: B.ctx.selection_projection(table, pred, proj), steps, warmup)
+    step = lambda: B.ctx.selection_projection(table, pred, proj)
+    cold_ms = B.cold(step) if cold else None
+    ms, kernels, spread = B.timed(step, steps, warmup, blocks)
     names = ["select_fused", "keep_from_simple", "compact_expr"]
-    res = {"metric": "filter_project_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms,
-           "workload": f"select age + 100 from t where id < N/2; t(id Int64, age Int64), {n} rows per GPU",
-           "rows_per_gpu": n, "roofline": roofline((16.0 + 0.5 * 8.0) * n, kernels, names)}
-    # the compaction does not read the source words of 4096-row tiles in which nothing was kept: with ids = row numbers the kept
-    # rows are the first half, so only that half of `age` moves.  frac stays SURVEY 8d's 2.0 GB (age counted as read in full);
-    # frac_physical is what this data actually moves (the PMC `traffic` of the same config shows it)
-    phys = (8.0 + 0.5 * 8.0 + 0.5 * 8.0) * n
-    kms = res["roofline"]["kernel_ms_per_step"]
-    res["roofline"].update({"physical_bytes_per_step": phys, "frac_physical": (phys / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms > 0 else 0.0,
-                            "note": "frac = SURVEY 8d's 20 B/row (age counted as read in full); the compaction skips tiles without kept rows, "
-                                    "so with sorted ids only the kept half of `age` is read: frac_physical = 16 B/row"})
-    return res, dict(ids=ids, age=age, n=n, proj=proj, fields=fields)
+    # SURVEY §8d: 16 B/row read + 8 B per kept row written = 20 B/row at 50 %.  The compaction does not read the source words of
+    # 4096-row tiles in which nothing was kept: with ids = row numbers the kept rows are the first half, so only that half of `age`
+    # moves (16 B/row) — §8d forbids taking that as skip credit, so for sorted ids `frac` is quoted on the bytes that MOVE and the
+    # 20 B/row figure is kept as `frac_8d`; with random ids every tile holds kept rows and the two coincide.
+    algo = 20.0 * n
+    phys = algo if random_ids else 16.0 * n
+    roof = roofline(algo, kernels, names, phys_bytes=phys)
+    if not random_ids:
+        roof["frac_8d"] = roof["frac"]
+        roof["frac"] = roof["frac_physical"]
+        roof["achieved"] = roof["frac"] * HBM_PEAK_GBS
+        roof["note"] = "sorted ids: tiles without kept rows are not read; frac counts the 16 B/row that move, frac_8d SURVEY 8d's 20 B/row"
+    res = {"metric": "filter_project_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms, "spread": spread, "cold_ms": cold_ms,
+           "workload": f"select age + 100 from t where id < N/2; t(id Int64 {'random' if random_ids else 'row number'}, age Int64), {n} rows per GPU",
+           "rows_per_gpu": n, "roofline": roof}
+    return res, dict(ids=ids, age=age, n=n, total=total, proj=proj, fields=fields, random_ids=random_ids)
 
 
 def parity_c2(B, st, sample_rows):
@@ -324,10 +399,10 @@ def parity_c2(B, st, sample_rows):
     from oracle import oracle as orc
 
     m = min(st["n"], sample_rows)
-    ids = orc.synth_fill(0, 0, 0, m).view(np.int64)
+    ids = (orc.synth_fill(1, 1, 0, m, st["total"], 0) if st["random_ids"] else orc.synth_fill(0, 0, 0, m)).view(np.int64)
     x = orc.synth_fill(1, 2, 0, m, 60, 18).view(np.int64)
     h = orc.upload([[Column.from_numpy(ids), Column.from_numpy(x)]])
-    pred = binop(col(0), Operator.Lt, lit_i64(m // 2)).flatten(st["fields"])
+    pred = binop(col(0), Operator.Lt, lit_i64(st["total"] // 2 if st["random_ids"] else m // 2)).flatten(st["fields"])
     t0 = time.perf_counter()
     sel = orc.selection(h, pred, raw=True)
     ref = orc.projection(sel, st["proj"])[0]
@@ -336,24 +411,32 @@ def parity_c2(B, st, sample_rows):
     got = B.ctx.selection_projection(prefix, pred, st["proj"]).to_host()
     ok = len(got) == len(ref) == 1 and got[0].length == ref[0].length and bool((got[0].to_numpy() == ref[0].to_numpy()).all())
     cpu = {"value": m / dt, "unit": "rows/s", "cores": 1, "kind": "port", "sample": f"same query on the first {m} rows (single thread)", "seconds": dt}
-    return {"rows": m, "ok": ok, "tolerance": "bit-exact"}, cpu
+    return {"rows": m, "ok": ok, "output_rows": int(ref[0].length), "tolerance": "bit-exact"}, cpu
 
 
-def make_join_data(B, rows, nb, sparse, first, wide=False):
-    """dim(id unique, attr) = LEFT/build, fact(key, val) = RIGHT/probe, every probe row matches once.
-    dense: id = a permutation of 0..nb-1 (the direct-address PK-FK path); sparse: unique ids spread over a 2^20 x nb domain (the
-    general hashed path)."""
+# ------------------------------------------------------------------------------------------------ C4
+def make_join_data(B, rows, nb, variant, first):
+    """dim(id, attr) = LEFT/build, fact(key, val) = RIGHT/probe.
+    dense:   id = a permutation of 0..nb-1 (a primary key; every fact row matches once);
+    wide:    the same with an attribute spanning 2^62 (the key-ordered payload table cannot be bit-packed);
+    sparse:  unique ids spread over a 2^20 x nb domain (the general hashed path);
+    dup:     every build key FOUR times (nb/4 distinct keys), fact keys drawn from [0, nb): a quarter matches, 4 output rows each
+             (the reference's general case: chains of build rows per key, hash_join.rs:86-101);
+    partial: a gap-free primary key, fact keys drawn from [0, nb/0.9): 90 % of the foreign keys match."""
     torch = B.torch
     g = torch.Generator(device=B.dev).manual_seed(7)
     perm = torch.randperm(nb, device=B.dev, generator=g).to(torch.int64)
-    # the dim attribute: 20 bits of range (stored bit-packed in the key-ordered payload table of the dense path), or — `wide` — 62 bits
-    attr = B.synth(1, 4, nb, 0, (1 << 62) if wide else (1 << 20), 0)
-    fidx = B.synth(1, 5, rows, first, nb, 0)  # which dim row a fact row references
-    if sparse:
+    attr = B.synth(1, 4, nb, 0, (1 << 62) if variant == "wide" else (1 << 20), 0)
+    fdom = int(math.ceil(nb / 0.9)) if variant == "partial" else nb
+    fidx = B.synth(1, 5, rows, first, fdom, 0)  # which dim key a fact row references
+    if variant == "sparse":
         # unique by construction: key j = j * 2^20 + (u(j, 11) mod 2^20): span 2^20 x nb, far beyond the direct-address limit
         dom = (torch.arange(nb, device=B.dev, dtype=torch.int64) << 20) + B.synth(1, 11, nb, 0, 1 << 20, 0)
         dkey = dom[perm].contiguous()          # build rows in shuffled order
         fkey = dom[fidx].contiguous()
+    elif variant == "dup":
+        dkey = (perm % (nb // 4)).contiguous()
+        fkey = fidx
     else:
         dkey = perm
         fkey = fidx
@@ -362,17 +445,18 @@ def make_join_data(B, rows, nb, sparse, first, wide=False):
     return dkey, attr, fkey, val
 
 
-def wl_c4(B, rows, nb, sparse, steps, warmup, gather=False, wide=False):
+def wl_c4(B, rows, nb, variant, steps, warmup, gather=False, blocks=1, cold=False):
     from naive_query_engine_amd import DType
 
     torch = B.torch
-
     n, first = rows, B.rank * rows
-    dkey, attr, fkey, val = make_join_data(B, n, nb, sparse, first, wide)
+    dkey, attr, fkey, val = make_join_data(B, n, nb, variant, first)
     dim = B.ctx.table_from_device([(DType.INT64, nb, dkey.data_ptr(), None), (DType.INT64, nb, attr.data_ptr(), None)])
     fact = B.ctx.table_from_device([(DType.INT64, n, fkey.data_ptr(), None), (DType.FLOAT64, n, val.data_ptr(), None)])
+    # the first HashJoin::execute of the process: build + probe, nothing remembered
+    cold_ms = B.cold(lambda: B.ctx.hash_join(dim, fact, 0, 0)) if cold else None
     # build (HashJoin::build, hash_join.rs:124-166): timed on its own — replicated on every rank, once per query
-    build_ms, bk = B.timed(lambda: B.ctx.hash_join_build(dim, 0), max(3, steps // 2), 1)
+    build_ms, _, _ = B.timed(lambda: B.ctx.hash_join_build(dim, 0), max(3, steps // 2), 1)
     jt = B.ctx.hash_join_build(dim, 0)
 
     def probe():
@@ -380,17 +464,28 @@ def wl_c4(B, rows, nb, sparse, steps, warmup, gather=False, wide=False):
             return B.comm.sharded_hash_join_probe(jt, fact, 0, gather=True)
         return B.ctx.hash_join_probe(jt, fact, 0)
 
-    ms, kernels = B.timed(probe, steps, warmup)
+    r0 = probe()
+    out_rows = int(r0.num_rows)
+    del r0
+    ms, kernels, spread = B.timed(probe, steps, warmup, blocks)
     names = ["join_probe", "join_fused_write", "compact_gather", "compact_column"]
     total = n * B.world
-    algo = 48.0 * n + 16.0 * nb     # 16 B/probe row read + 32 B/output row written + the build side once
-    phys = 40.0 * n + 16.0 * nb     # the output's two key columns are one shared buffer: 24 B/row are written
+    # 16 B/probe row read + 32 B/output row written + the build side once.  The output's two key columns are one shared
+    # buffer when the join can alias them (unique build keys): then 24 B/output row are written
+    m_out = out_rows if not gather else out_rows // B.world
+    algo = 16.0 * n + 32.0 * m_out + 16.0 * nb
+    phys = 16.0 * n + 24.0 * m_out + 16.0 * nb
     kms = kernel_ms(kernels, names)
-    extra = {"probe_kernels_ms": kms, "build_ms": build_ms, "probe_ms": ms, "execute_ms": ms + build_ms,
-             "frac_physical": (phys / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms > 0 else 0.0, "physical_bytes_per_step": phys,
+    extra = {"probe_kernels_ms": kms, "build_ms": build_ms, "probe_ms": ms, "execute_ms": ms + build_ms, "output_rows": m_out,
              "frac_end_to_end": algo / ((ms + build_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-             "note": "frac = SURVEY 8d's 48 B/probe row over the probe kernels; frac_physical = the 40 B/row that move (shared key column); "
-                     "frac_end_to_end = 8d bytes over build + probe wall time (HashJoin::execute)"}
+             "note": "frac = SURVEY 8d's bytes (16 B/probe row + 32 B/output row) over the probe kernels; frac_physical = with the shared key "
+                     "column written once (24 B/output row); frac_end_to_end = 8d bytes over build + probe wall time (HashJoin::execute)"}
+    if variant == "partial":
+        # what the reference's call pattern costs: HashJoin::execute = a fresh build + probe per call (nqe_hash_join_execute, the entry
+        # point integration/rust/gpu.rs calls), against the remembered two-pass form of the reused join table above
+        ex_ms, _, exs = B.timed(lambda: B.ctx.hash_join(dim, fact, 0, 0), steps, 1, blocks)
+        extra.update({"execute_call_ms": ex_ms, "execute_call_ms_min": exs["ms_min"], "execute_call_ms_max": exs["ms_max"],
+                      "two_pass_ms": ms + build_ms, "execute_over_two_pass": ex_ms / (ms + build_ms)})
     gather_check = None
     if B.comm is not None and gather:
         # no oracle at this size: size-independent properties of the GATHERED output on every rank — every probe row matches once,
@@ -419,13 +514,15 @@ def wl_c4(B, rows, nb, sparse, steps, warmup, gather=False, wide=False):
         if not gather_check["ok"]:
             sys.stderr.write("bench.py: the gathered join output failed its check\n")
             sys.exit(3)
-    res = {"metric": "hash_join_probe_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms,
-           "workload": f"dim(id,attr{' of 62-bit range' if wide else ' of 20-bit range'}) {nb} rows ({'sparse 2^40-domain' if sparse else 'dense'} unique keys, LEFT/build) join fact(key,val) {n} rows per GPU "
-                       f"(RIGHT/probe), 1 match per probe row; 4 output columns{'; outputs all-gathered in rank order' if gather else ''}",
-           "rows_per_gpu": n, "build_rows": nb, "roofline": roofline(algo, kernels, names, extra)}
+    shape = {"dense": "dense unique keys, attr of 20-bit range", "wide": "dense unique keys, attr of 62-bit range", "sparse": "sparse unique keys over a 2^40 domain",
+             "dup": "every build key 4 times, 25 % of the fact keys match", "partial": "gap-free primary key, 90 % of the fact keys match"}[variant]
+    res = {"metric": "hash_join_probe_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms, "spread": spread, "cold_ms": cold_ms,
+           "workload": f"dim(id,attr) {nb} rows ({shape}; LEFT/build) join fact(key,val) {n} rows per GPU (RIGHT/probe) -> {m_out} rows x 4 columns"
+                       f"{'; outputs all-gathered in rank order' if gather else ''}",
+           "rows_per_gpu": n, "build_rows": nb, "roofline": roofline(algo, kernels, names, phys_bytes=phys, extra=extra)}
     if gather_check:
         res["gather_check"] = gather_check
-    return res, dict(dim=dim, jt=jt, dkey=dkey, attr=attr, fkey=fkey, val=val, n=n, nb=nb, fact=fact)
+    return res, dict(dim=dim, jt=jt, dkey=dkey, attr=attr, fkey=fkey, val=val, n=n, nb=nb, fact=fact, variant=variant)
 
 
 def parity_c4(B, st, sample_rows):
@@ -441,11 +538,64 @@ def parity_c4(B, st, sample_rows):
     ref = orc.hash_join([left], [right], 0, 0)[0]
     dt = time.perf_counter() - t0
     prefix = B.ctx.table_from_device([(DType.INT64, m, st["fkey"].data_ptr(), None), (DType.FLOAT64, m, st["val"].data_ptr(), None)])
-    got = B.ctx.hash_join_probe(st["jt"], prefix, 0).to_host()
-    ok = len(got) == len(ref) and all(g.length == r.length and bool((g.to_numpy().view(np.int64) == r.to_numpy().view(np.int64)).all()) for g, r in zip(got, ref))
+    same = lambda got: len(got) == len(ref) and all(g.length == r.length and bool((g.to_numpy().view(np.int64) == r.to_numpy().view(np.int64)).all()) for g, r in zip(got, ref))
+    ok = same(B.ctx.hash_join_probe(st["jt"], prefix, 0).to_host())
+    if st["variant"] == "partial":   # the one-call entry point too (fresh build, the optimistic form and its fallback)
+        ok = ok and same(B.ctx.hash_join(st["dim"], prefix, 0, 0).to_host())
     cpu = {"value": m / dt, "unit": "probe rows/s", "cores": 1, "kind": "port",
            "sample": f"HashJoin build ({st['nb']} rows) + probe of the first {m} fact rows (single thread)", "seconds": dt}
     return {"rows": m, "ok": ok, "output_rows": int(ref[0].length), "tolerance": "bit-exact, row order included"}, cpu
+
+
+# ------------------------------------------------------------------------------------------------ the compact record
+def r4(x):
+    """4 significant digits: the line must stay small"""
+    if x is None:
+        return None
+    return float(f"{x:.4g}")
+
+
+def compact(res):
+    """a config's record in the line: numbers only (the text and the per-kernel map go to the details file)"""
+    roof = res["roofline"]
+    out = {"ms": r4(res["ms_per_step"]), "ms_min": r4(res["spread"]["ms_min"]), "ms_max": r4(res["spread"]["ms_max"]),
+           "kernel_ms": r4(roof["kernel_ms_per_step"]), "frac": r4(roof["frac"]), "frac_physical": r4(roof.get("frac_physical")),
+           "rows": res["rows_per_gpu"]}
+    for k in ("frac_8d", "frac_end_to_end", "build_ms", "execute_call_ms", "two_pass_ms", "execute_over_two_pass", "traffic_ratio"):
+        if roof.get(k) is not None:
+            out[k] = r4(roof[k])
+    if res.get("cold_ms") is not None:
+        out["cold_ms"] = r4(res["cold_ms"])
+    if "gather_check" in res:
+        out["gather_check"] = {"ok": res["gather_check"]["ok"], "rows": res["gather_check"]["rows"]}
+    if "parity_checked" in res:
+        p = res["parity_checked"]
+        out["parity"] = {"ok": p["ok"], "rows": p["rows"]}
+        out["cpu_rows_per_s"] = r4(res["cpu_baseline"]["value"])
+    return out
+
+
+def summary_of(out):
+    s = {"headline": [r4(out["ms_per_step"]), r4(out["roofline"]["frac"]), r4(out["roofline"].get("frac_physical")),
+                      (out.get("parity_checked") or {}).get("ok")]}
+    for k, c in out.get("configs", {}).items():
+        if "ms" in c:
+            s[k] = [c["ms"], c["frac"], c.get("frac_physical"), (c.get("parity") or {}).get("ok")]
+    return s
+
+
+def finish_line(out):
+    """→ the JSON line, `summary` as its LAST key, shortened until it fits LINE_LIMIT (the details file holds what is shed)"""
+    out.pop("summary", None)
+    out["summary"] = summary_of(out)
+    line = json.dumps(out, separators=(",", ":"))
+    for k in ("rows", "ms_min", "ms_max", "cpu_rows_per_s", "cold_ms", "kernel_ms"):
+        if len(line) <= LINE_LIMIT:
+            break
+        for c in out.get("configs", {}).values():
+            c.pop(k, None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -467,34 +617,41 @@ def main():
 
     from naive_query_engine_amd import AggregateFunc
 
-    global AGGS5
-    AGGS5 = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1), (AggregateFunc.Min, 1), (AggregateFunc.Max, 1)]
+    global AGG
+    AGG = AggregateFunc
     B = Bench(args, world, rank, local_rank)
-    default_rows = {"headline": 10**9, "c3": 10**9, "c2": 10**8, "c4": 10**8, "c4_sparse": 10**8, "agg_groups": 10**8}[args.workload]
+    wl = args.workload
+    default_rows = {"headline": 10**9, "headline_int64": 10**9, "headline_single": 10**9, "agg3": 10**9, "tree_pred": 10**9, "c3": 10**9}.get(wl, 10**8)
     n = args.rows or default_rows
     want_cpu = world == 1 and not args.no_cpu_baseline
-    csteps, cwarm = max(3, min(args.steps, 10)), 2  # the side configs: a few steps each
+    csteps, cwarm, cblocks = max(3, min(args.steps, 10)), 2, 3  # the side configs: three blocks of a few steps each
 
     # ---- the main line
-    if args.workload in ("headline", "c3"):
-        res, st = wl_aggregate(B, n, args.workload == "headline", args.random_keys, args.steps, args.warmup)
-        par = parity_aggregate(B, st, args.cpu_sample_rows) if want_cpu else None
-        name = args.workload + ("_random_keys" if args.random_keys else "")
-    elif args.workload == "agg_groups":
+    agg_shapes = {"headline": ("v", True), "c3": ("v", False), "headline_int64": ("age", True), "headline_single": ("id", True), "agg3": ("three", False),
+                  "tree_pred": ("tree", True)}
+    if wl in agg_shapes:
+        shape, filt = agg_shapes[wl]
+        res, st = wl_aggregate(B, n, filt, args.random_keys, args.steps, args.warmup, shape=shape)
+        par = parity_aggregate(B, st, args.cpu_sample_rows if wl == "headline" else 20_000_000) if want_cpu else None
+        name = {"headline_int64": "headline_int64_values", "headline_single": "headline_single_column", "agg3": "agg_three_value_columns",
+                "tree_pred": "agg_tree_predicate"}.get(wl, wl) + ("_random_keys" if args.random_keys else "")
+    elif wl == "agg_groups":
         res, st = wl_aggregate(B, n, False, False, args.steps, args.warmup, groups=args.groups)
         par = parity_aggregate(B, st, min(args.cpu_sample_rows, 20_000_000)) if want_cpu else None
         name = f"agg_{args.groups}_groups"
-    elif args.workload == "c2":
-        res, st = wl_c2(B, n, args.steps, args.warmup)
+    elif wl in ("c2", "c2_random"):
+        res, st = wl_c2(B, n, args.steps, args.warmup, random_ids=wl == "c2_random")
         par = parity_c2(B, st, args.cpu_sample_rows) if want_cpu else None
-        name = "c2"
+        name = "c2" if wl == "c2" else "c2_random_ids"
     else:
-        sparse = args.workload == "c4_sparse"
-        res, st = wl_c4(B, n, args.dim_rows, sparse, args.steps, args.warmup, gather=args.gather)
+        variant = {"c4": "dense", "c4_sparse": "sparse", "c4_wide": "wide", "c4_dup": "dup", "c4_partial": "partial"}[wl]
+        res, st = wl_c4(B, n, args.dim_rows, variant, args.steps, args.warmup, gather=args.gather)
         par = parity_c4(B, st, 5_000_000) if want_cpu else None
-        name = args.workload
+        name = {"c4": "c4", "c4_sparse": "c4_sparse_keys", "c4_wide": "c4_wide_payload", "c4_dup": "c4_dup_keys", "c4_partial": "c4_partial_match"}[wl]
     attach_traffic(res["roofline"], name)
     n_main = res["rows_per_gpu"]
+    details = {"main": {"name": name, "workload": res["workload"], "kernels": res["roofline"].pop("kernels")}, "configs": {}}
+    res["roofline"].pop("note", None)
     out = {
         "metric": res["metric"], "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -507,17 +664,14 @@ def main():
         out["exchange"] = "nqe_sharded_* (C ABI) on RCCL, collectives on the context's stream"
     if par:
         out["parity_checked"], out["cpu_baseline"] = par
-    if B.comm is not None and args.workload == "headline" and not args.random_keys and args.pass_frac == 0.5:
+    if B.comm is not None and wl == "headline" and not args.random_keys and args.pass_frac == 0.5:
         # no oracle at this size: a size-independent check of the SHARDED result on every rank — ids are row numbers, so group g of
         # `id % 1024` holds exactly the ids g, g + 1024, ... below total/2, and every value lies in [0, 100)
         import numpy as np
 
-        from naive_query_engine_amd import Operator
-        from naive_query_engine_amd.expression import binop, col, lit_i64
-
-        pred = binop(col(0), Operator.Lt, lit_i64(st["total"] // 2)).flatten([F("id"), F("v")])
-        res, keys = B.comm.sharded_aggregate(st["table"], AGGS5, group_nodes=st["key"], pred_nodes=pred)
-        cols = [c.to_numpy() for c in res.to_host()]
+        rs, keys = B.comm.sharded_aggregate(st["table"], st["sh"]["aggs"], group_nodes=st["key"],
+                                            pred_nodes=st["sh"]["pred"](st["total"] // 2).flatten(st["fields"]))
+        cols = [c.to_numpy() for c in rs.to_host()]
         kk = keys.to_host()[0].to_numpy()
         half = st["total"] // 2
         exp_cnt = np.array([(half - g + 1023) // 1024 if g < half else 0 for g in range(1024)], dtype=np.uint64)
@@ -529,51 +683,74 @@ def main():
     del st
 
     # ---- every other config, in the same line
-    if args.workload == "headline" and not args.no_configs and not args.random_keys:
+    if wl == "headline" and not args.no_configs and not args.random_keys:
         cfg = {}
-
+        only = set(x for x in args.only.split(",") if x)
         B.min_warm_s = 0.15
 
         def add(cname, fn, parity=None):
             # (no allocator trimming between configs: memory handed back to the driver and mapped again came back slower — C3 over
             # re-allocated columns ran 8-10 % below the same kernel over the process's first allocations)
+            if only and cname not in only:
+                return
             r, s = fn()
             attach_traffic(r["roofline"], cname)
             if parity and want_cpu:
                 r["parity_checked"], r["cpu_baseline"] = parity(s)
             del s
-            cfg[cname] = r
+            details["configs"][cname] = {"workload": r["workload"], "kernels": r["roofline"].get("kernels"), "spread": r["spread"], "cold_ms": r.get("cold_ms"),
+                                         "roofline": {k: v for k, v in r["roofline"].items() if k != "kernels"},
+                                         "parity_checked": r.get("parity_checked"), "cpu_baseline": r.get("cpu_baseline")}
+            cfg[cname] = compact(r)
 
+        kw = dict(blocks=cblocks, cold=True)
+        pa = lambda rows: (lambda s: parity_aggregate(B, s, rows))
+        pj = lambda s: parity_c4(B, s, 5_000_000)
         # (NQE_BENCH_MULTI_CONFIGS with NQE_FORCE_EXCHANGE: the multi-rank block on one rank through RCCL — a dry run of that code)
         if world == 1 and not (B.distributed and os.environ.get("NQE_BENCH_MULTI_CONFIGS")):
-            add("c3", lambda: wl_aggregate(B, n, False, False, csteps, cwarm), lambda s: parity_aggregate(B, s, 20_000_000))
-            add("headline_random_keys", lambda: wl_aggregate(B, n, True, True, csteps, cwarm), lambda s: parity_aggregate(B, s, 20_000_000))
-            add("c3_random_keys", lambda: wl_aggregate(B, n, False, True, csteps, cwarm))
-            add("c2", lambda: wl_c2(B, 10**8, csteps, cwarm), lambda s: parity_c2(B, s, 20_000_000))
-            add("c4", lambda: wl_c4(B, 10**8, 10**6, False, csteps, cwarm), lambda s: parity_c4(B, s, 5_000_000))
-            add("c4_wide_payload", lambda: wl_c4(B, 10**8, 10**6, False, csteps, cwarm, wide=True))  # attr spans 2^62: an 8 MB payload table
-            add("c4_dim_1e7", lambda: wl_c4(B, 10**8, 10**7, False, csteps, cwarm))
-            add("c4_sparse_keys", lambda: wl_c4(B, 10**8, 10**6, True, csteps, cwarm), lambda s: parity_c4(B, s, 5_000_000))
+            add("c3", lambda: wl_aggregate(B, n, False, False, csteps, cwarm, **kw), pa(20_000_000))
+            add("headline_random_keys", lambda: wl_aggregate(B, n, True, True, csteps, cwarm, **kw), pa(20_000_000))
+            add("c3_random_keys", lambda: wl_aggregate(B, n, False, True, csteps, cwarm, **kw), pa(20_000_000))
+            add("headline_int64_values", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, shape="age", **kw), pa(20_000_000))
+            add("headline_single_column", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, shape="id", **kw), pa(20_000_000))
+            add("agg_three_value_columns", lambda: wl_aggregate(B, n, False, False, csteps, cwarm, shape="three", **kw), pa(20_000_000))
+            add("agg_tree_predicate", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, shape="tree", **kw), pa(20_000_000))
+            add("c2", lambda: wl_c2(B, 10**8, csteps, cwarm, **kw), lambda s: parity_c2(B, s, 20_000_000))
+            add("c2_random_ids", lambda: wl_c2(B, 10**8, csteps, cwarm, random_ids=True, **kw), lambda s: parity_c2(B, s, 20_000_000))
+            add("c4", lambda: wl_c4(B, 10**8, 10**6, "dense", csteps, cwarm, **kw), pj)
+            add("c4_wide_payload", lambda: wl_c4(B, 10**8, 10**6, "wide", csteps, cwarm, **kw), pj)  # attr spans 2^62: an 8 MB payload table
+            add("c4_dim_1e7", lambda: wl_c4(B, 10**8, 10**7, "dense", csteps, cwarm, **kw), pj)
+            add("c4_sparse_keys", lambda: wl_c4(B, 10**8, 10**6, "sparse", csteps, cwarm, **kw), pj)
+            add("c4_dup_keys", lambda: wl_c4(B, 10**8, 10**6, "dup", csteps, cwarm, **kw), pj)
+            add("c4_partial_match", lambda: wl_c4(B, 10**8, 10**6, "partial", csteps, cwarm, **kw), pj)
             for G in (4096, 65536, 1 << 20):
-                add(f"agg_{G}_groups", lambda G=G: wl_aggregate(B, 10**8, False, False, csteps, cwarm, groups=G),
-                    (lambda s: parity_aggregate(B, s, 10_000_000)) if G == 65536 else None)
+                add(f"agg_{G}_groups", lambda G=G: wl_aggregate(B, 10**8, False, False, csteps, cwarm, groups=G, **kw), pa(10_000_000))
         else:
             # the headline without its exchange (every rank aggregates its shard only): step time with and without
-            add("headline_local_only", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, exchange=False))
-            out["exchange_ms_per_step"] = out["ms_per_step"] - cfg["headline_local_only"]["ms_per_step"]
+            add("headline_local_only", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, exchange=False, blocks=cblocks))
+            out["exchange_ms_per_step"] = r4(out["ms_per_step"] - cfg["headline_local_only"]["ms"])
             # C5: the C4 join strong-scaled — build replicated, 10^8 fact rows range-split over the ranks
             shard = 10**8 // world
-            add("c5_probe_only", lambda: wl_c4(B, shard, 10**6, False, csteps, cwarm, gather=False))
-            add("c5_probe_and_gather", lambda: wl_c4(B, shard, 10**6, False, csteps, cwarm, gather=True))
+            add("c5_probe_only", lambda: wl_c4(B, shard, 10**6, "dense", csteps, cwarm, gather=False, blocks=cblocks))
+            add("c5_probe_and_gather", lambda: wl_c4(B, shard, 10**6, "dense", csteps, cwarm, gather=True, blocks=cblocks))
             p, g = cfg["c5_probe_only"], cfg["c5_probe_and_gather"]
-            gather_ms = g["ms_per_step"] - p["ms_per_step"]
+            gather_ms = g["ms"] - p["ms"]
             out_bytes = 24.0 * shard * world  # three distinct 8-byte output columns per row (the shared key column travels once)
             inbound = out_bytes * (world - 1) / world
-            cfg["c5"] = {"workload": f"C4 with the probe side range-split over {world} GPUs ({shard} fact rows each), build replicated; output all-gathered on every rank",
-                         "probe_only_ms": p["ms_per_step"], "gather_ms": gather_ms, "end_to_end_ms": g["ms_per_step"],
-                         "gathered_bytes_per_rank_inbound": inbound, "xgmi_GBps_per_gpu_inbound": inbound / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else None,
-                         "probe_rows_per_s_all_gpus": 10**8 / (p["ms_per_step"] * 1e-3)}
+            cfg["c5"] = {"fact_rows_per_gpu": shard, "probe_only_ms": p["ms"], "gather_ms": r4(gather_ms), "end_to_end_ms": g["ms"],
+                         "gathered_bytes_per_rank_inbound": inbound, "xgmi_GBps_per_gpu_inbound": r4(inbound / (gather_ms * 1e-3) / 1e9) if gather_ms > 0 else None,
+                         "probe_rows_per_s_all_gpus": r4(10**8 / (p["ms"] * 1e-3))}
         out["configs"] = cfg
+
+    line = finish_line(out)  # `summary` = the LAST key: what a record that keeps only the tail of the line still holds
+    dpath = args.details or (os.path.join(ROOT, "gpurun_out", "bench_details.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "")
+    if dpath and rank == 0:
+        try:
+            details["line"] = out
+            with open(dpath, "w") as f:
+                json.dump(details, f, indent=1)
+        except OSError as e:
+            sys.stderr.write(f"bench.py: could not write {dpath}: {e}\n")
 
     # RCCL writes a version banner through C stdio, which (redirected) is flushed at process exit — after Python's own output.
     # Everything buffered so far goes out on every rank first, so that rank 0's JSON line is the LAST line of the job's stdout.
@@ -584,15 +761,16 @@ def main():
     if B.distributed:
         B.dist.barrier()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(line, flush=True)
     if par and not par[0]["ok"]:
         sys.stderr.write("bench.py: PARITY FAILURE against the oracle on the sample\n")
         sys.exit(3)
     if "result_check" in out and not out["result_check"]["ok"]:
         sys.stderr.write("bench.py: the sharded result failed its analytic check\n")
         sys.exit(3)
-    if "configs" in out and any(not c.get("parity_checked", {"ok": True})["ok"] for c in out["configs"].values()):
-        sys.stderr.write("bench.py: PARITY FAILURE against the oracle in a side config\n")
+    bad = [k for k, c in out.get("configs", {}).items() if not c.get("parity", {"ok": True})["ok"]]
+    if bad:
+        sys.stderr.write(f"bench.py: PARITY FAILURE against the oracle in side config(s) {bad}\n")
         sys.exit(3)
     if B.distributed:
         B.dist.barrier()

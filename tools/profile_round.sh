@@ -2,9 +2,9 @@
 # Runs on the GPU box (via gpurun): the default bench line, rocprofv3 kernel stats per config, and the PMC traffic passes
 # (counters in their own runs, --kernel-trace only, one counter per pass) for every config plus the calibration kernels.
 # Output under gpurun_out/$1/ ; tools/summarize_profiles.py turns it into profiles/$1/ (tracked).
-#   usage: tools/profile_round.sh r02
+#   usage: tools/profile_round.sh r03
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

@@ -11,7 +11,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = os.path.join("gpurun_out", tag), os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
 rev = open(os.path.join(src, "csrc_rev.txt")).read().strip() if os.path.exists(os.path.join(src, "csrc_rev.txt")) else None
@@ -105,7 +105,7 @@ for name, (kernels, algo) in CONFIGS.items():
     summary[name] = {"traffic_GB": (fetch_b + write_b) / 1e9, "algorithmic_GB": algo / 1e9, "traffic_ratio": rec["traffic_ratio"]}
 
 for f in sorted(os.listdir(src)):
-    if f.startswith("bench_") and f.endswith(".json"):
+    if (f.startswith("bench_") or f.startswith("cold_")) and f.endswith(".json"):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
     if (f.startswith("probe_") or f == "micro_bench.txt") and f.endswith(".txt"):
         lines = [l for l in open(os.path.join(src, f), errors="replace").read().splitlines() if "amdgpu.ids" not in l and not l.startswith("Hostname") and "Librccl" not in l]
@@ -114,7 +114,7 @@ try:
     d = json.load(open(os.path.join(src, "bench_default.json")))
     summary["bench_default"] = {"headline": {"ms_per_step": d["ms_per_step"], "frac": d["roofline"]["frac"], "parity": d.get("parity_checked")}}
     for k, v in d.get("configs", {}).items():
-        summary["bench_default"][k] = {"ms_per_step": v.get("ms_per_step"), "frac": v.get("roofline", {}).get("frac"), "parity": v.get("parity_checked")}
+        summary["bench_default"][k] = {"ms_per_step": v.get("ms"), "frac": v.get("frac"), "frac_physical": v.get("frac_physical"), "parity": v.get("parity")}
 except Exception as e:  # noqa: BLE001
     summary["bench_default"] = {"error": str(e)}
 json.dump(summary, open(os.path.join(dst, "summary.json"), "w"), indent=1)
