@@ -309,7 +309,16 @@ nqe_status nqe_table_unpack_words(nqe_ctx *ctx, const void *src_device, int32_t 
  *
  * The default transport is RCCL over xGMI, bound at run time (librccl.so.1 is dlopen'ed by the first nqe_comm_* call, never
  * by single-GPU use): rank 0 calls nqe_comm_get_unique_id, the host distributes the 128 bytes by whatever it has (MPI, a
- * store, torch.distributed), every rank calls nqe_comm_create.  nqe_comm_create_custom plugs in the host's own transport. */
+ * store, torch.distributed), every rank calls nqe_comm_create.  nqe_comm_create_custom plugs in the host's own collectives
+ * (all_gather / all_gather_v), nqe_comm_create_p2p the host's own point-to-point primitives (send / recv / group brackets —
+ * MPI, a test fabric): the library then builds its collectives from them with the very code it runs over RCCL's ncclSend /
+ * ncclRecv.
+ *
+ * Failure is collective: every sharded entry point runs its fallible local work (the partial aggregate, the probe, the
+ * selection: data-dependent DivideByZero, out of memory, ...) first, and a rank that fails there STILL enters the operator's
+ * exchange, with its status in the header every exchange starts with — so that every rank returns an error together (the
+ * failing rank its own, the others NQE_ERR_RCCL naming the rank and its status) instead of blocking in a collective the failed
+ * rank never joined. */
 #define NQE_COMM_ID_BYTES 128
 /* rows of the fixed-size buffer a partial aggregate travels in (one collective, counts read on the device); larger partials take
  * an exact-size two-step exchange */
@@ -334,18 +343,34 @@ nqe_status nqe_comm_get_unique_id(void *id_out /* NQE_COMM_ID_BYTES */);
 nqe_status nqe_comm_rccl_version(int32_t *version_out);
 nqe_status nqe_comm_create(nqe_ctx *ctx, const void *unique_id, int32_t rank, int32_t world, nqe_comm **out);
 nqe_status nqe_comm_create_custom(nqe_ctx *ctx, const nqe_transport *transport, int32_t rank, int32_t world, nqe_comm **out);
+/* Point-to-point primitives with RCCL's semantics: send/recv are enqueued on `stream` (or complete before group_end returns),
+ * a send is matched by the peer's recv of the SAME byte count in the same order per (sender, receiver) pair, calls between
+ * group_begin and group_end (which may nest) are issued together, so that a rank may post its sends and receives in any order
+ * without deadlock.  0 = success.  destroy is optional (called by nqe_comm_destroy). */
+typedef struct nqe_p2p {
+    void *user;
+    int32_t (*send)(void *user, const void *buf, size_t bytes, int32_t peer, void *stream);
+    int32_t (*recv)(void *user, void *buf, size_t bytes, int32_t peer, void *stream);
+    int32_t (*group_begin)(void *user);
+    int32_t (*group_end)(void *user);
+    void (*destroy)(void *user);
+} nqe_p2p;
+nqe_status nqe_comm_create_p2p(nqe_ctx *ctx, const nqe_p2p *p2p, int32_t rank, int32_t world, nqe_comm **out);
 nqe_status nqe_comm_destroy(nqe_comm *comm);
 int32_t nqe_comm_rank(const nqe_comm *comm);
 int32_t nqe_comm_world(const nqe_comm *comm);
 /* Ordered variable-length all-gather of a per-rank result table: out = the ranks' tables concatenated in rank order (= row
- * order for row-range shards), on every rank.  8-byte columns without validity only (NQE_ERR_NOT_SUPPORTED otherwise).  Counts
- * travel first (one host wait), then each column moves peer to peer straight from the local table into its place in `out`;
- * columns that share a buffer locally are moved once and share it in `out`. */
+ * order for row-range shards), on every rank — what `concat_batches` (hash_join.rs:258-273) would make of them.  Every column
+ * type of the path travels: 8-byte words move peer to peer straight from the local table into their place in `out` (columns
+ * that share a buffer locally are moved once and share it in `out`); validity bitmaps and Boolean values are received per rank
+ * and shifted to their bit offset (a column is nullable in `out` when it is on any rank); Utf8 bytes land in place and the
+ * offsets are rebased.  A fixed-size header (status, rows, per-column flags and byte counts) travels first: the one host wait. */
 nqe_status nqe_table_all_gather(nqe_comm *comm, const nqe_table *local, nqe_table **out);
 /* PhysicalAggregatePlan::execute (aggregate/mod.rs:113-222) over the union of every rank's `in`: per-rank partial state
  * {count,sum,min,max} → ONE all-gather → merge on every rank; avg is finalised after the merge.  Same output contract as
- * nqe_aggregate_execute on the concatenated input (f64 sums in a different order: 1e-9 relative).  Utf8 group keys are
- * NQE_ERR_NOT_SUPPORTED here. */
+ * nqe_aggregate_execute on the concatenated input (f64 sums in a different order: 1e-9 relative).  Utf8 group keys
+ * (aggregate/mod.rs:170-216) travel as strings: the partials' (key string, state) rows are all-gathered and merged by string;
+ * the output is ordered by first appearance in rank order. */
 nqe_status nqe_sharded_aggregate_execute(nqe_comm *comm, const nqe_table *in, const nqe_expr_node *pred, int32_t pred_nodes,
                                          const nqe_expr_node *group, int32_t group_nodes, const nqe_aggregate *aggs,
                                          int32_t num_aggs, nqe_table **out, nqe_table **keys_out);

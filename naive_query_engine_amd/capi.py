@@ -30,7 +30,7 @@ SYMBOLS = [
     "nqe_aggregate_execute", "nqe_aggregate_partial", "nqe_aggregate_merge", "nqe_aggregate_merge_packed", "nqe_hash_join_execute",
     "nqe_hash_join_build", "nqe_hash_join_probe", "nqe_join_table_release", "nqe_take", "nqe_synth_fill",
     "nqe_device_alloc", "nqe_device_free",
-    "nqe_comm_get_unique_id", "nqe_comm_rccl_version", "nqe_comm_create", "nqe_comm_create_custom", "nqe_comm_destroy", "nqe_comm_rank",
+    "nqe_comm_get_unique_id", "nqe_comm_rccl_version", "nqe_comm_create", "nqe_comm_create_custom", "nqe_comm_create_p2p", "nqe_comm_destroy", "nqe_comm_rank",
     "nqe_comm_world", "nqe_table_all_gather", "nqe_sharded_aggregate_execute", "nqe_sharded_hash_join_probe",
     "nqe_sharded_selection_projection_execute", "nqe_table_import_arrow", "nqe_table_export_arrow",
 ]
@@ -55,6 +55,15 @@ class ArrowArrayStruct(C.Structure):
     """struct ArrowArray of the Arrow C Data Interface (80 bytes)"""
     _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64), ("n_children", C.c_int64),
                 ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+_P2P_SEND_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p)
+
+
+class NqeP2P(C.Structure):
+    """nqe_p2p (include/nqe.h): point-to-point primitives the library builds its collectives from (send and recv share a signature)"""
+    _fields_ = [("user", C.c_void_p), ("send", _P2P_SEND_FN), ("recv", _P2P_SEND_FN), ("group_begin", _GRP_FN), ("group_end", _GRP_FN),
+                ("destroy", _DESTROY_FN)]
 
 
 class NqeTransport(C.Structure):
@@ -126,6 +135,7 @@ def lib():
         "nqe_comm_rccl_version": (i32, [C.POINTER(i32)]),
         "nqe_comm_create": (i32, [vp, vp, i32, i32, pvp]),
         "nqe_comm_create_custom": (i32, [vp, C.POINTER(NqeTransport), i32, i32, pvp]),
+        "nqe_comm_create_p2p": (i32, [vp, C.POINTER(NqeP2P), i32, i32, pvp]),
         "nqe_comm_destroy": (i32, [vp]),
         "nqe_comm_rank": (i32, [vp]),
         "nqe_comm_world": (i32, [vp]),

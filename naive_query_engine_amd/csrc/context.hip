@@ -39,6 +39,7 @@ BufRef dev_alloc(nqe_ctx *ctx, size_t bytes) {
     b->ctx = ctx;
     b->bytes = bytes;
     b->owned = true;
+    b->lib_memory = true;
     size_t cap = round_capacity(bytes);
     auto it = ctx->pool.lower_bound(cap);
     if (it != ctx->pool.end() && it->first <= cap + cap / 4) {
@@ -88,6 +89,7 @@ BufRef dev_view(const BufRef &parent, size_t offset, size_t bytes) {
     v->bytes = bytes;
     v->capacity = bytes;
     v->owned = false;
+    v->lib_memory = parent->lib_memory;
     return BufRef(v, [parent](DevBuf *p) { delete p; });
 }
 
@@ -393,6 +395,14 @@ DevColumn slice_column(nqe_ctx *ctx, const DevColumn &src, int64_t off, int64_t 
         out.null_count = -1;
     }
     return out;
+}
+
+void bitmap_place(nqe_ctx *ctx, const uint8_t *src, uint64_t *dst, int64_t dst_off, int64_t n) {
+    if (n > 0) launch(ctx, "bitmap_place", bitmap_place_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, src, dst, dst_off, n);
+}
+
+void utf8_rebase_offsets(nqe_ctx *ctx, const int32_t *src, int64_t n, int32_t delta, int32_t *dst) {
+    launch(ctx, "utf8_rebase", rebase_offsets_kernel, dim3(stream_grid(ctx, n + 1, 256)), dim3(256), 0, src, n, delta, dst);
 }
 
 DevColumn concat_columns(nqe_ctx *ctx, const std::vector<const DevColumn *> &parts) {

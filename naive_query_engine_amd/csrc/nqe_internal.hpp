@@ -86,6 +86,9 @@ struct DevBuf {
     size_t bytes = 0;    // usable size requested
     size_t capacity = 0; // pooled block size
     bool owned = false;
+    // the memory belongs to the context's pool (an allocation of ours, or a view into one): its reuse is ordered on the context's
+    // stream, so work enqueued on that stream may still be reading it when the last reference goes away.  false: the caller's.
+    bool lib_memory = false;
     ~DevBuf();
 };
 using BufRef = std::shared_ptr<DevBuf>;
@@ -196,6 +199,10 @@ DevColumn take_utf8(nqe_ctx *ctx, const DevColumn &src, const int64_t *idx, int6
 BufRef iota_i64(nqe_ctx *ctx, int64_t first, int64_t n);
 DevColumn slice_column(nqe_ctx *ctx, const DevColumn &src, int64_t off, int64_t len);
 DevColumn concat_columns(nqe_ctx *ctx, const std::vector<const DevColumn *> &parts);
+// dst bits [dst_off, dst_off + n) |= src bits [0, n) (src == nullptr: ones); dst zero-initialised and padded to whole words + 8 bytes
+void bitmap_place(nqe_ctx *ctx, const uint8_t *src, uint64_t *dst, int64_t dst_off, int64_t n);
+// dst[i] = src[i] - src[0] + delta for i in [0, n]: the offsets of a Utf8 part moved behind `delta` bytes of earlier parts
+void utf8_rebase_offsets(nqe_ctx *ctx, const int32_t *src, int64_t n, int32_t delta, int32_t *dst);
 // exclusive prefix sum of n uint32 counts into uint64 offsets (offsets[n] = total); device arrays
 void exclusive_scan_u32_to_u64(nqe_ctx *ctx, const uint32_t *counts, uint64_t *offsets, int64_t n);
 void exclusive_scan_u32_inplace(nqe_ctx *ctx, uint32_t *data, int64_t n);

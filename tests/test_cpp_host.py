@@ -30,3 +30,10 @@ def test_reference_tests_through_cpp_host_mirror():
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "15/15 tests passed" in out.stdout
+
+
+def test_exchange_fabric_test_compiles_and_links():
+    """tests/cpp/test_exchange_fabric.cpp (run on the GPU by tests/test_gpu_parallel.py) builds against the C ABI here"""
+    from tests.test_gpu_parallel import build_fabric_exe
+
+    assert os.path.exists(build_fabric_exe())

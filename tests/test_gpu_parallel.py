@@ -177,6 +177,133 @@ def test_sharded_hash_join_two_ranks_keeps_probe_order():
         assert sp == exp_sp
 
 
+def wide_worker(rank, world, port, q):
+    """nullable + Boolean + Utf8 columns through the exchange: README query 2's shape (Utf8 payloads on both join sides) sharded, a
+    gathered selection over every column type, and a group-by over a Utf8 key"""
+    import torch
+    import torch.distributed as dist
+
+    from naive_query_engine_amd import AggregateFunc, Column, DType, Operator, capi
+    from naive_query_engine_amd.expression import binop, col, lit_i64
+    from naive_query_engine_amd.parallel import make_staged_comm, shard_range, sharded_aggregate, sharded_hash_join, sharded_selection_projection
+    from tests.helpers import fields
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ctx = capi.Context(0)
+        left, right = wide_data()
+        lo, hi = shard_range(right[0].length, rank, world)
+        sub = [Column.from_list(c.to_list()[lo:hi], c.dtype) for c in right]  # (from_list drops a validity bitmap without nulls)
+        comm = make_staged_comm(ctx)
+        t = ctx.table_from_host(sub)
+        out = sharded_hash_join(comm, ctx.table_from_host(left), t, 0, 0, gather=True)
+        f = fields("k", "v", "name", "flag")
+        sp = sharded_selection_projection(comm, t, binop(col(0), Operator.Lt, lit_i64(40)).flatten(f),
+                                          [col(2).flatten(f), col(1).flatten(f), col(3).flatten(f), binop(col(0), Operator.Plus, lit_i64(1)).flatten(f)], gather=True)
+        aggs = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Max, 1), (AggregateFunc.Count, 3)]
+        res, keys = sharded_aggregate(comm, t, aggs, group_nodes=col(2).flatten(f))
+        pack = lambda cols: [(c.dtype.value, c.to_list()) for c in cols]
+        q.put((rank, pack(out.to_host()), pack(sp.to_host()), pack(keys.to_host()), pack(res.to_host())))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def wide_data():
+    from naive_query_engine_amd import Column, DType
+    from tests.helpers import random_utf8
+
+    rng = np.random.default_rng(5)
+    nb, npr = 64, 5003
+    left = [Column.from_numpy(rng.permutation(nb).astype(np.int64)), random_utf8(rng, nb, null_frac=0.2),
+            Column.from_numpy(rng.random(nb), rng.random(nb) > 0.3)]
+    # nulls only in the first third of the probe rows: the second rank's shard has no validity bitmap at all
+    third = npr // 3
+    vmask = np.concatenate([rng.random(third) > 0.2, np.ones(npr - third, dtype=bool)])
+    right = [Column.from_numpy(rng.integers(-2, nb + 2, npr).astype(np.int64)), Column.from_numpy(rng.random(npr) * 10, vmask),
+             random_utf8(rng, npr, null_frac=0.0), Column.from_numpy(rng.random(npr) < 0.5, np.concatenate([rng.random(third) > 0.1, np.ones(npr - third, dtype=bool)]))]
+    return left, right
+
+
+@pytest.mark.timeout(300)
+def test_sharded_operators_move_nullable_boolean_and_utf8_columns():
+    import torch.multiprocessing as mp
+
+    from naive_query_engine_amd import AggregateFunc, Operator
+    from naive_query_engine_amd.expression import binop, col, lit_i64
+    from oracle import oracle as orc
+    from tests.helpers import fields
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = free_port()
+    procs = [mpc.Process(target=wide_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    left, right = wide_data()
+    pack = lambda cols: [(c.dtype.value, c.to_list()) for c in cols]
+    exp_join = pack(orc.hash_join([left], [right], 0, 0)[0])
+    f = fields("k", "v", "name", "flag")
+    sel = orc.selection([right], binop(col(0), Operator.Lt, lit_i64(40)).flatten(f), raw=True)
+    exp_sp = pack(orc.projection(sel, [col(2).flatten(f), col(1).flatten(f), col(3).flatten(f), binop(col(0), Operator.Plus, lit_i64(1)).flatten(f)])[0])
+    aggs = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Max, 1), (AggregateFunc.Count, 3)]
+    # the oracle has no key output: expected rows by key string, computed on the host
+    names, v, flag = right[2].to_list(), right[1].to_list(), right[3].to_list()
+    exp = {}
+    for s, x, b in zip(names, v, flag):
+        e = exp.setdefault(s, [0, 0.0, -np.finfo(np.float64).max, 0])
+        if x is not None:
+            e[0] += 1
+            e[1] += x
+            e[2] = max(e[2], x)
+        if b is not None:
+            e[3] += 1
+    ref_rows = orc.aggregate([right], aggs, group_nodes=col(2).flatten(f))[0]
+    assert ref_rows[0].length == len(exp)  # the oracle agrees on the number of groups
+    for rank, got_join, got_sp, got_keys, got_res in results:
+        assert got_join == exp_join      # Utf8 + nullable payloads of both sides, probe order across the ranks
+        assert got_sp == exp_sp          # Utf8, nullable Float64 (validity on rank 0 only), nullable Boolean, computed Int64
+        keys = got_keys[0][1]
+        assert sorted(keys) == sorted(exp) and len(set(keys)) == len(keys)
+        for i, s in enumerate(keys):
+            cnt, sm, mx, cb = (got_res[c][1][i] for c in range(4))
+            assert cnt == exp[s][0] and cb == exp[s][3] and mx == exp[s][2] and abs(sm - exp[s][1]) <= 1e-9 * abs(exp[s][1])
+
+
+FABRIC_EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_exchange_fabric")
+
+
+def build_fabric_exe():
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "cpp", "test_exchange_fabric.cpp")
+    libdir = os.path.join(root, "naive_query_engine_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", FABRIC_EXE, f"-L{libdir}", "-lnqe_hip",
+                           f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-lpthread"])
+    return FABRIC_EXE
+
+
+@pytest.mark.timeout(900)
+def test_exchange_over_point_to_point_fabric_2_3_8_ranks():
+    """tests/cpp/test_exchange_fabric.cpp: ranks as threads over a send/recv test fabric with RCCL's matching rules — the library's
+    own p2p_all_gather_v (what runs over ncclSend/ncclRecv) with world = 2, 3, 8; every column type; collective failure"""
+    import subprocess
+
+    exe = build_fabric_exe()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=850)
+    print(out.stdout[-6000:], out.stderr[-3000:])
+    assert out.returncode == 0, out.stdout[-6000:] + out.stderr[-3000:]
+    assert "FAIL" not in out.stdout and "checks passed" in out.stdout
+
+
 def _run_check_exchange(nranks):
     import subprocess
     import sys
