@@ -1107,9 +1107,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         static const bool no_hints = getenv("NQE_NO_PLAN_HINTS") != nullptr; // diagnostics (A/B runs)
         auto it = ctx->agg_hints.find(hint_key);
         if (!no_hints && it != ctx->agg_hints.end()) {
-            if (it->second == 1 || it->second == 16) { // 1: PARTS partitions, 16: the smaller first count was enough
-                partition_mode = true;
+            if (it->second == 1 || it->second == 16 || it->second == 17) { // 1: PARTS partitions, 16: the smaller first count was enough
+                partition_mode = true;                                          // 17: the exact form (a slab overflowed or did not fit)
                 if (it->second == 1) slab_parts_log2 = PARTS_LOG2;
+                if (it->second == 17) slab_failed = true;
                 cap = std::max(cap, sized_cap);
             } else if (it->second >= 2 && it->second - 1 <= subsets_max) {
                 subsets_log2 = it->second - 1;
@@ -1135,6 +1136,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         // nullable sources: one value column per pass — the two-column VNULL variants of the fast kernel spill 60-135 VGPRs
         // (3.1-3.4 TB/s); two passes of the one-column variant (5.3 TB/s each over key + one value column) are faster
         const int nv_step = (any_val_nullable || a.key_src.valid || (a.pred_mode != 0 && a.pred_src.valid)) ? 1 : NV;
+        bool slab_oom = false; // the slab allocation failed: redo the attempt in the exact form
         for (int v0 = 0; v0 < std::max(V, 1); v0 += nv_step) {
             a.nv = std::min(nv_step, V - v0);
             if (a.nv < 0) a.nv = 0;
@@ -1296,8 +1298,22 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         // step (the scatter took 0.78 or 0.97 ms depending on where the buffer happened to land)
                         const int64_t capt = ((mean + mean / 4 + 64 + 15) / 16 | 1) * 16;
                         const size_t tw = size_t(1 + a.nv);
-                        BufRef slabs = dev_alloc(ctx, size_t(sparts) * size_t(W) * size_t(capt) * tw * 8 + 16);
-                        BufRef fill = dev_alloc(ctx, size_t(sparts) * size_t(W) * 4);
+                        // the slabs take 1.25x the tuple volume (+ padding) on top of the group table: when that does not fit, the exact
+                        // form (count → scan → scatter into exactly sized partitions) still may — fall back instead of failing
+                        BufRef slabs, fill;
+                        try {
+                            static const bool test_oom = getenv("NQE_TEST_SLAB_OOM") != nullptr; // tests: as if the allocation had failed
+                            if (test_oom) fail(NQE_ERR_OUT_OF_MEMORY, "slab allocation (NQE_TEST_SLAB_OOM)");
+                            slabs = dev_alloc(ctx, size_t(sparts) * size_t(W) * size_t(capt) * tw * 8 + 16);
+                            fill = dev_alloc(ctx, size_t(sparts) * size_t(W) * 4);
+                        } catch (const Error &e) {
+                            if (e.code != NQE_ERR_OUT_OF_MEMORY) throw;
+                            slab_failed = true;
+                            if (hint_key) ctx->agg_hints[hint_key] = 17; // partitioned, exact form: do not try the slabs again
+                            flags_reset(ctx);
+                            slab_oom = true;
+                            break;
+                        }
                         SlabArgs sl;
                         sl.slabs = (uint64_t *)slabs->ptr;
                         sl.fill = (uint32_t *)fill->ptr;
@@ -1406,6 +1422,9 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             if (m > 0 && span <= uint64_t(ka.lds_cap)) {
                                 ka.direct = 1;
                                 ka.direct_bias = sgn ? int64_t(m) - 1 : 0;
+                                // few groups: replicate the table so that the lanes of a wave do not all update the same words
+                                // (at most 64 replicas, at most 1024 slots in all: the merge walks them)
+                                while (ka.direct_rep < 6 && (span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
                             }
                         }
                         ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
@@ -1454,6 +1473,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                        (const Partial *)partials->ptr, grid, a.nv, v0, tb.g);
             }
         }
+        if (slab_oom) continue;
         Collected pre;
         AggResult ranked;
         if (grouped && !tb.g.dense_count && tb.g.cap <= RANK_MAX_CAP) {
@@ -1480,6 +1500,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
         if (f[NQE_FLAG_SLAB_OVERFLOW] && partition_mode && !slab_failed) {
             slab_failed = true; // a partition outgrew its slab (skewed keys): exact partition sizes instead
+            if (hint_key) ctx->agg_hints[hint_key] = 17; // … and the next execution of this query shape starts there
             flags_reset(ctx);
             continue;
         }

@@ -82,6 +82,7 @@ struct AggArgs {
     // fast kernel, key = `col % m` with a small m: the key's value range (-m, m) fits the LDS table, so slot = key + direct_bias —
     // no hash, no probe, no compare on the per-row path of inputs whose key changes every row
     int32_t direct;
+    int32_t direct_rep; // log2 of the replication of a small direct-mapped table (see the fast kernel): span << direct_rep <= lds_cap
     int64_t direct_bias;
     // fast kernel, key subsets: 2^subsets_log2 workgroups share every row range and each keeps only the keys whose hash bits
     // [subset_shift, subset_shift + subsets_log2) name it — 2^subsets_log2 LDS tables' worth of groups without partitioning the rows
@@ -152,8 +153,14 @@ __device__ __forceinline__ uint64_t inline_key(const SimpleExpr &ke, uint64_t x,
     if (KEY == 3) return eval_simple<false>(ke, x, false, nullptr);
     // truncated remainder by a literal: |x| mod |d|, sign of the dividend
     uint64_t sgn = key_signed ? uint64_t((long long)x >> 63) : 0ull;
+    if (KEY == 1) {
+        // |d| = 2^k: x - ((x + (x < 0 ? 2^k - 1 : 0)) & ~(2^k - 1)) — the multiple of 2^k that truncated division rounds to, without
+        // taking and re-applying the sign (8 instead of 12 vector instructions per row)
+        const uint64_t y = (x + (sgn & key_mask)) & ~key_mask;
+        return x - y;
+    }
     uint64_t ux = (x ^ sgn) - sgn;
-    uint64_t ur = KEY == 1 ? (ux & key_mask) : ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
+    uint64_t ur = ux - udiv_magic(ux, key_aux) * key_aux.abs_lit;
     return (ur ^ sgn) - sgn;
 }
 

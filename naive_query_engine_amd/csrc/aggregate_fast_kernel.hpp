@@ -82,6 +82,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         const uint64_t h = key * GOLD;
         return ((uint32_t(h >> a.subset_shift) ^ uint32_t(h >> 23)) & sub_mask) != my_subset;
     };
+    // direct-mapped table (`… % m`): slot of a key.  With few groups every row of a wave would hit the same handful of LDS words
+    // (same-address atomics serialise: `id % 3` over rows whose key changes every row ran at a fifth of the random-key rate), so a
+    // small table is REPLICATED 2^direct_rep times, lane l of a wave updating replica l & (2^rep - 1); the replicas are folded into
+    // replica 0 before the merge.
+    const uint32_t rep_log2 = uint32_t(a.direct_rep), rep_lane = threadIdx.x & ((1u << rep_log2) - 1u);
+    auto direct_slot = [&](uint64_t key) { return int((uint32_t(int64_t(key) + a.direct_bias) << rep_log2) | rep_lane); };
     auto flush_run = [&]() {
         if (SUB && foreign(run_key)) { // another workgroup's key: drop the run
 #pragma unroll
@@ -95,7 +101,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         // early and the host redoes the query partitioned) or, for small inputs, goes to the global table.
         int slot;
         if (a.direct) { // wave-uniform
-            slot = int(int64_t(run_key) + a.direct_bias);
+            slot = direct_slot(run_key);
             // the final merge recognises a used slot by its count; only NULL-able values (a group of NULLs has count 0) need the
             // key word as the mark (every writer stores the same word)
             if (VNULL) lkeys[slot] = run_key;
@@ -152,11 +158,43 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         uint64_t vv[VNULL ? NVT : 1][AGG_U]; // validity word of the wave's 64 rows
         uint64_t kpv[VNULL ? AGG_U : 1];     // key validity AND predicate validity
     };
+    // `base` is wave-uniform (the tile loop's control flow depends on nothing but uniform values, see `stream`): a tile that lies
+    // wholly inside the table is addressed as scalar tile pointer + loop-invariant 32-bit lane offset — no address arithmetic on the
+    // vector unit (the clamped 64-bit row index of the general form cost 8 VALU instructions per row: the kernel is issue-bound)
+    const int64_t step = int64_t(AGG_BLOCK) * AGG_U;
+    uint32_t lane_row[AGG_U];
+#pragma unroll
+    for (int u = 0; u < AGG_U; ++u) lane_row[u] = uint32_t(u) * AGG_BLOCK + threadIdx.x;
+    // rows of tile `base` that exist (wave-uniform, 0 … step)
+    auto tile_rows = [&](int64_t base) {
+        const int64_t r = n - base;
+        return uint32_t(r < 0 ? 0 : (r > step ? step : r));
+    };
     auto load_tile = [&](Tile &t, int64_t base) {
+        if (NT && !VNULL && base + step <= n) {
+            const uint64_t *__restrict__ kt = keyp + base;
+            const uint64_t *__restrict__ pt = predp + (PRED == 2 ? (base >> fp.row_shift) : base);
+            const uint64_t *__restrict__ vt[NVT];
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) vt[j] = valp[j] + base;
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) {
+                t.kw[u] = __builtin_nontemporal_load(&kt[lane_row[u]]);
+                // (a Boolean bitmap predicate: word (base + lane_row) >> 6 with base a multiple of the tile = of 64)
+                if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&pt[lane_row[u] >> fp.row_shift]);
+                if (PRED == 3) t.pw[u] = __builtin_nontemporal_load(&pt[lane_row[u]]);
+                if (PRED == 4) t.pw[u] = a.conj.need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull; // wave-uniform
+#pragma unroll
+                for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&vt[j][lane_row[u]]);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             row = row < last ? row : last; // clamp: unconditional, in-bounds
+            // (the compiler merges the load sequences of the two branches, so both must carry the same non-temporal hint — ordinary
+            // loads here made it drop the hint from the pointer form as well)
             if (NT) {
                 t.kw[u] = __builtin_nontemporal_load(&keyp[row]);
                 if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
@@ -173,6 +211,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 t.kw[u] = keyp[row];
                 if (PRED == 2) t.pw[u] = predp[row >> fp.row_shift];
                 if (PRED == 3) t.pw[u] = predp[row];
+                if (PRED == 4) t.pw[u] = a.conj.need_pw ? predp[row] : 0ull; // wave-uniform
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = valp[j][row];
             }
@@ -198,7 +237,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             slot[u] = -1;
             if (!pass[u]) continue;
             if (a.direct) {
-                slot[u] = int(int64_t(key[u]) + a.direct_bias);
+                slot[u] = direct_slot(key[u]);
                 if (VNULL) lkeys[slot[u]] = key[u];
             } else if (k0[u] == key[u] && key[u] != EMPTY_KEY) {
                 slot[u] = int(uint32_t((key[u] * GOLD) >> a.lds_shift));
@@ -301,10 +340,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
         uint64_t keys[KEY == 3 ? AGG_U : 1];
         if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, reinterpret_cast<uint64_t (&)[AGG_U]>(keys), key_mask, key_aux, key_signed);
+        const uint32_t nrows = tile_rows(base);
 #pragma unroll
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-            bool pass = row < n;
+            bool pass = lane_row[u] < nrows;
             if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
             else if (PRED == 4) pass = pass && conj_pass<3>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) {
@@ -329,10 +369,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         bool pass[AGG_U];
         uint64_t key[AGG_U];
         tile_keys(t, key);
+        const uint32_t nrows = tile_rows(base);
 #pragma unroll
         for (int u = 0; u < AGG_U; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-            pass[u] = row < n;
+            pass[u] = lane_row[u] < nrows;
             if (PRED == 3) pass[u] = pass[u] && pvals[PRED == 3 ? u : 0] != 0;
             else if (PRED == 4) pass[u] = pass[u] && conj_pass<3>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
@@ -358,7 +399,6 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         }
     };
 
-    const int64_t step = int64_t(AGG_BLOCK) * AGG_U;
     const int64_t stride = int64_t(lanes) * step;
     int64_t base = int64_t(lane_id) * step;
     // up to 2 x `budget` tiles.  In: A holds tile `base` (< n).  Out: base >= n (done or abandoned), or A holds tile `base`.
@@ -373,11 +413,14 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             process(B, base);
             base += stride;
             if (base >= n) return;
-            if (*lds_full && (a.allow_partition || __hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            // (the flags are read through readfirstlane: every lane reads the same word, and the compiler must see that the loop's
+            // control flow — hence `base` — is wave-uniform, or the tile pointers above turn into per-lane 64-bit arithmetic)
+            if (__builtin_amdgcn_readfirstlane(*lds_full) &&
+                (a.allow_partition || __builtin_amdgcn_readfirstlane(__hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))) {
                 base = n; // the host redoes the query (partitioned path / larger table)
                 return;
             }
-            if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            if (a.allow_partition && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 base = n; // another workgroup's table overflowed: this attempt is abandoned anyway
                 return;
             }
@@ -407,11 +450,40 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // an abandoned attempt (the host re-runs the query partitioned) does not merge: 2048 slots x 512 workgroups of
     // device-scope atomics were two thirds of what the abandoned attempt cost
     if (a.allow_partition && __hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (a.direct && rep_log2) {
+        // fold the replicas of every key into replica 0 (one thread per key and value column; plain LDS reads and writes)
+        const uint32_t R = 1u << rep_log2, nkeys = cap >> rep_log2;
+        for (uint32_t w = threadIdx.x; w < nkeys * NVT; w += blockDim.x) {
+            const uint32_t kslot = (w % nkeys) << rep_log2, o0 = (w / nkeys) * slots + kslot;
+            uint32_t c = lcnt[o0];
+            double sm = lsum[o0], mn = lmn[o0], mx = lmx[o0];
+            bool used = VNULL && lkeys[kslot] != EMPTY_KEY;
+            uint64_t kw = VNULL ? lkeys[kslot] : 0;
+            for (uint32_t r = 1; r < R; ++r) {
+                const uint32_t cr = lcnt[o0 + r];
+                c = ((c & ~NAN_BIT) + (cr & ~NAN_BIT)) | ((c | cr) & NAN_BIT);
+                sm += lsum[o0 + r];
+                mn = fmin(mn, lmn[o0 + r]);
+                mx = fmax(mx, lmx[o0 + r]);
+                if (VNULL && lkeys[kslot + r] != EMPTY_KEY) {
+                    used = true;
+                    kw = lkeys[kslot + r];
+                }
+            }
+            lcnt[o0] = c;
+            lsum[o0] = sm;
+            lmn[o0] = mn;
+            lmx[o0] = mx;
+            if (VNULL && used && w < nkeys) lkeys[kslot] = kw;
+        }
+        __syncthreads();
+    }
     for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
         uint64_t k;
+        if (a.direct && (s & ((1u << rep_log2) - 1u)) && s != cap) continue; // replicas were folded into replica 0
         if (a.direct && !VNULL) {
             if (lcnt[s] == 0) continue;
-            k = uint64_t(int64_t(s) - a.direct_bias);
+            k = uint64_t(int64_t(s >> rep_log2) - a.direct_bias);
         } else {
             k = lkeys[s];
             if (k == EMPTY_KEY) continue;

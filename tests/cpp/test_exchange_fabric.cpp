@@ -71,6 +71,7 @@ struct RankEnd {
     int rank;
     int depth = 0;
     std::vector<Op> pending;
+    hipStream_t copy_stream = nullptr;
 
     int32_t flush() {
         std::vector<Op> ops;
@@ -120,7 +121,11 @@ struct RankEnd {
                 f->cv.notify_all();
                 break;
             }
-            hipError_t e = hipMemcpy(o.rbuf, msg->buf, o.bytes, hipMemcpyDeviceToDevice);
+            // (a device-to-device hipMemcpy may return before the copy has run: copy on a stream of the fabric's own and wait for it —
+            // the sender reuses its buffer, and this rank's stream reads the destination, as soon as the message counts as done)
+            if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) return 95;
+            hipError_t e = hipMemcpyAsync(o.rbuf, msg->buf, o.bytes, hipMemcpyDeviceToDevice, copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(copy_stream);
             {
                 std::lock_guard<std::mutex> l(f->m);
                 msg->done = true;
@@ -457,7 +462,7 @@ static void check(bool ok, const std::string &what) {
 static std::vector<std::string> run_ranks(int world, const std::vector<HostCol> &whole, double timeout_s, const std::function<void(RankCtx &)> &fn,
                                           bool expect_drained = true) {
     Fabric fab(world, timeout_s);
-    std::vector<RankEnd> ends(size_t(world), RankEnd{&fab, 0});
+    std::vector<RankEnd> ends(static_cast<size_t>(world), RankEnd{&fab, 0, 0, {}, nullptr});
     const std::vector<int64_t> b = shard_bounds(whole[0].n, world);
     std::vector<std::thread> th;
     for (int r = 0; r < world; ++r)

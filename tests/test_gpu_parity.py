@@ -1,6 +1,8 @@
 """GPU parity tests: every hot-path operator through the C ABI (libnqe_hip.so) against the CPU
 oracle on the same seeded inputs.  Bit-exact for integers/booleans/validity/row order; Float64
 sums/avgs within 1e-9 relative (north_star tolerance)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1320,3 +1322,67 @@ def test_aggregate_partitioned_path_two_value_columns(ctx, pred_kind):
     for _ in range(2):  # second run: from the plan hint
         got = ctx.aggregate(t, aggs, group_nodes=col(0).flatten(f3), pred_nodes=pn)
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0, 5], what=f"two value columns, predicate {pred_kind}")
+
+
+@pytest.mark.parametrize("nullable", [False, True])
+@pytest.mark.parametrize("m", [1, 2, 3, 7, 16, 100, 511, 512, 513, 2047])
+def test_aggregate_small_modulus_keys_replicated_table(ctx, m, nullable):
+    """`group by id % m` with few groups (C1's own `id % 3`): the direct-mapped LDS table is replicated per lane group so that a
+    wave's rows do not all update the same words (aggregate_fast_kernel.hpp, direct_rep), and the replicas are folded before the
+    merge.  Signed ids on both sides of zero (keys in (-m, m)), keys that change on every row of a thread, one / two / three value
+    columns (one and two passes), nullable values and keys, an unsigned source; counts exact, sums 1e-9"""
+    rng = np.random.default_rng(1000 + m)
+    n = 300_007
+    ids = (np.arange(n, dtype=np.int64) - n // 3) * (1 if m % 2 else 3)
+    age = rng.integers(-50, 50, n).astype(np.int64)
+    v = rng.random(n) * 200.0 - 100.0
+    u = rng.integers(0, 1 << 40, n).astype(np.uint64)
+    mk = (lambda: rng.random(n) > 0.1) if nullable else (lambda: None)
+    cols = [Column.from_numpy(ids, mk()), Column.from_numpy(age, mk()), Column.from_numpy(v, mk()), Column.from_numpy(u)]
+    f4 = fields("id", "age", "v", "u")
+    t = ctx.table_from_host(cols)
+    for key_col in (0, 3):
+        key = binop(col(key_col), Operator.Modulos, lit_i64(m) if key_col == 0 else lit_u64(m)).flatten(f4)
+        for aggs in (ALL_AGGS(2), ALL_AGGS(1) + ALL_AGGS(2), [(AggregateFunc.Count, 0), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 2)]):
+            for pred in (None, binop(col(0), Operator.Lt, lit_i64(n // 4)).flatten(f4)):
+                exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=pred)[0]
+                got, gk = ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred, with_keys=True)
+                exact = [i for i, (fn, _) in enumerate(aggs) if fn == AggregateFunc.Count]
+                assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=exact, what=f"m={m} key_col={key_col} aggs={len(aggs)} pred={pred is not None}")
+                kk = gk.to_host()[0].to_numpy()
+                assert (np.diff(kk.astype(np.int64 if key_col == 0 else np.uint64)) > 0).all() and len(kk) == exp[0].length
+
+
+def test_aggregate_slab_allocation_failure_falls_back_to_the_exact_form():
+    """when the slab form's scatter buffers cannot be allocated the partitioned aggregate must take the exact
+    count/scan/scatter form instead of failing (NQE_TEST_SLAB_OOM makes the allocation fail), and remember it per query shape"""
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np
+from naive_query_engine_amd import AggregateFunc, Column, capi
+from naive_query_engine_amd.expression import col
+from oracle import oracle as orc
+from tests.helpers import assert_rows_multiset_equal, fields
+rng = np.random.default_rng(3)
+n = 600_000
+cols = [Column.from_numpy(rng.integers(0, 50_000, n).astype(np.int64)), Column.from_numpy(rng.random(n))]
+f = fields("k", "v")
+aggs = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Min, 1), (AggregateFunc.Max, 1)]
+ctx = capi.Context(0)
+t = ctx.table_from_host(cols)
+exp = orc.aggregate([cols], aggs, group_nodes=col(0).flatten(f))[0]
+for rep in range(2):   # the second execution starts from the plan hint (exact form)
+    ctx.timing_enable(True); ctx.timing_reset()
+    got = ctx.aggregate(t, aggs, group_nodes=col(0).flatten(f)).to_host()
+    ctx.timing_enable(False)
+    names = set(ctx.timing_report())
+    assert_rows_multiset_equal(got, exp, 1e-9, exact_cols=[0])
+    assert "agg_partition_count" in names, names      # the exact form ran
+print("fallback ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NQE_TEST_SLAB_OOM="1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 0 and "fallback ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
