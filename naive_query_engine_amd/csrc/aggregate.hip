@@ -738,6 +738,11 @@ __global__ void iota_slots_kernel(uint32_t *out, int64_t n) {
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) out[i] = uint32_t(i);
 }
 
+// the program of a predicate tree, from the kernel arguments into the device buffer the streaming kernel reads it from
+__global__ void store_tree_kernel(TreePred p, TreeInstr *dst) {
+    if (int(threadIdx.x) < p.n) dst[threadIdx.x] = p.ins[threadIdx.x];
+}
+
 // ------------------------------------------------------------------ host side
 struct TableBufs {
     BufRef keys, cnt, sum, mn, mx, nan, dense_counter;
@@ -998,6 +1003,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     DevColumn pred_col; // keeps a materialised predicate alive
     bool pred_may_fault = false;
     int conj_col[CONJ_MAX] = {-1, -1, -1, -1};
+    TreePred tree;   // pred_mode 4
+    BufRef tree_buf; // its program on the device
     auto materialize_pred = [&]() { // the predicate tree as a Boolean column (expression machine), tested bit by bit
         pred_col = evaluate_expr(ctx, in, pred, pred_nodes);
         a.pred_mode = 2;
@@ -1014,6 +1021,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             a.pred_src = src_of(in->cols[size_t(pinfo.s.col)]);
         } else if (grouped && match_conj(in, pred, pred_nodes, &a.conj, conj_col)) {
             a.pred_mode = 3; // resolved (or materialised) per pass, see the launch section
+        } else if (grouped && !pinfo.may_fault && match_tree_pred(in, pred, pred_nodes, &tree)) {
+            a.pred_mode = 4; // likewise
         } else {
             materialize_pred();
         }
@@ -1092,6 +1101,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         if (a.pred_mode == 3) {
             mix(&a.conj, sizeof(a.conj));
             mix(conj_col, sizeof(conj_col));
+        } else if (a.pred_mode == 4) {
+            mix(&tree, sizeof(tree));
         } else if (a.pred_mode) {
             mix(&a.pred, sizeof(a.pred));
             mix(&a.pred_src, sizeof(a.pred_src));
@@ -1218,11 +1229,46 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     }
                     if (!ok) materialize_pred();
                 }
+                // ---- any other fault-free tree over the same columns (pred_mode 4): the stack machine inside the streaming kernel
+                if (a.pred_mode == 4) {
+                    // (instances: one value column per pass, built-in key shapes — the stack machine's registers)
+                    bool ok = !partition_mode && subsets_log2 == 0 && fast_key >= 0 && fast_key != 3 && a.nv == 1 && is_word_type(a.key_src.dtype) && !a.key_src.valid;
+                    for (int j = 0; j < a.nv; ++j) ok = ok && a.val[j].values && !a.val[j].valid;
+                    TreePred tp = tree;
+                    const void *other = nullptr;
+                    int slot_of[TREE_MAX_COLS] = {0, 0, 0};
+                    a.tree_need_pw = 0;
+                    for (int c = 0; ok && c < tree.ncols; ++c) {
+                        const DevColumn &lc = in->cols[size_t(tree.col[c])];
+                        const void *lp = lc.values->ptr;
+                        if (lp == a.key_src.values) slot_of[c] = 0;
+                        else if (lp == a.val[0].values) slot_of[c] = 1;
+                        else {
+                            if (other && other != lp) ok = false; // two such columns: not this kernel's shape
+                            other = lp;
+                            slot_of[c] = 2;
+                            a.tree_need_pw = 1;
+                            a.pred_src = src_of(lc);
+                        }
+                    }
+                    if (ok) {
+                        for (int i = 0; i < tp.n; ++i) {
+                            if (tp.ins[i].a_src >= TS_W0) tp.ins[i].a_src = TS_W0 + slot_of[tp.ins[i].a_src - TS_W0];
+                            if (tp.ins[i].b_src >= TS_W0) tp.ins[i].b_src = TS_W0 + slot_of[tp.ins[i].b_src - TS_W0];
+                        }
+                        tree_buf = dev_alloc(ctx, sizeof(TreeInstr) * TREE_MAX_INSTR);
+                        launch(ctx, "agg_store_tree", store_tree_kernel, dim3(1), dim3(64), 0, tp, (TreeInstr *)tree_buf->ptr);
+                        a.tree_prog = reinterpret_cast<uint64_t>(tree_buf->ptr);
+                        a.tree_n = tp.n;
+                    } else
+                        materialize_pred();
+                }
                 // ---- kernel variant (see the template comment)
                 int pk = 0;
                 AggArgs ka = a;
                 if (a.pred_mode == 2) pk = 2;
                 else if (a.pred_mode == 3) pk = 4;
+                else if (a.pred_mode == 4) pk = 5;
                 else if (a.pred_mode == 1) {
                     const SimpleExpr &pe = a.pred;
                     pk = 3;
@@ -1275,12 +1321,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         }
                     }
                 }
-                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || pk == 4 || bitmap_pred || range_pred || chain_pred);
-                if (pk == 4 && (!fast || vnull)) fail(NQE_ERR_NOT_SUPPORTED, "internal: a two-test predicate reached a kernel that cannot evaluate it");
+                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || pk == 4 || pk == 5 || bitmap_pred || range_pred || chain_pred);
+                if ((pk == 4 || pk == 5) && (!fast || vnull)) fail(NQE_ERR_NOT_SUPPORTED, "internal: a tree predicate reached a kernel that cannot evaluate it");
                 if (fast) {
                     // variant 1 tests the key word with the integer range test alone; Float64 predicates and bitmaps use the
                     // "other column" variant, whose extraction step applies the order mapping
-                    int fp = pk == 0 ? 0 : pk == 4 ? 4 : (chain_pred ? 3 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2));
+                    int fp = pk == 0 ? 0 : pk == 4 ? 4 : pk == 5 ? 5 : (chain_pred ? 3 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2));
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
                     if (partition_mode && !level2 && !slab_failed) {

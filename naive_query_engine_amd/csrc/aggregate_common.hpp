@@ -89,7 +89,108 @@ struct AggArgs {
     int32_t subsets_log2;
     int32_t subset_shift;
     ConjPred conj; // pred_mode 3
+    // pred_mode 4: a predicate tree (nqe_internal.hpp, TreePred) run per row by the fast kernel's stack machine.  The program
+    // lives in a small device buffer that the kernel reads through the scalar cache (a by-value array indexed at run time would
+    // be copied to scratch memory); word slots: 0 key column, 1 first value column, 2 the predicate column (pred_src)
+    uint64_t tree_prog; // device address of TreeInstr[tree_n]
+    int32_t tree_n;
+    int32_t tree_need_pw; // some operand reads word slot 2
 };
+
+// ------------------------------------------------------------------ predicate trees (pred_mode 4)
+typedef const __attribute__((address_space(4))) TreeInstr *TreeProg; // constant address space: uniform loads go through the scalar unit
+
+// Runs the program over a register tile of U rows, operator-major: the instruction's fields are scalars, the (wave-uniform)
+// dispatch on operator, type and operand sources happens once per instruction per tile, the U rows are straight-line code under
+// it.  Two typed stacks: 64-bit VALUES (depth 1: the accumulator `acc`) and BOOLEANS — which stay what a vector compare makes
+// them on this machine, lane masks in scalar registers, so that `and` / `or` are scalar instructions and cost the vector unit
+// nothing (depth 3).  Instruction forms (the host normalises to them, match_tree_pred): x ∈ {acc, word k}, y ∈ {literal, acc,
+// word k}, `rev` swaps the operands of a subtraction or comparison whose literal stood on the left.  No NULLs (the host admits
+// neither nullable columns nor NULL literals) and no faults (divisors are vetted literals).
+template <int U>
+__device__ __forceinline__ void tree_pred_eval(uint64_t prog_addr, int n, const uint64_t (&w0)[U], const uint64_t (&w1)[U], const uint64_t (&w2)[U],
+                                               bool (&res)[U]) {
+    TreeProg prog = (TreeProg)prog_addr;
+    uint64_t acc[U];
+    bool b0[U], b1[U], b2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        acc[u] = 0;
+        b0[u] = b1[u] = b2[u] = false;
+    }
+    for (int pc = 0; pc < n; ++pc) {
+        const int op = prog[pc].op, dt = prog[pc].dt, x_src = prog[pc].a_src, y_src = prog[pc].b_src;
+        if (op == NQE_OP_AND) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { b0[u] = b1[u] && b0[u]; b1[u] = b2[u]; }
+            continue;
+        }
+        if (op == NQE_OP_OR) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { b0[u] = b1[u] || b0[u]; b1[u] = b2[u]; }
+            continue;
+        }
+        const uint64_t lit = prog[pc].lit_b;
+        const bool rev = prog[pc].lit_a != 0;
+        OpAux aux;
+        aux.pow2_shift = prog[pc].aux.pow2_shift;
+        aux.more = prog[pc].aux.more;
+        aux.abs_lit = prog[pc].aux.abs_lit;
+        aux.magic = prog[pc].aux.magic;
+        uint64_t x[U], y[U];
+        if (x_src == TS_STACK) { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = acc[u]; }
+        else if (x_src == TS_W0) { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = w0[u]; }
+        else if (x_src == TS_W0 + 1) { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = w1[u]; }
+        else { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = w2[u]; }
+        if (y_src == TS_LIT) { _Pragma("unroll") for (int u = 0; u < U; ++u) y[u] = lit; }
+        else if (y_src == TS_STACK) { _Pragma("unroll") for (int u = 0; u < U; ++u) y[u] = acc[u]; }
+        else if (y_src == TS_W0) { _Pragma("unroll") for (int u = 0; u < U; ++u) y[u] = w0[u]; }
+        else if (y_src == TS_W0 + 1) { _Pragma("unroll") for (int u = 0; u < U; ++u) y[u] = w1[u]; }
+        else { _Pragma("unroll") for (int u = 0; u < U; ++u) y[u] = w2[u]; }
+        if (rev) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const uint64_t t = x[u]; x[u] = y[u]; y[u] = t; }
+        }
+        if (op <= NQE_OP_GT_EQ) {
+            bool r[U];
+#define NQE_TREE_CMP(O)                                                                                                      \
+    case O:                                                                                                                  \
+        if (dt == NQE_INT64) { _Pragma("unroll") for (int u = 0; u < U; ++u) r[u] = apply_binary<false>(O, NQE_INT64, x[u], y[u], aux, false, nullptr) != 0; }        \
+        else if (dt == NQE_FLOAT64) { _Pragma("unroll") for (int u = 0; u < U; ++u) r[u] = apply_binary<false>(O, NQE_FLOAT64, x[u], y[u], aux, false, nullptr) != 0; } \
+        else { _Pragma("unroll") for (int u = 0; u < U; ++u) r[u] = apply_binary<false>(O, NQE_UINT64, x[u], y[u], aux, false, nullptr) != 0; }                       \
+        break;
+            switch (op) {
+                NQE_TREE_CMP(NQE_OP_EQ) NQE_TREE_CMP(NQE_OP_NOT_EQ) NQE_TREE_CMP(NQE_OP_LT) NQE_TREE_CMP(NQE_OP_LT_EQ) NQE_TREE_CMP(NQE_OP_GT)
+            default:
+                if (dt == NQE_INT64) { _Pragma("unroll") for (int u = 0; u < U; ++u) r[u] = apply_binary<false>(NQE_OP_GT_EQ, NQE_INT64, x[u], y[u], aux, false, nullptr) != 0; }
+                else if (dt == NQE_FLOAT64) { _Pragma("unroll") for (int u = 0; u < U; ++u) r[u] = apply_binary<false>(NQE_OP_GT_EQ, NQE_FLOAT64, x[u], y[u], aux, false, nullptr) != 0; }
+                else { _Pragma("unroll") for (int u = 0; u < U; ++u) r[u] = apply_binary<false>(NQE_OP_GT_EQ, NQE_UINT64, x[u], y[u], aux, false, nullptr) != 0; }
+                break;
+            }
+#undef NQE_TREE_CMP
+#pragma unroll
+            for (int u = 0; u < U; ++u) { b2[u] = b1[u]; b1[u] = b0[u]; b0[u] = r[u]; }
+        } else {
+#define NQE_TREE_OP(O)                                                                                                       \
+    case O:                                                                                                                  \
+        if (dt == NQE_INT64) { _Pragma("unroll") for (int u = 0; u < U; ++u) acc[u] = apply_binary<false>(O, NQE_INT64, x[u], y[u], aux, false, nullptr); }        \
+        else if (dt == NQE_FLOAT64) { _Pragma("unroll") for (int u = 0; u < U; ++u) acc[u] = apply_binary<false>(O, NQE_FLOAT64, x[u], y[u], aux, false, nullptr); } \
+        else { _Pragma("unroll") for (int u = 0; u < U; ++u) acc[u] = apply_binary<false>(O, NQE_UINT64, x[u], y[u], aux, false, nullptr); }                       \
+        break;
+            switch (op) {
+                NQE_TREE_OP(NQE_OP_PLUS) NQE_TREE_OP(NQE_OP_MINUS) NQE_TREE_OP(NQE_OP_MULTIPLY) NQE_TREE_OP(NQE_OP_DIVIDE)
+            default:
+                if (dt == NQE_INT64) { _Pragma("unroll") for (int u = 0; u < U; ++u) acc[u] = apply_binary<false>(NQE_OP_MODULOS, NQE_INT64, x[u], y[u], aux, false, nullptr); }
+                else if (dt == NQE_FLOAT64) { _Pragma("unroll") for (int u = 0; u < U; ++u) acc[u] = apply_binary<false>(NQE_OP_MODULOS, NQE_FLOAT64, x[u], y[u], aux, false, nullptr); }
+                else { _Pragma("unroll") for (int u = 0; u < U; ++u) acc[u] = apply_binary<false>(NQE_OP_MODULOS, NQE_UINT64, x[u], y[u], aux, false, nullptr); }
+                break;
+            }
+#undef NQE_TREE_OP
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) res[u] = b0[u];
+}
 
 __device__ __forceinline__ int lds_find_or_insert(uint64_t *keys, uint64_t key, uint32_t cap, int shift) {
     if (key == EMPTY_KEY) {

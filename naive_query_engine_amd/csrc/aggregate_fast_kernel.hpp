@@ -7,6 +7,15 @@
 #ifndef NQE_AGG_BATCH
 #define NQE_AGG_BATCH 1 // 0: the round-1 row loop (A/B runs)
 #endif
+#ifndef NQE_AGG_BATCH2
+#define NQE_AGG_BATCH2 0 // the batch loop for two value columns, rows one by one (NQE_AGG_BG2): built and measured at the register limit — 8-22 VGPRs spill in every such instance, so it stays off
+#endif
+#ifndef NQE_AGG_BATCH_TREE
+#define NQE_AGG_BATCH_TREE 0 // the batch loop under a tree predicate (PRED = 5)
+#endif
+#ifndef NQE_AGG_BG2
+#define NQE_AGG_BG2 1
+#endif
 #ifndef NQE_AGG_RUN_BUDGET
 #define NQE_AGG_RUN_BUDGET 32 // tile pairs between two looks at the keys while in the run loop
 #endif
@@ -30,7 +39,8 @@ namespace {
 //     computes.
 // PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column, 3 a fault-free integer chain
 // `col op lit … cmp lit` over any column, interpreted operator-major like the KEY = 3 keys, 4 `A and B` / `A or B` of two range
-// tests over the key column, the first value column and at most one more column (AggArgs::conj).
+// tests over the key column, the first value column and at most one more column (AggArgs::conj), 5 any other fault-free predicate
+// tree over those columns, run by the register stack machine of aggregate_common.hpp (tree_pred_eval; AggArgs::tree_prog).
 template <int PRED, int KEY, int NVT, bool VF64, bool VNULL, bool SUB = false>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -135,7 +145,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     };
 
     const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
-    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED >= 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(((PRED >= 2 && PRED != 5) || (PRED == 5 && a.tree_need_pw)) ? a.pred_src.values : a.key_src.values);
     const uint64_t *__restrict__ valp[NVT];
     const uint64_t *__restrict__ kvalid = reinterpret_cast<const uint64_t *>(a.key_src.valid);
     const uint64_t *__restrict__ pvalid = reinterpret_cast<const uint64_t *>(PRED != 0 ? a.pred_src.valid : nullptr);
@@ -184,6 +194,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&pt[lane_row[u] >> fp.row_shift]);
                 if (PRED == 3) t.pw[u] = __builtin_nontemporal_load(&pt[lane_row[u]]);
                 if (PRED == 4) t.pw[u] = a.conj.need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull; // wave-uniform
+                if (PRED == 5) t.pw[u] = a.tree_need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull;
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&vt[j][lane_row[u]]);
             }
@@ -200,6 +211,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
                 if (PRED == 3) t.pw[u] = __builtin_nontemporal_load(&predp[row]);
                 if (PRED == 4) t.pw[u] = a.conj.need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull; // wave-uniform
+                if (PRED == 5) t.pw[u] = a.tree_need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull;
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
                 if (VNULL) {
@@ -221,58 +233,65 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // flush a dependent LDS round trip (slot → read min/max → compare → atomics); the kernel was bound by those waits, not by
     // LDS-atomic throughput (tools/micro_bench.hip: the same update stream issued back to back runs 3x faster).  Such a tile
     // goes to the table directly, all its rows at once: AGG_U slots, one batch of min/max reads, one wait, then the atomics.
+    // (two value columns: the rows of a tile go in two halves — eight more min/max words in flight would not fit the registers)
+    constexpr int BG = NVT == 1 ? AGG_U : NQE_AGG_BG2;
     auto direct_rows = [&](const Tile &t, int64_t base, const bool (&pass)[AGG_U], const uint64_t (&key)[AGG_U]) {
-        int slot[AGG_U];
-        uint64_t k0[AGG_U];
-        if (!a.direct) {
-            // first probe of every row, issued together.  (Advancing all four probe sequences in lockstep, one slot of every
-            // unresolved row per round, was slower: 0.34 -> 0.38 ms per 10^8 rows at 1000 groups, 0.43 -> 0.46 at 3000 — the
-            // kernel is bound by instruction issue, not by the probes' latency.)
-#pragma unroll
-            for (int u = 0; u < AGG_U; ++u) k0[u] = lkeys[uint32_t((key[u] * GOLD) >> a.lds_shift)];
-        }
         bool cold = false;
+        int slot[AGG_U];
 #pragma unroll
-        for (int u = 0; u < AGG_U; ++u) {
-            slot[u] = -1;
-            if (!pass[u]) continue;
-            if (a.direct) {
-                slot[u] = direct_slot(key[u]);
-                if (VNULL) lkeys[slot[u]] = key[u];
-            } else if (k0[u] == key[u] && key[u] != EMPTY_KEY) {
-                slot[u] = int(uint32_t((key[u] * GOLD) >> a.lds_shift));
-            } else {
-                slot[u] = lds_find_or_insert(lkeys, key[u], cap, a.lds_shift);
+        for (int g0 = 0; g0 < AGG_U; g0 += BG) {
+            uint64_t k0[BG];
+            if (!a.direct) {
+                // first probe of every row, issued together.  (Advancing all four probe sequences in lockstep, one slot of every
+                // unresolved row per round, was slower: 0.34 -> 0.38 ms per 10^8 rows at 1000 groups, 0.43 -> 0.46 at 3000 — the
+                // kernel is bound by instruction issue, not by the probes' latency.)
+#pragma unroll
+                for (int i = 0; i < BG; ++i) k0[i] = lkeys[uint32_t((key[g0 + i] * GOLD) >> a.lds_shift)];
             }
-            cold = cold || slot[u] < 0;
-        }
-        double cmn[NVT][AGG_U], cmx[NVT][AGG_U];
 #pragma unroll
-        for (int j = 0; j < NVT; ++j) {
-#pragma unroll
-            for (int u = 0; u < AGG_U; ++u) {
-                const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u] < 0 ? 0 : slot[u]);
-                cmn[j][u] = lmn[o]; // read-before-atomic, all rows of the tile in flight together
-                cmx[j][u] = lmx[o];
+            for (int i = 0; i < BG; ++i) {
+                const int u = g0 + i;
+                slot[u] = -1;
+                if (!pass[u]) continue;
+                if (a.direct) {
+                    slot[u] = direct_slot(key[u]);
+                    if (VNULL) lkeys[slot[u]] = key[u];
+                } else if (k0[i] == key[u] && key[u] != EMPTY_KEY) {
+                    slot[u] = int(uint32_t((key[u] * GOLD) >> a.lds_shift));
+                } else {
+                    slot[u] = lds_find_or_insert(lkeys, key[u], cap, a.lds_shift);
+                }
+                cold = cold || slot[u] < 0;
             }
-        }
-        // the per-row path: one branch (the row takes part), the updates themselves predicated by ordered compares — a NaN fails
-        // both and only raises the group's flag
+            double cmn[NVT][BG], cmx[NVT][BG];
 #pragma unroll
-        for (int j = 0; j < NVT; ++j) {
+            for (int j = 0; j < NVT; ++j) {
 #pragma unroll
-            for (int u = 0; u < AGG_U; ++u) {
-                if (slot[u] < 0) continue;
-                const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-                const double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
-                const bool vb = VNULL ? bool((t.vv[VNULL ? j : 0][u] >> (row & 63)) & 1ull) : true;
-                if (!vb) continue; // a NULL value contributes nothing; its row has created the group above
-                const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
-                atomicAdd(&lcnt[o], 1u);
-                unsafeAtomicAdd(&lsum[o], x);
-                if (x < cmn[j][u]) unsafeAtomicMin(&lmn[o], x);
-                if (x > cmx[j][u]) unsafeAtomicMax(&lmx[o], x);
-                if (x != x) atomicOr(&lcnt[o], NAN_BIT);
+                for (int i = 0; i < BG; ++i) {
+                    const uint32_t o = uint32_t(j) * slots + uint32_t(slot[g0 + i] < 0 ? 0 : slot[g0 + i]);
+                    cmn[j][i] = lmn[o]; // read-before-atomic, all rows of the group in flight together
+                    cmx[j][i] = lmx[o];
+                }
+            }
+            // the per-row path: one branch (the row takes part), the updates themselves predicated by ordered compares — a NaN fails
+            // both and only raises the group's flag
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) {
+#pragma unroll
+                for (int i = 0; i < BG; ++i) {
+                    const int u = g0 + i;
+                    if (slot[u] < 0) continue;
+                    const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+                    const double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+                    const bool vb = VNULL ? bool((t.vv[VNULL ? j : 0][u] >> (row & 63)) & 1ull) : true;
+                    if (!vb) continue; // a NULL value contributes nothing; its row has created the group above
+                    const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
+                    atomicAdd(&lcnt[o], 1u);
+                    unsafeAtomicAdd(&lsum[o], x);
+                    if (x < cmn[j][i]) unsafeAtomicMin(&lmn[o], x);
+                    if (x > cmx[j][i]) unsafeAtomicMax(&lmx[o], x);
+                    if (x != x) atomicOr(&lcnt[o], NAN_BIT);
+                }
             }
         }
         if (cold) { // the table rejected a key (see flush_run): off the per-row path
@@ -338,6 +357,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         // where the compiler sinks them below the predicate (hoisting them cost the headline 1.5 %)
         uint64_t pvals[PRED == 3 ? AGG_U : 1];
         if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
+        bool tpass[PRED == 5 ? AGG_U : 1];
+        if (PRED == 5) tree_pred_eval<AGG_U>(a.tree_prog, a.tree_n, t.kw, t.vw[0], t.pw, reinterpret_cast<bool (&)[AGG_U]>(tpass));
         uint64_t keys[KEY == 3 ? AGG_U : 1];
         if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, reinterpret_cast<uint64_t (&)[AGG_U]>(keys), key_mask, key_aux, key_signed);
         const uint32_t nrows = tile_rows(base);
@@ -346,6 +367,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = lane_row[u] < nrows;
             if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
+            else if (PRED == 5) pass = pass && tpass[PRED == 5 ? u : 0];
             else if (PRED == 4) pass = pass && conj_pass<3>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) {
                 pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
@@ -366,6 +388,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     auto process_batch = [&](const Tile &t, int64_t base) {
         uint64_t pvals[PRED == 3 ? AGG_U : 1];
         if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
+        bool tpass[PRED == 5 ? AGG_U : 1];
+        if (PRED == 5) tree_pred_eval<AGG_U>(a.tree_prog, a.tree_n, t.kw, t.vw[0], t.pw, reinterpret_cast<bool (&)[AGG_U]>(tpass));
         bool pass[AGG_U];
         uint64_t key[AGG_U];
         tile_keys(t, key);
@@ -375,6 +399,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             pass[u] = lane_row[u] < nrows;
             if (PRED == 3) pass[u] = pass[u] && pvals[PRED == 3 ? u : 0] != 0;
+            else if (PRED == 5) pass[u] = pass[u] && tpass[PRED == 5 ? u : 0];
             else if (PRED == 4) pass[u] = pass[u] && conj_pass<3>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             if (VNULL) pass[u] = pass[u] && ((t.kpv[u] >> (row & 63)) & 1ull);
@@ -402,7 +427,28 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     const int64_t stride = int64_t(lanes) * step;
     int64_t base = int64_t(lane_id) * step;
     // up to 2 x `budget` tiles.  In: A holds tile `base` (< n).  Out: base >= n (done or abandoned), or A holds tile `base`.
+    // (PRED = 5: ONE tile in flight — the stack machine's registers take the place of the prefetched tile's; the workgroup's 16
+    // waves hide the loads' latency among themselves)
+    constexpr bool PIPE = PRED != 5;
     auto stream = [&](auto &&process, Tile &A, int budget) {
+        if constexpr (!PIPE) {
+            for (int64_t it = 0; it < 2 * int64_t(budget); ++it) {
+                process(A, base);
+                base += stride;
+                if (base >= n) return;
+                load_tile(A, base);
+                if (__builtin_amdgcn_readfirstlane(*lds_full) &&
+                    (a.allow_partition || __builtin_amdgcn_readfirstlane(__hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))) {
+                    base = n;
+                    return;
+                }
+                if (a.allow_partition && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&flags[NQE_FLAG_NEED_PARTITION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    base = n;
+                    return;
+                }
+            }
+            return;
+        }
         Tile B;
         for (int it = 0; it < budget; ++it) {
             load_tile(B, base + stride); // prefetch (clamped, always issued)
@@ -430,7 +476,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         Tile A;
         load_tile(A, base);
         // not where registers are short: the VNULL variants (37 VGPRs spilled: 2.2x slower), two value columns, interpreted predicates
-        constexpr bool CAN_BATCH = NQE_AGG_BATCH && !VNULL && NVT == 1 && PRED != 3 && !(PRED == 2 && KEY == 3) && !(PRED == 4 && KEY == 3);
+        constexpr bool CAN_BATCH = NQE_AGG_BATCH && !VNULL && PRED != 3 && (PRED != 5 || (NQE_AGG_BATCH_TREE && KEY != 3 && NVT == 1)) && !(PRED == 2 && KEY == 3) && !(PRED == 4 && KEY == 3) &&
+                                   (NVT == 1 || (NQE_AGG_BATCH2 && KEY != 3 && PRED != 4));
         while (base < n) {
             bool batch = false; // wave-uniform
             if (CAN_BATCH) {
@@ -503,14 +550,15 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64, bool sub) {
     if (sub) {
         // (PRED 4: a query that outgrows one table continues with a materialised predicate; its slice is built without validity only)
-        if constexpr (VNULL || PRED == 4) return nullptr;
+        if constexpr (VNULL || PRED >= 4) return nullptr;
         else {
             if (nv != 1) return nullptr;
             return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, false, true> : agg_grouped_fast_kernel<PRED, KEY, 1, false, false, true>;
         }
     }
-    if (nv == 1) return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 1, false, VNULL>;
-    if constexpr (VNULL) {
+    if constexpr (PRED == 5 && KEY == 3) return nullptr; // (a tree predicate under an interpreted key: registers)
+    else if (nv == 1) return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 1, false, VNULL>;
+    if constexpr (VNULL || PRED == 5) {
         return nullptr; // nullable sources take one value column per pass (aggregate.hip): the two-column variants spilled 60-135 VGPRs
     } else {
         return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 2, false, VNULL>;

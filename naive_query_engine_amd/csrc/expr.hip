@@ -803,6 +803,82 @@ bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred
     return true;
 }
 
+bool match_tree_pred(const nqe_table *in, const nqe_expr_node *nodes, int n, TreePred *out) {
+    std::memset(out, 0, sizeof(*out));
+    int root;
+    std::vector<Node> t;
+    try {
+        t = parse(in, nodes, n, &root);
+    } catch (...) {
+        return false; // the operator's own analysis reports the problem
+    }
+    if (t[size_t(root)].out_dtype != NQE_BOOLEAN || t[size_t(root)].kind != NQE_EXPR_BINARY) return false;
+    ExProgram P;
+    bool needs_valid = false;
+    if (!build_program(in, t, root, &P, &needs_valid) || needs_valid) return false;
+    if (P.n > TREE_MAX_INSTR || P.ncols > TREE_MAX_COLS) return false;
+    // typed stacks (see tree_pred_eval): one VALUE register, three BOOLEAN levels; normal forms x ∈ {stack, word}, y ∈ {literal,
+    // stack, word}, lit_a = 1: the operands are swapped back before the operation
+    int vdepth = 0, bdepth = 0;
+    for (int i = 0; i < P.n; ++i) {
+        const ExInstr &I = P.ins[i];
+        if (I.a_src == EX_LIT_NULL || I.b_src == EX_LIT_NULL) return false;
+        TreeInstr &T = out->ins[i];
+        T.op = I.op;
+        T.dt = I.dt;
+        T.lit_a = 0;
+        T.lit_b = 0;
+        T.aux = I.aux;
+        auto src = [](int s) { return s >= EX_COL ? int(TS_W0) + (s - EX_COL) : (s == EX_LIT ? int(TS_LIT) : int(TS_STACK)); };
+        if (I.op == NQE_OP_AND || I.op == NQE_OP_OR) {
+            if (I.a_src != EX_STACK || I.b_src != EX_STACK) return false; // a Boolean literal or column as an operand: not this machine's
+            if (bdepth < 2) return false;
+            --bdepth;
+            T.a_src = T.b_src = TS_STACK;
+            continue;
+        }
+        if (I.dt == NQE_BOOLEAN) return false; // comparing Booleans
+        if (I.a_src == EX_LIT && I.b_src == EX_LIT) return false;
+        int xs = src(I.a_src), ys = src(I.b_src);
+        uint64_t lit = I.lit_b;
+        bool rev = false;
+        if (xs == TS_LIT) { // literal on the left: swap, and remember it for the operators that are not commutative
+            xs = ys;
+            ys = TS_LIT;
+            lit = I.lit_a;
+            rev = I.op != NQE_OP_PLUS && I.op != NQE_OP_MULTIPLY && I.op != NQE_OP_EQ && I.op != NQE_OP_NOT_EQ;
+            T.aux.pow2_shift = T.aux.more = -1;
+        }
+        if (I.op == NQE_OP_DIVIDE || I.op == NQE_OP_MODULOS) {
+            // no fault may be possible: the kernel has no flag path for the predicate
+            if (ys != TS_LIT || rev) return false;
+            if (I.dt == NQE_FLOAT64 ? (lit == 0 || lit == 0x8000000000000000ull) : (lit == 0 || lit == ~0ull)) return false;
+        }
+        const int pops = int(xs == TS_STACK) + int(ys == TS_STACK);
+        if (pops > vdepth) return false;
+        vdepth -= pops;
+        if (I.op <= NQE_OP_GT_EQ) {
+            if (++bdepth > 3) return false;
+        } else if (++vdepth > 1)
+            return false; // two arithmetic subtrees alive at once
+        T.a_src = xs;
+        T.b_src = ys;
+        T.lit_a = rev ? 1 : 0;
+        T.lit_b = lit;
+    }
+    if (vdepth != 0 || bdepth != 1) return false;
+    for (int c = 0; c < P.ncols; ++c) {
+        if (!is_word_type(P.col_dtype[c])) return false;
+        out->col[c] = -1;
+        for (size_t k = 0; k < in->cols.size(); ++k)
+            if (in->cols[k].values && in->cols[k].values->ptr == P.col_values[c] && in->cols[k].dtype == P.col_dtype[c] && !in->cols[k].validity) out->col[c] = int(k);
+        if (out->col[c] < 0) return false;
+    }
+    out->n = P.n;
+    out->ncols = P.ncols;
+    return true;
+}
+
 FastPred bitmap_fast_pred() {
     FastPred fp{};
     fp.lo = fp.hi = 1;

@@ -280,6 +280,26 @@ struct ConjPred {
     int32_t need_pw; // aggregate: some test reads the predicate column (src == 2)
     int32_t pad;
 };
+// Any other fault-free predicate tree over at most three non-null 8-byte columns (`v < 20 or id % 3 = 0`, `a + b > c`, …): a
+// register stack machine runs it per row INSIDE the consuming kernel (the aggregate's streaming kernel: the tested columns are
+// its key column, its first value column and at most one more) instead of a pass that materialises a Boolean column.  One
+// instruction per BINARY node, post-order; operands: the stack (depth <= 2), a literal, or one of the row's loaded words.
+constexpr int TREE_MAX_INSTR = 12, TREE_MAX_COLS = 3;
+enum TreeSrc : int32_t { TS_STACK = 0, TS_LIT = 1, TS_W0 = 4 /* + word slot */ };
+struct TreeInstr {
+    int32_t op, dt;       // operator, operand dtype
+    int32_t a_src, b_src; // TreeSrc
+    uint64_t lit_a, lit_b;
+    OpAux aux;            // host-prepared divisor constants when b is a literal
+};
+struct TreePred {
+    int32_t n, ncols;
+    TreeInstr ins[TREE_MAX_INSTR];
+    int32_t col[TREE_MAX_COLS]; // table column behind word slot k of the program as built (the consumer renumbers the slots)
+};
+// false: the tree does not fit (nullable / non-word columns, NULL or Utf8 literals, more columns or instructions, a deeper stack, a
+// divisor that is not a literal other than 0 and -1 — anything that could raise a device flag)
+bool match_tree_pred(const nqe_table *in, const nqe_expr_node *nodes, int n, TreePred *out);
 // recognises the shape (see expr.hip); cols[CONJ_MAX] receive the tested column of every test
 bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred *out, int *cols);
 // FastPred "bit r of a non-null Boolean bitmap is set"

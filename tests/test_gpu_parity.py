@@ -1386,3 +1386,54 @@ print("fallback ok")
     env = dict(os.environ, NQE_TEST_SLAB_OOM="1", PYTHONPATH=root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert out.returncode == 0 and "fallback ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("groups", [3, 1000, 70000])
+def test_aggregate_predicate_trees_run_inside_the_streaming_kernel(ctx, groups):
+    """predicate trees that are neither a chain nor a list of range tests (`v < 20 or id % 3 = 0`, `a + w > 50 and …`, a literal on
+    the left of a subtraction, column-with-column arithmetic and comparisons, three columns): the typed stack machine of
+    aggregate_common.hpp (tree_pred_eval, PRED = 5) inside agg_grouped_fast_kernel — no materialised Boolean column (no expr_tree
+    launch) while the groups fit one workgroup table; with 70000 groups (partitioned path) and for shapes the machine does not take
+    (two arithmetic subtrees alive at once) the predicate is materialised.  Always equal to the oracle."""
+    rng = np.random.default_rng(77 + groups)
+    n = 400_003
+    ids = rng.permutation(n).astype(np.int64) - n // 5
+    k = rng.integers(0, groups, n).astype(np.int64)
+    v = rng.random(n) * 100.0
+    w = rng.integers(-100, 100, n).astype(np.int64)
+    v[::97] = np.nan
+    cols = [Column.from_numpy(ids), Column.from_numpy(k), Column.from_numpy(v), Column.from_numpy(w)]
+    f4 = fields("id", "k", "v", "w")
+    t = ctx.table_from_host(cols)
+    I, K, V, W = col(0), col(1), col(2), col(3)
+    B = lambda a, op, b: binop(a, op, b)
+    O = Operator
+    trees = [
+        (True, B(B(V, O.Lt, lit_f64(20.0)), O.Or, B(B(I, O.Modulos, lit_i64(3)), O.Eq, lit_i64(0)))),
+        (True, B(B(B(lit_i64(100), O.Minus, W), O.Gt, lit_i64(120)), O.Or, B(B(V, O.Multiply, lit_f64(2.0)), O.GtEq, lit_f64(150.0)))),
+        (True, B(B(B(W, O.Plus, K), O.Lt, lit_i64(50)), O.And, B(B(V, O.NotEq, V), O.Or, B(lit_f64(30.0), O.Lt, V)))),     # col + col, NaN != NaN, literal-left compare
+        (True, B(B(B(B(W, O.Divide, lit_i64(7)), O.Multiply, lit_i64(3)), O.LtEq, K), O.Or, B(W, O.Eq, lit_i64(5)))),       # chain compared with a column
+        (True, B(B(K, O.Lt, W), O.And, B(B(K, O.Gt, lit_i64(1)), O.Or, B(B(W, O.Modulos, lit_i64(-4)), O.Eq, lit_i64(-3))))),
+        (False, B(B(B(W, O.Plus, lit_i64(1)), O.Lt, B(K, O.Multiply, lit_i64(2))), O.Or, B(W, O.Eq, lit_i64(5)))),         # two arithmetic subtrees alive
+        (False, B(B(B(W, O.Modulos, lit_i64(0)), O.Lt, lit_i64(3)), O.Or, B(W, O.Eq, lit_i64(5)))),                           # faults: DivideByZero
+    ]
+    aggs = ALL_AGGS(2)
+    key = K.flatten(f4)
+    for in_kernel, tree in trees:
+        pred = tree.flatten(f4)
+        try:
+            exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=pred)[0]
+        except ErrorCode as e:
+            with pytest.raises(ErrorCode) as ge:
+                ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred)
+            assert ge.value.status == e.status
+            continue
+        for rep in range(2):  # the second execution starts from the plan hint
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            got = ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred).to_host()
+            ctx.timing_enable(False)
+            names = set(ctx.timing_report())
+            assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"groups={groups} tree={tree!r}")
+            if groups <= 1000:
+                assert ("expr_tree" not in names) == in_kernel, (names, repr(tree))
