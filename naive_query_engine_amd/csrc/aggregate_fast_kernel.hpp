@@ -13,6 +13,9 @@
 #ifndef NQE_AGG_BATCH_TREE
 #define NQE_AGG_BATCH_TREE 0 // the batch loop under a tree predicate (PRED = 5)
 #endif
+#ifndef NQE_TREE_PIPE
+#define NQE_TREE_PIPE 0 // the prefetched second tile under a tree predicate (A/B)
+#endif
 #ifndef NQE_AGG_BG2
 #define NQE_AGG_BG2 1
 #endif
@@ -429,7 +432,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // up to 2 x `budget` tiles.  In: A holds tile `base` (< n).  Out: base >= n (done or abandoned), or A holds tile `base`.
     // (PRED = 5: ONE tile in flight — the stack machine's registers take the place of the prefetched tile's; the workgroup's 16
     // waves hide the loads' latency among themselves)
-    constexpr bool PIPE = PRED != 5;
+    constexpr bool PIPE = PRED != 5 || NQE_TREE_PIPE;
     auto stream = [&](auto &&process, Tile &A, int budget) {
         if constexpr (!PIPE) {
             for (int64_t it = 0; it < 2 * int64_t(budget); ++it) {

@@ -53,7 +53,7 @@ print(f"upload {n} rows x 2 cols ({1.6:.1f} GB, pageable numpy): {up*1e3:.1f} ms
 del t
 
 # ---- 2. nullable columns (1% nulls) → general kernel
-n = 200_000_000 if SECTION in ('all', 'paths', 'keys', 'exprs') else 100_000_000
+n = 200_000_000 if SECTION in ('all', 'paths', 'keys', 'exprs', 'trees') else 100_000_000
 idt = torch.empty(n, dtype=torch.int64, device=dev); ctx.synchronize()
 ctx.synth_fill(0, 0, 0, n, 1, 0, idt.data_ptr())
 vt = torch.empty(n, dtype=torch.float64, device=dev)
@@ -224,3 +224,26 @@ if SECTION in ("all", "joinshapes"):
     bk = torch.randperm(nb, device=dev, generator=g)
     pk3 = torch.randint(0, nb * 10, (npr,), device=dev, generator=g)
     run("dense unique, ~10% match", bk, pk3)
+
+# ---- 6. predicate trees inside the aggregate's streaming kernel (PRED = 5) against chains / range lists / the materialised form
+if SECTION in ("all", "trees"):
+    from naive_query_engine_amd.expression import lit_f64
+    B = binop
+    O = Operator
+    I, V = col(0), col(1)
+    trees = [("id < N/2 (range test)", B(I, O.Lt, lit_i64(n // 2))),
+             ("id % 10 < 5 (chain)", B(B(I, O.Modulos, lit_i64(10)), O.Lt, lit_i64(5))),
+             ("id < N/2 and v > 10 (range list)", B(B(I, O.Lt, lit_i64(n // 2)), O.And, B(V, O.Gt, lit_f64(10.0)))),
+             ("v < 20 or id % 3 == 0 (tree)", B(B(V, O.Lt, lit_f64(20.0)), O.Or, B(B(I, O.Modulos, lit_i64(3)), O.Eq, lit_i64(0)))),
+             ("v < 20 or id % 4 == 0 (tree, pow2)", B(B(V, O.Lt, lit_f64(20.0)), O.Or, B(B(I, O.Modulos, lit_i64(4)), O.Eq, lit_i64(0)))),
+             ("v < 20 or id + 5 < 1000 (tree, add)", B(B(V, O.Lt, lit_f64(20.0)), O.Or, B(B(I, O.Plus, lit_i64(5)), O.Lt, lit_i64(1000)))),
+             ("v * 2.0 < id-free: v * 2.0 < 40.0 or v > 90.0 (tree)", B(B(B(V, O.Multiply, lit_f64(2.0)), O.Lt, lit_f64(40.0)), O.Or, B(V, O.Gt, lit_f64(90.0)))),
+             ("6 compares and/or", B(B(B(V, O.Lt, lit_f64(20.0)), O.Or, B(B(I, O.Modulos, lit_i64(3)), O.Eq, lit_i64(0))), O.And,
+                                     B(B(B(I, O.Plus, lit_i64(7)), O.Gt, lit_i64(100)), O.Or, B(B(V, O.Multiply, V), O.Lt, lit_f64(2500.0)))))]
+    for name, tr in trees:
+        q = timeit(lambda: ctx.aggregate(plain, aggs, group_nodes=key, pred_nodes=tr.flatten(f)), reps=10)
+        ctx.timing_enable(True); ctx.timing_reset()
+        r = ctx.aggregate(plain, aggs, group_nodes=key, pred_nodes=tr.flatten(f)); del r
+        ctx.timing_enable(False)
+        br = {k: round(v[0], 3) for k, v in ctx.timing_report().items() if v[0] > 0.02}
+        print(f"aggregate {n} rows under {name}: {q*1e3:.3f} ms = {16*n/q/1e9:.0f} GB/s  {br}")
