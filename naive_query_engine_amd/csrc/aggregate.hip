@@ -1209,6 +1209,9 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 }
                 if (a.pred_mode == 3) {
                     bool ok = !partition_mode && subsets_log2 == 0 && fast_key >= 0 && a.nv >= 1 && is_word_type(a.key_src.dtype) && !a.key_src.valid;
+                    // (the general form — tests with an arithmetic step, nested and/or — runs in the PRED = 5 instances: one value
+                    // column per pass, built-in key shapes)
+                    if (a.conj.general) ok = ok && a.nv == 1 && fast_key != 3;
                     for (int j = 0; j < a.nv; ++j) ok = ok && a.val[j].values && !a.val[j].valid;
                     const void *other = nullptr; // the one column the kernel would load for the predicate alone
                     if (ok) {
@@ -1267,7 +1270,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 int pk = 0;
                 AggArgs ka = a;
                 if (a.pred_mode == 2) pk = 2;
-                else if (a.pred_mode == 3) pk = 4;
+                else if (a.pred_mode == 3) pk = a.conj.general ? 5 : 4;
                 else if (a.pred_mode == 4) pk = 5;
                 else if (a.pred_mode == 1) {
                     const SimpleExpr &pe = a.pred;
@@ -1280,6 +1283,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             ka.pred.lit_left[0] = 0;
                         }
                     }
+                }
+                if (pk == 5 && a.pred_mode == 3) { // the general range-test form in the interpreted-predicate instances
+                    ka.tree_n = 0;
+                    ka.tree_need_pw = a.conj.need_pw;
                 }
                 bool plain = is_word_type(a.key_src.dtype);
                 // a Boolean predicate column without nulls (a Boolean input column, or any predicate tree evaluated by the

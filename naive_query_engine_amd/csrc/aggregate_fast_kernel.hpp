@@ -327,6 +327,15 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // 2.36 -> 2.47 ms with the test on every tile, still +2-3 % with a per-tile mode branch inside one loop), so they are two
     // separate streaming loops and a wave re-picks between them every 64 tiles from the keys of the tile in hand: batch when a
     // quarter of its lanes see mixed keys (random keys: 2.90 -> 2.57 ms).
+    // PRED = 5, the interpreted predicates: tree_n == 0 — tests with an arithmetic step under any and/or nesting (ConjPred, general
+    // form: straight-line tests + truth table); else the stack machine's program
+    auto eval_interpreted = [&](const Tile &t, bool (&res)[AGG_U]) {
+        if (a.tree_n == 0) { // wave-uniform
+#pragma unroll
+            for (int u = 0; u < AGG_U; ++u) res[u] = conj_pass<3, true>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
+        } else
+            tree_pred_eval<AGG_U>(a.tree_prog, a.tree_n, t.kw, t.vw[0], t.pw, res);
+    };
     auto accumulate_row = [&](const Tile &t, int u, int64_t row, uint64_t key) {
         if (!run_live || key != run_key) {
             if (run_live) flush_run();
@@ -361,7 +370,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         uint64_t pvals[PRED == 3 ? AGG_U : 1];
         if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
         bool tpass[PRED == 5 ? AGG_U : 1];
-        if (PRED == 5) tree_pred_eval<AGG_U>(a.tree_prog, a.tree_n, t.kw, t.vw[0], t.pw, reinterpret_cast<bool (&)[AGG_U]>(tpass));
+        if (PRED == 5) eval_interpreted(t, reinterpret_cast<bool (&)[AGG_U]>(tpass));
         uint64_t keys[KEY == 3 ? AGG_U : 1];
         if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, reinterpret_cast<uint64_t (&)[AGG_U]>(keys), key_mask, key_aux, key_signed);
         const uint32_t nrows = tile_rows(base);
@@ -371,7 +380,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             bool pass = lane_row[u] < nrows;
             if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
             else if (PRED == 5) pass = pass && tpass[PRED == 5 ? u : 0];
-            else if (PRED == 4) pass = pass && conj_pass<3>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
+            else if (PRED == 4) pass = pass && conj_pass<3, false>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) {
                 pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             }
@@ -392,7 +401,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         uint64_t pvals[PRED == 3 ? AGG_U : 1];
         if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
         bool tpass[PRED == 5 ? AGG_U : 1];
-        if (PRED == 5) tree_pred_eval<AGG_U>(a.tree_prog, a.tree_n, t.kw, t.vw[0], t.pw, reinterpret_cast<bool (&)[AGG_U]>(tpass));
+        if (PRED == 5) eval_interpreted(t, reinterpret_cast<bool (&)[AGG_U]>(tpass));
         bool pass[AGG_U];
         uint64_t key[AGG_U];
         tile_keys(t, key);
@@ -403,7 +412,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             pass[u] = lane_row[u] < nrows;
             if (PRED == 3) pass[u] = pass[u] && pvals[PRED == 3 ? u : 0] != 0;
             else if (PRED == 5) pass[u] = pass[u] && tpass[PRED == 5 ? u : 0];
-            else if (PRED == 4) pass[u] = pass[u] && conj_pass<3>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
+            else if (PRED == 4) pass[u] = pass[u] && conj_pass<3, false>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             if (VNULL) pass[u] = pass[u] && ((t.kpv[u] >> (row & 63)) & 1ull);
         }

@@ -217,13 +217,46 @@ __device__ __forceinline__ bool conj_test(const ConjTest &t, uint64_t w) {
     const int64_t xs = int64_t(x ^ t.flip);
     return ((xs >= t.lo) && (xs <= t.hi)) != (t.negate != 0);
 }
+// the arithmetic step of a test (wave-uniform dispatch; operands vetted by the host: no fault possible)
+__device__ __forceinline__ uint64_t conj_pre(const ConjTest &t, uint64_t w) {
+    const uint64_t a = t.pre_rev ? t.pre_lit : w, b = t.pre_rev ? w : t.pre_lit;
+    if (t.pre_dt == NQE_FLOAT64) {
+        const double x = u2d(a), y = u2d(b);
+        switch (t.pre) {
+        case NQE_OP_PLUS: return d2u(x + y);
+        case NQE_OP_MINUS: return d2u(x - y);
+        case NQE_OP_MULTIPLY: return d2u(x * y);
+        default: return d2u(x / y); // (Float64 modulus is not admitted)
+        }
+    }
+    switch (t.pre) {
+    case NQE_OP_PLUS: return a + b;
+    case NQE_OP_MINUS: return a - b;
+    case NQE_OP_MULTIPLY: return a * b;
+    default: break;
+    }
+    if (t.pre_dt == NQE_INT64) return apply_binary<false>(t.pre == NQE_OP_DIVIDE ? NQE_OP_DIVIDE : NQE_OP_MODULOS, NQE_INT64, a, b, t.pre_aux, false, nullptr);
+    return apply_binary<false>(t.pre == NQE_OP_DIVIDE ? NQE_OP_DIVIDE : NQE_OP_MODULOS, NQE_UINT64, a, b, t.pre_aux, false, nullptr);
+}
+
 // NSRC: how many distinct words a test may name (the selects are VALU work the aggregate's streaming kernel feels: with the
 // four-way select `id < N/2 and v > 10` ran at 4.5 TB/s, with the three words it actually has at 5.3)
-template <int NSRC>
+// GENERAL = false: the caller guarantees c.general == 0 (the aggregate's lean PRED = 4 instances: the general form's registers made
+// every one of them spill; it runs in the PRED = 5 instances instead)
+template <int NSRC, bool GENERAL = true>
 __device__ __forceinline__ bool conj_pass(const ConjPred &c, uint64_t w0, uint64_t w1 = 0, uint64_t w2 = 0, uint64_t w3 = 0) {
     // (constant test indices throughout: a helper taking the index at run time sent the whole ConjPred to scratch memory — 3.7x slower)
-#define NQE_CONJ_TEST(T)                                                                               \
-    conj_test(c.t[T], (NSRC > 3 && c.t[T].src == 3) ? w3 : (NSRC > 2 && c.t[T].src == 2) ? w2 : (NSRC > 1 && c.t[T].src == 1) ? w1 : w0)
+#define NQE_CONJ_WORD(T) ((NSRC > 3 && c.t[T].src == 3) ? w3 : (NSRC > 2 && c.t[T].src == 2) ? w2 : (NSRC > 1 && c.t[T].src == 1) ? w1 : w0)
+    if (GENERAL && c.general) { // wave-uniform: tests with an arithmetic step, combined through the truth table
+#define NQE_CONJ_GTEST(T) (conj_test(c.t[T], c.t[T].pre ? conj_pre(c.t[T], NQE_CONJ_WORD(T)) : NQE_CONJ_WORD(T)) ? (1u << T) : 0u)
+        uint32_t idx = NQE_CONJ_GTEST(0);
+        if (c.n > 1) idx |= NQE_CONJ_GTEST(1);
+        if (c.n > 2) idx |= NQE_CONJ_GTEST(2);
+        if (c.n > 3) idx |= NQE_CONJ_GTEST(3);
+#undef NQE_CONJ_GTEST
+        return (c.truth >> idx) & 1u;
+    }
+#define NQE_CONJ_TEST(T) conj_test(c.t[T], NQE_CONJ_WORD(T))
     const bool r0 = NQE_CONJ_TEST(0), r1 = NQE_CONJ_TEST(1);
     bool r = c.is_or ? (r0 || r1) : (r0 && r1);
     if (c.n > 2) { // wave-uniform; the two-test form stays straight-line code (a branch per test cost it 15 %)
@@ -235,6 +268,7 @@ __device__ __forceinline__ bool conj_pass(const ConjPred &c, uint64_t w0, uint64
         }
     }
 #undef NQE_CONJ_TEST
+#undef NQE_CONJ_WORD
     return r;
 }
 

@@ -740,15 +740,16 @@ bool make_fast_pred(const SimpleExpr &pe, FastPred *fp) {
     return true;
 }
 
-// `A and B [and …]` / `A or B [or …]`, two to CONJ_MAX leaves `col cmp lit` / `lit cmp col` over non-null Int64/UInt64/Float64
-// columns, in any association of the one operator (cols[] names the tested column of every test; which loaded word of a row
-// serves a test — ConjTest::src — is the consumer's business).  Nodes are in postfix order.
+// Any nesting of `and` / `or` over ONE to CONJ_MAX tests, a test being `col cmp lit` (either side) or `(col arith lit) cmp lit` with a
+// fault-free arithmetic step (`id % 3 = 0`, `v * 2.0 > 100.0`, `100 - w >= 7`), over non-null Int64/UInt64/Float64 columns (cols[]
+// names the tested column of every test; which loaded word of a row serves a test — ConjTest::src — is the consumer's business).
+// A pure and-list / or-list of plain range tests keeps the straight-line form (general = 0); everything else is evaluated through
+// the truth table of the and/or structure.  Nodes are in postfix order.
 bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred *out, int *cols) {
-    if (n < 7 || n > 4 * CONJ_MAX - 1 || nodes[n - 1].kind != NQE_EXPR_BINARY) return false;
-    const int root_op = nodes[n - 1].op;
-    if (root_op != NQE_OP_AND && root_op != NQE_OP_OR) return false;
+    constexpr int MAXN = 8 * CONJ_MAX;
+    if (n < 3 || n > MAXN || nodes[n - 1].kind != NQE_EXPR_BINARY) return false;
     // first node of the subtree that ends at node i
-    int start[4 * CONJ_MAX], stack[4 * CONJ_MAX], sp = 0;
+    int start[MAXN], stack[MAXN], sp = 0;
     for (int i = 0; i < n; ++i) {
         if (nodes[i].kind == NQE_EXPR_BINARY) {
             if (sp < 2) return false;
@@ -760,46 +761,104 @@ bool match_conj(const nqe_table *in, const nqe_expr_node *nodes, int n, ConjPred
     }
     if (sp != 1) return false;
     std::memset(out, 0, sizeof(*out));
-    int todo[4 * CONJ_MAX], nt = 0;
-    todo[nt++] = n - 1;
+    // leaves = maximal subtrees that are not and/or nodes, left to right
+    int leaf_of[MAXN]; // node -> leaf number when the node is a leaf's root
     int leaves[CONJ_MAX], nl = 0;
-    while (nt) {
-        const int i = todo[--nt];
-        if (nodes[i].kind == NQE_EXPR_BINARY && nodes[i].op == root_op) {
-            todo[nt++] = start[i - 1] - 1; // left operand's root (examined after the right one: leaves come out right to left)
-            todo[nt++] = i - 1;
-        } else {
-            if (nl == CONJ_MAX) return false;
-            leaves[nl++] = i;
+    bool plain_list = true;
+    const int root_op = nodes[n - 1].op;
+    {
+        int todo[MAXN], nt = 0;
+        todo[nt++] = n - 1;
+        int rev[CONJ_MAX], nr = 0;
+        while (nt) {
+            const int i = todo[--nt];
+            if (nodes[i].kind == NQE_EXPR_BINARY && (nodes[i].op == NQE_OP_AND || nodes[i].op == NQE_OP_OR)) {
+                if (nodes[i].op != root_op) plain_list = false;
+                todo[nt++] = start[i - 1] - 1; // left operand's root (examined after the right one: leaves come out right to left)
+                todo[nt++] = i - 1;
+            } else {
+                if (nr == CONJ_MAX) return false;
+                rev[nr++] = i;
+            }
         }
+        for (int k = 0; k < nr; ++k) leaves[nl++] = rev[nr - 1 - k];
     }
-    if (nl < 2) return false;
+    if (nl < 1) return false;
+    if (root_op != NQE_OP_AND && root_op != NQE_OP_OR) plain_list = false; // a single test (with an arithmetic step, or it would be a SimpleExpr)
+    bool any_pre = false;
     for (int t = 0; t < nl; ++t) {
-        const int i = leaves[nl - 1 - t]; // left to right
-        if (i - start[i] != 2) return false;
+        const int i = leaves[t];
+        leaf_of[i] = t;
         const nqe_expr_node *leaf = nodes + start[i];
-        if (leaf[2].kind != NQE_EXPR_BINARY || leaf[2].op > NQE_OP_GT_EQ) return false;
-        if (!((leaf[0].kind == NQE_EXPR_COLUMN && leaf[1].kind == NQE_EXPR_LITERAL) || (leaf[0].kind == NQE_EXPR_LITERAL && leaf[1].kind == NQE_EXPR_COLUMN)))
-            return false;
+        const int len = i - start[i] + 1;
+        if (len != 3 && len != 5) return false;
         ExprInfo li;
         try {
-            li = analyze_expr(in, leaf, 3);
+            li = analyze_expr(in, leaf, len);
         } catch (...) {
             return false; // whatever the leaf's problem is, the tree as a whole reports it
         }
-        FastPred fp{};
-        if (!li.simple || li.out_dtype != NQE_BOOLEAN || !make_fast_pred(li.s, &fp)) return false;
+        if (!li.simple || li.out_dtype != NQE_BOOLEAN || li.may_fault) return false;
         const DevColumn &c = in->cols[size_t(li.s.col)];
         if (!is_word_type(c.dtype) || c.validity || !c.values) return false;
+        ConjTest &T = out->t[t];
+        SimpleExpr cmp = li.s; // the comparison alone, over the type it compares
+        if (li.s.nops == 2) {
+            const int op = li.s.op[0], dt = li.s.op_dtype[0];
+            if (op < NQE_OP_PLUS || op > NQE_OP_MODULOS) return false;
+            if (dt == NQE_FLOAT64 && op == NQE_OP_MODULOS) return false;
+            if ((op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS) && li.s.lit_left[0]) return false; // (analyze_expr: may_fault — kept explicit)
+            T.pre = op;
+            T.pre_dt = dt;
+            T.pre_rev = li.s.lit_left[0];
+            T.pre_lit = li.s.lit[0];
+            T.pre_aux = li.s.aux[0];
+            any_pre = true;
+            cmp.nops = 1;
+            cmp.op[0] = li.s.op[1];
+            cmp.lit_left[0] = li.s.lit_left[1];
+            cmp.op_dtype[0] = li.s.op_dtype[1];
+            cmp.lit[0] = li.s.lit[1];
+            cmp.src_dtype = li.s.op_dtype[1];
+        } else if (li.s.nops != 1)
+            return false;
+        FastPred fp{};
+        if (!make_fast_pred(cmp, &fp)) return false;
         cols[t] = li.s.col;
-        out->t[t].lo = fp.lo;
-        out->t[t].hi = fp.hi;
-        out->t[t].flip = fp.flip;
-        out->t[t].fmask = fp.fmask;
-        out->t[t].negate = fp.negate;
+        T.lo = fp.lo;
+        T.hi = fp.hi;
+        T.flip = fp.flip;
+        T.fmask = fp.fmask;
+        T.negate = fp.negate;
     }
     out->n = nl;
-    out->is_or = root_op == NQE_OP_OR ? 1 : 0;
+    if (plain_list && !any_pre && nl >= 2) {
+        out->is_or = root_op == NQE_OP_OR ? 1 : 0;
+        return true;
+    }
+    if (nl == 1 && !any_pre) return false; // a bare compare: the SimpleExpr paths are leaner
+    // truth table: evaluate the and/or structure for every assignment of the tests
+    out->general = 1;
+    for (uint32_t asg = 0; asg < (1u << nl); ++asg) {
+        bool val[MAXN];
+        int vs = 0;
+        // postfix walk over the and/or skeleton: a leaf's subtree contributes its assigned value at its root
+        for (int i = 0; i < n; ++i) {
+            bool is_leaf_root = false;
+            for (int t = 0; t < nl; ++t) is_leaf_root = is_leaf_root || leaves[t] == i;
+            if (is_leaf_root) {
+                val[vs++] = (asg >> leaf_of[i]) & 1u;
+                continue;
+            }
+            bool inside = false; // a node strictly inside some leaf's subtree
+            for (int t = 0; t < nl; ++t) inside = inside || (i >= start[leaves[t]] && i < leaves[t]);
+            if (inside) continue;
+            // an and/or node of the skeleton
+            const bool rv = val[--vs], lv = val[--vs];
+            val[vs++] = nodes[i].op == NQE_OP_AND ? (lv && rv) : (lv || rv);
+        }
+        if (val[0]) out->truth |= 1u << asg;
+    }
     return true;
 }
 

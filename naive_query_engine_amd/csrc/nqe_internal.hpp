@@ -272,12 +272,22 @@ struct ConjTest {
     int32_t negate;
     int32_t src;    // which loaded word of the row (aggregate: 0 key column, 1 first value column, 2 the predicate column;
                     // selection: the column's slot among the distinct tested columns)
+    // one fault-free arithmetic step on the word ahead of the range test — `id % 3 = 0`, `v * 2.0 > 100.0`, `100 - w >= 7`:
+    // pre = 0: none; else the nqe_operator (PLUS … MODULOS) over operands of type pre_dt, the literal on the right unless pre_rev
+    int32_t pre, pre_dt, pre_rev, pad;
+    uint64_t pre_lit;
+    OpAux pre_aux;
 };
 struct ConjPred {
     ConjTest t[CONJ_MAX];
     int32_t n;       // tests
-    int32_t is_or;
+    int32_t is_or;   // (lists only)
     int32_t need_pw; // aggregate: some test reads the predicate column (src == 2)
+    // general = 0: an and-list / or-list of plain range tests (the straight-line form).  general = 1: ANY nesting of and / or over
+    // the tests, some of them with an arithmetic step: the tests' outcomes index the truth table (bit i of `truth`: the predicate's
+    // value when test k's outcome is bit k of i)
+    int32_t general;
+    uint32_t truth;
     int32_t pad;
 };
 // Any other fault-free predicate tree over at most three non-null 8-byte columns (`v < 20 or id % 3 = 0`, `a + b > c`, …): a

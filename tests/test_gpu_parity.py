@@ -1041,7 +1041,15 @@ def test_selection_two_test_predicates(ctx, n):
               binop(l1, A, binop(l2, A, binop(l3, A, l4))),         # four tests, right-deep
               binop(binop(l1, O, l2), O, binop(l3, O, l4)),         # four tests, balanced, or
               binop(binop(binop(binop(l1, A, l2), A, l3), A, l4), A, l5),   # five tests: the general path
-              binop(binop(l1, A, l2), O, l3)]                       # mixed and / or: the general path
+              binop(binop(l1, A, l2), O, l3)]                       # mixed and / or: the truth-table form
+    # tests with an arithmetic step, nested and / or (ConjPred's general form: straight-line tests + truth table)
+    m1 = binop(binop(K, Operator.Modulos, lit_i64(3)), Operator.Eq, lit_i64(0))
+    m2 = binop(binop(V, Operator.Multiply, lit_f64(2.0)), Operator.Gt, lit_f64(50.0))
+    m3 = binop(binop(lit_i64(10), Operator.Minus, K), Operator.GtEq, lit_i64(7))
+    m4 = binop(binop(U, Operator.Divide, lit_u64(1000)), Operator.Lt, lit_u64(1 << 28))
+    m5 = binop(binop(K, Operator.Modulos, lit_i64(-4)), Operator.NotEq, lit_i64(-1))
+    preds += [binop(l2, O, m1), binop(m1, A, m2), binop(binop(m3, O, l3), A, binop(m4, O, m5)), binop(m2, O, binop(l1, A, binop(m1, O, m4))),
+              binop(binop(binop(V, Operator.Divide, lit_f64(4.0)), Operator.LtEq, lit_f64(-0.0)), O, m3)]
     for pred in preds:
         exp = orc.selection([cols], pred.flatten(f4))[0]
         got = ctx.selection(t, pred.flatten(f4)).to_host()
