@@ -1271,7 +1271,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 AggArgs ka = a;
                 if (a.pred_mode == 2) pk = 2;
                 else if (a.pred_mode == 3) pk = a.conj.general ? 5 : 4;
-                else if (a.pred_mode == 4) pk = 5;
+                else if (a.pred_mode == 4) pk = 6;
                 else if (a.pred_mode == 1) {
                     const SimpleExpr &pe = a.pred;
                     pk = 3;
@@ -1284,10 +1284,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         }
                     }
                 }
-                if (pk == 5 && a.pred_mode == 3) { // the general range-test form in the interpreted-predicate instances
-                    ka.tree_n = 0;
-                    ka.tree_need_pw = a.conj.need_pw;
-                }
+                if (pk == 5) ka.tree_need_pw = a.conj.need_pw; // (the interpreted-predicate instances load the third word on this flag)
                 bool plain = is_word_type(a.key_src.dtype);
                 // a Boolean predicate column without nulls (a Boolean input column, or any predicate tree evaluated by the
                 // expression machine) is tested by the same variants as a separate integer predicate column: the word of a
@@ -1328,12 +1325,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         }
                     }
                 }
-                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || pk == 4 || pk == 5 || bitmap_pred || range_pred || chain_pred);
-                if ((pk == 4 || pk == 5) && (!fast || vnull)) fail(NQE_ERR_NOT_SUPPORTED, "internal: a tree predicate reached a kernel that cannot evaluate it");
+                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || pk >= 4 || bitmap_pred || range_pred || chain_pred);
+                if (pk >= 4 && (!fast || vnull)) fail(NQE_ERR_NOT_SUPPORTED, "internal: a tree predicate reached a kernel that cannot evaluate it");
                 if (fast) {
                     // variant 1 tests the key word with the integer range test alone; Float64 predicates and bitmaps use the
                     // "other column" variant, whose extraction step applies the order mapping
-                    int fp = pk == 0 ? 0 : pk == 4 ? 4 : pk == 5 ? 5 : (chain_pred ? 3 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2));
+                    int fp = pk == 0 ? 0 : pk >= 4 ? pk : (chain_pred ? 3 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2));
                     bool vf64 = true;
                     for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
                     if (partition_mode && !level2 && !slab_failed) {

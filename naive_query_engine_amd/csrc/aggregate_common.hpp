@@ -212,6 +212,66 @@ __device__ __forceinline__ void tree_pred_eval(uint64_t prog_addr, int n, const 
     for (int u = 0; u < U; ++u) res[u] = b0[u];
 }
 
+template <bool MOD, bool SGN, bool POW2> __device__ __forceinline__ uint64_t divmod_by_literal(uint64_t a, uint64_t lit, const OpAux &aux);
+// ConjPred's general form over a register tile of U rows, test-major: the (wave-uniform) dispatch on a test's source word and
+// arithmetic step happens once per test per tile — evaluated row by row (conj_pass) it was repeated for every row, and the scalar
+// unit, one instruction per clock per CU, became the bound: +0.75 ms per 2x10^8 rows for two tests.
+template <int U>
+__device__ __forceinline__ void conj_general_tile(const ConjPred &c, const uint64_t (&w0)[U], const uint64_t (&w1)[U], const uint64_t (&w2)[U],
+                                                  bool (&res)[U]) {
+    uint32_t idx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) idx[u] = 0;
+    // (constant test indices: a run-time index would send the ConjPred to scratch memory)
+#define NQE_CONJ_TILE_TEST(T)                                                                                                \
+    if (c.n > T) {                                                                                                           \
+        uint64_t x[U];                                                                                                       \
+        /* (neither three branches around copies nor selects: the compiler turns both into ONE load through a selected     */ \
+        /* pointer, and the tile's words — indexed through a pointer — then live in scratch memory)                       */ \
+        /* hence bit masks, which are arithmetic on VALUES)                                                                */ \
+        const uint64_t m0 = c.t[T].src == 0 ? ~0ull : 0ull, m1 = c.t[T].src == 1 ? ~0ull : 0ull;                              \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = (w0[u] & m0) | (~m0 & ((w1[u] & m1) | (~m1 & w2[u])));             \
+        if (c.t[T].pre) {                                                                                                         \
+            const uint64_t lit = c.t[T].pre_lit;                                                                                  \
+            if (c.t[T].pre_dt == NQE_FLOAT64) {                                                                                   \
+                const double dl = u2d(lit);                                                                                  \
+                if (c.t[T].pre == NQE_OP_PLUS) { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = d2u(u2d(x[u]) + dl); }      \
+                else if (c.t[T].pre == NQE_OP_MULTIPLY) { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = d2u(u2d(x[u]) * dl); } \
+                else if (c.t[T].pre == NQE_OP_MINUS) {                                                                            \
+                    if (c.t[T].pre_rev) { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = d2u(dl - u2d(x[u])); }             \
+                    else { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = d2u(u2d(x[u]) - dl); }                       \
+                } else if (c.t[T].pre_rev) { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = d2u(dl / u2d(x[u])); }          \
+                else { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = d2u(u2d(x[u]) / dl); }                           \
+            } else if (c.t[T].pre == NQE_OP_PLUS) { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] += lit; }                  \
+            else if (c.t[T].pre == NQE_OP_MULTIPLY) { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] *= lit; }                \
+            else if (c.t[T].pre == NQE_OP_MINUS) {                                                                                \
+                if (c.t[T].pre_rev) { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = lit - x[u]; }                          \
+                else { _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] -= lit; }                                          \
+            } else {                                                                                                         \
+                OpAux aux; aux.pow2_shift = c.t[T].pre_aux.pow2_shift; aux.more = c.t[T].pre_aux.more; aux.abs_lit = c.t[T].pre_aux.abs_lit; aux.magic = c.t[T].pre_aux.magic;                                                                                 \
+                const bool mod = c.t[T].pre == NQE_OP_MODULOS, sgn = c.t[T].pre_dt == NQE_INT64, pow2 = aux.pow2_shift >= 0;           \
+                if (mod) {                                                                                                   \
+                    if (sgn) { if (pow2) { NQE_CONJ_DM(true, true, true); } else { NQE_CONJ_DM(true, true, false); } }        \
+                    else { if (pow2) { NQE_CONJ_DM(true, false, true); } else { NQE_CONJ_DM(true, false, false); } }          \
+                } else {                                                                                                     \
+                    if (sgn) { if (pow2) { NQE_CONJ_DM(false, true, true); } else { NQE_CONJ_DM(false, true, false); } }      \
+                    else { if (pow2) { NQE_CONJ_DM(false, false, true); } else { NQE_CONJ_DM(false, false, false); } }        \
+                }                                                                                                            \
+            }                                                                                                                \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) idx[u] |= conj_test(c.t[T], x[u]) ? (1u << T) : 0u;                         \
+    }
+#define NQE_CONJ_DM(M, S, P) _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = divmod_by_literal<M, S, P>(x[u], lit, aux)
+    NQE_CONJ_TILE_TEST(0)
+    NQE_CONJ_TILE_TEST(1)
+    NQE_CONJ_TILE_TEST(2)
+    NQE_CONJ_TILE_TEST(3)
+#undef NQE_CONJ_DM
+#undef NQE_CONJ_TILE_TEST
+#pragma unroll
+    for (int u = 0; u < U; ++u) res[u] = (c.truth >> idx[u]) & 1u;
+}
+
 __device__ __forceinline__ int lds_find_or_insert(uint64_t *keys, uint64_t key, uint32_t cap, int shift) {
     if (key == EMPTY_KEY) {
         keys[cap] = 0; // mark special slot used (idempotent plain store)

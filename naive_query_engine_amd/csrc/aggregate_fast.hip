@@ -15,6 +15,7 @@ NQE_FAST_DECL(3)
 #undef NQE_FAST_DECL
 FastKernel pick_fast_p4_v0(int key, int nv, bool vf64, bool sub);
 FastKernel pick_fast_p5_v0(int key, int nv, bool vf64, bool sub);
+FastKernel pick_fast_p6_v0(int key, int nv, bool vf64, bool sub);
 
 FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull, bool sub) {
     switch (pred) {
@@ -23,7 +24,8 @@ FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull, bo
     case 2: return vnull ? pick_fast_p2_v1(key, nv, vf64, sub) : pick_fast_p2_v0(key, nv, vf64, sub);
     case 3: return vnull ? pick_fast_p3_v1(key, nv, vf64, sub) : pick_fast_p3_v0(key, nv, vf64, sub);
     case 4: return vnull ? nullptr : pick_fast_p4_v0(key, nv, vf64, sub);
-    default: return vnull ? nullptr : pick_fast_p5_v0(key, nv, vf64, sub);
+    case 5: return vnull ? nullptr : pick_fast_p5_v0(key, nv, vf64, sub);
+    default: return vnull ? nullptr : pick_fast_p6_v0(key, nv, vf64, sub);
     }
 }
 

@@ -11,7 +11,7 @@
 #define NQE_AGG_BATCH2 0 // the batch loop for two value columns, rows one by one (NQE_AGG_BG2): built and measured at the register limit — 8-22 VGPRs spill in every such instance, so it stays off
 #endif
 #ifndef NQE_AGG_BATCH_TREE
-#define NQE_AGG_BATCH_TREE 0 // the batch loop under a tree predicate (PRED = 5)
+#define NQE_AGG_BATCH_TREE 0 // the batch loop under the general range-test form (PRED = 5): 47-220 VGPRs spill, so it stays off
 #endif
 #ifndef NQE_TREE_PIPE
 #define NQE_TREE_PIPE 0 // the prefetched second tile under a tree predicate (A/B)
@@ -43,7 +43,9 @@ namespace {
 // PRED: 0 none, 1 range test on the key column itself (one load serves both), 2 on another column, 3 a fault-free integer chain
 // `col op lit … cmp lit` over any column, interpreted operator-major like the KEY = 3 keys, 4 `A and B` / `A or B` of two range
 // tests over the key column, the first value column and at most one more column (AggArgs::conj), 5 any other fault-free predicate
-// tree over those columns, run by the register stack machine of aggregate_common.hpp (tree_pred_eval; AggArgs::tree_prog).
+// nesting of and / or over up to four such tests, a test possibly with an arithmetic step (`id % 3 = 0`; ConjPred's general form),
+// 6 any other fault-free predicate tree over those columns, run by the typed stack machine of aggregate_common.hpp
+// (tree_pred_eval; AggArgs::tree_prog).
 template <int PRED, int KEY, int NVT, bool VF64, bool VNULL, bool SUB = false>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     };
 
     const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
-    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(((PRED >= 2 && PRED != 5) || (PRED == 5 && a.tree_need_pw)) ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(((PRED >= 2 && (PRED != 5 && PRED != 6)) || ((PRED == 5 || PRED == 6) && a.tree_need_pw)) ? a.pred_src.values : a.key_src.values);
     const uint64_t *__restrict__ valp[NVT];
     const uint64_t *__restrict__ kvalid = reinterpret_cast<const uint64_t *>(a.key_src.valid);
     const uint64_t *__restrict__ pvalid = reinterpret_cast<const uint64_t *>(PRED != 0 ? a.pred_src.valid : nullptr);
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&pt[lane_row[u] >> fp.row_shift]);
                 if (PRED == 3) t.pw[u] = __builtin_nontemporal_load(&pt[lane_row[u]]);
                 if (PRED == 4) t.pw[u] = a.conj.need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull; // wave-uniform
-                if (PRED == 5) t.pw[u] = a.tree_need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull;
+                if ((PRED == 5 || PRED == 6)) t.pw[u] = a.tree_need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull;
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&vt[j][lane_row[u]]);
             }
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
                 if (PRED == 3) t.pw[u] = __builtin_nontemporal_load(&predp[row]);
                 if (PRED == 4) t.pw[u] = a.conj.need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull; // wave-uniform
-                if (PRED == 5) t.pw[u] = a.tree_need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull;
+                if ((PRED == 5 || PRED == 6)) t.pw[u] = a.tree_need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull;
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
                 if (VNULL) {
@@ -327,14 +329,16 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // 2.36 -> 2.47 ms with the test on every tile, still +2-3 % with a per-tile mode branch inside one loop), so they are two
     // separate streaming loops and a wave re-picks between them every 64 tiles from the keys of the tile in hand: batch when a
     // quarter of its lanes see mixed keys (random keys: 2.90 -> 2.57 ms).
-    // PRED = 5, the interpreted predicates: tree_n == 0 — tests with an arithmetic step under any and/or nesting (ConjPred, general
-    // form: straight-line tests + truth table); else the stack machine's program
+    // the interpreted predicates.  PRED = 5: tests with an arithmetic step under any and/or nesting (ConjPred's general form:
+    // test-major straight-line code + truth table); PRED = 6: the stack machine's program
     auto eval_interpreted = [&](const Tile &t, bool (&res)[AGG_U]) {
-        if (a.tree_n == 0) { // wave-uniform
+#ifdef NQE_TREE_TRIVIAL // diagnostics: the instance's skeleton without the predicate's work
 #pragma unroll
-            for (int u = 0; u < AGG_U; ++u) res[u] = conj_pass<3, true>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
-        } else
-            tree_pred_eval<AGG_U>(a.tree_prog, a.tree_n, t.kw, t.vw[0], t.pw, res);
+        for (int u = 0; u < AGG_U; ++u) res[u] = (t.kw[u] ^ t.vw[0][u]) != 12345;
+        return;
+#endif
+        if (PRED == 5) conj_general_tile<AGG_U>(a.conj, t.kw, t.vw[0], t.pw, res);
+        else tree_pred_eval<AGG_U>(a.tree_prog, a.tree_n, t.kw, t.vw[0], t.pw, res);
     };
     auto accumulate_row = [&](const Tile &t, int u, int64_t row, uint64_t key) {
         if (!run_live || key != run_key) {
@@ -369,8 +373,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         // where the compiler sinks them below the predicate (hoisting them cost the headline 1.5 %)
         uint64_t pvals[PRED == 3 ? AGG_U : 1];
         if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
-        bool tpass[PRED == 5 ? AGG_U : 1];
-        if (PRED == 5) eval_interpreted(t, reinterpret_cast<bool (&)[AGG_U]>(tpass));
+        bool tpass[(PRED == 5 || PRED == 6) ? AGG_U : 1];
+        if ((PRED == 5 || PRED == 6)) eval_interpreted(t, reinterpret_cast<bool (&)[AGG_U]>(tpass));
         uint64_t keys[KEY == 3 ? AGG_U : 1];
         if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, reinterpret_cast<uint64_t (&)[AGG_U]>(keys), key_mask, key_aux, key_signed);
         const uint32_t nrows = tile_rows(base);
@@ -379,7 +383,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = lane_row[u] < nrows;
             if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
-            else if (PRED == 5) pass = pass && tpass[PRED == 5 ? u : 0];
+            else if ((PRED == 5 || PRED == 6)) pass = pass && tpass[(PRED == 5 || PRED == 6) ? u : 0];
             else if (PRED == 4) pass = pass && conj_pass<3, false>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) {
                 pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
@@ -400,8 +404,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     auto process_batch = [&](const Tile &t, int64_t base) {
         uint64_t pvals[PRED == 3 ? AGG_U : 1];
         if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
-        bool tpass[PRED == 5 ? AGG_U : 1];
-        if (PRED == 5) eval_interpreted(t, reinterpret_cast<bool (&)[AGG_U]>(tpass));
+        bool tpass[(PRED == 5 || PRED == 6) ? AGG_U : 1];
+        if ((PRED == 5 || PRED == 6)) eval_interpreted(t, reinterpret_cast<bool (&)[AGG_U]>(tpass));
         bool pass[AGG_U];
         uint64_t key[AGG_U];
         tile_keys(t, key);
@@ -411,7 +415,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             pass[u] = lane_row[u] < nrows;
             if (PRED == 3) pass[u] = pass[u] && pvals[PRED == 3 ? u : 0] != 0;
-            else if (PRED == 5) pass[u] = pass[u] && tpass[PRED == 5 ? u : 0];
+            else if ((PRED == 5 || PRED == 6)) pass[u] = pass[u] && tpass[(PRED == 5 || PRED == 6) ? u : 0];
             else if (PRED == 4) pass[u] = pass[u] && conj_pass<3, false>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
             else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
             if (VNULL) pass[u] = pass[u] && ((t.kpv[u] >> (row & 63)) & 1ull);
@@ -439,9 +443,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     const int64_t stride = int64_t(lanes) * step;
     int64_t base = int64_t(lane_id) * step;
     // up to 2 x `budget` tiles.  In: A holds tile `base` (< n).  Out: base >= n (done or abandoned), or A holds tile `base`.
-    // (PRED = 5: ONE tile in flight — the stack machine's registers take the place of the prefetched tile's; the workgroup's 16
+    // (PRED = 6: ONE tile in flight — the stack machine's registers take the place of the prefetched tile's; the workgroup's 16
     // waves hide the loads' latency among themselves)
-    constexpr bool PIPE = PRED != 5 || NQE_TREE_PIPE;
+    constexpr bool PIPE = PRED != 6 || NQE_TREE_PIPE;
     auto stream = [&](auto &&process, Tile &A, int budget) {
         if constexpr (!PIPE) {
             for (int64_t it = 0; it < 2 * int64_t(budget); ++it) {
@@ -488,7 +492,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         Tile A;
         load_tile(A, base);
         // not where registers are short: the VNULL variants (37 VGPRs spilled: 2.2x slower), two value columns, interpreted predicates
-        constexpr bool CAN_BATCH = NQE_AGG_BATCH && !VNULL && PRED != 3 && (PRED != 5 || (NQE_AGG_BATCH_TREE && KEY != 3 && NVT == 1)) && !(PRED == 2 && KEY == 3) && !(PRED == 4 && KEY == 3) &&
+        constexpr bool CAN_BATCH = NQE_AGG_BATCH && !VNULL && PRED != 3 && (PRED != 6 && (PRED != 5 || (NQE_AGG_BATCH_TREE && KEY != 3 && NVT == 1))) && !(PRED == 2 && KEY == 3) && !(PRED == 4 && KEY == 3) &&
                                    (NVT == 1 || (NQE_AGG_BATCH2 && KEY != 3 && PRED != 4));
         while (base < n) {
             bool batch = false; // wave-uniform
@@ -568,9 +572,9 @@ template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf
             return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, false, true> : agg_grouped_fast_kernel<PRED, KEY, 1, false, false, true>;
         }
     }
-    if constexpr (PRED == 5 && KEY == 3) return nullptr; // (a tree predicate under an interpreted key: registers)
+    if constexpr (PRED >= 5 && KEY == 3) return nullptr; // (a tree predicate under an interpreted key: registers)
     else if (nv == 1) return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 1, false, VNULL>;
-    if constexpr (VNULL || PRED == 5) {
+    if constexpr (VNULL || PRED >= 5) {
         return nullptr; // nullable sources take one value column per pass (aggregate.hip): the two-column variants spilled 60-135 VGPRs
     } else {
         return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 2, false, VNULL>;

@@ -17,7 +17,7 @@ done
 for p in 0 1 2 3; do for v in 0 1; do
   ( $HIPCC $CXX -DNQE_FAST_PRED=$p -DNQE_FAST_VNULL=$v -c aggregate_fast_inst.hip -o $D/aggregate_fast_p${p}_v${v}.o ) & pids+=($!)
 done; done
-for p in 4 5; do ( $HIPCC $CXX -DNQE_FAST_PRED=$p -DNQE_FAST_VNULL=0 -c aggregate_fast_inst.hip -o $D/aggregate_fast_p${p}_v0.o ) & pids+=($!); done
+for p in 4 5 6; do ( $HIPCC $CXX -DNQE_FAST_PRED=$p -DNQE_FAST_VNULL=0 -c aggregate_fast_inst.hip -o $D/aggregate_fast_p${p}_v0.o ) & pids+=($!); done
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC -shared -fPIC --offload-arch=gfx950 -o ../libnqe_hip_$NAME.so $D/*.o -ldl
 ls -la ../libnqe_hip_$NAME.so
