@@ -509,6 +509,11 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
         uint64_t my_word = 0;
         uint32_t tot = 0, my_off = 0;
         uint64_t base = 0;
+        if (IDENT) {
+            // some wave (or the sampling kernel ahead of this one) found a foreign key without its primary key: the host discards the
+            // output, so stop writing it (checked once per 4096-row tile; the flag only ever goes from 0 to 1)
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(miss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+        }
         if (!IDENT) {
             my_word = w < nwords ? keep[w] : 0;
             my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
@@ -593,6 +598,17 @@ __global__ void __launch_bounds__(256) join_fused_write_kernel(const uint64_t *r
             }
         }
     }
+}
+
+// ahead of the optimistic one-pass probe: 2^16 probe keys spread evenly over the column, tested against the primary key's range.  A
+// foreign key column that misses on any noticeable fraction of its rows is caught here in ~10 µs — the one-pass kernel behind
+// it then leaves at once (it reads the flag before its first tile) instead of writing an output the host would discard
+__global__ void __launch_bounds__(256) join_sample_range_kernel(const uint64_t *rkeys, int64_t n, uint64_t dmin, uint64_t span, int *miss) {
+    const int64_t samples = int64_t(gridDim.x) * blockDim.x;
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t row = n <= samples ? i : int64_t((__int128)(i) * n / samples);
+    const bool bad = row < n && !(rkeys[row < n ? row : n - 1] - dmin < span);
+    if (__ballot(bad) && lane_id() == 0) *miss = 1;
 }
 
 // ---- unique hashed keys with ONE plain payload column: the lookup IS the gather.  Pass 1 of the two-pass probe looks every
@@ -1142,15 +1158,34 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         // once) writes everything — while checking every key against the range.  A key outside it discards the output, and this
         // join table takes the two-pass form from then on.
         static const bool no_optimistic = getenv("NQE_JOIN_NO_OPTIMISTIC") != nullptr; // diagnostics (A/B)
+        // what the context remembers of this join (the table itself may be a fresh one: nqe_hash_join_execute builds per call)
+        uint64_t jhint = 1469598103934665603ull;
+        {
+            const void *lp = jt->left_cols[size_t(jt->left_key)].values ? jt->left_cols[size_t(jt->left_key)].values->ptr : nullptr, *rp = rk.values->ptr;
+            const int64_t lrows = jt->left_cols[size_t(jt->left_key)].length;
+            auto mix = [&](const void *p, size_t nb) {
+                const unsigned char *b = static_cast<const unsigned char *>(p);
+                for (size_t i = 0; i < nb; ++i) jhint = (jhint ^ b[i]) * 1099511628211ull;
+            };
+            mix(&lp, sizeof(lp));
+            mix(&lrows, sizeof(lrows));
+            mix(&rp, sizeof(rp));
+            mix(&n, sizeof(n));
+        }
+        if (ctx->join_hints.count(jhint)) jt->all_match_failed = true;
         if (jt->dense_full && !jt->all_match_failed && !no_optimistic && n > 0) {
             FusedCols fc;
             auto out = build_out(n, fc);
             BufRef miss = dev_alloc_zero(ctx, 4);
             const int64_t ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+            if (n >= (int64_t(1) << 20))
+                launch(ctx, "join_sample_range", join_sample_range_kernel, dim3(256), dim3(256), 0, rk.words(), n, jt->dense_min, jt->dense_span, (int *)miss->ptr);
             launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS, true>, dim3(stream_grid(ctx, ntiles, 4)), dim3(256), 0, rk.words(), n, ntiles,
                    (const uint64_t *)nullptr, (const uint64_t *)nullptr, jt->dense_min, (const uint32_t *)nullptr, fc, jt->dense_span, (int *)miss->ptr);
             if (!read_scalar(ctx, (const int *)miss->ptr)) return out;
             jt->all_match_failed = true;
+            if (ctx->join_hints.size() >= 256) ctx->join_hints.clear();
+            ctx->join_hints[jhint] = 1;
         }
         // PK–FK fast path: presence test + counts, scan, then one fused write of every output column
         KeepMask km;

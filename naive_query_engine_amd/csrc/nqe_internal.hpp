@@ -68,6 +68,10 @@ struct nqe_ctx {
     // instead of paying for an abandoned single-pass attempt and its read-back first.  Only a starting point — a partitioned run
     // is correct for any number of groups, and a single-pass run still falls back when its tables overflow.
     std::map<uint64_t, uint8_t> agg_hints;
+    // PK-FK joins whose optimistic one-pass probe failed (some foreign key without its primary key), by (build key column, build
+    // rows, probe key column, probe rows): HashJoin::execute builds a fresh join table per call (nqe_hash_join_execute), so the
+    // verdict has to outlive the table for the next execution of the same join to go straight to the two-pass form
+    std::map<uint64_t, uint8_t> join_hints;
 
     int *d_flags = nullptr; // NQE_NUM_FLAGS ints on the device
     int *h_flags = nullptr; // pinned host mirror
