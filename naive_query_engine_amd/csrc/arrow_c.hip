@@ -48,30 +48,30 @@ struct ExportedArray {
     std::vector<const void *> buffer_ptrs;
     std::vector<ArrowArray *> children;
     std::vector<std::unique_ptr<ArrowArray>> child_store;
+    // releases the children it still owns: also on the export's error path, where the half-built parent is simply destroyed
+    // (a child's private data is not reachable from the unique_ptr that holds its struct)
+    ~ExportedArray() {
+        for (auto &c : child_store)
+            if (c && c->release) c->release(c.get());
+    }
 };
 void release_array(ArrowArray *a) {
     if (!a || !a->release) return;
-    auto *p = static_cast<ExportedArray *>(a->private_data);
-    if (p) {
-        for (auto &c : p->child_store)
-            if (c && c->release) c->release(c.get());
-        delete p;
-    }
+    delete static_cast<ExportedArray *>(a->private_data); // children first (destructor)
     a->release = nullptr;
 }
 struct ExportedSchema {
     std::string format, name;
     std::vector<ArrowSchema *> children;
     std::vector<std::unique_ptr<ArrowSchema>> child_store;
+    ~ExportedSchema() {
+        for (auto &c : child_store)
+            if (c && c->release) c->release(c.get());
+    }
 };
 void release_schema(ArrowSchema *s) {
     if (!s || !s->release) return;
-    auto *p = static_cast<ExportedSchema *>(s->private_data);
-    if (p) {
-        for (auto &c : p->child_store)
-            if (c && c->release) c->release(c.get());
-        delete p;
-    }
+    delete static_cast<ExportedSchema *>(s->private_data);
     s->release = nullptr;
 }
 
@@ -103,6 +103,13 @@ nqe_status nqe_table_import_arrow(nqe_ctx *ctx, struct ArrowArray *array, const 
         if (c->dictionary) fail(NQE_ERR_NOT_SUPPORTED, "import: dictionary-encoded column");
         const int64_t off = c->offset + poff; // a sliced batch: the parent's offset applies to every child
         if (c->length < poff + rows) fail(NQE_ERR_ARROW, "import: a column is shorter than its batch");
+        // buffers as the format prescribes: validity + values (+ bytes for Utf8); a producer may leave the data pointers of a
+        // zero-length array NULL, never those of one with rows
+        const int64_t need = dt == NQE_UTF8 ? 3 : 2;
+        if (c->n_buffers < need || !c->buffers) fail(NQE_ERR_ARROW, "import: a column has fewer buffers than its format prescribes");
+        if (rows > 0 && !c->buffers[1]) fail(NQE_ERR_ARROW, "import: a column of a non-empty batch has no values buffer");
+        if (rows > 0 && dt == NQE_UTF8 && !c->buffers[2] && static_cast<const int32_t *>(c->buffers[1])[off + rows] != static_cast<const int32_t *>(c->buffers[1])[off])
+            fail(NQE_ERR_ARROW, "import: a Utf8 column with bytes has no data buffer");
         nqe_column &d = cols[size_t(i)];
         std::memset(&d, 0, sizeof(d));
         d.dtype = dt;
@@ -116,10 +123,17 @@ nqe_status nqe_table_import_arrow(nqe_ctx *ctx, struct ArrowArray *array, const 
                 d.validity = keep.back().data();
             } else
                 d.validity = valid + (off >> 3);
-            if (poff) d.null_count = -1; // counted for the unsliced child: recount
+            // the producer counted the nulls of ITS array: whenever this batch is a different row range of it, recount
+            if (off != 0 || c->length != rows) d.null_count = -1;
         } else
             d.null_count = 0;
-        if (dt == NQE_BOOLEAN) {
+        if (rows == 0) { // nothing to read: the producer's pointers may be NULL
+            static const uint64_t zero_words[2] = {0, 0};
+            d.values = zero_words;
+            d.validity = nullptr;
+            d.null_count = 0;
+            d.data = dt == NQE_UTF8 ? reinterpret_cast<const char *>(zero_words) : nullptr;
+        } else if (dt == NQE_BOOLEAN) {
             const uint8_t *bits = static_cast<const uint8_t *>(c->buffers[1]);
             if (off & 7) {
                 keep.push_back(rebase_bits(bits, off, rows));

@@ -9,7 +9,7 @@ import pytest
 from naive_query_engine_amd import AggregateFunc, Column, DType, ErrorCode, Operator, Status
 from naive_query_engine_amd.expression import binop, col, lit_bool, lit_f64, lit_i64, lit_u64, lit_utf8
 from oracle import oracle as orc
-from tests.helpers import assert_batches_equal, assert_column_equal, assert_rows_multiset_equal, fields, random_batch, random_utf8
+from tests.helpers import assert_batches_equal, assert_column_equal, assert_rows_multiset_equal, fields, random_batch, random_utf8, rows_sorted
 
 pytestmark = pytest.mark.gpu
 
@@ -1445,3 +1445,29 @@ def test_aggregate_predicate_trees_run_inside_the_streaming_kernel(ctx, groups):
             assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"groups={groups} tree={tree!r}")
             if groups <= 1000:
                 assert ("expr_tree" not in names) == in_kernel, (names, repr(tree))
+
+
+@pytest.mark.parametrize("groups", [7, 5000, 70000])
+def test_aggregate_mixed_sign_zeros_across_kernel_paths(ctx, groups):
+    """groups holding both +0.0 and -0.0 (and nothing else, or zeros as the extreme): on every tier (one workgroup table, two key
+    subsets, slabs) min and max EQUAL the oracle's under `==` — which zero comes back is arrival order (the LDS tables compare plain
+    doubles, the global table the total-order image; the reference keeps the first in row order): the documented divergence of
+    DESIGN §4, pinned here so that nothing beyond the sign of a zero can ever differ"""
+    rng = np.random.default_rng(groups)
+    n = 400_000
+    k = rng.integers(0, groups, n).astype(np.int64)
+    v = np.where(rng.random(n) < 0.5, 0.0, -0.0)
+    v[k % 3 == 1] = np.abs(rng.random(int((k % 3 == 1).sum())))          # zeros are the minimum there
+    v[k % 3 == 2] = -np.abs(rng.random(int((k % 3 == 2).sum())))         # ... and the maximum here
+    zero = rng.random(n) < 0.3
+    v[zero] = np.where(rng.random(int(zero.sum())) < 0.5, 0.0, -0.0)
+    cols = [Column.from_numpy(k), Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    aggs = [(AggregateFunc.Count, 1), (AggregateFunc.Min, 1), (AggregateFunc.Max, 1), (AggregateFunc.Sum, 1)]
+    exp = orc.aggregate([cols], aggs, group_nodes=col(0).flatten(f2))[0]
+    t = ctx.table_from_host(cols)
+    for rep in range(2):
+        got = ctx.aggregate(t, aggs, group_nodes=col(0).flatten(f2)).to_host()
+        assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"groups={groups}")   # -0.0 == 0.0 under allclose / ==
+        g = rows_sorted(got)
+        assert not np.isnan(g).any()

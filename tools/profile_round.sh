@@ -10,11 +10,15 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python tools/csrc_rev.py > $OUT/csrc_rev.txt
-python bench.py 2>&1 | tail -1 > $OUT/bench_default.json
+python bench.py --details $OUT/bench_details.json 2>&1 | tail -1 > $OUT/bench_default.json
 declare -A WL=( [headline]="--workload headline" [headline_random_keys]="--workload headline --random-keys" [c2]="--workload c2" [c4]="--workload c4" \
-                [c4_sparse_keys]="--workload c4_sparse" [agg_65536_groups]="--workload agg_groups --groups 65536" )
+                [c4_sparse_keys]="--workload c4_sparse" [agg_65536_groups]="--workload agg_groups --groups 65536" \
+                [headline_single_column]="--workload headline_single" [headline_int64_values]="--workload headline_int64" \
+                [agg_tree_predicate]="--workload tree_pred" [agg_three_value_columns]="--workload agg3" [c2_random_ids]="--workload c2_random" \
+                [c4_dup_keys]="--workload c4_dup" [c4_partial_match]="--workload c4_partial" )
+CONFIGS=${NQE_PROFILE_CONFIGS:-"headline headline_random_keys headline_single_column headline_int64_values agg_tree_predicate agg_three_value_columns c2 c2_random_ids c4 c4_sparse_keys c4_dup_keys c4_partial_match agg_65536_groups"}
 cd /tmp
-for name in headline headline_random_keys c2 c4 c4_sparse_keys agg_65536_groups; do
+for name in $CONFIGS; do
   args="${WL[$name]} --no-configs --no-cpu-baseline"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o $name -- python $R/bench.py $args --steps 20 --warmup 3 > $OUT/prof_$name.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$name -o $name -- python $R/bench.py $args --steps 3 --warmup 1 > $OUT/pmc_fetch_$name.log 2>&1
@@ -29,5 +33,6 @@ python tools/probe_paths.py groups 2>&1 | grep -v amdgpu.ids > $OUT/probe_groups
 python tools/probe_paths.py joinshapes 2>&1 | grep -v amdgpu.ids > $OUT/probe_joinshapes.txt
 python tools/probe_paths.py keys 2>&1 | grep -v amdgpu.ids > $OUT/probe_keys.txt
 python tools/probe_paths.py exprs 2>&1 | grep -v amdgpu.ids > $OUT/probe_exprs.txt
+python tools/probe_paths.py trees 2>&1 | grep -v amdgpu.ids > $OUT/probe_trees.txt
 ./tools/micro_bench all > $OUT/micro_bench.txt 2>&1
 ls $OUT
