@@ -205,6 +205,53 @@ __global__ void __launch_bounds__(256) dense_unique_build_kernel(const uint64_t 
         }
     }
 }
+// The same build WITHOUT device-scope atomics (they run at a flat ~2.4x10^10/s on this chip whatever the table size: two to three per
+// row made a 10^8-row build 9.8 ms, a 10^7-row one 1.2 ms).  Pass A scatters row numbers with plain stores — of several rows with
+// one key any one wins.  Pass B walks the table in KEY order, 64 entries per wave: the presence words are ballots, the number of
+// occupied entries (== rows ⇔ the keys are unique) one atomic per workgroup, and the payload columns are GATHERED by the stored
+// row (random reads, which the chip serves at 5-10x10^10/s) and written in whole coalesced words — bit-packed entries are
+// assembled in LDS, a wave's 64 entries being exactly 2 x bits words.
+__global__ void __launch_bounds__(256) dense_scatter_rows_kernel(const uint64_t *keys, int64_t n, uint64_t dmin, uint32_t *dense) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) dense[keys[r] - dmin] = uint32_t(r) + 1u;
+}
+__global__ void __launch_bounds__(256) dense_finish_kernel(const uint32_t *dense, uint64_t span, uint32_t *presence, DensePayload dp, unsigned long long *occupied) {
+    __shared__ uint32_t pack[4][2 * 25];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const uint64_t ngroups = (span + 63) / 64;
+    uint32_t mine = 0;
+    for (uint64_t g = uint64_t(blockIdx.x) * 4 + wave; g < ngroups; g += uint64_t(gridDim.x) * 4) {
+        const uint64_t d = g * 64 + lane;
+        const uint32_t e = d < span ? dense[d] : 0u;
+        const bool present = e != 0;
+        const uint64_t m = __ballot(present);
+        mine += __popcll(m);
+        // presence: bit d of 32-bit words — this wave's 64 entries are words 2g and 2g + 1 (the bitmap is allocated in whole pairs)
+        if (presence && lane < 2 && 2 * g + lane < (span + 31) / 32) presence[2 * g + lane] = uint32_t(m >> (32 * lane));
+        for (int c = 0; c < dp.n; ++c) {
+            const uint64_t v = present ? dp.src[c][e - 1] : dp.base[c];
+            const int nb = dp.packed[c];
+            if (nb >= 2) {
+                if (lane < 2 * nb) pack[wave][lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t bit = uint32_t(lane) * uint32_t(nb);
+                const uint64_t o = uint64_t(uint32_t(v - dp.base[c])) << (bit & 31);
+                atomicOr(&pack[wave][bit >> 5], uint32_t(o));
+                if (o >> 32) atomicOr(&pack[wave][(bit >> 5) + 1], uint32_t(o >> 32));
+                __builtin_amdgcn_wave_barrier();
+                // entry d at bit d * nb: the wave's first entry starts word 2 * nb * g
+                if (lane < 2 * nb) static_cast<uint32_t *>(dp.dst[c])[g * uint64_t(2 * nb) + lane] = pack[wave][lane];
+                __builtin_amdgcn_wave_barrier();
+            } else if (d < span) {
+                if (nb) static_cast<uint32_t *>(dp.dst[c])[d] = uint32_t(v - dp.base[c]);
+                else static_cast<uint64_t *>(dp.dst[c])[d] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64); // (every lane of a wave holds the same count: lane 0's sum counts it 64 times)
+    if (lane == 0 && mine) atomicAdd(occupied, (unsigned long long)(mine / 64));
+}
 // claims the first free slot of the probe sequence for every row (no key comparison: equal keys simply occupy several slots),
 // then writes the key (and the 32-byte companion slot at the same index)
 __global__ void __launch_bounds__(256) hashed_insert_rows_kernel(const uint64_t *keys, int64_t n, ulonglong2 *slots, uint32_t cap, int shift, int *dup) {
@@ -865,7 +912,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
     if (span != 0 && span <= std::max<uint64_t>(4ull * uint64_t(n), 1024ull) && span < (1ull << 31)) {
         // ---- dense keys: direct-address table (+ key-ordered payload columns and the presence bitmap when everything is plain)
         BufRef dense = dev_alloc_zero(ctx, size_t(span) * 4);
-        BufRef presence = dev_alloc_zero(ctx, size_t((span + 31) / 32) * 4);
+        BufRef presence = dev_alloc_zero(ctx, size_t((span + 63) / 64) * 8);
         DensePayload dp;
         std::memset(&dp, 0, sizeof(dp));
         std::vector<BufRef> dense_cols(ncols);
@@ -889,7 +936,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
                         dense_base[ci] = mmh[2 * k] ^ (pc.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull);
                     }
                 dense_packed[ci] = packed;
-                dense_cols[ci] = packed >= 2 ? dev_alloc_zero(ctx, (size_t(span) * size_t(packed) + 7) / 8 + 16)
+                dense_cols[ci] = packed >= 2 ? dev_alloc_zero(ctx, size_t((span + 63) / 64) * 8 * size_t(packed) + 16) // whole 64-entry groups (dense_finish_kernel)
                                              : (packed ? dev_alloc_zero(ctx, size_t(span) * 4 + 8) : dev_alloc(ctx, size_t(span) * 8));
                 dp.src[dp.n] = pc.words();
                 dp.dst[dp.n] = dense_cols[ci]->ptr;
@@ -898,9 +945,19 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
                 dp.n++;
             }
         }
-        launch(ctx, "join_build_dense", dense_unique_build_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, kmin, (uint32_t *)dense->ptr,
-               (uint32_t *)presence->ptr, dp, (int *)dupflag->ptr);
-        dup = read_scalar(ctx, (const int *)dupflag->ptr);
+        static const bool atomic_build = getenv("NQE_JOIN_ATOMIC_BUILD") != nullptr; // diagnostics (A/B): the one-kernel form with device atomics
+        if (n >= (int64_t(1) << 16) && !atomic_build) {
+            // larger builds: scatter row numbers, then finish in key order (see dense_finish_kernel) — no device-scope atomics
+            BufRef occupied = dev_alloc_zero(ctx, 8);
+            launch(ctx, "join_build_dense", dense_scatter_rows_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, kmin, (uint32_t *)dense->ptr);
+            launch(ctx, "join_build_finish", dense_finish_kernel, dim3(stream_grid(ctx, int64_t((span + 63) / 64), 4)), dim3(256), 0, (const uint32_t *)dense->ptr, span,
+                   (uint32_t *)presence->ptr, dp, (unsigned long long *)occupied->ptr);
+            dup = read_scalar(ctx, (const unsigned long long *)occupied->ptr) != (unsigned long long)n;
+        } else {
+            launch(ctx, "join_build_dense", dense_unique_build_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, kmin, (uint32_t *)dense->ptr,
+                   (uint32_t *)presence->ptr, dp, (int *)dupflag->ptr);
+            dup = read_scalar(ctx, (const int *)dupflag->ptr);
+        }
         if (dup) return false;
         jt->direct = true;
         jt->dense = dense;

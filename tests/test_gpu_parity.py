@@ -1471,3 +1471,35 @@ def test_aggregate_mixed_sign_zeros_across_kernel_paths(ctx, groups):
         assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"groups={groups}")   # -0.0 == 0.0 under allclose / ==
         g = rows_sorted(got)
         assert not np.isnan(g).any()
+
+
+@pytest.mark.parametrize("span_bits", [3, 13, 25, 31, 40])
+@pytest.mark.parametrize("shape", ["pk", "holes", "dup"])
+def test_join_large_dense_builds_without_device_atomics(ctx, shape, span_bits):
+    """builds of >= 2^16 rows take the two-kernel form (dense_scatter_rows_kernel + dense_finish_kernel: row numbers scattered with
+    plain stores, presence words / occupancy count / bit-packed payloads produced in key order): a gap-free primary key, keys with
+    holes (presence bitmap, entries of absent keys), a build size that is no multiple of 64, every payload width, and duplicate
+    keys — detected by the occupancy count, after which the sort-based build takes over; probe order and duplicate order exact"""
+    rng = np.random.default_rng(span_bits * 7 + len(shape))
+    nb, n = 70_001, 200_000
+    if shape == "pk":
+        dk = rng.permutation(nb).astype(np.int64) - 500
+    elif shape == "holes":
+        dk = rng.permutation(3 * nb)[:nb].astype(np.int64) - 500
+    else:
+        dk = rng.permutation(nb).astype(np.int64)
+        dk[rng.integers(0, nb, 50)] = dk[rng.integers(0, nb, 50)]      # a few duplicate keys
+    top = (1 << span_bits) - 1
+    a = rng.integers(0, top + 1, nb).astype(np.int64) - (1 << 10)
+    a[:2] = [-(1 << 10), top - (1 << 10)]
+    c = rng.random(nb)
+    left = [Column.from_numpy(dk), Column.from_numpy(a), Column.from_numpy(c)]
+    rk = rng.integers(int(dk.min()) - 10, int(dk.max()) + 10, n).astype(np.int64)
+    right = [Column.from_numpy(rk), Column.from_numpy(rng.random(n))]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    lt, rt = ctx.table_from_host(left), ctx.table_from_host(right)
+    got = ctx.hash_join(lt, rt, 0, 0).to_host()
+    assert_batches_equal(got, exp, what=f"{shape}, payload range of {span_bits} bits")
+    jt = ctx.hash_join_build(lt, 0)                                 # the reused table: optimistic form / its fallback / two passes
+    for _ in range(2):
+        assert_batches_equal(ctx.hash_join_probe(jt, rt, 0).to_host(), exp, what=f"{shape} reused table")
