@@ -84,6 +84,7 @@ __device__ __forceinline__ uint64_t apply_binary(int op, int dt, uint64_t a, uin
         case NQE_OP_MINUS: z = x - y; break;
         case NQE_OP_MULTIPLY: z = x * y; break;
         default:
+            if (op == NQE_OP_DIVIDE && aux.more == -2) return d2u(x * u2d(aux.magic)); // literal divisor ±2^k: its exact reciprocal (make_aux)
             if (y == 0.0) {
                 if (valid) atomicOr(&flags[NQE_FLAG_DIV_ZERO], 1);
                 return 0;

@@ -97,6 +97,16 @@ OpAux make_aux(int op, int dt, uint64_t lit) {
     a.more = -1;
     a.abs_lit = 0;
     a.magic = 0;
+    if (op == NQE_OP_DIVIDE && dt == NQE_FLOAT64) {
+        // x / ±2^k  ==  x * ±2^-k bit for bit (scaling by a power of two is exact; where the quotient is subnormal both round the same
+        // real number): a multiplication instead of the ~40-instruction Float64 division — when 2^k and 2^-k are both normal
+        const uint64_t mant = lit & 0x000fffffffffffffull, ex = (lit >> 52) & 0x7ff;
+        if (mant == 0 && ex >= 2 && ex <= 2044) {
+            a.more = -2;
+            a.magic = (lit & 0x8000000000000000ull) | ((2046 - ex) << 52);
+        }
+        return a;
+    }
     if ((op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS) && (dt == NQE_INT64 || dt == NQE_UINT64) && lit != 0) {
         uint64_t ab = lit;
         if (dt == NQE_INT64 && int64_t(lit) < 0) ab = 0ull - lit;
@@ -282,9 +292,8 @@ __device__ __forceinline__ void ex_combine(const ExInstr &in, uint64_t &a, bool 
 // Loads the EX_ROWS rows a lane owns (row0 + r*64) of every program column; `inm` = rows that exist / are wanted.
 // NULLS = false: no column has a validity bitmap and no literal is NULL, so every mask equals `inm` and none is computed
 // (the kernel is VALU-issue bound once the program has a few instructions; mask bookkeeping is ~40% of it).
-template <bool NULLS, int NC>
-__device__ __forceinline__ void ex_load(const ExProgram &P, int64_t row0, int64_t n, uint32_t inm, uint64_t (&cw)[NC][EX_ROWS], uint32_t (&cvm)[NC]) {
-    constexpr int R = EX_ROWS;
+template <bool NULLS, int NC, int R = EX_ROWS>
+__device__ __forceinline__ void ex_load(const ExProgram &P, int64_t row0, int64_t n, uint32_t inm, uint64_t (&cw)[NC][R], uint32_t (&cvm)[NC]) {
     // issue every load of the chunk (rows clamped to n-1 so that no load is predicated), then consume
     int64_t rc[R];
 #pragma unroll
@@ -327,10 +336,9 @@ __device__ __forceinline__ void ex_load(const ExProgram &P, int64_t row0, int64_
 }
 
 // Runs the program on the loaded rows; the result words are left in res[], the returned mask holds their validity.
-template <bool NULLS, int NC>
-__device__ __forceinline__ uint32_t ex_run(const ExProgram &P, const uint64_t (&cw)[NC][EX_ROWS], const uint32_t (&cvm)[NC],
-                                           uint32_t inm, uint32_t litm, uint64_t (&res)[EX_ROWS], int *flags) {
-    constexpr int R = EX_ROWS;
+template <bool NULLS, int NC, int R = EX_ROWS>
+__device__ __forceinline__ uint32_t ex_run(const ExProgram &P, const uint64_t (&cw)[NC][R], const uint32_t (&cvm)[NC],
+                                           uint32_t inm, uint32_t litm, uint64_t (&res)[R], int *flags) {
     // ---- run the program
     uint64_t s[EX_MAX_DEPTH][R];
     uint32_t vm[EX_MAX_DEPTH];
@@ -455,10 +463,11 @@ __device__ __forceinline__ uint32_t ex_run(const ExProgram &P, const uint64_t (&
     return vm[0];
 }
 
-template <bool NULLS, int NC>
+// R rows per lane: the dispatch of an instruction (scalar work) is paid once per R x 64 rows; 4 by default (8 halves the scalar work
+// but takes 176 VGPRs — see the launch site)
+template <bool NULLS, int NC, int R = EX_ROWS>
 __global__ void __launch_bounds__(256) expr_tree_kernel(ExProgram P, int64_t n, uint64_t *out_words, uint64_t *out_bits, uint64_t *out_valid,
                                                         int *flags) {
-    constexpr int R = EX_ROWS;
     const int lane = lane_id();
     const int64_t n_chunks = (n + 64 * R - 1) / (64 * R);
     const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, n_waves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -469,8 +478,8 @@ __global__ void __launch_bounds__(256) expr_tree_kernel(ExProgram P, int64_t n, 
         for (int r = 0; r < R; ++r) inm |= (row0 + r * 64 < n ? 1u : 0u) << r;
         uint64_t cw[NC][R], res[R];
         uint32_t cvm[NC];
-        ex_load<NULLS, NC>(P, row0, n, inm, cw, cvm);
-        const uint32_t vm = ex_run<NULLS, NC>(P, cw, cvm, inm, inm, res, flags);
+        ex_load<NULLS, NC, R>(P, row0, n, inm, cw, cvm);
+        const uint32_t vm = ex_run<NULLS, NC, R>(P, cw, cvm, inm, inm, res, flags);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t row = row0 + r * 64;
@@ -980,8 +989,13 @@ DevColumn evaluate_expr(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             uint64_t *ov = needs_valid ? (uint64_t *)out.validity->ptr : nullptr;
             // instantiated per (nullable, <=2 / <=4 columns): the column registers of a lane are the largest block of VGPRs
 #define NQE_TREE(NU, NC) launch(ctx, "expr_tree", expr_tree_kernel<NU, NC>, grid, dim3(256), 0, P, rows, ow, ob, ov, ctx->d_flags)
+            // (8 rows per lane, measured: 176 VGPRs = 2 waves per SIMD — an 8-operator chain 1.19 -> 1.13 ms per 2x10^8 rows, but
+            // `(id % 1000) * 3 + id / 7` 1.11 -> 1.36 and `v > 50 and id % 3 = 0` 0.98 -> 1.19: off unless asked for)
+            static const bool rows8 = getenv("NQE_EXPR_ROWS8") != nullptr; // diagnostics (A/B)
             if (needs_valid) { if (P.ncols <= 2) NQE_TREE(true, 2); else NQE_TREE(true, 4); }
-            else { if (P.ncols <= 2) NQE_TREE(false, 2); else NQE_TREE(false, 4); }
+            else if (P.ncols <= 2 && rows8) {
+                launch(ctx, "expr_tree", expr_tree_kernel<false, 2, 8>, dim3(stream_grid(ctx, (rows + 7) / 8, 256)), dim3(256), 0, P, rows, ow, ob, ov, ctx->d_flags);
+            } else { if (P.ncols <= 2) NQE_TREE(false, 2); else NQE_TREE(false, 4); }
 #undef NQE_TREE
         }
         return out;
