@@ -196,9 +196,17 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t x, int lane) {
 __device__ __forceinline__ uint32_t bcast32(uint32_t x, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x, lane); }
 
 // integer `x op lit` as a branch-free range test (host-prepared, see make_fast_pred)
+// lo <= (x ^ flip) <= hi (signed) as ONE subtraction and ONE unsigned compare: flip is 0 or the sign bit, and x ^ signbit == x + 2^63,
+// so with everything moved to the unsigned image the test is (x - base) < width, base and width wave-uniform (scalar arithmetic,
+// hoisted out of the row loops).  width == 0 is the empty range — which the host always writes as lo = hi + 1 (make_fast_pred; any
+// other lo > hi would wrap to a non-zero width) — or the full one, whose width 2^64 wraps.  Two vector
+// instructions per row instead of four (two 32-bit xors + two 64-bit compares): the streaming kernels are issue-bound.
 __device__ __forceinline__ bool range_pass(const FastPred &fp, uint64_t x) {
-    int64_t xs = int64_t(x ^ fp.flip);
-    return ((xs >= fp.lo) && (xs <= fp.hi)) != (fp.negate != 0);
+    const uint64_t f2 = fp.flip ^ 0x8000000000000000ull;                       // 2^63 for signed operands, 0 for unsigned ones
+    const uint64_t nbase = f2 - (uint64_t(fp.lo) + 0x8000000000000000ull);     // -(LO - f2)
+    const uint64_t width = uint64_t(fp.hi) - uint64_t(fp.lo) + 1ull;
+    const bool full = width == 0 && fp.lo <= fp.hi;
+    return (((x + nbase) < width) || full) != (fp.negate != 0);
 }
 
 // Float64 → order-preserving signed integer (fmask = 0 leaves integers alone).  Deliberately NOT part of range_pass: the
@@ -215,8 +223,12 @@ __device__ __forceinline__ uint64_t pred_extract(const FastPred &fp, uint64_t w,
 // one leaf of a ConjPred on the row's word
 __device__ __forceinline__ bool conj_test(const ConjTest &t, uint64_t w) {
     const uint64_t x = w ^ (uint64_t(int64_t(w) >> 63) & t.fmask);
-    const int64_t xs = int64_t(x ^ t.flip);
-    return ((xs >= t.lo) && (xs <= t.hi)) != (t.negate != 0);
+    // (the one-subtraction form of range_pass)
+    const uint64_t f2 = t.flip ^ 0x8000000000000000ull;
+    const uint64_t nbase = f2 - (uint64_t(t.lo) + 0x8000000000000000ull);
+    const uint64_t width = uint64_t(t.hi) - uint64_t(t.lo) + 1ull;
+    const bool full = width == 0 && t.lo <= t.hi;
+    return (((x + nbase) < width) || full) != (t.negate != 0);
 }
 // the arithmetic step of a test (wave-uniform dispatch; operands vetted by the host: no fault possible)
 __device__ __forceinline__ uint64_t conj_pre(const ConjTest &t, uint64_t w) {
