@@ -349,6 +349,8 @@ pub enum NqeJoinTable {}
 extern "C" {
     fn nqe_comm_get_unique_id(id_out: *mut u8 /* 128 bytes */) -> i32;
     fn nqe_comm_create(ctx: *mut NqeCtx, unique_id: *const u8, rank: i32, world: i32, out: *mut *mut NqeComm) -> i32;
+    // (hosts without RCCL between their ranks: nqe_comm_create_custom takes all_gather / all_gather_v, nqe_comm_create_p2p takes
+    // send / recv / group brackets with RCCL's matching rules — see nqe.h; a failed rank fails every rank, nobody blocks)
     fn nqe_comm_destroy(comm: *mut NqeComm) -> i32;
     fn nqe_sharded_aggregate_execute(comm: *mut NqeComm, t: *const NqeTable, pred: *const NqeExprNode, pn: i32, group: *const NqeExprNode, gn: i32,
                                      aggs: *const NqeAggregate, na: i32, out: *mut *mut NqeTable, keys_out: *mut *mut NqeTable) -> i32;
