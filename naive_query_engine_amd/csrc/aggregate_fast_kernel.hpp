@@ -46,7 +46,9 @@ namespace {
 // nesting of and / or over up to four such tests, a test possibly with an arithmetic step (`id % 3 = 0`; ConjPred's general form),
 // 6 any other fault-free predicate tree over those columns, run by the typed stack machine of aggregate_common.hpp
 // (tree_pred_eval; AggArgs::tree_prog).
-template <int PRED, int KEY, int NVT, bool VF64, bool VNULL, bool SUB = false>
+// MM = false: no aggregate of the pass asks for min / max (C1's count / sum / avg): their registers and LDS reads are left out,
+// which is what lets the batch loop run beside TWO value columns (instances: no predicate or the key-range test, built-in keys).
+template <int PRED, int KEY, int NVT, bool VF64, bool VNULL, bool SUB = false, bool MM = true>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
@@ -140,8 +142,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 }
                 if (rnan[j]) atomicOr(&lcnt[o], NAN_BIT);
                 // read-before-atomic (see the general kernel)
-                if (rmn[j] < lmn[o]) unsafeAtomicMin(&lmn[o], rmn[j]);
-                if (rmx[j] > lmx[o]) unsafeAtomicMax(&lmx[o], rmx[j]);
+                if (MM) {
+                    if (rmn[j] < lmn[o]) unsafeAtomicMin(&lmn[o], rmn[j]);
+                    if (rmx[j] > lmx[o]) unsafeAtomicMax(&lmx[o], rmx[j]);
+                }
             } else if (gslot >= 0) {
                 global_update(g, gslot, a.v0 + j, rcnt[j], rsum[j], true, f64_to_ord(rmn[j]), f64_to_ord(rmx[j]), true, rnan[j]);
             }
@@ -239,7 +243,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // LDS-atomic throughput (tools/micro_bench.hip: the same update stream issued back to back runs 3x faster).  Such a tile
     // goes to the table directly, all its rows at once: AGG_U slots, one batch of min/max reads, one wait, then the atomics.
     // (two value columns: the rows of a tile go in two halves — eight more min/max words in flight would not fit the registers)
-    constexpr int BG = NVT == 1 ? AGG_U : NQE_AGG_BG2;
+    constexpr int BG = NVT == 1 ? AGG_U : (MM ? NQE_AGG_BG2 : 2);
     auto direct_rows = [&](const Tile &t, int64_t base, const bool (&pass)[AGG_U], const uint64_t (&key)[AGG_U]) {
         bool cold = false;
         int slot[AGG_U];
@@ -268,14 +272,16 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 }
                 cold = cold || slot[u] < 0;
             }
-            double cmn[NVT][BG], cmx[NVT][BG];
+            double cmn[MM ? NVT : 1][BG], cmx[MM ? NVT : 1][BG];
+            if (MM) {
 #pragma unroll
-            for (int j = 0; j < NVT; ++j) {
+                for (int j = 0; j < NVT; ++j) {
 #pragma unroll
-                for (int i = 0; i < BG; ++i) {
-                    const uint32_t o = uint32_t(j) * slots + uint32_t(slot[g0 + i] < 0 ? 0 : slot[g0 + i]);
-                    cmn[j][i] = lmn[o]; // read-before-atomic, all rows of the group in flight together
-                    cmx[j][i] = lmx[o];
+                    for (int i = 0; i < BG; ++i) {
+                        const uint32_t o = uint32_t(j) * slots + uint32_t(slot[g0 + i] < 0 ? 0 : slot[g0 + i]);
+                        cmn[MM ? j : 0][i] = lmn[o]; // read-before-atomic, all rows of the group in flight together
+                        cmx[MM ? j : 0][i] = lmx[o];
+                    }
                 }
             }
             // the per-row path: one branch (the row takes part), the updates themselves predicated by ordered compares — a NaN fails
@@ -293,8 +299,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                     const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
                     atomicAdd(&lcnt[o], 1u);
                     unsafeAtomicAdd(&lsum[o], x);
-                    if (x < cmn[j][i]) unsafeAtomicMin(&lmn[o], x);
-                    if (x > cmx[j][i]) unsafeAtomicMax(&lmx[o], x);
+                    if (MM) {
+                        if (x < cmn[MM ? j : 0][i]) unsafeAtomicMin(&lmn[o], x);
+                        if (x > cmx[MM ? j : 0][i]) unsafeAtomicMax(&lmx[o], x);
+                    }
                     if (x != x) atomicOr(&lcnt[o], NAN_BIT);
                 }
             }
@@ -357,14 +365,18 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 rsum[j] += vb ? x : 0.0;
                 rnan[j] = rnan[j] || (vb && x != x);
                 const double xm = vb ? x : __builtin_nan("");
-                rmn[j] = fmin(rmn[j], xm);
-                rmx[j] = fmax(rmx[j], xm);
+                if (MM) {
+                    rmn[j] = fmin(rmn[j], xm);
+                    rmx[j] = fmax(rmx[j], xm);
+                }
             } else {
                 rcnt[j] += 1;
                 rsum[j] += x;
                 rnan[j] = rnan[j] || (x != x);
-                rmn[j] = fmin(rmn[j], x); // NaN operand ignored
-                rmx[j] = fmax(rmx[j], x);
+                if (MM) {
+                    rmn[j] = fmin(rmn[j], x); // NaN operand ignored
+                    rmx[j] = fmax(rmx[j], x);
+                }
             }
         }
     };
@@ -493,7 +505,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         load_tile(A, base);
         // not where registers are short: the VNULL variants (37 VGPRs spilled: 2.2x slower), two value columns, interpreted predicates
         constexpr bool CAN_BATCH = NQE_AGG_BATCH && !VNULL && PRED != 3 && (PRED != 6 && (PRED != 5 || (NQE_AGG_BATCH_TREE && KEY != 3 && NVT == 1))) && !(PRED == 2 && KEY == 3) && !(PRED == 4 && KEY == 3) &&
-                                   (NVT == 1 || (NQE_AGG_BATCH2 && KEY != 3 && PRED != 4));
+                                   (NVT == 1 || ((NQE_AGG_BATCH2 || !MM) && KEY != 3 && PRED != 4));
         while (base < n) {
             bool batch = false; // wave-uniform
             if (CAN_BATCH) {
@@ -563,7 +575,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     }
 }
 
-template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64, bool sub) {
+template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64, bool sub, bool nomm) {
+    if constexpr (!VNULL && PRED <= 1 && KEY != 3) {
+        if (nomm && nv == 2 && !sub)
+            return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, false, false, false> : agg_grouped_fast_kernel<PRED, KEY, 2, false, false, false, false>;
+    }
     if (sub) {
         // (PRED 4: a query that outgrows one table continues with a materialised predicate; its slice is built without validity only)
         if constexpr (VNULL || PRED >= 4) return nullptr;
@@ -580,12 +596,12 @@ template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf
         return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 2, false, VNULL>;
     }
 }
-template <int PRED, bool VNULL> FastKernel pick_fast_key(int key, int nv, bool vf64, bool sub) {
+template <int PRED, bool VNULL> FastKernel pick_fast_key(int key, int nv, bool vf64, bool sub, bool nomm) {
     switch (key) {
-    case 0: return pick_fast_nv<PRED, 0, VNULL>(nv, vf64, sub);
-    case 1: return pick_fast_nv<PRED, 1, VNULL>(nv, vf64, sub);
-    case 2: return pick_fast_nv<PRED, 2, VNULL>(nv, vf64, sub);
-    default: return pick_fast_nv<PRED, 3, VNULL>(nv, vf64, sub);
+    case 0: return pick_fast_nv<PRED, 0, VNULL>(nv, vf64, sub, nomm);
+    case 1: return pick_fast_nv<PRED, 1, VNULL>(nv, vf64, sub, nomm);
+    case 2: return pick_fast_nv<PRED, 2, VNULL>(nv, vf64, sub, nomm);
+    default: return pick_fast_nv<PRED, 3, VNULL>(nv, vf64, sub, nomm);
     }
 }
 

@@ -32,6 +32,10 @@ struct nqe_join_table {
     int key_dtype = NQE_INT64;
     nqe::BufRef slots; // ulonglong2[cap]
     nqe::BufRef perm;  // uint32[left_rows], build rows sorted by (key, row)
+    // duplicate build keys: plain 8-byte payload columns re-laid out in `perm` order, so that the matches of one probe row — consecutive
+    // entries of the sorted row list — are ADJACENT words (one line per probe row instead of two dependent random reads per
+    // output row: perm[...] then the column; PMC showed 20 GB of traffic for 4.8 GB algorithmic on the 4-rows-per-key join)
+    std::vector<nqe::BufRef> sorted_cols; // per left column, null where none
     uint32_t cap = 0;
     int shift = 0;
     bool direct = false; // all build keys unique: slot.y>>32 is the build row itself
@@ -765,9 +769,16 @@ __global__ void __launch_bounds__(JT_BLOCK) probe_count_kernel(const uint64_t *r
     }
 }
 
+// dst[i] = src[perm[i]]: a payload column in sorted-row order (build side, once)
+__global__ void __launch_bounds__(256) permute_words_kernel(const uint64_t *src, const uint32_t *perm, int64_t n, uint64_t *dst) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) dst[i] = src[perm[i]];
+}
+
 struct JoinCols {
     int32_t n;
     int32_t n_left;
+    int32_t need_perm;               // some left column is addressed by build row (else: all by position in the sorted row list)
+    int32_t by_pos[MAX_JOIN_COLS];   // left column k: src is the `perm`-ordered copy, addressed by start + match number
     const void *src[MAX_JOIN_COLS];
     const uint8_t *src_valid[MAX_JOIN_COLS];
     int32_t dtype[MAX_JOIN_COLS];
@@ -822,7 +833,7 @@ __global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *p
             __syncthreads();
             // ---- one lane per output row
             for (uint32_t j0 = 0; j0 < total; j0 += JT_BLOCK * 4) {
-                uint32_t prow[4], brow[4];
+                uint32_t prow[4], brow[4], bpos[4];
                 bool live[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -839,7 +850,8 @@ __global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *p
                     }
                     prow[q] = lo;
                     uint32_t mth = jj - off[lo];
-                    brow[q] = live[q] ? (direct ? startv[lo] : perm[startv[lo] + mth]) : 0u;
+                    bpos[q] = live[q] ? startv[lo] + mth : 0u;
+                    brow[q] = live[q] ? (direct ? startv[lo] : (jc.need_perm ? perm[startv[lo] + mth] : 0u)) : 0u;
                 }
                 for (int c = 0; c < jc.n; ++c) {
                     const bool left = c < jc.n_left;
@@ -849,7 +861,7 @@ __global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *p
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (!live[q]) continue;
-                        int64_t srow = left ? int64_t(brow[q]) : row0 + prow[q];
+                        int64_t srow = left ? int64_t(jc.by_pos[c] ? bpos[q] : brow[q]) : row0 + prow[q];
                         bool ok = sv ? get_bit(sv, srow) : true;
                         uint64_t v = load_word(src, dt, srow);
                         uint64_t pos = out_base + j0 + q * JT_BLOCK + threadIdx.x;
@@ -1055,6 +1067,17 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
                (const uint32_t *)flags->ptr, (const uint64_t *)offs->ptr, n, U, (uint32_t *)ustart->ptr);
     }
     jt->direct = (int64_t(U) == n);
+    if (!jt->direct && n > 0) {
+        // duplicate keys: plain payload columns in sorted-row order (see nqe_join_table::sorted_cols)
+        jt->sorted_cols.resize(left->cols.size());
+        for (size_t ci = 0; ci < left->cols.size(); ++ci) {
+            const DevColumn &pc = left->cols[ci];
+            if (int(ci) == left_key || !is_word_type(pc.dtype) || pc.validity) continue;
+            jt->sorted_cols[ci] = dev_alloc(ctx, size_t(n) * 8 + 8);
+            launch(ctx, "join_permute_payload", permute_words_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, pc.words(), (const uint32_t *)jt->perm->ptr, n,
+                   (uint64_t *)jt->sorted_cols[ci]->ptr);
+        }
+    }
     uint32_t cap = 64;
     while (uint64_t(cap) < 2ull * U) cap <<= 1;
     int lg = 0;
@@ -1430,6 +1453,18 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
     }
     jc.n = int(srcs.size());
     if (jc.n > MAX_JOIN_COLS) fail(NQE_ERR_NOT_SUPPORTED, "join output wider than 32 columns");
+    // left columns with a copy in sorted-row order are read at start + match number: the matches of a probe row are adjacent words
+    std::vector<DevColumn> by_pos_cols(size_t(jc.n_left));
+    for (int k = 0; k < jc.n_left; ++k) {
+        const int ci = out_slot[size_t(k)];
+        if (!jt->direct && ci >= 0 && size_t(ci) < jt->sorted_cols.size() && jt->sorted_cols[size_t(ci)]) {
+            by_pos_cols[size_t(k)] = *srcs[size_t(k)];
+            by_pos_cols[size_t(k)].values = jt->sorted_cols[size_t(ci)];
+            srcs[size_t(k)] = &by_pos_cols[size_t(k)];
+            jc.by_pos[k] = 1;
+        } else
+            jc.need_perm = 1;
+    }
     out->cols.resize(ncols);
     std::vector<BufRef> bool_bytes(srcs.size()), valid_bytes(srcs.size());
     std::vector<DevColumn> dsts(srcs.size());
