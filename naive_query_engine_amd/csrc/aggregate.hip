@@ -1072,7 +1072,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         while (int64_t(sized_cap) < 2 * guess) sized_cap <<= 1;
         cap = std::min(sized_cap, RANK_MAX_CAP);
     }
-    bool partition_mode = false, level2 = false, dense_ok = true, slab_failed = false;
+    bool partition_mode = false, level2 = false, dense_ok = true, slab_failed = false, key32_failed = false;
     // Between one LDS table's worth of groups and the partitioned path: the fast kernel with two key subsets (see
     // AggArgs::subsets_log2) — every row is read by two workgroups, each of which keeps its half of the keys.  Rows of the other
     // half cost a wave as many issue slots as its own (lanes are masked, instructions are not skipped), so the kernel time doubles:
@@ -1118,13 +1118,15 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         static const bool no_hints = getenv("NQE_NO_PLAN_HINTS") != nullptr; // diagnostics (A/B runs)
         auto it = ctx->agg_hints.find(hint_key);
         if (!no_hints && it != ctx->agg_hints.end()) {
-            if (it->second == 1 || it->second == 16 || it->second == 17) { // 1: PARTS partitions, 16: the smaller first count was enough
-                partition_mode = true;                                          // 17: the exact form (a slab overflowed or did not fit)
-                if (it->second == 1) slab_parts_log2 = PARTS_LOG2;
-                if (it->second == 17) slab_failed = true;
+            const uint8_t hv = it->second & 0x3f;
+            if (it->second & 0x40) key32_failed = true; // keys beyond int32: 16-byte tuples
+            if (hv == 1 || hv == 16 || hv == 17) { // 1: PARTS partitions, 16: the smaller first count was enough
+                partition_mode = true;             // 17: the exact form (a slab overflowed or did not fit)
+                if (hv == 1) slab_parts_log2 = PARTS_LOG2;
+                if (hv == 17) slab_failed = true;
                 cap = std::max(cap, sized_cap);
-            } else if (it->second >= 2 && it->second - 1 <= subsets_max) {
-                subsets_log2 = it->second - 1;
+            } else if (hv >= 2 && hv - 1 <= subsets_max) {
+                subsets_log2 = hv - 1;
                 cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
             }
         }
@@ -1348,18 +1350,21 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         // step (the scatter took 0.78 or 0.97 ms depending on where the buffer happened to land)
                         const int64_t capt = ((mean + mean / 4 + 64 + 15) / 16 | 1) * 16;
                         const size_t tw = size_t(1 + a.nv);
+                        // one value column, integer keys: 12-byte tuples {int32 key, value} unless a key was seen not to fit
+                        const bool k32 = a.nv == 1 && !key32_failed;
+                        const size_t tuple_bytes = k32 ? 12 : tw * 8;
                         // the slabs take 1.25x the tuple volume (+ padding) on top of the group table: when that does not fit, the exact
                         // form (count → scan → scatter into exactly sized partitions) still may — fall back instead of failing
                         BufRef slabs, fill;
                         try {
                             static const bool test_oom = getenv("NQE_TEST_SLAB_OOM") != nullptr; // tests: as if the allocation had failed
                             if (test_oom) fail(NQE_ERR_OUT_OF_MEMORY, "slab allocation (NQE_TEST_SLAB_OOM)");
-                            slabs = dev_alloc(ctx, size_t(sparts) * size_t(W) * size_t(capt) * tw * 8 + 16);
+                            slabs = dev_alloc(ctx, size_t(sparts) * size_t(W) * size_t(capt) * tuple_bytes + 16);
                             fill = dev_alloc(ctx, size_t(sparts) * size_t(W) * 4);
                         } catch (const Error &e) {
                             if (e.code != NQE_ERR_OUT_OF_MEMORY) throw;
                             slab_failed = true;
-                            if (hint_key) ctx->agg_hints[hint_key] = 17; // partitioned, exact form: do not try the slabs again
+                            if (hint_key) ctx->agg_hints[hint_key] = uint8_t(17 | (key32_failed ? 0x40 : 0)); // partitioned, exact form: do not try the slabs again
                             flags_reset(ctx);
                             slab_oom = true;
                             break;
@@ -1372,7 +1377,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         sl.cap = int32_t(capt);
                         sl.parts_log2 = slab_parts_log2;
                         const size_t sc_shmem = size_t(tile_rows) * 8 * tw + size_t(PARTS) * 12;
-                        launch(ctx, "agg_partition_scatter", pick_slab_scatter_kernel(fp, fast_key, a.nv), dim3(W), dim3(AGG_BLOCK), sc_shmem, ka, fpred, sl,
+                        launch(ctx, "agg_partition_scatter", pick_slab_scatter_kernel(fp, fast_key, a.nv, k32), dim3(W), dim3(AGG_BLOCK), sc_shmem, ka, fpred, sl,
                                ctx->d_flags);
                         AggArgs sa = ka;
                         size_t sshmem = shmem;
@@ -1383,7 +1388,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             sshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
                             sblocks = 1;
                         }
-                        launch(ctx, "agg_segments", pick_slab_segments_kernel(a.nv, vf64), dim3(std::min(sparts, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem,
+                        launch(ctx, "agg_segments", pick_slab_segments_kernel(a.nv, vf64, k32), dim3(std::min(sparts, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem,
                                sa, sl, tb.g, ctx->d_flags);
                         sync(ctx); // the slabs are released at the end of this scope
                     } else if (partition_mode) {
@@ -1550,15 +1555,21 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     f[NQE_FLAG_TABLE_FULL], f[NQE_FLAG_DENSE_OVERFLOW]);
         if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
+        if (f[NQE_FLAG_KEY32_OVERFLOW] && partition_mode && !key32_failed) {
+            key32_failed = true; // a group key outside int32: the 16-byte tuple form
+            if (hint_key) ctx->agg_hints[hint_key] = uint8_t(0x40 | (slab_parts_log2 < PARTS_LOG2 ? 16 : 1));
+            flags_reset(ctx);
+            continue;
+        }
         if (f[NQE_FLAG_SLAB_OVERFLOW] && partition_mode && !slab_failed) {
             slab_failed = true; // a partition outgrew its slab (skewed keys): exact partition sizes instead
-            if (hint_key) ctx->agg_hints[hint_key] = 17; // … and the next execution of this query shape starts there
+            if (hint_key) ctx->agg_hints[hint_key] = uint8_t(17 | (key32_failed ? 0x40 : 0)); // … and the next execution of this query shape starts there
             flags_reset(ctx);
             continue;
         }
         if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2 && !slab_failed && slab_parts_log2 < PARTS_LOG2) {
             slab_parts_log2 = PARTS_LOG2; // a partition outgrew a workgroup table: the full partition count, still in slab form
-            if (hint_key) ctx->agg_hints[hint_key] = 1;
+            if (hint_key) ctx->agg_hints[hint_key] = uint8_t(1 | (key32_failed ? 0x40 : 0));
             flags_reset(ctx);
             continue;
         }
@@ -1580,7 +1591,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             }
             if (hint_key) {
                 if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
-                ctx->agg_hints[hint_key] = partition_mode ? (slab_parts_log2 < PARTS_LOG2 ? 16 : 1) : 1 + subsets_log2;
+                ctx->agg_hints[hint_key] = uint8_t((partition_mode ? (slab_parts_log2 < PARTS_LOG2 ? 16 : 1) : 1 + subsets_log2) | (key32_failed ? 0x40 : 0));
             }
             flags_reset(ctx);
             continue;

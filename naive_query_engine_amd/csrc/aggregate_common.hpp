@@ -504,10 +504,11 @@ SubpartitionKernel pick_subpartition_kernel(int nv);
 using SegmentsKernel = void (*)(AggArgs, const uint64_t *, int64_t, int, int, int, const uint64_t *, const uint64_t *, const uint64_t *, GroupTable, int *);
 SegmentsKernel pick_segments_kernel(int nv, bool vf64);
 using SlabScatterKernel = void (*)(AggArgs, FastPred, SlabArgs, int *);
-SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv);
+// k32 (one value column): 12-byte tuples {int32 key, value} — the scatter raises NQE_FLAG_KEY32_OVERFLOW on a key outside int32
+SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv, bool k32 = false);
 int slab_scatter_rows_per_thread(int pred, int key, int nv);
 using SlabSegmentsKernel = void (*)(AggArgs, SlabArgs, GroupTable, int *);
-SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64);
+SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64, bool k32 = false);
 
 } // namespace agg
 } // namespace nqe

@@ -419,7 +419,14 @@ template <int PRED, int KEY, int NVT> struct SlabShape {
 // tuples of one partition into THIS workgroup's slab of it.  The next tile's words are requested before the copy-out, so the
 // loads overlap the LDS phases and the stores (one workgroup per CU fits — 136 KB of LDS — and the unpipelined form spent
 // 22 µs per 8192-row tile where the CU's share of HBM needs 13).
-template <int PRED, int KEY, int NVT>
+// K32 (one value column): the tuple written to the slab is {int32 key, value} = 12 bytes — passes 2 and 3 of the partitioned
+// aggregate move 12 instead of 16 bytes per row (40 B/row in all instead of 48).  Optimistic: a key outside int32 raises
+// NQE_FLAG_KEY32_OVERFLOW and the host redoes the query with 16-byte tuples (and remembers).
+struct __attribute__((packed, aligned(4))) Tuple12 {
+    int32_t key;
+    uint64_t val;
+};
+template <int PRED, int KEY, int NVT, bool K32 = false>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, FastPred fp, SlabArgs sa, int *flags) {
     constexpr int RPT = SlabShape<PRED, KEY, NVT>::RPT;
     constexpr int SC_ROWS = AGG_BLOCK * RPT;
@@ -523,7 +530,13 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
             const uint32_t at = gcur[p] + (i - tstart[p]);
             if (at < cap) {
                 uint64_t *dst = sa.slabs + ((size_t(blockIdx.x) * size_t(parts) + p) * size_t(cap) + at) * TW;
-                if (TW == 2) {
+                if (K32) {
+                    if (int64_t(int32_t(uint32_t(k))) != int64_t(k)) atomicOr(&flags[NQE_FLAG_KEY32_OVERFLOW], 1);
+                    Tuple12 t;
+                    t.key = int32_t(uint32_t(k));
+                    t.val = v0;
+                    reinterpret_cast<Tuple12 *>(sa.slabs)[(size_t(blockIdx.x) * size_t(parts) + p) * size_t(cap) + at] = t;
+                } else if (TW == 2) {
                     *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(k, v0);
                 } else {
                     dst[0] = k;
@@ -556,7 +569,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
 // one workgroup per partition (grid-stride); its waves take the partition's slabs round-robin and stream their tuples, four
 // per lane per step, into the workgroup's LDS table with the batched update of the fast kernel (all first probes, then all
 // min/max reads of the step in flight together — tuples of a partition arrive in no particular order, every row is an update).
-template <int NVT, bool VF64>
+template <int NVT, bool VF64, bool K32 = false>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a, SlabArgs sa, GroupTable g, int *flags) {
     constexpr int TW = 1 + NVT;
     constexpr int SU = 4; // tuples per lane per step
@@ -617,7 +630,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
                 const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
                 st.live[u] = i < f;
                 const uint32_t ic = st.live[u] ? i : f - 1;
-                if (TW == 2) {
+                if (K32) {
+                    const Tuple12 t = reinterpret_cast<const Tuple12 *>(sa.slabs)[(size_t(wave + l * nwaves) * size_t(parts) + size_t(p)) * size_t(sa.cap) + ic];
+                    st.key[u] = uint64_t(int64_t(t.key));
+                    st.vw[0][u] = t.val;
+                } else if (TW == 2) {
                     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
                     const v2u64 t = __builtin_nontemporal_load(reinterpret_cast<const v2u64 *>(&slab[size_t(ic) * 2]));
                     st.key[u] = t.x;
@@ -772,15 +789,16 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
     }
 }
 
-template <int PRED, int KEY> SlabScatterKernel pick_slab_scatter_nv(int nv) {
-    return nv == 1 ? agg_slab_scatter_kernel<PRED, KEY, 1> : agg_slab_scatter_kernel<PRED, KEY, 2>;
+template <int PRED, int KEY> SlabScatterKernel pick_slab_scatter_nv(int nv, bool k32) {
+    if (nv == 1) return k32 ? agg_slab_scatter_kernel<PRED, KEY, 1, true> : agg_slab_scatter_kernel<PRED, KEY, 1>;
+    return agg_slab_scatter_kernel<PRED, KEY, 2>;
 }
-template <int PRED> SlabScatterKernel pick_slab_scatter_key(int key, int nv) {
+template <int PRED> SlabScatterKernel pick_slab_scatter_key(int key, int nv, bool k32) {
     switch (key) {
-    case 0: return pick_slab_scatter_nv<PRED, 0>(nv);
-    case 1: return pick_slab_scatter_nv<PRED, 1>(nv);
-    case 2: return pick_slab_scatter_nv<PRED, 2>(nv);
-    default: return pick_slab_scatter_nv<PRED, 3>(nv);
+    case 0: return pick_slab_scatter_nv<PRED, 0>(nv, k32);
+    case 1: return pick_slab_scatter_nv<PRED, 1>(nv, k32);
+    case 2: return pick_slab_scatter_nv<PRED, 2>(nv, k32);
+    default: return pick_slab_scatter_nv<PRED, 3>(nv, k32);
     }
 }
 
@@ -828,16 +846,17 @@ PartKernel pick_part_kernel(int pred, int key, int nv, bool scatter) {
     default: return pick_part_key<3>(key, nv, scatter);
     }
 }
-SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv) {
+SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv, bool k32) {
     switch (pred) {
-    case 0: return pick_slab_scatter_key<0>(key, nv);
-    case 1: return pick_slab_scatter_key<1>(key, nv);
-    case 2: return pick_slab_scatter_key<2>(key, nv);
-    default: return pick_slab_scatter_key<3>(key, nv);
+    case 0: return pick_slab_scatter_key<0>(key, nv, k32);
+    case 1: return pick_slab_scatter_key<1>(key, nv, k32);
+    case 2: return pick_slab_scatter_key<2>(key, nv, k32);
+    default: return pick_slab_scatter_key<3>(key, nv, k32);
     }
 }
 int slab_scatter_rows_per_thread(int pred, int key, int nv) { return (nv == 1 && pred <= 1 && (key == 0 || (NQE_SLAB_KEYMOD_RPT == 8 && key != 3))) ? 8 : 4; }
-SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64) {
+SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64, bool k32) {
+    if (nv == 1 && k32) return vf64 ? agg_slab_segments_kernel<1, true, true> : agg_slab_segments_kernel<1, false, true>;
     return nv == 1 ? (vf64 ? agg_slab_segments_kernel<1, true> : agg_slab_segments_kernel<1, false>)
                    : (vf64 ? agg_slab_segments_kernel<2, true> : agg_slab_segments_kernel<2, false>);
 }

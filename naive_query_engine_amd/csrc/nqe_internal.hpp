@@ -41,7 +41,8 @@ inline bool is_word_type(int dt) { return dt == NQE_INT64 || dt == NQE_UINT64 ||
 // Device error flag slots (ctx->d_flags[i])
 enum { NQE_FLAG_DIV_ZERO = 0, NQE_FLAG_OVERFLOW = 1, NQE_FLAG_TABLE_FULL = 2, NQE_FLAG_OOB = 3, NQE_FLAG_NEED_PARTITION = 4, NQE_FLAG_NEED_LEVEL2 = 5, NQE_FLAG_DENSE_OVERFLOW = 6,
        NQE_FLAG_GROUP_COUNT = 7 /* not an error: the aggregate's group count rides along with the flag read-back */,
-       NQE_FLAG_SLAB_OVERFLOW = 8 /* a partition slab of the count-free scatter is full: the host takes the exact form */, NQE_NUM_FLAGS = 9 };
+       NQE_FLAG_SLAB_OVERFLOW = 8 /* a partition slab of the count-free scatter is full: the host takes the exact form */,
+       NQE_FLAG_KEY32_OVERFLOW = 9 /* a group key outside the int32 range met the 12-byte-tuple slab form: the host takes 16-byte tuples */, NQE_NUM_FLAGS = 10 };
 
 struct nqe_ctx {
     int device = 0;

@@ -1503,3 +1503,31 @@ def test_join_large_dense_builds_without_device_atomics(ctx, shape, span_bits):
     jt = ctx.hash_join_build(lt, 0)                                 # the reused table: optimistic form / its fallback / two passes
     for _ in range(2):
         assert_batches_equal(ctx.hash_join_probe(jt, rt, 0).to_host(), exp, what=f"{shape} reused table")
+
+
+@pytest.mark.parametrize("keys", ["small", "negative", "wide", "one_wide", "uint64_high"])
+def test_aggregate_partitioned_path_twelve_byte_tuples_and_their_fallback(ctx, keys):
+    """the slab form of the partitioned aggregate moves {int32 key, value} tuples (12 bytes) while every group key fits int32
+    (agg_slab_scatter_kernel<…, K32>); a key outside int32 — all of them, a single one, UInt64 keys beyond 2^63 — raises
+    NQE_FLAG_KEY32_OVERFLOW and the query is redone with 16-byte tuples, which the plan hint then remembers"""
+    rng = np.random.default_rng(len(keys))
+    n, groups = 600_000, 70_000
+    k = rng.integers(0, groups, n).astype(np.int64)
+    if keys == "negative":
+        k = k - groups // 2 - (1 << 31) + groups      # down to exactly int32 min
+        k[0] = -(1 << 31)
+    elif keys == "wide":
+        k = k * (1 << 34) - (1 << 50)
+    elif keys == "one_wide":
+        k[n // 2] = (1 << 31)                        # the first value beyond int32
+    kc = Column.from_numpy(k.astype(np.uint64) + np.uint64(1 << 63)) if keys == "uint64_high" else Column.from_numpy(k)
+    v = rng.random(n) * 10 - 5
+    cols = [kc, Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=col(0).flatten(f2))[0]
+    t = ctx.table_from_host(cols)
+    for rep in range(3):
+        got, gk = ctx.aggregate(t, ALL_AGGS(1), group_nodes=col(0).flatten(f2), with_keys=True)
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{keys} rep {rep}")
+        kk = gk.to_host()[0].to_numpy()
+        assert (kk == np.unique(kc.to_numpy())).all()
