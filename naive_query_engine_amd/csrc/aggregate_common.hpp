@@ -495,7 +495,8 @@ constexpr int SUB = 1 << SUB_LOG2;
 using FastKernel = void (*)(AggArgs, FastPred, GroupTable, int *);
 // sub: the two-key-subset variant (AggArgs::subsets_log2 = 1), built for one value column without validity bitmaps — nullptr otherwise
 // nomm: no aggregate of the pass needs min / max (two value columns, PRED 0/1, built-in keys: an instance whose batch loop fits)
-FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull, bool sub = false, bool nomm = false);
+// share: the one value column is the key column's own buffer (an instance that loads it once, eight rows per lane)
+FastKernel pick_fast_kernel(int pred, int key, int nv, bool vf64, bool vnull, bool sub = false, bool nomm = false, bool share = false);
 using PartKernel = void (*)(AggArgs, FastPred, PartArgs);
 PartKernel pick_scatter_kernel(int pred, int key, int nv);
 PartKernel pick_part_kernel(int pred, int key, int nv, bool scatter);

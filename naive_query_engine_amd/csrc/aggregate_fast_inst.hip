@@ -16,8 +16,8 @@
 namespace nqe {
 namespace agg {
 
-FastKernel NQE_FAST_CAT(NQE_FAST_PRED, NQE_FAST_VNULL)(int key, int nv, bool vf64, bool sub, bool nomm) {
-    return pick_fast_key<NQE_FAST_PRED, NQE_FAST_VNULL != 0>(key, nv, vf64, sub, nomm);
+FastKernel NQE_FAST_CAT(NQE_FAST_PRED, NQE_FAST_VNULL)(int key, int nv, bool vf64, bool sub, bool nomm, bool share) {
+    return pick_fast_key<NQE_FAST_PRED, NQE_FAST_VNULL != 0>(key, nv, vf64, sub, nomm, share);
 }
 
 } // namespace agg

@@ -48,8 +48,13 @@ namespace {
 // (tree_pred_eval; AggArgs::tree_prog).
 // MM = false: no aggregate of the pass asks for min / max (C1's count / sum / avg): their registers and LDS reads are left out,
 // which is what lets the batch loop run beside TWO value columns (instances: no predicate or the key-range test, built-in keys).
-template <int PRED, int KEY, int NVT, bool VF64, bool VNULL, bool SUB = false, bool MM = true>
+// SHARE = true: the one value column IS the key column (`sum(id) … group by id % 1024`, SURVEY §8d's 8 B/row form): no second load
+// of the same words, and EIGHT rows per lane per tile instead of four — with one 8-byte column a wave's two tiles held only 4 KB
+// in flight (64 KB per CU, the chip's latency-bandwidth product is ~16 MB): the kernel ran at 4.6 TB/s with the vector and scalar
+// units 30-40 % busy (PMC), i.e. latency-bound.
+template <int PRED, int KEY, int NVT, bool VF64, bool VNULL, bool SUB = false, bool MM = true, bool SHARE = false>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
+    constexpr int TU = SHARE ? 2 * AGG_U : AGG_U; // rows per lane per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
     const uint32_t slots = cap + 1;
@@ -173,22 +178,23 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 
     constexpr bool NT = true; // non-temporal loads: -2..3 % (and the loop below keeps a prefetched second tile in flight: 3.24 -> 2.69 ms with the lean loop)
     struct Tile {
-        uint64_t kw[AGG_U], pw[AGG_U], vw[NVT][AGG_U];
-        uint64_t vv[VNULL ? NVT : 1][AGG_U]; // validity word of the wave's 64 rows
-        uint64_t kpv[VNULL ? AGG_U : 1];     // key validity AND predicate validity
+        uint64_t kw[TU], pw[SHARE ? 1 : TU], vw[SHARE ? 1 : NVT][SHARE ? 1 : TU];
+        uint64_t vv[VNULL ? NVT : 1][TU]; // validity word of the wave's 64 rows
+        uint64_t kpv[VNULL ? TU : 1];     // key validity AND predicate validity
     };
     // `base` is wave-uniform (the tile loop's control flow depends on nothing but uniform values, see `stream`): a tile that lies
     // wholly inside the table is addressed as scalar tile pointer + loop-invariant 32-bit lane offset — no address arithmetic on the
     // vector unit (the clamped 64-bit row index of the general form cost 8 VALU instructions per row: the kernel is issue-bound)
-    const int64_t step = int64_t(AGG_BLOCK) * AGG_U;
-    uint32_t lane_row[AGG_U];
+    const int64_t step = int64_t(AGG_BLOCK) * TU;
+    uint32_t lane_row[TU];
 #pragma unroll
-    for (int u = 0; u < AGG_U; ++u) lane_row[u] = uint32_t(u) * AGG_BLOCK + threadIdx.x;
+    for (int u = 0; u < TU; ++u) lane_row[u] = uint32_t(u) * AGG_BLOCK + threadIdx.x;
     // rows of tile `base` that exist (wave-uniform, 0 … step)
     auto tile_rows = [&](int64_t base) {
         const int64_t r = n - base;
         return uint32_t(r < 0 ? 0 : (r > step ? step : r));
     };
+    auto vword = [&](const Tile &t, int j, int u) -> uint64_t { return SHARE ? t.kw[u] : t.vw[SHARE ? 0 : j][SHARE ? 0 : u]; };
     auto load_tile = [&](Tile &t, int64_t base) {
         if (NT && !VNULL && base + step <= n) {
             const uint64_t *__restrict__ kt = keyp + base;
@@ -197,32 +203,32 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 #pragma unroll
             for (int j = 0; j < NVT; ++j) vt[j] = valp[j] + base;
 #pragma unroll
-            for (int u = 0; u < AGG_U; ++u) {
+            for (int u = 0; u < TU; ++u) {
                 t.kw[u] = __builtin_nontemporal_load(&kt[lane_row[u]]);
                 // (a Boolean bitmap predicate: word (base + lane_row) >> 6 with base a multiple of the tile = of 64)
-                if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&pt[lane_row[u] >> fp.row_shift]);
-                if (PRED == 3) t.pw[u] = __builtin_nontemporal_load(&pt[lane_row[u]]);
-                if (PRED == 4) t.pw[u] = a.conj.need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull; // wave-uniform
-                if ((PRED == 5 || PRED == 6)) t.pw[u] = a.tree_need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull;
+                if (PRED == 2) t.pw[SHARE ? 0 : u] = __builtin_nontemporal_load(&pt[lane_row[u] >> fp.row_shift]);
+                if (PRED == 3) t.pw[SHARE ? 0 : u] = __builtin_nontemporal_load(&pt[lane_row[u]]);
+                if (PRED == 4) t.pw[SHARE ? 0 : u] = a.conj.need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull; // wave-uniform
+                if ((PRED == 5 || PRED == 6)) t.pw[SHARE ? 0 : u] = a.tree_need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull;
 #pragma unroll
-                for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&vt[j][lane_row[u]]);
+                for (int j = 0; j < NVT; ++j) if (!SHARE) t.vw[SHARE ? 0 : j][SHARE ? 0 : u] = __builtin_nontemporal_load(&vt[j][lane_row[u]]);
             }
             return;
         }
 #pragma unroll
-        for (int u = 0; u < AGG_U; ++u) {
+        for (int u = 0; u < TU; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             row = row < last ? row : last; // clamp: unconditional, in-bounds
             // (the compiler merges the load sequences of the two branches, so both must carry the same non-temporal hint — ordinary
             // loads here made it drop the hint from the pointer form as well)
             if (NT) {
                 t.kw[u] = __builtin_nontemporal_load(&keyp[row]);
-                if (PRED == 2) t.pw[u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
-                if (PRED == 3) t.pw[u] = __builtin_nontemporal_load(&predp[row]);
-                if (PRED == 4) t.pw[u] = a.conj.need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull; // wave-uniform
-                if ((PRED == 5 || PRED == 6)) t.pw[u] = a.tree_need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull;
+                if (PRED == 2) t.pw[SHARE ? 0 : u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
+                if (PRED == 3) t.pw[SHARE ? 0 : u] = __builtin_nontemporal_load(&predp[row]);
+                if (PRED == 4) t.pw[SHARE ? 0 : u] = a.conj.need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull; // wave-uniform
+                if ((PRED == 5 || PRED == 6)) t.pw[SHARE ? 0 : u] = a.tree_need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull;
 #pragma unroll
-                for (int j = 0; j < NVT; ++j) t.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
+                for (int j = 0; j < NVT; ++j) if (!SHARE) t.vw[SHARE ? 0 : j][SHARE ? 0 : u] = __builtin_nontemporal_load(&valp[j][row]);
                 if (VNULL) {
 #pragma unroll
                     for (int j = 0; j < NVT; ++j) t.vv[j][u] = vvalid[j] ? vvalid[j][row >> 6] : ~0ull;
@@ -230,25 +236,25 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 }
             } else {
                 t.kw[u] = keyp[row];
-                if (PRED == 2) t.pw[u] = predp[row >> fp.row_shift];
-                if (PRED == 3) t.pw[u] = predp[row];
-                if (PRED == 4) t.pw[u] = a.conj.need_pw ? predp[row] : 0ull; // wave-uniform
+                if (PRED == 2) t.pw[SHARE ? 0 : u] = predp[row >> fp.row_shift];
+                if (PRED == 3) t.pw[SHARE ? 0 : u] = predp[row];
+                if (PRED == 4) t.pw[SHARE ? 0 : u] = a.conj.need_pw ? predp[row] : 0ull; // wave-uniform
 #pragma unroll
-                for (int j = 0; j < NVT; ++j) t.vw[j][u] = valp[j][row];
+                for (int j = 0; j < NVT; ++j) if (!SHARE) t.vw[SHARE ? 0 : j][SHARE ? 0 : u] = valp[j][row];
             }
         }
     };
     // Rows of a thread whose keys differ inside one register tile (random keys): the run cache would flush once per row, each
     // flush a dependent LDS round trip (slot → read min/max → compare → atomics); the kernel was bound by those waits, not by
     // LDS-atomic throughput (tools/micro_bench.hip: the same update stream issued back to back runs 3x faster).  Such a tile
-    // goes to the table directly, all its rows at once: AGG_U slots, one batch of min/max reads, one wait, then the atomics.
+    // goes to the table directly, all its rows at once: TU slots, one batch of min/max reads, one wait, then the atomics.
     // (two value columns: the rows of a tile go in two halves — eight more min/max words in flight would not fit the registers)
     constexpr int BG = NVT == 1 ? AGG_U : (MM ? NQE_AGG_BG2 : 2);
-    auto direct_rows = [&](const Tile &t, int64_t base, const bool (&pass)[AGG_U], const uint64_t (&key)[AGG_U]) {
+    auto direct_rows = [&](const Tile &t, int64_t base, const bool (&pass)[TU], const uint64_t (&key)[TU]) {
         bool cold = false;
-        int slot[AGG_U];
+        int slot[TU];
 #pragma unroll
-        for (int g0 = 0; g0 < AGG_U; g0 += BG) {
+        for (int g0 = 0; g0 < TU; g0 += BG) {
             uint64_t k0[BG];
             if (!a.direct) {
                 // first probe of every row, issued together.  (Advancing all four probe sequences in lockstep, one slot of every
@@ -293,7 +299,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                     const int u = g0 + i;
                     if (slot[u] < 0) continue;
                     const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
-                    const double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+                    const double x = VF64 ? u2d(vword(t, j, u)) : word_as_f64(vword(t, j, u), vdt[j]);
                     const bool vb = VNULL ? bool((t.vv[VNULL ? j : 0][u] >> (row & 63)) & 1ull) : true;
                     if (!vb) continue; // a NULL value contributes nothing; its row has created the group above
                     const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
@@ -309,7 +315,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         }
         if (cold) { // the table rejected a key (see flush_run): off the per-row path
 #pragma unroll
-            for (int u = 0; u < AGG_U; ++u) {
+            for (int u = 0; u < TU; ++u) {
                 if (!pass[u] || slot[u] >= 0) continue;
                 if (!*lds_full) {
                     *lds_full = 1;
@@ -320,7 +326,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) {
-                    const double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+                    const double x = VF64 ? u2d(vword(t, j, u)) : word_as_f64(vword(t, j, u), vdt[j]);
                     const bool vb = VNULL ? bool((t.vv[VNULL ? j : 0][u] >> (row & 63)) & 1ull) : true;
                     if (!vb) continue;
                     const bool isn = x != x;
@@ -339,14 +345,16 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // quarter of its lanes see mixed keys (random keys: 2.90 -> 2.57 ms).
     // the interpreted predicates.  PRED = 5: tests with an arithmetic step under any and/or nesting (ConjPred's general form:
     // test-major straight-line code + truth table); PRED = 6: the stack machine's program
-    auto eval_interpreted = [&](const Tile &t, bool (&res)[AGG_U]) {
+    auto eval_interpreted = [&](const Tile &t, bool (&res)[TU]) {
 #ifdef NQE_TREE_TRIVIAL // diagnostics: the instance's skeleton without the predicate's work
 #pragma unroll
-        for (int u = 0; u < AGG_U; ++u) res[u] = (t.kw[u] ^ t.vw[0][u]) != 12345;
+        for (int u = 0; u < TU; ++u) res[u] = (t.kw[u] ^ vword(t, 0, u)) != 12345;
         return;
 #endif
-        if (PRED == 5) conj_general_tile<AGG_U>(a.conj, t.kw, t.vw[0], t.pw, res);
-        else tree_pred_eval<AGG_U>(a.tree_prog, a.tree_n, t.kw, t.vw[0], t.pw, res);
+        if constexpr (!SHARE) {
+            if (PRED == 5) conj_general_tile<TU>(a.conj, t.kw, t.vw[0], t.pw, res);
+            else tree_pred_eval<TU>(a.tree_prog, a.tree_n, t.kw, t.vw[0], t.pw, res);
+        }
     };
     auto accumulate_row = [&](const Tile &t, int u, int64_t row, uint64_t key) {
         if (!run_live || key != run_key) {
@@ -356,7 +364,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         }
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
-            double x = VF64 ? u2d(t.vw[j][u]) : word_as_f64(t.vw[j][u], vdt[j]);
+            double x = VF64 ? u2d(vword(t, j, u)) : word_as_f64(vword(t, j, u), vdt[j]);
             if (VNULL) {
                 // a NULL value contributes nothing (count of non-null, Q10) but its row still creates the group:
                 // branch-free — count += bit, sum += 0, and a NaN operand that min/max ignore and the flag skips
@@ -383,22 +391,22 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     auto process_run = [&](const Tile &t, int64_t base) {
         // interpreted keys are computed for the whole tile up front (operator-major); the built-in shapes stay inside the row loop,
         // where the compiler sinks them below the predicate (hoisting them cost the headline 1.5 %)
-        uint64_t pvals[PRED == 3 ? AGG_U : 1];
-        if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
-        bool tpass[(PRED == 5 || PRED == 6) ? AGG_U : 1];
-        if ((PRED == 5 || PRED == 6)) eval_interpreted(t, reinterpret_cast<bool (&)[AGG_U]>(tpass));
-        uint64_t keys[KEY == 3 ? AGG_U : 1];
-        if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, reinterpret_cast<uint64_t (&)[AGG_U]>(keys), key_mask, key_aux, key_signed);
+        uint64_t pvals[PRED == 3 ? TU : 1];
+        if constexpr (PRED == 3 && !SHARE) inline_keys<3, TU, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[TU]>(pvals), 0, no_aux(), false);
+        bool tpass[(PRED == 5 || PRED == 6) ? TU : 1];
+        if ((PRED == 5 || PRED == 6)) eval_interpreted(t, reinterpret_cast<bool (&)[TU]>(tpass));
+        uint64_t keys[KEY == 3 ? TU : 1];
+        if (KEY == 3) inline_keys<3, TU>(a.key, t.kw, reinterpret_cast<uint64_t (&)[TU]>(keys), key_mask, key_aux, key_signed);
         const uint32_t nrows = tile_rows(base);
 #pragma unroll
-        for (int u = 0; u < AGG_U; ++u) {
+        for (int u = 0; u < TU; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             bool pass = lane_row[u] < nrows;
             if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
             else if ((PRED == 5 || PRED == 6)) pass = pass && tpass[(PRED == 5 || PRED == 6) ? u : 0];
-            else if (PRED == 4) pass = pass && conj_pass<3, false>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
+            else if (PRED == 4) pass = pass && conj_pass<3, false>(a.conj, t.kw[u], vword(t, 0, u), t.pw[SHARE ? 0 : u]);
             else if (PRED != 0) {
-                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
+                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[SHARE ? 0 : u], row));
             }
             if (VNULL) pass = pass && ((t.kpv[u] >> (row & 63)) & 1ull);
             const uint64_t key = KEY == 3 ? keys[KEY == 3 ? u : 0] : inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
@@ -406,38 +414,38 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             accumulate_row(t, u, row, key);
         }
     };
-    auto tile_keys = [&](const Tile &t, uint64_t (&key)[AGG_U]) {
-        if (KEY == 3) inline_keys<3, AGG_U>(a.key, t.kw, key, key_mask, key_aux, key_signed);
+    auto tile_keys = [&](const Tile &t, uint64_t (&key)[TU]) {
+        if (KEY == 3) inline_keys<3, TU>(a.key, t.kw, key, key_mask, key_aux, key_signed);
         else {
 #pragma unroll
-            for (int u = 0; u < AGG_U; ++u) key[u] = inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
+            for (int u = 0; u < TU; ++u) key[u] = inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
         }
     };
     auto process_batch = [&](const Tile &t, int64_t base) {
-        uint64_t pvals[PRED == 3 ? AGG_U : 1];
-        if (PRED == 3) inline_keys<3, AGG_U, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[AGG_U]>(pvals), 0, no_aux(), false);
-        bool tpass[(PRED == 5 || PRED == 6) ? AGG_U : 1];
-        if ((PRED == 5 || PRED == 6)) eval_interpreted(t, reinterpret_cast<bool (&)[AGG_U]>(tpass));
-        bool pass[AGG_U];
-        uint64_t key[AGG_U];
+        uint64_t pvals[PRED == 3 ? TU : 1];
+        if constexpr (PRED == 3 && !SHARE) inline_keys<3, TU, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[TU]>(pvals), 0, no_aux(), false);
+        bool tpass[(PRED == 5 || PRED == 6) ? TU : 1];
+        if ((PRED == 5 || PRED == 6)) eval_interpreted(t, reinterpret_cast<bool (&)[TU]>(tpass));
+        bool pass[TU];
+        uint64_t key[TU];
         tile_keys(t, key);
         const uint32_t nrows = tile_rows(base);
 #pragma unroll
-        for (int u = 0; u < AGG_U; ++u) {
+        for (int u = 0; u < TU; ++u) {
             int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
             pass[u] = lane_row[u] < nrows;
             if (PRED == 3) pass[u] = pass[u] && pvals[PRED == 3 ? u : 0] != 0;
             else if ((PRED == 5 || PRED == 6)) pass[u] = pass[u] && tpass[(PRED == 5 || PRED == 6) ? u : 0];
-            else if (PRED == 4) pass[u] = pass[u] && conj_pass<3, false>(a.conj, t.kw[u], t.vw[0][u], t.pw[u]);
-            else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[u], row));
+            else if (PRED == 4) pass[u] = pass[u] && conj_pass<3, false>(a.conj, t.kw[u], vword(t, 0, u), t.pw[SHARE ? 0 : u]);
+            else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[SHARE ? 0 : u], row));
             if (VNULL) pass[u] = pass[u] && ((t.kpv[u] >> (row & 63)) & 1ull);
         }
         bool mixed = false; // keys of rows that fail the predicate take part: a false "mixed" costs nothing but the batch path
 #pragma unroll
-        for (int u = 1; u < AGG_U; ++u) mixed = mixed || key[u] != key[0];
+        for (int u = 1; u < TU; ++u) mixed = mixed || key[u] != key[0];
         if (SUB) {
 #pragma unroll
-            for (int u = 0; u < AGG_U; ++u) pass[u] = pass[u] && !foreign(key[u]);
+            for (int u = 0; u < TU; ++u) pass[u] = pass[u] && !foreign(key[u]);
         }
         if (mixed) {
             if (run_live) {
@@ -447,7 +455,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             direct_rows(t, base, pass, key);
         } else {
 #pragma unroll
-            for (int u = 0; u < AGG_U; ++u)
+            for (int u = 0; u < TU; ++u)
                 if (pass[u]) accumulate_row(t, u, base + int64_t(u) * AGG_BLOCK + threadIdx.x, key[u]);
         }
     };
@@ -509,11 +517,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         while (base < n) {
             bool batch = false; // wave-uniform
             if (CAN_BATCH) {
-                uint64_t key[AGG_U];
+                uint64_t key[TU];
                 tile_keys(A, key);
                 bool mixed = false;
 #pragma unroll
-                for (int u = 1; u < AGG_U; ++u) mixed = mixed || key[u] != key[0];
+                for (int u = 1; u < TU; ++u) mixed = mixed || key[u] != key[0];
                 batch = __popcll(__ballot(mixed)) >= 16;
             }
             if (CAN_BATCH && batch) stream(process_batch, A, 32);
@@ -575,7 +583,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     }
 }
 
-template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64, bool sub, bool nomm) {
+template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64, bool sub, bool nomm, bool share) {
+    if constexpr (!VNULL && PRED <= 1 && KEY != 3) {
+        if (share && nv == 1 && !vf64 && !sub) return agg_grouped_fast_kernel<PRED, KEY, 1, false, false, false, true, true>;
+    }
     if constexpr (!VNULL && PRED <= 1 && KEY != 3) {
         if (nomm && nv == 2 && !sub)
             return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, false, false, false> : agg_grouped_fast_kernel<PRED, KEY, 2, false, false, false, false>;
@@ -596,12 +607,12 @@ template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf
         return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, VNULL> : agg_grouped_fast_kernel<PRED, KEY, 2, false, VNULL>;
     }
 }
-template <int PRED, bool VNULL> FastKernel pick_fast_key(int key, int nv, bool vf64, bool sub, bool nomm) {
+template <int PRED, bool VNULL> FastKernel pick_fast_key(int key, int nv, bool vf64, bool sub, bool nomm, bool share) {
     switch (key) {
-    case 0: return pick_fast_nv<PRED, 0, VNULL>(nv, vf64, sub, nomm);
-    case 1: return pick_fast_nv<PRED, 1, VNULL>(nv, vf64, sub, nomm);
-    case 2: return pick_fast_nv<PRED, 2, VNULL>(nv, vf64, sub, nomm);
-    default: return pick_fast_nv<PRED, 3, VNULL>(nv, vf64, sub, nomm);
+    case 0: return pick_fast_nv<PRED, 0, VNULL>(nv, vf64, sub, nomm, share);
+    case 1: return pick_fast_nv<PRED, 1, VNULL>(nv, vf64, sub, nomm, share);
+    case 2: return pick_fast_nv<PRED, 2, VNULL>(nv, vf64, sub, nomm, share);
+    default: return pick_fast_nv<PRED, 3, VNULL>(nv, vf64, sub, nomm, share);
     }
 }
 
