@@ -7,6 +7,9 @@
 #ifndef NQE_AGG_BATCH
 #define NQE_AGG_BATCH 1 // 0: the round-1 row loop (A/B runs)
 #endif
+#ifndef NQE_WIDE_TILES
+#define NQE_WIDE_TILES 0 // that many (6, 8) rows per lane per tile for the TWO-column one-value instances (A/B): 8 spills 60-76 VGPRs, 6 fits (2 spilled) and is 4 % slower (headline kernel 2.45 -> 2.55 ms)
+#endif
 #ifndef NQE_AGG_BATCH2
 #define NQE_AGG_BATCH2 0 // the batch loop for two value columns, rows one by one (NQE_AGG_BG2): built and measured at the register limit — 8-22 VGPRs spill in every such instance, so it stays off
 #endif
@@ -54,7 +57,7 @@ namespace {
 // units 30-40 % busy (PMC), i.e. latency-bound.
 template <int PRED, int KEY, int NVT, bool VF64, bool VNULL, bool SUB = false, bool MM = true, bool SHARE = false>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
-    constexpr int TU = SHARE ? 2 * AGG_U : AGG_U; // rows per lane per tile
+    constexpr int TU = SHARE ? 2 * AGG_U : ((NQE_WIDE_TILES && NVT == 1 && !VNULL && !SUB && PRED <= 1 && KEY != 3) ? NQE_WIDE_TILES : AGG_U); // rows per lane per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
     const uint32_t slots = cap + 1;
@@ -249,7 +252,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // LDS-atomic throughput (tools/micro_bench.hip: the same update stream issued back to back runs 3x faster).  Such a tile
     // goes to the table directly, all its rows at once: TU slots, one batch of min/max reads, one wait, then the atomics.
     // (two value columns: the rows of a tile go in two halves — eight more min/max words in flight would not fit the registers)
-    constexpr int BG = NVT == 1 ? AGG_U : (MM ? NQE_AGG_BG2 : 2);
+    constexpr int BG = NVT == 1 ? (TU % AGG_U == 0 ? AGG_U : TU / 2) : (MM ? NQE_AGG_BG2 : 2);
     auto direct_rows = [&](const Tile &t, int64_t base, const bool (&pass)[TU], const uint64_t (&key)[TU]) {
         bool cold = false;
         int slot[TU];
