@@ -8,7 +8,8 @@ sharded operator on its row range and checks the result against the single-GPU o
 Covers: the one-collective aggregate exchange (few groups), the exact-size path (> NQE_EXCHANGE_ROWS groups on a rank), the
 un-grouped aggregate, disjoint key sets per rank, the join with the build side replicated and the probe side range-split
 (gathered, probe order kept, shared key columns), filter+projection gathered with EQUAL shard counts (no count-dependent
-shortcut may skip a synchronisation) and with ragged ones."""
+shortcut may skip a synchronisation) and with ragged ones, a Utf8-key aggregate (strings exchanged and merged) and the gather of
+nullable / Boolean / Utf8 columns."""
 import os
 import sys
 
@@ -104,15 +105,34 @@ for name, pr in (("equal counts", binop(col(0), Operator.GtEq, lit_i64(0)).flatt
         got = host_cols(comm.sharded_selection_projection(m2, pr, proj, gather=True))
         assert all(a.shape == b.shape and (a == b).all() for a, b in zip(exp, got)), f"gathered selection+projection differs ({name})"
 
-# ---- Utf8 group keys are rejected, not merged wrongly
-from naive_query_engine_amd import DType, ErrorCode
+# ---- Utf8 group keys travel as strings and are merged by string; nullable / Boolean / Utf8 columns are gathered
+from naive_query_engine_amd import DType
 
-ut = ctx.table_from_host([Column.from_list(["a", "b", "a", "c"], DType.UTF8), Column.from_numpy(np.arange(4, dtype=np.float64))])
-try:
-    comm.sharded_aggregate(ut, [(AggregateFunc.Sum, 1)], group_nodes=col(0).flatten([F("s"), F("x")]))
-    raise SystemExit("sharded aggregate accepted Utf8 keys")
-except ErrorCode as e:
-    assert "Utf8" in str(e), e
+NS = 30_011
+names = ["alice", "bob", "", "véé", "grandmaster", "x" * 40]
+sk = [names[int(i)] + (str(int(j)) if j % 4 == 0 else "") for i, j in zip(rng.integers(0, len(names), NS), rng.integers(0, 200, NS))]
+sv = rng.random(NS)
+svm = rng.random(NS) > 0.1
+sb = rng.random(NS) < 0.5
+ucols = [Column.from_list(sk, DType.UTF8), Column.from_numpy(sv, svm), Column.from_numpy(sb)]
+fu = [F("s"), F("x"), F("b")]
+uaggs = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Max, 1), (AggregateFunc.Count, 2)]
+uwhole = ctx.table_from_host(ucols)
+lo3, hi3 = parallel.shard_range(NS, rank, world)
+umine = ctx.table_from_host([Column.from_list(c.to_list()[lo3:hi3], c.dtype) for c in ucols])
+exp, expk = ctx.aggregate(uwhole, uaggs, group_nodes=col(0).flatten(fu), with_keys=True)
+got, gotk = comm.sharded_aggregate(umine, uaggs, group_nodes=col(0).flatten(fu))
+def by_key(keys, res):
+    ks = keys.to_host()[0].to_list()
+    cs = [c.to_numpy() for c in res.to_host()]
+    return {k: tuple(float(c[i]) for c in cs) for i, k in enumerate(ks)}
+em, gm = by_key(expk, exp), by_key(gotk, got)
+assert em.keys() == gm.keys(), "Utf8-key aggregate: key sets differ"
+for k in em:
+    assert em[k][0] == gm[k][0] and em[k][3] == gm[k][3] and np.allclose(em[k], gm[k], rtol=1e-9, atol=0), f"Utf8-key aggregate differs at {k!r}"
+allg = comm.all_gather_table(umine).to_host()
+for c_exp, c_got in zip(ucols, allg):
+    assert c_exp.to_list() == c_got.to_list(), "gathered nullable / Boolean / Utf8 columns differ"
 
 dist.barrier()
 print(f"exchange checks passed on rank {rank} of {world} (RCCL {capi.Comm.rccl_version()})", flush=True)
