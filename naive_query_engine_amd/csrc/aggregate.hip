@@ -1073,6 +1073,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         cap = std::min(sized_cap, RANK_MAX_CAP);
     }
     bool partition_mode = false, level2 = false, dense_ok = true, slab_failed = false, key32_failed = false;
+    static const bool no_three = getenv("NQE_NO_THREE_COLUMN_PASS") != nullptr; // diagnostics (A/B runs)
+    bool three_on = !no_three;
     // Between one LDS table's worth of groups and the partitioned path: the fast kernel with two key subsets (see
     // AggArgs::subsets_log2) — every row is read by two workgroups, each of which keeps its half of the keys.  Rows of the other
     // half cost a wave as many issue slots as its own (lanes are masked, instructions are not skipped), so the kernel time doubles:
@@ -1120,6 +1122,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         if (!no_hints && it != ctx->agg_hints.end()) {
             const uint8_t hv = it->second & 0x3f;
             if (it->second & 0x40) key32_failed = true; // keys beyond int32: 16-byte tuples
+            if (it->second & 0x80) three_on = false;    // more groups than the three-column instance holds
             if (hv == 1 || hv == 16 || hv == 17) { // 1: PARTS partitions, 16: the smaller first count was enough
                 partition_mode = true;             // 17: the exact form (a slab overflowed or did not fit)
                 if (hv == 1) slab_parts_log2 = PARTS_LOG2;
@@ -1150,12 +1153,25 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         // (3.1-3.4 TB/s); two passes of the one-column variant (5.3 TB/s each over key + one value column) are faster
         const int nv_step = (any_val_nullable || a.key_src.valid || (a.pred_mode != 0 && a.pred_src.valid)) ? 1 : NV;
         bool slab_oom = false; // the slab allocation failed: redo the attempt in the exact form
-        for (int v0 = 0; v0 < std::max(V, 1); v0 += nv_step) {
-            a.nv = std::min(nv_step, V - v0);
+        // three value columns, none asking for min / max, over a key and predicate the streaming kernel computes itself (C1's
+        // `count(id), sum(age), avg(score) … group by id % 3`): ONE pass of the three-column instance (2048-slot workgroup table without min / max arrays)
+        // instead of two passes — 32 B/row read once instead of 16 + 24.  A pass that turns out not to fit (another kernel
+        // variant, more groups than that table holds) clears `three_on` and the attempt is redone in passes of one and two.
+        bool three = three_on && V == 3 && nv_step == NV && grouped && !partition_mode && subsets_log2 == 0 && (a.pred_mode == 0 || a.pred_mode == 1);
+        for (int j = 0; three && j < V; ++j) three = !plan.need_minmax[size_t(j)];
+        bool three_redo = false;
+        // an odd number of value columns in passes of two leaves one pass with a single column: let it be the FIRST column when that
+        // one is the key column itself — its pass then reads 8 B/row through the single-load instance instead of 16
+        const bool first_alone = !three && nv_step == 2 && V >= 3 && (V % 2) == 1 && grouped && key_col >= 0 && !utf8_key && plan.val_cols[0] == key_col &&
+                                 is_word_type(in->cols[size_t(key_col)].dtype);
+        int pass_nv = 0;
+        for (int v0 = 0; v0 < std::max(V, 1); v0 += pass_nv) {
+            pass_nv = three ? NVMAX : (first_alone && v0 == 0) ? 1 : nv_step;
+            a.nv = std::min(pass_nv, V - v0);
             if (a.nv < 0) a.nv = 0;
             a.v0 = v0;
             bool valid_words_ok = true; // validity bitmaps readable as whole 64-bit words (owned buffers are padded)
-            for (int j = 0; j < NV; ++j) {
+            for (int j = 0; j < NVMAX; ++j) {
                 std::memset(&a.val[j], 0, sizeof(ColSrc));
                 a.val_shares_key[j] = a.need_sum[j] = a.need_minmax[j] = 0;
                 if (j < a.nv) {
@@ -1171,12 +1187,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             }
             if (in->rows == 0) continue;
             if (grouped) {
-                a.lds_cap = 2048; // 1 value column: 72 KB (2 WG/CU); 2: 128 KB (1 WG/CU)
+                a.lds_cap = 2048; // 1 value column: 72 KB (2 WG/CU); 2: 128 KB (1 WG/CU); 3 (no min / max arrays): 136 KB
                 int lg = 0;
                 while ((1 << lg) < a.lds_cap) ++lg;
                 a.lds_shift = 64 - lg;
                 size_t slots = size_t(a.lds_cap) + 1;
-                size_t shmem = slots * 8 + size_t(std::max(a.nv, 1)) * slots * (8 + 8 + 8 + 4);
+                size_t shmem = slots * 8 + size_t(std::max(a.nv, 1)) * slots * (a.nv == NVMAX ? 8 + 4 : 8 + 8 + 8 + 4);
                 shmem = (shmem + 15) / 16 * 16;
                 int blocks_per_cu = shmem <= 80 * 1024 ? 2 : 1;
                 int grid = int(std::min<int64_t>(int64_t(ctx->num_cus) * blocks_per_cu,
@@ -1329,6 +1345,15 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 }
                 bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || pk >= 4 || bitmap_pred || range_pred || chain_pred);
                 if (pk >= 4 && (!fast || vnull)) fail(NQE_ERR_NOT_SUPPORTED, "internal: a tree predicate reached a kernel that cannot evaluate it");
+                if (a.nv == NVMAX) {
+                    // the three-column instances: no predicate or a range test on the key column, the built-in key shapes, no validity
+                    const bool key_range = pk == 1 && range_pred && a.pred_shares_key && !bitmap_pred && !fpred.fmask;
+                    if (!(fast && (pk == 0 || key_range) && fast_key != 3 && !vnull && !partition_mode)) {
+                        three_on = false;
+                        three_redo = true;
+                        break;
+                    }
+                }
                 if (fast) {
                     // variant 1 tests the key word with the integer range test alone; Float64 predicates and bitmaps use the
                     // "other column" variant, whose extraction step applies the order mapping
@@ -1483,7 +1508,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             }
                         }
                         ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
-                        bool nomm = a.nv == 2;
+                        bool nomm = a.nv >= 2;
                         for (int j = 0; j < a.nv; ++j) nomm = nomm && !a.need_minmax[j];
                         // the value column is the key column itself (and the predicate, if any, tests it too): the single-load instance
                         const bool share = a.nv == 1 && a.val_shares_key[0] && a.val[0].values == a.key_src.values && (fp == 0 || fp == 1) && fast_key != 3 && !vnull && !vf64 &&
@@ -1533,7 +1558,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                        (const Partial *)partials->ptr, grid, a.nv, v0, tb.g);
             }
         }
-        if (slab_oom) continue;
+        if (slab_oom || three_redo) continue;
         Collected pre;
         AggResult ranked;
         if (grouped && !tb.g.dense_count && tb.g.cap <= RANK_MAX_CAP) {
@@ -1579,6 +1604,16 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2) {
             level2 = true; // partitions hold more distinct keys than a workgroup table: one more partitioning level
             cap = std::max<uint32_t>(cap, 1u << 24);
+            flags_reset(ctx);
+            continue;
+        }
+        if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode && three) {
+            // more groups than the three-column instance's table holds: passes of one and two columns (2048 / 4096 slots) may still do
+            three_on = false;
+            if (hint_key) {
+                if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
+                ctx->agg_hints[hint_key] = 0x80;
+            }
             flags_reset(ctx);
             continue;
         }

@@ -14,6 +14,7 @@ namespace agg {
 constexpr uint64_t EMPTY_KEY = 0x8000000000000000ull; // i64::MIN; that key uses the extra slot [cap]
 constexpr uint64_t GOLD = 0x9E3779B97F4A7C15ull;
 constexpr int NV = 2;      // value columns per kernel pass
+constexpr int NVMAX = 3;   // … of the one kind of instance that takes three (fast kernel, no min/max: C1's count / sum / avg over three columns)
 #ifndef NQE_AGG_U
 #define NQE_AGG_U 4
 #endif
@@ -71,10 +72,10 @@ struct AggArgs {
     ColSrc key_src;
     SimpleExpr pred;
     SimpleExpr key;
-    ColSrc val[NV];
-    int32_t val_shares_key[NV];
-    int32_t need_sum[NV];
-    int32_t need_minmax[NV];
+    ColSrc val[NVMAX];
+    int32_t val_shares_key[NVMAX];
+    int32_t need_sum[NVMAX];
+    int32_t need_minmax[NVMAX];
     int32_t v0; // first value slot of this pass in the global table
     int32_t lds_cap;
     int32_t lds_shift;

@@ -65,9 +65,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     double *lsum = reinterpret_cast<double *>(lkeys + slots);            // [NVT][slots]
     // min / max live in LDS as plain doubles (ds_min_f64 / ds_max_f64; a NaN never reaches them: every update is guarded by an
     // ordered compare, which a NaN fails) and take the order-preserving integer form only for the global table at the merge
+    // (MM = false — no aggregate of the pass asks for min / max: the two arrays do not exist, 20 instead of 36 bytes per slot and
+    // value column, and the host sizes the table accordingly: 2048 slots for three columns)
     double *lmn = lsum + NVT * slots;                                    // [NVT][slots]
     double *lmx = lmn + NVT * slots;                                     // [NVT][slots]
-    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + NVT * slots);    // [NVT][slots]
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(MM ? lmx + NVT * slots : lmn); // [NVT][slots]
     const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
     __shared__ int lds_full_flag;
     volatile int *lds_full = &lds_full_flag;
@@ -77,8 +79,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
             lsum[j * slots + s] = 0.0;
-            lmn[j * slots + s] = DBL_MAX;
-            lmx[j * slots + s] = -DBL_MAX;
+            if (MM) {
+                lmn[j * slots + s] = DBL_MAX;
+                lmx[j * slots + s] = -DBL_MAX;
+            }
             lcnt[j * slots + s] = 0;
         }
     }
@@ -197,7 +201,13 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         const int64_t r = n - base;
         return uint32_t(r < 0 ? 0 : (r > step ? step : r));
     };
-    auto vword = [&](const Tile &t, int j, int u) -> uint64_t { return SHARE ? t.kw[u] : t.vw[SHARE ? 0 : j][SHARE ? 0 : u]; };
+    // (three value columns: when the first one is the key column itself — `count(id) … group by id % 3` — its word is the key word)
+    const bool first_is_key = NVT == 3 && a.val_shares_key[0] && a.val[0].values == a.key_src.values; // wave-uniform
+    auto vword = [&](const Tile &t, int j, int u) -> uint64_t {
+        if (SHARE) return t.kw[u];
+        if (NVT == 3 && j == 0 && first_is_key) return t.kw[u];
+        return t.vw[SHARE ? 0 : j][SHARE ? 0 : u];
+    };
     auto load_tile = [&](Tile &t, int64_t base) {
         if (NT && !VNULL && base + step <= n) {
             const uint64_t *__restrict__ kt = keyp + base;
@@ -214,7 +224,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 if (PRED == 4) t.pw[SHARE ? 0 : u] = a.conj.need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull; // wave-uniform
                 if ((PRED == 5 || PRED == 6)) t.pw[SHARE ? 0 : u] = a.tree_need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull;
 #pragma unroll
-                for (int j = 0; j < NVT; ++j) if (!SHARE) t.vw[SHARE ? 0 : j][SHARE ? 0 : u] = __builtin_nontemporal_load(&vt[j][lane_row[u]]);
+                for (int j = 0; j < NVT; ++j)
+                    if (!SHARE && !(NVT == 3 && j == 0 && first_is_key)) t.vw[SHARE ? 0 : j][SHARE ? 0 : u] = __builtin_nontemporal_load(&vt[j][lane_row[u]]);
             }
             return;
         }
@@ -252,7 +263,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // LDS-atomic throughput (tools/micro_bench.hip: the same update stream issued back to back runs 3x faster).  Such a tile
     // goes to the table directly, all its rows at once: TU slots, one batch of min/max reads, one wait, then the atomics.
     // (two value columns: the rows of a tile go in two halves — eight more min/max words in flight would not fit the registers)
-    constexpr int BG = NVT == 1 ? (TU % AGG_U == 0 ? AGG_U : TU / 2) : (MM ? NQE_AGG_BG2 : 2);
+    constexpr int BG = NVT == 1 ? (TU % AGG_U == 0 ? AGG_U : TU / 2) : (MM ? NQE_AGG_BG2 : (NVT == 2 ? 2 : 1));
     auto direct_rows = [&](const Tile &t, int64_t base, const bool (&pass)[TU], const uint64_t (&key)[TU]) {
         bool cold = false;
         int slot[TU];
@@ -468,7 +479,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // up to 2 x `budget` tiles.  In: A holds tile `base` (< n).  Out: base >= n (done or abandoned), or A holds tile `base`.
     // (PRED = 6: ONE tile in flight — the stack machine's registers take the place of the prefetched tile's; the workgroup's 16
     // waves hide the loads' latency among themselves)
-    constexpr bool PIPE = PRED != 6 || NQE_TREE_PIPE;
+    // (three value columns: one tile is 8 KB per wave = 128 KB per CU in flight already, and a second one does not fit the registers)
+    constexpr bool PIPE = (PRED != 6 || NQE_TREE_PIPE) && NVT != 3;
     auto stream = [&](auto &&process, Tile &A, int budget) {
         if constexpr (!PIPE) {
             for (int64_t it = 0; it < 2 * int64_t(budget); ++it) {
@@ -542,15 +554,17 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         for (uint32_t w = threadIdx.x; w < nkeys * NVT; w += blockDim.x) {
             const uint32_t kslot = (w % nkeys) << rep_log2, o0 = (w / nkeys) * slots + kslot;
             uint32_t c = lcnt[o0];
-            double sm = lsum[o0], mn = lmn[o0], mx = lmx[o0];
+            double sm = lsum[o0], mn = MM ? lmn[o0] : 0.0, mx = MM ? lmx[o0] : 0.0;
             bool used = VNULL && lkeys[kslot] != EMPTY_KEY;
             uint64_t kw = VNULL ? lkeys[kslot] : 0;
             for (uint32_t r = 1; r < R; ++r) {
                 const uint32_t cr = lcnt[o0 + r];
                 c = ((c & ~NAN_BIT) + (cr & ~NAN_BIT)) | ((c | cr) & NAN_BIT);
                 sm += lsum[o0 + r];
-                mn = fmin(mn, lmn[o0 + r]);
-                mx = fmax(mx, lmx[o0 + r]);
+                if (MM) {
+                    mn = fmin(mn, lmn[o0 + r]);
+                    mx = fmax(mx, lmx[o0 + r]);
+                }
                 if (VNULL && lkeys[kslot + r] != EMPTY_KEY) {
                     used = true;
                     kw = lkeys[kslot + r];
@@ -558,8 +572,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             }
             lcnt[o0] = c;
             lsum[o0] = sm;
-            lmn[o0] = mn;
-            lmx[o0] = mx;
+            if (MM) {
+                lmn[o0] = mn;
+                lmx[o0] = mx;
+            }
             if (VNULL && used && w < nkeys) lkeys[kslot] = kw;
         }
         __syncthreads();
@@ -581,7 +597,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         for (int j = 0; j < NVT; ++j) {
             uint32_t o = uint32_t(j) * slots + s;
             uint32_t c = lcnt[o];
-            global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, f64_to_ord(lmn[o]), f64_to_ord(lmx[o]), true, (c & NAN_BIT) != 0);
+            global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, MM ? f64_to_ord(lmn[o]) : 0ull, MM ? f64_to_ord(lmx[o]) : 0ull, MM, (c & NAN_BIT) != 0);
         }
     }
 }
@@ -591,9 +607,12 @@ template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf
         if (share && nv == 1 && !vf64 && !sub) return agg_grouped_fast_kernel<PRED, KEY, 1, false, false, false, true, true>;
     }
     if constexpr (!VNULL && PRED <= 1 && KEY != 3) {
+        if (nomm && nv == 3 && !sub)
+            return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 3, true, false, false, false> : agg_grouped_fast_kernel<PRED, KEY, 3, false, false, false, false>;
         if (nomm && nv == 2 && !sub)
             return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, false, false, false> : agg_grouped_fast_kernel<PRED, KEY, 2, false, false, false, false>;
     }
+    if (nv == 3) return nullptr; // (three columns: the instances above only)
     if (sub) {
         // (PRED 4: a query that outgrows one table continues with a materialised predicate; its slice is built without validity only)
         if constexpr (VNULL || PRED >= 4) return nullptr;

@@ -1531,3 +1531,47 @@ def test_aggregate_partitioned_path_twelve_byte_tuples_and_their_fallback(ctx, k
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{keys} rep {rep}")
         kk = gk.to_host()[0].to_numpy()
         assert (kk == np.unique(kc.to_numpy())).all()
+
+
+@pytest.mark.parametrize("groups", [3, 700, 1500, 3000, 50000])
+def test_aggregate_three_value_columns_in_one_pass(ctx, groups):
+    """C1's `count(id), sum(age), avg(score) … group by key` — three value columns, no min/max: ONE launch of the three-column
+    instance of agg_grouped_fast_kernel (2048-slot workgroup table) while the key and the predicate are ones the kernel computes
+    itself and the groups fit; every other shape (a predicate on another column, a key chain, min/max asked for, a nullable column,
+    more groups than the table holds — 3000: passes of one and two columns, 50000: the partitioned path) is redone in passes of
+    one and two.  n >= 2^18 so that an overfull workgroup table asks for the other path instead of spilling to the global table.
+    Second execution: from the plan hint."""
+    rng = np.random.default_rng(4242 + groups)
+    n = 300_011
+    ids = np.arange(n, dtype=np.int64) - n // 7
+    k = rng.integers(-(groups // 2), groups - groups // 2, n).astype(np.int64)
+    age = rng.integers(-60, 60, n).astype(np.int64)
+    score = rng.random(n) * 100.0
+    score[::101] = np.nan
+    cols = [Column.from_numpy(ids), Column.from_numpy(k), Column.from_numpy(age), Column.from_numpy(score), Column.from_numpy(score, rng.random(n) > 0.2)]
+    f5 = fields("id", "k", "age", "score", "score_n")
+    t = ctx.table_from_host(cols)
+    C1 = lambda kc: [(AggregateFunc.Count, kc), (AggregateFunc.Sum, 2), (AggregateFunc.Avg, 3)]
+    keys = [(True, 0, binop(col(0), Operator.Modulos, lit_i64(max(groups // 2, 2)))), (True, 1, col(1)),
+            (True, 1, binop(col(1), Operator.Modulos, lit_i64(1 << 20))), (False, 1, binop(binop(col(1), Operator.Plus, lit_i64(5)), Operator.Multiply, lit_i64(3)))]
+    for key_ok, kc, key in keys:
+        kn = key.flatten(f5)
+        shapes = [(True, C1(kc), None), (True, C1(kc), binop(col(kc), Operator.GtEq, lit_i64(-5))), (False, C1(kc), binop(col(2), Operator.Lt, lit_i64(10))),
+                  (True, [(AggregateFunc.Avg, 3), (AggregateFunc.Sum, 3), (AggregateFunc.Count, 2), (AggregateFunc.Sum, 0)], None),
+                  (False, [(AggregateFunc.Count, kc), (AggregateFunc.Sum, 2), (AggregateFunc.Max, 3)], None),
+                  (False, [(AggregateFunc.Count, kc), (AggregateFunc.Sum, 2), (AggregateFunc.Avg, 4)], None)]
+        for ok, aggs, pred in shapes:
+            pn = pred.flatten(f5) if pred is not None else None
+            exp = orc.aggregate([cols], aggs, group_nodes=kn, pred_nodes=pn)[0]
+            for rep in range(2):
+                ctx.timing_enable(True)
+                ctx.timing_reset()
+                got = ctx.aggregate(t, aggs, group_nodes=kn, pred_nodes=pn).to_host()
+                ctx.timing_enable(False)
+                rep_ = ctx.timing_report()
+                exact = [i for i, (fn, _) in enumerate(aggs) if fn == AggregateFunc.Count]
+                assert_rows_multiset_equal(got, exp, RTOL, exact_cols=exact, what=f"groups={groups} key={key!r} aggs={aggs} pred={pred!r}")
+                if ok and key_ok and groups <= 700:
+                    assert rep_.get("agg_grouped_fast", (0, 0))[1] == 1, (rep_, repr(key), aggs)
+                elif groups <= 700:  # passes of one and two columns (one each for a nullable column)
+                    assert rep_.get("agg_grouped_fast", (0, 0))[1] == (3 if any(c == 4 for _, c in aggs) else 2), (rep_, repr(key), aggs)
