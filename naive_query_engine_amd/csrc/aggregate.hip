@@ -1508,11 +1508,13 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             }
                         }
                         ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
-                        bool nomm = a.nv >= 2;
-                        for (int j = 0; j < a.nv; ++j) nomm = nomm && !a.need_minmax[j];
                         // the value column is the key column itself (and the predicate, if any, tests it too): the single-load instance
                         const bool share = a.nv == 1 && a.val_shares_key[0] && a.val[0].values == a.key_src.values && (fp == 0 || fp == 1) && fast_key != 3 && !vnull && !vf64 &&
                                            subsets_log2 == 0;
+                        // no aggregate of the pass asks for min / max: instances without those LDS arrays (two and three columns, and the
+                        // single-load one — `count(id) … group by id % 3` updates one LDS word per row instead of reading two and updating four)
+                        bool nomm = a.nv >= 2 || share;
+                        for (int j = 0; j < a.nv; ++j) nomm = nomm && !a.need_minmax[j];
                         FastKernel fk = pick_fast_kernel(fp, fast_key, a.nv, vf64, vnull, subsets_log2 != 0, nomm, share);
                         if (!fk) fail(NQE_ERR_NOT_SUPPORTED, "internal: no such variant of the streaming aggregate kernel");
                         launch(ctx, "agg_grouped_fast", fk, dim3(fgrid), dim3(AGG_BLOCK), fshmem, ka, fpred, tb.g, ctx->d_flags);

@@ -88,6 +88,14 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     }
     __syncthreads();
 
+    // LDS atomics per row are what bounds inputs whose key changes on every row of a thread (`id % 3` over row numbers: the run
+    // cache never holds).  Without validity bitmaps every value column of a row counts the same rows: only column 0's counter is
+    // updated and the merge hands its count to the others (their own words carry just the NaN mark); and a column nobody asks the
+    // sum of (count(id)) gets no sum update (AggArgs::need_sum, wave-uniform) — count(id), sum(age), avg(score): 3 instead of 6.
+    constexpr bool OWN_CNT = VNULL;
+    bool nsum[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) nsum[j] = a.need_sum[j] != 0;
     bool run_live = false;
     uint64_t run_key = 0;
     uint32_t rcnt[NVT];
@@ -149,8 +157,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             if (slot >= 0) {
                 uint32_t o = uint32_t(j) * slots + uint32_t(slot);
                 if (rcnt[j]) {
-                    atomicAdd(&lcnt[o], rcnt[j]);
-                    unsafeAtomicAdd(&lsum[o], rsum[j]);
+                    if (OWN_CNT || j == 0) atomicAdd(&lcnt[o], rcnt[j]);
+                    if (nsum[j]) unsafeAtomicAdd(&lsum[o], rsum[j]);
                 }
                 if (rnan[j]) atomicOr(&lcnt[o], NAN_BIT);
                 // read-before-atomic (see the general kernel)
@@ -317,8 +325,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                     const bool vb = VNULL ? bool((t.vv[VNULL ? j : 0][u] >> (row & 63)) & 1ull) : true;
                     if (!vb) continue; // a NULL value contributes nothing; its row has created the group above
                     const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
-                    atomicAdd(&lcnt[o], 1u);
-                    unsafeAtomicAdd(&lsum[o], x);
+                    if (OWN_CNT || j == 0) atomicAdd(&lcnt[o], 1u);
+                    if (nsum[j]) unsafeAtomicAdd(&lsum[o], x);
                     if (MM) {
                         if (x < cmn[MM ? j : 0][i]) unsafeAtomicMin(&lmn[o], x);
                         if (x > cmx[MM ? j : 0][i]) unsafeAtomicMax(&lmx[o], x);
@@ -479,7 +487,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // up to 2 x `budget` tiles.  In: A holds tile `base` (< n).  Out: base >= n (done or abandoned), or A holds tile `base`.
     // (PRED = 6: ONE tile in flight — the stack machine's registers take the place of the prefetched tile's; the workgroup's 16
     // waves hide the loads' latency among themselves)
-    // (three value columns: one tile is 8 KB per wave = 128 KB per CU in flight already, and a second one does not fit the registers)
+    // (three value columns: one tile is 6-8 KB per wave = 96-128 KB per CU in flight already; a second one spills ~30 VGPRs)
     constexpr bool PIPE = (PRED != 6 || NQE_TREE_PIPE) && NVT != 3;
     auto stream = [&](auto &&process, Tile &A, int budget) {
         if constexpr (!PIPE) {
@@ -597,6 +605,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         for (int j = 0; j < NVT; ++j) {
             uint32_t o = uint32_t(j) * slots + s;
             uint32_t c = lcnt[o];
+            if (!OWN_CNT && j > 0) c = (lcnt[s] & ~NAN_BIT) | (c & NAN_BIT);
             global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, MM ? f64_to_ord(lmn[o]) : 0ull, MM ? f64_to_ord(lmx[o]) : 0ull, MM, (c & NAN_BIT) != 0);
         }
     }
@@ -604,7 +613,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 
 template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf64, bool sub, bool nomm, bool share) {
     if constexpr (!VNULL && PRED <= 1 && KEY != 3) {
-        if (share && nv == 1 && !vf64 && !sub) return agg_grouped_fast_kernel<PRED, KEY, 1, false, false, false, true, true>;
+        if (share && nv == 1 && !vf64 && !sub)
+            return nomm ? agg_grouped_fast_kernel<PRED, KEY, 1, false, false, false, false, true> : agg_grouped_fast_kernel<PRED, KEY, 1, false, false, false, true, true>;
     }
     if constexpr (!VNULL && PRED <= 1 && KEY != 3) {
         if (nomm && nv == 3 && !sub)

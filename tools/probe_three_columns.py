@@ -25,3 +25,7 @@ for kn, k in (("id%3", k3), ("id%1024", k1024)):
     run(kn + " sum(age)", [(A.Sum, 1)], k)
     run(kn + " all three", [(A.Count, 0), (A.Sum, 1), (A.Avg, 2)], k)
     run(kn + " 5 aggs of score", [(A.Count, 2), (A.Sum, 2), (A.Avg, 2), (A.Min, 2), (A.Max, 2)], k)
+# what a changing key costs the single-load instance: mask key vs magic-multiply key, few vs many groups
+for m in (3, 1000, 1024, 2048, 2047):
+    run(f"id%{m} count(id)", [(A.Count, 0)], binop(col(0), Operator.Modulos, lit_i64(m)))
+    run(f"id%{m} sum(id)", [(A.Sum, 0)], binop(col(0), Operator.Modulos, lit_i64(m)))
