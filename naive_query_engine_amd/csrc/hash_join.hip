@@ -64,6 +64,12 @@ struct nqe_join_table {
     nqe::BufRef slotsp;
     uint64_t filler = 0;
     int pis_col = -1; // the left column carried in the slot
+    // … in 8-byte slots when key and payload fit one word together: (key - pp_kmin) << pp_bits | (payload - pp_base), empty = all
+    // ones (key bits + payload bits <= 63), 16-slot = 128-byte buckets, pp_nb of them (not a power of two: load ~0.6) — 10^6 keys
+    // of a 2^40 domain with a 20-bit payload: 13 MB instead of 32, so more of the probe's line fetches stay in the 4 MB per-XCD L2
+    int pp_bits = 0; // 0: the 16-byte form
+    uint32_t pp_nb = 0;
+    uint64_t pp_kmin = 0, pp_kspan = 0, pp_base = 0;
     // Utf8 join keys: the build strings are encoded to representative-row codes (strings.hip)
     nqe::Utf8Dict dict;
 };
@@ -302,6 +308,34 @@ __global__ void __launch_bounds__(256) hashed_insert_pairs_kernel(const uint64_t
             }
             if (old == key) break; // the same key twice
             slot = (slot + 1) & (cap - 1);
+        }
+        if (!placed) *dup = 1;
+    }
+}
+// the packed form of the {key, payload} table (nqe_join_table::pp_bits)
+struct PackedPairs {
+    uint64_t kmin, kspan, pbase;
+    uint32_t nb;   // buckets of 16 slots
+    int32_t pbits; // payload bits (the low ones)
+};
+constexpr int PACKED_BUCKET = 16;
+__device__ __forceinline__ uint32_t packed_home(uint64_t key, uint32_t nb) { return uint32_t((uint64_t(uint32_t((key * GOLD) >> 32)) * nb) >> 32); }
+__global__ void __launch_bounds__(256) packed_insert_kernel(const uint64_t *keys, const uint64_t *payload, int64_t n, unsigned long long *tab, PackedPairs pp, int *dup) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const uint32_t total = pp.nb * PACKED_BUCKET;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const uint64_t key = keys[r], kd = key - pp.kmin;
+        const unsigned long long w = (kd << pp.pbits) | (payload[r] - pp.pbase);
+        uint32_t slot = packed_home(key, pp.nb) * PACKED_BUCKET;
+        bool placed = false;
+        for (int p = 0; p < UNIQUE_MAX_PROBE; ++p) {
+            const unsigned long long old = atomicCAS(&tab[slot], ~0ull, w);
+            if (old == ~0ull) {
+                placed = true;
+                break;
+            }
+            if ((old >> pp.pbits) == kd) break; // the same key twice
+            slot = slot + 1 == total ? 0 : slot + 1;
         }
         if (!placed) *dup = 1;
     }
@@ -727,6 +761,66 @@ __global__ void __launch_bounds__(256) probe_pairs_kernel(const uint64_t *rkeys,
     }
 }
 
+// the same over the packed table: a bucket is 16 eight-byte slots = the same one line, lane (g, i) loads slots 2i and 2i + 1
+__global__ void __launch_bounds__(256) probe_packed_kernel(const uint64_t *rkeys, int64_t n, int64_t ntiles, const ulonglong2 *tab, PackedPairs pp, uint64_t *keep,
+                                                           uint64_t *payload, uint32_t *tile_counts) {
+    const int waves_per_block = blockDim.x / 64;
+    const int64_t last = n - 1;
+    const int my_t = lane_id() >> 3, my_g = lane_id() & 7;
+    const uint64_t pmask = (1ull << pp.pbits) - 1ull;
+    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
+         tile += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t row0 = tile * TILE_ROWS;
+        uint32_t total = 0;
+        for (int k0 = 0; k0 < TILE_WORDS; ++k0) {
+            const int64_t row = row0 + int64_t(k0) * 64 + lane_id();
+            const uint64_t key = __builtin_nontemporal_load(&rkeys[row < last ? row : last]);
+            const uint64_t kd = key - pp.kmin;
+            uint64_t kdg[8];
+            ulonglong2 s[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint64_t kg = (uint64_t)__shfl((unsigned long long)key, t * 8 + (lane_id() >> 3), 64);
+                kdg[t] = kg - pp.kmin;
+                s[t] = tab[packed_home(kg, pp.nb) * (PACKED_BUCKET / 2) + uint32_t(lane_id() & 7)];
+            }
+            uint64_t pay = 0;
+            bool hit = false, settled = false;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool mx = (s[t].x >> pp.pbits) == kdg[t], my = (s[t].y >> pp.pbits) == kdg[t];
+                const uint64_t m = __ballot(mx || my), f = __ballot(s[t].x == ~0ull || s[t].y == ~0ull);
+                const uint32_t mb = uint32_t(m >> (8 * my_g)) & 0xFFu, fb = uint32_t(f >> (8 * my_g)) & 0xFFu;
+                const int src = 8 * my_g + (mb ? __ffs(int(mb)) - 1 : 0);
+                const uint64_t pl = (uint64_t)__shfl((unsigned long long)(mx ? s[t].x : s[t].y), src, 64);
+                if (t == my_t) {
+                    hit = mb != 0;
+                    pay = pl;
+                    settled = hit || fb != 0;
+                }
+            }
+            if (!settled) { // a full bucket without the key (1-2 % of the buckets at load 0.6): walk the following slots alone
+                const unsigned long long *words = reinterpret_cast<const unsigned long long *>(tab);
+                const uint32_t slots = pp.nb * PACKED_BUCKET;
+                uint32_t sl = packed_home(key, pp.nb) * PACKED_BUCKET + PACKED_BUCKET;
+                if (sl == slots) sl = 0;
+                for (int p = 0; p < 2 * UNIQUE_MAX_PROBE; ++p) {
+                    const unsigned long long c = words[sl];
+                    if ((c >> pp.pbits) == kd) { hit = true; pay = c; break; }
+                    if (c == ~0ull) break;
+                    sl = sl + 1 == slots ? 0 : sl + 1;
+                }
+            }
+            hit = hit && row < n && kd <= pp.kspan; // (a key outside the build range shifts to bits no stored word has — except the empty word's)
+            const uint64_t kw = __ballot(hit);
+            if (row < n) __builtin_nontemporal_store(hit ? pp.pbase + (pay & pmask) : 0ull, &payload[row]);
+            if (row0 + int64_t(k0) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0] = kw;
+            total += __popcll(kw);
+        }
+        if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
 // 16 rows per lane in flight: the kernel is bound by the latency of its gathers, and memory-level parallelism per wave
 // beats occupancy (A/B on one box, C4: 4 rows/lane (70 VGPRs, 7 waves/SIMD) 1.53 ms, 8 (116, 4) 1.33 ms, 16 (210, 2)
 // 1.24 ms, 32 (256, 1) 1.31 ms)
@@ -999,7 +1093,31 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
     uint64_t filler = 0;
     int pis_col = -1;
     const bool have_filler = kmax != ~0ull || kmin != 0ull; // a value outside [kmin, kmax] (unsigned) is not a build key
-    if (payload_plain && ncols == 2 && have_filler) { // exactly one payload column: it rides in the slot
+    auto bit_length = [](uint64_t x) {
+        int b = 0;
+        while (b < 64 && (x >> b) != 0) ++b;
+        return b;
+    };
+    static const bool no_packed = getenv("NQE_JOIN_NO_PACKED_PAIRS") != nullptr; // diagnostics (A/B)
+    PackedPairs pp{};
+    if (payload_plain && ncols == 2 && mm_cols.size() == 2 && !no_packed) { // one integer payload column whose offset fits a word together with the key's
+        const int kbits = std::max(1, bit_length(kmax - kmin)), pbits = std::max(1, bit_length(mmh[3] - mmh[2]));
+        const uint64_t nb = uint64_t(n) * 5 / 48 + 1; // 16-slot buckets at load 0.6
+        if (kbits + pbits <= 63 && nb * PACKED_BUCKET < (1ull << 31)) {
+            pis_col = jt->left_key == 0 ? 1 : 0;
+            pp.kmin = kmin;
+            pp.kspan = kmax - kmin;
+            pp.pbase = mmh[2] ^ (left->cols[size_t(pis_col)].dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull);
+            pp.nb = uint32_t(nb);
+            pp.pbits = pbits;
+            slotsp = dev_alloc(ctx, size_t(nb) * PACKED_BUCKET * 8);
+            NQE_HIP_CHECK(hipMemsetAsync(slotsp->ptr, 0xFF, size_t(nb) * PACKED_BUCKET * 8, ctx->stream));
+            launch(ctx, "join_build_insert", packed_insert_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), left->cols[size_t(pis_col)].words(), n,
+                   (unsigned long long *)slotsp->ptr, pp, (int *)dupflag->ptr);
+        }
+    }
+    if (slotsp) { // (the packed insert has checked uniqueness itself)
+    } else if (payload_plain && ncols == 2 && have_filler) { // exactly one payload column: it rides in the slot
         filler = kmax != ~0ull ? kmax + 1 : kmin - 1;
         pis_col = jt->left_key == 0 ? 1 : 0;
         slotsp = dev_alloc(ctx, size_t(cap) * 16);
@@ -1019,6 +1137,11 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
     jt->slotsp = slotsp;
     jt->filler = filler;
     jt->pis_col = pis_col;
+    jt->pp_bits = pp.pbits;
+    jt->pp_nb = pp.nb;
+    jt->pp_kmin = pp.kmin;
+    jt->pp_kspan = pp.kspan;
+    jt->pp_base = pp.pbase;
     return true;
 }
 
@@ -1316,7 +1439,11 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         BufRef bidx, payload;
         if (pairs) {
             payload = dev_alloc(ctx, size_t(n) * 8 + 8);
-            if (km.ntiles)
+            if (km.ntiles && jt->pp_bits) {
+                PackedPairs pp{jt->pp_kmin, jt->pp_kspan, jt->pp_base, jt->pp_nb, jt->pp_bits};
+                launch(ctx, "join_probe_pairs", probe_packed_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,
+                       (const ulonglong2 *)jt->slotsp->ptr, pp, (uint64_t *)km.keep->ptr, (uint64_t *)payload->ptr, (uint32_t *)counts->ptr);
+            } else if (km.ntiles)
                 launch(ctx, "join_probe_pairs", probe_pairs_kernel, dim3(stream_grid(ctx, km.ntiles, 4)), dim3(256), 0, rk.words(), n, km.ntiles,
                        (const ulonglong2 *)jt->slotsp->ptr, jt->cap, jt->shift, jt->filler, (uint64_t *)km.keep->ptr, (uint64_t *)payload->ptr,
                        (uint32_t *)counts->ptr);

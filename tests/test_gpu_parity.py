@@ -1575,3 +1575,59 @@ def test_aggregate_three_value_columns_in_one_pass(ctx, groups):
                     assert rep_.get("agg_grouped_fast", (0, 0))[1] == 1, (rep_, repr(key), aggs)
                 elif groups <= 700:  # passes of one and two columns (one each for a nullable column)
                     assert rep_.get("agg_grouped_fast", (0, 0))[1] == (3 if any(c == 4 for _, c in aggs) else 2), (rep_, repr(key), aggs)
+
+
+def _packed_home(keys, nb):
+    h = ((keys.astype(np.uint64) * np.uint64(GOLD)) >> np.uint64(32)).astype(np.uint64)
+    return ((h * np.uint64(nb)) >> np.uint64(32)).astype(np.int64)
+
+
+@pytest.mark.parametrize("case", ["20bit", "1bit", "63bits", "64bits", "negative_payload", "crowded_bucket", "last_bucket", "overfull"])
+def test_hash_join_packed_key_payload_table(ctx, case):
+    """sparse unique build keys with ONE integer payload column whose offset fits a word together with the key's offset: the 8-byte
+    {key - min, payload - min} slots in 16-slot buckets (hash_join.hip, PackedPairs).  Payload widths 1 / 20 bits, key + payload
+    = 63 bits (packed) and 64 bits (the 16-byte form), negative Int64 payloads, probe keys below / above / just outside the build
+    range and ones whose offset has the empty word's bit pattern; 40 keys in ONE bucket (the probe's walk beyond a full bucket),
+    the same in the table's LAST bucket (the walk wraps to slot 0), and more colliding keys than the insert's bound (fall-back
+    to the sort-based build).  Output bit-exact incl. row order."""
+    rng = np.random.default_rng(len(case) * 7 + 1)
+    nk = 6000
+    kbits = 40
+    lo = 1 << 44
+    pay_lo, pay_hi = 0, 1 << 20
+    if case == "1bit":
+        pay_hi = 2
+    if case in ("63bits", "64bits"):
+        pay_hi = 1 << (23 if case == "63bits" else 24)
+    if case == "negative_payload":
+        pay_lo, pay_hi = -(1 << 19), 1 << 19
+    ends = np.array([lo, lo + (1 << kbits) - 1], dtype=np.uint64)  # pin the range: kbits exactly
+    keys = np.setdiff1d(np.unique(rng.integers(lo, lo + (1 << kbits), nk).astype(np.uint64)), ends)
+    if case in ("crowded_bucket", "last_bucket", "overfull"):
+        # keys that share ONE bucket of the table this build will get (the bucket count follows from the final key count)
+        want = 300 if case == "overfull" else 40
+        cand = np.setdiff1d(np.unique(rng.integers(lo, lo + (1 << kbits), 4_000_000).astype(np.uint64)), np.concatenate([keys, ends]))
+        nb = (len(keys) + want + 2) * 5 // 48 + 1
+        b = _packed_home(cand, nb)
+        target = nb - 1 if case == "last_bucket" else int(np.bincount(b, minlength=nb).argmax())
+        pick = cand[b == target][:want]
+        assert len(pick) == want
+        keys = np.concatenate([keys, pick])
+    keys = np.concatenate([keys, ends])
+    keys = np.unique(keys)
+    rng.shuffle(keys)
+    pay = rng.integers(pay_lo, pay_hi, len(keys)).astype(np.int64)
+    pay[:2] = [pay_lo, pay_hi - 1]
+    left = [Column.from_numpy(keys), Column.from_numpy(pay)]
+    pbits = max(1, int(pay_hi - 1 - pay_lo).bit_length())
+    empty_pattern = lo + (1 << (64 - pbits)) - 1  # key whose offset, shifted, is all ones in the key field
+    specials = [0, 1, lo - 1, lo + (1 << kbits), (1 << 64) - 1, empty_pattern % (1 << 64), int(keys.min()), int(keys.max())]
+    probe = np.concatenate([rng.choice(keys, 30000), np.array(specials * 20, dtype=np.uint64), rng.integers(lo, lo + (1 << kbits), 5000).astype(np.uint64),
+                            rng.integers(0, 1 << 63, 2000).astype(np.uint64)])
+    rng.shuffle(probe)
+    right = [Column.from_numpy(probe), Column.from_numpy(rng.random(len(probe)))]
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    _join_both_ways(ctx, left, right)
+    ctx.timing_enable(False)
+    assert "join_probe_pairs" in ctx.timing_report() or case == "overfull"
