@@ -739,6 +739,27 @@ __global__ void iota_slots_kernel(uint32_t *out, int64_t n) {
 }
 
 // the program of a predicate tree, from the kernel arguments into the device buffer the streaming kernel reads it from
+// min / max of a plain 8-byte integer key column in its own order (flip = the sign bit for Int64): out[0] = min, out[1] = max, both
+// in the flipped (unsigned-comparable) form; the caller starts them at ~0 / 0
+__global__ void __launch_bounds__(256) key_range_kernel(const uint64_t *keys, int64_t n, uint64_t flip, unsigned long long *out) {
+    uint64_t mn = ~0ull, mx = 0ull;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        const uint64_t k = __builtin_nontemporal_load(&keys[i]) ^ flip;
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t a = (uint64_t)__shfl_down((unsigned long long)mn, o, 64), b = (uint64_t)__shfl_down((unsigned long long)mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&out[0], (unsigned long long)mn);
+        atomicMax(&out[1], (unsigned long long)mx);
+    }
+}
+
 __global__ void store_tree_kernel(TreePred p, TreeInstr *dst) {
     if (int(threadIdx.x) < p.n) dst[threadIdx.x] = p.ins[threadIdx.x];
 }
@@ -1075,6 +1096,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     bool partition_mode = false, level2 = false, dense_ok = true, slab_failed = false, key32_failed = false;
     static const bool no_three = getenv("NQE_NO_THREE_COLUMN_PASS") != nullptr; // diagnostics (A/B runs)
     bool three_on = !no_three;
+    // a plain integer key column whose value RANGE fits a workgroup table (nqe_ctx::agg_key_ranges)
+    static const bool no_range = getenv("NQE_NO_KEY_RANGE") != nullptr; // diagnostics (A/B runs)
+    bool range_on = false;
+    int64_t range_min = 0;
+    uint64_t range_span = 0;
     // Between one LDS table's worth of groups and the partitioned path: the fast kernel with two key subsets (see
     // AggArgs::subsets_log2) — every row is read by two workgroups, each of which keeps its half of the keys.  Rows of the other
     // half cost a wave as many issue slots as its own (lanes are masked, instructions are not skipped), so the kernel time doubles:
@@ -1132,6 +1158,33 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 subsets_log2 = hv - 1;
                 cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
             }
+        }
+    }
+    if (hint_key && !no_range && !partition_mode && subsets_log2 == 0 && !getenv("NQE_NO_PLAN_HINTS") && key_col >= 0 && !utf8_key && a.key.nops == 0 &&
+        !a.key_src.valid && (a.key_src.dtype == NQE_INT64 || a.key_src.dtype == NQE_UINT64)) {
+        // `group by k`, k a plain integer column (dictionary codes, small ids): the first execution of the query shape measures the
+        // column's min / max — one more read of the key column, once — and remembers them; a range that fits a workgroup table makes
+        // the streaming kernel address it by key - min (no hash, no probe sequence, replicas for a handful of groups)
+        auto rt = ctx->agg_key_ranges.find(hint_key);
+        if (rt == ctx->agg_key_ranges.end()) {
+            BufRef mm = dev_alloc(ctx, 16);
+            NQE_HIP_CHECK(hipMemsetAsync(mm->ptr, 0xFF, 8, ctx->stream));
+            NQE_HIP_CHECK(hipMemsetAsync(static_cast<char *>(mm->ptr) + 8, 0, 8, ctx->stream));
+            const uint64_t flip = a.key_src.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
+            launch(ctx, "agg_key_range", key_range_kernel, dim3(stream_grid(ctx, in->rows, 256)), dim3(256), 0, (const uint64_t *)a.key_src.values, in->rows, flip,
+                   (unsigned long long *)mm->ptr);
+            uint64_t h[2];
+            NQE_HIP_CHECK(hipMemcpyAsync(h, mm->ptr, 16, hipMemcpyDeviceToHost, ctx->stream));
+            sync(ctx);
+            if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
+            // (span 0: the whole 64-bit range, or no rows)
+            rt = ctx->agg_key_ranges.emplace(hint_key, std::make_pair(int64_t(h[0] ^ flip), h[1] >= h[0] ? h[1] - h[0] + 1 : 0ull)).first;
+        }
+        const uint64_t limit = V <= 1 ? 4096 : 2048; // the smallest workgroup table among the passes
+        if (rt->second.second != 0 && rt->second.second <= limit) {
+            range_on = true;
+            range_min = rt->second.first;
+            range_span = rt->second.second;
         }
     }
     bool any_val_nullable = false;
@@ -1507,6 +1560,13 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                                 while (ka.direct_rep < 6 && (span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
                             }
                         }
+                        if (range_on && fast_key == 0 && !ka.direct && range_span <= uint64_t(ka.lds_cap)) {
+                            // the key column's measured range fits the table: slot = key - min, every key checked against the range
+                            ka.direct = 2;
+                            ka.direct_bias = int64_t(0ull - uint64_t(range_min));
+                            ka.direct_span = range_span;
+                            while (ka.direct_rep < 6 && (range_span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
+                        }
                         ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
                         // the value column is the key column itself (and the predicate, if any, tests it too): the single-load instance
                         const bool share = a.nv == 1 && a.val_shares_key[0] && a.val[0].values == a.key_src.values && (fp == 0 || fp == 1) && fast_key != 3 && !vnull && !vf64 &&
@@ -1606,6 +1666,13 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2) {
             level2 = true; // partitions hold more distinct keys than a workgroup table: one more partitioning level
             cap = std::max<uint32_t>(cap, 1u << 24);
+            flags_reset(ctx);
+            continue;
+        }
+        if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode && range_on) {
+            // a key outside the remembered range (the column's contents changed), or a pass whose table is smaller than the range
+            range_on = false;
+            if (hint_key) ctx->agg_key_ranges.erase(hint_key);
             flags_reset(ctx);
             continue;
         }

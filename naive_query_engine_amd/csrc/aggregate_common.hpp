@@ -85,6 +85,7 @@ struct AggArgs {
     int32_t direct;
     int32_t direct_rep; // log2 of the replication of a small direct-mapped table (see the fast kernel): span << direct_rep <= lds_cap
     int64_t direct_bias;
+    uint64_t direct_span; // direct == 2 (a MEASURED key range, nqe_ctx::agg_key_ranges): keys with key + direct_bias >= direct_span are not in it
     // fast kernel, key subsets: 2^subsets_log2 workgroups share every row range and each keeps only the keys whose hash bits
     // [subset_shift, subset_shift + subsets_log2) name it — 2^subsets_log2 LDS tables' worth of groups without partitioning the rows
     int32_t subsets_log2;

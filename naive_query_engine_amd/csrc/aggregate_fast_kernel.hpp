@@ -124,7 +124,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // small table is REPLICATED 2^direct_rep times, lane l of a wave updating replica l & (2^rep - 1); the replicas are folded into
     // replica 0 before the merge.
     const uint32_t rep_log2 = uint32_t(a.direct_rep), rep_lane = threadIdx.x & ((1u << rep_log2) - 1u);
-    auto direct_slot = [&](uint64_t key) { return int((uint32_t(int64_t(key) + a.direct_bias) << rep_log2) | rep_lane); };
+    auto direct_slot = [&](uint64_t key) {
+        const uint64_t d = uint64_t(int64_t(key) + a.direct_bias);
+        if (a.direct == 2 && d >= a.direct_span) return -1; // outside the measured range (wave-uniform test first): the cold path
+        return int((uint32_t(d) << rep_log2) | rep_lane);
+    };
     auto flush_run = [&]() {
         if (SUB && foreign(run_key)) { // another workgroup's key: drop the run
 #pragma unroll
@@ -141,7 +145,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             slot = direct_slot(run_key);
             // the final merge recognises a used slot by its count; only NULL-able values (a group of NULLs has count 0) need the
             // key word as the mark (every writer stores the same word)
-            if (VNULL) lkeys[slot] = run_key;
+            if (VNULL && slot >= 0) lkeys[slot] = run_key;
         } else
             slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
         int64_t gslot = 0;
@@ -292,7 +296,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 if (!pass[u]) continue;
                 if (a.direct) {
                     slot[u] = direct_slot(key[u]);
-                    if (VNULL) lkeys[slot[u]] = key[u];
+                    if (VNULL && slot[u] >= 0) lkeys[slot[u]] = key[u];
                 } else if (k0[i] == key[u] && key[u] != EMPTY_KEY) {
                     slot[u] = int(uint32_t((key[u] * GOLD) >> a.lds_shift));
                 } else {

@@ -69,6 +69,11 @@ struct nqe_ctx {
     // instead of paying for an abandoned single-pass attempt and its read-back first.  Only a starting point — a partitioned run
     // is correct for any number of groups, and a single-pass run still falls back when its tables overflow.
     std::map<uint64_t, uint8_t> agg_hints;
+    // … and, by the same key: the value range {min, span} of a plain integer key column (`group by k`: dictionary codes, small ids),
+    // measured by the first execution of the query shape.  A range that fits a workgroup table makes the streaming kernel address
+    // the table by key - min.  The kernel checks every key against the range (the column's contents may have changed under the
+    // entry): a key outside it asks for the other paths, and the entry is dropped.
+    std::map<uint64_t, std::pair<int64_t, uint64_t>> agg_key_ranges;
     // PK-FK joins whose optimistic one-pass probe failed (some foreign key without its primary key), by (build key column, build
     // rows, probe key column, probe rows): HashJoin::execute builds a fresh join table per call (nqe_hash_join_execute), so the
     // verdict has to outlive the table for the next execution of the same join to go straight to the two-pass form
