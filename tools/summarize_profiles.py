@@ -23,12 +23,13 @@ CONFIGS = {
     "headline_random_keys": ({"agg_grouped_fast_kernel": 1}, 16e9),
     "c2": ({"keep_from_simple_kernel": 1, "compact_kernel": 1}, 2.0e9),
     "c4": ({"probe_presence_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
-    "c4_sparse_keys": ({"probe_pairs_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
+    "c4_sparse_keys": ({"probe_packed_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
     "agg_65536_groups": ({"agg_grouped_fast_kernel": 1, "agg_slab_scatter_kernel": 1, "agg_slab_segments_kernel": 1}, 1.6e9),
     "headline_single_column": ({"agg_grouped_fast_kernel": 1}, 8e9),
     "headline_int64_values": ({"agg_grouped_fast_kernel": 1}, 16e9),
     "agg_tree_predicate": ({"agg_grouped_fast_kernel": 1}, 16e9),
-    "agg_three_value_columns": ({"agg_grouped_fast_kernel": 2}, 24e9),
+    "agg_three_value_columns": ({"agg_grouped_fast_kernel": 1}, 24e9),
+    "agg_4096_groups": ({"agg_grouped_fast_kernel": 1}, 1.6e9),
     "c2_random_ids": ({"keep_from_simple_kernel": 1, "compact_kernel": 1}, 2.0e9),
     "c4_dup_keys": ({"probe_count_kernel": 1, "probe_write_kernel": 1}, 4.816e9),
     "c4_partial_match": ({"probe_presence_kernel": 1, "join_fused_write_kernel": 1}, 4.496e9),
