@@ -194,6 +194,13 @@ nqe_status nqe_ctx_timing_reset(nqe_ctx *ctx);
 /* every kernel family launched since the last reset by exact name, one "name\tms\tlaunches\n" line each, NUL-terminated;
  * *needed = bytes required (call with capacity 0 to size the buffer). */
 nqe_status nqe_ctx_timing_report(nqe_ctx *ctx, char *buf, int64_t capacity, int64_t *needed);
+/* Expression trees of three or more operators over large inputs (binary.rs:108-155 nested) are, besides being interpreted by the
+ * stack machine, specialised at run time: the tree becomes straight-line HIP source compiled with hipRTC on a worker thread, and
+ * executions of the same tree shape switch to the compiled kernel once it is ready (results are identical; without libhiprtc the
+ * interpreter simply stays).  This call blocks until every compilation in flight for the context has finished — for tests and
+ * benchmarks that want the steady state.  NQE_NO_JIT=1 disables the specialisation, NQE_JIT_SYNC=1 compiles before the first
+ * execution. */
+nqe_status nqe_ctx_jit_wait(nqe_ctx *ctx);
 
 /* ------------------------------------------------------------------ tables
  * MemTable::try_create + ScanPlan::execute (datasource/memory.rs:21-41, scan.rs:34-36):

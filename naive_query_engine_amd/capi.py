@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("NQE_LIB_PATH") or os.path.join(_HERE, "libnqe_hip.so"
 # every symbol include/nqe.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
     "nqe_abi_version", "nqe_ctx_create", "nqe_ctx_destroy", "nqe_ctx_synchronize", "nqe_ctx_memory_stats", "nqe_ctx_trim", "nqe_last_error",
-    "nqe_last_global_error", "nqe_ctx_timing_enable", "nqe_ctx_timing_query", "nqe_ctx_timing_reset", "nqe_ctx_timing_report",
+    "nqe_last_global_error", "nqe_ctx_timing_enable", "nqe_ctx_timing_query", "nqe_ctx_timing_reset", "nqe_ctx_timing_report", "nqe_ctx_jit_wait",
     "nqe_table_create", "nqe_table_release", "nqe_table_num_rows", "nqe_table_num_columns", "nqe_table_column",
     "nqe_table_download_column", "nqe_table_project", "nqe_table_slice", "nqe_table_concat", "nqe_table_pack_words",
     "nqe_table_unpack_words", "nqe_csv_infer_schema", "nqe_csv_read", "nqe_expr_evaluate",
@@ -100,6 +100,7 @@ def lib():
         "nqe_ctx_timing_query": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
         "nqe_ctx_timing_reset": (i32, [vp]),
         "nqe_ctx_timing_report": (i32, [vp, C.c_char_p, i64, C.POINTER(i64)]),
+        "nqe_ctx_jit_wait": (i32, [vp]),
         "nqe_table_create": (i32, [vp, C.POINTER(NqeColumn), i32, pvp]),
         "nqe_table_release": (i32, [vp]),
         "nqe_table_num_rows": (i64, [vp]),
@@ -199,6 +200,10 @@ class Context:
         ms, cnt = C.c_double(), C.c_int64()
         self.check(lib().nqe_ctx_timing_query(self.handle, name_substr.encode(), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def jit_wait(self):
+        """blocks until the run-time specialisations being compiled for this context are ready (the next execution takes them)"""
+        self.check(lib().nqe_ctx_jit_wait(self.handle))
 
     def timing_report(self) -> dict:
         """{kernel name: (total ms, launches)} since the last reset, by exact name"""

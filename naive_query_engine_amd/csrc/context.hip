@@ -604,6 +604,13 @@ nqe_status nqe_ctx_timing_query(nqe_ctx *ctx, const char *name_substr, double *t
 }
 
 // every kernel family launched since the last reset, by exact name: "name\tms\tlaunches\n" per line (sorted by name)
+nqe_status nqe_ctx_jit_wait(nqe_ctx *ctx) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx) fail(NQE_ERR_INVALID_ARGUMENT, "null context");
+    jit_wait(ctx);
+    NQE_API_END()
+}
+
 nqe_status nqe_ctx_timing_report(nqe_ctx *ctx, char *buf, int64_t capacity, int64_t *needed) {
     NQE_API_BEGIN(ctx)
     if (!ctx || !needed || capacity < 0 || (capacity > 0 && !buf)) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");

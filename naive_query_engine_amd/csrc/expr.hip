@@ -253,6 +253,13 @@ struct ExProgram {
     int32_t col_dtype[EX_MAX_COLS];
 };
 
+} // namespace
+} // namespace nqe
+#include "expr_jit.hpp" // the same programs as straight-line source, compiled at run time (hipRTC)
+namespace nqe {
+void jit_wait(nqe_ctx *ctx) { jit_wait_all(ctx); }
+namespace {
+
 template <int OP, int DT> struct OpTag { static constexpr int op = OP, dt = DT; };
 // wave-uniform (op, dtype) → compile-time constants.  Boolean operands compare like UInt64 words (0/1).
 template <class F> __device__ __forceinline__ void dispatch_binary(int op, int dt, F &&f) {
@@ -992,7 +999,9 @@ DevColumn evaluate_expr(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             // (8 rows per lane, measured: 176 VGPRs = 2 waves per SIMD — an 8-operator chain 1.19 -> 1.13 ms per 2x10^8 rows, but
             // `(id % 1000) * 3 + id / 7` 1.11 -> 1.36 and `v > 50 and id % 3 = 0` 0.98 -> 1.19: off unless asked for)
             static const bool rows8 = getenv("NQE_EXPR_ROWS8") != nullptr; // diagnostics (A/B)
-            if (needs_valid) { if (P.ncols <= 2) NQE_TREE(true, 2); else NQE_TREE(true, 4); }
+            // three or more steps over a large input: the run-time specialised form of this very program, once it has been compiled
+            if (jit_expr_tree(ctx, P, needs_valid, rows, ow, ob, ov)) {
+            } else if (needs_valid) { if (P.ncols <= 2) NQE_TREE(true, 2); else NQE_TREE(true, 4); }
             else if (P.ncols <= 2 && rows8) {
                 launch(ctx, "expr_tree", expr_tree_kernel<false, 2, 8>, dim3(stream_grid(ctx, (rows + 7) / 8, 256)), dim3(256), 0, P, rows, ow, ob, ov, ctx->d_flags);
             } else { if (P.ncols <= 2) NQE_TREE(false, 2); else NQE_TREE(false, 4); }

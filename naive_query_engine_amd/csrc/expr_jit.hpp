@@ -1,0 +1,358 @@
+// expr_jit.hpp — run-time specialisation of the expression machine (included by expr.hip, host code only).
+//
+// The stack machine of expr.hip (expr_tree_kernel) interprets an ExProgram per 256-row chunk: operand fetch, stack moves and the
+// (operator, dtype) dispatch are wave-uniform branches around register copies — ≈ 10-14 vector instructions per program step per
+// row against 1-2 for the arithmetic itself, so a tree of more than ~4 operators is issue-bound (an 8-operator chain ran at
+// 2.7 TB/s, `(id % 1000) * 3 + id / 7` at 2.9).  For such trees over large inputs the SAME program is turned into straight-line
+// HIP source — one SSA value per step, operands named at generation time, literal divisors baked in so that the compiler emits
+// its own multiply-shift sequences — and compiled for gfx950 with hipRTC (libhiprtc.so, loaded on first use).
+//
+// Compilation (≈ 0.3 s, 2-3 s for the first one of a process) happens on a worker thread that makes no HIP calls; executions
+// of the query shape keep using the interpreter until the code object is ready, then the calling thread loads it
+// (hipModuleLoadData) and launches it with hipModuleLaunchKernel on the context's stream.  Kernels are cached in the context by
+// a hash of everything baked into the source (steps, dtypes, which columns carry validity, output form, baked divisors); other
+// literals and all pointers are kernel arguments, so `v * 2 > K` does not compile once per K.  Any failure — no libhiprtc, a
+// compile error — marks the entry failed and the interpreter stays: results never depend on the specialisation.
+// Semantics are those of apply_binary / ex_combine (device_utils.hpp, expr.hip), restated in the generated source; the parity
+// tests run every tree through both forms.
+#pragma once
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <atomic>
+#include <mutex>
+#include <sstream>
+#include <thread>
+
+namespace nqe {
+namespace {
+
+struct HipRtcApi {
+    decltype(&hiprtcCreateProgram) create = nullptr;
+    decltype(&hiprtcCompileProgram) compile = nullptr;
+    decltype(&hiprtcGetCodeSize) code_size = nullptr;
+    decltype(&hiprtcGetCode) code = nullptr;
+    decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+    decltype(&hiprtcGetProgramLog) log = nullptr;
+    decltype(&hiprtcDestroyProgram) destroy = nullptr;
+    bool ok = false;
+};
+
+// (called from worker threads: initialised once)
+const HipRtcApi &hiprtc_api() {
+    static HipRtcApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = dlopen("libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("/opt/rocm/lib/libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        api.create = reinterpret_cast<decltype(api.create)>(dlsym(h, "hiprtcCreateProgram"));
+        api.compile = reinterpret_cast<decltype(api.compile)>(dlsym(h, "hiprtcCompileProgram"));
+        api.code_size = reinterpret_cast<decltype(api.code_size)>(dlsym(h, "hiprtcGetCodeSize"));
+        api.code = reinterpret_cast<decltype(api.code)>(dlsym(h, "hiprtcGetCode"));
+        api.log_size = reinterpret_cast<decltype(api.log_size)>(dlsym(h, "hiprtcGetProgramLogSize"));
+        api.log = reinterpret_cast<decltype(api.log)>(dlsym(h, "hiprtcGetProgramLog"));
+        api.destroy = reinterpret_cast<decltype(api.destroy)>(dlsym(h, "hiprtcDestroyProgram"));
+        api.ok = api.create && api.compile && api.code_size && api.code && api.log_size && api.log && api.destroy;
+    });
+    return api;
+}
+
+constexpr int JIT_MAX_LITS = 2 * EX_MAX_INSTR;
+// the generated kernel's one argument (restated in the source: keep in step with gen_source)
+struct JitArgs {
+    const void *col[EX_MAX_COLS];
+    const uint8_t *valid[EX_MAX_COLS];
+    uint64_t lit[JIT_MAX_LITS]; // lit[2 * step] = lit_a, lit[2 * step + 1] = lit_b
+    int64_t n;
+    uint64_t *out_words, *out_bits, *out_valid;
+    int *flags;
+};
+
+struct JitEntry {
+    std::thread worker;
+    std::atomic<int> state{0}; // 0: compiling, 1: code ready, 2: loaded, -1: failed
+    std::string source, log;
+    std::vector<char> code;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+};
+
+struct JitCache {
+    std::map<uint64_t, std::unique_ptr<JitEntry>> entries;
+    ~JitCache() {
+        for (auto &kv : entries) {
+            if (kv.second->worker.joinable()) kv.second->worker.join();
+            if (kv.second->mod) (void)hipModuleUnload(kv.second->mod);
+        }
+    }
+};
+
+JitCache *jit_cache(nqe_ctx *ctx) {
+    if (!ctx->jit) ctx->jit = std::shared_ptr<void>(new JitCache, [](void *p) { delete static_cast<JitCache *>(p); });
+    return static_cast<JitCache *>(ctx->jit.get());
+}
+
+// is this literal operand baked into the source?  Only the divisors of integer `/` and `%` (the compiler's multiply-shift forms)
+bool jit_bakes_b(const ExInstr &in) {
+    return in.b_src == EX_LIT && (in.op == NQE_OP_DIVIDE || in.op == NQE_OP_MODULOS) && in.dt != NQE_FLOAT64;
+}
+
+uint64_t jit_hash(const ExProgram &P, bool nulls, bool bool_out) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t nb) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < nb; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    const int32_t head[4] = {P.n, P.ncols, nulls ? 1 : 0, bool_out ? 1 : 0};
+    mix(head, sizeof(head));
+    for (int c = 0; c < P.ncols; ++c) {
+        const int32_t cd[2] = {P.col_dtype[c], (nulls && P.col_valid[c]) ? 1 : 0};
+        mix(cd, sizeof(cd));
+    }
+    for (int i = 0; i < P.n; ++i) {
+        const ExInstr &in = P.ins[i];
+        const int32_t w[4] = {in.op, in.dt, in.a_src, in.b_src};
+        mix(w, sizeof(w));
+        if (jit_bakes_b(in)) mix(&in.lit_b, 8);
+    }
+    return h ? h : 1;
+}
+
+// ---- source generation
+std::string gen_source(const ExProgram &P, bool nulls, bool bool_out) {
+    std::ostringstream s;
+    s << "#pragma clang fp contract(off)\n" // (hipRTC's own -ffp-contract=fast-honor-pragmas comes after the caller's options)
+      << "typedef unsigned long long u64; typedef long long i64; typedef unsigned int u32;\n"
+      << "#define R " << EX_ROWS << "\n"
+      << "struct Args { const void *col[" << EX_MAX_COLS << "]; const unsigned char *valid[" << EX_MAX_COLS << "]; u64 lit[" << JIT_MAX_LITS
+      << "]; i64 n; u64 *out_words, *out_bits, *out_valid; int *flags; };\n"
+      << "static __device__ __forceinline__ double u2d(u64 w) { return __longlong_as_double((i64)w); }\n"
+      << "static __device__ __forceinline__ u64 d2u(double d) { return (u64)__double_as_longlong(d); }\n"
+      << "extern \"C\" __global__ void __launch_bounds__(256) nqe_jit_expr(Args A) {\n"
+      << "  const int lane = threadIdx.x & 63;\n"
+      << "  const i64 n = A.n, n_chunks = (n + 64 * R - 1) / (64 * R);\n"
+      << "  const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;\n"
+      << "  for (i64 chunk = wave; chunk < n_chunks; chunk += n_waves) {\n"
+      << "    const i64 row0 = chunk * (64 * R) + lane;\n"
+      << "    i64 rc[R]; bool in[R];\n"
+      << "#pragma unroll\n"
+      << "    for (int r = 0; r < R; ++r) { const i64 row = row0 + r * 64; in[r] = row < n; rc[r] = row < n - 1 ? row : n - 1; }\n";
+    // every load of the chunk first
+    for (int c = 0; c < P.ncols; ++c) {
+        s << "    u64 c" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) ";
+        if (P.col_dtype[c] == NQE_BOOLEAN) s << "c" << c << "[r] = ((const unsigned char *)A.col[" << c << "])[rc[r] >> 3];\n";
+        else s << "c" << c << "[r] = __builtin_nontemporal_load((const u64 *)A.col[" << c << "] + rc[r]);\n";
+        if (nulls && P.col_valid[c])
+            s << "    u32 vb" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) vb" << c << "[r] = A.valid[" << c << "][rc[r] >> 3];\n";
+    }
+    for (int c = 0; c < P.ncols; ++c) {
+        if (P.col_dtype[c] == NQE_BOOLEAN) s << "#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "[r] = (c" << c << "[r] >> ((int)rc[r] & 7)) & 1ull;\n";
+        if (nulls && P.col_valid[c])
+            s << "    bool c" << c << "v[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "v[r] = in[r] && ((vb" << c << "[r] >> ((int)rc[r] & 7)) & 1u);\n";
+    }
+    // the program: a stack of value names
+    std::vector<std::string> st, stv;
+    auto hex = [](uint64_t v) {
+        std::ostringstream o;
+        o << "0x" << std::hex << v << "ull";
+        return o.str();
+    };
+    for (int i = 0; i < P.n; ++i) {
+        const ExInstr &in = P.ins[i];
+        const bool a_st = in.a_src == EX_STACK, b_st = in.b_src == EX_STACK;
+        std::string a, av, b, bv;
+        auto operand = [&](int src, int which, std::string &w, std::string &v) {
+            if (src >= EX_COL) {
+                const int c = src - EX_COL;
+                w = "c" + std::to_string(c) + "[r]";
+                v = (nulls && P.col_valid[c]) ? "c" + std::to_string(c) + "v[r]" : "in[r]";
+            } else {
+                w = (which == 1 && jit_bakes_b(in)) ? hex(in.lit_b) : "A.lit[" + std::to_string(2 * i + which) + "]";
+                v = src == EX_LIT ? "in[r]" : "false";
+            }
+        };
+        if (a_st && b_st) {
+            b = st.back() + "[r]"; bv = stv.back(); st.pop_back(); stv.pop_back();
+            a = st.back() + "[r]"; av = stv.back(); st.pop_back(); stv.pop_back();
+        } else if (a_st) {
+            a = st.back() + "[r]"; av = stv.back(); st.pop_back(); stv.pop_back();
+            operand(in.b_src, 1, b, bv);
+        } else if (b_st) {
+            b = st.back() + "[r]"; bv = stv.back(); st.pop_back(); stv.pop_back();
+            operand(in.a_src, 0, a, av);
+        } else {
+            operand(in.a_src, 0, a, av);
+            operand(in.b_src, 1, b, bv);
+        }
+        const std::string t = "t" + std::to_string(i), tv = t + "v";
+        s << "    u64 " << t << "[R];";
+        if (nulls) s << " bool " << tv << "[R];";
+        s << "\n#pragma unroll\n    for (int r = 0; r < R; ++r) {\n      const u64 a = " << a << ", b = " << b << ";\n";
+        if (nulls) s << "      const bool av = " << av << ", bv = " << bv << ";\n";
+        const std::string ok = nulls ? "(av && bv)" : "in[r]";
+        const int op = in.op, dt = in.dt;
+        if (op == NQE_OP_AND || op == NQE_OP_OR) {
+            if (nulls) { // and_kleene / or_kleene (ex_combine)
+                s << "      const bool lb = av && a, rb = bv && b;\n";
+                if (op == NQE_OP_AND) s << "      const bool ok = (av && bv) || (av && !lb) || (bv && !rb), res = ok && lb && rb;\n";
+                else s << "      const bool ok = (av && bv) || lb || rb, res = ok && (lb || rb);\n";
+                s << "      " << t << "[r] = res ? 1ull : 0ull; " << tv << "[r] = ok;\n";
+            } else
+                s << "      " << t << "[r] = a " << (op == NQE_OP_AND ? "&" : "|") << " b;\n";
+        } else {
+            if (nulls) s << "      " << tv << "[r] = av && bv;\n";
+            if (op <= NQE_OP_GT_EQ) {
+                static const char *cmp[6] = {"==", "!=", "<", "<=", ">", ">="}; // NQE_OP_EQ … NQE_OP_GT_EQ
+                const char *c = cmp[op - NQE_OP_EQ];
+                if (dt == NQE_INT64) s << "      " << t << "[r] = ((i64)a " << c << " (i64)b) ? 1ull : 0ull;\n";
+                else if (dt == NQE_FLOAT64) s << "      " << t << "[r] = (u2d(a) " << c << " u2d(b)) ? 1ull : 0ull;\n";
+                else s << "      " << t << "[r] = (a " << c << " b) ? 1ull : 0ull;\n";
+            } else if (op == NQE_OP_PLUS || op == NQE_OP_MINUS || op == NQE_OP_MULTIPLY) {
+                const char *c = op == NQE_OP_PLUS ? "+" : op == NQE_OP_MINUS ? "-" : "*";
+                if (dt == NQE_FLOAT64) s << "      " << t << "[r] = d2u(u2d(a) " << c << " u2d(b));\n";
+                else s << "      " << t << "[r] = a " << c << " b;\n";
+            } else { // divide / modulus: a zero divisor (and MIN / -1) of a VALID row raises the flag, the word becomes 0
+                const bool div = op == NQE_OP_DIVIDE;
+                if (dt == NQE_FLOAT64) {
+                    s << "      if (u2d(b) == 0.0) { if (" << ok << ") atomicOr(&A.flags[" << NQE_FLAG_DIV_ZERO << "], 1); " << t << "[r] = 0; }\n"
+                      << "      else " << t << "[r] = d2u(" << (div ? "u2d(a) / u2d(b)" : "fmod(u2d(a), u2d(b))") << ");\n";
+                } else {
+                    s << "      if (b == 0) { if (" << ok << ") atomicOr(&A.flags[" << NQE_FLAG_DIV_ZERO << "], 1); " << t << "[r] = 0; }\n";
+                    if (dt == NQE_INT64) {
+                        s << "      else if ((i64)a == (i64)0x8000000000000000ull && (i64)b == -1) { if (" << ok << ") atomicOr(&A.flags[" << NQE_FLAG_OVERFLOW
+                          << "], 1); " << t << "[r] = 0; }\n"
+                          << "      else " << t << "[r] = (u64)((i64)a " << (div ? "/" : "%") << " (i64)b);\n";
+                    } else
+                        s << "      else " << t << "[r] = a " << (div ? "/" : "%") << " b;\n";
+                }
+            }
+        }
+        s << "    }\n";
+        st.push_back(t);
+        stv.push_back(nulls ? tv + "[r]" : "in[r]");
+    }
+    const std::string res = st.back(), resv = stv.back();
+    s << "#pragma unroll\n    for (int r = 0; r < R; ++r) {\n"
+      << "      const i64 row = row0 + r * 64;\n"
+      << "      if (row - lane >= n) break;\n"
+      << "      const bool ok = " << resv << ";\n";
+    if (!bool_out) s << "      if (row < n) __builtin_nontemporal_store(ok ? " << res << "[r] : 0ull, A.out_words + row);\n";
+    else s << "      { const u64 w = __ballot(ok && " << res << "[r]); if (lane == 0) A.out_bits[row >> 6] = w; }\n";
+    s << "      if (A.out_valid) { const u64 w = __ballot(ok); if (lane == 0) A.out_valid[row >> 6] = w; }\n"
+      << "    }\n  }\n}\n";
+    return s.str();
+}
+
+void jit_compile(JitEntry *e) {
+    const HipRtcApi &rt = hiprtc_api();
+    if (!rt.ok) {
+        e->log = "libhiprtc.so not available";
+        e->state.store(-1, std::memory_order_release);
+        return;
+    }
+    hiprtcProgram prog = nullptr;
+    bool good = rt.create(&prog, e->source.c_str(), "nqe_jit_expr.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS;
+    if (good) {
+        // -ffp-contract=off: `v * v + w` is two roundings in arrow (and in the interpreter, whose steps are separate), never an fma
+        const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+        good = rt.compile(prog, 4, opts) == HIPRTC_SUCCESS;
+        size_t ls = 0;
+        if (rt.log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+            e->log.resize(ls);
+            (void)rt.log(prog, &e->log[0]);
+        }
+        size_t cs = 0;
+        if (good) good = rt.code_size(prog, &cs) == HIPRTC_SUCCESS && cs > 0;
+        if (good) {
+            e->code.resize(cs);
+            good = rt.code(prog, e->code.data()) == HIPRTC_SUCCESS;
+        }
+    }
+    if (prog) (void)rt.destroy(&prog);
+    e->state.store(good ? 1 : -1, std::memory_order_release);
+}
+
+// The specialised kernel of P, if it is ready; starts its compilation otherwise (null: use the interpreter this time).
+JitEntry *jit_lookup(nqe_ctx *ctx, const ExProgram &P, bool nulls, bool bool_out) {
+    JitCache *cache = jit_cache(ctx);
+    const uint64_t key = jit_hash(P, nulls, bool_out);
+    auto it = cache->entries.find(key);
+    if (it == cache->entries.end()) {
+        if (cache->entries.size() >= 128) return nullptr; // (entries hold threads and modules: no eviction, just stop specialising)
+        auto e = std::make_unique<JitEntry>();
+        e->source = gen_source(P, nulls, bool_out);
+        JitEntry *raw = e.get();
+        if (const char *dump = getenv("NQE_JIT_DUMP")) { // diagnostics: the generated source, appended to this file
+            if (FILE *f = fopen(dump, "a")) {
+                fprintf(f, "// ---- %016llx\n%s\n", (unsigned long long)key, e->source.c_str());
+                fclose(f);
+            }
+        }
+        e->worker = std::thread(jit_compile, raw);
+        it = cache->entries.emplace(key, std::move(e)).first;
+        if (getenv("NQE_JIT_SYNC")) raw->worker.join(); // tests / benchmarks: compile before the first execution
+    }
+    JitEntry *e = it->second.get();
+    int st = e->state.load(std::memory_order_acquire);
+    if (st == 1) { // code ready: load it on this thread (the only one that makes HIP calls for the context)
+        if (e->worker.joinable()) e->worker.join();
+        const bool ok = hipModuleLoadData(&e->mod, e->code.data()) == hipSuccess && hipModuleGetFunction(&e->fn, e->mod, "nqe_jit_expr") == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            e->log = "hipModuleLoadData failed";
+        }
+        e->code.clear();
+        e->code.shrink_to_fit();
+        st = ok ? 2 : -1;
+        e->state.store(st, std::memory_order_release);
+    }
+    if (st == -1 && getenv("NQE_DEBUG") && !e->log.empty()) {
+        fprintf(stderr, "[nqe] expression specialisation failed: %s\n", e->log.c_str());
+        e->log.clear();
+    }
+    return st == 2 ? e : nullptr;
+}
+
+// Runs P specialised when that pays and the kernel is ready.  Returns false when the caller should interpret.
+bool jit_expr_tree(nqe_ctx *ctx, const ExProgram &P, bool nulls, int64_t rows, uint64_t *ow, uint64_t *ob, uint64_t *ov) {
+    // (read per call, not once per process: tests switch them around single calls)
+    const bool off = getenv("NQE_NO_JIT") != nullptr; // diagnostics (A/B)
+    const char *mr = getenv("NQE_JIT_MIN_ROWS");
+    const int64_t min_rows = mr ? atoll(mr) : (int64_t(1) << 22);
+    if (off || P.n < 3 || rows < min_rows) return false; // one or two steps run at the memory system's rate interpreted
+    JitEntry *e = jit_lookup(ctx, P, nulls, ob != nullptr);
+    if (!e) return false;
+    JitArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int c = 0; c < P.ncols; ++c) {
+        a.col[c] = P.col_values[c];
+        a.valid[c] = P.col_valid[c];
+    }
+    for (int i = 0; i < P.n; ++i) {
+        a.lit[2 * i] = P.ins[i].lit_a;
+        a.lit[2 * i + 1] = P.ins[i].lit_b;
+    }
+    a.n = rows;
+    a.out_words = ow;
+    a.out_bits = ob;
+    a.out_valid = ov;
+    a.flags = ctx->d_flags;
+    void *params[] = {&a};
+    const unsigned grid = unsigned(stream_grid(ctx, (rows + EX_ROWS - 1) / EX_ROWS, 256));
+    TimerScope t(ctx, "expr_jit");
+    ctx->flags_clean = false;
+    NQE_HIP_CHECK(hipModuleLaunchKernel(e->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+    return true;
+}
+
+// blocks until every compilation in flight has finished (tests: the next execution takes the specialised kernels)
+void jit_wait_all(nqe_ctx *ctx) {
+    if (!ctx->jit) return;
+    for (auto &kv : static_cast<JitCache *>(ctx->jit.get())->entries)
+        if (kv.second->worker.joinable()) kv.second->worker.join();
+}
+
+} // namespace
+} // namespace nqe

@@ -78,6 +78,8 @@ struct nqe_ctx {
     // rows, probe key column, probe rows): HashJoin::execute builds a fresh join table per call (nqe_hash_join_execute), so the
     // verdict has to outlive the table for the next execution of the same join to go straight to the two-pass form
     std::map<uint64_t, uint8_t> join_hints;
+    // run-time specialised expression kernels (expr_jit.hpp: JitCache — worker threads, code objects), created on first use
+    std::shared_ptr<void> jit;
 
     int *d_flags = nullptr; // NQE_NUM_FLAGS ints on the device
     int *h_flags = nullptr; // pinned host mirror
@@ -172,6 +174,8 @@ inline int stream_grid(nqe_ctx *ctx, int64_t work_items, int per_block, int bloc
 }
 
 void flags_reset(nqe_ctx *ctx);
+// expr.hip: waits for the run-time specialisations being compiled for this context
+void jit_wait(nqe_ctx *ctx);
 // synchronises the stream, returns flag values
 void flags_read(nqe_ctx *ctx, int out[NQE_NUM_FLAGS]);
 // the same when the last kernel of the stream copied the flags into the pinned mirror itself (no device-to-host copy)

@@ -1698,3 +1698,90 @@ def test_aggregate_measured_key_range_addresses_the_table_directly(ctx, kind):
     del t
     for p_ in (pk, pv, pw):
         ctx.device_free(p_)
+
+
+def test_expression_trees_specialised_at_run_time(ctx, monkeypatch):
+    """trees of three or more operators are also compiled to straight-line kernels at run time (csrc/expr_jit.hpp: hipRTC on a worker
+    thread; executions switch to the compiled form once it is ready).  Every tree here runs interpreted first, then — after
+    nqe_ctx_jit_wait — specialised (an `expr_jit` launch, no `expr_tree`), and both results must be bit-identical and equal to the
+    oracle's: integer wrap-around, literal and column divisors (DivideByZero and MIN / -1 must still raise), Float64 division and
+    fmod, compares of every type, Boolean results, Kleene and/or over nullable columns, a NULL literal, a Boolean input column.
+    A second literal value reuses the compiled kernel (literals other than baked divisors are arguments)."""
+    monkeypatch.setenv("NQE_JIT_MIN_ROWS", "1000")
+    rng = np.random.default_rng(2024)
+    n = 70_001
+    a = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    b = rng.integers(1, 50, n).astype(np.int64) * rng.choice([-1, 1], n)
+    u = rng.integers(0, 1 << 63, n).astype(np.uint64)
+    v = rng.random(n) * 200.0 - 100.0
+    v[::97] = np.nan
+    v[::89] = 0.0
+    bo = rng.random(n) < 0.5
+    cols_plain = [Column.from_numpy(a), Column.from_numpy(b), Column.from_numpy(u), Column.from_numpy(v), Column.from_numpy(bo)]
+    cols_null = [Column.from_numpy(a, rng.random(n) > 0.1), Column.from_numpy(b, rng.random(n) > 0.1), Column.from_numpy(u), Column.from_numpy(v, rng.random(n) > 0.2),
+                 Column.from_numpy(bo, rng.random(n) > 0.3)]
+    f5 = fields("a", "b", "u", "v", "bo")
+    A, B, U, V, BO = (col(i) for i in range(5))
+    O = Operator
+    X = binop
+    trees = [
+        X(X(X(X(A, O.Plus, lit_i64(1)), O.Plus, lit_i64(2)), O.Multiply, lit_i64(3)), O.Minus, lit_i64(7)),
+        X(X(X(A, O.Modulos, lit_i64(1000)), O.Multiply, lit_i64(3)), O.Plus, X(A, O.Divide, lit_i64(7))),
+        X(X(X(A, O.Divide, lit_i64(-8)), O.Plus, X(A, O.Modulos, lit_i64(-16))), O.Minus, X(lit_i64(100), O.Minus, B)),
+        X(X(X(A, O.Plus, B), O.Divide, B), O.Plus, X(A, O.Modulos, B)),                       # column divisors (never zero here)
+        X(X(X(U, O.Divide, lit_u64(10)), O.Plus, X(U, O.Modulos, lit_u64(1 << 20))), O.Multiply, lit_u64(3)),
+        X(X(X(V, O.Multiply, V), O.Plus, X(V, O.Divide, lit_f64(4.0))), O.Minus, X(V, O.Modulos, lit_f64(7.5))),
+        X(X(X(V, O.Gt, lit_f64(50.0)), O.And, X(X(A, O.Modulos, lit_i64(3)), O.Eq, lit_i64(0))), O.Or, BO),
+        X(X(X(A, O.Lt, B), O.Or, X(U, O.GtEq, lit_u64(1 << 62))), O.And, X(X(V, O.NotEq, V), O.Or, X(V, O.LtEq, lit_f64(0.0)))),
+        X(X(X(A, O.Plus, lit_i64(5)), O.Multiply, B), O.Gt, X(B, O.Multiply, lit_i64(1000))),
+    ]
+    faulting = [
+        X(X(X(A, O.Plus, lit_i64(1)), O.Divide, X(B, O.Minus, B)), O.Plus, lit_i64(1)),      # DivideByZero
+        X(X(X(A, O.Minus, A), O.Plus, lit_i64(-(1 << 63))), O.Divide, lit_i64(-1)),         # i64::MIN / -1
+        X(X(X(V, O.Plus, lit_f64(1.0)), O.Divide, X(V, O.Minus, V)), O.Plus, lit_f64(1.0)),  # Float64 zero divisor (NaN - NaN is not zero; 0 - 0 is)
+    ]
+    for cols in (cols_plain, cols_null):
+        t = ctx.table_from_host(cols)
+        for tree in trees + faulting:
+            nodes = tree.flatten(f5)
+            try:
+                exp = orc.expr_evaluate([cols], nodes)
+                err = None
+            except ErrorCode as e:
+                exp, err = None, e
+            results = []
+            for phase in ("interpreted", "specialised"):
+                ctx.timing_enable(True)
+                ctx.timing_reset()
+                try:
+                    got = ctx.expr_evaluate(t, nodes).to_host()[0]
+                    gerr = None
+                except ErrorCode as e:
+                    got, gerr = None, e
+                ctx.timing_enable(False)
+                names = ctx.timing_report()
+                if phase == "interpreted":
+                    ctx.jit_wait()
+                elif gerr is None or "expr_jit" in names:
+                    assert "expr_jit" in names and "expr_tree" not in names, (names, repr(tree))
+                results.append((got, gerr))
+            (g0, e0), (g1, e1) = results
+            assert (e0 is None) == (e1 is None), repr(tree)
+            if e0 is not None:
+                assert e0.status == e1.status and (tree in faulting), repr(tree)
+                if err is not None:
+                    assert err.status == e0.status
+                continue
+            assert_column_equal(g1, g0, what=f"specialised vs interpreted {tree!r}")
+            if exp is not None:
+                assert_column_equal(g1, exp, what=f"specialised vs oracle {tree!r}")
+    # another literal, same shape: no new compilation (the kernel is ready at once), still right
+    t = ctx.table_from_host(cols_plain)
+    for k in (11, 12345):
+        tree = X(X(X(X(A, O.Plus, lit_i64(k)), O.Plus, lit_i64(2)), O.Multiply, lit_i64(3)), O.Minus, lit_i64(7))
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got = ctx.expr_evaluate(t, tree.flatten(f5)).to_host()[0]
+        ctx.timing_enable(False)
+        assert "expr_jit" in ctx.timing_report()
+        assert (got.to_numpy() == ((a + np.int64(k) + 2) * 3 - 7)).all()

@@ -29,6 +29,9 @@ def timeit(fn, reps=5, warm=2):
     for _ in range(warm):
         r = fn(); del r
     ctx.synchronize()
+    ctx.jit_wait()  # expression trees: the steady state is the run-time specialised kernel (NQE_NO_JIT=1 for the interpreter)
+    r = fn(); del r
+    ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         r = fn(); del r
