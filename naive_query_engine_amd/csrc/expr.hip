@@ -1048,6 +1048,90 @@ bool evaluate_expr_compacted(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_n
     return true;
 }
 
+bool project_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, const int32_t *expr_offsets, int num_exprs, const KeepMask &km,
+                         std::vector<DevColumn> *result) {
+    const char *mr = getenv("NQE_JIT_MIN_ROWS");
+    const int64_t min_rows = mr ? atoll(mr) : (int64_t(1) << 22);
+    if (getenv("NQE_NO_JIT") || num_exprs < 1 || num_exprs > JP_MAX_OUTS || km.n < min_rows || km.total <= 0) return false;
+    JitProj J;
+    std::memset(J.col_values, 0, sizeof(J.col_values));
+    std::memset(J.col_valid, 0, sizeof(J.col_valid));
+    std::memset(J.col_dtype, 0, sizeof(J.col_dtype));
+    J.nulls = km.pvalid != nullptr;
+    auto slot_of = [&](const void *values, const uint8_t *valid, int dtype) {
+        for (int k = 0; k < J.ncols; ++k)
+            if (J.col_values[k] == values && J.col_valid[k] == valid && J.col_dtype[k] == dtype) return k;
+        if (J.ncols == JP_MAX_COLS) return -1;
+        J.col_values[J.ncols] = values;
+        J.col_valid[J.ncols] = valid;
+        J.col_dtype[J.ncols] = dtype;
+        return J.ncols++;
+    };
+    int steps = 0;
+    for (int e = 0; e < num_exprs; ++e) {
+        int root;
+        std::vector<Node> t = parse(in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e], &root);
+        const Node &rt = t[size_t(root)];
+        JitProjOut o;
+        o.out_dtype = rt.out_dtype;
+        if (rt.kind == NQE_EXPR_COLUMN) {
+            const DevColumn &c = in->cols[size_t(rt.column)];
+            if (!is_word_type(c.dtype) || c.length < km.n) return false; // (Boolean / Utf8 columns: their own compaction kernels)
+            o.is_column = true;
+            o.col = slot_of(c.values->ptr, c.valid(), c.dtype);
+            if (o.col < 0) return false;
+            o.needs_valid = c.validity != nullptr || km.pvalid != nullptr;
+            J.nulls = J.nulls || c.validity != nullptr;
+        } else if (rt.kind == NQE_EXPR_BINARY) {
+            bool nv = false;
+            if (!build_program(in, t, root, &o.P, &nv)) return false;
+            for (int i = 0; i < o.P.n; ++i) {
+                ExInstr &I = o.P.ins[i];
+                for (int32_t *src : {&I.a_src, &I.b_src}) {
+                    if (*src < EX_COL) continue;
+                    const int k = *src - EX_COL, u = slot_of(o.P.col_values[k], o.P.col_valid[k], o.P.col_dtype[k]);
+                    if (u < 0) return false;
+                    *src = EX_COL + u;
+                }
+            }
+            o.bool_out = rt.out_dtype == NQE_BOOLEAN;
+            o.needs_valid = nv || km.pvalid != nullptr;
+            J.nulls = J.nulls || nv;
+            steps += o.P.n;
+        } else
+            return false; // a bare literal
+        J.outs.push_back(o);
+    }
+    // one output with one or two steps is at the memory system's rate interpreted (compact_expr / the machine): nothing to gain
+    if (num_exprs == 1 && steps < 3) return false;
+    // outputs
+    const int64_t m = km.total;
+    std::vector<DevColumn> cols;
+    std::vector<BufRef> bool_bytes(static_cast<size_t>(num_exprs)), valid_bytes(static_cast<size_t>(num_exprs));
+    uint64_t *ow[JP_MAX_OUTS] = {};
+    uint8_t *ob[JP_MAX_OUTS] = {}, *ov[JP_MAX_OUTS] = {};
+    for (int e = 0; e < num_exprs; ++e) {
+        const JitProjOut &o = J.outs[size_t(e)];
+        cols.push_back(o.bool_out ? make_bool_column(ctx, m, o.needs_valid) : make_word_column(ctx, o.out_dtype, m, o.needs_valid));
+        if (o.bool_out) {
+            bool_bytes[size_t(e)] = dev_alloc(ctx, size_t(m) + 8);
+            ob[e] = (uint8_t *)bool_bytes[size_t(e)]->ptr;
+        } else
+            ow[e] = (uint64_t *)cols.back().values->ptr;
+        if (o.needs_valid) {
+            valid_bytes[size_t(e)] = dev_alloc(ctx, size_t(m) + 8);
+            ov[e] = (uint8_t *)valid_bytes[size_t(e)]->ptr;
+        }
+    }
+    if (!jit_project(ctx, J, km, ow, ob, ov)) return false;
+    for (int e = 0; e < num_exprs; ++e) {
+        if (ob[e]) pack_bytes_to_bits(ctx, ob[e], m, (uint64_t *)cols[size_t(e)].values->ptr);
+        if (ov[e]) pack_bytes_to_bits(ctx, ov[e], m, (uint64_t *)cols[size_t(e)].validity->ptr);
+    }
+    *result = std::move(cols);
+    return true;
+}
+
 } // namespace nqe
 
 using namespace nqe;

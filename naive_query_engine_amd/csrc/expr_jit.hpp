@@ -121,38 +121,11 @@ uint64_t jit_hash(const ExProgram &P, bool nulls, bool bool_out) {
 }
 
 // ---- source generation
-std::string gen_source(const ExProgram &P, bool nulls, bool bool_out) {
-    std::ostringstream s;
-    s << "#pragma clang fp contract(off)\n" // (hipRTC's own -ffp-contract=fast-honor-pragmas comes after the caller's options)
-      << "typedef unsigned long long u64; typedef long long i64; typedef unsigned int u32;\n"
-      << "#define R " << EX_ROWS << "\n"
-      << "struct Args { const void *col[" << EX_MAX_COLS << "]; const unsigned char *valid[" << EX_MAX_COLS << "]; u64 lit[" << JIT_MAX_LITS
-      << "]; i64 n; u64 *out_words, *out_bits, *out_valid; int *flags; };\n"
-      << "static __device__ __forceinline__ double u2d(u64 w) { return __longlong_as_double((i64)w); }\n"
-      << "static __device__ __forceinline__ u64 d2u(double d) { return (u64)__double_as_longlong(d); }\n"
-      << "extern \"C\" __global__ void __launch_bounds__(256) nqe_jit_expr(Args A) {\n"
-      << "  const int lane = threadIdx.x & 63;\n"
-      << "  const i64 n = A.n, n_chunks = (n + 64 * R - 1) / (64 * R);\n"
-      << "  const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;\n"
-      << "  for (i64 chunk = wave; chunk < n_chunks; chunk += n_waves) {\n"
-      << "    const i64 row0 = chunk * (64 * R) + lane;\n"
-      << "    i64 rc[R]; bool in[R];\n"
-      << "#pragma unroll\n"
-      << "    for (int r = 0; r < R; ++r) { const i64 row = row0 + r * 64; in[r] = row < n; rc[r] = row < n - 1 ? row : n - 1; }\n";
-    // every load of the chunk first
-    for (int c = 0; c < P.ncols; ++c) {
-        s << "    u64 c" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) ";
-        if (P.col_dtype[c] == NQE_BOOLEAN) s << "c" << c << "[r] = ((const unsigned char *)A.col[" << c << "])[rc[r] >> 3];\n";
-        else s << "c" << c << "[r] = __builtin_nontemporal_load((const u64 *)A.col[" << c << "] + rc[r]);\n";
-        if (nulls && P.col_valid[c])
-            s << "    u32 vb" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) vb" << c << "[r] = A.valid[" << c << "][rc[r] >> 3];\n";
-    }
-    for (int c = 0; c < P.ncols; ++c) {
-        if (P.col_dtype[c] == NQE_BOOLEAN) s << "#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "[r] = (c" << c << "[r] >> ((int)rc[r] & 7)) & 1ull;\n";
-        if (nulls && P.col_valid[c])
-            s << "    bool c" << c << "v[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "v[r] = in[r] && ((vb" << c << "[r] >> ((int)rc[r] & 7)) & 1u);\n";
-    }
-    // the program: a stack of value names
+// Emits the steps of P (column slots already in the kernel's numbering: values c<k>[r], validity c<k>v[r] where col_has_valid[k])
+// as one unrolled R-row loop per step; returns the names of the result's value array and validity expression.
+// `in[r]`: the row takes part (and its column values count); lit_valid: the validity of a non-NULL literal.
+std::pair<std::string, std::string> emit_steps(std::ostringstream &s, const ExProgram &P, const bool *col_has_valid, bool nulls, const std::string &prefix,
+                                               const std::string &lit_array, const std::string &lit_valid) {
     std::vector<std::string> st, stv;
     auto hex = [](uint64_t v) {
         std::ostringstream o;
@@ -167,10 +140,10 @@ std::string gen_source(const ExProgram &P, bool nulls, bool bool_out) {
             if (src >= EX_COL) {
                 const int c = src - EX_COL;
                 w = "c" + std::to_string(c) + "[r]";
-                v = (nulls && P.col_valid[c]) ? "c" + std::to_string(c) + "v[r]" : "in[r]";
+                v = (nulls && col_has_valid[c]) ? "c" + std::to_string(c) + "v[r]" : "in[r]";
             } else {
-                w = (which == 1 && jit_bakes_b(in)) ? hex(in.lit_b) : "A.lit[" + std::to_string(2 * i + which) + "]";
-                v = src == EX_LIT ? "in[r]" : "false";
+                w = (which == 1 && jit_bakes_b(in)) ? hex(in.lit_b) : lit_array + "[" + std::to_string(2 * i + which) + "]";
+                v = src == EX_LIT ? lit_valid : "false";
             }
         };
         if (a_st && b_st) {
@@ -186,7 +159,7 @@ std::string gen_source(const ExProgram &P, bool nulls, bool bool_out) {
             operand(in.a_src, 0, a, av);
             operand(in.b_src, 1, b, bv);
         }
-        const std::string t = "t" + std::to_string(i), tv = t + "v";
+        const std::string t = prefix + std::to_string(i), tv = t + "v";
         s << "    u64 " << t << "[R];";
         if (nulls) s << " bool " << tv << "[R];";
         s << "\n#pragma unroll\n    for (int r = 0; r < R; ++r) {\n      const u64 a = " << a << ", b = " << b << ";\n";
@@ -233,7 +206,44 @@ std::string gen_source(const ExProgram &P, bool nulls, bool bool_out) {
         st.push_back(t);
         stv.push_back(nulls ? tv + "[r]" : "in[r]");
     }
-    const std::string res = st.back(), resv = stv.back();
+    return {st.back(), stv.back()};
+}
+
+std::string gen_source(const ExProgram &P, bool nulls, bool bool_out) {
+    std::ostringstream s;
+    s << "#pragma clang fp contract(off)\n" // (hipRTC's own -ffp-contract=fast-honor-pragmas comes after the caller's options)
+      << "typedef unsigned long long u64; typedef long long i64; typedef unsigned int u32;\n"
+      << "#define R " << EX_ROWS << "\n"
+      << "struct Args { const void *col[" << EX_MAX_COLS << "]; const unsigned char *valid[" << EX_MAX_COLS << "]; u64 lit[" << JIT_MAX_LITS
+      << "]; i64 n; u64 *out_words, *out_bits, *out_valid; int *flags; };\n"
+      << "static __device__ __forceinline__ double u2d(u64 w) { return __longlong_as_double((i64)w); }\n"
+      << "static __device__ __forceinline__ u64 d2u(double d) { return (u64)__double_as_longlong(d); }\n"
+      << "extern \"C\" __global__ void __launch_bounds__(256) nqe_jit_expr(Args A) {\n"
+      << "  const int lane = threadIdx.x & 63;\n"
+      << "  const i64 n = A.n, n_chunks = (n + 64 * R - 1) / (64 * R);\n"
+      << "  const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;\n"
+      << "  for (i64 chunk = wave; chunk < n_chunks; chunk += n_waves) {\n"
+      << "    const i64 row0 = chunk * (64 * R) + lane;\n"
+      << "    i64 rc[R]; bool in[R];\n"
+      << "#pragma unroll\n"
+      << "    for (int r = 0; r < R; ++r) { const i64 row = row0 + r * 64; in[r] = row < n; rc[r] = row < n - 1 ? row : n - 1; }\n";
+    // every load of the chunk first
+    for (int c = 0; c < P.ncols; ++c) {
+        s << "    u64 c" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) ";
+        if (P.col_dtype[c] == NQE_BOOLEAN) s << "c" << c << "[r] = ((const unsigned char *)A.col[" << c << "])[rc[r] >> 3];\n";
+        else s << "c" << c << "[r] = __builtin_nontemporal_load((const u64 *)A.col[" << c << "] + rc[r]);\n";
+        if (nulls && P.col_valid[c])
+            s << "    u32 vb" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) vb" << c << "[r] = A.valid[" << c << "][rc[r] >> 3];\n";
+    }
+    for (int c = 0; c < P.ncols; ++c) {
+        if (P.col_dtype[c] == NQE_BOOLEAN) s << "#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "[r] = (c" << c << "[r] >> ((int)rc[r] & 7)) & 1ull;\n";
+        if (nulls && P.col_valid[c])
+            s << "    bool c" << c << "v[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "v[r] = in[r] && ((vb" << c << "[r] >> ((int)rc[r] & 7)) & 1u);\n";
+    }
+    bool has_valid[EX_MAX_COLS];
+    for (int c = 0; c < EX_MAX_COLS; ++c) has_valid[c] = c < P.ncols && P.col_valid[c] != nullptr;
+    const auto result = emit_steps(s, P, has_valid, nulls, "t", "A.lit", "in[r]");
+    const std::string res = result.first, resv = result.second;
     s << "#pragma unroll\n    for (int r = 0; r < R; ++r) {\n"
       << "      const i64 row = row0 + r * 64;\n"
       << "      if (row - lane >= n) break;\n"
@@ -275,14 +285,13 @@ void jit_compile(JitEntry *e) {
 }
 
 // The specialised kernel of P, if it is ready; starts its compilation otherwise (null: use the interpreter this time).
-JitEntry *jit_lookup(nqe_ctx *ctx, const ExProgram &P, bool nulls, bool bool_out) {
+template <class MakeSource> JitEntry *jit_get(nqe_ctx *ctx, uint64_t key, const char *kernel_name, MakeSource &&make_source) {
     JitCache *cache = jit_cache(ctx);
-    const uint64_t key = jit_hash(P, nulls, bool_out);
     auto it = cache->entries.find(key);
     if (it == cache->entries.end()) {
         if (cache->entries.size() >= 128) return nullptr; // (entries hold threads and modules: no eviction, just stop specialising)
         auto e = std::make_unique<JitEntry>();
-        e->source = gen_source(P, nulls, bool_out);
+        e->source = make_source();
         JitEntry *raw = e.get();
         if (const char *dump = getenv("NQE_JIT_DUMP")) { // diagnostics: the generated source, appended to this file
             if (FILE *f = fopen(dump, "a")) {
@@ -298,7 +307,7 @@ JitEntry *jit_lookup(nqe_ctx *ctx, const ExProgram &P, bool nulls, bool bool_out
     int st = e->state.load(std::memory_order_acquire);
     if (st == 1) { // code ready: load it on this thread (the only one that makes HIP calls for the context)
         if (e->worker.joinable()) e->worker.join();
-        const bool ok = hipModuleLoadData(&e->mod, e->code.data()) == hipSuccess && hipModuleGetFunction(&e->fn, e->mod, "nqe_jit_expr") == hipSuccess;
+        const bool ok = hipModuleLoadData(&e->mod, e->code.data()) == hipSuccess && hipModuleGetFunction(&e->fn, e->mod, kernel_name) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
             e->log = "hipModuleLoadData failed";
@@ -322,7 +331,8 @@ bool jit_expr_tree(nqe_ctx *ctx, const ExProgram &P, bool nulls, int64_t rows, u
     const char *mr = getenv("NQE_JIT_MIN_ROWS");
     const int64_t min_rows = mr ? atoll(mr) : (int64_t(1) << 22);
     if (off || P.n < 3 || rows < min_rows) return false; // one or two steps run at the memory system's rate interpreted
-    JitEntry *e = jit_lookup(ctx, P, nulls, ob != nullptr);
+    const bool bool_out = ob != nullptr;
+    JitEntry *e = jit_get(ctx, jit_hash(P, nulls, bool_out), "nqe_jit_expr", [&] { return gen_source(P, nulls, bool_out); });
     if (!e) return false;
     JitArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -342,6 +352,177 @@ bool jit_expr_tree(nqe_ctx *ctx, const ExProgram &P, bool nulls, int64_t rows, u
     void *params[] = {&a};
     const unsigned grid = unsigned(stream_grid(ctx, (rows + EX_ROWS - 1) / EX_ROWS, 256));
     TimerScope t(ctx, "expr_jit");
+    ctx->flags_clean = false;
+    NQE_HIP_CHECK(hipModuleLaunchKernel(e->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+    return true;
+}
+
+
+// ---- the projection behind a selection, every output in ONE pass over the kept rows
+// (expr_tree_compact_kernel's job — one wave per 4096-row tile of the keep bitmap, results written straight to their compacted
+// positions, a NULL predicate emits a NULL row, dropped rows never evaluate — for the whole projection list at once: each
+// referenced column is read once whatever the number of outputs that use it; bare columns are outputs like any other)
+constexpr int JP_MAX_COLS = 8, JP_MAX_OUTS = 4;
+struct JitProjOut {
+    bool is_column = false; // a bare column: slot `col`
+    int col = 0;
+    bool bool_out = false, needs_valid = false;
+    int out_dtype = NQE_INT64;
+    ExProgram P; // column operands renumbered to the projection's slots (col_values etc. unused)
+};
+struct JitProj {
+    int ncols = 0;
+    const void *col_values[JP_MAX_COLS];
+    const uint8_t *col_valid[JP_MAX_COLS];
+    int32_t col_dtype[JP_MAX_COLS];
+    std::vector<JitProjOut> outs;
+    bool nulls = false; // some column carries validity, some literal is NULL, or the predicate was NULL on some row
+};
+struct JitProjArgs {
+    const void *col[JP_MAX_COLS];
+    const uint8_t *valid[JP_MAX_COLS];
+    uint64_t lit[JP_MAX_OUTS][JIT_MAX_LITS];
+    const uint64_t *keep, *pvalid, *tile_offsets;
+    int64_t n, ntiles;
+    uint64_t *out_words[JP_MAX_OUTS];
+    uint8_t *out_bool[JP_MAX_OUTS], *out_valid[JP_MAX_OUTS];
+    int *flags;
+};
+
+uint64_t jit_hash_proj(const JitProj &J) {
+    uint64_t h = 1469598103934665603ull ^ 0x70726f6aull;
+    auto mix = [&](const void *p, size_t nb) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < nb; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    const int32_t head[3] = {J.ncols, int32_t(J.outs.size()), J.nulls ? 1 : 0};
+    mix(head, sizeof(head));
+    for (int c = 0; c < J.ncols; ++c) {
+        const int32_t cd[2] = {J.col_dtype[c], (J.nulls && J.col_valid[c]) ? 1 : 0};
+        mix(cd, sizeof(cd));
+    }
+    for (const JitProjOut &o : J.outs) {
+        const int32_t od[5] = {o.is_column ? 1 : 0, o.col, o.bool_out ? 1 : 0, o.needs_valid ? 1 : 0, o.is_column ? 0 : o.P.n};
+        mix(od, sizeof(od));
+        if (o.is_column) continue;
+        for (int i = 0; i < o.P.n; ++i) {
+            const ExInstr &in = o.P.ins[i];
+            const int32_t w[4] = {in.op, in.dt, in.a_src, in.b_src};
+            mix(w, sizeof(w));
+            if (jit_bakes_b(in)) mix(&in.lit_b, 8);
+        }
+    }
+    return h ? h : 1;
+}
+
+std::string gen_source_proj(const JitProj &J) {
+    std::ostringstream s;
+    const bool nulls = J.nulls;
+    s << "#pragma clang fp contract(off)\n"
+      << "typedef unsigned long long u64; typedef long long i64; typedef unsigned int u32;\n"
+      << "#define R " << EX_ROWS << "\n"
+      << "struct Args { const void *col[" << JP_MAX_COLS << "]; const unsigned char *valid[" << JP_MAX_COLS << "]; u64 lit[" << JP_MAX_OUTS << "][" << JIT_MAX_LITS
+      << "]; const u64 *keep, *pvalid, *tile_offsets; i64 n, ntiles; u64 *out_words[" << JP_MAX_OUTS << "]; unsigned char *out_bool[" << JP_MAX_OUTS
+      << "], *out_valid[" << JP_MAX_OUTS << "]; int *flags; };\n"
+      << "static __device__ __forceinline__ double u2d(u64 w) { return __longlong_as_double((i64)w); }\n"
+      << "static __device__ __forceinline__ u64 d2u(double d) { return (u64)__double_as_longlong(d); }\n"
+      << "extern \"C\" __global__ void __launch_bounds__(256) nqe_jit_proj(Args A) {\n"
+      << "  const int lane = threadIdx.x & 63, wpb = blockDim.x / 64;\n"
+      << "  const i64 n = A.n, nwords = (n + 63) / 64;\n"
+      << "  const u64 lt = (1ull << lane) - 1ull;\n"
+      << "  for (i64 tile = (i64)blockIdx.x * wpb + threadIdx.x / 64; tile < A.ntiles; tile += (i64)gridDim.x * wpb) {\n"
+      << "    const i64 w = tile * 64 + lane;\n"
+      << "    const u64 my_word = w < nwords ? A.keep[w] : 0ull;\n"
+      << "    const u64 my_pv = (A.pvalid && w < nwords) ? A.pvalid[w] : ~0ull;\n"
+      << "    const u32 cnt = (u32)__popcll(my_word);\n"
+      << "    u32 off = cnt;\n"
+      << "    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(off, d, 64); if (lane >= d) off += t; }\n"
+      << "    const u32 tot = __shfl(off, 63, 64);\n"
+      << "    off -= cnt;\n"
+      << "    if (tot == 0) continue;\n"
+      << "    const u64 base = A.tile_offsets[tile];\n"
+      << "    for (int k0 = 0; k0 < 64; k0 += R) {\n"
+      << "    u64 kw[R]; u32 po[R]; bool in[R], emit[R]; bool anyk = false;\n"
+      << "#pragma unroll\n"
+      << "    for (int r = 0; r < R; ++r) {\n"
+      << "      kw[r] = __shfl(my_word, k0 + r, 64);\n"
+      << "      const u64 pv = __shfl(my_pv, k0 + r, 64);\n"
+      << "      anyk = anyk || kw[r] != 0;\n"
+      << "      emit[r] = (kw[r] >> lane) & 1ull;\n"          // every emitted row: literals are valid there
+      << "      in[r] = ((kw[r] & pv) >> lane) & 1ull;\n"      // … whose predicate was valid: column values count
+      << "      po[r] = __shfl(off, k0 + r, 64) + (u32)__popcll(kw[r] & lt);\n" // position inside the tile's output range (all lanes active here)
+      << "    }\n"
+      << "    if (!anyk) continue;\n"
+      << "    const i64 row0 = (tile * 64 + k0) * 64 + lane;\n"
+      << "    i64 rc[R];\n"
+      << "#pragma unroll\n"
+      << "    for (int r = 0; r < R; ++r) { const i64 row = row0 + r * 64; rc[r] = row < n - 1 ? row : n - 1; }\n";
+    bool has_valid[JP_MAX_COLS];
+    for (int c = 0; c < JP_MAX_COLS; ++c) has_valid[c] = c < J.ncols && nulls && J.col_valid[c] != nullptr;
+    for (int c = 0; c < J.ncols; ++c) {
+        s << "    u64 c" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) ";
+        if (J.col_dtype[c] == NQE_BOOLEAN) s << "c" << c << "[r] = ((const unsigned char *)A.col[" << c << "])[rc[r] >> 3];\n";
+        else s << "c" << c << "[r] = __builtin_nontemporal_load((const u64 *)A.col[" << c << "] + rc[r]);\n";
+        if (has_valid[c]) s << "    u32 vb" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) vb" << c << "[r] = A.valid[" << c << "][rc[r] >> 3];\n";
+    }
+    for (int c = 0; c < J.ncols; ++c) {
+        if (J.col_dtype[c] == NQE_BOOLEAN) s << "#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "[r] = (c" << c << "[r] >> ((int)rc[r] & 7)) & 1ull;\n";
+        if (has_valid[c])
+            s << "    bool c" << c << "v[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "v[r] = in[r] && ((vb" << c << "[r] >> ((int)rc[r] & 7)) & 1u);\n";
+    }
+    std::vector<std::pair<std::string, std::string>> results;
+    for (size_t o = 0; o < J.outs.size(); ++o) {
+        const JitProjOut &out = J.outs[o];
+        if (out.is_column) results.push_back({"c" + std::to_string(out.col), has_valid[out.col] ? "c" + std::to_string(out.col) + "v[r]" : "in[r]"});
+        else results.push_back(emit_steps(s, out.P, has_valid, nulls, "t" + std::to_string(o) + "_", "A.lit[" + std::to_string(o) + "]", "emit[r]"));
+    }
+    s << "#pragma unroll\n    for (int r = 0; r < R; ++r) {\n"
+      << "      if (!emit[r]) continue;\n"
+      << "      const u64 pos = base + po[r];\n";
+    std::string body;
+    for (size_t o = 0; o < J.outs.size(); ++o) {
+        const JitProjOut &out = J.outs[o];
+        std::ostringstream b;
+        b << "      { const bool ok = " << results[o].second << "; const u64 v = " << results[o].first << "[r];\n";
+        if (!out.bool_out) b << "        __builtin_nontemporal_store(ok ? v : 0ull, A.out_words[" << o << "] + pos);\n";
+        else b << "        A.out_bool[" << o << "][pos] = (ok && v) ? 1 : 0;\n";
+        if (out.needs_valid) b << "        A.out_valid[" << o << "][pos] = ok ? 1 : 0;\n";
+        b << "      }\n";
+        body += b.str();
+    }
+    s << body << "    }\n    }\n  }\n}\n";
+    return s.str();
+}
+
+// launches the fused projection when its kernel is ready; false: the caller takes the per-expression path
+bool jit_project(nqe_ctx *ctx, const JitProj &J, const KeepMask &km, uint64_t *const *out_words, uint8_t *const *out_bool, uint8_t *const *out_valid) {
+    JitEntry *e = jit_get(ctx, jit_hash_proj(J), "nqe_jit_proj", [&] { return gen_source_proj(J); });
+    if (!e) return false;
+    JitProjArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int c = 0; c < J.ncols; ++c) {
+        a.col[c] = J.col_values[c];
+        a.valid[c] = J.col_valid[c];
+    }
+    for (size_t o = 0; o < J.outs.size(); ++o) {
+        if (!J.outs[o].is_column)
+            for (int i = 0; i < J.outs[o].P.n; ++i) {
+                a.lit[o][2 * i] = J.outs[o].P.ins[i].lit_a;
+                a.lit[o][2 * i + 1] = J.outs[o].P.ins[i].lit_b;
+            }
+        a.out_words[o] = out_words[o];
+        a.out_bool[o] = out_bool[o];
+        a.out_valid[o] = out_valid[o];
+    }
+    a.keep = (const uint64_t *)km.keep->ptr;
+    a.pvalid = km.pvalid ? (const uint64_t *)km.pvalid->ptr : nullptr;
+    a.tile_offsets = (const uint64_t *)km.tile_offsets->ptr;
+    a.n = km.n;
+    a.ntiles = km.ntiles;
+    a.flags = ctx->d_flags;
+    void *params[] = {&a};
+    const unsigned grid = unsigned(stream_grid(ctx, km.ntiles, 4));
+    TimerScope t(ctx, "proj_jit");
     ctx->flags_clean = false;
     NQE_HIP_CHECK(hipModuleLaunchKernel(e->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
     return true;

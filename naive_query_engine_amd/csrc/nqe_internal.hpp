@@ -371,6 +371,10 @@ DevColumn utf8_compare(nqe_ctx *ctx, int op, const DevColumn *lcol, const std::s
 DevColumn utf8_literal_column(nqe_ctx *ctx, const std::string &lit, bool lit_null, int64_t n);
 // general tree `nodes` over the rows of `km`, compacted in the same pass; false = does not fit the stack machine
 bool evaluate_expr_compacted(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, int n, const KeepMask &km, DevColumn *result);
+// the whole projection list behind a selection in ONE run-time specialised kernel (expr_jit.hpp); false when the list does not fit it
+// or its kernel is not compiled yet (the caller then takes the per-expression path)
+bool project_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, const int32_t *expr_offsets, int num_exprs, const KeepMask &km,
+                         std::vector<DevColumn> *out);
 // evaluates `e` over `in` and compacts the result in the same pass
 DevColumn compact_simple_expr(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &e, const KeepMask &km);
 

@@ -400,7 +400,19 @@ static KeepMask mask_for_predicate(nqe_ctx *ctx, const nqe_table *in, const nqe_
     ExprInfo info = analyze_expr(in, pred, pred_nodes);
     if (info.out_dtype != NQE_BOOLEAN)
         fail(NQE_ERR_NOT_SUPPORTED, "predicate is not a BooleanArray (selection.rs:61 unwrap panics)");
-    if (info.simple) return build_keep_mask_simple(ctx, in, info.s);
+    if (info.simple) {
+        // a chain that is not a range test (`(id + 1) % 10 < 5`) over a large plain column: keep_from_simple_kernel<0> interprets it
+        // row by row (1.6 TB/s); the expression machine — tile-wise, and specialised at run time from three steps on — writes the
+        // Boolean column at 5+ TB/s, and the mask pass over 1 bit per row is nearly free
+        const DevColumn &c = in->cols[size_t(info.s.col)];
+        FastPred fp{};
+        static const bool off = getenv("NQE_NO_CHAIN_VIA_MACHINE") != nullptr; // diagnostics (A/B)
+        if (!off && info.s.nops >= 2 && in->rows >= (int64_t(1) << 20) && is_word_type(c.dtype) && !c.validity && !make_fast_pred(info.s, &fp)) {
+            DevColumn p = evaluate_expr(ctx, in, pred, pred_nodes);
+            return build_keep_mask(ctx, p, in->rows);
+        }
+        return build_keep_mask_simple(ctx, in, info.s);
+    }
     ConjPred conj;
     int conj_cols[CONJ_MAX];
     if (match_conj(in, pred, pred_nodes, &conj, conj_cols)) return build_keep_mask_conj(ctx, in, conj, conj_cols);
@@ -470,7 +482,12 @@ nqe_status nqe_selection_projection_execute(nqe_ctx *ctx, const nqe_table *in, c
     // compacted in one pass over the columns it references; otherwise compact the inputs once, then evaluate on the
     // compacted batch.  In every case rows the filter dropped can never raise DivideByZero, as in the reference.
     std::unique_ptr<nqe_table> sel;
-    for (int e = 0; e < num_exprs; ++e) {
+    // large inputs: the whole list in one run-time specialised pass over the kept rows, once that kernel has been compiled
+    std::vector<DevColumn> fused;
+    const bool all_fused = project_specialised(ctx, in, nodes, expr_offsets, num_exprs, km, &fused);
+    if (all_fused)
+        for (auto &c : fused) t->cols.push_back(std::move(c));
+    for (int e = 0; e < num_exprs && !all_fused; ++e) {
         const nqe_expr_node *en = nodes + expr_offsets[e];
         const int nn = expr_offsets[e + 1] - expr_offsets[e];
         DevColumn c;

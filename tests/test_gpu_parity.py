@@ -1785,3 +1785,66 @@ def test_expression_trees_specialised_at_run_time(ctx, monkeypatch):
         ctx.timing_enable(False)
         assert "expr_jit" in ctx.timing_report()
         assert (got.to_numpy() == ((a + np.int64(k) + 2) * 3 - 7)).all()
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.15])
+def test_projection_list_behind_a_selection_specialised_at_run_time(ctx, null_frac, monkeypatch):
+    """the whole projection list behind a selection in ONE run-time specialised kernel (expr_jit.hpp, nqe_jit_proj): bare columns,
+    chains, trees and Boolean outputs in one pass over the kept rows, each referenced column read once.  First execution: the
+    per-expression kernels; after nqe_ctx_jit_wait: a `proj_jit` launch and no compact_* / expr_tree* — both equal to the oracle's
+    projection of the oracle's selection, bit for bit, validity included.  Nullable columns, a nullable predicate column (a NULL
+    predicate emits an all-NULL row, literals stay valid under Kleene or), divisors that are zero only in dropped rows (must not
+    raise) and in kept rows (must raise from both forms), lists the kernel does not take (a Boolean bare column, five outputs)."""
+    monkeypatch.setenv("NQE_JIT_MIN_ROWS", "1000")
+    rng = np.random.default_rng(5 + int(null_frac * 100))
+    n = 50_003
+    cols = random_batch(rng, n, null_frac, key_mod=7, with_bool=True)   # id, k in 0..6, v, u, b
+    t = ctx.table_from_host(cols)
+    ID, K, V, U, B = (col(i) for i in range(5))
+    O = Operator
+    X = binop
+    lists = [
+        [X(X(V, O.Multiply, V), O.Plus, X(V, O.Divide, lit_f64(4.0))), ID],
+        [ID, K, V],
+        [X(ID, O.Plus, lit_i64(100)), X(X(ID, O.Modulos, lit_i64(1000)), O.Multiply, lit_i64(3)), X(V, O.Lt, lit_f64(0.0)), U],
+        [X(X(ID, O.Divide, K), O.Plus, ID), X(X(V, O.Gt, lit_f64(10.0)), O.Or, X(ID, O.Lt, K))],          # k == 0 rows are dropped by the predicates that allow this list
+        [X(X(X(U, O.Divide, lit_u64(7)), O.Plus, U), O.Modulos, lit_u64(1 << 20))],
+        [X(X(B, O.And, X(V, O.Lt, lit_f64(0.0))), O.Or, lit_bool(True)), X(X(B, O.Or, X(K, O.Eq, lit_i64(3))), O.And, X(V, O.GtEq, V))],
+    ]
+    not_taken = [[B, ID], [ID, K, V, U, X(ID, O.Plus, lit_i64(1))]]
+    preds = [X(K, O.NotEq, lit_i64(0)), X(X(X(ID, O.Plus, lit_i64(1)), O.Modulos, lit_i64(10)), O.Lt, X(K, O.Plus, lit_i64(1))),
+             X(X(K, O.Gt, lit_i64(0)), O.And, X(V, O.Lt, lit_f64(50.0))), X(B, O.And, X(K, O.GtEq, lit_i64(1)))]
+    for p in preds:
+        sel = orc.selection([cols], flat(p))
+        for exprs in lists + not_taken:
+            nodes = [flat(e) for e in exprs]
+            try:
+                exp = orc.projection(sel, nodes)[0]
+            except ErrorCode as oe:   # a zero divisor in a kept row: both forms must raise the same
+                for phase in (0, 1):
+                    with pytest.raises(ErrorCode) as ge:
+                        ctx.selection_projection(t, flat(p), nodes)
+                    assert ge.value.status == oe.status
+                    ctx.jit_wait()
+                continue
+            for phase in (0, 1):
+                ctx.timing_enable(True)
+                ctx.timing_reset()
+                got = ctx.selection_projection(t, flat(p), nodes).to_host()
+                ctx.timing_enable(False)
+                names = ctx.timing_report()
+                assert_batches_equal(got, exp, what=f"phase {phase} pred {p!r} list {exprs!r}")
+                if phase == 0:
+                    ctx.jit_wait()
+                elif exprs in not_taken:
+                    assert "proj_jit" not in names, names
+                else:
+                    assert "proj_jit" in names and not any(k.startswith(("compact", "expr_tree_compact")) for k in names), (names, repr(exprs))
+    # a divisor that is zero in KEPT rows raises from both forms
+    bad = X(K, O.LtEq, lit_i64(2))
+    nodes = [flat(e) for e in lists[3]]
+    for phase in (0, 1):
+        with pytest.raises(ErrorCode) as ge:
+            ctx.selection_projection(t, flat(bad), nodes)
+        assert ge.value.status == Status.ArrowError
+        ctx.jit_wait()
