@@ -56,7 +56,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="headline", choices=["headline", "headline_int64", "headline_single", "agg3", "tree_pred", "c2", "c2_random", "c3",
+    ap.add_argument("--workload", default="headline", choices=["headline", "headline_int64", "headline_single", "agg3", "tree_pred", "c2", "c2_random", "c2_tree", "c3",
                                                                "c4", "c4_sparse", "c4_wide", "c4_dup", "c4_partial", "agg_groups"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the BASELINE size of the workload)")
     ap.add_argument("--random-keys", action="store_true", help="c3/headline: group by a random id column instead of the row number")
@@ -414,6 +414,59 @@ def parity_c2(B, st, sample_rows):
     return {"rows": m, "ok": ok, "output_rows": int(ref[0].length), "tolerance": "bit-exact"}, cpu
 
 
+
+def wl_c2_tree(B, rows, steps, warmup, blocks=1, cold=False):
+    """C2's shape with expression TREES on both sides: `select v * v + v / 4, id from t where (id + 1) % 10 < 5` (50 % pass, spread
+    evenly).  Steady state = the run-time specialised kernels (csrc/expr_jit.hpp): the predicate as straight-line code into a
+    Boolean column, the whole projection list in one pass over the kept rows; `cold_ms` is the first execution, which interprets
+    (compilation runs on a worker thread)."""
+    from naive_query_engine_amd import DType, Operator
+    from naive_query_engine_amd.expression import binop, col, lit_f64, lit_i64
+
+    n, first = rows, B.rank * rows
+    ids = B.synth(0, 0, n, first)
+    v = B.synth(2, 3, n, first, dtype=B.torch.float64)
+    table = B.ctx.table_from_device([(DType.INT64, n, ids.data_ptr(), None), (DType.FLOAT64, n, v.data_ptr(), None)])
+    fields = [F("id"), F("v")]
+    pred = binop(binop(binop(col(0), Operator.Plus, lit_i64(1)), Operator.Modulos, lit_i64(10)), Operator.Lt, lit_i64(5)).flatten(fields)
+    proj = [binop(binop(col(1), Operator.Multiply, col(1)), Operator.Plus, binop(col(1), Operator.Divide, lit_f64(4.0))).flatten(fields), col(0).flatten(fields)]
+    step = lambda: B.ctx.selection_projection(table, pred, proj)
+    cold_ms = B.cold(step) if cold else None
+    r = step()
+    del r
+    B.ctx.jit_wait()
+    ms, kernels, spread = B.timed(step, steps, warmup, blocks)
+    names = ["expr_jit", "proj_jit", "keep_from_pred", "keep_from_simple", "expr_tree", "expr_tree_compact", "compact_column", "compact_expr"]
+    algo = 24.0 * n  # 16 B/row read (id, v) + two 8-byte columns written for half of the rows
+    roof = roofline(algo, kernels, names, phys_bytes=algo + 8.0 * n + n / 4.0)  # + id read by both passes, the Boolean column written and read
+    specialised = any(k.startswith(("expr_jit", "proj_jit")) for k in kernels)
+    res = {"metric": "filter_project_rows_per_s", "value": rows * B.world / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms, "spread": spread, "cold_ms": cold_ms,
+           "workload": f"select v * v + v / 4, id from t where (id + 1) % 10 < 5; t(id Int64 row number, v Float64), {n} rows per GPU; run-time specialised kernels: {specialised}",
+           "rows_per_gpu": n, "roofline": roof}
+    return res, dict(ids=ids, v=v, n=n, pred=pred, proj=proj, fields=fields)
+
+
+def parity_c2_tree(B, st, sample_rows):
+    import numpy as np
+
+    from naive_query_engine_amd import Column, DType
+    from oracle import oracle as orc
+
+    m = min(st["n"], sample_rows)
+    ids = orc.synth_fill(0, 0, 0, m).view(np.int64)
+    v = orc.synth_fill(2, 3, 0, m).view(np.float64)
+    h = orc.upload([[Column.from_numpy(ids), Column.from_numpy(v)]])
+    t0 = time.perf_counter()
+    sel = orc.selection(h, st["pred"], raw=True)
+    ref = orc.projection(sel, st["proj"])[0]
+    dt = time.perf_counter() - t0
+    prefix = B.ctx.table_from_device([(DType.INT64, m, st["ids"].data_ptr(), None), (DType.FLOAT64, m, st["v"].data_ptr(), None)])
+    got = B.ctx.selection_projection(prefix, st["pred"], st["proj"]).to_host()
+    ok = len(got) == len(ref) == 2 and all(g.length == r.length and bool((g.to_numpy().view(np.uint64) == r.to_numpy().view(np.uint64)).all()) for g, r in zip(got, ref))
+    cpu = {"value": m / dt, "unit": "rows/s", "cores": 1, "kind": "port", "sample": f"same query on the first {m} rows (single thread)", "seconds": dt}
+    return {"rows": m, "ok": ok, "output_rows": int(ref[0].length), "tolerance": "bit-exact (Float64 bit patterns)"}, cpu
+
+
 # ------------------------------------------------------------------------------------------------ C4
 def make_join_data(B, rows, nb, variant, first):
     """dim(id, attr) = LEFT/build, fact(key, val) = RIGHT/probe.
@@ -639,6 +692,10 @@ def main():
         res, st = wl_aggregate(B, n, False, False, args.steps, args.warmup, groups=args.groups)
         par = parity_aggregate(B, st, min(args.cpu_sample_rows, 20_000_000)) if want_cpu else None
         name = f"agg_{args.groups}_groups"
+    elif wl == "c2_tree":
+        res, st = wl_c2_tree(B, n, args.steps, args.warmup)
+        par = parity_c2_tree(B, st, 20_000_000) if want_cpu else None
+        name = "c2_expression_trees"
     elif wl in ("c2", "c2_random"):
         res, st = wl_c2(B, n, args.steps, args.warmup, random_ids=wl == "c2_random")
         par = parity_c2(B, st, args.cpu_sample_rows) if want_cpu else None
@@ -717,6 +774,7 @@ def main():
             add("agg_tree_predicate", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, shape="tree", **kw), pa(20_000_000))
             add("c2", lambda: wl_c2(B, 10**8, csteps, cwarm, **kw), lambda s: parity_c2(B, s, 20_000_000))
             add("c2_random_ids", lambda: wl_c2(B, 10**8, csteps, cwarm, random_ids=True, **kw), lambda s: parity_c2(B, s, 20_000_000))
+            add("c2_expression_trees", lambda: wl_c2_tree(B, 10**8, csteps, cwarm, **kw), lambda s: parity_c2_tree(B, s, 20_000_000))
             add("c4", lambda: wl_c4(B, 10**8, 10**6, "dense", csteps, cwarm, **kw), pj)
             add("c4_wide_payload", lambda: wl_c4(B, 10**8, 10**6, "wide", csteps, cwarm, **kw), pj)  # attr spans 2^62: an 8 MB payload table
             add("c4_dim_1e7", lambda: wl_c4(B, 10**8, 10**7, "dense", csteps, cwarm, **kw), pj)
