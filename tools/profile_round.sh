@@ -12,11 +12,11 @@ export TMPDIR=/tmp
 python tools/csrc_rev.py > $OUT/csrc_rev.txt
 python bench.py --details $OUT/bench_details.json 2>&1 | tail -1 > $OUT/bench_default.json
 declare -A WL=( [headline]="--workload headline" [headline_random_keys]="--workload headline --random-keys" [c2]="--workload c2" [c4]="--workload c4" \
-                [c4_sparse_keys]="--workload c4_sparse" [agg_65536_groups]="--workload agg_groups --groups 65536" [agg_4096_groups]="--workload agg_groups --groups 4096" \
+                [c4_sparse_keys]="--workload c4_sparse" [agg_65536_groups]="--workload agg_groups --groups 65536" [agg_4096_groups]="--workload agg_groups --groups 4096" [c2_expression_trees]="--workload c2_tree" \
                 [headline_single_column]="--workload headline_single" [headline_int64_values]="--workload headline_int64" \
                 [agg_tree_predicate]="--workload tree_pred" [agg_three_value_columns]="--workload agg3" [c2_random_ids]="--workload c2_random" \
                 [c4_dup_keys]="--workload c4_dup" [c4_partial_match]="--workload c4_partial" )
-CONFIGS=${NQE_PROFILE_CONFIGS:-"headline headline_random_keys headline_single_column headline_int64_values agg_tree_predicate agg_three_value_columns c2 c2_random_ids c4 c4_sparse_keys c4_dup_keys c4_partial_match agg_4096_groups agg_65536_groups"}
+CONFIGS=${NQE_PROFILE_CONFIGS:-"headline headline_random_keys headline_single_column headline_int64_values agg_tree_predicate agg_three_value_columns c2 c2_random_ids c2_expression_trees c4 c4_sparse_keys c4_dup_keys c4_partial_match agg_4096_groups agg_65536_groups"}
 cd /tmp
 for name in $CONFIGS; do
   args="${WL[$name]} --no-configs --no-cpu-baseline"

@@ -31,6 +31,7 @@ CONFIGS = {
     "agg_three_value_columns": ({"agg_grouped_fast_kernel": 1}, 24e9),
     "agg_4096_groups": ({"agg_grouped_fast_kernel": 1}, 1.6e9),
     "c2_random_ids": ({"keep_from_simple_kernel": 1, "compact_kernel": 1}, 2.0e9),
+    "c2_expression_trees": ({"nqe_jit_expr": 1, "keep_from_pred_kernel": 1, "nqe_jit_proj": 1}, 2.4e9),
     "c4_dup_keys": ({"probe_count_kernel": 1, "probe_write_kernel": 1}, 4.816e9),
     "c4_partial_match": ({"probe_presence_kernel": 1, "join_fused_write_kernel": 1}, 4.496e9),
 }
