@@ -17,6 +17,10 @@ namespace nqe {
 
 namespace {
 
+#ifndef NQE_COMPACT_CHUNK_WORDS
+#define NQE_COMPACT_CHUNK_WORDS 16
+#endif
+constexpr int COMPACT_CHUNK_WORDS = NQE_COMPACT_CHUNK_WORDS; // keep words (x 64 rows) per chunk of the striped compaction
 constexpr int SEL_B = 8; // 8-byte loads per lane per step of the streaming selection kernels (two steps are unrolled together: 16 in
                          // flight; an explicit 16 without the unroll measured slower for the compaction, faster for the mask kernel)
 
@@ -105,6 +109,35 @@ __global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *value
             }
         }
         if (lane_id() == 0) tile_counts[tile] = total;
+    }
+}
+
+// The range-test form with the rows striped over the waves in 512-row chunks (chunk c goes to wave c mod #waves) instead of one
+// 4096-row tile per wave: at any moment the chip reads one compact window of the column.  Per-tile totals meet in tile_counts
+// through one atomic per chunk (the caller zeroes them).
+template <int RANGE>
+__global__ void __launch_bounds__(256) keep_from_range_strided_kernel(const uint64_t *__restrict__ words, FastPred fp, int64_t n, uint64_t *keep, uint32_t *tile_counts) {
+    constexpr int R = 8;
+    const int lane = lane_id();
+    const int64_t n_chunks = (n + 64 * R - 1) / (64 * R), last = n - 1;
+    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, n_waves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        const int64_t row0 = chunk * (64 * R) + lane;
+        uint64_t v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row0 + r * 64;
+            v[r] = __builtin_nontemporal_load(&words[row < last ? row : last]);
+        }
+        uint32_t total = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row0 + r * 64;
+            const uint64_t kw = __ballot(row < n && range_pass(fp, RANGE == 2 ? f64_order_map(fp, v[r]) : v[r]));
+            if (row - lane < n && lane == 0) keep[chunk * R + r] = kw;
+            total += __popcll(kw);
+        }
+        if (lane == 0 && total) atomicAdd(&tile_counts[(chunk * (64 * R)) / TILE_ROWS], total);
     }
 }
 
@@ -288,8 +321,15 @@ KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleE
     FastPred fp{};
     const bool range = is_word_type(c.dtype) && !c.validity && make_fast_pred(pred, &fp);
     if (km.ntiles) {
-        dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
-        if (range && fp.fmask)
+        static const int bpc = getenv("NQE_SEL_BPC") ? atoi(getenv("NQE_SEL_BPC")) : 8; // diagnostics (A/B): workgroups per CU
+        dim3 grid(stream_grid(ctx, km.ntiles, 4, bpc)), block(256);
+        static const bool strided = getenv("NQE_SEL_TILED") == nullptr; // diagnostics (A/B): NQE_SEL_TILED=1 restores one 4096-row tile per wave
+        if (range && strided) {
+            NQE_HIP_CHECK(hipMemsetAsync(counts->ptr, 0, size_t(km.ntiles + 1) * 4, ctx->stream));
+            dim3 sgrid(stream_grid(ctx, (km.n + 7) / 8, 256));
+            if (fp.fmask) launch(ctx, "keep_from_simple", keep_from_range_strided_kernel<2>, sgrid, block, 0, c.words(), fp, km.n, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
+            else launch(ctx, "keep_from_simple", keep_from_range_strided_kernel<1>, sgrid, block, 0, c.words(), fp, km.n, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
+        } else if (range && fp.fmask)
             launch(ctx, "keep_from_simple", keep_from_simple_kernel<2>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred, fp,
                    km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint64_t *)nullptr, (uint32_t *)counts->ptr, ctx->d_flags);
         else if (range)
@@ -341,6 +381,53 @@ const int64_t *kept_rows(nqe_ctx *ctx, const KeepMask &km) {
     return (const int64_t *)km.kept_idx->ptr;
 }
 
+
+// compact_kernel's PLAINW form with the rows striped over the waves in 512-row chunks (SEL_B keep words; chunk c goes to wave
+// c mod #waves) instead of one 4096-row tile per wave — at any moment the chip reads one compact window of the column (the same
+// change made keep_from_range 17 % faster).  A wave re-derives the offsets of its chunk from the tile's 64 keep words (one
+// coalesced 512-byte read that hits L2, one wave scan).
+template <bool EXPR>
+__global__ void __launch_bounds__(256) compact_strided_kernel(const uint64_t *__restrict__ words, SimpleExpr e, const uint64_t *keep, const uint64_t *tile_offsets,
+                                                              int64_t n, int64_t ntiles, uint64_t *out_words, int *flags) {
+    constexpr int CW = COMPACT_CHUNK_WORDS, CPT = TILE_WORDS / CW; // keep words per chunk, chunks per tile
+    const int64_t nwords = (n + 63) / 64, last = n - 1, n_chunks = ntiles * CPT;
+    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, n_waves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        const int64_t tile = chunk / CPT;
+        const int c0 = int(chunk % CPT) * CW;
+        const uint64_t base = tile_offsets[tile];
+        if (tile_offsets[tile + 1] == base) continue; // (wave-uniform, two scalar loads) nothing kept in the whole tile: clustered data
+        const int64_t w = tile * TILE_WORDS + lane_id();
+        const uint64_t my_word = w < nwords ? keep[w] : 0;
+        uint32_t tot;
+        const uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+        for (int k0 = c0; k0 < c0 + CW; k0 += SEL_B) {
+            uint64_t kw[SEL_B];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < SEL_B; ++k) {
+                kw[k] = bcast64(my_word, k0 + k);
+                any = any || kw[k] != 0;
+            }
+            if (!any) continue; // (wave-uniform) nothing kept in these 512 rows: their source words are not read
+            uint64_t v[SEL_B];
+#pragma unroll
+            for (int k = 0; k < SEL_B; ++k) {
+                const int64_t row = (tile * TILE_WORDS + k0 + k) * 64 + lane_id();
+                v[k] = __builtin_nontemporal_load(&words[row < last ? row : last]);
+            }
+#pragma unroll
+            for (int k = 0; k < SEL_B; ++k) {
+                const uint32_t off = bcast32(my_off, k0 + k);
+                if ((kw[k] >> lane_id()) & 1) {
+                    const uint64_t x = EXPR ? eval_simple(e, v[k], true, flags) : v[k];
+                    __builtin_nontemporal_store(x, &out_words[base + off + __popcll(kw[k] & lanemask_lt())]);
+                }
+            }
+        }
+    }
+}
+
 static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExpr *e, int out_dtype, const KeepMask &km,
                              const uint32_t *gidx = nullptr) {
     if (src.dtype == NQE_UTF8 && !e && !gidx) // StringBuilder path of selection.rs:82-97: gather by the emitted-row list
@@ -357,7 +444,8 @@ static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExp
     SimpleExpr dummy;
     std::memset(&dummy, 0, sizeof(dummy));
     if (km.ntiles && km.total > 0) { // nothing kept: nothing to read or write (and a gather source may be empty)
-        dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
+        static const int bpc = getenv("NQE_COMPACT_BPC") ? atoi(getenv("NQE_COMPACT_BPC")) : 8; // diagnostics (A/B): workgroups per CU
+        dim3 grid(stream_grid(ctx, km.ntiles, 4, bpc)), block(256);
         const void *sv = (const void *)src.values->ptr;
         const uint64_t *kp = (const uint64_t *)km.keep->ptr;
         const uint64_t *pv = km.pvalid ? (const uint64_t *)km.pvalid->ptr : nullptr;
@@ -370,7 +458,12 @@ static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExp
 #define NQE_COMPACT(NAME, E, P, G)                                                                                     \
     launch(ctx, NAME, compact_kernel<E, P, G>, grid, block, 0, sv, src.dtype, src.valid(), gidx, ex, kp, pv, to, km.n,  \
            km.ntiles, ow, ob, ov, ctx->d_flags)
-        if (gidx) {
+        static const bool strided = getenv("NQE_SEL_TILED") == nullptr; // diagnostics (A/B): NQE_SEL_TILED=1 restores one 4096-row tile per wave
+        if (strided && !gidx && plainw) {
+            dim3 sgrid(stream_grid(ctx, km.ntiles * (TILE_WORDS / COMPACT_CHUNK_WORDS), 4));
+            if (e) launch(ctx, "compact_expr", compact_strided_kernel<true>, sgrid, block, 0, (const uint64_t *)sv, ex, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
+            else launch(ctx, "compact_column", compact_strided_kernel<false>, sgrid, block, 0, (const uint64_t *)sv, ex, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
+        } else if (gidx) {
             if (plainw) NQE_COMPACT("compact_gather", false, true, true);
             else NQE_COMPACT("compact_gather", false, false, true);
         } else if (e && plainw) NQE_COMPACT("compact_expr", true, true, false);
