@@ -147,17 +147,22 @@ __global__ void __launch_bounds__(256) keep_from_range_strided_kernel(const uint
 struct ConjCols {
     const uint64_t *w[CONJ_MAX];
 };
-template <int NC>
+// STRIPED: the rows go to the waves in chunks of 2 x B keep words (chunk c to wave c mod #waves; per-tile totals through one atomic
+// per chunk into zeroed tile_counts) instead of one 4096-row tile per wave — see keep_from_range_strided_kernel
+template <int NC, bool STRIPED>
 __global__ void __launch_bounds__(256) keep_from_conj_kernel(ConjCols cols, ConjPred c, int64_t n, int64_t ntiles, uint64_t *keep, uint32_t *tile_counts) {
     constexpr int B = NC <= 2 ? SEL_B : SEL_B / 2; // words in flight per lane stay at 8-16
+    constexpr int CW = STRIPED ? 2 * B : TILE_WORDS, CPT = TILE_WORDS / CW;
     const int waves_per_block = blockDim.x / 64;
     const int64_t last = n - 1;
-    for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
-         tile += int64_t(gridDim.x) * waves_per_block) {
+    for (int64_t chunk = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; chunk < ntiles * CPT;
+         chunk += int64_t(gridDim.x) * waves_per_block) {
+        const int64_t tile = chunk / CPT;
+        const int kfirst = int(chunk % CPT) * CW;
         const int64_t row0 = tile * TILE_ROWS;
         uint32_t total = 0;
 #pragma unroll 2
-        for (int k0 = 0; k0 < TILE_WORDS; k0 += B) {
+        for (int k0 = kfirst; k0 < kfirst + CW; k0 += B) {
             uint64_t w[CONJ_MAX][B];
 #pragma unroll
             for (int k = 0; k < B; ++k) {
@@ -174,7 +179,10 @@ __global__ void __launch_bounds__(256) keep_from_conj_kernel(ConjCols cols, Conj
                 total += __popcll(kw);
             }
         }
-        if (lane_id() == 0) tile_counts[tile] = total;
+        if (STRIPED) {
+            if (lane_id() == 0 && total) atomicAdd(&tile_counts[tile], total);
+        } else if (lane_id() == 0)
+            tile_counts[tile] = total;
     }
 }
 
@@ -364,8 +372,15 @@ KeepMask build_keep_mask_conj(nqe_ctx *ctx, const nqe_table *in, ConjPred c, con
     }
     if (km.ntiles) {
         dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
-        auto k = nc == 1 ? keep_from_conj_kernel<1> : nc == 2 ? keep_from_conj_kernel<2> : nc == 3 ? keep_from_conj_kernel<3> : keep_from_conj_kernel<4>;
-        launch(ctx, "keep_from_conj", k, grid, block, 0, cc, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
+        static const bool striped = getenv("NQE_SEL_TILED") == nullptr; // diagnostics (A/B)
+        if (striped) {
+            NQE_HIP_CHECK(hipMemsetAsync(counts->ptr, 0, size_t(km.ntiles + 1) * 4, ctx->stream));
+            auto k = nc == 1 ? keep_from_conj_kernel<1, true> : nc == 2 ? keep_from_conj_kernel<2, true> : nc == 3 ? keep_from_conj_kernel<3, true> : keep_from_conj_kernel<4, true>;
+            launch(ctx, "keep_from_conj", k, dim3(stream_grid(ctx, km.ntiles * 4, 4)), block, 0, cc, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
+        } else {
+            auto k = nc == 1 ? keep_from_conj_kernel<1, false> : nc == 2 ? keep_from_conj_kernel<2, false> : nc == 3 ? keep_from_conj_kernel<3, false> : keep_from_conj_kernel<4, false>;
+            launch(ctx, "keep_from_conj", k, grid, block, 0, cc, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
+        }
     }
     return finish_mask(ctx, km, counts);
 }

@@ -1805,13 +1805,12 @@ def test_projection_list_behind_a_selection_specialised_at_run_time(ctx, null_fr
     X = binop
     lists = [
         [X(X(V, O.Multiply, V), O.Plus, X(V, O.Divide, lit_f64(4.0))), ID],
-        [ID, K, V],
         [X(ID, O.Plus, lit_i64(100)), X(X(ID, O.Modulos, lit_i64(1000)), O.Multiply, lit_i64(3)), X(V, O.Lt, lit_f64(0.0)), U],
         [X(X(ID, O.Divide, K), O.Plus, ID), X(X(V, O.Gt, lit_f64(10.0)), O.Or, X(ID, O.Lt, K))],          # k == 0 rows are dropped by the predicates that allow this list
         [X(X(X(U, O.Divide, lit_u64(7)), O.Plus, U), O.Modulos, lit_u64(1 << 20))],
         [X(X(B, O.And, X(V, O.Lt, lit_f64(0.0))), O.Or, lit_bool(True)), X(X(B, O.Or, X(K, O.Eq, lit_i64(3))), O.And, X(V, O.GtEq, V))],
     ]
-    not_taken = [[B, ID], [ID, K, V, U, X(ID, O.Plus, lit_i64(1))]]
+    not_taken = [[B, ID], [ID, K, V, U, X(ID, O.Plus, lit_i64(1))], [ID, K, V], [X(ID, O.Plus, lit_i64(100)), V]]  # Boolean bare column, five outputs, nothing to specialise
     preds = [X(K, O.NotEq, lit_i64(0)), X(X(X(ID, O.Plus, lit_i64(1)), O.Modulos, lit_i64(10)), O.Lt, X(K, O.Plus, lit_i64(1))),
              X(X(K, O.Gt, lit_i64(0)), O.And, X(V, O.Lt, lit_f64(50.0))), X(B, O.And, X(K, O.GtEq, lit_i64(1)))]
     for p in preds:
@@ -1842,7 +1841,7 @@ def test_projection_list_behind_a_selection_specialised_at_run_time(ctx, null_fr
                     assert "proj_jit" in names and not any(k.startswith(("compact", "expr_tree_compact")) for k in names), (names, repr(exprs))
     # a divisor that is zero in KEPT rows raises from both forms
     bad = X(K, O.LtEq, lit_i64(2))
-    nodes = [flat(e) for e in lists[3]]
+    nodes = [flat(e) for e in (X(X(ID, O.Divide, K), O.Plus, ID), X(X(V, O.Gt, lit_f64(10.0)), O.Or, X(ID, O.Lt, K)))]
     for phase in (0, 1):
         with pytest.raises(ErrorCode) as ge:
             ctx.selection_projection(t, flat(bad), nodes)
