@@ -1569,8 +1569,9 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         }
                         ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
                         // the value column is the key column itself (and the predicate, if any, tests it too): the single-load instance
-                        const bool share = a.nv == 1 && a.val_shares_key[0] && a.val[0].values == a.key_src.values && (fp == 0 || fp == 1) && fast_key != 3 && !vnull && !vf64 &&
-                                           subsets_log2 == 0;
+                        // (three columns: the instance whose tile leaves the first value column out because it IS the key column)
+                        const bool share = (a.nv == 1 || a.nv == NVMAX) && a.val_shares_key[0] && a.val[0].values == a.key_src.values && (fp == 0 || fp == 1) && fast_key != 3 &&
+                                           !vnull && (a.nv == NVMAX || !vf64) && subsets_log2 == 0;
                         // no aggregate of the pass asks for min / max: instances without those LDS arrays (two and three columns, and the
                         // single-load one — `count(id) … group by id % 3` updates one LDS word per row instead of reading two and updating four)
                         bool nomm = a.nv >= 2 || share;

@@ -57,7 +57,12 @@ namespace {
 // units 30-40 % busy (PMC), i.e. latency-bound.
 template <int PRED, int KEY, int NVT, bool VF64, bool VNULL, bool SUB = false, bool MM = true, bool SHARE = false>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, FastPred fp, GroupTable g, int *flags) {
-    constexpr int TU = SHARE ? 2 * AGG_U : ((NQE_WIDE_TILES && NVT == 1 && !VNULL && !SUB && PRED <= 1 && KEY != 3) ? NQE_WIDE_TILES : AGG_U); // rows per lane per tile
+    // SHARE with ONE value column: that column is the key column (one load, eight rows per lane).  SHARE with THREE: the FIRST value
+    // column is the key column (C1's `count(id), sum(age), avg(score) … group by id % 3`) — the tile holds two value words per row, and
+    // a second tile in flight fits the registers (the general three-column instance keeps one)
+    constexpr bool SH1 = SHARE && NVT == 1, FK = SHARE && NVT == 3;
+    constexpr int NVL = FK ? NVT - 1 : NVT; // value columns the tile loads
+    constexpr int TU = SH1 ? 2 * AGG_U : ((NQE_WIDE_TILES && NVT == 1 && !VNULL && !SUB && PRED <= 1 && KEY != 3) ? NQE_WIDE_TILES : AGG_U); // rows per lane per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
     const uint32_t slots = cap + 1;
@@ -197,7 +202,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 
     constexpr bool NT = true; // non-temporal loads: -2..3 % (and the loop below keeps a prefetched second tile in flight: 3.24 -> 2.69 ms with the lean loop)
     struct Tile {
-        uint64_t kw[TU], pw[SHARE ? 1 : TU], vw[SHARE ? 1 : NVT][SHARE ? 1 : TU];
+        uint64_t kw[TU], pw[SH1 ? 1 : TU], vw[SH1 ? 1 : NVL][SH1 ? 1 : TU];
         uint64_t vv[VNULL ? NVT : 1][TU]; // validity word of the wave's 64 rows
         uint64_t kpv[VNULL ? TU : 1];     // key validity AND predicate validity
     };
@@ -214,11 +219,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         return uint32_t(r < 0 ? 0 : (r > step ? step : r));
     };
     // (three value columns: when the first one is the key column itself — `count(id) … group by id % 3` — its word is the key word)
-    const bool first_is_key = NVT == 3 && a.val_shares_key[0] && a.val[0].values == a.key_src.values; // wave-uniform
+    const bool first_is_key = NVT == 3 && !FK && a.val_shares_key[0] && a.val[0].values == a.key_src.values; // wave-uniform
     auto vword = [&](const Tile &t, int j, int u) -> uint64_t {
-        if (SHARE) return t.kw[u];
+        if (SH1) return t.kw[u];
+        if (FK) return j == 0 ? t.kw[u] : t.vw[FK ? (j > 0 ? j - 1 : 0) : 0][SH1 ? 0 : u];
         if (NVT == 3 && j == 0 && first_is_key) return t.kw[u];
-        return t.vw[SHARE ? 0 : j][SHARE ? 0 : u];
+        return t.vw[SH1 ? 0 : j][SH1 ? 0 : u];
     };
     auto load_tile = [&](Tile &t, int64_t base) {
         if (NT && !VNULL && base + step <= n) {
@@ -231,13 +237,14 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             for (int u = 0; u < TU; ++u) {
                 t.kw[u] = __builtin_nontemporal_load(&kt[lane_row[u]]);
                 // (a Boolean bitmap predicate: word (base + lane_row) >> 6 with base a multiple of the tile = of 64)
-                if (PRED == 2) t.pw[SHARE ? 0 : u] = __builtin_nontemporal_load(&pt[lane_row[u] >> fp.row_shift]);
-                if (PRED == 3) t.pw[SHARE ? 0 : u] = __builtin_nontemporal_load(&pt[lane_row[u]]);
-                if (PRED == 4) t.pw[SHARE ? 0 : u] = a.conj.need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull; // wave-uniform
-                if ((PRED == 5 || PRED == 6)) t.pw[SHARE ? 0 : u] = a.tree_need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull;
+                if (PRED == 2) t.pw[SH1 ? 0 : u] = __builtin_nontemporal_load(&pt[lane_row[u] >> fp.row_shift]);
+                if (PRED == 3) t.pw[SH1 ? 0 : u] = __builtin_nontemporal_load(&pt[lane_row[u]]);
+                if (PRED == 4) t.pw[SH1 ? 0 : u] = a.conj.need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull; // wave-uniform
+                if ((PRED == 5 || PRED == 6)) t.pw[SH1 ? 0 : u] = a.tree_need_pw ? __builtin_nontemporal_load(&pt[lane_row[u]]) : 0ull;
 #pragma unroll
                 for (int j = 0; j < NVT; ++j)
-                    if (!SHARE && !(NVT == 3 && j == 0 && first_is_key)) t.vw[SHARE ? 0 : j][SHARE ? 0 : u] = __builtin_nontemporal_load(&vt[j][lane_row[u]]);
+                    if (!SH1 && !(FK && j == 0) && !(NVT == 3 && j == 0 && first_is_key))
+                        t.vw[SH1 ? 0 : (FK ? (j > 0 ? j - 1 : 0) : j)][SH1 ? 0 : u] = __builtin_nontemporal_load(&vt[j][lane_row[u]]);
             }
             return;
         }
@@ -249,12 +256,13 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             // loads here made it drop the hint from the pointer form as well)
             if (NT) {
                 t.kw[u] = __builtin_nontemporal_load(&keyp[row]);
-                if (PRED == 2) t.pw[SHARE ? 0 : u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
-                if (PRED == 3) t.pw[SHARE ? 0 : u] = __builtin_nontemporal_load(&predp[row]);
-                if (PRED == 4) t.pw[SHARE ? 0 : u] = a.conj.need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull; // wave-uniform
-                if ((PRED == 5 || PRED == 6)) t.pw[SHARE ? 0 : u] = a.tree_need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull;
+                if (PRED == 2) t.pw[SH1 ? 0 : u] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
+                if (PRED == 3) t.pw[SH1 ? 0 : u] = __builtin_nontemporal_load(&predp[row]);
+                if (PRED == 4) t.pw[SH1 ? 0 : u] = a.conj.need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull; // wave-uniform
+                if ((PRED == 5 || PRED == 6)) t.pw[SH1 ? 0 : u] = a.tree_need_pw ? __builtin_nontemporal_load(&predp[row]) : 0ull;
 #pragma unroll
-                for (int j = 0; j < NVT; ++j) if (!SHARE) t.vw[SHARE ? 0 : j][SHARE ? 0 : u] = __builtin_nontemporal_load(&valp[j][row]);
+                for (int j = 0; j < NVT; ++j)
+                    if (!SH1 && !(FK && j == 0)) t.vw[SH1 ? 0 : (FK ? (j > 0 ? j - 1 : 0) : j)][SH1 ? 0 : u] = __builtin_nontemporal_load(&valp[j][row]);
                 if (VNULL) {
 #pragma unroll
                     for (int j = 0; j < NVT; ++j) t.vv[j][u] = vvalid[j] ? vvalid[j][row >> 6] : ~0ull;
@@ -262,11 +270,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 }
             } else {
                 t.kw[u] = keyp[row];
-                if (PRED == 2) t.pw[SHARE ? 0 : u] = predp[row >> fp.row_shift];
-                if (PRED == 3) t.pw[SHARE ? 0 : u] = predp[row];
-                if (PRED == 4) t.pw[SHARE ? 0 : u] = a.conj.need_pw ? predp[row] : 0ull; // wave-uniform
+                if (PRED == 2) t.pw[SH1 ? 0 : u] = predp[row >> fp.row_shift];
+                if (PRED == 3) t.pw[SH1 ? 0 : u] = predp[row];
+                if (PRED == 4) t.pw[SH1 ? 0 : u] = a.conj.need_pw ? predp[row] : 0ull; // wave-uniform
 #pragma unroll
-                for (int j = 0; j < NVT; ++j) if (!SHARE) t.vw[SHARE ? 0 : j][SHARE ? 0 : u] = valp[j][row];
+                for (int j = 0; j < NVT; ++j)
+                    if (!SH1 && !(FK && j == 0)) t.vw[SH1 ? 0 : (FK ? (j > 0 ? j - 1 : 0) : j)][SH1 ? 0 : u] = valp[j][row];
             }
         }
     };
@@ -377,7 +386,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         for (int u = 0; u < TU; ++u) res[u] = (t.kw[u] ^ vword(t, 0, u)) != 12345;
         return;
 #endif
-        if constexpr (!SHARE) {
+        if constexpr (!SH1) {
             if (PRED == 5) conj_general_tile<TU>(a.conj, t.kw, t.vw[0], t.pw, res);
             else tree_pred_eval<TU>(a.tree_prog, a.tree_n, t.kw, t.vw[0], t.pw, res);
         }
@@ -418,7 +427,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         // interpreted keys are computed for the whole tile up front (operator-major); the built-in shapes stay inside the row loop,
         // where the compiler sinks them below the predicate (hoisting them cost the headline 1.5 %)
         uint64_t pvals[PRED == 3 ? TU : 1];
-        if constexpr (PRED == 3 && !SHARE) inline_keys<3, TU, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[TU]>(pvals), 0, no_aux(), false);
+        if constexpr (PRED == 3 && !SH1) inline_keys<3, TU, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[TU]>(pvals), 0, no_aux(), false);
         bool tpass[(PRED == 5 || PRED == 6) ? TU : 1];
         if ((PRED == 5 || PRED == 6)) eval_interpreted(t, reinterpret_cast<bool (&)[TU]>(tpass));
         uint64_t keys[KEY == 3 ? TU : 1];
@@ -430,9 +439,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             bool pass = lane_row[u] < nrows;
             if (PRED == 3) pass = pass && pvals[PRED == 3 ? u : 0] != 0;
             else if ((PRED == 5 || PRED == 6)) pass = pass && tpass[(PRED == 5 || PRED == 6) ? u : 0];
-            else if (PRED == 4) pass = pass && conj_pass<3, false>(a.conj, t.kw[u], vword(t, 0, u), t.pw[SHARE ? 0 : u]);
+            else if (PRED == 4) pass = pass && conj_pass<3, false>(a.conj, t.kw[u], vword(t, 0, u), t.pw[SH1 ? 0 : u]);
             else if (PRED != 0) {
-                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[SHARE ? 0 : u], row));
+                pass = pass && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[SH1 ? 0 : u], row));
             }
             if (VNULL) pass = pass && ((t.kpv[u] >> (row & 63)) & 1ull);
             const uint64_t key = KEY == 3 ? keys[KEY == 3 ? u : 0] : inline_key<KEY>(a.key, t.kw[u], key_mask, key_aux, key_signed);
@@ -449,7 +458,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     };
     auto process_batch = [&](const Tile &t, int64_t base) {
         uint64_t pvals[PRED == 3 ? TU : 1];
-        if constexpr (PRED == 3 && !SHARE) inline_keys<3, TU, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[TU]>(pvals), 0, no_aux(), false);
+        if constexpr (PRED == 3 && !SH1) inline_keys<3, TU, NVT == 1>(a.pred, t.pw, reinterpret_cast<uint64_t (&)[TU]>(pvals), 0, no_aux(), false);
         bool tpass[(PRED == 5 || PRED == 6) ? TU : 1];
         if ((PRED == 5 || PRED == 6)) eval_interpreted(t, reinterpret_cast<bool (&)[TU]>(tpass));
         bool pass[TU];
@@ -462,8 +471,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             pass[u] = lane_row[u] < nrows;
             if (PRED == 3) pass[u] = pass[u] && pvals[PRED == 3 ? u : 0] != 0;
             else if ((PRED == 5 || PRED == 6)) pass[u] = pass[u] && tpass[(PRED == 5 || PRED == 6) ? u : 0];
-            else if (PRED == 4) pass[u] = pass[u] && conj_pass<3, false>(a.conj, t.kw[u], vword(t, 0, u), t.pw[SHARE ? 0 : u]);
-            else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[SHARE ? 0 : u], row));
+            else if (PRED == 4) pass[u] = pass[u] && conj_pass<3, false>(a.conj, t.kw[u], vword(t, 0, u), t.pw[SH1 ? 0 : u]);
+            else if (PRED != 0) pass[u] = pass[u] && range_pass(fp, PRED == 1 ? t.kw[u] : pred_extract(fp, t.pw[SH1 ? 0 : u], row));
             if (VNULL) pass[u] = pass[u] && ((t.kpv[u] >> (row & 63)) & 1ull);
         }
         bool mixed = false; // keys of rows that fail the predicate take part: a false "mixed" costs nothing but the batch path
@@ -492,7 +501,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // (PRED = 6: ONE tile in flight — the stack machine's registers take the place of the prefetched tile's; the workgroup's 16
     // waves hide the loads' latency among themselves)
     // (three value columns: one tile is 6-8 KB per wave = 96-128 KB per CU in flight already; a second one spills ~30 VGPRs)
-    constexpr bool PIPE = (PRED != 6 || NQE_TREE_PIPE) && NVT != 3;
+    constexpr bool PIPE = (PRED != 6 || NQE_TREE_PIPE) && (NVT != 3 || FK);
     auto stream = [&](auto &&process, Tile &A, int budget) {
         if constexpr (!PIPE) {
             for (int64_t it = 0; it < 2 * int64_t(budget); ++it) {
@@ -621,6 +630,7 @@ template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf
             return nomm ? agg_grouped_fast_kernel<PRED, KEY, 1, false, false, false, false, true> : agg_grouped_fast_kernel<PRED, KEY, 1, false, false, false, true, true>;
     }
     if constexpr (!VNULL && PRED <= 1 && KEY != 3) {
+        if (nomm && nv == 3 && !sub && share) return agg_grouped_fast_kernel<PRED, KEY, 3, false, false, false, false, true>; // the first column is the key column
         if (nomm && nv == 3 && !sub)
             return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 3, true, false, false, false> : agg_grouped_fast_kernel<PRED, KEY, 3, false, false, false, false>;
         if (nomm && nv == 2 && !sub)
