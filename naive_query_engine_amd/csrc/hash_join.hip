@@ -225,21 +225,28 @@ __global__ void __launch_bounds__(256) dense_scatter_rows_kernel(const uint64_t 
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n; r += stride) dense[keys[r] - dmin] = uint32_t(r) + 1u;
 }
-__global__ void __launch_bounds__(256) dense_finish_kernel(const uint32_t *dense, uint64_t span, uint32_t *presence, DensePayload dp, unsigned long long *occupied) {
+// `kord` (the partitioned build below): the entries arrive as key-ordered records of `twp` words {row + 1, payload words…} — the row
+// table is written from them here, and the payloads are read from the record of entry d, not gathered by row.
+__global__ void __launch_bounds__(256) dense_finish_kernel(uint32_t *dense, uint64_t span, uint32_t *presence, DensePayload dp, unsigned long long *occupied,
+                                                           const uint64_t *kord, int twp) {
     __shared__ uint32_t pack[4][2 * 25];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const uint64_t ngroups = (span + 63) / 64;
     uint32_t mine = 0;
     for (uint64_t g = uint64_t(blockIdx.x) * 4 + wave; g < ngroups; g += uint64_t(gridDim.x) * 4) {
         const uint64_t d = g * 64 + lane;
-        const uint32_t e = d < span ? dense[d] : 0u;
+        uint32_t e = 0;
+        if (d < span) {
+            if (kord) dense[d] = e = uint32_t(__builtin_nontemporal_load(&kord[d * uint64_t(twp)]));
+            else e = dense[d];
+        }
         const bool present = e != 0;
         const uint64_t m = __ballot(present);
         mine += __popcll(m);
         // presence: bit d of 32-bit words — this wave's 64 entries are words 2g and 2g + 1 (the bitmap is allocated in whole pairs)
         if (presence && lane < 2 && 2 * g + lane < (span + 31) / 32) presence[2 * g + lane] = uint32_t(m >> (32 * lane));
         for (int c = 0; c < dp.n; ++c) {
-            const uint64_t v = present ? dp.src[c][e - 1] : dp.base[c];
+            const uint64_t v = present ? (kord ? __builtin_nontemporal_load(&kord[d * uint64_t(twp) + 1 + c]) : dp.src[c][e - 1]) : dp.base[c];
             const int nb = dp.packed[c];
             if (nb >= 2) {
                 if (lane < 2 * nb) pack[wave][lane] = 0;
@@ -261,6 +268,158 @@ __global__ void __launch_bounds__(256) dense_finish_kernel(const uint32_t *dense
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64); // (every lane of a wave holds the same count: lane 0's sum counts it 64 times)
     if (lane == 0 && mine) atomicAdd(occupied, (unsigned long long)(mine / 64));
+}
+// ---- Partitioned dense build (builds of >= 2^25 rows).  A table of gigabytes takes neither form above: random 4-byte stores and
+// gathers over that range run at a fraction of the chip's line rate (22 ms per 10^8 rows), the atomics at their flat
+// 2.4x10^10/s (10-11 ms).  Here the rows are first PARTITIONED BY KEY RANGE — tuples {key - min | row, payload words} in one
+// stream; count, scan, then per 8192-row tile a counting sort in LDS so that a partition's tuples leave as one run — into
+// slices of the table that fit one XCD's L2 (<= 3 MB of table per partition).  The second pass then scatters partition by
+// partition: the workgroups of one XCD (blockIdx % 8) walk the same partitions together, their random stores land in an
+// L2-resident slice and leave it as whole lines.  Payload words travel with the tuple (no gather by build row afterwards);
+// dense_finish_kernel packs them from the key-ordered copies and counts the occupied entries (== rows <=> unique keys).
+constexpr int PB_BLOCK = 1024;
+constexpr int PB_MAX_PARTS = 1024;
+constexpr int PB_XCDS = 8;
+struct PartBuild {
+    const uint64_t *keys;
+    int64_t n;
+    uint64_t dmin;
+    int32_t shift; // partition = (key - dmin) >> shift
+    int32_t parts;
+    int64_t chunk; // rows per workgroup of the count / scatter passes (a multiple of the tile)
+    int32_t W;     // workgroups of the count / scatter passes
+    int32_t nc;    // payload words per tuple
+    const uint64_t *src[MAX_JOIN_COLS];
+};
+__global__ void __launch_bounds__(PB_BLOCK) part_build_count_kernel(PartBuild pb, uint32_t *counts) {
+    __shared__ uint32_t hist[PB_MAX_PARTS];
+    for (int p = threadIdx.x; p < PB_MAX_PARTS; p += blockDim.x) hist[p] = 0;
+    __syncthreads();
+    const int64_t lo = int64_t(blockIdx.x) * pb.chunk;
+    const int64_t hi = lo + pb.chunk < pb.n ? lo + pb.chunk : pb.n;
+    for (int64_t r = lo + threadIdx.x; r < hi; r += blockDim.x) atomicAdd(&hist[uint32_t((pb.keys[r] - pb.dmin) >> pb.shift)], 1u);
+    __syncthreads();
+    for (int p = threadIdx.x; p < pb.parts; p += blockDim.x) counts[size_t(p) * size_t(pb.W) + blockIdx.x] = hist[p];
+}
+// offsets[p * W + w] (exclusive scan of the counts): where workgroup w's tuples of partition p start in the tuple stream
+template <int RPT>
+__global__ void __launch_bounds__(PB_BLOCK) part_build_scatter_kernel(PartBuild pb, const uint64_t *offsets, uint64_t *tuples) {
+    constexpr int ROWS = PB_BLOCK * RPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int TW = 1 + pb.nc;
+    uint64_t *stup = reinterpret_cast<uint64_t *>(smem);                          // [ROWS][TW]
+    uint32_t *gcur = reinterpret_cast<uint32_t *>(stup + size_t(ROWS) * size_t(TW)); // [PB_MAX_PARTS] next tuple of (partition, this workgroup)
+    uint32_t *tcnt = gcur + PB_MAX_PARTS;                                         // tuples of this tile per partition
+    uint32_t *tstart = tcnt + PB_MAX_PARTS;                                       // tile-local exclusive scan
+    __shared__ uint32_t wave_tot[PB_BLOCK / 64];
+    const int parts = pb.parts;
+    for (int p = threadIdx.x; p < PB_MAX_PARTS; p += blockDim.x) {
+        gcur[p] = p < parts ? uint32_t(offsets[size_t(p) * size_t(pb.W) + blockIdx.x]) : 0u; // (rows < 2^32)
+        tcnt[p] = 0;
+    }
+    __syncthreads();
+    const int64_t lo = int64_t(blockIdx.x) * pb.chunk;
+    const int64_t hi = lo + pb.chunk < pb.n ? lo + pb.chunk : pb.n;
+    for (int64_t base = lo; base < hi; base += ROWS) {
+        uint32_t d[RPT], rank[RPT];
+        bool ok[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int64_t row = base + int64_t(u) * PB_BLOCK + threadIdx.x;
+            ok[u] = row < hi;
+            d[u] = ok[u] ? uint32_t(__builtin_nontemporal_load(&pb.keys[row]) - pb.dmin) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) rank[u] = ok[u] ? atomicAdd(&tcnt[d[u] >> pb.shift], 1u) : 0u;
+        __syncthreads();
+        const uint32_t c = tcnt[threadIdx.x]; // PB_MAX_PARTS == PB_BLOCK: one counter per thread
+        uint32_t wt;
+        const uint32_t ex = wave_exclusive_scan(c, wt);
+        if (lane_id() == 63) wave_tot[threadIdx.x / 64] = wt;
+        __syncthreads();
+        uint32_t pre = 0, tile_total = 0;
+        for (int w = 0; w < PB_BLOCK / 64; ++w) {
+            if (w < int(threadIdx.x) / 64) pre += wave_tot[w];
+            tile_total += wave_tot[w];
+        }
+        tstart[threadIdx.x] = pre + ex;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            if (!ok[u]) continue;
+            const int64_t row = base + int64_t(u) * PB_BLOCK + threadIdx.x;
+            const uint32_t i = tstart[d[u] >> pb.shift] + rank[u];
+            stup[size_t(i) * TW] = (uint64_t(d[u]) << 32) | uint64_t(uint32_t(row));
+            for (int cc = 0; cc < pb.nc; ++cc) stup[size_t(i) * TW + 1 + cc] = __builtin_nontemporal_load(&pb.src[cc][row]);
+        }
+        __syncthreads();
+        if (TW == 2) {
+            for (uint32_t i = threadIdx.x; i < tile_total; i += PB_BLOCK) {
+                const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(&stup[size_t(i) * 2]);
+                const uint32_t p = uint32_t(t.x >> 32) >> pb.shift;
+                *reinterpret_cast<ulonglong2 *>(&tuples[(size_t(gcur[p]) + (i - tstart[p])) * 2]) = t;
+            }
+        } else {
+            // word e of the tile's sorted tuples: consecutive lanes write consecutive words, across tuple boundaries
+            const uint32_t words = tile_total * uint32_t(TW);
+            for (uint32_t e = threadIdx.x; e < words; e += PB_BLOCK) {
+                const uint32_t i = e / uint32_t(TW), k = e - i * uint32_t(TW);
+                const uint32_t p = uint32_t(stup[size_t(i) * TW] >> 32) >> pb.shift;
+                tuples[(size_t(gcur[p]) + (i - tstart[p])) * size_t(TW) + k] = stup[e];
+            }
+        }
+        __syncthreads();
+        gcur[threadIdx.x] += tcnt[threadIdx.x];
+        tcnt[threadIdx.x] = 0;
+        __syncthreads();
+    }
+}
+// pass 2: the workgroups of XCD x (HW_REG_XCC_ID — a performance matter only) take the partitions p = x, x + 8, … one after the other,
+// sharing each 2048 tuples at a time through the partition's cursor; afterwards every workgroup sweeps all cursors once and takes
+// what is left (nothing, when the hardware numbers its XCDs 0 … 7), so every tuple is placed whatever the mapping.
+constexpr int PB_CHUNK = 2048;
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 15u;
+}
+// Key-only build sides store the row number into `dense`; with payload words the whole entry goes into a key-ordered record of
+// twp = 2 * ceil((1 + nc) / 2) words in 16-byte stores (random stores cost per store, not per byte: 6-8x10^10/s whatever the slice).
+__global__ void __launch_bounds__(256) part_build_place_kernel(PartBuild pb, const uint64_t *offsets, const uint64_t *tuples, uint32_t *dense, uint64_t *kord,
+                                                               int twp, uint32_t *cursor, int by_block) {
+    __shared__ uint32_t got;
+    const int x = by_block ? int(blockIdx.x % PB_XCDS) : int(xcc_id() % PB_XCDS);
+    const int TW = 1 + pb.nc;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        for (int p = sweep ? 0 : x; p < pb.parts; p += sweep ? 1 : PB_XCDS) {
+            const uint64_t s = offsets[size_t(p) * size_t(pb.W)], e = offsets[size_t(p + 1) * size_t(pb.W)]; // (offsets[parts * W] = rows)
+            for (;;) {
+                // the sweep over everybody's partitions only looks first (one thread: the answer must be workgroup-uniform)
+                if (threadIdx.x == 0)
+                    got = (sweep && s + __hip_atomic_load(&cursor[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= e) ? ~0u : atomicAdd(&cursor[p], uint32_t(PB_CHUNK));
+                __syncthreads();
+                const uint64_t c0 = got == ~0u ? e : s + got;
+                __syncthreads();
+                if (c0 >= e) break;
+                const uint64_t c1 = c0 + PB_CHUNK < e ? c0 + PB_CHUNK : e;
+                for (uint64_t i = c0 + threadIdx.x; i < c1; i += 256) {
+                    const uint64_t w0 = __builtin_nontemporal_load(&tuples[i * TW]);
+                    const uint32_t d = uint32_t(w0 >> 32);
+                    if (!kord) {
+                        dense[d] = uint32_t(w0) + 1u;
+                        continue;
+                    }
+                    uint64_t *rec = kord + uint64_t(d) * uint64_t(twp);
+                    uint64_t a = uint64_t(uint32_t(w0) + 1u);
+                    for (int k = 0; k < twp; k += 2) {
+                        const uint64_t b = k + 1 < TW ? __builtin_nontemporal_load(&tuples[i * TW + k + 1]) : 0ull;
+                        *reinterpret_cast<ulonglong2 *>(rec + k) = make_ulonglong2(a, b);
+                        a = k + 2 < TW ? __builtin_nontemporal_load(&tuples[i * TW + k + 2]) : 0ull;
+                    }
+                }
+            }
+        }
+    }
 }
 // claims the first free slot of the probe sequence for every row (no key comparison: equal keys simply occupy several slots),
 // then writes the key (and the 32-byte companion slot at the same index)
@@ -1005,7 +1164,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
         mc.src[k] = c.words();
         mc.flip[k] = (mm_cols[k] >= 0 && c.dtype == NQE_INT64) ? 0x8000000000000000ull : 0ull; // the key range is taken unsigned
     }
-    launch(ctx, "join_build_minmax", minmax_cols_kernel, dim3(unsigned(std::min<int64_t>(256, (n + 255) / 256)), unsigned(K)), dim3(256), 0, mc, n,
+    launch(ctx, "join_build_minmax", minmax_cols_kernel, dim3(unsigned(std::min<int64_t>(n >= (int64_t(1) << 22) ? 8 * ctx->num_cus : 256, (n + 255) / 256)), unsigned(K)), dim3(256), 0, mc, n,
            (unsigned long long *)mm->ptr, (unsigned long long *)mm->ptr + K);
     std::vector<uint64_t> mmraw(K * 2), mmh(K * 2);
     NQE_HIP_CHECK(hipMemcpyAsync(mmraw.data(), mm->ptr, K * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1053,12 +1212,61 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
         }
         static const bool atomic_build = getenv("NQE_JOIN_ATOMIC_BUILD") != nullptr; // diagnostics (A/B): the one-kernel form with device atomics
         // (measured: 10^7 rows 1.29 -> 0.67 ms; at 10^8 rows the random stores and gathers over gigabytes lose to the atomics, 22 vs 11 ms)
-        if (n >= (int64_t(1) << 16) && n < (int64_t(1) << 25) && !atomic_build) {
+        const char *part_min_env = getenv("NQE_JOIN_PART_BUILD_MIN"); // read per call: the tests lower it for some builds only
+        const int64_t part_min = part_min_env ? atoll(part_min_env) : (int64_t(1) << 25);
+        bool part_done = false;
+        if (n >= part_min && !atomic_build && (!with_payload || dp.n <= 15) && span <= 0xffffffffull) {
+            // ---- partitioned form (see part_build_* above)
+            const int nc = with_payload ? dp.n : 0;
+            static const int slice_kb = getenv("NQE_JOIN_PART_SLICE_KB") ? atoi(getenv("NQE_JOIN_PART_SLICE_KB")) : 3072; // table bytes per partition (4-byte entries: 1.35 ms per 10^8 rows at 3 MB, 1.8 at 6, 2.5 at 24; 16-byte records: 2.1 either way)
+            PartBuild pb;
+            std::memset(&pb, 0, sizeof(pb));
+            int shift = 10; // the widest slice of 4 + 8 nc bytes per entry within slice_kb, and no more than PB_MAX_PARTS of them
+            while (shift < 31 && (uint64_t(2) << shift) * uint64_t(4 + 8 * nc) <= uint64_t(slice_kb) * 1024) ++shift;
+            while (((span - 1) >> shift) + 1 > uint64_t(PB_MAX_PARTS)) ++shift;
+            pb.keys = kc.words();
+            pb.n = n;
+            pb.dmin = kmin;
+            pb.shift = shift;
+            pb.parts = int(((span - 1) >> shift) + 1);
+            pb.nc = nc;
+            for (int c = 0; c < nc; ++c) pb.src[c] = dp.src[c];
+            const int rpt = nc <= 1 ? 8 : (nc <= 3 ? 4 : (nc <= 7 ? 2 : 1)); // 1024 * rpt tuples of 8 * (1 + nc) bytes in <= 128 KB of LDS
+            const int64_t tile = int64_t(PB_BLOCK) * rpt;
+            pb.W = int(std::min<int64_t>(ctx->num_cus, (n + tile - 1) / tile));
+            pb.chunk = ((n + pb.W - 1) / pb.W + tile - 1) / tile * tile;
+            const size_t cells = size_t(pb.parts) * size_t(pb.W);
+            BufRef counts = dev_alloc(ctx, cells * 4), offsets = dev_alloc(ctx, (cells + 1) * 8);
+            BufRef tuples = dev_alloc(ctx, size_t(n) * size_t(1 + nc) * 8 + 16);
+            // key-ordered records {row + 1, payload words} of an even number of words (16-byte aligned), zeroed: an entry nobody wrote is absent
+            const int twp = nc ? (1 + nc + 1) / 2 * 2 : 0;
+            BufRef kord;
+            if (nc) {
+                kord = dev_alloc(ctx, size_t(span) * size_t(twp) * 8);
+                NQE_HIP_CHECK(hipMemsetAsync(kord->ptr, 0, size_t(span) * size_t(twp) * 8, ctx->stream));
+            }
+            launch(ctx, "join_build_part_count", part_build_count_kernel, dim3(unsigned(pb.W)), dim3(PB_BLOCK), 0, pb, (uint32_t *)counts->ptr);
+            exclusive_scan_u32_to_u64(ctx, (const uint32_t *)counts->ptr, (uint64_t *)offsets->ptr, int64_t(cells));
+            const size_t shmem = size_t(tile) * size_t(1 + nc) * 8 + size_t(PB_MAX_PARTS) * 12;
+            auto sk = rpt == 8 ? part_build_scatter_kernel<8> : (rpt == 4 ? part_build_scatter_kernel<4> : (rpt == 2 ? part_build_scatter_kernel<2> : part_build_scatter_kernel<1>));
+            launch(ctx, "join_build_part_scatter", sk, dim3(unsigned(pb.W)), dim3(PB_BLOCK), shmem, pb, (const uint64_t *)offsets->ptr, (uint64_t *)tuples->ptr);
+            BufRef cursor = dev_alloc_zero(ctx, size_t(pb.parts) * 4);
+            static const int place_by_block = getenv("NQE_JOIN_PART_PLACE_BY_BLOCK") ? atoi(getenv("NQE_JOIN_PART_PLACE_BY_BLOCK")) : 0; // diagnostics (A/B)
+            launch(ctx, "join_build_part_place", part_build_place_kernel, dim3(unsigned(PB_XCDS * ctx->num_cus)), dim3(256), 0, pb, (const uint64_t *)offsets->ptr,
+                   (const uint64_t *)tuples->ptr, (uint32_t *)dense->ptr, kord ? (uint64_t *)kord->ptr : (uint64_t *)nullptr, twp, (uint32_t *)cursor->ptr, place_by_block);
+            BufRef occupied = dev_alloc_zero(ctx, 8);
+            launch(ctx, "join_build_finish", dense_finish_kernel, dim3(stream_grid(ctx, int64_t((span + 63) / 64), 4)), dim3(256), 0, (uint32_t *)dense->ptr, span,
+                   (uint32_t *)presence->ptr, dp, (unsigned long long *)occupied->ptr, kord ? (const uint64_t *)kord->ptr : (const uint64_t *)nullptr, twp);
+            dup = read_scalar(ctx, (const unsigned long long *)occupied->ptr) != (unsigned long long)n; // (also keeps the tuples and records alive until the kernels are done)
+            part_done = true;
+        }
+        if (part_done) {
+        } else if (n >= (int64_t(1) << 16) && n < (int64_t(1) << 25) && !atomic_build) {
             // larger builds: scatter row numbers, then finish in key order (see dense_finish_kernel) — no device-scope atomics
             BufRef occupied = dev_alloc_zero(ctx, 8);
             launch(ctx, "join_build_dense", dense_scatter_rows_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, kmin, (uint32_t *)dense->ptr);
-            launch(ctx, "join_build_finish", dense_finish_kernel, dim3(stream_grid(ctx, int64_t((span + 63) / 64), 4)), dim3(256), 0, (const uint32_t *)dense->ptr, span,
-                   (uint32_t *)presence->ptr, dp, (unsigned long long *)occupied->ptr);
+            launch(ctx, "join_build_finish", dense_finish_kernel, dim3(stream_grid(ctx, int64_t((span + 63) / 64), 4)), dim3(256), 0, (uint32_t *)dense->ptr, span,
+                   (uint32_t *)presence->ptr, dp, (unsigned long long *)occupied->ptr, (const uint64_t *)nullptr, 0);
             dup = read_scalar(ctx, (const unsigned long long *)occupied->ptr) != (unsigned long long)n;
         } else {
             launch(ctx, "join_build_dense", dense_unique_build_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, kmin, (uint32_t *)dense->ptr,

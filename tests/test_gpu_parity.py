@@ -1505,6 +1505,49 @@ def test_join_large_dense_builds_without_device_atomics(ctx, shape, span_bits):
         assert_batches_equal(ctx.hash_join_probe(jt, rt, 0).to_host(), exp, what=f"{shape} reused table")
 
 
+@pytest.mark.parametrize("ncols", [0, 1, 2, 5, 9])
+@pytest.mark.parametrize("shape", ["pk", "sorted", "holes", "dup"])
+def test_join_partitioned_dense_build(ctx, monkeypatch, shape, ncols):
+    """builds of >= 2^25 rows (here: the threshold lowered through NQE_JOIN_PART_BUILD_MIN) partition the rows by key range first
+    (part_build_count / scatter / place kernels: tuples {key - min | row, payload words}, every tile width of the scatter), then
+    finish in key order from the key-ordered payload copies: random and ascending primary keys, keys with holes, a row count that
+    is no multiple of the tile, 0 … 9 payload columns of every packing, duplicates (occupancy count → sort-based build)"""
+    monkeypatch.setenv("NQE_JOIN_PART_BUILD_MIN", "1000")
+    rng = np.random.default_rng(ncols * 11 + len(shape))
+    nb, n = 150_001, 300_000
+    if shape == "pk":
+        dk = rng.permutation(nb).astype(np.int64) + 700
+    elif shape == "sorted":
+        dk = np.arange(nb, dtype=np.int64) + 5
+    elif shape == "holes":
+        dk = rng.permutation(3 * nb)[:nb].astype(np.int64) + 700
+    else:
+        dk = rng.permutation(nb).astype(np.int64)
+        dk[rng.integers(0, nb, 50)] = dk[rng.integers(0, nb, 50)]
+    left = [Column.from_numpy(dk)]
+    for c in range(ncols):
+        if c % 3 == 2:
+            left.append(Column.from_numpy(rng.random(nb)))
+        else:
+            bits = [20, 31, 45, 7, 25, 2][c % 6]
+            a = rng.integers(0, 1 << bits, nb).astype(np.int64) - (1 << 9)
+            a[:2] = [-(1 << 9), (1 << bits) - 1 - (1 << 9)]
+            left.append(Column.from_numpy(a))
+    rk = rng.integers(int(dk.min()) - 10, int(dk.max()) + 10, n).astype(np.int64)
+    right = [Column.from_numpy(rk), Column.from_numpy(rng.random(n))]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    lt, rt = ctx.table_from_host(left), ctx.table_from_host(right)
+    ctx.timing_enable(True); ctx.timing_reset()
+    got = ctx.hash_join(lt, rt, 0, 0).to_host()
+    took = ctx.timing_query("join_build_part_scatter")[1]
+    ctx.timing_enable(False)
+    assert took >= 1, "the partitioned build did not run"    # (non-negative keys: the unsigned key range is dense)
+    assert_batches_equal(got, exp, what=f"{shape}, {ncols} payload columns")
+    jt = ctx.hash_join_build(lt, 0)
+    for _ in range(2):
+        assert_batches_equal(ctx.hash_join_probe(jt, rt, 0).to_host(), exp, what=f"{shape} reused table")
+
+
 @pytest.mark.parametrize("keys", ["small", "negative", "wide", "one_wide", "uint64_high"])
 def test_aggregate_partitioned_path_twelve_byte_tuples_and_their_fallback(ctx, keys):
     """the slab form of the partitioned aggregate moves {int32 key, value} tuples (12 bytes) while every group key fits int32

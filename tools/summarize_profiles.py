@@ -21,7 +21,7 @@ rev = open(os.path.join(src, "csrc_rev.txt")).read().strip() if os.path.exists(o
 CONFIGS = {
     "headline": ({"agg_grouped_fast_kernel": 1}, 16e9),
     "headline_random_keys": ({"agg_grouped_fast_kernel": 1}, 16e9),
-    "c2": ({"keep_from_simple_kernel": 1, "compact_kernel": 1}, 2.0e9),
+    "c2": ({"keep_from_range_strided_kernel": 1, "compact_strided_kernel": 1}, 2.0e9),
     "c4": ({"probe_presence_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
     "c4_sparse_keys": ({"probe_packed_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
     "agg_65536_groups": ({"agg_grouped_fast_kernel": 1, "agg_slab_scatter_kernel": 1, "agg_slab_segments_kernel": 1}, 1.6e9),
@@ -30,7 +30,7 @@ CONFIGS = {
     "agg_tree_predicate": ({"agg_grouped_fast_kernel": 1}, 16e9),
     "agg_three_value_columns": ({"agg_grouped_fast_kernel": 1}, 24e9),
     "agg_4096_groups": ({"agg_grouped_fast_kernel": 1}, 1.6e9),
-    "c2_random_ids": ({"keep_from_simple_kernel": 1, "compact_kernel": 1}, 2.0e9),
+    "c2_random_ids": ({"keep_from_range_strided_kernel": 1, "compact_strided_kernel": 1}, 2.0e9),
     "c2_expression_trees": ({"nqe_jit_expr": 1, "keep_from_pred_kernel": 1, "nqe_jit_proj": 1}, 2.4e9),
     "c4_dup_keys": ({"probe_count_kernel": 1, "probe_write_kernel": 1}, 4.816e9),
     "c4_partial_match": ({"probe_presence_kernel": 1, "join_fused_write_kernel": 1}, 4.496e9),
