@@ -600,6 +600,30 @@ def parity_c4(B, st, sample_rows):
     return {"rows": m, "ok": ok, "output_rows": int(ref[0].length), "tolerance": "bit-exact, row order included"}, cpu
 
 
+def parity_c4_property(B, st):
+    """a build side the oracle cannot hold in minutes (10^8 rows): the whole output checked at full size against what it must be for
+    a primary-key join in which every fact row matches once — computed independently with torch on the device: same row count and
+    order (fact key and value columns bit-identical to the input), dim id == fact key, attr == the attribute stored under that key.
+    (The partitioned build itself has oracle parity at reduced size: tests/test_gpu_parity.py::test_join_partitioned_dense_build.)"""
+    from naive_query_engine_amd.parallel import table_columns_as_tensors
+
+    torch = B.torch
+    out_t = B.ctx.hash_join_probe(st["jt"], st["fact"], 0)
+    B.ctx.synchronize()
+    ok = out_t.num_rows == st["n"] and out_t.num_columns == 4
+    if ok:
+        cols_t = table_columns_as_tensors(out_t, B.dev)
+        by_key = torch.empty(st["nb"], dtype=torch.int64, device=B.dev)
+        by_key[st["dkey"]] = st["attr"]
+        ok = (bool(torch.equal(cols_t[0], st["fkey"])) and bool(torch.equal(cols_t[2], st["fkey"])) and bool(torch.equal(cols_t[1], by_key[st["fkey"]]))
+              and bool(torch.equal(cols_t[3].view(torch.int64), st["val"].view(torch.int64))))
+        del cols_t, by_key
+    del out_t
+    return ({"rows": st["n"], "ok": ok, "output_rows": st["n"], "tolerance": "bit-exact, row order included",
+             "what": "full-size property check (torch, device): order, dim id == fact key, attr == attribute under that key"},
+            {"value": None, "unit": "probe rows/s", "cores": 1, "kind": "port", "sample": "none: a 10^8-row build side is minutes of oracle time"})
+
+
 # ------------------------------------------------------------------------------------------------ the compact record
 def r4(x):
     """4 significant digits: the line must stay small"""
@@ -778,6 +802,8 @@ def main():
             add("c4", lambda: wl_c4(B, 10**8, 10**6, "dense", csteps, cwarm, **kw), pj)
             add("c4_wide_payload", lambda: wl_c4(B, 10**8, 10**6, "wide", csteps, cwarm, **kw), pj)  # attr spans 2^62: an 8 MB payload table
             add("c4_dim_1e7", lambda: wl_c4(B, 10**8, 10**7, "dense", csteps, cwarm, **kw), pj)
+            # a build side as large as the probe side (the partitioned dense build, >= 2^25 rows): build_ms is the number to read
+            add("c4_dim_1e8", lambda: wl_c4(B, 10**8, 10**8, "dense", csteps, cwarm, **kw), lambda s: parity_c4_property(B, s))
             add("c4_sparse_keys", lambda: wl_c4(B, 10**8, 10**6, "sparse", csteps, cwarm, **kw), pj)
             add("c4_dup_keys", lambda: wl_c4(B, 10**8, 10**6, "dup", csteps, cwarm, **kw), pj)
             add("c4_partial_match", lambda: wl_c4(B, 10**8, 10**6, "partial", csteps, cwarm, **kw), pj)

@@ -25,7 +25,7 @@ def fake_result(i, join=False):
 
 
 NAMES = ["c3", "headline_random_keys", "c3_random_keys", "headline_int64_values", "headline_single_column", "agg_three_value_columns", "agg_tree_predicate",
-         "c2", "c2_random_ids", "c4", "c4_wide_payload", "c4_dim_1e7", "c4_sparse_keys", "c4_dup_keys", "c4_partial_match", "agg_4096_groups",
+         "c2", "c2_random_ids", "c4", "c4_wide_payload", "c4_dim_1e7", "c4_dim_1e8", "c4_sparse_keys", "c4_dup_keys", "c4_partial_match", "agg_4096_groups",
          "agg_65536_groups", "agg_1048576_groups"]
 
 
@@ -70,7 +70,8 @@ def test_every_side_config_has_a_parity_check():
     adds = [l for l in block.splitlines() if l.strip().startswith("add(")]
     assert len(adds) >= 16
     for l in adds:
-        assert l.rstrip().endswith(("pa(20_000_000))", "pa(10_000_000))", "pj)", "parity_c2(B, s, 20_000_000))", "parity_c2_tree(B, s, 20_000_000))", "pj)  # attr spans 2^62: an 8 MB payload table")), l
+        assert l.rstrip().endswith(("pa(20_000_000))", "pa(10_000_000))", "pj)", "parity_c2(B, s, 20_000_000))", "parity_c2_tree(B, s, 20_000_000))", "pj)  # attr spans 2^62: an 8 MB payload table",
+                                  "parity_c4_property(B, s))")), l
 
 
 def test_parse_defaults_finish_quickly():
