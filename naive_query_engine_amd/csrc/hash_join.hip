@@ -386,22 +386,29 @@ __device__ __forceinline__ uint32_t xcc_id() {
 // Key-only build sides store the row number into `dense`; with payload words the whole entry goes into a key-ordered record of
 // twp = 2 * ceil((1 + nc) / 2) words in 16-byte stores (random stores cost per store, not per byte: 6-8x10^10/s whatever the slice).
 __global__ void __launch_bounds__(256) part_build_place_kernel(PartBuild pb, const uint64_t *offsets, const uint64_t *tuples, uint32_t *dense, uint64_t *kord,
-                                                               int twp, uint32_t *cursor, int by_block) {
+                                                               int twp, uint32_t *cursor, int by_block, uint32_t chunk) {
     __shared__ uint32_t got;
+    __shared__ int left;
     const int x = by_block ? int(blockIdx.x % PB_XCDS) : int(xcc_id() % PB_XCDS);
     const int TW = 1 + pb.nc;
     for (int sweep = 0; sweep < 2; ++sweep) {
+        if (sweep) { // anything left?  (all cursors looked at together; normally nothing is)
+            if (threadIdx.x == 0) left = 0;
+            __syncthreads();
+            for (int p = threadIdx.x; p < pb.parts; p += 256)
+                if (offsets[size_t(p) * size_t(pb.W)] + __hip_atomic_load(&cursor[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < offsets[size_t(p + 1) * size_t(pb.W)]) left = 1;
+            __syncthreads();
+            if (!left) break; // (workgroup-uniform)
+        }
         for (int p = sweep ? 0 : x; p < pb.parts; p += sweep ? 1 : PB_XCDS) {
             const uint64_t s = offsets[size_t(p) * size_t(pb.W)], e = offsets[size_t(p + 1) * size_t(pb.W)]; // (offsets[parts * W] = rows)
             for (;;) {
-                // the sweep over everybody's partitions only looks first (one thread: the answer must be workgroup-uniform)
-                if (threadIdx.x == 0)
-                    got = (sweep && s + __hip_atomic_load(&cursor[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= e) ? ~0u : atomicAdd(&cursor[p], uint32_t(PB_CHUNK));
+                if (threadIdx.x == 0) got = atomicAdd(&cursor[p], chunk);
                 __syncthreads();
-                const uint64_t c0 = got == ~0u ? e : s + got;
+                const uint64_t c0 = s + got;
                 __syncthreads();
                 if (c0 >= e) break;
-                const uint64_t c1 = c0 + PB_CHUNK < e ? c0 + PB_CHUNK : e;
+                const uint64_t c1 = c0 + chunk < e ? c0 + chunk : e;
                 for (uint64_t i = c0 + threadIdx.x; i < c1; i += 256) {
                     const uint64_t w0 = __builtin_nontemporal_load(&tuples[i * TW]);
                     const uint32_t d = uint32_t(w0 >> 32);
@@ -1252,8 +1259,10 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             launch(ctx, "join_build_part_scatter", sk, dim3(unsigned(pb.W)), dim3(PB_BLOCK), shmem, pb, (const uint64_t *)offsets->ptr, (uint64_t *)tuples->ptr);
             BufRef cursor = dev_alloc_zero(ctx, size_t(pb.parts) * 4);
             static const int place_by_block = getenv("NQE_JOIN_PART_PLACE_BY_BLOCK") ? atoi(getenv("NQE_JOIN_PART_PLACE_BY_BLOCK")) : 0; // diagnostics (A/B)
-            launch(ctx, "join_build_part_place", part_build_place_kernel, dim3(unsigned(PB_XCDS * ctx->num_cus)), dim3(256), 0, pb, (const uint64_t *)offsets->ptr,
-                   (const uint64_t *)tuples->ptr, (uint32_t *)dense->ptr, kord ? (uint64_t *)kord->ptr : (uint64_t *)nullptr, twp, (uint32_t *)cursor->ptr, place_by_block);
+            static const int place_chunk = getenv("NQE_JOIN_PART_CHUNK") ? atoi(getenv("NQE_JOIN_PART_CHUNK")) : PB_CHUNK;         // diagnostics (A/B)
+            static const int place_bpc = getenv("NQE_JOIN_PART_PLACE_BPC") ? atoi(getenv("NQE_JOIN_PART_PLACE_BPC")) : 3;            // workgroups per CU (measured per 10^8 records: 8 -> 2.6 ms, 2-4 -> 2.1, 1 -> 3.1)
+            launch(ctx, "join_build_part_place", part_build_place_kernel, dim3(unsigned(place_bpc * ctx->num_cus)), dim3(256), 0, pb, (const uint64_t *)offsets->ptr,
+                   (const uint64_t *)tuples->ptr, (uint32_t *)dense->ptr, kord ? (uint64_t *)kord->ptr : (uint64_t *)nullptr, twp, (uint32_t *)cursor->ptr, place_by_block, uint32_t(place_chunk));
             BufRef occupied = dev_alloc_zero(ctx, 8);
             launch(ctx, "join_build_finish", dense_finish_kernel, dim3(stream_grid(ctx, int64_t((span + 63) / 64), 4)), dim3(256), 0, (uint32_t *)dense->ptr, span,
                    (uint32_t *)presence->ptr, dp, (unsigned long long *)occupied->ptr, kord ? (const uint64_t *)kord->ptr : (const uint64_t *)nullptr, twp);
