@@ -1783,7 +1783,10 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         srcs.push_back(&left_rowid); out_slot.push_back(-1);
     }
     jc.n_left = int(srcs.size());
-    if (key_shortcut) {
+    // … and when equal keys are identical bits the two key columns of the output are ONE buffer (as in the unique-key forms): a
+    // column less to write
+    const bool key_shared = key_shortcut && share_key_column(jt->left_cols[size_t(jt->left_key)], rk_orig);
+    if (key_shortcut && !key_shared) {
         key_from_probe = rk;
         key_from_probe.validity = nullptr;
         key_from_probe.null_count = 0;
@@ -1841,6 +1844,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         else if (out_slot[k] == -1) outer_pos = dsts[k];
         else inner_pos = dsts[k];
     }
+    if (key_shared) out->cols[size_t(jt->left_key)] = out->cols[jt->left_cols.size() + size_t(right_key)];
     for (size_t c = 0; c < jt->left_cols.size(); ++c)
         if (jt->left_cols[c].dtype == NQE_UTF8)
             out->cols[c] = take_utf8(ctx, jt->left_cols[c], (const int64_t *)outer_pos.words(), M, false);
