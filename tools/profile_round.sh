@@ -15,8 +15,8 @@ declare -A WL=( [headline]="--workload headline" [headline_random_keys]="--workl
                 [c4_sparse_keys]="--workload c4_sparse" [agg_65536_groups]="--workload agg_groups --groups 65536" [agg_4096_groups]="--workload agg_groups --groups 4096" [c2_expression_trees]="--workload c2_tree" \
                 [headline_single_column]="--workload headline_single" [headline_int64_values]="--workload headline_int64" \
                 [agg_tree_predicate]="--workload tree_pred" [agg_three_value_columns]="--workload agg3" [c2_random_ids]="--workload c2_random" \
-                [c4_dup_keys]="--workload c4_dup" [c4_partial_match]="--workload c4_partial" )
-CONFIGS=${NQE_PROFILE_CONFIGS:-"headline headline_random_keys headline_single_column headline_int64_values agg_tree_predicate agg_three_value_columns c2 c2_random_ids c2_expression_trees c4 c4_sparse_keys c4_dup_keys c4_partial_match agg_4096_groups agg_65536_groups"}
+                [c4_dup_keys]="--workload c4_dup" [c4_partial_match]="--workload c4_partial" [c4_dim_1e8]="--workload c4 --dim-rows 100000000" )
+CONFIGS=${NQE_PROFILE_CONFIGS:-"headline headline_random_keys headline_single_column headline_int64_values agg_tree_predicate agg_three_value_columns c2 c2_random_ids c2_expression_trees c4 c4_sparse_keys c4_dup_keys c4_partial_match c4_dim_1e8 agg_4096_groups agg_65536_groups"}
 cd /tmp
 for name in $CONFIGS; do
   args="${WL[$name]} --no-configs --no-cpu-baseline"
@@ -31,6 +31,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_
 cd $R
 python tools/probe_paths.py groups 2>&1 | grep -v amdgpu.ids > $OUT/probe_groups.txt
 python tools/probe_paths.py joinshapes 2>&1 | grep -v amdgpu.ids > $OUT/probe_joinshapes.txt
+python tools/probe_build.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_build.txt
 python tools/probe_paths.py keys 2>&1 | grep -v amdgpu.ids > $OUT/probe_keys.txt
 python tools/probe_paths.py exprs 2>&1 | grep -v amdgpu.ids > $OUT/probe_exprs.txt
 python tools/probe_paths.py trees 2>&1 | grep -v amdgpu.ids > $OUT/probe_trees.txt

@@ -34,6 +34,8 @@ CONFIGS = {
     "c2_expression_trees": ({"nqe_jit_expr": 1, "keep_from_pred_kernel": 1, "nqe_jit_proj": 1}, 2.4e9),
     "c4_dup_keys": ({"probe_count_kernel": 1, "probe_write_kernel": 1}, 4.816e9),
     "c4_partial_match": ({"probe_presence_kernel": 1, "join_fused_write_kernel": 1}, 4.496e9),
+    # 10^8-row build side: the probe kernels per step as for c4 (the kernel stats of this config also hold the partitioned build's kernels)
+    "c4_dim_1e8": ({"probe_presence_kernel": 1, "join_fused_write_kernel": 1}, 6.4e9),
 }
 
 
