@@ -1243,15 +1243,22 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             pb.W = int(std::min<int64_t>(ctx->num_cus, (n + tile - 1) / tile));
             pb.chunk = ((n + pb.W - 1) / pb.W + tile - 1) / tile * tile;
             const size_t cells = size_t(pb.parts) * size_t(pb.W);
-            BufRef counts = dev_alloc(ctx, cells * 4), offsets = dev_alloc(ctx, (cells + 1) * 8);
-            BufRef tuples = dev_alloc(ctx, size_t(n) * size_t(1 + nc) * 8 + 16);
             // key-ordered records {row + 1, payload words} of an even number of words (16-byte aligned), zeroed: an entry nobody wrote is absent
             const int twp = nc ? (1 + nc + 1) / 2 * 2 : 0;
-            BufRef kord;
-            if (nc) {
-                kord = dev_alloc(ctx, size_t(span) * size_t(twp) * 8);
-                NQE_HIP_CHECK(hipMemsetAsync(kord->ptr, 0, size_t(span) * size_t(twp) * 8, ctx->stream));
+            BufRef counts, offsets, tuples, kord;
+            bool part_oom = false;
+            try { // the tuple stream and the records come on top of the table: when they do not fit, the one-kernel form below still may
+                if (getenv("NQE_TEST_PART_BUILD_OOM")) fail(NQE_ERR_OUT_OF_MEMORY, "partitioned build (NQE_TEST_PART_BUILD_OOM)"); // tests: as if the allocation had failed
+                counts = dev_alloc(ctx, cells * 4);
+                offsets = dev_alloc(ctx, (cells + 1) * 8);
+                tuples = dev_alloc(ctx, size_t(n) * size_t(1 + nc) * 8 + 16);
+                if (nc) kord = dev_alloc(ctx, size_t(span) * size_t(twp) * 8);
+            } catch (const Error &e) {
+                if (e.code != NQE_ERR_OUT_OF_MEMORY) throw;
+                part_oom = true;
             }
+            if (!part_oom) {
+            if (nc) NQE_HIP_CHECK(hipMemsetAsync(kord->ptr, 0, size_t(span) * size_t(twp) * 8, ctx->stream));
             launch(ctx, "join_build_part_count", part_build_count_kernel, dim3(unsigned(pb.W)), dim3(PB_BLOCK), 0, pb, (uint32_t *)counts->ptr);
             exclusive_scan_u32_to_u64(ctx, (const uint32_t *)counts->ptr, (uint64_t *)offsets->ptr, int64_t(cells));
             const size_t shmem = size_t(tile) * size_t(1 + nc) * 8 + size_t(PB_MAX_PARTS) * 12;
@@ -1268,6 +1275,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
                    (uint32_t *)presence->ptr, dp, (unsigned long long *)occupied->ptr, kord ? (const uint64_t *)kord->ptr : (const uint64_t *)nullptr, twp);
             dup = read_scalar(ctx, (const unsigned long long *)occupied->ptr) != (unsigned long long)n; // (also keeps the tuples and records alive until the kernels are done)
             part_done = true;
+            }
         }
         if (part_done) {
         } else if (n >= (int64_t(1) << 16) && n < (int64_t(1) << 25) && !atomic_build) {

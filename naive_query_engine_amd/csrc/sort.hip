@@ -12,11 +12,8 @@ namespace nqe {
 
 namespace {
 
-// keys per lane per wave-block: 64 (4096-key chunks) for large inputs, 16 (1024-key chunks) up to 4M keys — a chunk is walked
-// by ONE wave in `items` dependent steps, so the sorts that sit in an operator's tail (10^4..10^6 group keys, a 10^6-row build
-// side) were a handful of waves doing 64 serial steps per pass
-constexpr int SORT_ITEMS_LARGE = 64, SORT_ITEMS_SMALL = 16;
-constexpr int64_t SORT_SMALL_LIMIT = int64_t(1) << 22;
+// keys per workgroup tile of a digit pass: 256 threads x 8
+constexpr int RT_BLOCK = 256, RT_ITEMS = 8, RT_TILE = RT_BLOCK * RT_ITEMS;
 constexpr int SCAN_CHUNK = 4096;               // entries per scan block (1024 threads x 4)
 
 __device__ __forceinline__ uint64_t flip_key(uint64_t k, bool signed_order) { return signed_order ? k ^ 0x8000000000000000ull : k; }
@@ -37,56 +34,106 @@ __global__ void __launch_bounds__(256) radix_hist_kernel(const uint64_t *keys, i
         if (h[i]) atomicAdd(&ghist[i], h[i]);
 }
 
-// ---- per wave-block digit counts, digit-major layout: counts[digit * nblocks + block]
-__global__ void __launch_bounds__(64) radix_count_kernel(const uint64_t *keys, int64_t n, int shift, bool signed_order,
-                                                         uint32_t *counts, int64_t nblocks, int items) {
+// ---- per tile digit counts, digit-major layout: counts[digit * nblocks + tile]
+__global__ void __launch_bounds__(RT_BLOCK) radix_count_kernel(const uint64_t *keys, int64_t n, int shift, bool signed_order, uint32_t *counts, int64_t nblocks) {
     __shared__ uint32_t h[256];
-    for (int i = threadIdx.x; i < 256; i += 64) h[i] = 0;
+    h[threadIdx.x] = 0;
     __syncthreads();
-    int64_t base = int64_t(blockIdx.x) * 64 * items;
-    for (int it = 0; it < items; ++it) {
-        int64_t i = base + int64_t(it) * 64 + threadIdx.x;
+    const int64_t base = int64_t(blockIdx.x) * RT_TILE;
+#pragma unroll
+    for (int it = 0; it < RT_ITEMS; ++it) {
+        const int64_t i = base + int64_t(it) * RT_BLOCK + threadIdx.x;
         if (i < n) atomicAdd(&h[int((flip_key(keys[i], signed_order) >> shift) & 255)], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += 64) counts[int64_t(i) * nblocks + blockIdx.x] = h[i];
+    counts[int64_t(threadIdx.x) * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// ---- stable scatter: one wave per chunk, keys visited in chunk order
-__global__ void __launch_bounds__(64) radix_scatter_kernel(const uint64_t *keys_in, const uint32_t *vals_in, int64_t n,
-                                                           int shift, bool signed_order, const uint32_t *offsets,
-                                                           int64_t nblocks, uint64_t *keys_out, uint32_t *vals_out, int items) {
-    __shared__ uint32_t base_of[256];
-    for (int i = threadIdx.x; i < 256; i += 64) base_of[i] = offsets[int64_t(i) * nblocks + blockIdx.x];
+// ---- stable scatter, one workgroup per 2048-key tile.  A scattered store costs the same whatever it carries (5-8x10^10/s on this
+// chip), and a wave writing its 64 keys straight to their digits' places is 64 such stores per step (the first form of this kernel:
+// 0.69 ms per pass over 1.6x10^7 pairs).  Here the tile is sorted by digit in LDS first — wave w takes keys [512 w, 512 w + 512) in
+// eight steps of 64, so (wave, step, lane) is input order; per-wave digit counts, their scan over the waves and digits, then each
+// wave places its keys step by step through the wave multi-split (8 ballots) — and leaves as runs: consecutive lanes write
+// consecutive pairs of one digit.
+__global__ void __launch_bounds__(RT_BLOCK) radix_scatter_kernel(const uint64_t *keys_in, const uint32_t *vals_in, int64_t n, int shift, bool signed_order,
+                                                                 const uint32_t *offsets, int64_t nblocks, uint64_t *keys_out, uint32_t *vals_out) {
+    constexpr int NW = RT_BLOCK / 64;
+    __shared__ uint64_t skey[RT_TILE];
+    __shared__ uint32_t sval[RT_TILE];
+    __shared__ uint32_t wbase[NW][256]; // per wave: count, then next tile-local position, of each digit
+    __shared__ uint32_t tstart[256], gbase[256];
+    __shared__ uint32_t wtot[NW];
+    const int wave = threadIdx.x >> 6, lane = lane_id(), t = threadIdx.x;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) wbase[w][t] = 0;
+    gbase[t] = offsets[int64_t(t) * nblocks + blockIdx.x];
     __syncthreads();
-    int64_t base = int64_t(blockIdx.x) * 64 * items;
-    for (int it = 0; it < items; ++it) {
-        int64_t i = base + int64_t(it) * 64 + threadIdx.x;
-        bool in = i < n;
-        uint64_t k = in ? keys_in[i] : 0;
-        uint32_t v = in ? vals_in[i] : 0;
-        int digit = int((flip_key(k, signed_order) >> shift) & 255);
+    const int64_t row0 = int64_t(blockIdx.x) * RT_TILE + int64_t(wave) * (64 * RT_ITEMS);
+    uint64_t k[RT_ITEMS];
+    uint32_t v[RT_ITEMS];
+    int dg[RT_ITEMS];
+    bool in[RT_ITEMS];
+#pragma unroll
+    for (int it = 0; it < RT_ITEMS; ++it) {
+        const int64_t i = row0 + it * 64 + lane;
+        in[it] = i < n;
+        k[it] = in[it] ? keys_in[i] : 0;
+        v[it] = in[it] ? vals_in[i] : 0;
+        dg[it] = int((flip_key(k[it], signed_order) >> shift) & 255);
+        if (in[it]) atomicAdd(&wbase[wave][dg[it]], 1u);
+    }
+    __syncthreads();
+    // digit t: exclusive over the waves, then over the digits
+    uint32_t c[NW], tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        c[w] = tot;
+        tot += wbase[w][t];
+    }
+    uint32_t wt;
+    const uint32_t ex = wave_exclusive_scan(tot, wt);
+    if (lane == 63) wtot[wave] = wt;
+    __syncthreads();
+    uint32_t pre = 0, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        if (w < wave) pre += wtot[w];
+        tile_total += wtot[w];
+    }
+    tstart[t] = pre + ex;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) wbase[w][t] = pre + ex + c[w];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RT_ITEMS; ++it) {
         // lanes with the same digit (wave multi-split by 8 ballots)
-        uint64_t peers = __ballot(in);
+        uint64_t peers = __ballot(in[it]);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            uint64_t m = __ballot((digit >> b) & 1);
-            peers &= ((digit >> b) & 1) ? m : ~m;
+            const uint64_t m = __ballot((dg[it] >> b) & 1);
+            peers &= ((dg[it] >> b) & 1) ? m : ~m;
         }
-        uint32_t rank = __popcll(peers & lanemask_lt());
-        uint32_t cnt = __popcll(peers);
+        const uint32_t rank = __popcll(peers & lanemask_lt()), cnt = __popcll(peers);
         uint32_t start = 0;
-        if (in && rank == 0) { // leader of its digit group
-            start = base_of[digit];
-            base_of[digit] = start + cnt;
+        if (in[it] && rank == 0) { // leader of its digit group (this wave's LDS operations execute in order)
+            start = wbase[wave][dg[it]];
+            wbase[wave][dg[it]] = start + cnt;
         }
-        int leader = in ? __ffsll((long long)peers) - 1 : 0;
+        const int leader = in[it] ? __ffsll((long long)peers) - 1 : 0;
         start = __shfl(start, leader, 64);
-        if (in) {
-            keys_out[start + rank] = k;
-            vals_out[start + rank] = v;
+        if (in[it]) {
+            skey[start + rank] = k[it];
+            sval[start + rank] = v[it];
         }
-        __syncthreads(); // base_of updates visible to the next iteration
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < tile_total; i += RT_BLOCK) {
+        const uint64_t kk = skey[i];
+        const int d = int((flip_key(kk, signed_order) >> shift) & 255);
+        const uint32_t dst = gbase[d] + (i - tstart[d]);
+        keys_out[dst] = kk;
+        vals_out[dst] = sval[i];
     }
 }
 
@@ -271,9 +318,7 @@ void radix_sort_pairs_u64(nqe_ctx *ctx, const uint64_t *keys_in, const uint32_t 
             if (h[size_t(d * 256 + b)] == uint32_t(n)) trivial = true;
         if (!trivial) passes.push_back(d);
     }
-    const int items = n <= SORT_SMALL_LIMIT ? SORT_ITEMS_SMALL : SORT_ITEMS_LARGE;
-    const int64_t chunk = int64_t(64) * items;
-    const int64_t nblocks = (n + chunk - 1) / chunk;
+    const int64_t nblocks = (n + RT_TILE - 1) / RT_TILE;
     BufRef counts = dev_alloc(ctx, size_t(nblocks) * 256 * 4);
     BufRef tmp_k, tmp_v;
     if (passes.size() > 1 || passes.empty()) {
@@ -293,11 +338,11 @@ void radix_sort_pairs_u64(nqe_ctx *ctx, const uint64_t *keys_in, const uint32_t 
         uint64_t *dst_k = to_out ? keys_out : (uint64_t *)tmp_k->ptr;
         uint32_t *dst_v = to_out ? vals_out : (uint32_t *)tmp_v->ptr;
         int shift = passes[p] * 8;
-        launch(ctx, "radix_count", radix_count_kernel, dim3((unsigned)nblocks), dim3(64), 0, src_k, n, shift, signed_order,
-               (uint32_t *)counts->ptr, nblocks, items);
+        launch(ctx, "radix_count", radix_count_kernel, dim3((unsigned)nblocks), dim3(RT_BLOCK), 0, src_k, n, shift, signed_order,
+               (uint32_t *)counts->ptr, nblocks);
         exclusive_scan_u32_inplace(ctx, (uint32_t *)counts->ptr, nblocks * 256);
-        launch(ctx, "radix_scatter", radix_scatter_kernel, dim3((unsigned)nblocks), dim3(64), 0, src_k, src_v, n, shift,
-               signed_order, (const uint32_t *)counts->ptr, nblocks, dst_k, dst_v, items);
+        launch(ctx, "radix_scatter", radix_scatter_kernel, dim3((unsigned)nblocks), dim3(RT_BLOCK), 0, src_k, src_v, n, shift,
+               signed_order, (const uint32_t *)counts->ptr, nblocks, dst_k, dst_v);
         src_k = dst_k;
         src_v = dst_v;
     }

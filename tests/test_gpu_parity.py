@@ -1548,6 +1548,43 @@ def test_join_partitioned_dense_build(ctx, monkeypatch, shape, ncols):
         assert_batches_equal(ctx.hash_join_probe(jt, rt, 0).to_host(), exp, what=f"{shape} reused table")
 
 
+@pytest.mark.parametrize("nb", [4097, 6145, 200_003])
+@pytest.mark.parametrize("keys", ["narrow", "wide_signed"])
+def test_join_sort_based_build_order_of_duplicates(ctx, nb, keys):
+    """duplicate build keys go through the stable LSD radix sort (sort.hip: 2048-key tiles sorted by digit in LDS, four waves, eight
+    steps each): the matches of a probe row must come out in ascending build row after two (narrow keys) to six (keys over 2^41,
+    both signs) digit passes, with a last tile that is not full and one that holds a single key"""
+    rng = np.random.default_rng(nb)
+    distinct = max(3, nb // 4)
+    pool = rng.integers(0, 50_000, distinct) if keys == "narrow" else rng.integers(-(1 << 40), 1 << 40, distinct)
+    lk = pool[rng.integers(0, distinct, nb)].astype(np.int64)
+    left = [Column.from_numpy(lk), Column.from_numpy(np.arange(nb, dtype=np.int64)), Column.from_numpy(rng.random(nb))]
+    rk = np.concatenate([pool[rng.integers(0, distinct, 20_000)], rng.integers(-5, 5, 100)]).astype(np.int64)
+    right = [Column.from_numpy(rk), Column.from_numpy(np.arange(rk.size, dtype=np.int64))]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    got = ctx.hash_join(ctx.table_from_host(left), ctx.table_from_host(right), 0, 0).to_host()
+    assert_batches_equal(got, exp, what=f"duplicates, {keys} keys, {nb} build rows")
+
+
+def test_join_partitioned_dense_build_falls_back_when_its_buffers_do_not_fit(ctx, monkeypatch):
+    """the partitioned build's tuple stream and records are extra memory: an allocation failure (NQE_TEST_PART_BUILD_OOM) takes
+    the forms that need none instead of failing the build"""
+    monkeypatch.setenv("NQE_JOIN_PART_BUILD_MIN", "1000")
+    monkeypatch.setenv("NQE_TEST_PART_BUILD_OOM", "1")
+    rng = np.random.default_rng(5)
+    nb, n = 100_003, 200_000
+    left = [Column.from_numpy(rng.permutation(nb).astype(np.int64) + 3), Column.from_numpy(rng.integers(0, 1 << 40, nb).astype(np.int64))]
+    right = [Column.from_numpy(rng.integers(0, nb + 10, n).astype(np.int64)), Column.from_numpy(rng.random(n))]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    lt, rt = ctx.table_from_host(left), ctx.table_from_host(right)
+    ctx.timing_enable(True); ctx.timing_reset()
+    got = ctx.hash_join(lt, rt, 0, 0).to_host()
+    took = ctx.timing_query("join_build_part_scatter")[1]
+    ctx.timing_enable(False)
+    assert took == 0
+    assert_batches_equal(got, exp, what="partitioned build without memory")
+
+
 @pytest.mark.parametrize("keys", ["small", "negative", "wide", "one_wide", "uint64_high"])
 def test_aggregate_partitioned_path_twelve_byte_tuples_and_their_fallback(ctx, keys):
     """the slab form of the partitioned aggregate moves {int32 key, value} tuples (12 bytes) while every group key fits int32
