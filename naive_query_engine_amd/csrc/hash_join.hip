@@ -908,13 +908,20 @@ __global__ void __launch_bounds__(256) probe_pairs_kernel(const uint64_t *rkeys,
                     settled = hit || fb != 0; // found, or the bucket has a free slot: the key is not in the table
                 }
             }
-            if (!settled) { // rare: a full bucket without the key — walk the following slots alone
+            if (!settled) { // a full bucket without the key — the following buckets, alone, a whole bucket (eight loads issued together) per round trip
                 uint32_t sl = (home_slot(key, shift) + 8u) & (cap - 1);
-                for (int p = 0; p < 2 * UNIQUE_MAX_PROBE; ++p) {
-                    const ulonglong2 c = tab[sl];
-                    if (c.x == key) { hit = true; pay = c.y; break; }
-                    if (c.x == filler) break;
-                    sl = (sl + 1) & (cap - 1);
+                bool done = false;
+                for (int hop = 0; hop < 2 * UNIQUE_MAX_PROBE / 8 && !done; ++hop) {
+                    ulonglong2 c[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) c[i] = tab[sl + uint32_t(i)]; // (buckets are 8-slot aligned, cap is a multiple of 8)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (done) continue;
+                        if (c[i].x == key) { hit = true; pay = c[i].y; done = true; }
+                        else if (c[i].x == filler) done = true;
+                    }
+                    sl = (sl + 8u) & (cap - 1);
                 }
             }
             hit = hit && row < n && key != filler;
@@ -965,16 +972,25 @@ __global__ void __launch_bounds__(256) probe_packed_kernel(const uint64_t *rkeys
                     settled = hit || fb != 0;
                 }
             }
-            if (!settled) { // a full bucket without the key (1-2 % of the buckets at load 0.6): walk the following slots alone
-                const unsigned long long *words = reinterpret_cast<const unsigned long long *>(tab);
-                const uint32_t slots = pp.nb * PACKED_BUCKET;
-                uint32_t sl = packed_home(key, pp.nb) * PACKED_BUCKET + PACKED_BUCKET;
-                if (sl == slots) sl = 0;
-                for (int p = 0; p < 2 * UNIQUE_MAX_PROBE; ++p) {
-                    const unsigned long long c = words[sl];
-                    if ((c >> pp.pbits) == kd) { hit = true; pay = c; break; }
-                    if (c == ~0ull) break;
-                    sl = sl + 1 == slots ? 0 : sl + 1;
+            if (!settled) { // a full bucket without the key (2-4 % of the buckets at load 0.6): the following buckets, alone — a whole bucket
+                // per round trip (its eight 16-byte loads issued together, then examined in slot order): walking slot by slot made a
+                // probe side of mostly absent keys twice as slow as one that matches (a wave waits for its slowest lane)
+                uint32_t b = packed_home(key, pp.nb) + 1;
+                bool done = false;
+                for (int hop = 0; hop < 2 * UNIQUE_MAX_PROBE / PACKED_BUCKET && !done; ++hop) {
+                    if (b == pp.nb) b = 0;
+                    ulonglong2 w[PACKED_BUCKET / 2];
+#pragma unroll
+                    for (int i = 0; i < PACKED_BUCKET / 2; ++i) w[i] = tab[size_t(b) * (PACKED_BUCKET / 2) + i];
+#pragma unroll
+                    for (int i = 0; i < PACKED_BUCKET / 2; ++i) {
+                        if (done) continue;
+                        if ((w[i].x >> pp.pbits) == kd) { hit = true; pay = w[i].x; done = true; }
+                        else if (w[i].x == ~0ull) done = true;
+                        else if ((w[i].y >> pp.pbits) == kd) { hit = true; pay = w[i].y; done = true; }
+                        else if (w[i].y == ~0ull) done = true;
+                    }
+                    ++b;
                 }
             }
             hit = hit && row < n && kd <= pp.kspan; // (a key outside the build range shifts to bits no stored word has — except the empty word's)
