@@ -628,13 +628,20 @@ __global__ void __launch_bounds__(256) probe_unique_coop_kernel(const uint64_t *
                     settled = mb != 0 || fb != 0;
                 }
             }
-            if (!settled) { // rare: a full bucket without the key
+            if (!settled) { // a full bucket without the key: the following buckets, a whole bucket per round trip (see probe_pairs_kernel)
                 uint32_t sl = (home_slot(key, shift) + 8u) & (cap - 1);
-                for (uint32_t p = 8; p < cap; ++p) {
-                    const ulonglong2 c = tab[sl];
-                    if (c.y == 0ull) break;
-                    if (c.x == key) { meta = c.y; break; }
-                    sl = (sl + 1) & (cap - 1);
+                bool done = false;
+                for (uint32_t p = 8; p < cap && !done; p += 8) {
+                    ulonglong2 c[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) c[i] = tab[sl + uint32_t(i)];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (done) continue;
+                        if (c[i].y == 0ull) done = true;
+                        else if (c[i].x == key) { meta = c[i].y; done = true; }
+                    }
+                    sl = (sl + 8u) & (cap - 1);
                 }
             }
             const bool hit = row < n && meta != 0ull;
