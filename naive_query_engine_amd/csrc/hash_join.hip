@@ -151,16 +151,28 @@ struct MinMaxCols {
     const uint64_t *src[MAX_JOIN_COLS];
     uint64_t flip[MAX_JOIN_COLS];
 };
-__global__ void __launch_bounds__(256) minmax_cols_kernel(MinMaxCols mc, int64_t n, unsigned long long *mins, unsigned long long *maxs) {
+// `descents` (column 0 = the key only): the number of rows whose key is below its predecessor's — a build side in (nearly) ascending
+// key order, the usual shape of a dimension table, writes and gathers coalesced whatever its size
+__global__ void __launch_bounds__(256) minmax_cols_kernel(MinMaxCols mc, int64_t n, unsigned long long *mins, unsigned long long *maxs, unsigned long long *descents) {
     __shared__ uint64_t smn[4], smx[4];
     const int c = blockIdx.y;
     const uint64_t *__restrict__ v = mc.src[c];
     const uint64_t flip = mc.flip[c];
     uint64_t mn = ~0ull, mx = 0;
+    uint32_t desc = 0;
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
         const uint64_t x = v[i] ^ flip;
         mn = x < mn ? x : mn;
         mx = x > mx ? x : mx;
+        if (c == 0 && descents && i > 0 && (v[i - 1] ^ flip) > x) ++desc; // (the neighbour's word is in the line just read)
+    }
+    if (c == 0 && descents) {
+        const uint64_t m = __ballot(desc != 0);
+        if (m) { // (rare for the shapes this is for)
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) desc += __shfl_down(desc, d, 64);
+            if (lane_id() == 0) atomicAdd(descents, (unsigned long long)desc);
+        }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -1184,9 +1196,9 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
         for (size_t ci = 0; ci < ncols; ++ci)
             if (int(ci) != jt->left_key && (left->cols[ci].dtype == NQE_INT64 || left->cols[ci].dtype == NQE_UINT64)) mm_cols.push_back(int(ci));
     const size_t K = mm_cols.size();
-    BufRef mm = dev_alloc(ctx, K * 16); // [K mins][K maxs]
+    BufRef mm = dev_alloc(ctx, K * 16 + 8); // [K mins][K maxs][descents of the key]
     NQE_HIP_CHECK(hipMemsetAsync(mm->ptr, 0xFF, K * 8, ctx->stream));
-    NQE_HIP_CHECK(hipMemsetAsync(static_cast<char *>(mm->ptr) + K * 8, 0, K * 8, ctx->stream));
+    NQE_HIP_CHECK(hipMemsetAsync(static_cast<char *>(mm->ptr) + K * 8, 0, K * 8 + 8, ctx->stream));
     MinMaxCols mc;
     std::memset(&mc, 0, sizeof(mc));
     for (size_t k = 0; k < K; ++k) {
@@ -1195,10 +1207,12 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
         mc.flip[k] = (mm_cols[k] >= 0 && c.dtype == NQE_INT64) ? 0x8000000000000000ull : 0ull; // the key range is taken unsigned
     }
     launch(ctx, "join_build_minmax", minmax_cols_kernel, dim3(unsigned(std::min<int64_t>(n >= (int64_t(1) << 22) ? 8 * ctx->num_cus : 256, (n + 255) / 256)), unsigned(K)), dim3(256), 0, mc, n,
-           (unsigned long long *)mm->ptr, (unsigned long long *)mm->ptr + K);
-    std::vector<uint64_t> mmraw(K * 2), mmh(K * 2);
-    NQE_HIP_CHECK(hipMemcpyAsync(mmraw.data(), mm->ptr, K * 16, hipMemcpyDeviceToHost, ctx->stream));
+           (unsigned long long *)mm->ptr, (unsigned long long *)mm->ptr + K, (unsigned long long *)mm->ptr + 2 * K);
+    std::vector<uint64_t> mmraw(K * 2 + 1), mmh(K * 2);
+    NQE_HIP_CHECK(hipMemcpyAsync(mmraw.data(), mm->ptr, K * 16 + 8, hipMemcpyDeviceToHost, ctx->stream));
     sync(ctx);
+    // (nearly) ascending keys: fewer than one descent per 64 rows — the scatter / finish form below is then coalesced at any size
+    const bool ascending = getenv("NQE_JOIN_NO_ASCENDING") == nullptr && mmraw[K * 2] * 64 <= uint64_t(n);
     for (size_t k = 0; k < K; ++k) mmh[2 * k] = mmraw[k], mmh[2 * k + 1] = mmraw[K + k];
     const uint64_t kmin = mmh[0], kmax = mmh[1];
     const uint64_t span = kmax - kmin + 1; // 0 on wrap-around: not dense
@@ -1245,7 +1259,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
         const char *part_min_env = getenv("NQE_JOIN_PART_BUILD_MIN"); // read per call: the tests lower it for some builds only
         const int64_t part_min = part_min_env ? atoll(part_min_env) : (int64_t(1) << 25);
         bool part_done = false;
-        if (n >= part_min && !atomic_build && (!with_payload || dp.n <= 15) && span <= 0xffffffffull) {
+        if (n >= part_min && !ascending && !atomic_build && (!with_payload || dp.n <= 15) && span <= 0xffffffffull) {
             // ---- partitioned form (see part_build_* above)
             const int nc = with_payload ? dp.n : 0;
             static const int slice_kb = getenv("NQE_JOIN_PART_SLICE_KB") ? atoi(getenv("NQE_JOIN_PART_SLICE_KB")) : 3072; // table bytes per partition (4-byte entries: 1.35 ms per 10^8 rows at 3 MB, 1.8 at 6, 2.5 at 24; 16-byte records: 2.1 either way)
@@ -1301,7 +1315,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             }
         }
         if (part_done) {
-        } else if (n >= (int64_t(1) << 16) && n < (int64_t(1) << 25) && !atomic_build) {
+        } else if (n >= (int64_t(1) << 16) && (n < (int64_t(1) << 25) || ascending) && !atomic_build) {
             // larger builds: scatter row numbers, then finish in key order (see dense_finish_kernel) — no device-scope atomics
             BufRef occupied = dev_alloc_zero(ctx, 8);
             launch(ctx, "join_build_dense", dense_scatter_rows_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, kmin, (uint32_t *)dense->ptr);

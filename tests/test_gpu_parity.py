@@ -1513,6 +1513,8 @@ def test_join_partitioned_dense_build(ctx, monkeypatch, shape, ncols):
     finish in key order from the key-ordered payload copies: random and ascending primary keys, keys with holes, a row count that
     is no multiple of the tile, 0 … 9 payload columns of every packing, duplicates (occupancy count → sort-based build)"""
     monkeypatch.setenv("NQE_JOIN_PART_BUILD_MIN", "1000")
+    if shape == "sorted":
+        monkeypatch.setenv("NQE_JOIN_NO_ASCENDING", "1")     # (ascending keys normally skip the partitioning: next test)
     rng = np.random.default_rng(ncols * 11 + len(shape))
     nb, n = 150_001, 300_000
     if shape == "pk":
@@ -1546,6 +1548,35 @@ def test_join_partitioned_dense_build(ctx, monkeypatch, shape, ncols):
     jt = ctx.hash_join_build(lt, 0)
     for _ in range(2):
         assert_batches_equal(ctx.hash_join_probe(jt, rt, 0).to_host(), exp, what=f"{shape} reused table")
+
+
+@pytest.mark.parametrize("order", ["ascending", "runs", "one_descent_in_60", "random"])
+def test_join_dense_build_of_ascending_keys_skips_the_partitioning(ctx, monkeypatch, order):
+    """the build's min/max pass also counts the rows whose key is below its predecessor's: with fewer than one in 64 (an ascending
+    primary key, a few sorted runs) the scatter / finish form is coalesced at any size and the partitioning is skipped; one
+    descent in 60 rows, or random order, partitions"""
+    monkeypatch.setenv("NQE_JOIN_PART_BUILD_MIN", "1000")
+    rng = np.random.default_rng(len(order))
+    nb, n = 120_000, 200_000
+    dk = np.arange(nb, dtype=np.int64) + 11
+    if order == "runs":
+        dk = np.concatenate([dk[2::3], dk[0::3], dk[1::3]])
+    elif order == "one_descent_in_60":
+        dk = dk.reshape(-1, 60).copy()
+        dk[:, [0, 59]] = dk[:, [59, 0]]                                             # swap first and last of every 60: two descents per 60 rows
+        dk = dk.reshape(-1)
+    elif order == "random":
+        dk = rng.permutation(dk)
+    left = [Column.from_numpy(dk), Column.from_numpy(rng.integers(0, 1 << 33, nb).astype(np.int64)), Column.from_numpy(rng.random(nb))]
+    right = [Column.from_numpy(rng.integers(0, nb + 30, n).astype(np.int64)), Column.from_numpy(rng.random(n))]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    lt, rt = ctx.table_from_host(left), ctx.table_from_host(right)
+    ctx.timing_enable(True); ctx.timing_reset()
+    got = ctx.hash_join(lt, rt, 0, 0).to_host()
+    took = ctx.timing_query("join_build_part_scatter")[1]
+    ctx.timing_enable(False)
+    assert (took == 0) == (order in ("ascending", "runs")), (order, took)
+    assert_batches_equal(got, exp, what=f"{order} build keys")
 
 
 @pytest.mark.parametrize("nb", [4097, 6145, 200_003])
