@@ -30,7 +30,10 @@
  *     outputs are nqe_table handles owned by the caller (nqe_table_release).
  *     Tables are immutable and their columns may share device buffers (a
  *     projection of a column, a slice, the two key columns of an equi-join on
- *     an integer key are one buffer): never write through nqe_table_column.
+ *     an integer key are one buffer; the probe-side columns of a join on unique
+ *     build keys in which every probe row matched are the probe table's own
+ *     buffers): never write through nqe_table_column, and keep borrowed
+ *     NQE_DEVICE memory alive while any table derived from it is.
  *   - a context owns one HIP stream on one device and is used by one host
  *     thread at a time (the reference is single-threaded).
  *   - calls are stream-ordered: an operator may return while its last kernels

@@ -1576,7 +1576,11 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
     bool left_all_plain = ncols <= size_t(MAX_JOIN_COLS);
     for (auto &c : jt->left_cols) left_all_plain = left_all_plain && is_word_type(c.dtype) && !c.validity;
     if (jt->dense_payload && right_plain) {
-        auto build_out = [&](int64_t out_rows, FusedCols &fc) {
+        // `share_probe` (the optimistic form: output row = probe row): the probe-side columns of the output ARE the probe table's
+        // columns — tables are immutable and their columns may share buffers — so only the build payloads are written
+        const bool no_share_probe = getenv("NQE_JOIN_NO_SHARED_PROBE_COLUMNS") != nullptr; // (read per call: bench.py times both forms)
+        auto build_out = [&](int64_t out_rows, FusedCols &fc, bool share_probe = false) {
+        share_probe = share_probe && !no_share_probe;
         auto out = std::make_unique<nqe_table>();
         out->ctx = ctx;
         out->rows = out_rows;
@@ -1603,6 +1607,12 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         }
         for (size_t cj = 0; cj < right->cols.size(); ++cj) {
             const DevColumn &c = right->cols[cj];
+            if (share_probe) {
+                out->cols.push_back(c);
+                out->cols.back().null_count = 0;
+                if (int(cj) == right_key) right_key_pos = int(out->cols.size()) - 1;
+                continue;
+            }
             out->cols.push_back(make_word_column(ctx, c.dtype, out_rows, false));
             if (int(cj) == right_key) right_key_pos = int(out->cols.size()) - 1;
             // the probe key column is in registers already (kind 1): loading it again as a probe-side column cost pass 2 8-15 %
@@ -1641,7 +1651,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         if (ctx->join_hints.count(jhint)) jt->all_match_failed = true;
         if (jt->dense_full && !jt->all_match_failed && !no_optimistic && n > 0) {
             FusedCols fc;
-            auto out = build_out(n, fc);
+            auto out = build_out(n, fc, true);
             BufRef miss = dev_alloc_zero(ctx, 4);
             const int64_t ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
             if (n >= (int64_t(1) << 20))
@@ -1722,6 +1732,26 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         auto out = std::make_unique<nqe_table>();
         out->ctx = ctx;
         out->rows = km.total;
+        const bool no_share_probe = getenv("NQE_JOIN_NO_SHARED_PROBE_COLUMNS") != nullptr; // (read per call)
+        if (pairs && km.total == n && n > 0 && !no_share_probe && share_key_column(jt->left_cols[size_t(jt->left_key)], rk)) {
+            // every probe row matched: output row = probe row.  The payload words the lookup wrote per probe row ARE the build
+            // payload column of the output, and the other three columns are the probe table's own (shared buffers): no second pass
+            for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
+                DevColumn c;
+                if (int(ci) == jt->left_key) {
+                    c = rk;
+                } else {
+                    c.length = n;
+                    c.values = payload;
+                }
+                c.dtype = jt->left_cols[ci].dtype;
+                c.null_count = 0;
+                out->cols.push_back(c);
+            }
+            for (auto &c : right->cols) out->cols.push_back(c);
+            sync(ctx);
+            return out;
+        }
         if (left_plain && right_plain) {
             // every column is a plain 8-byte column: ONE pass writes all of them (probe columns streamed, the build key taken
             // from the probe key, build payloads gathered by the recorded build row) instead of one compaction per column

@@ -1550,6 +1550,38 @@ def test_join_partitioned_dense_build(ctx, monkeypatch, shape, ncols):
         assert_batches_equal(ctx.hash_join_probe(jt, rt, 0).to_host(), exp, what=f"{shape} reused table")
 
 
+@pytest.mark.parametrize("keys", ["dense", "sparse"])
+@pytest.mark.parametrize("all_match", [True, False])
+def test_join_in_which_every_probe_row_matches_shares_the_probe_columns(ctx, keys, all_match):
+    """unique build keys and every probe row matching: output row = probe row, so the probe-side columns of the output are the
+    probe table's own buffers (dense keys: the optimistic one-pass form writes the build payload only; hashed keys with the payload
+    in the slot: the words the lookup wrote are the payload column, no second pass) — same rows, same order, the same device
+    pointers, and still readable after the probe table's handle is released; one absent key and everything is written as before"""
+    import gc
+    rng = np.random.default_rng(3 + len(keys))
+    nb, n = 50_000, 130_001
+    dk = rng.permutation(nb).astype(np.int64) + 2 if keys == "dense" else (np.arange(nb, dtype=np.int64) << 21) + rng.integers(0, 1 << 21, nb)
+    dk = dk[rng.permutation(nb)]
+    left = [Column.from_numpy(dk), Column.from_numpy(rng.integers(0, 1 << 18, nb).astype(np.int64))]
+    rk = dk[rng.integers(0, nb, n)].copy()
+    if not all_match:
+        rk[n // 3] = dk.max() + 7
+    right = [Column.from_numpy(rk), Column.from_numpy(rng.random(n))]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    lt, rt = ctx.table_from_host(left), ctx.table_from_host(right)
+    for attempt in range(2):                                   # (the second execution of the failing shape starts in the two-pass form)
+        out = ctx.hash_join(lt, rt, 0, 0)
+        shared = [out.column_info(2 + j).values == rt.column_info(j).values for j in range(2)]
+        assert out.column_info(0).values == out.column_info(2).values            # the two key columns are one buffer either way
+        assert shared == [all_match, all_match], (keys, all_match, shared)
+        assert_batches_equal(out.to_host(), exp, what=f"{keys} keys, all_match={all_match}")
+    del rt
+    gc.collect()
+    scratch = ctx.table_from_host([Column.from_numpy(rng.random(n)) for _ in range(4)])   # allocations that would reuse released blocks
+    assert_batches_equal(out.to_host(), exp, what="after the probe table was released")
+    del scratch
+
+
 @pytest.mark.parametrize("order", ["ascending", "runs", "one_descent_in_60", "random"])
 def test_join_dense_build_of_ascending_keys_skips_the_partitioning(ctx, monkeypatch, order):
     """the build's min/max pass also counts the rows whose key is below its predecessor's: with fewer than one in 64 (an ascending
