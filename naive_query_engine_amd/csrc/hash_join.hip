@@ -1689,7 +1689,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         }
         km = finish_mask(ctx, km, counts);
         FusedCols fc;
-        auto out = build_out(km.total, fc);
+        auto out = build_out(km.total, fc, km.total == n); // (every probe row matched after all — a primary key with gaps, say: share the probe columns)
         if (km.ntiles && km.total > 0)
             launch(ctx, "join_fused_write", join_fused_write_kernel<FUSED_WRITE_ROWS>, grid, block, 0, rk.words(), n, km.ntiles, (const uint64_t *)km.keep->ptr,
                    (const uint64_t *)km.tile_offsets->ptr, jt->dense_min, (const uint32_t *)nullptr, fc, uint64_t(0), (int *)nullptr);
@@ -1772,8 +1772,15 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
                 fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
                 fc.n++;
             }
+            const bool share_probe = km.total == n && !no_share_probe; // every probe row matched: the probe-side columns are the probe table's own
             for (size_t cj = 0; cj < right->cols.size(); ++cj) {
                 const DevColumn &c = right->cols[cj];
+                if (share_probe) {
+                    out->cols.push_back(c);
+                    out->cols.back().null_count = 0;
+                    if (int(cj) == right_key) right_key_pos = int(out->cols.size()) - 1;
+                    continue;
+                }
                 out->cols.push_back(make_word_column(ctx, c.dtype, km.total, false));
                 if (int(cj) == right_key) right_key_pos = int(out->cols.size()) - 1;
                 fc.kind[fc.n] = int(cj) == right_key ? 1 : 0;
