@@ -1550,7 +1550,7 @@ def test_join_partitioned_dense_build(ctx, monkeypatch, shape, ncols):
         assert_batches_equal(ctx.hash_join_probe(jt, rt, 0).to_host(), exp, what=f"{shape} reused table")
 
 
-@pytest.mark.parametrize("keys", ["dense", "sparse"])
+@pytest.mark.parametrize("keys", ["dense", "sparse", "dense_gaps", "sparse_two_payloads"])
 @pytest.mark.parametrize("all_match", [True, False])
 def test_join_in_which_every_probe_row_matches_shares_the_probe_columns(ctx, keys, all_match):
     """unique build keys and every probe row matching: output row = probe row, so the probe-side columns of the output are the
@@ -1560,9 +1560,16 @@ def test_join_in_which_every_probe_row_matches_shares_the_probe_columns(ctx, key
     import gc
     rng = np.random.default_rng(3 + len(keys))
     nb, n = 50_000, 130_001
-    dk = rng.permutation(nb).astype(np.int64) + 2 if keys == "dense" else (np.arange(nb, dtype=np.int64) << 21) + rng.integers(0, 1 << 21, nb)
+    if keys == "dense":
+        dk = rng.permutation(nb).astype(np.int64) + 2
+    elif keys == "dense_gaps":                      # a primary key with gaps: the two-pass dense form, which finds n matches out of n
+        dk = rng.permutation(2 * nb)[:nb].astype(np.int64) + 2
+    else:
+        dk = (np.arange(nb, dtype=np.int64) << 21) + rng.integers(0, 1 << 21, nb)
     dk = dk[rng.permutation(nb)]
     left = [Column.from_numpy(dk), Column.from_numpy(rng.integers(0, 1 << 18, nb).astype(np.int64))]
+    if keys == "sparse_two_payloads":               # no payload-in-the-slot table: the generic unique-key form (build rows recorded, gathered)
+        left.append(Column.from_numpy(rng.random(nb)))
     rk = dk[rng.integers(0, nb, n)].copy()
     if not all_match:
         rk[n // 3] = dk.max() + 7
@@ -1571,8 +1578,9 @@ def test_join_in_which_every_probe_row_matches_shares_the_probe_columns(ctx, key
     lt, rt = ctx.table_from_host(left), ctx.table_from_host(right)
     for attempt in range(2):                                   # (the second execution of the failing shape starts in the two-pass form)
         out = ctx.hash_join(lt, rt, 0, 0)
-        shared = [out.column_info(2 + j).values == rt.column_info(j).values for j in range(2)]
-        assert out.column_info(0).values == out.column_info(2).values            # the two key columns are one buffer either way
+        nl = len(left)
+        shared = [out.column_info(nl + j).values == rt.column_info(j).values for j in range(2)]
+        assert out.column_info(0).values == out.column_info(nl).values           # the two key columns are one buffer either way
         assert shared == [all_match, all_match], (keys, all_match, shared)
         assert_batches_equal(out.to_host(), exp, what=f"{keys} keys, all_match={all_match}")
     del rt
