@@ -28,7 +28,10 @@ compact: `frac` = SURVEY §8d's algorithmic bytes over the summed HIP-event time
 8 TB/s peak — EXCEPT where the data lets a kernel skip reads (C2 over sorted ids): there `frac` counts only the bytes that move
 and `frac_8d` is shown beside it; `frac_physical` = the bytes that physically move; `cold_ms` = the first execution of the query
 shape in the process (no plan hints, no remembered join form).  The LAST key, `summary`, repeats {config: [ms, frac,
-frac_physical, parity ok]}.  Per-kernel maps and full workload descriptions go to `--details PATH` (default:
+frac_physical, parity ok]} ({dropin_*: [ms, raw C-ABI ms, ms / raw, parity ok]}).  `dropin_headline` / `dropin_c2` / `dropin_c4` run the
+same queries the way the reference's caller does — a fresh operator tree per execution through the mirrors of its PhysicalPlan surface,
+the rewrite pass, root.execute(), tables registered once — and `upload` is what registering the headline's table from HOST memory costs
+(pageable and page-locked numpy arrays through nqe_table_create).  Per-kernel maps and full workload descriptions go to `--details PATH` (default:
 gpurun_out/bench_details.json when that directory exists).  `--workload X` runs one config as the main line; `--no-configs`
 skips the block (used under rocprofv3).
 """
@@ -498,14 +501,17 @@ def make_join_data(B, rows, nb, variant, first):
     return dkey, attr, fkey, val
 
 
-def wl_c4(B, rows, nb, variant, steps, warmup, gather=False, blocks=1, cold=False):
+def wl_c4(B, rows, nb, variant, steps, warmup, gather=False, blocks=1, cold=False, immutable=False):
     from naive_query_engine_amd import DType
 
     torch = B.torch
     n, first = rows, B.rank * rows
     dkey, attr, fkey, val = make_join_data(B, n, nb, variant, first)
     dim = B.ctx.table_from_device([(DType.INT64, nb, dkey.data_ptr(), None), (DType.INT64, nb, attr.data_ptr(), None)])
-    fact = B.ctx.table_from_device([(DType.INT64, n, fkey.data_ptr(), None), (DType.FLOAT64, n, val.data_ptr(), None)])
+    # the fact table is BORROWED torch memory: by default every output column is written (outputs are the library's own memory,
+    # SURVEY 8b); `immutable` = created with NQE_TABLE_IMMUTABLE (the caller keeps it alive and unmodified, as Arc-shared Arrow
+    # buffers are in the reference): an all-match join may then hand the probe table's own columns on
+    fact = B.ctx.table_from_device([(DType.INT64, n, fkey.data_ptr(), None), (DType.FLOAT64, n, val.data_ptr(), None)], immutable=immutable, keepalive=(fkey, val))
     # the first HashJoin::execute of the process: build + probe, nothing remembered
     cold_ms = B.cold(lambda: B.ctx.hash_join(dim, fact, 0, 0)) if cold else None
     # build (HashJoin::build, hash_join.rs:124-166): timed on its own — replicated on every rank, once per query
@@ -531,7 +537,7 @@ def wl_c4(B, rows, nb, variant, steps, warmup, gather=False, blocks=1, cold=Fals
     # unique build keys and EVERY probe row matches (output row = probe row): the probe-side columns of the output are the probe
     # table's own buffers (tables are immutable, columns may share buffers) — the probe keys are read and the build payload written,
     # nothing else moves.  `frac` is then quoted on those bytes and SURVEY 8d's figure kept as `frac_8d` (as for C2's skipped tiles)
-    shared_probe = variant in ("dense", "wide", "sparse") and m_out == n and not os.environ.get("NQE_JOIN_NO_SHARED_PROBE_COLUMNS")
+    shared_probe = immutable and variant in ("dense", "wide", "sparse") and m_out == n and not os.environ.get("NQE_JOIN_NO_SHARED_PROBE_COLUMNS")
     if shared_probe:
         phys = 8.0 * n + 8.0 * m_out + 16.0 * nb
     kms = kernel_ms(kernels, names)
@@ -637,6 +643,163 @@ def parity_c4_property(B, st):
             {"value": None, "unit": "probe rows/s", "cores": 1, "kind": "port", "sample": "none: a 10^8-row build side is minutes of oracle time"})
 
 
+# ------------------------------------------------------------------------------------------------ the drop-in path and the ingest
+def mem_available_bytes():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def upload_record(B, table, ncols, n):
+    """SURVEY 7 / 8f rank 1: what registering the table costs when it starts in HOST memory (MemTable::try_create over real
+    RecordBatches: nqe_table_create with NQE_HOST columns).  The device-generated columns are downloaded to numpy arrays (pageable
+    memory), uploaded as they are, then page-locked in place (hipHostRegister) and uploaded again.  All `ncols` 8-byte columns of the
+    first `rows` rows; rows = the whole table when host memory allows (3x the table must be available), else 10^8.
+    → (record, the library-owned device table of the LAST upload or None)"""
+    import numpy as np
+
+    from naive_query_engine_amd import Column
+
+    torch = B.torch
+    need = 3 * ncols * 8 * n
+    rows = n if mem_available_bytes() >= need else min(n, 10**8)
+    t0 = time.perf_counter()
+    prefix = table if rows == n else B.ctx.slice(table, 0, rows)
+    host = [prefix.download_column(i).to_numpy() for i in range(ncols)]
+    dl_s = time.perf_counter() - t0
+    del prefix
+    nbytes = float(ncols * 8 * rows)
+    cols = [Column.from_numpy(a) for a in host]
+    rec = {"rows": rows, "bytes": nbytes, "download_GBps": r4(nbytes / dl_s / 1e9), "what": "nqe_table_create over NQE_HOST columns (numpy arrays), blocking; pinned = the same arrays page-locked in place"}
+    up = None
+    for kind in ("pageable", "pinned"):
+        registered = []
+        if kind == "pinned":
+            try:
+                rt = torch.cuda.cudart()
+                for a in host:
+                    if int(rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)) != 0:
+                        raise RuntimeError("hipHostRegister failed")
+                    registered.append(a)
+            except Exception as e:  # noqa: BLE001 - a host that cannot page-lock this much memory still reports the pageable figure
+                rec["pinned_error"] = str(e)[:120]
+                for a in registered:
+                    rt.cudaHostUnregister(a.ctypes.data)
+                break
+        best = None
+        for _ in range(2):
+            del up
+            up = None
+            B.ctx.synchronize()
+            t0 = time.perf_counter()
+            up = B.ctx.table_from_host(cols)
+            B.ctx.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        rec[f"{kind}_ms"] = r4(best * 1e3)
+        rec[f"{kind}_GBps"] = r4(nbytes / best / 1e9)
+        for a in registered:
+            rt.cudaHostUnregister(a.ctypes.data)
+    return rec, (up if rows == n else None)
+
+
+def dropin_record(B, make_tree, raw_step, steps, warmup, blocks, same):
+    """The reference's call pattern over the mirrors of its own operator surface (physical_plan.py): per step a FRESH operator tree as
+    QueryPlanner::create_physical_plan builds it (planner/mod.rs:42-182), the rewrite pass, root.execute() (db.rs:34-36) — tables
+    registered once, results left in HBM — beside the raw C-ABI call of the same query (`raw_ms`), timed back to back here."""
+    from naive_query_engine_amd.rewrite import rewrite
+
+    step = lambda: rewrite(make_tree()).execute()
+    got, exp = step(), raw_step()
+    B.ctx.synchronize()
+    ok = bool(same(got[0].table, exp))
+    del got, exp
+    raw_ms, _, _ = B.timed(raw_step, steps, warmup, blocks)
+    ms, _, spread = B.timed(step, steps, warmup, blocks)
+    return {"ms": r4(ms), "ms_min": r4(spread["ms_min"]), "ms_max": r4(spread["ms_max"]), "raw_ms": r4(raw_ms), "over_raw": r4(ms / raw_ms),
+            "parity": {"ok": ok, "what": "rewrite(tree).execute() == the raw C-ABI call, bit for bit, at full size"}}
+
+
+def same_tables_device(B):
+    from naive_query_engine_amd.parallel import table_columns_as_tensors
+
+    def same(a, b):
+        if a.num_rows != b.num_rows or a.num_columns != b.num_columns:
+            return False
+        ca, cb = table_columns_as_tensors(a, B.dev), table_columns_as_tensors(b, B.dev)
+        B.ctx.synchronize()
+        return all(bool(B.torch.equal(x, y)) for x, y in zip(ca, cb))
+    return same
+
+
+def dropin_aggregate(B, table, sh, total, steps, warmup, blocks, with_filter=True):
+    """dropin_headline: PhysicalAggregatePlan(SelectionPlan(ScanPlan(MemTable))) exactly as the planner builds it"""
+    from naive_query_engine_amd import DType
+    from naive_query_engine_amd.arrow_host import Field
+    from naive_query_engine_amd.expression import ColumnExpr
+    from naive_query_engine_amd.physical_plan import Avg, Count, Max, MemTable, Min, PhysicalAggregatePlan, ScanPlan, SelectionPlan, Sum
+
+    schema = [Field(c[0], DType.FLOAT64 if c[5] == "f64" else DType.INT64, False) for c in sh["cols"]]
+    mt = MemTable.from_device(schema, [table])
+    ops = {AGG.Count: Count, AGG.Sum: Sum, AGG.Avg: Avg, AGG.Min: Min, AGG.Max: Max}
+    pred_expr = sh["pred"](int(total * B.args.pass_frac)) if (with_filter and sh["pred"] is not None) else None
+
+    def make_tree():
+        below = ScanPlan.create(mt, None)
+        if pred_expr is not None:
+            below = SelectionPlan.create(below, pred_expr)
+        return PhysicalAggregatePlan.create([sh["key"]], [ops[f].create(ColumnExpr.try_create(None, c)) for f, c in sh["aggs"]], below)
+
+    fields = [F(c[0]) for c in sh["cols"]]
+    key, pred = sh["key"].flatten(fields), (pred_expr.flatten(fields) if pred_expr is not None else None)
+    raw = lambda: B.ctx.aggregate(table, sh["aggs"], group_nodes=key, pred_nodes=pred)
+    return dropin_record(B, make_tree, raw, steps, warmup, blocks, same_tables_device(B))
+
+
+def dropin_c2(B, rows, steps, warmup, blocks):
+    from naive_query_engine_amd import DType, Operator
+    from naive_query_engine_amd.arrow_host import Field
+    from naive_query_engine_amd.expression import binop, col, lit_i64
+    from naive_query_engine_amd.physical_plan import MemTable, ProjectionPlan, ScanPlan, SelectionPlan
+
+    n = rows
+    ids, age = B.synth(0, 0, n, 0), B.synth(1, 2, n, 0, 60, 18)
+    table = B.ctx.table_from_device([(DType.INT64, n, ids.data_ptr(), None), (DType.INT64, n, age.data_ptr(), None)])
+    schema = [Field("id", DType.INT64, False), Field("age", DType.INT64, False)]
+    mt = MemTable.from_device(schema, [table])
+    pred_e, proj_e = binop(col("id"), Operator.Lt, lit_i64(n // 2)), binop(col("age"), Operator.Plus, lit_i64(100))
+    make_tree = lambda: ProjectionPlan.create(SelectionPlan.create(ScanPlan.create(mt, None), pred_e), [Field("age + 100", DType.INT64, True)], [proj_e])
+    fields = [F("id"), F("age")]
+    raw = lambda: B.ctx.selection_projection(table, pred_e.flatten(fields), [proj_e.flatten(fields)])
+    rec = dropin_record(B, make_tree, raw, steps, warmup, blocks, same_tables_device(B))
+    del ids, age
+    return rec
+
+
+def dropin_c4(B, rows, nb, steps, warmup, blocks):
+    """HashJoin(ScanPlan(dim), ScanPlan(fact)) — a fresh tree per step, so a fresh build per execute (hash_join.rs:280-284) — beside
+    nqe_hash_join_execute.  The tables are registered from HOST columns (library-owned memory, as a drop-in's tables are)."""
+    from naive_query_engine_amd import Column, DType
+    from naive_query_engine_amd.arrow_host import Field
+    from naive_query_engine_amd.physical_plan import ColumnRef, HashJoin, JoinType, MemTable, ScanPlan
+
+    dkey, attr, fkey, val = make_join_data(B, rows, nb, "dense", 0)
+    dim = B.ctx.table_from_host([Column.from_numpy(dkey.cpu().numpy()), Column.from_numpy(attr.cpu().numpy())])
+    fact = B.ctx.table_from_host([Column.from_numpy(fkey.cpu().numpy()), Column.from_numpy(val.cpu().numpy())])
+    del dkey, attr, fkey, val
+    ls = [Field("id", DType.INT64, False), Field("attr", DType.INT64, False)]
+    rs = [Field("key", DType.INT64, False), Field("val", DType.FLOAT64, False)]
+    ml, mr = MemTable.from_device(ls, [dim]), MemTable.from_device(rs, [fact])
+    make_tree = lambda: HashJoin.create(ScanPlan.create(ml, None), ScanPlan.create(mr, None), [(ColumnRef(None, "id"), ColumnRef(None, "key"))], JoinType.Inner, ls + rs)
+    raw = lambda: B.ctx.hash_join(dim, fact, 0, 0)
+    return dropin_record(B, make_tree, raw, steps, warmup, blocks, same_tables_device(B))
+
+
 # ------------------------------------------------------------------------------------------------ the compact record
 def r4(x):
     """4 significant digits: the line must stay small"""
@@ -669,8 +832,10 @@ def summary_of(out):
     s = {"headline": [r4(out["ms_per_step"]), r4(out["roofline"]["frac"]), r4(out["roofline"].get("frac_physical")),
                       (out.get("parity_checked") or {}).get("ok")]}
     for k, c in out.get("configs", {}).items():
-        if "ms" in c:
-            s[k] = [c["ms"], c["frac"], c.get("frac_physical"), (c.get("parity") or {}).get("ok")]
+        if "raw_ms" in c:      # a drop-in row: [ms, raw C-ABI ms, ms / raw ms, parity ok]
+            s[k] = [c["ms"], c["raw_ms"], c["over_raw"], (c.get("parity") or {}).get("ok")]
+        elif "ms" in c:
+            s[k] = [c["ms"], c.get("frac"), c.get("frac_physical"), (c.get("parity") or {}).get("ok")]
     return s
 
 
@@ -721,7 +886,7 @@ def main():
                   "tree_pred": ("tree", True)}
     if wl in agg_shapes:
         shape, filt = agg_shapes[wl]
-        res, st = wl_aggregate(B, n, filt, args.random_keys, args.steps, args.warmup, shape=shape)
+        res, st = wl_aggregate(B, n, filt, args.random_keys, args.steps, args.warmup, shape=shape, cold=True)
         par = parity_aggregate(B, st, args.cpu_sample_rows if wl == "headline" else 20_000_000) if want_cpu else None
         name = {"headline_int64": "headline_int64_values", "headline_single": "headline_single_column", "agg3": "agg_three_value_columns",
                 "tree_pred": "agg_tree_predicate"}.get(wl, wl) + ("_random_keys" if args.random_keys else "")
@@ -752,6 +917,8 @@ def main():
         "config": {"workload": res["workload"], "rows_per_gpu": n_main, "total_rows": n_main * world, "parallelism": f"row-range x{world}"},
         "roofline": res["roofline"],
     }
+    if res.get("cold_ms") is not None:
+        out["cold_ms"] = r4(res["cold_ms"])  # the first execution of the query in the process (run_sql is one-shot: db.rs:24-37)
     if B.distributed:
         out["rccl_ranks"] = B.dist.get_world_size()
         out["rccl_version"] = B.capi.Comm.rccl_version()
@@ -774,6 +941,7 @@ def main():
         okt = B.torch.tensor([1 if ok else 0], dtype=B.torch.int64, device=B.dev)
         B.dist.all_reduce(okt, op=B.dist.ReduceOp.MIN)
         out["result_check"] = {"ok": bool(int(okt.item())), "what": "sharded headline on every rank: 1024 keys, analytic counts, avg = sum / count, min/max in [0, 100)"}
+    main_state = st if (wl == "headline" and not args.no_configs and not args.random_keys and world == 1) else None
     del st
 
     # ---- every other config, in the same line
@@ -813,14 +981,9 @@ def main():
             add("c2_random_ids", lambda: wl_c2(B, 10**8, csteps, cwarm, random_ids=True, **kw), lambda s: parity_c2(B, s, 20_000_000))
             add("c2_expression_trees", lambda: wl_c2_tree(B, 10**8, csteps, cwarm, **kw), lambda s: parity_c2_tree(B, s, 20_000_000))
             add("c4", lambda: wl_c4(B, 10**8, 10**6, "dense", csteps, cwarm, **kw), pj)
-            # the same join with every output column WRITTEN (the probe-side columns copied instead of shared): SURVEY 8d's bytes all move
-            def c4_written():
-                os.environ["NQE_JOIN_NO_SHARED_PROBE_COLUMNS"] = "1"
-                try:
-                    return wl_c4(B, 10**8, 10**6, "dense", csteps, cwarm, **kw)
-                finally:
-                    del os.environ["NQE_JOIN_NO_SHARED_PROBE_COLUMNS"]
-            add("c4_all_columns_written", c4_written, pj)
+            # the same join over a probe table the caller declared immutable (NQE_TABLE_IMMUTABLE): every probe row matches, so the output's
+            # probe-side columns are the probe table's own buffers and only the keys are read and the build payload written
+            add("c4_shared_probe_columns", lambda: wl_c4(B, 10**8, 10**6, "dense", csteps, cwarm, immutable=True, **kw), pj)
             add("c4_wide_payload", lambda: wl_c4(B, 10**8, 10**6, "wide", csteps, cwarm, **kw), pj)  # attr spans 2^62: an 8 MB payload table
             add("c4_dim_1e7", lambda: wl_c4(B, 10**8, 10**7, "dense", csteps, cwarm, **kw), pj)
             # a build side as large as the probe side (the partitioned dense build, >= 2^25 rows): build_ms is the number to read
@@ -845,6 +1008,17 @@ def main():
             cfg["c5"] = {"fact_rows_per_gpu": shard, "probe_only_ms": p["ms"], "gather_ms": r4(gather_ms), "end_to_end_ms": g["ms"],
                          "gathered_bytes_per_rank_inbound": inbound, "xgmi_GBps_per_gpu_inbound": r4(inbound / (gather_ms * 1e-3) / 1e9) if gather_ms > 0 else None,
                          "probe_rows_per_s_all_gpus": r4(10**8 / (p["ms"] * 1e-3))}
+        if world == 1 and not B.distributed and (not only or any(x.startswith(("dropin", "upload")) for x in only)):
+            # ---- the drop-in path (rewrite(tree).execute() through the mirrors of the reference's operator surface) and the ingest
+            B.torch.cuda.empty_cache()
+            up_rec, up_table = upload_record(B, main_state["table"], len(main_state["sh"]["cols"]), main_state["n"])
+            out["upload"] = up_rec
+            dtab = up_table if up_table is not None else main_state["table"]
+            cfg["dropin_headline"] = dropin_aggregate(B, dtab, main_state["sh"], main_state["total"], csteps, cwarm, cblocks)
+            cfg["dropin_headline"]["table"] = "registered from host columns (library-owned)" if up_table is not None else "borrowed device columns"
+            del up_table, dtab
+            cfg["dropin_c2"] = dropin_c2(B, 10**8, csteps, cwarm, cblocks)
+            cfg["dropin_c4"] = dropin_c4(B, 10**8, 10**6, csteps, cwarm, cblocks)
         out["configs"] = cfg
 
     line = finish_line(out)  # `summary` = the LAST key: what a record that keeps only the tail of the line still holds

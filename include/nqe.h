@@ -28,12 +28,16 @@
  *     bit-packed LSB-first, Utf8 = int32 offsets[length+1] + bytes.
  *   - inputs are borrowed for the duration of the call and never mutated;
  *     outputs are nqe_table handles owned by the caller (nqe_table_release).
- *     Tables are immutable and their columns may share device buffers (a
- *     projection of a column, a slice, the two key columns of an equi-join on
- *     an integer key are one buffer; the probe-side columns of a join on unique
- *     build keys in which every probe row matched are the probe table's own
- *     buffers): never write through nqe_table_column, and keep borrowed
- *     NQE_DEVICE memory alive while any table derived from it is.
+ *     Tables are immutable and their columns may share device buffers the
+ *     LIBRARY owns (reference-counted: a projection of a column, the two key
+ *     columns of an equi-join on an integer key are one buffer; the probe-side
+ *     columns of a join on unique build keys in which every probe row matched
+ *     are the probe table's own buffers): never write through nqe_table_column.
+ *     Borrowed NQE_DEVICE memory (nqe_table_create) is never aliased by an
+ *     operator's output — it is the caller's to free or overwrite as soon as
+ *     the operator has returned and the stream has been synchronised — unless
+ *     the table was created with NQE_TABLE_IMMUTABLE.  The explicit zero-copy
+ *     views (nqe_table_project) borrow what their input borrows.
  *   - a context owns one HIP stream on one device and is used by one host
  *     thread at a time (the reference is single-threaded).
  *   - calls are stream-ordered: an operator may return while its last kernels
@@ -211,6 +215,12 @@ nqe_status nqe_ctx_jit_wait(nqe_ctx *ctx);
  * columns are borrowed (zero-copy; the caller keeps them alive). All columns must
  * have the same length. */
 nqe_status nqe_table_create(nqe_ctx *ctx, const nqe_column *columns, int32_t num_columns, nqe_table **out);
+/* The same with flags.  NQE_TABLE_IMMUTABLE: the caller promises that the borrowed NQE_DEVICE buffers stay alive and
+ * unmodified for as long as ANY table derived from this one lives (what `Arc`-shared Arrow buffers give the reference for
+ * free): operator outputs may then alias them instead of copying — the probe-side columns of a join in which every probe
+ * row matched, a projected bare column.  Without it every output of an operator is memory the library owns. */
+#define NQE_TABLE_IMMUTABLE 1u
+nqe_status nqe_table_create_flags(nqe_ctx *ctx, const nqe_column *columns, int32_t num_columns, uint32_t flags, nqe_table **out);
 nqe_status nqe_table_release(nqe_table *table);
 int64_t nqe_table_num_rows(const nqe_table *table);
 int32_t nqe_table_num_columns(const nqe_table *table);

@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("NQE_LIB_PATH") or os.path.join(_HERE, "libnqe_hip.so"
 SYMBOLS = [
     "nqe_abi_version", "nqe_ctx_create", "nqe_ctx_destroy", "nqe_ctx_synchronize", "nqe_ctx_memory_stats", "nqe_ctx_trim", "nqe_last_error",
     "nqe_last_global_error", "nqe_ctx_timing_enable", "nqe_ctx_timing_query", "nqe_ctx_timing_reset", "nqe_ctx_timing_report", "nqe_ctx_jit_wait",
-    "nqe_table_create", "nqe_table_release", "nqe_table_num_rows", "nqe_table_num_columns", "nqe_table_column",
+    "nqe_table_create", "nqe_table_create_flags", "nqe_table_release", "nqe_table_num_rows", "nqe_table_num_columns", "nqe_table_column",
     "nqe_table_download_column", "nqe_table_project", "nqe_table_slice", "nqe_table_concat", "nqe_table_pack_words",
     "nqe_table_unpack_words", "nqe_csv_infer_schema", "nqe_csv_read", "nqe_expr_evaluate",
     "nqe_filter", "nqe_selection_execute", "nqe_projection_execute", "nqe_selection_projection_execute",
@@ -102,6 +102,7 @@ def lib():
         "nqe_ctx_timing_report": (i32, [vp, C.c_char_p, i64, C.POINTER(i64)]),
         "nqe_ctx_jit_wait": (i32, [vp]),
         "nqe_table_create": (i32, [vp, C.POINTER(NqeColumn), i32, pvp]),
+        "nqe_table_create_flags": (i32, [vp, C.POINTER(NqeColumn), i32, C.c_uint32, pvp]),
         "nqe_table_release": (i32, [vp]),
         "nqe_table_num_rows": (i64, [vp]),
         "nqe_table_num_columns": (i32, [vp]),
@@ -153,6 +154,9 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+TABLE_IMMUTABLE = 1  # NQE_TABLE_IMMUTABLE
 
 
 class Context:
@@ -227,9 +231,11 @@ class Context:
         self.check(lib().nqe_table_create(self.handle, arr, len(columns), C.byref(h)))
         return Table(self, h)
 
-    def table_from_device(self, cols: Sequence[tuple]) -> "Table":
-        """cols: [(DType, length, values_device_ptr, validity_device_ptr_or_None)] — zero-copy; the
-        caller keeps the memory alive (e.g. torch tensors)."""
+    def table_from_device(self, cols: Sequence[tuple], immutable: bool = False, keepalive=None) -> "Table":
+        """cols: [(DType, length, values_device_ptr, validity_device_ptr_or_None)] — zero-copy; the caller keeps the memory alive
+        (e.g. torch tensors) while this table is in use.  Operator outputs never alias it — unless `immutable` (NQE_TABLE_IMMUTABLE):
+        the caller then promises the memory stays alive and unmodified while ANY table derived from this one lives; pass the
+        owning objects as `keepalive` and every table derived from this one holds on to them."""
         arr = (NqeColumn * max(1, len(cols)))()
         for i, (dt, n, vptr, valid) in enumerate(cols):
             arr[i].dtype = int(dt)
@@ -239,8 +245,11 @@ class Context:
             arr[i].values = vptr
             arr[i].validity = valid
         h = C.c_void_p()
-        self.check(lib().nqe_table_create(self.handle, arr, len(cols), C.byref(h)))
-        return Table(self, h)
+        self.check(lib().nqe_table_create_flags(self.handle, arr, len(cols), TABLE_IMMUTABLE if immutable else 0, C.byref(h)))
+        t = Table(self, h)
+        if immutable:
+            t._keep = [keepalive]
+        return t
 
     def table_from_arrow(self, record_batch) -> "Table":
         """a pyarrow.RecordBatch through the Arrow C Data Interface (nqe_table_import_arrow): the batch is exported as a struct array
@@ -284,7 +293,7 @@ class Context:
         arr, n = self._nodes(nodes)
         h = C.c_void_p()
         self.check(lib().nqe_expr_evaluate(self.handle, table.handle, arr, n, C.byref(h)))
-        return Table(self, h)
+        return Table(self, h, derived_from=(table,))
 
     def filter(self, table: "Table", pred_table: "Table", pred_column: int = 0) -> "Table":
         h = C.c_void_p()
@@ -301,7 +310,7 @@ class Context:
         arr, offs, ne = self._flat(exprs)
         h = C.c_void_p()
         self.check(lib().nqe_projection_execute(self.handle, table.handle, arr, offs, ne, C.byref(h)))
-        return Table(self, h)
+        return Table(self, h, derived_from=(table,))
 
     def selection_projection(self, table: "Table", pred_nodes, exprs) -> "Table":
         parr, pn = self._nodes(pred_nodes)
@@ -357,7 +366,7 @@ class Context:
     def hash_join(self, left: "Table", right: "Table", left_key: int, right_key: int) -> "Table":
         h = C.c_void_p()
         self.check(lib().nqe_hash_join_execute(self.handle, left.handle, right.handle, left_key, right_key, C.byref(h)))
-        return Table(self, h)
+        return Table(self, h, derived_from=(right,))
 
     def hash_join_build(self, left: "Table", left_key: int) -> "JoinTable":
         h = C.c_void_p()
@@ -367,7 +376,7 @@ class Context:
     def hash_join_probe(self, jt: "JoinTable", right: "Table", right_key: int) -> "Table":
         h = C.c_void_p()
         self.check(lib().nqe_hash_join_probe(self.handle, jt.handle, right.handle, right_key, C.byref(h)))
-        return Table(self, h)
+        return Table(self, h, derived_from=(right,))
 
     def take(self, table: "Table", idx_table: "Table", idx_column: int = 0) -> "Table":
         h = C.c_void_p()
@@ -378,7 +387,7 @@ class Context:
         arr = (C.c_int32 * max(1, len(indices)))(*indices)
         h = C.c_void_p()
         self.check(lib().nqe_table_project(self.handle, table.handle, arr, len(indices), C.byref(h)))
-        return Table(self, h)
+        return Table(self, h, derived_from=(table,), view=True)
 
     def slice(self, table: "Table", offset: int, length: int) -> "Table":
         h = C.c_void_p()
@@ -389,7 +398,7 @@ class Context:
         arr = (C.c_void_p * max(1, len(tables)))(*[t.handle for t in tables])
         h = C.c_void_p()
         self.check(lib().nqe_table_concat(self.handle, arr, len(tables), C.byref(h)))
-        return Table(self, h)
+        return Table(self, h, derived_from=tuple(tables))
 
     # ---- CSV ingest (datasource/csv.rs)
     def csv_infer_schema(self, data: bytes, has_header: bool = True, delimiter: str = ",", max_read_records: int = 3, batch_size: int = 1_000_000):
@@ -532,7 +541,7 @@ class Comm:
     def sharded_hash_join_probe(self, jt: "JoinTable", right_local: "Table", right_key: int, gather: bool = False) -> "Table":
         h = C.c_void_p()
         self.ctx.check(lib().nqe_sharded_hash_join_probe(self.handle, jt.handle, right_local.handle, right_key, 1 if gather else 0, C.byref(h)))
-        return Table(self.ctx, h)
+        return Table(self.ctx, h, derived_from=(right_local,))
 
     def sharded_selection_projection(self, table: "Table", pred_nodes, exprs, gather: bool = False) -> "Table":
         c = self.ctx
@@ -546,9 +555,14 @@ class Comm:
 class Table:
     """nqe_table: one device-resident RecordBatch (owned handle)."""
 
-    def __init__(self, ctx: Context, handle):
+    def __init__(self, ctx: Context, handle, derived_from=(), view: bool = False):
         self.ctx = ctx
         self.handle = handle
+        # what an NQE_TABLE_IMMUTABLE table was told to keep alive travels to every table that may alias its buffers; a zero-copy
+        # view (nqe_table_project) of plainly borrowed memory keeps its parent table object (a handle, no memory) instead
+        self._keep = [k for t in derived_from for k in getattr(t, "_keep", ())]
+        if view:
+            self._keep.append(derived_from)
 
     def __del__(self):
         self.release()

@@ -90,6 +90,7 @@ BufRef dev_view(const BufRef &parent, size_t offset, size_t bytes) {
     v->capacity = bytes;
     v->owned = false;
     v->lib_memory = parent->lib_memory;
+    v->caller_immutable = parent->caller_immutable;
     return BufRef(v, [parent](DevBuf *p) { delete p; });
 }
 
@@ -692,8 +693,14 @@ static int64_t count_valid(nqe_ctx *ctx, const void *bitmap, int64_t n_rows) {
 }
 
 nqe_status nqe_table_create(nqe_ctx *ctx, const nqe_column *columns, int32_t num_columns, nqe_table **out) {
+    return nqe_table_create_flags(ctx, columns, num_columns, 0u, out);
+}
+
+nqe_status nqe_table_create_flags(nqe_ctx *ctx, const nqe_column *columns, int32_t num_columns, uint32_t flags, nqe_table **out) {
     NQE_API_BEGIN(ctx)
     if (!ctx || !out || num_columns < 0 || (num_columns > 0 && !columns)) fail(NQE_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (flags & ~uint32_t(NQE_TABLE_IMMUTABLE)) fail(NQE_ERR_INVALID_ARGUMENT, "unknown table flags");
+    const bool immutable = (flags & NQE_TABLE_IMMUTABLE) != 0;
     auto t = std::make_unique<nqe_table>();
     t->ctx = ctx;
     for (int i = 0; i < num_columns; ++i) {
@@ -715,6 +722,8 @@ nqe_status nqe_table_create(nqe_ctx *ctx, const nqe_column *columns, int32_t num
                 d.data = dev_borrow(ctx, c.data, size_t(c.data_length));
                 d.data_length = c.data_length;
             }
+            for (const BufRef *b : {&d.values, &d.validity, &d.data})
+                if (*b) (*b)->caller_immutable = immutable;
         } else {
             // pad bitmaps to whole words so word-wise kernels may read them
             size_t ab = c.dtype == NQE_BOOLEAN ? bitmap_alloc_bytes(c.length) : vb;
@@ -824,7 +833,14 @@ nqe_status nqe_table_concat(nqe_ctx *ctx, const nqe_table *const *tables, int32_
         t->rows += tables[k]->rows;
     }
     if (n == 1) {
-        t->cols = tables[0]->cols;
+        // one part: the library's own buffers are shared (tables are immutable); borrowed ones are copied like any output
+        for (auto &c : tables[0]->cols) {
+            if (c.shareable()) t->cols.push_back(c);
+            else {
+                t->cols.push_back(slice_column(ctx, c, 0, c.length));
+                t->cols.back().null_count = c.null_count;
+            }
+        }
     } else {
         for (size_t c = 0; c < nc; ++c) {
             std::vector<const DevColumn *> parts;

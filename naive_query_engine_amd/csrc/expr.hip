@@ -1139,6 +1139,15 @@ using namespace nqe;
 
 extern "C" {
 
+// A bare column evaluates to the input column itself (the reference's Arc clone, column.rs:41-43).  As an operator's OUTPUT it
+// may stay an alias only of memory that an alias keeps alive; a column borrowed from the caller is copied.
+static nqe::DevColumn own_output(nqe_ctx *ctx, nqe::DevColumn c) {
+    if (c.shareable()) return c;
+    nqe::DevColumn o = nqe::slice_column(ctx, c, 0, c.length);
+    o.null_count = c.null_count;
+    return o;
+}
+
 nqe_status nqe_expr_evaluate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, int32_t num_nodes,
                              nqe_table **out) {
     NQE_API_BEGIN(ctx)
@@ -1149,7 +1158,7 @@ nqe_status nqe_expr_evaluate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_n
     auto t = std::make_unique<nqe_table>();
     t->ctx = ctx;
     t->rows = in->rows;
-    t->cols.push_back(evaluate_expr(ctx, in, nodes, num_nodes));
+    t->cols.push_back(own_output(ctx, evaluate_expr(ctx, in, nodes, num_nodes)));
     if (fault) throw_on_flags(ctx);
     *out = t.release();
     NQE_API_END()
@@ -1167,7 +1176,7 @@ nqe_status nqe_projection_execute(nqe_ctx *ctx, const nqe_table *in, const nqe_e
     t->ctx = ctx;
     t->rows = in->rows;
     for (int e = 0; e < num_exprs; ++e)
-        t->cols.push_back(evaluate_expr(ctx, in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e]));
+        t->cols.push_back(own_output(ctx, evaluate_expr(ctx, in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e])));
     if (fault) throw_on_flags(ctx);
     *out = t.release();
     NQE_API_END()

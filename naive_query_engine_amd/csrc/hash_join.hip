@@ -1452,17 +1452,6 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
                (const uint32_t *)flags->ptr, (const uint64_t *)offs->ptr, n, U, (uint32_t *)ustart->ptr);
     }
     jt->direct = (int64_t(U) == n);
-    if (!jt->direct && n > 0) {
-        // duplicate keys: plain payload columns in sorted-row order (see nqe_join_table::sorted_cols)
-        jt->sorted_cols.resize(left->cols.size());
-        for (size_t ci = 0; ci < left->cols.size(); ++ci) {
-            const DevColumn &pc = left->cols[ci];
-            if (int(ci) == left_key || !is_word_type(pc.dtype) || pc.validity) continue;
-            jt->sorted_cols[ci] = dev_alloc(ctx, size_t(n) * 8 + 8);
-            launch(ctx, "join_permute_payload", permute_words_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, pc.words(), (const uint32_t *)jt->perm->ptr, n,
-                   (uint64_t *)jt->sorted_cols[ci]->ptr);
-        }
-    }
     uint32_t cap = 64;
     while (uint64_t(cap) < 2ull * U) cap <<= 1;
     int lg = 0;
@@ -1532,6 +1521,27 @@ std::unique_ptr<nqe_join_table> build_table(nqe_ctx *ctx, const nqe_table *left,
             }
         }
     }
+    if (!jt->direct && n > 0) {
+        // duplicate keys: plain payload columns in sorted-row order (see nqe_join_table::sorted_cols).  An optimisation on top of
+        // everything the table needs (allocated above): a copy that does not fit is left out and the probe gathers that column
+        // through the permutation instead (probe_table: need_perm)
+        jt->sorted_cols.resize(left->cols.size());
+        const bool test_oom = getenv("NQE_TEST_SORTED_COLS_OOM") != nullptr; // tests: as if the allocation had failed
+        for (size_t ci = 0; ci < left->cols.size(); ++ci) {
+            const DevColumn &pc = left->cols[ci];
+            if (int(ci) == left_key || !is_word_type(pc.dtype) || pc.validity) continue;
+            try {
+                if (test_oom) fail(NQE_ERR_OUT_OF_MEMORY, "sorted payload copy (NQE_TEST_SORTED_COLS_OOM)");
+                jt->sorted_cols[ci] = dev_alloc(ctx, size_t(n) * 8 + 8);
+            } catch (const Error &e) {
+                if (e.code != NQE_ERR_OUT_OF_MEMORY) throw;
+                jt->sorted_cols[ci] = nullptr;
+                continue;
+            }
+            launch(ctx, "join_permute_payload", permute_words_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, pc.words(), (const uint32_t *)jt->perm->ptr, n,
+                   (uint64_t *)jt->sorted_cols[ci]->ptr);
+        }
+    }
     sync(ctx); // skeys/flags/ustart are released on return
     if (getenv("NQE_DEBUG"))
         fprintf(stderr, "[nqe] join build: n=%lld U=%u direct=%d dense_span=%llu dense_payload=%d dense_full=%d cap=%u\n", (long long)n, U, int(jt->direct),
@@ -1573,6 +1583,10 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
 
     bool right_plain = true;
     for (auto &c : right->cols) right_plain = right_plain && is_word_type(c.dtype) && !c.validity;
+    // the output may reference the probe table's buffers only where an alias keeps them alive (the library's own memory) or the
+    // caller has promised to (NQE_TABLE_IMMUTABLE); borrowed columns are copied — the caller may free them once the join returned
+    bool probe_shareable = true;
+    for (auto &c : right->cols) probe_shareable = probe_shareable && c.shareable();
     bool left_all_plain = ncols <= size_t(MAX_JOIN_COLS);
     for (auto &c : jt->left_cols) left_all_plain = left_all_plain && is_word_type(c.dtype) && !c.validity;
     if (jt->dense_payload && right_plain) {
@@ -1580,7 +1594,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         // columns — tables are immutable and their columns may share buffers — so only the build payloads are written
         const bool no_share_probe = getenv("NQE_JOIN_NO_SHARED_PROBE_COLUMNS") != nullptr; // (read per call: bench.py times both forms)
         auto build_out = [&](int64_t out_rows, FusedCols &fc, bool share_probe = false) {
-        share_probe = share_probe && !no_share_probe;
+        share_probe = share_probe && !no_share_probe && probe_shareable;
         auto out = std::make_unique<nqe_table>();
         out->ctx = ctx;
         out->rows = out_rows;
@@ -1733,7 +1747,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         out->ctx = ctx;
         out->rows = km.total;
         const bool no_share_probe = getenv("NQE_JOIN_NO_SHARED_PROBE_COLUMNS") != nullptr; // (read per call)
-        if (pairs && km.total == n && n > 0 && !no_share_probe && share_key_column(jt->left_cols[size_t(jt->left_key)], rk)) {
+        if (pairs && km.total == n && n > 0 && !no_share_probe && probe_shareable && share_key_column(jt->left_cols[size_t(jt->left_key)], rk)) {
             // every probe row matched: output row = probe row.  The payload words the lookup wrote per probe row ARE the build
             // payload column of the output, and the other three columns are the probe table's own (shared buffers): no second pass
             for (size_t ci = 0; ci < jt->left_cols.size(); ++ci) {
@@ -1772,7 +1786,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
                 fc.dst[fc.n] = (uint64_t *)out->cols.back().values->ptr;
                 fc.n++;
             }
-            const bool share_probe = km.total == n && !no_share_probe; // every probe row matched: the probe-side columns are the probe table's own
+            const bool share_probe = km.total == n && !no_share_probe && probe_shareable; // every probe row matched: the probe-side columns are the probe table's own
             for (size_t cj = 0; cj < right->cols.size(); ++cj) {
                 const DevColumn &c = right->cols[cj];
                 if (share_probe) {

@@ -101,9 +101,15 @@ struct DevBuf {
     // the memory belongs to the context's pool (an allocation of ours, or a view into one): its reuse is ordered on the context's
     // stream, so work enqueued on that stream may still be reading it when the last reference goes away.  false: the caller's.
     bool lib_memory = false;
+    // borrowed memory the caller has promised to keep alive and unmodified while any table derived from it lives
+    // (NQE_TABLE_IMMUTABLE at nqe_table_create_flags): an output may then alias it, as it may alias the library's own buffers
+    bool caller_immutable = false;
     ~DevBuf();
 };
 using BufRef = std::shared_ptr<DevBuf>;
+// may an OUTPUT table reference this buffer instead of a copy?  The library's own memory is reference-counted, so an alias keeps
+// it alive; borrowed memory is the caller's to free or overwrite the moment the producing call returns — unless promised otherwise.
+inline bool buf_shareable(const BufRef &b) { return !b || b->lib_memory || b->caller_immutable; }
 
 BufRef dev_alloc(nqe_ctx *ctx, size_t bytes);
 BufRef dev_alloc_zero(nqe_ctx *ctx, size_t bytes);
@@ -125,6 +131,7 @@ struct DevColumn {
     const uint64_t *words() const { return values ? static_cast<const uint64_t *>(values->ptr) : nullptr; }
     const uint8_t *bits() const { return values ? static_cast<const uint8_t *>(values->ptr) : nullptr; }
     const uint8_t *valid() const { return validity ? static_cast<const uint8_t *>(validity->ptr) : nullptr; }
+    bool shareable() const { return buf_shareable(values) && buf_shareable(validity) && buf_shareable(data); }
 };
 
 } // namespace nqe

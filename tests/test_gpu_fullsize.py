@@ -155,8 +155,16 @@ def test_hash_join_1e8_x_1e6_properties(ctx):
         assert ctx.selection(out, binop(col(0), Operator.NotEq, col(2)).flatten(fo)).num_rows == 0
         rel = binop(binop(binop(col(2), Operator.Multiply, lit_i64(7)), Operator.Plus, lit_i64(3)), Operator.NotEq, col(1))
         assert ctx.selection(out, rel.flatten(fo)).num_rows == 0
-        both = ctx.table_from_device([(DType.INT64, n, out.column_info(2).values, None), (DType.INT64, n, fkey, None),
-                                      (DType.FLOAT64, n, out.column_info(3).values, None), (DType.FLOAT64, n, val, None)])
+        # the probe-side output columns against FRESHLY generated copies of the fact columns, after the caller has overwritten its own
+        # (borrowed) buffers: the output owns its memory and must not be a view of what the caller passed in
+        assert out.column_info(2).values != fkey and out.column_info(3).values != val
+        ctx.synth_fill(1, 77, 0, n, 1 << 40, 0, fkey)
+        ctx.synth_fill(1, 78, 0, n, 1 << 40, 0, val)
+        fkey2, val2 = d.synth(1, 5, n, 0, nb, 0), d.synth(2, 3, n)
+        both = ctx.table_from_device([(DType.INT64, n, out.column_info(2).values, None), (DType.INT64, n, fkey2, None),
+                                      (DType.FLOAT64, n, out.column_info(3).values, None), (DType.FLOAT64, n, val2, None)])
+        fkey, val = fkey2, val2
+        fact = table(ctx, (DType.INT64, n, fkey), (DType.FLOAT64, n, val))
         fb = fields("a", "b", "c", "d")
         assert ctx.selection(both, binop(col(0), Operator.NotEq, col(1)).flatten(fb)).num_rows == 0
         assert ctx.selection(both, binop(col(2), Operator.NotEq, col(3)).flatten(fb)).num_rows == 0

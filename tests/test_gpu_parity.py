@@ -1590,6 +1590,76 @@ def test_join_in_which_every_probe_row_matches_shares_the_probe_columns(ctx, key
     del scratch
 
 
+@pytest.mark.parametrize("keys", ["dense", "sparse", "dense_gaps", "sparse_two_payloads"])
+@pytest.mark.parametrize("immutable", [False, True])
+def test_join_output_never_aliases_borrowed_probe_memory(ctx, keys, immutable):
+    """outputs are callee-allocated and owned by the caller.  A probe table over BORROWED device memory (nqe_table_create
+    with NQE_DEVICE columns) is the caller's to free or overwrite once the join has returned: the all-match forms that share the
+    probe table's columns apply only to memory the library owns or to tables created with NQE_TABLE_IMMUTABLE.  Here the borrowed
+    probe buffers are overwritten right after the join and the output must still equal the oracle's (default), respectively alias
+    them (immutable: same device pointers)."""
+    rng = np.random.default_rng(11 + len(keys))
+    nb, n = 40_000, 100_003
+    if keys == "dense":
+        dk = rng.permutation(nb).astype(np.int64) + 2
+    elif keys == "dense_gaps":
+        dk = rng.permutation(2 * nb)[:nb].astype(np.int64) + 2
+    else:
+        dk = (np.arange(nb, dtype=np.int64) << 21) + rng.integers(0, 1 << 21, nb)
+    dk = dk[rng.permutation(nb)]
+    left = [Column.from_numpy(dk), Column.from_numpy(rng.integers(0, 1 << 18, nb).astype(np.int64))]
+    if keys == "sparse_two_payloads":
+        left.append(Column.from_numpy(rng.random(nb)))
+    rk = dk[rng.integers(0, nb, n)].copy()
+    rv = rng.random(n)
+    exp = orc.hash_join([left], [[Column.from_numpy(rk), Column.from_numpy(rv)]], 0, 0)[0]
+    lt = ctx.table_from_host(left)
+    # the caller's own device memory: torch tensors
+    import torch
+
+    tk, tv = torch.from_numpy(rk).cuda(), torch.from_numpy(rv).cuda()
+    torch.cuda.synchronize()
+    pk, pv = tk.data_ptr(), tv.data_ptr()
+    try:
+        rt = ctx.table_from_device([(DType.INT64, n, pk, None), (DType.FLOAT64, n, pv, None)], immutable=immutable)
+        nl = len(left)
+        out = ctx.hash_join(lt, rt, 0, 0)
+        ctx.synchronize()
+        aliased = [out.column_info(nl + j).values == p for j, p in enumerate((pk, pv))]
+        assert aliased == [immutable, immutable], (keys, immutable, aliased)
+        # a projected bare column follows the same rule
+        pr = ctx.projection(rt, [col(1).flatten(fields("key", "val"))])
+        assert (pr.column_info(0).values == pv) == immutable
+        if not immutable:
+            # the caller reuses its buffers: every word overwritten
+            ctx.synth_fill(1, 99, 0, n, 1 << 40, 0, pk)
+            ctx.synth_fill(1, 98, 0, n, 1 << 40, 0, pv)
+            ctx.synchronize()
+        assert_batches_equal(out.to_host(), exp, what=f"{keys} keys, borrowed probe memory, immutable={immutable}")
+        if not immutable:
+            assert_column_equal(pr.to_host()[0], Column.from_numpy(rv), what="projected bare column of borrowed memory")
+        del out, pr, rt
+    finally:
+        ctx.synchronize()
+        del tk, tv
+
+
+def test_join_duplicate_keys_when_the_sorted_payload_copy_does_not_fit(ctx, monkeypatch):
+    """duplicate build keys: the key-ordered copy of each plain payload column is an optimisation on top of the table — when its
+    allocation fails (NQE_TEST_SORTED_COLS_OOM stands in for the failed hipMalloc) the build still succeeds and the probe gathers
+    the payload through the permutation: same rows, same order"""
+    rng = np.random.default_rng(5)
+    nb, n = 30_000, 80_000
+    dk = rng.integers(0, nb // 4, nb).astype(np.int64)
+    left = [Column.from_numpy(dk), Column.from_numpy(rng.integers(0, 1 << 40, nb).astype(np.int64)), Column.from_numpy(rng.random(nb))]
+    right = [Column.from_numpy(rng.integers(0, nb // 3, n).astype(np.int64)), Column.from_numpy(rng.random(n))]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    lt, rt = ctx.table_from_host(left), ctx.table_from_host(right)
+    assert_batches_equal(ctx.hash_join(lt, rt, 0, 0).to_host(), exp, what="with the sorted payload copies")
+    monkeypatch.setenv("NQE_TEST_SORTED_COLS_OOM", "1")
+    assert_batches_equal(ctx.hash_join(lt, rt, 0, 0).to_host(), exp, what="without them (allocation failed)")
+
+
 @pytest.mark.parametrize("order", ["ascending", "runs", "one_descent_in_60", "random"])
 def test_join_dense_build_of_ascending_keys_skips_the_partitioning(ctx, monkeypatch, order):
     """the build's min/max pass also counts the rows whose key is below its predecessor's: with fewer than one in 64 (an ascending

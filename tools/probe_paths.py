@@ -39,21 +39,23 @@ def timeit(fn, reps=5, warm=2):
     return (time.perf_counter() - t0) / reps
 
 
-# ---- 1. PCIe-inclusive: host numpy columns → nqe_table_create → aggregate
-if SECTION not in ('all', 'pcie'):
-    pass
-n = 100_000_000 if SECTION in ('all', 'pcie') else 1000
-ids = np.arange(n, dtype=np.int64)
-v = np.random.default_rng(0).random(n) * 100
-t0 = time.perf_counter()
-t = ctx.table_from_host([Column.from_numpy(ids), Column.from_numpy(v)])
-up = time.perf_counter() - t0
-key = binop(col(0), Operator.Modulos, lit_i64(1024)).flatten(f)
-pred = binop(col(0), Operator.Lt, lit_i64(n // 2)).flatten(f)
-q = timeit(lambda: ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred))
-print(f"upload {n} rows x 2 cols ({1.6:.1f} GB, pageable numpy): {up*1e3:.1f} ms = {1.6/up:.1f} GB/s; query {q*1e3:.3f} ms; "
-      f"PCIe-inclusive {n/(up+q):.3e} rows/s vs resident {n/q:.3e} rows/s")
-del t
+# ---- 1. PCIe-inclusive: host numpy columns → nqe_table_create → aggregate (only when asked for: SECTION all / pcie)
+if SECTION in ('all', 'pcie'):
+    n = 100_000_000
+    ids = np.arange(n, dtype=np.int64)
+    v = np.random.default_rng(0).random(n) * 100
+    gb = 2 * 8 * n / 1e9
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    t = ctx.table_from_host([Column.from_numpy(ids), Column.from_numpy(v)])
+    ctx.synchronize()
+    up = time.perf_counter() - t0
+    key = binop(col(0), Operator.Modulos, lit_i64(1024)).flatten(f)
+    pred = binop(col(0), Operator.Lt, lit_i64(n // 2)).flatten(f)
+    q = timeit(lambda: ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred))
+    print(f"upload {n} rows x 2 cols ({gb:.2f} GB, pageable numpy): {up*1e3:.1f} ms = {gb/up:.1f} GB/s; query {q*1e3:.3f} ms; "
+          f"PCIe-inclusive {n/(up+q):.3e} rows/s vs resident {n/q:.3e} rows/s")
+    del t, ids, v
 
 # ---- 2. nullable columns (1% nulls) → general kernel
 n = 200_000_000 if SECTION in ('all', 'paths', 'keys', 'exprs', 'trees') else 100_000_000
