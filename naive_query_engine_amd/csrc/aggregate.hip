@@ -1869,3 +1869,6 @@ nqe_status nqe_aggregate_merge_packed(nqe_ctx *ctx, const void *gathered_device,
 }
 
 } // extern "C"
+
+// this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
+NQE_MODULE_PROBE(nqe::agg_ungrouped_fold_kernel);

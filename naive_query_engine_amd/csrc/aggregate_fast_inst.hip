@@ -22,3 +22,8 @@ FastKernel NQE_FAST_CAT(NQE_FAST_PRED, NQE_FAST_VNULL)(int key, int nv, bool vf6
 
 } // namespace agg
 } // namespace nqe
+
+// this slice's code object is loaded when a context is created, not by the first query that picks one of its instances
+// (context.hip: load_modules): any instance names the module
+static const bool nqe_module_probe_ = (nqe::register_module_probe(reinterpret_cast<const void *>(
+                                           nqe::agg::pick_fast_key<NQE_FAST_PRED, NQE_FAST_VNULL != 0>(0, 1, true, false, false, false))), true);

@@ -867,3 +867,6 @@ SegmentsKernel pick_segments_kernel(int nv, bool vf64) {
 
 } // namespace agg
 } // namespace nqe
+
+// this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
+NQE_MODULE_PROBE((nqe::agg::agg_slab_segments_kernel<1, true, false>));

@@ -954,3 +954,6 @@ nqe_status nqe_device_free(nqe_ctx *ctx, void *ptr) {
 }
 
 } // extern "C"
+
+// this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
+NQE_MODULE_PROBE(nqe::synth_kernel);

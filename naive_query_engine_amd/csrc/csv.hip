@@ -458,3 +458,6 @@ nqe_status nqe_csv_read(nqe_ctx *ctx, const void *bytes, int32_t location, int64
 }
 
 } // extern "C"
+
+// this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
+NQE_MODULE_PROBE(nqe::csv_block_scan_kernel);

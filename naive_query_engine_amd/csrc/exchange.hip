@@ -712,3 +712,6 @@ nqe_status nqe_sharded_selection_projection_execute(nqe_comm *comm, const nqe_ta
 }
 
 } // extern "C"
+
+// this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
+NQE_MODULE_PROBE(nqe::store_word_kernel);

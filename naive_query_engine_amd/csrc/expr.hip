@@ -1183,3 +1183,6 @@ nqe_status nqe_projection_execute(nqe_ctx *ctx, const nqe_table *in, const nqe_e
 }
 
 } // extern "C"
+
+// this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
+NQE_MODULE_PROBE(nqe::fill_words_kernel);

@@ -1994,3 +1994,6 @@ nqe_status nqe_hash_join_execute(nqe_ctx *ctx, const nqe_table *left, const nqe_
 }
 
 } // extern "C"
+
+// this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
+NQE_MODULE_PROBE(nqe::iota_u32_kernel);

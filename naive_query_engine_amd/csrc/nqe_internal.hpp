@@ -144,6 +144,14 @@ struct nqe_table {
 
 namespace nqe {
 
+// ---- code objects ------------------------------------------------------------------------
+// HIP loads a translation unit's code object (1-5 MB each here) on the FIRST launch of one of its kernels: 2-5 ms that the first
+// query of a process would pay per operator family (the reference's run_sql is one-shot, db.rs:24-37).  Every translation unit
+// registers one of its kernels at static-initialisation time; nqe_ctx_create asks the runtime for that kernel's attributes, which
+// loads the unit for the context's device (NQE_LAZY_MODULES=1 leaves the loading to the first launch).
+void register_module_probe(const void *kernel);
+#define NQE_MODULE_PROBE(kernel) static const bool nqe_module_probe_ = (nqe::register_module_probe(reinterpret_cast<const void *>(&kernel)), true)
+
 // ---- launch helpers ---------------------------------------------------------------------
 struct TimerScope {
     nqe_ctx *ctx;

@@ -617,3 +617,6 @@ nqe_status nqe_selection_projection_execute(nqe_ctx *ctx, const nqe_table *in, c
 }
 
 } // extern "C"
+
+// this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
+NQE_MODULE_PROBE(nqe::keep_from_pred_kernel);

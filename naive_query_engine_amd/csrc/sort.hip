@@ -349,3 +349,6 @@ void radix_sort_pairs_u64(nqe_ctx *ctx, const uint64_t *keys_in, const uint32_t 
 }
 
 } // namespace nqe
+
+// this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
+NQE_MODULE_PROBE(nqe::radix_hist_kernel);

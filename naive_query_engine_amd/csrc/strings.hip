@@ -219,3 +219,6 @@ DevColumn utf8_literal_column(nqe_ctx *ctx, const std::string &lit, bool lit_nul
 }
 
 } // namespace nqe
+
+// this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
+NQE_MODULE_PROBE(nqe::fill_i64_kernel);
