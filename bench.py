@@ -59,7 +59,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="headline", choices=["headline", "headline_int64", "headline_single", "agg3", "tree_pred", "c2", "c2_random", "c2_tree", "c3",
+    ap.add_argument("--workload", default="headline", choices=["headline", "headline_int64", "headline_single", "agg3", "agg_readme", "headline_nullable", "tree_pred", "c2", "c2_random", "c2_tree", "c3",
                                                                "c4", "c4_sparse", "c4_wide", "c4_dup", "c4_partial", "agg_groups"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the BASELINE size of the workload)")
     ap.add_argument("--random-keys", action="store_true", help="c3/headline: group by a random id column instead of the row number")
@@ -289,12 +289,40 @@ def agg_shape(name, total, random_keys=False, groups=None):
     if name == "three":         # C1's query shape (src/main.rs:36-40) at scale: three DIFFERENT value columns
         return dict(cols=[idc, ("age", 1, 2, 60, 18, "i64"), ("score", 2, 3, 1, 0, "f64")], aggs=[(AGG.Count, 0), (AGG.Sum, 1), (AGG.Avg, 2)],
                     key=key_mod(3), pred=None, bpr=24.0, text="select count(id),sum(age),avg(score) from t group by id % 3; t(id Int64, age Int64, score Float64)")
+    if name == "readme":        # the reference's own aggregate query (src/main.rs:36-40, README.md:105-111) at scale: three DIFFERENT value columns, one with min / max
+        return dict(cols=[idc, ("age", 1, 2, 60, 18, "i64"), ("score", 2, 3, 1, 0, "f64")],
+                    aggs=[(AGG.Count, 0), (AGG.Sum, 1), (AGG.Sum, 2), (AGG.Avg, 2), (AGG.Max, 2), (AGG.Min, 2)], key=key_mod(3), pred=None, bpr=24.0,
+                    text="select count(id),sum(age),sum(score),avg(score),max(score),min(score) from t group by id % 3; t(id Int64, age Int64, score Float64)")
+    if name == "vnull":         # SURVEY 8d's correctness run at full size: the headline with 1 % NULLs in v (validity bitmap: 1 bit/row more)
+        return dict(cols=[idc, ("v", 2, 3, 1, 0, "f64")], aggs=five(1), key=key_mod(1024), pred=lt, bpr=16.125, nullable={1: (4, 100)},
+                    text="select count(v),sum(v),avg(v),min(v),max(v) from t{w} group by id % 1024; t(id Int64, v Float64 with 1 % NULLs: u(i,4) mod 100 = 0)")
     if name == "tree":          # a predicate that is neither a chain nor a list of compares: `v < 20 or id % 3 == 0`
         tree = lambda limit: binop(binop(col(1), Operator.Lt, lit_f64(20.0)), Operator.Or,
                                    binop(binop(col(0), Operator.Modulos, lit_i64(3)), Operator.Eq, lit_i64(0)))
         return dict(cols=[idc, ("v", 2, 3, 1, 0, "f64")], aggs=five(1), key=key_mod(1024), pred=tree, bpr=16.0,
                     text="select count(v),sum(v),avg(v),min(v),max(v) from t where v < 20 or id % 3 = 0 group by id % 1024; t(id Int64, v Float64)")
     raise ValueError(name)
+
+
+def device_validity(B, seed, mod, n, first):
+    """LSB-first validity bitmap (padded to whole 64-bit words) of `n` rows on the device: row i is NULL when u(first + i, seed) mod `mod` == 0
+    (SURVEY 8d's 1 % nulls: seed 4, mod 100).  Built in chunks with torch from the library's own generator."""
+    torch = B.torch
+    nbytes = (n + 63) // 64 * 8
+    out = torch.zeros(nbytes, dtype=torch.uint8, device=B.dev)
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=B.dev)
+    chunk = 1 << 27
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        u = B.synth(1, seed, m, first + lo, mod, 0)
+        bits = (u != 0)
+        del u
+        if m % 8:
+            bits = torch.cat([bits, torch.zeros(8 - m % 8, dtype=torch.bool, device=B.dev)])
+        out[lo // 8: lo // 8 + (m + 7) // 8] = (bits.view(-1, 8).to(torch.uint8) * w).sum(dim=1, dtype=torch.uint8)
+        del bits
+    torch.cuda.synchronize()
+    return out
 
 
 def wl_aggregate(B, rows, with_filter, random_keys, steps, warmup, groups=None, exchange=True, shape="v", blocks=1, cold=False):
@@ -306,7 +334,9 @@ def wl_aggregate(B, rows, with_filter, random_keys, steps, warmup, groups=None, 
     sh = agg_shape(shape, total, random_keys, groups)
     fields = [F(c[0]) for c in sh["cols"]]
     tens = [B.synth(kind, seed, n, first, mod, base, dtype=torch.float64 if dt == "f64" else torch.int64) for (_, kind, seed, mod, base, dt) in sh["cols"]]
-    table = B.ctx.table_from_device([(DType.FLOAT64 if c[5] == "f64" else DType.INT64, n, t.data_ptr(), None) for c, t in zip(sh["cols"], tens)])
+    valid = {j: device_validity(B, seed, mod, n, first) for j, (seed, mod) in sh.get("nullable", {}).items()}
+    table = B.ctx.table_from_device([(DType.FLOAT64 if c[5] == "f64" else DType.INT64, n, t.data_ptr(), valid[j].data_ptr() if j in valid else None)
+                                     for j, (c, t) in enumerate(zip(sh["cols"], tens))])
     key = sh["key"].flatten(fields)
     use_pred = with_filter and sh["pred"] is not None
     pred = sh["pred"](int(total * B.args.pass_frac)).flatten(fields) if use_pred else None
@@ -323,7 +353,7 @@ def wl_aggregate(B, rows, with_filter, random_keys, steps, warmup, groups=None, 
     names = ["agg_grouped", "agg_partition", "agg_slab", "agg_segments", "agg_subpartition", "agg_sample", "expr_tree", "keep_from"]
     res = {"metric": "filter_hash_aggregate_rows_per_s" if use_pred else "hash_aggregate_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s",
            "ms_per_step": ms, "spread": spread, "cold_ms": cold_ms, "workload": desc, "rows_per_gpu": n, "roofline": roofline(sh["bpr"] * n, kernels, names)}
-    return res, dict(table=table, tens=tens, sh=sh, key=key, fields=fields, n=n, total=total, use_pred=use_pred, random_keys=random_keys, groups=groups)
+    return res, dict(table=table, tens=tens, valid=valid, sh=sh, key=key, fields=fields, n=n, total=total, use_pred=use_pred, random_keys=random_keys, groups=groups)
 
 
 def parity_aggregate(B, st, sample_rows):
@@ -339,14 +369,16 @@ def parity_aggregate(B, st, sample_rows):
     for (_, kind, seed, mod, base, dt) in sh["cols"]:
         a = orc.synth_fill(kind, seed, 0, m, mod, base)
         host.append(a.view(np.float64) if dt == "f64" else a.view(np.int64))
-    h = orc.upload([[Column.from_numpy(a) for a in host]])
+    masks = {j: orc.synth_fill(1, seed, 0, m, mod, 0).view(np.int64) != 0 for j, (seed, mod) in sh.get("nullable", {}).items()}
+    h = orc.upload([[Column.from_numpy(a, masks.get(j)) for j, a in enumerate(host)]])
     # `id < limit`: half of the id range of the SAMPLE (sorted ids: the prefix's own range; random ids: drawn from [0, total))
     plimit = st["total"] // 2 if st["random_keys"] else m // 2
     pred = sh["pred"](plimit).flatten(st["fields"]) if st["use_pred"] else None
     t0 = time.perf_counter()
     ref = orc.aggregate(h, sh["aggs"], group_nodes=st["key"], pred_nodes=pred)[0]
     dt_s = time.perf_counter() - t0
-    prefix = B.ctx.table_from_device([(DType.FLOAT64 if c[5] == "f64" else DType.INT64, m, t.data_ptr(), None) for c, t in zip(sh["cols"], st["tens"])])
+    prefix = B.ctx.table_from_device([(DType.FLOAT64 if c[5] == "f64" else DType.INT64, m, t.data_ptr(), st["valid"][j].data_ptr() if j in st.get("valid", {}) else None)
+                                      for j, (c, t) in enumerate(zip(sh["cols"], st["tens"]))])
     got = B.ctx.aggregate(prefix, sh["aggs"], group_nodes=st["key"], pred_nodes=pred).to_host()
     g = np.stack([c.to_numpy().astype(np.float64) for c in got], axis=1)
     e = np.stack([c.to_numpy().astype(np.float64) for c in ref], axis=1)
@@ -889,19 +921,20 @@ def main():
     AGG = AggregateFunc
     B = Bench(args, world, rank, local_rank)
     wl = args.workload
-    default_rows = {"headline": 10**9, "headline_int64": 10**9, "headline_single": 10**9, "agg3": 10**9, "tree_pred": 10**9, "c3": 10**9}.get(wl, 10**8)
+    default_rows = {"headline": 10**9, "headline_int64": 10**9, "headline_single": 10**9, "agg3": 10**9, "agg_readme": 10**9, "headline_nullable": 10**9, "tree_pred": 10**9,
+                    "c3": 10**9}.get(wl, 10**8)
     n = args.rows or default_rows
     want_cpu = world == 1 and not args.no_cpu_baseline
     csteps, cwarm, cblocks = max(3, min(args.steps, 10)), 2, 3  # the side configs: three blocks of a few steps each
 
     # ---- the main line
     agg_shapes = {"headline": ("v", True), "c3": ("v", False), "headline_int64": ("age", True), "headline_single": ("id", True), "agg3": ("three", False),
-                  "tree_pred": ("tree", True)}
+                  "tree_pred": ("tree", True), "agg_readme": ("readme", False), "headline_nullable": ("vnull", True)}
     if wl in agg_shapes:
         shape, filt = agg_shapes[wl]
         res, st = wl_aggregate(B, n, filt, args.random_keys, args.steps, args.warmup, shape=shape, cold=True)
         par = parity_aggregate(B, st, args.cpu_sample_rows if wl == "headline" else 20_000_000) if want_cpu else None
-        name = {"headline_int64": "headline_int64_values", "headline_single": "headline_single_column", "agg3": "agg_three_value_columns",
+        name = {"headline_int64": "headline_int64_values", "headline_single": "headline_single_column", "agg3": "agg_three_value_columns", "agg_readme": "agg_readme_shape",
                 "tree_pred": "agg_tree_predicate"}.get(wl, wl) + ("_random_keys" if args.random_keys else "")
     elif wl == "agg_groups":
         res, st = wl_aggregate(B, n, False, False, args.steps, args.warmup, groups=args.groups)
@@ -989,6 +1022,8 @@ def main():
             add("headline_int64_values", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, shape="age", **kw), pa(20_000_000))
             add("headline_single_column", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, shape="id", **kw), pa(20_000_000))
             add("agg_three_value_columns", lambda: wl_aggregate(B, n, False, False, csteps, cwarm, shape="three", **kw), pa(20_000_000))
+            add("agg_readme_shape", lambda: wl_aggregate(B, n, False, False, csteps, cwarm, shape="readme", **kw), pa(20_000_000))
+            add("headline_nullable", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, shape="vnull", **kw), pa(20_000_000))
             add("agg_tree_predicate", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, shape="tree", **kw), pa(20_000_000))
             add("c2", lambda: wl_c2(B, 10**8, csteps, cwarm, **kw), lambda s: parity_c2(B, s, 20_000_000))
             add("c2_random_ids", lambda: wl_c2(B, 10**8, csteps, cwarm, random_ids=True, **kw), lambda s: parity_c2(B, s, 20_000_000))
