@@ -16,6 +16,23 @@ void set_global_error(const std::string &msg) {
     g_global_error = msg;
 }
 
+// ---------------------------------------------------------------- code objects
+static std::vector<const void *> &module_probes() {
+    static std::vector<const void *> v; // constructed on first use: registrations run during static initialisation, in any order
+    return v;
+}
+void register_module_probe(const void *kernel) {
+    if (kernel) module_probes().push_back(kernel);
+}
+// loads every translation unit's code object for the current device (see nqe_internal.hpp)
+static void load_modules() {
+    if (getenv("NQE_LAZY_MODULES")) return;
+    for (const void *k : module_probes()) {
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, k) != hipSuccess) (void)hipGetLastError(); // the first launch reports a real problem
+    }
+}
+
 // ---------------------------------------------------------------- allocator
 static size_t round_capacity(size_t bytes) {
     if (bytes < 256) return 256;
@@ -528,6 +545,7 @@ nqe_status nqe_ctx_create(int32_t device, void *stream, nqe_ctx **out) {
     NQE_HIP_CHECK(hipHostMalloc(&ctx->h_flags, sizeof(int) * NQE_NUM_FLAGS, hipHostMallocMapped | hipHostMallocCoherent));
     NQE_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_flags_dev), ctx->h_flags, 0));
     NQE_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NQE_NUM_FLAGS, ctx->stream));
+    load_modules();
     *out = ctx.release();
     NQE_API_END()
 }
