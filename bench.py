@@ -88,7 +88,7 @@ def self_launch(args):
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("NQE_BENCH_TRANSPORT") != "host":
         sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, this box has {have}; refusing to run on fewer\n")
         sys.exit(2)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -112,6 +112,13 @@ class Bench:
         self.args, self.world, self.rank, self.local_rank = args, world, rank, local_rank
         self.torch, self.dist, self.capi = torch, dist, capi
         self.distributed = world > 1 or bool(os.environ.get("NQE_FORCE_EXCHANGE"))  # one rank through RCCL too (diagnostics)
+        # NQE_BENCH_TRANSPORT=host: the ranks exchange through host memory over gloo (parallel.HostStagedTransport, plugged into the
+        # library with nqe_comm_create_custom) and may therefore SHARE a device — `--gpus 2` on a one-GPU box runs this file's
+        # multi-rank blocks (the sharded headline, C5) end to end, at reduced rows.  Not a scaling measurement: the line says so.
+        self.host_transport = self.distributed and os.environ.get("NQE_BENCH_TRANSPORT") == "host"
+        if self.host_transport:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            self.local_rank = local_rank
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
         self.comm = None
@@ -120,12 +127,16 @@ class Bench:
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-            dist.init_process_group("nccl", device_id=self.dev)
+            if self.host_transport:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
             if dist.get_world_size() != world:
                 sys.exit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {world}")
         self.ctx = capi.Context(local_rank)
         if self.distributed:
-            self.comm = parallel.make_comm(self.ctx)  # the data path's own RCCL communicator, on the context's stream
+            # the data path's own communicator, on the context's stream: RCCL, or the host-staged transport
+            self.comm = parallel.make_staged_comm(self.ctx) if self.host_transport else parallel.make_comm(self.ctx)
         self.keep = []
         self.min_warm_s = 0.0
 
@@ -149,9 +160,14 @@ class Bench:
     def max_over_ranks(self, x: float) -> float:
         if not self.distributed:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.coll_dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    @property
+    def coll_dev(self):
+        """where the tensors of torch.distributed collectives live: the device under RCCL, the host under gloo"""
+        return self.torch.device("cpu") if self.host_transport else self.dev
 
     def _warm(self, step, warmup):
         """W untimed steps; the side configs (self.min_warm_s > 0) additionally warm up for a minimum wall time: they start right
@@ -597,12 +613,12 @@ def wl_c4(B, rows, nb, variant, steps, warmup, gather=False, blocks=1, cold=Fals
             cols_t = table_columns_as_tensors(out_t, B.dev)
             mine = cols_t[2][B.rank * n:(B.rank + 1) * n]
             ok = bool(torch.equal(mine, fkey)) and bool(torch.equal(cols_t[0], cols_t[2]))
-            sums = torch.stack([fkey.sum(), val.view(torch.int64).sum()])
+            sums = torch.stack([fkey.sum(), val.view(torch.int64).sum()]).to(B.coll_dev)
             if B.distributed:
                 B.dist.all_reduce(sums)  # int64 sums wrap identically everywhere
             ok = ok and int(cols_t[2].sum()) == int(sums[0]) and int(cols_t[3].sum()) == int(sums[1])
             del cols_t, mine
-        okt = torch.tensor([1 if ok else 0], device=B.dev)
+        okt = torch.tensor([1 if ok else 0], device=B.coll_dev)
         if B.distributed:
             B.dist.all_reduce(okt, op=B.dist.ReduceOp.MIN)
         gather_check = {"ok": bool(int(okt.item())), "rows": int(out_t.num_rows),
@@ -911,7 +927,7 @@ def main():
         sys.exit(2)
     import torch
 
-    if torch.cuda.device_count() <= local_rank:
+    if torch.cuda.device_count() <= local_rank and os.environ.get("NQE_BENCH_TRANSPORT") != "host":
         sys.stderr.write(f"bench.py: rank {rank} needs device {local_rank}, this box has {torch.cuda.device_count()}\n")
         sys.exit(2)
 
@@ -965,7 +981,11 @@ def main():
     }
     if res.get("cold_ms") is not None:
         out["cold_ms"] = r4(res["cold_ms"])  # the first execution of the query in the process (run_sql is one-shot: db.rs:24-37)
-    if B.distributed:
+    if B.host_transport:
+        out["ranks"] = B.dist.get_world_size()
+        out["exchange"] = ("nqe_sharded_* (C ABI) over the HOST-STAGED transport (gloo; NQE_BENCH_TRANSPORT=host), every rank on device "
+                           f"{B.local_rank}: a functional run of the multi-rank code, NOT a scaling measurement")
+    elif B.distributed:
         out["rccl_ranks"] = B.dist.get_world_size()
         out["rccl_version"] = B.capi.Comm.rccl_version()
         out["exchange"] = "nqe_sharded_* (C ABI) on RCCL, collectives on the context's stream"
@@ -984,7 +1004,7 @@ def main():
         exp_cnt = np.array([(half - g + 1023) // 1024 if g < half else 0 for g in range(1024)], dtype=np.uint64)
         ok = bool(len(kk) == 1024 and (kk == np.arange(1024)).all() and (cols[0] == exp_cnt).all() and (cols[3] >= 0).all() and (cols[4] < 100).all()
                   and np.allclose(cols[2], cols[1] / cols[0].astype(np.float64), rtol=1e-12))
-        okt = B.torch.tensor([1 if ok else 0], dtype=B.torch.int64, device=B.dev)
+        okt = B.torch.tensor([1 if ok else 0], dtype=B.torch.int64, device=B.coll_dev)
         B.dist.all_reduce(okt, op=B.dist.ReduceOp.MIN)
         out["result_check"] = {"ok": bool(int(okt.item())), "what": "sharded headline on every rank: 1024 keys, analytic counts, avg = sum / count, min/max in [0, 100)"}
     main_state = st if (wl == "headline" and not args.no_configs and not args.random_keys and world == 1) else None
@@ -1045,17 +1065,24 @@ def main():
             # the headline without its exchange (every rank aggregates its shard only): step time with and without
             add("headline_local_only", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, exchange=False, blocks=cblocks))
             out["exchange_ms_per_step"] = r4(out["ms_per_step"] - cfg["headline_local_only"]["ms"])
-            # C5: the C4 join strong-scaled — build replicated, 10^8 fact rows range-split over the ranks
-            shard = 10**8 // world
+            # C5: the C4 join strong-scaled — build replicated, the fact rows (10^8; NQE_BENCH_C5_ROWS for functional runs) range-split
+            # over the ranks.  The consumer-local form (gather = 0: every rank keeps its own output rows, rank order == row order) is
+            # C5's headline — SURVEY 8e: the ordered all-gather of 3.2 GB is bound by one xGMI link per peer pair and dominates the probe
+            # by an order of magnitude — with the gathered form (BASELINE configs[4] as written) beside it.
+            c5_rows = int(os.environ.get("NQE_BENCH_C5_ROWS", 10**8))
+            shard = c5_rows // world
             add("c5_probe_only", lambda: wl_c4(B, shard, 10**6, "dense", csteps, cwarm, gather=False, blocks=cblocks))
             add("c5_probe_and_gather", lambda: wl_c4(B, shard, 10**6, "dense", csteps, cwarm, gather=True, blocks=cblocks))
             p, g = cfg["c5_probe_only"], cfg["c5_probe_and_gather"]
             gather_ms = g["ms"] - p["ms"]
-            out_bytes = 24.0 * shard * world  # three distinct 8-byte output columns per row (the shared key column travels once)
+            out_bytes = 24.0 * shard * world  # three distinct 8-byte output columns per row (the two key columns are one buffer and travel once)
             inbound = out_bytes * (world - 1) / world
-            cfg["c5"] = {"fact_rows_per_gpu": shard, "probe_only_ms": p["ms"], "gather_ms": r4(gather_ms), "end_to_end_ms": g["ms"],
-                         "gathered_bytes_per_rank_inbound": inbound, "xgmi_GBps_per_gpu_inbound": r4(inbound / (gather_ms * 1e-3) / 1e9) if gather_ms > 0 else None,
-                         "probe_rows_per_s_all_gpus": r4(10**8 / (p["ms"] * 1e-3))}
+            cfg["c5"] = {"fact_rows_per_gpu": shard, "ms": p["ms"], "probe_only_ms": p["ms"], "probe_rows_per_s_all_gpus": r4(shard * world / (p["ms"] * 1e-3)),
+                         "frac": p["frac"], "gather": 0, "with_gather": {"gather_ms": r4(gather_ms), "end_to_end_ms": g["ms"], "gathered_bytes_per_rank_inbound": inbound,
+                                                                         "xgmi_GBps_per_gpu_inbound": r4(inbound / (gather_ms * 1e-3) / 1e9) if gather_ms > 0 else None,
+                                                                         "gather_check": g.get("gather_check")},
+                         "gather_ms": r4(gather_ms), "end_to_end_ms": g["ms"],
+                         "xgmi_GBps_per_gpu_inbound": r4(inbound / (gather_ms * 1e-3) / 1e9) if gather_ms > 0 else None}
         if world == 1 and not B.distributed and (not only or any(x.startswith(("dropin", "upload")) for x in only)):
             # ---- the drop-in path (rewrite(tree).execute() through the mirrors of the reference's operator surface) and the ingest
             B.torch.cuda.empty_cache()

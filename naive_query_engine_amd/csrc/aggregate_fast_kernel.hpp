@@ -22,6 +22,9 @@
 #ifndef NQE_AGG_BG2
 #define NQE_AGG_BG2 1
 #endif
+#ifndef NQE_ML_PIPE
+#define NQE_ML_PIPE 1 // the prefetched second tile in the three-column instance with min / max on its last column (A/B: 10-12 VGPRs spill with it)
+#endif
 #ifndef NQE_AGG_RUN_BUDGET
 #define NQE_AGG_RUN_BUDGET 32 // tile pairs between two looks at the keys while in the run loop
 #endif
@@ -61,6 +64,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // column is the key column (C1's `count(id), sum(age), avg(score) … group by id % 3`) — the tile holds two value words per row, and
     // a second tile in flight fits the registers (the general three-column instance keeps one)
     constexpr bool SH1 = SHARE && NVT == 1, FK = SHARE && NVT == 3;
+    // MM with THREE value columns: only the LAST one carries min / max (the reference's own query, src/main.rs:36-40: count(id), sum(age),
+    // sum/avg/max/min(score) — the host orders the pass so): one pair of LDS arrays and one pair of run registers instead of three
+    constexpr bool ML = MM && NVT == 3;
+    constexpr int NMM = !MM ? 0 : (ML ? 1 : NVT); // value columns with min / max arrays
+    auto mmcol = [](int j) { return MM && (!ML || j == NVT - 1); };
     constexpr int NVL = FK ? NVT - 1 : NVT; // value columns the tile loads
     constexpr int TU = SH1 ? 2 * AGG_U : ((NQE_WIDE_TILES && NVT == 1 && !VNULL && !SUB && PRED <= 1 && KEY != 3) ? NQE_WIDE_TILES : AGG_U); // rows per lane per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -72,9 +80,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // ordered compare, which a NaN fails) and take the order-preserving integer form only for the global table at the merge
     // (MM = false — no aggregate of the pass asks for min / max: the two arrays do not exist, 20 instead of 36 bytes per slot and
     // value column, and the host sizes the table accordingly: 2048 slots for three columns)
-    double *lmn = lsum + NVT * slots;                                    // [NVT][slots]
-    double *lmx = lmn + NVT * slots;                                     // [NVT][slots]
-    uint32_t *lcnt = reinterpret_cast<uint32_t *>(MM ? lmx + NVT * slots : lmn); // [NVT][slots]
+    double *lmn = lsum + NVT * slots;                                    // [NMM][slots]
+    double *lmx = lmn + NMM * slots;                                     // [NMM][slots]
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(MM ? lmx + NMM * slots : lmn); // [NVT][slots]
+    auto mmo = [&](int j, uint32_t slot) { return uint32_t(ML ? 0 : j) * slots + slot; }; // a column's word in the min / max arrays
     const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
     __shared__ int lds_full_flag;
     volatile int *lds_full = &lds_full_flag;
@@ -84,9 +93,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
             lsum[j * slots + s] = 0.0;
-            if (MM) {
-                lmn[j * slots + s] = DBL_MAX;
-                lmx[j * slots + s] = -DBL_MAX;
+            if (mmcol(j)) {
+                lmn[mmo(j, s)] = DBL_MAX;
+                lmx[mmo(j, s)] = -DBL_MAX;
             }
             lcnt[j * slots + s] = 0;
         }
@@ -171,12 +180,13 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 }
                 if (rnan[j]) atomicOr(&lcnt[o], NAN_BIT);
                 // read-before-atomic (see the general kernel)
-                if (MM) {
-                    if (rmn[j] < lmn[o]) unsafeAtomicMin(&lmn[o], rmn[j]);
-                    if (rmx[j] > lmx[o]) unsafeAtomicMax(&lmx[o], rmx[j]);
+                if (mmcol(j)) {
+                    const uint32_t mo = mmo(j, uint32_t(slot));
+                    if (rmn[j] < lmn[mo]) unsafeAtomicMin(&lmn[mo], rmn[j]);
+                    if (rmx[j] > lmx[mo]) unsafeAtomicMax(&lmx[mo], rmx[j]);
                 }
             } else if (gslot >= 0) {
-                global_update(g, gslot, a.v0 + j, rcnt[j], rsum[j], true, f64_to_ord(rmn[j]), f64_to_ord(rmx[j]), true, rnan[j]);
+                global_update(g, gslot, a.v0 + j, rcnt[j], rsum[j], true, f64_to_ord(rmn[j]), f64_to_ord(rmx[j]), !ML || mmcol(j), rnan[j]);
             }
             rcnt[j] = 0; rsum[j] = 0.0; rmn[j] = DBL_MAX; rmx[j] = -DBL_MAX; rnan[j] = false;
         }
@@ -317,9 +327,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             if (MM) {
 #pragma unroll
                 for (int j = 0; j < NVT; ++j) {
+                    if (!mmcol(j)) continue;
 #pragma unroll
                     for (int i = 0; i < BG; ++i) {
-                        const uint32_t o = uint32_t(j) * slots + uint32_t(slot[g0 + i] < 0 ? 0 : slot[g0 + i]);
+                        const uint32_t o = mmo(j, uint32_t(slot[g0 + i] < 0 ? 0 : slot[g0 + i]));
                         cmn[MM ? j : 0][i] = lmn[o]; // read-before-atomic, all rows of the group in flight together
                         cmx[MM ? j : 0][i] = lmx[o];
                     }
@@ -340,9 +351,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                     const uint32_t o = uint32_t(j) * slots + uint32_t(slot[u]);
                     if (OWN_CNT || j == 0) atomicAdd(&lcnt[o], 1u);
                     if (nsum[j]) unsafeAtomicAdd(&lsum[o], x);
-                    if (MM) {
-                        if (x < cmn[MM ? j : 0][i]) unsafeAtomicMin(&lmn[o], x);
-                        if (x > cmx[MM ? j : 0][i]) unsafeAtomicMax(&lmx[o], x);
+                    if (mmcol(j)) {
+                        const uint32_t mo = mmo(j, uint32_t(slot[u]));
+                        if (x < cmn[MM ? j : 0][i]) unsafeAtomicMin(&lmn[mo], x);
+                        if (x > cmx[MM ? j : 0][i]) unsafeAtomicMax(&lmx[mo], x);
                     }
                     if (x != x) atomicOr(&lcnt[o], NAN_BIT);
                 }
@@ -408,7 +420,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 rsum[j] += vb ? x : 0.0;
                 rnan[j] = rnan[j] || (vb && x != x);
                 const double xm = vb ? x : __builtin_nan("");
-                if (MM) {
+                if (mmcol(j)) {
                     rmn[j] = fmin(rmn[j], xm);
                     rmx[j] = fmax(rmx[j], xm);
                 }
@@ -416,7 +428,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 rcnt[j] += 1;
                 rsum[j] += x;
                 rnan[j] = rnan[j] || (x != x);
-                if (MM) {
+                if (mmcol(j)) {
                     rmn[j] = fmin(rmn[j], x); // NaN operand ignored
                     rmx[j] = fmax(rmx[j], x);
                 }
@@ -501,7 +513,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     // (PRED = 6: ONE tile in flight — the stack machine's registers take the place of the prefetched tile's; the workgroup's 16
     // waves hide the loads' latency among themselves)
     // (three value columns: one tile is 6-8 KB per wave = 96-128 KB per CU in flight already; a second one spills ~30 VGPRs)
-    constexpr bool PIPE = (PRED != 6 || NQE_TREE_PIPE) && (NVT != 3 || FK);
+    constexpr bool PIPE = (PRED != 6 || NQE_TREE_PIPE) && (NVT != 3 || FK) && (!ML || NQE_ML_PIPE);
     auto stream = [&](auto &&process, Tile &A, int budget) {
         if constexpr (!PIPE) {
             for (int64_t it = 0; it < 2 * int64_t(budget); ++it) {
@@ -549,7 +561,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         load_tile(A, base);
         // not where registers are short: the VNULL variants (37 VGPRs spilled: 2.2x slower), two value columns, interpreted predicates
         constexpr bool CAN_BATCH = NQE_AGG_BATCH && !VNULL && PRED != 3 && (PRED != 6 && (PRED != 5 || (NQE_AGG_BATCH_TREE && KEY != 3 && NVT == 1))) && !(PRED == 2 && KEY == 3) && !(PRED == 4 && KEY == 3) &&
-                                   (NVT == 1 || ((NQE_AGG_BATCH2 || !MM) && KEY != 3 && PRED != 4));
+                                   (NVT == 1 || ((NQE_AGG_BATCH2 || !MM || ML) && KEY != 3 && PRED != 4));
         while (base < n) {
             bool batch = false; // wave-uniform
             if (CAN_BATCH) {
@@ -574,17 +586,19 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         const uint32_t R = 1u << rep_log2, nkeys = cap >> rep_log2;
         for (uint32_t w = threadIdx.x; w < nkeys * NVT; w += blockDim.x) {
             const uint32_t kslot = (w % nkeys) << rep_log2, o0 = (w / nkeys) * slots + kslot;
+            const bool mmw = MM && (!ML || (w / nkeys) == uint32_t(NVT - 1)); // this value column has min / max words
+            const uint32_t m0 = (ML ? 0u : (w / nkeys)) * slots + kslot;
             uint32_t c = lcnt[o0];
-            double sm = lsum[o0], mn = MM ? lmn[o0] : 0.0, mx = MM ? lmx[o0] : 0.0;
+            double sm = lsum[o0], mn = mmw ? lmn[m0] : 0.0, mx = mmw ? lmx[m0] : 0.0;
             bool used = VNULL && lkeys[kslot] != EMPTY_KEY;
             uint64_t kw = VNULL ? lkeys[kslot] : 0;
             for (uint32_t r = 1; r < R; ++r) {
                 const uint32_t cr = lcnt[o0 + r];
                 c = ((c & ~NAN_BIT) + (cr & ~NAN_BIT)) | ((c | cr) & NAN_BIT);
                 sm += lsum[o0 + r];
-                if (MM) {
-                    mn = fmin(mn, lmn[o0 + r]);
-                    mx = fmax(mx, lmx[o0 + r]);
+                if (mmw) {
+                    mn = fmin(mn, lmn[m0 + r]);
+                    mx = fmax(mx, lmx[m0 + r]);
                 }
                 if (VNULL && lkeys[kslot + r] != EMPTY_KEY) {
                     used = true;
@@ -593,9 +607,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             }
             lcnt[o0] = c;
             lsum[o0] = sm;
-            if (MM) {
-                lmn[o0] = mn;
-                lmx[o0] = mx;
+            if (mmw) {
+                lmn[m0] = mn;
+                lmx[m0] = mx;
             }
             if (VNULL && used && w < nkeys) lkeys[kslot] = kw;
         }
@@ -619,7 +633,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             uint32_t o = uint32_t(j) * slots + s;
             uint32_t c = lcnt[o];
             if (!OWN_CNT && j > 0) c = (lcnt[s] & ~NAN_BIT) | (c & NAN_BIT);
-            global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, MM ? f64_to_ord(lmn[o]) : 0ull, MM ? f64_to_ord(lmx[o]) : 0ull, MM, (c & NAN_BIT) != 0);
+            global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, mmcol(j) ? f64_to_ord(lmn[mmo(j, s)]) : 0ull, mmcol(j) ? f64_to_ord(lmx[mmo(j, s)]) : 0ull,
+                          mmcol(j), (c & NAN_BIT) != 0);
         }
     }
 }
@@ -635,6 +650,13 @@ template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf
             return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 3, true, false, false, false> : agg_grouped_fast_kernel<PRED, KEY, 3, false, false, false, false>;
         if (nomm && nv == 2 && !sub)
             return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 2, true, false, false, false> : agg_grouped_fast_kernel<PRED, KEY, 2, false, false, false, false>;
+    }
+    if constexpr (!VNULL && PRED <= 1 && KEY != 3) {
+        // three columns, min / max asked of the LAST one only (the host checks): src/main.rs:36-40's shape in one pass
+        if (!nomm && nv == 3 && !sub) {
+            if (share) return agg_grouped_fast_kernel<PRED, KEY, 3, false, false, false, true, true>;
+            return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 3, true, false, false, true> : agg_grouped_fast_kernel<PRED, KEY, 3, false, false, false, true>;
+        }
     }
     if (nv == 3) return nullptr; // (three columns: the instances above only)
     if (sub) {

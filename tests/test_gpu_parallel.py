@@ -379,3 +379,31 @@ def test_bench_multi_rank_block_dry_run_on_one_rank():
     assert d["configs"]["c5_probe_and_gather"]["gather_check"]["ok"]
     c5 = d["configs"]["c5"]
     assert c5["end_to_end_ms"] >= c5["probe_only_ms"] > 0 and "exchange_ms_per_step" in d
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu_through_the_host_transport():
+    """`bench.py --gpus 2` on a ONE-GPU box: NQE_BENCH_TRANSPORT=host lets the two ranks share the device and exchange through host
+    memory (gloo), so the multi-rank blocks of the bench — the sharded headline with its analytic result check, the headline without
+    its exchange, C5 with gather = 0 as its headline and the gathered form beside it — execute with world > 1, at reduced rows.
+    A functional run, not a scaling measurement (the line says so)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(NQE_BENCH_TRANSPORT="host", NQE_BENCH_C5_ROWS="20000000")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "20000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=850, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and "HOST-STAGED" in d["exchange"] and d["scaling"] == "weak"
+    assert d["config"]["total_rows"] == 40000000 and d["result_check"]["ok"]          # the sharded headline on every rank: analytic counts
+    cfg = d["configs"]
+    assert {"headline_local_only", "c5_probe_only", "c5_probe_and_gather", "c5"} <= set(cfg)
+    assert "exchange_ms_per_step" in d and cfg["headline_local_only"]["ms"] > 0
+    c5 = cfg["c5"]
+    assert c5["gather"] == 0 and c5["fact_rows_per_gpu"] == 10000000 and c5["probe_only_ms"] > 0 and c5["ms"] == c5["probe_only_ms"]
+    assert c5["gather_ms"] is not None and c5["xgmi_GBps_per_gpu_inbound"] is not None and c5["end_to_end_ms"] >= c5["probe_only_ms"]
+    assert cfg["c5_probe_and_gather"]["gather_check"]["ok"] and cfg["c5_probe_and_gather"]["gather_check"]["rows"] == 20000000

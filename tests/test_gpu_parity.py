@@ -1756,9 +1756,9 @@ def test_aggregate_partitioned_path_twelve_byte_tuples_and_their_fallback(ctx, k
 
 @pytest.mark.parametrize("groups", [3, 700, 1500, 3000, 50000])
 def test_aggregate_three_value_columns_in_one_pass(ctx, groups):
-    """C1's `count(id), sum(age), avg(score) … group by key` — three value columns, no min/max: ONE launch of the three-column
-    instance of agg_grouped_fast_kernel (2048-slot workgroup table) while the key and the predicate are ones the kernel computes
-    itself and the groups fit; every other shape (a predicate on another column, a key chain, min/max asked for, a nullable column,
+    """C1's `count(id), sum(age), avg(score) … group by key` — three value columns, no min/max or min/max of the last one only: ONE launch
+    of the three-column instance of agg_grouped_fast_kernel (2048-slot workgroup table) while the key and the predicate are ones the kernel
+    computes itself and the groups fit; every other shape (a predicate on another column, a key chain, min/max of another column, a nullable column,
     more groups than the table holds — 3000: passes of one and two columns, 50000: the partitioned path) is redone in passes of
     one and two.  n >= 2^18 so that an overfull workgroup table asks for the other path instead of spilling to the global table.
     Second execution: from the plan hint."""
@@ -1779,7 +1779,13 @@ def test_aggregate_three_value_columns_in_one_pass(ctx, groups):
         kn = key.flatten(f5)
         shapes = [(True, C1(kc), None), (True, C1(kc), binop(col(kc), Operator.GtEq, lit_i64(-5))), (False, C1(kc), binop(col(2), Operator.Lt, lit_i64(10))),
                   (True, [(AggregateFunc.Avg, 3), (AggregateFunc.Sum, 3), (AggregateFunc.Count, 2), (AggregateFunc.Sum, 0)], None),
-                  (False, [(AggregateFunc.Count, kc), (AggregateFunc.Sum, 2), (AggregateFunc.Max, 3)], None),
+                  # min / max asked of the LAST value column only: the three-column instance that carries one pair of min / max arrays — the
+                  # reference's own query shape (src/main.rs:36-40: count(id), sum(age), sum(score), avg(score), max(score), min(score))
+                  (True, [(AggregateFunc.Count, kc), (AggregateFunc.Sum, 2), (AggregateFunc.Max, 3)], None),
+                  (True, [(AggregateFunc.Count, kc), (AggregateFunc.Sum, 2), (AggregateFunc.Sum, 3), (AggregateFunc.Avg, 3), (AggregateFunc.Max, 3), (AggregateFunc.Min, 3)], None),
+                  (True, [(AggregateFunc.Count, kc), (AggregateFunc.Sum, 2), (AggregateFunc.Min, 3), (AggregateFunc.Max, 3)], binop(col(kc), Operator.GtEq, lit_i64(-5))),
+                  # … of another column: passes of one and two
+                  (False, [(AggregateFunc.Count, kc), (AggregateFunc.Max, 2), (AggregateFunc.Sum, 3)], None),
                   (False, [(AggregateFunc.Count, kc), (AggregateFunc.Sum, 2), (AggregateFunc.Avg, 4)], None)]
         for ok, aggs, pred in shapes:
             pn = pred.flatten(f5) if pred is not None else None
