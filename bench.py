@@ -487,12 +487,13 @@ def wl_c2_tree(B, rows, steps, warmup, blocks=1, cold=False):
     del r
     B.ctx.jit_wait()
     ms, kernels, spread = B.timed(step, steps, warmup, blocks)
-    names = ["expr_jit", "proj_jit", "keep_from_pred", "keep_from_simple", "expr_tree", "expr_tree_compact", "compact_column", "compact_expr"]
+    names = ["select_project_jit", "expr_jit", "proj_jit", "keep_from_pred", "keep_from_simple", "expr_tree", "expr_tree_compact", "compact_column", "compact_expr"]
     algo = 24.0 * n  # 16 B/row read (id, v) + two 8-byte columns written for half of the rows
-    roof = roofline(algo, kernels, names, phys_bytes=algo + 8.0 * n + n / 4.0)  # + id read by both passes, the Boolean column written and read
-    specialised = any(k.startswith(("expr_jit", "proj_jit")) for k in kernels)
+    one_pass = any(k.startswith("select_project_jit") for k in kernels)  # predicate, compaction and projection list in ONE kernel: every column read once
+    roof = roofline(algo, kernels, names, phys_bytes=algo if one_pass else algo + 8.0 * n + n / 4.0)  # two kernels: + id read by both, the Boolean column written and read
+    specialised = one_pass or any(k.startswith(("expr_jit", "proj_jit")) for k in kernels)
     res = {"metric": "filter_project_rows_per_s", "value": rows * B.world / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms, "spread": spread, "cold_ms": cold_ms,
-           "workload": f"select v * v + v / 4, id from t where (id + 1) % 10 < 5; t(id Int64 row number, v Float64), {n} rows per GPU; run-time specialised kernels: {specialised}",
+           "workload": f"select v * v + v / 4, id from t where (id + 1) % 10 < 5; t(id Int64 row number, v Float64), {n} rows per GPU; run-time specialised kernels: {specialised}, one pass: {one_pass}",
            "rows_per_gpu": n, "roofline": roof}
     return res, dict(ids=ids, v=v, n=n, pred=pred, proj=proj, fields=fields)
 

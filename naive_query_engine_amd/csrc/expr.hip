@@ -1133,6 +1133,97 @@ bool project_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node 
     return true;
 }
 
+// Fused ProjectionPlan(SelectionPlan(input)) in ONE pass (expr_jit.hpp: jit_select_project): a predicate TREE (three or more
+// operators: the shapes whose mask the specialised kernel computes anyway) over columns without validity, a projection list of
+// word-typed outputs over columns without validity, a large input.  Returns false when the shape does not qualify or the kernel is
+// still being compiled — the caller then takes the mask + compaction path, whose results are identical.
+bool select_project_fused(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, const nqe_expr_node *nodes, const int32_t *expr_offsets,
+                          int num_exprs, std::vector<DevColumn> *result, int64_t *total_out) {
+    const char *mr = getenv("NQE_JIT_MIN_ROWS");
+    const int64_t min_rows = mr ? atoll(mr) : (int64_t(1) << 22);
+    const int64_t n = in->rows;
+    if (getenv("NQE_NO_JIT") || getenv("NQE_NO_FUSED_SELECT") || num_exprs < 1 || num_exprs > JP_MAX_OUTS || n < min_rows || !pred || pred_nodes < 1) return false;
+    JitSelProj S;
+    JitProj &J = S.proj;
+    std::memset(J.col_values, 0, sizeof(J.col_values));
+    std::memset(J.col_valid, 0, sizeof(J.col_valid));
+    std::memset(J.col_dtype, 0, sizeof(J.col_dtype));
+    auto slot_of = [&](const void *values, const uint8_t *valid, int dtype) {
+        if (valid || !is_word_type(dtype)) return -1; // (nullable or bit-packed inputs: the two-kernel form handles them)
+        for (int k = 0; k < J.ncols; ++k)
+            if (J.col_values[k] == values && J.col_dtype[k] == dtype) return k;
+        if (J.ncols == JP_MAX_COLS) return -1;
+        J.col_values[J.ncols] = values;
+        J.col_dtype[J.ncols] = dtype;
+        return J.ncols++;
+    };
+    auto renumber = [&](ExProgram &P, uint32_t *mask) {
+        for (int i = 0; i < P.n; ++i) {
+            ExInstr &I = P.ins[i];
+            for (int32_t *src : {&I.a_src, &I.b_src}) {
+                if (*src == EX_LIT_NULL) return false;
+                if (*src < EX_COL) continue;
+                const int k = *src - EX_COL, u = slot_of(P.col_values[k], P.col_valid[k], P.col_dtype[k]);
+                if (u < 0) return false;
+                *src = EX_COL + u;
+                *mask |= 1u << u;
+            }
+        }
+        return true;
+    };
+    {
+        int root;
+        std::vector<Node> t = parse(in, pred, pred_nodes, &root);
+        bool nv = false;
+        if (t[size_t(root)].kind != NQE_EXPR_BINARY || t[size_t(root)].out_dtype != NQE_BOOLEAN || !build_program(in, t, root, &S.pred, &nv) || nv) return false;
+        if (S.pred.n < 3 || !renumber(S.pred, &S.pred_cols)) return false;
+    }
+    for (int e = 0; e < num_exprs; ++e) {
+        int root;
+        std::vector<Node> t = parse(in, nodes + expr_offsets[e], expr_offsets[e + 1] - expr_offsets[e], &root);
+        const Node &rt = t[size_t(root)];
+        JitProjOut o;
+        o.out_dtype = rt.out_dtype;
+        if (rt.kind == NQE_EXPR_COLUMN) {
+            const DevColumn &c = in->cols[size_t(rt.column)];
+            if (!is_word_type(c.dtype) || c.validity || c.length < n) return false;
+            o.is_column = true;
+            o.col = slot_of(c.values->ptr, nullptr, c.dtype);
+            if (o.col < 0) return false;
+            S.proj_cols |= 1u << o.col;
+        } else if (rt.kind == NQE_EXPR_BINARY) {
+            bool nv = false;
+            if (rt.out_dtype == NQE_BOOLEAN || !build_program(in, t, root, &o.P, &nv) || nv) return false;
+            if (!renumber(o.P, &S.proj_cols)) return false;
+        } else
+            return false; // a bare literal
+        J.outs.push_back(o);
+    }
+    JitEntry *kernel = jit_select_project_entry(ctx, S);
+    if (!kernel) return false; // being compiled (or no hipRTC): nothing allocated yet
+    // worst-case outputs (every row kept), the chunk status words, ticket and total
+    const int64_t n_chunks = (n + 64 * SP_R - 1) / (64 * SP_R);
+    std::vector<DevColumn> cols;
+    uint64_t *ow[JP_MAX_OUTS] = {};
+    for (int e = 0; e < num_exprs; ++e) {
+        cols.push_back(make_word_column(ctx, J.outs[size_t(e)].out_dtype, n, false));
+        ow[e] = (uint64_t *)cols.back().values->ptr;
+    }
+    BufRef status = dev_alloc(ctx, size_t(n_chunks) * 8 + 16);
+    NQE_HIP_CHECK(hipMemsetAsync(status->ptr, 0, size_t(n_chunks) * 8 + 16, ctx->stream));
+    unsigned long long *st = (unsigned long long *)status->ptr;
+    jit_select_project(ctx, kernel, S, n, ow, st, reinterpret_cast<uint32_t *>(st + n_chunks), st + n_chunks + 1);
+    const int64_t total = int64_t(read_scalar(ctx, (const unsigned long long *)(st + n_chunks + 1)));
+    for (auto &c : cols) {
+        c.length = total;
+        // far fewer rows than the buffer holds: give the large block back (the copy moves total rows, a fraction of the pass)
+        if (total * 8 < n) c = slice_column(ctx, c, 0, total);
+    }
+    *total_out = total;
+    *result = std::move(cols);
+    return true;
+}
+
 } // namespace nqe
 
 using namespace nqe;

@@ -528,6 +528,171 @@ bool jit_project(nqe_ctx *ctx, const JitProj &J, const KeepMask &km, uint64_t *c
     return true;
 }
 
+// ---- selection + projection in ONE pass over the table (a tree predicate, a projection list, inputs without NULLs)
+// The two-kernel form reads the predicate's columns (mask kernel), then — behind a scan and a host wait for the row count — the
+// projection's columns for the kept rows: a column both sides use is read twice (`select v * v + v / 4, id … where (id + 1) % 10 < 5`
+// moved 1.37x its algorithmic bytes).  Here every wave takes 512-row chunks in ticket order, evaluates the predicate on its rows,
+// counts the kept ones with ballots, publishes the count and obtains the number of rows kept before its chunk by decoupled
+// look-back over the chunks' status words (flag in the top two bits: 1 = this chunk's count, 2 = the inclusive prefix; a wave
+// inspects 64 predecessors per step; tickets are drawn in order, so every predecessor is already running), then evaluates the
+// projection list on the kept rows and writes them at prefix + position: stable order, each column read once, no mask, no scan
+// kernel.  The output columns are allocated for the worst case (every row kept); the last chunk's inclusive prefix is the row
+// count the host reads back.  Columns only the projection uses are loaded after the count is known to be non-zero.
+constexpr int SP_R = 8; // rows per lane per chunk
+struct JitSelProj {
+    JitProj proj;       // the union of the predicate's and the projection's columns, the outputs
+    ExProgram pred;     // column operands renumbered to proj's slots
+    uint32_t pred_cols = 0, proj_cols = 0; // slot bit masks: read by the predicate / by some output
+};
+struct JitSelProjArgs {
+    const void *col[JP_MAX_COLS];
+    uint64_t lit[JP_MAX_OUTS][JIT_MAX_LITS];
+    uint64_t plit[JIT_MAX_LITS];
+    int64_t n, n_chunks;
+    uint64_t *out_words[JP_MAX_OUTS];
+    unsigned long long *status; // [n_chunks], zeroed
+    uint32_t *ticket;           // zeroed
+    unsigned long long *total;  // rows kept
+    int *flags;
+};
+
+uint64_t jit_hash_selproj(const JitSelProj &S) {
+    uint64_t h = jit_hash_proj(S.proj) ^ 0x73656c70726f6aull;
+    auto mix = [&](const void *p, size_t nb) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < nb; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    const int32_t head[3] = {S.pred.n, int32_t(S.pred_cols), int32_t(S.proj_cols)};
+    mix(head, sizeof(head));
+    for (int i = 0; i < S.pred.n; ++i) {
+        const ExInstr &in = S.pred.ins[i];
+        const int32_t w[4] = {in.op, in.dt, in.a_src, in.b_src};
+        mix(w, sizeof(w));
+        if (jit_bakes_b(in)) mix(&in.lit_b, 8);
+    }
+    return h ? h : 1;
+}
+
+std::string gen_source_selproj(const JitSelProj &S) {
+    const JitProj &J = S.proj;
+    std::ostringstream s;
+    s << "#pragma clang fp contract(off)\n"
+      << "typedef unsigned long long u64; typedef long long i64; typedef unsigned int u32;\n"
+      << "#define R " << SP_R << "\n"
+      << "struct Args { const void *col[" << JP_MAX_COLS << "]; u64 lit[" << JP_MAX_OUTS << "][" << JIT_MAX_LITS << "]; u64 plit[" << JIT_MAX_LITS
+      << "]; i64 n, n_chunks; u64 *out_words[" << JP_MAX_OUTS << "]; u64 *status; u32 *ticket; u64 *total; int *flags; };\n"
+      << "static __device__ __forceinline__ double u2d(u64 w) { return __longlong_as_double((i64)w); }\n"
+      << "static __device__ __forceinline__ u64 d2u(double d) { return (u64)__double_as_longlong(d); }\n"
+      << "static __device__ __forceinline__ u64 wave_sum(u64 v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }\n"
+      << "static __device__ __forceinline__ u64 st_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
+      << "static __device__ __forceinline__ void st_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
+      << "extern \"C\" __global__ void __launch_bounds__(256) nqe_jit_selproj(Args A) {\n"
+      << "  const int lane = threadIdx.x & 63;\n"
+      << "  const i64 n = A.n;\n"
+      << "  const u64 lt = (1ull << lane) - 1ull, VAL = (1ull << 62) - 1ull;\n"
+      << "  for (;;) {\n"
+      << "    u32 tk = 0;\n"
+      << "    if (lane == 0) tk = atomicAdd(A.ticket, 1u);\n"
+      << "    const i64 chunk = (i64)__shfl(tk, 0, 64);\n"
+      << "    if (chunk >= A.n_chunks) break;\n"
+      << "    const i64 row0 = chunk * (64 * R) + lane;\n"
+      << "    i64 rc[R]; bool in[R];\n"
+      << "#pragma unroll\n"
+      << "    for (int r = 0; r < R; ++r) { const i64 row = row0 + r * 64; in[r] = row < n; rc[r] = row < n - 1 ? row : n - 1; }\n";
+    auto load_col = [&](int c) {
+        s << "    u64 c" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "[r] = __builtin_nontemporal_load((const u64 *)A.col[" << c << "] + rc[r]);\n";
+    };
+    bool has_valid[JP_MAX_COLS];
+    for (int c = 0; c < JP_MAX_COLS; ++c) has_valid[c] = false;
+    for (int c = 0; c < J.ncols; ++c)
+        if (S.pred_cols & (1u << c)) load_col(c);
+    const auto pres = emit_steps(s, S.pred, has_valid, false, "p", "A.plit", "in[r]");
+    s << "    u64 kw[R]; u32 po[R]; u32 cnt = 0;\n"
+      << "#pragma unroll\n"
+      << "    for (int r = 0; r < R; ++r) { kw[r] = __ballot(in[r] && " << pres.first << "[r] != 0); po[r] = cnt + (u32)__popcll(kw[r] & lt); cnt += (u32)__popcll(kw[r]); }\n"
+      << "    if (chunk > 0 && lane == 0) st_store(A.status + chunk, (1ull << 62) | (u64)cnt);\n";
+    // the projection's own columns: requested before the look-back, so that their latency overlaps it — and only when rows were
+    // kept (cnt is wave-uniform: a chunk that keeps nothing never touches them)
+    for (int c = 0; c < J.ncols; ++c)
+        if (!(S.pred_cols & (1u << c)))
+            s << "    u64 c" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "[r] = cnt ? __builtin_nontemporal_load((const u64 *)A.col[" << c
+              << "] + rc[r]) : 0ull;\n";
+    s << "    u64 excl = 0;\n"
+      << "    if (chunk > 0) {\n"
+      << "      i64 look = chunk - 1;\n"
+      << "      for (;;) {\n"
+      << "        const i64 idx = look - lane;\n"
+      << "        u64 sv = idx >= 0 ? st_load(A.status + idx) : (2ull << 62);\n" // (before chunk 0: an inclusive prefix of zero rows)
+      << "        while (__ballot((sv >> 62) == 0ull) != 0ull) { __builtin_amdgcn_s_sleep(1); if (idx >= 0) sv = st_load(A.status + idx); }\n"
+      << "        const u64 pm = __ballot((sv >> 62) == 2ull);\n"
+      << "        if (pm != 0ull) {\n"
+      << "          const int first = __ffsll((i64)pm) - 1;\n"
+      << "          excl += wave_sum(lane <= first ? (sv & VAL) : 0ull);\n"
+      << "          break;\n"
+      << "        }\n"
+      << "        excl += wave_sum(sv & VAL);\n"
+      << "        look -= 64;\n"
+      << "      }\n"
+      << "    }\n"
+      << "    if (lane == 0) st_store(A.status + chunk, (2ull << 62) | (excl + (u64)cnt));\n"
+      << "    if (chunk == A.n_chunks - 1 && lane == 0) *A.total = excl + (u64)cnt;\n"
+      << "    if (cnt == 0) continue;\n"
+      << "    bool keep[R];\n"
+      << "#pragma unroll\n"
+      << "    for (int r = 0; r < R; ++r) keep[r] = (kw[r] >> lane) & 1ull;\n"
+      << "    {\n"
+      << "    bool in[R];\n" // the projection's rows: the kept ones (a dropped row never evaluates: no DivideByZero from it)
+      << "#pragma unroll\n"
+      << "    for (int r = 0; r < R; ++r) in[r] = keep[r];\n";
+    std::vector<std::pair<std::string, std::string>> results;
+    for (size_t o = 0; o < J.outs.size(); ++o) {
+        const JitProjOut &out = J.outs[o];
+        if (out.is_column) results.push_back({"c" + std::to_string(out.col), "in[r]"});
+        else results.push_back(emit_steps(s, out.P, has_valid, false, "t" + std::to_string(o) + "_", "A.lit[" + std::to_string(o) + "]", "in[r]"));
+    }
+    s << "#pragma unroll\n    for (int r = 0; r < R; ++r) {\n"
+      << "      if (!in[r]) continue;\n"
+      << "      const u64 pos = excl + po[r];\n";
+    for (size_t o = 0; o < J.outs.size(); ++o) s << "      __builtin_nontemporal_store(" << results[o].first << "[r], A.out_words[" << o << "] + pos);\n";
+    s << "    }\n    }\n  }\n}\n";
+    return s.str();
+}
+
+// the one-pass selection + projection kernel of S when it is ready (null: the caller takes the mask + compaction path this time)
+JitEntry *jit_select_project_entry(nqe_ctx *ctx, const JitSelProj &S) {
+    return jit_get(ctx, jit_hash_selproj(S), "nqe_jit_selproj", [&] { return gen_source_selproj(S); });
+}
+void jit_select_project(nqe_ctx *ctx, JitEntry *e, const JitSelProj &S, int64_t n, uint64_t *const *out_words, unsigned long long *status, uint32_t *ticket,
+                        unsigned long long *total) {
+    JitSelProjArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const JitProj &J = S.proj;
+    for (int c = 0; c < J.ncols; ++c) a.col[c] = J.col_values[c];
+    for (size_t o = 0; o < J.outs.size(); ++o) {
+        if (!J.outs[o].is_column)
+            for (int i = 0; i < J.outs[o].P.n; ++i) {
+                a.lit[o][2 * i] = J.outs[o].P.ins[i].lit_a;
+                a.lit[o][2 * i + 1] = J.outs[o].P.ins[i].lit_b;
+            }
+        a.out_words[o] = out_words[o];
+    }
+    for (int i = 0; i < S.pred.n; ++i) {
+        a.plit[2 * i] = S.pred.ins[i].lit_a;
+        a.plit[2 * i + 1] = S.pred.ins[i].lit_b;
+    }
+    a.n = n;
+    a.n_chunks = (n + 64 * SP_R - 1) / (64 * SP_R);
+    a.status = status;
+    a.ticket = ticket;
+    a.total = total;
+    a.flags = ctx->d_flags;
+    void *params[] = {&a};
+    const unsigned grid = unsigned(stream_grid(ctx, a.n_chunks, 4));
+    TimerScope t(ctx, "select_project_jit");
+    ctx->flags_clean = false;
+    NQE_HIP_CHECK(hipModuleLaunchKernel(e->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+}
+
 // blocks until every compilation in flight has finished (tests: the next execution takes the specialised kernels)
 void jit_wait_all(nqe_ctx *ctx) {
     if (!ctx->jit) return;

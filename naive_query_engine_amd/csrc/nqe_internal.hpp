@@ -390,6 +390,9 @@ bool evaluate_expr_compacted(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_n
 // or its kernel is not compiled yet (the caller then takes the per-expression path)
 bool project_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *nodes, const int32_t *expr_offsets, int num_exprs, const KeepMask &km,
                          std::vector<DevColumn> *out);
+// selection + projection in one run-time specialised pass (tree predicate, inputs without NULLs, word-typed outputs); false: take the mask + compaction path
+bool select_project_fused(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, const nqe_expr_node *nodes, const int32_t *expr_offsets,
+                          int num_exprs, std::vector<DevColumn> *result, int64_t *total_out);
 // evaluates `e` over `in` and compacts the result in the same pass
 DevColumn compact_simple_expr(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &e, const KeepMask &km);
 

@@ -582,6 +582,20 @@ nqe_status nqe_selection_projection_execute(nqe_ctx *ctx, const nqe_table *in, c
     bool fault = analyze_expr(in, pred, pred_nodes).may_fault;
     for (auto &inf : infos) fault = fault || inf.may_fault;
     if (fault) flags_reset(ctx);
+    {
+        // a tree predicate over a large input without NULLs: predicate, compaction and projection list in ONE specialised pass
+        std::vector<DevColumn> one_pass;
+        int64_t kept = 0;
+        if (select_project_fused(ctx, in, pred, pred_nodes, nodes, expr_offsets, num_exprs, &one_pass, &kept)) {
+            auto t1 = std::make_unique<nqe_table>();
+            t1->ctx = ctx;
+            t1->rows = kept;
+            for (auto &c : one_pass) t1->cols.push_back(std::move(c));
+            if (fault) throw_on_flags(ctx);
+            *out = t1.release();
+            return NQE_OK;
+        }
+    }
     KeepMask km = mask_for_predicate(ctx, in, pred, pred_nodes);
     auto t = std::make_unique<nqe_table>();
     t->ctx = ctx;

@@ -2065,7 +2065,8 @@ def test_projection_list_behind_a_selection_specialised_at_run_time(ctx, null_fr
                 elif exprs in not_taken:
                     assert "proj_jit" not in names, names
                 else:
-                    assert "proj_jit" in names and not any(k.startswith(("compact", "expr_tree_compact")) for k in names), (names, repr(exprs))
+                    # (a tree predicate over inputs without NULLs and word-typed outputs: predicate, compaction and list in ONE kernel)
+                    assert ("proj_jit" in names or "select_project_jit" in names) and not any(k.startswith(("compact", "expr_tree_compact")) for k in names), (names, repr(exprs))
     # a divisor that is zero in KEPT rows raises from both forms
     bad = X(K, O.LtEq, lit_i64(2))
     nodes = [flat(e) for e in (X(X(ID, O.Divide, K), O.Plus, ID), X(X(V, O.Gt, lit_f64(10.0)), O.Or, X(ID, O.Lt, K)))]
@@ -2074,3 +2075,62 @@ def test_projection_list_behind_a_selection_specialised_at_run_time(ctx, null_fr
             ctx.selection_projection(t, flat(bad), nodes)
         assert ge.value.status == Status.ArrowError
         ctx.jit_wait()
+
+
+@pytest.mark.parametrize("n", [1 << 12, 70_001, 512 * 300 + 7])
+@pytest.mark.parametrize("keep", ["first_half", "spread", "nothing", "everything", "one_row", "last_row"])
+def test_selection_and_projection_in_one_specialised_pass(ctx, monkeypatch, n, keep):
+    """a tree predicate + a projection list over inputs without NULLs: ONE run-time specialised kernel (expr_jit.hpp, nqe_jit_selproj)
+    evaluates the predicate, compacts by decoupled look-back over 512-row chunks and writes the projected kept rows — stable order,
+    every column read once, no mask, no scan.  After nqe_ctx_jit_wait the step is one `select_project_jit` launch; results equal the
+    oracle's (and the two-kernel form's, NQE_NO_FUSED_SELECT) bit for bit for kept rows at the front, spread out, none, all, a single
+    row and the very last row, at sizes around the chunk size; a zero divisor only in dropped rows does not raise, one in a kept row does."""
+    monkeypatch.setenv("NQE_JIT_MIN_ROWS", "1000")
+    rng = np.random.default_rng(n + len(keep))
+    ids = np.arange(n, dtype=np.int64)
+    v = rng.random(n) * 100.0
+    k = rng.integers(0, 5, n).astype(np.int64)
+    cols = [Column.from_numpy(ids), Column.from_numpy(v), Column.from_numpy(k)]
+    f3 = fields("id", "v", "k")
+    ID, V, K = col(0), col(1), col(2)
+    O, X = Operator, binop
+    pred = {"first_half": X(X(X(ID, O.Plus, lit_i64(0)), O.Multiply, lit_i64(2)), O.Lt, lit_i64(n)),
+            "spread": X(X(X(ID, O.Plus, lit_i64(1)), O.Modulos, lit_i64(10)), O.Lt, lit_i64(5)),
+            "nothing": X(X(X(ID, O.Plus, lit_i64(1)), O.Multiply, lit_i64(1)), O.Lt, lit_i64(0)),
+            "everything": X(X(X(ID, O.Plus, lit_i64(1)), O.Multiply, lit_i64(1)), O.Gt, lit_i64(0)),
+            "one_row": X(X(X(ID, O.Plus, lit_i64(1)), O.Multiply, lit_i64(3)), O.Eq, lit_i64(3 * (n // 3 + 1))),
+            "last_row": X(X(X(ID, O.Plus, lit_i64(1)), O.Multiply, lit_i64(1)), O.GtEq, lit_i64(n))}[keep]
+    exprs = [X(X(V, O.Multiply, V), O.Plus, X(V, O.Divide, lit_f64(4.0))), ID, X(X(ID, O.Modulos, lit_i64(1000)), O.Multiply, lit_i64(3))]
+    pn, en = pred.flatten(f3), [e.flatten(f3) for e in exprs]
+    exp = orc.projection(orc.selection([cols], pn), en)[0]
+    t = ctx.table_from_host(cols)
+    for phase in (0, 1, 2):
+        if phase == 2:
+            monkeypatch.setenv("NQE_NO_FUSED_SELECT", "1")
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got = ctx.selection_projection(t, pn, en).to_host()
+        ctx.timing_enable(False)
+        names = ctx.timing_report()
+        assert_batches_equal(got, exp, what=f"phase {phase} keep={keep} n={n}")
+        if phase == 0:
+            ctx.jit_wait()
+        elif phase == 1:
+            assert names.get("select_project_jit", (0, 0))[1] == 1 and not any(x.startswith(("keep_from", "compact", "proj_jit", "expr_jit")) for x in names), names
+        else:
+            assert "select_project_jit" not in names, names
+    monkeypatch.delenv("NQE_NO_FUSED_SELECT")
+    if keep == "spread":
+        # k == 0 rows are dropped by the predicate: `id / k` must not raise; with them kept it must (from the fused kernel too)
+        safe = X(X(X(K, O.Plus, lit_i64(0)), O.Multiply, lit_i64(1)), O.Gt, lit_i64(0))
+        div = [X(X(ID, O.Divide, K), O.Plus, ID).flatten(f3)]
+        exp2 = orc.projection(orc.selection([cols], safe.flatten(f3)), div)[0]
+        for phase in (0, 1):
+            assert_batches_equal(ctx.selection_projection(t, safe.flatten(f3), div).to_host(), exp2, what=f"divisor zero in dropped rows only, phase {phase}")
+            ctx.jit_wait()
+        unsafe = X(X(X(K, O.Plus, lit_i64(0)), O.Multiply, lit_i64(1)), O.GtEq, lit_i64(0))
+        for phase in (0, 1):
+            with pytest.raises(ErrorCode) as ge:
+                ctx.selection_projection(t, unsafe.flatten(f3), div)
+            assert ge.value.status == Status.ArrowError
+            ctx.jit_wait()
