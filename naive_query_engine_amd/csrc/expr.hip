@@ -1202,7 +1202,7 @@ bool select_project_fused(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node
     JitEntry *kernel = jit_select_project_entry(ctx, S);
     if (!kernel) return false; // being compiled (or no hipRTC): nothing allocated yet
     // worst-case outputs (every row kept), the chunk status words, ticket and total
-    const int64_t n_chunks = (n + 64 * SP_R - 1) / (64 * SP_R);
+    const int64_t n_chunks = (n + SP_BLOCK * SP_R - 1) / (SP_BLOCK * SP_R); // steps: one status word per workgroup step
     std::vector<DevColumn> cols;
     uint64_t *ow[JP_MAX_OUTS] = {};
     for (int e = 0; e < num_exprs; ++e) {

@@ -531,14 +531,18 @@ bool jit_project(nqe_ctx *ctx, const JitProj &J, const KeepMask &km, uint64_t *c
 // ---- selection + projection in ONE pass over the table (a tree predicate, a projection list, inputs without NULLs)
 // The two-kernel form reads the predicate's columns (mask kernel), then — behind a scan and a host wait for the row count — the
 // projection's columns for the kept rows: a column both sides use is read twice (`select v * v + v / 4, id … where (id + 1) % 10 < 5`
-// moved 1.37x its algorithmic bytes).  Here every wave takes 512-row chunks in ticket order, evaluates the predicate on its rows,
+// moved 1.37x its algorithmic bytes).  Here every wave takes 512-row chunks in ticket order (one ticket per 16-wave workgroup and step), evaluates the predicate on its rows,
 // counts the kept ones with ballots, publishes the count and obtains the number of rows kept before its chunk by decoupled
 // look-back over the chunks' status words (flag in the top two bits: 1 = this chunk's count, 2 = the inclusive prefix; a wave
 // inspects 64 predecessors per step; tickets are drawn in order, so every predecessor is already running), then evaluates the
 // projection list on the kept rows and writes them at prefix + position: stable order, each column read once, no mask, no scan
 // kernel.  The output columns are allocated for the worst case (every row kept); the last chunk's inclusive prefix is the row
 // count the host reads back.  Columns only the projection uses are loaded after the count is known to be non-zero.
-constexpr int SP_R = 8; // rows per lane per chunk
+// rows per lane per chunk, threads per workgroup (twelve chunks = 6144 rows per ticket and status word; 74 VGPRs: two such workgroups
+// per CU).  NQE_SP_R / NQE_SP_BLOCK: A/B runs — per 10^8 rows of `select v * v + v / 4, id … where (id + 1) % 10 < 5`: 256x8 0.78 ms,
+// 512x4 0.76, 512x8 0.60, 512x16 0.60, 1024x8 0.60, 768x8 0.56 (the two-kernel form: 0.67 + its scan and host wait)
+static const int SP_R = getenv("NQE_SP_R") ? atoi(getenv("NQE_SP_R")) : 8;
+static const int SP_BLOCK = getenv("NQE_SP_BLOCK") ? atoi(getenv("NQE_SP_BLOCK")) : 768;
 struct JitSelProj {
     JitProj proj;       // the union of the predicate's and the projection's columns, the outputs
     ExProgram pred;     // column operands renumbered to proj's slots
@@ -548,9 +552,9 @@ struct JitSelProjArgs {
     const void *col[JP_MAX_COLS];
     uint64_t lit[JP_MAX_OUTS][JIT_MAX_LITS];
     uint64_t plit[JIT_MAX_LITS];
-    int64_t n, n_chunks;
+    int64_t n, n_steps;
     uint64_t *out_words[JP_MAX_OUTS];
-    unsigned long long *status; // [n_chunks], zeroed
+    unsigned long long *status; // [n_steps], zeroed
     uint32_t *ticket;           // zeroed
     unsigned long long *total;  // rows kept
     int *flags;
@@ -562,7 +566,7 @@ uint64_t jit_hash_selproj(const JitSelProj &S) {
         const unsigned char *b = static_cast<const unsigned char *>(p);
         for (size_t i = 0; i < nb; ++i) h = (h ^ b[i]) * 1099511628211ull;
     };
-    const int32_t head[3] = {S.pred.n, int32_t(S.pred_cols), int32_t(S.proj_cols)};
+    const int32_t head[5] = {S.pred.n, int32_t(S.pred_cols), int32_t(S.proj_cols), SP_R, SP_BLOCK};
     mix(head, sizeof(head));
     for (int i = 0; i < S.pred.n; ++i) {
         const ExInstr &in = S.pred.ins[i];
@@ -580,21 +584,26 @@ std::string gen_source_selproj(const JitSelProj &S) {
       << "typedef unsigned long long u64; typedef long long i64; typedef unsigned int u32;\n"
       << "#define R " << SP_R << "\n"
       << "struct Args { const void *col[" << JP_MAX_COLS << "]; u64 lit[" << JP_MAX_OUTS << "][" << JIT_MAX_LITS << "]; u64 plit[" << JIT_MAX_LITS
-      << "]; i64 n, n_chunks; u64 *out_words[" << JP_MAX_OUTS << "]; u64 *status; u32 *ticket; u64 *total; int *flags; };\n"
+      << "]; i64 n, n_steps; u64 *out_words[" << JP_MAX_OUTS << "]; u64 *status; u32 *ticket; u64 *total; int *flags; };\n"
       << "static __device__ __forceinline__ double u2d(u64 w) { return __longlong_as_double((i64)w); }\n"
       << "static __device__ __forceinline__ u64 d2u(double d) { return (u64)__double_as_longlong(d); }\n"
       << "static __device__ __forceinline__ u64 wave_sum(u64 v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }\n"
       << "static __device__ __forceinline__ u64 st_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
       << "static __device__ __forceinline__ void st_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
-      << "extern \"C\" __global__ void __launch_bounds__(256) nqe_jit_selproj(Args A) {\n"
-      << "  const int lane = threadIdx.x & 63;\n"
+      << "extern \"C\" __global__ void __launch_bounds__(" << SP_BLOCK << ") nqe_jit_selproj(Args A) {\n"
+      << "  __shared__ u32 s_base; __shared__ u32 s_cnt[" << SP_BLOCK / 64 << "]; __shared__ u64 s_excl;\n"
+      << "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;\n"
       << "  const i64 n = A.n;\n"
       << "  const u64 lt = (1ull << lane) - 1ull, VAL = (1ull << 62) - 1ull;\n"
+      // one ticket per WORKGROUP per step (its waves take consecutive chunks): a ticket per wave was 195 000 atomics on one word
+      // for 10^8 rows — at ~12 ns each they alone took 2.4 ms.  (Drawing the NEXT step's ticket while this step runs hid the
+      // atomic's latency and lengthened the look-back chains — a workgroup then holds a step it has not started: 0.60 -> 0.82 ms.)
       << "  for (;;) {\n"
-      << "    u32 tk = 0;\n"
-      << "    if (lane == 0) tk = atomicAdd(A.ticket, 1u);\n"
-      << "    const i64 chunk = (i64)__shfl(tk, 0, 64);\n"
-      << "    if (chunk >= A.n_chunks) break;\n"
+      << "    if (threadIdx.x == 0) s_base = atomicAdd(A.ticket, 1u);\n"
+      << "    __syncthreads();\n"
+      << "    const i64 step = (i64)s_base;\n"
+      << "    if (step >= A.n_steps) break;\n"
+      << "    const i64 chunk = step * wpb + wave;\n" // (a chunk past the table: no row exists, nothing kept — it still takes part in the barriers)
       << "    const i64 row0 = chunk * (64 * R) + lane;\n"
       << "    i64 rc[R]; bool in[R];\n"
       << "#pragma unroll\n"
@@ -610,32 +619,43 @@ std::string gen_source_selproj(const JitSelProj &S) {
     s << "    u64 kw[R]; u32 po[R]; u32 cnt = 0;\n"
       << "#pragma unroll\n"
       << "    for (int r = 0; r < R; ++r) { kw[r] = __ballot(in[r] && " << pres.first << "[r] != 0); po[r] = cnt + (u32)__popcll(kw[r] & lt); cnt += (u32)__popcll(kw[r]); }\n"
-      << "    if (chunk > 0 && lane == 0) st_store(A.status + chunk, (1ull << 62) | (u64)cnt);\n";
+      << "    if (lane == 0) s_cnt[wave] = cnt;\n";
     // the projection's own columns: requested before the look-back, so that their latency overlaps it — and only when rows were
     // kept (cnt is wave-uniform: a chunk that keeps nothing never touches them)
     for (int c = 0; c < J.ncols; ++c)
         if (!(S.pred_cols & (1u << c)))
             s << "    u64 c" << c << "[R];\n#pragma unroll\n    for (int r = 0; r < R; ++r) c" << c << "[r] = cnt ? __builtin_nontemporal_load((const u64 *)A.col[" << c
               << "] + rc[r]) : 0ull;\n";
-    s << "    u64 excl = 0;\n"
-      << "    if (chunk > 0) {\n"
-      << "      i64 look = chunk - 1;\n"
-      << "      for (;;) {\n"
-      << "        const i64 idx = look - lane;\n"
-      << "        u64 sv = idx >= 0 ? st_load(A.status + idx) : (2ull << 62);\n" // (before chunk 0: an inclusive prefix of zero rows)
-      << "        while (__ballot((sv >> 62) == 0ull) != 0ull) { __builtin_amdgcn_s_sleep(1); if (idx >= 0) sv = st_load(A.status + idx); }\n"
-      << "        const u64 pm = __ballot((sv >> 62) == 2ull);\n"
-      << "        if (pm != 0ull) {\n"
-      << "          const int first = __ffsll((i64)pm) - 1;\n"
-      << "          excl += wave_sum(lane <= first ? (sv & VAL) : 0ull);\n"
-      << "          break;\n"
+    // The workgroup's kept rows are summed through LDS and ONE wave looks back over the statuses of the steps before this one (a
+    // status per 512-row chunk had every wave walk back through the ~4000 chunks in flight, 64 per memory round trip: 0.94 ms per
+    // 10^8 rows against 0.72 for the two kernels); the other waves wait at the barrier with their projection loads in flight.
+    s << "    __syncthreads();\n"
+      << "    if (wave == 0) {\n"
+      << "      const u32 mine = lane < wpb ? s_cnt[lane] : 0u;\n"
+      << "      const u64 tot = wave_sum((u64)mine);\n"
+      << "      u64 ex = 0;\n"
+      << "      if (step > 0) {\n"
+      << "        if (lane == 0) st_store(A.status + step, (1ull << 62) | tot);\n"
+      << "        i64 look = step - 1;\n"
+      << "        for (;;) {\n"
+      << "          const i64 idx = look - lane;\n"
+      << "          u64 sv = idx >= 0 ? st_load(A.status + idx) : (2ull << 62);\n" // (before step 0: an inclusive prefix of zero rows)
+      << "          while (__ballot((sv >> 62) == 0ull) != 0ull) { __builtin_amdgcn_s_sleep(1); if (idx >= 0) sv = st_load(A.status + idx); }\n"
+      << "          const u64 pm = __ballot((sv >> 62) == 2ull);\n"
+      << "          if (pm != 0ull) {\n"
+      << "            const int nearest = __ffsll((i64)pm) - 1;\n"
+      << "            ex += wave_sum(lane <= nearest ? (sv & VAL) : 0ull);\n"
+      << "            break;\n"
+      << "          }\n"
+      << "          ex += wave_sum(sv & VAL);\n"
+      << "          look -= 64;\n"
       << "        }\n"
-      << "        excl += wave_sum(sv & VAL);\n"
-      << "        look -= 64;\n"
       << "      }\n"
+      << "      if (lane == 0) { st_store(A.status + step, (2ull << 62) | (ex + tot)); s_excl = ex; if (step == A.n_steps - 1) *A.total = ex + tot; }\n"
       << "    }\n"
-      << "    if (lane == 0) st_store(A.status + chunk, (2ull << 62) | (excl + (u64)cnt));\n"
-      << "    if (chunk == A.n_chunks - 1 && lane == 0) *A.total = excl + (u64)cnt;\n"
+      << "    __syncthreads();\n"
+      << "    u64 excl = s_excl;\n"
+      << "    for (int w = 0; w < wave; ++w) excl += s_cnt[w];\n"
       << "    if (cnt == 0) continue;\n"
       << "    bool keep[R];\n"
       << "#pragma unroll\n"
@@ -681,16 +701,16 @@ void jit_select_project(nqe_ctx *ctx, JitEntry *e, const JitSelProj &S, int64_t 
         a.plit[2 * i + 1] = S.pred.ins[i].lit_b;
     }
     a.n = n;
-    a.n_chunks = (n + 64 * SP_R - 1) / (64 * SP_R);
+    a.n_steps = (n + SP_BLOCK * SP_R - 1) / (SP_BLOCK * SP_R);
     a.status = status;
     a.ticket = ticket;
     a.total = total;
     a.flags = ctx->d_flags;
     void *params[] = {&a};
-    const unsigned grid = unsigned(stream_grid(ctx, a.n_chunks, 4));
+    const unsigned grid = unsigned(stream_grid(ctx, a.n_steps, 1, 4));
     TimerScope t(ctx, "select_project_jit");
     ctx->flags_clean = false;
-    NQE_HIP_CHECK(hipModuleLaunchKernel(e->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+    NQE_HIP_CHECK(hipModuleLaunchKernel(e->fn, grid, 1, 1, SP_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
 }
 
 // blocks until every compilation in flight has finished (tests: the next execution takes the specialised kernels)
