@@ -48,7 +48,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable)
-PROFILE_TAG = "r03"    # profiles/<tag>/pmc_traffic_<config>.json are quoted as `roofline.traffic`
+PROFILE_TAG = "r04"    # profiles/<tag>/pmc_traffic_<config>.json are quoted as `roofline.traffic`
 # kernels that do not belong to an operator's step (data generation, diagnostics)
 NOT_STEP_KERNELS = ("synth_fill",)
 LINE_LIMIT = 8000      # bytes of the JSON line
@@ -67,6 +67,7 @@ def parse(argv=None):
     ap.add_argument("--dim-rows", type=int, default=10**6, help="c4: build-side rows")
     ap.add_argument("--pass-frac", type=float, default=0.5, help="headline: fraction of rows passing `id < K` (diagnostics; the metric uses 0.5)")
     ap.add_argument("--gather", action="store_true", help="c4 with --gpus N: also all-gather every rank's output batch in rank order (BASELINE config C5)")
+    ap.add_argument("--immutable", action="store_true", help="c4*: the probe table is created with NQE_TABLE_IMMUTABLE (an all-match join may share its columns)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="only the main workload's line (no `configs` block)")
     ap.add_argument("--only", default="", help="comma-separated side configs to run (default: all)")
@@ -967,9 +968,13 @@ def main():
         name = "c2" if wl == "c2" else "c2_random_ids"
     else:
         variant = {"c4": "dense", "c4_sparse": "sparse", "c4_wide": "wide", "c4_dup": "dup", "c4_partial": "partial"}[wl]
-        res, st = wl_c4(B, n, args.dim_rows, variant, args.steps, args.warmup, gather=args.gather)
+        res, st = wl_c4(B, n, args.dim_rows, variant, args.steps, args.warmup, gather=args.gather, immutable=args.immutable)
         par = parity_c4(B, st, 5_000_000) if want_cpu else None
         name = {"c4": "c4", "c4_sparse": "c4_sparse_keys", "c4_wide": "c4_wide_payload", "c4_dup": "c4_dup_keys", "c4_partial": "c4_partial_match"}[wl]
+        if args.immutable and wl == "c4":
+            name = "c4_shared_probe_columns"
+        if wl == "c4" and args.dim_rows != 10**6:
+            name = {10**7: "c4_dim_1e7", 10**8: "c4_dim_1e8"}.get(args.dim_rows, name)
     attach_traffic(res["roofline"], name)
     n_main = res["rows_per_gpu"]
     details = {"main": {"name": name, "workload": res["workload"], "kernels": res["roofline"].pop("kernels")}, "configs": {}}

@@ -334,11 +334,13 @@ nqe_status nqe_table_unpack_words(nqe_ctx *ctx, const void *src_device, int32_t 
  * MPI, a test fabric): the library then builds its collectives from them with the very code it runs over RCCL's ncclSend /
  * ncclRecv.
  *
- * Failure is collective: every sharded entry point runs its fallible local work (the partial aggregate, the probe, the
+ * Nobody blocks on a failed rank: every sharded entry point runs its fallible local work (the partial aggregate, the probe, the
  * selection: data-dependent DivideByZero, out of memory, ...) first, and a rank that fails there STILL enters the operator's
  * exchange, with its status in the header every exchange starts with — so that every rank returns an error together (the
  * failing rank its own, the others NQE_ERR_RCCL naming the rank and its status) instead of blocking in a collective the failed
- * rank never joined. */
+ * rank never joined.  A failure AFTER the exchange (the merge of the gathered partials, a Utf8 re-encode: out of memory on one
+ * rank) is that rank's alone: the others have their result and return NQE_OK — statuses may then differ between ranks, but no
+ * rank waits for another. */
 #define NQE_COMM_ID_BYTES 128
 /* rows of the fixed-size buffer a partial aggregate travels in (one collective, counts read on the device); larger partials take
  * an exact-size two-step exchange */

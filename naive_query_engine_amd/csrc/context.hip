@@ -541,6 +541,11 @@ nqe_status nqe_ctx_create(int32_t device, void *stream, nqe_ctx **out) {
     hipDeviceProp_t prop;
     NQE_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.sharedMemPerBlock > 0) ctx->lds_per_block = size_t(prop.sharedMemPerBlock);
+    if (prop.gcnArchName[0]) { // "gfx950:sramecc+:xnack-" -> "gfx950"
+        ctx->arch = prop.gcnArchName;
+        ctx->arch = ctx->arch.substr(0, ctx->arch.find(':'));
+    }
     NQE_HIP_CHECK(hipMalloc(&ctx->d_flags, sizeof(int) * NQE_NUM_FLAGS));
     NQE_HIP_CHECK(hipHostMalloc(&ctx->h_flags, sizeof(int) * NQE_NUM_FLAGS, hipHostMallocMapped | hipHostMallocCoherent));
     NQE_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_flags_dev), ctx->h_flags, 0));

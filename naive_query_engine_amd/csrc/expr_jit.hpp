@@ -73,7 +73,7 @@ struct JitArgs {
 struct JitEntry {
     std::thread worker;
     std::atomic<int> state{0}; // 0: compiling, 1: code ready, 2: loaded, -1: failed
-    std::string source, log;
+    std::string source, log, arch; // source: kept for the entry's lifetime — a lookup compares it (a 64-bit hash alone could collide)
     std::vector<char> code;
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
@@ -81,6 +81,7 @@ struct JitEntry {
 
 struct JitCache {
     std::map<uint64_t, std::unique_ptr<JitEntry>> entries;
+    bool unavailable = false;
     ~JitCache() {
         for (auto &kv : entries) {
             if (kv.second->worker.joinable()) kv.second->worker.join();
@@ -266,7 +267,9 @@ void jit_compile(JitEntry *e) {
     bool good = rt.create(&prog, e->source.c_str(), "nqe_jit_expr.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS;
     if (good) {
         // -ffp-contract=off: `v * v + w` is two roundings in arrow (and in the interpreter, whose steps are separate), never an fma
-        const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+        const std::string target = "--offload-arch=" + e->arch; // the context's device (this library ships gfx950 code objects only, but
+                                                                 // a run-time kernel for another target would never load)
+        const char *opts[] = {target.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
         good = rt.compile(prog, 4, opts) == HIPRTC_SUCCESS;
         size_t ls = 0;
         if (rt.log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
@@ -287,11 +290,14 @@ void jit_compile(JitEntry *e) {
 // The specialised kernel of P, if it is ready; starts its compilation otherwise (null: use the interpreter this time).
 template <class MakeSource> JitEntry *jit_get(nqe_ctx *ctx, uint64_t key, const char *kernel_name, MakeSource &&make_source) {
     JitCache *cache = jit_cache(ctx);
+    if (cache->unavailable) return nullptr; // a code object failed to load on this device: no further compilations
     auto it = cache->entries.find(key);
+    if (it != cache->entries.end() && it->second->source != make_source()) return nullptr; // hash collision: interpret, never launch another tree's kernel
     if (it == cache->entries.end()) {
         if (cache->entries.size() >= 128) return nullptr; // (entries hold threads and modules: no eviction, just stop specialising)
         auto e = std::make_unique<JitEntry>();
         e->source = make_source();
+        e->arch = ctx->arch;
         JitEntry *raw = e.get();
         if (const char *dump = getenv("NQE_JIT_DUMP")) { // diagnostics: the generated source, appended to this file
             if (FILE *f = fopen(dump, "a")) {
@@ -311,6 +317,7 @@ template <class MakeSource> JitEntry *jit_get(nqe_ctx *ctx, uint64_t key, const 
         if (!ok) {
             (void)hipGetLastError();
             e->log = "hipModuleLoadData failed";
+            cache->unavailable = true;
         }
         e->code.clear();
         e->code.shrink_to_fit();

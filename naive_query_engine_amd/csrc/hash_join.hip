@@ -1275,7 +1275,10 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             pb.parts = int(((span - 1) >> shift) + 1);
             pb.nc = nc;
             for (int c = 0; c < nc; ++c) pb.src[c] = dp.src[c];
-            const int rpt = nc <= 1 ? 8 : (nc <= 3 ? 4 : (nc <= 7 ? 2 : 1)); // 1024 * rpt tuples of 8 * (1 + nc) bytes in <= 128 KB of LDS
+            int rpt = nc <= 1 ? 8 : (nc <= 3 ? 4 : (nc <= 7 ? 2 : 1)); // 1024 * rpt tuples of 8 * (1 + nc) bytes in <= 128 KB of LDS
+            // (gfx950 has 160 KB per workgroup; a device with less takes fewer rows per thread, and the one-kernel build when even one does not fit)
+            while (rpt > 1 && size_t(PB_BLOCK) * size_t(rpt) * size_t(1 + nc) * 8 + size_t(PB_MAX_PARTS) * 12 > ctx->lds_per_block) rpt >>= 1;
+            const bool part_lds_ok = size_t(PB_BLOCK) * size_t(rpt) * size_t(1 + nc) * 8 + size_t(PB_MAX_PARTS) * 12 <= ctx->lds_per_block;
             const int64_t tile = int64_t(PB_BLOCK) * rpt;
             pb.W = int(std::min<int64_t>(ctx->num_cus, (n + tile - 1) / tile));
             pb.chunk = ((n + pb.W - 1) / pb.W + tile - 1) / tile * tile;
@@ -1286,6 +1289,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             bool part_oom = false;
             try { // the tuple stream and the records come on top of the table: when they do not fit, the one-kernel form below still may
                 if (getenv("NQE_TEST_PART_BUILD_OOM")) fail(NQE_ERR_OUT_OF_MEMORY, "partitioned build (NQE_TEST_PART_BUILD_OOM)"); // tests: as if the allocation had failed
+                if (!part_lds_ok) fail(NQE_ERR_OUT_OF_MEMORY, "partitioned build: the scatter tile does not fit this device's LDS");
                 counts = dev_alloc(ctx, cells * 4);
                 offsets = dev_alloc(ctx, (cells + 1) * 8);
                 tuples = dev_alloc(ctx, size_t(n) * size_t(1 + nc) * 8 + 16);

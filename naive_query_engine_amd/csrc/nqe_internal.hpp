@@ -81,6 +81,8 @@ struct nqe_ctx {
     // run-time specialised expression kernels (expr_jit.hpp: JitCache — worker threads, code objects), created on first use
     std::shared_ptr<void> jit;
 
+    size_t lds_per_block = 160 * 1024; // LDS a workgroup may ask for on this device (hipDeviceProp_t::sharedMemPerBlock)
+    std::string arch = "gfx950";      // the device's ISA name (hipRTC target of the run-time specialised kernels)
     int *d_flags = nullptr; // NQE_NUM_FLAGS ints on the device
     int *h_flags = nullptr; // pinned host mirror
     int *h_flags_dev = nullptr; // the mirror's address as seen by kernels (a tail kernel may write it directly)
