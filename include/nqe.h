@@ -187,6 +187,12 @@ nqe_status nqe_ctx_synchronize(nqe_ctx *ctx);
  * the cached blocks to the driver (after a stream synchronisation). */
 nqe_status nqe_ctx_memory_stats(nqe_ctx *ctx, int64_t *live_bytes, int64_t *pooled_bytes);
 nqe_status nqe_ctx_trim(nqe_ctx *ctx);
+/* Takes `bytes` of device memory from the driver NOW (one block, pages touched) and serves later allocations of the context —
+ * operator outputs, scratch — from it (best fit, freed ranges coalesced; what does not fit falls back to the pool / the driver).
+ * A first query then pays no hipMalloc: the reference's run_sql is one-shot (db.rs:24-37), and a first hipMalloc of a gigabyte
+ * output costs as much as the query.  Once per context; released by nqe_ctx_destroy (nqe_ctx_trim leaves it alone).  The free part
+ * counts as `pooled_bytes`.  NQE_RESERVE_MB=<n> in the environment reserves at nqe_ctx_create. */
+nqe_status nqe_ctx_reserve(nqe_ctx *ctx, size_t bytes);
 const char *nqe_last_error(const nqe_ctx *ctx);
 /* global message for failures with no ctx (nqe_ctx_create itself) */
 const char *nqe_last_global_error(void);

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("NQE_LIB_PATH") or os.path.join(_HERE, "libnqe_hip.so"
 
 # every symbol include/nqe.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
-    "nqe_abi_version", "nqe_ctx_create", "nqe_ctx_destroy", "nqe_ctx_synchronize", "nqe_ctx_memory_stats", "nqe_ctx_trim", "nqe_last_error",
+    "nqe_abi_version", "nqe_ctx_create", "nqe_ctx_destroy", "nqe_ctx_synchronize", "nqe_ctx_memory_stats", "nqe_ctx_trim", "nqe_ctx_reserve", "nqe_last_error",
     "nqe_last_global_error", "nqe_ctx_timing_enable", "nqe_ctx_timing_query", "nqe_ctx_timing_reset", "nqe_ctx_timing_report", "nqe_ctx_jit_wait",
     "nqe_table_create", "nqe_table_create_flags", "nqe_table_release", "nqe_table_num_rows", "nqe_table_num_columns", "nqe_table_column",
     "nqe_table_download_column", "nqe_table_project", "nqe_table_slice", "nqe_table_concat", "nqe_table_pack_words",
@@ -96,6 +96,7 @@ def lib():
         "nqe_last_global_error": (C.c_char_p, []),
         "nqe_ctx_memory_stats": (i32, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "nqe_ctx_trim": (i32, [vp]),
+        "nqe_ctx_reserve": (i32, [vp, C.c_size_t]),
         "nqe_ctx_timing_enable": (i32, [vp, i32]),
         "nqe_ctx_timing_query": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
         "nqe_ctx_timing_reset": (i32, [vp]),
@@ -196,6 +197,10 @@ class Context:
         live, pooled = C.c_int64(), C.c_int64()
         self.check(lib().nqe_ctx_memory_stats(self.handle, C.byref(live), C.byref(pooled)))
         return live.value, pooled.value
+
+    def reserve(self, nbytes: int) -> None:
+        """nqe_ctx_reserve: take `nbytes` from the driver now; later allocations of the context are served from that block"""
+        self.check(lib().nqe_ctx_reserve(self.handle, nbytes))
 
     def trim(self) -> None:
         self.check(lib().nqe_ctx_trim(self.handle))

@@ -51,6 +51,38 @@ void pool_trim(nqe_ctx *ctx) {
     ctx->pool_bytes = 0;
 }
 
+// best fit in the reserved block; null when nothing fits
+static void *arena_alloc(nqe_ctx *ctx, size_t cap) {
+    if (!ctx->arena_base || cap > ctx->arena_free_bytes) return nullptr;
+    auto best = ctx->arena_free.end();
+    for (auto it = ctx->arena_free.begin(); it != ctx->arena_free.end(); ++it)
+        if (it->second >= cap && (best == ctx->arena_free.end() || it->second < best->second)) best = it;
+    if (best == ctx->arena_free.end()) return nullptr;
+    const size_t off = best->first, len = best->second;
+    ctx->arena_free.erase(best);
+    if (len > cap) ctx->arena_free.emplace(off + cap, len - cap);
+    ctx->arena_free_bytes -= cap;
+    return ctx->arena_base + off;
+}
+static void arena_release(nqe_ctx *ctx, void *ptr, size_t cap) {
+    size_t off = size_t(static_cast<char *>(ptr) - ctx->arena_base), len = cap;
+    auto next = ctx->arena_free.lower_bound(off);
+    if (next != ctx->arena_free.begin()) {
+        auto prev = std::prev(next);
+        if (prev->first + prev->second == off) { // coalesce with the free range below
+            off = prev->first;
+            len += prev->second;
+            ctx->arena_free.erase(prev);
+        }
+    }
+    if (next != ctx->arena_free.end() && off + len == next->first) { // … and above
+        len += next->second;
+        ctx->arena_free.erase(next);
+    }
+    ctx->arena_free.emplace(off, len);
+    ctx->arena_free_bytes += cap;
+}
+
 BufRef dev_alloc(nqe_ctx *ctx, size_t bytes) {
     auto b = std::make_shared<DevBuf>();
     b->ctx = ctx;
@@ -64,6 +96,10 @@ BufRef dev_alloc(nqe_ctx *ctx, size_t bytes) {
         b->capacity = it->first;
         ctx->pool_bytes -= it->first;
         ctx->pool.erase(it);
+    } else if (void *ap = arena_alloc(ctx, cap)) {
+        b->ptr = ap;
+        b->capacity = cap;
+        b->in_arena = true;
     } else {
         hipError_t e = hipMalloc(&b->ptr, cap);
         if (e == hipErrorOutOfMemory) {
@@ -116,6 +152,10 @@ DevBuf::~DevBuf() {
         // stream-ordered reuse: every consumer of this block was enqueued on ctx->stream before
         // any later allocation's first use, so handing it back to the pool is safe.
         ctx->live_bytes -= capacity;
+        if (in_arena) {
+            arena_release(ctx, ptr, capacity);
+            return;
+        }
         ctx->pool.emplace(capacity, ptr);
         ctx->pool_bytes += capacity;
     }
@@ -552,6 +592,11 @@ nqe_status nqe_ctx_create(int32_t device, void *stream, nqe_ctx **out) {
     NQE_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NQE_NUM_FLAGS, ctx->stream));
     load_modules();
     *out = ctx.release();
+    if (const char *mb = getenv("NQE_RESERVE_MB")) {
+        const long long n = atoll(mb);
+        if (n > 0 && nqe_ctx_reserve(*out, size_t(n) << 20) != NQE_OK) { // (a failed reservation is not a failed context: the pool takes over)
+        }
+    }
     NQE_API_END()
 }
 
@@ -564,6 +609,7 @@ nqe_status nqe_ctx_destroy(nqe_ctx *ctx) {
         (void)hipEventDestroy(t.stop);
     }
     pool_trim(ctx);
+    if (ctx->arena_base) (void)hipFree(ctx->arena_base);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -581,7 +627,29 @@ nqe_status nqe_ctx_memory_stats(nqe_ctx *ctx, int64_t *live_bytes, int64_t *pool
     NQE_API_BEGIN(ctx)
     if (!ctx) fail(NQE_ERR_INVALID_ARGUMENT, "null context");
     if (live_bytes) *live_bytes = int64_t(ctx->live_bytes);
-    if (pooled_bytes) *pooled_bytes = int64_t(ctx->pool_bytes);
+    if (pooled_bytes) *pooled_bytes = int64_t(ctx->pool_bytes + ctx->arena_free_bytes);
+    NQE_API_END()
+}
+
+nqe_status nqe_ctx_reserve(nqe_ctx *ctx, size_t bytes) {
+    NQE_API_BEGIN(ctx)
+    if (!ctx) fail(NQE_ERR_INVALID_ARGUMENT, "null context");
+    if (ctx->arena_base) fail(NQE_ERR_INVALID_ARGUMENT, "the context has a reserved block already");
+    if (bytes == 0) return NQE_OK;
+    const size_t g = size_t(2) << 20;
+    bytes = (bytes + g - 1) / g * g;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(e == hipErrorOutOfMemory ? NQE_ERR_OUT_OF_MEMORY : NQE_ERR_HIP, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    }
+    // touch every page once (the driver maps lazily: the first kernel to write a fresh block would pay for it)
+    NQE_HIP_CHECK(hipMemsetAsync(p, 0, bytes, ctx->stream));
+    sync(ctx);
+    ctx->arena_base = static_cast<char *>(p);
+    ctx->arena_size = ctx->arena_free_bytes = bytes;
+    ctx->arena_free.emplace(size_t(0), bytes);
     NQE_API_END()
 }
 

@@ -54,6 +54,12 @@ struct nqe_ctx {
     // caching device allocator: freed blocks are reused by later (stream-ordered) work
     std::multimap<size_t, void *> pool;
     size_t pool_bytes = 0;
+    // nqe_ctx_reserve: one block taken from the driver up front and sub-allocated (best fit, free neighbours coalesced): the scratch
+    // and output buffers of a FIRST query then cost no hipMalloc (a first hipMalloc of a gigabyte block is a millisecond and more —
+    // the reference's run_sql is one-shot, so the first execution is the one that counts).  Reuse is stream-ordered like the pool's.
+    char *arena_base = nullptr;
+    size_t arena_size = 0, arena_free_bytes = 0;
+    std::map<size_t, size_t> arena_free; // offset -> bytes, address-ordered
     size_t live_bytes = 0;
 
     // per-kernel timing (bench.py roofline leg)
@@ -100,6 +106,7 @@ struct DevBuf {
     size_t bytes = 0;    // usable size requested
     size_t capacity = 0; // pooled block size
     bool owned = false;
+    bool in_arena = false; // a range of the context's reserved block (returned to its free list)
     // the memory belongs to the context's pool (an allocation of ours, or a view into one): its reuse is ordered on the context's
     // stream, so work enqueued on that stream may still be reading it when the last reference goes away.  false: the caller's.
     bool lib_memory = false;

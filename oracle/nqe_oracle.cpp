@@ -34,6 +34,8 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <cfloat>
 #include <unordered_map>
 #include <vector>
 
@@ -1358,6 +1360,47 @@ int orc_synth_fill(int32_t kind, uint64_t seed, int64_t first_row, int64_t n, ui
             case NQE_SYNTH_F64_0_100: o[r] = f64_bits(double(splitmix64(seed + i) >> 11) * 0x1.0p-53 * 100.0); break;
             default: fail(NQE_ERR_INVALID_ARGUMENT, "unknown synth kind");
             }
+        }
+    });
+}
+
+// ---- an OPTIMISED multi-core CPU form of the headline query, for bench.py's optional second CPU number (last row): NOT
+// the reference's algorithm (which is single-threaded by construction, aggregate/mod.rs:33) — what a tuned CPU engine would do for
+// `select count(v), sum(v), min(v), max(v) from t where id < limit group by id % modulus` over plain columns: `threads` workers over
+// contiguous row ranges, each with its own direct-mapped table of `modulus` groups (modulus <= 65536, id >= 0), merged at the end.
+// out: modulus x {count, sum, min, max} as doubles.  Checked against orc_aggregate by tests/test_oracle_golden.py.
+int orc_headline_parallel(const int64_t *ids, const double *v, int64_t n, int64_t limit, int64_t modulus, int32_t threads, double *out) {
+    return guarded([&] {
+        if (modulus <= 0 || modulus > 65536 || threads < 1 || n < 0) fail(NQE_ERR_INVALID_ARGUMENT, "orc_headline_parallel: bad arguments");
+        struct Acc { uint64_t cnt; double sum, mn, mx; };
+        std::vector<std::vector<Acc>> part(size_t(threads), std::vector<Acc>(size_t(modulus), Acc{0, 0.0, DBL_MAX, -DBL_MAX}));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&, t] {
+                Acc *a = part[size_t(t)].data();
+                const int64_t lo = n * t / threads, hi = n * (t + 1) / threads;
+                for (int64_t r = lo; r < hi; ++r) {
+                    const int64_t id = ids[r];
+                    if (id >= limit) continue;
+                    Acc &g = a[uint64_t(id) % uint64_t(modulus)];
+                    const double x = v[r];
+                    g.cnt += 1;
+                    g.sum += x;
+                    g.mn = x < g.mn ? x : g.mn;
+                    g.mx = x > g.mx ? x : g.mx;
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (int64_t k = 0; k < modulus; ++k) {
+            Acc m{0, 0.0, DBL_MAX, -DBL_MAX};
+            for (int t = 0; t < threads; ++t) {
+                const Acc &g = part[size_t(t)][size_t(k)];
+                m.cnt += g.cnt;
+                m.sum += g.sum;
+                m.mn = g.mn < m.mn ? g.mn : m.mn;
+                m.mx = g.mx > m.mx ? g.mx : m.mx;
+            }
+            out[4 * k] = double(m.cnt); out[4 * k + 1] = m.sum; out[4 * k + 2] = m.mn; out[4 * k + 3] = m.mx;
         }
     });
 }

@@ -65,6 +65,7 @@ def lib():
         L.orc_xxhash64.restype = C.c_uint64
         L.orc_xxhash64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
         L.orc_synth_fill.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, vp]
+        L.orc_headline_parallel.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp]
         L.orc_csv_read.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(vp), C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.c_int32]
         L.orc_csv_read.restype = C.c_int
         _lib = L
@@ -235,4 +236,16 @@ def synth_fill(kind: int, seed: int, first_row: int, n: int, modulus: int = 1, b
 
     out = np.empty(n, dtype=np.uint64)
     _check(lib().orc_synth_fill(kind, seed, first_row, n, modulus, base, out.ctypes.data if n else None))
+    return out
+
+
+def headline_parallel(ids, v, limit: int, modulus: int, threads: int):
+    """the OPTIMISED multi-core CPU form of the headline query (orc_headline_parallel: per-thread direct-mapped tables, merged) — not the
+    reference's algorithm; bench.py's optional second CPU number.  → float64[modulus, 4] = count, sum, min, max per key"""
+    import numpy as np
+
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    out = np.zeros((modulus, 4), dtype=np.float64)
+    _check(lib().orc_headline_parallel(ids.ctypes.data, v.ctypes.data, ids.size, limit, modulus, threads, out.ctypes.data))
     return out

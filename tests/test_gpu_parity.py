@@ -2134,3 +2134,44 @@ def test_selection_and_projection_in_one_specialised_pass(ctx, monkeypatch, n, k
                 ctx.selection_projection(t, unsafe.flatten(f3), div)
             assert ge.value.status == Status.ArrowError
             ctx.jit_wait()
+
+
+def test_reserved_block_serves_allocations_and_falls_back(monkeypatch):
+    """nqe_ctx_reserve: a context with a reserved block sub-allocates operator outputs and scratch from it (best fit, freed ranges
+    coalesced) and falls back to the pool / the driver for what does not fit — same results either way, the free part is reported
+    as pooled bytes, and released tables give their ranges back."""
+    from naive_query_engine_amd import capi
+
+    c = capi.Context(0)
+    try:
+        c.reserve(48 << 20)
+        with pytest.raises(ErrorCode):
+            c.reserve(1 << 20)                       # once per context
+        live0, pooled0 = c.memory_stats()
+        assert pooled0 >= 48 << 20
+        rng = np.random.default_rng(77)
+        n = 400_003
+        cols = random_batch(rng, n, 0.0, key_mod=1000)
+        t = c.table_from_host(cols)                  # 4 x 3.2 MB: from the block
+        live1, pooled1 = c.memory_stats()
+        assert pooled1 < pooled0 and live1 > live0
+        f = FLD[:4]
+        pred = binop(col(1), Operator.Lt, lit_i64(500)).flatten(f)
+        exp = orc.selection([cols], pred)[0]
+        for _ in range(3):
+            assert_batches_equal(c.selection(t, pred).to_host(), exp, what="selection from the reserved block")
+        aggs = ALL_AGGS(2)
+        expa = orc.aggregate([cols], aggs, group_nodes=col(1).flatten(f))[0]
+        assert_rows_multiset_equal(c.aggregate(t, aggs, group_nodes=col(1).flatten(f)).to_host(), expa, RTOL, exact_cols=[0], what="aggregate")
+        # more than the block holds: the driver serves it, results unchanged
+        big = [Column.from_numpy(rng.integers(0, 1 << 40, 3_000_000).astype(np.int64)) for _ in range(3)]   # 72 MB
+        tb = c.table_from_host(big)
+        got = c.projection(tb, [binop(col(0), Operator.Plus, col(1)).flatten(fields("a", "b", "c"))]).to_host()[0]
+        assert (got.to_numpy() == big[0].to_numpy() + big[1].to_numpy()).all()
+        del t, tb, got
+        import gc
+        gc.collect()
+        live2, pooled2 = c.memory_stats()
+        assert live2 <= live0 + (1 << 20) and pooled2 >= pooled0   # everything came back (the driver's blocks to the pool)
+    finally:
+        c.close()

@@ -117,11 +117,13 @@ def main():
         worker(sys.argv[2])
         return
     shapes = [s for s in (os.environ.get("NQE_COLD_SHAPES", "").split(",")) if s] or SHAPES
-    variants = [("default", {})] + [(v, {v: "1"}) for v in os.environ.get("NQE_COLD_VARIANTS", "NQE_LAZY_MODULES").split(",") if v]
+    # default = code objects loaded at context creation + a 24 GB block reserved at context creation (NQE_RESERVE_MB)
+    variants = [("default (NQE_RESERVE_MB=24576)", {"NQE_RESERVE_MB": "24576"})] + [(v, {v: "1"}) for v in os.environ.get("NQE_COLD_VARIANTS", "NQE_NO_RESERVE,NQE_LAZY_MODULES").split(",") if v]
     for label, extra in variants:
         print(f"# {label}")
         for s in shapes:
             env = dict(os.environ, **extra)
+            env.pop("NQE_NO_RESERVE", None)  # (a label, not a switch: this variant simply has no NQE_RESERVE_MB)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", s], env=env, capture_output=True, text=True, timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             print(line[-1] if line else f"{s}: FAILED rc={r.returncode} {r.stderr[-300:]}")
