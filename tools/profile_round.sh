@@ -14,7 +14,7 @@ python bench.py --details $OUT/bench_details.json 2>&1 | tail -1 > $OUT/bench_de
 # the same line with nothing remembered between executions (every execution plans from scratch; the key sample still runs)
 NQE_NO_PLAN_HINTS=1 python bench.py --details $OUT/bench_details_no_plan_hints.json 2>&1 | tail -1 > $OUT/bench_no_plan_hints.json
 # first-execution cost of every query shape, each in a fresh process
-NQE_COLD_VARIANTS=NQE_LAZY_MODULES python tools/probe_cold.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_cold.txt
+NQE_COLD_VARIANTS=NQE_NO_RESERVE,NQE_LAZY_MODULES python tools/probe_cold.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_cold.txt
 declare -A WL=( [headline]="--workload headline" [headline_random_keys]="--workload headline --random-keys" [c2]="--workload c2" [c4]="--workload c4" \
                 [c4_sparse_keys]="--workload c4_sparse" [agg_65536_groups]="--workload agg_groups --groups 65536" [agg_4096_groups]="--workload agg_groups --groups 4096" [c2_expression_trees]="--workload c2_tree" \
                 [headline_single_column]="--workload headline_single" [headline_int64_values]="--workload headline_int64" \
