@@ -212,7 +212,8 @@ nqe_status nqe_ctx_timing_report(nqe_ctx *ctx, char *buf, int64_t capacity, int6
  * executions of the same tree shape switch to the compiled kernel once it is ready (results are identical; without libhiprtc the
  * interpreter simply stays).  This call blocks until every compilation in flight for the context has finished — for tests and
  * benchmarks that want the steady state.  NQE_NO_JIT=1 disables the specialisation, NQE_JIT_SYNC=1 compiles before the first
- * execution. */
+ * execution.  Code objects are kept on disk (NQE_JIT_CACHE_DIR, default ~/.cache/nqe_jit; NQE_NO_JIT_DISK_CACHE=1: not) with the
+ * source they were compiled from, so that a new process takes a known tree's kernel on its first execution. */
 nqe_status nqe_ctx_jit_wait(nqe_ctx *ctx);
 
 /* ------------------------------------------------------------------ tables

@@ -19,6 +19,9 @@
 
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <mutex>
@@ -73,6 +76,7 @@ struct JitArgs {
 struct JitEntry {
     std::thread worker;
     std::atomic<int> state{0}; // 0: compiling, 1: code ready, 2: loaded, -1: failed
+    std::string disk_path; // where the code object is kept between processes (empty: nowhere)
     std::string source, log, arch; // source: kept for the entry's lifetime — a lookup compares it (a 64-bit hash alone could collide)
     std::vector<char> code;
     hipModule_t mod = nullptr;
@@ -256,6 +260,52 @@ std::string gen_source(const ExProgram &P, bool nulls, bool bool_out) {
     return s.str();
 }
 
+// ---- code objects on disk: a NEW process finds the kernels an earlier one compiled (hipRTC takes 0.3-3 s per tree shape, during
+// which a one-shot process would only ever interpret).  One file per (source hash, ISA, HIP runtime version) under NQE_JIT_CACHE_DIR
+// (default $XDG_CACHE_HOME/nqe_jit, $HOME/.cache/nqe_jit, /tmp/nqe_jit-<uid>): magic, the generated SOURCE (compared on load: a
+// hash collision or a changed generator never hands out another tree's kernel) and the code object; written to a temporary name and
+// renamed.  NQE_NO_JIT_DISK_CACHE=1 switches it off.  Failures of any kind just mean "compile".
+std::string jit_disk_path(uint64_t key, const std::string &arch) {
+    if (getenv("NQE_NO_JIT_DISK_CACHE")) return std::string();
+    std::string dir;
+    if (const char *d = getenv("NQE_JIT_CACHE_DIR")) dir = d;
+    else if (const char *x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/nqe_jit";
+    else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/nqe_jit";
+    else dir = "/tmp/nqe_jit-" + std::to_string((unsigned long)getuid());
+    for (size_t i = 1; i <= dir.size(); ++i) // mkdir -p
+        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0700);
+    int rtv = 0;
+    (void)hipRuntimeGetVersion(&rtv);
+    char name[96];
+    snprintf(name, sizeof(name), "/%016llx-%s-%d.nqejit", (unsigned long long)key, arch.c_str(), rtv);
+    return dir + name;
+}
+constexpr uint64_t JIT_DISK_MAGIC = 0x3130544a5145514eull; // "NQEQJT01"
+bool jit_disk_load(const std::string &path, const std::string &source, std::vector<char> *code) {
+    if (path.empty()) return false;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    uint64_t head[3];
+    if (fread(head, 8, 3, f) == 3 && head[0] == JIT_DISK_MAGIC && head[1] == source.size() && head[2] > 0 && head[2] < (uint64_t(1) << 28)) {
+        std::string src(size_t(head[1]), '\0');
+        code->resize(size_t(head[2]));
+        ok = fread(&src[0], 1, src.size(), f) == src.size() && fread(code->data(), 1, code->size(), f) == code->size() && src == source;
+    }
+    fclose(f);
+    if (!ok) code->clear();
+    return ok;
+}
+void jit_disk_store(const std::string &path, const std::string &source, const std::vector<char> &code) {
+    if (path.empty() || code.empty()) return;
+    const std::string tmp = path + ".tmp" + std::to_string((unsigned long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const uint64_t head[3] = {JIT_DISK_MAGIC, source.size(), code.size()};
+    const bool ok = fwrite(head, 8, 3, f) == 3 && fwrite(source.data(), 1, source.size(), f) == source.size() && fwrite(code.data(), 1, code.size(), f) == code.size();
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+}
+
 void jit_compile(JitEntry *e) {
     const HipRtcApi &rt = hiprtc_api();
     if (!rt.ok) {
@@ -284,6 +334,7 @@ void jit_compile(JitEntry *e) {
         }
     }
     if (prog) (void)rt.destroy(&prog);
+    if (good) jit_disk_store(e->disk_path, e->source, e->code);
     e->state.store(good ? 1 : -1, std::memory_order_release);
 }
 
@@ -305,9 +356,14 @@ template <class MakeSource> JitEntry *jit_get(nqe_ctx *ctx, uint64_t key, const 
                 fclose(f);
             }
         }
-        e->worker = std::thread(jit_compile, raw);
+        e->disk_path = jit_disk_path(key, e->arch);
+        if (jit_disk_load(e->disk_path, e->source, &e->code)) {
+            e->state.store(1, std::memory_order_release); // an earlier process compiled this very source: loaded below, used by THIS execution
+        } else {
+            e->worker = std::thread(jit_compile, raw);
+            if (getenv("NQE_JIT_SYNC")) raw->worker.join(); // tests / benchmarks: compile before the first execution
+        }
         it = cache->entries.emplace(key, std::move(e)).first;
-        if (getenv("NQE_JIT_SYNC")) raw->worker.join(); // tests / benchmarks: compile before the first execution
     }
     JitEntry *e = it->second.get();
     int st = e->state.load(std::memory_order_acquire);

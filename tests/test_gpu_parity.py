@@ -2175,3 +2175,64 @@ def test_reserved_block_serves_allocations_and_falls_back(monkeypatch):
         assert live2 <= live0 + (1 << 20) and pooled2 >= pooled0   # everything came back (the driver's blocks to the pool)
     finally:
         c.close()
+
+
+def test_specialised_kernels_are_found_on_disk_by_a_new_context(tmp_path, monkeypatch):
+    """the code object hipRTC produces for a tree is kept under NQE_JIT_CACHE_DIR (source hash + ISA + runtime version; the generated
+    source is stored with it and compared on load): a context that has never seen the tree — a new process, in production — takes the
+    specialised kernel on its FIRST execution instead of interpreting until a compilation finishes.  A file whose source differs is
+    ignored (recompiled), NQE_NO_JIT_DISK_CACHE switches the cache off."""
+    from naive_query_engine_amd import capi
+
+    monkeypatch.setenv("NQE_JIT_MIN_ROWS", "1000")
+    monkeypatch.setenv("NQE_JIT_CACHE_DIR", str(tmp_path / "jit"))
+    rng = np.random.default_rng(31)
+    n = 40_000
+    a = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    cols = [Column.from_numpy(a)]
+    O, X = Operator, binop
+    tree = X(X(X(col(0), O.Modulos, lit_i64(977)), O.Multiply, lit_i64(3)), O.Plus, X(col(0), O.Divide, lit_i64(7)))
+    nodes = tree.flatten(fields("a"))
+    exp = orc.expr_evaluate([cols], nodes)
+
+    def run(ctx):
+        t = ctx.table_from_host(cols)
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got = ctx.expr_evaluate(t, nodes).to_host()[0]
+        ctx.timing_enable(False)
+        assert_column_equal(got, exp, what="tree")
+        return set(ctx.timing_report())
+
+    c1 = capi.Context(0)
+    try:
+        assert "expr_jit" not in run(c1)          # nothing on disk yet: interpreted, compilation started
+        c1.jit_wait()
+        assert "expr_jit" in run(c1)
+    finally:
+        c1.close()
+    files = list((tmp_path / "jit").glob("*.nqejit"))
+    assert len(files) == 1 and files[0].stat().st_size > 1000
+    c2 = capi.Context(0)
+    try:
+        assert "expr_jit" in run(c2)              # first execution of a fresh context: from the file
+    finally:
+        c2.close()
+    # a file that does not hold this source is not used
+    blob = bytearray(files[0].read_bytes())
+    blob[24 + 10] ^= 0x20                         # one character of the stored source
+    files[0].write_bytes(bytes(blob))
+    c3 = capi.Context(0)
+    try:
+        assert "expr_jit" not in run(c3)
+        c3.jit_wait()
+        assert "expr_jit" in run(c3)
+    finally:
+        c3.close()
+    monkeypatch.setenv("NQE_NO_JIT_DISK_CACHE", "1")
+    c4 = capi.Context(0)
+    try:
+        assert "expr_jit" not in run(c4)
+    finally:
+        c4.jit_wait()
+        c4.close()
