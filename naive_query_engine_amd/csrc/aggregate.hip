@@ -1528,7 +1528,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         // capacity (no count pass, no scan, no read-back), then one workgroup per partition aggregates its slabs
                         const int rpt = slab_scatter_rows_per_thread(fp, fast_key, a.nv);
                         const int64_t tile_rows = int64_t(AGG_BLOCK) * rpt;
-                        int W = int(std::min<int64_t>(ctx->num_cus, (in->rows + tile_rows - 1) / tile_rows));
+                        int W = int(std::min<int64_t>(int64_t(ctx->num_cus) * slab_scatter_wg_per_cu(), (in->rows + tile_rows - 1) / tile_rows));
                         int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
                         W = int((in->rows + chunk - 1) / chunk);
                         const int sparts = 1 << slab_parts_log2;

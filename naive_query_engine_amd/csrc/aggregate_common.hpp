@@ -510,6 +510,7 @@ using SlabScatterKernel = void (*)(AggArgs, FastPred, SlabArgs, int *);
 // k32 (one value column): 12-byte tuples {int32 key, value} — the scatter raises NQE_FLAG_KEY32_OVERFLOW on a key outside int32
 SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv, bool k32 = false);
 int slab_scatter_rows_per_thread(int pred, int key, int nv);
+int slab_scatter_wg_per_cu();
 using SlabSegmentsKernel = void (*)(AggArgs, SlabArgs, GroupTable, int *);
 SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64, bool k32 = false);
 

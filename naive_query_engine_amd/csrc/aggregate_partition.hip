@@ -410,8 +410,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
 #ifndef NQE_SLAB_KEYMOD_RPT
 #define NQE_SLAB_KEYMOD_RPT 8 // rows per thread of the `col % m` key variants: 8 spill 14-16 VGPRs and are still faster than 4 without (scatter 0.85 vs 0.93 ms)
 #endif
+#ifndef NQE_SLAB_WG_PER_CU
+#define NQE_SLAB_WG_PER_CU 1 // scatter workgroups per CU (A/B): 2 = half tiles (4 rows per thread, 70 KB of LDS each) whose barrier phases overlap —
+                             // measured slower: kernels 1.06 -> 1.12 ms at 65536 groups, 1.17 -> 1.29 at 2^20 (shorter runs per partition per tile)
+#endif
 template <int PRED, int KEY, int NVT> struct SlabShape {
-    static constexpr int RPT = (NVT == 1 && PRED <= 1 && (KEY == 0 || (NQE_SLAB_KEYMOD_RPT == 8 && KEY != 3))) ? 8 : 4;
+    static constexpr int RPT = NQE_SLAB_WG_PER_CU > 1 ? 4 : ((NVT == 1 && PRED <= 1 && (KEY == 0 || (NQE_SLAB_KEYMOD_RPT == 8 && KEY != 3))) ? 8 : 4);
 };
 
 // One workgroup per chunk of rows.  Per tile: fused predicate + key → partition → rank (LDS atomic on the tile's counter) →
@@ -854,7 +858,8 @@ SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv, bool k32) 
     default: return pick_slab_scatter_key<3>(key, nv, k32);
     }
 }
-int slab_scatter_rows_per_thread(int pred, int key, int nv) { return (nv == 1 && pred <= 1 && (key == 0 || (NQE_SLAB_KEYMOD_RPT == 8 && key != 3))) ? 8 : 4; }
+int slab_scatter_rows_per_thread(int pred, int key, int nv) { return NQE_SLAB_WG_PER_CU > 1 ? 4 : ((nv == 1 && pred <= 1 && (key == 0 || (NQE_SLAB_KEYMOD_RPT == 8 && key != 3))) ? 8 : 4); }
+int slab_scatter_wg_per_cu() { return NQE_SLAB_WG_PER_CU; }
 SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64, bool k32) {
     if (nv == 1 && k32) return vf64 ? agg_slab_segments_kernel<1, true, true> : agg_slab_segments_kernel<1, false, true>;
     return nv == 1 ? (vf64 ? agg_slab_segments_kernel<1, true> : agg_slab_segments_kernel<1, false>)

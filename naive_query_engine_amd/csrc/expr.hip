@@ -1176,7 +1176,10 @@ bool select_project_fused(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node
         std::vector<Node> t = parse(in, pred, pred_nodes, &root);
         bool nv = false;
         if (t[size_t(root)].kind != NQE_EXPR_BINARY || t[size_t(root)].out_dtype != NQE_BOOLEAN || !build_program(in, t, root, &S.pred, &nv) || nv) return false;
-        if (S.pred.n < 3 || !renumber(S.pred, &S.pred_cols)) return false;
+        // (A/B, NQE_FUSED_SELECT_MIN_STEPS=1: plain `id < K` / `age + 100` through this kernel is SLOWER than the two static kernels —
+        // C2 0.36 -> 0.42 ms, random ids 0.46 -> 0.49: their mask and compaction passes already read each column once)
+        static const int min_steps = getenv("NQE_FUSED_SELECT_MIN_STEPS") ? atoi(getenv("NQE_FUSED_SELECT_MIN_STEPS")) : 3;
+        if (S.pred.n < min_steps || !renumber(S.pred, &S.pred_cols)) return false;
     }
     for (int e = 0; e < num_exprs; ++e) {
         int root;
