@@ -1189,7 +1189,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             mix(&dc.dtype, sizeof(dc.dtype));
         }
         if (hint_key == 0) hint_key = 1;
-        static const bool no_hints = getenv("NQE_NO_PLAN_HINTS") != nullptr; // diagnostics (A/B runs)
+        const bool no_hints = getenv("NQE_NO_PLAN_HINTS") != nullptr; // diagnostics (A/B runs; read per call: tests switch it)
         auto it = ctx->agg_hints.find(hint_key);
         if (!no_hints && it != ctx->agg_hints.end()) {
             const uint8_t hv = it->second & 0x3f;
@@ -1232,7 +1232,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     // rules out would certainly have overflowed; their min / max stand in for the full pass over a plain key column (the streaming
     // kernel checks every key against the range, and a key outside it asks for the exact measurement).  Only without a predicate: a
     // filter may leave far fewer groups than the table holds.
-    static const bool no_hints_env = getenv("NQE_NO_PLAN_HINTS") != nullptr, no_sample = getenv("NQE_NO_KEY_SAMPLE") != nullptr;
+    const bool no_hints_env = getenv("NQE_NO_PLAN_HINTS") != nullptr, no_sample = getenv("NQE_NO_KEY_SAMPLE") != nullptr; // (read per call)
     bool range_sampled = false;
     const bool simple_mod_key = a.key.nops == 1 && a.key.op[0] == NQE_OP_MODULOS && !a.key.lit_left[0] && (a.key.op_dtype[0] == NQE_INT64 || a.key.op_dtype[0] == NQE_UINT64) &&
                                 a.key.aux[0].abs_lit > 1;

@@ -2236,3 +2236,64 @@ def test_specialised_kernels_are_found_on_disk_by_a_new_context(tmp_path, monkey
     finally:
         c4.jit_wait()
         c4.close()
+
+
+@pytest.mark.parametrize("shape", ["few", "dense_4096", "sparse_3000", "sparse_6000", "sparse_20000", "groups_300000", "all_distinct", "mod_100000",
+                                   "range_with_outliers", "skewed"])
+@pytest.mark.parametrize("no_hints", [False, True])
+def test_aggregate_first_execution_starts_in_the_tier_its_key_sample_picks(ctx, monkeypatch, shape, no_hints):
+    """tables of 2^22 rows and more without a predicate: the FIRST execution samples 65536 keys (key_sample_kernel) and starts in the
+    tier their distinct count calls for — one workgroup table (a range that fits: addressed by key - min), two key subsets, the
+    partitioned path (256 or 512 partitions) — instead of falling through abandoned tiers; later executions take the remembered
+    tier (or, NQE_NO_PLAN_HINTS, sample again).  Results equal the oracle's in every case, including the ones the sample gets wrong:
+    a plain key column whose few outliers the sample misses (the kernel's range check asks for the exact measurement), heavy skew
+    (the sample's distinct count is far below the table's)."""
+    if no_hints:
+        monkeypatch.setenv("NQE_NO_PLAN_HINTS", "1")
+    rng = np.random.default_rng(len(shape) * 7 + 1)
+    # (a row count of its own per case: what the context remembers is keyed by buffer, rows and query shape, and the pool hands the
+    # same buffers to consecutive cases)
+    n = (1 << 22) + 12_345 + 64 * (sum(map(ord, shape)) + (1 if no_hints else 0))
+    key_expr = col(0)
+    if shape == "few":
+        k = rng.integers(-3, 4, n)
+    elif shape == "dense_4096":
+        k = rng.integers(100, 4196, n)
+    elif shape.startswith("sparse_"):
+        g = int(shape.split("_")[1])
+        k = rng.integers(0, g, n) * 1_000_003 - 5
+    elif shape == "groups_300000":
+        k = rng.integers(0, 300_000, n) * 7
+    elif shape == "all_distinct":
+        k = rng.permutation(n).astype(np.int64) * 3 - n
+    elif shape == "mod_100000":
+        k = rng.integers(0, 1 << 40, n)
+        key_expr = binop(col(0), Operator.Modulos, lit_i64(100_000))
+    elif shape == "range_with_outliers":
+        k = rng.integers(0, 1000, n)
+        k[[5, n // 2, n - 3]] = [10**12, -7, 4095 + 10**6]         # three rows the sample will not see
+    else:                                                           # skewed: 99.9 % of the rows in 50 keys, the rest in 200 000
+        k = np.where(rng.random(n) < 0.999, rng.integers(0, 50, n), rng.integers(1000, 201_000, n))
+    k = k.astype(np.int64)
+    v = rng.random(n) * 100.0
+    cols = [Column.from_numpy(k), Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    kn = key_expr.flatten(f2)
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=kn)[0]
+    t = ctx.table_from_host(cols)
+    for rep in range(3):
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn).to_host()
+        ctx.timing_enable(False)
+        names = ctx.timing_report()
+        assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"{shape} rep {rep} no_hints={no_hints}")
+        sampled = "agg_key_sample" in names
+        assert sampled == (rep == 0 or no_hints), (shape, rep, no_hints, sorted(names))
+        if rep == 0 and shape in ("sparse_20000", "groups_300000", "all_distinct", "mod_100000"):
+            # straight to the partitioned path: no abandoned streaming attempt before it
+            assert "agg_partition_scatter" in names and "agg_grouped_fast" not in names, sorted(names)
+        if rep == 0 and shape in ("few", "dense_4096", "sparse_3000"):
+            assert names.get("agg_grouped_fast", (0, 0))[1] == 1 and "agg_key_range" not in names, sorted(names)
+        if rep == 0 and shape == "range_with_outliers":
+            assert "agg_key_range" in names                        # the sampled range was too narrow: measured exactly, once
