@@ -373,10 +373,14 @@ def wl_aggregate(B, rows, with_filter, random_keys, steps, warmup, groups=None, 
         return B.ctx.aggregate(table, sh["aggs"], group_nodes=key, pred_nodes=pred)
 
     cold_ms = B.cold(step) if cold else None
+    if shape == "tree":  # steady state = the run-time specialised streaming kernel (compiled on a worker thread during the first execution)
+        r = step()
+        del r
+        B.ctx.jit_wait()
     ms, kernels, spread = B.timed(step, steps, warmup, blocks)
     where = " where id < N/2" if (use_pred and shape != "tree") else ""
     desc = sh["text"].replace("{w}", where) + f"; id = {'random' if random_keys else 'row number'}; {n} rows per GPU"
-    names = ["agg_grouped", "agg_partition", "agg_slab", "agg_segments", "agg_subpartition", "agg_sample", "expr_tree", "keep_from"]
+    names = ["agg_grouped", "agg_merge_partials", "agg_partition", "agg_slab", "agg_segments", "agg_subpartition", "agg_sample", "expr_tree", "keep_from"]
     res = {"metric": "filter_hash_aggregate_rows_per_s" if use_pred else "hash_aggregate_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s",
            "ms_per_step": ms, "spread": spread, "cold_ms": cold_ms, "workload": desc, "rows_per_gpu": n, "roofline": roofline(sh["bpr"] * n, kernels, names)}
     return res, dict(table=table, tens=tens, valid=valid, sh=sh, key=key, fields=fields, n=n, total=total, use_pred=use_pred, random_keys=random_keys, groups=groups)

@@ -806,6 +806,32 @@ __global__ void __launch_bounds__(256) key_sample_kernel(const uint64_t *keys, i
     }
 }
 
+// folds the per-workgroup direct-mapped tables the run-time specialised streaming kernel wrote (expr_jit.hpp: nqe_jit_agg;
+// [grid][span] sums | mins | maxs, then counts with the NaN mark in their top bit) into the group table: one thread per slot,
+// key = slot - bias
+__global__ void __launch_bounds__(256) agg_merge_partials_kernel(const double *psum, const double *pmn, const double *pmx, const uint32_t *pcnt, int grid, uint32_t span,
+                                                                 int64_t bias, GroupTable g, int v, int *flags) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= span) return;
+    uint64_t c = 0;
+    bool nan = false;
+    double sum = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
+    for (int b = 0; b < grid; ++b) {
+        const size_t o = size_t(b) * span + s;
+        const uint32_t cc = pcnt[o];
+        if (cc == 0) continue;
+        c += cc & ~NAN_BIT;
+        nan = nan || (cc & NAN_BIT) != 0;
+        sum += psum[o];
+        mn = fmin(mn, pmn[o]);
+        mx = fmax(mx, pmx[o]);
+    }
+    if (c == 0) return; // no row of this key passed the predicate
+    const int64_t gslot = global_find_or_insert(g, uint64_t(int64_t(s) - bias), flags);
+    if (gslot < 0) return;
+    global_update(g, gslot, v, c, sum, true, f64_to_ord(mn), f64_to_ord(mx), true, nan);
+}
+
 __global__ void store_tree_kernel(TreePred p, TreeInstr *dst) {
     if (int(threadIdx.x) < p.n) dst[threadIdx.x] = p.ins[threadIdx.x];
 }
@@ -1686,9 +1712,24 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         // single-load one — `count(id) … group by id % 3` updates one LDS word per row instead of reading two and updating four)
                         bool nomm = a.nv >= 2 || share;
                         for (int j = 0; j < a.nv; ++j) nomm = nomm && !a.need_minmax[j];
+                        // a predicate tree the static kernel would interpret (PRED 5 / 6) over `col % m` keys and one value column: the lean
+                        // run-time specialised kernel, once it has been compiled — its workgroup tables are folded into the group table here
+                        BufRef jit_partials;
+                        uint32_t jit_span = 0;
+                        int64_t jit_bias = 0;
+                        if (fp >= 5 && has_pred && (fast_key == 1 || fast_key == 2) && ka.direct == 1 && ka.direct_rep == 0 && a.nv == 1 && !vnull && subsets_log2 == 0 &&
+                            key_col >= 0 && a.val[0].values &&
+                            aggregate_tree_specialised(ctx, in, pred, pred_nodes, key_col, a.key.aux[0].abs_lit, a.key.op_dtype[0] == NQE_INT64, plan.val_cols[size_t(v0)], fgrid,
+                                                       &jit_partials, &jit_span, &jit_bias)) {
+                            const size_t cells = size_t(fgrid) * jit_span;
+                            const double *ps = (const double *)jit_partials->ptr;
+                            launch(ctx, "agg_merge_partials", agg_merge_partials_kernel, dim3((jit_span + 255) / 256), dim3(256), 0, ps, ps + cells, ps + 2 * cells,
+                                   reinterpret_cast<const uint32_t *>(ps + 3 * cells), fgrid, jit_span, jit_bias, tb.g, a.v0, ctx->d_flags);
+                        } else {
                         FastKernel fk = pick_fast_kernel(fp, fast_key, a.nv, vf64, vnull, subsets_log2 != 0, nomm, share);
                         if (!fk) fail(NQE_ERR_NOT_SUPPORTED, "internal: no such variant of the streaming aggregate kernel");
                         launch(ctx, "agg_grouped_fast", fk, dim3(fgrid), dim3(AGG_BLOCK), fshmem, ka, fpred, tb.g, ctx->d_flags);
+                        }
                     }
                 } else {
                     // the general kernel's PLAIN variant reads predicate and values as bare 8-byte words: not for a Boolean

@@ -2297,3 +2297,59 @@ def test_aggregate_first_execution_starts_in_the_tier_its_key_sample_picks(ctx, 
             assert names.get("agg_grouped_fast", (0, 0))[1] == 1 and "agg_key_range" not in names, sorted(names)
         if rep == 0 and shape == "range_with_outliers":
             assert "agg_key_range" in names                        # the sampled range was too narrow: measured exactly, once
+
+
+@pytest.mark.parametrize("n", [70_001, 4096 * 3])
+def test_aggregate_under_a_predicate_tree_through_the_specialised_streaming_kernel(ctx, monkeypatch, n):
+    """predicate trees the static streaming kernel interprets (PRED 5 / 6), grouped by `col % m` with a direct-mapped table of 512 to
+    4096 slots, one value column, no NULLs: a lean run-time specialised kernel (expr_jit.hpp: nqe_jit_agg — the predicate as
+    straight-line code, run cache, native LDS f64 atomics) whose per-workgroup tables agg_merge_partials_kernel folds into the group
+    table.  First execution: the interpreters; after nqe_ctx_jit_wait: one `agg_grouped_jit` + one `agg_merge_partials` launch and no
+    `agg_grouped_fast`; NQE_NO_AGG_JIT: the interpreters again — all three equal to the oracle (counts exact, Float64 1e-9).  Signed
+    keys on both sides of zero, unsigned keys, Float64 values with NaNs and +-0, Int64 / UInt64 values, the value column being the key
+    column, predicates over a third column; shapes that do not qualify (few slots, a plain key, a nullable value) keep the static kernel."""
+    monkeypatch.setenv("NQE_JIT_MIN_ROWS", "1000")
+    rng = np.random.default_rng(n)
+    ids = np.arange(n, dtype=np.int64) - n // 3
+    u = rng.integers(0, 1 << 50, n).astype(np.uint64)
+    v = rng.random(n) * 100.0
+    v[::97] = np.nan
+    v[::89] = -0.0
+    w = rng.integers(-1000, 1000, n).astype(np.int64)
+    cols = [Column.from_numpy(ids), Column.from_numpy(u), Column.from_numpy(v), Column.from_numpy(w), Column.from_numpy(v, rng.random(n) > 0.1)]
+    f5 = fields("id", "u", "v", "w", "vn")
+    ID, U, V, W = col(0), col(1), col(2), col(3)
+    O, X = Operator, binop
+    trees = [X(X(V, O.Lt, lit_f64(20.0)), O.Or, X(X(ID, O.Modulos, lit_i64(3)), O.Eq, lit_i64(0))),
+             X(X(X(W, O.Plus, lit_i64(7)), O.Multiply, lit_i64(3)), O.Gt, X(ID, O.Modulos, lit_i64(50))),
+             X(X(X(V, O.Multiply, V), O.Lt, lit_f64(2500.0)), O.And, X(X(W, O.Lt, lit_i64(500)), O.Or, X(ID, O.GtEq, lit_i64(0))))]
+    # (key expression, value column, qualifies)
+    # (None: whether the static path hands the tree to its in-kernel interpreters — the specialised kernel's hook — or materialises it
+    # depends on the predicate / key / value combination: results are checked, the kernel taken is not)
+    shapes = [(X(ID, O.Modulos, lit_i64(1024)), 2, True), (X(ID, O.Modulos, lit_i64(300)), 3, True), (X(U, O.Modulos, lit_u64(4096)), 1, None),
+              (X(U, O.Modulos, lit_u64(1000)), 2, None), (X(ID, O.Modulos, lit_i64(-2048)), 0, None),
+              (X(ID, O.Modulos, lit_i64(100)), 2, False), (X(U, O.Modulos, lit_u64(5000)), 2, False), (W, 2, False), (X(ID, O.Modulos, lit_i64(1024)), 4, False)]
+    t = ctx.table_from_host(cols)
+    for ti, tree in enumerate(trees):
+        pn = tree.flatten(f5)
+        for key, vc, qualifies in shapes:
+            if ti > 0 and qualifies:
+                qualifies = None   # (a column-with-column compare, a product of columns: the static path may materialise these trees instead)
+            kn = key.flatten(f5)
+            exp = orc.aggregate([cols], ALL_AGGS(vc), group_nodes=kn, pred_nodes=pn)[0]
+            for phase in (0, 1, 2):
+                if phase == 2:
+                    monkeypatch.setenv("NQE_NO_AGG_JIT", "1")
+                ctx.timing_enable(True)
+                ctx.timing_reset()
+                got = ctx.aggregate(t, ALL_AGGS(vc), group_nodes=kn, pred_nodes=pn).to_host()
+                ctx.timing_enable(False)
+                names = ctx.timing_report()
+                assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"phase {phase} tree {tree!r} key {key!r} value {vc}")
+                if phase == 0:
+                    ctx.jit_wait()
+                elif phase == 1 and qualifies:
+                    assert names.get("agg_grouped_jit", (0, 0))[1] == 1 and names.get("agg_merge_partials", (0, 0))[1] == 1 and "agg_grouped_fast" not in names, (sorted(names), repr(key))
+                elif phase == 2 or qualifies is False:
+                    assert "agg_grouped_jit" not in names, (sorted(names), repr(key), phase)
+            monkeypatch.delenv("NQE_NO_AGG_JIT")
