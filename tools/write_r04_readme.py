@@ -47,6 +47,7 @@ is parity-checked against the oracle in the same run.
   / 10⁷ / 10⁸-row-dim / sparse-key rows are the written forms too (round 3 quoted them with shared columns).
 * **Selection + projection in one specialised pass** (`c2_expression_trees`): 0.70 → 0.57–0.59 ms, frac 0.45 → 0.54–0.56, PMC
   1.37× → 1.03×. For plain predicates the static two-kernel form stays (the one-pass kernel measured 0.42 vs 0.36 ms on C2).
+* **Predicate trees in the aggregate through a lean specialised kernel** (`agg_tree_predicate`): 3.71 → 2.70 ms, 0.55 → 0.76.
 * **Two ranks on one GPU** through the host-staged transport run `bench.py`'s multi-rank blocks (`world = 2`); C5's headline is
   the consumer-local join with the gathered form beside it. No scaling claim: the pool has one GPU per box.
 * Tried and left out, with numbers: two scatter workgroups per CU in the partitioned aggregate (kernels 1.06 → 1.12 ms);
@@ -58,7 +59,7 @@ is parity-checked against the oracle in the same run.
 
 More than one physical GPU (C5, the xGMI numbers); the partitioned aggregate (0.16–0.18: PMC traffic is within 4 % of its
 three-pass floor, the two kernels are latency / LDS-bound at 3.4–3.7 TB/s); sparse 4 K–8 K-group band (two key subsets = every row
-issued twice); predicate trees inside the aggregate kernel (0.55, interpreted); joins beyond L2 (line-fetch floor).
+issued twice); trees the aggregate still materialises (column-with-column compares); joins beyond L2 (line-fetch floor).
 """
 open("profiles/r04/README.md", "w").write(text)
 print(len(text))
