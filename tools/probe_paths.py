@@ -22,7 +22,8 @@ SECTION = sys.argv[1] if len(sys.argv) > 1 else "all"
 ctx = capi.Context(0)
 dev = torch.device("cuda", 0)
 f = [F("id"), F("v")]
-aggs = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1), (AggregateFunc.Min, 1), (AggregateFunc.Max, 1)]
+aggs5 = lambda c: [(AggregateFunc.Count, c), (AggregateFunc.Sum, c), (AggregateFunc.Avg, c), (AggregateFunc.Min, c), (AggregateFunc.Max, c)]
+aggs = aggs5(1)
 
 
 def timeit(fn, reps=5, warm=2):
@@ -162,6 +163,49 @@ if SECTION in ("all", "csv"):
     print(f"csv {m} rows, {len(data)/1e6:.1f} MB: infer {t_inf*1e3:.2f} ms (host); read from host bytes {q_host*1e3:.2f} ms ({len(data)/q_host/1e9:.2f} GB/s), "
           f"HBM-resident image {q_dev*1e3:.2f} ms ({len(data)/q_dev/1e9:.2f} GB/s = {m/q_dev:.3e} rows/s); oracle (1 thread) {t_cpu*1e3:.0f} ms ({len(data)/t_cpu/1e9:.3f} GB/s)")
     print("   kernels(ms):", br)
+
+# ---- 2c. Utf8 columns in filter / group key / join key: 10^7 rows, strings of 3-22 bytes
+if SECTION in ("all", "strings"):
+    from oracle import oracle as orc
+    from naive_query_engine_amd.expression import lit_utf8
+    rng = np.random.default_rng(1)
+    m = 10_000_000
+
+    def utf8_column(words, idx):
+        lens = np.array([len(w) for w in words], dtype=np.int32)
+        width = int(lens.max())
+        mat = np.zeros((len(words), width), dtype=np.uint8)
+        for i, w in enumerate(words):
+            mat[i, :len(w)] = np.frombuffer(w, dtype=np.uint8)
+        ln = lens[idx]
+        offs = np.zeros(len(idx) + 1, dtype=np.int32)
+        np.cumsum(ln, out=offs[1:])
+        data = mat[idx][np.arange(width)[None, :] < ln[:, None]]
+        return Column(DType.UTF8, len(idx), offs, None, data)
+
+    few = [b"alice", b"bob", b"carol", b"dave", b"eve", b"mallory, the quoted one"]
+    many = [f"customer-{i:07d}".encode() for i in range(100_000)]
+    name = utf8_column(few, rng.integers(0, len(few), m))
+    cust = utf8_column(many, rng.integers(0, len(many), m))
+    v = Column.from_numpy(rng.random(m) * 100)
+    fs = [type("F", (), {"name": x})() for x in ("name", "cust", "v")]
+    t = ctx.table_from_host([name, cust, v])
+    nbytes = name.data.size + cust.data.size + 8 * m + 8 * m
+    pred = binop(col(0), Operator.Eq, lit_utf8("carol")).flatten(fs)
+    q = timeit(lambda: ctx.selection(t, pred), reps=5, warm=2)
+    print(f"utf8 filter name = 'carol' over {m} rows x (Utf8, Utf8, Float64), all columns compacted: {q*1e3:.2f} ms = {m/q:.3e} rows/s")
+    for label, kc in (("6 distinct strings", 0), ("100000 distinct strings", 1)):
+        q = timeit(lambda: ctx.aggregate(t, aggs5(2), group_nodes=col(kc).flatten(fs)), reps=5, warm=2)
+        print(f"utf8 group key ({label}): count/sum/avg/min/max(v) over {m} rows: {q*1e3:.2f} ms = {m/q:.3e} rows/s")
+    dim = ctx.table_from_host([utf8_column(many, rng.permutation(len(many))), Column.from_numpy(rng.integers(0, 1 << 20, len(many)).astype(np.int64))])
+    q = timeit(lambda: ctx.hash_join(dim, t, 0, 1), reps=3, warm=1)
+    print(f"utf8 join key: dim(100000 strings, attr) join fact({m} rows) on cust: {q*1e3:.2f} ms = {m/q:.3e} probe rows/s (output {m} rows x 5 columns incl. 3 Utf8)")
+    sample = 1_000_000
+    hs = orc.upload([[Column(DType.UTF8, sample, name.values[:sample + 1].copy(), None, name.data[:name.values[sample]].copy()),
+                      Column(DType.UTF8, sample, cust.values[:sample + 1].copy(), None, cust.data[:cust.values[sample]].copy()), Column.from_numpy(v.to_numpy()[:sample])]])
+    t0 = time.perf_counter(); orc.selection(hs, pred, raw=True); t_f = time.perf_counter() - t0
+    t0 = time.perf_counter(); orc.aggregate(hs, aggs5(2), group_nodes=col(1).flatten(fs)); t_a = time.perf_counter() - t0
+    print(f"   oracle (1 thread, first {sample} rows): filter {sample/t_f:.3e} rows/s, utf8-key aggregate {sample/t_a:.3e} rows/s")
 
 # ---- 3. high-cardinality group-by
 for groups in ((1 << 10, 2000, 3000, 1 << 12, 6000, 1 << 14, 1 << 17, 500_000, 1 << 20, 1 << 24) if SECTION in ('all', 'groups') else ()):

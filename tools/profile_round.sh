@@ -41,5 +41,7 @@ python tools/probe_build.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_build.txt
 python tools/probe_paths.py keys 2>&1 | grep -v amdgpu.ids > $OUT/probe_keys.txt
 python tools/probe_paths.py exprs 2>&1 | grep -v amdgpu.ids > $OUT/probe_exprs.txt
 python tools/probe_paths.py trees 2>&1 | grep -v amdgpu.ids > $OUT/probe_trees.txt
+python tools/probe_paths.py csv 2>&1 | grep -v amdgpu.ids > $OUT/probe_csv.txt
+python tools/probe_paths.py strings 2>&1 | grep -v amdgpu.ids > $OUT/probe_strings.txt
 ./tools/micro_bench all > $OUT/micro_bench.txt 2>&1
 ls $OUT
