@@ -27,7 +27,7 @@ CONFIGS = {
     "agg_65536_groups": ({"agg_slab_scatter_kernel": 1, "agg_slab_segments_kernel": 1}, 1.6e9),
     "headline_single_column": ({"agg_grouped_fast_kernel": 1}, 8e9),
     "headline_int64_values": ({"agg_grouped_fast_kernel": 1}, 16e9),
-    "agg_tree_predicate": ({"agg_grouped_fast_kernel": 1}, 16e9),
+    "agg_tree_predicate": ({"nqe_jit_agg": 1, "agg_merge_partials_kernel": 1}, 16e9),
     "agg_three_value_columns": ({"agg_grouped_fast_kernel": 1}, 24e9),
     "agg_4096_groups": ({"agg_grouped_fast_kernel": 1}, 1.6e9),
     "c2_random_ids": ({"keep_from_range_strided_kernel": 1, "compact_strided_kernel": 1}, 2.0e9),

@@ -18,7 +18,7 @@ file by `tools/write_r04_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | `probe_cold.txt` | first execution / first execution over a second table / steady state of 12 query shapes, each in a FRESH process: default (code objects loaded and 24 GB reserved at context creation), without the reservation, with lazy code-object loading (`tools/probe_cold.py`) |
 | `rocprofv3_kernel_stats_<config>.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --workload … --steps 20 --warmup 3` |
 | `pmc_traffic_<config>.json`, `pmc_calibration.json`, `summary.json` | HBM bytes per step from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, calibrated in the same run on `tools/stream_bench` |
-| `probe_*.txt`, `micro_bench.txt` | the diagnostic sweeps of earlier rounds, re-run on this revision |
+| `probe_*.txt`, `micro_bench.txt` | the diagnostic sweeps of earlier rounds, re-run on this revision; new: `probe_strings.txt` (Utf8 filter / group key / join key, 10⁷ rows) and `probe_csv.txt` (CSV parse on the GPU) — SURVEY §8f ranks 3 and 4 |
 
 ## The bench line
 
