@@ -1202,6 +1202,10 @@ bool select_project_fused(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node
             return false; // a bare literal
         J.outs.push_back(o);
     }
+    // the outputs are allocated for the worst case (every row kept): beyond 16 GB of them (NQE_FUSED_SELECT_MAX_GB) the two-kernel
+    // form, which sizes its outputs exactly, is the better citizen
+    static const double max_gb = getenv("NQE_FUSED_SELECT_MAX_GB") ? atof(getenv("NQE_FUSED_SELECT_MAX_GB")) : 16.0;
+    if (double(n) * 8.0 * num_exprs > max_gb * double(1ull << 30)) return false;
     JitEntry *kernel = jit_select_project_entry(ctx, S);
     if (!kernel) return false; // being compiled (or no hipRTC): nothing allocated yet
     // worst-case outputs (every row kept), the chunk status words, ticket and total
