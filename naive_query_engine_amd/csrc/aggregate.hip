@@ -1098,6 +1098,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     int conj_col[CONJ_MAX] = {-1, -1, -1, -1};
     TreePred tree;   // pred_mode 4
     BufRef tree_buf; // its program on the device
+    bool jit_whole = false, jit_redo = false; // the predicate is evaluated by the run-time specialised streaming kernel (see below)
+    uint64_t jit_modulus = 0;
     auto materialize_pred = [&]() { // the predicate tree as a Boolean column (expression machine), tested bit by bit
         pred_col = evaluate_expr(ctx, in, pred, pred_nodes);
         a.pred_mode = 2;
@@ -1117,7 +1119,27 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         } else if (grouped && !pinfo.may_fault && match_tree_pred(in, pred, pred_nodes, &tree)) {
             a.pred_mode = 4; // likewise
         } else {
-            materialize_pred();
+            // A tree the static kernels can only take as a materialised Boolean column (column-with-column compares, products of
+            // columns, ...): one more pass over its columns plus the bitmap.  When the query has the shape of the lean specialised
+            // streaming kernel (expr_jit.hpp: nqe_jit_agg — key `col % m` with 512-4096 table slots, value columns without NULLs)
+            // and that kernel is compiled, the predicate is evaluated there, in the aggregation pass: the rest of this function then
+            // sees a query without a predicate, and every pass is launched through the specialised kernel (jit_whole).
+            bool cand = grouped && !utf8_key && kinfo.simple && !pinfo.may_fault && kinfo.s.nops == 1 && kinfo.s.op[0] == NQE_OP_MODULOS && !kinfo.s.lit_left[0] &&
+                        (kinfo.s.op_dtype[0] == NQE_INT64 || kinfo.s.op_dtype[0] == NQE_UINT64) && !in->cols[size_t(kinfo.s.col)].validity && !plan.val_cols.empty() &&
+                        plan.val_cols.size() <= 2 && !getenv("NQE_NO_AGG_JIT");
+            for (int c : plan.val_cols) cand = cand && is_word_type(in->cols[size_t(c)].dtype) && !in->cols[size_t(c)].validity;
+            if (cand) {
+                const bool sgn = kinfo.s.op_dtype[0] == NQE_INT64;
+                const uint64_t lit = kinfo.s.lit[0];
+                jit_modulus = sgn ? uint64_t(int64_t(lit) < 0 ? 0ull - lit : lit) : lit;
+                for (int c : plan.val_cols) {
+                    uint32_t sp;
+                    int64_t bi;
+                    cand = cand && aggregate_tree_specialised(ctx, in, pred, pred_nodes, kinfo.s.col, jit_modulus, sgn, c, 1, nullptr, &sp, &bi, true);
+                }
+            }
+            if (cand) jit_whole = true; // (a.pred_mode stays 0)
+            else materialize_pred();
         }
     }
     DevColumn key_colbuf;
@@ -1338,7 +1360,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         bool flagless = !grouped && !pred_may_fault;
         // nullable sources: one value column per pass — the two-column VNULL variants of the fast kernel spill 60-135 VGPRs
         // (3.1-3.4 TB/s); two passes of the one-column variant (5.3 TB/s each over key + one value column) are faster
-        const int nv_step = (any_val_nullable || a.key_src.valid || (a.pred_mode != 0 && a.pred_src.valid)) ? 1 : NV;
+        const int nv_step = (jit_whole || any_val_nullable || a.key_src.valid || (a.pred_mode != 0 && a.pred_src.valid)) ? 1 : NV;
         bool slab_oom = false; // the slab allocation failed: redo the attempt in the exact form
         // three value columns, none asking for min / max, over a key and predicate the streaming kernel computes itself (C1's
         // `count(id), sum(age), avg(score) … group by id % 3`): ONE pass of the three-column instance (2048-slot workgroup table without min / max arrays)
@@ -1354,6 +1376,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                                  is_word_type(in->cols[size_t(key_col)].dtype);
         int pass_nv = 0;
         for (int v0 = 0; v0 < std::max(V, 1); v0 += pass_nv) {
+            bool jit_launched = false;
             pass_nv = three ? NVMAX : (first_alone && v0 == 0) ? 1 : nv_step;
             a.nv = std::min(pass_nv, V - v0);
             if (a.nv < 0) a.nv = 0;
@@ -1717,14 +1740,18 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         BufRef jit_partials;
                         uint32_t jit_span = 0;
                         int64_t jit_bias = 0;
-                        if (fp >= 5 && has_pred && (fast_key == 1 || fast_key == 2) && ka.direct == 1 && ka.direct_rep == 0 && a.nv == 1 && !vnull && subsets_log2 == 0 &&
+                        if ((fp >= 5 || jit_whole) && has_pred && (fast_key == 1 || fast_key == 2) && ka.direct == 1 && ka.direct_rep == 0 && a.nv == 1 && !vnull && subsets_log2 == 0 &&
                             key_col >= 0 && a.val[0].values &&
                             aggregate_tree_specialised(ctx, in, pred, pred_nodes, key_col, a.key.aux[0].abs_lit, a.key.op_dtype[0] == NQE_INT64, plan.val_cols[size_t(v0)], fgrid,
                                                        &jit_partials, &jit_span, &jit_bias)) {
                             const size_t cells = size_t(fgrid) * jit_span;
                             const double *ps = (const double *)jit_partials->ptr;
+                            jit_launched = true;
                             launch(ctx, "agg_merge_partials", agg_merge_partials_kernel, dim3((jit_span + 255) / 256), dim3(256), 0, ps, ps + cells, ps + 2 * cells,
                                    reinterpret_cast<const uint32_t *>(ps + 3 * cells), fgrid, jit_span, jit_bias, tb.g, a.v0, ctx->d_flags);
+                        } else if (jit_whole) {
+                            jit_redo = true; // (cannot happen once the dry run said yes — but a static kernel must never run without the predicate)
+                            break;
                         } else {
                         FastKernel fk = pick_fast_kernel(fp, fast_key, a.nv, vf64, vnull, subsets_log2 != 0, nomm, share);
                         if (!fk) fail(NQE_ERR_NOT_SUPPORTED, "internal: no such variant of the streaming aggregate kernel");
@@ -1771,6 +1798,16 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 launch(ctx, "agg_ungrouped_fold", agg_ungrouped_fold_kernel, dim3(1), dim3(64), 0,
                        (const Partial *)partials->ptr, grid, a.nv, v0, tb.g);
             }
+            if (jit_whole && !jit_launched) { // a pass went through a static kernel, i.e. WITHOUT the predicate: this attempt's table is discarded
+                jit_redo = true;
+                break;
+            }
+        }
+        if (jit_redo) { // the specialised kernel was not to be had after all: the predicate as a Boolean column, the attempt again
+            jit_redo = jit_whole = false;
+            materialize_pred();
+            flags_reset(ctx);
+            continue;
         }
         if (slab_oom || three_redo) continue;
         Collected pre;

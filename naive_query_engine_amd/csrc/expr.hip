@@ -1235,7 +1235,7 @@ bool select_project_fused(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node
 // workgroups' tables are in *partials ([grid][span] sums | mins | maxs as doubles, then counts as uint32 with the NaN mark in the
 // top bit) for aggregate.hip's merge kernel; false: the shape does not qualify or the kernel is still being compiled.
 bool aggregate_tree_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, int key_col, uint64_t modulus, bool key_signed,
-                                int val_col, int grid, BufRef *partials, uint32_t *span_out, int64_t *bias_out) {
+                                int val_col, int grid, BufRef *partials, uint32_t *span_out, int64_t *bias_out, bool dry_run) {
     const char *mr = getenv("NQE_JIT_MIN_ROWS");
     const int64_t min_rows = mr ? atoll(mr) : (int64_t(1) << 22);
     const int64_t n = in->rows;
@@ -1280,6 +1280,7 @@ bool aggregate_tree_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_exp
     }
     JitEntry *kernel = jit_aggregate_entry(ctx, G);
     if (!kernel) return false;
+    if (dry_run) return true; // the caller only asks whether this query can take the kernel NOW (its compilation has been started otherwise)
     const size_t cells = size_t(grid) * G.span;
     *partials = dev_alloc(ctx, cells * 28 + 64);
     double *ps = (double *)(*partials)->ptr;

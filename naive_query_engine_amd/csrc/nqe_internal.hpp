@@ -405,7 +405,7 @@ bool select_project_fused(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node
 // the streaming aggregate of `val_col` grouped by `key_col % modulus` under a predicate tree, through the lean run-time specialised kernel
 // (expr.hip); on success *partials holds every workgroup's table for aggregate.hip's merge kernel
 bool aggregate_tree_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, int key_col, uint64_t modulus, bool key_signed,
-                                int val_col, int grid, BufRef *partials, uint32_t *span_out, int64_t *bias_out);
+                                int val_col, int grid, BufRef *partials, uint32_t *span_out, int64_t *bias_out, bool dry_run = false);
 // evaluates `e` over `in` and compacts the result in the same pass
 DevColumn compact_simple_expr(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &e, const KeepMask &km);
 

@@ -2333,8 +2333,8 @@ def test_aggregate_under_a_predicate_tree_through_the_specialised_streaming_kern
     for ti, tree in enumerate(trees):
         pn = tree.flatten(f5)
         for key, vc, qualifies in shapes:
-            if ti > 0 and qualifies:
-                qualifies = None   # (a column-with-column compare, a product of columns: the static path may materialise these trees instead)
+            # (trees 1 and 2 — a column-with-column compare, a product of columns — are ones the static kernels can only take as a
+            # materialised Boolean column: with the specialised kernel compiled they are evaluated in the aggregation pass instead)
             kn = key.flatten(f5)
             exp = orc.aggregate([cols], ALL_AGGS(vc), group_nodes=kn, pred_nodes=pn)[0]
             for phase in (0, 1, 2):
@@ -2349,7 +2349,24 @@ def test_aggregate_under_a_predicate_tree_through_the_specialised_streaming_kern
                 if phase == 0:
                     ctx.jit_wait()
                 elif phase == 1 and qualifies:
-                    assert names.get("agg_grouped_jit", (0, 0))[1] == 1 and names.get("agg_merge_partials", (0, 0))[1] == 1 and "agg_grouped_fast" not in names, (sorted(names), repr(key))
+                    assert names.get("agg_grouped_jit", (0, 0))[1] == 1 and names.get("agg_merge_partials", (0, 0))[1] == 1 and "agg_grouped_fast" not in names and \
+                        not any(x.startswith(("expr_jit", "expr_tree", "binary")) for x in names), (sorted(names), repr(key), ti)
                 elif phase == 2 or qualifies is False:
                     assert "agg_grouped_jit" not in names, (sorted(names), repr(key), phase)
             monkeypatch.delenv("NQE_NO_AGG_JIT")
+    # two value columns under a tree the static path would materialise: one specialised launch per column, no Boolean column
+    tree = trees[1]
+    pn, kn = tree.flatten(f5), X(ID, O.Modulos, lit_i64(1024)).flatten(f5)
+    aggs2 = ALL_AGGS(2) + [(AggregateFunc.Sum, 3), (AggregateFunc.Max, 3), (AggregateFunc.Count, 3)]
+    exp = orc.aggregate([cols], aggs2, group_nodes=kn, pred_nodes=pn)[0]
+    for phase in (0, 1):
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got = ctx.aggregate(t, aggs2, group_nodes=kn, pred_nodes=pn).to_host()
+        ctx.timing_enable(False)
+        names = ctx.timing_report()
+        assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0, 7], what=f"two value columns, phase {phase}")
+        if phase == 0:
+            ctx.jit_wait()
+        else:
+            assert names.get("agg_grouped_jit", (0, 0))[1] == 2 and not any(x.startswith(("expr_jit", "expr_tree", "agg_grouped_fast")) for x in names), sorted(names)

@@ -59,7 +59,7 @@ is parity-checked against the oracle in the same run.
 
 More than one physical GPU (C5, the xGMI numbers); the partitioned aggregate (0.16–0.18: PMC traffic is within 4 % of its
 three-pass floor, the two kernels are latency / LDS-bound at 3.4–3.7 TB/s); sparse 4 K–8 K-group band (two key subsets = every row
-issued twice); trees the aggregate still materialises (column-with-column compares); joins beyond L2 (line-fetch floor).
+issued twice); predicate trees over keys other than `col % m` (interpreted or materialised); joins beyond L2 (line-fetch floor).
 """
 open("profiles/r04/README.md", "w").write(text)
 print(len(text))
