@@ -307,18 +307,24 @@ __global__ void utf8_take_lengths_kernel(const int32_t *src_off, const uint8_t *
     if (blockIdx.x == 0 && threadIdx.x == 0 && (m & 63) == 0) lens[m] = 0;
 }
 
-__global__ void utf8_take_copy_kernel(const int32_t *src_off, const uint8_t *src_data, const uint8_t *src_valid, int64_t src_len,
-                                      const int64_t *idx, int64_t m, const uint32_t *out_off, uint8_t *out_data) {
-    // one wave per output string: lanes stride over its bytes (coalesced for long strings, cheap for short ones)
-    const int waves_per_block = blockDim.x / 64;
-    for (int64_t j = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; j < m; j += int64_t(gridDim.x) * waves_per_block) {
-        int64_t i = idx[j];
+// 2^LG lanes per output string, 64 >> LG strings per wave and step: a whole wave per string left 50-60 of its lanes idle on the 5-20
+// byte strings of names and keys (10^7 strings per column took 1.6 ms); the host picks LG from the mean output length.  The lanes of
+// a group read the same index / offsets (one broadcast load) and stride over the string's bytes.
+template <int LG>
+__global__ void __launch_bounds__(256) utf8_take_copy_kernel(const int32_t *src_off, const uint8_t *src_data, const uint8_t *src_valid, int64_t src_len,
+                                                             const int64_t *idx, int64_t m, const uint32_t *out_off, uint8_t *out_data) {
+    constexpr int G = 1 << LG, PER_WAVE = 64 >> LG;
+    const int64_t waves = (int64_t(gridDim.x) * blockDim.x) >> 6, wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t sub = uint32_t(lane_id()) & uint32_t(G - 1), grp = uint32_t(lane_id()) >> LG;
+    for (int64_t j0 = wave * PER_WAVE; j0 < m; j0 += waves * PER_WAVE) {
+        const int64_t j = j0 + grp;
+        if (j >= m) continue;
+        const int64_t i = idx[j];
         if (i < 0 || i >= src_len) continue;
         if (src_valid && !get_bit(src_valid, i)) continue;
-        int32_t so = src_off[i];
-        uint32_t len = out_off[j + 1] - out_off[j];
-        uint32_t d = out_off[j];
-        for (uint32_t b = lane_id(); b < len; b += 64) out_data[d + b] = src_data[so + b];
+        const int32_t so = src_off[i];
+        const uint32_t d = out_off[j], len = out_off[j + 1] - d;
+        for (uint32_t b = sub; b < len; b += G) out_data[d + b] = src_data[so + b];
     }
 }
 
@@ -389,10 +395,15 @@ DevColumn take_utf8(nqe_ctx *ctx, const DevColumn &src, const int64_t *idx, int6
     if (total >= 0x80000000u) fail(NQE_ERR_ARROW, "Utf8 take: offsets overflow int32");
     out.data_length = total;
     out.data = dev_alloc(ctx, size_t(total) + 8);
-    if (m && total)
-        launch(ctx, "utf8_take_copy", utf8_take_copy_kernel, dim3(stream_grid(ctx, m, 4)), dim3(256), 0, (const int32_t *)src.values->ptr,
+    if (m && total) {
+        const uint64_t mean = uint64_t(total) / uint64_t(m);
+        const int lg = mean <= 4 ? 2 : mean <= 12 ? 3 : mean <= 24 ? 4 : mean <= 48 ? 5 : 6; // lanes per string
+        auto k = lg == 2 ? utf8_take_copy_kernel<2> : lg == 3 ? utf8_take_copy_kernel<3> : lg == 4 ? utf8_take_copy_kernel<4> : lg == 5 ? utf8_take_copy_kernel<5>
+                                                                                                                                     : utf8_take_copy_kernel<6>;
+        launch(ctx, "utf8_take_copy", k, dim3(stream_grid(ctx, (m + (64 >> lg) - 1) / (64 >> lg), 4)), dim3(256), 0, (const int32_t *)src.values->ptr,
                src.data ? (const uint8_t *)src.data->ptr : nullptr, src.valid(), src.length, idx, m, (const uint32_t *)out.values->ptr,
                (uint8_t *)out.data->ptr);
+    }
     return out;
 }
 
