@@ -324,7 +324,12 @@ __global__ void __launch_bounds__(256) utf8_take_copy_kernel(const int32_t *src_
         if (src_valid && !get_bit(src_valid, i)) continue;
         const int32_t so = src_off[i];
         const uint32_t d = out_off[j], len = out_off[j + 1] - d;
-        for (uint32_t b = sub; b < len; b += G) out_data[d + b] = src_data[so + b];
+        // whole 8-byte words first (unaligned 8-byte loads and stores: fine for global memory on gfx9 and later), then the tail's bytes
+        typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+        const uint32_t nw = len >> 3;
+        for (uint32_t w = sub; w < nw; w += G)
+            *reinterpret_cast<u64_unaligned *>(out_data + d + 8 * w) = *reinterpret_cast<const u64_unaligned *>(src_data + so + 8 * w);
+        for (uint32_t b = (nw << 3) + sub; b < len; b += G) out_data[d + b] = src_data[so + b];
     }
 }
 
@@ -397,7 +402,7 @@ DevColumn take_utf8(nqe_ctx *ctx, const DevColumn &src, const int64_t *idx, int6
     out.data = dev_alloc(ctx, size_t(total) + 8);
     if (m && total) {
         const uint64_t mean = uint64_t(total) / uint64_t(m);
-        const int lg = mean <= 4 ? 2 : mean <= 12 ? 3 : mean <= 24 ? 4 : mean <= 48 ? 5 : 6; // lanes per string
+        const int lg = mean <= 32 ? 2 : mean <= 96 ? 3 : mean <= 256 ? 4 : mean <= 1024 ? 5 : 6; // lanes per string (a lane moves 8 bytes per step)
         auto k = lg == 2 ? utf8_take_copy_kernel<2> : lg == 3 ? utf8_take_copy_kernel<3> : lg == 4 ? utf8_take_copy_kernel<4> : lg == 5 ? utf8_take_copy_kernel<5>
                                                                                                                                      : utf8_take_copy_kernel<6>;
         launch(ctx, "utf8_take_copy", k, dim3(stream_grid(ctx, (m + (64 >> lg) - 1) / (64 >> lg), 4)), dim3(256), 0, (const int32_t *)src.values->ptr,
