@@ -1088,6 +1088,9 @@ struct JoinCols {
 // output rows of every column (coalesced), probe-row-major with ascending build row inside a probe row —
 // exactly the order of the reference's outer_pos/inner_pos (hash_join.rs:86-101).
 constexpr int PW_TILE = 1024; // probe rows per tile (= JT_ROWS / 4); tile_offsets are per JT_ROWS, so 4 sub-tiles share one base
+// PLAIN: every source column is a plain 8-byte column without validity written as words (C4 with duplicate build keys: the whole
+// output): no dtype dispatch, validity test or byte-array branches in the per-column loop
+template <bool PLAIN>
 __global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *pmeta, int64_t n, const uint64_t *tile_offsets,
                                                                const uint32_t *perm, int direct, JoinCols jc) {
     __shared__ uint32_t off[PW_TILE + 1];
@@ -1151,6 +1154,18 @@ __global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *p
                 for (int c = 0; c < jc.n; ++c) {
                     const bool left = c < jc.n_left;
                     const void *src = jc.src[c];
+                    if (PLAIN) {
+                        const uint64_t *__restrict__ sw = static_cast<const uint64_t *>(src);
+                        uint64_t *__restrict__ dw = jc.dst_words[c];
+                        const bool by_pos = jc.by_pos[c] != 0;
+                        uint64_t v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = sw[left ? int64_t(by_pos ? bpos[q] : brow[q]) : (live[q] ? row0 + prow[q] : int64_t(0))]; // (dead lanes read row 0)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (live[q]) __builtin_nontemporal_store(v[q], &dw[out_base + j0 + q * JT_BLOCK + threadIdx.x]);
+                        continue;
+                    }
                     const uint8_t *sv = jc.src_valid[c];
                     const int dt = jc.dtype[c];
 #pragma unroll
@@ -1934,8 +1949,11 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         }
         dsts[k] = std::move(dst);
     }
+    bool all_plain = true;
+    for (size_t k = 0; k < srcs.size(); ++k)
+        all_plain = all_plain && is_word_type(srcs[k]->dtype) && !srcs[k]->validity && jc.dst_words[k] && !jc.dst_bool_bytes[k] && !jc.dst_valid_bytes[k] && srcs[k]->length > 0;
     if (n && M)
-        launch(ctx, "join_probe_write", probe_write_kernel, dim3(grid), dim3(JT_BLOCK), 0, (const uint64_t *)pmeta->ptr, n,
+        launch(ctx, "join_probe_write", all_plain ? probe_write_kernel<true> : probe_write_kernel<false>, dim3(grid), dim3(JT_BLOCK), 0, (const uint64_t *)pmeta->ptr, n,
                (const uint64_t *)offs->ptr, (const uint32_t *)jt->perm->ptr, jt->direct ? 1 : 0, jc);
     for (size_t k = 0; k < srcs.size(); ++k) {
         if (bool_bytes[k]) pack_bytes_to_bits(ctx, (const uint8_t *)bool_bytes[k]->ptr, M, (uint64_t *)dsts[k].values->ptr);
