@@ -40,6 +40,7 @@ def timeit(fn, reps=5, warm=2):
     return (time.perf_counter() - t0) / reps
 
 
+key = binop(col(0), Operator.Modulos, lit_i64(1024)).flatten(f)   # (used by several sections below)
 # ---- 1. PCIe-inclusive: host numpy columns → nqe_table_create → aggregate (only when asked for: SECTION all / pcie)
 if SECTION in ('all', 'pcie'):
     n = 100_000_000
@@ -60,6 +61,7 @@ if SECTION in ('all', 'pcie'):
 
 # ---- 2. nullable columns (1% nulls) → general kernel
 n = 200_000_000 if SECTION in ('all', 'paths', 'keys', 'exprs', 'trees') else 100_000_000
+pred = binop(col(0), Operator.Lt, lit_i64(n // 2)).flatten(f)   # `id < n / 2` over THIS table (rounds 1-3 left it at `id < 500`: their key / path sweeps had next to no row pass)
 idt = torch.empty(n, dtype=torch.int64, device=dev); ctx.synchronize()
 ctx.synth_fill(0, 0, 0, n, 1, 0, idt.data_ptr())
 vt = torch.empty(n, dtype=torch.float64, device=dev)
