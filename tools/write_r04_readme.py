@@ -47,7 +47,8 @@ is parity-checked against the oracle in the same run.
   / 10⁷ / 10⁸-row-dim / sparse-key rows are the written forms too (round 3 quoted them with shared columns).
 * **Selection + projection in one specialised pass** (`c2_expression_trees`): 0.70 → 0.57–0.59 ms, frac 0.45 → 0.54–0.56, PMC
   1.37× → 1.03×. For plain predicates the static two-kernel form stays (the one-pass kernel measured 0.42 vs 0.36 ms on C2).
-* **Predicate trees in the aggregate through a lean specialised kernel** (`agg_tree_predicate`): 3.71 → 2.70 ms, 0.55 → 0.76.
+* **Predicate trees in the aggregate through a lean specialised kernel** (`agg_tree_predicate`): 3.71 → 2.6 ms, 0.55 → 0.78–0.79; trees the static kernels can only
+  materialise (column-with-column compares) take the same kernel once it is compiled. Duplicate-key join: a plain-words write pass, 2.40 → 2.03 ms.
 * **Utf8 and CSV measured** (`probe_strings.txt`, `probe_csv.txt`; SURVEY §8f ranks 3-4): the string take with 4-64 lanes per
   string and 8-byte moves, 8 bytes per step in the dictionary hash / compare: Utf8-key join of 10⁷ rows 6.96 → 1.88 ms, Utf8 filter
   0.91 → 0.42 ms, 10⁵-string group-by 1.81 → 1.16 ms; CSV parse of a 56 MB image 1.28 ms (44 GB/s HBM-resident, 24 GB/s from host bytes).
