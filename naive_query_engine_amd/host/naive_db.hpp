@@ -109,6 +109,8 @@ class Context {
     ~Context() { nqe_ctx_destroy(ctx_); }
     Context(const Context &) = delete;
     nqe_ctx *raw() const { return ctx_; }
+    // nqe_ctx_reserve: one block from the driver now, later outputs and scratch sub-allocated from it (a first query pays no hipMalloc)
+    void reserve(size_t bytes) const { check(nqe_ctx_reserve(ctx_, bytes)); }
     void check(nqe_status st) const {
         if (st != NQE_OK) throw ErrorCode(int(st), nqe_last_error(ctx_));
     }
