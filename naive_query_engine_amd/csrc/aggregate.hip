@@ -1109,7 +1109,6 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     TreePred tree;   // pred_mode 4
     BufRef tree_buf; // its program on the device
     bool jit_whole = false, jit_redo = false; // the predicate is evaluated by the run-time specialised streaming kernel (see below)
-    uint64_t jit_modulus = 0;
     auto materialize_pred = [&]() { // the predicate tree as a Boolean column (expression machine), tested bit by bit
         pred_col = evaluate_expr(ctx, in, pred, pred_nodes);
         a.pred_mode = 2;
@@ -1134,18 +1133,16 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             // streaming kernel (expr_jit.hpp: nqe_jit_agg — key `col % m` with 512-4096 table slots, value columns without NULLs)
             // and that kernel is compiled, the predicate is evaluated there, in the aggregation pass: the rest of this function then
             // sees a query without a predicate, and every pass is launched through the specialised kernel (jit_whole).
-            bool cand = grouped && !utf8_key && kinfo.simple && !pinfo.may_fault && kinfo.s.nops == 1 && kinfo.s.op[0] == NQE_OP_MODULOS && !kinfo.s.lit_left[0] &&
-                        (kinfo.s.op_dtype[0] == NQE_INT64 || kinfo.s.op_dtype[0] == NQE_UINT64) && !in->cols[size_t(kinfo.s.col)].validity && !plan.val_cols.empty() &&
+            const int klast = kinfo.s.nops - 1;
+            bool cand = grouped && !utf8_key && kinfo.simple && !kinfo.may_fault && !pinfo.may_fault && klast >= 0 && kinfo.s.op[klast] == NQE_OP_MODULOS && !kinfo.s.lit_left[klast] &&
+                        (kinfo.s.op_dtype[klast] == NQE_INT64 || kinfo.s.op_dtype[klast] == NQE_UINT64) && !in->cols[size_t(kinfo.s.col)].validity && !plan.val_cols.empty() &&
                         plan.val_cols.size() <= 2 && !getenv("NQE_NO_AGG_JIT");
             for (int c : plan.val_cols) cand = cand && is_word_type(in->cols[size_t(c)].dtype) && !in->cols[size_t(c)].validity;
             if (cand) {
-                const bool sgn = kinfo.s.op_dtype[0] == NQE_INT64;
-                const uint64_t lit = kinfo.s.lit[0];
-                jit_modulus = sgn ? uint64_t(int64_t(lit) < 0 ? 0ull - lit : lit) : lit;
                 for (int c : plan.val_cols) {
                     uint32_t sp;
                     int64_t bi;
-                    cand = cand && aggregate_tree_specialised(ctx, in, pred, pred_nodes, kinfo.s.col, jit_modulus, sgn, c, 1, nullptr, &sp, &bi, true);
+                    cand = cand && aggregate_tree_specialised(ctx, in, pred, pred_nodes, group, group_nodes, c, 1, nullptr, &sp, &bi, true);
                 }
             }
             if (cand) jit_whole = true; // (a.pred_mode stays 0)
@@ -1747,12 +1744,19 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         for (int j = 0; j < a.nv; ++j) nomm = nomm && !a.need_minmax[j];
                         // a predicate tree the static kernel would interpret (PRED 5 / 6) over `col % m` keys and one value column: the lean
                         // run-time specialised kernel, once it has been compiled — its workgroup tables are folded into the group table here
+                        // interpreted chain predicates (PRED 3: `id % 10 < 5`, `id * 3 >= K`) take the specialised kernel too: 0.70 -> 0.555 ms per 2x10^8 rows
+                        const bool jit_chains = getenv("NQE_NO_AGG_JIT_CHAINS") == nullptr;
                         BufRef jit_partials;
                         uint32_t jit_span = 0;
                         int64_t jit_bias = 0;
-                        if ((fp >= 5 || jit_whole) && has_pred && (fast_key == 1 || fast_key == 2) && ka.direct == 1 && ka.direct_rep == 0 && a.nv == 1 && !vnull && subsets_log2 == 0 &&
+                        // … and so do interpreted chain KEYS (`(id + 1) % 1000`, KEY 3) whatever the predicate: the kernel bakes the whole key program
+                        // NQE_AGG_JIT_ALL: 1 (default) = also `col % m` by magic multiply (KEY 2: the literal modulus baked in — `id % 1000` 0.584 -> 0.548 ms, `id % 2000`
+                        // 0.643 -> 0.560 per 2x10^8 rows), 2 = every `% m` key (A/B: the headline's power-of-two key 2.53 vs 2.47 ms — within noise, it stays static), 0 = neither
+                        static const int jit_all = getenv("NQE_AGG_JIT_ALL") ? atoi(getenv("NQE_AGG_JIT_ALL")) : 1;
+                        const bool jit_try = jit_whole || (has_pred && (fp >= 5 || (fp == 3 && jit_chains))) || (fast_key == 3 && jit_chains) || (jit_all >= 1 && fast_key == 2) || jit_all >= 2;
+                        if (jit_try && (fast_key == 1 || fast_key == 2 || fast_key == 3) && ka.direct == 1 && ka.direct_rep == 0 && a.nv == 1 && !vnull && subsets_log2 == 0 &&
                             key_col >= 0 && a.val[0].values &&
-                            aggregate_tree_specialised(ctx, in, pred, pred_nodes, key_col, a.key.aux[0].abs_lit, a.key.op_dtype[0] == NQE_INT64, plan.val_cols[size_t(v0)], fgrid,
+                            aggregate_tree_specialised(ctx, in, has_pred ? pred : nullptr, pred_nodes, group, group_nodes, plan.val_cols[size_t(v0)], fgrid,
                                                        &jit_partials, &jit_span, &jit_bias)) {
                             const size_t cells = size_t(fgrid) * jit_span;
                             const double *ps = (const double *)jit_partials->ptr;

@@ -1234,20 +1234,18 @@ bool select_project_fused(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node
 // The streaming aggregate under a predicate tree through the lean specialised kernel (expr_jit.hpp: nqe_jit_agg).  On success the
 // workgroups' tables are in *partials ([grid][span] sums | mins | maxs as doubles, then counts as uint32 with the NaN mark in the
 // top bit) for aggregate.hip's merge kernel; false: the shape does not qualify or the kernel is still being compiled.
-bool aggregate_tree_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, int key_col, uint64_t modulus, bool key_signed,
+bool aggregate_tree_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, const nqe_expr_node *group, int group_nodes,
                                 int val_col, int grid, BufRef *partials, uint32_t *span_out, int64_t *bias_out, bool dry_run) {
     const char *mr = getenv("NQE_JIT_MIN_ROWS");
     const int64_t min_rows = mr ? atoll(mr) : (int64_t(1) << 22);
     const int64_t n = in->rows;
-    if (getenv("NQE_NO_JIT") || getenv("NQE_NO_AGG_JIT") || n < min_rows || !pred || pred_nodes < 1 || key_col < 0 || val_col < 0 || modulus < 2) return false;
-    const uint64_t span64 = key_signed ? 2 * modulus - 1 : modulus;
-    if (span64 < 512 || span64 > 4096) return false; // (fewer slots: every lane of a wave updates the same few words — the static kernel replicates such tables)
-    const DevColumn &kc = in->cols[size_t(key_col)], &vc = in->cols[size_t(val_col)];
-    if (kc.validity || vc.validity || !(kc.dtype == NQE_INT64 || kc.dtype == NQE_UINT64) || !is_word_type(vc.dtype) || kc.length < n || vc.length < n) return false;
+    if (getenv("NQE_NO_JIT") || getenv("NQE_NO_AGG_JIT") || n < min_rows || !group || group_nodes < 1 || val_col < 0) return false;
+    const DevColumn &vc = in->cols[size_t(val_col)];
+    if (vc.validity || !is_word_type(vc.dtype) || vc.length < n) return false;
     JitAgg G;
     std::memset(G.col, 0, sizeof(G.col));
-    G.col[0] = kc.values->ptr;
-    G.ncols = 1;
+    std::memset(&G.pred, 0, sizeof(G.pred));
+    G.ncols = 0;
     auto slot_of = [&](const void *values, const uint8_t *valid, int dtype) {
         if (valid || !is_word_type(dtype)) return -1;
         for (int k = 0; k < G.ncols; ++k)
@@ -1256,27 +1254,48 @@ bool aggregate_tree_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_exp
         G.col[G.ncols] = values;
         return G.ncols++;
     };
-    G.val_slot = slot_of(vc.values->ptr, nullptr, vc.dtype);
-    if (G.val_slot < 0) return false;
-    G.val_dtype = vc.dtype;
-    G.key_signed = key_signed;
-    G.modulus = modulus;
-    G.span = uint32_t(span64);
-    {
-        int root;
-        std::vector<Node> t = parse(in, pred, pred_nodes, &root);
-        bool nv = false;
-        if (t[size_t(root)].kind != NQE_EXPR_BINARY || t[size_t(root)].out_dtype != NQE_BOOLEAN || !build_program(in, t, root, &G.pred, &nv) || nv) return false;
-        for (int i = 0; i < G.pred.n; ++i) {
-            ExInstr &I = G.pred.ins[i];
+    auto renumber = [&](ExProgram &P) {
+        for (int i = 0; i < P.n; ++i) {
+            ExInstr &I = P.ins[i];
             for (int32_t *src : {&I.a_src, &I.b_src}) {
                 if (*src == EX_LIT_NULL) return false;
                 if (*src < EX_COL) continue;
-                const int k = *src - EX_COL, u = slot_of(G.pred.col_values[k], G.pred.col_valid[k], G.pred.col_dtype[k]);
+                const int k = *src - EX_COL, u = slot_of(P.col_values[k], P.col_valid[k], P.col_dtype[k]);
                 if (u < 0) return false;
                 *src = EX_COL + u;
             }
         }
+        return true;
+    };
+    { // the key: `… % m`, m a literal other than 0, -1, +-1; integer all the way (the static path has vetted it as fault-free)
+        int root;
+        std::vector<Node> t = parse(in, group, group_nodes, &root);
+        bool nv = false;
+        if (t[size_t(root)].kind != NQE_EXPR_BINARY || !build_program(in, t, root, &G.key, &nv) || nv || G.key.n < 1) return false;
+        const ExInstr &last = G.key.ins[G.key.n - 1];
+        if (last.op != NQE_OP_MODULOS || last.b_src != EX_LIT || !(last.dt == NQE_INT64 || last.dt == NQE_UINT64)) return false;
+        for (int i = 0; i < G.key.n; ++i) {
+            const ExInstr &I = G.key.ins[i];
+            if (!(I.dt == NQE_INT64 || I.dt == NQE_UINT64) || I.op < NQE_OP_PLUS || I.op > NQE_OP_MODULOS) return false;
+            if ((I.op == NQE_OP_DIVIDE || I.op == NQE_OP_MODULOS) && (I.b_src != EX_LIT || I.lit_b == 0 || I.lit_b == ~0ull)) return false; // could fault
+        }
+        G.key_signed = last.dt == NQE_INT64;
+        G.modulus = G.key_signed ? uint64_t(int64_t(last.lit_b) < 0 ? 0ull - last.lit_b : last.lit_b) : last.lit_b;
+        if (G.modulus < 2) return false;
+        const uint64_t span64 = G.key_signed ? 2 * G.modulus - 1 : G.modulus;
+        if (span64 < 512 || span64 > 4096) return false; // (fewer slots: every lane of a wave updates the same few words — the static kernel replicates such tables)
+        G.span = uint32_t(span64);
+        if (!renumber(G.key)) return false;
+    }
+    G.val_slot = slot_of(vc.values->ptr, nullptr, vc.dtype);
+    if (G.val_slot < 0) return false;
+    G.val_dtype = vc.dtype;
+    if (pred && pred_nodes > 0) {
+        int root;
+        std::vector<Node> t = parse(in, pred, pred_nodes, &root);
+        bool nv = false;
+        if (t[size_t(root)].kind != NQE_EXPR_BINARY || t[size_t(root)].out_dtype != NQE_BOOLEAN || !build_program(in, t, root, &G.pred, &nv) || nv) return false;
+        if (!renumber(G.pred)) return false;
     }
     JitEntry *kernel = jit_aggregate_entry(ctx, G);
     if (!kernel) return false;
@@ -1286,7 +1305,7 @@ bool aggregate_tree_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_exp
     double *ps = (double *)(*partials)->ptr;
     jit_aggregate_launch(ctx, kernel, G, n, unsigned(grid), ps, ps + cells, ps + 2 * cells, reinterpret_cast<uint32_t *>(ps + 3 * cells));
     *span_out = G.span;
-    *bias_out = key_signed ? int64_t(modulus) - 1 : 0;
+    *bias_out = G.key_signed ? int64_t(G.modulus) - 1 : 0;
     return true;
 }
 

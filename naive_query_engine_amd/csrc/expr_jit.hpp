@@ -791,8 +791,10 @@ void jit_select_project(nqe_ctx *ctx, JitEntry *e, const JitSelProj &S, int64_t 
 // source knows nothing of that table's layout.  Compiles in ~1 s; until then, and for every other shape, the interpreters run.
 constexpr int JA_TU = 4, JA_BLOCK = 1024, JA_MAX_COLS = EX_MAX_COLS;
 struct JitAgg {
-    ExProgram pred;          // column operands renumbered to the slots below
-    int ncols = 0;           // slot 0 = the key column; the value column is slot val_slot (0 when it IS the key column)
+    ExProgram pred;          // the predicate (n = 0: none); column operands renumbered to the slots of `col`
+    ExProgram key;           // the group key: any fault-free integer program whose LAST step is `… % m` with a literal m (`id % 1024`,
+                             // `(id + 1) % 1000`, `id / 7 % 50`)
+    int ncols = 0;           // columns loaded: the union of what predicate, key and value reference
     const void *col[JA_MAX_COLS];
     int val_slot = 0, val_dtype = NQE_FLOAT64;
     bool key_signed = true;
@@ -801,14 +803,14 @@ struct JitAgg {
 };
 struct JitAggArgs {
     const void *col[JA_MAX_COLS];
-    uint64_t plit[JIT_MAX_LITS];
+    uint64_t plit[JIT_MAX_LITS], klit[JIT_MAX_LITS];
     int64_t n;
     double *psum, *pmn, *pmx;
     uint32_t *pcnt;
     int *flags;
 };
 uint64_t jit_hash_agg(const JitAgg &G) {
-    uint64_t h = jit_hash(G.pred, false, true) ^ 0x616767ull;
+    uint64_t h = jit_hash(G.pred, false, true) ^ (jit_hash(G.key, false, false) * 0x9E3779B97F4A7C15ull) ^ 0x616767ull;
     auto mix = [&](const void *p, size_t nb) {
         const unsigned char *b = static_cast<const unsigned char *>(p);
         for (size_t i = 0; i < nb; ++i) h = (h ^ b[i]) * 1099511628211ull;
@@ -824,7 +826,7 @@ std::string gen_source_agg(const JitAgg &G) {
       << "typedef unsigned long long u64; typedef long long i64; typedef unsigned int u32;\n"
       << "#define R " << JA_TU << "\n#define TU " << JA_TU << "\n#define BLOCK " << JA_BLOCK << "\n#define NC " << G.ncols << "\n#define S " << G.span << "u\n"
       << "#define NAN_BIT 0x80000000u\n"
-      << "struct Args { const void *col[" << JA_MAX_COLS << "]; u64 plit[" << JIT_MAX_LITS << "]; i64 n; double *psum, *pmn, *pmx; u32 *pcnt; int *flags; };\n"
+      << "struct Args { const void *col[" << JA_MAX_COLS << "]; u64 plit[" << JIT_MAX_LITS << "], klit[" << JIT_MAX_LITS << "]; i64 n; double *psum, *pmn, *pmx; u32 *pcnt; int *flags; };\n"
       << "struct Tile { u64 c[NC][TU]; };\n"
       << "static __device__ __forceinline__ double u2d(u64 w) { return __longlong_as_double((i64)w); }\n"
       << "static __device__ __forceinline__ u64 d2u(double d) { return (u64)__double_as_longlong(d); }\n"
@@ -864,11 +866,18 @@ std::string gen_source_agg(const JitAgg &G) {
     for (int c = 0; c < G.ncols; ++c) s << "    const u64 (&c" << c << ")[TU] = t.c[" << c << "];\n";
     bool has_valid[JP_MAX_COLS];
     for (int c = 0; c < JP_MAX_COLS; ++c) has_valid[c] = false;
-    const auto pres = emit_steps(s, G.pred, has_valid, false, "p", "A.plit", "in[r]");
+    std::string pass = "in[u]";
+    if (G.pred.n > 0) {
+        const auto pres = emit_steps(s, G.pred, has_valid, false, "p", "A.plit", "in[r]");
+        pass = "(in[u] && " + pres.first + "[u] != 0ull)";
+    }
+    // the key: its steps as straight-line code (the literal modulus of the last step is baked in: multiply-shift sequences); rows the
+    // predicate drops compute a key nobody uses
+    const auto kres = emit_steps(s, G.key, has_valid, false, "k", "A.klit", "in[r]");
     s << "#pragma unroll\n    for (int u = 0; u < TU; ++u) {\n"
-      << "      if (!(in[u] && " << pres.first << "[u] != 0ull)) continue;\n";
-    if (G.key_signed) s << "      const u32 slot = (u32)((i64)c0[u] % (i64)" << G.modulus << "ll + (i64)" << (G.modulus - 1) << "ll);\n";
-    else s << "      const u32 slot = (u32)(c0[u] % " << G.modulus << "ull);\n";
+      << "      if (!" << pass << ") continue;\n";
+    if (G.key_signed) s << "      const u32 slot = (u32)((i64)" << kres.first << "[u] + (i64)" << (G.modulus - 1) << "ll);\n";
+    else s << "      const u32 slot = (u32)" << kres.first << "[u];\n";
     if (G.val_dtype == NQE_FLOAT64) s << "      const double x = u2d(c" << vs << "[u]);\n";
     else if (G.val_dtype == NQE_INT64) s << "      const double x = (double)(i64)c" << vs << "[u];\n";
     else s << "      const double x = (double)c" << vs << "[u];\n";
@@ -904,6 +913,10 @@ void jit_aggregate_launch(nqe_ctx *ctx, JitEntry *e, const JitAgg &G, int64_t n,
     for (int i = 0; i < G.pred.n; ++i) {
         a.plit[2 * i] = G.pred.ins[i].lit_a;
         a.plit[2 * i + 1] = G.pred.ins[i].lit_b;
+    }
+    for (int i = 0; i < G.key.n; ++i) {
+        a.klit[2 * i] = G.key.ins[i].lit_a;
+        a.klit[2 * i + 1] = G.key.ins[i].lit_b;
     }
     a.n = n;
     a.psum = psum; a.pmn = pmn; a.pmx = pmx; a.pcnt = pcnt;

@@ -402,9 +402,10 @@ bool project_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node 
 // selection + projection in one run-time specialised pass (tree predicate, inputs without NULLs, word-typed outputs); false: take the mask + compaction path
 bool select_project_fused(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, const nqe_expr_node *nodes, const int32_t *expr_offsets,
                           int num_exprs, std::vector<DevColumn> *result, int64_t *total_out);
-// the streaming aggregate of `val_col` grouped by `key_col % modulus` under a predicate tree, through the lean run-time specialised kernel
-// (expr.hip); on success *partials holds every workgroup's table for aggregate.hip's merge kernel
-bool aggregate_tree_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, int key_col, uint64_t modulus, bool key_signed,
+// the streaming aggregate of `val_col` grouped by a key `… % m` (any fault-free integer chain or tree ending in a literal modulus), under an
+// optional predicate, through the lean run-time specialised kernel (expr.hip); on success *partials holds every workgroup's table for
+// aggregate.hip's merge kernel
+bool aggregate_tree_specialised(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, const nqe_expr_node *group, int group_nodes,
                                 int val_col, int grid, BufRef *partials, uint32_t *span_out, int64_t *bias_out, bool dry_run = false);
 // evaluates `e` over `in` and compacts the result in the same pass
 DevColumn compact_simple_expr(nqe_ctx *ctx, const nqe_table *in, const SimpleExpr &e, const KeepMask &km);

@@ -2322,7 +2322,9 @@ def test_aggregate_under_a_predicate_tree_through_the_specialised_streaming_kern
     O, X = Operator, binop
     trees = [X(X(V, O.Lt, lit_f64(20.0)), O.Or, X(X(ID, O.Modulos, lit_i64(3)), O.Eq, lit_i64(0))),
              X(X(X(W, O.Plus, lit_i64(7)), O.Multiply, lit_i64(3)), O.Gt, X(ID, O.Modulos, lit_i64(50))),
-             X(X(X(V, O.Multiply, V), O.Lt, lit_f64(2500.0)), O.And, X(X(W, O.Lt, lit_i64(500)), O.Or, X(ID, O.GtEq, lit_i64(0))))]
+             X(X(X(V, O.Multiply, V), O.Lt, lit_f64(2500.0)), O.And, X(X(W, O.Lt, lit_i64(500)), O.Or, X(ID, O.GtEq, lit_i64(0)))),
+             # chain predicates (`col op lit ... cmp lit`: the static kernel's operator-major interpreter, PRED 3)
+             X(X(X(W, O.Plus, lit_i64(7)), O.Modulos, lit_i64(10)), O.Lt, lit_i64(6)), X(X(ID, O.Multiply, lit_i64(3)), O.GtEq, lit_i64(300))]
     # (key expression, value column, qualifies)
     # (None: whether the static path hands the tree to its in-kernel interpreters — the specialised kernel's hook — or materialises it
     # depends on the predicate / key / value combination: results are checked, the kernel taken is not)
@@ -2354,6 +2356,25 @@ def test_aggregate_under_a_predicate_tree_through_the_specialised_streaming_kern
                 elif phase == 2 or qualifies is False:
                     assert "agg_grouped_jit" not in names, (sorted(names), repr(key), phase)
             monkeypatch.delenv("NQE_NO_AGG_JIT")
+    # interpreted chain KEYS (`(id + 1) % 1000`, `u / 7 % 4096`: KEY 3 of the static kernel) take the specialised kernel whatever the
+    # predicate — none, a plain range test, a tree
+    for key in (X(X(ID, O.Plus, lit_i64(1)), O.Modulos, lit_i64(1000)), X(X(U, O.Divide, lit_u64(7)), O.Modulos, lit_u64(4096)),
+                X(X(X(ID, O.Multiply, lit_i64(3)), O.Minus, lit_i64(5)), O.Modulos, lit_i64(-700))):
+        kn = key.flatten(f5)
+        for pred in (None, X(ID, O.Lt, lit_i64(n // 3)), trees[0]):
+            pn = pred.flatten(f5) if pred is not None else None
+            exp = orc.aggregate([cols], ALL_AGGS(2), group_nodes=kn, pred_nodes=pn)[0]
+            for phase in (0, 1):
+                ctx.timing_enable(True)
+                ctx.timing_reset()
+                got = ctx.aggregate(t, ALL_AGGS(2), group_nodes=kn, pred_nodes=pn).to_host()
+                ctx.timing_enable(False)
+                names = ctx.timing_report()
+                assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"chain key {key!r} pred {pred!r} phase {phase}")
+                if phase == 0:
+                    ctx.jit_wait()
+                else:
+                    assert names.get("agg_grouped_jit", (0, 0))[1] == 1 and "agg_grouped_fast" not in names and "agg_grouped" not in names, (sorted(names), repr(key), repr(pred))
     # two value columns under a tree the static path would materialise: one specialised launch per column, no Boolean column
     tree = trees[1]
     pn, kn = tree.flatten(f5), X(ID, O.Modulos, lit_i64(1024)).flatten(f5)

@@ -52,10 +52,21 @@ int main() {
     S.proj = J; S.pred = pred; S.pred_cols = 1; S.proj_cols = 3;
     printf("//==== nqe_jit_selproj\n%s", gen_source_selproj(S).c_str());
 
+    ExProgram keyp; // (id + 1) % 1024
+    std::memset(&keyp, 0, sizeof(keyp));
+    keyp.n = 2; keyp.ncols = 1; keyp.col_dtype[0] = NQE_INT64;
+    keyp.ins[0] = ins(NQE_OP_PLUS, NQE_INT64, EX_COL + 0, EX_LIT, 0, 1);
+    keyp.ins[1] = ins(NQE_OP_MODULOS, NQE_INT64, EX_STACK, EX_LIT, 0, 1024);
     JitAgg G;
     std::memset(G.col, 0, sizeof(G.col));
-    G.pred = tree; G.ncols = 2; G.val_slot = 1; G.val_dtype = NQE_FLOAT64; G.key_signed = true; G.modulus = 1024; G.span = 2047;
+    G.pred = tree; G.key = keyp; G.ncols = 2; G.val_slot = 1; G.val_dtype = NQE_FLOAT64; G.key_signed = true; G.modulus = 1024; G.span = 2047;
     printf("//==== nqe_jit_agg -munsafe-fp-atomics\n%s", gen_source_agg(G).c_str());
+    // unsigned key `u % 4096`, Int64 value = the key column, no predicate
+    std::memset(&G.pred, 0, sizeof(G.pred));
+    std::memset(&G.key, 0, sizeof(G.key));
+    G.key.n = 1; G.key.ncols = 1; G.key.col_dtype[0] = NQE_UINT64;
+    G.key.ins[0] = ins(NQE_OP_MODULOS, NQE_UINT64, EX_COL + 0, EX_LIT, 0, 4096);
+    G.ncols = 1;
     G.val_dtype = NQE_INT64; G.val_slot = 0; G.key_signed = false; G.modulus = 4096; G.span = 4096;
     printf("//==== nqe_jit_agg_u64key_i64val -munsafe-fp-atomics\n%s", gen_source_agg(G).c_str());
     return 0;
