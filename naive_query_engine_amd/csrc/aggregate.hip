@@ -582,10 +582,183 @@ __device__ __forceinline__ void finalize_row(const GroupTable &g, uint32_t s, in
     }
 }
 
+// N output rows of one thread: the state words of all N slots are requested before any is used (finalize_row N times in a row
+// is N dependent round trips — the stores of one row may alias the loads of the next as far as the compiler can tell)
+template <int N>
+__device__ __forceinline__ void finalize_rows(const GroupTable &g, const uint32_t (&s)[N], const bool (&live)[N], const int64_t (&r)[N], const FinalizeArgs &f) {
+    const size_t slots = size_t(g.cap) + 1;
+    for (int v = 0; v < f.nslots; ++v) {
+        uint64_t cnt[N], mnw[N], mxw[N];
+        double sum[N];
+        uint32_t nan[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const size_t o = size_t(v) * slots + (live[u] ? s[u] : 0u);
+            cnt[u] = g.cnt[o];
+            sum[u] = g.sum[o];
+            mnw[u] = g.mn[o];
+            mxw[u] = g.mx[o];
+            nan[u] = g.nan[o];
+        }
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            if (!live[u]) continue;
+            const double mn = ord_to_f64(mnw[u]), mx = nan[u] ? __longlong_as_double(0x7FF8000000000000ll) : ord_to_f64(mxw[u]);
+            if (f.partial) {
+                f.out[4 * v + 0][r[u]] = cnt[u];
+                f.out[4 * v + 1][r[u]] = d2u(sum[u]);
+                f.out[4 * v + 2][r[u]] = d2u(mn);
+                f.out[4 * v + 3][r[u]] = d2u(mx);
+                continue;
+            }
+            for (int i = 0; i < f.naggs; ++i) {
+                if (f.vslot[i] != v) continue;
+                uint64_t w;
+                switch (f.func[i]) {
+                case NQE_AGG_COUNT: w = cnt[u]; break;
+                case NQE_AGG_SUM: w = d2u(sum[u]); break;
+                case NQE_AGG_AVG: w = d2u(sum[u] / double(uint32_t(cnt[u]))); break; // avg.rs:121 (cnt is u32)
+                case NQE_AGG_MIN: w = d2u(mn); break;
+                default: w = d2u(mx); break;
+                }
+                f.out[i][r[u]] = w;
+            }
+        }
+    }
+}
+
 __global__ void finalize_kernel(GroupTable g, const uint32_t *sorted_slots, int64_t G, FinalizeArgs f) {
     int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < G; r += stride)
         finalize_row(g, sorted_slots ? sorted_slots[r] : 0, r, f);
+}
+
+// ------------------------------------------------------------------ tail of a DENSELY written table whose keys lie in a compact range
+// The partitioned path leaves its groups in slots [0, G) in no order.  Sorting them by key was a histogram, a host read of it,
+// two or three counting passes and the finalize gather — twelve launches and three host waits, 0.2 ms of a 1.3 ms step at 65536
+// groups, 0.44 of 1.6 ms at 2^20.  Keys of the shapes that reach this path are mostly compact — `col % m`, ids, dates — so:
+//   dense_key_range_kernel   min / max of the keys in sort order, ahead of the flag read-back; its words and the group count
+//                            travel to the host with the flags (ONE wait for the whole tail);
+//   dense_rank_mark_kernel   pos[key − min] = slot + 1 over a zeroed array of the range's length;
+//   dense_rank_emit_kernel   one pass over pos: the non-zero entries, counted across workgroups by a decoupled look-back, are the
+//                            groups in key order — key and aggregates are written at their rank (finalize_row fused).
+// A range wider than 8 G + 65536 entries keeps the radix sort.
+__global__ void __launch_bounds__(256) dense_key_range_kernel(const uint64_t *__restrict__ keys, uint32_t cap, uint64_t flip, uint32_t *dense) {
+    // dense: [0] group count; words [2,3] = max of ~ord(key), [4,5] = max of ord(key) as uint64 (zero-initialised with the counter).
+    // One pair of atomics per WORKGROUP and few workgroups: same-address device atomics retire one at a time (a pair per wave of
+    // 512 workgroups took 37 us for 90000 keys)
+    __shared__ unsigned long long wlo[4], whi[4];
+    const uint32_t G = dense[0] < cap ? dense[0] : cap;
+    uint64_t lo = ~0ull, hi = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) {
+        const uint64_t o = keys[i] ^ flip;
+        lo = o < lo ? o : lo;
+        hi = o > hi ? o : hi;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t l2 = __shfl_xor((unsigned long long)lo, d), h2 = __shfl_xor((unsigned long long)hi, d);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (lane_id() == 0) {
+        wlo[threadIdx.x / 64] = lo;
+        whi[threadIdx.x / 64] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            lo = wlo[w] < lo ? wlo[w] : lo;
+            hi = whi[w] > hi ? whi[w] : hi;
+        }
+        if (lo <= hi) {
+            atomicMax(reinterpret_cast<unsigned long long *>(dense + 2), (unsigned long long)~lo);
+            atomicMax(reinterpret_cast<unsigned long long *>(dense + 4), (unsigned long long)hi);
+        }
+    }
+}
+
+__global__ void dense_rank_mark_kernel(const uint64_t *__restrict__ keys, uint32_t G, uint64_t flip, uint64_t ordmin, uint32_t *pos) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) pos[(keys[i] ^ flip) - ordmin] = i + 1;
+}
+
+constexpr int DR_BLOCK = 256;
+// consecutive entries of pos per thread (one 16-byte load; their groups' state is gathered together: finalize_rows).  One entry per
+// thread was slower — 33 against 18 us for 90000 entries: four times the chunks for the look-back to walk
+// status[0]: ticket counter; status[1 + c]: (value << 2) | 1 = chunk c's own count, | 2 = the count of chunks 0..c.  A chunk is taken
+// by ticket, so every chunk below a waiting one has been started — the look-back cannot wait on a workgroup that is not running.
+template <int DR_ITEMS>
+__global__ void __launch_bounds__(DR_BLOCK) dense_rank_emit_kernel(GroupTable g, const uint32_t *__restrict__ pos, uint64_t span, uint64_t flip, uint64_t ordmin,
+                                                                   unsigned long long *status, uint64_t *out_keys, FinalizeArgs f) {
+    __shared__ uint32_t s_chunk;
+    __shared__ uint32_t wcnt[DR_BLOCK / 64];
+    __shared__ unsigned long long s_excl;
+    if (threadIdx.x == 0) s_chunk = uint32_t(atomicAdd(&status[0], 1ull));
+    __syncthreads();
+    const uint64_t c = s_chunk;
+    const uint64_t j0 = (c * DR_BLOCK + threadIdx.x) * DR_ITEMS;
+    uint32_t p[DR_ITEMS];
+    if (DR_ITEMS == 4 && j0 + DR_ITEMS <= span) { // (pos is allocated in whole chunks)
+        const uint4 q = *reinterpret_cast<const uint4 *>(pos + j0);
+        p[0] = q.x;
+        p[DR_ITEMS > 1 ? 1 : 0] = q.y;
+        p[DR_ITEMS > 2 ? 2 : 0] = q.z;
+        p[DR_ITEMS > 3 ? 3 : 0] = q.w;
+    } else {
+#pragma unroll
+        for (int u = 0; u < DR_ITEMS; ++u) p[u] = j0 + u < span ? pos[j0 + u] : 0u;
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < DR_ITEMS; ++u) mine += p[u] ? 1u : 0u;
+    uint32_t wtot;
+    const uint32_t wexcl = wave_exclusive_scan(mine, wtot);
+    const int wv = int(threadIdx.x) / 64;
+    if (lane_id() == 0) wcnt[wv] = wtot;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < DR_BLOCK / 64; ++w) {
+        before += w < wv ? wcnt[w] : 0u;
+        total += wcnt[w];
+    }
+    if (wv == 0) {
+        if (lane_id() == 0 && c > 0) __hip_atomic_store(&status[1 + c], ((unsigned long long)total << 2) | 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long excl = 0;
+        for (int64_t look = int64_t(c) - 1; look >= 0; look -= 64) {
+            const int64_t idx = look - lane_id();
+            unsigned long long v = 2; // below chunk 0: an inclusive count of zero
+            if (idx >= 0) {
+                do v = __hip_atomic_load(&status[1 + idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                while ((v & 3ull) == 0);
+            }
+            const uint64_t incl = __ballot((v & 3ull) == 2ull);
+            const int stop = incl ? __ffsll((unsigned long long)incl) - 1 : 64; // the nearest chunk whose inclusive count is known
+            unsigned long long part = lane_id() <= stop ? (v >> 2) : 0ull;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+            excl += part;
+            if (incl) break;
+        }
+        if (lane_id() == 0) {
+            __hip_atomic_store(&status[1 + c], ((excl + total) << 2) | 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+        }
+    }
+    __syncthreads();
+    int64_t r = int64_t(s_excl) + before + wexcl;
+    uint32_t slot[DR_ITEMS];
+    bool live[DR_ITEMS];
+    int64_t row[DR_ITEMS];
+#pragma unroll
+    for (int u = 0; u < DR_ITEMS; ++u) {
+        live[u] = p[u] != 0;
+        slot[u] = p[u] - 1;
+        row[u] = r;
+        if (live[u]) out_keys[r++] = (ordmin + j0 + u) ^ flip;
+    }
+    if (f.naggs > 0) finalize_rows<DR_ITEMS>(g, slot, live, row, f);
 }
 
 // Tail of a SMALL hashed table (the first-attempt 8192-slot table: the headline's 1024 groups): collect + sort + finalize in one
@@ -875,7 +1048,7 @@ TableBufs make_table(nqe_ctx *ctx, uint32_t cap, int V, bool mark_slot0, bool de
     t.g.V = V;
     t.g.dense_count = nullptr;
     if (dense) { // every used slot is written in full by the producer: nothing to initialise but the counter
-        t.dense_counter = dev_alloc_zero(ctx, 8);
+        t.dense_counter = dev_alloc_zero(ctx, 32); // [0] the counter; words [2..5]: the keys' range (dense_key_range_kernel)
         t.g.dense_count = (uint32_t *)t.dense_counter->ptr;
         return t;
     }
@@ -960,6 +1133,9 @@ struct AggResult {
 struct Collected {
     BufRef keys, slots;
     int64_t G = -1; // -1: not collected yet
+    // a densely written table (partitioned path): group count and key range in sort order, read back with the flags
+    int64_t dense_G = -1;
+    uint64_t ordmin = 0, ordmax = 0;
 };
 
 // output columns of an aggregate (or its partial state) with room for `rows` rows, and the kernel arguments that fill them
@@ -1027,7 +1203,42 @@ AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const n
             ck = pre->keys;
             cs = pre->slots;
         } else if (tb.g.dense_count) { // groups already occupy slots [0, G)
-            G = int64_t(read_scalar(ctx, (const uint32_t *)tb.g.dense_count));
+            G = pre && pre->dense_G >= 0 ? pre->dense_G : int64_t(read_scalar(ctx, (const uint32_t *)tb.g.dense_count));
+            const bool no_range_tail = getenv("NQE_NO_RANGE_TAIL") != nullptr; // A/B (read per call): the radix-sort tail
+            if (pre && pre->dense_G > 4096 && !no_range_tail && pre->ordmax >= pre->ordmin && pre->ordmax - pre->ordmin < uint64_t(8) * uint64_t(G) + 65536) {
+                // compact key range: rank by key - min (three launches, no further host wait) instead of sorting
+                const uint64_t span = pre->ordmax - pre->ordmin + 1;
+                const int items = 4;
+                const uint64_t chunks = (span + uint64_t(DR_BLOCK) * items - 1) / (uint64_t(DR_BLOCK) * items);
+                const size_t pos_bytes = size_t(chunks) * DR_BLOCK * items * 4, status_bytes = (size_t(chunks) + 1) * 8;
+                BufRef work;
+                try {
+                    work = dev_alloc(ctx, pos_bytes + status_bytes);
+                } catch (const Error &e) {
+                    if (e.code != NQE_ERR_OUT_OF_MEMORY) throw;
+                }
+                if (work) {
+                    const uint64_t flip = key_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
+                    NQE_HIP_CHECK(hipMemsetAsync(work->ptr, 0, pos_bytes + status_bytes, ctx->stream));
+                    uint32_t *pos = (uint32_t *)work->ptr;
+                    launch(ctx, "agg_dense_rank_mark", dense_rank_mark_kernel, dim3(stream_grid(ctx, G, 256)), dim3(256), 0, (const uint64_t *)tb.g.keys, uint32_t(G), flip,
+                           pre->ordmin, pos);
+                    AggResult r;
+                    FinalizeArgs f = alloc_outputs(ctx, r, G, aggs, naggs, vslot, partial);
+                    sorted_keys = dev_alloc(ctx, size_t(G) * 8 + 8);
+                    launch(ctx, "agg_dense_rank_emit", dense_rank_emit_kernel<4>, dim3(unsigned(chunks)), dim3(DR_BLOCK), 0, tb.g, (const uint32_t *)pos, span, flip, pre->ordmin,
+                           reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(work->ptr) + pos_bytes), (uint64_t *)sorted_keys->ptr, f);
+                    r.keys = std::make_unique<nqe_table>();
+                    r.keys->ctx = ctx;
+                    r.keys->rows = G;
+                    DevColumn kc;
+                    kc.dtype = key_dtype;
+                    kc.length = G;
+                    kc.values = sorted_keys;
+                    r.keys->cols.push_back(kc);
+                    return r;
+                }
+            }
             ck = tb.keys;
             cs = dev_alloc(ctx, size_t(G) * 4 + 8);
             if (G) launch(ctx, "iota_u32", iota_slots_kernel, dim3(stream_grid(ctx, G, 256)), dim3(256), 0, (uint32_t *)cs->ptr, G);
@@ -1837,11 +2048,24 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             launch(ctx, "agg_collect", collect_kernel, dim3(stream_grid(ctx, int64_t(slots), 256)), dim3(256), 0, tb.g, (uint64_t *)pre.keys->ptr,
                    (uint32_t *)pre.slots->ptr, reinterpret_cast<uint32_t *>(ctx->d_flags + NQE_FLAG_GROUP_COUNT));
         }
+        const bool dense_tail = grouped && tb.g.dense_count != nullptr;
+        if (dense_tail) { // group count and key range of the densely written table ride along with the flags (emit: the ranked tail)
+            launch(ctx, "agg_dense_key_range", dense_key_range_kernel, dim3(unsigned(std::min<int64_t>(128, (int64_t(tb.g.cap) + 4095) / 4096))), dim3(256), 0, (const uint64_t *)tb.g.keys, tb.g.cap,
+                   kinfo.out_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull, tb.g.dense_count);
+            NQE_HIP_CHECK(hipMemcpyAsync(ctx->h_flags + NQE_NUM_FLAGS, tb.g.dense_count, 24, hipMemcpyDeviceToHost, ctx->stream));
+        }
         int f[NQE_NUM_FLAGS];
         if (flagless) std::memset(f, 0, sizeof(f)); // nothing on this path raises a flag and the result has exactly one row: no read-back
         else if (ranked.out) flags_read_mirrored(ctx, f);
         else flags_read(ctx, f);
         if (pre.keys) pre.G = int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT]));
+        if (dense_tail && !flagless) {
+            const volatile int *x = ctx->h_flags + NQE_NUM_FLAGS;
+            const uint64_t inv_min = uint64_t(uint32_t(x[2])) | (uint64_t(uint32_t(x[3])) << 32), mx = uint64_t(uint32_t(x[4])) | (uint64_t(uint32_t(x[5])) << 32);
+            pre.dense_G = int64_t(std::min<uint32_t>(uint32_t(x[0]), tb.g.cap));
+            pre.ordmin = ~inv_min;
+            pre.ordmax = mx;
+        }
         if (getenv("NQE_DEBUG"))
             fprintf(stderr, "[nqe] aggregate attempt %d: partition %d subsets_log2 %d cap %u flags need_partition %d slab_overflow %d level2 %d table_full %d dense_overflow %d\n",
                     attempt, int(partition_mode), subsets_log2, cap, f[NQE_FLAG_NEED_PARTITION], f[NQE_FLAG_SLAB_OVERFLOW], f[NQE_FLAG_NEED_LEVEL2],

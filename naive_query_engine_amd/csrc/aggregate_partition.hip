@@ -426,6 +426,20 @@ template <int PRED, int KEY, int NVT> struct SlabShape {
 // K32 (one value column): the tuple written to the slab is {int32 key, value} = 12 bytes — passes 2 and 3 of the partitioned
 // aggregate move 12 instead of 16 bytes per row (40 B/row in all instead of 48).  Optimistic: a key outside int32 raises
 // NQE_FLAG_KEY32_OVERFLOW and the host redoes the query with 16-byte tuples (and remembers).
+#ifdef NQE_SLAB_PROFILE
+// diagnostic build (tools/probe_slab_phases.py): shader-clock time of thread 0 of every scatter workgroup per phase of a tile
+__device__ unsigned long long nqe_slab_prof[8];
+#define SLAB_STAMP(i)                                   \
+    do {                                                \
+        if (threadIdx.x == 0) {                         \
+            const unsigned long long now_ = clock64();  \
+            prof_acc[i] += now_ - prof_t;               \
+            prof_t = now_;                              \
+        }                                               \
+    } while (0)
+#else
+#define SLAB_STAMP(i) do { } while (0)
+#endif
 struct __attribute__((packed, aligned(4))) Tuple12 {
     int32_t key;
     uint64_t val;
@@ -474,6 +488,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
             for (int j = 0; j < NVT; ++j) r.vw[j][u] = __builtin_nontemporal_load(&valp[j][row]);
         }
     };
+#ifdef NQE_SLAB_PROFILE
+    unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0}, prof_t = clock64();
+#endif
     auto tile = [&](const Regs &r, Regs &next, int64_t base) {
         uint64_t key[RPT];
         uint32_t part[RPT], rank[RPT];
@@ -492,6 +509,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
 #pragma unroll
         for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
         __syncthreads();
+        SLAB_STAMP(0); // wait for the tile's words, key / partition, rank atomics
         // tile-local exclusive scan of the PARTS counters (threads 0..PARTS-1)
         uint32_t c = int(threadIdx.x) < parts ? tcnt[threadIdx.x] : 0u, wt;
         uint32_t ex = wave_exclusive_scan(c, wt);
@@ -505,6 +523,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
         uint32_t tile_total = 0;
         for (int w = 0; w < PARTS / 64; ++w) tile_total += wave_tot[w];
         __syncthreads();
+        SLAB_STAMP(1); // scan of the tile's counters
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
             if (!pass[u]) continue;
@@ -519,6 +538,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
         }
         if (base + SC_ROWS < hi) load(next, base + SC_ROWS); // workgroup-uniform: the next tile's words fly during the copy-out
         __syncthreads();
+        SLAB_STAMP(2); // tuples to LDS, next tile's loads issued
         for (uint32_t i = threadIdx.x; i < tile_total; i += blockDim.x) {
             uint64_t k, v0 = 0, v1 = 0;
             if (TW == 2) {
@@ -552,11 +572,13 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
             }
         }
         __syncthreads();
+        SLAB_STAMP(3); // copy-out
         if (int(threadIdx.x) < parts) {
             gcur[threadIdx.x] += tcnt[threadIdx.x];
             tcnt[threadIdx.x] = 0;
         }
         __syncthreads();
+        SLAB_STAMP(4); // cursors
     };
     if (lo < hi) {
         Regs A, B;
@@ -568,6 +590,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
         }
     }
     for (int p = threadIdx.x; p < parts; p += blockDim.x) sa.fill[size_t(p) * size_t(sa.W) + blockIdx.x] = gcur[p] < cap ? gcur[p] : cap;
+#ifdef NQE_SLAB_PROFILE
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&nqe_slab_prof[i], prof_acc[i]);
+        atomicAdd(&nqe_slab_prof[7], 1ull);
+    }
+#endif
 }
 
 // one workgroup per partition (grid-stride); its waves take the partition's slabs round-robin and stream their tuples, four
@@ -875,3 +903,11 @@ SegmentsKernel pick_segments_kernel(int nv, bool vf64) {
 
 // this translation unit's code object is loaded when a context is created, not by the first query that needs it (context.hip: load_modules)
 NQE_MODULE_PROBE((nqe::agg::agg_slab_segments_kernel<1, true, false>));
+
+#ifdef NQE_SLAB_PROFILE
+extern "C" void nqe_debug_slab_profile(unsigned long long *out) { // reads and clears the phase clocks
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(nqe::agg::nqe_slab_prof), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(nqe::agg::nqe_slab_prof), z, sizeof(z));
+}
+#endif

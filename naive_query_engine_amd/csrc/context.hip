@@ -603,7 +603,7 @@ nqe_status nqe_ctx_create(int32_t device, void *stream, nqe_ctx **out) {
         ctx->arch = ctx->arch.substr(0, ctx->arch.find(':'));
     }
     NQE_HIP_CHECK(hipMalloc(&ctx->d_flags, sizeof(int) * NQE_NUM_FLAGS));
-    NQE_HIP_CHECK(hipHostMalloc(&ctx->h_flags, sizeof(int) * NQE_NUM_FLAGS, hipHostMallocMapped | hipHostMallocCoherent));
+    NQE_HIP_CHECK(hipHostMalloc(&ctx->h_flags, sizeof(int) * (NQE_NUM_FLAGS + NQE_FLAG_MIRROR_EXTRA), hipHostMallocMapped | hipHostMallocCoherent));
     NQE_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_flags_dev), ctx->h_flags, 0));
     NQE_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NQE_NUM_FLAGS, ctx->stream));
     load_modules();

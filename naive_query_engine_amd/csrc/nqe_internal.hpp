@@ -43,6 +43,9 @@ enum { NQE_FLAG_DIV_ZERO = 0, NQE_FLAG_OVERFLOW = 1, NQE_FLAG_TABLE_FULL = 2, NQ
        NQE_FLAG_GROUP_COUNT = 7 /* not an error: the aggregate's group count rides along with the flag read-back */,
        NQE_FLAG_SLAB_OVERFLOW = 8 /* a partition slab of the count-free scatter is full: the host takes the exact form */,
        NQE_FLAG_KEY32_OVERFLOW = 9 /* a group key outside the int32 range met the 12-byte-tuple slab form: the host takes 16-byte tuples */, NQE_NUM_FLAGS = 10 };
+// words of the pinned flag mirror past the flags: results a tail kernel sends along with the flag read-back (aggregate.hip: the dense table's
+// group count and key range)
+constexpr int NQE_FLAG_MIRROR_EXTRA = 8;
 
 struct nqe_ctx {
     int device = 0;

@@ -2391,3 +2391,68 @@ def test_aggregate_under_a_predicate_tree_through_the_specialised_streaming_kern
             ctx.jit_wait()
         else:
             assert names.get("agg_grouped_jit", (0, 0))[1] == 2 and not any(x.startswith(("expr_jit", "expr_tree", "agg_grouped_fast")) for x in names), sorted(names)
+
+
+@pytest.mark.parametrize("shape", ["dense", "gaps", "negative", "uint64", "at_limit", "past_limit", "outlier", "modulus_key"])
+def test_aggregate_dense_table_tail_ranks_by_key_range(ctx, shape, monkeypatch):
+    """the partitioned path leaves its groups in no order; when their keys lie in a compact range (at most 8 G + 65536 values) the tail
+    ranks them by key - min (dense_key_range → dense_rank_mark → dense_rank_emit: no sort, one host wait) — keys and aggregates must
+    come out exactly as the radix-sort tail (NQE_NO_RANGE_TAIL=1) and the oracle give them, whole and as partial states; a wider range
+    (one outlying key, keys with a large common factor) keeps the sort.  aggregate/mod.rs:113-222 (the output order is the map's:
+    unobservable; this build emits key order)"""
+    rng = np.random.default_rng(len(shape) * 17)
+    n, G = 600_000, 70_000
+    base = rng.integers(0, G, n).astype(np.int64)
+    expect_range = True
+    if shape == "dense":
+        k = base
+    elif shape == "gaps":
+        k = base * 5 - 1234                      # span 5 G: inside 8 G + 65536
+    elif shape == "negative":
+        k = base - G                             # every key negative, -1 (the all-ones word) among them
+    elif shape == "uint64":
+        k = base
+    elif shape == "at_limit":
+        k = base.copy()
+        k[0] = 8 * len(np.unique(base[1:])) + 65536 - 2   # max - min just inside the limit whatever the distinct count turns out to be
+    elif shape == "past_limit":
+        k = base * 40                            # span 40 G
+        expect_range = False
+    elif shape == "outlier":
+        k = base.copy()
+        k[n // 3] = 1 << 45
+        expect_range = False
+    else:
+        k = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)
+    kc = Column.from_numpy(k.astype(np.uint64) + np.uint64(1 << 63)) if shape == "uint64" else Column.from_numpy(k)
+    v = rng.random(n) * 100 - 50
+    v[7] = np.nan
+    cols = [kc, Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    key = binop(col(0), Operator.Modulos, lit_i64(77_777)) if shape == "modulus_key" else col(0)
+    kn = key.flatten(f2)
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=kn)[0]
+    t = ctx.table_from_host(cols)
+    results = []
+    for tail in ("range", "sort"):
+        if tail == "sort":
+            monkeypatch.setenv("NQE_NO_RANGE_TAIL", "1")
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got, gk = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn, with_keys=True)
+        st, sk = ctx.aggregate_partial(t, ALL_AGGS(1), group_nodes=kn)
+        ctx.timing_enable(False)
+        ranked = ctx.timing_query("agg_dense_rank_emit")[1]
+        assert ctx.timing_query("agg_segments")[1] > 0, "the partitioned path was expected"
+        assert (ranked > 0) == (expect_range and tail == "range"), f"{shape} {tail}: {ranked} ranked tails"
+        kk = gk.to_host()[0].to_numpy()
+        order = np.argsort(kk, kind="stable")
+        assert (order == np.arange(len(kk))).all(), f"{shape} {tail}: keys not in order"
+        assert (sk.to_host()[0].to_numpy() == kk).all()
+        h = got.to_host()
+        assert_rows_multiset_equal(h, exp, RTOL, exact_cols=[0], what=f"{shape} {tail}")
+        results.append((kk, [c.to_numpy() for c in h], [c.to_numpy() for c in st.to_host()]))
+    (ka, ha, sa), (kb, hb, sb) = results
+    assert (ka == kb).all()
+    for x, y in zip(ha + sa, hb + sb):
+        assert np.allclose(x, y, rtol=1e-9, atol=0, equal_nan=True)   # f64 sums: LDS atomics in no fixed order
