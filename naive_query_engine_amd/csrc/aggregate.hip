@@ -1273,6 +1273,8 @@ AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const n
     return r;
 }
 
+constexpr uint64_t PART_RANGE_SALT = 0x9E3779B97F4A7C15ull; // nqe_ctx::agg_key_ranges[hint ^ salt]: the key range of the query's groups (range partitions)
+
 AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes,
                         const nqe_expr_node *group, int group_nodes, const nqe_aggregate *aggs, int naggs, bool partial) {
     AggPlan plan = plan_aggs(in, aggs, naggs);
@@ -1406,6 +1408,14 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         cap = std::min(sized_cap, RANK_MAX_CAP);
     }
     bool partition_mode = false, level2 = false, dense_ok = true, slab_failed = false, key32_failed = false;
+    // KEY-RANGE partitions of the slab form (aggregate_common.hpp: SlabArgs::range_span): the range they work from — the exact one an
+    // earlier execution's dense tail measured (remembered under a salted hint key), or this execution's key sample (`col % m`: what the
+    // modulus allows; a plain column: the sample's range padded by 1/256).  span 0: none; a key outside it sends the attempt back to hashed
+    // partitions (a sampled range is then replaced by the measured one, a remembered one by (0, 0): never again).
+    // NQE_NO_RANGE_PARTITION=1: hashed partitions only (A/B)
+    bool range_part_ok = getenv("NQE_NO_RANGE_PARTITION") == nullptr, range_part_used = false, part_range_sampled = false;
+    int64_t part_min = 0;
+    uint64_t part_span = 0;
     static const bool no_three = getenv("NQE_NO_THREE_COLUMN_PASS") != nullptr; // diagnostics (A/B runs)
     bool three_on = !no_three;
     // a plain integer key column whose value RANGE fits a workgroup table (nqe_ctx::agg_key_ranges)
@@ -1456,6 +1466,16 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
         if (hint_key == 0) hint_key = 1;
         const bool no_hints = getenv("NQE_NO_PLAN_HINTS") != nullptr; // diagnostics (A/B runs; read per call: tests switch it)
+        if (!no_hints) {
+            auto pr = ctx->agg_key_ranges.find(hint_key ^ PART_RANGE_SALT);
+            if (pr != ctx->agg_key_ranges.end()) {
+                if (pr->second.second == 0) range_part_ok = false;
+                else {
+                    part_min = pr->second.first;
+                    part_span = pr->second.second;
+                }
+            }
+        }
         auto it = ctx->agg_hints.find(hint_key);
         if (!no_hints && it != ctx->agg_hints.end()) {
             const uint8_t hv = it->second & 0x3f;
@@ -1532,6 +1552,24 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             cap = std::max(cap, sized_cap);
             if (G > 800e3) slab_parts_log2 = PARTS_LOG2; // … and more than 256 partitions of one table each
             ctx->agg_hints[hint_key] = uint8_t(slab_parts_log2 < PARTS_LOG2 ? 16 : 1);
+            if (range_part_ok && part_span == 0 && h[1] >= h[0]) { // the range the partitions are cut from (see part_min / part_span)
+                uint64_t lo = h[0], hi = h[1]; // sort order: key ^ key_flip
+                if (simple_mod_key) {
+                    const uint64_t m1 = a.key.aux[0].abs_lit - 1;
+                    const bool sgn = key_flip != 0;
+                    lo = (sgn && lo < key_flip) ? (uint64_t(0) - m1) ^ key_flip : key_flip; // a negative key in the sample: -(m - 1), else 0
+                    hi = m1 ^ key_flip;
+                } else {
+                    const uint64_t pad = (hi - lo) / 256 + 16;
+                    lo = lo > pad ? lo - pad : 0;
+                    hi = hi < ~uint64_t(0) - pad ? hi + pad : ~uint64_t(0);
+                }
+                if (hi - lo < (uint64_t(PARTS) << 12)) {
+                    part_min = int64_t(lo ^ key_flip);
+                    part_span = hi - lo + 1;
+                    part_range_sampled = true;
+                }
+            }
         } else if (D > range_limit) {
             subsets_log2 = 1;
             cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
@@ -1567,6 +1605,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     }
     if (!subsets_ok) subsets_log2 = 0;
     for (int attempt = 0;; ++attempt) {
+        range_part_used = false;
         // The partitioned path (entered after the fast kernel asked for it) with a single pass over the value columns writes
         // its groups densely: at most one LDS table's worth per (sub-)partition, never more than the input rows.
         const bool dense = grouped && partition_mode && dense_ok && V <= NV && !any_val_nullable && !a.key_src.valid &&
@@ -1798,15 +1837,26 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         int W = int(std::min<int64_t>(int64_t(ctx->num_cus) * slab_scatter_wg_per_cu(), (in->rows + tile_rows - 1) / tile_rows));
                         int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
                         W = int((in->rows + chunk - 1) / chunk);
-                        const int sparts = 1 << slab_parts_log2;
-                        const int64_t mean = chunk / sparts;
+                        // one value column, integer keys: 12-byte tuples {value, int32 key} unless a key was seen not to fit
+                        const bool k32 = a.nv == 1 && !key32_failed;
+                        // key-range partitions (aggregate_common.hpp: SlabArgs::range_span): 256 tables (512 beyond 2^20 values) of ceil(span / parts) <= 4096 slots
+                        const bool range_part = k32 && dense && range_part_ok && part_span != 0 && part_span <= (uint64_t(PARTS) << 12);
+                        int sparts_log2 = slab_parts_log2;
+                        if (range_part) sparts_log2 = part_span <= (uint64_t(256) << 12) ? 8 : PARTS_LOG2;
+                        const int used_parts = 1 << sparts_log2;
+                        const uint64_t rslots = range_part ? (part_span + (uint64_t(1) << sparts_log2) - 1) >> sparts_log2 : 0;
+                        range_part_used = range_part;
+                        if (getenv("NQE_DEBUG"))
+                            fprintf(stderr, "[nqe] slab partitions (hint %llx, k32 %d dense %d ok %d): range %d min %lld span %llu: %d tables of %llu slots (sampled %d)\n",
+                                    (unsigned long long)hint_key, int(k32), int(dense), int(range_part_ok), int(range_part), (long long)part_min, (unsigned long long)part_span, used_parts,
+                                    (unsigned long long)rslots, int(part_range_sampled));
+                        const int sparts = 1 << sparts_log2;
+                        const int64_t mean = chunk / used_parts;
                         // an ODD number of 256-byte units per slab: with a power-of-two slab stride (16 KB at 10^8 rows) the 512 write
                         // streams of a workgroup — and those of every other workgroup — start on the same HBM channel and move in
                         // step (the scatter took 0.78 or 0.97 ms depending on where the buffer happened to land)
                         const int64_t capt = ((mean + mean / 4 + 64 + 15) / 16 | 1) * 16;
                         const size_t tw = size_t(1 + a.nv);
-                        // one value column, integer keys: 12-byte tuples {int32 key, value} unless a key was seen not to fit
-                        const bool k32 = a.nv == 1 && !key32_failed;
                         const size_t tuple_bytes = k32 ? 12 : tw * 8;
                         // the slabs take 1.25x the tuple volume (+ padding) on top of the group table: when that does not fit, the exact
                         // form (count → scan → scatter into exactly sized partitions) still may — fall back instead of failing
@@ -1830,7 +1880,9 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         sl.chunk = chunk;
                         sl.W = W;
                         sl.cap = int32_t(capt);
-                        sl.parts_log2 = slab_parts_log2;
+                        sl.parts_log2 = sparts_log2;
+                        sl.range_min = part_min;
+                        sl.range_span = range_part ? part_span : 0;
                         const size_t sc_shmem = size_t(tile_rows) * 8 * tw + size_t(PARTS) * 12;
                         launch(ctx, "agg_partition_scatter", pick_slab_scatter_kernel(fp, fast_key, a.nv, k32), dim3(W), dim3(AGG_BLOCK), sc_shmem, ka, fpred, sl,
                                ctx->d_flags);
@@ -1843,8 +1895,14 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                             sshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
                             sblocks = 1;
                         }
-                        launch(ctx, "agg_segments", pick_slab_segments_kernel(a.nv, vf64, k32), dim3(std::min(sparts, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem,
-                               sa, sl, tb.g, ctx->d_flags);
+                        if (range_part) { // tables addressed by key - base: 28 bytes per key of the partition's interval
+                            const size_t dshmem = size_t(28) * size_t(rslots) + 16;
+                            const int dblocks = int(std::max<size_t>(1, std::min<size_t>(4, (size_t(144) << 10) / dshmem)));
+                            launch(ctx, "agg_segments_direct", pick_slab_segments_direct_kernel(vf64), dim3(std::min(used_parts, ctx->num_cus * dblocks)), dim3(AGG_BLOCK), dshmem, sa,
+                                   sl, tb.g, ctx->d_flags);
+                        } else
+                            launch(ctx, "agg_segments", pick_slab_segments_kernel(a.nv, vf64, k32), dim3(std::min(sparts, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem,
+                                   sa, sl, tb.g, ctx->d_flags);
                         sync(ctx); // the slabs are released at the end of this scope
                     } else if (partition_mode) {
                         // ---- partitioned path, exact form: count → scan → scatter → one workgroup per partition (skewed keys whose
@@ -1910,6 +1968,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         // (only kernels that have a partitioned counterpart may ask for it — the fuzzer found an interpreted predicate
                         // asking before the partition kernels had that variant: a densely laid out table went to the hashed general kernel)
                         ka.allow_partition = in->rows >= (int64_t(1) << 18) ? 1 : 0;
+                        {
+                            // how often a wave looks at the overflow flags (aggregate_common.hpp): every 8th iteration; NQE_FLAG_CHECK_MASK=0: every one (A/B)
+                            const char *fm = getenv("NQE_FLAG_CHECK_MASK");
+                            const int m = fm ? atoi(fm) : 7;
+                            ka.flag_check_mask = (m == 0 || m == 1 || m == 3 || m == 7 || m == 15) ? m : 7;
+                        }
                         // ONE 1024-thread workgroup per CU: fewer concurrent streams read HBM faster (A/B on one box: headline
                         // 2.44 -> 2.39 ms, C3 2.56 -> 2.41 ms, random keys 3.63 -> 3.54 ms, 1 % nulls 0.81 -> 0.69 ms per 2e8 rows;
                         // tools/stream_bench.hip shows the same for a bare read kernel)
@@ -2072,6 +2136,23 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     f[NQE_FLAG_TABLE_FULL], f[NQE_FLAG_DENSE_OVERFLOW]);
         if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
         if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
+        if ((f[NQE_FLAG_OOB] || f[NQE_FLAG_SLAB_OVERFLOW]) && partition_mode && range_part_used) {
+            // a key outside the range the partitions were cut from (the sample missed it, the column changed), or key intervals of very
+            // unequal weight: hashed partitions, now and for this query shape's later executions
+            // (a range that came from the SAMPLE and missed a key: the hashed attempt's dense tail measures the exact one for the next
+            // execution; a remembered range that no longer holds, or lopsided intervals: never again for this query shape)
+            const bool remeasure = part_range_sampled && f[NQE_FLAG_OOB] && !f[NQE_FLAG_SLAB_OVERFLOW];
+            range_part_used = false;
+            part_span = 0;
+            part_range_sampled = false;
+            if (!remeasure) range_part_ok = false;
+            if (hint_key && !remeasure) {
+                if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
+                ctx->agg_key_ranges[hint_key ^ PART_RANGE_SALT] = std::make_pair(int64_t(0), uint64_t(0));
+            }
+            flags_reset(ctx);
+            continue;
+        }
         if (f[NQE_FLAG_KEY32_OVERFLOW] && partition_mode && !key32_failed) {
             key32_failed = true; // a group key outside int32: the 16-byte tuple form
             if (hint_key) ctx->agg_hints[hint_key] = uint8_t(0x40 | (slab_parts_log2 < PARTS_LOG2 ? 16 : 1));
@@ -2153,6 +2234,15 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             cap = uint32_t(std::min<uint64_t>(next, uint64_t(1) << 31));
             flags_reset(ctx);
             continue;
+        }
+        if (pre.dense_G > 0 && hint_key && range_part_ok && pre.ordmax >= pre.ordmin && pre.ordmax - pre.ordmin < (uint64_t(PARTS) << 12)) {
+            // the exact key range of this query's groups: the next execution cuts its partitions from it
+            const uint64_t flip = kinfo.out_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
+            if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
+            ctx->agg_key_ranges[hint_key ^ PART_RANGE_SALT] = std::make_pair(int64_t(pre.ordmin ^ flip), pre.ordmax - pre.ordmin + 1);
+            if (getenv("NQE_DEBUG"))
+                fprintf(stderr, "[nqe] aggregate: remembered key range %lld + %llu (hint %llx)\n", (long long)int64_t(pre.ordmin ^ flip), (unsigned long long)(pre.ordmax - pre.ordmin + 1),
+                        (unsigned long long)hint_key);
         }
         AggResult res;
         if (ranked.out) {

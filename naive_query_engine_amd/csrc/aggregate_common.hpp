@@ -97,6 +97,9 @@ struct AggArgs {
     uint64_t tree_prog; // device address of TreeInstr[tree_n]
     int32_t tree_n;
     int32_t tree_need_pw; // some operand reads word slot 2
+    // the streaming kernel looks at the overflow flags (its own LDS word, two device words) when (iteration & mask) == mask: each look
+    // drains the wave's vector-memory queue — the tile it has just prefetched — before the flag loads can return (0: every iteration)
+    int32_t flag_check_mask;
 };
 
 // ------------------------------------------------------------------ predicate trees (pred_mode 4)
@@ -488,6 +491,17 @@ struct SlabArgs {
     int32_t parts_log2; // partitions of this run: 8 (twice the run length per partition and tile: the scatter's stores are what bound
                         // it — 0.72-0.82 ms per 10^8 rows against 0.88-0.93 with 512, while 128 leave the second kernel half the
                         // chip) until a partition holds more distinct keys than a workgroup table, then PARTS_LOG2
+    // KEY-RANGE partitioning (round 4; 12-byte tuples only) for keys known to lie in a compact range [range_min, range_min + range_span)
+    // (`col % m`, a sampled or remembered range): with d = key - range_min and hi = d >> parts_log2,
+    //     partition = (d ^ ((hi * 0x9E3779B1) >> (32 - parts_log2))) & (parts - 1),   slot in the partition's table = hi
+    // — a bijection between the range and parts x ceil(span / parts) slots, so the second kernel addresses its LDS table directly (no hash,
+    // no probe, no key words: agg_slab_segments_direct_kernel) and rebuilds the key from (partition, slot).  The LOW bits pick the
+    // partition: consecutive keys (sorted ids, `row number % m`) fall into different partitions — contiguous intervals sent a workgroup's
+    // whole chunk to a few of them, whose slabs overflowed.  They are scrambled by a multiplicative hash of the high bits: plain XOR folds
+    // of the high bits left keys with a common odd factor (5 k + c) on a quarter of the partitions at four times the load.  A key outside the range raises NQE_FLAG_OOB and the host redoes the query with hash partitions.  range_span 0: hash
+    // partitioning.
+    int64_t range_min;
+    uint64_t range_span;
 };
 
 constexpr int SUB_LOG2 = 6;
@@ -513,6 +527,7 @@ int slab_scatter_rows_per_thread(int pred, int key, int nv);
 int slab_scatter_wg_per_cu();
 using SlabSegmentsKernel = void (*)(AggArgs, SlabArgs, GroupTable, int *);
 SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64, bool k32 = false);
+SlabSegmentsKernel pick_slab_segments_direct_kernel(bool vf64); // range partitions (SlabArgs::range_span != 0), one value column, 12-byte tuples
 
 } // namespace agg
 } // namespace nqe

@@ -521,6 +521,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 base += stride;
                 if (base >= n) return;
                 load_tile(A, base);
+                if ((int(it) & a.flag_check_mask) != a.flag_check_mask) continue;
                 if (__builtin_amdgcn_readfirstlane(*lds_full) &&
                     (a.allow_partition || __builtin_amdgcn_readfirstlane(__hip_atomic_load(&flags[NQE_FLAG_TABLE_FULL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))) {
                     base = n;
@@ -543,6 +544,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             process(B, base);
             base += stride;
             if (base >= n) return;
+            // The overflow flags, every (flag_check_mask + 1)-th iteration only: the loads below — a FLAT load of the LDS word and a
+            // device-scope load — are waited for with s_waitcnt vmcnt(0), i.e. behind tile A's prefetch issued a moment ago, and the
+            // wave then sits with nothing in flight for a round trip to L2 (seen in the ISA; an abandoned attempt ends 16 tiles later)
+            if ((it & a.flag_check_mask) != a.flag_check_mask) continue;
             // (the flags are read through readfirstlane: every lane reads the same word, and the compiler must see that the loop's
             // control flow — hence `base` — is wave-uniform, or the tile pointers above turn into per-lane 64-bit arithmetic)
             if (__builtin_amdgcn_readfirstlane(*lds_full) &&

@@ -268,8 +268,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
     int vdt[NVT];
 #pragma unroll
     for (int j = 0; j < NVT; ++j) vdt[j] = a.val[j].dtype;
+    // read and written as an LDS word (ds_read / ds_write): through a generic `volatile int *` the accesses were FLAT loads, each
+    // followed by s_waitcnt vmcnt(0) — on every first-probe miss the wave waited for the tuples it had just prefetched
     __shared__ int seg_full_flag;
-    volatile int *seg_full = &seg_full_flag;
+#define SEG_FULL() __hip_atomic_load(&seg_full_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define SEG_FULL_SET() __hip_atomic_store(&seg_full_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
     for (int seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
         __syncthreads();
         if (signal_level2 && __hip_atomic_load(&flags[NQE_FLAG_NEED_LEVEL2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
                 // tuples of a partition arrive in no particular order: no run cache, one table update per row
                 int slot;
                 if (key == EMPTY_KEY) { lkeys[cap] = 0; slot = int(cap); }
-                else if (*seg_full) slot = -1; // this partition has more distinct keys than the table: spill the rest
+                else if (SEG_FULL()) slot = -1; // this partition has more distinct keys than the table: spill the rest
                 else {
                     uint32_t sl = uint32_t(((key * GOLD) << part_bits) >> a.lds_shift);
                     slot = -1;
@@ -318,8 +321,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_segments_kernel(AggArgs a, cons
                         sl = (sl + 1) & (cap - 1);
                     }
                 }
-                if (slot < 0 && !*seg_full) {
-                    *seg_full = 1;
+                if (slot < 0 && !SEG_FULL()) {
+                    SEG_FULL_SET();
                     if (signal_level2) atomicOr(&flags[NQE_FLAG_NEED_LEVEL2], 1); // the host re-partitions one level deeper
                 }
                 if (slot < 0 && signal_level2) continue;                              // result will be discarded
@@ -426,6 +429,13 @@ template <int PRED, int KEY, int NVT> struct SlabShape {
 // K32 (one value column): the tuple written to the slab is {int32 key, value} = 12 bytes — passes 2 and 3 of the partitioned
 // aggregate move 12 instead of 16 bytes per row (40 B/row in all instead of 48).  Optimistic: a key outside int32 raises
 // NQE_FLAG_KEY32_OVERFLOW and the host redoes the query with 16-byte tuples (and remembers).
+// key-range partitions (aggregate_common.hpp: SlabArgs::range_span): partition of d = key - range_min, and the scramble of the slot that
+// rebuilds the key's low bits from (partition, slot)
+__device__ __forceinline__ uint32_t range_scramble(uint32_t hi, int parts_log2) { return (hi * 0x9E3779B1u) >> (32 - parts_log2); }
+__device__ __forceinline__ uint32_t range_partition(uint64_t d, int parts_log2) {
+    return (uint32_t(d) ^ range_scramble(uint32_t(d >> parts_log2), parts_log2)) & ((1u << parts_log2) - 1u);
+}
+
 #ifdef NQE_SLAB_PROFILE
 // diagnostic build (tools/probe_slab_phases.py): shader-clock time of thread 0 of every scatter workgroup per phase of a tile
 __device__ unsigned long long nqe_slab_prof[8];
@@ -440,9 +450,11 @@ __device__ unsigned long long nqe_slab_prof[8];
 #else
 #define SLAB_STAMP(i) do { } while (0)
 #endif
+// (value first: a dwordx3 load lands in an even-aligned register triple, and gfx950's 64-bit operands want an even pair — with the key
+// first every loaded value was copied to another pair right behind its load, i.e. the wave waited for the loads it had just issued)
 struct __attribute__((packed, aligned(4))) Tuple12 {
-    int32_t key;
     uint64_t val;
+    int32_t key;
 };
 template <int PRED, int KEY, int NVT, bool K32 = false>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, FastPred fp, SlabArgs sa, int *flags) {
@@ -456,6 +468,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
     uint32_t *tstart = tcnt + PARTS;                                        // [PARTS] tile-local exclusive scan
     __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
     const int parts_log2 = sa.parts_log2, parts = 1 << parts_log2; // <= PARTS (the LDS counters are sized for PARTS)
+    const bool range_part = K32 && sa.range_span != 0;
     for (int p = threadIdx.x; p < PARTS; p += blockDim.x) {
         gcur[p] = 0;
         tcnt[p] = 0;
@@ -503,8 +516,16 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
             else if (PRED == 2) ok = ok && range_pass(fp, pred_extract(fp, r.pw[PRED >= 2 ? u : 0], row < last ? row : last));
             else if (PRED == 1) ok = ok && range_pass(fp, r.kw[u]);
             key[u] = inline_key<KEY>(a.key, r.kw[u], key_mask, key_aux, key_signed);
+            if (K32 && range_part) { // (wave-uniform choice) aggregate_common.hpp: SlabArgs::range_span; a key outside the range: the host redoes the query hashed
+                const uint64_t d = key[u] - uint64_t(sa.range_min);
+                if (ok && d >= sa.range_span) {
+                    atomicOr(&flags[NQE_FLAG_OOB], 1);
+                    ok = false;
+                }
+                part[u] = range_partition(d, parts_log2);
+            } else
+                part[u] = uint32_t((key[u] * GOLD) >> (64 - parts_log2));
             pass[u] = ok;
-            part[u] = uint32_t((key[u] * GOLD) >> (64 - parts_log2));
         }
 #pragma unroll
         for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
@@ -550,7 +571,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
                 v0 = stup[size_t(i) * TW + 1];
                 if (NVT > 1) v1 = stup[size_t(i) * TW + 2];
             }
-            const uint32_t p = uint32_t((k * GOLD) >> (64 - parts_log2));
+            uint32_t p;
+            if (K32 && range_part) {
+                p = range_partition(k - uint64_t(sa.range_min), parts_log2);
+            } else
+                p = uint32_t((k * GOLD) >> (64 - parts_log2));
             const uint32_t at = gcur[p] + (i - tstart[p]);
             if (at < cap) {
                 uint64_t *dst = sa.slabs + ((size_t(blockIdx.x) * size_t(parts) + p) * size_t(cap) + at) * TW;
@@ -617,8 +642,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
     int vdt[NVT];
 #pragma unroll
     for (int j = 0; j < NVT; ++j) vdt[j] = a.val[j].dtype;
+    // read and written as an LDS word (ds_read / ds_write): through a generic `volatile int *` the accesses were FLAT loads, each
+    // followed by s_waitcnt vmcnt(0) — on every first-probe miss the wave waited for the tuples it had just prefetched
     __shared__ int seg_full_flag;
-    volatile int *seg_full = &seg_full_flag;
     const int wave = int(threadIdx.x) / 64, nwaves = AGG_BLOCK / 64;
     const int parts_log2 = sa.parts_log2, parts = 1 << parts_log2;
     for (int p = blockIdx.x; p < parts; p += gridDim.x) {
@@ -644,6 +670,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
         const uint64_t *__restrict__ pbase = sa.slabs + size_t(p) * size_t(sa.cap) * TW; // slab (w, p) = pbase + w * PARTS * cap tuples
         struct Step {
             uint64_t key[SU], vw[NVT][SU];
+            int32_t k32[K32 ? SU : 1]; // the 12-byte tuple's key AS LOADED: widening it here would make fetch() wait for its own loads
             bool live[SU];
         };
         int cl = 0;          // current slab (index into the wave's list), wave-uniform
@@ -654,17 +681,20 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
                 i0 = 0;
             }
         };
-        auto fetch = [&](Step &st, int l, uint32_t i0) {
+        // `on` false: a dummy step (every tuple dead) over a position known to hold tuples — the prefetch of the step past the last is
+        // issued unconditionally, because a conditional fetch makes the step's registers a phi and the copies that resolve it sit
+        // right behind the loads (s_waitcnt vmcnt(0) before the CURRENT step is processed: no prefetch at all; seen in the ISA)
+        auto fetch = [&](Step &st, int l, uint32_t i0, bool on) {
             const uint32_t f = uint32_t(__builtin_amdgcn_readlane(int(myfill), l));
             const uint64_t *__restrict__ slab = pbase + size_t(wave + l * nwaves) * size_t(parts) * size_t(sa.cap) * TW;
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
-                st.live[u] = i < f;
+                st.live[u] = on && i < f;
                 const uint32_t ic = st.live[u] ? i : f - 1;
                 if (K32) {
                     const Tuple12 t = reinterpret_cast<const Tuple12 *>(sa.slabs)[(size_t(wave + l * nwaves) * size_t(parts) + size_t(p)) * size_t(sa.cap) + ic];
-                    st.key[u] = uint64_t(int64_t(t.key));
+                    st.k32[K32 ? u : 0] = t.key;
                     st.vw[0][u] = t.val;
                 } else if (TW == 2) {
                     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
@@ -679,12 +709,15 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
             }
         };
         auto update = [&](const Step &st) {
+            uint64_t skey[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) skey[u] = K32 ? uint64_t(int64_t(st.k32[K32 ? u : 0])) : st.key[u];
             // ---- slots: every first probe issued before any is examined
             uint32_t s0[SU];
             uint64_t k0[SU];
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
-                s0[u] = uint32_t(((st.key[u] * GOLD) << parts_log2) >> a.lds_shift);
+                s0[u] = uint32_t(((skey[u] * GOLD) << parts_log2) >> a.lds_shift);
                 k0[u] = lkeys[s0[u]];
             }
             int slot[SU];
@@ -692,13 +725,13 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
             for (int u = 0; u < SU; ++u) {
                 slot[u] = -1;
                 if (!st.live[u]) continue;
-                const uint64_t key = st.key[u];
+                const uint64_t key = skey[u];
                 if (key == EMPTY_KEY) {
                     lkeys[cap] = 0;
                     slot[u] = int(cap);
                 } else if (k0[u] == key) {
                     slot[u] = int(s0[u]);
-                } else if (!*seg_full) {
+                } else if (!SEG_FULL()) {
                     uint32_t sl = s0[u];
                     for (int probe = 0; probe < 32; ++probe) {
                         uint64_t k = lkeys[sl];
@@ -710,8 +743,8 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
                         sl = (sl + 1) & (cap - 1);
                     }
                 }
-                if (slot[u] < 0 && !*seg_full) { // more distinct keys than the table: the host partitions one level deeper (exact form)
-                    *seg_full = 1;
+                if (slot[u] < 0 && !SEG_FULL()) { // more distinct keys than the table: the host partitions one level deeper (exact form)
+                    SEG_FULL_SET();
                     atomicOr(&flags[NQE_FLAG_NEED_LEVEL2], 1);
                 }
             }
@@ -747,25 +780,29 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
         };
         seek(cl, ci0);
         if (cl < nl) {
+            const int fl = cl;
+            const uint32_t fi0 = ci0;
             Step A, B;
-            fetch(A, cl, ci0);
+            fetch(A, cl, ci0, true);
             for (;;) {
                 int nlx = cl;
                 uint32_t ni0 = ci0 + 64 * SU;
                 seek(nlx, ni0);
-                if (nlx < nl) fetch(B, nlx, ni0);
+                const bool more_b = nlx < nl;
+                fetch(B, more_b ? nlx : fl, more_b ? ni0 : fi0, more_b);
                 update(A);
-                if (nlx >= nl) break;
+                if (!more_b) break;
                 cl = nlx;
                 ci0 = ni0 + 64 * SU;
                 seek(cl, ci0);
-                if (cl < nl) fetch(A, cl, ci0);
+                const bool more_a = cl < nl;
+                fetch(A, more_a ? cl : fl, more_a ? ci0 : fi0, more_a);
                 update(B);
-                if (cl >= nl) break;
+                if (!more_a) break;
             }
         }
         __syncthreads();
-        if (*seg_full) break; // result discarded
+        if (SEG_FULL()) break; // result discarded
         if (g.dense_count) {
             // ---- dense output: count this partition's groups, reserve [base, base + n) with one atomic, write them there
             __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
@@ -817,6 +854,144 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
                 uint32_t c = lcnt[o];
                 global_update(g, gslot, a.v0 + j, uint64_t(c & ~NAN_BIT), lsum[o], true, lmn[o], lmx[o], true, (c & NAN_BIT) != 0);
             }
+        }
+    }
+}
+
+// Key-range partitions (SlabArgs::range_span != 0; one value column, 12-byte tuples): the table of partition p is addressed by
+// (key - range_min) >> parts_log2 — no hash, no probe sequence, no key words, no overflow; the key of a slot is rebuilt from (p, slot);
+// min / max are doubles behind ordered compares (native LDS f64 atomics).  The hashed kernel above spends ~75 instructions
+// per tuple (64-bit multiply, probe, compare, ordered-integer min / max); this one a dozen.  Same tuple stream (a wave's slabs as one
+// sequence of 256-tuple steps, the next step requested before the current one is processed), same dense output.
+template <bool VF64>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_direct_kernel(AggArgs a, SlabArgs sa, GroupTable g, int *flags) {
+    constexpr int SU = 4; // tuples per lane per step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int parts_log2 = sa.parts_log2;
+    const uint32_t W = uint32_t((sa.range_span + (uint64_t(1) << parts_log2) - 1) >> parts_log2); // slots per partition (<= 4096: the host checks)
+    double *lsum = reinterpret_cast<double *>(smem);
+    double *lmn = lsum + W;
+    double *lmx = lmn + W;
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + W);
+    const int vdt = a.val[0].dtype;
+    const int wave = int(threadIdx.x) / 64, nwaves = AGG_BLOCK / 64;
+    const int parts = 1 << parts_log2;
+    for (int p = blockIdx.x; p < parts; p += gridDim.x) {
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s < W; s += blockDim.x) {
+            lsum[s] = 0.0;
+            lmn[s] = DBL_MAX;
+            lmx[s] = -DBL_MAX;
+            lcnt[s] = 0;
+        }
+        __syncthreads();
+        const int nl = (sa.W - wave + nwaves - 1) / nwaves; // slabs of this wave (<= 64: W <= 1024)
+        const uint32_t myfill = lane_id() < nl ? sa.fill[size_t(p) * size_t(sa.W) + size_t(wave + lane_id() * nwaves)] : 0u;
+        struct Step {
+            uint64_t vw[SU];
+            int32_t k32[SU]; // as loaded (widened where it is used: see agg_slab_segments_kernel)
+            bool live[SU];
+        };
+        int cl = 0;       // current slab (index into the wave's list), wave-uniform
+        uint32_t ci0 = 0; // first tuple of the current step
+        auto seek = [&](int &l, uint32_t &i0) { // first position at or after (l, i0) that holds tuples; l == nl: none
+            while (l < nl && i0 >= uint32_t(__builtin_amdgcn_readlane(int(myfill), l))) {
+                ++l;
+                i0 = 0;
+            }
+        };
+        auto fetch = [&](Step &st, int l, uint32_t i0, bool on) { // (`on` false: a dummy step over a position known to hold tuples)
+            const uint32_t f = uint32_t(__builtin_amdgcn_readlane(int(myfill), l));
+            const Tuple12 *__restrict__ slab = reinterpret_cast<const Tuple12 *>(sa.slabs) + (size_t(wave + l * nwaves) * size_t(parts) + size_t(p)) * size_t(sa.cap);
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
+                st.live[u] = on && i < f;
+                const Tuple12 t = slab[i < f ? i : f - 1];
+                st.k32[u] = t.key;
+                st.vw[u] = t.val;
+            }
+        };
+        auto update = [&](const Step &st) {
+            uint32_t slot[SU];
+            double x[SU], cmn[SU], cmx[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                slot[u] = st.live[u] ? uint32_t(uint64_t(int64_t(st.k32[u]) - sa.range_min) >> parts_log2) : 0u; // (< W: the scatter checked the range)
+                x[u] = VF64 ? u2d(st.vw[u]) : word_as_f64(st.vw[u], vdt);
+                cmn[u] = lmn[slot[u]];
+                cmx[u] = lmx[slot[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                if (!st.live[u]) continue;
+                atomicAdd(&lcnt[slot[u]], 1u);
+                unsafeAtomicAdd(&lsum[slot[u]], x[u]);
+                if (x[u] != x[u]) atomicOr(&lcnt[slot[u]], NAN_BIT);
+                else {
+                    if (x[u] < cmn[u]) unsafeAtomicMin(&lmn[slot[u]], x[u]);
+                    if (x[u] > cmx[u]) unsafeAtomicMax(&lmx[slot[u]], x[u]);
+                }
+            }
+        };
+        seek(cl, ci0);
+        if (cl < nl) {
+            const int fl = cl;
+            const uint32_t fi0 = ci0;
+            Step A, B;
+            fetch(A, cl, ci0, true);
+            for (;;) {
+                int nlx = cl;
+                uint32_t ni0 = ci0 + 64 * SU;
+                seek(nlx, ni0);
+                const bool more_b = nlx < nl;
+                fetch(B, more_b ? nlx : fl, more_b ? ni0 : fi0, more_b);
+                update(A);
+                if (!more_b) break;
+                cl = nlx;
+                ci0 = ni0 + 64 * SU;
+                seek(cl, ci0);
+                const bool more_a = cl < nl;
+                fetch(A, more_a ? cl : fl, more_a ? ci0 : fi0, more_a);
+                update(B);
+                if (!more_a) break;
+            }
+        }
+        __syncthreads();
+        // ---- dense output: count this partition's groups, reserve [base, base + n) with one atomic, write them there
+        __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
+        __shared__ uint32_t dense_base;
+        uint32_t mine = 0;
+        for (uint32_t s = threadIdx.x; s < W; s += blockDim.x) mine += lcnt[s] != 0 ? 1u : 0u;
+        uint32_t wtot;
+        const uint32_t wexcl = wave_exclusive_scan(mine, wtot);
+        if (lane_id() == 0) wave_tot[threadIdx.x / 64] = wtot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < AGG_BLOCK / 64; ++w) {
+                const uint32_t c = wave_tot[w];
+                wave_tot[w] = tot;
+                tot += c;
+            }
+            dense_base = tot ? atomicAdd(g.dense_count, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t pos = dense_base + wave_tot[threadIdx.x / 64] + wexcl;
+        const size_t gstride = size_t(g.cap) + 1;
+        for (uint32_t s = threadIdx.x; s < W; s += blockDim.x) {
+            const uint32_t c = lcnt[s];
+            if (c == 0) continue;
+            if (pos < g.cap) {
+                const size_t go = size_t(a.v0) * gstride + pos;
+                g.keys[pos] = uint64_t(sa.range_min + int64_t((uint64_t(s) << parts_log2) | uint64_t((uint32_t(p) ^ range_scramble(s, parts_log2)) & uint32_t(parts - 1))));
+                g.cnt[go] = uint64_t(c & ~NAN_BIT);
+                g.sum[go] = lsum[s];
+                g.mn[go] = f64_to_ord(lmn[s]);
+                g.mx[go] = f64_to_ord(lmx[s]);
+                g.nan[go] = (c & NAN_BIT) ? 1u : 0u;
+            } else atomicOr(&flags[NQE_FLAG_DENSE_OVERFLOW], 1);
+            ++pos;
         }
     }
 }
@@ -893,6 +1068,7 @@ SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64, bool k32) {
     return nv == 1 ? (vf64 ? agg_slab_segments_kernel<1, true> : agg_slab_segments_kernel<1, false>)
                    : (vf64 ? agg_slab_segments_kernel<2, true> : agg_slab_segments_kernel<2, false>);
 }
+SlabSegmentsKernel pick_slab_segments_direct_kernel(bool vf64) { return vf64 ? agg_slab_segments_direct_kernel<true> : agg_slab_segments_direct_kernel<false>; }
 SubpartitionKernel pick_subpartition_kernel(int nv) { return nv == 1 ? agg_subpartition_kernel<1> : agg_subpartition_kernel<2>; }
 SegmentsKernel pick_segments_kernel(int nv, bool vf64) {
     return nv == 1 ? (vf64 ? agg_segments_kernel<1, true> : agg_segments_kernel<1, false>) : (vf64 ? agg_segments_kernel<2, true> : agg_segments_kernel<2, false>);

@@ -2456,3 +2456,92 @@ def test_aggregate_dense_table_tail_ranks_by_key_range(ctx, shape, monkeypatch):
     assert (ka == kb).all()
     for x, y in zip(ha + sa, hb + sb):
         assert np.allclose(x, y, rtol=1e-9, atol=0, equal_nan=True)   # f64 sums: LDS atomics in no fixed order
+
+
+@pytest.mark.parametrize("shape", ["dense", "negative", "gaps", "wide_512_parts", "too_wide", "mod_key", "mod_key_mixed_signs", "sorted_ids_mod", "int64_values", "predicate",
+                                   "skewed", "uint64_keys"])
+def test_aggregate_partitioned_path_range_partitions(ctx, shape, monkeypatch):
+    """the slab form of the partitioned aggregate picks a row's partition from its key's position in the KEY RANGE when it knows one of at most 2^21 values —
+    the first execution's key sample (tables of 2^22 rows and more without a predicate; `col % m`: what the modulus allows), or the
+    exact range the dense tail of an earlier execution measured — and the second kernel then addresses its LDS table by key - base
+    (agg_slab_segments_direct_kernel).  Every execution must equal the oracle and the hashed form (NQE_NO_RANGE_PARTITION=1); a range
+    that turns out wrong or lopsided (a key the sample missed, half the rows in one key) falls back to hashed partitions.
+    aggregate/mod.rs:113-222"""
+    rng = np.random.default_rng(len(shape) * 31 + 5)
+    n = (1 << 22) + 4321 + 128 * sum(map(ord, shape))     # (a row count per case: remembered plans are keyed by buffer and rows)
+    G = 70_000
+    base = rng.integers(0, G, n).astype(np.int64)
+    key = col(0)
+    pred = None
+    first_direct, later_direct = True, True
+    v = rng.random(n) * 100 - 50
+    v[11] = np.nan
+    if shape == "dense":
+        k = base
+    elif shape == "negative":
+        k = base - G - 5
+    elif shape == "gaps":
+        k = base * 5 + 1000
+    elif shape == "wide_512_parts":
+        k = base * 25                                     # 1.75 M values: 512 tables of 3418 slots
+    elif shape == "too_wide":
+        k = base * 40                                     # 2.8 M values: hashed partitions
+        first_direct = later_direct = False
+    elif shape in ("mod_key", "mod_key_mixed_signs"):
+        k = rng.integers(0, 1 << 40, n).astype(np.int64)
+        key = binop(col(0), Operator.Modulos, lit_i64(60_000))
+        if shape == "mod_key_mixed_signs":
+            # a thousand negative keys: a sample that sees none takes [0, m) and meets a key outside it (hashed partitions this time, the
+            # measured range from then on); one that sees some takes (-m, m)
+            k[:1000] -= 1 << 41
+            first_direct = None
+    elif shape == "sorted_ids_mod":
+        # a row number modulo m: consecutive keys must land in different partitions (the low bits pick the partition), or a scatter
+        # workgroup's whole chunk goes to a few of them and their slabs overflow
+        k = np.arange(n, dtype=np.int64)
+        key = binop(col(0), Operator.Modulos, lit_i64(65_536))
+    elif shape == "int64_values":
+        k = base
+        v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    elif shape == "predicate":
+        k = base
+        pred = binop(col(1), Operator.Gt, lit_f64(-20.0))
+        first_direct = False                              # no key sample under a predicate: hashed first, the measured range later
+    elif shape == "skewed":
+        k = base.copy()
+        k[rng.random(n) < 0.5] = 12_345                   # half the rows in one key: its interval's slabs overflow
+        first_direct = later_direct = None
+    else:
+        k = base + 3
+    kc = Column.from_numpy(k.astype(np.uint64)) if shape == "uint64_keys" else Column.from_numpy(k)
+    cols = [kc, Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    kn = key.flatten(f2)
+    pn = pred.flatten(f2) if pred is not None else None
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=kn, pred_nodes=pn)[0]
+    t = ctx.table_from_host(cols)
+    keys_seen = None
+    for rep in range(3):
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got, gk = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn, pred_nodes=pn, with_keys=True)
+        ctx.timing_enable(False)
+        direct = ctx.timing_query("agg_segments_direct")[1] > 0
+        want = first_direct if rep == 0 else later_direct
+        assert ctx.timing_query("agg_partition_scatter")[1] > 0, f"{shape}: the partitioned path was expected"
+        if want is not None:
+            assert direct == want, f"{shape} rep {rep}: direct segments kernel {direct}, expected {want}"
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{shape} rep {rep}")
+        kk = gk.to_host()[0].to_numpy()
+        assert (np.diff(kk.astype(np.int64) if shape != "uint64_keys" else kk.astype(np.uint64).astype(np.float64)) > 0).all(), f"{shape}: keys not in order"
+        if keys_seen is not None:
+            assert (kk == keys_seen).all()
+        keys_seen = kk
+    monkeypatch.setenv("NQE_NO_RANGE_PARTITION", "1")
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    got, gk = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn, pred_nodes=pn, with_keys=True)
+    ctx.timing_enable(False)
+    assert ctx.timing_query("agg_segments_direct")[1] == 0
+    assert (gk.to_host()[0].to_numpy() == keys_seen).all()
+    assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{shape} hashed")

@@ -24,7 +24,7 @@ CONFIGS = {
     "c2": ({"keep_from_range_strided_kernel": 1, "compact_strided_kernel": 1}, 2.0e9),
     "c4": ({"join_sample_range_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
     "c4_sparse_keys": ({"probe_packed_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
-    "agg_65536_groups": ({"agg_slab_scatter_kernel": 1, "agg_slab_segments_kernel": 1}, 1.6e9),
+    "agg_65536_groups": ({"agg_slab_scatter_kernel": 1, "agg_slab_segments": 1}, 1.6e9),
     "headline_single_column": ({"agg_grouped_fast_kernel": 1}, 8e9),
     "headline_int64_values": ({"agg_grouped_fast_kernel": 1}, 16e9),
     "agg_tree_predicate": ({"nqe_jit_agg": 1, "agg_merge_partials_kernel": 1}, 16e9),
@@ -34,7 +34,7 @@ CONFIGS = {
     "c2_expression_trees": ({"nqe_jit_selproj": 1}, 2.4e9),
     "agg_readme_shape": ({"agg_grouped_fast_kernel": 1}, 24e9),
     "headline_nullable": ({"agg_grouped_fast_kernel": 1}, 16.125e9),
-    "agg_1048576_groups": ({"agg_slab_scatter_kernel": 1, "agg_slab_segments_kernel": 1}, 1.6e9),
+    "agg_1048576_groups": ({"agg_slab_scatter_kernel": 1, "agg_slab_segments": 1}, 1.6e9),
     # borrowed probe table: every output column written (one optimistic pass); immutable probe table: its columns are shared
     "c4_shared_probe_columns": ({"join_sample_range_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
     "c4_wide_payload": ({"join_sample_range_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
