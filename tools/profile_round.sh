@@ -43,5 +43,22 @@ python tools/probe_paths.py exprs 2>&1 | grep -v amdgpu.ids > $OUT/probe_exprs.t
 python tools/probe_paths.py trees 2>&1 | grep -v amdgpu.ids > $OUT/probe_trees.txt
 python tools/probe_paths.py csv 2>&1 | grep -v amdgpu.ids > $OUT/probe_csv.txt
 python tools/probe_paths.py strings 2>&1 | grep -v amdgpu.ids > $OUT/probe_strings.txt
+# A/B of the round's switches on this box (two rounds each: the boxes differ by more than some of the effects)
+{
+  for round in 1 2; do
+    for sw in "" NQE_NO_RANGE_TAIL=1 NQE_NO_RANGE_PARTITION=1; do
+      for g in 65536 1048576; do
+        ms=$(env $sw python bench.py --workload agg_groups --groups $g --no-configs --no-cpu-baseline --steps 30 2>/dev/null | tail -1 | python -c "import sys,json; print(round(json.loads(sys.stdin.read())['ms_per_step'],4))")
+        echo "round $round  agg_groups --groups $g  ${sw:-default}: $ms ms per step"
+      done
+    done
+    for m in 0 7; do
+      for wl in headline agg3 agg_readme; do
+        ms=$(NQE_FLAG_CHECK_MASK=$m python bench.py --workload $wl --no-configs --no-cpu-baseline --steps 20 2>/dev/null | tail -1 | python -c "import sys,json; print(round(json.loads(sys.stdin.read())['ms_per_step'],4))")
+        echo "round $round  $wl  NQE_FLAG_CHECK_MASK=$m: $ms ms per step"
+      done
+    done
+  done
+} > $OUT/probe_switches.txt 2>&1
 ./tools/micro_bench all > $OUT/micro_bench.txt 2>&1
 ls $OUT
