@@ -97,8 +97,9 @@ struct AggArgs {
     uint64_t tree_prog; // device address of TreeInstr[tree_n]
     int32_t tree_n;
     int32_t tree_need_pw; // some operand reads word slot 2
-    // the streaming kernel looks at the overflow flags (its own LDS word, two device words) when (iteration & mask) == mask: each look
-    // drains the wave's vector-memory queue — the tile it has just prefetched — before the flag loads can return (0: every iteration)
+    // the streaming kernel's ONE-tile loop (three value columns, the stack-machine predicate) looks at the overflow flags (its own LDS
+    // word, two device words) when (iteration & mask) == mask: each look drains the wave's vector-memory queue — the tile it has just
+    // requested — before the flag loads can return (0: every iteration).  The two-tile loop looks every iteration (see there).
     int32_t flag_check_mask;
 };
 

@@ -544,10 +544,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             process(B, base);
             base += stride;
             if (base >= n) return;
-            // The overflow flags, every (flag_check_mask + 1)-th iteration only: the loads below — a FLAT load of the LDS word and a
-            // device-scope load — are waited for with s_waitcnt vmcnt(0), i.e. behind tile A's prefetch issued a moment ago, and the
-            // wave then sits with nothing in flight for a round trip to L2 (seen in the ISA; an abandoned attempt ends 16 tiles later)
-            if ((it & a.flag_check_mask) != a.flag_check_mask) continue;
+            // (The flag loads below — a FLAT load of the LDS word and a device-scope load — are waited for with s_waitcnt vmcnt(0), i.e.
+            // behind tile A's prefetch issued a moment ago, and the wave then sits with nothing in flight for a round trip to L2.  Looking
+            // only every 8th iteration helps the one-tile loop above — three value columns 4.59 -> 4.42 ms, four A/B rounds — but not
+            // this one: headline 2.39-2.55 ms looking every iteration, 2.45-2.70 every 8th over four rounds on two boxes.  Fewer
+            // requests in flight per CU read HBM faster here — the same effect as one workgroup per CU, aggregate.hip.)
             // (the flags are read through readfirstlane: every lane reads the same word, and the compiler must see that the loop's
             // control flow — hence `base` — is wave-uniform, or the tile pointers above turn into per-lane 64-bit arithmetic)
             if (__builtin_amdgcn_readfirstlane(*lds_full) &&
