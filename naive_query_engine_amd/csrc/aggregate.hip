@@ -1443,6 +1443,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             for (size_t i = 0; i < nbytes; ++i) hint_key = (hint_key ^ b[i]) * 1099511628211ull;
         };
         const void *kp = a.key_src.values;
+        mix(&in->uid, sizeof(in->uid)); // (the table handle's identity: nqe_internal.hpp)
         mix(&kp, sizeof(kp));
         mix(&in->rows, sizeof(in->rows));
         mix(&a.key, sizeof(a.key));

@@ -10,6 +10,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/nqe.h"
@@ -148,10 +149,18 @@ struct DevColumn {
 
 } // namespace nqe
 
+inline uint64_t nqe_next_table_uid() {
+    static std::atomic<uint64_t> counter{1};
+    return counter.fetch_add(1, std::memory_order_relaxed);
+}
 struct nqe_table {
     nqe_ctx *ctx = nullptr;
     std::vector<nqe::DevColumn> cols;
     int64_t rows = 0;
+    // identity of this handle: what a context remembers about a query (aggregate plan hints, key ranges) is keyed by it as well as by
+    // the buffers — a NEW table over the same device memory (a caller refilling its buffers, the pool handing a block out again)
+    // holds other data and starts from nothing instead of from the previous table's plan
+    uint64_t uid = nqe_next_table_uid();
 };
 
 namespace nqe {
