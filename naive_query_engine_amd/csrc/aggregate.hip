@@ -940,10 +940,14 @@ __global__ void __launch_bounds__(256) key_range_kernel(const uint64_t *keys, in
 // distinct keys among them (open-addressing set of KEY_SAMPLE_SLOTS words, all ones = empty; a key of all ones is counted through
 // out[3]).  The distinct count is a LOWER BOUND of the query's groups: a tier it rules out would certainly have overflowed.
 constexpr int KEY_SAMPLE = 1 << 16, KEY_SAMPLE_SLOTS_LOG2 = 18;
+// tables sampled: from 2^18 rows (a quarter of the keys then) — below, an overfull workgroup table spills to the global one instead of
+// asking for another tier.  (2^22 until the end of round 4: half a million rows over 90 000 groups went single pass -> two key subsets
+// -> partitioned, 2.0 ms for a 0.13 ms query)
+constexpr int64_t KEY_SAMPLE_MIN_ROWS = int64_t(1) << 18;
 __global__ void __launch_bounds__(256) key_sample_kernel(const uint64_t *keys, int64_t n, SimpleExpr ke, uint64_t flip, unsigned long long *set,
                                                          unsigned long long *out) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int64_t stride = n / KEY_SAMPLE; // the host samples tables of 2^22 rows and more
+    const int64_t stride = n / KEY_SAMPLE; // the host samples tables of KEY_SAMPLE_MIN_ROWS rows and more (stride >= 4)
     uint64_t h = uint64_t(i) + 0x9E3779B97F4A7C15ull;
     h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
     h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
@@ -1523,7 +1527,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     bool range_sampled = false;
     const bool simple_mod_key = a.key.nops == 1 && a.key.op[0] == NQE_OP_MODULOS && !a.key.lit_left[0] && (a.key.op_dtype[0] == NQE_INT64 || a.key.op_dtype[0] == NQE_UINT64) &&
                                 a.key.aux[0].abs_lit > 1;
-    if (grouped && hint_key && !no_sample && in->rows >= (int64_t(1) << 22) && a.pred_mode == 0 && a.key_src.values && !a.key_src.valid && !utf8_key &&
+    if (grouped && hint_key && !no_sample && in->rows >= KEY_SAMPLE_MIN_ROWS && a.pred_mode == 0 && a.key_src.values && !a.key_src.valid && !utf8_key &&
         (a.key_src.dtype == NQE_INT64 || a.key_src.dtype == NQE_UINT64) &&
         (a.key.nops == 0 || (simple_mod_key && a.key.aux[0].abs_lit > range_limit)) && // (`col % m`, m within a workgroup table: nothing to find out)
         (no_hints_env || (ctx->agg_hints.find(hint_key) == ctx->agg_hints.end() && ctx->agg_key_ranges.find(hint_key) == ctx->agg_key_ranges.end()))) {
@@ -1607,6 +1611,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     if (!subsets_ok) subsets_log2 = 0;
     for (int attempt = 0;; ++attempt) {
         range_part_used = false;
+        bool asked_partition = false; // a streaming pass of this attempt ran with allow_partition (see the TABLE_FULL handler below)
         // The partitioned path (entered after the fast kernel asked for it) with a single pass over the value columns writes
         // its groups densely: at most one LDS table's worth per (sub-)partition, never more than the input rows.
         const bool dense = grouped && partition_mode && dense_ok && V <= NV && !any_val_nullable && !a.key_src.valid &&
@@ -1969,6 +1974,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         // (only kernels that have a partitioned counterpart may ask for it — the fuzzer found an interpreted predicate
                         // asking before the partition kernels had that variant: a densely laid out table went to the hashed general kernel)
                         ka.allow_partition = in->rows >= (int64_t(1) << 18) ? 1 : 0;
+                        asked_partition = asked_partition || ka.allow_partition != 0;
                         {
                             // how often a wave looks at the overflow flags (aggregate_common.hpp): every 8th iteration; NQE_FLAG_CHECK_MASK=0: every one (A/B)
                             const char *fm = getenv("NQE_FLAG_CHECK_MASK");
@@ -2225,6 +2231,21 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
         if (f[NQE_FLAG_DENSE_OVERFLOW]) { // a sub-partition with more distinct keys than an LDS table: hashed global table instead
             dense_ok = false;
+            flags_reset(ctx);
+            continue;
+        }
+        if (f[NQE_FLAG_TABLE_FULL] && !partition_mode && asked_partition) {
+            // More groups than the global table of the streaming tiers holds, while no workgroup's LDS table overflowed: a table of
+            // 2^18 .. a few million rows with many groups (every workgroup sees fewer distinct keys than its table holds).  Growing
+            // the global table would leave each workgroup folding its LDS table into it through device-scope atomics — as many of
+            // them as rows (500 000 rows, 90 000 groups: 1.33 ms in the streaming kernel); the partitioned path has none.
+            subsets_log2 = 0;
+            partition_mode = true;
+            cap = std::max(cap, sized_cap);
+            if (hint_key) {
+                if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
+                ctx->agg_hints[hint_key] = uint8_t((slab_parts_log2 < PARTS_LOG2 ? 16 : 1) | (key32_failed ? 0x40 : 0));
+            }
             flags_reset(ctx);
             continue;
         }

@@ -2545,3 +2545,32 @@ def test_aggregate_partitioned_path_range_partitions(ctx, shape, monkeypatch):
     assert ctx.timing_query("agg_segments_direct")[1] == 0
     assert (gk.to_host()[0].to_numpy() == keys_seen).all()
     assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{shape} hashed")
+
+
+@pytest.mark.parametrize("sample", [True, False])
+def test_aggregate_mid_size_table_with_many_groups_takes_the_partitioned_path(ctx, monkeypatch, sample):
+    """half a million rows over 90 000 groups: no workgroup sees more distinct keys than its LDS table holds, so nothing ever asked
+    for the partitioned path — the global table was grown instead and every workgroup folded its LDS table into it through
+    device-scope atomics (1.3 ms for a 0.13 ms query).  The first execution's key sample (tables of 2^18 rows and more) starts the
+    query partitioned; without the sample (NQE_NO_KEY_SAMPLE=1) the overfull global table of the two-subset tier sends it there.
+    aggregate/mod.rs:113-222"""
+    if not sample:
+        monkeypatch.setenv("NQE_NO_KEY_SAMPLE", "1")
+    rng = np.random.default_rng(77 + int(sample))
+    n, G = 500_000 + 64 * int(sample), 90_000
+    k = rng.integers(0, G, n).astype(np.int64) * 3 - 1000
+    v = rng.random(n) * 10
+    cols = [Column.from_numpy(k), Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    kn = col(0).flatten(f2)
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=kn)[0]
+    t = ctx.table_from_host(cols)
+    for rep in range(3):
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn)
+        ctx.timing_enable(False)
+        assert ctx.timing_query("agg_partition_scatter")[1] > 0, f"rep {rep}: the partitioned path was expected"
+        if rep > 0 or sample:
+            assert ctx.timing_query("agg_grouped_fast")[1] == 0, f"rep {rep}: no streaming attempt was expected"
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"mid-size table, rep {rep}")
