@@ -54,6 +54,20 @@ is parity-checked against the oracle in the same run.
   0.91 → 0.42 ms, 10⁵-string group-by 1.81 → 1.16 ms; CSV parse of a 56 MB image 1.28 ms (44 GB/s HBM-resident, 24 GB/s from host bytes).
 * **Two ranks on one GPU** through the host-staged transport run `bench.py`'s multi-rank blocks (`world = 2`); C5's headline is
   the consumer-local join with the gathered form beside it. No scaling claim: the pool has one GPU per box.
+* **The partitioned aggregate** (`agg_65536_groups` 1.26 → 1.14–1.15 ms per step, `agg_1048576_groups` 1.61 → 1.32–1.36;
+  A/B of every switch on one box: `probe_switches.txt`): (i) its tail ranks the groups by key − min instead of sorting them when
+  their keys lie in a compact range — one host wait and three launches instead of three and twelve; (ii) key-range partitions
+  with LDS tables addressed by slot (`agg_slab_segments_direct_kernel`; 256 partitions where hashing needs 512); (iii) the
+  prefetch of its second kernel never worked — odd-aligned 64-bit pairs out of a `dwordx3` load, a phi behind a conditional fetch and
+  a FLAT load of an LDS flag each made the wave wait for the loads it had just issued (found in the ISA; DESIGN §3.3); (iv) where a
+  tile's time goes, measured with shader-clock stamps (`tools/probe_slab_phases.py`): the scatter moves its read + write mix at
+  3.9–4.6 TB/s whatever the partition count, the second kernel is bound by LDS read-modify-writes.
+* **Mid-size tables with many groups** (2¹⁸ … a few million rows) never reached the partitioned path: the global table was grown
+  and every workgroup folded its LDS table into it through device-scope atomics. The key sample now runs from 2¹⁸ rows and an
+  overfull global table goes to partitions: 500 000 rows / 90 000 groups 1.5 → 0.13 ms (first execution 2.0 → 0.49).
+* **What a context remembers is bound to the table handle** (`nqe_table::uid`): `bench.py`'s consecutive many-group configs got the
+  same torch buffers, so the 2²⁰-group config started from the 65536-group config's plan — a 20 ms "first execution" of four
+  abandoned attempts in one bench line.
 * Tried and left out, with numbers: two scatter workgroups per CU in the partitioned aggregate (kernels 1.06 → 1.12 ms);
   drawing the look-back's next ticket early (0.60 → 0.82 ms); a status word per 512-row chunk (0.94 ms); the one-pass selection
   for plain predicates; an order-restoring radix join (DESIGN §3.7: ≈ 8 GB of streamed traffic to save ≤ 0.3 ms — the beyond-L2
@@ -61,8 +75,8 @@ is parity-checked against the oracle in the same run.
 
 ## Open
 
-More than one physical GPU (C5, the xGMI numbers); the partitioned aggregate (0.16–0.18: PMC traffic is within 4 % of its
-three-pass floor, the two kernels are latency / LDS-bound at 3.4–3.7 TB/s); sparse 4 K–8 K-group band (two key subsets = every row
+More than one physical GPU (C5, the xGMI numbers); the partitioned aggregate (three passes: PMC traffic is within 4 % of
+that floor; the scatter's read + write mix runs at 3.9–4.6 TB/s, the second kernel is bound by LDS read-modify-writes); sparse 4 K–8 K-group band (two key subsets = every row
 issued twice); predicate trees over keys other than `col % m` (interpreted or materialised); joins beyond L2 (line-fetch floor).
 """
 open("profiles/r04/README.md", "w").write(text)
