@@ -71,6 +71,8 @@ def parse(argv=None):
     ap.add_argument("--reserve-gb", type=float, default=32.0, help="nqe_ctx_reserve: device memory the context takes from the driver at start-up and serves its outputs "
                                                                     "and scratch from (0 = none: every first allocation is a hipMalloc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the communicator self-test that runs before the big allocations")
+    ap.add_argument("--preflight-timeout", type=float, default=180.0, help="seconds a preflight stage may take before the rank reports where it is stuck and exits")
     ap.add_argument("--no-configs", action="store_true", help="only the main workload's line (no `configs` block)")
     ap.add_argument("--only", default="", help="comma-separated side configs to run (default: all)")
     ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the OPTIONAL second CPU number of the headline — an optimised multi-core form, not the reference's "
@@ -107,6 +109,102 @@ class F:
         self.name = name
 
 
+def preflight(B, parallel):
+    """N > 1 ranks: the exchange layer's first contact with real peers, made cheap to diagnose (task 7).  Before the
+    10^9-row allocations every rank (1) creates the library's communicator (nqe_comm_create: ncclCommInitRank with N ids), (2) runs
+    one fixed-size collective — a sharded aggregate of 1000 rows per rank, i.e. ONE ncclAllGather of a packed partial — and (3) one
+    ordered variable-length all-gather of a 3-column, (1000 + rank)-row table (p2p_all_gather_v: a group of N^2 ncclSend / ncclRecv
+    per column), checks both results against what they must be, and reports rank / device / RCCL version on stderr.  A stage that
+    raises names itself and the rank; a stage that HANGS is reported by a watchdog after --preflight-timeout seconds (the process
+    exits 4).  Every rank learns every rank's verdict (all_gather_object) and all exit non-zero together."""
+    import threading
+
+    import numpy as np
+
+    from naive_query_engine_amd import Column, Operator
+    from naive_query_engine_amd.expression import binop, col, lit_i64
+
+    torch, dist = B.torch, B.dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    t_start = time.perf_counter()
+    stage = {"name": "start", "since": t_start}
+    done = threading.Event()
+    tag = f"bench.py preflight: rank {rank}/{world} (device {B.local_rank}, pid {os.getpid()})"
+
+    def watchdog():
+        if not done.wait(B.args.preflight_timeout):
+            sys.stderr.write(f"{tag}: STUCK in stage '{stage['name']}' for {time.perf_counter() - stage['since']:.0f} s — a peer never joined, or the "
+                             f"transport hangs (RCCL: NCCL_DEBUG=INFO shows the ring / p2p set-up); exiting 4\n")
+            sys.stderr.flush()
+            os._exit(4)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+
+    def enter(name):
+        stage["name"], stage["since"] = name, time.perf_counter()
+
+    rec = {"rank": rank, "device": B.local_rank, "ok": False, "stage": None, "error": None}
+    try:
+        enter("device properties")
+        rec["device_name"] = torch.cuda.get_device_name(B.local_rank)
+        enter("communicator (nqe_comm_create: ncclCommInitRank)" if not B.host_transport else "communicator (host-staged transport)")
+        B.comm = parallel.make_staged_comm(B.ctx) if B.host_transport else parallel.make_comm(B.ctx)
+        rec["comm_world"], rec["comm_rank"] = B.comm.world, B.comm.rank
+        rec["rccl_version"] = None if B.host_transport else B.capi.Comm.rccl_version()
+        if B.comm.world != world or B.comm.rank != rank:
+            raise RuntimeError(f"communicator says rank {B.comm.rank} of {B.comm.world}")
+        m = 1000
+        # (2) one fixed-size collective: `select count(v), sum(v) from t group by id % 3` over 1000 rows per rank, ids = global row numbers
+        enter("fixed-size collective (sharded aggregate: one ncclAllGather of a packed partial)")
+        ids = np.arange(rank * m, (rank + 1) * m, dtype=np.int64)
+        v = (ids % 7).astype(np.float64)
+        w = ids * 3 + 1
+        t = B.ctx.table_from_host([Column.from_numpy(ids), Column.from_numpy(v), Column.from_numpy(w)])
+        f = [F("id"), F("v"), F("w")]
+        out, keys = B.comm.sharded_aggregate(t, [(AGG.Count, 1), (AGG.Sum, 1)], group_nodes=binop(col(0), Operator.Modulos, lit_i64(3)).flatten(f))
+        B.ctx.synchronize()
+        allid = np.arange(world * m, dtype=np.int64)
+        cnt, sm = [c.to_numpy() for c in out.to_host()]
+        kk = keys.to_host()[0].to_numpy()
+        exp_cnt = np.array([(allid % 3 == g).sum() for g in range(3)])
+        exp_sum = np.array([float((allid[allid % 3 == g] % 7).sum()) for g in range(3)])
+        if not ((kk == np.arange(3)).all() and (cnt.astype(np.int64) == exp_cnt).all() and (sm == exp_sum).all()):
+            raise RuntimeError(f"sharded aggregate returned keys {kk.tolist()} counts {cnt.tolist()} sums {sm.tolist()}, expected counts {exp_cnt.tolist()} sums {exp_sum.tolist()}")
+        # (3) one ordered variable-length all-gather: rank r contributes 1000 + r rows of three columns
+        enter("variable-length all-gather (p2p_all_gather_v: ncclSend / ncclRecv between every pair of ranks)")
+        mr = m + rank
+        base = sum(m + r for r in range(rank))
+        gi = np.arange(base, base + mr, dtype=np.int64)
+        tv = B.ctx.table_from_host([Column.from_numpy(gi), Column.from_numpy(gi * 0.5), Column.from_numpy(gi * 3 + 1)])
+        g = B.comm.all_gather_table(tv)
+        B.ctx.synchronize()
+        total = sum(m + r for r in range(world))
+        cols = [c.to_numpy() for c in g.to_host()]
+        ei = np.arange(total, dtype=np.int64)
+        if not (g.num_rows == total and (cols[0] == ei).all() and (cols[1] == ei * 0.5).all() and (cols[2] == ei * 3 + 1).all()):
+            raise RuntimeError(f"gathered table has {g.num_rows} rows (expected {total}) or rows out of rank order")
+        rec["ok"] = True
+    except BaseException as e:  # noqa: BLE001 - reported with its stage and rank; every rank exits together below
+        rec["stage"], rec["error"] = stage["name"], f"{type(e).__name__}: {e}"
+    rec["seconds"] = r4(time.perf_counter() - t_start)
+    sys.stderr.write(f"{tag}: {rec.get('device_name')}, RCCL version {rec.get('rccl_version')}, communicator {rec.get('comm_rank')}/{rec.get('comm_world')}: "
+                     + ("ok" if rec["ok"] else f"FAILED in stage '{rec['stage']}': {rec['error']}") + f" ({rec['seconds']} s)\n")
+    sys.stderr.flush()
+    enter("verdict exchange (torch.distributed all_gather_object)")
+    allrec = [None] * world
+    dist.all_gather_object(allrec, rec)
+    done.set()
+    bad = [r for r in allrec if not r["ok"]]
+    if bad:
+        if rank == 0:
+            for r in bad:
+                sys.stderr.write(f"bench.py preflight: FAILED on rank {r['rank']} (device {r['device']}) in stage '{r['stage']}': {r['error']}\n")
+        sys.exit(4)
+    return {"ok": True, "ranks": world, "seconds": max(r["seconds"] for r in allrec), "rccl_version": rec.get("rccl_version"),
+            "devices": [r.get("device_name") for r in allrec],
+            "what": "communicator + one fixed-size collective (sharded aggregate) + one ordered variable-length all-gather (3 columns), results checked on every rank, before the big allocations"}
+
+
 class Bench:
     def __init__(self, args, world, rank, local_rank):
         import torch
@@ -139,6 +237,17 @@ class Bench:
             if dist.get_world_size() != world:
                 sys.exit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {world}")
         self.ctx = capi.Context(local_rank)
+        self.preflight = None
+        if self.distributed:
+            # the data path's own communicator, on the context's stream: RCCL, or the host-staged transport — created and SELF-TESTED
+            # (preflight) before anything large is allocated: the first contact of N real RCCL peers should cost seconds to diagnose
+            if args.no_preflight:
+                self.comm = parallel.make_staged_comm(self.ctx) if self.host_transport else parallel.make_comm(self.ctx)
+            else:
+                self.preflight = preflight(self, parallel)
+            if self.comm.world != world:
+                sys.stderr.write(f"bench.py: the library's communicator has {self.comm.world} ranks, --gpus asked for {world}\n")
+                sys.exit(2)
         self.reserve_ms = None
         if args.reserve_gb > 0 and not self.host_transport:
             t0 = time.perf_counter()
@@ -147,9 +256,6 @@ class Bench:
                 self.reserve_ms = (time.perf_counter() - t0) * 1e3
             except Exception as e:  # noqa: BLE001 - a device without that much free memory: the pool and the driver serve every allocation
                 sys.stderr.write(f"bench.py: nqe_ctx_reserve({args.reserve_gb} GB) failed ({e}); continuing without a reserved block\n")
-        if self.distributed:
-            # the data path's own communicator, on the context's stream: RCCL, or the host-staged transport
-            self.comm = parallel.make_staged_comm(self.ctx) if self.host_transport else parallel.make_comm(self.ctx)
         self.keep = []
         self.min_warm_s = 0.0
 
@@ -221,15 +327,21 @@ class Bench:
                    if kn not in NOT_STEP_KERNELS}
         return self.max_over_ranks(dt) / steps * 1e3, kernels
 
-    def timed(self, step, steps, warmup, blocks=1):
+    def timed(self, step, steps, warmup, blocks=1, spread_blocks=None):
         """→ (ms per step, kernels, spread).  blocks = 1: the contract's W warm-up steps + exactly K timed steps.  blocks > 1 (the
         side configs): that many timed blocks of K steps behind one warm-up; the MEDIAN block is reported (its ms and its kernel
-        times), with min/max over the blocks as `spread`."""
+        times), with min/max over the blocks as `spread`.  `spread_blocks` more blocks of K steps follow the reported one(s) and
+        feed ONLY the spread (the main line: its value is the contract's single block, its roofline says how far two more moved)."""
+        if spread_blocks is None:
+            spread_blocks = 2 if blocks == 1 else 0
         self._warm(step, warmup)
         runs = [self._block(step, steps) for _ in range(blocks)]
+        more = [self._block(step, steps) for _ in range(spread_blocks)]
+        every = runs + more
         runs.sort(key=lambda r: r[0])
         ms, kernels = runs[len(runs) // 2]
-        return ms, kernels, {"ms_min": runs[0][0], "ms_max": runs[-1][0], "blocks": blocks, "steps_per_block": steps}
+        return ms, kernels, {"ms_min": min(r[0] for r in every), "ms_max": max(r[0] for r in every), "blocks": len(every), "steps_per_block": steps,
+                             "block_kernels": [r[1] for r in every]}
 
     def cold(self, step):
         """wall time of the FIRST execution of a query shape in this process (no plan hint, no remembered join form)"""
@@ -264,6 +376,23 @@ def roofline(algo_bytes, kernels, prefixes, phys_bytes=None, extra=None):
     if extra:
         out.update(extra)
     return out
+
+
+def attach_spread(res):
+    """roofline.kernel_ms_min / _max (and frac_min / frac_max): the summed HIP-event time of the roofline's kernels in EVERY timed
+    block of the config, not only the reported (median) one — three boxes disagreed by 8 % on the headline kernel last round"""
+    roof = res["roofline"]
+    blocks = res["spread"].pop("block_kernels", None)
+    names = [k for k in roof.get("kernel", "").split("+") if k]
+    if not blocks or not names or not roof.get("kernel_ms_per_step"):
+        return
+    kms = [sum(b[k]["ms_per_step"] for k in names if k in b) for b in blocks]
+    kms = [x for x in kms if x > 0]
+    if not kms:
+        return
+    roof["kernel_ms_min"], roof["kernel_ms_max"], roof["kernel_ms_blocks"] = min(kms), max(kms), len(kms)
+    roof["frac_min"] = roof["frac"] * roof["kernel_ms_per_step"] / max(kms)
+    roof["frac_max"] = roof["frac"] * roof["kernel_ms_per_step"] / min(kms)
 
 
 def attach_traffic(roof, config_name):
@@ -304,16 +433,16 @@ def agg_shape(name, total, random_keys=False, groups=None):
     key_mod = lambda m: binop(col(0), Operator.Modulos, lit_i64(m))
     lt = lambda limit: binop(col(0), Operator.Lt, lit_i64(limit))
     if groups is not None:      # many distinct keys: key = a random Int64 column in [0, groups)
-        return dict(cols=[("k", 1, 7, groups, 0, "i64"), ("v", 2, 3, 1, 0, "f64")], aggs=five(1), key=col(0), pred=None, bpr=16.0,
+        return dict(cols=[("k", 1, 7, groups, 0, "i64"), ("v", 2, 3, 1, 0, "f64")], aggs=five(1), key=col(0), pred=None, bpr=16.0, full=(groups, 1),
                     text=f"select count(v),sum(v),avg(v),min(v),max(v) from t group by k; k random in [0, {groups})")
     if name == "v":             # the headline / C3: Float64 values
-        return dict(cols=[idc, ("v", 2, 3, 1, 0, "f64")], aggs=five(1), key=key_mod(1024), pred=lt, bpr=16.0,
+        return dict(cols=[idc, ("v", 2, 3, 1, 0, "f64")], aggs=five(1), key=key_mod(1024), pred=lt, bpr=16.0, full=(1024, 1),
                     text="select count(v),sum(v),avg(v),min(v),max(v) from t{w} group by id % 1024; t(id Int64, v Float64)")
     if name == "age":           # north_star's literal "10^9 Int64 rows": Int64 values (`val as f64` per row, sum.rs:86-101)
-        return dict(cols=[idc, ("age", 1, 2, 60, 18, "i64")], aggs=five(1), key=key_mod(1024), pred=lt, bpr=16.0,
+        return dict(cols=[idc, ("age", 1, 2, 60, 18, "i64")], aggs=five(1), key=key_mod(1024), pred=lt, bpr=16.0, full=(1024, 1),
                     text="select count(age),sum(age),avg(age),min(age),max(age) from t{w} group by id % 1024; t(id Int64, age Int64)")
     if name == "id":            # SURVEY §8d's single-column variant: key, predicate and value are ONE Int64 column = 8 B/row
-        return dict(cols=[idc], aggs=five(0), key=key_mod(1024), pred=lt, bpr=8.0,
+        return dict(cols=[idc], aggs=five(0), key=key_mod(1024), pred=lt, bpr=8.0, full=(1024, 0),
                     text="select count(id),sum(id),avg(id),min(id),max(id) from t{w} group by id % 1024; t(id Int64)")
     if name == "three":         # C1's query shape (src/main.rs:36-40) at scale: three DIFFERENT value columns
         return dict(cols=[idc, ("age", 1, 2, 60, 18, "i64"), ("score", 2, 3, 1, 0, "f64")], aggs=[(AGG.Count, 0), (AGG.Sum, 1), (AGG.Avg, 2)],
@@ -425,6 +554,56 @@ def parity_aggregate(B, st, sample_rows):
     return {"rows": m, "ok": ok, "groups": int(e.shape[0]), "tolerance": "counts exact, f64 rtol 1e-9"}, cpu
 
 
+def parity_aggregate_full(B, st, threads):
+    """EVERY row of the config (task 1): the device columns are downloaded in chunks of 2^27 rows and aggregated on the host
+    by oracle/nqe_oracle.cpp: orc_grouped_parallel (per-thread direct-mapped tables over row ranges — checked against the
+    reference-faithful port in tests/test_oracle_golden.py::test_parallel_grouped_form_matches_the_port), the chunks merged, and every
+    group compared with the GPU's result over the whole table: keys and counts exact, min / max exact, sum / avg within 1e-9."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    sh, n = st["sh"], st["n"]
+    modulus, vcol = sh["full"]
+    limit = int(st["total"] * B.args.pass_frac) if st["use_pred"] else None
+    t0 = time.perf_counter()
+    parts, cpu_s = [], 0.0
+    for lo in range(0, n, 1 << 27):
+        hi = min(n, lo + (1 << 27))
+        ids = st["tens"][0][lo:hi].cpu().numpy()
+        v = ids if vcol == 0 else st["tens"][vcol][lo:hi].cpu().numpy()
+        t1 = time.perf_counter()
+        parts.append(orc.grouped_parallel(ids, v, limit, modulus, threads))
+        cpu_s += time.perf_counter() - t1
+        del ids, v
+    exp = orc.merge_grouped(parts)
+    pred = sh["pred"](limit).flatten(st["fields"]) if st["use_pred"] else None
+    out, keys = B.ctx.aggregate(st["table"], sh["aggs"], group_nodes=st["key"], pred_nodes=pred, with_keys=True)
+    cnt, sm, avg, mn, mx = [c.to_numpy() for c in out.to_host()]
+    k = keys.to_host()[0].to_numpy()
+    live = np.nonzero(exp[:, 0] > 0)[0]
+    ok = bool(len(k) == len(live) and (k == live).all())
+    if ok:
+        e = exp[live]
+        ok = bool((cnt.astype(np.float64) == e[:, 0]).all() and np.allclose(sm, e[:, 1], rtol=1e-9, atol=0) and np.allclose(avg, e[:, 1] / e[:, 0], rtol=1e-9, atol=0)
+                  and (mn == e[:, 2]).all() and (mx == e[:, 3]).all())
+    return {"rows": n, "ok": ok, "groups": int(len(live)), "tolerance": "keys, counts, min, max exact; sum, avg rtol 1e-9",
+            "against": f"orc_grouped_parallel over the downloaded device columns, {threads} threads (itself checked against the single-threaded port)",
+            "cpu_seconds": r4(cpu_s), "seconds": r4(time.perf_counter() - t0)}
+
+
+def parity_aggregate_both(B, st, sample_rows, threads):
+    """→ (parity_checked, cpu_baseline): the reference-faithful port on a sample (the CPU baseline, and the pin of the semantics) AND,
+    for the shapes the parallel CPU form covers, every row of the config at full size.  `rows` is what was compared with an independent
+    CPU result: the full row count when the full-size check ran."""
+    par, cpu = parity_aggregate(B, st, sample_rows)
+    if "full" in st["sh"] and st["n"] > par["rows"] and B.world == 1:
+        full = parity_aggregate_full(B, st, threads)
+        par = {"rows": full["rows"], "ok": bool(par["ok"] and full["ok"]), "groups": full["groups"], "tolerance": full["tolerance"], "full_size": full,
+               "port_sample": {"rows": par["rows"], "ok": par["ok"], "groups": par["groups"]}}
+    return par, cpu
+
+
 def cpu_multicore_headline(st, threads, sample_rows):
     """SURVEY 8d's optional last row: an OPTIMISED multi-core CPU form of the headline (oracle/nqe_oracle.cpp: orc_headline_parallel — per-thread
     direct-mapped tables over contiguous row ranges, merged), so that the GPU/CPU ratio is not only against the reference's naive
@@ -489,8 +668,8 @@ def parity_c2(B, st, sample_rows):
     from oracle import oracle as orc
 
     m = min(st["n"], sample_rows)
-    ids = (orc.synth_fill(1, 1, 0, m, st["total"], 0) if st["random_ids"] else orc.synth_fill(0, 0, 0, m)).view(np.int64)
-    x = orc.synth_fill(1, 2, 0, m, 60, 18).view(np.int64)
+    ids = (orc.synth_fill_mt(1, 1, 0, m, st["total"], 0) if st["random_ids"] else orc.synth_fill_mt(0, 0, 0, m)).view(np.int64)
+    x = orc.synth_fill_mt(1, 2, 0, m, 60, 18).view(np.int64)
     h = orc.upload([[Column.from_numpy(ids), Column.from_numpy(x)]])
     pred = binop(col(0), Operator.Lt, lit_i64(st["total"] // 2 if st["random_ids"] else m // 2)).flatten(st["fields"])
     t0 = time.perf_counter()
@@ -544,8 +723,8 @@ def parity_c2_tree(B, st, sample_rows):
     from oracle import oracle as orc
 
     m = min(st["n"], sample_rows)
-    ids = orc.synth_fill(0, 0, 0, m).view(np.int64)
-    v = orc.synth_fill(2, 3, 0, m).view(np.float64)
+    ids = orc.synth_fill_mt(0, 0, 0, m).view(np.int64)
+    v = orc.synth_fill_mt(2, 3, 0, m).view(np.float64)
     h = orc.upload([[Column.from_numpy(ids), Column.from_numpy(v)]])
     t0 = time.perf_counter()
     sel = orc.selection(h, st["pred"], raw=True)
@@ -603,7 +782,7 @@ def wl_c4(B, rows, nb, variant, steps, warmup, gather=False, blocks=1, cold=Fals
     # the first HashJoin::execute of the process: build + probe, nothing remembered
     cold_ms = B.cold(lambda: B.ctx.hash_join(dim, fact, 0, 0)) if cold else None
     # build (HashJoin::build, hash_join.rs:124-166): timed on its own — replicated on every rank, once per query
-    build_ms, _, _ = B.timed(lambda: B.ctx.hash_join_build(dim, 0), max(3, steps // 2), 1)
+    build_ms, _, _ = B.timed(lambda: B.ctx.hash_join_build(dim, 0), max(3, steps // 2), 1, spread_blocks=0)
     jt = B.ctx.hash_join_build(dim, 0)
 
     def probe():
@@ -915,7 +1094,7 @@ def compact(res):
     out = {"ms": r4(res["ms_per_step"]), "ms_min": r4(res["spread"]["ms_min"]), "ms_max": r4(res["spread"]["ms_max"]),
            "kernel_ms": r4(roof["kernel_ms_per_step"]), "frac": r4(roof["frac"]), "frac_physical": r4(roof.get("frac_physical")),
            "rows": res["rows_per_gpu"]}
-    for k in ("frac_8d", "frac_end_to_end", "build_ms", "execute_call_ms", "two_pass_ms", "execute_over_two_pass", "traffic_ratio"):
+    for k in ("kernel_ms_min", "kernel_ms_max", "frac_8d", "frac_end_to_end", "build_ms", "execute_call_ms", "two_pass_ms", "execute_over_two_pass", "traffic_ratio"):
         if roof.get(k) is not None:
             out[k] = r4(roof[k])
     if res.get("cold_ms") is not None:
@@ -945,13 +1124,30 @@ def finish_line(out):
     out.pop("summary", None)
     out["summary"] = summary_of(out)
     line = json.dumps(out, separators=(",", ":"))
-    for k in ("rows", "ms_min", "ms_max", "cpu_rows_per_s", "cold_ms", "kernel_ms"):
+    for k in ("rows", "ms_min", "ms_max", "cpu_rows_per_s", "cold_ms", "kernel_ms_min", "kernel_ms_max", "kernel_ms"):
         if len(line) <= LINE_LIMIT:
             break
         for c in out.get("configs", {}).values():
             c.pop(k, None)
         line = json.dumps(out, separators=(",", ":"))
     return line
+
+
+def sharded_headline_check(B, st):
+    """no oracle at this size: a size-independent check of the SHARDED result on every rank — ids are row numbers, so group g of
+    `id % 1024` holds exactly the ids g, g + 1024, ... below total/2, and every value lies in [0, 100)"""
+    import numpy as np
+
+    rs, keys = B.comm.sharded_aggregate(st["table"], st["sh"]["aggs"], group_nodes=st["key"], pred_nodes=st["sh"]["pred"](st["total"] // 2).flatten(st["fields"]))
+    cols = [c.to_numpy() for c in rs.to_host()]
+    kk = keys.to_host()[0].to_numpy()
+    half = st["total"] // 2
+    exp_cnt = np.array([(half - g + 1023) // 1024 if g < half else 0 for g in range(1024)], dtype=np.uint64)
+    ok = bool(len(kk) == 1024 and (kk == np.arange(1024)).all() and (cols[0] == exp_cnt).all() and (cols[3] >= 0).all() and (cols[4] < 100).all()
+              and np.allclose(cols[2], cols[1] / cols[0].astype(np.float64), rtol=1e-12))
+    okt = B.torch.tensor([1 if ok else 0], dtype=B.torch.int64, device=B.coll_dev)
+    B.dist.all_reduce(okt, op=B.dist.ReduceOp.MIN)
+    return {"ok": bool(int(okt.item())), "what": "sharded headline on every rank: 1024 keys, analytic counts, avg = sum / count, min/max in [0, 100)"}
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -981,6 +1177,7 @@ def main():
                     "c3": 10**9}.get(wl, 10**8)
     n = args.rows or default_rows
     want_cpu = world == 1 and not args.no_cpu_baseline
+    par_threads = args.cpu_threads if args.cpu_threads > 0 else max(1, min(64, os.cpu_count() or 1))  # the full-size CPU form of the parity checks
     csteps, cwarm, cblocks = max(3, min(args.steps, 10)), 2, 3  # the side configs: three blocks of a few steps each
 
     # ---- the main line
@@ -989,31 +1186,32 @@ def main():
     if wl in agg_shapes:
         shape, filt = agg_shapes[wl]
         res, st = wl_aggregate(B, n, filt, args.random_keys, args.steps, args.warmup, shape=shape, cold=True)
-        par = parity_aggregate(B, st, args.cpu_sample_rows if wl == "headline" else 20_000_000) if want_cpu else None
+        par = parity_aggregate_both(B, st, args.cpu_sample_rows if wl == "headline" else 20_000_000, par_threads) if want_cpu else None
         name = {"headline_int64": "headline_int64_values", "headline_single": "headline_single_column", "agg3": "agg_three_value_columns", "agg_readme": "agg_readme_shape",
                 "tree_pred": "agg_tree_predicate"}.get(wl, wl) + ("_random_keys" if args.random_keys else "")
     elif wl == "agg_groups":
         res, st = wl_aggregate(B, n, False, False, args.steps, args.warmup, groups=args.groups)
-        par = parity_aggregate(B, st, min(args.cpu_sample_rows, 20_000_000)) if want_cpu else None
+        par = parity_aggregate_both(B, st, min(args.cpu_sample_rows, 20_000_000), par_threads) if want_cpu else None
         name = f"agg_{args.groups}_groups"
     elif wl == "c2_tree":
         res, st = wl_c2_tree(B, n, args.steps, args.warmup)
-        par = parity_c2_tree(B, st, 20_000_000) if want_cpu else None
+        par = parity_c2_tree(B, st, n) if want_cpu else None
         name = "c2_expression_trees"
     elif wl in ("c2", "c2_random"):
         res, st = wl_c2(B, n, args.steps, args.warmup, random_ids=wl == "c2_random")
-        par = parity_c2(B, st, args.cpu_sample_rows) if want_cpu else None
+        par = parity_c2(B, st, n) if want_cpu else None
         name = "c2" if wl == "c2" else "c2_random_ids"
     else:
         variant = {"c4": "dense", "c4_sparse": "sparse", "c4_wide": "wide", "c4_dup": "dup", "c4_partial": "partial"}[wl]
         res, st = wl_c4(B, n, args.dim_rows, variant, args.steps, args.warmup, gather=args.gather, immutable=args.immutable)
-        par = parity_c4(B, st, 5_000_000) if want_cpu else None
+        par = parity_c4(B, st, n if (wl == "c4" and args.dim_rows <= 10**6) else 5_000_000) if want_cpu else None
         name = {"c4": "c4", "c4_sparse": "c4_sparse_keys", "c4_wide": "c4_wide_payload", "c4_dup": "c4_dup_keys", "c4_partial": "c4_partial_match"}[wl]
         if args.immutable and wl == "c4":
             name = "c4_shared_probe_columns"
         if wl == "c4" and args.dim_rows != 10**6:
             name = {10**7: "c4_dim_1e7", 10**8: "c4_dim_1e8"}.get(args.dim_rows, name)
     attach_traffic(res["roofline"], name)
+    attach_spread(res)
     n_main = res["rows_per_gpu"]
     details = {"main": {"name": name, "workload": res["workload"], "kernels": res["roofline"].pop("kernels")}, "configs": {}}
     res["roofline"].pop("note", None)
@@ -1025,8 +1223,6 @@ def main():
     }
     if B.reserve_ms is not None:
         out["reserved"] = {"GB": args.reserve_gb, "ms": r4(B.reserve_ms)}  # nqe_ctx_reserve at start-up: outputs and scratch come from this block
-    if B.reserve_ms is not None:
-        out["reserved"] = {"GB": args.reserve_gb, "ms": r4(B.reserve_ms)}  # nqe_ctx_reserve at start-up: outputs and scratch come from this block
     if res.get("cold_ms") is not None:
         out["cold_ms"] = r4(res["cold_ms"])  # the first execution of the query in the process (run_sql is one-shot: db.rs:24-37)
     if B.host_transport:
@@ -1034,29 +1230,17 @@ def main():
         out["exchange"] = ("nqe_sharded_* (C ABI) over the HOST-STAGED transport (gloo; NQE_BENCH_TRANSPORT=host), every rank on device "
                            f"{B.local_rank}: a functional run of the multi-rank code, NOT a scaling measurement")
     elif B.distributed:
-        out["rccl_ranks"] = B.dist.get_world_size()
+        out["rccl_ranks"] = B.comm.world  # the library's own communicator (asserted == --gpus when it was created)
         out["rccl_version"] = B.capi.Comm.rccl_version()
         out["exchange"] = "nqe_sharded_* (C ABI) on RCCL, collectives on the context's stream"
+    if B.preflight:
+        out["preflight"] = {k: B.preflight[k] for k in ("ok", "ranks", "seconds")}
     if par:
         out["parity_checked"], out["cpu_baseline"] = par
     if par and wl == "headline" and not args.random_keys and args.cpu_threads != 0:
         out["cpu_optimised_multicore"] = cpu_multicore_headline(st, args.cpu_threads if args.cpu_threads > 0 else min(64, os.cpu_count() or 1), args.cpu_sample_rows)
     if B.comm is not None and wl == "headline" and not args.random_keys and args.pass_frac == 0.5:
-        # no oracle at this size: a size-independent check of the SHARDED result on every rank — ids are row numbers, so group g of
-        # `id % 1024` holds exactly the ids g, g + 1024, ... below total/2, and every value lies in [0, 100)
-        import numpy as np
-
-        rs, keys = B.comm.sharded_aggregate(st["table"], st["sh"]["aggs"], group_nodes=st["key"],
-                                            pred_nodes=st["sh"]["pred"](st["total"] // 2).flatten(st["fields"]))
-        cols = [c.to_numpy() for c in rs.to_host()]
-        kk = keys.to_host()[0].to_numpy()
-        half = st["total"] // 2
-        exp_cnt = np.array([(half - g + 1023) // 1024 if g < half else 0 for g in range(1024)], dtype=np.uint64)
-        ok = bool(len(kk) == 1024 and (kk == np.arange(1024)).all() and (cols[0] == exp_cnt).all() and (cols[3] >= 0).all() and (cols[4] < 100).all()
-                  and np.allclose(cols[2], cols[1] / cols[0].astype(np.float64), rtol=1e-12))
-        okt = B.torch.tensor([1 if ok else 0], dtype=B.torch.int64, device=B.coll_dev)
-        B.dist.all_reduce(okt, op=B.dist.ReduceOp.MIN)
-        out["result_check"] = {"ok": bool(int(okt.item())), "what": "sharded headline on every rank: 1024 keys, analytic counts, avg = sum / count, min/max in [0, 100)"}
+        out["result_check"] = sharded_headline_check(B, st)
     main_state = st if (wl == "headline" and not args.no_configs and not args.random_keys and world == 1) else None
     del st
 
@@ -1073,6 +1257,7 @@ def main():
                 return
             r, s = fn()
             attach_traffic(r["roofline"], cname)
+            attach_spread(r)
             if parity and want_cpu:
                 r["parity_checked"], r["cpu_baseline"] = parity(s)
             del s
@@ -1082,8 +1267,9 @@ def main():
             cfg[cname] = compact(r)
 
         kw = dict(blocks=cblocks, cold=True)
-        pa = lambda rows: (lambda s: parity_aggregate(B, s, rows))
+        pa = lambda rows: (lambda s: parity_aggregate_both(B, s, rows, par_threads))  # + every row at full size where the parallel CPU form covers the shape
         pj = lambda s: parity_c4(B, s, 5_000_000)
+        pj_full = lambda s: parity_c4(B, s, s["n"])  # C4 itself: all 10^8 output rows against the port (single thread, ~25 s)
         # (NQE_BENCH_MULTI_CONFIGS with NQE_FORCE_EXCHANGE: the multi-rank block on one rank through RCCL — a dry run of that code)
         if world == 1 and not (B.distributed and os.environ.get("NQE_BENCH_MULTI_CONFIGS")):
             add("c3", lambda: wl_aggregate(B, n, False, False, csteps, cwarm, **kw), pa(20_000_000))
@@ -1095,10 +1281,10 @@ def main():
             add("agg_readme_shape", lambda: wl_aggregate(B, n, False, False, csteps, cwarm, shape="readme", **kw), pa(20_000_000))
             add("headline_nullable", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, shape="vnull", **kw), pa(20_000_000))
             add("agg_tree_predicate", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, shape="tree", **kw), pa(20_000_000))
-            add("c2", lambda: wl_c2(B, 10**8, csteps, cwarm, **kw), lambda s: parity_c2(B, s, 20_000_000))
-            add("c2_random_ids", lambda: wl_c2(B, 10**8, csteps, cwarm, random_ids=True, **kw), lambda s: parity_c2(B, s, 20_000_000))
-            add("c2_expression_trees", lambda: wl_c2_tree(B, 10**8, csteps, cwarm, **kw), lambda s: parity_c2_tree(B, s, 20_000_000))
-            add("c4", lambda: wl_c4(B, 10**8, 10**6, "dense", csteps, cwarm, **kw), pj)
+            add("c2", lambda: wl_c2(B, 10**8, csteps, cwarm, **kw), lambda s: parity_c2(B, s, s["n"]))
+            add("c2_random_ids", lambda: wl_c2(B, 10**8, csteps, cwarm, random_ids=True, **kw), lambda s: parity_c2(B, s, s["n"]))
+            add("c2_expression_trees", lambda: wl_c2_tree(B, 10**8, csteps, cwarm, **kw), lambda s: parity_c2_tree(B, s, s["n"]))
+            add("c4", lambda: wl_c4(B, 10**8, 10**6, "dense", csteps, cwarm, **kw), pj_full)
             # the same join over a probe table the caller declared immutable (NQE_TABLE_IMMUTABLE): every probe row matches, so the output's
             # probe-side columns are the probe table's own buffers and only the keys are read and the build payload written
             add("c4_shared_probe_columns", lambda: wl_c4(B, 10**8, 10**6, "dense", csteps, cwarm, immutable=True, **kw), pj)
@@ -1115,6 +1301,24 @@ def main():
             # the headline without its exchange (every rank aggregates its shard only): step time with and without
             add("headline_local_only", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, exchange=False, blocks=cblocks))
             out["exchange_ms_per_step"] = r4(out["ms_per_step"] - cfg["headline_local_only"]["ms"])
+            # BASELINE's metric as worded — "10^9-row filter->hash-agg, 1/2/4/8 MI355X": the SAME 10^9 rows (NQE_BENCH_STRONG_ROWS for
+            # functional runs) split over the ranks, exchange included = STRONG scaling, beside the weak-scaled main line (10^9 per GPU)
+            strong_total = int(os.environ.get("NQE_BENCH_STRONG_ROWS", 10**9))
+            strong_state = {}
+
+            def strong():
+                r, s_ = wl_aggregate(B, strong_total // world, True, False, csteps, cwarm, blocks=cblocks)
+                if args.pass_frac == 0.5:
+                    strong_state["check"] = sharded_headline_check(B, s_)
+                return r, s_
+
+            add("headline_strong", strong)
+            if "headline_strong" in cfg:
+                hs = cfg["headline_strong"]
+                hs.update({"scaling": "strong", "total_rows": strong_total // world * world, "rows_per_s_all_gpus": r4(strong_total // world * world / (hs["ms"] * 1e-3)),
+                           "result_check": strong_state.get("check")})
+                if strong_state.get("check") and not strong_state["check"]["ok"]:
+                    out.setdefault("result_check", {"ok": False, "what": "strong-scaled headline"})["ok"] = False
             # C5: the C4 join strong-scaled — build replicated, the fact rows (10^8; NQE_BENCH_C5_ROWS for functional runs) range-split
             # over the ranks.  The consumer-local form (gather = 0: every rank keeps its own output rows, rank order == row order) is
             # C5's headline — SURVEY 8e: the ordered all-gather of 3.2 GB is bound by one xGMI link per peer pair and dominates the probe

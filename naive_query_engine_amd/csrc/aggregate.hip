@@ -1462,6 +1462,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             mix(&a.pred, sizeof(a.pred));
             mix(&a.pred_src, sizeof(a.pred_src));
         }
+        if (jit_whole) // the predicate lives in the specialised kernel only (pred_mode 0): its nodes tell this shape from the unfiltered query
+            for (int i = 0; i < pred_nodes; ++i) {
+                mix(&pred[i], offsetof(nqe_expr_node, value));
+                if (!(pred[i].kind == NQE_EXPR_LITERAL && pred[i].dtype == NQE_UTF8)) mix(&pred[i].value, sizeof(pred[i].value));
+            }
         for (int c : plan.val_cols) {
             const DevColumn &dc = in->cols[size_t(c)];
             const void *vp = dc.values ? dc.values->ptr : nullptr, *vv = dc.valid();
@@ -1527,7 +1532,12 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     bool range_sampled = false;
     const bool simple_mod_key = a.key.nops == 1 && a.key.op[0] == NQE_OP_MODULOS && !a.key.lit_left[0] && (a.key.op_dtype[0] == NQE_INT64 || a.key.op_dtype[0] == NQE_UINT64) &&
                                 a.key.aux[0].abs_lit > 1;
-    if (grouped && hint_key && !no_sample && in->rows >= KEY_SAMPLE_MIN_ROWS && a.pred_mode == 0 && a.key_src.values && !a.key_src.valid && !utf8_key &&
+    // (the tiers the sample may start in exist for the streaming kernel's shapes only: at least one value column, every one of them
+    // 8-byte words — `select k from t group by k` and count() over a Utf8 / Boolean column go through the general kernel, which takes
+    // neither key subsets nor a densely written table)
+    bool sample_shape = V >= 1;
+    for (int c : plan.val_cols) sample_shape = sample_shape && is_word_type(in->cols[size_t(c)].dtype) && in->cols[size_t(c)].values;
+    if (grouped && hint_key && !no_sample && sample_shape && in->rows >= KEY_SAMPLE_MIN_ROWS && a.pred_mode == 0 && !jit_whole && a.key_src.values && !a.key_src.valid && !utf8_key &&
         (a.key_src.dtype == NQE_INT64 || a.key_src.dtype == NQE_UINT64) &&
         (a.key.nops == 0 || (simple_mod_key && a.key.aux[0].abs_lit > range_limit)) && // (`col % m`, m within a workgroup table: nothing to find out)
         (no_hints_env || (ctx->agg_hints.find(hint_key) == ctx->agg_hints.end() && ctx->agg_key_ranges.find(hint_key) == ctx->agg_key_ranges.end()))) {
@@ -1632,7 +1642,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         bool three = three_on && V == 3 && nv_step == NV && grouped && !partition_mode && subsets_log2 == 0 && (a.pred_mode == 0 || a.pred_mode == 1);
         // (min / max of the LAST column only: its instance carries one pair of min / max arrays — count(id), sum(age), …, max(score), min(score))
         for (int j = 0; three && j < V; ++j) three = !plan.need_minmax[size_t(j)] || j == V - 1;
-        bool three_redo = false;
+        bool three_redo = false, dense_redo = false;
         // an odd number of value columns in passes of two leaves one pass with a single column: let it be the FIRST column when that
         // one is the key column itself — its pass then reads 8 B/row through the single-load instance instead of 16
         const bool first_alone = !three && nv_step == 2 && V >= 3 && (V % 2) == 1 && grouped && key_col >= 0 && !utf8_key && plan.val_cols[0] == key_col &&
@@ -1844,9 +1854,10 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                         int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
                         W = int((in->rows + chunk - 1) / chunk);
                         // one value column, integer keys: 12-byte tuples {value, int32 key} unless a key was seen not to fit
-                        const bool k32 = a.nv == 1 && !key32_failed;
-                        // key-range partitions (aggregate_common.hpp: SlabArgs::range_span): 256 tables (512 beyond 2^20 values) of ceil(span / parts) <= 4096 slots
-                        const bool range_part = k32 && dense && range_part_ok && part_span != 0 && part_span <= (uint64_t(PARTS) << 12);
+                        // key-range partitions (aggregate_common.hpp: SlabArgs::range_span): 256 tables (512 beyond 2^20 values) of ceil(span / parts) <= 4096 slots;
+                        // their tuples hold key - range_min, which fits 32 bits whatever the keys' magnitude
+                        const bool range_part = a.nv == 1 && dense && range_part_ok && part_span != 0 && part_span <= (uint64_t(PARTS) << 12);
+                        const bool k32 = a.nv == 1 && (!key32_failed || range_part);
                         int sparts_log2 = slab_parts_log2;
                         if (range_part) sparts_log2 = part_span <= (uint64_t(256) << 12) ? 8 : PARTS_LOG2;
                         const int used_parts = 1 << sparts_log2;
@@ -2058,7 +2069,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                     // the general kernel's PLAIN variant reads predicate and values as bare 8-byte words: not for a Boolean
                     // predicate column (bits) nor nullable values (found by the differential fuzzer: a bitmap predicate with
                     // a key shape the fast kernel does not cover was read as words)
-                    if (dense) fail(NQE_ERR_NOT_SUPPORTED, "internal: the hashed aggregate kernel was handed a densely laid out group table");
+                    if (dense) { // a pass the partition kernels do not cover under a densely written table: the hashed table, the attempt again
+                        dense_ok = false;
+                        dense_redo = true;
+                        break;
+                    }
                     launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain && !vnull && !bitmap_pred), dim3(std::min(grid, ctx->num_cus)), dim3(AGG_BLOCK), shmem, ka, tb.g,
                            ctx->d_flags);
                 }
@@ -2105,7 +2120,8 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             flags_reset(ctx);
             continue;
         }
-        if (slab_oom || three_redo) continue;
+        if (dense_redo) flags_reset(ctx);
+        if (slab_oom || three_redo || dense_redo) continue;
         Collected pre;
         AggResult ranked;
         if (grouped && !tb.g.dense_count && tb.g.cap <= RANK_MAX_CAP) {

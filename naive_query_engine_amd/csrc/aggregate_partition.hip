@@ -580,9 +580,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
             if (at < cap) {
                 uint64_t *dst = sa.slabs + ((size_t(blockIdx.x) * size_t(parts) + p) * size_t(cap) + at) * TW;
                 if (K32) {
-                    if (int64_t(int32_t(uint32_t(k))) != int64_t(k)) atomicOr(&flags[NQE_FLAG_KEY32_OVERFLOW], 1);
+                    // key-range partitions store d = key - range_min (< span <= PARTS << 12: always 32 bits, whatever the keys' magnitude);
+                    // hashed partitions the key itself, and a key outside int32 asks for the 16-byte tuple form
+                    const uint64_t kw = range_part ? k - uint64_t(sa.range_min) : k;
+                    if (!range_part && int64_t(int32_t(uint32_t(k))) != int64_t(k)) atomicOr(&flags[NQE_FLAG_KEY32_OVERFLOW], 1);
                     Tuple12 t;
-                    t.key = int32_t(uint32_t(k));
+                    t.key = int32_t(uint32_t(kw));
                     t.val = v0;
                     reinterpret_cast<Tuple12 *>(sa.slabs)[(size_t(blockIdx.x) * size_t(parts) + p) * size_t(cap) + at] = t;
                 } else if (TW == 2) {
@@ -920,7 +923,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_direct_kernel(Agg
             double x[SU], cmn[SU], cmx[SU];
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
-                slot[u] = st.live[u] ? uint32_t(uint64_t(int64_t(st.k32[u]) - sa.range_min) >> parts_log2) : 0u; // (< W: the scatter checked the range)
+                slot[u] = st.live[u] ? uint32_t(st.k32[u]) >> parts_log2 : 0u; // the tuple holds key - range_min (< span: the scatter checked the range, so slot < W)
                 x[u] = VF64 ? u2d(st.vw[u]) : word_as_f64(st.vw[u], vdt);
                 cmn[u] = lmn[slot[u]];
                 cmx[u] = lmx[slot[u]];

@@ -1369,21 +1369,31 @@ int orc_synth_fill(int32_t kind, uint64_t seed, int64_t first_row, int64_t n, ui
 // `select count(v), sum(v), min(v), max(v) from t where id < limit group by id % modulus` over plain columns: `threads` workers over
 // contiguous row ranges, each with its own direct-mapped table of `modulus` groups (modulus <= 65536, id >= 0), merged at the end.
 // out: modulus x {count, sum, min, max} as doubles.  Checked against orc_aggregate by tests/test_oracle_golden.py.
-int orc_headline_parallel(const int64_t *ids, const double *v, int64_t n, int64_t limit, int64_t modulus, int32_t threads, double *out) {
+// `v_dtype`: NQE_FLOAT64, or NQE_INT64 / NQE_UINT64 values accumulated `as f64` (sum.rs:86-101); `has_limit` 0: no predicate (C3);
+// modulus <= 2^21 (the many-group configs: key = a column in [0, G) and modulus = G).  ids must be >= 0 (then the reference's truncated
+// signed `%` is the unsigned one).  NaN-free values (the synthetic columns): min / max are plain compares from -DBL_MAX / DBL_MAX.
+int orc_grouped_parallel(const int64_t *ids, const void *v, int32_t v_dtype, int64_t n, int32_t has_limit, int64_t limit, int64_t modulus, int32_t threads,
+                         double *out) {
     return guarded([&] {
-        if (modulus <= 0 || modulus > 65536 || threads < 1 || n < 0) fail(NQE_ERR_INVALID_ARGUMENT, "orc_headline_parallel: bad arguments");
+        if (modulus <= 0 || modulus > (int64_t(1) << 21) || threads < 1 || n < 0) fail(NQE_ERR_INVALID_ARGUMENT, "orc_grouped_parallel: bad arguments");
+        if (v_dtype != NQE_FLOAT64 && v_dtype != NQE_INT64 && v_dtype != NQE_UINT64) fail(NQE_ERR_INVALID_ARGUMENT, "orc_grouped_parallel: value type");
         struct Acc { uint64_t cnt; double sum, mn, mx; };
         std::vector<std::vector<Acc>> part(size_t(threads), std::vector<Acc>(size_t(modulus), Acc{0, 0.0, DBL_MAX, -DBL_MAX}));
+        std::vector<int> negative(size_t(threads), 0);
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; ++t)
             pool.emplace_back([&, t] {
                 Acc *a = part[size_t(t)].data();
                 const int64_t lo = n * t / threads, hi = n * (t + 1) / threads;
+                const double *vf = static_cast<const double *>(v);
+                const int64_t *vi = static_cast<const int64_t *>(v);
+                const uint64_t *vu = static_cast<const uint64_t *>(v);
                 for (int64_t r = lo; r < hi; ++r) {
                     const int64_t id = ids[r];
-                    if (id >= limit) continue;
+                    if (id < 0) { negative[size_t(t)] = 1; continue; }
+                    if (has_limit && id >= limit) continue;
                     Acc &g = a[uint64_t(id) % uint64_t(modulus)];
-                    const double x = v[r];
+                    const double x = v_dtype == NQE_FLOAT64 ? vf[r] : v_dtype == NQE_INT64 ? double(vi[r]) : double(vu[r]);
                     g.cnt += 1;
                     g.sum += x;
                     g.mn = x < g.mn ? x : g.mn;
@@ -1391,6 +1401,8 @@ int orc_headline_parallel(const int64_t *ids, const double *v, int64_t n, int64_
                 }
             });
         for (auto &th : pool) th.join();
+        for (int t = 0; t < threads; ++t)
+            if (negative[size_t(t)]) fail(NQE_ERR_INVALID_ARGUMENT, "orc_grouped_parallel: negative id");
         for (int64_t k = 0; k < modulus; ++k) {
             Acc m{0, 0.0, DBL_MAX, -DBL_MAX};
             for (int t = 0; t < threads; ++t) {
@@ -1403,6 +1415,27 @@ int orc_headline_parallel(const int64_t *ids, const double *v, int64_t n, int64_
             out[4 * k] = double(m.cnt); out[4 * k + 1] = m.sum; out[4 * k + 2] = m.mn; out[4 * k + 3] = m.mx;
         }
     });
+}
+
+int orc_headline_parallel(const int64_t *ids, const double *v, int64_t n, int64_t limit, int64_t modulus, int32_t threads, double *out) {
+    if (modulus > 65536) return guarded([&] { fail(NQE_ERR_INVALID_ARGUMENT, "orc_headline_parallel: bad arguments"); });
+    return orc_grouped_parallel(ids, v, NQE_FLOAT64, n, 1, limit, modulus, threads, out);
+}
+
+// orc_synth_fill on `threads` threads (bench.py / tests: host copies of 10^8..10^9-row synthetic columns in a second, not ten)
+int orc_synth_fill_mt(int32_t kind, uint64_t seed, int64_t first_row, int64_t n, uint64_t modulus, int64_t base, void *out, int32_t threads) {
+    if (threads < 1) threads = 1;
+    std::vector<int> rc(size_t(threads), 0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            const int64_t lo = n * t / threads, hi = n * (t + 1) / threads;
+            rc[size_t(t)] = orc_synth_fill(kind, seed, first_row + lo, hi - lo, modulus, base, static_cast<uint64_t *>(out) + lo);
+        });
+    for (auto &th : pool) th.join();
+    for (int t = 0; t < threads; ++t)
+        if (rc[size_t(t)]) return rc[size_t(t)];
+    return 0;
 }
 
 } // extern "C"

@@ -66,6 +66,8 @@ def lib():
         L.orc_xxhash64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
         L.orc_synth_fill.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, vp]
         L.orc_headline_parallel.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp]
+        L.orc_grouped_parallel.argtypes = [vp, vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, vp]
+        L.orc_synth_fill_mt.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, vp, C.c_int32]
         L.orc_csv_read.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(vp), C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.c_int32]
         L.orc_csv_read.restype = C.c_int
         _lib = L
@@ -248,4 +250,49 @@ def headline_parallel(ids, v, limit: int, modulus: int, threads: int):
     v = np.ascontiguousarray(v, dtype=np.float64)
     out = np.zeros((modulus, 4), dtype=np.float64)
     _check(lib().orc_headline_parallel(ids.ctypes.data, v.ctypes.data, ids.size, limit, modulus, threads, out.ctypes.data))
+    return out
+
+
+
+def grouped_parallel(ids, v, limit, modulus: int, threads: int):
+    """`select count(v), sum(v), min(v), max(v) from t [where id < limit] group by id % modulus` on `threads` threads
+    (orc_grouped_parallel: per-thread direct-mapped tables over row ranges, merged) — the form the full-size parity checks use; it is
+    itself checked against the reference-faithful single-threaded `aggregate` in tests/test_oracle_golden.py.  `v`: float64, int64 or
+    uint64 (accumulated `as f64`); `limit` None: no predicate.  → float64[modulus, 4] = count, sum, min, max per key (count 0: no rows)"""
+    import numpy as np
+
+    from naive_query_engine_amd import DType
+
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    v = np.ascontiguousarray(v)
+    dt = {np.dtype(np.float64): DType.FLOAT64, np.dtype(np.int64): DType.INT64, np.dtype(np.uint64): DType.UINT64}[v.dtype]
+    assert v.size == ids.size
+    out = np.zeros((modulus, 4), dtype=np.float64)
+    _check(lib().orc_grouped_parallel(ids.ctypes.data, v.ctypes.data, int(dt), ids.size, 0 if limit is None else 1, 0 if limit is None else int(limit), modulus, threads,
+                                      out.ctypes.data))
+    return out
+
+
+def merge_grouped(parts):
+    """fold float64[modulus, 4] partials of `grouped_parallel` over disjoint row ranges (counts and sums add; min / max of the extremes)"""
+    import numpy as np
+
+    acc = None
+    for p in parts:
+        if acc is None:
+            acc = p.copy()
+        else:
+            acc[:, 0] += p[:, 0]
+            acc[:, 1] += p[:, 1]
+            acc[:, 2] = np.minimum(acc[:, 2], p[:, 2])
+            acc[:, 3] = np.maximum(acc[:, 3], p[:, 3])
+    return acc
+
+
+def synth_fill_mt(kind: int, seed: int, first_row: int, n: int, modulus: int = 1, base: int = 0, threads: int = 16):
+    """`synth_fill` on several threads → uint64[n]"""
+    import numpy as np
+
+    out = np.empty(n, dtype=np.uint64)
+    _check(lib().orc_synth_fill_mt(kind, seed, first_row, n, modulus, base, out.ctypes.data, threads))
     return out

@@ -70,7 +70,7 @@ def test_every_side_config_has_a_parity_check():
     adds = [l for l in block.splitlines() if l.strip().startswith("add(")]
     assert len(adds) >= 16
     for l in adds:
-        assert l.rstrip().endswith(("pa(20_000_000))", "pa(10_000_000))", "pj)", "parity_c2(B, s, 20_000_000))", "parity_c2_tree(B, s, 20_000_000))", "pj)  # attr spans 2^62: an 8 MB payload table",
+        assert l.rstrip().endswith(("pa(20_000_000))", "pa(10_000_000))", "pj)", "pj_full)", 'parity_c2(B, s, s["n"]))', 'parity_c2_tree(B, s, s["n"]))', "pj)  # attr spans 2^62: an 8 MB payload table",
                                   "parity_c4_property(B, s))")), l
 
 

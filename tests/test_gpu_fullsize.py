@@ -177,3 +177,159 @@ def test_hash_join_1e8_x_1e6_properties(ctx):
         assert ctx.selection(both2, binop(col(0), Operator.NotEq, col(1)).flatten(fields("a", "b"))).num_rows == 0
     finally:
         d.free()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's configs at FULL size against an independent CPU result (task 1): every group of the 10^9-row aggregates,
+# every output row of C2 and C4.  The device columns themselves are downloaded (the CPU sees the very inputs the GPU saw); the
+# aggregates are computed by oracle/nqe_oracle.cpp: orc_grouped_parallel — checked against the reference-faithful single-threaded port
+# in tests/test_oracle_golden.py::test_parallel_grouped_form_matches_the_port — C2 and C4 by the port itself.
+import os
+
+from oracle import oracle as orc
+
+CPU_THREADS = max(1, min(64, os.cpu_count() or 1))
+
+
+def download_words(ctx, dtype, ptr, lo, hi):
+    """rows [lo, hi) of a device column of 8-byte words → numpy"""
+    t = ctx.table_from_device([(dtype, hi - lo, ptr + lo * 8, None)])
+    return t.to_host()[0].to_numpy()
+
+
+def cpu_grouped_full(ctx, ids_ptr, v_ptr, v_dtype, n, limit, modulus, chunk=1 << 27):
+    parts = []
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        ids = download_words(ctx, DType.INT64, ids_ptr, lo, hi)
+        v = ids if v_ptr == ids_ptr else download_words(ctx, v_dtype, v_ptr, lo, hi)
+        parts.append(orc.grouped_parallel(ids, v, limit, modulus, CPU_THREADS))
+        del ids, v
+    return orc.merge_grouped(parts)
+
+
+def assert_groups_equal(out, keys, exp, what):
+    """GPU result [count, sum, avg, min, max] + keys against float64[modulus, 4] = count, sum, min, max per key: every group"""
+    cnt, s, avg, mn, mx = host(out)
+    k = host(keys)[0]
+    live = np.nonzero(exp[:, 0] > 0)[0]
+    assert len(k) == len(live) and (k == live).all(), f"{what}: group keys differ"
+    e = exp[live]
+    assert (cnt.astype(np.float64) == e[:, 0]).all(), f"{what}: counts differ"
+    assert np.allclose(s, e[:, 1], rtol=1e-9, atol=0), f"{what}: sums differ beyond 1e-9"
+    assert np.allclose(avg, e[:, 1] / e[:, 0], rtol=1e-9, atol=0), f"{what}: averages differ beyond 1e-9"
+    assert (mn == e[:, 2]).all() and (mx == e[:, 3]).all(), f"{what}: min / max differ"
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("random_ids", [False, True])
+def test_headline_and_c3_1e9_rows_every_group_against_the_cpu(ctx, random_ids):
+    """headline (`where id < N/2`) and C3 (no filter) at 10^9 rows, ids = row numbers or random: all 1024 groups — counts exact, min / max
+    exact, sum / avg within 1e-9 (aggregate/mod.rs:54-102, sum.rs, avg.rs, max.rs, min.rs)"""
+    n = 10**9
+    d = DevCols(ctx)
+    try:
+        ids = d.synth(1, 1, n, 0, n, 0) if random_ids else d.synth(0, 0, n)
+        v = d.synth(2, 3, n)
+        t = table(ctx, (DType.INT64, n, ids), (DType.FLOAT64, n, v))
+        f = fields("id", "v")
+        key = binop(col(0), Operator.Modulos, lit_i64(1024)).flatten(f)
+        pred = binop(col(0), Operator.Lt, lit_i64(n // 2)).flatten(f)
+        for limit in (n // 2, None):
+            exp = cpu_grouped_full(ctx, ids, v, DType.FLOAT64, n, limit, 1024)
+            out, keys = ctx.aggregate(t, ALL(1), group_nodes=key, pred_nodes=pred if limit is not None else None, with_keys=True)
+            assert int(exp[:, 0].sum()) == (n if limit is None else (n // 2 if not random_ids else int(exp[:, 0].sum())))
+            assert_groups_equal(out, keys, exp, f"{'headline' if limit is not None else 'C3'}, {'random' if random_ids else 'sorted'} ids")
+    finally:
+        d.free()
+
+
+@pytest.mark.timeout(600)
+def test_headline_1e9_int64_values_and_single_column_against_the_cpu(ctx):
+    """north_star's literal "10^9 Int64 rows": Int64 values accumulated `as f64`, and key = predicate = value = ONE column"""
+    n = 10**9
+    d = DevCols(ctx)
+    try:
+        ids, age = d.synth(0, 0, n), d.synth(1, 2, n, 0, 60, 18)
+        f = fields("id", "age")
+        key = binop(col(0), Operator.Modulos, lit_i64(1024)).flatten(f)
+        pred = binop(col(0), Operator.Lt, lit_i64(n // 2)).flatten(f)
+        t = table(ctx, (DType.INT64, n, ids), (DType.INT64, n, age))
+        out, keys = ctx.aggregate(t, ALL(1), group_nodes=key, pred_nodes=pred, with_keys=True)
+        assert_groups_equal(out, keys, cpu_grouped_full(ctx, ids, age, DType.INT64, n, n // 2, 1024), "Int64 values")
+        out, keys = ctx.aggregate(t, ALL(0), group_nodes=key, pred_nodes=pred, with_keys=True)
+        assert_groups_equal(out, keys, cpu_grouped_full(ctx, ids, ids, DType.INT64, n, n // 2, 1024), "single column")
+    finally:
+        d.free()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("groups", [65536, 1 << 20])
+def test_many_group_aggregate_1e8_rows_every_group_against_the_cpu(ctx, groups):
+    """the partitioned path at bench size: 10^8 rows over 65536 / 2^20 random keys, every group"""
+    n = 10**8
+    d = DevCols(ctx)
+    try:
+        k, v = d.synth(1, 7, n, 0, groups, 0), d.synth(2, 3, n)
+        t = table(ctx, (DType.INT64, n, k), (DType.FLOAT64, n, v))
+        exp = cpu_grouped_full(ctx, k, v, DType.FLOAT64, n, None, groups)
+        for rep in range(2):       # first execution (sampled plan) and the remembered one
+            out, keys = ctx.aggregate(t, ALL(1), group_nodes=col(0).flatten(fields("k", "v")), with_keys=True)
+            assert_groups_equal(out, keys, exp, f"{groups} groups, execution {rep}")
+    finally:
+        d.free()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("random_ids", [False, True])
+def test_c2_1e8_rows_every_output_row_against_the_port(ctx, random_ids):
+    """C2 at 10^8 rows: the whole 5x10^7-row output of `select age + 100 from t where id < N/2`, bit for bit and in order, against the
+    oracle's SelectionPlan + ProjectionPlan (selection.rs:34-107, projection.rs:43-70)"""
+    from naive_query_engine_amd import Column
+
+    n = 10**8
+    d = DevCols(ctx)
+    try:
+        ids = d.synth(1, 1, n, 0, n, 0) if random_ids else d.synth(0, 0, n)
+        age = d.synth(1, 2, n, 0, 60, 18)
+        t = table(ctx, (DType.INT64, n, ids), (DType.INT64, n, age))
+        f = fields("id", "age")
+        pred = binop(col(0), Operator.Lt, lit_i64(n // 2)).flatten(f)
+        proj = [binop(col(1), Operator.Plus, lit_i64(100)).flatten(f), col(0).flatten(f)]
+        h = orc.upload([[Column.from_numpy(download_words(ctx, DType.INT64, ids, 0, n)), Column.from_numpy(download_words(ctx, DType.INT64, age, 0, n))]])
+        ref = orc.projection(orc.selection(h, pred, raw=True), proj)[0]
+        got = ctx.selection_projection(t, pred, proj).to_host()
+        assert len(got) == len(ref) == 2
+        for g, r in zip(got, ref):
+            assert g.length == r.length and (g.to_numpy() == r.to_numpy()).all()
+        assert (not random_ids and ref[0].length == n // 2) or (random_ids and abs(ref[0].length - n // 2) < 10**5)
+    finally:
+        d.free()
+
+
+@pytest.mark.timeout(900)
+def test_c4_1e8_x_1e6_every_output_row_against_the_port(ctx):
+    """C4 at full size: inner hash join of the 10^8-row fact table with the 10^6-row dimension — all four output columns of all 10^8
+    rows, bit for bit and in the reference's order (probe-major, hash_join.rs:80-103, 168-254), against the oracle's HashJoin
+    (single thread, ~25 s)"""
+    from naive_query_engine_amd import Column
+
+    n, nb = 10**8, 10**6
+    d = DevCols(ctx)
+    try:
+        rng = np.random.default_rng(7)
+        perm = rng.permutation(nb).astype(np.int64)
+        attr = rng.integers(0, 1 << 20, nb).astype(np.int64)
+        dim_cols = [Column.from_numpy(perm), Column.from_numpy(attr)]
+        dim = ctx.table_from_host(dim_cols)
+        fkey, val = d.synth(1, 5, n, 0, nb, 0), d.synth(2, 3, n)
+        fact = table(ctx, (DType.INT64, n, fkey), (DType.FLOAT64, n, val))
+        right = [Column.from_numpy(download_words(ctx, DType.INT64, fkey, 0, n)), Column.from_numpy(download_words(ctx, DType.FLOAT64, val, 0, n))]
+        ref = orc.hash_join([dim_cols], [right], 0, 0)[0]
+        got = ctx.hash_join(dim, fact, 0, 0).to_host()
+        assert len(got) == len(ref) == 4
+        for j, (g, r) in enumerate(zip(got, ref)):
+            assert g.length == r.length == n, f"column {j}: {g.length} rows, expected {r.length}"
+            assert (g.to_numpy().view(np.int64) == r.to_numpy().view(np.int64)).all(), f"column {j} differs"
+    finally:
+        d.free()

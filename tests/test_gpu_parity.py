@@ -2574,3 +2574,52 @@ def test_aggregate_mid_size_table_with_many_groups_takes_the_partitioned_path(ct
         if rep > 0 or sample:
             assert ctx.timing_query("agg_grouped_fast")[1] == 0, f"rep {rep}: no streaming attempt was expected"
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"mid-size table, rep {rep}")
+
+
+@pytest.mark.parametrize("shape", ["keys_only", "count_utf8", "count_bool", "count_utf8_and_values"])
+def test_aggregate_many_groups_over_shapes_the_streaming_kernel_does_not_cover(ctx, shape):
+    """the first execution's key sample put EVERY query with > 8192 sampled keys on the partitioned path with a
+    densely written table — also `select k from t group by k` (no aggregates) and count() over a Utf8 / Boolean column, which only
+    the general (hashed) kernel evaluates: NQE_ERR_NOT_SUPPORTED "… handed a densely laid out group table", remembered for every
+    later execution.  aggregate/mod.rs:113-222, count.rs:33-82"""
+    rng = np.random.default_rng(991)
+    n, G = (1 << 18) + 4321, 40_000
+    k = rng.integers(0, G, n).astype(np.int64) * 7 - 12345
+    v = rng.random(n) * 10
+    s = random_utf8(rng, n, 0.1)
+    b = Column.from_numpy(rng.random(n) < 0.5, rng.random(n) >= 0.1)
+    cols = [Column.from_numpy(k), Column.from_numpy(v), s, b]
+    aggs = {"keys_only": [], "count_utf8": [(AggregateFunc.Count, 2)], "count_bool": [(AggregateFunc.Count, 3)],
+            "count_utf8_and_values": [(AggregateFunc.Count, 2)] + ALL_AGGS(1)}[shape]
+    kn = col(0).flatten(fields("k", "v", "s", "b"))
+    exp = orc.aggregate([cols], aggs, group_nodes=kn)[0]
+    t = ctx.table_from_host(cols)
+    for rep in range(2):                                  # the second execution runs from what the first remembered
+        got, gk = ctx.aggregate(t, aggs, group_nodes=kn, with_keys=True)
+        keys = gk.to_host()[0].to_numpy()
+        assert len(keys) == len(np.unique(k)) and (np.sort(keys) == np.unique(k)).all(), f"{shape} rep {rep}: keys"
+        if aggs:
+            assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{shape} rep {rep}")
+        else:
+            assert got.num_rows == len(keys) and got.num_columns == 0
+
+
+def test_aggregate_range_partitions_with_keys_beyond_int32(ctx):
+    """key-range partitions kept the key truncated to int32 in the 12-byte tuple; keys around 5e9 whose RANGE is
+    small made the second kernel address LDS by garbage (and cost a retry).  The tuple now holds key - range_min."""
+    rng = np.random.default_rng(5)
+    n, G = 600_000, 70_000
+    k = rng.integers(0, G, n).astype(np.int64) + 5_000_000_000
+    v = rng.random(n) * 10 - 3
+    cols = [Column.from_numpy(k), Column.from_numpy(v)]
+    kn = col(0).flatten(fields("k", "v"))
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=kn)[0]
+    t = ctx.table_from_host(cols)
+    for rep in range(3):
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got, gk = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn, with_keys=True)
+        ctx.timing_enable(False)
+        assert ctx.timing_query("agg_segments_direct")[1] > 0, f"rep {rep}: key-range partitions were expected"
+        assert (np.sort(gk.to_host()[0].to_numpy()) == np.unique(k)).all()
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"wide keys, rep {rep}")

@@ -248,3 +248,44 @@ def test_optimised_multicore_headline_matches_the_port():
         g = orc.headline_parallel(ids, v, n // 2, 1024, threads)
         g = g[np.lexsort(g.T[::-1])]
         assert g.shape == e.shape and (g[:, 0] == e[:, 0]).all() and np.allclose(g, e, rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("form", ["filter_sorted", "no_filter_sorted", "filter_random", "no_filter_random", "int64_values", "single_column", "many_groups"])
+def test_parallel_grouped_form_matches_the_port(form):
+    """The full-size parity checks (tests/test_gpu_fullsize.py, bench.py's `parity_checked`) compare the GPU with orc_grouped_parallel —
+    every BASELINE aggregate shape it is used for is first checked here against the reference-faithful single-threaded port
+    (aggregate/mod.rs:113-222): keyed rows, counts exact, Float64 within 1e-9; chunked evaluation + merge_grouped included."""
+    from naive_query_engine_amd import AggregateFunc as A
+    from naive_query_engine_amd import Operator
+    from naive_query_engine_amd.expression import binop, col, lit_i64
+    from tests.helpers import fields
+
+    n, mod = 200_003, 1024
+    total = 10 * n
+    random_ids = "random" in form
+    ids = (orc.synth_fill(1, 1, 0, n, total, 0) if random_ids else orc.synth_fill(0, 0, 0, n)).view(np.int64)
+    v = orc.synth_fill(2, 3, 0, n).view(np.float64)
+    limit = None if form.startswith("no_filter") else (total // 2 if random_ids else n // 2)
+    if form == "int64_values":
+        v = orc.synth_fill(1, 2, 0, n, 60, 18).view(np.int64)
+    if form == "single_column":
+        v = ids
+    if form == "many_groups":
+        mod, limit = 70_000, None
+        ids = orc.synth_fill(1, 7, 0, n, mod, 0).view(np.int64)
+    assert (orc.synth_fill_mt(2, 3, 0, n, threads=5).view(np.float64) == orc.synth_fill(2, 3, 0, n).view(np.float64)).all()
+    f = fields("id", "v")
+    cols = [Column.from_numpy(ids), Column.from_numpy(v)]
+    key = (col(0) if form == "many_groups" else binop(col(0), Operator.Modulos, lit_i64(mod))).flatten(f)
+    ref, = orc.aggregate([cols], [(A.Count, 1), (A.Sum, 1), (A.Min, 1), (A.Max, 1)], group_nodes=key,
+                         pred_nodes=None if limit is None else binop(col(0), Operator.Lt, lit_i64(limit)).flatten(f))
+    e = np.stack([c.to_numpy().astype(np.float64) for c in ref], axis=1)
+    e = e[np.lexsort(e.T[::-1])]
+    for threads in (1, 7):
+        whole = orc.grouped_parallel(ids, v, limit, mod, threads)
+        h = n // 3
+        merged = orc.merge_grouped([orc.grouped_parallel(ids[:h], v[:h], limit, mod, threads), orc.grouped_parallel(ids[h:], v[h:], limit, mod, threads)])
+        for g in (whole, merged):
+            g = g[g[:, 0] > 0]                      # keys without rows: not groups
+            g = g[np.lexsort(g.T[::-1])]
+            assert g.shape == e.shape and (g[:, 0] == e[:, 0]).all() and (g[:, 2:] == e[:, 2:]).all() and np.allclose(g, e, rtol=1e-9, atol=0), (form, threads)
