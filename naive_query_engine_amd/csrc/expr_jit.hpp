@@ -18,6 +18,7 @@
 #pragma once
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
 #include <sys/types.h>
@@ -80,6 +81,7 @@ struct JitEntry {
     std::string extra_opt; // one more hipRTC option (the aggregate kernel: -munsafe-fp-atomics → ds_add_f64 / ds_min_f64 / ds_max_f64)
     std::string source, log, arch; // source: kept for the entry's lifetime — a lookup compares it (a 64-bit hash alone could collide)
     std::vector<char> code;
+    bool from_disk = false; // `code` was read from disk_path (not compiled by this process): a failed load deletes the file and compiles
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
 };
@@ -264,8 +266,22 @@ std::string gen_source(const ExProgram &P, bool nulls, bool bool_out) {
 // ---- code objects on disk: a NEW process finds the kernels an earlier one compiled (hipRTC takes 0.3-3 s per tree shape, during
 // which a one-shot process would only ever interpret).  One file per (source hash, ISA, HIP runtime version) under NQE_JIT_CACHE_DIR
 // (default $XDG_CACHE_HOME/nqe_jit, $HOME/.cache/nqe_jit, /tmp/nqe_jit-<uid>): magic, the generated SOURCE (compared on load: a
-// hash collision or a changed generator never hands out another tree's kernel) and the code object; written to a temporary name and
-// renamed.  NQE_NO_JIT_DISK_CACHE=1 switches it off.  Failures of any kind just mean "compile".
+// hash collision or a changed generator never hands out another tree's kernel), a checksum of the code object, and the code object;
+// written to a temporary name and renamed.  NQE_NO_JIT_DISK_CACHE=1 switches it off.  Failures of any kind just mean "compile".
+// The directory is trusted only when it is a real directory (not a symlink) OWNED BY THIS USER with no group / other permissions
+// (the /tmp fallback has a predictable name another local user could create first and fill with crafted code objects);
+// files are opened O_NOFOLLOW and must be regular files of this user; a file whose checksum or load fails is deleted and recompiled.
+inline uint64_t jit_checksum(const char *p, size_t n) { // FNV-1a over 8-byte words (+ the tail bytes)
+    uint64_t h = 1469598103934665603ull;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, p + i, 8);
+        h = (h ^ w) * 1099511628211ull;
+    }
+    for (; i < n; ++i) h = (h ^ uint64_t((unsigned char)p[i])) * 1099511628211ull;
+    return h;
+}
 std::string jit_disk_path(uint64_t key, const std::string &arch) {
     if (getenv("NQE_NO_JIT_DISK_CACHE")) return std::string();
     std::string dir;
@@ -273,37 +289,55 @@ std::string jit_disk_path(uint64_t key, const std::string &arch) {
     else if (const char *x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/nqe_jit";
     else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/nqe_jit";
     else dir = "/tmp/nqe_jit-" + std::to_string((unsigned long)getuid());
+    while (dir.size() > 1 && dir.back() == '/') dir.pop_back();
     for (size_t i = 1; i <= dir.size(); ++i) // mkdir -p
         if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0700);
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return std::string(); // not ours alone: no disk cache
     int rtv = 0;
     (void)hipRuntimeGetVersion(&rtv);
     char name[96];
     snprintf(name, sizeof(name), "/%016llx-%s-%d.nqejit", (unsigned long long)key, arch.c_str(), rtv);
     return dir + name;
 }
-constexpr uint64_t JIT_DISK_MAGIC = 0x3130544a5145514eull; // "NQEQJT01"
+constexpr uint64_t JIT_DISK_MAGIC = 0x3230544a5145514eull; // "NQEQJT02" (02: + checksum)
 bool jit_disk_load(const std::string &path, const std::string &source, std::vector<char> *code) {
     if (path.empty()) return false;
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    bool ok = false;
-    uint64_t head[3];
-    if (fread(head, 8, 3, f) == 3 && head[0] == JIT_DISK_MAGIC && head[1] == source.size() && head[2] > 0 && head[2] < (uint64_t(1) << 28)) {
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    FILE *f = (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid()) ? fdopen(fd, "rb") : nullptr;
+    if (!f) {
+        close(fd);
+        return false;
+    }
+    bool ok = false, mine = false;
+    uint64_t head[4];
+    if (fread(head, 8, 4, f) == 4 && head[0] == JIT_DISK_MAGIC && head[1] == source.size() && head[2] > 0 && head[2] < (uint64_t(1) << 28)) {
         std::string src(size_t(head[1]), '\0');
         code->resize(size_t(head[2]));
-        ok = fread(&src[0], 1, src.size(), f) == src.size() && fread(code->data(), 1, code->size(), f) == code->size() && src == source;
+        mine = fread(&src[0], 1, src.size(), f) == src.size() && src == source; // (another tree under the same hash: not this entry's file to judge)
+        ok = mine && fread(code->data(), 1, code->size(), f) == code->size() && jit_checksum(code->data(), code->size()) == head[3];
     }
     fclose(f);
-    if (!ok) code->clear();
+    if (!ok) {
+        code->clear();
+        if (mine) (void)unlink(path.c_str()); // truncated or corrupt: the next store replaces it
+    }
     return ok;
 }
 void jit_disk_store(const std::string &path, const std::string &source, const std::vector<char> &code) {
     if (path.empty() || code.empty()) return;
     const std::string tmp = path + ".tmp" + std::to_string((unsigned long)getpid());
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f) return;
-    const uint64_t head[3] = {JIT_DISK_MAGIC, source.size(), code.size()};
-    const bool ok = fwrite(head, 8, 3, f) == 3 && fwrite(source.data(), 1, source.size(), f) == source.size() && fwrite(code.data(), 1, code.size(), f) == code.size();
+    (void)unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    FILE *f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+    if (!f) {
+        if (fd >= 0) close(fd);
+        return;
+    }
+    const uint64_t head[4] = {JIT_DISK_MAGIC, source.size(), code.size(), jit_checksum(code.data(), code.size())};
+    const bool ok = fwrite(head, 8, 4, f) == 4 && fwrite(source.data(), 1, source.size(), f) == source.size() && fwrite(code.data(), 1, code.size(), f) == code.size();
     if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
 }
 
@@ -360,6 +394,7 @@ template <class MakeSource> JitEntry *jit_get(nqe_ctx *ctx, uint64_t key, const 
         }
         e->disk_path = jit_disk_path(key, e->arch);
         if (jit_disk_load(e->disk_path, e->source, &e->code)) {
+            e->from_disk = true;
             e->state.store(1, std::memory_order_release); // an earlier process compiled this very source: loaded below, used by THIS execution
         } else {
             e->worker = std::thread(jit_compile, raw);
@@ -372,13 +407,27 @@ template <class MakeSource> JitEntry *jit_get(nqe_ctx *ctx, uint64_t key, const 
     if (st == 1) { // code ready: load it on this thread (the only one that makes HIP calls for the context)
         if (e->worker.joinable()) e->worker.join();
         const bool ok = hipModuleLoadData(&e->mod, e->code.data()) == hipSuccess && hipModuleGetFunction(&e->fn, e->mod, kernel_name) == hipSuccess;
+        e->code.clear();
+        e->code.shrink_to_fit();
+        if (!ok && e->from_disk) {
+            // a code object from DISK that does not load (another driver's leftovers, a damaged file that kept its checksum): delete it and
+            // compile — interpreting meanwhile — instead of switching specialisation off for the whole context and for every later process
+            (void)hipGetLastError();
+            if (e->mod) (void)hipModuleUnload(e->mod);
+            e->mod = nullptr;
+            e->fn = nullptr;
+            e->from_disk = false;
+            (void)unlink(e->disk_path.c_str());
+            e->state.store(0, std::memory_order_release);
+            e->worker = std::thread(jit_compile, e);
+            if (getenv("NQE_JIT_SYNC")) e->worker.join();
+            return nullptr;
+        }
         if (!ok) {
             (void)hipGetLastError();
             e->log = "hipModuleLoadData failed";
             cache->unavailable = true;
         }
-        e->code.clear();
-        e->code.shrink_to_fit();
         st = ok ? 2 : -1;
         e->state.store(st, std::memory_order_release);
     }

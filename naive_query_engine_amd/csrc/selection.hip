@@ -141,6 +141,41 @@ __global__ void __launch_bounds__(256) keep_from_range_strided_kernel(const uint
     }
 }
 
+// Round 5 (tools/compact_bench.hip, 10^8 rows, keep and compaction alternating so that nothing is cache-warm): one 256-thread workgroup
+// per 4096-row tile, sixteen rows per lane all in flight, the tile's count written ONCE by the workgroup — no zeroing pass, no atomic
+// per 512-row chunk: 0.148-0.150 ms -> 0.131-0.133 ms per 0.8 GB column (6.05 TB/s; the atomics were the whole difference — the strided
+// form without them measured the same, and a 1024-thread two-tile pipelined form like the aggregate's stream was slower, 0.156-0.166 ms).
+template <int RANGE>
+__global__ void __launch_bounds__(256) keep_from_range_tile_kernel(const uint64_t *__restrict__ words, FastPred fp, int64_t n, int64_t ntiles, uint64_t *keep, uint32_t *tile_counts) {
+    static_assert(TILE_ROWS == 4096, "four waves x sixteen keep words");
+    __shared__ uint32_t wtot[4];
+    const int lane = lane_id(), wave = int(threadIdx.x) >> 6;
+    const int64_t last = n - 1;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * TILE_ROWS + wave * 1024 + lane;
+        uint64_t v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + r * 64;
+            v[r] = __builtin_nontemporal_load(&words[row < last ? row : last]);
+        }
+        uint32_t total = 0;
+        uint64_t mine = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + r * 64;
+            const uint64_t kw = __ballot(row < n && range_pass(fp, RANGE == 2 ? f64_order_map(fp, v[r]) : v[r]));
+            if (lane == r) mine = kw;
+            total += __popcll(kw);
+        }
+        if (lane < 16 && (tile * TILE_WORDS + wave * 16 + lane) * 64 < n) keep[tile * TILE_WORDS + wave * 16 + lane] = mine;
+        if (lane == 0) wtot[wave] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_counts[tile] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+}
+
 // keep mask of `A and B [and …]` / `A or B [or …]`, up to four range tests over NC <= 4 plain 8-byte columns (ConjTest::src = the
 // column's slot): the WHERE clause's usual shape in one streaming pass over its column(s), without the expression machine's
 // Boolean column
@@ -332,7 +367,13 @@ KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleE
         static const int bpc = getenv("NQE_SEL_BPC") ? atoi(getenv("NQE_SEL_BPC")) : 8; // diagnostics (A/B): workgroups per CU
         dim3 grid(stream_grid(ctx, km.ntiles, 4, bpc)), block(256);
         static const bool strided = getenv("NQE_SEL_TILED") == nullptr; // diagnostics (A/B): NQE_SEL_TILED=1 restores one 4096-row tile per wave
-        if (range && strided) {
+        // NQE_KEEP_TILE=0: keep_from_range_strided_kernel (A/B)
+        static const bool tile_form = !(getenv("NQE_KEEP_TILE") && atoi(getenv("NQE_KEEP_TILE")) == 0);
+        if (range && strided && tile_form) {
+            dim3 tgrid(stream_grid(ctx, km.ntiles, 1, 8));
+            if (fp.fmask) launch(ctx, "keep_from_simple", keep_from_range_tile_kernel<2>, tgrid, block, 0, c.words(), fp, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
+            else launch(ctx, "keep_from_simple", keep_from_range_tile_kernel<1>, tgrid, block, 0, c.words(), fp, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
+        } else if (range && strided) {
             NQE_HIP_CHECK(hipMemsetAsync(counts->ptr, 0, size_t(km.ntiles + 1) * 4, ctx->stream));
             dim3 sgrid(stream_grid(ctx, (km.n + 7) / 8, 256));
             if (fp.fmask) launch(ctx, "keep_from_simple", keep_from_range_strided_kernel<2>, sgrid, block, 0, c.words(), fp, km.n, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
@@ -443,6 +484,72 @@ __global__ void __launch_bounds__(256) compact_strided_kernel(const uint64_t *__
     }
 }
 
+// The PLAINW compaction at stream speed (round 5).  compact_strided_kernel stores straight from the registers: a wave's store covers
+// popcount(keep word) x 8 bytes — ~256 B at 50 % selectivity, starting anywhere — so every store instruction touches a partial line on
+// each side, and a chunk's neighbours are written by other waves, often on another XCD (another L2: the shared line reaches memory
+// twice, each time partially): 4.2-4.7 TB/s of mixed traffic over random ids where a plain copy reaches 5.5-6.  Here a 512-thread
+// workgroup takes a whole 4096-row tile: wave w the keep words 8 w .. 8 w + 7 (offsets from one scan of the tile's 64 keep words, as
+// before), the kept words are STAGED in LDS at their rank within the tile, and the tile's T kept words leave as whole-wave 512-byte
+// stores aligned to the 128-byte lines of the output (the first store is shifted by base mod 16 words) — two partial lines per tile
+// instead of two per store.  Two workgroups per CU overlap their barrier phases.  Tiles without kept rows are skipped on two scalar
+// loads (clustered data).  tools/compact_bench.hip (10^8 rows, 50 % kept): random ids 0.256 -> 0.195 ms (6.1 TB/s), sorted ids 0.140 =
+// 0.140; 256 / 512 / 1024 threads, 2-8 workgroups per CU, a prefetched second register tile and plain instead of non-temporal stores
+// were all measured there — prefetching bought nothing (±1 %), plain stores cost 7-10 %, 1024 threads 8-30 %.
+// EX: 0 the column itself; 1 any SimpleExpr (interpreted per row: +12 % kernel time); 2 `x * mul + add` in wrapping 64-bit integers —
+// `col + lit`, `col - lit`, `lit - col`, `col * lit` (the projection of C2, `age + 100`) — as straight-line code.
+template <int EX>
+__global__ void __launch_bounds__(512) compact_staged_kernel(const uint64_t *__restrict__ words, SimpleExpr e, uint64_t mul, uint64_t add, const uint64_t *__restrict__ keep,
+                                                             const uint64_t *__restrict__ tile_offsets, int64_t n, int64_t ntiles, uint64_t *__restrict__ out_words, int *flags) {
+    static_assert(TILE_WORDS == 64, "one keep word of the tile per lane");
+    constexpr int R = TILE_WORDS / 8; // keep words (64-row groups) per wave: 8 waves per tile
+    __shared__ uint64_t stage[TILE_ROWS];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+    const int64_t nwords = (n + 63) / 64, last = n - 1;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t base = tile_offsets[tile];
+        const uint32_t T = uint32_t(tile_offsets[tile + 1] - base);
+        if (T == 0) continue; // (workgroup-uniform)
+        const int64_t w = tile * TILE_WORDS + lane;
+        const uint64_t my_word = w < nwords ? keep[w] : 0;
+        uint64_t v[R];
+        const int64_t row0 = (tile * TILE_WORDS + int64_t(wave) * R) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int64_t row = row0 + int64_t(k) * 64;
+            v[k] = __builtin_nontemporal_load(&words[row < last ? row : last]);
+        }
+        uint32_t tot;
+        const uint32_t my_off = wave_exclusive_scan(uint32_t(__popcll(my_word)), tot);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const uint64_t kw = bcast64(my_word, wave * R + k);
+            const uint32_t off = bcast32(my_off, wave * R + k);
+            if ((kw >> lane) & 1) stage[off + __popcll(kw & lanemask_lt())] = EX == 1 ? eval_simple(e, v[k], true, flags) : EX == 2 ? v[k] * mul + add : v[k];
+        }
+        __syncthreads();
+        const int head = int(base & 15); // words between the preceding line boundary and the tile's first output word
+        for (int j = int(threadIdx.x) - head; j < int(T); j += 512)
+            if (j >= 0) __builtin_nontemporal_store(stage[j], &out_words[base + uint64_t(j)]);
+        __syncthreads();
+    }
+}
+
+// `x * mul + add` (wrapping) for a one-step Int64 / UInt64 SimpleExpr with a literal: + - * only (division and modulus can fault)
+static bool affine_form(const SimpleExpr &e, uint64_t *mul, uint64_t *add) {
+    if (e.nops != 1 || !(e.op_dtype[0] == NQE_INT64 || e.op_dtype[0] == NQE_UINT64) || !(e.src_dtype == NQE_INT64 || e.src_dtype == NQE_UINT64)) return false;
+    const uint64_t lit = e.lit[0];
+    switch (e.op[0]) {
+    case NQE_OP_PLUS: *mul = 1; *add = lit; return true;
+    case NQE_OP_MINUS:
+        if (e.lit_left[0]) { *mul = ~uint64_t(0); *add = lit; } // lit - x
+        else { *mul = 1; *add = uint64_t(0) - lit; }
+        return true;
+    case NQE_OP_MULTIPLY: *mul = lit; *add = 0; return true;
+    default: return false;
+    }
+}
+
 static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExpr *e, int out_dtype, const KeepMask &km,
                              const uint32_t *gidx = nullptr) {
     if (src.dtype == NQE_UTF8 && !e && !gidx) // StringBuilder path of selection.rs:82-97: gather by the emitted-row list
@@ -474,7 +581,17 @@ static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExp
     launch(ctx, NAME, compact_kernel<E, P, G>, grid, block, 0, sv, src.dtype, src.valid(), gidx, ex, kp, pv, to, km.n,  \
            km.ntiles, ow, ob, ov, ctx->d_flags)
         static const bool strided = getenv("NQE_SEL_TILED") == nullptr; // diagnostics (A/B): NQE_SEL_TILED=1 restores one 4096-row tile per wave
-        if (strided && !gidx && plainw) {
+        // NQE_COMPACT_STAGED=0: the register-to-memory form (compact_strided_kernel) for A/B; NQE_COMPACT_STAGED_WGS: workgroups per CU
+        static const bool staged = !(getenv("NQE_COMPACT_STAGED") && atoi(getenv("NQE_COMPACT_STAGED")) == 0);
+        static const int staged_wgs = getenv("NQE_COMPACT_STAGED_WGS") ? std::max(1, atoi(getenv("NQE_COMPACT_STAGED_WGS"))) : 2;
+        if (staged && strided && !gidx && plainw && km.ntiles >= 64) {
+            dim3 ggrid(unsigned(std::min<int64_t>(km.ntiles, int64_t(ctx->num_cus) * staged_wgs))), gblock(512);
+            uint64_t mul = 1, add = 0;
+            if (e && affine_form(*e, &mul, &add))
+                launch(ctx, "compact_expr", compact_staged_kernel<2>, ggrid, gblock, 0, (const uint64_t *)sv, ex, mul, add, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
+            else if (e) launch(ctx, "compact_expr", compact_staged_kernel<1>, ggrid, gblock, 0, (const uint64_t *)sv, ex, mul, add, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
+            else launch(ctx, "compact_column", compact_staged_kernel<0>, ggrid, gblock, 0, (const uint64_t *)sv, ex, mul, add, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
+        } else if (strided && !gidx && plainw) {
             dim3 sgrid(stream_grid(ctx, km.ntiles * (TILE_WORDS / COMPACT_CHUNK_WORDS), 4));
             if (e) launch(ctx, "compact_expr", compact_strided_kernel<true>, sgrid, block, 0, (const uint64_t *)sv, ex, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
             else launch(ctx, "compact_column", compact_strided_kernel<false>, sgrid, block, 0, (const uint64_t *)sv, ex, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
