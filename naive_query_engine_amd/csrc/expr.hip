@@ -1212,19 +1212,27 @@ bool select_project_fused(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node
     const int64_t n_chunks = (n + SP_BLOCK * SP_R - 1) / (SP_BLOCK * SP_R); // steps: one status word per workgroup step
     std::vector<DevColumn> cols;
     uint64_t *ow[JP_MAX_OUTS] = {};
-    for (int e = 0; e < num_exprs; ++e) {
-        cols.push_back(make_word_column(ctx, J.outs[size_t(e)].out_dtype, n, false));
-        ow[e] = (uint64_t *)cols.back().values->ptr;
+    BufRef status;
+    try {
+        for (int e = 0; e < num_exprs; ++e) {
+            cols.push_back(make_word_column(ctx, J.outs[size_t(e)].out_dtype, n, false));
+            ow[e] = (uint64_t *)cols.back().values->ptr;
+        }
+        status = dev_alloc(ctx, size_t(n_chunks) * 8 + 16);
+    } catch (const Error &e) {
+        // the worst-case outputs do not fit: the two-kernel form sizes its outputs exactly and may still run
+        if (e.code != NQE_ERR_OUT_OF_MEMORY) throw;
+        return false;
     }
-    BufRef status = dev_alloc(ctx, size_t(n_chunks) * 8 + 16);
     NQE_HIP_CHECK(hipMemsetAsync(status->ptr, 0, size_t(n_chunks) * 8 + 16, ctx->stream));
     unsigned long long *st = (unsigned long long *)status->ptr;
     jit_select_project(ctx, kernel, S, n, ow, st, reinterpret_cast<uint32_t *>(st + n_chunks), st + n_chunks + 1);
     const int64_t total = int64_t(read_scalar(ctx, (const unsigned long long *)(st + n_chunks + 1)));
     for (auto &c : cols) {
         c.length = total;
-        // far fewer rows than the buffer holds: give the large block back (the copy moves total rows, a fraction of the pass)
-        if (total * 8 < n) c = slice_column(ctx, c, 0, total);
+        // fewer than half the rows the buffer holds and more than 64 MB of it unused: give the large block back (the copy moves
+        // `total` rows — less than the pass wrote — and the result no longer pins several times the memory it needs)
+        if (total * 2 < n && (n - total) * 8 > (int64_t(64) << 20)) c = slice_column(ctx, c, 0, total);
     }
     *total_out = total;
     *result = std::move(cols);
