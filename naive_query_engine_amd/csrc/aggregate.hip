@@ -1279,22 +1279,114 @@ AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const n
 
 constexpr uint64_t PART_RANGE_SALT = 0x9E3779B97F4A7C15ull; // nqe_ctx::agg_key_ranges[hint ^ salt]: the key range of the query's groups (range partitions)
 
-AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes,
-                        const nqe_expr_node *group, int group_nodes, const nqe_aggregate *aggs, int naggs, bool partial) {
-    AggPlan plan = plan_aggs(in, aggs, naggs);
-    const bool grouped = group && group_nodes > 0;
-    const bool has_pred = pred && pred_nodes > 0;
+// ---- PhysicalAggregatePlan::execute (aggregate/mod.rs:113-222) on the device, one object per execution:
+//   plan      prepare (key expression, predicate) -> size_tables -> load_hints (what this query shape did last time) -> sample_keys (the
+//             first execution's key sample picks the starting tier) -> pick_key_range (a plain key column addressed by key - min);
+//   execute   run: per attempt begin_attempt (the group table), then per pass of 1-3 value columns launch_pass = shape_pass (which
+//             kernel variant the pass's columns, key and predicate admit) + ONE tier: tier_slab (partitioned, fixed-capacity slabs),
+//             tier_exact (partitioned, exact sizes / two levels), tier_streaming (the single-pass LDS-table kernels and the run-time
+//             specialised one), the general hashed kernel, or pass_ungrouped;
+//   react     finish_attempt: the tail ahead of ONE flag read-back, then react_to_flags — an overflowed tier names the next one, the
+//             attempt is redone there and the plan hint remembers it — or the result.
+// Switches: the A/B diagnostics are read ONCE per context (nqe_ctx::agg_sw, AggSwitches in nqe_internal.hpp; listed in DESIGN.md §9);
+// the ones tests flip between calls are read per call where they are used (NQE_NO_PLAN_HINTS, NQE_NO_KEY_SAMPLE, NQE_NO_RANGE_PARTITION,
+// NQE_NO_RANGE_TAIL, NQE_NO_AGG_JIT, NQE_TEST_SLAB_OOM).
+AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, const nqe_expr_node *group, int group_nodes,
+                        const nqe_aggregate *aggs, int naggs, bool partial);
 
+enum class PassStatus { Done, Abort }; // Abort: leave the pass loop — slab_oom / three_redo / dense_redo / jit_redo says why
+
+struct AggRun {
+    // ---- the call
+    nqe_ctx *ctx;
+    const nqe_table *in;
+    const nqe_expr_node *pred;
+    int pred_nodes;
+    const nqe_expr_node *group;
+    int group_nodes;
+    const nqe_aggregate *aggs;
+    int naggs;
+    bool partial;
+    const AggSwitches &sw;
+    AggResult early; // prepare(): the query was answered by a selection + a predicate-free aggregate
+    // ---- plan
+    AggPlan plan;
+    bool grouped = false, has_pred = false;
     AggArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.n = in->rows;
-    for (int k = 0; k < SIMPLE_MAX_OPS; ++k) a.pred.aux[k].pow2_shift = a.pred.aux[k].more = a.key.aux[k].pow2_shift = a.key.aux[k].more = -1;
-
-    // ---- key expression (group_expr[0] only, quirk Q8)
     ExprInfo kinfo;
     int key_col = -1;
     bool utf8_key = false;
     DevColumn utf8_codes, utf8_src;
+    DevColumn pred_col; // keeps a materialised predicate alive
+    bool pred_may_fault = false;
+    int conj_col[CONJ_MAX] = {-1, -1, -1, -1};
+    TreePred tree;   // pred_mode 4
+    BufRef tree_buf; // its program on the device
+    bool jit_whole = false, jit_redo = false; // the predicate is evaluated by the run-time specialised streaming kernel (see prepare)
+    DevColumn key_colbuf;
+    bool kp_valid_words_ok = true, pred_bits_words_ok = true;
+    int V = 0;
+    uint32_t cap = 1, sized_cap = 1;
+    bool partition_mode = false, level2 = false, dense_ok = true, slab_failed = false, key32_failed = false;
+    bool range_part_ok = true, range_part_used = false, part_range_sampled = false;
+    int64_t part_min = 0;
+    uint64_t part_span = 0;
+    bool three_on = true;
+    bool range_on = false;
+    int64_t range_min = 0;
+    uint64_t range_span = 0;
+    int subsets_log2 = 0, slab_parts_log2 = 8;
+    uint64_t hint_key = 0;
+    bool any_val_nullable = false, subsets_ok = false, plain_int_key = false, no_hints_env = false, range_sampled = false;
+    uint64_t range_limit = 4096, key_flip = 0;
+    // ---- the attempt
+    int attempt = 0;
+    bool asked_partition = false, dense = false, flagless = false, slab_oom = false, three = false, three_redo = false, dense_redo = false, first_alone = false;
+    int nv_step = 1, pass_nv = 0;
+    TableBufs tb;
+    // ---- the pass (shape_pass)
+    bool jit_launched = false, valid_words_ok = true, plain = false, bitmap_pred = false, vnull = false, range_pred = false, chain_pred = false, fast = false, vf64 = true;
+    size_t shmem = 0;
+    int blocks_per_cu = 1, grid = 1, kk = 2, fast_key = -1, pk = 0, fp = 0;
+    AggArgs ka;
+    FastPred fpred;
+
+    AggRun(nqe_ctx *c, const nqe_table *t, const nqe_expr_node *p, int pn, const nqe_expr_node *g, int gn, const nqe_aggregate *ag, int na, bool part)
+        : ctx(c), in(t), pred(p), pred_nodes(pn), group(g), group_nodes(gn), aggs(ag), naggs(na), partial(part), sw(c->agg_sw) {}
+
+    void materialize_pred() { // the predicate tree as a Boolean column (expression machine), tested bit by bit
+        pred_col = evaluate_expr(ctx, in, pred, pred_nodes);
+        a.pred_mode = 2;
+        a.pred_src = src_of(pred_col);
+    }
+    std::pair<int64_t, uint64_t> measure_key_range();
+    bool prepare();
+    void size_tables();
+    void load_hints();
+    void sample_keys();
+    void pick_key_range();
+    void begin_attempt();
+    PassStatus launch_pass(int v0);
+    PassStatus shape_pass();
+    PassStatus tier_slab();
+    void tier_exact();
+    PassStatus tier_streaming(int v0);
+    void pass_ungrouped(int v0);
+    bool finish_attempt(AggResult *out);
+    bool react_to_flags(const int *f, const Collected &pre);
+    AggResult run();
+};
+
+// key expression (group_expr[0] only, quirk Q8) and predicate.  true: `early` holds the result (a general key expression under a filter)
+bool AggRun::prepare() {
+    plan = plan_aggs(in, aggs, naggs);
+    grouped = group && group_nodes > 0;
+    has_pred = pred && pred_nodes > 0;
+
+    std::memset(&a, 0, sizeof(a));
+    a.n = in->rows;
+    for (int k = 0; k < SIMPLE_MAX_OPS; ++k) a.pred.aux[k].pow2_shift = a.pred.aux[k].more = a.key.aux[k].pow2_shift = a.key.aux[k].more = -1;
+
     if (grouped) {
         kinfo = analyze_expr(in, group, group_nodes);
         if (kinfo.out_dtype == NQE_UTF8) {
@@ -1316,21 +1408,11 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             nqe_status st = nqe_selection_execute(ctx, in, pred, pred_nodes, &sel);
             if (st != NQE_OK) fail(st, ctx->last_error);
             std::unique_ptr<nqe_table> guard(sel);
-            return run_aggregate(ctx, sel, nullptr, 0, group, group_nodes, aggs, naggs, partial);
+            early = run_aggregate(ctx, sel, nullptr, 0, group, group_nodes, aggs, naggs, partial);
+            return true;
         }
     }
     // ---- predicate
-    DevColumn pred_col; // keeps a materialised predicate alive
-    bool pred_may_fault = false;
-    int conj_col[CONJ_MAX] = {-1, -1, -1, -1};
-    TreePred tree;   // pred_mode 4
-    BufRef tree_buf; // its program on the device
-    bool jit_whole = false, jit_redo = false; // the predicate is evaluated by the run-time specialised streaming kernel (see below)
-    auto materialize_pred = [&]() { // the predicate tree as a Boolean column (expression machine), tested bit by bit
-        pred_col = evaluate_expr(ctx, in, pred, pred_nodes);
-        a.pred_mode = 2;
-        a.pred_src = src_of(pred_col);
-    };
     if (has_pred) {
         ExprInfo pinfo = analyze_expr(in, pred, pred_nodes);
         pred_may_fault = pinfo.may_fault;
@@ -1366,7 +1448,6 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             else materialize_pred();
         }
     }
-    DevColumn key_colbuf;
     if (grouped) {
         a.has_key = 1;
         if (utf8_key) {
@@ -1386,60 +1467,56 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
     // validity bitmaps the fast kernels read as whole 64-bit words: library-owned buffers are padded, a borrowed one only
     // if its length is a multiple of 64
     auto words_ok = [](const DevColumn &c) { return !c.validity || c.validity->owned || (c.length % 64) == 0; };
-    bool kp_valid_words_ok = true;
+    kp_valid_words_ok = true;
     if (grouped && key_col >= 0 && !utf8_key) kp_valid_words_ok = kp_valid_words_ok && words_ok(in->cols[size_t(key_col)]);
     if (grouped && utf8_key) kp_valid_words_ok = kp_valid_words_ok && words_ok(utf8_src); // the codes share the strings' validity buffer
     if (a.pred_mode == 1) kp_valid_words_ok = kp_valid_words_ok && words_ok(in->cols[size_t(a.pred.col)]);
     // a Boolean INPUT column used as the predicate is read by the fast kernels as whole 64-bit words of its VALUES bitmap too: a
     // borrowed one ends at ceil(n/8) bytes, so unless n is a multiple of 64 (and the pointer 8-byte aligned) take the general kernel
-    bool pred_bits_words_ok = true;
+    pred_bits_words_ok = true;
     if (a.pred_mode == 1 && a.pred.nops == 0 && a.pred_src.dtype == NQE_BOOLEAN) {
         const DevColumn &pc = in->cols[size_t(a.pred.col)];
         if (pc.values && !pc.values->owned && ((pc.length % 64) != 0 || (reinterpret_cast<uintptr_t>(pc.values->ptr) & 7) != 0)) pred_bits_words_ok = false;
     }
 
-    const int V = int(plan.val_cols.size());
+    return false;
+}
+
+void AggRun::size_tables() {
+    V = int(plan.val_cols.size());
     // Global table: the first attempt is SMALL (8192 slots) whatever the input size — every workgroup merges at most one LDS
     // table's worth of groups, and unless the workgroups see different key sets their union fits, so that initialisation is
     // 0.4 MB instead of 92 MB and the whole tail is one launch (rank_finalize_kernel).  When the union does not fit (TABLE_FULL:
     // keys correlated with the tile→workgroup assignment, or a small input of mostly distinct keys) the retry is sized for the
     // worst case (every workgroup inserting its own ≤4096 groups, at most one per row), as is the partitioned path.
-    uint32_t cap = 1, sized_cap = 1;
+    cap = 1, sized_cap = 1;
     if (grouped) {
         int64_t guess = std::min<int64_t>(std::max<int64_t>(in->rows, 1), int64_t(1) << 20);
         sized_cap = 4096;
         while (int64_t(sized_cap) < 2 * guess) sized_cap <<= 1;
         cap = std::min(sized_cap, RANK_MAX_CAP);
     }
-    bool partition_mode = false, level2 = false, dense_ok = true, slab_failed = false, key32_failed = false;
     // KEY-RANGE partitions of the slab form (aggregate_common.hpp: SlabArgs::range_span): the range they work from — the exact one an
     // earlier execution's dense tail measured (remembered under a salted hint key), or this execution's key sample (`col % m`: what the
     // modulus allows; a plain column: the sample's range padded by 1/256).  span 0: none; a key outside it sends the attempt back to hashed
     // partitions (a sampled range is then replaced by the measured one, a remembered one by (0, 0): never again).
     // NQE_NO_RANGE_PARTITION=1: hashed partitions only (A/B)
-    bool range_part_ok = getenv("NQE_NO_RANGE_PARTITION") == nullptr, range_part_used = false, part_range_sampled = false;
-    int64_t part_min = 0;
-    uint64_t part_span = 0;
-    static const bool no_three = getenv("NQE_NO_THREE_COLUMN_PASS") != nullptr; // diagnostics (A/B runs)
-    bool three_on = !no_three;
+    range_part_ok = getenv("NQE_NO_RANGE_PARTITION") == nullptr; // (read per call: tests switch it)
+    three_on = !sw.no_three_column_pass;
     // a plain integer key column whose value RANGE fits a workgroup table (nqe_ctx::agg_key_ranges)
-    static const bool no_range = getenv("NQE_NO_KEY_RANGE") != nullptr; // diagnostics (A/B runs)
-    bool range_on = false;
-    int64_t range_min = 0;
-    uint64_t range_span = 0;
     // Between one LDS table's worth of groups and the partitioned path: the fast kernel with two key subsets (see
     // AggArgs::subsets_log2) — every row is read by two workgroups, each of which keeps its half of the keys.  Rows of the other
     // half cost a wave as many issue slots as its own (lanes are masked, instructions are not skipped), so the kernel time doubles:
     // per 10^8 rows 0.80-0.91 ms at 4096-6000 groups against 1.29 ms partitioned; with four subsets (1.5-1.7 ms) partitioning wins.
-    static const int subsets_max = getenv("NQE_AGG_SUBSETS_MAX") ? atoi(getenv("NQE_AGG_SUBSETS_MAX")) : 1; // log2; diagnostics
-    int subsets_log2 = 0;
     // slab form of the partitioned path: 256 partitions first, PARTS when one of them holds more distinct keys than a workgroup table
-    static const int slab_parts_first = getenv("NQE_SLAB_PARTS_LOG2") ? atoi(getenv("NQE_SLAB_PARTS_LOG2")) : 8; // diagnostics
-    int slab_parts_log2 = std::min(std::max(slab_parts_first, 6), PARTS_LOG2);
+    slab_parts_log2 = std::min(std::max(sw.slab_parts_first, 6), PARTS_LOG2);
+}
+
+void AggRun::load_hints() {
     // plan hint (see nqe_ctx::agg_hints): FNV-1a over everything that decides which kernels the query takes — the key column's
     // buffer and expression, the predicate and its column, the value columns (buffers, validity, types) and the row count — so
     // that a hint is only ever applied to the very query shape that recorded it
-    uint64_t hint_key = 0;
+    hint_key = 0;
     if (grouped && a.key_src.values && in->rows >= (int64_t(1) << 18)) {
         hint_key = 1469598103934665603ull;
         auto mix = [&](const void *p, size_t nbytes) {
@@ -1496,40 +1573,43 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
                 if (hv == 1) slab_parts_log2 = PARTS_LOG2;
                 if (hv == 17) slab_failed = true;
                 cap = std::max(cap, sized_cap);
-            } else if (hv >= 2 && hv - 1 <= subsets_max) {
+            } else if (hv >= 2 && hv - 1 <= sw.subsets_max) {
                 subsets_log2 = hv - 1;
                 cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
             }
         }
     }
-    bool any_val_nullable = false;
+    any_val_nullable = false;
     for (int c : plan.val_cols) any_val_nullable = any_val_nullable || in->cols[size_t(c)].validity != nullptr;
     // the two-subset instances exist for one value column and sources without validity bitmaps
-    const bool subsets_ok = V == 1 && !any_val_nullable && !a.key_src.valid && !(a.pred_mode != 0 && a.pred_src.valid);
-    const uint64_t range_limit = V <= 1 ? 4096 : 2048; // the smallest workgroup table among the passes
-    const uint64_t key_flip = a.key_src.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
-    const bool plain_int_key = key_col >= 0 && !utf8_key && a.key.nops == 0 && !a.key_src.valid && (a.key_src.dtype == NQE_INT64 || a.key_src.dtype == NQE_UINT64);
-    // exact min / max of a plain integer key column: one more read of the column (the fallback behind a sampled range)
-    auto measure_key_range = [&]() {
-        BufRef mm = dev_alloc(ctx, 16);
-        NQE_HIP_CHECK(hipMemsetAsync(mm->ptr, 0xFF, 8, ctx->stream));
-        NQE_HIP_CHECK(hipMemsetAsync(static_cast<char *>(mm->ptr) + 8, 0, 8, ctx->stream));
-        launch(ctx, "agg_key_range", key_range_kernel, dim3(stream_grid(ctx, in->rows, 256)), dim3(256), 0, (const uint64_t *)a.key_src.values, in->rows, key_flip,
-               (unsigned long long *)mm->ptr);
-        uint64_t h[2];
-        NQE_HIP_CHECK(hipMemcpyAsync(h, mm->ptr, 16, hipMemcpyDeviceToHost, ctx->stream));
-        sync(ctx);
-        // (span 0: the whole 64-bit range, or no rows)
-        return std::make_pair(int64_t(h[0] ^ key_flip), h[1] >= h[0] ? h[1] - h[0] + 1 : 0ull);
-    };
+    subsets_ok = V == 1 && !any_val_nullable && !a.key_src.valid && !(a.pred_mode != 0 && a.pred_src.valid);
+    range_limit = V <= 1 ? 4096 : 2048; // the smallest workgroup table among the passes
+    key_flip = a.key_src.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
+    plain_int_key = key_col >= 0 && !utf8_key && a.key.nops == 0 && !a.key_src.valid && (a.key_src.dtype == NQE_INT64 || a.key_src.dtype == NQE_UINT64);
+}
+
+// exact min / max of a plain integer key column: one more read of the column (the fallback behind a sampled range)
+std::pair<int64_t, uint64_t> AggRun::measure_key_range() {
+    BufRef mm = dev_alloc(ctx, 16);
+    NQE_HIP_CHECK(hipMemsetAsync(mm->ptr, 0xFF, 8, ctx->stream));
+    NQE_HIP_CHECK(hipMemsetAsync(static_cast<char *>(mm->ptr) + 8, 0, 8, ctx->stream));
+    launch(ctx, "agg_key_range", key_range_kernel, dim3(stream_grid(ctx, in->rows, 256)), dim3(256), 0, (const uint64_t *)a.key_src.values, in->rows, key_flip,
+           (unsigned long long *)mm->ptr);
+    uint64_t h[2];
+    NQE_HIP_CHECK(hipMemcpyAsync(h, mm->ptr, 16, hipMemcpyDeviceToHost, ctx->stream));
+    sync(ctx);
+    // (span 0: the whole 64-bit range, or no rows)
+    return std::make_pair(int64_t(h[0] ^ key_flip), h[1] >= h[0] ? h[1] - h[0] + 1 : 0ull);
+}
+void AggRun::sample_keys() {
     // ---- the first execution of a query shape (nothing remembered, or NQE_NO_PLAN_HINTS): a SAMPLE of the keys picks the starting
     // tier instead of falling through abandoned ones — the reference's run_sql is one-shot (db.rs:24-37), so the first execution is
     // the one that counts.  65536 keys (key_sample_kernel, ~20 us): their distinct count is a lower bound of the groups, so a tier it
     // rules out would certainly have overflowed; their min / max stand in for the full pass over a plain key column (the streaming
     // kernel checks every key against the range, and a key outside it asks for the exact measurement).  Only without a predicate: a
     // filter may leave far fewer groups than the table holds.
-    const bool no_hints_env = getenv("NQE_NO_PLAN_HINTS") != nullptr, no_sample = getenv("NQE_NO_KEY_SAMPLE") != nullptr; // (read per call)
-    bool range_sampled = false;
+    no_hints_env = getenv("NQE_NO_PLAN_HINTS") != nullptr; // (both read per call: tests switch them)
+    const bool no_sample = getenv("NQE_NO_KEY_SAMPLE") != nullptr;
     const bool simple_mod_key = a.key.nops == 1 && a.key.op[0] == NQE_OP_MODULOS && !a.key.lit_left[0] && (a.key.op_dtype[0] == NQE_INT64 || a.key.op_dtype[0] == NQE_UINT64) &&
                                 a.key.aux[0].abs_lit > 1;
     // (the tiers the sample may start in exist for the streaming kernel's shapes only: at least one value column, every one of them
@@ -1562,7 +1642,7 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             G = lo;
         }
         if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
-        if (D > 2 * range_limit || (D > range_limit && (!subsets_ok || subsets_max < 1))) {
+        if (D > 2 * range_limit || (D > range_limit && (!subsets_ok || sw.subsets_max < 1))) {
             partition_mode = true; // more distinct keys in the sample than the workgroup tables of the streaming tiers hold
             cap = std::max(cap, sized_cap);
             if (G > 800e3) slab_parts_log2 = PARTS_LOG2; // … and more than 256 partitions of one table each
@@ -1591,18 +1671,21 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             ctx->agg_hints[hint_key] = uint8_t(2);
         } else {
             ctx->agg_hints.emplace(hint_key, uint8_t(0)); // sampled: the single-pass tier (a later overflow overwrites this)
-            if (plain_int_key && !no_range) {
+            if (plain_int_key && !sw.no_key_range) {
                 // the sample's range: the whole column's when it is as narrow as a workgroup table (checked row by row by the kernel)
                 if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
                 ctx->agg_key_ranges[hint_key] = std::make_pair(int64_t(h[0] ^ key_flip), h[1] >= h[0] ? h[1] - h[0] + 1 : 0ull);
                 range_sampled = true;
             }
         }
-        if (getenv("NQE_DEBUG"))
+        if (sw.debug)
             fprintf(stderr, "[nqe] aggregate key sample: distinct %llu of %d -> ~%.3g groups; start partition %d subsets_log2 %d slab_parts_log2 %d\n",
                     (unsigned long long)D, KEY_SAMPLE, G, int(partition_mode), subsets_log2, slab_parts_log2);
     }
-    if (hint_key && !no_range && !partition_mode && subsets_log2 == 0 && (!no_hints_env || range_sampled) && plain_int_key) {
+}
+
+void AggRun::pick_key_range() {
+    if (hint_key && !sw.no_key_range && !partition_mode && subsets_log2 == 0 && (!no_hints_env || range_sampled) && plain_int_key) {
         // `group by k`, k a plain integer column (dictionary codes, small ids): a value range that fits a workgroup table makes the
         // streaming kernel address it by key - min (no hash, no probe sequence, replicas for a handful of groups).  The range comes
         // from the first execution's key sample, or — tables too small to sample, queries with a predicate — from one pass over the
@@ -1619,501 +1702,714 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
     }
     if (!subsets_ok) subsets_log2 = 0;
-    for (int attempt = 0;; ++attempt) {
-        range_part_used = false;
-        bool asked_partition = false; // a streaming pass of this attempt ran with allow_partition (see the TABLE_FULL handler below)
-        // The partitioned path (entered after the fast kernel asked for it) with a single pass over the value columns writes
-        // its groups densely: at most one LDS table's worth per (sub-)partition, never more than the input rows.
-        const bool dense = grouped && partition_mode && dense_ok && V <= NV && !any_val_nullable && !a.key_src.valid &&
-                           !(a.pred_mode != 0 && a.pred_src.valid);
-        uint32_t tcap = cap;
-        if (dense) tcap = uint32_t(std::min<int64_t>(int64_t(PARTS) * (level2 ? SUB : 1) * 4097, std::max<int64_t>(in->rows, 1)));
-        TableBufs tb = make_table(ctx, tcap, V, !grouped, dense);
-        // an un-grouped aggregate whose passes all took the fast kernel (no flag argument) under a predicate that cannot fault
-        bool flagless = !grouped && !pred_may_fault;
-        // nullable sources: one value column per pass — the two-column VNULL variants of the fast kernel spill 60-135 VGPRs
-        // (3.1-3.4 TB/s); two passes of the one-column variant (5.3 TB/s each over key + one value column) are faster
-        const int nv_step = (jit_whole || any_val_nullable || a.key_src.valid || (a.pred_mode != 0 && a.pred_src.valid)) ? 1 : NV;
-        bool slab_oom = false; // the slab allocation failed: redo the attempt in the exact form
-        // three value columns, none asking for min / max, over a key and predicate the streaming kernel computes itself (C1's
-        // `count(id), sum(age), avg(score) … group by id % 3`): ONE pass of the three-column instance (2048-slot workgroup table without min / max arrays)
-        // instead of two passes — 32 B/row read once instead of 16 + 24.  A pass that turns out not to fit (another kernel
-        // variant, more groups than that table holds) clears `three_on` and the attempt is redone in passes of one and two.
-        bool three = three_on && V == 3 && nv_step == NV && grouped && !partition_mode && subsets_log2 == 0 && (a.pred_mode == 0 || a.pred_mode == 1);
-        // (min / max of the LAST column only: its instance carries one pair of min / max arrays — count(id), sum(age), …, max(score), min(score))
-        for (int j = 0; three && j < V; ++j) three = !plan.need_minmax[size_t(j)] || j == V - 1;
-        bool three_redo = false, dense_redo = false;
-        // an odd number of value columns in passes of two leaves one pass with a single column: let it be the FIRST column when that
-        // one is the key column itself — its pass then reads 8 B/row through the single-load instance instead of 16
-        const bool first_alone = !three && nv_step == 2 && V >= 3 && (V % 2) == 1 && grouped && key_col >= 0 && !utf8_key && plan.val_cols[0] == key_col &&
-                                 is_word_type(in->cols[size_t(key_col)].dtype);
-        int pass_nv = 0;
-        for (int v0 = 0; v0 < std::max(V, 1); v0 += pass_nv) {
-            bool jit_launched = false;
-            pass_nv = three ? NVMAX : (first_alone && v0 == 0) ? 1 : nv_step;
-            a.nv = std::min(pass_nv, V - v0);
-            if (a.nv < 0) a.nv = 0;
-            a.v0 = v0;
-            bool valid_words_ok = true; // validity bitmaps readable as whole 64-bit words (owned buffers are padded)
-            for (int j = 0; j < NVMAX; ++j) {
-                std::memset(&a.val[j], 0, sizeof(ColSrc));
-                a.val_shares_key[j] = a.need_sum[j] = a.need_minmax[j] = 0;
-                if (j < a.nv) {
-                    int c = plan.val_cols[size_t(v0 + j)];
-                    const DevColumn &dc = in->cols[size_t(c)];
-                    if (dc.validity && !dc.validity->owned && (dc.length % 64) != 0) valid_words_ok = false;
-                    a.val[j] = src_of(dc);
-                    if (!is_word_type(dc.dtype)) a.val[j].values = nullptr; // count-only over Boolean/Utf8: validity only
-                    a.need_sum[j] = plan.need_sum[size_t(v0 + j)];
-                    a.need_minmax[j] = plan.need_minmax[size_t(v0 + j)];
-                    a.val_shares_key[j] = (grouped && c == key_col && is_word_type(dc.dtype)) ? 1 : 0;
+}
+
+void AggRun::begin_attempt() {
+    range_part_used = false;
+    asked_partition = false; // a streaming pass of this attempt ran with allow_partition (see the TABLE_FULL handler below)
+    // The partitioned path (entered after the fast kernel asked for it) with a single pass over the value columns writes
+    // its groups densely: at most one LDS table's worth per (sub-)partition, never more than the input rows.
+    dense = grouped && partition_mode && dense_ok && V <= NV && !any_val_nullable && !a.key_src.valid &&
+                       !(a.pred_mode != 0 && a.pred_src.valid);
+    uint32_t tcap = cap;
+    if (dense) tcap = uint32_t(std::min<int64_t>(int64_t(PARTS) * (level2 ? SUB : 1) * 4097, std::max<int64_t>(in->rows, 1)));
+    tb = make_table(ctx, tcap, V, !grouped, dense);
+    // an un-grouped aggregate whose passes all took the fast kernel (no flag argument) under a predicate that cannot fault
+    flagless = !grouped && !pred_may_fault;
+    // nullable sources: one value column per pass — the two-column VNULL variants of the fast kernel spill 60-135 VGPRs
+    // (3.1-3.4 TB/s); two passes of the one-column variant (5.3 TB/s each over key + one value column) are faster
+    nv_step = (jit_whole || any_val_nullable || a.key_src.valid || (a.pred_mode != 0 && a.pred_src.valid)) ? 1 : NV;
+    slab_oom = false; // the slab allocation failed: redo the attempt in the exact form
+    // three value columns, none asking for min / max, over a key and predicate the streaming kernel computes itself (C1's
+    // `count(id), sum(age), avg(score) … group by id % 3`): ONE pass of the three-column instance (2048-slot workgroup table without min / max arrays)
+    // instead of two passes — 32 B/row read once instead of 16 + 24.  A pass that turns out not to fit (another kernel
+    // variant, more groups than that table holds) clears `three_on` and the attempt is redone in passes of one and two.
+    three = three_on && V == 3 && nv_step == NV && grouped && !partition_mode && subsets_log2 == 0 && (a.pred_mode == 0 || a.pred_mode == 1);
+    // (min / max of the LAST column only: its instance carries one pair of min / max arrays — count(id), sum(age), …, max(score), min(score))
+    for (int j = 0; three && j < V; ++j) three = !plan.need_minmax[size_t(j)] || j == V - 1;
+    three_redo = dense_redo = false;
+    // an odd number of value columns in passes of two leaves one pass with a single column: let it be the FIRST column when that
+    // one is the key column itself — its pass then reads 8 B/row through the single-load instance instead of 16
+    first_alone = !three && nv_step == 2 && V >= 3 && (V % 2) == 1 && grouped && key_col >= 0 && !utf8_key && plan.val_cols[0] == key_col &&
+                             is_word_type(in->cols[size_t(key_col)].dtype);
+    pass_nv = 0;
+}
+
+// which kernel variant the pass's key, predicate and value columns admit (the members the tier functions read)
+PassStatus AggRun::shape_pass() {
+    a.lds_cap = 2048; // 1 value column: 72 KB (2 WG/CU); 2: 128 KB (1 WG/CU); 3 (no min / max arrays): 136 KB
+    int lg = 0;
+    while ((1 << lg) < a.lds_cap) ++lg;
+    a.lds_shift = 64 - lg;
+    size_t slots = size_t(a.lds_cap) + 1;
+    shmem = slots * 8 + size_t(std::max(a.nv, 1)) * slots * (a.nv == NVMAX ? 8 + 4 : 8 + 8 + 8 + 4);
+    if (a.nv == NVMAX && a.need_minmax[NVMAX - 1]) shmem += slots * 16; // the three-column instance with min / max on its last column
+    shmem = (shmem + 15) / 16 * 16;
+    blocks_per_cu = shmem <= 80 * 1024 ? 2 : 1;
+    grid = int(std::min<int64_t>(int64_t(ctx->num_cus) * blocks_per_cu,
+                                     (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
+    kk = 2, fast_key = -1; // kk: general-kernel key kind; fast_key: fast-kernel key kind (-1 = not covered)
+    if (a.key.nops == 0) kk = 0, fast_key = 0;
+    else if (a.key.nops == 1 && a.key.op[0] == NQE_OP_MODULOS && !a.key.lit_left[0] &&
+             (a.key.op_dtype[0] == NQE_INT64 || a.key.op_dtype[0] == NQE_UINT64)) {
+        if (a.key.aux[0].pow2_shift >= 0) kk = 1, fast_key = 1;
+        else if (a.key.aux[0].more >= 0) fast_key = 2; // `col % d`, d not a power of two: magic multiply
+    }
+    if (fast_key < 0 && a.key.nops >= 1) {
+        // any other chain of integer arithmetic with literals that cannot fault (divisors: literals other than 0
+        // and -1): the fast kernels evaluate it with the generic interpreter (KEY = 3)
+        bool ok = true;
+        for (int k = 0; k < a.key.nops; ++k) {
+            const int op = a.key.op[k];
+            ok = ok && op >= NQE_OP_PLUS && op <= NQE_OP_MODULOS && (a.key.op_dtype[k] == NQE_INT64 || a.key.op_dtype[k] == NQE_UINT64);
+            if (op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS)
+                ok = ok && !a.key.lit_left[k] && a.key.lit[k] != 0 && a.key.lit[k] != ~0ull;
+        }
+        if (ok) fast_key = 3;
+    }
+    // ---- `A and B [and …]` / `A or B [or …]` of up to four range tests (pred_mode 3): inside the single-pass streaming kernel when everything it
+    // reads is a plain 8-byte column; everywhere else (more groups than one workgroup table, validity bitmaps, a key the
+    // kernel does not compute) the predicate is materialised as a Boolean column first, as any other tree is
+    if (a.pred_mode == 1 && a.nv > 1 && a.pred.nops > 1) {
+        // a chain with Float64 steps is interpreted by the one-value-column instances only
+        bool f64_steps = false;
+        for (int k = 0; k < a.pred.nops; ++k) f64_steps = f64_steps || a.pred.op_dtype[k] == NQE_FLOAT64;
+        if (f64_steps) materialize_pred();
+    }
+    if (a.pred_mode == 3) {
+        bool ok = !partition_mode && subsets_log2 == 0 && fast_key >= 0 && a.nv >= 1 && is_word_type(a.key_src.dtype) && !a.key_src.valid;
+        // (the general form — tests with an arithmetic step, nested and/or — runs in the PRED = 5 instances: one value
+        // column per pass, built-in key shapes)
+        if (a.conj.general) ok = ok && a.nv == 1 && fast_key != 3;
+        for (int j = 0; j < a.nv; ++j) ok = ok && a.val[j].values && !a.val[j].valid;
+        const void *other = nullptr; // the one column the kernel would load for the predicate alone
+        if (ok) {
+            a.conj.need_pw = 0;
+            for (int t = 0; t < a.conj.n; ++t) {
+                const DevColumn &lc = in->cols[size_t(conj_col[t])];
+                const void *lp = lc.values->ptr;
+                if (lp == a.key_src.values) a.conj.t[t].src = 0;
+                else if (lp == a.val[0].values) a.conj.t[t].src = 1;
+                else {
+                    if (other && other != lp) ok = false; // two such columns: not this kernel's shape
+                    other = lp;
+                    a.conj.t[t].src = 2;
+                    a.conj.need_pw = 1;
+                    a.pred_src = src_of(lc);
                 }
-            }
-            if (in->rows == 0) continue;
-            if (grouped) {
-                a.lds_cap = 2048; // 1 value column: 72 KB (2 WG/CU); 2: 128 KB (1 WG/CU); 3 (no min / max arrays): 136 KB
-                int lg = 0;
-                while ((1 << lg) < a.lds_cap) ++lg;
-                a.lds_shift = 64 - lg;
-                size_t slots = size_t(a.lds_cap) + 1;
-                size_t shmem = slots * 8 + size_t(std::max(a.nv, 1)) * slots * (a.nv == NVMAX ? 8 + 4 : 8 + 8 + 8 + 4);
-                if (a.nv == NVMAX && a.need_minmax[NVMAX - 1]) shmem += slots * 16; // the three-column instance with min / max on its last column
-                shmem = (shmem + 15) / 16 * 16;
-                int blocks_per_cu = shmem <= 80 * 1024 ? 2 : 1;
-                int grid = int(std::min<int64_t>(int64_t(ctx->num_cus) * blocks_per_cu,
-                                                 (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
-                int kk = 2, fast_key = -1; // kk: general-kernel key kind; fast_key: fast-kernel key kind (-1 = not covered)
-                if (a.key.nops == 0) kk = 0, fast_key = 0;
-                else if (a.key.nops == 1 && a.key.op[0] == NQE_OP_MODULOS && !a.key.lit_left[0] &&
-                         (a.key.op_dtype[0] == NQE_INT64 || a.key.op_dtype[0] == NQE_UINT64)) {
-                    if (a.key.aux[0].pow2_shift >= 0) kk = 1, fast_key = 1;
-                    else if (a.key.aux[0].more >= 0) fast_key = 2; // `col % d`, d not a power of two: magic multiply
-                }
-                if (fast_key < 0 && a.key.nops >= 1) {
-                    // any other chain of integer arithmetic with literals that cannot fault (divisors: literals other than 0
-                    // and -1): the fast kernels evaluate it with the generic interpreter (KEY = 3)
-                    bool ok = true;
-                    for (int k = 0; k < a.key.nops; ++k) {
-                        const int op = a.key.op[k];
-                        ok = ok && op >= NQE_OP_PLUS && op <= NQE_OP_MODULOS && (a.key.op_dtype[k] == NQE_INT64 || a.key.op_dtype[k] == NQE_UINT64);
-                        if (op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS)
-                            ok = ok && !a.key.lit_left[k] && a.key.lit[k] != 0 && a.key.lit[k] != ~0ull;
-                    }
-                    if (ok) fast_key = 3;
-                }
-                // ---- `A and B [and …]` / `A or B [or …]` of up to four range tests (pred_mode 3): inside the single-pass streaming kernel when everything it
-                // reads is a plain 8-byte column; everywhere else (more groups than one workgroup table, validity bitmaps, a key the
-                // kernel does not compute) the predicate is materialised as a Boolean column first, as any other tree is
-                if (a.pred_mode == 1 && a.nv > 1 && a.pred.nops > 1) {
-                    // a chain with Float64 steps is interpreted by the one-value-column instances only
-                    bool f64_steps = false;
-                    for (int k = 0; k < a.pred.nops; ++k) f64_steps = f64_steps || a.pred.op_dtype[k] == NQE_FLOAT64;
-                    if (f64_steps) materialize_pred();
-                }
-                if (a.pred_mode == 3) {
-                    bool ok = !partition_mode && subsets_log2 == 0 && fast_key >= 0 && a.nv >= 1 && is_word_type(a.key_src.dtype) && !a.key_src.valid;
-                    // (the general form — tests with an arithmetic step, nested and/or — runs in the PRED = 5 instances: one value
-                    // column per pass, built-in key shapes)
-                    if (a.conj.general) ok = ok && a.nv == 1 && fast_key != 3;
-                    for (int j = 0; j < a.nv; ++j) ok = ok && a.val[j].values && !a.val[j].valid;
-                    const void *other = nullptr; // the one column the kernel would load for the predicate alone
-                    if (ok) {
-                        a.conj.need_pw = 0;
-                        for (int t = 0; t < a.conj.n; ++t) {
-                            const DevColumn &lc = in->cols[size_t(conj_col[t])];
-                            const void *lp = lc.values->ptr;
-                            if (lp == a.key_src.values) a.conj.t[t].src = 0;
-                            else if (lp == a.val[0].values) a.conj.t[t].src = 1;
-                            else {
-                                if (other && other != lp) ok = false; // two such columns: not this kernel's shape
-                                other = lp;
-                                a.conj.t[t].src = 2;
-                                a.conj.need_pw = 1;
-                                a.pred_src = src_of(lc);
-                            }
-                        }
-                    }
-                    if (!ok) materialize_pred();
-                }
-                // ---- any other fault-free tree over the same columns (pred_mode 4): the stack machine inside the streaming kernel
-                if (a.pred_mode == 4) {
-                    // (instances: one value column per pass, built-in key shapes — the stack machine's registers)
-                    bool ok = !partition_mode && subsets_log2 == 0 && fast_key >= 0 && fast_key != 3 && a.nv == 1 && is_word_type(a.key_src.dtype) && !a.key_src.valid;
-                    for (int j = 0; j < a.nv; ++j) ok = ok && a.val[j].values && !a.val[j].valid;
-                    TreePred tp = tree;
-                    const void *other = nullptr;
-                    int slot_of[TREE_MAX_COLS] = {0, 0, 0};
-                    a.tree_need_pw = 0;
-                    for (int c = 0; ok && c < tree.ncols; ++c) {
-                        const DevColumn &lc = in->cols[size_t(tree.col[c])];
-                        const void *lp = lc.values->ptr;
-                        if (lp == a.key_src.values) slot_of[c] = 0;
-                        else if (lp == a.val[0].values) slot_of[c] = 1;
-                        else {
-                            if (other && other != lp) ok = false; // two such columns: not this kernel's shape
-                            other = lp;
-                            slot_of[c] = 2;
-                            a.tree_need_pw = 1;
-                            a.pred_src = src_of(lc);
-                        }
-                    }
-                    if (ok) {
-                        for (int i = 0; i < tp.n; ++i) {
-                            if (tp.ins[i].a_src >= TS_W0) tp.ins[i].a_src = TS_W0 + slot_of[tp.ins[i].a_src - TS_W0];
-                            if (tp.ins[i].b_src >= TS_W0) tp.ins[i].b_src = TS_W0 + slot_of[tp.ins[i].b_src - TS_W0];
-                        }
-                        tree_buf = dev_alloc(ctx, sizeof(TreeInstr) * TREE_MAX_INSTR);
-                        launch(ctx, "agg_store_tree", store_tree_kernel, dim3(1), dim3(64), 0, tp, (TreeInstr *)tree_buf->ptr);
-                        a.tree_prog = reinterpret_cast<uint64_t>(tree_buf->ptr);
-                        a.tree_n = tp.n;
-                    } else
-                        materialize_pred();
-                }
-                // ---- kernel variant (see the template comment)
-                int pk = 0;
-                AggArgs ka = a;
-                if (a.pred_mode == 2) pk = 2;
-                else if (a.pred_mode == 3) pk = a.conj.general ? 5 : 4;
-                else if (a.pred_mode == 4) pk = 6;
-                else if (a.pred_mode == 1) {
-                    const SimpleExpr &pe = a.pred;
-                    pk = 3;
-                    if (pe.nops == 1 && pe.op[0] <= NQE_OP_GT_EQ && is_word_type(pe.src_dtype)) {
-                        pk = 1;
-                        if (pe.lit_left[0]) { // lit op x  ≡  x op' lit
-                            static const int flip[6] = {NQE_OP_EQ, NQE_OP_NOT_EQ, NQE_OP_GT, NQE_OP_GT_EQ, NQE_OP_LT, NQE_OP_LT_EQ};
-                            ka.pred.op[0] = flip[pe.op[0]];
-                            ka.pred.lit_left[0] = 0;
-                        }
-                    }
-                }
-                if (pk == 5) ka.tree_need_pw = a.conj.need_pw; // (the interpreted-predicate instances load the third word on this flag)
-                bool plain = is_word_type(a.key_src.dtype);
-                // a Boolean predicate column without nulls (a Boolean input column, or any predicate tree evaluated by the
-                // expression machine) is tested by the same variants as a separate integer predicate column: the word of a
-                // row is its bit
-                // NULL keys are dropped and a NULL predicate filters the row out (the NULL row a selection would emit has a NULL
-                // key / NULL values, Q4 + Q8): the VNULL variants AND both validity bits into the row's pass flag
-                const bool kp_nullable = a.key_src.valid != nullptr || (a.pred_mode != 0 && a.pred_src.valid != nullptr);
-                const bool bitmap_pred = a.pred_src.dtype == NQE_BOOLEAN && (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
-                if (a.pred_mode == 1 && !bitmap_pred) plain = plain && is_word_type(a.pred_src.dtype);
-                // value columns may carry validity bitmaps (VNULL variants of the fast kernel); the partitioned path and
-                // everything else nullable stays with the general kernel
-                bool vnull = kp_nullable;
-                for (int j = 0; j < a.nv; ++j) {
-                    plain = plain && a.val[j].values;
-                    vnull = vnull || a.val[j].valid != nullptr;
-                }
-                if (vnull && (partition_mode || !valid_words_ok || !kp_valid_words_ok)) plain = false;
-                if (bitmap_pred && !pred_bits_words_ok) plain = false;
-                FastPred fpred{};
-                if (bitmap_pred) fpred = bitmap_fast_pred();
-                bool range_pred = pk == 1 && make_fast_pred(a.pred, &fpred);
-                // any other fault-free integer chain `col op lit [op lit]` ending in a comparison: interpreted inside the fast kernel
-                bool chain_pred = false;
-                if (a.pred_mode == 1 && !bitmap_pred && !range_pred && a.pred.nops >= 1 &&
-                    a.pred.op[a.pred.nops - 1] <= NQE_OP_GT_EQ) {
-                    chain_pred = true;
-                    for (int k = 0; k < a.pred.nops; ++k) {
-                        const int op = a.pred.op[k], dt = a.pred.op_dtype[k];
-                        chain_pred = chain_pred && op <= NQE_OP_MODULOS && (dt == NQE_INT64 || dt == NQE_UINT64 || (dt == NQE_FLOAT64 && op != NQE_OP_MODULOS));
-                        if (op <= NQE_OP_GT_EQ && k != a.pred.nops - 1) chain_pred = false; // a comparison feeds nothing but the result
-                        if (op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS) {
-                            if (dt == NQE_FLOAT64) { // x / lit, lit != +-0 (a zero divisor is arrow's DivideByZero)
-                                double dl;
-                                std::memcpy(&dl, &a.pred.lit[k], 8);
-                                chain_pred = chain_pred && !a.pred.lit_left[k] && dl != 0.0;
-                            } else
-                                chain_pred = chain_pred && !a.pred.lit_left[k] && a.pred.lit[k] != 0 && a.pred.lit[k] != ~0ull;
-                        }
-                    }
-                }
-                bool fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || pk >= 4 || bitmap_pred || range_pred || chain_pred);
-                if (pk >= 4 && (!fast || vnull)) fail(NQE_ERR_NOT_SUPPORTED, "internal: a tree predicate reached a kernel that cannot evaluate it");
-                if (a.nv == NVMAX) {
-                    // the three-column instances: no predicate or a range test on the key column, the built-in key shapes, no validity
-                    const bool key_range = pk == 1 && range_pred && a.pred_shares_key && !bitmap_pred && !fpred.fmask;
-                    if (!(fast && (pk == 0 || key_range) && fast_key != 3 && !vnull && !partition_mode)) {
-                        three_on = false;
-                        three_redo = true;
-                        break;
-                    }
-                }
-                if (fast) {
-                    // variant 1 tests the key word with the integer range test alone; Float64 predicates and bitmaps use the
-                    // "other column" variant, whose extraction step applies the order mapping
-                    int fp = pk == 0 ? 0 : pk >= 4 ? pk : (chain_pred ? 3 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2));
-                    bool vf64 = true;
-                    for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
-                    if (partition_mode && !level2 && !slab_failed) {
-                        // ---- partitioned path, slab form: ONE pass scatters (key, values) tuples into per-workgroup slabs of fixed
-                        // capacity (no count pass, no scan, no read-back), then one workgroup per partition aggregates its slabs
-                        const int rpt = slab_scatter_rows_per_thread(fp, fast_key, a.nv);
-                        const int64_t tile_rows = int64_t(AGG_BLOCK) * rpt;
-                        int W = int(std::min<int64_t>(int64_t(ctx->num_cus) * slab_scatter_wg_per_cu(), (in->rows + tile_rows - 1) / tile_rows));
-                        int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
-                        W = int((in->rows + chunk - 1) / chunk);
-                        // one value column, integer keys: 12-byte tuples {value, int32 key} unless a key was seen not to fit
-                        // key-range partitions (aggregate_common.hpp: SlabArgs::range_span): 256 tables (512 beyond 2^20 values) of ceil(span / parts) <= 4096 slots;
-                        // their tuples hold key - range_min, which fits 32 bits whatever the keys' magnitude
-                        const bool range_part = a.nv == 1 && dense && range_part_ok && part_span != 0 && part_span <= (uint64_t(PARTS) << 12);
-                        const bool k32 = a.nv == 1 && (!key32_failed || range_part);
-                        int sparts_log2 = slab_parts_log2;
-                        if (range_part) sparts_log2 = part_span <= (uint64_t(256) << 12) ? 8 : PARTS_LOG2;
-                        const int used_parts = 1 << sparts_log2;
-                        const uint64_t rslots = range_part ? (part_span + (uint64_t(1) << sparts_log2) - 1) >> sparts_log2 : 0;
-                        range_part_used = range_part;
-                        if (getenv("NQE_DEBUG"))
-                            fprintf(stderr, "[nqe] slab partitions (hint %llx, k32 %d dense %d ok %d): range %d min %lld span %llu: %d tables of %llu slots (sampled %d)\n",
-                                    (unsigned long long)hint_key, int(k32), int(dense), int(range_part_ok), int(range_part), (long long)part_min, (unsigned long long)part_span, used_parts,
-                                    (unsigned long long)rslots, int(part_range_sampled));
-                        const int sparts = 1 << sparts_log2;
-                        const int64_t mean = chunk / used_parts;
-                        // an ODD number of 256-byte units per slab: with a power-of-two slab stride (16 KB at 10^8 rows) the 512 write
-                        // streams of a workgroup — and those of every other workgroup — start on the same HBM channel and move in
-                        // step (the scatter took 0.78 or 0.97 ms depending on where the buffer happened to land)
-                        const int64_t capt = ((mean + mean / 4 + 64 + 15) / 16 | 1) * 16;
-                        const size_t tw = size_t(1 + a.nv);
-                        const size_t tuple_bytes = k32 ? 12 : tw * 8;
-                        // the slabs take 1.25x the tuple volume (+ padding) on top of the group table: when that does not fit, the exact
-                        // form (count → scan → scatter into exactly sized partitions) still may — fall back instead of failing
-                        BufRef slabs, fill;
-                        try {
-                            static const bool test_oom = getenv("NQE_TEST_SLAB_OOM") != nullptr; // tests: as if the allocation had failed
-                            if (test_oom) fail(NQE_ERR_OUT_OF_MEMORY, "slab allocation (NQE_TEST_SLAB_OOM)");
-                            slabs = dev_alloc(ctx, size_t(sparts) * size_t(W) * size_t(capt) * tuple_bytes + 16);
-                            fill = dev_alloc(ctx, size_t(sparts) * size_t(W) * 4);
-                        } catch (const Error &e) {
-                            if (e.code != NQE_ERR_OUT_OF_MEMORY) throw;
-                            slab_failed = true;
-                            if (hint_key) ctx->agg_hints[hint_key] = uint8_t(17 | (key32_failed ? 0x40 : 0)); // partitioned, exact form: do not try the slabs again
-                            flags_reset(ctx);
-                            slab_oom = true;
-                            break;
-                        }
-                        SlabArgs sl;
-                        sl.slabs = (uint64_t *)slabs->ptr;
-                        sl.fill = (uint32_t *)fill->ptr;
-                        sl.chunk = chunk;
-                        sl.W = W;
-                        sl.cap = int32_t(capt);
-                        sl.parts_log2 = sparts_log2;
-                        sl.range_min = part_min;
-                        sl.range_span = range_part ? part_span : 0;
-                        const size_t sc_shmem = size_t(tile_rows) * 8 * tw + size_t(PARTS) * 12;
-                        launch(ctx, "agg_partition_scatter", pick_slab_scatter_kernel(fp, fast_key, a.nv, k32), dim3(W), dim3(AGG_BLOCK), sc_shmem, ka, fpred, sl,
-                               ctx->d_flags);
-                        AggArgs sa = ka;
-                        size_t sshmem = shmem;
-                        int sblocks = blocks_per_cu;
-                        if (a.nv == 1) { // one value column: a 4096-slot table (147 KB, one workgroup per CU) doubles the distinct keys a partition may hold
-                            sa.lds_cap = 4096;
-                            sa.lds_shift = 64 - 12;
-                            sshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
-                            sblocks = 1;
-                        }
-                        if (range_part) { // tables addressed by key - base: 28 bytes per key of the partition's interval
-                            const size_t dshmem = size_t(28) * size_t(rslots) + 16;
-                            const int dblocks = int(std::max<size_t>(1, std::min<size_t>(4, (size_t(144) << 10) / dshmem)));
-                            launch(ctx, "agg_segments_direct", pick_slab_segments_direct_kernel(vf64), dim3(std::min(used_parts, ctx->num_cus * dblocks)), dim3(AGG_BLOCK), dshmem, sa,
-                                   sl, tb.g, ctx->d_flags);
-                        } else
-                            launch(ctx, "agg_segments", pick_slab_segments_kernel(a.nv, vf64, k32), dim3(std::min(sparts, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem,
-                                   sa, sl, tb.g, ctx->d_flags);
-                        sync(ctx); // the slabs are released at the end of this scope
-                    } else if (partition_mode) {
-                        // ---- partitioned path, exact form: count → scan → scatter → one workgroup per partition (skewed keys whose
-                        // partitions overflow a slab, and the two-level form for more distinct keys than PARTS tables hold)
-                        const int64_t stepr = int64_t(AGG_BLOCK) * 8; // multiple of the count tile (4096) and the scatter tile (8192/4096)
-                        int nblk = int(std::min<int64_t>(512, (in->rows + stepr - 1) / stepr));
-                        int64_t chunk = ((in->rows + nblk - 1) / nblk + stepr - 1) / stepr * stepr;
-                        nblk = int((in->rows + chunk - 1) / chunk);
-                        const int64_t ncnt = int64_t(PARTS) * nblk;
-                        BufRef counts = dev_alloc(ctx, size_t(ncnt) * 4), offs = dev_alloc(ctx, size_t(ncnt + 1) * 8);
-                        PartArgs pa;
-                        std::memset(&pa, 0, sizeof(pa));
-                        pa.counts = (uint32_t *)counts->ptr;
-                        pa.offsets = (const uint64_t *)offs->ptr;
-                        pa.chunk = chunk;
-                        launch(ctx, "agg_partition_count", pick_part_kernel(fp, fast_key, a.nv, false), dim3(nblk), dim3(AGG_BLOCK), 0, ka, fpred, pa);
-                        exclusive_scan_u32_to_u64(ctx, (const uint32_t *)counts->ptr, (uint64_t *)offs->ptr, ncnt);
-                        const int64_t R = int64_t(read_scalar(ctx, (const uint64_t *)offs->ptr + ncnt));
-                        if (R > 0) {
-                            BufRef okey = dev_alloc(ctx, size_t(R) * 8 + 8), ov0 = dev_alloc(ctx, size_t(R) * 8 + 8), ov1;
-                            if (a.nv > 1) ov1 = dev_alloc(ctx, size_t(R) * 8 + 8);
-                            pa.out_key = (uint64_t *)okey->ptr;
-                            pa.out_val[0] = (uint64_t *)ov0->ptr;
-                            pa.out_val[1] = ov1 ? (uint64_t *)ov1->ptr : nullptr;
-                            const size_t sc_rows = size_t(AGG_BLOCK) * (a.nv == 1 ? 8 : 4);
-                            const size_t sc_shmem = sc_rows * 8 * size_t(1 + a.nv) + size_t(PARTS) * (8 + 4 + 4);
-                            launch(ctx, "agg_partition_scatter", pick_scatter_kernel(fp, fast_key, a.nv), dim3(nblk), dim3(AGG_BLOCK), sc_shmem, ka, fpred,
-                                   pa);
-                            // one value column: a 4096-slot table (147 KB, one workgroup per CU) doubles the distinct keys a partition may hold
-                            AggArgs sa = ka;
-                            size_t sshmem = shmem;
-                            int sblocks = blocks_per_cu;
-                            if (a.nv == 1) {
-                                sa.lds_cap = 4096;
-                                sa.lds_shift = 64 - 12;
-                                sshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
-                                sblocks = 1;
-                            }
-                            int sgrid = std::min(PARTS, ctx->num_cus * sblocks);
-                            auto segk = pick_segments_kernel(a.nv, vf64);
-                            if (!level2) {
-                                launch(ctx, "agg_segments", segk, dim3(sgrid), dim3(AGG_BLOCK), sshmem, sa, (const uint64_t *)offs->ptr, int64_t(nblk), PARTS,
-                                       PARTS_LOG2, 1, (const uint64_t *)okey->ptr, (const uint64_t *)ov0->ptr,
-                                       ov1 ? (const uint64_t *)ov1->ptr : (const uint64_t *)nullptr, tb.g, ctx->d_flags);
-                            } else {
-                                // partitions were overfull: split each into 64 sub-partitions, then one workgroup per sub-partition
-                                BufRef k2 = dev_alloc(ctx, size_t(R) * 8 + 8), v02 = dev_alloc(ctx, size_t(R) * 8 + 8), v12;
-                                if (a.nv > 1) v12 = dev_alloc(ctx, size_t(R) * 8 + 8);
-                                BufRef suboff = dev_alloc(ctx, size_t(PARTS) * SUB * 8 + 16);
-                                auto subk = pick_subpartition_kernel(a.nv);
-                                launch(ctx, "agg_subpartition", subk, dim3(std::min(PARTS, ctx->num_cus)), dim3(AGG_BLOCK), sc_rows * 8 * size_t(1 + a.nv),
-                                       (const uint64_t *)offs->ptr, int64_t(nblk), (const uint64_t *)okey->ptr, (const uint64_t *)ov0->ptr,
-                                       ov1 ? (const uint64_t *)ov1->ptr : (const uint64_t *)nullptr, (uint64_t *)k2->ptr, (uint64_t *)v02->ptr,
-                                       v12 ? (uint64_t *)v12->ptr : (uint64_t *)nullptr, (uint64_t *)suboff->ptr);
-                                launch(ctx, "agg_segments", segk, dim3(std::min(PARTS * SUB, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem, sa,
-                                       (const uint64_t *)suboff->ptr, int64_t(1), PARTS * SUB, PARTS_LOG2 + SUB_LOG2, 0, (const uint64_t *)k2->ptr,
-                                       (const uint64_t *)v02->ptr, v12 ? (const uint64_t *)v12->ptr : (const uint64_t *)nullptr, tb.g, ctx->d_flags);
-                                sync(ctx);
-                            }
-                            sync(ctx); // the partition buffers are released at the end of this scope
-                        }
-                    } else {
-                        // (only kernels that have a partitioned counterpart may ask for it — the fuzzer found an interpreted predicate
-                        // asking before the partition kernels had that variant: a densely laid out table went to the hashed general kernel)
-                        ka.allow_partition = in->rows >= (int64_t(1) << 18) ? 1 : 0;
-                        asked_partition = asked_partition || ka.allow_partition != 0;
-                        {
-                            // how often a wave looks at the overflow flags (aggregate_common.hpp): every 8th iteration; NQE_FLAG_CHECK_MASK=0: every one (A/B)
-                            const char *fm = getenv("NQE_FLAG_CHECK_MASK");
-                            const int m = fm ? atoi(fm) : 7;
-                            ka.flag_check_mask = (m == 0 || m == 1 || m == 3 || m == 7 || m == 15) ? m : 7;
-                        }
-                        // ONE 1024-thread workgroup per CU: fewer concurrent streams read HBM faster (A/B on one box: headline
-                        // 2.44 -> 2.39 ms, C3 2.56 -> 2.41 ms, random keys 3.63 -> 3.54 ms, 1 % nulls 0.81 -> 0.69 ms per 2e8 rows;
-                        // tools/stream_bench.hip shows the same for a bare read kernel)
-                        int fgrid = std::min(grid, ctx->num_cus);
-                        ka.subsets_log2 = subsets_log2;
-                        if (subsets_log2) fgrid = std::max(1, ctx->num_cus / (8 << subsets_log2)) * (8 << subsets_log2);
-                        size_t fshmem = shmem;
-                        if (a.nv == 1) { // the CU's LDS is this workgroup's alone: a 4096-slot table (147 KB) keeps up to ~3500 groups on this path
-                            ka.lds_cap = 4096;
-                            ka.lds_shift = 64 - 12;
-                            fshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
-                        }
-                        const int lastop = a.key.nops - 1;
-                        if (fast_key == 1 || fast_key == 2 ||
-                            (fast_key == 3 && a.key.op[lastop] == NQE_OP_MODULOS && !a.key.lit_left[lastop])) {
-                            // `… % m`: keys lie in (-m, m) (signed) or [0, m) — direct-mapped LDS table when that span fits
-                            const bool sgn = a.key.op_dtype[lastop] == NQE_INT64;
-                            const uint64_t m = a.key.aux[lastop].abs_lit;
-                            const uint64_t span = sgn ? 2 * m - 1 : m;
-                            if (m > 0 && span <= uint64_t(ka.lds_cap)) {
-                                ka.direct = 1;
-                                ka.direct_bias = sgn ? int64_t(m) - 1 : 0;
-                                // few groups: replicate the table so that the lanes of a wave do not all update the same words
-                                // (at most 64 replicas, at most 1024 slots in all: the merge walks them)
-                                while (ka.direct_rep < 6 && (span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
-                            }
-                        }
-                        if (range_on && fast_key == 0 && !ka.direct && range_span <= uint64_t(ka.lds_cap)) {
-                            // the key column's measured range fits the table: slot = key - min, every key checked against the range
-                            ka.direct = 2;
-                            ka.direct_bias = int64_t(0ull - uint64_t(range_min));
-                            ka.direct_span = range_span;
-                            while (ka.direct_rep < 6 && (range_span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
-                        }
-                        ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
-                        // the value column is the key column itself (and the predicate, if any, tests it too): the single-load instance
-                        // (three columns: the instance whose tile leaves the first value column out because it IS the key column)
-                        const bool share = (a.nv == 1 || a.nv == NVMAX) && a.val_shares_key[0] && a.val[0].values == a.key_src.values && (fp == 0 || fp == 1) && fast_key != 3 &&
-                                           !vnull && (a.nv == NVMAX || !vf64) && subsets_log2 == 0;
-                        // no aggregate of the pass asks for min / max: instances without those LDS arrays (two and three columns, and the
-                        // single-load one — `count(id) … group by id % 3` updates one LDS word per row instead of reading two and updating four)
-                        bool nomm = a.nv >= 2 || share;
-                        for (int j = 0; j < a.nv; ++j) nomm = nomm && !a.need_minmax[j];
-                        // a predicate tree the static kernel would interpret (PRED 5 / 6) over `col % m` keys and one value column: the lean
-                        // run-time specialised kernel, once it has been compiled — its workgroup tables are folded into the group table here
-                        // interpreted chain predicates (PRED 3: `id % 10 < 5`, `id * 3 >= K`) take the specialised kernel too: 0.70 -> 0.555 ms per 2x10^8 rows
-                        const bool jit_chains = getenv("NQE_NO_AGG_JIT_CHAINS") == nullptr;
-                        BufRef jit_partials;
-                        uint32_t jit_span = 0;
-                        int64_t jit_bias = 0;
-                        // … and so do interpreted chain KEYS (`(id + 1) % 1000`, KEY 3) whatever the predicate: the kernel bakes the whole key program
-                        // NQE_AGG_JIT_ALL: 1 (default) = also `col % m` by magic multiply (KEY 2: the literal modulus baked in — `id % 1000` 0.584 -> 0.548 ms, `id % 2000`
-                        // 0.643 -> 0.560 per 2x10^8 rows), 2 = every `% m` key (A/B: the headline's power-of-two key 2.53 vs 2.47 ms — within noise, it stays static), 0 = neither
-                        static const int jit_all = getenv("NQE_AGG_JIT_ALL") ? atoi(getenv("NQE_AGG_JIT_ALL")) : 1;
-                        const bool jit_try = jit_whole || (has_pred && (fp >= 5 || (fp == 3 && jit_chains))) || (fast_key == 3 && jit_chains) || (jit_all >= 1 && fast_key == 2) || jit_all >= 2;
-                        if (jit_try && (fast_key == 1 || fast_key == 2 || fast_key == 3) && ka.direct == 1 && ka.direct_rep == 0 && a.nv == 1 && !vnull && subsets_log2 == 0 &&
-                            key_col >= 0 && a.val[0].values &&
-                            aggregate_tree_specialised(ctx, in, has_pred ? pred : nullptr, pred_nodes, group, group_nodes, plan.val_cols[size_t(v0)], fgrid,
-                                                       &jit_partials, &jit_span, &jit_bias)) {
-                            const size_t cells = size_t(fgrid) * jit_span;
-                            const double *ps = (const double *)jit_partials->ptr;
-                            jit_launched = true;
-                            launch(ctx, "agg_merge_partials", agg_merge_partials_kernel, dim3((jit_span + 3) / 4), dim3(256), 0, ps, ps + cells, ps + 2 * cells,
-                                   reinterpret_cast<const uint32_t *>(ps + 3 * cells), fgrid, jit_span, jit_bias, tb.g, a.v0, ctx->d_flags);
-                        } else if (jit_whole) {
-                            jit_redo = true; // (cannot happen once the dry run said yes — but a static kernel must never run without the predicate)
-                            break;
-                        } else {
-                        FastKernel fk = pick_fast_kernel(fp, fast_key, a.nv, vf64, vnull, subsets_log2 != 0, nomm, share);
-                        if (!fk) fail(NQE_ERR_NOT_SUPPORTED, "internal: no such variant of the streaming aggregate kernel");
-                        launch(ctx, "agg_grouped_fast", fk, dim3(fgrid), dim3(AGG_BLOCK), fshmem, ka, fpred, tb.g, ctx->d_flags);
-                        }
-                    }
-                } else {
-                    // the general kernel's PLAIN variant reads predicate and values as bare 8-byte words: not for a Boolean
-                    // predicate column (bits) nor nullable values (found by the differential fuzzer: a bitmap predicate with
-                    // a key shape the fast kernel does not cover was read as words)
-                    if (dense) { // a pass the partition kernels do not cover under a densely written table: the hashed table, the attempt again
-                        dense_ok = false;
-                        dense_redo = true;
-                        break;
-                    }
-                    launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain && !vnull && !bitmap_pred), dim3(std::min(grid, ctx->num_cus)), dim3(AGG_BLOCK), shmem, ka, tb.g,
-                           ctx->d_flags);
-                }
-            } else {
-                int grid = int(std::min<int64_t>(int64_t(ctx->num_cus), // one 1024-thread workgroup per CU (A/B: 0.82 -> 0.57 ms per 2e8 rows)
-                                                 (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
-                BufRef partials = dev_alloc(ctx, size_t(grid) * NV * sizeof(Partial));
-                // fast path: plain 8-byte value columns, predicate none or an integer `col cmp lit`
-                FastPred ufp{};
-                bool uplain = a.nv >= 1;
-                bool uvnull = a.pred_mode != 0 && a.pred_src.valid != nullptr;
-                for (int j = 0; j < a.nv; ++j) {
-                    uplain = uplain && a.val[j].values;
-                    uvnull = uvnull || a.val[j].valid != nullptr;
-                }
-                if (uvnull && (!valid_words_ok || !kp_valid_words_ok)) uplain = false; // bitmaps must be readable as whole words
-                if (a.pred_src.dtype == NQE_BOOLEAN && a.pred_mode == 1 && a.pred.nops == 0 && !pred_bits_words_ok) uplain = false;
-                const bool ubitmap = a.pred_src.dtype == NQE_BOOLEAN && (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
-                if (ubitmap) ufp = bitmap_fast_pred();
-                bool upred_ok = a.pred_mode == 0 || ubitmap ||
-                                (a.pred_mode == 1 && is_word_type(a.pred_src.dtype) && make_fast_pred(a.pred, &ufp));
-                if (uplain && upred_ok) {
-                    int up = a.pred_mode == 0 ? 0 : ((a.pred_src.values == a.val[0].values && !ubitmap && !ufp.fmask) ? 1 : 2);
-                    bool vf64 = true;
-                    for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
-                    launch(ctx, "agg_ungrouped_fast", pick_ungrouped_fast(up, a.nv, vf64, uvnull), dim3(grid), dim3(AGG_BLOCK), 0, a, ufp,
-                           (Partial *)partials->ptr);
-                } else {
-                    flagless = false;
-                    launch(ctx, "agg_ungrouped", agg_ungrouped_kernel, dim3(grid), dim3(AGG_BLOCK), 0, a, (Partial *)partials->ptr,
-                           ctx->d_flags);
-                }
-                launch(ctx, "agg_ungrouped_fold", agg_ungrouped_fold_kernel, dim3(1), dim3(64), 0,
-                       (const Partial *)partials->ptr, grid, a.nv, v0, tb.g);
-            }
-            if (jit_whole && !jit_launched) { // a pass went through a static kernel, i.e. WITHOUT the predicate: this attempt's table is discarded
-                jit_redo = true;
-                break;
             }
         }
+        if (!ok) materialize_pred();
+    }
+    // ---- any other fault-free tree over the same columns (pred_mode 4): the stack machine inside the streaming kernel
+    if (a.pred_mode == 4) {
+        // (instances: one value column per pass, built-in key shapes — the stack machine's registers)
+        bool ok = !partition_mode && subsets_log2 == 0 && fast_key >= 0 && fast_key != 3 && a.nv == 1 && is_word_type(a.key_src.dtype) && !a.key_src.valid;
+        for (int j = 0; j < a.nv; ++j) ok = ok && a.val[j].values && !a.val[j].valid;
+        TreePred tp = tree;
+        const void *other = nullptr;
+        int slot_of[TREE_MAX_COLS] = {0, 0, 0};
+        a.tree_need_pw = 0;
+        for (int c = 0; ok && c < tree.ncols; ++c) {
+            const DevColumn &lc = in->cols[size_t(tree.col[c])];
+            const void *lp = lc.values->ptr;
+            if (lp == a.key_src.values) slot_of[c] = 0;
+            else if (lp == a.val[0].values) slot_of[c] = 1;
+            else {
+                if (other && other != lp) ok = false; // two such columns: not this kernel's shape
+                other = lp;
+                slot_of[c] = 2;
+                a.tree_need_pw = 1;
+                a.pred_src = src_of(lc);
+            }
+        }
+        if (ok) {
+            for (int i = 0; i < tp.n; ++i) {
+                if (tp.ins[i].a_src >= TS_W0) tp.ins[i].a_src = TS_W0 + slot_of[tp.ins[i].a_src - TS_W0];
+                if (tp.ins[i].b_src >= TS_W0) tp.ins[i].b_src = TS_W0 + slot_of[tp.ins[i].b_src - TS_W0];
+            }
+            tree_buf = dev_alloc(ctx, sizeof(TreeInstr) * TREE_MAX_INSTR);
+            launch(ctx, "agg_store_tree", store_tree_kernel, dim3(1), dim3(64), 0, tp, (TreeInstr *)tree_buf->ptr);
+            a.tree_prog = reinterpret_cast<uint64_t>(tree_buf->ptr);
+            a.tree_n = tp.n;
+        } else
+            materialize_pred();
+    }
+    // ---- kernel variant (see the template comment)
+    pk = 0;
+    ka = a;
+    if (a.pred_mode == 2) pk = 2;
+    else if (a.pred_mode == 3) pk = a.conj.general ? 5 : 4;
+    else if (a.pred_mode == 4) pk = 6;
+    else if (a.pred_mode == 1) {
+        const SimpleExpr &pe = a.pred;
+        pk = 3;
+        if (pe.nops == 1 && pe.op[0] <= NQE_OP_GT_EQ && is_word_type(pe.src_dtype)) {
+            pk = 1;
+            if (pe.lit_left[0]) { // lit op x  ≡  x op' lit
+                static const int flip[6] = {NQE_OP_EQ, NQE_OP_NOT_EQ, NQE_OP_GT, NQE_OP_GT_EQ, NQE_OP_LT, NQE_OP_LT_EQ};
+                ka.pred.op[0] = flip[pe.op[0]];
+                ka.pred.lit_left[0] = 0;
+            }
+        }
+    }
+    if (pk == 5) ka.tree_need_pw = a.conj.need_pw; // (the interpreted-predicate instances load the third word on this flag)
+    plain = is_word_type(a.key_src.dtype);
+    // a Boolean predicate column without nulls (a Boolean input column, or any predicate tree evaluated by the
+    // expression machine) is tested by the same variants as a separate integer predicate column: the word of a
+    // row is its bit
+    // NULL keys are dropped and a NULL predicate filters the row out (the NULL row a selection would emit has a NULL
+    // key / NULL values, Q4 + Q8): the VNULL variants AND both validity bits into the row's pass flag
+    const bool kp_nullable = a.key_src.valid != nullptr || (a.pred_mode != 0 && a.pred_src.valid != nullptr);
+    bitmap_pred = a.pred_src.dtype == NQE_BOOLEAN && (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
+    if (a.pred_mode == 1 && !bitmap_pred) plain = plain && is_word_type(a.pred_src.dtype);
+    // value columns may carry validity bitmaps (VNULL variants of the fast kernel); the partitioned path and
+    // everything else nullable stays with the general kernel
+    vnull = kp_nullable;
+    for (int j = 0; j < a.nv; ++j) {
+        plain = plain && a.val[j].values;
+        vnull = vnull || a.val[j].valid != nullptr;
+    }
+    if (vnull && (partition_mode || !valid_words_ok || !kp_valid_words_ok)) plain = false;
+    if (bitmap_pred && !pred_bits_words_ok) plain = false;
+    fpred = FastPred{};
+    if (bitmap_pred) fpred = bitmap_fast_pred();
+    range_pred = pk == 1 && make_fast_pred(a.pred, &fpred);
+    // any other fault-free integer chain `col op lit [op lit]` ending in a comparison: interpreted inside the fast kernel
+    chain_pred = false;
+    if (a.pred_mode == 1 && !bitmap_pred && !range_pred && a.pred.nops >= 1 &&
+        a.pred.op[a.pred.nops - 1] <= NQE_OP_GT_EQ) {
+        chain_pred = true;
+        for (int k = 0; k < a.pred.nops; ++k) {
+            const int op = a.pred.op[k], dt = a.pred.op_dtype[k];
+            chain_pred = chain_pred && op <= NQE_OP_MODULOS && (dt == NQE_INT64 || dt == NQE_UINT64 || (dt == NQE_FLOAT64 && op != NQE_OP_MODULOS));
+            if (op <= NQE_OP_GT_EQ && k != a.pred.nops - 1) chain_pred = false; // a comparison feeds nothing but the result
+            if (op == NQE_OP_DIVIDE || op == NQE_OP_MODULOS) {
+                if (dt == NQE_FLOAT64) { // x / lit, lit != +-0 (a zero divisor is arrow's DivideByZero)
+                    double dl;
+                    std::memcpy(&dl, &a.pred.lit[k], 8);
+                    chain_pred = chain_pred && !a.pred.lit_left[k] && dl != 0.0;
+                } else
+                    chain_pred = chain_pred && !a.pred.lit_left[k] && a.pred.lit[k] != 0 && a.pred.lit[k] != ~0ull;
+            }
+        }
+    }
+    fast = plain && a.nv >= 1 && fast_key >= 0 && (pk == 0 || pk >= 4 || bitmap_pred || range_pred || chain_pred);
+    if (pk >= 4 && (!fast || vnull)) fail(NQE_ERR_NOT_SUPPORTED, "internal: a tree predicate reached a kernel that cannot evaluate it");
+    if (a.nv == NVMAX) {
+        // the three-column instances: no predicate or a range test on the key column, the built-in key shapes, no validity
+        const bool key_range = pk == 1 && range_pred && a.pred_shares_key && !bitmap_pred && !fpred.fmask;
+        if (!(fast && (pk == 0 || key_range) && fast_key != 3 && !vnull && !partition_mode)) {
+            three_on = false;
+            three_redo = true;
+            return PassStatus::Abort;
+        }
+    }
+    return PassStatus::Done;
+}
+
+// ---- partitioned path, slab form
+PassStatus AggRun::tier_slab() {
+    // ---- partitioned path, slab form: ONE pass scatters (key, values) tuples into per-workgroup slabs of fixed
+    // capacity (no count pass, no scan, no read-back), then one workgroup per partition aggregates its slabs
+    const int rpt = slab_scatter_rows_per_thread(fp, fast_key, a.nv);
+    const int64_t tile_rows = int64_t(AGG_BLOCK) * rpt;
+    int W = int(std::min<int64_t>(int64_t(ctx->num_cus) * slab_scatter_wg_per_cu(), (in->rows + tile_rows - 1) / tile_rows));
+    int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
+    W = int((in->rows + chunk - 1) / chunk);
+    // one value column, integer keys: 12-byte tuples {value, int32 key} unless a key was seen not to fit
+    // key-range partitions (aggregate_common.hpp: SlabArgs::range_span): 256 tables (512 beyond 2^20 values) of ceil(span / parts) <= 4096 slots;
+    // their tuples hold key - range_min, which fits 32 bits whatever the keys' magnitude
+    const bool range_part = a.nv == 1 && dense && range_part_ok && part_span != 0 && part_span <= (uint64_t(PARTS) << 12);
+    const bool k32 = a.nv == 1 && (!key32_failed || range_part);
+    int sparts_log2 = slab_parts_log2;
+    if (range_part) sparts_log2 = part_span <= (uint64_t(256) << 12) ? 8 : PARTS_LOG2;
+    const int used_parts = 1 << sparts_log2;
+    const uint64_t rslots = range_part ? (part_span + (uint64_t(1) << sparts_log2) - 1) >> sparts_log2 : 0;
+    range_part_used = range_part;
+    if (sw.debug)
+        fprintf(stderr, "[nqe] slab partitions (hint %llx, k32 %d dense %d ok %d): range %d min %lld span %llu: %d tables of %llu slots (sampled %d)\n",
+                (unsigned long long)hint_key, int(k32), int(dense), int(range_part_ok), int(range_part), (long long)part_min, (unsigned long long)part_span, used_parts,
+                (unsigned long long)rslots, int(part_range_sampled));
+    const int sparts = 1 << sparts_log2;
+    const int64_t mean = chunk / used_parts;
+    // an ODD number of 256-byte units per slab: with a power-of-two slab stride (16 KB at 10^8 rows) the 512 write
+    // streams of a workgroup — and those of every other workgroup — start on the same HBM channel and move in
+    // step (the scatter took 0.78 or 0.97 ms depending on where the buffer happened to land)
+    const int64_t capt = ((mean + mean / 4 + 64 + 15) / 16 | 1) * 16;
+    const size_t tw = size_t(1 + a.nv);
+    const size_t tuple_bytes = k32 ? 12 : tw * 8;
+    // the slabs take 1.25x the tuple volume (+ padding) on top of the group table: when that does not fit, the exact
+    // form (count → scan → scatter into exactly sized partitions) still may — fall back instead of failing
+    BufRef slabs, fill;
+    try {
+        if (getenv("NQE_TEST_SLAB_OOM")) fail(NQE_ERR_OUT_OF_MEMORY, "slab allocation (NQE_TEST_SLAB_OOM)"); // tests: as if the allocation had failed
+        slabs = dev_alloc(ctx, size_t(sparts) * size_t(W) * size_t(capt) * tuple_bytes + 16);
+        fill = dev_alloc(ctx, size_t(sparts) * size_t(W) * 4);
+    } catch (const Error &e) {
+        if (e.code != NQE_ERR_OUT_OF_MEMORY) throw;
+        slab_failed = true;
+        if (hint_key) ctx->agg_hints[hint_key] = uint8_t(17 | (key32_failed ? 0x40 : 0)); // partitioned, exact form: do not try the slabs again
+        flags_reset(ctx);
+        slab_oom = true;
+        return PassStatus::Abort;
+    }
+    SlabArgs sl;
+    sl.slabs = (uint64_t *)slabs->ptr;
+    sl.fill = (uint32_t *)fill->ptr;
+    sl.chunk = chunk;
+    sl.W = W;
+    sl.cap = int32_t(capt);
+    sl.parts_log2 = sparts_log2;
+    sl.range_min = part_min;
+    sl.range_span = range_part ? part_span : 0;
+    const size_t sc_shmem = size_t(tile_rows) * 8 * tw + size_t(PARTS) * 12;
+    launch(ctx, "agg_partition_scatter", pick_slab_scatter_kernel(fp, fast_key, a.nv, k32), dim3(W), dim3(AGG_BLOCK), sc_shmem, ka, fpred, sl,
+           ctx->d_flags);
+    AggArgs sa = ka;
+    size_t sshmem = shmem;
+    int sblocks = blocks_per_cu;
+    if (a.nv == 1) { // one value column: a 4096-slot table (147 KB, one workgroup per CU) doubles the distinct keys a partition may hold
+        sa.lds_cap = 4096;
+        sa.lds_shift = 64 - 12;
+        sshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
+        sblocks = 1;
+    }
+    if (range_part) { // tables addressed by key - base: 28 bytes per key of the partition's interval
+        const size_t dshmem = size_t(28) * size_t(rslots) + 16;
+        const int dblocks = int(std::max<size_t>(1, std::min<size_t>(4, (size_t(144) << 10) / dshmem)));
+        launch(ctx, "agg_segments_direct", pick_slab_segments_direct_kernel(vf64), dim3(std::min(used_parts, ctx->num_cus * dblocks)), dim3(AGG_BLOCK), dshmem, sa,
+               sl, tb.g, ctx->d_flags);
+    } else
+        launch(ctx, "agg_segments", pick_slab_segments_kernel(a.nv, vf64, k32), dim3(std::min(sparts, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem,
+               sa, sl, tb.g, ctx->d_flags);
+    sync(ctx); // the slabs are released at the end of this scope
+    return PassStatus::Done;
+}
+
+void AggRun::tier_exact() {
+    // ---- partitioned path, exact form: count → scan → scatter → one workgroup per partition (skewed keys whose
+    // partitions overflow a slab, and the two-level form for more distinct keys than PARTS tables hold)
+    const int64_t stepr = int64_t(AGG_BLOCK) * 8; // multiple of the count tile (4096) and the scatter tile (8192/4096)
+    int nblk = int(std::min<int64_t>(512, (in->rows + stepr - 1) / stepr));
+    int64_t chunk = ((in->rows + nblk - 1) / nblk + stepr - 1) / stepr * stepr;
+    nblk = int((in->rows + chunk - 1) / chunk);
+    const int64_t ncnt = int64_t(PARTS) * nblk;
+    BufRef counts = dev_alloc(ctx, size_t(ncnt) * 4), offs = dev_alloc(ctx, size_t(ncnt + 1) * 8);
+    PartArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.counts = (uint32_t *)counts->ptr;
+    pa.offsets = (const uint64_t *)offs->ptr;
+    pa.chunk = chunk;
+    launch(ctx, "agg_partition_count", pick_part_kernel(fp, fast_key, a.nv, false), dim3(nblk), dim3(AGG_BLOCK), 0, ka, fpred, pa);
+    exclusive_scan_u32_to_u64(ctx, (const uint32_t *)counts->ptr, (uint64_t *)offs->ptr, ncnt);
+    const int64_t R = int64_t(read_scalar(ctx, (const uint64_t *)offs->ptr + ncnt));
+    if (R > 0) {
+        BufRef okey = dev_alloc(ctx, size_t(R) * 8 + 8), ov0 = dev_alloc(ctx, size_t(R) * 8 + 8), ov1;
+        if (a.nv > 1) ov1 = dev_alloc(ctx, size_t(R) * 8 + 8);
+        pa.out_key = (uint64_t *)okey->ptr;
+        pa.out_val[0] = (uint64_t *)ov0->ptr;
+        pa.out_val[1] = ov1 ? (uint64_t *)ov1->ptr : nullptr;
+        const size_t sc_rows = size_t(AGG_BLOCK) * (a.nv == 1 ? 8 : 4);
+        const size_t sc_shmem = sc_rows * 8 * size_t(1 + a.nv) + size_t(PARTS) * (8 + 4 + 4);
+        launch(ctx, "agg_partition_scatter", pick_scatter_kernel(fp, fast_key, a.nv), dim3(nblk), dim3(AGG_BLOCK), sc_shmem, ka, fpred,
+               pa);
+        // one value column: a 4096-slot table (147 KB, one workgroup per CU) doubles the distinct keys a partition may hold
+        AggArgs sa = ka;
+        size_t sshmem = shmem;
+        int sblocks = blocks_per_cu;
+        if (a.nv == 1) {
+            sa.lds_cap = 4096;
+            sa.lds_shift = 64 - 12;
+            sshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
+            sblocks = 1;
+        }
+        int sgrid = std::min(PARTS, ctx->num_cus * sblocks);
+        auto segk = pick_segments_kernel(a.nv, vf64);
+        if (!level2) {
+            launch(ctx, "agg_segments", segk, dim3(sgrid), dim3(AGG_BLOCK), sshmem, sa, (const uint64_t *)offs->ptr, int64_t(nblk), PARTS,
+                   PARTS_LOG2, 1, (const uint64_t *)okey->ptr, (const uint64_t *)ov0->ptr,
+                   ov1 ? (const uint64_t *)ov1->ptr : (const uint64_t *)nullptr, tb.g, ctx->d_flags);
+        } else {
+            // partitions were overfull: split each into 64 sub-partitions, then one workgroup per sub-partition
+            BufRef k2 = dev_alloc(ctx, size_t(R) * 8 + 8), v02 = dev_alloc(ctx, size_t(R) * 8 + 8), v12;
+            if (a.nv > 1) v12 = dev_alloc(ctx, size_t(R) * 8 + 8);
+            BufRef suboff = dev_alloc(ctx, size_t(PARTS) * SUB * 8 + 16);
+            auto subk = pick_subpartition_kernel(a.nv);
+            launch(ctx, "agg_subpartition", subk, dim3(std::min(PARTS, ctx->num_cus)), dim3(AGG_BLOCK), sc_rows * 8 * size_t(1 + a.nv),
+                   (const uint64_t *)offs->ptr, int64_t(nblk), (const uint64_t *)okey->ptr, (const uint64_t *)ov0->ptr,
+                   ov1 ? (const uint64_t *)ov1->ptr : (const uint64_t *)nullptr, (uint64_t *)k2->ptr, (uint64_t *)v02->ptr,
+                   v12 ? (uint64_t *)v12->ptr : (uint64_t *)nullptr, (uint64_t *)suboff->ptr);
+            launch(ctx, "agg_segments", segk, dim3(std::min(PARTS * SUB, ctx->num_cus * sblocks)), dim3(AGG_BLOCK), sshmem, sa,
+                   (const uint64_t *)suboff->ptr, int64_t(1), PARTS * SUB, PARTS_LOG2 + SUB_LOG2, 0, (const uint64_t *)k2->ptr,
+                   (const uint64_t *)v02->ptr, v12 ? (const uint64_t *)v12->ptr : (const uint64_t *)nullptr, tb.g, ctx->d_flags);
+            sync(ctx);
+        }
+        sync(ctx); // the partition buffers are released at the end of this scope
+    }
+}
+
+PassStatus AggRun::tier_streaming(int v0) {
+    // (only kernels that have a partitioned counterpart may ask for it — the fuzzer found an interpreted predicate
+    // asking before the partition kernels had that variant: a densely laid out table went to the hashed general kernel)
+    ka.allow_partition = in->rows >= (int64_t(1) << 18) ? 1 : 0;
+    asked_partition = asked_partition || ka.allow_partition != 0;
+    ka.flag_check_mask = sw.flag_check_mask; // how often a wave looks at the overflow flags (aggregate_common.hpp): every 8th iteration; NQE_FLAG_CHECK_MASK=0: every one
+    // ONE 1024-thread workgroup per CU: fewer concurrent streams read HBM faster (A/B on one box: headline
+    // 2.44 -> 2.39 ms, C3 2.56 -> 2.41 ms, random keys 3.63 -> 3.54 ms, 1 % nulls 0.81 -> 0.69 ms per 2e8 rows;
+    // tools/stream_bench.hip shows the same for a bare read kernel)
+    int fgrid = std::min(grid, ctx->num_cus);
+    ka.subsets_log2 = subsets_log2;
+    if (subsets_log2) fgrid = std::max(1, ctx->num_cus / (8 << subsets_log2)) * (8 << subsets_log2);
+    size_t fshmem = shmem;
+    if (a.nv == 1) { // the CU's LDS is this workgroup's alone: a 4096-slot table (147 KB) keeps up to ~3500 groups on this path
+        ka.lds_cap = 4096;
+        ka.lds_shift = 64 - 12;
+        fshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
+    }
+    const int lastop = a.key.nops - 1;
+    if (fast_key == 1 || fast_key == 2 ||
+        (fast_key == 3 && a.key.op[lastop] == NQE_OP_MODULOS && !a.key.lit_left[lastop])) {
+        // `… % m`: keys lie in (-m, m) (signed) or [0, m) — direct-mapped LDS table when that span fits
+        const bool sgn = a.key.op_dtype[lastop] == NQE_INT64;
+        const uint64_t m = a.key.aux[lastop].abs_lit;
+        const uint64_t span = sgn ? 2 * m - 1 : m;
+        if (m > 0 && span <= uint64_t(ka.lds_cap)) {
+            ka.direct = 1;
+            ka.direct_bias = sgn ? int64_t(m) - 1 : 0;
+            // few groups: replicate the table so that the lanes of a wave do not all update the same words
+            // (at most 64 replicas, at most 1024 slots in all: the merge walks them)
+            while (ka.direct_rep < 6 && (span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
+        }
+    }
+    if (range_on && fast_key == 0 && !ka.direct && range_span <= uint64_t(ka.lds_cap)) {
+        // the key column's measured range fits the table: slot = key - min, every key checked against the range
+        ka.direct = 2;
+        ka.direct_bias = int64_t(0ull - uint64_t(range_min));
+        ka.direct_span = range_span;
+        while (ka.direct_rep < 6 && (range_span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
+    }
+    ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
+    // the value column is the key column itself (and the predicate, if any, tests it too): the single-load instance
+    // (three columns: the instance whose tile leaves the first value column out because it IS the key column)
+    const bool share = (a.nv == 1 || a.nv == NVMAX) && a.val_shares_key[0] && a.val[0].values == a.key_src.values && (fp == 0 || fp == 1) && fast_key != 3 &&
+                       !vnull && (a.nv == NVMAX || !vf64) && subsets_log2 == 0;
+    // no aggregate of the pass asks for min / max: instances without those LDS arrays (two and three columns, and the
+    // single-load one — `count(id) … group by id % 3` updates one LDS word per row instead of reading two and updating four)
+    bool nomm = a.nv >= 2 || share;
+    for (int j = 0; j < a.nv; ++j) nomm = nomm && !a.need_minmax[j];
+    // a predicate tree the static kernel would interpret (PRED 5 / 6) over `col % m` keys and one value column: the lean
+    // run-time specialised kernel, once it has been compiled — its workgroup tables are folded into the group table here
+    // interpreted chain predicates (PRED 3: `id % 10 < 5`, `id * 3 >= K`) take the specialised kernel too: 0.70 -> 0.555 ms per 2x10^8 rows
+    const bool jit_chains = !sw.no_agg_jit_chains;
+    BufRef jit_partials;
+    uint32_t jit_span = 0;
+    int64_t jit_bias = 0;
+    // … and so do interpreted chain KEYS (`(id + 1) % 1000`, KEY 3) whatever the predicate: the kernel bakes the whole key program
+    // NQE_AGG_JIT_ALL: 1 (default) = also `col % m` by magic multiply (KEY 2: the literal modulus baked in — `id % 1000` 0.584 -> 0.548 ms, `id % 2000`
+    // 0.643 -> 0.560 per 2x10^8 rows), 2 = every `% m` key (A/B: the headline's power-of-two key 2.53 vs 2.47 ms — within noise, it stays static), 0 = neither
+    const int jit_all = sw.agg_jit_all;
+    const bool jit_try = jit_whole || (has_pred && (fp >= 5 || (fp == 3 && jit_chains))) || (fast_key == 3 && jit_chains) || (jit_all >= 1 && fast_key == 2) || jit_all >= 2;
+    if (jit_try && (fast_key == 1 || fast_key == 2 || fast_key == 3) && ka.direct == 1 && ka.direct_rep == 0 && a.nv == 1 && !vnull && subsets_log2 == 0 &&
+        key_col >= 0 && a.val[0].values &&
+        aggregate_tree_specialised(ctx, in, has_pred ? pred : nullptr, pred_nodes, group, group_nodes, plan.val_cols[size_t(v0)], fgrid,
+                                   &jit_partials, &jit_span, &jit_bias)) {
+        const size_t cells = size_t(fgrid) * jit_span;
+        const double *ps = (const double *)jit_partials->ptr;
+        jit_launched = true;
+        launch(ctx, "agg_merge_partials", agg_merge_partials_kernel, dim3((jit_span + 3) / 4), dim3(256), 0, ps, ps + cells, ps + 2 * cells,
+               reinterpret_cast<const uint32_t *>(ps + 3 * cells), fgrid, jit_span, jit_bias, tb.g, a.v0, ctx->d_flags);
+    } else if (jit_whole) {
+        jit_redo = true; // (cannot happen once the dry run said yes — but a static kernel must never run without the predicate)
+        return PassStatus::Abort;
+    } else {
+    FastKernel fk = pick_fast_kernel(fp, fast_key, a.nv, vf64, vnull, subsets_log2 != 0, nomm, share);
+    if (!fk) fail(NQE_ERR_NOT_SUPPORTED, "internal: no such variant of the streaming aggregate kernel");
+    launch(ctx, "agg_grouped_fast", fk, dim3(fgrid), dim3(AGG_BLOCK), fshmem, ka, fpred, tb.g, ctx->d_flags);
+    }
+    return PassStatus::Done;
+}
+
+void AggRun::pass_ungrouped(int v0) {
+    const int grid = int(std::min<int64_t>(int64_t(ctx->num_cus), // one 1024-thread workgroup per CU (A/B: 0.82 -> 0.57 ms per 2e8 rows)
+                                     (in->rows + int64_t(AGG_BLOCK) * AGG_U - 1) / (int64_t(AGG_BLOCK) * AGG_U)));
+    BufRef partials = dev_alloc(ctx, size_t(grid) * NV * sizeof(Partial));
+    // fast path: plain 8-byte value columns, predicate none or an integer `col cmp lit`
+    FastPred ufp{};
+    bool uplain = a.nv >= 1;
+    bool uvnull = a.pred_mode != 0 && a.pred_src.valid != nullptr;
+    for (int j = 0; j < a.nv; ++j) {
+        uplain = uplain && a.val[j].values;
+        uvnull = uvnull || a.val[j].valid != nullptr;
+    }
+    if (uvnull && (!valid_words_ok || !kp_valid_words_ok)) uplain = false; // bitmaps must be readable as whole words
+    if (a.pred_src.dtype == NQE_BOOLEAN && a.pred_mode == 1 && a.pred.nops == 0 && !pred_bits_words_ok) uplain = false;
+    const bool ubitmap = a.pred_src.dtype == NQE_BOOLEAN && (a.pred_mode == 2 || (a.pred_mode == 1 && a.pred.nops == 0));
+    if (ubitmap) ufp = bitmap_fast_pred();
+    bool upred_ok = a.pred_mode == 0 || ubitmap ||
+                    (a.pred_mode == 1 && is_word_type(a.pred_src.dtype) && make_fast_pred(a.pred, &ufp));
+    if (uplain && upred_ok) {
+        int up = a.pred_mode == 0 ? 0 : ((a.pred_src.values == a.val[0].values && !ubitmap && !ufp.fmask) ? 1 : 2);
+        bool vf64 = true;
+        for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
+        launch(ctx, "agg_ungrouped_fast", pick_ungrouped_fast(up, a.nv, vf64, uvnull), dim3(grid), dim3(AGG_BLOCK), 0, a, ufp,
+               (Partial *)partials->ptr);
+    } else {
+        flagless = false;
+        launch(ctx, "agg_ungrouped", agg_ungrouped_kernel, dim3(grid), dim3(AGG_BLOCK), 0, a, (Partial *)partials->ptr,
+               ctx->d_flags);
+    }
+    launch(ctx, "agg_ungrouped_fold", agg_ungrouped_fold_kernel, dim3(1), dim3(64), 0,
+           (const Partial *)partials->ptr, grid, a.nv, v0, tb.g);
+}
+
+PassStatus AggRun::launch_pass(int v0) {
+    jit_launched = false;
+    pass_nv = three ? NVMAX : (first_alone && v0 == 0) ? 1 : nv_step;
+    a.nv = std::min(pass_nv, V - v0);
+    if (a.nv < 0) a.nv = 0;
+    a.v0 = v0;
+    valid_words_ok = true; // validity bitmaps readable as whole 64-bit words (owned buffers are padded)
+    for (int j = 0; j < NVMAX; ++j) {
+        std::memset(&a.val[j], 0, sizeof(ColSrc));
+        a.val_shares_key[j] = a.need_sum[j] = a.need_minmax[j] = 0;
+        if (j < a.nv) {
+            int c = plan.val_cols[size_t(v0 + j)];
+            const DevColumn &dc = in->cols[size_t(c)];
+            if (dc.validity && !dc.validity->owned && (dc.length % 64) != 0) valid_words_ok = false;
+            a.val[j] = src_of(dc);
+            if (!is_word_type(dc.dtype)) a.val[j].values = nullptr; // count-only over Boolean/Utf8: validity only
+            a.need_sum[j] = plan.need_sum[size_t(v0 + j)];
+            a.need_minmax[j] = plan.need_minmax[size_t(v0 + j)];
+            a.val_shares_key[j] = (grouped && c == key_col && is_word_type(dc.dtype)) ? 1 : 0;
+        }
+    }
+    if (in->rows == 0) return PassStatus::Done;
+    if (!grouped) {
+        pass_ungrouped(v0);
+    } else {
+        if (shape_pass() == PassStatus::Abort) return PassStatus::Abort;
+        if (fast) {
+            // variant 1 tests the key word with the integer range test alone; Float64 predicates and bitmaps use the
+            // "other column" variant, whose extraction step applies the order mapping
+            fp = pk == 0 ? 0 : pk >= 4 ? pk : (chain_pred ? 3 : ((a.pred_shares_key && !bitmap_pred && !fpred.fmask) ? 1 : 2));
+            vf64 = true;
+            for (int j = 0; j < a.nv; ++j) vf64 = vf64 && a.val[j].dtype == NQE_FLOAT64;
+            if (partition_mode && !level2 && !slab_failed) {
+                if (tier_slab() == PassStatus::Abort) return PassStatus::Abort;
+            } else if (partition_mode) {
+                tier_exact();
+            } else if (tier_streaming(v0) == PassStatus::Abort)
+                return PassStatus::Abort;
+        } else {
+            // the general kernel's PLAIN variant reads predicate and values as bare 8-byte words: not for a Boolean
+            // predicate column (bits) nor nullable values (found by the differential fuzzer: a bitmap predicate with
+            // a key shape the fast kernel does not cover was read as words)
+            if (dense) { // a pass the partition kernels do not cover under a densely written table: the hashed table, the attempt again
+                dense_ok = false;
+                dense_redo = true;
+                return PassStatus::Abort;
+            }
+            launch(ctx, "agg_grouped", pick_grouped_kernel(pk, kk, plain && !vnull && !bitmap_pred), dim3(std::min(grid, ctx->num_cus)), dim3(AGG_BLOCK), shmem, ka, tb.g,
+                   ctx->d_flags);
+        }
+    }
+    if (jit_whole && !jit_launched) { // a pass went through a static kernel, i.e. WITHOUT the predicate: this attempt's table is discarded
+        jit_redo = true;
+        return PassStatus::Abort;
+    }
+    return PassStatus::Done;
+}
+
+// what the flags of a finished attempt ask for.  true: the attempt is redone (the members say where)
+bool AggRun::react_to_flags(const int *f, const Collected &pre) {
+    (void)pre;
+    if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
+    if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
+    if ((f[NQE_FLAG_OOB] || f[NQE_FLAG_SLAB_OVERFLOW]) && partition_mode && range_part_used) {
+        // a key outside the range the partitions were cut from (the sample missed it, the column changed), or key intervals of very
+        // unequal weight: hashed partitions, now and for this query shape's later executions
+        // (a range that came from the SAMPLE and missed a key: the hashed attempt's dense tail measures the exact one for the next
+        // execution; a remembered range that no longer holds, or lopsided intervals: never again for this query shape)
+        const bool remeasure = part_range_sampled && f[NQE_FLAG_OOB] && !f[NQE_FLAG_SLAB_OVERFLOW];
+        range_part_used = false;
+        part_span = 0;
+        part_range_sampled = false;
+        if (!remeasure) range_part_ok = false;
+        if (hint_key && !remeasure) {
+            if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
+            ctx->agg_key_ranges[hint_key ^ PART_RANGE_SALT] = std::make_pair(int64_t(0), uint64_t(0));
+        }
+        flags_reset(ctx);
+        return true;
+    }
+    if (f[NQE_FLAG_KEY32_OVERFLOW] && partition_mode && !key32_failed) {
+        key32_failed = true; // a group key outside int32: the 16-byte tuple form
+        if (hint_key) ctx->agg_hints[hint_key] = uint8_t(0x40 | (slab_parts_log2 < PARTS_LOG2 ? 16 : 1));
+        flags_reset(ctx);
+        return true;
+    }
+    if (f[NQE_FLAG_SLAB_OVERFLOW] && partition_mode && !slab_failed) {
+        slab_failed = true; // a partition outgrew its slab (skewed keys): exact partition sizes instead
+        if (hint_key) ctx->agg_hints[hint_key] = uint8_t(17 | (key32_failed ? 0x40 : 0)); // … and the next execution of this query shape starts there
+        flags_reset(ctx);
+        return true;
+    }
+    if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2 && !slab_failed && slab_parts_log2 < PARTS_LOG2) {
+        slab_parts_log2 = PARTS_LOG2; // a partition outgrew a workgroup table: the full partition count, still in slab form
+        if (hint_key) ctx->agg_hints[hint_key] = uint8_t(1 | (key32_failed ? 0x40 : 0));
+        flags_reset(ctx);
+        return true;
+    }
+    if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2) {
+        level2 = true; // partitions hold more distinct keys than a workgroup table: one more partitioning level
+        cap = std::max<uint32_t>(cap, 1u << 24);
+        flags_reset(ctx);
+        return true;
+    }
+    if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode && range_on) {
+        // a key outside the remembered range (the column's contents changed, or the range came from a sample that missed the
+        // column's extremes), or a pass whose table is smaller than the range
+        range_on = false;
+        if (hint_key) ctx->agg_key_ranges.erase(hint_key);
+        flags_reset(ctx);
+        if (range_sampled && hint_key) {
+            range_sampled = false;
+            const auto exact = measure_key_range(); // the exact range: addressed by key - min after all, or remembered as too wide
+            ctx->agg_key_ranges[hint_key] = exact;
+            if (exact.second != 0 && exact.second <= range_limit) {
+                range_on = true;
+                range_min = exact.first;
+                range_span = exact.second;
+            }
+        }
+        return true;
+    }
+    if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode && three) {
+        // more groups than the three-column instance's table holds: passes of one and two columns (2048 / 4096 slots) may still do
+        three_on = false;
+        if (hint_key) {
+            if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
+            ctx->agg_hints[hint_key] = 0x80;
+        }
+        flags_reset(ctx);
+        return true;
+    }
+    if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode) {
+        // a workgroup table overflowed: two key subsets, and beyond those hash-partitioned rows
+        if (subsets_ok && subsets_log2 < sw.subsets_max) {
+            ++subsets_log2;
+            cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
+        } else {
+            subsets_log2 = 0;
+            partition_mode = true;
+            cap = std::max(cap, sized_cap);
+        }
+        if (hint_key) {
+            if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
+            ctx->agg_hints[hint_key] = uint8_t((partition_mode ? (slab_parts_log2 < PARTS_LOG2 ? 16 : 1) : 1 + subsets_log2) | (key32_failed ? 0x40 : 0));
+        }
+        flags_reset(ctx);
+        return true;
+    }
+    if (f[NQE_FLAG_DENSE_OVERFLOW]) { // a sub-partition with more distinct keys than an LDS table: hashed global table instead
+        dense_ok = false;
+        flags_reset(ctx);
+        return true;
+    }
+    if (f[NQE_FLAG_TABLE_FULL] && !partition_mode && asked_partition) {
+        // More groups than the global table of the streaming tiers holds, while no workgroup's LDS table overflowed: a table of
+        // 2^18 .. a few million rows with many groups (every workgroup sees fewer distinct keys than its table holds).  Growing
+        // the global table would leave each workgroup folding its LDS table into it through device-scope atomics — as many of
+        // them as rows (500 000 rows, 90 000 groups: 1.33 ms in the streaming kernel); the partitioned path has none.
+        subsets_log2 = 0;
+        partition_mode = true;
+        cap = std::max(cap, sized_cap);
+        if (hint_key) {
+            if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
+            ctx->agg_hints[hint_key] = uint8_t((slab_parts_log2 < PARTS_LOG2 ? 16 : 1) | (key32_failed ? 0x40 : 0));
+        }
+        flags_reset(ctx);
+        return true;
+    }
+    if (f[NQE_FLAG_TABLE_FULL]) {
+        // grow in 64 bits: 2^30 << 3 wraps a uint32_t to 0 (a zero-capacity table, then a spurious overflow error)
+        const uint64_t next = cap < sized_cap ? uint64_t(sized_cap) : uint64_t(cap) << 3;
+        if (cap >= (1u << 31) || attempt > 8) fail(NQE_ERR_OUT_OF_MEMORY, "group table overflow");
+        cap = uint32_t(std::min<uint64_t>(next, uint64_t(1) << 31));
+        flags_reset(ctx);
+        return true;
+    }
+    return false;
+}
+
+// the tail ahead of the flag read-back, the reactions, the result.  false: redo the attempt
+bool AggRun::finish_attempt(AggResult *out) {
+    Collected pre;
+    AggResult ranked;
+    if (grouped && !tb.g.dense_count && tb.g.cap <= RANK_MAX_CAP) {
+        // first-attempt table: the whole tail (collect, sort, finalize) runs ahead of the read-back
+        ranked = emit_ranked(ctx, tb, kinfo.out_dtype, aggs, naggs, plan.vslot, partial);
+    } else if (grouped && !tb.g.dense_count && tb.g.cap <= (1u << 16)) {
+        // small table: collect speculatively; the count lands in the spare flag slot and is read with the flags
+        const size_t slots = size_t(tb.g.cap) + 1;
+        pre.keys = dev_alloc(ctx, slots * 8);
+        pre.slots = dev_alloc(ctx, slots * 4);
+        launch(ctx, "agg_collect", collect_kernel, dim3(stream_grid(ctx, int64_t(slots), 256)), dim3(256), 0, tb.g, (uint64_t *)pre.keys->ptr,
+               (uint32_t *)pre.slots->ptr, reinterpret_cast<uint32_t *>(ctx->d_flags + NQE_FLAG_GROUP_COUNT));
+    }
+    const bool dense_tail = grouped && tb.g.dense_count != nullptr;
+    if (dense_tail) { // group count and key range of the densely written table ride along with the flags (emit: the ranked tail)
+        launch(ctx, "agg_dense_key_range", dense_key_range_kernel, dim3(unsigned(std::min<int64_t>(128, (int64_t(tb.g.cap) + 4095) / 4096))), dim3(256), 0, (const uint64_t *)tb.g.keys, tb.g.cap,
+               kinfo.out_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull, tb.g.dense_count);
+        NQE_HIP_CHECK(hipMemcpyAsync(ctx->h_flags + NQE_NUM_FLAGS, tb.g.dense_count, 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    int f[NQE_NUM_FLAGS];
+    if (flagless) std::memset(f, 0, sizeof(f)); // nothing on this path raises a flag and the result has exactly one row: no read-back
+    else if (ranked.out) flags_read_mirrored(ctx, f);
+    else flags_read(ctx, f);
+    if (pre.keys) pre.G = int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT]));
+    if (dense_tail && !flagless) {
+        const volatile int *x = ctx->h_flags + NQE_NUM_FLAGS;
+        const uint64_t inv_min = uint64_t(uint32_t(x[2])) | (uint64_t(uint32_t(x[3])) << 32), mx = uint64_t(uint32_t(x[4])) | (uint64_t(uint32_t(x[5])) << 32);
+        pre.dense_G = int64_t(std::min<uint32_t>(uint32_t(x[0]), tb.g.cap));
+        pre.ordmin = ~inv_min;
+        pre.ordmax = mx;
+    }
+    if (sw.debug)
+        fprintf(stderr, "[nqe] aggregate attempt %d: partition %d subsets_log2 %d cap %u flags need_partition %d slab_overflow %d level2 %d table_full %d dense_overflow %d\n",
+                attempt, int(partition_mode), subsets_log2, cap, f[NQE_FLAG_NEED_PARTITION], f[NQE_FLAG_SLAB_OVERFLOW], f[NQE_FLAG_NEED_LEVEL2],
+                f[NQE_FLAG_TABLE_FULL], f[NQE_FLAG_DENSE_OVERFLOW]);
+    if (react_to_flags(f, pre)) return false;
+    if (pre.dense_G > 0 && hint_key && range_part_ok && pre.ordmax >= pre.ordmin && pre.ordmax - pre.ordmin < (uint64_t(PARTS) << 12)) {
+        // the exact key range of this query's groups: the next execution cuts its partitions from it
+        const uint64_t flip = kinfo.out_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
+        if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
+        ctx->agg_key_ranges[hint_key ^ PART_RANGE_SALT] = std::make_pair(int64_t(pre.ordmin ^ flip), pre.ordmax - pre.ordmin + 1);
+        if (sw.debug)
+            fprintf(stderr, "[nqe] aggregate: remembered key range %lld + %llu (hint %llx)\n", (long long)int64_t(pre.ordmin ^ flip), (unsigned long long)(pre.ordmax - pre.ordmin + 1),
+                    (unsigned long long)hint_key);
+    }
+    AggResult res;
+    if (ranked.out) {
+        set_group_count(ranked, int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT])));
+        res = std::move(ranked);
+    } else
+        res = emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial, &pre);
+    if (utf8_key && res.keys) { // keys_out: the strings of the representative rows
+        DevColumn codes = res.keys->cols[0];
+        res.keys->cols[0] = take_utf8(ctx, utf8_src, (const int64_t *)codes.words(), codes.length, false);
+        sync(ctx);
+    }
+    *out = std::move(res);
+    return true;
+}
+
+AggResult AggRun::run() {
+    for (attempt = 0;; ++attempt) {
+        begin_attempt();
+        for (int v0 = 0; v0 < std::max(V, 1); v0 += pass_nv)
+            if (launch_pass(v0) == PassStatus::Abort) break;
         if (jit_redo) { // the specialised kernel was not to be had after all: the predicate as a Boolean column, the attempt again
             jit_redo = jit_whole = false;
             materialize_pred();
@@ -2122,179 +2418,20 @@ AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
         }
         if (dense_redo) flags_reset(ctx);
         if (slab_oom || three_redo || dense_redo) continue;
-        Collected pre;
-        AggResult ranked;
-        if (grouped && !tb.g.dense_count && tb.g.cap <= RANK_MAX_CAP) {
-            // first-attempt table: the whole tail (collect, sort, finalize) runs ahead of the read-back
-            ranked = emit_ranked(ctx, tb, kinfo.out_dtype, aggs, naggs, plan.vslot, partial);
-        } else if (grouped && !tb.g.dense_count && tb.g.cap <= (1u << 16)) {
-            // small table: collect speculatively; the count lands in the spare flag slot and is read with the flags
-            const size_t slots = size_t(tb.g.cap) + 1;
-            pre.keys = dev_alloc(ctx, slots * 8);
-            pre.slots = dev_alloc(ctx, slots * 4);
-            launch(ctx, "agg_collect", collect_kernel, dim3(stream_grid(ctx, int64_t(slots), 256)), dim3(256), 0, tb.g, (uint64_t *)pre.keys->ptr,
-                   (uint32_t *)pre.slots->ptr, reinterpret_cast<uint32_t *>(ctx->d_flags + NQE_FLAG_GROUP_COUNT));
-        }
-        const bool dense_tail = grouped && tb.g.dense_count != nullptr;
-        if (dense_tail) { // group count and key range of the densely written table ride along with the flags (emit: the ranked tail)
-            launch(ctx, "agg_dense_key_range", dense_key_range_kernel, dim3(unsigned(std::min<int64_t>(128, (int64_t(tb.g.cap) + 4095) / 4096))), dim3(256), 0, (const uint64_t *)tb.g.keys, tb.g.cap,
-                   kinfo.out_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull, tb.g.dense_count);
-            NQE_HIP_CHECK(hipMemcpyAsync(ctx->h_flags + NQE_NUM_FLAGS, tb.g.dense_count, 24, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        int f[NQE_NUM_FLAGS];
-        if (flagless) std::memset(f, 0, sizeof(f)); // nothing on this path raises a flag and the result has exactly one row: no read-back
-        else if (ranked.out) flags_read_mirrored(ctx, f);
-        else flags_read(ctx, f);
-        if (pre.keys) pre.G = int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT]));
-        if (dense_tail && !flagless) {
-            const volatile int *x = ctx->h_flags + NQE_NUM_FLAGS;
-            const uint64_t inv_min = uint64_t(uint32_t(x[2])) | (uint64_t(uint32_t(x[3])) << 32), mx = uint64_t(uint32_t(x[4])) | (uint64_t(uint32_t(x[5])) << 32);
-            pre.dense_G = int64_t(std::min<uint32_t>(uint32_t(x[0]), tb.g.cap));
-            pre.ordmin = ~inv_min;
-            pre.ordmax = mx;
-        }
-        if (getenv("NQE_DEBUG"))
-            fprintf(stderr, "[nqe] aggregate attempt %d: partition %d subsets_log2 %d cap %u flags need_partition %d slab_overflow %d level2 %d table_full %d dense_overflow %d\n",
-                    attempt, int(partition_mode), subsets_log2, cap, f[NQE_FLAG_NEED_PARTITION], f[NQE_FLAG_SLAB_OVERFLOW], f[NQE_FLAG_NEED_LEVEL2],
-                    f[NQE_FLAG_TABLE_FULL], f[NQE_FLAG_DENSE_OVERFLOW]);
-        if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
-        if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
-        if ((f[NQE_FLAG_OOB] || f[NQE_FLAG_SLAB_OVERFLOW]) && partition_mode && range_part_used) {
-            // a key outside the range the partitions were cut from (the sample missed it, the column changed), or key intervals of very
-            // unequal weight: hashed partitions, now and for this query shape's later executions
-            // (a range that came from the SAMPLE and missed a key: the hashed attempt's dense tail measures the exact one for the next
-            // execution; a remembered range that no longer holds, or lopsided intervals: never again for this query shape)
-            const bool remeasure = part_range_sampled && f[NQE_FLAG_OOB] && !f[NQE_FLAG_SLAB_OVERFLOW];
-            range_part_used = false;
-            part_span = 0;
-            part_range_sampled = false;
-            if (!remeasure) range_part_ok = false;
-            if (hint_key && !remeasure) {
-                if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
-                ctx->agg_key_ranges[hint_key ^ PART_RANGE_SALT] = std::make_pair(int64_t(0), uint64_t(0));
-            }
-            flags_reset(ctx);
-            continue;
-        }
-        if (f[NQE_FLAG_KEY32_OVERFLOW] && partition_mode && !key32_failed) {
-            key32_failed = true; // a group key outside int32: the 16-byte tuple form
-            if (hint_key) ctx->agg_hints[hint_key] = uint8_t(0x40 | (slab_parts_log2 < PARTS_LOG2 ? 16 : 1));
-            flags_reset(ctx);
-            continue;
-        }
-        if (f[NQE_FLAG_SLAB_OVERFLOW] && partition_mode && !slab_failed) {
-            slab_failed = true; // a partition outgrew its slab (skewed keys): exact partition sizes instead
-            if (hint_key) ctx->agg_hints[hint_key] = uint8_t(17 | (key32_failed ? 0x40 : 0)); // … and the next execution of this query shape starts there
-            flags_reset(ctx);
-            continue;
-        }
-        if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2 && !slab_failed && slab_parts_log2 < PARTS_LOG2) {
-            slab_parts_log2 = PARTS_LOG2; // a partition outgrew a workgroup table: the full partition count, still in slab form
-            if (hint_key) ctx->agg_hints[hint_key] = uint8_t(1 | (key32_failed ? 0x40 : 0));
-            flags_reset(ctx);
-            continue;
-        }
-        if (f[NQE_FLAG_NEED_LEVEL2] && partition_mode && !level2) {
-            level2 = true; // partitions hold more distinct keys than a workgroup table: one more partitioning level
-            cap = std::max<uint32_t>(cap, 1u << 24);
-            flags_reset(ctx);
-            continue;
-        }
-        if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode && range_on) {
-            // a key outside the remembered range (the column's contents changed, or the range came from a sample that missed the
-            // column's extremes), or a pass whose table is smaller than the range
-            range_on = false;
-            if (hint_key) ctx->agg_key_ranges.erase(hint_key);
-            flags_reset(ctx);
-            if (range_sampled && hint_key) {
-                range_sampled = false;
-                const auto exact = measure_key_range(); // the exact range: addressed by key - min after all, or remembered as too wide
-                ctx->agg_key_ranges[hint_key] = exact;
-                if (exact.second != 0 && exact.second <= range_limit) {
-                    range_on = true;
-                    range_min = exact.first;
-                    range_span = exact.second;
-                }
-            }
-            continue;
-        }
-        if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode && three) {
-            // more groups than the three-column instance's table holds: passes of one and two columns (2048 / 4096 slots) may still do
-            three_on = false;
-            if (hint_key) {
-                if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
-                ctx->agg_hints[hint_key] = 0x80;
-            }
-            flags_reset(ctx);
-            continue;
-        }
-        if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode) {
-            // a workgroup table overflowed: two key subsets, and beyond those hash-partitioned rows
-            if (subsets_ok && subsets_log2 < subsets_max) {
-                ++subsets_log2;
-                cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
-            } else {
-                subsets_log2 = 0;
-                partition_mode = true;
-                cap = std::max(cap, sized_cap);
-            }
-            if (hint_key) {
-                if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
-                ctx->agg_hints[hint_key] = uint8_t((partition_mode ? (slab_parts_log2 < PARTS_LOG2 ? 16 : 1) : 1 + subsets_log2) | (key32_failed ? 0x40 : 0));
-            }
-            flags_reset(ctx);
-            continue;
-        }
-        if (f[NQE_FLAG_DENSE_OVERFLOW]) { // a sub-partition with more distinct keys than an LDS table: hashed global table instead
-            dense_ok = false;
-            flags_reset(ctx);
-            continue;
-        }
-        if (f[NQE_FLAG_TABLE_FULL] && !partition_mode && asked_partition) {
-            // More groups than the global table of the streaming tiers holds, while no workgroup's LDS table overflowed: a table of
-            // 2^18 .. a few million rows with many groups (every workgroup sees fewer distinct keys than its table holds).  Growing
-            // the global table would leave each workgroup folding its LDS table into it through device-scope atomics — as many of
-            // them as rows (500 000 rows, 90 000 groups: 1.33 ms in the streaming kernel); the partitioned path has none.
-            subsets_log2 = 0;
-            partition_mode = true;
-            cap = std::max(cap, sized_cap);
-            if (hint_key) {
-                if (ctx->agg_hints.size() >= 256) ctx->agg_hints.clear();
-                ctx->agg_hints[hint_key] = uint8_t((slab_parts_log2 < PARTS_LOG2 ? 16 : 1) | (key32_failed ? 0x40 : 0));
-            }
-            flags_reset(ctx);
-            continue;
-        }
-        if (f[NQE_FLAG_TABLE_FULL]) {
-            // grow in 64 bits: 2^30 << 3 wraps a uint32_t to 0 (a zero-capacity table, then a spurious overflow error)
-            const uint64_t next = cap < sized_cap ? uint64_t(sized_cap) : uint64_t(cap) << 3;
-            if (cap >= (1u << 31) || attempt > 8) fail(NQE_ERR_OUT_OF_MEMORY, "group table overflow");
-            cap = uint32_t(std::min<uint64_t>(next, uint64_t(1) << 31));
-            flags_reset(ctx);
-            continue;
-        }
-        if (pre.dense_G > 0 && hint_key && range_part_ok && pre.ordmax >= pre.ordmin && pre.ordmax - pre.ordmin < (uint64_t(PARTS) << 12)) {
-            // the exact key range of this query's groups: the next execution cuts its partitions from it
-            const uint64_t flip = kinfo.out_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
-            if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
-            ctx->agg_key_ranges[hint_key ^ PART_RANGE_SALT] = std::make_pair(int64_t(pre.ordmin ^ flip), pre.ordmax - pre.ordmin + 1);
-            if (getenv("NQE_DEBUG"))
-                fprintf(stderr, "[nqe] aggregate: remembered key range %lld + %llu (hint %llx)\n", (long long)int64_t(pre.ordmin ^ flip), (unsigned long long)(pre.ordmax - pre.ordmin + 1),
-                        (unsigned long long)hint_key);
-        }
         AggResult res;
-        if (ranked.out) {
-            set_group_count(ranked, int64_t(uint32_t(f[NQE_FLAG_GROUP_COUNT])));
-            res = std::move(ranked);
-        } else
-            res = emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial, &pre);
-        if (utf8_key && res.keys) { // keys_out: the strings of the representative rows
-            DevColumn codes = res.keys->cols[0];
-            res.keys->cols[0] = take_utf8(ctx, utf8_src, (const int64_t *)codes.words(), codes.length, false);
-            sync(ctx);
-        }
-        return res;
+        if (finish_attempt(&res)) return res;
     }
+}
+
+AggResult run_aggregate(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *pred, int pred_nodes, const nqe_expr_node *group, int group_nodes,
+                        const nqe_aggregate *aggs, int naggs, bool partial) {
+    AggRun r(ctx, in, pred, pred_nodes, group, group_nodes, aggs, naggs, partial);
+    if (r.prepare()) return std::move(r.early);
+    r.size_tables();
+    r.load_hints();
+    r.sample_keys();
+    r.pick_key_range();
+    return r.run();
 }
 
 } // namespace

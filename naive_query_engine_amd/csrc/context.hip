@@ -7,7 +7,24 @@
 #include "device_utils.hpp"
 #include "nqe_internal.hpp"
 
+void AggSwitches::read_environment() {
+    auto num = [](const char *name, int dflt) {
+        const char *e = getenv(name);
+        return e ? atoi(e) : dflt;
+    };
+    no_three_column_pass = getenv("NQE_NO_THREE_COLUMN_PASS") != nullptr;
+    no_key_range = getenv("NQE_NO_KEY_RANGE") != nullptr;
+    subsets_max = num("NQE_AGG_SUBSETS_MAX", 1);
+    slab_parts_first = num("NQE_SLAB_PARTS_LOG2", 8);
+    const int m = num("NQE_FLAG_CHECK_MASK", 7);
+    flag_check_mask = (m == 0 || m == 1 || m == 3 || m == 7 || m == 15) ? m : 7;
+    no_agg_jit_chains = getenv("NQE_NO_AGG_JIT_CHAINS") != nullptr;
+    agg_jit_all = num("NQE_AGG_JIT_ALL", 1);
+    debug = getenv("NQE_DEBUG") != nullptr;
+}
+
 namespace nqe {
+
 
 static std::mutex g_err_mu;
 static std::string g_global_error;
@@ -606,6 +623,7 @@ nqe_status nqe_ctx_create(int32_t device, void *stream, nqe_ctx **out) {
     NQE_HIP_CHECK(hipHostMalloc(&ctx->h_flags, sizeof(int) * (NQE_NUM_FLAGS + NQE_FLAG_MIRROR_EXTRA), hipHostMallocMapped | hipHostMallocCoherent));
     NQE_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_flags_dev), ctx->h_flags, 0));
     NQE_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NQE_NUM_FLAGS, ctx->stream));
+    ctx->agg_sw.read_environment();
     load_modules();
     *out = ctx.release();
     if (const char *mb = getenv("NQE_RESERVE_MB")) {

@@ -48,6 +48,22 @@ enum { NQE_FLAG_DIV_ZERO = 0, NQE_FLAG_OVERFLOW = 1, NQE_FLAG_TABLE_FULL = 2, NQ
 // group count and key range)
 constexpr int NQE_FLAG_MIRROR_EXTRA = 8;
 
+// A/B switches of the aggregate operator (aggregate.hip), read from the environment ONCE when a context is created (nqe_ctx::agg_sw).
+// Diagnostics only: every default is the measured-best setting; DESIGN.md §9 lists them with what each was used to measure.  (The
+// switches the tests flip between calls — NQE_NO_PLAN_HINTS, NQE_NO_KEY_SAMPLE, NQE_NO_RANGE_PARTITION, NQE_NO_RANGE_TAIL,
+// NQE_NO_AGG_JIT, NQE_TEST_SLAB_OOM — are read per call where they are used.)
+struct AggSwitches {
+    bool no_three_column_pass = false; // NQE_NO_THREE_COLUMN_PASS=1: three value columns in passes of one and two
+    bool no_key_range = false;         // NQE_NO_KEY_RANGE=1: a plain key column is never addressed by key - min
+    int subsets_max = 1;               // NQE_AGG_SUBSETS_MAX: log2 of the key subsets of the streaming tier (0: none)
+    int slab_parts_first = 8;          // NQE_SLAB_PARTS_LOG2: log2 of the first partition count of the slab form (6..9)
+    int flag_check_mask = 7;           // NQE_FLAG_CHECK_MASK: a wave of the one-tile streaming loop looks at the overflow flags every (mask + 1)th iteration
+    bool no_agg_jit_chains = false;    // NQE_NO_AGG_JIT_CHAINS=1: chain predicates / chain keys stay on the interpreting static kernel
+    int agg_jit_all = 1;               // NQE_AGG_JIT_ALL: 0 = neither, 1 = `col % m` by magic multiply through the specialised kernel, 2 = every `% m` key
+    bool debug = false;                // NQE_DEBUG=1: the tier decisions on stderr
+    void read_environment();
+};
+
 struct nqe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -78,6 +94,7 @@ struct nqe_ctx {
     // (key column buffer, rows, key expression): the next execution of the same query over the same table starts partitioned
     // instead of paying for an abandoned single-pass attempt and its read-back first.  Only a starting point — a partitioned run
     // is correct for any number of groups, and a single-pass run still falls back when its tables overflow.
+    AggSwitches agg_sw;
     std::map<uint64_t, uint8_t> agg_hints;
     // … and, by the same key: the value range {min, span} of a plain integer key column (`group by k`: dictionary codes, small ids),
     // measured by the first execution of the query shape.  A range that fits a workgroup table makes the streaming kernel address

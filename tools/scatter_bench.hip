@@ -66,6 +66,16 @@ __global__ void __launch_bounds__(THREADS) synth_scatter(const uint64_t *__restr
                 t.y = k;
                 if (NTS) __builtin_nontemporal_store(t, reinterpret_cast<v2u64 *>(out) + at);
                 else reinterpret_cast<v2u64 *>(out)[at] = t;
+            } else if (LAYOUT == 3) { // SoA: 8-byte values, 4-byte keys (what whole-block flushes of a carry buffer would write)
+                uint64_t *ov = reinterpret_cast<uint64_t *>(out);
+                uint32_t *ok = reinterpret_cast<uint32_t *>(out + size_t(gridDim.x) * size_t(S) * size_t(cap) * 8);
+                if (NTS) {
+                    __builtin_nontemporal_store(v, ov + at);
+                    __builtin_nontemporal_store(k, ok + at);
+                } else {
+                    ov[at] = v;
+                    ok[at] = k;
+                }
             } else {
                 uint64_t *ov = reinterpret_cast<uint64_t *>(out);
                 uint16_t *ok = reinterpret_cast<uint16_t *>(out + size_t(gridDim.x) * size_t(S) * size_t(cap) * 8);
@@ -103,7 +113,7 @@ void run(const char *name, const uint64_t *a, const uint64_t *b, unsigned char *
         CK(hipEventElapsedTime(&ms, e0, e1));
         if (r > 0 && ms < best) best = ms;
     }
-    const double wb = LAYOUT == 0 ? 12.0 : LAYOUT == 1 ? 16.0 : 10.0;
+    const double wb = LAYOUT == 0 ? 12.0 : LAYOUT == 1 ? 16.0 : LAYOUT == 3 ? 12.0 : 10.0;
     printf("%-22s thr %4d x %d/CU tile %5d S %3d run %4d tuples skew %2d: %.3f ms  %.0f GB/s\n", name, THREADS, wgs_per_cu, TILE, S, TILE / S, skew, best, (16.0 + wb) * n / best / 1e6);
 }
 
@@ -116,22 +126,15 @@ int main() {
     CK(hipMalloc(&out, size_t(n) * 16 * 2));
     CK(hipMemset(a, 1, n * 8));
     CK(hipMemset(b, 2, n * 8));
-    for (int S : {16, 64, 128, 256, 512}) {
+    for (int S : {64, 256, 512}) {
         for (int skew : {0, 5}) {
             run<1024, 8, 0, 0>("rec12 plain", a, b, out, n, 1, S, skew);
-            run<512, 8, 0, 0>("rec12 plain", a, b, out, n, 2, S, skew);
-            run<512, 8, 0, 0>("rec12 plain", a, b, out, n, 3, S, skew);
-            run<256, 16, 0, 0>("rec12 plain", a, b, out, n, 4, S, skew);
-            run<1024, 8, 1, 0>("rec16 plain", a, b, out, n, 1, S, skew);
+            run<1024, 8, 3, 0>("soa12 plain", a, b, out, n, 1, S, skew);
+            run<1024, 8, 3, 1>("soa12 nt", a, b, out, n, 1, S, skew);
+            run<1024, 4, 3, 0>("soa12 plain", a, b, out, n, 1, S, skew);
+            run<1024, 4, 3, 1>("soa12 nt", a, b, out, n, 1, S, skew);
+            run<512, 8, 3, 1>("soa12 nt", a, b, out, n, 2, S, skew);
             run<1024, 8, 1, 1>("rec16 nt", a, b, out, n, 1, S, skew);
-            run<512, 8, 1, 1>("rec16 nt", a, b, out, n, 2, S, skew);
-            run<1024, 8, 2, 0>("soa10 plain", a, b, out, n, 1, S, skew);
-            run<1024, 8, 2, 1>("soa10 nt", a, b, out, n, 1, S, skew);
-            run<512, 8, 2, 0>("soa10 plain", a, b, out, n, 2, S, skew);
-            run<512, 8, 2, 1>("soa10 nt", a, b, out, n, 2, S, skew);
-            run<512, 8, 2, 1>("soa10 nt", a, b, out, n, 3, S, skew);
-            run<256, 16, 2, 1>("soa10 nt", a, b, out, n, 4, S, skew);
-            run<1024, 12, 2, 1>("soa10 nt", a, b, out, n, 1, S, skew);
         }
     }
     return 0;
