@@ -761,6 +761,137 @@ __global__ void __launch_bounds__(DR_BLOCK) dense_rank_emit_kernel(GroupTable g,
     if (f.naggs > 0) finalize_rows<DR_ITEMS>(g, slot, live, row, f);
 }
 
+// ------------------------------------------------------------------ tail of the RANGE TIER (aggregate_common.hpp: RangeRec)
+// tab[(p * Q + q) * W + s]: the table of partition p as workgroup q of Q saw it.  A workgroup (taken by ticket, so that every block
+// below a waiting one has been started) owns the slots [s0, s0 + SB) of EVERY partition = the RE_BLOCK x ITEMS consecutive keys from
+// key_min + s0 * parts on: it adds the Q partials of each (partition, slot) — SB consecutive 32-byte records per partition: coalesced
+// — into LDS at the key's place (d = slot * parts + ((p ^ scramble(slot)) & (parts - 1)): the inverse of range_partition), then walks
+// the keys in order, ITEMS per thread: occupied ones are counted across workgroups by the decoupled look-back of
+// dense_rank_emit_kernel and written — key and aggregates — at their rank.  The last block leaves the group count in *total.
+constexpr int RE_BLOCK = 1024;
+template <int ITEMS>
+__global__ void __launch_bounds__(RE_BLOCK) agg_range_emit_kernel(const RangeRec *__restrict__ tab, int parts_log2, int Q, uint32_t W, uint64_t span, uint64_t key_min,
+                                                                  unsigned long long *status, uint64_t *out_keys, FinalizeArgs f, uint32_t *total) {
+    constexpr int KB = RE_BLOCK * ITEMS; // keys per block
+    extern __shared__ __attribute__((aligned(16))) unsigned char re_smem[];
+    double *lsum = reinterpret_cast<double *>(re_smem);
+    double *lmn = lsum + KB;
+    double *lmx = lmn + KB;
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + KB);
+    __shared__ uint32_t s_chunk;
+    __shared__ uint32_t wcnt[RE_BLOCK / 64];
+    __shared__ unsigned long long s_excl;
+    if (threadIdx.x == 0) s_chunk = uint32_t(atomicAdd(&status[0], 1ull));
+    __syncthreads();
+    const uint64_t c = s_chunk;
+    const uint32_t parts = 1u << parts_log2, SB = uint32_t(KB) >> parts_log2, s0 = uint32_t(c) * SB; // (KB >= parts: SB >= 1)
+    const uint32_t nblocks = (W + SB - 1) / SB;
+    int sb_log2 = 0;
+    while ((1u << sb_log2) < SB) ++sb_log2;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const uint32_t i = uint32_t(k) * RE_BLOCK + threadIdx.x, p = i >> sb_log2, sl = i & (SB - 1), sg = s0 + sl;
+        double sum = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
+        uint32_t cnt = 0;
+        if (sg < W) {
+            const RangeRec *__restrict__ r = tab + size_t(p) * size_t(Q) * size_t(W) + sg;
+            for (int q = 0; q < Q; ++q) {
+                const RangeRec x = r[size_t(q) * size_t(W)];
+                sum += x.sum;
+                mn = x.mn < mn ? x.mn : mn;
+                mx = x.mx > mx ? x.mx : mx;
+                cnt = ((cnt & ~NAN_BIT) + (x.cnt & ~NAN_BIT)) | ((cnt | x.cnt) & NAN_BIT);
+            }
+        }
+        const uint32_t low = (p ^ range_scramble(sg, parts_log2)) & (parts - 1u), dl = (sl << parts_log2) | low;
+        if (((uint64_t(sg) << parts_log2) | low) >= span) cnt = 0; // (beyond the range: no tuple can have named this slot)
+        lsum[dl] = sum;
+        lmn[dl] = mn;
+        lmx[dl] = mx;
+        lcnt[dl] = cnt;
+    }
+    __syncthreads();
+    const uint32_t j0 = threadIdx.x * ITEMS;
+    uint32_t cnts[ITEMS], mine = 0;
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+        cnts[u] = lcnt[j0 + u];
+        mine += cnts[u] ? 1u : 0u;
+    }
+    uint32_t wtot;
+    const uint32_t wexcl = wave_exclusive_scan(mine, wtot);
+    const int wv = int(threadIdx.x) / 64;
+    if (lane_id() == 0) wcnt[wv] = wtot;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < RE_BLOCK / 64; ++w) {
+        before += w < wv ? wcnt[w] : 0u;
+        tot += wcnt[w];
+    }
+    if (wv == 0) {
+        if (lane_id() == 0 && c > 0) __hip_atomic_store(&status[1 + c], ((unsigned long long)tot << 2) | 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long excl = 0;
+        for (int64_t look = int64_t(c) - 1; look >= 0; look -= 64) {
+            const int64_t idx = look - lane_id();
+            unsigned long long v = 2; // below block 0: an inclusive count of zero
+            if (idx >= 0) {
+                do v = __hip_atomic_load(&status[1 + idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                while ((v & 3ull) == 0);
+            }
+            const uint64_t incl = __ballot((v & 3ull) == 2ull);
+            const int stop = incl ? __ffsll((unsigned long long)incl) - 1 : 64; // the nearest block whose inclusive count is known
+            unsigned long long part = lane_id() <= stop ? (v >> 2) : 0ull;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+            excl += part;
+            if (incl) break;
+        }
+        if (lane_id() == 0) {
+            __hip_atomic_store(&status[1 + c], ((excl + tot) << 2) | 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+            if (c + 1 == nblocks) *total = uint32_t(excl + tot);
+        }
+    }
+    __syncthreads();
+    int64_t r = int64_t(s_excl) + before + wexcl;
+    const uint64_t key0 = key_min + (uint64_t(s0) << parts_log2) + j0;
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+        if (!cnts[u]) continue;
+        out_keys[r] = key0 + uint64_t(u);
+        const uint64_t cnt = cnts[u] & ~NAN_BIT;
+        const double sum = lsum[j0 + u], mn = lmn[j0 + u], mx = (cnts[u] & NAN_BIT) ? __longlong_as_double(0x7FF8000000000000ll) : lmx[j0 + u];
+        if (f.partial) { // (one value column: table slot 0)
+            f.out[0][r] = cnt;
+            f.out[1][r] = d2u(sum);
+            f.out[2][r] = d2u(mn);
+            f.out[3][r] = d2u(mx);
+        } else {
+            for (int i = 0; i < f.naggs; ++i) {
+                uint64_t w;
+                switch (f.func[i]) {
+                case NQE_AGG_COUNT: w = cnt; break;
+                case NQE_AGG_SUM: w = d2u(sum); break;
+                case NQE_AGG_AVG: w = d2u(sum / double(uint32_t(cnt))); break; // avg.rs:121 (cnt is u32)
+                case NQE_AGG_MIN: w = d2u(mn); break;
+                default: w = d2u(mx); break;
+                }
+                f.out[i][r] = w;
+            }
+        }
+        ++r;
+    }
+}
+
+// the group count and — the keys being written in order — the exact key range, in one place for the host (read back with the flags)
+__global__ void agg_range_summary_kernel(const uint32_t *total, const uint64_t *keys, uint64_t *out) {
+    const uint32_t G = *total;
+    out[0] = G;
+    out[1] = G ? keys[0] : 0;
+    out[2] = G ? keys[G - 1] : 0;
+}
+
 // Tail of a SMALL hashed table (the first-attempt 8192-slot table: the headline's 1024 groups): collect + sort + finalize in one
 // launch, enqueued ahead of the flag read-back.  Every workgroup compacts the occupied slots into LDS (keys in sort order + slot
 // numbers; the same deterministic order in every workgroup), owns 64 of the G entries, and ranks each by counting the keys below
@@ -1344,6 +1475,8 @@ struct AggRun {
     bool asked_partition = false, dense = false, flagless = false, slab_oom = false, three = false, three_redo = false, dense_redo = false, first_alone = false;
     int nv_step = 1, pass_nv = 0;
     TableBufs tb;
+    AggResult ranged;        // tier_range: outputs allocated for the whole key range, cut to the group count once it has travelled back with the flags
+    BufRef range_total, range_tab, range_status; // ... which agg_range_emit_kernel leaves in range_total; its inputs, kept until the attempt is over
     // ---- the pass (shape_pass)
     bool jit_launched = false, valid_words_ok = true, plain = false, bitmap_pred = false, vnull = false, range_pred = false, chain_pred = false, fast = false, vf64 = true;
     size_t shmem = 0;
@@ -1369,6 +1502,7 @@ struct AggRun {
     PassStatus launch_pass(int v0);
     PassStatus shape_pass();
     PassStatus tier_slab();
+    void range_tail(const AggArgs &sa, const SlabArgs &sl, uint32_t rslots);
     void tier_exact();
     PassStatus tier_streaming(int v0);
     void pass_ungrouped(int v0);
@@ -1705,6 +1839,8 @@ void AggRun::pick_key_range() {
 }
 
 void AggRun::begin_attempt() {
+    ranged = AggResult();
+    range_total = range_tab = range_status = BufRef();
     range_part_used = false;
     asked_partition = false; // a streaming pass of this attempt ran with allow_partition (see the TABLE_FULL handler below)
     // The partitioned path (entered after the fast kernel asked for it) with a single pass over the value columns writes
@@ -1924,6 +2060,14 @@ PassStatus AggRun::tier_slab() {
     const bool k32 = a.nv == 1 && (!key32_failed || range_part);
     int sparts_log2 = slab_parts_log2;
     if (range_part) sparts_log2 = part_span <= (uint64_t(256) << 12) ? 8 : PARTS_LOG2;
+    // the range tier (aggregate_common.hpp: RangeRec): as many partitions as the RANGE needs at 2^range_slots_log2 slots per table (16 .. 256;
+    // 512 beyond 2^20 values), several workgroups per partition in the second kernel, the transposing tail.  One value column (V == 1).
+    const bool range_tier = range_part && V == 1 && sw.range_tier;
+    if (range_tier && sparts_log2 == 8) {
+        int need = 4;
+        while (need < 8 && (uint64_t(1) << (need + sw.range_slots_log2)) < part_span) ++need;
+        sparts_log2 = need;
+    }
     const int used_parts = 1 << sparts_log2;
     const uint64_t rslots = range_part ? (part_span + (uint64_t(1) << sparts_log2) - 1) >> sparts_log2 : 0;
     range_part_used = range_part;
@@ -1975,6 +2119,11 @@ PassStatus AggRun::tier_slab() {
         sshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
         sblocks = 1;
     }
+    if (range_tier) {
+        range_tail(sa, sl, uint32_t(rslots));
+        // (the slabs go back to the pool when this scope ends: whatever takes them next runs behind these kernels on the same stream)
+        return PassStatus::Done;
+    }
     if (range_part) { // tables addressed by key - base: 28 bytes per key of the partition's interval
         const size_t dshmem = size_t(28) * size_t(rslots) + 16;
         const int dblocks = int(std::max<size_t>(1, std::min<size_t>(4, (size_t(144) << 10) / dshmem)));
@@ -1985,6 +2134,43 @@ PassStatus AggRun::tier_slab() {
                sa, sl, tb.g, ctx->d_flags);
     sync(ctx); // the slabs are released at the end of this scope
     return PassStatus::Done;
+}
+
+// the range tier behind its scatter: Q workgroups per partition aggregate the slabs into whole tables, the transposing tail ranks and
+// writes the groups.  Nothing here waits for the device: the group count travels back with the flags (finish_attempt).
+void AggRun::range_tail(const AggArgs &sa, const SlabArgs &sl, uint32_t rslots) {
+    const int parts = 1 << sl.parts_log2;
+    const size_t dshmem = size_t(28) * size_t(rslots) + 16;
+    const int per_cu = dshmem <= (size_t(72) << 10) ? 2 : 1; // 1024-thread workgroups: two per CU when their tables fit side by side
+    const int Q = std::max(1, std::min(ctx->num_cus * per_cu / parts, sl.W));
+    range_tab = dev_alloc(ctx, size_t(parts) * size_t(Q) * size_t(rslots) * sizeof(RangeRec) + 64);
+    const BufRef &tab = range_tab;
+    launch(ctx, "agg_segments_direct", pick_range_segments_kernel(vf64), dim3(unsigned(parts * Q)), dim3(AGG_BLOCK), dshmem, sa, sl, Q, (RangeRec *)tab->ptr);
+    // outputs for the whole range (an upper bound of the groups, and never more than the rows); cut to the group count in finish_attempt
+    const int64_t room = int64_t(std::min<uint64_t>(part_span, uint64_t(std::max<int64_t>(in->rows, 1))));
+    ranged = AggResult();
+    FinalizeArgs f = alloc_outputs(ctx, ranged, room, aggs, naggs, plan.vslot, partial);
+    ranged.keys = std::make_unique<nqe_table>();
+    ranged.keys->ctx = ctx;
+    ranged.keys->rows = room;
+    ranged.keys->cols.push_back(make_word_column(ctx, kinfo.out_dtype, room, false));
+    const int items = part_span >= (uint64_t(1) << 19) ? 4 : 1; // keys per thread of the tail: 4096-key blocks for wide ranges, 1024-key blocks to keep narrow ones parallel
+    const uint32_t kb = uint32_t(RE_BLOCK * items), sb = std::max<uint32_t>(1u, kb >> sl.parts_log2), nblocks = (rslots + sb - 1) / sb;
+    range_status = dev_alloc(ctx, (size_t(nblocks) + 2) * 8);
+    const BufRef &status = range_status;
+    NQE_HIP_CHECK(hipMemsetAsync(status->ptr, 0, (size_t(nblocks) + 2) * 8, ctx->stream));
+    range_total = dev_alloc_zero(ctx, 32); // [0] the group count (the tail's last block); [1..3] count, first key, last key (agg_range_summary_kernel)
+    auto *st = (unsigned long long *)status->ptr;
+    auto *keys_out = (uint64_t *)ranged.keys->cols[0].values->ptr;
+    const size_t eshmem = size_t(kb) * 28;
+    if (items == 4)
+        launch(ctx, "agg_range_emit", agg_range_emit_kernel<4>, dim3(nblocks), dim3(RE_BLOCK), eshmem, (const RangeRec *)tab->ptr, int(sl.parts_log2), Q, rslots, part_span, uint64_t(part_min), st, keys_out,
+               f, (uint32_t *)range_total->ptr);
+    else
+        launch(ctx, "agg_range_emit", agg_range_emit_kernel<1>, dim3(nblocks), dim3(RE_BLOCK), eshmem, (const RangeRec *)tab->ptr, int(sl.parts_log2), Q, rslots, part_span, uint64_t(part_min), st, keys_out,
+               f, (uint32_t *)range_total->ptr);
+    launch(ctx, "agg_range_summary", agg_range_summary_kernel, dim3(1), dim3(1), 0, (const uint32_t *)range_total->ptr, (const uint64_t *)keys_out, (uint64_t *)range_total->ptr + 1);
+    NQE_HIP_CHECK(hipMemcpyAsync(ctx->h_flags + NQE_NUM_FLAGS, (const uint64_t *)range_total->ptr + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
 }
 
 void AggRun::tier_exact() {
@@ -2347,7 +2533,9 @@ bool AggRun::react_to_flags(const int *f, const Collected &pre) {
 bool AggRun::finish_attempt(AggResult *out) {
     Collected pre;
     AggResult ranked;
-    if (grouped && !tb.g.dense_count && tb.g.cap <= RANK_MAX_CAP) {
+    if (ranged.out) {
+        // the range tier wrote keys and aggregates already; its group count rides along with the flags
+    } else if (grouped && !tb.g.dense_count && tb.g.cap <= RANK_MAX_CAP) {
         // first-attempt table: the whole tail (collect, sort, finalize) runs ahead of the read-back
         ranked = emit_ranked(ctx, tb, kinfo.out_dtype, aggs, naggs, plan.vslot, partial);
     } else if (grouped && !tb.g.dense_count && tb.g.cap <= (1u << 16)) {
@@ -2358,7 +2546,7 @@ bool AggRun::finish_attempt(AggResult *out) {
         launch(ctx, "agg_collect", collect_kernel, dim3(stream_grid(ctx, int64_t(slots), 256)), dim3(256), 0, tb.g, (uint64_t *)pre.keys->ptr,
                (uint32_t *)pre.slots->ptr, reinterpret_cast<uint32_t *>(ctx->d_flags + NQE_FLAG_GROUP_COUNT));
     }
-    const bool dense_tail = grouped && tb.g.dense_count != nullptr;
+    const bool dense_tail = grouped && tb.g.dense_count != nullptr && !ranged.out;
     if (dense_tail) { // group count and key range of the densely written table ride along with the flags (emit: the ranked tail)
         launch(ctx, "agg_dense_key_range", dense_key_range_kernel, dim3(unsigned(std::min<int64_t>(128, (int64_t(tb.g.cap) + 4095) / 4096))), dim3(256), 0, (const uint64_t *)tb.g.keys, tb.g.cap,
                kinfo.out_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull, tb.g.dense_count);
@@ -2381,6 +2569,22 @@ bool AggRun::finish_attempt(AggResult *out) {
                 attempt, int(partition_mode), subsets_log2, cap, f[NQE_FLAG_NEED_PARTITION], f[NQE_FLAG_SLAB_OVERFLOW], f[NQE_FLAG_NEED_LEVEL2],
                 f[NQE_FLAG_TABLE_FULL], f[NQE_FLAG_DENSE_OVERFLOW]);
     if (react_to_flags(f, pre)) return false;
+    if (ranged.out) {
+        uint64_t sum3[3];
+        std::memcpy(sum3, (const void *)(ctx->h_flags + NQE_NUM_FLAGS), sizeof(sum3));
+        const int64_t G = int64_t(sum3[0]);
+        set_group_count(ranged, G);
+        if (hint_key && G > 0) { // the exact range of the groups (the keys come out in order): the next execution cuts its partitions from it
+            const uint64_t flip = kinfo.out_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
+            const uint64_t lo = sum3[1] ^ flip, hi = sum3[2] ^ flip;
+            if (hi >= lo && hi - lo < (uint64_t(PARTS) << 12)) {
+                if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
+                ctx->agg_key_ranges[hint_key ^ PART_RANGE_SALT] = std::make_pair(int64_t(sum3[1]), hi - lo + 1);
+            }
+        }
+        *out = std::move(ranged);
+        return true;
+    }
     if (pre.dense_G > 0 && hint_key && range_part_ok && pre.ordmax >= pre.ordmin && pre.ordmax - pre.ordmin < (uint64_t(PARTS) << 12)) {
         // the exact key range of this query's groups: the next execution cuts its partitions from it
         const uint64_t flip = kinfo.out_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;

@@ -429,12 +429,7 @@ template <int PRED, int KEY, int NVT> struct SlabShape {
 // K32 (one value column): the tuple written to the slab is {int32 key, value} = 12 bytes — passes 2 and 3 of the partitioned
 // aggregate move 12 instead of 16 bytes per row (40 B/row in all instead of 48).  Optimistic: a key outside int32 raises
 // NQE_FLAG_KEY32_OVERFLOW and the host redoes the query with 16-byte tuples (and remembers).
-// key-range partitions (aggregate_common.hpp: SlabArgs::range_span): partition of d = key - range_min, and the scramble of the slot that
-// rebuilds the key's low bits from (partition, slot)
-__device__ __forceinline__ uint32_t range_scramble(uint32_t hi, int parts_log2) { return (hi * 0x9E3779B1u) >> (32 - parts_log2); }
-__device__ __forceinline__ uint32_t range_partition(uint64_t d, int parts_log2) {
-    return (uint32_t(d) ^ range_scramble(uint32_t(d >> parts_log2), parts_log2)) & ((1u << parts_log2) - 1u);
-}
+// (key-range partitions: range_partition / range_scramble in aggregate_common.hpp)
 
 #ifdef NQE_SLAB_PROFILE
 // diagnostic build (tools/probe_slab_phases.py): shader-clock time of thread 0 of every scatter workgroup per phase of a tile
@@ -1002,6 +997,117 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_direct_kernel(Agg
     }
 }
 
+// The range tier's second kernel (aggregate_common.hpp: RangeRec): workgroup (p, q) = blockIdx / Q, blockIdx % Q streams the slabs
+// w = q, q + Q, q + 2Q, ... of partition p into its LDS table (agg_slab_segments_direct_kernel's tuple stream and update) and writes
+// the whole table to tab[(p * Q + q) * W + slot].
+template <bool VF64>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_range_segments_kernel(AggArgs a, SlabArgs sa, int Q, RangeRec *__restrict__ tab) {
+    constexpr int SU = NQE_DIRECT_SU; // tuples per lane per step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int parts_log2 = sa.parts_log2;
+    const uint32_t W = uint32_t((sa.range_span + (uint64_t(1) << parts_log2) - 1) >> parts_log2); // slots per partition (<= 4096: the host checks)
+    double *lsum = reinterpret_cast<double *>(smem);
+    double *lmn = lsum + W;
+    double *lmx = lmn + W;
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + W);
+    const int vdt = a.val[0].dtype;
+    const int wave = int(threadIdx.x) / 64, nwaves = AGG_BLOCK / 64;
+    const int parts = 1 << parts_log2;
+    const int p = int(blockIdx.x) / Q, q = int(blockIdx.x) % Q;
+    for (uint32_t s = threadIdx.x; s < W; s += blockDim.x) {
+        lsum[s] = 0.0;
+        lmn[s] = DBL_MAX;
+        lmx[s] = -DBL_MAX;
+        lcnt[s] = 0;
+    }
+    __syncthreads();
+    const int nq = (sa.W - q + Q - 1) / Q;               // slabs of this workgroup: w = q + Q * j, j < nq
+    const int nl = nq > wave ? (nq - wave + nwaves - 1) / nwaves : 0; // ... of this wave: j = wave + l * nwaves (<= 64: W <= 1024)
+    auto slab_of = [&](int l) { return q + Q * (wave + l * nwaves); };
+    const uint32_t myfill = lane_id() < nl ? sa.fill[size_t(p) * size_t(sa.W) + size_t(slab_of(lane_id()))] : 0u;
+    struct Step {
+        uint64_t vw[SU];
+        int32_t k32[SU];
+        bool live[SU];
+    };
+    int cl = 0;
+    uint32_t ci0 = 0;
+    auto seek = [&](int &l, uint32_t &i0) {
+        while (l < nl && i0 >= uint32_t(__builtin_amdgcn_readlane(int(myfill), l))) {
+            ++l;
+            i0 = 0;
+        }
+    };
+    auto fetch = [&](Step &st, int l, uint32_t i0, bool on) { // (`on` false: a dummy step over a position known to hold tuples)
+        const uint32_t f = uint32_t(__builtin_amdgcn_readlane(int(myfill), l));
+        const Tuple12 *__restrict__ slab = reinterpret_cast<const Tuple12 *>(sa.slabs) + (size_t(slab_of(l)) * size_t(parts) + size_t(p)) * size_t(sa.cap);
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
+            st.live[u] = on && i < f;
+            const Tuple12 t = slab[i < f ? i : f - 1];
+            st.k32[u] = t.key;
+            st.vw[u] = t.val;
+        }
+    };
+    auto update = [&](const Step &st) {
+        uint32_t slot[SU];
+        double x[SU], cmn[SU], cmx[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            slot[u] = st.live[u] ? uint32_t(st.k32[u]) >> parts_log2 : 0u; // the tuple holds key - range_min (< span: the scatter checked the range, so slot < W)
+            x[u] = VF64 ? u2d(st.vw[u]) : word_as_f64(st.vw[u], vdt);
+            cmn[u] = lmn[slot[u]];
+            cmx[u] = lmx[slot[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            if (!st.live[u]) continue;
+            atomicAdd(&lcnt[slot[u]], 1u);
+            unsafeAtomicAdd(&lsum[slot[u]], x[u]);
+            if (x[u] != x[u]) atomicOr(&lcnt[slot[u]], NAN_BIT);
+            else {
+                if (x[u] < cmn[u]) unsafeAtomicMin(&lmn[slot[u]], x[u]);
+                if (x[u] > cmx[u]) unsafeAtomicMax(&lmx[slot[u]], x[u]);
+            }
+        }
+    };
+    seek(cl, ci0);
+    if (cl < nl) {
+        const int fl = cl;
+        const uint32_t fi0 = ci0;
+        Step A, B;
+        fetch(A, cl, ci0, true);
+        for (;;) {
+            int nlx = cl;
+            uint32_t ni0 = ci0 + 64 * SU;
+            seek(nlx, ni0);
+            const bool more_b = nlx < nl;
+            fetch(B, more_b ? nlx : fl, more_b ? ni0 : fi0, more_b);
+            update(A);
+            if (!more_b) break;
+            cl = nlx;
+            ci0 = ni0 + 64 * SU;
+            seek(cl, ci0);
+            const bool more_a = cl < nl;
+            fetch(A, more_a ? cl : fl, more_a ? ci0 : fi0, more_a);
+            update(B);
+            if (!more_a) break;
+        }
+    }
+    __syncthreads();
+    RangeRec *__restrict__ mine = tab + size_t(blockIdx.x) * size_t(W);
+    for (uint32_t s = threadIdx.x; s < W; s += blockDim.x) {
+        RangeRec r;
+        r.sum = lsum[s];
+        r.mn = lmn[s];
+        r.mx = lmx[s];
+        r.cnt = lcnt[s];
+        r.pad = 0;
+        mine[s] = r;
+    }
+}
+
 template <int PRED, int KEY> SlabScatterKernel pick_slab_scatter_nv(int nv, bool k32) {
     if (nv == 1) return k32 ? agg_slab_scatter_kernel<PRED, KEY, 1, true> : agg_slab_scatter_kernel<PRED, KEY, 1>;
     return agg_slab_scatter_kernel<PRED, KEY, 2>;
@@ -1074,6 +1180,7 @@ SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64, bool k32) {
     return nv == 1 ? (vf64 ? agg_slab_segments_kernel<1, true> : agg_slab_segments_kernel<1, false>)
                    : (vf64 ? agg_slab_segments_kernel<2, true> : agg_slab_segments_kernel<2, false>);
 }
+RangeSegmentsKernel pick_range_segments_kernel(bool vf64) { return vf64 ? agg_range_segments_kernel<true> : agg_range_segments_kernel<false>; }
 SlabSegmentsKernel pick_slab_segments_direct_kernel(bool vf64) { return vf64 ? agg_slab_segments_direct_kernel<true> : agg_slab_segments_direct_kernel<false>; }
 SubpartitionKernel pick_subpartition_kernel(int nv) { return nv == 1 ? agg_subpartition_kernel<1> : agg_subpartition_kernel<2>; }
 SegmentsKernel pick_segments_kernel(int nv, bool vf64) {
