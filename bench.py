@@ -48,7 +48,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable)
-PROFILE_TAG = "r04"    # profiles/<tag>/pmc_traffic_<config>.json are quoted as `roofline.traffic`
+PROFILE_TAG = "r05"    # profiles/<tag>/pmc_traffic_<config>.json are quoted as `roofline.traffic`
 # kernels that do not belong to an operator's step (data generation, diagnostics)
 NOT_STEP_KERNELS = ("synth_fill",)
 LINE_LIMIT = 8000      # bytes of the JSON line
@@ -512,7 +512,8 @@ def wl_aggregate(B, rows, with_filter, random_keys, steps, warmup, groups=None, 
     ms, kernels, spread = B.timed(step, steps, warmup, blocks)
     where = " where id < N/2" if (use_pred and shape != "tree") else ""
     desc = sh["text"].replace("{w}", where) + f"; id = {'random' if random_keys else 'row number'}; {n} rows per GPU"
-    names = ["agg_grouped", "agg_merge_partials", "agg_partition", "agg_slab", "agg_segments", "agg_subpartition", "agg_sample", "expr_tree", "keep_from"]
+    # (agg_range: the range tier's transposing tail — it is part of the partitioned path's data flow, so it counts; round 4's dense tail did not)
+    names = ["agg_grouped", "agg_merge_partials", "agg_partition", "agg_slab", "agg_segments", "agg_range", "agg_subpartition", "agg_sample", "expr_tree", "keep_from"]
     res = {"metric": "filter_hash_aggregate_rows_per_s" if use_pred else "hash_aggregate_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s",
            "ms_per_step": ms, "spread": spread, "cold_ms": cold_ms, "workload": desc, "rows_per_gpu": n, "roofline": roofline(sh["bpr"] * n, kernels, names)}
     return res, dict(table=table, tens=tens, valid=valid, sh=sh, key=key, fields=fields, n=n, total=total, use_pred=use_pred, random_keys=random_keys, groups=groups)

@@ -2048,16 +2048,16 @@ PassStatus AggRun::shape_pass() {
 PassStatus AggRun::tier_slab() {
     // ---- partitioned path, slab form: ONE pass scatters (key, values) tuples into per-workgroup slabs of fixed
     // capacity (no count pass, no scan, no read-back), then one workgroup per partition aggregates its slabs
-    const int rpt = slab_scatter_rows_per_thread(fp, fast_key, a.nv);
-    const int64_t tile_rows = int64_t(AGG_BLOCK) * rpt;
-    int W = int(std::min<int64_t>(int64_t(ctx->num_cus) * slab_scatter_wg_per_cu(), (in->rows + tile_rows - 1) / tile_rows));
-    int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
-    W = int((in->rows + chunk - 1) / chunk);
     // one value column, integer keys: 12-byte tuples {value, int32 key} unless a key was seen not to fit
     // key-range partitions (aggregate_common.hpp: SlabArgs::range_span): 256 tables (512 beyond 2^20 values) of ceil(span / parts) <= 4096 slots;
     // their tuples hold key - range_min, which fits 32 bits whatever the keys' magnitude
     const bool range_part = a.nv == 1 && dense && range_part_ok && part_span != 0 && part_span <= (uint64_t(PARTS) << 12);
     const bool k32 = a.nv == 1 && (!key32_failed || range_part);
+    const int rpt = k32 ? slab_scatter_soa_rows_per_thread() : slab_scatter_rows_per_thread(fp, fast_key, a.nv);
+    const int64_t tile_rows = int64_t(AGG_BLOCK) * rpt;
+    int W = int(std::min<int64_t>(int64_t(ctx->num_cus) * slab_scatter_wg_per_cu(), (in->rows + tile_rows - 1) / tile_rows));
+    int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
+    W = int((in->rows + chunk - 1) / chunk);
     int sparts_log2 = slab_parts_log2;
     if (range_part) sparts_log2 = part_span <= (uint64_t(256) << 12) ? 8 : PARTS_LOG2;
     // the range tier (aggregate_common.hpp: RangeRec): as many partitions as the RANGE needs at 2^range_slots_log2 slots per table (16 .. 256;
@@ -2107,7 +2107,8 @@ PassStatus AggRun::tier_slab() {
     sl.parts_log2 = sparts_log2;
     sl.range_min = part_min;
     sl.range_span = range_part ? part_span : 0;
-    const size_t sc_shmem = size_t(tile_rows) * 8 * tw + size_t(PARTS) * 12;
+    // (K32: the SoA scatter — stage and carry buffers of 12 bytes per tuple, five counters per partition, the block owner map)
+    const size_t sc_shmem = k32 ? (size_t(tile_rows) + size_t(PARTS) * 8) * 12 + size_t(PARTS) * 20 + (size_t(tile_rows) / 8 + PARTS) * 2 + 16 : size_t(tile_rows) * 8 * tw + size_t(PARTS) * 12;
     launch(ctx, "agg_partition_scatter", pick_slab_scatter_kernel(fp, fast_key, a.nv, k32), dim3(W), dim3(AGG_BLOCK), sc_shmem, ka, fpred, sl,
            ctx->d_flags);
     AggArgs sa = ka;

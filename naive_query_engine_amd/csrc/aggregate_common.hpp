@@ -525,6 +525,7 @@ using SlabScatterKernel = void (*)(AggArgs, FastPred, SlabArgs, int *);
 // k32 (one value column): 12-byte tuples {int32 key, value} — the scatter raises NQE_FLAG_KEY32_OVERFLOW on a key outside int32
 SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv, bool k32 = false);
 int slab_scatter_rows_per_thread(int pred, int key, int nv);
+int slab_scatter_soa_rows_per_thread(); // the K32 (SoA, whole-block) scatter
 int slab_scatter_wg_per_cu();
 // key-range partitions: partition of d = key - range_min, and the scramble of the slot that rebuilds the key's low bits from (partition, slot)
 __device__ __forceinline__ uint32_t range_scramble(uint32_t hi, int parts_log2) { return (hi * 0x9E3779B1u) >> (32 - parts_log2); }

@@ -621,6 +621,208 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
 #endif
 }
 
+// ------------------------------------------------------------------ the K32 scatter with WHOLE-LINE stores (round 5)
+// tools/scatter_bench.hip: what the 12-byte-record scatter above pays for is not its 256 streams but the shape of its stores — runs
+// of ~32 records that start and end anywhere, plain stores (a non-temporal store of a PARTIAL line is far worse: 1.1 ms), 0.70-0.83 ms
+// per 10^8 rows at 256 partitions where separate value / key streams written in whole aligned lines with non-temporal stores take
+// 0.57.  So the slab of (workgroup, partition) is two arrays — cap 8-byte values, then (behind every slab's values) cap 4-byte keys —
+// and a slab only ever receives whole BLOCKS of 16 tuples (8 with 512 partitions): one 128-byte line of values + 64 bytes of keys per
+// block, written by 16 consecutive lanes.  What a tile leaves over per partition (< 16 tuples) waits in an LDS carry buffer and leads
+// the partition's next block.  Per tile: rank the rows per partition (LDS atomic), scan the counts and the block counts, stage the
+// tuples by partition, copy out whole blocks — a block's tuples come from the carry buffer first, then from the stage — move the
+// leftovers to the carry buffer, advance the cursors.  The last, partial block of every partition is written when the chunk ends.
+// (Run length no longer matters — every store is a whole block — so neither does the tile size; the tile stays 8 rows per thread where
+// the registers allow two tiles in flight.)  Key as stored: key - range_min under key-range partitions, else the key's low 32 bits
+// (a key outside int32 raises NQE_FLAG_KEY32_OVERFLOW as before).
+#ifndef NQE_SOA_RPT
+#define NQE_SOA_RPT 4 // rows per thread per tile of the SoA scatter (every store is a whole block: the tile size no longer decides the store shape)
+#endif
+template <int PRED, int KEY>
+__global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_soa_kernel(AggArgs a, FastPred fp, SlabArgs sa, int *flags) {
+    constexpr int RPT = NQE_SOA_RPT;
+    constexpr int SC_ROWS = AGG_BLOCK * RPT;
+    constexpr int CARRY = PARTS * 8; // carry slots: parts x block (256 x 16 or 512 x 8)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *sval = reinterpret_cast<uint64_t *>(smem);      // [SC_ROWS] the tile's values by partition
+    uint64_t *cval = sval + SC_ROWS;                          // [CARRY]
+    uint32_t *skey = reinterpret_cast<uint32_t *>(cval + CARRY); // [SC_ROWS]
+    uint32_t *ckey = skey + SC_ROWS;                          // [CARRY]
+    uint32_t *gblk = ckey + CARRY;                            // [PARTS] blocks this workgroup has written per partition
+    uint32_t *ccnt = gblk + PARTS;                            // [PARTS] tuples in the carry buffer
+    uint32_t *tcnt = ccnt + PARTS;                            // [PARTS] tuples of this tile
+    uint32_t *tstart = tcnt + PARTS;                          // [PARTS] tile-local exclusive scan of tcnt
+    uint32_t *bstart = tstart + PARTS;                        // [PARTS] exclusive scan of the blocks this tile completes
+    uint16_t *bown = reinterpret_cast<uint16_t *>(bstart + PARTS); // [SC_ROWS / 8 + PARTS] partition of each such block
+    __shared__ uint32_t wave_tot[2][AGG_BLOCK / 64];
+    const int parts_log2 = sa.parts_log2, parts = 1 << parts_log2;
+    const int blk_log2 = parts_log2 <= 8 ? 4 : 3, blk = 1 << blk_log2;
+    const bool range_part = sa.range_span != 0;
+    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) gblk[p] = ccnt[p] = tcnt[p] = 0;
+    __syncthreads();
+    const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
+    const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED >= 2 ? a.pred_src.values : a.key_src.values);
+    const uint64_t *__restrict__ valp = static_cast<const uint64_t *>(a.val[0].values);
+    const uint64_t key_mask = a.key.aux[0].abs_lit - 1;
+    const OpAux key_aux = a.key.aux[0];
+    const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
+    const int64_t lo = int64_t(blockIdx.x) * sa.chunk;
+    const int64_t hi = lo + sa.chunk < a.n ? lo + sa.chunk : a.n;
+    const int64_t last = a.n - 1;
+    const uint32_t cap = uint32_t(sa.cap);
+    // this workgroup's slabs: values of (w, p) at vbase + p * cap, keys at kbase + p * cap
+    uint64_t *__restrict__ vbase = sa.slabs + size_t(blockIdx.x) * size_t(parts) * size_t(cap);
+    uint32_t *__restrict__ kbase = reinterpret_cast<uint32_t *>(sa.slabs + size_t(sa.W) * size_t(parts) * size_t(cap)) + size_t(blockIdx.x) * size_t(parts) * size_t(cap);
+    struct Regs {
+        uint64_t kw[RPT], pw[PRED >= 2 ? RPT : 1], vw[RPT];
+    };
+    auto load = [&](Regs &r, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            row = row < last ? row : last; // clamp: unconditional, in-bounds
+            r.kw[u] = __builtin_nontemporal_load(&keyp[row]);
+            if (PRED == 2) r.pw[PRED >= 2 ? u : 0] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
+            if (PRED == 3) r.pw[PRED >= 2 ? u : 0] = __builtin_nontemporal_load(&predp[row]);
+            r.vw[u] = __builtin_nontemporal_load(&valp[row]);
+        }
+    };
+    // tuple j of partition p's pending sequence: the carried tuples first, then the tile's
+    // (one index into sval / skey — the carry buffers lie right behind the stages: a selected POINTER sends the pointers to scratch memory)
+    auto pending = [&](uint32_t p, uint32_t j, uint32_t cc, uint64_t &v, uint32_t &k) {
+        const uint32_t i = j < cc ? uint32_t(SC_ROWS) + (p << blk_log2) + j : tstart[p] + (j - cc);
+        v = sval[i];
+        k = skey[i];
+    };
+    auto tile = [&](const Regs &r, Regs &next, int64_t base) {
+        uint32_t k32[RPT], part[RPT], rank[RPT];
+        bool pass[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            bool ok = row < hi;
+            if (PRED == 3) ok = ok && eval_simple<false>(a.pred, r.pw[PRED >= 2 ? u : 0], false, nullptr) != 0; // host-vetted chain: cannot fault
+            else if (PRED == 2) ok = ok && range_pass(fp, pred_extract(fp, r.pw[PRED >= 2 ? u : 0], row < last ? row : last));
+            else if (PRED == 1) ok = ok && range_pass(fp, r.kw[u]);
+            const uint64_t key = inline_key<KEY>(a.key, r.kw[u], key_mask, key_aux, key_signed);
+            if (range_part) { // (wave-uniform choice) a key outside the range: the host redoes the query hashed
+                const uint64_t d = key - uint64_t(sa.range_min);
+                if (ok && d >= sa.range_span) {
+                    atomicOr(&flags[NQE_FLAG_OOB], 1);
+                    ok = false;
+                }
+                part[u] = range_partition(d, parts_log2);
+                k32[u] = uint32_t(d);
+            } else {
+                part[u] = uint32_t((key * GOLD) >> (64 - parts_log2));
+                k32[u] = uint32_t(key);
+                if (ok && int64_t(int32_t(uint32_t(key))) != int64_t(key)) atomicOr(&flags[NQE_FLAG_KEY32_OVERFLOW], 1);
+            }
+            pass[u] = ok;
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) rank[u] = pass[u] ? atomicAdd(&tcnt[part[u]], 1u) : 0u;
+        __syncthreads();
+        // threads 0..parts-1: exclusive scans of the tile's counts and of the blocks the tile completes
+        uint32_t c = 0, nb = 0;
+        if (int(threadIdx.x) < parts) {
+            c = tcnt[threadIdx.x];
+            nb = (ccnt[threadIdx.x] + c) >> blk_log2;
+        }
+        uint32_t wt0, wt1;
+        const uint32_t ex0 = wave_exclusive_scan(c, wt0), ex1 = wave_exclusive_scan(nb, wt1);
+        if (lane_id() == 63) {
+            wave_tot[0][threadIdx.x / 64] = wt0;
+            wave_tot[1][threadIdx.x / 64] = wt1;
+        }
+        __syncthreads();
+        uint32_t nblocks = 0;
+        {
+            uint32_t pre0 = 0, pre1 = 0;
+            for (int w = 0; w < PARTS / 64; ++w) {
+                if (w < int(threadIdx.x) / 64) {
+                    pre0 += wave_tot[0][w];
+                    pre1 += wave_tot[1][w];
+                }
+                nblocks += wave_tot[1][w];
+            }
+            if (int(threadIdx.x) < parts) {
+                tstart[threadIdx.x] = pre0 + ex0;
+                bstart[threadIdx.x] = pre1 + ex1;
+                for (uint32_t b = 0; b < nb; ++b) bown[pre1 + ex1 + b] = uint16_t(threadIdx.x);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            if (!pass[u]) continue;
+            const uint32_t i = tstart[part[u]] + rank[u];
+            sval[i] = r.vw[u];
+            skey[i] = k32[u];
+        }
+        if (base + SC_ROWS < hi) load(next, base + SC_ROWS); // workgroup-uniform: the next tile's words fly during the copy-out
+        __syncthreads();
+        // whole blocks: 2^blk_log2 consecutive lanes write one block — a 128-byte line of values and 64 bytes of keys
+        for (uint32_t t = threadIdx.x; t < (nblocks << blk_log2); t += blockDim.x) {
+            const uint32_t b = t >> blk_log2, l = t & uint32_t(blk - 1), p = bown[b];
+            const uint32_t j = ((b - bstart[p]) << blk_log2) + l, at = (gblk[p] << blk_log2) + j;
+            uint64_t v;
+            uint32_t k;
+            pending(p, j, ccnt[p], v, k);
+            if (at < cap) {
+                __builtin_nontemporal_store(v, vbase + size_t(p) * cap + at);
+                __builtin_nontemporal_store(k, kbase + size_t(p) * cap + at);
+            } else
+                atomicOr(&flags[NQE_FLAG_SLAB_OVERFLOW], 1); // skewed keys: the host redoes the query with exact partition sizes
+        }
+        __syncthreads();
+        // leftovers to the carry buffer (a partition that completed a block consumed its carry: the leftovers are the tile's own)
+        for (uint32_t t = threadIdx.x; t < uint32_t(parts << blk_log2); t += blockDim.x) {
+            const uint32_t p = t >> blk_log2, l = t & uint32_t(blk - 1);
+            const uint32_t cc = ccnt[p], tot = cc + tcnt[p], nbp = tot >> blk_log2, rem = tot & uint32_t(blk - 1);
+            const uint32_t j = (nbp << blk_log2) + l;
+            if (l < rem && j >= cc) {
+                uint64_t v;
+                uint32_t k;
+                pending(p, j, cc, v, k);
+                cval[(p << blk_log2) + l] = v;
+                ckey[(p << blk_log2) + l] = k;
+            }
+        }
+        __syncthreads();
+        if (int(threadIdx.x) < parts) {
+            const uint32_t tot = ccnt[threadIdx.x] + tcnt[threadIdx.x];
+            gblk[threadIdx.x] += tot >> blk_log2;
+            ccnt[threadIdx.x] = tot & uint32_t(blk - 1);
+            tcnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+    };
+    if (lo < hi) {
+        Regs A, B;
+        load(A, lo);
+        for (int64_t base = lo; base < hi; base += 2 * int64_t(SC_ROWS)) {
+            tile(A, B, base);
+            if (base + SC_ROWS >= hi) break;
+            tile(B, A, base + SC_ROWS);
+        }
+    }
+    // the last, partial block of every partition; the fill counts
+    for (uint32_t t = threadIdx.x; t < uint32_t(parts << blk_log2); t += blockDim.x) {
+        const uint32_t p = t >> blk_log2, l = t & uint32_t(blk - 1), at = (gblk[p] << blk_log2) + l;
+        if (l < ccnt[p]) {
+            if (at < cap) {
+                vbase[size_t(p) * cap + at] = cval[(p << blk_log2) + l];
+                kbase[size_t(p) * cap + at] = ckey[(p << blk_log2) + l];
+            } else
+                atomicOr(&flags[NQE_FLAG_SLAB_OVERFLOW], 1);
+        }
+    }
+    for (int p = threadIdx.x; p < parts; p += blockDim.x) {
+        const uint32_t n = (gblk[p] << blk_log2) + ccnt[p];
+        sa.fill[size_t(p) * size_t(sa.W) + blockIdx.x] = n < cap ? n : cap;
+    }
+}
+
 // one workgroup per partition (grid-stride); its waves take the partition's slabs round-robin and stream their tuples, four
 // per lane per step, into the workgroup's LDS table with the batched update of the fast kernel (all first probes, then all
 // min/max reads of the step in flight together — tuples of a partition arrive in no particular order, every row is an update).
@@ -690,10 +892,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_kernel(AggArgs a,
                 const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
                 st.live[u] = on && i < f;
                 const uint32_t ic = st.live[u] ? i : f - 1;
-                if (K32) {
-                    const Tuple12 t = reinterpret_cast<const Tuple12 *>(sa.slabs)[(size_t(wave + l * nwaves) * size_t(parts) + size_t(p)) * size_t(sa.cap) + ic];
-                    st.k32[K32 ? u : 0] = t.key;
-                    st.vw[0][u] = t.val;
+                if (K32) { // (two arrays: agg_slab_scatter_soa_kernel)
+                    const size_t at = (size_t(wave + l * nwaves) * size_t(parts) + size_t(p)) * size_t(sa.cap) + ic;
+                    st.k32[K32 ? u : 0] = int32_t(__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(sa.slabs + size_t(sa.W) * size_t(parts) * size_t(sa.cap)) + at));
+                    st.vw[0][u] = __builtin_nontemporal_load(sa.slabs + at);
                 } else if (TW == 2) {
                     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
                     const v2u64 t = __builtin_nontemporal_load(reinterpret_cast<const v2u64 *>(&slab[size_t(ic) * 2]));
@@ -903,14 +1105,16 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_segments_direct_kernel(Agg
         };
         auto fetch = [&](Step &st, int l, uint32_t i0, bool on) { // (`on` false: a dummy step over a position known to hold tuples)
             const uint32_t f = uint32_t(__builtin_amdgcn_readlane(int(myfill), l));
-            const Tuple12 *__restrict__ slab = reinterpret_cast<const Tuple12 *>(sa.slabs) + (size_t(wave + l * nwaves) * size_t(parts) + size_t(p)) * size_t(sa.cap);
+            const size_t sbase = (size_t(wave + l * nwaves) * size_t(parts) + size_t(p)) * size_t(sa.cap);
+            const uint64_t *__restrict__ svals = sa.slabs + sbase;
+            const uint32_t *__restrict__ skeys = reinterpret_cast<const uint32_t *>(sa.slabs + size_t(sa.W) * size_t(parts) * size_t(sa.cap)) + sbase;
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
                 st.live[u] = on && i < f;
-                const Tuple12 t = slab[i < f ? i : f - 1];
-                st.k32[u] = t.key;
-                st.vw[u] = t.val;
+                const uint32_t ic = i < f ? i : f - 1;
+                st.k32[u] = int32_t(__builtin_nontemporal_load(skeys + ic));
+                st.vw[u] = __builtin_nontemporal_load(svals + ic);
             }
         };
         auto update = [&](const Step &st) {
@@ -1040,14 +1244,16 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_range_segments_kernel(AggArgs a
     };
     auto fetch = [&](Step &st, int l, uint32_t i0, bool on) { // (`on` false: a dummy step over a position known to hold tuples)
         const uint32_t f = uint32_t(__builtin_amdgcn_readlane(int(myfill), l));
-        const Tuple12 *__restrict__ slab = reinterpret_cast<const Tuple12 *>(sa.slabs) + (size_t(slab_of(l)) * size_t(parts) + size_t(p)) * size_t(sa.cap);
+        const size_t sbase = (size_t(slab_of(l)) * size_t(parts) + size_t(p)) * size_t(sa.cap);
+        const uint64_t *__restrict__ svals = sa.slabs + sbase;
+        const uint32_t *__restrict__ skeys = reinterpret_cast<const uint32_t *>(sa.slabs + size_t(sa.W) * size_t(parts) * size_t(sa.cap)) + sbase;
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
             const uint32_t i = i0 + uint32_t(u) * 64 + uint32_t(lane_id());
             st.live[u] = on && i < f;
-            const Tuple12 t = slab[i < f ? i : f - 1];
-            st.k32[u] = t.key;
-            st.vw[u] = t.val;
+            const uint32_t ic = i < f ? i : f - 1;
+            st.k32[u] = int32_t(__builtin_nontemporal_load(skeys + ic));
+            st.vw[u] = __builtin_nontemporal_load(svals + ic);
         }
     };
     auto update = [&](const Step &st) {
@@ -1109,7 +1315,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_range_segments_kernel(AggArgs a
 }
 
 template <int PRED, int KEY> SlabScatterKernel pick_slab_scatter_nv(int nv, bool k32) {
-    if (nv == 1) return k32 ? agg_slab_scatter_kernel<PRED, KEY, 1, true> : agg_slab_scatter_kernel<PRED, KEY, 1>;
+    if (nv == 1) return k32 ? agg_slab_scatter_soa_kernel<PRED, KEY> : agg_slab_scatter_kernel<PRED, KEY, 1>;
     return agg_slab_scatter_kernel<PRED, KEY, 2>;
 }
 template <int PRED> SlabScatterKernel pick_slab_scatter_key(int key, int nv, bool k32) {
@@ -1173,6 +1379,7 @@ SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv, bool k32) 
     default: return pick_slab_scatter_key<3>(key, nv, k32);
     }
 }
+int slab_scatter_soa_rows_per_thread() { return NQE_SOA_RPT; }
 int slab_scatter_rows_per_thread(int pred, int key, int nv) { return NQE_SLAB_WG_PER_CU > 1 ? 4 : ((nv == 1 && pred <= 1 && (key == 0 || (NQE_SLAB_KEYMOD_RPT == 8 && key != 3))) ? 8 : 4); }
 int slab_scatter_wg_per_cu() { return NQE_SLAB_WG_PER_CU; }
 SlabSegmentsKernel pick_slab_segments_kernel(int nv, bool vf64, bool k32) {

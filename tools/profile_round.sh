@@ -2,19 +2,22 @@
 # Runs on the GPU box (via gpurun): the default bench line, rocprofv3 kernel stats per config, and the PMC traffic passes
 # (counters in their own runs, --kernel-trace only, one counter per pass) for every config plus the calibration kernels.
 # Output under gpurun_out/$1/ ; tools/summarize_profiles.py turns it into profiles/$1/ (tracked).
-#   usage: tools/profile_round.sh r04
+#   usage: tools/profile_round.sh r05        (NQE_PROFILE_LIGHT=1: the default line + the per-config rocprofv3 passes only)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python tools/csrc_rev.py > $OUT/csrc_rev.txt
 python bench.py --details $OUT/bench_details.json 2>&1 | tail -1 > $OUT/bench_default.json
+LIGHT=${NQE_PROFILE_LIGHT:-}
+if [ -z "$LIGHT" ]; then
 # the same line with nothing remembered between executions (every execution plans from scratch; the key sample still runs)
 NQE_NO_PLAN_HINTS=1 python bench.py --details $OUT/bench_details_no_plan_hints.json 2>&1 | tail -1 > $OUT/bench_no_plan_hints.json
 # first-execution cost of every query shape, each in a fresh process
 NQE_COLD_VARIANTS=NQE_NO_RESERVE,NQE_LAZY_MODULES python tools/probe_cold.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_cold.txt
+fi
 declare -A WL=( [headline]="--workload headline" [headline_random_keys]="--workload headline --random-keys" [c2]="--workload c2" [c4]="--workload c4" \
                 [c4_sparse_keys]="--workload c4_sparse" [agg_65536_groups]="--workload agg_groups --groups 65536" [agg_4096_groups]="--workload agg_groups --groups 4096" [c2_expression_trees]="--workload c2_tree" \
                 [headline_single_column]="--workload headline_single" [headline_int64_values]="--workload headline_int64" \
@@ -35,6 +38,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_calib -o calib -- $R/tools/stream_bench calib > $OUT/pmc_write_calib.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_gather -o gather -- $R/tools/micro_bench gather1 > $OUT/pmc_fetch_gather.log 2>&1
 cd $R
+if [ -n "$LIGHT" ]; then ls $OUT; exit 0; fi
 python tools/probe_paths.py groups 2>&1 | grep -v amdgpu.ids > $OUT/probe_groups.txt
 python tools/probe_paths.py joinshapes 2>&1 | grep -v amdgpu.ids > $OUT/probe_joinshapes.txt
 python tools/probe_build.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_build.txt
