@@ -513,7 +513,7 @@ def wl_aggregate(B, rows, with_filter, random_keys, steps, warmup, groups=None, 
     where = " where id < N/2" if (use_pred and shape != "tree") else ""
     desc = sh["text"].replace("{w}", where) + f"; id = {'random' if random_keys else 'row number'}; {n} rows per GPU"
     # (agg_range: the range tier's transposing tail — it is part of the partitioned path's data flow, so it counts; round 4's dense tail did not)
-    names = ["agg_grouped", "agg_merge_partials", "agg_partition", "agg_slab", "agg_segments", "agg_range", "agg_subpartition", "agg_sample", "expr_tree", "keep_from"]
+    names = ["agg_grouped", "agg_merge_partials", "agg_fold_partials", "agg_partition", "agg_slab", "agg_segments", "agg_range", "agg_subpartition", "agg_sample", "expr_tree", "keep_from"]
     res = {"metric": "filter_hash_aggregate_rows_per_s" if use_pred else "hash_aggregate_rows_per_s", "value": total / (ms * 1e-3), "unit": "rows/s",
            "ms_per_step": ms, "spread": spread, "cold_ms": cold_ms, "workload": desc, "rows_per_gpu": n, "roofline": roofline(sh["bpr"] * n, kernels, names)}
     return res, dict(table=table, tens=tens, valid=valid, sh=sh, key=key, fields=fields, n=n, total=total, use_pred=use_pred, random_keys=random_keys, groups=groups)

@@ -101,6 +101,12 @@ struct AggArgs {
     // word, two device words) when (iteration & mask) == mask: each look drains the wave's vector-memory queue — the tile it has just
     // requested — before the flag loads can return (0: every iteration).  The two-tile loop looks every iteration (see there).
     int32_t flag_check_mask;
+    // fast kernel, direct-mapped table without validity bitmaps: the workgroup's table leaves WHOLE — partials + ((j * grid + workgroup) *
+    // partial_span + key index) per value column j as [sums | mins | maxs] doubles then counts (uint32, NaN mark in the top bit), the layout
+    // agg_fold_partials_kernel reads — instead of being folded into the group table with device-scope atomics (0: the atomics).
+    // 256 workgroups x 4096 groups x 4 atomics were 0.17 ms of a 0.47 ms pass (10^8 rows, 4096 random keys).
+    uint32_t partial_span;
+    uint64_t partials;
 };
 
 // ------------------------------------------------------------------ predicate trees (pred_mode 4)

@@ -621,6 +621,26 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         }
         __syncthreads();
     }
+    if (!VNULL && a.direct && a.partials) {
+        // the table leaves whole (AggArgs::partials): coalesced stores, no atomics; agg_fold_partials_kernel folds the workgroups' tables
+        const uint32_t span = a.partial_span;
+        const size_t cells = size_t(gridDim.x) * span;
+#pragma unroll
+        for (int j = 0; j < NVT; ++j) {
+            double *__restrict__ ps = reinterpret_cast<double *>(a.partials) + size_t(j) * ((cells * 28 + 7) / 8) + size_t(blockIdx.x) * span;
+            uint32_t *__restrict__ pc = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(a.partials) + size_t(j) * ((cells * 28 + 7) / 8) + 3 * cells) + size_t(blockIdx.x) * span;
+            for (uint32_t ki = threadIdx.x; ki < span; ki += blockDim.x) {
+                const uint32_t s = ki << rep_log2, o = uint32_t(j) * slots + s;
+                uint32_t c = lcnt[o];
+                if (!OWN_CNT && j > 0) c = (lcnt[s] & ~NAN_BIT) | (c & NAN_BIT);
+                ps[ki] = lsum[o];
+                ps[cells + ki] = mmcol(j) ? lmn[mmo(j, s)] : DBL_MAX;
+                ps[2 * cells + ki] = mmcol(j) ? lmx[mmo(j, s)] : -DBL_MAX;
+                pc[ki] = c;
+            }
+        }
+        return;
+    }
     for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
         uint64_t k;
         if (a.direct && (s & ((1u << rep_log2) - 1u)) && s != cap) continue; // replicas were folded into replica 0
