@@ -1454,6 +1454,7 @@ AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const n
     return r;
 }
 
+constexpr uint64_t TINY_SALT = 0xC2B2AE3D27D4EB4Full;       // nqe_ctx::agg_key_ranges[hint ^ salt] present: the tiny-groups kernel met a key outside [0, m)
 constexpr uint64_t PART_RANGE_SALT = 0x9E3779B97F4A7C15ull; // nqe_ctx::agg_key_ranges[hint ^ salt]: the key range of the query's groups (range partitions)
 
 // ---- PhysicalAggregatePlan::execute (aggregate/mod.rs:113-222) on the device, one object per execution:
@@ -1521,6 +1522,7 @@ struct AggRun {
     bool asked_partition = false, dense = false, flagless = false, slab_oom = false, three = false, three_redo = false, dense_redo = false, first_alone = false;
     int nv_step = 1, pass_nv = 0;
     TableBufs tb;
+    bool tiny_ok = true, tiny_used = false; // the register-resident kernel for at most four groups (aggregate_tiny.hip)
     AggResult ranged;        // tier_range: outputs allocated for the whole key range, cut to the group count once it has travelled back with the flags
     BufRef range_total, range_tab, range_status; // ... which agg_range_emit_kernel leaves in range_total; its inputs, kept until the attempt is over
     // ---- the pass (shape_pass)
@@ -1743,6 +1745,7 @@ void AggRun::load_hints() {
                 }
             }
         }
+        if (!no_hints && ctx->agg_key_ranges.find(hint_key ^ TINY_SALT) != ctx->agg_key_ranges.end()) tiny_ok = false; // a key outside [0, m) was met before
         auto it = ctx->agg_hints.find(hint_key);
         if (!no_hints && it != ctx->agg_hints.end()) {
             const uint8_t hv = it->second & 0x3f;
@@ -1887,6 +1890,7 @@ void AggRun::pick_key_range() {
 void AggRun::begin_attempt() {
     ranged = AggResult();
     range_total = range_tab = range_status = BufRef();
+    tiny_used = false;
     range_part_used = false;
     asked_partition = false; // a streaming pass of this attempt ran with allow_partition (see the TABLE_FULL handler below)
     // The partitioned path (entered after the fast kernel asked for it) with a single pass over the value columns writes
@@ -2334,6 +2338,28 @@ PassStatus AggRun::tier_streaming(int v0) {
     // a predicate tree the static kernel would interpret (PRED 5 / 6) over `col % m` keys and one value column: the lean
     // run-time specialised kernel, once it has been compiled — its workgroup tables are folded into the group table here
     // interpreted chain predicates (PRED 3: `id % 10 < 5`, `id * 3 >= K`) take the specialised kernel too: 0.70 -> 0.555 ms per 2x10^8 rows
+    // ---- `col % m`, m <= 4 (the reference's own `group by id % 3`): the register-resident kernel (aggregate_tiny.hip) — no LDS table at all
+    {
+        const uint64_t tm = a.key.nops == 1 ? a.key.aux[0].abs_lit : 0;
+        bool tiny = sw.tiny_groups && tiny_ok && !jit_whole && ka.direct == 1 && (fast_key == 1 || fast_key == 2) && tm >= 1 && tm <= 4 && (fp == 0 || fp == 1) && !vnull &&
+                    subsets_log2 == 0 && key_col >= 0 && a.nv >= 1 && a.nv <= 3 && in->rows >= (int64_t(1) << 20);
+        for (int j = 0; tiny && j < a.nv; ++j) tiny = a.val[j].values != nullptr && (j == a.nv - 1 || !a.need_minmax[j]);
+        if (tiny) {
+            const size_t cells = size_t(fgrid) * size_t(tm), col_words = (cells * 28 + 7) / 8;
+            BufRef partials = dev_alloc(ctx, col_words * 8 * size_t(a.nv) + 64);
+            ka.partials = reinterpret_cast<uint64_t>(partials->ptr);
+            ka.partial_span = uint32_t(tm);
+            const bool mm = a.need_minmax[a.nv - 1] != 0;
+            launch(ctx, "agg_grouped_tiny", pick_tiny_groups_kernel(fp, a.nv, mm, uint32_t(tm), a.val[0].values == a.key_src.values), dim3(fgrid), dim3(AGG_BLOCK), 0, ka, fpred, uint32_t(tm), ctx->d_flags);
+            for (int j = 0; j < a.nv; ++j) {
+                const double *ps = reinterpret_cast<const double *>(partials->ptr) + size_t(j) * col_words;
+                launch(ctx, "agg_fold_partials", agg_fold_partials_kernel, dim3((unsigned(tm) + 15) / 16), dim3(256), 0, ps, ps + cells, ps + 2 * cells, reinterpret_cast<const uint32_t *>(ps + 3 * cells),
+                       fgrid, uint32_t(tm), int64_t(0), (mm && j == a.nv - 1) ? 1 : 0, tb.g, a.v0 + j, ctx->d_flags);
+            }
+            tiny_used = true;
+            return PassStatus::Done;
+        }
+    }
     const bool jit_chains = !sw.no_agg_jit_chains;
     BufRef jit_partials;
     uint32_t jit_span = 0;
@@ -2493,6 +2519,16 @@ bool AggRun::react_to_flags(const int *f, const Collected &pre) {
     (void)pre;
     if (f[NQE_FLAG_DIV_ZERO]) fail(NQE_ERR_ARROW, "Divide by zero");
     if (f[NQE_FLAG_OVERFLOW]) fail(NQE_ERR_ARROW, "attempt to divide with overflow");
+    if (f[NQE_FLAG_OOB] && tiny_used) {
+        // a key outside [0, m) — a negative Int64 — under the tiny-groups kernel: the streaming kernel, now and for this query shape's later executions
+        tiny_ok = false;
+        if (hint_key) {
+            if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
+            ctx->agg_key_ranges[hint_key ^ TINY_SALT] = std::make_pair(int64_t(0), uint64_t(0));
+        }
+        flags_reset(ctx);
+        return true;
+    }
     if ((f[NQE_FLAG_OOB] || f[NQE_FLAG_SLAB_OVERFLOW]) && partition_mode && range_part_used) {
         // a key outside the range the partitions were cut from (the sample missed it, the column changed), or key intervals of very
         // unequal weight: hashed partitions, now and for this query shape's later executions

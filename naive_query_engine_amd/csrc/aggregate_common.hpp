@@ -551,6 +551,9 @@ struct __attribute__((aligned(16))) RangeRec {
     double sum, mn, mx;
     uint32_t cnt, pad; // cnt: rows | NAN_BIT
 };
+// at most four groups (`col % m`, m <= 4): the group state in registers (aggregate_tiny.hip); partials in the layout of AggArgs::partials
+using TinyGroupsKernel = void (*)(AggArgs, FastPred, uint32_t, int *);
+TinyGroupsKernel pick_tiny_groups_kernel(int pred, int nv, bool minmax_last, uint32_t m, bool first_value_is_key);
 using RangeSegmentsKernel = void (*)(AggArgs, SlabArgs, int, RangeRec *);
 RangeSegmentsKernel pick_range_segments_kernel(bool vf64);
 using SlabSegmentsKernel = void (*)(AggArgs, SlabArgs, GroupTable, int *);

@@ -20,6 +20,7 @@ void AggSwitches::read_environment() {
     flag_check_mask = (m == 0 || m == 1 || m == 3 || m == 7 || m == 15) ? m : 7;
     no_agg_jit_chains = getenv("NQE_NO_AGG_JIT_CHAINS") != nullptr;
     agg_jit_all = num("NQE_AGG_JIT_ALL", 1);
+    tiny_groups = num("NQE_TINY_GROUPS", 1) != 0;
     direct_partials = num("NQE_DIRECT_PARTIALS", 1) != 0;
     range_tier = num("NQE_RANGE_TIER", 1) != 0;
     range_slots_log2 = std::min(12, std::max(8, num("NQE_RANGE_SLOTS_LOG2", 12)));

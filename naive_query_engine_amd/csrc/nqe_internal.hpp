@@ -60,6 +60,7 @@ struct AggSwitches {
     int flag_check_mask = 7;           // NQE_FLAG_CHECK_MASK: a wave of the one-tile streaming loop looks at the overflow flags every (mask + 1)th iteration
     bool no_agg_jit_chains = false;    // NQE_NO_AGG_JIT_CHAINS=1: chain predicates / chain keys stay on the interpreting static kernel
     int agg_jit_all = 1;               // NQE_AGG_JIT_ALL: 0 = neither, 1 = `col % m` by magic multiply through the specialised kernel, 2 = every `% m` key
+    bool tiny_groups = true;           // NQE_TINY_GROUPS=0: `col % m`, m <= 4 stays on the streaming kernel's replicated LDS tables (round 4's form)
     bool direct_partials = true;       // NQE_DIRECT_PARTIALS=0: the streaming kernel folds its direct-mapped workgroup tables into the group table with device-scope atomics (round 4's form)
     bool range_tier = true;            // NQE_RANGE_TIER=0: key-range partitions keep 256 tables, one workgroup per table and the dense tail (round 4's form)
     int range_slots_log2 = 12;         // NQE_RANGE_SLOTS_LOG2: log2 of the slots per table the range tier sizes its partition count for (8..12; measured at 10^8 rows / 65536 groups: 9: 1.11, 10: 1.03, 11: 0.99, 12: 0.97 ms per step)

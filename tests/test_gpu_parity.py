@@ -2629,3 +2629,50 @@ def test_aggregate_range_partitions_with_keys_beyond_int32(ctx):
         assert ctx.timing_query("agg_segments_direct")[1] > 0, f"rep {rep}: key-range partitions were expected"
         assert (np.sort(gk.to_host()[0].to_numpy()) == np.unique(k)).all()
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"wide keys, rep {rep}")
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape", ["readme", "c1", "five_on_one", "count_key_only", "uint64_key", "key_range_pred", "nan_values", "negative_keys"])
+def test_aggregate_at_most_four_groups_in_registers(ctx, m, shape):
+    """`group by id % m`, m <= 4 — the reference's own aggregate query (src/main.rs:36-40, README.md:105-111: count(id), sum(age), sum(score),
+    avg(score), max(score), min(score) … group by id % 3) — goes through the register-resident kernel (aggregate_tiny.hip) from 2^20 rows on:
+    every arrangement of value columns it takes, the key column as a value column, UInt64 keys, a range predicate on the key, NaN values
+    (max.rs:38-50), and negative keys (outside [0, m): the streaming kernel takes over, now and on the next execution).
+    aggregate/mod.rs:113-222, sum.rs, avg.rs, count.rs, max.rs, min.rs"""
+    rng = np.random.default_rng(100 * m + len(shape))
+    n = (1 << 20) + 777
+    ids = rng.integers(0, 1 << 40, n).astype(np.int64)
+    if shape == "negative_keys":
+        ids[n // 2] = -5
+        ids[7] = -(1 << 33)
+    age = rng.integers(18, 78, n).astype(np.int64)
+    score = rng.random(n) * 100.0
+    if shape == "nan_values":
+        score[rng.integers(0, n, 5)] = np.nan
+    idc = Column.from_numpy(ids.astype(np.uint64)) if shape == "uint64_key" else Column.from_numpy(ids)
+    cols = [idc, Column.from_numpy(age), Column.from_numpy(score)]
+    f3 = fields("id", "age", "score")
+    aggs = {"readme": [(AggregateFunc.Count, 0), (AggregateFunc.Sum, 1), (AggregateFunc.Sum, 2), (AggregateFunc.Avg, 2), (AggregateFunc.Max, 2), (AggregateFunc.Min, 2)],
+            "c1": [(AggregateFunc.Count, 0), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 2)],
+            "five_on_one": ALL_AGGS(2), "count_key_only": [(AggregateFunc.Count, 0), (AggregateFunc.Max, 0)]}.get(shape, ALL_AGGS(2) + [(AggregateFunc.Sum, 1)] if shape == "negative_keys" else
+                                                                                                                    [(AggregateFunc.Count, 0), (AggregateFunc.Sum, 1), (AggregateFunc.Max, 2), (AggregateFunc.Min, 2)])
+    lit = lit_u64 if shape == "uint64_key" else lit_i64
+    key = binop(col(0), Operator.Modulos, lit(m)).flatten(f3)
+    pred = binop(col(0), Operator.Lt, lit_i64(1 << 39)).flatten(f3) if shape == "key_range_pred" else None
+    exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=pred)[0]
+    t = ctx.table_from_host(cols)
+    for rep in range(2):
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got, gk = ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred, with_keys=True)
+        ctx.timing_enable(False)
+        tiny = ctx.timing_query("agg_grouped_tiny")[1]
+        last_needs_minmax_only = shape != "negative_keys"      # (its aggregate list asks min / max of a column that is not the pass's last: not this kernel's shape)
+        if shape == "negative_keys":
+            assert tiny == 0 or rep == 0
+        elif last_needs_minmax_only:
+            assert tiny > 0, f"{shape} m={m} rep {rep}: the register-resident kernel was expected"
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[i for i, (fn, _) in enumerate(aggs) if fn == AggregateFunc.Count], what=f"{shape} m={m} rep {rep}")
+        kk = gk.to_host()[0].to_numpy()
+        assert (np.sort(kk.astype(np.int64)) == np.unique(np.fmod(ids, m) if shape != "uint64_key" else (ids.astype(np.uint64) % np.uint64(m)).astype(np.int64))[
+            np.isin(np.unique(np.fmod(ids, m) if shape != "uint64_key" else (ids.astype(np.uint64) % np.uint64(m)).astype(np.int64)), kk.astype(np.int64))]).all()
