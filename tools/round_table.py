@@ -1,11 +1,19 @@
 #!/usr/bin/env python
 """Markdown table of a round's bench line: profiles/<tag>/bench_default.json (+ bench_no_plan_hints.json, summary.json's PMC traffic,
-the previous round's line for comparison).  usage: python tools/round_table.py r04 [r03]"""
+the previous round's line for comparison).  usage: python tools/round_table.py r05 [r04]
+
+Per config the table also puts the rocprofv3 --kernel-trace --stats average (profiles/<tag>/rocprofv3_kernel_stats_<config>.csv: the step's data
+kernels, average duration x launches per step) beside the HIP-event figure of the bench line and FLAGS a disagreement above 3 % — the two
+come from different processes, often different boxes."""
 import json
 import os
+import csv
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from profile_configs import CONFIGS  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 prev = sys.argv[2] if len(sys.argv) > 2 else None
 d = json.load(open(os.path.join("profiles", tag, "bench_default.json")))
 nh_path = os.path.join("profiles", tag, "bench_no_plan_hints.json")
@@ -18,18 +26,57 @@ def f(x, n=3):
     return "" if x is None else f"{x:.{n}g}" if isinstance(x, float) else str(x)
 
 
-rows = [("headline", {"ms": d["ms_per_step"], "frac": d["roofline"]["frac"], "cold_ms": d.get("cold_ms"), "parity": d.get("parity_checked", {})})]
+def rocprof_ms(name):
+    """the step's data kernels in the rocprofv3 stats of the config's own run: sum of average duration x launches per step (None: no file)"""
+    path = os.path.join("profiles", tag, f"rocprofv3_kernel_stats_{name}.csv")
+    if name not in CONFIGS or not os.path.exists(path):
+        return None
+    tot, hit = 0.0, False
+    stats = list(csv.DictReader(open(path)))
+    for sub, per_step in CONFIGS[name][0].items():
+        match = [r for r in stats if sub in r["Name"]]
+        if not match:
+            continue
+        hit = True
+        calls = sum(int(r["Calls"]) for r in match)
+        tot += sum(float(r["TotalDurationNs"]) for r in match) / calls * per_step / 1e6
+    return tot if hit else None
+
+
+# what changed in a row's DEFINITION since the previous round (so that the "previous round" column is not read as a like-for-like A/B)
+NOTES = {
+    "agg_65536_groups": "kernel time now includes the range tier's tail (agg_range_emit); r04's dense tail was not counted",
+    "agg_1048576_groups": "kernel time now includes the range tier's tail (agg_range_emit); r04's dense tail was not counted",
+    "agg_4096_groups": "kernel time now includes agg_fold_partials",
+    "agg_three_value_columns": "kernel time now includes agg_fold_partials",
+    "agg_readme_shape": "kernel time now includes agg_fold_partials",
+    "c2": "parity now over all 10^8 rows (r04: 2 x 10^7)",
+    "c2_random_ids": "parity now over all 10^8 rows (r04: 2 x 10^7)",
+    "c2_expression_trees": "parity now over all 10^8 rows (r04: 2 x 10^7)",
+    "c4": "parity now over all 10^8 probe rows (r04: 5 x 10^6)",
+    "headline": "parity now over all 10^9 rows, every group (r04: the first 1.5 x 10^8)",
+}
+rows = [("headline", {"ms": d["ms_per_step"], "kernel_ms": d["roofline"].get("kernel_ms_per_step"), "kernel_ms_min": d["roofline"].get("kernel_ms_min"),
+                      "kernel_ms_max": d["roofline"].get("kernel_ms_max"), "frac": d["roofline"]["frac"], "cold_ms": d.get("cold_ms"), "parity": d.get("parity_checked", {})})]
 rows += list(d.get("configs", {}).items())
-print("| config | ms / step | frac of 8 TB/s (8d bytes) | frac physical | PMC traffic / algorithmic | first execution ms | no plan hints ms | parity | previous round ms |")
-print("|---|---|---|---|---|---|---|---|---|")
+print("| config | ms / step | kernel ms (HIP events) [min .. max over blocks] | kernel ms (rocprofv3 avg) | differ | frac of 8 TB/s (8d bytes) | frac physical | PMC traffic / algorithmic | first execution ms | no plan hints ms | parity (rows) | previous round ms | definition changes |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for name, c in rows:
     if "raw_ms" in c:
         continue
     tr = (summ.get(name) or {}).get("traffic_ratio")
     nhc = nh.get("ms_per_step") if name == "headline" else (nh.get("configs", {}).get(name) or {}).get("ms")
     pvc = pv.get("ms_per_step") if name == "headline" else (pv.get("configs", {}).get(name) or {}).get("ms")
-    ok = (c.get("parity") or {}).get("ok")
-    print(f"| `{name}` | {f(c.get('ms'), 4)} | {f(c.get('frac'))} | {f(c.get('frac_physical'))} | {f(tr, 4)} | {f(c.get('cold_ms'), 4)} | {f(nhc, 4)} | {'ok' if ok else ok} | {f(pvc, 4)} |")
+    par = c.get("parity") or {}
+    ok = par.get("ok")
+    km, rp = c.get("kernel_ms"), rocprof_ms(name)
+    spread = f" [{f(c.get('kernel_ms_min'), 4)} .. {f(c.get('kernel_ms_max'), 4)}]" if c.get("kernel_ms_min") is not None else ""
+    diff = ""
+    if km and rp:
+        pct = (rp - km) / km * 100.0
+        diff = f"{pct:+.1f} %" + (" **(> 3 %)**" if abs(pct) > 3.0 else "")
+    print(f"| `{name}` | {f(c.get('ms'), 4)} | {f(km, 4)}{spread} | {f(rp, 4)} | {diff} | {f(c.get('frac'))} | {f(c.get('frac_physical'))} | {f(tr, 4)} | {f(c.get('cold_ms'), 4)} | {f(nhc, 4)} | "
+          f"{'ok' if ok else ok} ({par.get('rows', '')}) | {f(pvc, 4)} | {NOTES.get(name, '')} |")
 print()
 print("| drop-in row | ms / step | raw C-ABI ms | ratio | equal to the raw call |")
 print("|---|---|---|---|---|")

@@ -11,39 +11,14 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src, dst = os.path.join("gpurun_out", tag), os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
 rev = open(os.path.join(src, "csrc_rev.txt")).read().strip() if os.path.exists(os.path.join(src, "csrc_rev.txt")) else None
 
-# the kernels that make up one step of each config (substring of the rocprofv3 kernel name → launches per step), and the step's
-# algorithmic bytes
-CONFIGS = {
-    "headline": ({"agg_grouped_fast_kernel": 1}, 16e9),
-    "headline_random_keys": ({"agg_grouped_fast_kernel": 1}, 16e9),
-    "c2": ({"keep_from_range_strided_kernel": 1, "compact_strided_kernel": 1}, 2.0e9),
-    "c4": ({"join_sample_range_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
-    "c4_sparse_keys": ({"probe_packed_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
-    "agg_65536_groups": ({"agg_slab_scatter_kernel": 1, "agg_slab_segments": 1}, 1.6e9),
-    "headline_single_column": ({"agg_grouped_fast_kernel": 1}, 8e9),
-    "headline_int64_values": ({"agg_grouped_fast_kernel": 1}, 16e9),
-    "agg_tree_predicate": ({"nqe_jit_agg": 1, "agg_merge_partials_kernel": 1}, 16e9),
-    "agg_three_value_columns": ({"agg_grouped_fast_kernel": 1}, 24e9),
-    "agg_4096_groups": ({"agg_grouped_fast_kernel": 1}, 1.6e9),
-    "c2_random_ids": ({"keep_from_range_strided_kernel": 1, "compact_strided_kernel": 1}, 2.0e9),
-    "c2_expression_trees": ({"nqe_jit_selproj": 1}, 2.4e9),
-    "agg_readme_shape": ({"agg_grouped_fast_kernel": 1}, 24e9),
-    "headline_nullable": ({"agg_grouped_fast_kernel": 1}, 16.125e9),
-    "agg_1048576_groups": ({"agg_slab_scatter_kernel": 1, "agg_slab_segments": 1}, 1.6e9),
-    # borrowed probe table: every output column written (one optimistic pass); immutable probe table: its columns are shared
-    "c4_shared_probe_columns": ({"join_sample_range_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
-    "c4_wide_payload": ({"join_sample_range_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
-    "c4_dim_1e7": ({"join_sample_range_kernel": 1, "join_fused_write_kernel": 1}, 4.96e9),
-    "c4_dup_keys": ({"probe_count_kernel": 1, "probe_write_kernel": 1}, 4.816e9),
-    "c4_partial_match": ({"probe_presence_kernel": 1, "join_fused_write_kernel": 1}, 4.496e9),
-    # 10^8-row build side: the probe kernels per step as for c4 (the kernel stats of this config also hold the partitioned build's kernels)
-    "c4_dim_1e8": ({"join_sample_range_kernel": 1, "join_fused_write_kernel": 1}, 6.4e9),
-}
+from profile_configs import CONFIGS  # noqa: E402  (tools/profile_configs.py)
 
 
 def counter_means(path, counter):
