@@ -413,6 +413,10 @@ def attach_traffic(roof, config_name):
         roof["traffic"] = rec["hbm_bytes_per_step_corrected"]
         roof["traffic_ratio"] = rec["hbm_bytes_per_step_corrected"] / roof["algorithmic_bytes_per_step"] if roof["algorithmic_bytes_per_step"] else None
         roof["traffic_quoted_from"] = f"{os.path.relpath(path, ROOT)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this csrc revision, calibrated)"
+        # what the counters count (MI355X_MICROARCH.md, HBM): the L2s' memory-side requests — Infinity-Cache hits included.  For a streamed
+        # column that IS HBM traffic; for a join table of 25-80 MB gathered at random (c4_dim_1e7, c4_sparse_keys, c4_wide_payload) it is
+        # 128-byte line traffic on the fabric, much of it served by the 256 MB Infinity Cache
+        roof["traffic_counts"] = "L2 memory-side (fabric) requests; Infinity-Cache hits are included"
     except Exception as e:  # noqa: BLE001 - a missing/odd profile file must not fail the bench
         roof["traffic_quoted_from"] = f"unreadable {path}: {e}"
 

@@ -2205,7 +2205,8 @@ void AggRun::range_tail(const AggArgs &sa, const SlabArgs &sl, uint32_t rslots) 
     ranged.keys->ctx = ctx;
     ranged.keys->rows = room;
     ranged.keys->cols.push_back(make_word_column(ctx, kinfo.out_dtype, room, false));
-    const int items = part_span >= (uint64_t(1) << 19) ? 4 : 1; // keys per thread of the tail: 4096-key blocks for wide ranges, 1024-key blocks to keep narrow ones parallel
+    // keys per thread of the tail: 4096-key blocks for wide ranges, 1024-key blocks to keep narrow ones parallel (NQE_RANGE_EMIT_ITEMS: 1 / 4 for A/B)
+    const int items = sw.range_emit_items ? sw.range_emit_items : (part_span >= (uint64_t(1) << 19) ? 4 : 1);
     const uint32_t kb = uint32_t(RE_BLOCK * items), sb = std::max<uint32_t>(1u, kb >> sl.parts_log2), nblocks = (rslots + sb - 1) / sb;
     range_status = dev_alloc(ctx, (size_t(nblocks) + 2) * 8);
     const BufRef &status = range_status;

@@ -426,11 +426,8 @@ template <int PRED, int KEY, int NVT> struct SlabShape {
 // tuples of one partition into THIS workgroup's slab of it.  The next tile's words are requested before the copy-out, so the
 // loads overlap the LDS phases and the stores (one workgroup per CU fits — 136 KB of LDS — and the unpipelined form spent
 // 22 µs per 8192-row tile where the CU's share of HBM needs 13).
-// K32 (one value column): the tuple written to the slab is {int32 key, value} = 12 bytes — passes 2 and 3 of the partitioned
-// aggregate move 12 instead of 16 bytes per row (40 B/row in all instead of 48).  Optimistic: a key outside int32 raises
-// NQE_FLAG_KEY32_OVERFLOW and the host redoes the query with 16-byte tuples (and remembers).
-// (key-range partitions: range_partition / range_scramble in aggregate_common.hpp)
-
+// (Tuples of 16 or 24 bytes — a 64-bit key, or two value columns.  One value column under a key that fits 32 bits takes the two-stream
+// whole-block form: agg_slab_scatter_soa_kernel below.)
 #ifdef NQE_SLAB_PROFILE
 // diagnostic build (tools/probe_slab_phases.py): shader-clock time of thread 0 of every scatter workgroup per phase of a tile
 __device__ unsigned long long nqe_slab_prof[8];
@@ -445,13 +442,7 @@ __device__ unsigned long long nqe_slab_prof[8];
 #else
 #define SLAB_STAMP(i) do { } while (0)
 #endif
-// (value first: a dwordx3 load lands in an even-aligned register triple, and gfx950's 64-bit operands want an even pair — with the key
-// first every loaded value was copied to another pair right behind its load, i.e. the wave waited for the loads it had just issued)
-struct __attribute__((packed, aligned(4))) Tuple12 {
-    uint64_t val;
-    int32_t key;
-};
-template <int PRED, int KEY, int NVT, bool K32 = false>
+template <int PRED, int KEY, int NVT>
 __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, FastPred fp, SlabArgs sa, int *flags) {
     constexpr int RPT = SlabShape<PRED, KEY, NVT>::RPT;
     constexpr int SC_ROWS = AGG_BLOCK * RPT;
@@ -463,7 +454,6 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
     uint32_t *tstart = tcnt + PARTS;                                        // [PARTS] tile-local exclusive scan
     __shared__ uint32_t wave_tot[AGG_BLOCK / 64];
     const int parts_log2 = sa.parts_log2, parts = 1 << parts_log2; // <= PARTS (the LDS counters are sized for PARTS)
-    const bool range_part = K32 && sa.range_span != 0;
     for (int p = threadIdx.x; p < PARTS; p += blockDim.x) {
         gcur[p] = 0;
         tcnt[p] = 0;
@@ -511,15 +501,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
             else if (PRED == 2) ok = ok && range_pass(fp, pred_extract(fp, r.pw[PRED >= 2 ? u : 0], row < last ? row : last));
             else if (PRED == 1) ok = ok && range_pass(fp, r.kw[u]);
             key[u] = inline_key<KEY>(a.key, r.kw[u], key_mask, key_aux, key_signed);
-            if (K32 && range_part) { // (wave-uniform choice) aggregate_common.hpp: SlabArgs::range_span; a key outside the range: the host redoes the query hashed
-                const uint64_t d = key[u] - uint64_t(sa.range_min);
-                if (ok && d >= sa.range_span) {
-                    atomicOr(&flags[NQE_FLAG_OOB], 1);
-                    ok = false;
-                }
-                part[u] = range_partition(d, parts_log2);
-            } else
-                part[u] = uint32_t((key[u] * GOLD) >> (64 - parts_log2));
+            part[u] = uint32_t((key[u] * GOLD) >> (64 - parts_log2));
             pass[u] = ok;
         }
 #pragma unroll
@@ -566,24 +548,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
                 v0 = stup[size_t(i) * TW + 1];
                 if (NVT > 1) v1 = stup[size_t(i) * TW + 2];
             }
-            uint32_t p;
-            if (K32 && range_part) {
-                p = range_partition(k - uint64_t(sa.range_min), parts_log2);
-            } else
-                p = uint32_t((k * GOLD) >> (64 - parts_log2));
+            const uint32_t p = uint32_t((k * GOLD) >> (64 - parts_log2));
             const uint32_t at = gcur[p] + (i - tstart[p]);
             if (at < cap) {
                 uint64_t *dst = sa.slabs + ((size_t(blockIdx.x) * size_t(parts) + p) * size_t(cap) + at) * TW;
-                if (K32) {
-                    // key-range partitions store d = key - range_min (< span <= PARTS << 12: always 32 bits, whatever the keys' magnitude);
-                    // hashed partitions the key itself, and a key outside int32 asks for the 16-byte tuple form
-                    const uint64_t kw = range_part ? k - uint64_t(sa.range_min) : k;
-                    if (!range_part && int64_t(int32_t(uint32_t(k))) != int64_t(k)) atomicOr(&flags[NQE_FLAG_KEY32_OVERFLOW], 1);
-                    Tuple12 t;
-                    t.key = int32_t(uint32_t(kw));
-                    t.val = v0;
-                    reinterpret_cast<Tuple12 *>(sa.slabs)[(size_t(blockIdx.x) * size_t(parts) + p) * size_t(cap) + at] = t;
-                } else if (TW == 2) {
+                if (TW == 2) {
                     *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(k, v0);
                 } else {
                     dst[0] = k;

@@ -2676,3 +2676,41 @@ def test_aggregate_at_most_four_groups_in_registers(ctx, m, shape):
         kk = gk.to_host()[0].to_numpy()
         assert (np.sort(kk.astype(np.int64)) == np.unique(np.fmod(ids, m) if shape != "uint64_key" else (ids.astype(np.uint64) % np.uint64(m)).astype(np.int64))[
             np.isin(np.unique(np.fmod(ids, m) if shape != "uint64_key" else (ids.astype(np.uint64) % np.uint64(m)).astype(np.int64)), kk.astype(np.int64))]).all()
+
+
+@pytest.mark.parametrize("shape", ["range_1_5M_of_2M", "hashed_sparse_1M", "pred_on_other_column", "mod_key_70001"])
+def test_aggregate_block_scatter_forms(ctx, shape):
+    """the two-stream slabs written in whole 16-tuple blocks (round 5, agg_slab_scatter_soa_kernel): a key range beyond 2^20 values (512
+    partitions, blocks of 8 tuples, the range tier with one workgroup per partition), hashed partitions of sparse keys that fit int32,
+    a predicate on a column other than the key (PRED 2), a `col % m` key whose range comes from the modulus — against the oracle, first
+    and remembered execution.  aggregate/mod.rs:113-222"""
+    rng = np.random.default_rng(4242 + len(shape))
+    n = 3_000_000 if shape != "mod_key_70001" else 900_000
+    pred = None
+    key = col(0)
+    if shape == "range_1_5M_of_2M":
+        k = rng.integers(0, 2_000_000, n).astype(np.int64) + 7_000_000_000       # beyond int32: the tuple holds key - min
+    elif shape == "hashed_sparse_1M":
+        k = (rng.integers(0, 1_000_000, n).astype(np.int64) * 2_001) - 1_000_000_000   # sparse over 2 x 10^9: no compact range, fits int32
+    elif shape == "pred_on_other_column":
+        k = rng.integers(0, 300_000, n).astype(np.int64)
+        pred = binop(col(1), Operator.Gt, lit_f64(2.5))
+    else:
+        k = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)
+        key = binop(col(0), Operator.Modulos, lit_i64(70_001))
+    v = rng.random(n) * 10 - 2
+    cols = [Column.from_numpy(k), Column.from_numpy(v)]
+    f2 = fields("k", "v")
+    kn = key.flatten(f2)
+    pn = pred.flatten(f2) if pred is not None else None
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=kn, pred_nodes=pn)[0]
+    t = ctx.table_from_host(cols)
+    for rep in range(3):
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got, gk = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn, pred_nodes=pn, with_keys=True)
+        ctx.timing_enable(False)
+        assert ctx.timing_query("agg_partition_scatter")[1] > 0, f"{shape} rep {rep}: the partitioned path was expected"
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{shape} rep {rep}")
+        kk = gk.to_host()[0].to_numpy()
+        assert (np.diff(kk) > 0).all(), f"{shape}: keys not in order"

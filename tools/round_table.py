@@ -19,6 +19,8 @@ d = json.load(open(os.path.join("profiles", tag, "bench_default.json")))
 nh_path = os.path.join("profiles", tag, "bench_no_plan_hints.json")
 nh = json.load(open(nh_path)) if os.path.exists(nh_path) else {}
 summ = json.load(open(os.path.join("profiles", tag, "summary.json")))
+det_path = os.path.join("profiles", tag, "bench_details.json")
+det = json.load(open(det_path)).get("configs", {}) if os.path.exists(det_path) else {}  # what the line sheds to stay under its size limit (cold_ms, …) is here
 pv = json.load(open(os.path.join("profiles", prev, "bench_default.json"))) if prev and os.path.exists(os.path.join("profiles", prev, "bench_default.json")) else {}
 
 
@@ -75,7 +77,7 @@ for name, c in rows:
     if km and rp:
         pct = (rp - km) / km * 100.0
         diff = f"{pct:+.1f} %" + (" **(> 3 %)**" if abs(pct) > 3.0 else "")
-    print(f"| `{name}` | {f(c.get('ms'), 4)} | {f(km, 4)}{spread} | {f(rp, 4)} | {diff} | {f(c.get('frac'))} | {f(c.get('frac_physical'))} | {f(tr, 4)} | {f(c.get('cold_ms'), 4)} | {f(nhc, 4)} | "
+    print(f"| `{name}` | {f(c.get('ms'), 4)} | {f(km, 4)}{spread} | {f(rp, 4)} | {diff} | {f(c.get('frac'))} | {f(c.get('frac_physical'))} | {f(tr, 4)} | {f(c.get('cold_ms') if c.get('cold_ms') is not None else (det.get(name) or {}).get('cold_ms'), 4)} | {f(nhc, 4)} | "
           f"{'ok' if ok else ok} ({par.get('rows', '')}) | {f(pvc, 4)} | {NOTES.get(name, '')} |")
 print()
 print("| drop-in row | ms / step | raw C-ABI ms | ratio | equal to the raw call |")
