@@ -2104,8 +2104,10 @@ PassStatus AggRun::tier_slab() {
     const bool range_part = a.nv == 1 && dense && range_part_ok && part_span != 0 && part_span <= (uint64_t(PARTS) << 12);
     const bool k32 = a.nv == 1 && (!key32_failed || range_part);
     const int rpt = k32 ? slab_scatter_soa_rows_per_thread() : slab_scatter_rows_per_thread(fp, fast_key, a.nv);
-    const int64_t tile_rows = int64_t(AGG_BLOCK) * rpt;
-    int W = int(std::min<int64_t>(int64_t(ctx->num_cus) * slab_scatter_wg_per_cu(), (in->rows + tile_rows - 1) / tile_rows));
+    // the two-stream form runs 512-thread workgroups, two per CU (NQE_SOA_THREADS=1024: one of 1024): their barrier phases overlap
+    const int sc_threads = k32 ? sw.soa_threads : AGG_BLOCK, sc_per_cu = k32 ? (sw.soa_threads == 512 ? 2 : 1) : slab_scatter_wg_per_cu();
+    const int64_t tile_rows = int64_t(sc_threads) * rpt;
+    int W = int(std::min<int64_t>(int64_t(ctx->num_cus) * sc_per_cu, (in->rows + tile_rows - 1) / tile_rows));
     int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
     W = int((in->rows + chunk - 1) / chunk);
     int sparts_log2 = slab_parts_log2;
@@ -2158,8 +2160,9 @@ PassStatus AggRun::tier_slab() {
     sl.range_min = part_min;
     sl.range_span = range_part ? part_span : 0;
     // (K32: the SoA scatter — stage and carry buffers of 12 bytes per tuple, five counters per partition, the block owner map)
-    const size_t sc_shmem = k32 ? (size_t(tile_rows) + size_t(PARTS) * 8) * 12 + size_t(PARTS) * 20 + (size_t(tile_rows) / 8 + PARTS) * 2 + 16 : size_t(tile_rows) * 8 * tw + size_t(PARTS) * 12;
-    launch(ctx, "agg_partition_scatter", pick_slab_scatter_kernel(fp, fast_key, a.nv, k32), dim3(W), dim3(AGG_BLOCK), sc_shmem, ka, fpred, sl,
+    const size_t sc_carry = size_t(sparts) << (sparts_log2 <= 8 ? 4 : 3);
+    const size_t sc_shmem = k32 ? (size_t(tile_rows) + sc_carry) * 12 + size_t(sparts) * 20 + (size_t(tile_rows) / 8 + size_t(sparts)) * 2 + 16 : size_t(tile_rows) * 8 * tw + size_t(PARTS) * 12;
+    launch(ctx, "agg_partition_scatter", pick_slab_scatter_kernel(fp, fast_key, a.nv, k32, sc_threads), dim3(W), dim3(sc_threads), sc_shmem, ka, fpred, sl,
            ctx->d_flags);
     AggArgs sa = ka;
     size_t sshmem = shmem;

@@ -529,7 +529,7 @@ using SegmentsKernel = void (*)(AggArgs, const uint64_t *, int64_t, int, int, in
 SegmentsKernel pick_segments_kernel(int nv, bool vf64);
 using SlabScatterKernel = void (*)(AggArgs, FastPred, SlabArgs, int *);
 // k32 (one value column): 12-byte tuples {int32 key, value} — the scatter raises NQE_FLAG_KEY32_OVERFLOW on a key outside int32
-SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv, bool k32 = false);
+SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv, bool k32 = false, int soa_threads = 1024); // soa_threads: workgroup size of the K32 (two-stream) form
 int slab_scatter_rows_per_thread(int pred, int key, int nv);
 int slab_scatter_soa_rows_per_thread(); // the K32 (SoA, whole-block) scatter
 int slab_scatter_wg_per_cu();

@@ -606,27 +606,29 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_kernel(AggArgs a, 
 #ifndef NQE_SOA_RPT
 #define NQE_SOA_RPT 4 // rows per thread per tile of the SoA scatter (every store is a whole block: the tile size no longer decides the store shape)
 #endif
-template <int PRED, int KEY>
-__global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_soa_kernel(AggArgs a, FastPred fp, SlabArgs sa, int *flags) {
+// THREADS: 512 (two workgroups per CU: their barrier phases overlap, as the staged compaction's do) or 1024.  The LDS layout follows the
+// partition count of the run: stage [THREADS x RPT], carry [parts x block], five counters per partition, the block owner map.
+template <int PRED, int KEY, int THREADS>
+__global__ void __launch_bounds__(THREADS) agg_slab_scatter_soa_kernel(AggArgs a, FastPred fp, SlabArgs sa, int *flags) {
     constexpr int RPT = NQE_SOA_RPT;
-    constexpr int SC_ROWS = AGG_BLOCK * RPT;
-    constexpr int CARRY = PARTS * 8; // carry slots: parts x block (256 x 16 or 512 x 8)
+    constexpr int SC_ROWS = THREADS * RPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *sval = reinterpret_cast<uint64_t *>(smem);      // [SC_ROWS] the tile's values by partition
-    uint64_t *cval = sval + SC_ROWS;                          // [CARRY]
-    uint32_t *skey = reinterpret_cast<uint32_t *>(cval + CARRY); // [SC_ROWS]
-    uint32_t *ckey = skey + SC_ROWS;                          // [CARRY]
-    uint32_t *gblk = ckey + CARRY;                            // [PARTS] blocks this workgroup has written per partition
-    uint32_t *ccnt = gblk + PARTS;                            // [PARTS] tuples in the carry buffer
-    uint32_t *tcnt = ccnt + PARTS;                            // [PARTS] tuples of this tile
-    uint32_t *tstart = tcnt + PARTS;                          // [PARTS] tile-local exclusive scan of tcnt
-    uint32_t *bstart = tstart + PARTS;                        // [PARTS] exclusive scan of the blocks this tile completes
-    uint16_t *bown = reinterpret_cast<uint16_t *>(bstart + PARTS); // [SC_ROWS / 8 + PARTS] partition of each such block
-    __shared__ uint32_t wave_tot[2][AGG_BLOCK / 64];
     const int parts_log2 = sa.parts_log2, parts = 1 << parts_log2;
     const int blk_log2 = parts_log2 <= 8 ? 4 : 3, blk = 1 << blk_log2;
+    const int carry = parts << blk_log2;
+    uint64_t *sval = reinterpret_cast<uint64_t *>(smem);      // [SC_ROWS] the tile's values by partition
+    uint64_t *cval = sval + SC_ROWS;                          // [carry]
+    uint32_t *skey = reinterpret_cast<uint32_t *>(cval + carry); // [SC_ROWS]
+    uint32_t *ckey = skey + SC_ROWS;                          // [carry]
+    uint32_t *gblk = ckey + carry;                            // [parts] blocks this workgroup has written per partition
+    uint32_t *ccnt = gblk + parts;                            // [parts] tuples in the carry buffer
+    uint32_t *tcnt = ccnt + parts;                            // [parts] tuples of this tile
+    uint32_t *tstart = tcnt + parts;                          // [parts] tile-local exclusive scan of tcnt
+    uint32_t *bstart = tstart + parts;                        // [parts] exclusive scan of the blocks this tile completes
+    uint16_t *bown = reinterpret_cast<uint16_t *>(bstart + parts); // [SC_ROWS / 8 + parts] partition of each such block
+    __shared__ uint32_t wave_tot[2][THREADS / 64];
     const bool range_part = sa.range_span != 0;
-    for (int p = threadIdx.x; p < PARTS; p += blockDim.x) gblk[p] = ccnt[p] = tcnt[p] = 0;
+    for (int p = threadIdx.x; p < parts; p += blockDim.x) gblk[p] = ccnt[p] = tcnt[p] = 0;
     __syncthreads();
     const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
     const uint64_t *__restrict__ predp = static_cast<const uint64_t *>(PRED >= 2 ? a.pred_src.values : a.key_src.values);
@@ -647,7 +649,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_soa_kernel(AggArgs
     auto load = [&](Regs &r, int64_t base) {
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
-            int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            int64_t row = base + int64_t(u) * THREADS + threadIdx.x;
             row = row < last ? row : last; // clamp: unconditional, in-bounds
             r.kw[u] = __builtin_nontemporal_load(&keyp[row]);
             if (PRED == 2) r.pw[PRED >= 2 ? u : 0] = __builtin_nontemporal_load(&predp[row >> fp.row_shift]);
@@ -667,7 +669,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_soa_kernel(AggArgs
         bool pass[RPT];
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
-            const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            const int64_t row = base + int64_t(u) * THREADS + threadIdx.x;
             bool ok = row < hi;
             if (PRED == 3) ok = ok && eval_simple<false>(a.pred, r.pw[PRED >= 2 ? u : 0], false, nullptr) != 0; // host-vetted chain: cannot fault
             else if (PRED == 2) ok = ok && range_pass(fp, pred_extract(fp, r.pw[PRED >= 2 ? u : 0], row < last ? row : last));
@@ -707,7 +709,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_slab_scatter_soa_kernel(AggArgs
         uint32_t nblocks = 0;
         {
             uint32_t pre0 = 0, pre1 = 0;
-            for (int w = 0; w < PARTS / 64; ++w) {
+            for (int w = 0; w < THREADS / 64; ++w) {
                 if (w < int(threadIdx.x) / 64) {
                     pre0 += wave_tot[0][w];
                     pre1 += wave_tot[1][w];
@@ -1283,16 +1285,17 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_range_segments_kernel(AggArgs a
     }
 }
 
-template <int PRED, int KEY> SlabScatterKernel pick_slab_scatter_nv(int nv, bool k32) {
-    if (nv == 1) return k32 ? agg_slab_scatter_soa_kernel<PRED, KEY> : agg_slab_scatter_kernel<PRED, KEY, 1>;
+template <int PRED, int KEY> SlabScatterKernel pick_slab_scatter_nv(int nv, bool k32, int soa_threads) {
+    if (nv == 1 && k32) return soa_threads == 512 ? agg_slab_scatter_soa_kernel<PRED, KEY, 512> : agg_slab_scatter_soa_kernel<PRED, KEY, 1024>;
+    if (nv == 1) return agg_slab_scatter_kernel<PRED, KEY, 1>;
     return agg_slab_scatter_kernel<PRED, KEY, 2>;
 }
-template <int PRED> SlabScatterKernel pick_slab_scatter_key(int key, int nv, bool k32) {
+template <int PRED> SlabScatterKernel pick_slab_scatter_key(int key, int nv, bool k32, int soa_threads) {
     switch (key) {
-    case 0: return pick_slab_scatter_nv<PRED, 0>(nv, k32);
-    case 1: return pick_slab_scatter_nv<PRED, 1>(nv, k32);
-    case 2: return pick_slab_scatter_nv<PRED, 2>(nv, k32);
-    default: return pick_slab_scatter_nv<PRED, 3>(nv, k32);
+    case 0: return pick_slab_scatter_nv<PRED, 0>(nv, k32, soa_threads);
+    case 1: return pick_slab_scatter_nv<PRED, 1>(nv, k32, soa_threads);
+    case 2: return pick_slab_scatter_nv<PRED, 2>(nv, k32, soa_threads);
+    default: return pick_slab_scatter_nv<PRED, 3>(nv, k32, soa_threads);
     }
 }
 
@@ -1340,12 +1343,12 @@ PartKernel pick_part_kernel(int pred, int key, int nv, bool scatter) {
     default: return pick_part_key<3>(key, nv, scatter);
     }
 }
-SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv, bool k32) {
+SlabScatterKernel pick_slab_scatter_kernel(int pred, int key, int nv, bool k32, int soa_threads) {
     switch (pred) {
-    case 0: return pick_slab_scatter_key<0>(key, nv, k32);
-    case 1: return pick_slab_scatter_key<1>(key, nv, k32);
-    case 2: return pick_slab_scatter_key<2>(key, nv, k32);
-    default: return pick_slab_scatter_key<3>(key, nv, k32);
+    case 0: return pick_slab_scatter_key<0>(key, nv, k32, soa_threads);
+    case 1: return pick_slab_scatter_key<1>(key, nv, k32, soa_threads);
+    case 2: return pick_slab_scatter_key<2>(key, nv, k32, soa_threads);
+    default: return pick_slab_scatter_key<3>(key, nv, k32, soa_threads);
     }
 }
 int slab_scatter_soa_rows_per_thread() { return NQE_SOA_RPT; }
