@@ -160,11 +160,25 @@ __global__ void __launch_bounds__(256) minmax_cols_kernel(MinMaxCols mc, int64_t
     const uint64_t flip = mc.flip[c];
     uint64_t mn = ~0ull, mx = 0;
     uint32_t desc = 0;
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        const uint64_t x = v[i] ^ flip;
-        mn = x < mn ? x : mn;
-        mx = x > mx ? x : mx;
-        if (c == 0 && descents && i > 0 && (v[i - 1] ^ flip) > x) ++desc; // (the neighbour's word is in the line just read)
+    // four independent loads in flight per thread (one at a time read 1.6 GB of a 10^8-row build side at 3.2 TB/s: 0.50 ms of the build)
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x, last = n - 1;
+    const bool want_desc = c == 0 && descents != nullptr;
+    for (int64_t i0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint64_t x[4], p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride, ic = i < last ? i : last;
+            x[u] = v[ic] ^ flip;
+            p[u] = want_desc ? (v[ic > 0 ? ic - 1 : 0] ^ flip) : 0; // (the neighbour's word is in the line just read)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n) break;
+            mn = x[u] < mn ? x[u] : mn;
+            mx = x[u] > mx ? x[u] : mx;
+            if (want_desc && i > 0 && p[u] > x[u]) ++desc;
+        }
     }
     if (c == 0 && descents) {
         const uint64_t m = __ballot(desc != 0);
@@ -309,7 +323,17 @@ __global__ void __launch_bounds__(PB_BLOCK) part_build_count_kernel(PartBuild pb
     __syncthreads();
     const int64_t lo = int64_t(blockIdx.x) * pb.chunk;
     const int64_t hi = lo + pb.chunk < pb.n ? lo + pb.chunk : pb.n;
-    for (int64_t r = lo + threadIdx.x; r < hi; r += blockDim.x) atomicAdd(&hist[uint32_t((pb.keys[r] - pb.dmin) >> pb.shift)], 1u);
+    for (int64_t r0 = lo + threadIdx.x; r0 < hi; r0 += 4 * int64_t(blockDim.x)) { // (four loads in flight per thread)
+        uint64_t k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = r0 + u * int64_t(blockDim.x);
+            k[u] = __builtin_nontemporal_load(&pb.keys[r < hi ? r : hi - 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r0 + u * int64_t(blockDim.x) < hi) atomicAdd(&hist[uint32_t((k[u] - pb.dmin) >> pb.shift)], 1u);
+    }
     __syncthreads();
     for (int p = threadIdx.x; p < pb.parts; p += blockDim.x) counts[size_t(p) * size_t(pb.W) + blockIdx.x] = hist[p];
 }
