@@ -10,7 +10,6 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python tools/csrc_rev.py > $OUT/csrc_rev.txt
-python bench.py --details $OUT/bench_details.json 2>&1 | tail -1 > $OUT/bench_default.json
 LIGHT=${NQE_PROFILE_LIGHT:-}
 if [ -z "$LIGHT" ]; then
 # the same line with nothing remembered between executions (every execution plans from scratch; the key sample still runs)
@@ -38,6 +37,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_calib -o calib -- $R/tools/stream_bench calib > $OUT/pmc_write_calib.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_gather -o gather -- $R/tools/micro_bench gather1 > $OUT/pmc_fetch_gather.log 2>&1
 cd $R
+# the default line LAST among the measurements it quotes: summarised here, on the box, the PMC passes above are what its `roofline.traffic` is
+# quoted from (bench.py only quotes a file made from the csrc revision that is running)
+python tools/summarize_profiles.py $TAG > /dev/null 2>&1
+python bench.py --details $OUT/bench_details.json 2>&1 | tail -1 > $OUT/bench_default.json
 if [ -n "$LIGHT" ]; then ls $OUT; exit 0; fi
 python tools/probe_paths.py groups 2>&1 | grep -v amdgpu.ids > $OUT/probe_groups.txt
 python tools/probe_paths.py joinshapes 2>&1 | grep -v amdgpu.ids > $OUT/probe_joinshapes.txt

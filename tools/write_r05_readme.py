@@ -14,6 +14,7 @@ file by `tools/write_r05_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | File | What |
 |---|---|
 | `bench_default.json`, `bench_details.json` | the default `python bench.py` line (24 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity), per-kernel details |
+| `bench_default_box2.json`, `bench_details_box2.json` | the same default line run once more on ANOTHER box after the PMC passes were summarised — the one whose `roofline.traffic` is quoted from `pmc_traffic_headline.json` (16.03 GB, 1.002 x; the first line was produced before those files existed for this csrc revision). Headline kernel 2.405 ms (0.831) on the first box, 2.55 ms (0.784) on the second, 2.421 (0.826) in an earlier run of this round: the boxes of the pool differ by up to 6 % on this kernel |
 | `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
 | `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
 | `rocprofv3_kernel_stats_<config>.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --workload … --steps 20 --warmup 3` (its own process: the table below compares its averages with the bench line's HIP-event times) |
