@@ -1454,6 +1454,7 @@ AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const n
     return r;
 }
 
+constexpr uint64_t RANGE_TIER_MAX_SLOTS = 5120;             // slots of one LDS table of the range tier (28 bytes each)
 constexpr uint64_t TINY_SALT = 0xC2B2AE3D27D4EB4Full;       // nqe_ctx::agg_key_ranges[hint ^ salt] present: the tiny-groups kernel met a key outside [0, m)
 constexpr uint64_t PART_RANGE_SALT = 0x9E3779B97F4A7C15ull; // nqe_ctx::agg_key_ranges[hint ^ salt]: the key range of the query's groups (range partitions)
 
@@ -2111,10 +2112,13 @@ PassStatus AggRun::tier_slab() {
     int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
     W = int((in->rows + chunk - 1) / chunk);
     int sparts_log2 = slab_parts_log2;
-    if (range_part) sparts_log2 = part_span <= (uint64_t(256) << 12) ? 8 : PARTS_LOG2;
+    // (a table of the range tier may hold up to 5120 slots — 28 bytes each, 140 KB of LDS: a SAMPLED range of 2^20 keys is padded by 1/256
+    // and would otherwise need 512 partitions on the first execution: 1.58 instead of ~1.0 ms per 10^8 rows)
+    const bool tier_wanted = range_part && V == 1 && sw.range_tier;
+    if (range_part) sparts_log2 = part_span <= (uint64_t(256) * (tier_wanted ? RANGE_TIER_MAX_SLOTS : 4096)) ? 8 : PARTS_LOG2;
     // the range tier (aggregate_common.hpp: RangeRec): as many partitions as the RANGE needs at 2^range_slots_log2 slots per table (16 .. 256;
     // 512 beyond 2^20 values), several workgroups per partition in the second kernel, the transposing tail.  One value column (V == 1).
-    const bool range_tier = range_part && V == 1 && sw.range_tier;
+    const bool range_tier = tier_wanted;
     if (range_tier && sparts_log2 == 8) {
         int need = 4;
         while (need < 8 && (uint64_t(1) << (need + sw.range_slots_log2)) < part_span) ++need;
