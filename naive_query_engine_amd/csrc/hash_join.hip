@@ -180,13 +180,13 @@ __global__ void __launch_bounds__(256) minmax_cols_kernel(MinMaxCols mc, int64_t
             if (want_desc && i > 0 && p[u] > x[u]) ++desc;
         }
     }
-    if (c == 0 && descents) {
-        const uint64_t m = __ballot(desc != 0);
-        if (m) { // (rare for the shapes this is for)
+    // (one atomic per WORKGROUP: random keys make every wave count descents, and same-address device atomics retire one at a time —
+    // a pair per wave was ~0.1 ms of a 10^8-row build's min/max pass)
+    __shared__ uint32_t sdesc[4];
+    if (want_desc) {
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) desc += __shfl_down(desc, d, 64);
-            if (lane_id() == 0) atomicAdd(descents, (unsigned long long)desc);
-        }
+        for (int d = 32; d > 0; d >>= 1) desc += __shfl_down(desc, d, 64);
+        if (lane_id() == 0) sdesc[threadIdx.x / 64] = desc;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -203,6 +203,10 @@ __global__ void __launch_bounds__(256) minmax_cols_kernel(MinMaxCols mc, int64_t
         }
         atomicMin(&mins[c], (unsigned long long)mn);
         atomicMax(&maxs[c], (unsigned long long)mx);
+        if (want_desc) {
+            const uint32_t dsum = sdesc[0] + sdesc[1] + sdesc[2] + sdesc[3];
+            if (dsum) atomicAdd(descents, (unsigned long long)dsum);
+        }
     }
 }
 constexpr int UNIQUE_MAX_PROBE = 128;
@@ -1153,14 +1157,17 @@ __global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *p
             }
             if (threadIdx.x == 0) off[PW_TILE] = total;
             __syncthreads();
-            // ---- one lane per output row
-            for (uint32_t j0 = 0; j0 < total; j0 += JT_BLOCK * 4) {
+            // ---- one lane per output row.  The lanes are shifted by the output position's offset inside its 128-byte line, so that every
+            // wave's 64 consecutive words are four whole lines (round 5: a non-temporal store of a partial line is the costliest store there is)
+            const int32_t head = int32_t(out_base & 15);
+            for (int32_t j0 = -head; j0 < int32_t(total); j0 += JT_BLOCK * 4) {
                 uint32_t prow[4], brow[4], bpos[4];
                 bool live[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    uint32_t j = j0 + q * JT_BLOCK + threadIdx.x;
-                    live[q] = j < total;
+                    const int32_t js = j0 + q * JT_BLOCK + int32_t(threadIdx.x);
+                    const uint32_t j = uint32_t(js);
+                    live[q] = js >= 0 && js < int32_t(total);
                     uint32_t lo = 0, hi = PW_TILE; // largest lo with off[lo] <= j
                     uint32_t jj = live[q] ? j : 0;
 #pragma unroll
@@ -1187,7 +1194,7 @@ __global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *p
                         for (int q = 0; q < 4; ++q) v[q] = sw[left ? int64_t(by_pos ? bpos[q] : brow[q]) : (live[q] ? row0 + prow[q] : int64_t(0))]; // (dead lanes read row 0)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (live[q]) __builtin_nontemporal_store(v[q], &dw[out_base + j0 + q * JT_BLOCK + threadIdx.x]);
+                            if (live[q]) __builtin_nontemporal_store(v[q], &dw[out_base + uint64_t(int64_t(j0) + q * JT_BLOCK + int64_t(threadIdx.x))]);
                         continue;
                     }
                     const uint8_t *sv = jc.src_valid[c];
@@ -1198,7 +1205,7 @@ __global__ void __launch_bounds__(JT_BLOCK) probe_write_kernel(const uint64_t *p
                         int64_t srow = left ? int64_t(jc.by_pos[c] ? bpos[q] : brow[q]) : row0 + prow[q];
                         bool ok = sv ? get_bit(sv, srow) : true;
                         uint64_t v = load_word(src, dt, srow);
-                        uint64_t pos = out_base + j0 + q * JT_BLOCK + threadIdx.x;
+                        uint64_t pos = out_base + uint64_t(int64_t(j0) + q * JT_BLOCK + int64_t(threadIdx.x));
                         if (jc.dst_words[c]) jc.dst_words[c][pos] = ok ? v : 0;
                         if (jc.dst_bool_bytes[c]) jc.dst_bool_bytes[c][pos] = (ok && v) ? 1 : 0;
                         if (jc.dst_valid_bytes[c]) jc.dst_valid_bytes[c][pos] = ok ? 1 : 0;
@@ -1245,7 +1252,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
         mc.src[k] = c.words();
         mc.flip[k] = (mm_cols[k] >= 0 && c.dtype == NQE_INT64) ? 0x8000000000000000ull : 0ull; // the key range is taken unsigned
     }
-    launch(ctx, "join_build_minmax", minmax_cols_kernel, dim3(unsigned(std::min<int64_t>(n >= (int64_t(1) << 22) ? 8 * ctx->num_cus : 256, (n + 255) / 256)), unsigned(K)), dim3(256), 0, mc, n,
+    launch(ctx, "join_build_minmax", minmax_cols_kernel, dim3(unsigned(std::min<int64_t>(n >= (int64_t(1) << 22) ? 4 * ctx->num_cus : 256, (n + 255) / 256)), unsigned(K)), dim3(256), 0, mc, n,
            (unsigned long long *)mm->ptr, (unsigned long long *)mm->ptr + K, (unsigned long long *)mm->ptr + 2 * K);
     std::vector<uint64_t> mmraw(K * 2 + 1), mmh(K * 2);
     NQE_HIP_CHECK(hipMemcpyAsync(mmraw.data(), mm->ptr, K * 16 + 8, hipMemcpyDeviceToHost, ctx->stream));
