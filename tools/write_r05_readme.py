@@ -14,7 +14,7 @@ file by `tools/write_r05_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | File | What |
 |---|---|
 | `bench_default.json`, `bench_details.json` | the default `python bench.py` line (24 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity), per-kernel details |
-| `bench_default_box2.json`, `bench_details_box2.json` | the same default line on ANOTHER box of the pool, one csrc revision earlier (the range tier's table limit: no steady-state kernel differs): headline kernel 2.55 ms = 0.784 there, 2.31 ms = 0.864 on the box of `bench_default.json`, 2.405 (0.831) and 2.421 (0.826) in two earlier runs of this round — the boxes differ by up to 10 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
+| `bench_default_box2.json`, `bench_details_box2.json` | the same default line on ANOTHER box of the pool, a few csrc revisions earlier (no steady-state aggregate / selection kernel differs): headline kernel 2.55 ms = 0.784 there; this round's other full runs gave 2.316 (0.864), 2.405 (0.831), 2.421 (0.826) and `bench_default.json`'s own figure — the boxes differ by up to 10 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
 | `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
 | `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
 | `rocprofv3_kernel_stats_<config>.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --workload … --steps 20 --warmup 3` (its own process: the table below compares its averages with the bench line's HIP-event times) |
