@@ -1153,18 +1153,22 @@ __global__ void __launch_bounds__(256) agg_merge_partials_kernel(const double *p
 // the same fold for the STATIC streaming kernel's direct-mapped tables (AggArgs::partials), shaped for up to 4096 slots x 256 workgroups:
 // a 256-thread block takes 16 consecutive slots; thread (slot, g) = (tid & 15, tid >> 4) walks the workgroups g, g + 16, ... — 16
 // consecutive lanes read 128 contiguous bytes of one workgroup's table per array — the sixteen partial results of a slot meet in LDS.
+// sub_log2 (a direct-mapped table in 2^sub_log2 key-range subsets, AggArgs::direct_sub_shift): slot S of the whole range is slot S % span of
+// the tables of subset S / span — the workgroups whose index has that subset in bits [3, 3 + sub_log2)
 __global__ void __launch_bounds__(256) agg_fold_partials_kernel(const double *psum, const double *pmn, const double *pmx, const uint32_t *pcnt, int grid, uint32_t span,
-                                                                int64_t bias, int need_minmax, GroupTable g, int v, int *flags) {
+                                                                int64_t bias, int need_minmax, GroupTable g, int v, int *flags, int sub_log2, RangeRec *tab) {
     __shared__ double ssum[16][16], smn[16][16], smx[16][16];
     __shared__ unsigned long long scnt[16][16];
     __shared__ uint32_t snan[16][16];
-    const uint32_t sl = threadIdx.x & 15, gq = threadIdx.x >> 4, s = blockIdx.x * 16 + sl;
+    const uint32_t sl = threadIdx.x & 15, gq = threadIdx.x >> 4, S = blockIdx.x * 16 + sl, total = span << sub_log2;
+    const uint32_t subset = sub_log2 ? S / span : 0u, s = sub_log2 ? S % span : S;
     uint64_t c = 0;
     uint32_t nanm = 0;
     double sum = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
-    if (s < span) {
+    if (S < total) {
 #pragma unroll 4
-        for (int b = int(gq); b < grid; b += 16) {
+        for (int i = int(gq); i < (grid >> sub_log2); i += 16) {
+            const int b = sub_log2 ? int(((uint32_t(i) >> 3) << (3 + sub_log2)) | (subset << 3) | (uint32_t(i) & 7u)) : i;
             const size_t o = size_t(b) * span + s;
             const uint32_t cc = pcnt[o];
             const double x = psum[o], lo = need_minmax ? pmn[o] : DBL_MAX, hi = need_minmax ? pmx[o] : -DBL_MAX;
@@ -1182,7 +1186,7 @@ __global__ void __launch_bounds__(256) agg_fold_partials_kernel(const double *ps
     scnt[gq][sl] = c;
     snan[gq][sl] = nanm;
     __syncthreads();
-    if (gq != 0 || s >= span) return;
+    if (gq != 0 || S >= total) return;
     for (int q = 1; q < 16; ++q) {
         c += scnt[q][sl];
         nanm |= snan[q][sl];
@@ -1190,8 +1194,18 @@ __global__ void __launch_bounds__(256) agg_fold_partials_kernel(const double *ps
         mn = fmin(mn, smn[q][sl]);
         mx = fmax(mx, smx[q][sl]);
     }
+    if (tab) { // the range tier's tail takes it from here (agg_range_emit_kernel: one partition, one table of `total` slots in key order)
+        RangeRec r;
+        r.sum = sum;
+        r.mn = mn;
+        r.mx = mx;
+        r.cnt = uint32_t(c) | nanm;
+        r.pad = 0;
+        tab[S] = r;
+        return;
+    }
     if (c == 0) return;
-    const int64_t gslot = global_find_or_insert(g, uint64_t(int64_t(s) - bias), flags);
+    const int64_t gslot = global_find_or_insert(g, uint64_t(int64_t(S) - bias), flags);
     if (gslot < 0) return;
     global_update(g, gslot, v, c, sum, true, f64_to_ord(mn), f64_to_ord(mx), need_minmax != 0, nanm != 0);
 }
@@ -1552,6 +1566,7 @@ struct AggRun {
     PassStatus shape_pass();
     PassStatus tier_slab();
     void range_tail(const AggArgs &sa, const SlabArgs &sl, uint32_t rslots);
+    void range_emit(int parts_log2, int Q, uint32_t rslots, uint64_t span, int64_t key_min);
     void tier_exact();
     PassStatus tier_streaming(int v0);
     void pass_ungrouped(int v0);
@@ -1853,6 +1868,11 @@ void AggRun::sample_keys() {
             subsets_log2 = 1;
             cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
             ctx->agg_hints[hint_key] = uint8_t(2);
+            if (plain_int_key && !sw.no_key_range && V == 1 && sw.direct_subsets) { // the sample's range (pick_key_range: a direct-mapped table over the two subsets)
+                if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
+                ctx->agg_key_ranges[hint_key] = std::make_pair(int64_t(h[0] ^ key_flip), h[1] >= h[0] ? h[1] - h[0] + 1 : 0ull);
+                range_sampled = true;
+            }
         } else {
             ctx->agg_hints.emplace(hint_key, uint8_t(0)); // sampled: the single-pass tier (a later overflow overwrites this)
             if (plain_int_key && !sw.no_key_range) {
@@ -1869,7 +1889,10 @@ void AggRun::sample_keys() {
 }
 
 void AggRun::pick_key_range() {
-    if (hint_key && !sw.no_key_range && !partition_mode && subsets_log2 == 0 && (!no_hints_env || range_sampled) && plain_int_key) {
+    // (round 5: also under key subsets — two workgroups per row range, each holding one half of a range of up to 2 x 4096 values in a
+    // direct-mapped table (AggArgs::direct_sub_shift): one value column, NQE_DIRECT_SUBSETS=0 switches it off)
+    const bool sub_range = subsets_log2 == 1 && subsets_ok && V == 1 && sw.direct_subsets;
+    if (hint_key && !sw.no_key_range && !partition_mode && (subsets_log2 == 0 || sub_range) && (!no_hints_env || range_sampled) && plain_int_key) {
         // `group by k`, k a plain integer column (dictionary codes, small ids): a value range that fits a workgroup table makes the
         // streaming kernel address it by key - min (no hash, no probe sequence, replicas for a handful of groups).  The range comes
         // from the first execution's key sample, or — tables too small to sample, queries with a predicate — from one pass over the
@@ -1879,7 +1902,7 @@ void AggRun::pick_key_range() {
             if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
             rt = ctx->agg_key_ranges.emplace(hint_key, measure_key_range()).first;
         }
-        if (rt->second.second != 0 && rt->second.second <= range_limit) {
+        if (rt->second.second != 0 && rt->second.second <= (range_limit << subsets_log2)) {
             range_on = true;
             range_min = rt->second.first;
             range_span = rt->second.second;
@@ -2204,8 +2227,15 @@ void AggRun::range_tail(const AggArgs &sa, const SlabArgs &sl, uint32_t rslots) 
     range_tab = dev_alloc(ctx, size_t(parts) * size_t(Q) * size_t(rslots) * sizeof(RangeRec) + 64);
     const BufRef &tab = range_tab;
     launch(ctx, "agg_segments_direct", pick_range_segments_kernel(vf64), dim3(unsigned(parts * Q)), dim3(AGG_BLOCK), dshmem, sa, sl, Q, (RangeRec *)tab->ptr);
+    range_emit(sl.parts_log2, Q, rslots, part_span, part_min);
+}
+
+// the tail of the range tier over range_tab = [2^parts_log2][Q][rslots] records: ranks the occupied keys of [key_min, key_min + span) and writes
+// keys and aggregates in key order (`ranged`; the group count and the exact key range travel back with the flags)
+void AggRun::range_emit(int parts_log2, int Q, uint32_t rslots, uint64_t span, int64_t key_min) {
+    const BufRef &tab = range_tab;
     // outputs for the whole range (an upper bound of the groups, and never more than the rows); cut to the group count in finish_attempt
-    const int64_t room = int64_t(std::min<uint64_t>(part_span, uint64_t(std::max<int64_t>(in->rows, 1))));
+    const int64_t room = int64_t(std::min<uint64_t>(span, uint64_t(std::max<int64_t>(in->rows, 1))));
     ranged = AggResult();
     FinalizeArgs f = alloc_outputs(ctx, ranged, room, aggs, naggs, plan.vslot, partial);
     ranged.keys = std::make_unique<nqe_table>();
@@ -2213,8 +2243,8 @@ void AggRun::range_tail(const AggArgs &sa, const SlabArgs &sl, uint32_t rslots) 
     ranged.keys->rows = room;
     ranged.keys->cols.push_back(make_word_column(ctx, kinfo.out_dtype, room, false));
     // keys per thread of the tail: 4096-key blocks for wide ranges, 1024-key blocks to keep narrow ones parallel (NQE_RANGE_EMIT_ITEMS: 1 / 4 for A/B)
-    const int items = sw.range_emit_items ? sw.range_emit_items : (part_span >= (uint64_t(1) << 19) ? 4 : 1);
-    const uint32_t kb = uint32_t(RE_BLOCK * items), sb = std::max<uint32_t>(1u, kb >> sl.parts_log2), nblocks = (rslots + sb - 1) / sb;
+    const int items = sw.range_emit_items ? sw.range_emit_items : (span >= (uint64_t(1) << 19) ? 4 : 1);
+    const uint32_t kb = uint32_t(RE_BLOCK * items), sb = std::max<uint32_t>(1u, kb >> parts_log2), nblocks = (rslots + sb - 1) / sb;
     range_status = dev_alloc(ctx, (size_t(nblocks) + 2) * 8);
     const BufRef &status = range_status;
     NQE_HIP_CHECK(hipMemsetAsync(status->ptr, 0, (size_t(nblocks) + 2) * 8, ctx->stream));
@@ -2223,10 +2253,10 @@ void AggRun::range_tail(const AggArgs &sa, const SlabArgs &sl, uint32_t rslots) 
     auto *keys_out = (uint64_t *)ranged.keys->cols[0].values->ptr;
     const size_t eshmem = size_t(kb) * 28;
     if (items == 4)
-        launch(ctx, "agg_range_emit", agg_range_emit_kernel<4>, dim3(nblocks), dim3(RE_BLOCK), eshmem, (const RangeRec *)tab->ptr, int(sl.parts_log2), Q, rslots, part_span, uint64_t(part_min), st, keys_out,
+        launch(ctx, "agg_range_emit", agg_range_emit_kernel<4>, dim3(nblocks), dim3(RE_BLOCK), eshmem, (const RangeRec *)tab->ptr, parts_log2, Q, rslots, span, uint64_t(key_min), st, keys_out,
                f, (uint32_t *)range_total->ptr);
     else
-        launch(ctx, "agg_range_emit", agg_range_emit_kernel<1>, dim3(nblocks), dim3(RE_BLOCK), eshmem, (const RangeRec *)tab->ptr, int(sl.parts_log2), Q, rslots, part_span, uint64_t(part_min), st, keys_out,
+        launch(ctx, "agg_range_emit", agg_range_emit_kernel<1>, dim3(nblocks), dim3(RE_BLOCK), eshmem, (const RangeRec *)tab->ptr, parts_log2, Q, rslots, span, uint64_t(key_min), st, keys_out,
                f, (uint32_t *)range_total->ptr);
     launch(ctx, "agg_range_summary", agg_range_summary_kernel, dim3(1), dim3(1), 0, (const uint32_t *)range_total->ptr, (const uint64_t *)keys_out, (uint64_t *)range_total->ptr + 1);
     NQE_HIP_CHECK(hipMemcpyAsync(ctx->h_flags + NQE_NUM_FLAGS, (const uint64_t *)range_total->ptr + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -2327,12 +2357,16 @@ PassStatus AggRun::tier_streaming(int v0) {
             while (ka.direct_rep < 6 && (span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
         }
     }
-    if (range_on && fast_key == 0 && !ka.direct && range_span <= uint64_t(ka.lds_cap)) {
+    ka.direct_sub_shift = 0;
+    if (range_on && fast_key == 0 && !ka.direct && range_span <= (uint64_t(ka.lds_cap) << subsets_log2)) {
         // the key column's measured range fits the table: slot = key - min, every key checked against the range
         ka.direct = 2;
         ka.direct_bias = int64_t(0ull - uint64_t(range_min));
         ka.direct_span = range_span;
         while (ka.direct_rep < 6 && (range_span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
+        // ... or the tables of 2^subsets_log2 workgroups that share their rows, each holding a consecutive range of lds_cap keys (pick_key_range
+        // turns the range on under subsets for one value column only: lds_cap = 4096)
+        if (subsets_log2) ka.direct_sub_shift = 12;
     }
     ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
     // the value column is the key column itself (and the predicate, if any, tests it too): the single-load instance
@@ -2362,7 +2396,7 @@ PassStatus AggRun::tier_streaming(int v0) {
             for (int j = 0; j < a.nv; ++j) {
                 const double *ps = reinterpret_cast<const double *>(partials->ptr) + size_t(j) * col_words;
                 launch(ctx, "agg_fold_partials", agg_fold_partials_kernel, dim3((unsigned(tm) + 15) / 16), dim3(256), 0, ps, ps + cells, ps + 2 * cells, reinterpret_cast<const uint32_t *>(ps + 3 * cells),
-                       fgrid, uint32_t(tm), int64_t(0), (mm && j == a.nv - 1) ? 1 : 0, tb.g, a.v0 + j, ctx->d_flags);
+                       fgrid, uint32_t(tm), int64_t(0), (mm && j == a.nv - 1) ? 1 : 0, tb.g, a.v0 + j, ctx->d_flags, 0, (RangeRec *)nullptr);
             }
             tiny_used = true;
             return PassStatus::Done;
@@ -2396,8 +2430,8 @@ PassStatus AggRun::tier_streaming(int v0) {
     BufRef direct_partials;
     uint32_t pspan = 0;
     size_t pcol_words = 0;
-    if (ka.direct && !vnull && subsets_log2 == 0 && sw.direct_partials) {
-        pspan = uint32_t(ka.direct == 2 ? range_span : (a.key.op_dtype[a.key.nops - 1] == NQE_INT64 ? 2 * a.key.aux[a.key.nops - 1].abs_lit - 1 : a.key.aux[a.key.nops - 1].abs_lit));
+    if (ka.direct && !vnull && (subsets_log2 == 0 || ka.direct_sub_shift) && sw.direct_partials) {
+        pspan = ka.direct_sub_shift ? uint32_t(ka.lds_cap) : uint32_t(ka.direct == 2 ? range_span : (a.key.op_dtype[a.key.nops - 1] == NQE_INT64 ? 2 * a.key.aux[a.key.nops - 1].abs_lit - 1 : a.key.aux[a.key.nops - 1].abs_lit));
         const size_t cells = size_t(fgrid) * pspan;
         pcol_words = (cells * 28 + 7) / 8;
         // ... when the atomics would matter: workgroups x groups x 4 of them at ~2.4 x 10^10 / s against the rows' streaming time.  Measured
@@ -2423,8 +2457,15 @@ PassStatus AggRun::tier_streaming(int v0) {
         for (int j = 0; j < a.nv; ++j) {
             const double *ps = reinterpret_cast<const double *>(direct_partials->ptr) + size_t(j) * pcol_words;
             const bool mmj = a.need_minmax[j] != 0 && !(nomm);
-            launch(ctx, "agg_fold_partials", agg_fold_partials_kernel, dim3((pspan + 15) / 16), dim3(256), 0, ps, ps + cells, ps + 2 * cells, reinterpret_cast<const uint32_t *>(ps + 3 * cells),
-                   fgrid, pspan, ka.direct_bias, mmj ? 1 : 0, tb.g, a.v0 + j, ctx->d_flags);
+            const int fsub = ka.direct_sub_shift ? subsets_log2 : 0;
+            // the subsets' tables cover the key range in order: folded into ONE table of records the range tier's tail ranks and writes (no global
+            // hash table of 16384 slots, no collect / sort / finalize behind a host round trip: ~0.12 ms of a 10^8-row step)
+            const bool to_tail = fsub && V == 1 && sw.range_tier;
+            if (to_tail) range_tab = dev_alloc(ctx, (size_t(pspan) << fsub) * sizeof(RangeRec) + 64);
+            launch(ctx, "agg_fold_partials", agg_fold_partials_kernel, dim3(((pspan << fsub) + 15) / 16), dim3(256), 0, ps, ps + cells, ps + 2 * cells,
+                   reinterpret_cast<const uint32_t *>(ps + 3 * cells), fgrid, pspan, ka.direct_bias, mmj ? 1 : 0, tb.g, a.v0 + j, ctx->d_flags, fsub,
+                   to_tail ? (RangeRec *)range_tab->ptr : (RangeRec *)nullptr);
+            if (to_tail) range_emit(0, 1, pspan << fsub, range_span, range_min);
         }
     }
     }
@@ -2588,7 +2629,7 @@ bool AggRun::react_to_flags(const int *f, const Collected &pre) {
             range_sampled = false;
             const auto exact = measure_key_range(); // the exact range: addressed by key - min after all, or remembered as too wide
             ctx->agg_key_ranges[hint_key] = exact;
-            if (exact.second != 0 && exact.second <= range_limit) {
+            if (exact.second != 0 && exact.second <= (range_limit << subsets_log2)) {
                 range_on = true;
                 range_min = exact.first;
                 range_span = exact.second;

@@ -90,6 +90,11 @@ struct AggArgs {
     // [subset_shift, subset_shift + subsets_log2) name it — 2^subsets_log2 LDS tables' worth of groups without partitioning the rows
     int32_t subsets_log2;
     int32_t subset_shift;
+    // … over a direct-mapped table (direct != 0, round 5): the subsets are consecutive RANGES of 2^direct_sub_shift slots — subset of a
+    // key = (key + direct_bias) >> direct_sub_shift, slot = the bits below: a measured key range of up to 2 x 4096 values is aggregated
+    // without hashing, probing or partitioning (0: the subsets are hashed)
+    int32_t direct_sub_shift;
+    int32_t pad_direct_sub;
     ConjPred conj; // pred_mode 3
     // pred_mode 4: a predicate tree (nqe_internal.hpp, TreePred) run per row by the fast kernel's stack machine.  The program
     // lives in a small device buffer that the kernel reads through the scalar cache (a by-value array indexed at run time would

@@ -129,7 +129,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     const uint32_t lanes = gridDim.x >> sub_log2;
     // subset of a key: two bits of the slot hash's product below the slot bits, XORed (one bit alone — a rotation sequence for keys
     // in arithmetic progression, like the slot bits — left each half of `5r - 77` clustered: probe sequences of 69 slots at load 0.6)
+    const uint32_t dsub_shift = SUB ? uint32_t(a.direct_sub_shift) : 0u; // direct-mapped table in key-range subsets (wave-uniform)
     auto foreign = [&](uint64_t key) {
+        if (SUB && dsub_shift) return (uint32_t(uint64_t(int64_t(key) + a.direct_bias) >> dsub_shift) & sub_mask) != my_subset; // (a key outside the range: some subset's, whose direct_slot rejects it)
         const uint64_t h = key * GOLD;
         return ((uint32_t(h >> a.subset_shift) ^ uint32_t(h >> 23)) & sub_mask) != my_subset;
     };
@@ -141,6 +143,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     auto direct_slot = [&](uint64_t key) {
         const uint64_t d = uint64_t(int64_t(key) + a.direct_bias);
         if (a.direct == 2 && d >= a.direct_span) return -1; // outside the measured range (wave-uniform test first): the cold path
+        if (SUB && dsub_shift) return int(uint32_t(d) - (my_subset << dsub_shift)); // this subset's range of the table (foreign keys never get here)
         return int((uint32_t(d) << rep_log2) | rep_lane);
     };
     auto flush_run = [&]() {
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         if (a.direct && (s & ((1u << rep_log2) - 1u)) && s != cap) continue; // replicas were folded into replica 0
         if (a.direct && !VNULL) {
             if (lcnt[s] == 0) continue;
-            k = uint64_t(int64_t(s >> rep_log2) - a.direct_bias);
+            k = uint64_t(int64_t((s >> rep_log2) + ((SUB && dsub_shift) ? (my_subset << dsub_shift) : 0u)) - a.direct_bias);
         } else {
             k = lkeys[s];
             if (k == EMPTY_KEY) continue;

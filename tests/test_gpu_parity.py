@@ -1927,6 +1927,78 @@ def test_aggregate_measured_key_range_addresses_the_table_directly(ctx, kind):
         ctx.device_free(p_)
 
 
+@pytest.mark.parametrize("kind", ["i64_0", "i64_negative", "u64_high", "at_limit", "predicate", "int_values", "sparse"])
+def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
+    """More groups than one workgroup table holds, at most twice as many (4097 .. 8192 values between the column's min and max), one value
+    column: two workgroups share every row range and each keeps ONE HALF OF THE KEY RANGE in a direct-mapped table (AggArgs::direct_sub_shift)
+    — no hashing, no probing, no partition pass; the tables leave whole and agg_fold_partials_kernel folds them subset by subset.  The
+    range comes from the first execution's key sample and is remembered; "sparse" (every third integer: 15000 values) still hashes its two
+    subsets.  Then the column's contents change under the remembered range: the kernel must notice, and the result still equal the oracle's."""
+    rng = np.random.default_rng(len(kind) + 50)
+    # ("predicate": no key sample under a filter — the first execution overflows its tables and asks for subsets, the second measures the
+    # column's range; enough rows per workgroup for that overflow)
+    n = 4_000_000 if kind == "predicate" else 1_000_000
+    groups = {"i64_0": 6000, "i64_negative": 8000, "u64_high": 5000, "at_limit": 8192, "predicate": 7000, "int_values": 4500, "sparse": 5000}[kind]
+    base = {"i64_0": 0, "i64_negative": -5000, "u64_high": (1 << 63) + 999, "at_limit": 10**11, "predicate": 17, "int_values": -1, "sparse": 3}[kind]
+    dt = np.uint64 if kind == "u64_high" else np.int64
+    draw = rng.integers(0, groups, n)
+    if kind == "at_limit":
+        draw[:2] = [0, groups - 1]  # the whole range is there
+    k = (draw.astype(np.uint64) + np.uint64(base)) if kind == "u64_high" else (draw * (3 if kind == "sparse" else 1) + base).astype(dt)
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64) if kind == "int_values" else rng.random(n) * 100.0
+    v_dt = DType.INT64 if kind == "int_values" else DType.FLOAT64
+    w = rng.random(n)
+    aggs = ALL_AGGS(1)
+    f3 = fields("k", "v", "w")
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def upload(ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        ctx.synchronize()
+        assert hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(arr.ctypes.data), ctypes.c_size_t(arr.nbytes), 1) == 0
+        assert hip.hipDeviceSynchronize() == 0
+
+    pk, pv, pw = (ctx.device_alloc(n * 8) for _ in range(3))
+    upload(pk, k)
+    upload(pv, v)
+    upload(pw, w)
+    kdt = DType.UINT64 if kind == "u64_high" else DType.INT64
+    t = ctx.table_from_device([(kdt, n, pk, None), (v_dt, n, pv, None), (DType.FLOAT64, n, pw, None)])
+    key = col(0).flatten(f3)
+    pred = binop(col(2), Operator.Lt, lit_f64(0.5)).flatten(f3) if kind == "predicate" else None
+
+    def run():
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got = ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred).to_host()
+        ctx.timing_enable(False)
+        return got, ctx.timing_report()
+
+    cols = [Column.from_numpy(k), Column.from_numpy(v), Column.from_numpy(w)]
+    exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=pred)[0]
+    for rep in range(3):
+        got, names = run()
+        assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"{kind} run {rep}")
+        if rep >= 1:
+            assert "agg_partition_scatter" not in names and names["agg_grouped_fast"][1] == 1, names
+        if rep == 2:
+            assert ("agg_fold_partials" in names and "agg_range_emit" in names) == (kind != "sparse"), names
+    # the same buffer, other contents: a few keys outside the remembered range (above and below)
+    k2 = k.copy()
+    k2[::1000] = k2[::1000] + dt(100_000)
+    k2[5::1000] = k2[5::1000] - dt(3000) if kind not in ("i64_0",) else k2[5::1000] + dt(7777)
+    upload(pk, k2)
+    cols2 = [Column.from_numpy(k2), Column.from_numpy(v), Column.from_numpy(w)]
+    exp2 = orc.aggregate([cols2], aggs, group_nodes=key, pred_nodes=pred)[0]
+    for rep in range(2):
+        got, names = run()
+        assert_rows_multiset_equal(got, exp2, RTOL, exact_cols=[0], what=f"{kind} after the contents changed, run {rep}")
+    del t
+    for p_ in (pk, pv, pw):
+        ctx.device_free(p_)
+
+
 def test_expression_trees_specialised_at_run_time(ctx, monkeypatch):
     """trees of three or more operators are also compiled to straight-line kernels at run time (csrc/expr_jit.hpp: hipRTC on a worker
     thread; executions switch to the compiled form once it is ready).  Every tree here runs interpreted first, then — after
