@@ -1146,13 +1146,15 @@ def test_aggregate_special_float_values_under_random_keys(ctx, groups):
 
 
 def test_aggregate_key_subset_tier_is_taken_between_one_table_and_partitioning(ctx):
-    """5000 groups: the second attempt runs the streaming kernel with two key subsets, not the partition kernels; 20000: partitioned"""
+    """5000 groups spread over a range no table addresses directly: the streaming kernel with two HASHED key subsets, not the partition
+    kernels; 20000: partitioned.  (A range of up to 2 x 4096 values takes direct-mapped subsets, one of up to ~1.3 million the partitioned
+    path's range tier: test_aggregate_measured_key_range_over_two_key_subsets.)"""
     rng = np.random.default_rng(11)
     n = 700_000
     f2 = fields("k", "v")
     v = rng.random(n)
     for groups, want_partition in ((5000, False), (20000, True)):
-        k = rng.integers(0, groups, n).astype(np.int64) * 5 - 77
+        k = rng.integers(0, groups, n).astype(np.int64) * 1_000_033 - 77  # (k % 1_000_003 below: 30 g - 77, as many groups)
         cols = [Column.from_numpy(k), Column.from_numpy(v)]
         t = ctx.table_from_host(cols)
         exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=col(0).flatten(f2))[0]
@@ -1932,8 +1934,8 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
     """More groups than one workgroup table holds, at most twice as many (4097 .. 8192 values between the column's min and max), one value
     column: two workgroups share every row range and each keeps ONE HALF OF THE KEY RANGE in a direct-mapped table (AggArgs::direct_sub_shift)
     — no hashing, no probing, no partition pass; the tables leave whole and agg_fold_partials_kernel folds them subset by subset.  The
-    range comes from the first execution's key sample and is remembered; "sparse" (every third integer: 15000 values) still hashes its two
-    subsets.  Then the column's contents change under the remembered range: the kernel must notice, and the result still equal the oracle's."""
+    range comes from the first execution's key sample and is remembered; "sparse" (every third integer: 15000 values) takes the partitioned
+    path's range tier.  Then the column's contents change under the remembered range: the kernel must notice, and the result still equal the oracle's."""
     rng = np.random.default_rng(len(kind) + 50)
     # ("predicate": no key sample under a filter — the first execution overflows its tables and asks for subsets, the second measures the
     # column's range; enough rows per workgroup for that overflow)
@@ -1980,10 +1982,12 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
     for rep in range(3):
         got, names = run()
         assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"{kind} run {rep}")
-        if rep >= 1:
+        if rep >= 1 and kind == "sparse":  # 15000 values: the partitioned path's range tier (two HASHED subsets are slower than that)
+            assert "agg_partition_scatter" in names and "agg_grouped_fast" not in names, names
+        elif rep >= 1:
             assert "agg_partition_scatter" not in names and names["agg_grouped_fast"][1] == 1, names
-        if rep == 2:
-            assert ("agg_fold_partials" in names and "agg_range_emit" in names) == (kind != "sparse"), names
+        if rep == 2 and kind != "sparse":
+            assert "agg_fold_partials" in names and "agg_range_emit" in names, names
     # the same buffer, other contents: a few keys outside the remembered range (above and below)
     k2 = k.copy()
     k2[::1000] = k2[::1000] + dt(100_000)
@@ -2310,12 +2314,13 @@ def test_specialised_kernels_are_found_on_disk_by_a_new_context(tmp_path, monkey
         c4.close()
 
 
-@pytest.mark.parametrize("shape", ["few", "dense_4096", "sparse_3000", "sparse_6000", "sparse_20000", "groups_300000", "all_distinct", "mod_100000",
-                                   "range_with_outliers", "skewed"])
+@pytest.mark.parametrize("shape", ["few", "dense_4096", "dense_6000", "spread_6000", "sparse_3000", "sparse_6000", "sparse_20000", "groups_300000", "all_distinct",
+                                   "mod_100000", "range_with_outliers", "skewed"])
 @pytest.mark.parametrize("no_hints", [False, True])
 def test_aggregate_first_execution_starts_in_the_tier_its_key_sample_picks(ctx, monkeypatch, shape, no_hints):
     """tables of 2^22 rows and more without a predicate: the FIRST execution samples 65536 keys (key_sample_kernel) and starts in the
-    tier their distinct count calls for — one workgroup table (a range that fits: addressed by key - min), two key subsets, the
+    tier their distinct count calls for — one workgroup table (a range that fits: addressed by key - min), two key subsets (direct-mapped
+    when the sampled range fits two tables; the partitioned path's range tier instead of HASHED subsets when the range fits that), the
     partitioned path (256 or 512 partitions) — instead of falling through abandoned tiers; later executions take the remembered
     tier (or, NQE_NO_PLAN_HINTS, sample again).  Results equal the oracle's in every case, including the ones the sample gets wrong:
     a plain key column whose few outliers the sample misses (the kernel's range check asks for the exact measurement), heavy skew
@@ -2331,6 +2336,10 @@ def test_aggregate_first_execution_starts_in_the_tier_its_key_sample_picks(ctx, 
         k = rng.integers(-3, 4, n)
     elif shape == "dense_4096":
         k = rng.integers(100, 4196, n)
+    elif shape == "dense_6000":                                     # two key subsets over a direct-mapped table (round 5)
+        k = rng.integers(-2000, 4000, n)
+    elif shape == "spread_6000":                                    # 6000 keys over a range of 42000: the partitioned path's range tier, not two hashed subsets
+        k = rng.integers(0, 6000, n) * 7 + 11
     elif shape.startswith("sparse_"):
         g = int(shape.split("_")[1])
         k = rng.integers(0, g, n) * 1_000_003 - 5
@@ -2362,7 +2371,9 @@ def test_aggregate_first_execution_starts_in_the_tier_its_key_sample_picks(ctx, 
         assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"{shape} rep {rep} no_hints={no_hints}")
         sampled = "agg_key_sample" in names
         assert sampled == (rep == 0 or no_hints), (shape, rep, no_hints, sorted(names))
-        if rep == 0 and shape in ("sparse_20000", "groups_300000", "all_distinct", "mod_100000"):
+        if rep == 0 and shape == "dense_6000":
+            assert names.get("agg_grouped_fast", (0, 0))[1] == 1 and "agg_range_emit" in names and "agg_partition_scatter" not in names, sorted(names)
+        if rep == 0 and shape in ("sparse_20000", "groups_300000", "all_distinct", "mod_100000", "spread_6000"):
             # straight to the partitioned path: no abandoned streaming attempt before it
             assert "agg_partition_scatter" in names and "agg_grouped_fast" not in names, sorted(names)
         if rep == 0 and shape in ("few", "dense_4096", "sparse_3000"):
