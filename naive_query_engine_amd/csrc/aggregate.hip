@@ -1845,10 +1845,15 @@ void AggRun::sample_keys() {
         // (pick_key_range); otherwise the range tier of the partitioned path when it fits THAT (10^8 rows, 4500-6000 keys spread over 7x their
         // number: 0.89-0.90 ms per execution against 1.05-1.15 for two HASHED subsets, tools/probe_sparse_groups.py); hashed subsets for the rest
         const uint64_t sample_span = h[1] >= h[0] ? h[1] - h[0] + 1 : 0;
-        const bool sub_direct = plain_int_key && !sw.no_key_range && V == 1 && sw.direct_subsets && sample_span != 0 && sample_span <= 2 * range_limit;
+        // groups ONE workgroup table takes: every key of a range it addresses directly; three quarters of its slots when it hashes (the kernel's own
+        // limit, AggArgs::lds_limit: linear probing beyond that load costs more than the next tier)
+        const bool one_direct = plain_int_key && !sw.no_key_range && sample_span != 0 && sample_span <= range_limit;
+        const uint64_t one_limit = (one_direct || !sw.lds_load_limit) ? range_limit : range_limit * 3 / 4;
+        const bool sub_direct = plain_int_key && !sw.no_key_range && V == 1 && sw.direct_subsets && subsets_ok && sw.subsets_max >= 1 && sample_span != 0 &&
+                                sample_span <= 2 * range_limit;
         const bool tier_instead = !sub_direct && sw.direct_subsets && range_part_ok && V == 1 && sw.range_tier && plain_int_key && sample_span != 0 &&
                                   sample_span + sample_span / 128 + 32 < uint64_t(256) * RANGE_TIER_MAX_SLOTS;
-        if (D > 2 * range_limit || (D > range_limit && (!subsets_ok || sw.subsets_max < 1 || tier_instead))) {
+        if (!sub_direct && (D > 2 * one_limit || (D > one_limit && (!subsets_ok || sw.subsets_max < 1 || tier_instead)))) {
             partition_mode = true; // more distinct keys in the sample than the workgroup tables of the streaming tiers hold
             cap = std::max(cap, sized_cap);
             if (G > 800e3) slab_parts_log2 = PARTS_LOG2; // … and more than 256 partitions of one table each
@@ -1871,7 +1876,7 @@ void AggRun::sample_keys() {
                     part_range_sampled = true;
                 }
             }
-        } else if (D > range_limit) {
+        } else if (D > one_limit) {
             subsets_log2 = 1;
             cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
             ctx->agg_hints[hint_key] = uint8_t(2);
@@ -2365,6 +2370,7 @@ PassStatus AggRun::tier_streaming(int v0) {
         }
     }
     ka.direct_sub_shift = 0;
+    ka.lds_limit = (ka.allow_partition && sw.lds_load_limit) ? uint32_t(ka.lds_cap) * 3u / 4u : 0u; // (hashed tables only look at it)
     if (range_on && fast_key == 0 && !ka.direct && range_span <= (uint64_t(ka.lds_cap) << subsets_log2)) {
         // the key column's measured range fits the table: slot = key - min, every key checked against the range
         ka.direct = 2;
@@ -2656,7 +2662,28 @@ bool AggRun::react_to_flags(const int *f, const Collected &pre) {
     }
     if (f[NQE_FLAG_NEED_PARTITION] && !partition_mode) {
         // a workgroup table overflowed: two key subsets, and beyond those hash-partitioned rows
-        if (subsets_ok && subsets_log2 < sw.subsets_max) {
+        bool to_subsets = subsets_ok && subsets_log2 < sw.subsets_max;
+        if (to_subsets && subsets_log2 == 0 && plain_int_key && !sw.no_key_range && V == 1 && sw.direct_subsets && hint_key) {
+            // a plain integer key column: its exact range (one pass, remembered) decides as the key sample does for queries without a predicate —
+            // up to two tables' worth of values: the two subsets address their tables directly; a range the partitioned path's range tier takes:
+            // that tier; anything wider: hashed subsets
+            auto rt = ctx->agg_key_ranges.find(hint_key);
+            if (rt == ctx->agg_key_ranges.end() || range_sampled) {
+                if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
+                ctx->agg_key_ranges[hint_key] = measure_key_range();
+                rt = ctx->agg_key_ranges.find(hint_key);
+                range_sampled = false;
+            }
+            const uint64_t span = rt->second.second;
+            if (span != 0 && span <= 2 * range_limit) {
+                range_on = true;
+                range_min = rt->second.first;
+                range_span = span;
+            } else if (range_part_ok && sw.range_tier && span != 0 && span < uint64_t(256) * RANGE_TIER_MAX_SLOTS) {
+                to_subsets = false;
+            }
+        }
+        if (to_subsets) {
             ++subsets_log2;
             cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << subsets_log2));
         } else {

@@ -86,8 +86,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     auto mmo = [&](int j, uint32_t slot) { return uint32_t(ML ? 0 : j) * slots + slot; }; // a column's word in the min / max arrays
     const uint64_t ORD_MAX = f64_to_ord(DBL_MAX), ORD_MIN = f64_to_ord(-DBL_MAX);
     __shared__ int lds_full_flag;
+    __shared__ uint32_t lds_used; // distinct keys of the hashed table (lds_find_or_insert_counted)
     volatile int *lds_full = &lds_full_flag;
-    if (threadIdx.x == 0) lds_full_flag = 0;
+    if (threadIdx.x == 0) lds_full_flag = 0, lds_used = 0;
     for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
         lkeys[s] = EMPTY_KEY;
 #pragma unroll
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
             // key word as the mark (every writer stores the same word)
             if (VNULL && slot >= 0) lkeys[slot] = run_key;
         } else
-            slot = lds_find_or_insert(lkeys, run_key, cap, a.lds_shift);
+            slot = lds_find_or_insert_counted(lkeys, run_key, cap, a.lds_shift, &lds_used, a.lds_limit);
         int64_t gslot = 0;
         if (slot < 0) {
             if (!*lds_full) {
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
                 } else if (k0[i] == key[u] && key[u] != EMPTY_KEY) {
                     slot[u] = int(uint32_t((key[u] * GOLD) >> a.lds_shift));
                 } else {
-                    slot[u] = lds_find_or_insert(lkeys, key[u], cap, a.lds_shift);
+                    slot[u] = lds_find_or_insert_counted(lkeys, key[u], cap, a.lds_shift, &lds_used, a.lds_limit);
                 }
                 cold = cold || slot[u] < 0;
             }

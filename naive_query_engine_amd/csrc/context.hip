@@ -25,6 +25,7 @@ void AggSwitches::read_environment() {
     range_tier = num("NQE_RANGE_TIER", 1) != 0;
     range_slots_log2 = std::min(12, std::max(8, num("NQE_RANGE_SLOTS_LOG2", 12)));
     soa_threads = num("NQE_SOA_THREADS", 512) == 1024 ? 1024 : 512;
+    lds_load_limit = num("NQE_LDS_LOAD_LIMIT", 1) != 0;
     direct_subsets = num("NQE_DIRECT_SUBSETS", 1) != 0;
     { const int it = num("NQE_RANGE_EMIT_ITEMS", 0); range_emit_items = (it == 1 || it == 4) ? it : 0; }
     debug = getenv("NQE_DEBUG") != nullptr;

@@ -66,6 +66,7 @@ struct AggSwitches {
     int range_slots_log2 = 12;         // NQE_RANGE_SLOTS_LOG2: log2 of the slots per table the range tier sizes its partition count for (8..12; measured at 10^8 rows / 65536 groups: 9: 1.11, 10: 1.03, 11: 0.99, 12: 0.97 ms per step)
     int soa_threads = 512;             // NQE_SOA_THREADS: workgroup size of the two-stream scatter (512: two per CU; 1024: one)
     bool direct_subsets = true;        // NQE_DIRECT_SUBSETS=0: two key subsets always hash (round 4), even over a measured key range of up to 2 x 4096 values
+    bool lds_load_limit = true;        // NQE_LDS_LOAD_LIMIT=0: a hashed workgroup table of the streaming kernel takes keys until probe sequences fail (round 4), not three quarters of its slots
     int range_emit_items = 0;          // NQE_RANGE_EMIT_ITEMS: keys per thread of the range tier's tail (1 or 4; 0 = by the range)
     bool debug = false;                // NQE_DEBUG=1: the tier decisions on stderr
     void read_environment();

@@ -1,4 +1,4 @@
-"""10^8 rows over G random groups whose keys are SPARSE (key = 7 x a random number below G: the value range is seven times a workgroup
+"""10^8 rows over G random groups whose keys are SPARSE (key = SPREAD (default 7) x a random number below G: the value range is seven times a workgroup
 table's reach, so no tier can address a table by key - min): the hashed two-subset streaming form against the partitioned tier
 (NQE_AGG_SUBSETS_MAX=0), wall time per execution included.  usage: python tools/probe_sparse_groups.py [G ...]"""
 import os
@@ -31,7 +31,7 @@ def main():
         ctx.synth_fill(2, 3, 0, n, 1, 0, v)
         t = ctx.table_from_device([(DType.INT64, n, k, None), (DType.FLOAT64, n, v, None)])
         # the sparse key column, materialised once: k * 7
-        proj = ctx.projection(t, [binop(col(0), Operator.Multiply, lit_i64(7)).flatten(f), col(1).flatten(f)])
+        proj = ctx.projection(t, [binop(col(0), Operator.Multiply, lit_i64(int(os.environ.get("SPREAD", "7")))).flatten(f), col(1).flatten(f)])
         kn = col(0).flatten(f)
         for _ in range(3):
             ctx.aggregate(proj, aggs, group_nodes=kn)
