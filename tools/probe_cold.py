@@ -11,7 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SHAPES = ["headline", "c3", "agg_4096_groups", "agg_65536_groups", "agg_1048576_groups", "c2", "c2_random_ids", "c4", "c4_dim_1e7", "c4_dim_1e8", "c4_sparse_keys", "c4_dup_keys"]
+SHAPES = ["headline", "c3", "agg_4096_groups", "agg_6000_groups", "agg_65536_groups", "agg_1048576_groups", "c2", "c2_random_ids", "c4", "c4_dim_1e7", "c4_dim_1e8", "c4_sparse_keys", "c4_dup_keys"]
 
 
 def worker(shape):

@@ -13,7 +13,7 @@ file by `tools/write_r05_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 
 | File | What |
 |---|---|
-| `bench_default.json`, `bench_details.json` | the default `python bench.py` line (24 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity), per-kernel details |
+| `bench_default.json`, `bench_details.json` | the default `python bench.py` line (25 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity), per-kernel details |
 | `bench_default_box2.json`, `bench_details_box2.json` | the same default line on ANOTHER box of the pool, a few csrc revisions earlier (no steady-state aggregate / selection kernel differs): headline kernel 2.55 ms = 0.784 there; this round's other full runs gave 2.316 (0.864), 2.405 (0.831), 2.421 (0.826) and `bench_default.json`'s own figure — the boxes differ by up to 10 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
 | `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
 | `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
@@ -52,6 +52,12 @@ another definition.
   LDS read-modify-writes" for two rounds, was bound by its 12-byte record loads: two coalesced streams 0.32 → 0.21 ms.
 * **4096 random groups 0.42 → 0.75**: the streaming kernel's end-of-kernel merge (256 × 4096 × 4 device atomics = 0.17 of 0.47 ms)
   replaced by whole-table stores + a fold kernel — only where the atomics would matter (the headline measured 2 % slower with it).
+* **Between one and two tables' worth of groups** (`agg_6000_groups`, new): 4500–8000 groups of a dense key range 1.08–1.36 → 0.60–0.62
+  ms per step — two workgroups per row range, each with ONE HALF OF THE RANGE in a direct-mapped table, folded subset by subset into
+  the range tier's tail (`ab_groups_landscape_before.txt`, `ab_direct_subsets*.txt`).  Hashed workgroup tables hand over to the next
+  tier at three quarters of their slots instead of when a probe sequence fails (3500 / 4000 sparse keys 1.71 / 1.75 → 0.88 ms,
+  `probe_hashed_curve.txt`), and keys spread over a range the partitioned path's range tier takes go there instead of into two hashed
+  subsets (1.05–1.15 → 0.86–0.87, `probe_sparse_groups.txt`).
 * **`group by id % 3` in registers** (the reference's README query): `agg_three_value_columns` 0.67 → 0.76, `agg_readme_shape`
   0.67 → 0.73 on 24 B/row.
 * **Measurement**: `roofline.kernel_ms_min/_max` over all timed blocks; this table's rocprofv3 column; `bench.py --gpus N` runs a
@@ -63,13 +69,14 @@ another definition.
 * Tried and left out, with numbers (`../r05_notes.md`): chunking the partitioned passes to keep the tuples in the Infinity Cache (no
   gain: `mall_bench.txt`); LDS-staged outputs and other step sizes in the one-pass selection + projection kernel (0.558 → 0.572 ms;
   0.537–0.618); a 1024-thread pipelined keep pass (0.156–0.166 vs 0.132); 8 rows per thread in the block scatter (26–30 VGPRs
-  spilled); the whole-table fold for the headline.
+  spilled); the whole-table fold for the headline; 10-byte tuples for key-range partitions (scatter 0.56 → 0.71 ms: `ab_slot16.txt`); exact reciprocals, a 32-bit
+  `% 10` and eager projection loads in the one-pass selection kernel (0.537–0.62 vs 0.545: `ab_c2tree_switches.txt`).
 
 ## Open
 
 More than one physical GPU (C5, the xGMI numbers — the preflight is there for the first contact); the partitioned aggregate's scatter
 (4.4–4.8 TB/s of its 2.8 GB: the three-pass floor at 5.5–6 TB/s is ≈ 0.70 ms per 10⁸ rows, it runs at 0.82–0.88); `c2_expression_trees`
-(0.56: neither the look-back nor the store shape bounds the one-pass kernel); joins beyond L2 (line-fetch floor; the 10⁸-row build);
-the sparse 4 K–8 K-group band (two key subsets).
+(0.56: the per-step chain ticket → loads → look-back → stores bounds the one-pass kernel, not its arithmetic, store shape or second load);
+joins beyond L2 (line-fetch floor; the 10⁸-row build); hashed workgroup tables between 2500 and 3072 keys and under pathological key strides.
 """
 open("profiles/r05/README.md", "w").write(text)
