@@ -193,10 +193,18 @@ def test_fuzz_many_groups_partitioned_paths(ctx, seed):
     """enough rows and distinct keys to leave the single LDS table: partitioned (dense and hashed) and two-level paths,
     one and several value-column passes, nullable values"""
     rng = np.random.default_rng(3000 + BASE + seed)
-    n = int(rng.choice([300_000, 700_001, 1_500_000]))
-    groups = int(rng.choice([1500, 3000, 40_000, 900_000]))  # 1500 / 3000: a key RANGE that fits a workgroup table (two / one value column)
+    n = int(rng.choice([300_000, 700_001, 1_500_000, 4_000_000]))
+    # 1500 / 3000: a key RANGE that fits a workgroup table (two / one value column); 3300 .. 7000: between one and two tables' worth (hashed
+    # tables hand over at three quarters of their slots; two key subsets over a direct-mapped table, the range tier, hashed subsets)
+    groups = int(rng.choice([1500, 3000, 3300, 5000, 7000, 40_000, 900_000]))
     null_frac = float(rng.choice([0.0, 0.0, 0.1]))
-    ids = rng.integers(-groups // 2, groups // 2, n).astype(np.int64) if rng.random() < 0.5 else (rng.integers(0, 1 << 50, groups)[rng.integers(0, groups, n)]).astype(np.int64)
+    shape = rng.random()
+    if shape < 0.35:
+        ids = rng.integers(-groups // 2, groups // 2, n).astype(np.int64)
+    elif shape < 0.6:  # the same spread over 2 .. 9 times the range
+        ids = (rng.integers(-groups // 2, groups // 2, n) * int(rng.integers(2, 10)) + int(rng.integers(-50, 50))).astype(np.int64)
+    else:
+        ids = (rng.integers(0, 1 << 50, groups)[rng.integers(0, groups, n)]).astype(np.int64)
     mask = (lambda: None if null_frac == 0 else rng.random(n) >= null_frac)
     cols = [Column.from_numpy(ids), Column.from_numpy(rng.integers(-1000, 1000, n).astype(np.int64), mask()), Column.from_numpy(rng.random(n) * 10, mask()),
             Column.from_numpy(rng.integers(0, 1 << 30, n).astype(np.uint64)), Column.from_numpy(rng.random(n) < 0.5)]
@@ -216,6 +224,9 @@ def test_fuzz_many_groups_partitioned_paths(ctx, seed):
         if exp is not None:
             exact = [i for i, (f, _) in enumerate(aggs) if f == AggregateFunc.Count]
             assert_rows_multiset_equal(got, exp, RTOL, exact_cols=exact, what=what)
+            # the second execution starts from what the first one remembered (plan hint, key range)
+            again = ctx.aggregate(t, aggs, group_nodes=flat(key), pred_nodes=flat(pred)).to_host()
+            assert_rows_multiset_equal(again, exp, RTOL, exact_cols=exact, what=what + " (second execution)")
 
 
 @pytest.mark.parametrize("seed", range(4 + EXTRA // 4))
