@@ -2378,8 +2378,8 @@ PassStatus AggRun::tier_streaming(int v0) {
         ka.direct_span = range_span;
         while (ka.direct_rep < 6 && (range_span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
         // ... or the tables of 2^subsets_log2 workgroups that share their rows, each holding a consecutive range of lds_cap keys (pick_key_range
-        // turns the range on under subsets for one value column only: lds_cap = 4096)
-        if (subsets_log2) ka.direct_sub_shift = 12;
+        // turns the range on under subsets for one value column only: lds_cap = 4096, direct_sub_shift = 12)
+        if (subsets_log2) ka.direct_sub_shift = 63 - __builtin_clzll(uint64_t(ka.lds_cap)); // (lds_cap is a power of two)
     }
     ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
     // the value column is the key column itself (and the predicate, if any, tests it too): the single-load instance

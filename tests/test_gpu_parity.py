@@ -1988,6 +1988,20 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
             assert "agg_partition_scatter" not in names and names["agg_grouped_fast"][1] == 1, names
         if rep == 2 and kind != "sparse":
             assert "agg_fold_partials" in names and "agg_range_emit" in names, names
+    # the keys come out in order, and the per-shard states of the multi-GPU path (nqe_aggregate_partial: count, sum, min, max per group) take
+    # the same route: merged with themselves they are the single-pass result with doubled counts and sums
+    got, gk = ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred, with_keys=True)
+    kk = gk.to_host()[0].to_numpy()
+    assert (np.sort(kk) == kk).all() and len(np.unique(kk)) == len(kk), f"{kind}: keys not in order"
+    st, sk = ctx.aggregate_partial(t, aggs, group_nodes=key, pred_nodes=pred)
+    assert (sk.to_host()[0].to_numpy() == kk).all()
+    merged, mk = ctx.aggregate_merge([st, st], [sk, sk], aggs)
+    assert (mk.to_host()[0].to_numpy() == kk).all()
+    one, two = got.to_host(), merged.to_host()
+    for i, (fn, _) in enumerate(aggs):
+        a1, a2 = one[i].to_numpy().astype(np.float64), two[i].to_numpy().astype(np.float64)
+        factor = 2.0 if fn in (AggregateFunc.Count, AggregateFunc.Sum) else 1.0
+        assert np.allclose(a2, a1 * factor, rtol=1e-9, atol=0.0, equal_nan=True), f"{kind}: merged partial states, aggregate {i}"
     # the same buffer, other contents: a few keys outside the remembered range (above and below)
     k2 = k.copy()
     k2[::1000] = k2[::1000] + dt(100_000)
