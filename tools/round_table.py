@@ -50,6 +50,7 @@ NOTES = {
     "agg_65536_groups": "kernel time now includes the range tier's tail (agg_range_emit); r04's dense tail was not counted",
     "agg_1048576_groups": "kernel time now includes the range tier's tail (agg_range_emit); r04's dense tail was not counted",
     "agg_4096_groups": "kernel time now includes agg_fold_partials",
+    "agg_6000_groups": "new in round 5 (two key subsets over a direct-mapped table; round 4's form measured 1.18 ms per step: ab_groups_landscape_before.txt)",
     "agg_three_value_columns": "kernel time now includes agg_fold_partials",
     "agg_readme_shape": "kernel time now includes agg_fold_partials",
     "c2": "parity now over all 10^8 rows (r04: 2 x 10^7)",

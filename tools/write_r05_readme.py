@@ -22,6 +22,9 @@ file by `tools/write_r05_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | `probe_*.txt`, `micro_bench.txt` | the diagnostic sweeps of earlier rounds, re-run on this revision |
 | `compact_bench.txt`, `scatter_bench.txt`, `scatter_bench2.txt`, `mall_bench.txt` | this round's microbenchmarks (`tools/compact_bench.hip`: variants of C2's two kernels; `tools/scatter_bench.hip`: a synthetic partitioning pass — streams, run alignment, record layout; `tools/mall_bench.hip`: does the Infinity Cache absorb a write → read hand-over between kernels) |
 | `ab_c2.txt`, `ab_c2tree.txt`, `ab_groups*.txt` | A/B of this round's switches through `bench.py` on one box |
+| `ab_groups_landscape_before.txt`, `ab_direct_subsets.txt`, `ab_direct_subsets_tail.txt` | 10⁸ rows over 1024 … 65536 random groups before the direct-mapped key subsets (5000–7000 groups were SLOWER than 8192), and the 4500–8000-group band with / without them, with the sort tail and with the range tier's tail |
+| `probe_sparse_groups.txt`, `probe_hashed_curve.txt` | `tools/probe_sparse_groups.py`: keys spread over 7× / 10⁶× / 2× their number — hashed workgroup tables by load (2500 keys 0.32 ms … 3500 keys 1.71), two hashed subsets against the partitioned path's range tier, before and after the load limit |
+| `ab_slot16.txt`, `ab_c2tree_switches.txt` | two experiments that were reverted: 10-byte tuples for key-range partitions; exact reciprocals / 32-bit `%` / eager projection loads in the one-pass selection + projection kernel |
 | `../r05_notes.md` | the raw measurement notes the sections of DESIGN.md were written from |
 
 ## The bench line
