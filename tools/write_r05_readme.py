@@ -24,6 +24,7 @@ file by `tools/write_r05_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | `ab_c2.txt`, `ab_c2tree.txt`, `ab_groups*.txt` | A/B of this round's switches through `bench.py` on one box |
 | `ab_groups_landscape_before.txt`, `ab_direct_subsets.txt`, `ab_direct_subsets_tail.txt` | 10⁸ rows over 1024 … 65536 random groups before the direct-mapped key subsets (5000–7000 groups were SLOWER than 8192), and the 4500–8000-group band with / without them, with the sort tail and with the range tier's tail |
 | `probe_sparse_groups.txt`, `probe_hashed_curve.txt` | `tools/probe_sparse_groups.py`: keys spread over 7× / 10⁶× / 2× their number — hashed workgroup tables by load (2500 keys 0.32 ms … 3500 keys 1.71), two hashed subsets against the partitioned path's range tier, before and after the load limit |
+| `blocked_probe_bench.txt` | `tools/blocked_probe_bench.hip`: the blocked probe VERDICT r04 asked to measure (tiles of 2²² rows partitioned by table slice, looked up per slice, written back by row position) against the direct gather: 3.7–3.9 ms vs 1.93 ms over an 80 MB table — the line-fetch floor stands (DESIGN §3.7) |
 | `ab_slot16.txt`, `ab_c2tree_switches.txt` | two experiments that were reverted: 10-byte tuples for key-range partitions; exact reciprocals / 32-bit `%` / eager projection loads in the one-pass selection + projection kernel |
 | `../r05_notes.md` | the raw measurement notes the sections of DESIGN.md were written from |
 
@@ -69,6 +70,8 @@ another definition.
   context and listed in DESIGN §9; shapes the streaming kernel does not cover (`group by k` without aggregates, count over Utf8 /
   Boolean) no longer start partitioned on a dense table (ADVICE r04 high); the JIT disk cache trusts only a directory owned by this
   user alone and deletes what fails to load; the one-pass selection's worst-case outputs fall back on out-of-memory.
+* **Joins beyond L2: the blocked probe, measured** (`blocked_probe_bench.txt`): 3.7–3.9 ms against 1.93 ms for the direct gather over an
+  80 MB table (2.86 vs 1.67 over 25.6 MB) — the tile-local scatter by row position costs as much as the line fetches it was to replace.
 * Tried and left out, with numbers (`../r05_notes.md`): chunking the partitioned passes to keep the tuples in the Infinity Cache (no
   gain: `mall_bench.txt`); LDS-staged outputs and other step sizes in the one-pass selection + projection kernel (0.558 → 0.572 ms;
   0.537–0.618); a 1024-thread pipelined keep pass (0.156–0.166 vs 0.132); 8 rows per thread in the block scatter (26–30 VGPRs
