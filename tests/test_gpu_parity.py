@@ -1985,7 +1985,9 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
         if rep >= 1 and kind == "sparse":  # 15000 values: the partitioned path's range tier (two HASHED subsets are slower than that)
             assert "agg_partition_scatter" in names and "agg_grouped_fast" not in names, names
         elif rep >= 1:
-            assert "agg_partition_scatter" not in names and names["agg_grouped_fast"][1] == 1, names
+            # (NQE_NO_PLAN_HINTS: nothing is remembered — a query under a predicate overflows its single table on every execution first)
+            launches = (1, 2) if os.environ.get("NQE_NO_PLAN_HINTS") and kind == "predicate" else (1,)
+            assert "agg_partition_scatter" not in names and names["agg_grouped_fast"][1] in launches, names
         if rep == 2 and kind != "sparse":
             assert "agg_fold_partials" in names and "agg_range_emit" in names, names
     # the keys come out in order, and the per-shard states of the multi-GPU path (nqe_aggregate_partial: count, sum, min, max per group) take
