@@ -147,6 +147,7 @@ __device__ __forceinline__ uint64_t probe_one(const ulonglong2 *__restrict__ slo
 // sort-based build below, which handles duplicates (and their ascending-build-row order).
 // unsigned min / max of (value ^ flip) over up to MAX_JOIN_COLS columns in one launch: blockIdx.y = column; one atomic pair per
 // workgroup (per wave it was 16 K same-address atomics at ~12 ns each = 0.2 ms of a 1e6-row build)
+typedef unsigned long long nt_u64x2 __attribute__((ext_vector_type(2))); // (what __builtin_nontemporal_load takes for a 16-byte access)
 struct MinMaxCols {
     const uint64_t *src[MAX_JOIN_COLS];
     uint64_t flip[MAX_JOIN_COLS];
@@ -163,7 +164,34 @@ __global__ void __launch_bounds__(256) minmax_cols_kernel(MinMaxCols mc, int64_t
     // four independent loads in flight per thread (one at a time read 1.6 GB of a 10^8-row build side at 3.2 TB/s: 0.50 ms of the build)
     const int64_t stride = int64_t(gridDim.x) * blockDim.x, last = n - 1;
     const bool want_desc = c == 0 && descents != nullptr;
-    for (int64_t i0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    // 16-byte-aligned columns (the library's own always are): PAIRS of words in 16-byte non-temporal loads, four in flight — the word before
+    // a pair (the descent test across pairs) is the lane below's second word; lane 0 reads it
+    const int64_t npairs = (reinterpret_cast<uintptr_t>(v) & 15) == 0 ? n / 2 : 0;
+    for (int64_t p0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p0 - threadIdx.x % 64 < npairs; p0 += 4 * stride) { // (whole waves stay in the loop: shuffles)
+        nt_u64x2 x[4];
+        uint64_t before[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + u * stride, pc = p < npairs ? p : npairs - 1;
+            x[u] = __builtin_nontemporal_load(reinterpret_cast<const nt_u64x2 *>(v) + pc);
+            before[u] = (want_desc && lane_id() == 0 && pc > 0) ? v[2 * pc - 1] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + u * stride;
+            const uint64_t a = x[u].x ^ flip, b = x[u].y ^ flip;
+            uint64_t prev = __shfl_up((unsigned long long)b, 1, 64); // (the lane below holds the pair before this one: consecutive lanes, consecutive pairs)
+            if (lane_id() == 0) prev = before[u] ^ flip;
+            if (p >= npairs) continue;
+            mn = a < mn ? a : mn;
+            mn = b < mn ? b : mn;
+            mx = a > mx ? a : mx;
+            mx = b > mx ? b : mx;
+            if (want_desc) desc += (a > b ? 1u : 0u) + ((p > 0 && prev > a) ? 1u : 0u);
+        }
+    }
+    // (the rest: an odd last word, or the whole column when it is not 16-byte aligned)
+    for (int64_t i0 = 2 * npairs + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
         uint64_t x[4], p[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -257,6 +285,9 @@ __global__ void __launch_bounds__(256) dense_scatter_rows_kernel(const uint64_t 
 }
 // `kord` (the partitioned build below): the entries arrive as key-ordered records of `twp` words {row + 1, payload words…} — the row
 // table is written from them here, and the payloads are read from the record of entry d, not gathered by row.
+// WHOLE (kord with records of two or four words): a record is read in 16-byte loads — a wave's loads then cover its 1 or 2 KB of records
+// once; word-by-word non-temporal loads at a 16-byte stride fetched every line once per word
+template <bool WHOLE>
 __global__ void __launch_bounds__(256) dense_finish_kernel(uint32_t *dense, uint64_t span, uint32_t *presence, DensePayload dp, unsigned long long *occupied,
                                                            const uint64_t *kord, int twp) {
     __shared__ uint32_t pack[4][2 * 25];
@@ -266,8 +297,14 @@ __global__ void __launch_bounds__(256) dense_finish_kernel(uint32_t *dense, uint
     for (uint64_t g = uint64_t(blockIdx.x) * 4 + wave; g < ngroups; g += uint64_t(gridDim.x) * 4) {
         const uint64_t d = g * 64 + lane;
         uint32_t e = 0;
+        nt_u64x2 r0 = {0ull, 0ull}, r1 = r0;
+        constexpr bool whole = WHOLE;
         if (d < span) {
-            if (kord) dense[d] = e = uint32_t(__builtin_nontemporal_load(&kord[d * uint64_t(twp)]));
+            if (whole) {
+                r0 = __builtin_nontemporal_load(reinterpret_cast<const nt_u64x2 *>(kord + d * uint64_t(twp)));
+                if (twp == 4) r1 = __builtin_nontemporal_load(reinterpret_cast<const nt_u64x2 *>(kord + d * uint64_t(twp) + 2));
+                dense[d] = e = uint32_t(r0.x);
+            } else if (kord) dense[d] = e = uint32_t(__builtin_nontemporal_load(&kord[d * uint64_t(twp)]));
             else e = dense[d];
         }
         const bool present = e != 0;
@@ -276,7 +313,10 @@ __global__ void __launch_bounds__(256) dense_finish_kernel(uint32_t *dense, uint
         // presence: bit d of 32-bit words — this wave's 64 entries are words 2g and 2g + 1 (the bitmap is allocated in whole pairs)
         if (presence && lane < 2 && 2 * g + lane < (span + 31) / 32) presence[2 * g + lane] = uint32_t(m >> (32 * lane));
         for (int c = 0; c < dp.n; ++c) {
-            const uint64_t v = present ? (kord ? __builtin_nontemporal_load(&kord[d * uint64_t(twp) + 1 + c]) : dp.src[c][e - 1]) : dp.base[c];
+            const uint64_t v = !present ? dp.base[c]
+                               : whole  ? (c == 0 ? r0.y : (c == 1 ? r1.x : r1.y)) // (twp 2: one payload word; twp 4: up to three)
+                               : kord   ? __builtin_nontemporal_load(&kord[d * uint64_t(twp) + 1 + c])
+                                        : dp.src[c][e - 1];
             const int nb = dp.packed[c];
             if (nb >= 2) {
                 if (lane < 2 * nb) pack[wave][lane] = 0;
@@ -450,6 +490,11 @@ __global__ void __launch_bounds__(256) part_build_place_kernel(PartBuild pb, con
                 if (c0 >= e) break;
                 const uint64_t c1 = c0 + chunk < e ? c0 + chunk : e;
                 for (uint64_t i = c0 + threadIdx.x; i < c1; i += 256) {
+                    if (kord && TW == 2) { // {key - min | row, payload}: one 16-byte load, one 16-byte store
+                        const nt_u64x2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u64x2 *>(tuples + i * 2));
+                        *reinterpret_cast<ulonglong2 *>(kord + uint64_t(uint32_t(t.x >> 32)) * 2) = make_ulonglong2(uint64_t(uint32_t(t.x) + 1u), t.y);
+                        continue;
+                    }
                     const uint64_t w0 = __builtin_nontemporal_load(&tuples[i * TW]);
                     const uint32_t d = uint32_t(w0 >> 32);
                     if (!kord) {
@@ -1358,8 +1403,9 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             launch(ctx, "join_build_part_place", part_build_place_kernel, dim3(unsigned(place_bpc * ctx->num_cus)), dim3(256), 0, pb, (const uint64_t *)offsets->ptr,
                    (const uint64_t *)tuples->ptr, (uint32_t *)dense->ptr, kord ? (uint64_t *)kord->ptr : (uint64_t *)nullptr, twp, (uint32_t *)cursor->ptr, place_by_block, uint32_t(place_chunk));
             BufRef occupied = dev_alloc_zero(ctx, 8);
-            launch(ctx, "join_build_finish", dense_finish_kernel, dim3(stream_grid(ctx, int64_t((span + 63) / 64), 4)), dim3(256), 0, (uint32_t *)dense->ptr, span,
-                   (uint32_t *)presence->ptr, dp, (unsigned long long *)occupied->ptr, kord ? (const uint64_t *)kord->ptr : (const uint64_t *)nullptr, twp);
+            launch(ctx, "join_build_finish", (kord && (twp == 2 || twp == 4)) ? dense_finish_kernel<true> : dense_finish_kernel<false>, dim3(stream_grid(ctx, int64_t((span + 63) / 64), 4)),
+                   dim3(256), 0, (uint32_t *)dense->ptr, span, (uint32_t *)presence->ptr, dp, (unsigned long long *)occupied->ptr,
+                   kord ? (const uint64_t *)kord->ptr : (const uint64_t *)nullptr, twp);
             dup = read_scalar(ctx, (const unsigned long long *)occupied->ptr) != (unsigned long long)n; // (also keeps the tuples and records alive until the kernels are done)
             part_done = true;
             }
@@ -1369,7 +1415,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             // larger builds: scatter row numbers, then finish in key order (see dense_finish_kernel) — no device-scope atomics
             BufRef occupied = dev_alloc_zero(ctx, 8);
             launch(ctx, "join_build_dense", dense_scatter_rows_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, kmin, (uint32_t *)dense->ptr);
-            launch(ctx, "join_build_finish", dense_finish_kernel, dim3(stream_grid(ctx, int64_t((span + 63) / 64), 4)), dim3(256), 0, (uint32_t *)dense->ptr, span,
+            launch(ctx, "join_build_finish", dense_finish_kernel<false>, dim3(stream_grid(ctx, int64_t((span + 63) / 64), 4)), dim3(256), 0, (uint32_t *)dense->ptr, span,
                    (uint32_t *)presence->ptr, dp, (unsigned long long *)occupied->ptr, (const uint64_t *)nullptr, 0);
             dup = read_scalar(ctx, (const unsigned long long *)occupied->ptr) != (unsigned long long)n;
         } else {

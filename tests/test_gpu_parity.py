@@ -1592,6 +1592,44 @@ def test_join_in_which_every_probe_row_matches_shares_the_probe_columns(ctx, key
     del scratch
 
 
+@pytest.mark.parametrize("nb", [70_001, 70_002, 300_000])
+@pytest.mark.parametrize("order", ["random", "ascending", "one_descent"])
+def test_join_build_over_borrowed_columns_that_are_only_word_aligned(ctx, nb, order):
+    """the build's min / max / descents pass reads 16-byte-aligned columns in pairs of words; a BORROWED build column (NQE_DEVICE) need only be
+    8-byte aligned (include/nqe.h) and then takes the word-by-word form — both must find the same range and the same number of descents (an
+    ascending build side is built without the partition passes; a wrong count would only change the form, a wrong range the result), for even
+    and odd row counts, with a descent exactly between two pairs"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    rng = np.random.default_rng(nb + len(order))
+    dk = np.arange(nb, dtype=np.int64) * 3 - 1000
+    if order == "random":
+        dk = dk[rng.permutation(nb)]
+    elif order == "one_descent":
+        dk[[4001, 4002]] = dk[[4002, 4001]]  # rows 4001 > 4002: a descent between the pair (4000, 4001) and the pair (4002, 4003)
+    dv = rng.integers(0, 1 << 18, nb).astype(np.int64)
+    n = 200_003
+    rk = dk[rng.integers(0, nb, n)].copy()
+    rk[::7] = 5  # absent keys
+    rv = rng.random(n)
+    exp = orc.hash_join([[Column.from_numpy(dk), Column.from_numpy(dv)]], [[Column.from_numpy(rk), Column.from_numpy(rv)]], 0, 0)[0]
+    rt = ctx.table_from_host([Column.from_numpy(rk), Column.from_numpy(rv)])
+    bufs = [ctx.device_alloc(nb * 8 + 16) for _ in range(2)]
+    try:
+        for shift in (0, 8):  # aligned to 16 bytes; aligned to 8 only
+            for buf, arr in zip(bufs, (dk, dv)):
+                ctx.synchronize()
+                assert hip.hipMemcpy(ctypes.c_void_p(buf + shift), ctypes.c_void_p(arr.ctypes.data), ctypes.c_size_t(arr.nbytes), 1) == 0
+            assert hip.hipDeviceSynchronize() == 0
+            lt = ctx.table_from_device([(DType.INT64, nb, bufs[0] + shift, None), (DType.INT64, nb, bufs[1] + shift, None)])
+            got = ctx.hash_join(lt, rt, 0, 0).to_host()
+            assert_batches_equal(got, exp, what=f"{order} build keys at +{shift} bytes, {nb} rows")
+            del lt
+    finally:
+        for b in bufs:
+            ctx.device_free(b)
+
+
 @pytest.mark.parametrize("keys", ["dense", "sparse", "dense_gaps", "sparse_two_payloads"])
 @pytest.mark.parametrize("immutable", [False, True])
 def test_join_output_never_aliases_borrowed_probe_memory(ctx, keys, immutable):
