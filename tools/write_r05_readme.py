@@ -70,6 +70,8 @@ another definition.
   context and listed in DESIGN §9; shapes the streaming kernel does not cover (`group by k` without aggregates, count over Utf8 /
   Boolean) no longer start partitioned on a dense table (ADVICE r04 high); the JIT disk cache trusts only a directory owned by this
   user alone and deletes what fails to load; the one-pass selection's worst-case outputs fall back on out-of-memory.
+* **Join build**: the min / max pass in 16-byte loads, records and tuples of one payload word read whole: 10⁸ rows 4.73 → 4.26 ms, 2²⁵ rows
+  1.82 → 1.59 (`probe_build_after.txt`); the place pass is insensitive to its switches (`sweep_build_place.txt`).
 * **Joins beyond L2: the blocked probe, measured** (`blocked_probe_bench.txt`): 3.7–3.9 ms against 1.93 ms for the direct gather over an
   80 MB table (2.86 vs 1.67 over 25.6 MB) — the tile-local scatter by row position costs as much as the line fetches it was to replace.
 * Tried and left out, with numbers (`../r05_notes.md`): chunking the partitioned passes to keep the tuples in the Infinity Cache (no
