@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(DR_BLOCK) dense_rank_emit_kernel(GroupTable g,
 constexpr int RE_BLOCK = 1024;
 template <int ITEMS>
 __global__ void __launch_bounds__(RE_BLOCK) agg_range_emit_kernel(const RangeRec *__restrict__ tab, int parts_log2, int Q, uint32_t W, uint64_t span, uint64_t key_min,
-                                                                  unsigned long long *status, uint64_t *out_keys, FinalizeArgs f, uint32_t *total) {
+                                                                  unsigned long long *status, uint64_t *out_keys, FinalizeArgs f, unsigned long long *total) {
     constexpr int KB = RE_BLOCK * ITEMS; // keys per block
     extern __shared__ __attribute__((aligned(16))) unsigned char re_smem[];
     double *lsum = reinterpret_cast<double *>(re_smem);
@@ -850,12 +850,29 @@ __global__ void __launch_bounds__(RE_BLOCK) agg_range_emit_kernel(const RangeRec
         if (lane_id() == 0) {
             __hip_atomic_store(&status[1 + c], ((excl + tot) << 2) | 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             s_excl = excl;
-            if (c + 1 == nblocks) *total = uint32_t(excl + tot);
+            if (c + 1 == nblocks) total[0] = excl + tot; // the group count; total[1] / total[2]: ~(first key - key_min) / last key - key_min (below)
         }
     }
     __syncthreads();
     int64_t r = int64_t(s_excl) + before + wexcl;
     const uint64_t key0 = key_min + (uint64_t(s0) << parts_log2) + j0;
+    // the exact range of the keys, for the host (the next execution cuts its partitions from it): the block's first and last occupied key, two
+    // atomics per block on zeroed words (the minimum as the maximum of the complement)
+    if (mine) {
+        const uint64_t d0 = (uint64_t(s0) << parts_log2) + j0;
+        if (before + wexcl == 0) {
+            int u0 = 0;
+#pragma unroll
+            for (int u = ITEMS - 1; u >= 0; --u) u0 = cnts[u] ? u : u0;
+            atomicMax(&total[1], ~(unsigned long long)(d0 + uint64_t(u0)));
+        }
+        if (before + wexcl + mine == tot) {
+            int u1 = 0;
+#pragma unroll
+            for (int u = 0; u < ITEMS; ++u) u1 = cnts[u] ? u : u1;
+            atomicMax(&total[2], (unsigned long long)(d0 + uint64_t(u1)));
+        }
+    }
 #pragma unroll
     for (int u = 0; u < ITEMS; ++u) {
         if (!cnts[u]) continue;
@@ -882,14 +899,6 @@ __global__ void __launch_bounds__(RE_BLOCK) agg_range_emit_kernel(const RangeRec
         }
         ++r;
     }
-}
-
-// the group count and — the keys being written in order — the exact key range, in one place for the host (read back with the flags)
-__global__ void agg_range_summary_kernel(const uint32_t *total, const uint64_t *keys, uint64_t *out) {
-    const uint32_t G = *total;
-    out[0] = G;
-    out[1] = G ? keys[0] : 0;
-    out[2] = G ? keys[G - 1] : 0;
 }
 
 // Tail of a SMALL hashed table (the first-attempt 8192-slot table: the headline's 1024 groups): collect + sort + finalize in one
@@ -1539,6 +1548,7 @@ struct AggRun {
     TableBufs tb;
     bool tiny_ok = true, tiny_used = false; // the register-resident kernel for at most four groups (aggregate_tiny.hip)
     AggResult ranged;        // tier_range: outputs allocated for the whole key range, cut to the group count once it has travelled back with the flags
+    uint64_t range_emit_key_min = 0; // ... the key the tail's offsets count from
     BufRef range_total, range_tab, range_status; // ... which agg_range_emit_kernel leaves in range_total; its inputs, kept until the attempt is over
     // ---- the pass (shape_pass)
     bool jit_launched = false, valid_words_ok = true, plain = false, bitmap_pred = false, vnull = false, range_pred = false, chain_pred = false, fast = false, vf64 = true;
@@ -2257,21 +2267,23 @@ void AggRun::range_emit(int parts_log2, int Q, uint32_t rslots, uint64_t span, i
     // keys per thread of the tail: 4096-key blocks for wide ranges, 1024-key blocks to keep narrow ones parallel (NQE_RANGE_EMIT_ITEMS: 1 / 4 for A/B)
     const int items = sw.range_emit_items ? sw.range_emit_items : (span >= (uint64_t(1) << 19) ? 4 : 1);
     const uint32_t kb = uint32_t(RE_BLOCK * items), sb = std::max<uint32_t>(1u, kb >> parts_log2), nblocks = (rslots + sb - 1) / sb;
-    range_status = dev_alloc(ctx, (size_t(nblocks) + 2) * 8);
+    // block statuses (ticket + one word per block), then three zeroed words for the host: the group count, ~(first key - key_min), last key - key_min
+    range_status = dev_alloc(ctx, (size_t(nblocks) + 2 + 4) * 8);
     const BufRef &status = range_status;
-    NQE_HIP_CHECK(hipMemsetAsync(status->ptr, 0, (size_t(nblocks) + 2) * 8, ctx->stream));
-    range_total = dev_alloc_zero(ctx, 32); // [0] the group count (the tail's last block); [1..3] count, first key, last key (agg_range_summary_kernel)
+    NQE_HIP_CHECK(hipMemsetAsync(status->ptr, 0, (size_t(nblocks) + 2 + 4) * 8, ctx->stream));
+    range_total = range_status;
+    range_emit_key_min = uint64_t(key_min);
     auto *st = (unsigned long long *)status->ptr;
+    auto *tot = st + nblocks + 2;
     auto *keys_out = (uint64_t *)ranged.keys->cols[0].values->ptr;
     const size_t eshmem = size_t(kb) * 28;
     if (items == 4)
         launch(ctx, "agg_range_emit", agg_range_emit_kernel<4>, dim3(nblocks), dim3(RE_BLOCK), eshmem, (const RangeRec *)tab->ptr, parts_log2, Q, rslots, span, uint64_t(key_min), st, keys_out,
-               f, (uint32_t *)range_total->ptr);
+               f, tot);
     else
         launch(ctx, "agg_range_emit", agg_range_emit_kernel<1>, dim3(nblocks), dim3(RE_BLOCK), eshmem, (const RangeRec *)tab->ptr, parts_log2, Q, rslots, span, uint64_t(key_min), st, keys_out,
-               f, (uint32_t *)range_total->ptr);
-    launch(ctx, "agg_range_summary", agg_range_summary_kernel, dim3(1), dim3(1), 0, (const uint32_t *)range_total->ptr, (const uint64_t *)keys_out, (uint64_t *)range_total->ptr + 1);
-    NQE_HIP_CHECK(hipMemcpyAsync(ctx->h_flags + NQE_NUM_FLAGS, (const uint64_t *)range_total->ptr + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
+               f, tot);
+    NQE_HIP_CHECK(hipMemcpyAsync(ctx->h_flags + NQE_NUM_FLAGS, tot, 24, hipMemcpyDeviceToHost, ctx->stream));
 }
 
 void AggRun::tier_exact() {
@@ -2773,6 +2785,8 @@ bool AggRun::finish_attempt(AggResult *out) {
         uint64_t sum3[3];
         std::memcpy(sum3, (const void *)(ctx->h_flags + NQE_NUM_FLAGS), sizeof(sum3));
         const int64_t G = int64_t(sum3[0]);
+        sum3[1] = range_emit_key_min + ~sum3[1]; // (the tail leaves offsets from key_min: the first one complemented)
+        sum3[2] = range_emit_key_min + sum3[2];
         set_group_count(ranged, G);
         if (hint_key && G > 0) { // the exact range of the groups (the keys come out in order): the next execution cuts its partitions from it
             const uint64_t flip = kinfo.out_dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
