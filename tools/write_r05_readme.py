@@ -15,6 +15,7 @@ file by `tools/write_r05_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 |---|---|
 | `bench_default.json`, `bench_details.json` | the default `python bench.py` line (25 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity), per-kernel details |
 | `bench_default_box2.json`, `bench_details_box2.json` | the same default line on ANOTHER box of the pool, a few csrc revisions earlier (no steady-state aggregate / selection kernel differs): headline kernel 2.55 ms = 0.784 there; this round's other full runs gave 2.316 (0.864), 2.405 (0.831), 2.421 (0.826) and `bench_default.json`'s own figure — the boxes differ by up to 10 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
+| `bench_default_run2.json`, `bench_details_run2.json` | the same default line, SAME csrc revision, run again on another box of the pool minutes later: C2 0.739 (0.712 in `bench_default.json`), C4 0.733 (0.709), headline 0.795 (0.783), `agg_three_value_columns` 0.702 (0.757), `agg_readme_shape` 0.694 (0.731) — what a box and a run are worth: ± 4 % on the stream kernels |
 | `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
 | `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
 | `rocprofv3_kernel_stats_<config>.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --workload … --steps 20 --warmup 3` (its own process: the table below compares its averages with the bench line's HIP-event times) |
