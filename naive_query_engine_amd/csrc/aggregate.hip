@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(RE_BLOCK) agg_range_emit_kernel(const RangeRec
     double *lsum = reinterpret_cast<double *>(re_smem);
     double *lmn = lsum + KB;
     double *lmx = lmn + KB;
-    uint32_t *lcnt = reinterpret_cast<uint32_t *>(lmx + KB);
+    uint64_t *lcnt = reinterpret_cast<uint64_t *>(lmx + KB);
     __shared__ uint32_t s_chunk;
     __shared__ uint32_t wcnt[RE_BLOCK / 64];
     __shared__ unsigned long long s_excl;
@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(RE_BLOCK) agg_range_emit_kernel(const RangeRec
     for (int k = 0; k < ITEMS; ++k) {
         const uint32_t i = uint32_t(k) * RE_BLOCK + threadIdx.x, p = i >> sb_log2, sl = i & (SB - 1), sg = s0 + sl;
         double sum = 0.0, mn = DBL_MAX, mx = -DBL_MAX;
-        uint32_t cnt = 0;
+        uint64_t cnt = 0;
         if (sg < W) {
             const RangeRec *__restrict__ r = tab + size_t(p) * size_t(Q) * size_t(W) + sg;
             for (int q = 0; q < Q; ++q) {
@@ -800,7 +800,7 @@ __global__ void __launch_bounds__(RE_BLOCK) agg_range_emit_kernel(const RangeRec
                 sum += x.sum;
                 mn = x.mn < mn ? x.mn : mn;
                 mx = x.mx > mx ? x.mx : mx;
-                cnt = ((cnt & ~NAN_BIT) + (x.cnt & ~NAN_BIT)) | ((cnt | x.cnt) & NAN_BIT);
+                cnt = ((cnt & ~NAN_BIT64) + (x.cnt & ~NAN_BIT64)) | ((cnt | x.cnt) & NAN_BIT64);
             }
         }
         const uint32_t low = (p ^ range_scramble(sg, parts_log2)) & (parts - 1u), dl = (sl << parts_log2) | low;
@@ -812,7 +812,8 @@ __global__ void __launch_bounds__(RE_BLOCK) agg_range_emit_kernel(const RangeRec
     }
     __syncthreads();
     const uint32_t j0 = threadIdx.x * ITEMS;
-    uint32_t cnts[ITEMS], mine = 0;
+    uint64_t cnts[ITEMS];
+    uint32_t mine = 0;
 #pragma unroll
     for (int u = 0; u < ITEMS; ++u) {
         cnts[u] = lcnt[j0 + u];
@@ -877,8 +878,8 @@ __global__ void __launch_bounds__(RE_BLOCK) agg_range_emit_kernel(const RangeRec
     for (int u = 0; u < ITEMS; ++u) {
         if (!cnts[u]) continue;
         out_keys[r] = key0 + uint64_t(u);
-        const uint64_t cnt = cnts[u] & ~NAN_BIT;
-        const double sum = lsum[j0 + u], mn = lmn[j0 + u], mx = (cnts[u] & NAN_BIT) ? __longlong_as_double(0x7FF8000000000000ll) : lmx[j0 + u];
+        const uint64_t cnt = cnts[u] & ~NAN_BIT64;
+        const double sum = lsum[j0 + u], mn = lmn[j0 + u], mx = (cnts[u] & NAN_BIT64) ? __longlong_as_double(0x7FF8000000000000ll) : lmx[j0 + u];
         if (f.partial) { // (one value column: table slot 0)
             f.out[0][r] = cnt;
             f.out[1][r] = d2u(sum);
@@ -1208,8 +1209,7 @@ __global__ void __launch_bounds__(256) agg_fold_partials_kernel(const double *ps
         r.sum = sum;
         r.mn = mn;
         r.mx = mx;
-        r.cnt = uint32_t(c) | nanm;
-        r.pad = 0;
+        r.cnt = c | (nanm ? NAN_BIT64 : 0ull);
         tab[S] = r;
         return;
     }
@@ -1581,6 +1581,7 @@ struct AggRun {
     PassStatus tier_streaming(int v0);
     void pass_ungrouped(int v0);
     bool finish_attempt(AggResult *out);
+    void keys_to_strings(AggResult &res);
     bool react_to_flags(const int *f, const Collected &pre);
     AggResult run();
 };
@@ -2276,7 +2277,7 @@ void AggRun::range_emit(int parts_log2, int Q, uint32_t rslots, uint64_t span, i
     auto *st = (unsigned long long *)status->ptr;
     auto *tot = st + nblocks + 2;
     auto *keys_out = (uint64_t *)ranged.keys->cols[0].values->ptr;
-    const size_t eshmem = size_t(kb) * 28;
+    const size_t eshmem = size_t(kb) * 32;
     if (items == 4)
         launch(ctx, "agg_range_emit", agg_range_emit_kernel<4>, dim3(nblocks), dim3(RE_BLOCK), eshmem, (const RangeRec *)tab->ptr, parts_log2, Q, rslots, span, uint64_t(key_min), st, keys_out,
                f, tot);
@@ -2417,7 +2418,7 @@ PassStatus AggRun::tier_streaming(int v0) {
             ka.partials = reinterpret_cast<uint64_t>(partials->ptr);
             ka.partial_span = uint32_t(tm);
             const bool mm = a.need_minmax[a.nv - 1] != 0;
-            launch(ctx, "agg_grouped_tiny", pick_tiny_groups_kernel(fp, a.nv, mm, uint32_t(tm), a.val[0].values == a.key_src.values), dim3(fgrid), dim3(AGG_BLOCK), 0, ka, fpred, uint32_t(tm), ctx->d_flags);
+            launch(ctx, "agg_grouped_tiny", pick_tiny_groups_kernel(fp, a.nv, mm, uint32_t(tm), a.val[0].values == a.key_src.values), dim3(fgrid), dim3(AGG_BLOCK), 0, ka, fpred, uint32_t(tm), uint32_t(sw.tiny_unpack_tiles), ctx->d_flags);
             for (int j = 0; j < a.nv; ++j) {
                 const double *ps = reinterpret_cast<const double *>(partials->ptr) + size_t(j) * col_words;
                 launch(ctx, "agg_fold_partials", agg_fold_partials_kernel, dim3((unsigned(tm) + 15) / 16), dim3(256), 0, ps, ps + cells, ps + 2 * cells, reinterpret_cast<const uint32_t *>(ps + 3 * cells),
@@ -2693,6 +2694,11 @@ bool AggRun::react_to_flags(const int *f, const Collected &pre) {
                 range_span = span;
             } else if (range_part_ok && sw.range_tier && span != 0 && span < uint64_t(256) * RANGE_TIER_MAX_SLOTS) {
                 to_subsets = false;
+                if (span < (uint64_t(PARTS) << 12)) { // the measured (exact) range is what the range tier cuts its partitions from, in this execution already
+                    part_min = rt->second.first;
+                    part_span = span;
+                    part_range_sampled = false;
+                }
             }
         }
         if (to_subsets) {
@@ -2739,6 +2745,15 @@ bool AggRun::react_to_flags(const int *f, const Collected &pre) {
         return true;
     }
     return false;
+}
+
+// keys_out of a `group by <Utf8 column>`: every tier aggregates the Int64 codes (representative row of each distinct string,
+// utf8_encode_build); the result carries the strings of those rows.  Every return of finish_attempt passes through here.
+void AggRun::keys_to_strings(AggResult &res) {
+    if (!utf8_key || !res.keys) return;
+    DevColumn codes = res.keys->cols[0];
+    res.keys->cols[0] = take_utf8(ctx, utf8_src, (const int64_t *)codes.words(), codes.length, false);
+    sync(ctx);
 }
 
 // the tail ahead of the flag read-back, the reactions, the result.  false: redo the attempt
@@ -2796,6 +2811,7 @@ bool AggRun::finish_attempt(AggResult *out) {
                 ctx->agg_key_ranges[hint_key ^ PART_RANGE_SALT] = std::make_pair(int64_t(sum3[1]), hi - lo + 1);
             }
         }
+        keys_to_strings(ranged);
         *out = std::move(ranged);
         return true;
     }
@@ -2814,11 +2830,7 @@ bool AggRun::finish_attempt(AggResult *out) {
         res = std::move(ranked);
     } else
         res = emit(ctx, tb, grouped, grouped ? kinfo.out_dtype : NQE_INT64, aggs, naggs, plan.vslot, partial, &pre);
-    if (utf8_key && res.keys) { // keys_out: the strings of the representative rows
-        DevColumn codes = res.keys->cols[0];
-        res.keys->cols[0] = take_utf8(ctx, utf8_src, (const int64_t *)codes.words(), codes.length, false);
-        sync(ctx);
-    }
+    keys_to_strings(res);
     *out = std::move(res);
     return true;
 }

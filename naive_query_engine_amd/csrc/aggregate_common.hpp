@@ -21,6 +21,7 @@ constexpr int NVMAX = 3;   // … of the one kind of instance that takes three (
 constexpr int AGG_U = NQE_AGG_U;   // rows per thread per iteration
 constexpr int AGG_BLOCK = 1024;
 constexpr uint32_t NAN_BIT = 0x80000000u;
+constexpr uint64_t NAN_BIT64 = 0x8000000000000000ull; // the same mark in a 64-bit count (RangeRec)
 
 // order-preserving map f64 -> u64 (non-NaN): integer min/max atomics give the f64 min/max
 __host__ __device__ __forceinline__ uint64_t f64_to_ord(double d) {
@@ -563,7 +564,7 @@ int slab_scatter_rows_per_thread(int pred, int key, int nv);
 int slab_scatter_soa_rows_per_thread(); // the K32 (SoA, whole-block) scatter
 int slab_scatter_wg_per_cu();
 // key-range partitions: partition of d = key - range_min, and the scramble of the slot that rebuilds the key's low bits from (partition, slot)
-__device__ __forceinline__ uint32_t range_scramble(uint32_t hi, int parts_log2) { return (hi * 0x9E3779B1u) >> (32 - parts_log2); }
+__device__ __forceinline__ uint32_t range_scramble(uint32_t hi, int parts_log2) { return uint32_t((uint64_t(hi * 0x9E3779B1u) << parts_log2) >> 32); } // (parts_log2 == 0: 0)
 __device__ __forceinline__ uint32_t range_partition(uint64_t d, int parts_log2) {
     return (uint32_t(d) ^ range_scramble(uint32_t(d >> parts_log2), parts_log2)) & ((1u << parts_log2) - 1u);
 }
@@ -578,10 +579,10 @@ __device__ __forceinline__ uint32_t range_partition(uint64_t d, int parts_log2) 
 // keys, pos[key - min] = slot + 1, one gathered read of five state words per group: 0.21 ms per step at 2^20 groups) is gone.
 struct __attribute__((aligned(16))) RangeRec {
     double sum, mn, mx;
-    uint32_t cnt, pad; // cnt: rows | NAN_BIT
+    uint64_t cnt; // rows | NAN_BIT64 (64 bits: a group's rows over all workgroups may pass 2^31 on a 288 GB part)
 };
 // at most four groups (`col % m`, m <= 4): the group state in registers (aggregate_tiny.hip); partials in the layout of AggArgs::partials
-using TinyGroupsKernel = void (*)(AggArgs, FastPred, uint32_t, int *);
+using TinyGroupsKernel = void (*)(AggArgs, FastPred, uint32_t, uint32_t, int *); // (…, m, tiles between two unpackings of the packed counters, flags)
 TinyGroupsKernel pick_tiny_groups_kernel(int pred, int nv, bool minmax_last, uint32_t m, bool first_value_is_key);
 using RangeSegmentsKernel = void (*)(AggArgs, SlabArgs, int, RangeRec *);
 RangeSegmentsKernel pick_range_segments_kernel(bool vf64);

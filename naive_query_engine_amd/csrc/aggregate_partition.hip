@@ -1279,8 +1279,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_range_segments_kernel(AggArgs a
         r.sum = lsum[s];
         r.mn = lmn[s];
         r.mx = lmx[s];
-        r.cnt = lcnt[s];
-        r.pad = 0;
+        r.cnt = uint64_t(lcnt[s] & ~NAN_BIT) | ((lcnt[s] & NAN_BIT) ? NAN_BIT64 : 0ull); // (one workgroup's rows of a pass: below 2^31)
         mine[s] = r;
     }
 }

@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t mod_small(uint64_t x, uint32_t m) {
 // PRED: 0 none, 1 an integer range test on the key column.  NVT value columns, MM: min / max of the LAST one.  TG_K accumulator sets
 // (>= m).  SH0: the FIRST value column is the key column itself (`count(id) … group by id % 3`): its words are the key words.
 template <int PRED, int NVT, bool MM, int TG_K, bool SH0>
-__global__ void __launch_bounds__(AGG_BLOCK) agg_tiny_groups_kernel(AggArgs a, FastPred fp, uint32_t m, int *flags) {
+__global__ void __launch_bounds__(AGG_BLOCK) agg_tiny_groups_kernel(AggArgs a, FastPred fp, uint32_t m, uint32_t unpack_tiles, int *flags) {
     constexpr int TG_U = NQE_TINY_U; // rows per lane per register tile
     constexpr int NL = SH0 ? NVT - 1 : NVT; // value columns that are loaded
     const uint64_t *__restrict__ keyp = static_cast<const uint64_t *>(a.key_src.values);
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_tiny_groups_kernel(AggArgs a, F
             }
         }
     };
-    // Per row: ONE packed count update (a 64-bit word of TG_K fields of 64 / TG_K bits: `1 << (bits * key)` — unpacked every 4096 tiles, long
+    // Per row: ONE packed count update (a 64-bit word of TG_K fields of 64 / TG_K bits: `1 << (bits * key)` — unpacked every unpack_tiles (4096) tiles, long
     // before a field can carry), per key and summed column a selected add (2 v_cndmask + v_add_f64), per key ONE select for both min and max: the
     // row's value with its high word forced to a quiet NaN when the key does not match — v_min_f64 / v_max_f64 return their other operand for a
     // NaN, which is also exactly what a NaN VALUE must do to min (max.rs:38-50; its mark for max is kept per key).
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_tiny_groups_kernel(AggArgs a, F
                 }
             }
         }
-        if (++tiles_packed == 4096u) unpack(); // (4096 tiles x TG_U rows < 2^16: no field of the packed counter has carried)
+        if (++tiles_packed == unpack_tiles) unpack(); // (unpack_tiles <= 4096: 4096 tiles x TG_U rows < 2^16 — no field of the packed counter has carried; AggSwitches::tiny_unpack_tiles)
     };
     {
         Tile A, B;

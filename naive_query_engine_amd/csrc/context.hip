@@ -28,6 +28,7 @@ void AggSwitches::read_environment() {
     lds_load_limit = num("NQE_LDS_LOAD_LIMIT", 1) != 0;
     direct_subsets = num("NQE_DIRECT_SUBSETS", 1) != 0;
     { const int it = num("NQE_RANGE_EMIT_ITEMS", 0); range_emit_items = (it == 1 || it == 4) ? it : 0; }
+    tiny_unpack_tiles = std::min(4096, std::max(1, num("NQE_TINY_UNPACK_TILES", 4096)));
     debug = getenv("NQE_DEBUG") != nullptr;
 }
 

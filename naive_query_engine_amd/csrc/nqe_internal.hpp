@@ -67,6 +67,7 @@ struct AggSwitches {
     int soa_threads = 512;             // NQE_SOA_THREADS: workgroup size of the two-stream scatter (512: two per CU; 1024: one)
     bool direct_subsets = true;        // NQE_DIRECT_SUBSETS=0: two key subsets always hash (round 4), even over a measured key range of up to 2 x 4096 values
     bool lds_load_limit = true;        // NQE_LDS_LOAD_LIMIT=0: a hashed workgroup table of the streaming kernel takes keys until probe sequences fail (round 4), not three quarters of its slots
+    int tiny_unpack_tiles = 4096;      // NQE_TINY_UNPACK_TILES: tiles between two unpackings of the register kernel's packed row counters (1..4096; a TEST hook: at 4096 the branch first runs beyond ~2 x 10^9 rows)
     int range_emit_items = 0;          // NQE_RANGE_EMIT_ITEMS: keys per thread of the range tier's tail (1 or 4; 0 = by the range)
     bool debug = false;                // NQE_DEBUG=1: the tier decisions on stderr
     void read_environment();

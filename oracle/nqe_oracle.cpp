@@ -1372,13 +1372,19 @@ int orc_synth_fill(int32_t kind, uint64_t seed, int64_t first_row, int64_t n, ui
 // `v_dtype`: NQE_FLOAT64, or NQE_INT64 / NQE_UINT64 values accumulated `as f64` (sum.rs:86-101); `has_limit` 0: no predicate (C3);
 // modulus <= 2^21 (the many-group configs: key = a column in [0, G) and modulus = G).  ids must be >= 0 (then the reference's truncated
 // signed `%` is the unsigned one).  NaN-free values (the synthetic columns): min / max are plain compares from -DBL_MAX / DBL_MAX.
-int orc_grouped_parallel(const int64_t *ids, const void *v, int32_t v_dtype, int64_t n, int32_t has_limit, int64_t limit, int64_t modulus, int32_t threads,
-                         double *out) {
+// The masked form adds validity (Arrow semantics as the reference's operators read them): `id_valid` / `v_valid` are byte masks (one
+// uint8_t per row, 0 = NULL; nullptr = no NULLs).  A NULL id makes predicate and key NULL: SelectionPlan emits the row as a NULL row
+// (selection.rs:46, quirk Q4) and the aggregate drops NULL group keys (aggregate/mod.rs:64) — the row counts nowhere.  A NULL value
+// in a row that survives: the group exists, count / sum / min / max skip it (count.rs:63, sum.rs:86-101, max.rs:38).  out: modulus x
+// `stride` doubles = count, sum, min, max and (stride >= 5) the ROWS of the group whatever their value's validity — rows > 0 is what
+// makes a key a group (a group of NULL values only has count 0, sum 0.0, min f64::MAX, max f64::MIN: quirk Q10).
+int orc_grouped_parallel_masked(const int64_t *ids, const uint8_t *id_valid, const void *v, const uint8_t *v_valid, int32_t v_dtype, int64_t n, int32_t has_limit,
+                                int64_t limit, int64_t modulus, int32_t threads, int32_t stride, double *out) {
     return guarded([&] {
-        if (modulus <= 0 || modulus > (int64_t(1) << 21) || threads < 1 || n < 0) fail(NQE_ERR_INVALID_ARGUMENT, "orc_grouped_parallel: bad arguments");
+        if (modulus <= 0 || modulus > (int64_t(1) << 21) || threads < 1 || n < 0 || stride < 4) fail(NQE_ERR_INVALID_ARGUMENT, "orc_grouped_parallel: bad arguments");
         if (v_dtype != NQE_FLOAT64 && v_dtype != NQE_INT64 && v_dtype != NQE_UINT64) fail(NQE_ERR_INVALID_ARGUMENT, "orc_grouped_parallel: value type");
-        struct Acc { uint64_t cnt; double sum, mn, mx; };
-        std::vector<std::vector<Acc>> part(size_t(threads), std::vector<Acc>(size_t(modulus), Acc{0, 0.0, DBL_MAX, -DBL_MAX}));
+        struct Acc { uint64_t cnt, rows; double sum, mn, mx; };
+        std::vector<std::vector<Acc>> part(size_t(threads), std::vector<Acc>(size_t(modulus), Acc{0, 0, 0.0, DBL_MAX, -DBL_MAX}));
         std::vector<int> negative(size_t(threads), 0);
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; ++t)
@@ -1389,10 +1395,13 @@ int orc_grouped_parallel(const int64_t *ids, const void *v, int32_t v_dtype, int
                 const int64_t *vi = static_cast<const int64_t *>(v);
                 const uint64_t *vu = static_cast<const uint64_t *>(v);
                 for (int64_t r = lo; r < hi; ++r) {
+                    if (id_valid && !id_valid[r]) continue;
                     const int64_t id = ids[r];
                     if (id < 0) { negative[size_t(t)] = 1; continue; }
                     if (has_limit && id >= limit) continue;
                     Acc &g = a[uint64_t(id) % uint64_t(modulus)];
+                    g.rows += 1;
+                    if (v_valid && !v_valid[r]) continue;
                     const double x = v_dtype == NQE_FLOAT64 ? vf[r] : v_dtype == NQE_INT64 ? double(vi[r]) : double(vu[r]);
                     g.cnt += 1;
                     g.sum += x;
@@ -1404,17 +1413,25 @@ int orc_grouped_parallel(const int64_t *ids, const void *v, int32_t v_dtype, int
         for (int t = 0; t < threads; ++t)
             if (negative[size_t(t)]) fail(NQE_ERR_INVALID_ARGUMENT, "orc_grouped_parallel: negative id");
         for (int64_t k = 0; k < modulus; ++k) {
-            Acc m{0, 0.0, DBL_MAX, -DBL_MAX};
+            Acc m{0, 0, 0.0, DBL_MAX, -DBL_MAX};
             for (int t = 0; t < threads; ++t) {
                 const Acc &g = part[size_t(t)][size_t(k)];
                 m.cnt += g.cnt;
+                m.rows += g.rows;
                 m.sum += g.sum;
                 m.mn = g.mn < m.mn ? g.mn : m.mn;
                 m.mx = g.mx > m.mx ? g.mx : m.mx;
             }
-            out[4 * k] = double(m.cnt); out[4 * k + 1] = m.sum; out[4 * k + 2] = m.mn; out[4 * k + 3] = m.mx;
+            double *o = out + size_t(stride) * size_t(k);
+            o[0] = double(m.cnt); o[1] = m.sum; o[2] = m.mn; o[3] = m.mx;
+            if (stride >= 5) o[4] = double(m.rows);
         }
     });
+}
+
+int orc_grouped_parallel(const int64_t *ids, const void *v, int32_t v_dtype, int64_t n, int32_t has_limit, int64_t limit, int64_t modulus, int32_t threads,
+                         double *out) {
+    return orc_grouped_parallel_masked(ids, nullptr, v, nullptr, v_dtype, n, has_limit, limit, modulus, threads, 4, out);
 }
 
 int orc_headline_parallel(const int64_t *ids, const double *v, int64_t n, int64_t limit, int64_t modulus, int32_t threads, double *out) {

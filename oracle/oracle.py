@@ -67,6 +67,7 @@ def lib():
         L.orc_synth_fill.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, vp]
         L.orc_headline_parallel.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp]
         L.orc_grouped_parallel.argtypes = [vp, vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, vp]
+        L.orc_grouped_parallel_masked.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp]
         L.orc_synth_fill_mt.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, vp, C.c_int32]
         L.orc_csv_read.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(vp), C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.c_int32]
         L.orc_csv_read.restype = C.c_int
@@ -254,11 +255,13 @@ def headline_parallel(ids, v, limit: int, modulus: int, threads: int):
 
 
 
-def grouped_parallel(ids, v, limit, modulus: int, threads: int):
+def grouped_parallel(ids, v, limit, modulus: int, threads: int, v_valid=None, id_valid=None, with_rows: bool = False):
     """`select count(v), sum(v), min(v), max(v) from t [where id < limit] group by id % modulus` on `threads` threads
     (orc_grouped_parallel: per-thread direct-mapped tables over row ranges, merged) — the form the full-size parity checks use; it is
     itself checked against the reference-faithful single-threaded `aggregate` in tests/test_oracle_golden.py.  `v`: float64, int64 or
-    uint64 (accumulated `as f64`); `limit` None: no predicate.  → float64[modulus, 4] = count, sum, min, max per key (count 0: no rows)"""
+    uint64 (accumulated `as f64`); `limit` None: no predicate.  `v_valid` / `id_valid`: boolean row masks (False = NULL) or None.
+    → float64[modulus, 4] = count, sum, min, max per key (count 0: no non-NULL value); with_rows: a fifth column, the rows of the
+    group whatever their value's validity (rows 0: the key is no group)"""
     import numpy as np
 
     from naive_query_engine_amd import DType
@@ -267,14 +270,22 @@ def grouped_parallel(ids, v, limit, modulus: int, threads: int):
     v = np.ascontiguousarray(v)
     dt = {np.dtype(np.float64): DType.FLOAT64, np.dtype(np.int64): DType.INT64, np.dtype(np.uint64): DType.UINT64}[v.dtype]
     assert v.size == ids.size
-    out = np.zeros((modulus, 4), dtype=np.float64)
-    _check(lib().orc_grouped_parallel(ids.ctypes.data, v.ctypes.data, int(dt), ids.size, 0 if limit is None else 1, 0 if limit is None else int(limit), modulus, threads,
-                                      out.ctypes.data))
+    masks = []
+    for m in (id_valid, v_valid):
+        if m is not None:
+            m = np.ascontiguousarray(m, dtype=np.uint8)
+            assert m.size == ids.size
+        masks.append(m)
+    stride = 5 if with_rows else 4
+    out = np.zeros((modulus, stride), dtype=np.float64)
+    _check(lib().orc_grouped_parallel_masked(ids.ctypes.data, None if masks[0] is None else masks[0].ctypes.data, v.ctypes.data,
+                                             None if masks[1] is None else masks[1].ctypes.data, int(dt), ids.size, 0 if limit is None else 1,
+                                             0 if limit is None else int(limit), modulus, threads, stride, out.ctypes.data))
     return out
 
 
 def merge_grouped(parts):
-    """fold float64[modulus, 4] partials of `grouped_parallel` over disjoint row ranges (counts and sums add; min / max of the extremes)"""
+    """fold float64[modulus, 4 or 5] partials of `grouped_parallel` over disjoint row ranges (counts, sums and rows add; min / max of the extremes)"""
     import numpy as np
 
     acc = None
@@ -286,7 +297,49 @@ def merge_grouped(parts):
             acc[:, 1] += p[:, 1]
             acc[:, 2] = np.minimum(acc[:, 2], p[:, 2])
             acc[:, 3] = np.maximum(acc[:, 3], p[:, 3])
+            if acc.shape[1] > 4:
+                acc[:, 4] += p[:, 4]
     return acc
+
+
+def grouped_columns_parallel(ids, cols, limit, modulus: int, threads: int, valid=None, id_valid=None):
+    """`grouped_parallel` once per value column of a query with several: cols = {column index: array}, valid = {column index: bool
+    mask} (missing: no NULLs) → {column index: float64[modulus, 5]} (count, sum, min, max of the column's non-NULL values per key, and
+    the group's rows).  Partials of disjoint row ranges fold with `merge_grouped_columns`; `finalize_grouped` turns them into the
+    query's output columns."""
+    valid = valid or {}
+    return {c: grouped_parallel(ids, a, limit, modulus, threads, v_valid=valid.get(c), id_valid=id_valid, with_rows=True) for c, a in cols.items()}
+
+
+def merge_grouped_columns(parts):
+    return {c: merge_grouped([p[c] for p in parts]) for c in parts[0]}
+
+
+def finalize_grouped(state, aggs):
+    """{column: float64[modulus, 5]} + the aggregate list [(func, column)] → (keys of the groups in ascending order, one float64 array
+    per aggregate) with the reference's finals: count of non-NULL values (count.rs:76), sum (sum.rs:115), avg = sum / cnt — NaN for a
+    group without values (avg.rs:121), min / max from f64::MAX / f64::MIN (max.rs:30, min.rs)"""
+    import numpy as np
+
+    from naive_query_engine_amd import AggregateFunc as A
+
+    any_col = next(iter(state.values()))
+    live = np.nonzero(any_col[:, 4] > 0)[0]
+    out = []
+    for func, c in aggs:
+        s = state[c][live]
+        if func == A.Count:
+            out.append(s[:, 0])
+        elif func == A.Sum:
+            out.append(s[:, 1])
+        elif func == A.Avg:
+            with np.errstate(invalid="ignore", divide="ignore"):
+                out.append(s[:, 1] / s[:, 0])
+        elif func == A.Min:
+            out.append(s[:, 2])
+        else:
+            out.append(s[:, 3])
+    return live, out
 
 
 def synth_fill_mt(kind: int, seed: int, first_row: int, n: int, modulus: int = 1, base: int = 0, threads: int = 16):

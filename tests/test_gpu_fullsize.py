@@ -333,3 +333,80 @@ def test_c4_1e8_x_1e6_every_output_row_against_the_port(ctx):
             assert (g.to_numpy().view(np.int64) == r.to_numpy().view(np.int64)).all(), f"column {j} differs"
     finally:
         d.free()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the same for the reference's OWN aggregate query (src/main.rs:36-40, README.md:105-111: three different value columns, one
+# with max / min — served by the register-resident kernel of aggregate_tiny.hip) and for the headline over a value column with 1 % NULLs
+# (SURVEY §8d's correctness run), through the k-column / validity form of the parallel CPU aggregate (oracle.grouped_columns_parallel,
+# pinned against the port in tests/test_oracle_golden.py::test_parallel_grouped_columns_form_matches_the_port).
+def cpu_grouped_columns_full(ctx, ids_ptr, cols, n, limit, modulus, valid_bits=None, chunk=1 << 27):
+    """cols = {column index: (dtype, device pointer)}; valid_bits = {column index: uint8[] LSB-first validity bitmap on the host}"""
+    parts = []
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        ids = download_words(ctx, DType.INT64, ids_ptr, lo, hi)
+        host_cols = {c: (ids if p == ids_ptr else download_words(ctx, dt, p, lo, hi)) for c, (dt, p) in cols.items()}
+        masks = {c: np.unpackbits(b[lo // 8:(hi + 7) // 8], bitorder="little")[:hi - lo] for c, b in (valid_bits or {}).items()}
+        parts.append(orc.grouped_columns_parallel(ids, host_cols, limit, modulus, CPU_THREADS, valid=masks))
+        del ids, host_cols, masks
+    return orc.merge_grouped_columns(parts)
+
+
+def assert_agg_columns_equal(out, keys, state, aggs, what):
+    live, exp = orc.finalize_grouped(state, aggs)
+    k = host(keys)[0]
+    assert len(k) == len(live) and (k == live).all(), f"{what}: group keys differ"
+    for (func, c), g, e in zip(aggs, host(out), exp):
+        if func in (AggregateFunc.Count, AggregateFunc.Min, AggregateFunc.Max):
+            assert (g.astype(np.float64) == e).all(), f"{what}: {func.name}({c}) differs"
+        else:
+            assert np.allclose(g, e, rtol=1e-9, atol=0, equal_nan=True), f"{what}: {func.name}({c}) differs beyond 1e-9"
+
+
+@pytest.mark.timeout(900)
+def test_readme_aggregate_query_1e9_rows_every_group_against_the_cpu(ctx):
+    """`select count(id), sum(age), sum(score), avg(score), max(score), min(score) from t group by id % 3` (the reference's own query,
+    src/main.rs:36-40) at 10^9 rows, and C1's `count(id), sum(age), avg(score)`: every output value against the CPU"""
+    n = 10**9
+    d = DevCols(ctx)
+    try:
+        ids, age, score = d.synth(0, 0, n), d.synth(1, 2, n, 0, 60, 18), d.synth(2, 3, n)
+        t = table(ctx, (DType.INT64, n, ids), (DType.INT64, n, age), (DType.FLOAT64, n, score))
+        f = fields("id", "age", "score")
+        key = binop(col(0), Operator.Modulos, lit_i64(3)).flatten(f)
+        state = cpu_grouped_columns_full(ctx, ids, {0: (DType.INT64, ids), 1: (DType.INT64, age), 2: (DType.FLOAT64, score)}, n, None, 3)
+        A = AggregateFunc
+        for aggs in ([(A.Count, 0), (A.Sum, 1), (A.Sum, 2), (A.Avg, 2), (A.Max, 2), (A.Min, 2)], [(A.Count, 0), (A.Sum, 1), (A.Avg, 2)]):
+            out, keys = ctx.aggregate(t, aggs, group_nodes=key, with_keys=True)
+            assert_agg_columns_equal(out, keys, state, aggs, f"README query, {len(aggs)} aggregates")
+    finally:
+        d.free()
+
+
+@pytest.mark.timeout(900)
+def test_headline_1e9_rows_with_null_values_every_group_against_the_cpu(ctx):
+    """the headline over `v Float64` with 1 % NULLs (u(i,4) mod 100 == 0) at 10^9 rows: count skips NULLs, sum / min / max
+    ignore them (count.rs:63, sum.rs:86-101, max.rs:38); the bitmap the GPU reads is the one the CPU unpacks"""
+    n = 10**9
+    d = DevCols(ctx)
+    try:
+        ids, v, u = d.synth(0, 0, n), d.synth(2, 3, n), d.synth(1, 4, n, 0, 100, 0)
+        fu = fields("u")
+        bm = ctx.expr_evaluate(table(ctx, (DType.INT64, n, u)), binop(col(0), Operator.NotEq, lit_i64(0)).flatten(fu))   # Boolean column: its values ARE an LSB-first bitmap
+        info = bm.column_info(0)
+        assert DType(info.dtype) == DType.BOOLEAN and info.length == n and not info.validity
+        bits = bm.download_column(0).values
+        assert int(np.unpackbits(bits[:1 << 20], bitorder="little").sum()) < (1 << 23)      # ~1 % zeros
+        t = ctx.table_from_device([(DType.INT64, n, ids, None), (DType.FLOAT64, n, v, int(info.values))])
+        f = fields("id", "v")
+        key = binop(col(0), Operator.Modulos, lit_i64(1024)).flatten(f)
+        pred = binop(col(0), Operator.Lt, lit_i64(n // 2)).flatten(f)
+        state = cpu_grouped_columns_full(ctx, ids, {1: (DType.FLOAT64, v)}, n, n // 2, 1024, valid_bits={1: bits})
+        nulls = n // 2 - int(state[1][:, 0].sum())
+        assert 0.009 * (n // 2) < nulls < 0.011 * (n // 2) and int(state[1][:, 4].sum()) == n // 2
+        out, keys = ctx.aggregate(t, ALL(1), group_nodes=key, pred_nodes=pred, with_keys=True)
+        assert_agg_columns_equal(out, keys, state, ALL(1), "headline with 1 % NULLs")
+        del t, bm
+    finally:
+        d.free()

@@ -889,6 +889,35 @@ def test_group_by_utf8_key(ctx):
             assert keys.dtype == DType.UTF8 and len(set(keys.to_list())) == keys.length == got.num_rows
 
 
+@pytest.mark.parametrize("distinct", [10000, 70000])
+def test_group_by_utf8_key_many_strings_repeated(ctx, distinct):
+    """`group by <Utf8 column>` with more distinct strings than the workgroup tables hold, on a table large enough for the plan hints
+    (>= 2^18 rows), executed three times: the first execution measures the key range of the Int64 codes, later ones take the tiers
+    that range selects (the range tier writes keys itself) — every one of them must hand back STRINGS, paired with their own groups"""
+    rng = np.random.default_rng(77 + distinct)
+    n = 300000
+    code = rng.integers(0, distinct, n)
+    v = rng.random(n)
+    names = Column.from_list([f"name-{int(c):06d}" + ("é" if c % 5 == 0 else "") for c in code], DType.UTF8)
+    t = ctx.table_from_host([names, Column.from_numpy(v)])
+    f2 = fields("name", "v")
+    cnt = np.bincount(code, minlength=distinct)
+    sm = np.bincount(code, weights=v, minlength=distinct)
+    present = np.nonzero(cnt)[0]
+    exp = {f"name-{int(c):06d}" + ("é" if c % 5 == 0 else ""): (int(cnt[c]), float(sm[c])) for c in present}
+    for rep in range(3):
+        got, gk = ctx.aggregate(t, [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1)], group_nodes=col(0).flatten(f2), with_keys=True)
+        keys = gk.to_host()[0]
+        assert keys.dtype == DType.UTF8, f"execution {rep}: keys_out is {keys.dtype}, not strings"
+        ks = keys.to_list()
+        c_got, s_got = (x.to_numpy() for x in got.to_host())
+        assert len(ks) == len(exp) == got.num_rows and len(set(ks)) == len(ks), f"execution {rep}"
+        e_cnt = np.array([exp[k][0] for k in ks], dtype=np.uint64)
+        e_sum = np.array([exp[k][1] for k in ks])
+        assert np.array_equal(c_got, e_cnt), f"execution {rep}: counts"
+        assert np.allclose(s_got, e_sum, rtol=RTOL, atol=0), f"execution {rep}: sums"
+
+
 @pytest.mark.parametrize("unique", [True, False])
 def test_hash_join_on_utf8_keys(ctx, unique):
     rng = np.random.default_rng(99 + unique)
@@ -2649,7 +2678,8 @@ def test_aggregate_partitioned_path_range_partitions(ctx, shape, monkeypatch):
     elif shape == "predicate":
         k = base
         pred = binop(col(1), Operator.Gt, lit_f64(-20.0))
-        first_direct = False                              # no key sample under a predicate: hashed first, the measured range later
+        # no key sample under a predicate: the streaming attempt overflows, the key range is measured exactly (one pass) and the range
+        # tier cuts its partitions from it in the SAME execution (round 6: ADVICE r05, react_to_flags / NEED_PARTITION)
     elif shape == "skewed":
         k = base.copy()
         k[rng.random(n) < 0.5] = 12_345                   # half the rows in one key: its interval's slabs overflow
@@ -2813,6 +2843,40 @@ def test_aggregate_at_most_four_groups_in_registers(ctx, m, shape):
         kk = gk.to_host()[0].to_numpy()
         assert (np.sort(kk.astype(np.int64)) == np.unique(np.fmod(ids, m) if shape != "uint64_key" else (ids.astype(np.uint64) % np.uint64(m)).astype(np.int64))[
             np.isin(np.unique(np.fmod(ids, m) if shape != "uint64_key" else (ids.astype(np.uint64) % np.uint64(m)).astype(np.int64)), kk.astype(np.int64))]).all()
+
+
+@pytest.mark.parametrize("m", [3, 4])
+def test_register_kernel_unpacks_its_packed_counters_mid_run(m, monkeypatch):
+    """aggregate_tiny.hip keeps the per-key row counts of a lane in ONE packed word and unpacks it every 4096 tiles — a branch a workgroup
+    first reaches beyond ~2 x 10^9 rows.  NQE_TINY_UNPACK_TILES (read once per context, AggSwitches::tiny_unpack_tiles) lowers the
+    period to 2 tiles, so that the branch runs several times per lane at 6 x 10^6 rows: counts exact, everything else within 1e-9
+    against the oracle, for the README's aggregate list, C1's and five aggregates of one column (count.rs:63-76, aggregate/mod.rs:113-222)"""
+    from naive_query_engine_amd import capi
+
+    monkeypatch.setenv("NQE_TINY_UNPACK_TILES", "2")
+    c = capi.Context(0)
+    try:
+        rng = np.random.default_rng(900 + m)
+        n = 6_000_000 + 321
+        ids = rng.integers(0, 1 << 40, n).astype(np.int64)
+        age = rng.integers(18, 78, n).astype(np.int64)
+        score = rng.random(n) * 100.0
+        cols = [Column.from_numpy(ids), Column.from_numpy(age), Column.from_numpy(score)]
+        f3 = fields("id", "age", "score")
+        key = binop(col(0), Operator.Modulos, lit_i64(m)).flatten(f3)
+        t = c.table_from_host(cols)
+        A = AggregateFunc
+        for aggs, pred in (([(A.Count, 0), (A.Sum, 1), (A.Sum, 2), (A.Avg, 2), (A.Max, 2), (A.Min, 2)], None), ([(A.Count, 0), (A.Sum, 1), (A.Avg, 2)], None),
+                           (ALL_AGGS(2), binop(col(0), Operator.Lt, lit_i64(1 << 39)).flatten(f3))):
+            exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=pred)[0]
+            c.timing_enable(True)
+            c.timing_reset()
+            got = c.aggregate(t, aggs, group_nodes=key, pred_nodes=pred)
+            c.timing_enable(False)
+            assert c.timing_query("agg_grouped_tiny")[1] > 0, "the register-resident kernel was expected"
+            assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[i for i, (fn, _) in enumerate(aggs) if fn == A.Count], what=f"unpack period 2, m={m}, {len(aggs)} aggregates")
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("shape", ["range_1_5M_of_2M", "hashed_sparse_1M", "pred_on_other_column", "mod_key_70001"])

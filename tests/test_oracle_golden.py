@@ -289,3 +289,57 @@ def test_parallel_grouped_form_matches_the_port(form):
             g = g[g[:, 0] > 0]                      # keys without rows: not groups
             g = g[np.lexsort(g.T[::-1])]
             assert g.shape == e.shape and (g[:, 0] == e[:, 0]).all() and (g[:, 2:] == e[:, 2:]).all() and np.allclose(g, e, rtol=1e-9, atol=0), (form, threads)
+
+
+@pytest.mark.parametrize("form", ["readme_three_columns", "nullable_values", "nullable_ids_and_values", "all_null_group"])
+def test_parallel_grouped_columns_form_matches_the_port(form):
+    """The k-value-column / validity form of the parallel CPU aggregate (oracle.grouped_columns_parallel + finalize_grouped: what the
+    full-size checks of the reference's own README query — src/main.rs:36-40 — and of the nullable headline use) against the
+    reference-faithful single-threaded port (aggregate/mod.rs:113-222, count.rs, sum.rs, avg.rs, max.rs, min.rs; selection.rs:46 for
+    a NULL predicate): keys exact, counts exact, min / max exact, sum / avg within 1e-9 — NaN averages of value-less groups included"""
+    from naive_query_engine_amd import AggregateFunc as A
+    from naive_query_engine_amd import Operator
+    from naive_query_engine_amd.expression import binop, col, lit_i64
+    from tests.helpers import fields
+
+    n = 150_001
+    ids = orc.synth_fill(0, 0, 0, n).view(np.int64)
+    age = orc.synth_fill(1, 2, 0, n, 60, 18).view(np.int64)
+    score = orc.synth_fill(2, 3, 0, n).view(np.float64)
+    v_ok = orc.synth_fill(1, 4, 0, n, 100, 0).view(np.int64) != 0          # SURVEY 8d: 1 % NULLs
+    id_ok = orc.synth_fill(1, 9, 0, n, 50, 0).view(np.int64) != 0
+    if form == "readme_three_columns":
+        mod, limit, valid, id_valid = 3, None, {}, None
+        cols = {0: ids, 1: age, 2: score}
+        aggs = [(A.Count, 0), (A.Sum, 1), (A.Sum, 2), (A.Avg, 2), (A.Max, 2), (A.Min, 2)]
+    else:
+        mod, limit = 1024, n // 2
+        cols = {2: score}
+        aggs = [(A.Count, 2), (A.Sum, 2), (A.Avg, 2), (A.Min, 2), (A.Max, 2)]
+        valid, id_valid = {2: v_ok}, (id_ok if form == "nullable_ids_and_values" else None)
+        if form == "all_null_group":     # every value of the keys 5 and 700 is NULL: the groups exist, count 0, avg NaN, min f64::MAX, max f64::MIN
+            v_ok = v_ok & (ids % 1024 != 5) & (ids % 1024 != 700)
+            valid = {2: v_ok}
+    f = fields("id", "age", "score")
+    host_cols = [Column.from_numpy(ids, id_valid), Column.from_numpy(age), Column.from_numpy(score, valid.get(2))]
+    key = binop(col(0), Operator.Modulos, lit_i64(mod)).flatten(f)
+    pred = None if limit is None else binop(col(0), Operator.Lt, lit_i64(limit)).flatten(f)
+    ref, = orc.aggregate([host_cols], aggs, group_nodes=key, pred_nodes=pred)       # (the reference's output has no key column: rows as a multiset)
+    e = np.stack([c.to_numpy().astype(np.float64) for c in ref], axis=1)
+    e = e[np.lexsort(e.T[::-1])]
+    exact = [i for i, (func, _) in enumerate(aggs) if func in (A.Count, A.Min, A.Max)]
+    for threads in (1, 5):
+        h = n // 3
+        sl = lambda a, lo, hi: None if a is None else a[lo:hi]
+        parts = [orc.grouped_columns_parallel(ids[lo:hi], {c: a[lo:hi] for c, a in cols.items()}, limit, mod, threads,
+                                              valid={c: m[lo:hi] for c, m in valid.items()}, id_valid=sl(id_valid, lo, hi)) for lo, hi in ((0, h), (h, n))]
+        live, g = orc.finalize_grouped(orc.merge_grouped_columns(parts), aggs)
+        assert (live == np.arange(mod)).all(), (form, threads)                  # every key has rows at this size
+        gm = np.stack(g, axis=1)
+        gm = gm[np.lexsort(gm.T[::-1])]
+        assert gm.shape == e.shape, (form, threads)
+        assert all((gm[:, i] == e[:, i]).all() for i in exact), (form, threads)
+        assert np.allclose(gm, e, rtol=1e-9, atol=0, equal_nan=True), (form, threads)
+    if form == "all_null_group":
+        i5 = int(np.nonzero(live == 5)[0][0])
+        assert g[0][i5] == 0 and g[1][i5] == 0.0 and np.isnan(g[2][i5]) and g[3][i5] == np.finfo(np.float64).max and g[4][i5] == -np.finfo(np.float64).max
