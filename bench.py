@@ -48,7 +48,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable)
-PROFILE_TAG = "r05"    # profiles/<tag>/pmc_traffic_<config>.json are quoted as `roofline.traffic`
+PROFILE_TAG = "r06"    # profiles/<tag>/pmc_traffic_<config>.json are quoted as `roofline.traffic`
 # kernels that do not belong to an operator's step (data generation, diagnostics)
 NOT_STEP_KERNELS = ("synth_fill",)
 LINE_LIMIT = 8000      # bytes of the JSON line
@@ -382,6 +382,10 @@ def attach_spread(res):
     """roofline.kernel_ms_min / _max (and frac_min / frac_max): the summed HIP-event time of the roofline's kernels in EVERY timed
     block of the config, not only the reported (median) one — three boxes disagreed by 8 % on the headline kernel last round"""
     roof = res["roofline"]
+    # the same algorithmic bytes over the step's WALL time (the number the driver's own clock can vouch for; `frac` is over the HIP-event
+    # time of the step's data kernels): launch gaps, scans, tails and the host's part of a step are inside it, so frac_step <= frac
+    if res.get("ms_per_step") and roof.get("algorithmic_bytes_per_step"):
+        roof["frac_step"] = roof["algorithmic_bytes_per_step"] / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     blocks = res["spread"].pop("block_kernels", None)
     names = [k for k in roof.get("kernel", "").split("+") if k]
     if not blocks or not names or not roof.get("kernel_ms_per_step"):
@@ -659,7 +663,7 @@ def wl_c2(B, rows, steps, warmup, random_ids=False, blocks=1, cold=False):
     step = lambda: B.ctx.selection_projection(table, pred, proj)
     cold_ms = B.cold(step) if cold else None
     ms, kernels, spread = B.timed(step, steps, warmup, blocks)
-    names = ["select_fused", "keep_from_simple", "compact_expr"]
+    names = ["select_fused", "keep_from_simple", "scan_single", "scan_chunk", "scan_add", "compact_expr"]  # (the scan of the tile counts runs every step: 13 us of ~290)
     # 16 B/row read + 8 B per kept row written = 20 B/row at 50 %.  The compaction does not read the source words of
     # 4096-row tiles in which nothing was kept: with ids = row numbers the kept rows are the first half, so only that half of `age`
     # moves (16 B/row) — §8d forbids taking that as skip credit, so for sorted ids `frac` is quoted on the bytes that MOVE and the
@@ -723,7 +727,7 @@ def wl_c2_tree(B, rows, steps, warmup, blocks=1, cold=False):
     del r
     B.ctx.jit_wait()
     ms, kernels, spread = B.timed(step, steps, warmup, blocks)
-    names = ["select_project_jit", "expr_jit", "proj_jit", "keep_from_pred", "keep_from_simple", "expr_tree", "expr_tree_compact", "compact_column", "compact_expr"]
+    names = ["select_project_jit", "expr_jit", "proj_jit", "keep_from_pred", "keep_from_simple", "keep_jit", "compact_jit", "scan_single", "scan_chunk", "scan_add", "expr_tree", "expr_tree_compact", "compact_column", "compact_expr"]
     algo = 24.0 * n  # 16 B/row read (id, v) + two 8-byte columns written for half of the rows
     one_pass = any(k.startswith("select_project_jit") for k in kernels)  # predicate, compaction and projection list in ONE kernel: every column read once
     roof = roofline(algo, kernels, names, phys_bytes=algo if one_pass else algo + 8.0 * n + n / 4.0)  # two kernels: + id read by both, the Boolean column written and read
@@ -1112,7 +1116,7 @@ def compact(res):
     out = {"ms": r4(res["ms_per_step"]), "ms_min": r4(res["spread"]["ms_min"]), "ms_max": r4(res["spread"]["ms_max"]),
            "kernel_ms": r4(roof["kernel_ms_per_step"]), "frac": r4(roof["frac"]), "frac_physical": r4(roof.get("frac_physical")),
            "rows": res["rows_per_gpu"]}
-    for k in ("kernel_ms_min", "kernel_ms_max", "frac_8d", "frac_end_to_end", "build_ms", "execute_call_ms", "two_pass_ms", "execute_over_two_pass", "traffic_ratio"):
+    for k in ("frac_step", "kernel_ms_min", "kernel_ms_max", "frac_8d", "frac_end_to_end", "build_ms", "execute_call_ms", "two_pass_ms", "execute_over_two_pass", "traffic_ratio"):
         if roof.get(k) is not None:
             out[k] = r4(roof[k])
     if res.get("cold_ms") is not None:

@@ -18,6 +18,7 @@ def fake_result(i, join=False):
     if join:
         roof.update({"build_ms": 0.15123, "frac_end_to_end": 0.40123, "execute_call_ms": 1.2345, "two_pass_ms": 1.1234, "execute_over_two_pass": 1.0989,
                      "frac_8d": 0.81234, "traffic_ratio": 1.00234})
+    roof["frac_step"] = roof["frac"] * roof["kernel_ms_per_step"] / (2.4612345 + i)
     return {"ms_per_step": 2.4612345 + i, "spread": {"ms_min": 2.4012345, "ms_max": 2.5912345, "blocks": 3, "steps_per_block": 10}, "cold_ms": 3.912345,
             "workload": "select ... " * 20, "rows_per_gpu": 10**9, "roofline": roof,
             "parity_checked": {"rows": 20_000_000, "ok": True, "groups": 1024, "tolerance": "counts exact, f64 rtol 1e-9"},
@@ -52,6 +53,7 @@ def test_line_fits_and_ends_with_summary():
         ms, frac, fphys, ok = d["summary"][n]
         assert ms > 0 and 0 < frac < 1.2 and ok is True
         assert d["configs"][n]["parity"] == {"ok": True, "rows": 20_000_000}
+        assert 0 < d["configs"][n]["frac_step"] <= d["configs"][n]["frac"]      # the step's wall time holds its kernels
     # the trailing 2 KB alone hold the whole summary
     assert line.rfind('"summary"') > len(line) - 2048
     # the contract's keys

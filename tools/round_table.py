@@ -13,7 +13,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from profile_configs import CONFIGS  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 prev = sys.argv[2] if len(sys.argv) > 2 else None
 d = json.load(open(os.path.join("profiles", tag, "bench_default.json")))
 nh_path = os.path.join("profiles", tag, "bench_no_plan_hints.json")

@@ -13,7 +13,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src, dst = os.path.join("gpurun_out", tag), os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
 rev = open(os.path.join(src, "csrc_rev.txt")).read().strip() if os.path.exists(os.path.join(src, "csrc_rev.txt")) else None
