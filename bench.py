@@ -1317,7 +1317,7 @@ def main():
             add("c4_sparse_keys", lambda: wl_c4(B, 10**8, 10**6, "sparse", csteps, cwarm, **kw), pj)
             add("c4_dup_keys", lambda: wl_c4(B, 10**8, 10**6, "dup", csteps, cwarm, **kw), pj)
             add("c4_partial_match", lambda: wl_c4(B, 10**8, 10**6, "partial", csteps, cwarm, **kw), pj)
-            for G in (4096, 6000, 65536, 1 << 20):  # 6000: between one and two workgroup tables (two key subsets over a direct-mapped table)
+            for G in (4096, 5000, 6000, 65536, 1 << 20):  # 5000: one directly addressed table without key words (round 6); 6000: two key subsets over a direct-mapped table
                 add(f"agg_{G}_groups", lambda G=G: wl_aggregate(B, 10**8, False, False, csteps, cwarm, groups=G, **kw), pa(10_000_000))
         else:
             # the headline without its exchange (every rank aggregates its shard only): step time with and without

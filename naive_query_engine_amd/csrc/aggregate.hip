@@ -1477,6 +1477,9 @@ AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const n
     return r;
 }
 
+// one workgroup table of the streaming kernel addressed directly (`col % m`, a measured key range), one value column, no validity bitmaps:
+// the table carries no key words (aggregate_fast_kernel.hpp: nokeys) — 28 bytes per slot, 5841 slots in 160 KB
+constexpr uint64_t DIRECT_WIDE_SLOTS = 5840;
 constexpr uint64_t RANGE_TIER_MAX_SLOTS = 5120;             // slots of one LDS table of the range tier (28 bytes each)
 constexpr uint64_t TINY_SALT = 0xC2B2AE3D27D4EB4Full;       // nqe_ctx::agg_key_ranges[hint ^ salt] present: the tiny-groups kernel met a key outside [0, m)
 constexpr uint64_t PART_RANGE_SALT = 0x9E3779B97F4A7C15ull; // nqe_ctx::agg_key_ranges[hint ^ salt]: the key range of the query's groups (range partitions)
@@ -1541,6 +1544,7 @@ struct AggRun {
     uint64_t hint_key = 0;
     bool any_val_nullable = false, subsets_ok = false, plain_int_key = false, no_hints_env = false, range_sampled = false;
     uint64_t range_limit = 4096, key_flip = 0;
+    uint64_t direct_one_limit = 4096; // values of a key range ONE direct-mapped workgroup table takes (DIRECT_WIDE_SLOTS where the table has no key words)
     // ---- the attempt
     int attempt = 0;
     bool asked_partition = false, dense = false, flagless = false, slab_oom = false, three = false, three_redo = false, dense_redo = false, first_alone = false;
@@ -1582,6 +1586,8 @@ struct AggRun {
     void pass_ungrouped(int v0);
     bool finish_attempt(AggResult *out);
     void keys_to_strings(AggResult &res);
+    // values of a measured key range the streaming tier addresses directly: one table's (direct_one_limit), or 2^subsets_log2 tables of range_limit
+    uint64_t one_table_or_subsets_limit() const { return subsets_log2 ? (range_limit << subsets_log2) : direct_one_limit; }
     bool react_to_flags(const int *f, const Collected &pre);
     AggResult run();
 };
@@ -1794,6 +1800,7 @@ void AggRun::load_hints() {
     // the two-subset instances exist for one value column and sources without validity bitmaps
     subsets_ok = V == 1 && !any_val_nullable && !a.key_src.valid && !(a.pred_mode != 0 && a.pred_src.valid);
     range_limit = V <= 1 ? 4096 : 2048; // the smallest workgroup table among the passes
+    direct_one_limit = (subsets_ok && getenv("NQE_NO_WIDE_DIRECT") == nullptr) ? DIRECT_WIDE_SLOTS : range_limit; // (subsets_ok: one value column, no validity anywhere; the switch: A/B, read per call)
     key_flip = a.key_src.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
     plain_int_key = key_col >= 0 && !utf8_key && a.key.nops == 0 && !a.key_src.valid && (a.key_src.dtype == NQE_INT64 || a.key_src.dtype == NQE_UINT64);
 }
@@ -1829,7 +1836,7 @@ void AggRun::sample_keys() {
     for (int c : plan.val_cols) sample_shape = sample_shape && is_word_type(in->cols[size_t(c)].dtype) && in->cols[size_t(c)].values;
     if (grouped && hint_key && !no_sample && sample_shape && in->rows >= KEY_SAMPLE_MIN_ROWS && a.pred_mode == 0 && !jit_whole && a.key_src.values && !a.key_src.valid && !utf8_key &&
         (a.key_src.dtype == NQE_INT64 || a.key_src.dtype == NQE_UINT64) &&
-        (a.key.nops == 0 || (simple_mod_key && a.key.aux[0].abs_lit > range_limit)) && // (`col % m`, m within a workgroup table: nothing to find out)
+        (a.key.nops == 0 || (simple_mod_key && (key_flip ? 2 * a.key.aux[0].abs_lit - 1 : a.key.aux[0].abs_lit) > direct_one_limit && a.key.aux[0].abs_lit > range_limit)) && // (`col % m`, its keys within a workgroup table: nothing to find out)
         (no_hints_env || (ctx->agg_hints.find(hint_key) == ctx->agg_hints.end() && ctx->agg_key_ranges.find(hint_key) == ctx->agg_key_ranges.end()))) {
         BufRef set = dev_alloc(ctx, (size_t(1) << KEY_SAMPLE_SLOTS_LOG2) * 8), so = dev_alloc(ctx, 32);
         NQE_HIP_CHECK(hipMemsetAsync(set->ptr, 0xFF, (size_t(1) << KEY_SAMPLE_SLOTS_LOG2) * 8, ctx->stream));
@@ -1858,8 +1865,8 @@ void AggRun::sample_keys() {
         const uint64_t sample_span = h[1] >= h[0] ? h[1] - h[0] + 1 : 0;
         // groups ONE workgroup table takes: every key of a range it addresses directly; three quarters of its slots when it hashes (the kernel's own
         // limit, AggArgs::lds_limit: linear probing beyond that load costs more than the next tier)
-        const bool one_direct = plain_int_key && !sw.no_key_range && sample_span != 0 && sample_span <= range_limit;
-        const uint64_t one_limit = (one_direct || !sw.lds_load_limit) ? range_limit : range_limit * 3 / 4;
+        const bool one_direct = plain_int_key && !sw.no_key_range && sample_span != 0 && sample_span <= direct_one_limit;
+        const uint64_t one_limit = one_direct ? direct_one_limit : (!sw.lds_load_limit ? range_limit : range_limit * 3 / 4);
         const bool sub_direct = plain_int_key && !sw.no_key_range && V == 1 && sw.direct_subsets && subsets_ok && sw.subsets_max >= 1 && sample_span != 0 &&
                                 sample_span <= 2 * range_limit;
         const bool tier_instead = !sub_direct && sw.direct_subsets && range_part_ok && V == 1 && sw.range_tier && plain_int_key && sample_span != 0 &&
@@ -1925,10 +1932,11 @@ void AggRun::pick_key_range() {
             if (ctx->agg_key_ranges.size() >= 256) ctx->agg_key_ranges.clear();
             rt = ctx->agg_key_ranges.emplace(hint_key, measure_key_range()).first;
         }
-        if (rt->second.second != 0 && rt->second.second <= (range_limit << subsets_log2)) {
+        if (rt->second.second != 0 && rt->second.second <= one_table_or_subsets_limit()) {
             range_on = true;
             range_min = rt->second.first;
             range_span = rt->second.second;
+            if (range_span > range_limit && subsets_log2 == 0) cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << 1)); // (room in the group table should the fold go through it)
         }
     }
     if (!subsets_ok) subsets_log2 = 0;
@@ -2367,6 +2375,12 @@ PassStatus AggRun::tier_streaming(int v0) {
         ka.lds_shift = 64 - 12;
         fshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
     }
+    // (round 6) a directly addressed table without validity bitmaps has no key words: up to DIRECT_WIDE_SLOTS keys in ONE workgroup table
+    auto widen = [&](uint64_t span) {
+        if (a.nv != 1 || vnull || subsets_log2 != 0 || span > direct_one_limit || span > DIRECT_WIDE_SLOTS) return false;
+        ka.lds_cap = int32_t((span + 15) & ~uint64_t(15));
+        return true;
+    };
     const int lastop = a.key.nops - 1;
     if (fast_key == 1 || fast_key == 2 ||
         (fast_key == 3 && a.key.op[lastop] == NQE_OP_MODULOS && !a.key.lit_left[lastop])) {
@@ -2374,7 +2388,7 @@ PassStatus AggRun::tier_streaming(int v0) {
         const bool sgn = a.key.op_dtype[lastop] == NQE_INT64;
         const uint64_t m = a.key.aux[lastop].abs_lit;
         const uint64_t span = sgn ? 2 * m - 1 : m;
-        if (m > 0 && span <= uint64_t(ka.lds_cap)) {
+        if (m > 0 && (span <= uint64_t(ka.lds_cap) || widen(span))) {
             ka.direct = 1;
             ka.direct_bias = sgn ? int64_t(m) - 1 : 0;
             // few groups: replicate the table so that the lanes of a wave do not all update the same words
@@ -2384,7 +2398,7 @@ PassStatus AggRun::tier_streaming(int v0) {
     }
     ka.direct_sub_shift = 0;
     ka.lds_limit = (ka.allow_partition && sw.lds_load_limit) ? uint32_t(ka.lds_cap) * 3u / 4u : 0u; // (hashed tables only look at it)
-    if (range_on && fast_key == 0 && !ka.direct && range_span <= (uint64_t(ka.lds_cap) << subsets_log2)) {
+    if (range_on && fast_key == 0 && !ka.direct && (range_span <= (uint64_t(ka.lds_cap) << subsets_log2) || widen(range_span))) {
         // the key column's measured range fits the table: slot = key - min, every key checked against the range
         ka.direct = 2;
         ka.direct_bias = int64_t(0ull - uint64_t(range_min));
@@ -2393,6 +2407,11 @@ PassStatus AggRun::tier_streaming(int v0) {
         // ... or the tables of 2^subsets_log2 workgroups that share their rows, each holding a consecutive range of lds_cap keys (pick_key_range
         // turns the range on under subsets for one value column only: lds_cap = 4096, direct_sub_shift = 12)
         if (subsets_log2) ka.direct_sub_shift = 63 - __builtin_clzll(uint64_t(ka.lds_cap)); // (lds_cap is a power of two)
+    }
+    if (ka.direct && !vnull) { // no key words in the table (aggregate_fast_kernel.hpp: nokeys); a widened table: its own slot count
+        const size_t fslots = size_t(ka.lds_cap) + 1;
+        fshmem = a.nv == 1 ? fslots * 28 : fshmem - fslots * 8;
+        fshmem = (fshmem + 15) / 16 * 16;
     }
     ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
     // the value column is the key column itself (and the predicate, if any, tests it too): the single-load instance
@@ -2486,12 +2505,13 @@ PassStatus AggRun::tier_streaming(int v0) {
             const int fsub = ka.direct_sub_shift ? subsets_log2 : 0;
             // the subsets' tables cover the key range in order: folded into ONE table of records the range tier's tail ranks and writes (no global
             // hash table of 16384 slots, no collect / sort / finalize behind a host round trip: ~0.12 ms of a 10^8-row step)
-            const bool to_tail = fsub && V == 1 && sw.range_tier;
+            // (round 6: so does ONE table of more than 4096 keys — its groups would crowd the first attempt's 8192-slot group table)
+            const bool to_tail = (fsub || pspan > 4096) && V == 1 && sw.range_tier;
             if (to_tail) range_tab = dev_alloc(ctx, (size_t(pspan) << fsub) * sizeof(RangeRec) + 64);
             launch(ctx, "agg_fold_partials", agg_fold_partials_kernel, dim3(((pspan << fsub) + 15) / 16), dim3(256), 0, ps, ps + cells, ps + 2 * cells,
                    reinterpret_cast<const uint32_t *>(ps + 3 * cells), fgrid, pspan, ka.direct_bias, mmj ? 1 : 0, tb.g, a.v0 + j, ctx->d_flags, fsub,
                    to_tail ? (RangeRec *)range_tab->ptr : (RangeRec *)nullptr);
-            if (to_tail) range_emit(0, 1, pspan << fsub, range_span, range_min);
+            if (to_tail) range_emit(0, 1, pspan << fsub, fsub ? range_span : uint64_t(pspan), fsub ? range_min : -ka.direct_bias); // (one table: slot s holds the key s - direct_bias)
         }
     }
     }
@@ -2655,7 +2675,7 @@ bool AggRun::react_to_flags(const int *f, const Collected &pre) {
             range_sampled = false;
             const auto exact = measure_key_range(); // the exact range: addressed by key - min after all, or remembered as too wide
             ctx->agg_key_ranges[hint_key] = exact;
-            if (exact.second != 0 && exact.second <= (range_limit << subsets_log2)) {
+            if (exact.second != 0 && exact.second <= one_table_or_subsets_limit()) {
                 range_on = true;
                 range_min = exact.first;
                 range_span = exact.second;
@@ -2688,6 +2708,15 @@ bool AggRun::react_to_flags(const int *f, const Collected &pre) {
                 range_sampled = false;
             }
             const uint64_t span = rt->second.second;
+            if (span != 0 && span <= direct_one_limit) { // ONE table addressed by key - min takes it after all (the hashed attempt gave up at three quarters of its slots)
+                range_on = true;
+                range_min = rt->second.first;
+                range_span = span;
+                cap = std::max(cap, std::min(sized_cap, RANK_MAX_CAP << 1));
+                ctx->agg_hints[hint_key] = uint8_t(key32_failed ? 0x40 : 0);
+                flags_reset(ctx);
+                return true;
+            }
             if (span != 0 && span <= 2 * range_limit) {
                 range_on = true;
                 range_min = rt->second.first;

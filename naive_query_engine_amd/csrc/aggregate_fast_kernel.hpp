@@ -74,8 +74,12 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
     const uint32_t slots = cap + 1;
+    // A direct-mapped table over sources without validity bitmaps never reads a key word (a used slot is one with a count, its key is its
+    // index): the key array is not laid out at all — 28 instead of 36 bytes per slot and value column, so ONE workgroup table takes a key
+    // range of up to 5840 values (160 KB) where it took 4096 (round 6; the host sizes the table: AggRun::tier_streaming)
+    const bool nokeys = !VNULL && a.direct != 0; // wave-uniform
     uint64_t *lkeys = reinterpret_cast<uint64_t *>(smem);
-    double *lsum = reinterpret_cast<double *>(lkeys + slots);            // [NVT][slots]
+    double *lsum = reinterpret_cast<double *>(lkeys + (nokeys ? 0u : slots)); // [NVT][slots]
     // min / max live in LDS as plain doubles (ds_min_f64 / ds_max_f64; a NaN never reaches them: every update is guarded by an
     // ordered compare, which a NaN fails) and take the order-preserving integer form only for the global table at the merge
     // (MM = false — no aggregate of the pass asks for min / max: the two arrays do not exist, 20 instead of 36 bytes per slot and
@@ -90,7 +94,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     volatile int *lds_full = &lds_full_flag;
     if (threadIdx.x == 0) lds_full_flag = 0, lds_used = 0;
     for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
-        lkeys[s] = EMPTY_KEY;
+        if (!nokeys) lkeys[s] = EMPTY_KEY;
 #pragma unroll
         for (int j = 0; j < NVT; ++j) {
             lsum[j * slots + s] = 0.0;

@@ -2086,6 +2086,50 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
         ctx.device_free(p_)
 
 
+@pytest.mark.parametrize("kind", ["range_5000", "range_5840_at_limit", "range_5841_two_subsets", "negative_base", "u64_mod_5000", "predicate", "nan_values", "int_values"])
+def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
+    """4097 .. 5840 values between a key column's min and max (or `col % m`, m <= 5840, UInt64), one value column, no validity bitmaps:
+    ONE directly addressed workgroup table (round 6 — the table carries no key words: 28 bytes per slot), where two workgroups per row
+    range each read every row before; 5841 values still take two key subsets.  Against the oracle on the first, the remembered and a
+    third execution, keys in order, and the same with the switch NQE_NO_WIDE_DIRECT=1 (the two-subset form).  aggregate/mod.rs:113-222"""
+    rng = np.random.default_rng(len(kind) + 600)
+    n = 4_000_000 if kind == "predicate" else 1_200_000
+    groups = {"range_5840_at_limit": 5840, "range_5841_two_subsets": 5841}.get(kind, 5000)
+    base = {"negative_base": -2500, "range_5840_at_limit": 10**12}.get(kind, 0)
+    draw = rng.integers(0, groups, n)
+    draw[:2] = [0, groups - 1]
+    if kind == "u64_mod_5000":
+        kc = Column.from_numpy(rng.integers(0, 1 << 62, n).astype(np.uint64))
+        key = binop(col(0), Operator.Modulos, lit_u64(5000))
+    else:
+        kc = Column.from_numpy((draw + base).astype(np.int64))
+        key = col(0)
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64) if kind == "int_values" else rng.random(n) * 100.0 - 30.0
+    if kind == "nan_values":
+        v[rng.integers(0, n, 50)] = np.nan
+    cols = [kc, Column.from_numpy(v), Column.from_numpy(rng.random(n))]
+    f3 = fields("k", "v", "w")
+    kn = key.flatten(f3)
+    pn = binop(col(2), Operator.Lt, lit_f64(0.5)).flatten(f3) if kind == "predicate" else None
+    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=kn, pred_nodes=pn)[0]
+    t = ctx.table_from_host(cols)
+    for rep in range(3):
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got, gk = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn, pred_nodes=pn, with_keys=True)
+        ctx.timing_enable(False)
+        names = ctx.timing_report()
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{kind} run {rep}")
+        kk = gk.to_host()[0].to_numpy()
+        assert len(np.unique(kk)) == len(kk) == got.num_rows
+        if rep >= 1 and not os.environ.get("NQE_NO_PLAN_HINTS"):
+            assert "agg_partition_scatter" not in names and names["agg_grouped_fast"][1] == 1, names
+    monkeypatch.setenv("NQE_NO_WIDE_DIRECT", "1")
+    monkeypatch.setenv("NQE_NO_PLAN_HINTS", "1")
+    got = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn, pred_nodes=pn)
+    assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{kind}, NQE_NO_WIDE_DIRECT")
+
+
 def test_expression_trees_specialised_at_run_time(ctx, monkeypatch):
     """trees of three or more operators are also compiled to straight-line kernels at run time (csrc/expr_jit.hpp: hipRTC on a worker
     thread; executions switch to the compiled form once it is ready).  Every tree here runs interpreted first, then — after
