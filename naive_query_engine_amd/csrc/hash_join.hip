@@ -454,6 +454,91 @@ __global__ void __launch_bounds__(PB_BLOCK) part_build_scatter_kernel(PartBuild 
         __syncthreads();
     }
 }
+// The same scatter for key-only builds and one payload word (NC = 0 / 1: the shapes of the two-level form), with the tile's words in
+// REGISTERS from the start — the payload word was requested only after two barriers, its whole latency in front of the staging — and
+// the NEXT tile's words requested as soon as this tile's are staged: they arrive during the copy-out.  (One 1024-thread workgroup per
+// CU holds the LDS: nothing else overlaps its phases.)
+template <int NC>
+__global__ void __launch_bounds__(PB_BLOCK) part_build_scatter1_kernel(PartBuild pb, const uint64_t *offsets, uint64_t *tuples) {
+    constexpr int RPT = 8, ROWS = PB_BLOCK * RPT, TW = 1 + NC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *stup = reinterpret_cast<uint64_t *>(smem);                          // [ROWS][TW]
+    uint32_t *gcur = reinterpret_cast<uint32_t *>(stup + size_t(ROWS) * size_t(TW)); // [PB_MAX_PARTS] next tuple of (partition, this workgroup)
+    uint32_t *tcnt = gcur + PB_MAX_PARTS;
+    uint32_t *tstart = tcnt + PB_MAX_PARTS;
+    __shared__ uint32_t wave_tot[PB_BLOCK / 64];
+    const int parts = pb.parts;
+    for (int p = threadIdx.x; p < PB_MAX_PARTS; p += blockDim.x) {
+        gcur[p] = p < parts ? uint32_t(offsets[size_t(p) * size_t(pb.W) + blockIdx.x]) : 0u; // (rows < 2^32)
+        tcnt[p] = 0;
+    }
+    __syncthreads();
+    const int64_t lo = int64_t(blockIdx.x) * pb.chunk;
+    const int64_t hi = lo + pb.chunk < pb.n ? lo + pb.chunk : pb.n;
+    const uint64_t *__restrict__ keys = pb.keys;
+    const uint64_t *__restrict__ pay = NC ? pb.src[0] : pb.keys;
+    uint64_t kw[RPT], pw[NC ? RPT : 1];
+    auto load = [&](int64_t base) {
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            int64_t row = base + int64_t(u) * PB_BLOCK + threadIdx.x;
+            row = row < hi ? row : hi - 1; // clamp: unconditional, in-bounds (lo < hi)
+            kw[u] = __builtin_nontemporal_load(&keys[row]);
+            if (NC) pw[NC ? u : 0] = __builtin_nontemporal_load(&pay[row]);
+        }
+    };
+    if (lo < hi) load(lo);
+    for (int64_t base = lo; base < hi; base += ROWS) {
+        uint32_t d[RPT], rank[RPT];
+        bool ok[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            ok[u] = base + int64_t(u) * PB_BLOCK + threadIdx.x < hi;
+            d[u] = uint32_t(kw[u] - pb.dmin);
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) rank[u] = ok[u] ? atomicAdd(&tcnt[d[u] >> pb.shift], 1u) : 0u;
+        __syncthreads();
+        const uint32_t c = tcnt[threadIdx.x]; // PB_MAX_PARTS == PB_BLOCK: one counter per thread
+        uint32_t wt;
+        const uint32_t ex = wave_exclusive_scan(c, wt);
+        if (lane_id() == 63) wave_tot[threadIdx.x / 64] = wt;
+        __syncthreads();
+        uint32_t pre = 0, tile_total = 0;
+        for (int w = 0; w < PB_BLOCK / 64; ++w) {
+            if (w < int(threadIdx.x) / 64) pre += wave_tot[w];
+            tile_total += wave_tot[w];
+        }
+        tstart[threadIdx.x] = pre + ex;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            if (!ok[u]) continue;
+            const uint32_t row = uint32_t(base + int64_t(u) * PB_BLOCK + threadIdx.x);
+            const uint32_t i = tstart[d[u] >> pb.shift] + rank[u];
+            const uint64_t x = (uint64_t(d[u]) << 32) | uint64_t(row);
+            if (NC) *reinterpret_cast<ulonglong2 *>(&stup[size_t(i) * 2]) = make_ulonglong2(x, pw[NC ? u : 0]);
+            else stup[i] = x;
+        }
+        if (base + ROWS < hi) load(base + ROWS); // (workgroup-uniform) the next tile's words fly during the copy-out
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < tile_total; i += PB_BLOCK) {
+            if (NC) {
+                const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(&stup[size_t(i) * 2]);
+                const uint32_t p = uint32_t(t.x >> 32) >> pb.shift;
+                *reinterpret_cast<ulonglong2 *>(&tuples[(size_t(gcur[p]) + (i - tstart[p])) * 2]) = t;
+            } else {
+                const uint64_t t = stup[i];
+                const uint32_t p = uint32_t(t >> 32) >> pb.shift;
+                tuples[size_t(gcur[p]) + (i - tstart[p])] = t;
+            }
+        }
+        __syncthreads();
+        gcur[threadIdx.x] += tcnt[threadIdx.x];
+        tcnt[threadIdx.x] = 0;
+        __syncthreads();
+    }
+}
 // pass 2: the workgroups of XCD x (HW_REG_XCC_ID — a performance matter only) take the partitions p = x, x + 8, … one after the other,
 // sharing each 2048 tuples at a time through the partition's cursor; afterwards every workgroup sweeps all cursors once and takes
 // what is left (nothing, when the hardware numbers its XCDs 0 … 7), so every tuple is placed whatever the mapping.
@@ -511,6 +596,236 @@ __global__ void __launch_bounds__(256) part_build_place_kernel(PartBuild pb, con
                 }
             }
         }
+    }
+}
+// ---- Two-level form of the partitioned build (round 6): what the place pass pays for is one scattered 16-byte store per row —
+// 1.9 ms per 10^8 rows whatever its slice size, workgroup count or cursor chunk (profiles/r05/sweep_build_place.txt), plus a zeroed
+// 16-byte record per key written and read back (memset 0.3 + finish 0.6 ms).  Here every store is coalesced: the count pass takes a
+// FINE histogram (2^PB_FINE_LOG2 bins per partition, each PB_FILL_KEYS keys wide: fine_count), so that after the usual scatter into
+// partitions a second one — ONE workgroup per partition, a counting sort of 4096-tuple tiles in LDS, runs of a hundred tuples
+// (part_build_split_kernel) — leaves the tuples grouped by fine bin; a fine bin's keys then fit a workgroup's LDS, where its entries
+// are laid out in key order and leave as whole lines of the FINAL tables (row table, presence words, the packed payload column:
+// part_build_fill_kernel) — no key-ordered records, no finish pass.  Key-only builds and builds with one payload word.
+constexpr int PB_FILL_LOG2 = 13, PB_FILL_KEYS = 1 << PB_FILL_LOG2; // keys of a fine bin: 4 + 8 bytes of LDS each
+constexpr int PB_FINE_LOG2 = 5;                                     // fine bins per partition: partition = key >> (PB_FILL_LOG2 + PB_FINE_LOG2)
+constexpr int PB_MAX_FINE = 32768;                                  // bins in all: 128 KB of LDS in the count pass (2.7 x 10^8 keys)
+// count pass: this workgroup's rows per FINE bin in LDS; the partition counts of the scatter's offsets are sums of 2^PB_FINE_LOG2 of them, and the
+// workgroup's fine histogram goes to finehist[w][bin] (added up by part_build_fine_offsets_kernel)
+__global__ void __launch_bounds__(PB_BLOCK) part_build_count_fine_kernel(PartBuild pb, uint32_t *counts, uint32_t *finehist, int bins) {
+    extern __shared__ uint32_t fhist[];
+    for (int b = threadIdx.x; b < bins; b += blockDim.x) fhist[b] = 0;
+    __syncthreads();
+    const int64_t lo = int64_t(blockIdx.x) * pb.chunk;
+    const int64_t hi = lo + pb.chunk < pb.n ? lo + pb.chunk : pb.n;
+    for (int64_t r0 = lo + threadIdx.x; r0 < hi; r0 += 4 * int64_t(blockDim.x)) { // (four loads in flight per thread)
+        uint64_t k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = r0 + u * int64_t(blockDim.x);
+            k[u] = __builtin_nontemporal_load(&pb.keys[r < hi ? r : hi - 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r0 + u * int64_t(blockDim.x) < hi) atomicAdd(&fhist[uint32_t((k[u] - pb.dmin) >> PB_FILL_LOG2)], 1u);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < pb.parts; p += blockDim.x) {
+        uint32_t c = 0;
+        for (int f = 0; f < (1 << PB_FINE_LOG2); ++f) c += (p << PB_FINE_LOG2) + f < bins ? fhist[(p << PB_FINE_LOG2) + f] : 0u;
+        counts[size_t(p) * size_t(pb.W) + blockIdx.x] = c;
+    }
+    for (int b = threadIdx.x; b < bins; b += blockDim.x) finehist[size_t(blockIdx.x) * size_t(bins) + b] = fhist[b];
+}
+// fine_start[b]: where fine bin b's tuples start in the twice-partitioned stream = its partition's start (offsets[p * W], the scatter's
+// scan) + the bins of the partition before it.  One workgroup per partition (thread = bin x an eighth of the count workgroups);
+// fine_start[bins] = rows.
+__global__ void __launch_bounds__(256) part_build_fine_offsets_kernel(const uint32_t *finehist, int W, int bins, int parts, const uint64_t *offsets, uint64_t *fine_start) {
+    constexpr int F = 1 << PB_FINE_LOG2;
+    __shared__ uint32_t part[256 / F][F];
+    const int p = blockIdx.x, f = threadIdx.x % F, q = threadIdx.x / F, b = (p << PB_FINE_LOG2) + f;
+    uint32_t c = 0;
+    if (b < bins)
+        for (int w = q; w < W; w += 256 / F) c += finehist[size_t(w) * size_t(bins) + b];
+    part[q][f] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t at = offsets[size_t(p) * size_t(W)];
+        for (int ff = 0; ff < F && (p << PB_FINE_LOG2) + ff < bins; ++ff) {
+            fine_start[(p << PB_FINE_LOG2) + ff] = at;
+            for (int qq = 0; qq < 256 / F; ++qq) at += part[qq][ff];
+        }
+        if (p == parts - 1) fine_start[bins] = at;
+    }
+}
+// second scatter: workgroup p sorts partition p's tuples (offsets[p * W] .. offsets[(p + 1) * W) of `tuples`) by fine bin into `out`
+// (same positions overall: the partition's range, its bins in order).  Per 4096-tuple tile: rank per bin (LDS atomic), the bins'
+// starts inside the tile, tuples staged in LDS by bin, copy-out in runs — the only writer of its range, so the cursors are its own.
+constexpr int PB_SPLIT_TILE = 4096;
+template <int NC>
+__global__ void __launch_bounds__(PB_BLOCK) part_build_split_kernel(PartBuild pb, const uint64_t *offsets, const uint64_t *fine_start, int bins, const uint64_t *tuples, uint64_t *out) {
+    constexpr int F = 1 << PB_FINE_LOG2, RPT = PB_SPLIT_TILE / PB_BLOCK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
+    uint64_t *stage = reinterpret_cast<uint64_t *>(pb_smem); // [PB_SPLIT_TILE][1 + NC]
+    __shared__ uint32_t tcnt[F], tstart[F + 1];
+    __shared__ uint64_t cur[F];
+    for (int p = blockIdx.x; p < pb.parts; p += gridDim.x) {
+        const uint64_t s = offsets[size_t(p) * size_t(pb.W)], e = offsets[size_t(p + 1) * size_t(pb.W)];
+        __syncthreads(); // (the previous partition's cursors are done with)
+        if (threadIdx.x < F) {
+            const int b = (p << PB_FINE_LOG2) + int(threadIdx.x);
+            cur[threadIdx.x] = b < bins ? fine_start[b] : e;
+            tcnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        uint64_t x[RPT], y[NC ? RPT : 1];
+        auto load = [&](uint64_t base) { // (the partition is not empty: s < e)
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                const uint64_t i = base + uint64_t(u) * PB_BLOCK + threadIdx.x, ic = i < e ? i : e - 1;
+                if (NC) {
+                    const nt_u64x2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u64x2 *>(tuples + ic * 2));
+                    x[u] = t.x;
+                    y[NC ? u : 0] = t.y;
+                } else
+                    x[u] = __builtin_nontemporal_load(&tuples[ic]);
+            }
+        };
+        if (s < e) load(s);
+        for (uint64_t base = s; base < e; base += PB_SPLIT_TILE) {
+            uint32_t f[RPT], rank[RPT];
+            bool ok[RPT];
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                ok[u] = base + uint64_t(u) * PB_BLOCK + threadIdx.x < e;
+                f[u] = (uint32_t(x[u] >> 32) >> PB_FILL_LOG2) & uint32_t(F - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) rank[u] = ok[u] ? atomicAdd(&tcnt[f[u]], 1u) : 0u;
+            __syncthreads();
+            if (threadIdx.x < 64) { // F <= 64 counters: one wave scans them
+                const uint32_t c = threadIdx.x < F ? tcnt[threadIdx.x] : 0u;
+                uint32_t tot;
+                const uint32_t ex = wave_exclusive_scan(c, tot);
+                if (threadIdx.x < F) tstart[threadIdx.x] = ex;
+                if (threadIdx.x == 0) tstart[F] = tot;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                if (!ok[u]) continue;
+                const uint32_t i = tstart[f[u]] + rank[u];
+                if (NC) *reinterpret_cast<ulonglong2 *>(&stage[size_t(i) * 2]) = make_ulonglong2(x[u], y[NC ? u : 0]);
+                else stage[i] = x[u];
+            }
+            if (base + PB_SPLIT_TILE < e) load(base + PB_SPLIT_TILE); // (workgroup-uniform) the next tile flies during the copy-out
+            __syncthreads();
+            const uint32_t total = tstart[F];
+            for (uint32_t i = threadIdx.x; i < total; i += PB_BLOCK) {
+                if (NC) {
+                    const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(&stage[size_t(i) * 2]);
+                    const uint32_t fb = (uint32_t(t.x >> 32) >> PB_FILL_LOG2) & uint32_t(F - 1);
+                    *reinterpret_cast<ulonglong2 *>(&out[(cur[fb] + (i - tstart[fb])) * 2]) = t;
+                } else {
+                    const uint64_t t = stage[i];
+                    const uint32_t fb = (uint32_t(t >> 32) >> PB_FILL_LOG2) & uint32_t(F - 1);
+                    out[cur[fb] + (i - tstart[fb])] = t;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < F) {
+                cur[threadIdx.x] += tcnt[threadIdx.x];
+                tcnt[threadIdx.x] = 0;
+            }
+            __syncthreads();
+        }
+    }
+}
+// one key-ordered group of 64 table entries (a wave): the row table, the presence words, the payload column of entry d in the form the
+// join table keeps it (DensePayload::packed) — dense_finish_kernel's stores.  e: row + 1 (0: no such key), v: the payload word
+__device__ __forceinline__ void dense_store_group(uint32_t *dense, uint32_t *presence, const DensePayload &dp, uint32_t (*pack)[2 * 25], int wave, int lane, uint64_t g, uint64_t span,
+                                                  uint32_t e, uint64_t v) {
+    const uint64_t d = g * 64 + uint64_t(lane);
+    if (d < span) dense[d] = e;
+    const bool present = e != 0;
+    const uint64_t m = __ballot(present);
+    if (presence && lane < 2 && 2 * g + lane < (span + 31) / 32) presence[2 * g + lane] = uint32_t(m >> (32 * lane));
+    if (dp.n == 0) return;
+    if (!present) v = dp.base[0];
+    const int nb = dp.packed[0];
+    if (nb >= 2) {
+        if (lane < 2 * nb) pack[wave][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t bit = uint32_t(lane) * uint32_t(nb);
+        const uint64_t o = uint64_t(uint32_t(v - dp.base[0])) << (bit & 31);
+        atomicOr(&pack[wave][bit >> 5], uint32_t(o));
+        if (o >> 32) atomicOr(&pack[wave][(bit >> 5) + 1], uint32_t(o >> 32));
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 2 * nb) static_cast<uint32_t *>(dp.dst[0])[g * uint64_t(2 * nb) + lane] = pack[wave][lane];
+        __builtin_amdgcn_wave_barrier();
+    } else if (d < span) {
+        if (nb) static_cast<uint32_t *>(dp.dst[0])[d] = uint32_t(v - dp.base[0]);
+        else static_cast<uint64_t *>(dp.dst[0])[d] = v;
+    }
+}
+// fill: a workgroup takes fine bins (fine_start[b] .. fine_start[b + 1) of the twice-partitioned tuples = the keys [b, b + 1) <<
+// PB_FILL_LOG2), lays their entries out in key order in LDS (a key met twice: one of its rows stays — the occupied count then
+// falls short of the rows, and the caller takes the sort-based build) and writes the final tables in whole groups of 64 entries.
+template <int NC>
+__global__ void __launch_bounds__(PB_BLOCK) part_build_fill_kernel(const uint64_t *fine_start, int bins, const uint64_t *tuples, uint64_t span, uint32_t *dense, uint32_t *presence, DensePayload dp,
+                                                                   unsigned long long *occupied) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
+    uint64_t *lv = reinterpret_cast<uint64_t *>(pb_smem);                              // [NC ? PB_FILL_KEYS : 0] payload words
+    uint32_t *le = reinterpret_cast<uint32_t *>(lv + (NC ? PB_FILL_KEYS : 0));         // [PB_FILL_KEYS] row + 1
+    __shared__ uint32_t pack[PB_BLOCK / 64][2 * 25];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t mine = 0;
+    for (int b = blockIdx.x; b < bins; b += gridDim.x) {
+        __syncthreads(); // (the previous bin's entries have left)
+        for (int i = threadIdx.x; i < PB_FILL_KEYS; i += PB_BLOCK) le[i] = 0;
+        __syncthreads();
+        const uint64_t s = fine_start[b], e = fine_start[b + 1];
+        const uint32_t d0 = uint32_t(b) << PB_FILL_LOG2;
+        for (uint64_t i0 = s + threadIdx.x; i0 < e; i0 += 4 * uint64_t(PB_BLOCK)) { // (four loads in flight per thread)
+            uint64_t x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t i = i0 + uint64_t(u) * PB_BLOCK, ic = i < e ? i : e - 1;
+                if (NC) {
+                    const nt_u64x2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u64x2 *>(tuples + ic * 2));
+                    x[u] = t.x;
+                    y[u] = t.y;
+                } else {
+                    x[u] = __builtin_nontemporal_load(&tuples[ic]);
+                    y[u] = 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + uint64_t(u) * PB_BLOCK >= e) continue;
+                const uint32_t sl = (uint32_t(x[u] >> 32) - d0) & uint32_t(PB_FILL_KEYS - 1);
+                le[sl] = uint32_t(x[u]) + 1u;
+                if (NC) lv[NC ? sl : 0] = y[u];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < PB_FILL_KEYS; i += PB_BLOCK) { // (whole waves: i - lane is a multiple of 64)
+            const uint64_t g = (uint64_t(d0) + uint64_t(i)) >> 6;
+            if (g * 64 >= span) break; // (wave-uniform: the table ends inside the last bin)
+            const uint32_t ent = le[i];
+            mine += ent != 0 ? 1u : 0u;
+            dense_store_group(dense, presence, dp, pack, wave, lane, g, span, ent, NC ? lv[NC ? i : 0] : 0ull);
+        }
+    }
+    // occupied entries: one atomic per workgroup
+    __shared__ uint32_t wsum[PB_BLOCK / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if (lane == 0) wsum[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < PB_BLOCK / 64; ++w) t += wsum[w];
+        if (t) atomicAdd(occupied, t);
     }
 }
 // claims the first free slot of the probe sequence for every row (no key comparison: equal keys simply occupy several slots),
@@ -1311,8 +1626,10 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
     int dup = 0;
     if (span != 0 && span <= std::max<uint64_t>(4ull * uint64_t(n), 1024ull) && span < (1ull << 31)) {
         // ---- dense keys: direct-address table (+ key-ordered payload columns and the presence bitmap when everything is plain)
-        BufRef dense = dev_alloc_zero(ctx, size_t(span) * 4);
-        BufRef presence = dev_alloc_zero(ctx, size_t((span + 63) / 64) * 8);
+        // (zeroed by zero_tables() below on the paths that scatter into them; the two-level partitioned build writes every entry itself)
+        BufRef dense = dev_alloc(ctx, size_t(span) * 4);
+        BufRef presence = dev_alloc(ctx, size_t((span + 63) / 64) * 8);
+        std::vector<std::pair<BufRef, size_t>> to_zero{{dense, size_t(span) * 4}, {presence, size_t((span + 63) / 64) * 8}};
         DensePayload dp;
         std::memset(&dp, 0, sizeof(dp));
         std::vector<BufRef> dense_cols(ncols);
@@ -1336,8 +1653,10 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
                         dense_base[ci] = mmh[2 * k] ^ (pc.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull);
                     }
                 dense_packed[ci] = packed;
-                dense_cols[ci] = packed >= 2 ? dev_alloc_zero(ctx, size_t((span + 63) / 64) * 8 * size_t(packed) + 16) // whole 64-entry groups (dense_finish_kernel)
-                                             : (packed ? dev_alloc_zero(ctx, size_t(span) * 4 + 8) : dev_alloc(ctx, size_t(span) * 8));
+                const size_t col_bytes = packed >= 2 ? size_t((span + 63) / 64) * 8 * size_t(packed) + 16 // whole 64-entry groups (dense_finish_kernel)
+                                                     : (packed ? size_t(span) * 4 + 8 : size_t(span) * 8);
+                dense_cols[ci] = dev_alloc(ctx, col_bytes);
+                if (packed) to_zero.push_back({dense_cols[ci], col_bytes});
                 dp.src[dp.n] = pc.words();
                 dp.dst[dp.n] = dense_cols[ci]->ptr;
                 dp.base[dp.n] = dense_base[ci];
@@ -1345,6 +1664,12 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
                 dp.n++;
             }
         }
+        bool zeroed = false;
+        auto zero_tables = [&]() {
+            if (zeroed) return;
+            for (auto &z : to_zero) NQE_HIP_CHECK(hipMemsetAsync(z.first->ptr, 0, z.second, ctx->stream));
+            zeroed = true;
+        };
         static const bool atomic_build = getenv("NQE_JOIN_ATOMIC_BUILD") != nullptr; // diagnostics (A/B): the one-kernel form with device atomics
         // (measured: 10^7 rows 1.29 -> 0.67 ms; at 10^8 rows the random stores and gathers over gigabytes lose to the atomics, 22 vs 11 ms)
         const char *part_min_env = getenv("NQE_JOIN_PART_BUILD_MIN"); // read per call: the tests lower it for some builds only
@@ -1359,6 +1684,12 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             int shift = 10; // the widest slice of 4 + 8 nc bytes per entry within slice_kb, and no more than PB_MAX_PARTS of them
             while (shift < 31 && (uint64_t(2) << shift) * uint64_t(4 + 8 * nc) <= uint64_t(slice_kb) * 1024) ++shift;
             while (((span - 1) >> shift) + 1 > uint64_t(PB_MAX_PARTS)) ++shift;
+            // two-level form (part_build_split / part_build_fill above): at most one payload word, a key range of at most PB_MAX_PARTS x
+            // 2^PB_FINE_LOG2 fine bins (2.7 x 10^8 keys).  NQE_JOIN_PART_ONE_LEVEL=1 (read per call): the place pass (A/B)
+            const bool two_level = nc <= 1 && span <= (uint64_t(PB_MAX_FINE) << PB_FILL_LOG2) && getenv("NQE_JOIN_PART_ONE_LEVEL") == nullptr &&
+                                   size_t(PB_FILL_KEYS) * size_t(4 + 8 * nc) + 4096 <= ctx->lds_per_block && size_t(PB_MAX_FINE) * 4 <= ctx->lds_per_block;
+            const int bins = two_level ? int(((span - 1) >> PB_FILL_LOG2) + 1) : 0;
+            if (two_level) shift = PB_FILL_LOG2 + PB_FINE_LOG2;
             pb.keys = kc.words();
             pb.n = n;
             pb.dmin = kmin;
@@ -1376,7 +1707,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             const size_t cells = size_t(pb.parts) * size_t(pb.W);
             // key-ordered records {row + 1, payload words} of an even number of words (16-byte aligned), zeroed: an entry nobody wrote is absent
             const int twp = nc ? (1 + nc + 1) / 2 * 2 : 0;
-            BufRef counts, offsets, tuples, kord;
+            BufRef counts, offsets, tuples, kord, tuples2, finehist, fine_start;
             bool part_oom = false;
             try { // the tuple stream and the records come on top of the table: when they do not fit, the one-kernel form below still may
                 if (getenv("NQE_TEST_PART_BUILD_OOM")) fail(NQE_ERR_OUT_OF_MEMORY, "partitioned build (NQE_TEST_PART_BUILD_OOM)"); // tests: as if the allocation had failed
@@ -1384,18 +1715,40 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
                 counts = dev_alloc(ctx, cells * 4);
                 offsets = dev_alloc(ctx, (cells + 1) * 8);
                 tuples = dev_alloc(ctx, size_t(n) * size_t(1 + nc) * 8 + 16);
-                if (nc) kord = dev_alloc(ctx, size_t(span) * size_t(twp) * 8);
+                if (two_level) {
+                    tuples2 = dev_alloc(ctx, size_t(n) * size_t(1 + nc) * 8 + 16);
+                    finehist = dev_alloc(ctx, size_t(pb.W) * size_t(bins) * 4);
+                    fine_start = dev_alloc(ctx, (size_t(bins) + 1) * 8);
+                } else if (nc)
+                    kord = dev_alloc(ctx, size_t(span) * size_t(twp) * 8);
             } catch (const Error &e) {
                 if (e.code != NQE_ERR_OUT_OF_MEMORY) throw;
                 part_oom = true;
             }
             if (!part_oom) {
-            if (nc) NQE_HIP_CHECK(hipMemsetAsync(kord->ptr, 0, size_t(span) * size_t(twp) * 8, ctx->stream));
-            launch(ctx, "join_build_part_count", part_build_count_kernel, dim3(unsigned(pb.W)), dim3(PB_BLOCK), 0, pb, (uint32_t *)counts->ptr);
+            if (!two_level) zero_tables();
+            if (kord) NQE_HIP_CHECK(hipMemsetAsync(kord->ptr, 0, size_t(span) * size_t(twp) * 8, ctx->stream));
+            if (two_level)
+                launch(ctx, "join_build_part_count", part_build_count_fine_kernel, dim3(unsigned(pb.W)), dim3(PB_BLOCK), size_t(bins) * 4, pb, (uint32_t *)counts->ptr, (uint32_t *)finehist->ptr, bins);
+            else
+                launch(ctx, "join_build_part_count", part_build_count_kernel, dim3(unsigned(pb.W)), dim3(PB_BLOCK), 0, pb, (uint32_t *)counts->ptr);
             exclusive_scan_u32_to_u64(ctx, (const uint32_t *)counts->ptr, (uint64_t *)offsets->ptr, int64_t(cells));
             const size_t shmem = size_t(tile) * size_t(1 + nc) * 8 + size_t(PB_MAX_PARTS) * 12;
             auto sk = rpt == 8 ? part_build_scatter_kernel<8> : (rpt == 4 ? part_build_scatter_kernel<4> : (rpt == 2 ? part_build_scatter_kernel<2> : part_build_scatter_kernel<1>));
+            if (nc <= 1 && rpt == 8) sk = nc ? part_build_scatter1_kernel<1> : part_build_scatter1_kernel<0>; // (its tile in registers, the next one prefetched)
             launch(ctx, "join_build_part_scatter", sk, dim3(unsigned(pb.W)), dim3(PB_BLOCK), shmem, pb, (const uint64_t *)offsets->ptr, (uint64_t *)tuples->ptr);
+            if (two_level) {
+                launch(ctx, "join_build_part_fine_offsets", part_build_fine_offsets_kernel, dim3(unsigned(pb.parts)), dim3(256), 0, (const uint32_t *)finehist->ptr, pb.W, bins, pb.parts,
+                       (const uint64_t *)offsets->ptr, (uint64_t *)fine_start->ptr);
+                launch(ctx, "join_build_part_split", nc ? part_build_split_kernel<1> : part_build_split_kernel<0>, dim3(unsigned(std::min(pb.parts, 2 * ctx->num_cus))), dim3(PB_BLOCK),
+                       size_t(PB_SPLIT_TILE) * size_t(1 + nc) * 8, pb, (const uint64_t *)offsets->ptr, (const uint64_t *)fine_start->ptr, bins, (const uint64_t *)tuples->ptr, (uint64_t *)tuples2->ptr);
+                BufRef occupied = dev_alloc_zero(ctx, 8);
+                launch(ctx, "join_build_part_fill", nc ? part_build_fill_kernel<1> : part_build_fill_kernel<0>, dim3(unsigned(std::min(bins, 2 * ctx->num_cus))), dim3(PB_BLOCK),
+                       size_t(PB_FILL_KEYS) * size_t(4 + 8 * nc), (const uint64_t *)fine_start->ptr, bins, (const uint64_t *)tuples2->ptr, span, (uint32_t *)dense->ptr, (uint32_t *)presence->ptr, dp,
+                       (unsigned long long *)occupied->ptr);
+                dup = read_scalar(ctx, (const unsigned long long *)occupied->ptr) != (unsigned long long)n; // (also keeps the tuple streams alive until the kernels are done)
+                part_done = true;
+            } else {
             BufRef cursor = dev_alloc_zero(ctx, size_t(pb.parts) * 4);
             static const int place_by_block = getenv("NQE_JOIN_PART_PLACE_BY_BLOCK") ? atoi(getenv("NQE_JOIN_PART_PLACE_BY_BLOCK")) : 0; // diagnostics (A/B)
             static const int place_chunk = getenv("NQE_JOIN_PART_CHUNK") ? atoi(getenv("NQE_JOIN_PART_CHUNK")) : PB_CHUNK;         // diagnostics (A/B)
@@ -1409,7 +1762,9 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             dup = read_scalar(ctx, (const unsigned long long *)occupied->ptr) != (unsigned long long)n; // (also keeps the tuples and records alive until the kernels are done)
             part_done = true;
             }
+            }
         }
+        if (!part_done) zero_tables();
         if (part_done) {
         } else if (n >= (int64_t(1) << 16) && (n < (int64_t(1) << 25) || ascending) && !atomic_build) {
             // larger builds: scatter row numbers, then finish in key order (see dense_finish_kernel) — no device-scope atomics

@@ -1581,6 +1581,45 @@ def test_join_partitioned_dense_build(ctx, monkeypatch, shape, ncols):
         assert_batches_equal(ctx.hash_join_probe(jt, rt, 0).to_host(), exp, what=f"{shape} reused table")
 
 
+@pytest.mark.parametrize("one_level", [False, True])
+@pytest.mark.parametrize("shape", ["pk_int20", "pk_f64", "holes_int40", "key_only", "dup", "holes_key_only"])
+def test_join_partitioned_dense_build_two_levels(ctx, monkeypatch, shape, one_level):
+    """the two-level form of the partitioned build (round 6: count with a fine histogram, scatter into partitions, a second scatter
+    by fine bin inside every partition, LDS fill of the final tables — key-only builds and one payload word) over a key range of
+    several partitions (2.6 x 10^6 keys: 10 partitions, 320 fine bins, tiles that end inside a partition and inside a bin): bit-packed,
+    32-bit and 8-byte payload columns, keys with holes (absent entries inside and at the end of the table), duplicates (occupancy
+    count -> sort-based build) — and the same builds through the one-level form (NQE_JOIN_PART_ONE_LEVEL=1).  hash_join.rs:124-166"""
+    monkeypatch.setenv("NQE_JOIN_PART_BUILD_MIN", "1000")
+    if one_level:
+        monkeypatch.setenv("NQE_JOIN_PART_ONE_LEVEL", "1")
+    rng = np.random.default_rng(len(shape) + 77)
+    nb, n = 2_600_003, 400_000
+    holes = shape.startswith("holes")
+    dk = (rng.permutation(3 * nb)[:nb] if holes else rng.permutation(nb)).astype(np.int64) + 12345
+    if shape == "dup":
+        dk[rng.integers(0, nb, 30)] = dk[rng.integers(0, nb, 30)]
+    left = [Column.from_numpy(dk)]
+    if shape in ("pk_int20", "dup"):
+        left.append(Column.from_numpy(rng.integers(0, 1 << 20, nb).astype(np.int64) - 77))
+    elif shape == "pk_f64":
+        left.append(Column.from_numpy(rng.random(nb)))
+    elif shape == "holes_int40":
+        left.append(Column.from_numpy(rng.integers(0, 1 << 40, nb).astype(np.int64)))
+    rk = rng.integers(int(dk.min()) - 10, int(dk.max()) + 10, n).astype(np.int64)
+    right = [Column.from_numpy(rk), Column.from_numpy(rng.random(n))]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    lt, rt = ctx.table_from_host(left), ctx.table_from_host(right)
+    ctx.timing_enable(True); ctx.timing_reset()
+    got = ctx.hash_join(lt, rt, 0, 0).to_host()
+    names = ctx.timing_report()
+    ctx.timing_enable(False)
+    assert "join_build_part_scatter" in names, names
+    assert ("join_build_part_fill" in names) == (not one_level) and ("join_build_part_place" in names) == one_level, names
+    assert_batches_equal(got, exp, what=f"{shape}, one_level={one_level}")
+    jt = ctx.hash_join_build(lt, 0)
+    assert_batches_equal(ctx.hash_join_probe(jt, rt, 0).to_host(), exp, what=f"{shape} reused table")
+
+
 @pytest.mark.parametrize("keys", ["dense", "sparse", "dense_gaps", "sparse_two_payloads"])
 @pytest.mark.parametrize("all_match", [True, False])
 def test_join_in_which_every_probe_row_matches_shares_the_probe_columns(ctx, keys, all_match):

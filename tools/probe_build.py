@@ -15,7 +15,8 @@ ctx = capi.Context(0)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(1)
-KEYS = ("join_build_minmax", "join_build_part_count", "scan_", "join_build_part_scatter", "join_build_part_place", "join_build_dense", "join_build_finish")
+KEYS = ("join_build_minmax", "join_build_part_count", "scan_", "join_build_part_scatter", "join_build_part_fine_offsets", "join_build_part_split", "join_build_part_fill", "join_build_part_place", "join_build_dense",
+        "join_build_finish")
 
 
 def build_ms(dim, reps=3):
@@ -39,8 +40,14 @@ for nb in sizes:
         torch.cuda.synchronize()
         for name, cols in (("key + int payload", [bk, ba]), ("key + f64 payload", [bk, bf]), ("key only", [bk])):
             dim = ctx.table_from_device([(DType.FLOAT64 if c.dtype == torch.float64 else DType.INT64, nb, c.data_ptr(), None) for c in cols])
-            for form, env in (("partitioned", "1000"), ("previous", str(1 << 40))):
+            forms = (("two-level", "1000", None), ("one-level", "1000", "1")) if order == "random" else (("partitioned", "1000", None),)
+            if os.environ.get("NQE_PROBE_BUILD_PREVIOUS"):
+                forms += (("previous", str(1 << 40), None),)
+            for form, env, one in forms:
                 os.environ["NQE_JOIN_PART_BUILD_MIN"] = env
+                os.environ.pop("NQE_JOIN_PART_ONE_LEVEL", None)
+                if one:
+                    os.environ["NQE_JOIN_PART_ONE_LEVEL"] = one
                 ms, br = build_ms(dim)
                 print(f"build {nb:>11} rows, {order:9} keys, {name:18} [{form:11}] {ms:8.3f} ms  {br}", flush=True)
             del dim
