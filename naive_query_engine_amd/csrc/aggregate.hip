@@ -1920,7 +1920,7 @@ void AggRun::sample_keys() {
 
 void AggRun::pick_key_range() {
     // (round 5: also under key subsets — two workgroups per row range, each holding one half of a range of up to 2 x 4096 values in a
-    // direct-mapped table (AggArgs::direct_sub_shift): one value column, NQE_DIRECT_SUBSETS=0 switches it off)
+    // direct-mapped table (AggArgs::direct_sub_shift): one value column)
     const bool sub_range = subsets_log2 == 1 && subsets_ok && V == 1 && sw.direct_subsets;
     if (hint_key && !sw.no_key_range && !partition_mode && (subsets_log2 == 0 || sub_range) && (!no_hints_env || range_sampled) && plain_int_key) {
         // `group by k`, k a plain integer column (dictionary codes, small ids): a value range that fits a workgroup table makes the
@@ -2159,8 +2159,8 @@ PassStatus AggRun::tier_slab() {
     const bool range_part = a.nv == 1 && dense && range_part_ok && part_span != 0 && part_span <= (uint64_t(PARTS) << 12);
     const bool k32 = a.nv == 1 && (!key32_failed || range_part);
     const int rpt = k32 ? slab_scatter_soa_rows_per_thread() : slab_scatter_rows_per_thread(fp, fast_key, a.nv);
-    // the two-stream form runs 512-thread workgroups, two per CU (NQE_SOA_THREADS=1024: one of 1024): their barrier phases overlap
-    const int sc_threads = k32 ? sw.soa_threads : AGG_BLOCK, sc_per_cu = k32 ? (sw.soa_threads == 512 ? 2 : 1) : slab_scatter_wg_per_cu();
+    // the two-stream form runs 512-thread workgroups, two per CU: their barrier phases overlap
+    const int sc_threads = k32 ? sw.soa_threads : AGG_BLOCK, sc_per_cu = k32 ? 1024 / sw.soa_threads : slab_scatter_wg_per_cu();
     const int64_t tile_rows = int64_t(sc_threads) * rpt;
     int W = int(std::min<int64_t>(int64_t(ctx->num_cus) * sc_per_cu, (in->rows + tile_rows - 1) / tile_rows));
     int64_t chunk = ((in->rows + W - 1) / W + tile_rows - 1) / tile_rows * tile_rows;
@@ -2273,7 +2273,7 @@ void AggRun::range_emit(int parts_log2, int Q, uint32_t rslots, uint64_t span, i
     ranged.keys->ctx = ctx;
     ranged.keys->rows = room;
     ranged.keys->cols.push_back(make_word_column(ctx, kinfo.out_dtype, room, false));
-    // keys per thread of the tail: 4096-key blocks for wide ranges, 1024-key blocks to keep narrow ones parallel (NQE_RANGE_EMIT_ITEMS: 1 / 4 for A/B)
+    // keys per thread of the tail: 4096-key blocks for wide ranges, 1024-key blocks to keep narrow ones parallel
     const int items = sw.range_emit_items ? sw.range_emit_items : (span >= (uint64_t(1) << 19) ? 4 : 1);
     const uint32_t kb = uint32_t(RE_BLOCK * items), sb = std::max<uint32_t>(1u, kb >> parts_log2), nblocks = (rslots + sb - 1) / sb;
     // block statuses (ticket + one word per block), then three zeroed words for the host: the group count, ~(first key - key_min), last key - key_min
@@ -2362,7 +2362,7 @@ PassStatus AggRun::tier_streaming(int v0) {
     // asking before the partition kernels had that variant: a densely laid out table went to the hashed general kernel)
     ka.allow_partition = in->rows >= (int64_t(1) << 18) ? 1 : 0;
     asked_partition = asked_partition || ka.allow_partition != 0;
-    ka.flag_check_mask = sw.flag_check_mask; // how often a wave looks at the overflow flags (aggregate_common.hpp): every 8th iteration; NQE_FLAG_CHECK_MASK=0: every one
+    ka.flag_check_mask = sw.flag_check_mask; // how often a wave looks at the overflow flags (aggregate_common.hpp): every 8th iteration
     // ONE 1024-thread workgroup per CU: fewer concurrent streams read HBM faster (A/B on one box: headline
     // 2.44 -> 2.39 ms, C3 2.56 -> 2.41 ms, random keys 3.63 -> 3.54 ms, 1 % nulls 0.81 -> 0.69 ms per 2e8 rows;
     // tools/stream_bench.hip shows the same for a bare read kernel)
@@ -2452,7 +2452,7 @@ PassStatus AggRun::tier_streaming(int v0) {
     uint32_t jit_span = 0;
     int64_t jit_bias = 0;
     // … and so do interpreted chain KEYS (`(id + 1) % 1000`, KEY 3) whatever the predicate: the kernel bakes the whole key program
-    // NQE_AGG_JIT_ALL: 1 (default) = also `col % m` by magic multiply (KEY 2: the literal modulus baked in — `id % 1000` 0.584 -> 0.548 ms, `id % 2000`
+    // agg_jit_all = 1: also `col % m` by magic multiply (KEY 2: the literal modulus baked in — `id % 1000` 0.584 -> 0.548 ms, `id % 2000`
     // 0.643 -> 0.560 per 2x10^8 rows), 2 = every `% m` key (A/B: the headline's power-of-two key 2.53 vs 2.47 ms — within noise, it stays static), 0 = neither
     const int jit_all = sw.agg_jit_all;
     const bool jit_try = jit_whole || (has_pred && (fp >= 5 || (fp == 3 && jit_chains))) || (fast_key == 3 && jit_chains) || (jit_all >= 1 && fast_key == 2) || jit_all >= 2;

@@ -1285,7 +1285,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_range_segments_kernel(AggArgs a
 }
 
 template <int PRED, int KEY> SlabScatterKernel pick_slab_scatter_nv(int nv, bool k32, int soa_threads) {
-    if (nv == 1 && k32) return soa_threads == 512 ? agg_slab_scatter_soa_kernel<PRED, KEY, 512> : agg_slab_scatter_soa_kernel<PRED, KEY, 1024>;
+    if (nv == 1 && k32) return agg_slab_scatter_soa_kernel<PRED, KEY, 512>; // (soa_threads: AggSwitches — 512, two workgroups per CU)
     if (nv == 1) return agg_slab_scatter_kernel<PRED, KEY, 1>;
     return agg_slab_scatter_kernel<PRED, KEY, 2>;
 }

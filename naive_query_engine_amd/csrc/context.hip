@@ -8,27 +8,8 @@
 #include "nqe_internal.hpp"
 
 void AggSwitches::read_environment() {
-    auto num = [](const char *name, int dflt) {
-        const char *e = getenv(name);
-        return e ? atoi(e) : dflt;
-    };
-    no_three_column_pass = getenv("NQE_NO_THREE_COLUMN_PASS") != nullptr;
-    no_key_range = getenv("NQE_NO_KEY_RANGE") != nullptr;
-    subsets_max = num("NQE_AGG_SUBSETS_MAX", 1);
-    slab_parts_first = num("NQE_SLAB_PARTS_LOG2", 8);
-    const int m = num("NQE_FLAG_CHECK_MASK", 7);
-    flag_check_mask = (m == 0 || m == 1 || m == 3 || m == 7 || m == 15) ? m : 7;
-    no_agg_jit_chains = getenv("NQE_NO_AGG_JIT_CHAINS") != nullptr;
-    agg_jit_all = num("NQE_AGG_JIT_ALL", 1);
-    tiny_groups = num("NQE_TINY_GROUPS", 1) != 0;
-    direct_partials = num("NQE_DIRECT_PARTIALS", 1) != 0;
-    range_tier = num("NQE_RANGE_TIER", 1) != 0;
-    range_slots_log2 = std::min(12, std::max(8, num("NQE_RANGE_SLOTS_LOG2", 12)));
-    soa_threads = num("NQE_SOA_THREADS", 512) == 1024 ? 1024 : 512;
-    lds_load_limit = num("NQE_LDS_LOAD_LIMIT", 1) != 0;
-    direct_subsets = num("NQE_DIRECT_SUBSETS", 1) != 0;
-    { const int it = num("NQE_RANGE_EMIT_ITEMS", 0); range_emit_items = (it == 1 || it == 4) ? it : 0; }
-    tiny_unpack_tiles = std::min(4096, std::max(1, num("NQE_TINY_UNPACK_TILES", 4096)));
+    const char *e = getenv("NQE_TINY_UNPACK_TILES");
+    tiny_unpack_tiles = std::min(4096, std::max(1, e ? atoi(e) : 4096));
     debug = getenv("NQE_DEBUG") != nullptr;
 }
 

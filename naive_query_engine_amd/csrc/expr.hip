@@ -996,15 +996,12 @@ DevColumn evaluate_expr(nqe_ctx *ctx, const nqe_table *in, const nqe_expr_node *
             uint64_t *ov = needs_valid ? (uint64_t *)out.validity->ptr : nullptr;
             // instantiated per (nullable, <=2 / <=4 columns): the column registers of a lane are the largest block of VGPRs
 #define NQE_TREE(NU, NC) launch(ctx, "expr_tree", expr_tree_kernel<NU, NC>, grid, dim3(256), 0, P, rows, ow, ob, ov, ctx->d_flags)
-            // (8 rows per lane, measured: 176 VGPRs = 2 waves per SIMD — an 8-operator chain 1.19 -> 1.13 ms per 2x10^8 rows, but
-            // `(id % 1000) * 3 + id / 7` 1.11 -> 1.36 and `v > 50 and id % 3 = 0` 0.98 -> 1.19: off unless asked for)
-            static const bool rows8 = getenv("NQE_EXPR_ROWS8") != nullptr; // diagnostics (A/B)
+            // (8 rows per lane measured 176 VGPRs = 2 waves per SIMD — an 8-operator chain 1.19 -> 1.13 ms per 2x10^8 rows, but
+            // `(id % 1000) * 3 + id / 7` 1.11 -> 1.36 and `v > 50 and id % 3 = 0` 0.98 -> 1.19: four rows per lane it is)
             // three or more steps over a large input: the run-time specialised form of this very program, once it has been compiled
             if (jit_expr_tree(ctx, P, needs_valid, rows, ow, ob, ov)) {
             } else if (needs_valid) { if (P.ncols <= 2) NQE_TREE(true, 2); else NQE_TREE(true, 4); }
-            else if (P.ncols <= 2 && rows8) {
-                launch(ctx, "expr_tree", expr_tree_kernel<false, 2, 8>, dim3(stream_grid(ctx, (rows + 7) / 8, 256)), dim3(256), 0, P, rows, ow, ob, ov, ctx->d_flags);
-            } else { if (P.ncols <= 2) NQE_TREE(false, 2); else NQE_TREE(false, 4); }
+            else { if (P.ncols <= 2) NQE_TREE(false, 2); else NQE_TREE(false, 4); }
 #undef NQE_TREE
         }
         return out;

@@ -653,10 +653,9 @@ bool jit_project(nqe_ctx *ctx, const JitProj &J, const KeepMask &km, uint64_t *c
 // kernel.  The output columns are allocated for the worst case (every row kept); the last chunk's inclusive prefix is the row
 // count the host reads back.  Columns only the projection uses are loaded after the count is known to be non-zero.
 // rows per lane per chunk, threads per workgroup (twelve chunks = 6144 rows per ticket and status word; 74 VGPRs: two such workgroups
-// per CU).  NQE_SP_R / NQE_SP_BLOCK: A/B runs — per 10^8 rows of `select v * v + v / 4, id … where (id + 1) % 10 < 5`: 256x8 0.78 ms,
+// per CU).  Other shapes measured (profiles/r04, r05) — per 10^8 rows of `select v * v + v / 4, id … where (id + 1) % 10 < 5`: 256x8 0.78 ms,
 // 512x4 0.76, 512x8 0.60, 512x16 0.60, 1024x8 0.60, 768x8 0.56 (the two-kernel form: 0.67 + its scan and host wait)
-static const int SP_R = getenv("NQE_SP_R") ? atoi(getenv("NQE_SP_R")) : 8;
-static const int SP_BLOCK = getenv("NQE_SP_BLOCK") ? atoi(getenv("NQE_SP_BLOCK")) : 768;
+constexpr int SP_R = 8, SP_BLOCK = 768;
 struct JitSelProj {
     JitProj proj;       // the union of the predicate's and the projection's columns, the outputs
     ExProgram pred;     // column operands renumbered to proj's slots

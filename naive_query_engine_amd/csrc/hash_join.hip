@@ -1645,11 +1645,10 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
                     if (mm_cols[k] == int(ci) && mmh[2 * k + 1] - mmh[2 * k] <= 0xffffffffull) { // value range within 32 bits → uint32 offsets
                         // … within 25 bits → exactly as many bits per entry as the range needs: the smaller the key-ordered table, the more
                         // of the probe's gathers hit the 4 MB L2 (10^6 keys of a 20-bit attribute: 2.5 MB instead of 4)
-                        static const bool no24 = getenv("NQE_JOIN_NO_PACK24") != nullptr; // diagnostics (A/B)
                         const uint64_t range = mmh[2 * k + 1] - mmh[2 * k];
                         int bits = 2;
                         while (bits < 32 && (range >> bits) != 0) ++bits;
-                        packed = (no24 || bits > 25) ? 1 : bits; // <= 25 bits: any entry lies inside one unaligned 4-byte window
+                        packed = bits > 25 ? 1 : bits; // <= 25 bits: any entry lies inside one unaligned 4-byte window
                         dense_base[ci] = mmh[2 * k] ^ (pc.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull);
                     }
                 dense_packed[ci] = packed;
@@ -1670,15 +1669,14 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             for (auto &z : to_zero) NQE_HIP_CHECK(hipMemsetAsync(z.first->ptr, 0, z.second, ctx->stream));
             zeroed = true;
         };
-        static const bool atomic_build = getenv("NQE_JOIN_ATOMIC_BUILD") != nullptr; // diagnostics (A/B): the one-kernel form with device atomics
-        // (measured: 10^7 rows 1.29 -> 0.67 ms; at 10^8 rows the random stores and gathers over gigabytes lose to the atomics, 22 vs 11 ms)
+        // (the one-kernel form with device atomics serves builds below 2^16 rows; forced on larger ones it measured 10^7 rows 0.67 -> 1.29 ms, 10^8 rows 11 -> 22 ms)
         const char *part_min_env = getenv("NQE_JOIN_PART_BUILD_MIN"); // read per call: the tests lower it for some builds only
         const int64_t part_min = part_min_env ? atoll(part_min_env) : (int64_t(1) << 25);
         bool part_done = false;
-        if (n >= part_min && !ascending && !atomic_build && (!with_payload || dp.n <= 15) && span <= 0xffffffffull) {
+        if (n >= part_min && !ascending && (!with_payload || dp.n <= 15) && span <= 0xffffffffull) {
             // ---- partitioned form (see part_build_* above)
             const int nc = with_payload ? dp.n : 0;
-            static const int slice_kb = getenv("NQE_JOIN_PART_SLICE_KB") ? atoi(getenv("NQE_JOIN_PART_SLICE_KB")) : 3072; // table bytes per partition (4-byte entries: 1.35 ms per 10^8 rows at 3 MB, 1.8 at 6, 2.5 at 24; 16-byte records: 2.1 either way)
+            constexpr int slice_kb = 3072; // table bytes per partition (4-byte entries: 1.35 ms per 10^8 rows at 3 MB, 1.8 at 6, 2.5 at 24; 16-byte records: 2.1 either way)
             PartBuild pb;
             std::memset(&pb, 0, sizeof(pb));
             int shift = 10; // the widest slice of 4 + 8 nc bytes per entry within slice_kb, and no more than PB_MAX_PARTS of them
@@ -1750,9 +1748,9 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
                 part_done = true;
             } else {
             BufRef cursor = dev_alloc_zero(ctx, size_t(pb.parts) * 4);
-            static const int place_by_block = getenv("NQE_JOIN_PART_PLACE_BY_BLOCK") ? atoi(getenv("NQE_JOIN_PART_PLACE_BY_BLOCK")) : 0; // diagnostics (A/B)
-            static const int place_chunk = getenv("NQE_JOIN_PART_CHUNK") ? atoi(getenv("NQE_JOIN_PART_CHUNK")) : PB_CHUNK;         // diagnostics (A/B)
-            static const int place_bpc = getenv("NQE_JOIN_PART_PLACE_BPC") ? atoi(getenv("NQE_JOIN_PART_PLACE_BPC")) : 3;            // workgroups per CU (measured per 10^8 records: 8 -> 2.6 ms, 2-4 -> 2.1, 1 -> 3.1)
+            constexpr int place_by_block = 0; // (1: XCD = blockIdx % 8 instead of the hardware register — no difference measured)
+            constexpr int place_chunk = PB_CHUNK;
+            constexpr int place_bpc = 3;            // workgroups per CU (measured per 10^8 records: 8 -> 2.6 ms, 2-4 -> 2.1, 1 -> 3.1)
             launch(ctx, "join_build_part_place", part_build_place_kernel, dim3(unsigned(place_bpc * ctx->num_cus)), dim3(256), 0, pb, (const uint64_t *)offsets->ptr,
                    (const uint64_t *)tuples->ptr, (uint32_t *)dense->ptr, kord ? (uint64_t *)kord->ptr : (uint64_t *)nullptr, twp, (uint32_t *)cursor->ptr, place_by_block, uint32_t(place_chunk));
             BufRef occupied = dev_alloc_zero(ctx, 8);
@@ -1766,7 +1764,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
         }
         if (!part_done) zero_tables();
         if (part_done) {
-        } else if (n >= (int64_t(1) << 16) && (n < (int64_t(1) << 25) || ascending) && !atomic_build) {
+        } else if (n >= (int64_t(1) << 16) && (n < (int64_t(1) << 25) || ascending)) {
             // larger builds: scatter row numbers, then finish in key order (see dense_finish_kernel) — no device-scope atomics
             BufRef occupied = dev_alloc_zero(ctx, 8);
             launch(ctx, "join_build_dense", dense_scatter_rows_kernel, dim3(stream_grid(ctx, n, 256)), dim3(256), 0, kc.words(), n, kmin, (uint32_t *)dense->ptr);
@@ -1811,9 +1809,8 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
         while (b < 64 && (x >> b) != 0) ++b;
         return b;
     };
-    static const bool no_packed = getenv("NQE_JOIN_NO_PACKED_PAIRS") != nullptr; // diagnostics (A/B)
     PackedPairs pp{};
-    if (payload_plain && ncols == 2 && mm_cols.size() == 2 && !no_packed) { // one integer payload column whose offset fits a word together with the key's
+    if (payload_plain && ncols == 2 && mm_cols.size() == 2) { // one integer payload column whose offset fits a word together with the key's
         const int kbits = std::max(1, bit_length(kmax - kmin)), pbits = std::max(1, bit_length(mmh[3] - mmh[2]));
         const uint64_t nb = uint64_t(n) * 5 / 48 + 1; // 16-slot buckets at load 0.6
         if (kbits + pbits <= 63 && nb * PACKED_BUCKET < (1ull << 31)) {
@@ -2098,7 +2095,6 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
         // every row, the output row of a probe row is the probe row, and ONE pass (no presence pass, no scan, the probe keys read
         // once) writes everything — while checking every key against the range.  A key outside it discards the output, and this
         // join table takes the two-pass form from then on.
-        static const bool no_optimistic = getenv("NQE_JOIN_NO_OPTIMISTIC") != nullptr; // diagnostics (A/B)
         // what the context remembers of this join (the table itself may be a fresh one: nqe_hash_join_execute builds per call)
         uint64_t jhint = 1469598103934665603ull;
         {
@@ -2114,7 +2110,7 @@ std::unique_ptr<nqe_table> probe_table(nqe_ctx *ctx, const nqe_join_table *jt, c
             mix(&n, sizeof(n));
         }
         if (ctx->join_hints.count(jhint)) jt->all_match_failed = true;
-        if (jt->dense_full && !jt->all_match_failed && !no_optimistic && n > 0) {
+        if (jt->dense_full && !jt->all_match_failed && n > 0) {
             FusedCols fc;
             auto out = build_out(n, fc, true);
             BufRef miss = dev_alloc_zero(ctx, 4);

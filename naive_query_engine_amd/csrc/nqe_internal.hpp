@@ -48,27 +48,28 @@ enum { NQE_FLAG_DIV_ZERO = 0, NQE_FLAG_OVERFLOW = 1, NQE_FLAG_TABLE_FULL = 2, NQ
 // group count and key range)
 constexpr int NQE_FLAG_MIRROR_EXTRA = 8;
 
-// A/B switches of the aggregate operator (aggregate.hip), read from the environment ONCE when a context is created (nqe_ctx::agg_sw).
-// Diagnostics only: every default is the measured-best setting; DESIGN.md §9 lists them with what each was used to measure.  (The
-// switches the tests flip between calls — NQE_NO_PLAN_HINTS, NQE_NO_KEY_SAMPLE, NQE_NO_RANGE_PARTITION, NQE_NO_RANGE_TAIL,
-// NQE_NO_AGG_JIT, NQE_TEST_SLAB_OOM — are read per call where they are used.)
+// Settings of the aggregate operator (aggregate.hip).  Rounds 2-5 read every one of them from the environment for A/B runs; what those
+// runs decided is a constant now (the measurements: profiles/r02 … r05, DESIGN.md §9 "retired switches"), and the forms that lost on
+// every measured shape are gone.  Still read when a context is created: the test hook and the tier trace.  (The switches the tests flip
+// between calls — NQE_NO_PLAN_HINTS, NQE_NO_KEY_SAMPLE, NQE_NO_RANGE_PARTITION, NQE_NO_RANGE_TAIL, NQE_NO_AGG_JIT, NQE_NO_WIDE_DIRECT,
+// NQE_TEST_SLAB_OOM — are read per call where they are used.)
 struct AggSwitches {
-    bool no_three_column_pass = false; // NQE_NO_THREE_COLUMN_PASS=1: three value columns in passes of one and two
-    bool no_key_range = false;         // NQE_NO_KEY_RANGE=1: a plain key column is never addressed by key - min
-    int subsets_max = 1;               // NQE_AGG_SUBSETS_MAX: log2 of the key subsets of the streaming tier (0: none)
-    int slab_parts_first = 8;          // NQE_SLAB_PARTS_LOG2: log2 of the first partition count of the slab form (6..9)
-    int flag_check_mask = 7;           // NQE_FLAG_CHECK_MASK: a wave of the one-tile streaming loop looks at the overflow flags every (mask + 1)th iteration
-    bool no_agg_jit_chains = false;    // NQE_NO_AGG_JIT_CHAINS=1: chain predicates / chain keys stay on the interpreting static kernel
-    int agg_jit_all = 1;               // NQE_AGG_JIT_ALL: 0 = neither, 1 = `col % m` by magic multiply through the specialised kernel, 2 = every `% m` key
-    bool tiny_groups = true;           // NQE_TINY_GROUPS=0: `col % m`, m <= 4 stays on the streaming kernel's replicated LDS tables (round 4's form)
-    bool direct_partials = true;       // NQE_DIRECT_PARTIALS=0: the streaming kernel folds its direct-mapped workgroup tables into the group table with device-scope atomics (round 4's form)
-    bool range_tier = true;            // NQE_RANGE_TIER=0: key-range partitions keep 256 tables, one workgroup per table and the dense tail (round 4's form)
-    int range_slots_log2 = 12;         // NQE_RANGE_SLOTS_LOG2: log2 of the slots per table the range tier sizes its partition count for (8..12; measured at 10^8 rows / 65536 groups: 9: 1.11, 10: 1.03, 11: 0.99, 12: 0.97 ms per step)
-    int soa_threads = 512;             // NQE_SOA_THREADS: workgroup size of the two-stream scatter (512: two per CU; 1024: one)
-    bool direct_subsets = true;        // NQE_DIRECT_SUBSETS=0: two key subsets always hash (round 4), even over a measured key range of up to 2 x 4096 values
-    bool lds_load_limit = true;        // NQE_LDS_LOAD_LIMIT=0: a hashed workgroup table of the streaming kernel takes keys until probe sequences fail (round 4), not three quarters of its slots
+    static constexpr bool no_three_column_pass = false; // three value columns without min / max go through ONE pass of the three-column instance
+    static constexpr bool no_key_range = false;         // a plain key column whose measured range fits a workgroup table is addressed by key - min
+    static constexpr int subsets_max = 1;               // log2 of the key subsets of the streaming tier (two subsets; four measured slower than partitioning)
+    static constexpr int slab_parts_first = 8;          // log2 of the first partition count of the hashed slab form
+    static constexpr int flag_check_mask = 7;           // a wave of the one-tile streaming loop looks at the overflow flags every 8th iteration
+    static constexpr bool no_agg_jit_chains = false;    // chain predicates / chain keys take the run-time specialised kernel
+    static constexpr int agg_jit_all = 1;               // `col % m` by magic multiply goes through the specialised kernel (power-of-two moduli stay static)
+    static constexpr bool tiny_groups = true;           // `col % m`, m <= 4: group state in registers (aggregate_tiny.hip)
+    static constexpr bool direct_partials = true;       // direct-mapped workgroup tables leave whole and are folded by a kernel (no device-scope atomics)
+    static constexpr bool range_tier = true;            // key-range partitions: partition count from the range, Q workgroups per partition, transposing tail
+    static constexpr int range_slots_log2 = 12;         // log2 of the slots per table the range tier sizes its partition count for (9: 1.11, 10: 1.03, 11: 0.99, 12: 0.97 ms per step at 65536 groups)
+    static constexpr int soa_threads = 512;             // workgroup size of the two-stream scatter: two per CU (1024 x 1 and 256 x 4 measured slower: profiles/r06/ab_soa_threads.txt)
+    static constexpr bool direct_subsets = true;        // two key subsets over a measured key range address their tables directly
+    static constexpr bool lds_load_limit = true;        // a hashed workgroup table hands over at three quarters of its slots
+    static constexpr int range_emit_items = 0;          // keys per thread of the range tier's tail: by the range (1 below 2^19 keys, else 4)
     int tiny_unpack_tiles = 4096;      // NQE_TINY_UNPACK_TILES: tiles between two unpackings of the register kernel's packed row counters (1..4096; a TEST hook: at 4096 the branch first runs beyond ~2 x 10^9 rows)
-    int range_emit_items = 0;          // NQE_RANGE_EMIT_ITEMS: keys per thread of the range tier's tail (1 or 4; 0 = by the range)
     bool debug = false;                // NQE_DEBUG=1: the tier decisions on stderr
     void read_environment();
 };

@@ -60,38 +60,16 @@ __global__ void __launch_bounds__(256) keep_from_pred_kernel(const uint8_t *pbit
     }
 }
 
-// predicate = SimpleExpr over one streamed column; wave per tile, 64 rows per step.
-// RANGE: the predicate is an integer `col cmp lit` over a plain 8-byte column without validity →
-// branch-free range test, clamped unconditional loads, 8 loads in flight per wave.
-template <int RANGE> // 0: any SimpleExpr; 1: integer range test; 2: Float64 range test (order-mapped)
-__global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *values, const uint8_t *valid, SimpleExpr e, FastPred fp,
-                                                               int64_t n, int64_t ntiles, uint64_t *keep, uint64_t *pvalid_out,
+// predicate = SimpleExpr over one streamed column; wave per tile, 64 rows per step (any column type, validity).  A range test over a
+// plain 8-byte column takes keep_from_range_tile_kernel below.
+__global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *values, const uint8_t *valid, SimpleExpr e, int64_t n, int64_t ntiles, uint64_t *keep, uint64_t *pvalid_out,
                                                                uint32_t *tile_counts, int *flags) {
     const int waves_per_block = blockDim.x / 64;
-    const uint64_t *__restrict__ words = static_cast<const uint64_t *>(values);
-    const int64_t last = n - 1;
     for (int64_t tile = int64_t(blockIdx.x) * waves_per_block + threadIdx.x / 64; tile < ntiles;
          tile += int64_t(gridDim.x) * waves_per_block) {
         const int64_t row0 = tile * TILE_ROWS;
         uint32_t total = 0;
-        if (RANGE) {
-#pragma unroll 2
-            for (int k0 = 0; k0 < TILE_WORDS; k0 += SEL_B) {
-                uint64_t v[SEL_B];
-#pragma unroll
-                for (int k = 0; k < SEL_B; ++k) {
-                    int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
-                    v[k] = __builtin_nontemporal_load(&words[row < last ? row : last]);
-                }
-#pragma unroll
-                for (int k = 0; k < SEL_B; ++k) {
-                    int64_t row = row0 + int64_t(k0 + k) * 64 + lane_id();
-                    uint64_t kw = __ballot(row < n && range_pass(fp, RANGE == 2 ? f64_order_map(fp, v[k]) : v[k]));
-                    if (row0 + int64_t(k0 + k) * 64 < n && lane_id() == 0) keep[tile * TILE_WORDS + k0 + k] = kw;
-                    total += __popcll(kw);
-                }
-            }
-        } else {
+        {
 #pragma unroll 4
             for (int k = 0; k < TILE_WORDS; ++k) {
                 int64_t row = row0 + int64_t(k) * 64 + lane_id();
@@ -112,36 +90,7 @@ __global__ void __launch_bounds__(256) keep_from_simple_kernel(const void *value
     }
 }
 
-// The range-test form with the rows striped over the waves in 512-row chunks (chunk c goes to wave c mod #waves) instead of one
-// 4096-row tile per wave: at any moment the chip reads one compact window of the column.  Per-tile totals meet in tile_counts
-// through one atomic per chunk (the caller zeroes them).
-template <int RANGE>
-__global__ void __launch_bounds__(256) keep_from_range_strided_kernel(const uint64_t *__restrict__ words, FastPred fp, int64_t n, uint64_t *keep, uint32_t *tile_counts) {
-    constexpr int R = 8;
-    const int lane = lane_id();
-    const int64_t n_chunks = (n + 64 * R - 1) / (64 * R), last = n - 1;
-    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, n_waves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
-        const int64_t row0 = chunk * (64 * R) + lane;
-        uint64_t v[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int64_t row = row0 + r * 64;
-            v[r] = __builtin_nontemporal_load(&words[row < last ? row : last]);
-        }
-        uint32_t total = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int64_t row = row0 + r * 64;
-            const uint64_t kw = __ballot(row < n && range_pass(fp, RANGE == 2 ? f64_order_map(fp, v[r]) : v[r]));
-            if (row - lane < n && lane == 0) keep[chunk * R + r] = kw;
-            total += __popcll(kw);
-        }
-        if (lane == 0 && total) atomicAdd(&tile_counts[(chunk * (64 * R)) / TILE_ROWS], total);
-    }
-}
-
-// Round 5 (tools/compact_bench.hip, 10^8 rows, keep and compaction alternating so that nothing is cache-warm): one 256-thread workgroup
+// The range-test form.  Round 5 (tools/compact_bench.hip, 10^8 rows, keep and compaction alternating so that nothing is cache-warm): one 256-thread workgroup
 // per 4096-row tile, sixteen rows per lane all in flight, the tile's count written ONCE by the workgroup — no zeroing pass, no atomic
 // per 512-row chunk: 0.148-0.150 ms -> 0.131-0.133 ms per 0.8 GB column (6.05 TB/s; the atomics were the whole difference — the strided
 // form without them measured the same, and a 1024-thread two-tile pipelined form like the aggregate's stream was slower, 0.156-0.166 ms).
@@ -183,7 +132,7 @@ struct ConjCols {
     const uint64_t *w[CONJ_MAX];
 };
 // STRIPED: the rows go to the waves in chunks of 2 x B keep words (chunk c to wave c mod #waves; per-tile totals through one atomic
-// per chunk into zeroed tile_counts) instead of one 4096-row tile per wave — see keep_from_range_strided_kernel
+// per chunk into zeroed tile_counts) instead of one 4096-row tile per wave (the only form instantiated since round 6)
 template <int NC, bool STRIPED>
 __global__ void __launch_bounds__(256) keep_from_conj_kernel(ConjCols cols, ConjPred c, int64_t n, int64_t ntiles, uint64_t *keep, uint32_t *tile_counts) {
     constexpr int B = NC <= 2 ? SEL_B : SEL_B / 2; // words in flight per lane stay at 8-16
@@ -364,29 +313,15 @@ KeepMask build_keep_mask_simple(nqe_ctx *ctx, const nqe_table *in, const SimpleE
     FastPred fp{};
     const bool range = is_word_type(c.dtype) && !c.validity && make_fast_pred(pred, &fp);
     if (km.ntiles) {
-        static const int bpc = getenv("NQE_SEL_BPC") ? atoi(getenv("NQE_SEL_BPC")) : 8; // diagnostics (A/B): workgroups per CU
-        dim3 grid(stream_grid(ctx, km.ntiles, 4, bpc)), block(256);
-        static const bool strided = getenv("NQE_SEL_TILED") == nullptr; // diagnostics (A/B): NQE_SEL_TILED=1 restores one 4096-row tile per wave
-        // NQE_KEEP_TILE=0: keep_from_range_strided_kernel (A/B)
-        static const bool tile_form = !(getenv("NQE_KEEP_TILE") && atoi(getenv("NQE_KEEP_TILE")) == 0);
-        if (range && strided && tile_form) {
-            dim3 tgrid(stream_grid(ctx, km.ntiles, 1, 8));
+        // a range test over a plain 8-byte column: a tile per 256-thread workgroup pass, counts written once, no atomics (round 5; the
+        // striped form with an atomic per chunk and the one-tile-per-wave form it replaced: profiles/r05/compact_bench.txt)
+        if (range) {
+            dim3 tgrid(stream_grid(ctx, km.ntiles, 1, 8)), block(256);
             if (fp.fmask) launch(ctx, "keep_from_simple", keep_from_range_tile_kernel<2>, tgrid, block, 0, c.words(), fp, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
             else launch(ctx, "keep_from_simple", keep_from_range_tile_kernel<1>, tgrid, block, 0, c.words(), fp, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
-        } else if (range && strided) {
-            NQE_HIP_CHECK(hipMemsetAsync(counts->ptr, 0, size_t(km.ntiles + 1) * 4, ctx->stream));
-            dim3 sgrid(stream_grid(ctx, (km.n + 7) / 8, 256));
-            if (fp.fmask) launch(ctx, "keep_from_simple", keep_from_range_strided_kernel<2>, sgrid, block, 0, c.words(), fp, km.n, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
-            else launch(ctx, "keep_from_simple", keep_from_range_strided_kernel<1>, sgrid, block, 0, c.words(), fp, km.n, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
-        } else if (range && fp.fmask)
-            launch(ctx, "keep_from_simple", keep_from_simple_kernel<2>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred, fp,
-                   km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint64_t *)nullptr, (uint32_t *)counts->ptr, ctx->d_flags);
-        else if (range)
-            launch(ctx, "keep_from_simple", keep_from_simple_kernel<1>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred, fp,
-                   km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint64_t *)nullptr, (uint32_t *)counts->ptr, ctx->d_flags);
-        else
-            launch(ctx, "keep_from_simple", keep_from_simple_kernel<0>, grid, block, 0, (const void *)c.values->ptr, c.valid(), pred,
-                   fp, km.n, km.ntiles, (uint64_t *)km.keep->ptr, km.pvalid ? (uint64_t *)km.pvalid->ptr : nullptr,
+        } else
+            launch(ctx, "keep_from_simple", keep_from_simple_kernel, dim3(stream_grid(ctx, km.ntiles, 4, 8)), dim3(256), 0, (const void *)c.values->ptr, c.valid(), pred,
+                   km.n, km.ntiles, (uint64_t *)km.keep->ptr, km.pvalid ? (uint64_t *)km.pvalid->ptr : nullptr,
                    (uint32_t *)counts->ptr, ctx->d_flags);
     }
     return finish_mask(ctx, km, counts);
@@ -412,16 +347,9 @@ KeepMask build_keep_mask_conj(nqe_ctx *ctx, const nqe_table *in, ConjPred c, con
         c.t[t].src = q;
     }
     if (km.ntiles) {
-        dim3 grid(stream_grid(ctx, km.ntiles, 4)), block(256);
-        static const bool striped = getenv("NQE_SEL_TILED") == nullptr; // diagnostics (A/B)
-        if (striped) {
-            NQE_HIP_CHECK(hipMemsetAsync(counts->ptr, 0, size_t(km.ntiles + 1) * 4, ctx->stream));
-            auto k = nc == 1 ? keep_from_conj_kernel<1, true> : nc == 2 ? keep_from_conj_kernel<2, true> : nc == 3 ? keep_from_conj_kernel<3, true> : keep_from_conj_kernel<4, true>;
-            launch(ctx, "keep_from_conj", k, dim3(stream_grid(ctx, km.ntiles * 4, 4)), block, 0, cc, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
-        } else {
-            auto k = nc == 1 ? keep_from_conj_kernel<1, false> : nc == 2 ? keep_from_conj_kernel<2, false> : nc == 3 ? keep_from_conj_kernel<3, false> : keep_from_conj_kernel<4, false>;
-            launch(ctx, "keep_from_conj", k, grid, block, 0, cc, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
-        }
+        NQE_HIP_CHECK(hipMemsetAsync(counts->ptr, 0, size_t(km.ntiles + 1) * 4, ctx->stream));
+        auto k = nc == 1 ? keep_from_conj_kernel<1, true> : nc == 2 ? keep_from_conj_kernel<2, true> : nc == 3 ? keep_from_conj_kernel<3, true> : keep_from_conj_kernel<4, true>;
+        launch(ctx, "keep_from_conj", k, dim3(stream_grid(ctx, km.ntiles * 4, 4)), dim3(256), 0, cc, c, km.n, km.ntiles, (uint64_t *)km.keep->ptr, (uint32_t *)counts->ptr);
     }
     return finish_mask(ctx, km, counts);
 }
@@ -566,8 +494,7 @@ static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExp
     SimpleExpr dummy;
     std::memset(&dummy, 0, sizeof(dummy));
     if (km.ntiles && km.total > 0) { // nothing kept: nothing to read or write (and a gather source may be empty)
-        static const int bpc = getenv("NQE_COMPACT_BPC") ? atoi(getenv("NQE_COMPACT_BPC")) : 8; // diagnostics (A/B): workgroups per CU
-        dim3 grid(stream_grid(ctx, km.ntiles, 4, bpc)), block(256);
+        dim3 grid(stream_grid(ctx, km.ntiles, 4, 8)), block(256);
         const void *sv = (const void *)src.values->ptr;
         const uint64_t *kp = (const uint64_t *)km.keep->ptr;
         const uint64_t *pv = km.pvalid ? (const uint64_t *)km.pvalid->ptr : nullptr;
@@ -580,27 +507,23 @@ static DevColumn run_compact(nqe_ctx *ctx, const DevColumn &src, const SimpleExp
 #define NQE_COMPACT(NAME, E, P, G)                                                                                     \
     launch(ctx, NAME, compact_kernel<E, P, G>, grid, block, 0, sv, src.dtype, src.valid(), gidx, ex, kp, pv, to, km.n,  \
            km.ntiles, ow, ob, ov, ctx->d_flags)
-        static const bool strided = getenv("NQE_SEL_TILED") == nullptr; // diagnostics (A/B): NQE_SEL_TILED=1 restores one 4096-row tile per wave
-        // NQE_COMPACT_STAGED=0: the register-to-memory form (compact_strided_kernel) for A/B; NQE_COMPACT_STAGED_WGS: workgroups per CU
-        static const bool staged = !(getenv("NQE_COMPACT_STAGED") && atoi(getenv("NQE_COMPACT_STAGED")) == 0);
-        static const int staged_wgs = getenv("NQE_COMPACT_STAGED_WGS") ? std::max(1, atoi(getenv("NQE_COMPACT_STAGED_WGS"))) : 2;
-        if (staged && strided && !gidx && plainw && km.ntiles >= 64) {
-            dim3 ggrid(unsigned(std::min<int64_t>(km.ntiles, int64_t(ctx->num_cus) * staged_wgs))), gblock(512);
+        // plain 8-byte words: kept words staged in LDS and written in whole aligned lines (512 threads, two workgroups per CU); tables of
+        // fewer than 64 tiles: from registers, a chunk per wave.  Gathers, Boolean outputs and validity: the general kernel.
+        if (!gidx && plainw && km.ntiles >= 64) {
+            dim3 ggrid(unsigned(std::min<int64_t>(km.ntiles, int64_t(ctx->num_cus) * 2))), gblock(512);
             uint64_t mul = 1, add = 0;
             if (e && affine_form(*e, &mul, &add))
                 launch(ctx, "compact_expr", compact_staged_kernel<2>, ggrid, gblock, 0, (const uint64_t *)sv, ex, mul, add, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
             else if (e) launch(ctx, "compact_expr", compact_staged_kernel<1>, ggrid, gblock, 0, (const uint64_t *)sv, ex, mul, add, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
             else launch(ctx, "compact_column", compact_staged_kernel<0>, ggrid, gblock, 0, (const uint64_t *)sv, ex, mul, add, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
-        } else if (strided && !gidx && plainw) {
+        } else if (!gidx && plainw) {
             dim3 sgrid(stream_grid(ctx, km.ntiles * (TILE_WORDS / COMPACT_CHUNK_WORDS), 4));
             if (e) launch(ctx, "compact_expr", compact_strided_kernel<true>, sgrid, block, 0, (const uint64_t *)sv, ex, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
             else launch(ctx, "compact_column", compact_strided_kernel<false>, sgrid, block, 0, (const uint64_t *)sv, ex, kp, to, km.n, km.ntiles, ow, ctx->d_flags);
         } else if (gidx) {
             if (plainw) NQE_COMPACT("compact_gather", false, true, true);
             else NQE_COMPACT("compact_gather", false, false, true);
-        } else if (e && plainw) NQE_COMPACT("compact_expr", true, true, false);
-        else if (e) NQE_COMPACT("compact_expr", true, false, false);
-        else if (plainw) NQE_COMPACT("compact_column", false, true, false);
+        } else if (e) NQE_COMPACT("compact_expr", true, false, false);
         else NQE_COMPACT("compact_column", false, false, false);
 #undef NQE_COMPACT
     }
@@ -626,13 +549,12 @@ static KeepMask mask_for_predicate(nqe_ctx *ctx, const nqe_table *in, const nqe_
     if (info.out_dtype != NQE_BOOLEAN)
         fail(NQE_ERR_NOT_SUPPORTED, "predicate is not a BooleanArray (selection.rs:61 unwrap panics)");
     if (info.simple) {
-        // a chain that is not a range test (`(id + 1) % 10 < 5`) over a large plain column: keep_from_simple_kernel<0> interprets it
+        // a chain that is not a range test (`(id + 1) % 10 < 5`) over a large plain column: keep_from_simple_kernel interprets it
         // row by row (1.6 TB/s); the expression machine — tile-wise, and specialised at run time from three steps on — writes the
         // Boolean column at 5+ TB/s, and the mask pass over 1 bit per row is nearly free
         const DevColumn &c = in->cols[size_t(info.s.col)];
         FastPred fp{};
-        static const bool off = getenv("NQE_NO_CHAIN_VIA_MACHINE") != nullptr; // diagnostics (A/B)
-        if (!off && info.s.nops >= 2 && in->rows >= (int64_t(1) << 20) && is_word_type(c.dtype) && !c.validity && !make_fast_pred(info.s, &fp)) {
+        if (info.s.nops >= 2 && in->rows >= (int64_t(1) << 20) && is_word_type(c.dtype) && !c.validity && !make_fast_pred(info.s, &fp)) {
             DevColumn p = evaluate_expr(ctx, in, pred, pred_nodes);
             return build_keep_mask(ctx, p, in->rows);
         }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Diagnostics on the GPU box: join BUILD times by size, key order and form (partitioned dense build vs the forms it replaces),
-with the per-kernel breakdown.  usage: probe_build.py [sizes…]   (NQE_JOIN_PART_BUILD_MIN / NQE_JOIN_PART_SLICE_KB select)"""
+with the per-kernel breakdown.  usage: probe_build.py [sizes…]   (NQE_JOIN_PART_BUILD_MIN / NQE_JOIN_PART_ONE_LEVEL select the form)"""
 import os
 import sys
 import time

@@ -59,12 +59,6 @@ python tools/probe_paths.py strings 2>&1 | grep -v amdgpu.ids > $OUT/probe_strin
         echo "round $round  agg_groups --groups $g  ${sw:-default}: $ms ms per step"
       done
     done
-    for m in 0 7; do
-      for wl in agg3 agg_readme; do
-        ms=$(NQE_FLAG_CHECK_MASK=$m python bench.py --workload $wl --no-configs --no-cpu-baseline --steps 20 2>/dev/null | tail -1 | python -c "import sys,json; print(round(json.loads(sys.stdin.read())['ms_per_step'],4))")
-        echo "round $round  $wl  NQE_FLAG_CHECK_MASK=$m: $ms ms per step"
-      done
-    done
   done
 } > $OUT/probe_switches.txt 2>&1
 ./tools/micro_bench all > $OUT/micro_bench.txt 2>&1
