@@ -384,8 +384,9 @@ def attach_spread(res):
     roof = res["roofline"]
     # the same algorithmic bytes over the step's WALL time (the number the driver's own clock can vouch for; `frac` is over the HIP-event
     # time of the step's data kernels): launch gaps, scans, tails and the host's part of a step are inside it, so frac_step <= frac
-    if res.get("ms_per_step") and roof.get("algorithmic_bytes_per_step"):
-        roof["frac_step"] = roof["algorithmic_bytes_per_step"] / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    # (on the bytes `frac` counts: C2 over sorted ids quotes the bytes that move)
+    if res.get("ms_per_step") and roof.get("kernel_ms_per_step"):
+        roof["frac_step"] = roof["frac"] * roof["kernel_ms_per_step"] / res["ms_per_step"]
     blocks = res["spread"].pop("block_kernels", None)
     names = [k for k in roof.get("kernel", "").split("+") if k]
     if not blocks or not names or not roof.get("kernel_ms_per_step"):
