@@ -410,3 +410,43 @@ def test_headline_1e9_rows_with_null_values_every_group_against_the_cpu(ctx):
         del t, bm
     finally:
         d.free()
+
+
+@pytest.mark.timeout(900)
+def test_join_build_2p25_rows_over_512_partitions(ctx):
+    """the two-level partitioned build at its real threshold (2^25 build rows) and over a key range of 1.0 x 10^8 values with holes — 384
+    partitions, 12 288 fine bins: keys 3 i + (0 | 1 | 2) shuffled, an Int64 payload 7 key + 1 (beyond 25 bits: the 32-bit column form)
+    and a Float64 payload key / 8; probed with 2 x 10^7 keys of which two thirds exist: row count, every matched payload analytic, order
+    = probe order (hash_join.rs:124-254).  The one-level form (NQE_JOIN_PART_ONE_LEVEL=1) must give the same table."""
+    from naive_query_engine_amd import Column
+
+    nb, npr = 1 << 25, 20_000_000
+    rng = np.random.default_rng(25)
+    keys = (np.arange(nb, dtype=np.int64) * 3 + rng.integers(0, 3, nb)) + 1000
+    keys = keys[rng.permutation(nb)]
+    present = np.zeros(3 * nb + 1000 + 8, dtype=bool)
+    present[keys] = True
+    pk = rng.integers(1000, 3 * nb + 1000, npr).astype(np.int64)
+    exp_keys = pk[present[pk]]
+    right = ctx.table_from_host([Column.from_numpy(pk)])
+    for payload in ("int", "f64"):
+        pay = keys * 7 + 1 if payload == "int" else keys.astype(np.float64) / 8.0
+        left = ctx.table_from_host([Column.from_numpy(keys), Column.from_numpy(pay)])
+        outs = []
+        for one_level in (False, True):
+            if one_level:
+                os.environ["NQE_JOIN_PART_ONE_LEVEL"] = "1"
+            try:
+                ctx.timing_enable(True)
+                ctx.timing_reset()
+                got = ctx.hash_join(left, right, 0, 0)
+                names = ctx.timing_report()
+                ctx.timing_enable(False)
+            finally:
+                os.environ.pop("NQE_JOIN_PART_ONE_LEVEL", None)
+            assert ("join_build_part_fill" in names) == (not one_level) and ("join_build_part_place" in names) == one_level, names
+            k, p, rk = host(got)
+            assert len(k) == len(exp_keys) and (k == exp_keys).all() and (rk == exp_keys).all(), f"{payload}: keys / order"
+            assert (p == (exp_keys * 7 + 1 if payload == "int" else exp_keys.astype(np.float64) / 8.0)).all(), f"{payload}: payload"
+            outs.append(len(k))
+        assert outs[0] == outs[1]

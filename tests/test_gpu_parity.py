@@ -2125,7 +2125,8 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
         ctx.device_free(p_)
 
 
-@pytest.mark.parametrize("kind", ["range_5000", "range_5840_at_limit", "range_5841_two_subsets", "negative_base", "u64_mod_5000", "predicate", "nan_values", "int_values"])
+@pytest.mark.parametrize("kind", ["range_5000", "range_5840_at_limit", "range_5841_two_subsets", "negative_base", "u64_mod_5000", "predicate", "nan_values", "int_values", "value_is_key",
+                                  "count_and_sum_only"])
 def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
     """4097 .. 5840 values between a key column's min and max (or `col % m`, m <= 5840, UInt64), one value column, no validity bitmaps:
     ONE directly addressed workgroup table (round 6 — the table carries no key words: 28 bytes per slot), where two workgroups per row
@@ -2150,12 +2151,14 @@ def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
     f3 = fields("k", "v", "w")
     kn = key.flatten(f3)
     pn = binop(col(2), Operator.Lt, lit_f64(0.5)).flatten(f3) if kind == "predicate" else None
-    exp = orc.aggregate([cols], ALL_AGGS(1), group_nodes=kn, pred_nodes=pn)[0]
+    # (value_is_key: `sum(k) … group by k` — the single-load instance; count_and_sum_only: no aggregate asks for min / max)
+    aggs = ALL_AGGS(0) if kind == "value_is_key" else [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1)] if kind == "count_and_sum_only" else ALL_AGGS(1)
+    exp = orc.aggregate([cols], aggs, group_nodes=kn, pred_nodes=pn)[0]
     t = ctx.table_from_host(cols)
     for rep in range(3):
         ctx.timing_enable(True)
         ctx.timing_reset()
-        got, gk = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn, pred_nodes=pn, with_keys=True)
+        got, gk = ctx.aggregate(t, aggs, group_nodes=kn, pred_nodes=pn, with_keys=True)
         ctx.timing_enable(False)
         names = ctx.timing_report()
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{kind} run {rep}")
@@ -2165,7 +2168,7 @@ def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
             assert "agg_partition_scatter" not in names and names["agg_grouped_fast"][1] == 1, names
     monkeypatch.setenv("NQE_NO_WIDE_DIRECT", "1")
     monkeypatch.setenv("NQE_NO_PLAN_HINTS", "1")
-    got = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn, pred_nodes=pn)
+    got = ctx.aggregate(t, aggs, group_nodes=kn, pred_nodes=pn)
     assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{kind}, NQE_NO_WIDE_DIRECT")
 
 
