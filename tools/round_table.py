@@ -47,23 +47,21 @@ def rocprof_ms(name):
 
 # what changed in a row's DEFINITION since the previous round (so that the "previous round" column is not read as a like-for-like A/B)
 NOTES = {
-    "agg_65536_groups": "kernel time now includes the range tier's tail (agg_range_emit); r04's dense tail was not counted",
-    "agg_1048576_groups": "kernel time now includes the range tier's tail (agg_range_emit); r04's dense tail was not counted",
-    "agg_4096_groups": "kernel time now includes agg_fold_partials",
-    "agg_6000_groups": "new in round 5 (two key subsets over a direct-mapped table; round 4's form measured 1.18 ms per step: ab_groups_landscape_before.txt)",
-    "agg_three_value_columns": "kernel time now includes agg_fold_partials",
-    "agg_readme_shape": "kernel time now includes agg_fold_partials",
-    "c2": "parity now over all 10^8 rows (r04: 2 x 10^7)",
-    "c2_random_ids": "parity now over all 10^8 rows (r04: 2 x 10^7)",
-    "c2_expression_trees": "parity now over all 10^8 rows (r04: 2 x 10^7)",
-    "c4": "parity now over all 10^8 probe rows (r04: 5 x 10^6)",
-    "headline": "parity now over all 10^9 rows, every group (r04: the first 1.5 x 10^8)",
+    "agg_5000_groups": "new in round 6 (one directly addressed workgroup table without key words; the two-subset form it replaces: 0.60 ms per step, ab_wide_direct.txt)",
+    "c2": "kernel time now includes the tile-count scan (scan_single, 13 us)",
+    "c2_random_ids": "kernel time now includes the tile-count scan (scan_single, 13 us)",
+    "c2_expression_trees": "",
+    "agg_three_value_columns": "parity now over all 10^9 rows (r05: 2 x 10^7)",
+    "agg_readme_shape": "parity now over all 10^9 rows (r05: 2 x 10^7)",
+    "headline_nullable": "parity now over all 10^9 rows (r05: 2 x 10^7)",
+    "agg_tree_predicate": "parity now over all 10^9 rows (r05: 2 x 10^7)",
+    "c4_dim_1e8": "build_ms: the two-level partitioned build (r05: the place pass)",
 }
 rows = [("headline", {"ms": d["ms_per_step"], "kernel_ms": d["roofline"].get("kernel_ms_per_step"), "kernel_ms_min": d["roofline"].get("kernel_ms_min"),
-                      "kernel_ms_max": d["roofline"].get("kernel_ms_max"), "frac": d["roofline"]["frac"], "cold_ms": d.get("cold_ms"), "parity": d.get("parity_checked", {})})]
+                      "kernel_ms_max": d["roofline"].get("kernel_ms_max"), "frac": d["roofline"]["frac"], "frac_step": d["roofline"].get("frac_step"), "cold_ms": d.get("cold_ms"), "parity": d.get("parity_checked", {})})]
 rows += list(d.get("configs", {}).items())
-print("| config | ms / step | kernel ms (HIP events) [min .. max over blocks] | kernel ms (rocprofv3 avg) | differ | frac of 8 TB/s (8d bytes) | frac physical | PMC traffic / algorithmic | first execution ms | no plan hints ms | parity (rows) | previous round ms | definition changes |")
-print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+print("| config | ms / step | kernel ms (HIP events) [min .. max over blocks] | kernel ms (rocprofv3 avg) | differ | frac of 8 TB/s (8d bytes) | frac_step (same bytes / step wall time) | frac physical | PMC traffic / algorithmic | first execution ms | no plan hints ms | parity (rows) | previous round ms | definition changes |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for name, c in rows:
     if "raw_ms" in c:
         continue
@@ -78,7 +76,7 @@ for name, c in rows:
     if km and rp:
         pct = (rp - km) / km * 100.0
         diff = f"{pct:+.1f} %" + (" **(> 3 %)**" if abs(pct) > 3.0 else "")
-    print(f"| `{name}` | {f(c.get('ms'), 4)} | {f(km, 4)}{spread} | {f(rp, 4)} | {diff} | {f(c.get('frac'))} | {f(c.get('frac_physical'))} | {f(tr, 4)} | {f(c.get('cold_ms') if c.get('cold_ms') is not None else (det.get(name) or {}).get('cold_ms'), 4)} | {f(nhc, 4)} | "
+    print(f"| `{name}` | {f(c.get('ms'), 4)} | {f(km, 4)}{spread} | {f(rp, 4)} | {diff} | {f(c.get('frac'))} | {f(c.get('frac_step'))} | {f(c.get('frac_physical'))} | {f(tr, 4)} | {f(c.get('cold_ms') if c.get('cold_ms') is not None else (det.get(name) or {}).get('cold_ms'), 4)} | {f(nhc, 4)} | "
           f"{'ok' if ok else ok} ({par.get('rows', '')}) | {f(pvc, 4)} | {NOTES.get(name, '')} |")
 print()
 print("| drop-in row | ms / step | raw C-ABI ms | ratio | equal to the raw call |")

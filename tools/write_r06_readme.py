@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""profiles/r06/README.md = the narrative below + the table tools/round_table.py makes from the committed files (run after
+tools/summarize_profiles.py r06)."""
+import subprocess
+import sys
+
+table = subprocess.check_output([sys.executable, "tools/round_table.py", "r06", "r05"], text=True)
+text = f"""# Round 6 — results and evidence index
+
+Produced on one MI355X by `tools/profile_round.sh r06` (through `gpurun`), summarised by `tools/summarize_profiles.py r06`; this
+file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.json` records the `csrc_rev` it was made from
+(`tools/csrc_rev.py`), and `bench.py` quotes a file as `roofline.traffic` only while that hash matches the running tree.
+
+| File | What |
+|---|---|
+| `bench_default.json`, `bench_details.json` | the default `python bench.py` line (26 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity, `frac_step` beside `frac`), per-kernel details |
+| `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
+| `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
+| `rocprofv3_kernel_stats_<config>.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --workload … --steps 20 --warmup 3` (its own process: the table below compares its averages with the bench line's HIP-event times) — **C3 and C3 over random keys included** (round 5 had none) |
+| `pmc_traffic_<config>.json`, `pmc_calibration.json`, `summary.json` | HBM bytes per step from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, calibrated in the same run on `tools/stream_bench` |
+| `probe_*.txt`, `micro_bench.txt` | the diagnostic sweeps of earlier rounds, re-run on this revision (`probe_build.txt`: the join build, two-level against one-level) |
+| `ab_wide_direct.txt` | 10⁸ rows over 4096 … 6000 random groups: one directly addressed workgroup table without key words (round 6) against two key subsets (`NQE_NO_WIDE_DIRECT=1`) |
+| `probe_build.txt`, `probe_build_two_level_f32.txt`, `probe_build_two_level_f64.txt` | the join build by size and payload: the two-level form (final: 32 fine bins per partition, scatter with its tile in registers and the next prefetched) against the place pass; the first two-level build (before the scatter's prefetch); 64 fine bins per partition (split slower, scatter unchanged) |
+| `ab_c2tree.txt`, `ab_c2tree_look.txt`, `ab_c2tree_pipe.txt` | the one-pass selection + projection kernel taken apart: without its stores / look-back / both; K statuses per look-back round trip; a software-pipelined loop (experiment builds of the generator, not kept) |
+| `ab_soa_threads.txt` | the many-group aggregate's scatter at 512 × 2, 256 × 4 and 1024 × 1 threads × workgroups per CU |
+| `../r06_notes.md` | the raw measurement notes the sections of DESIGN.md were written from |
+
+## The bench line
+
+`ms` = whole step incl. host waits, median of three blocks; **kernel ms (HIP events)** = the step's data kernels as the library's own
+events time them in the bench process, with min .. max over the blocks; **kernel ms (rocprofv3 avg)** = the same kernels in the
+config's own `rocprofv3 --stats` run (another process, often another box); **differ** flags more than 3 % between the two — read
+`frac` with that spread in mind.  `frac` = SURVEY §8d bytes over the HIP-event kernel time as a fraction of 8 TB/s; **`frac_step`** =
+the same bytes over `ms` (the step's wall time — the number a clock outside the library can vouch for).  Parity: rows compared with an
+independent CPU result in the same run (every aggregate config, C2 forms, C4: EVERY row / group).  "previous round ms" is r05's line,
+another box and — where the last column says so — another definition.
+
+{table}
+## What changed in round 6, and what each change bought
+
+* **One workgroup table for key ranges of 4097–5840 values** (`agg_5000_groups`, new): a direct-mapped table over sources without
+  validity never reads its key words — the array is no longer laid out (28 B per slot, 5841 slots in 160 KB), the planner's one-table
+  limit follows, the table folds into the range tier's tail: 4500 / 5000 / 5840 random groups 0.62 / 0.60 / 0.59 → **0.36 / 0.34 / 0.34 ms**
+  per 10⁸ rows = 0.37 → **0.71** of 8 TB/s (`ab_wide_direct.txt`).
+* **The 10⁸-row join build 4.27 → 2.54 ms** (key + one payload; key only 2.23 → 1.58; 2²⁵ rows 1.53 → 0.88): a second partition
+  level — fine histogram in the count pass, one workgroup per partition sorting its tuples by 8192-key fine bin, LDS fill of the FINAL
+  tables in whole lines — replaces the place pass (one scattered 16-byte store per row: 1.9 ms), the zeroed key-ordered records and
+  the finish pass; the first scatter keeps its tile in registers and prefetches the next (0.93 → 0.78 ms) (`probe_build.txt`).
+  `c4_dim_1e8` end to end 0.115 → 0.15.
+* **Parity**: the reference's own aggregate query, C1's list, the headline with 1 % NULLs and the tree-predicate aggregate are compared
+  over ALL 10⁹ rows (k value columns + validity in the parallel CPU form, pinned against the port); **5×10⁹-row tests** (> 2³² input
+  rows through aggregate, selection, projection and join probe, > 2³² OUTPUT rows through the selection: green as written — the row
+  arithmetic was 64-bit); the register kernel's unpack branch runs under a test hook; ADVICE r05's Utf8-key bug reproduced on
+  hardware by the new test, then fixed.
+* **Measured, and left as it is** — with the numbers: the many-group aggregate's scatter (5.03 TB/s of its 2.8 GB; the memory pattern
+  alone takes as long; 256 × 4 and 1024 × 1 slower, more waves spill: `ab_soa_threads.txt`, DESIGN §3.3); the one-pass selection +
+  projection kernel (stores, look-back and loads ADD up to its 0.548 ms; wider look-backs and a pipelined loop both slower:
+  `ab_c2tree*.txt`, DESIGN §3.6).
+* **Measurement**: `frac_step` on every config; C2's kernel set includes the scan; C3 profiled like every other config.
+* **Structure**: 32 of round 5's 56 environment switches retired (constants; the forms that lost are deleted: the striped keep pass,
+  one-tile-per-wave selection kernels, the 1024-thread scatter instances, eight-rows-per-lane expression instance …); `aggregate.hip`
+  3035 → 2290 lines (`aggregate_tail.hip`); library 29.9 → 28.4 MB, clean build 4 → 3 min.
+
+## Open
+
+More than one physical GPU (C5, the xGMI numbers — the preflight is there for the first contact); the three-pass many-group
+aggregate's 40 B/row; `c2_expression_trees` (0.55–0.56); joins beyond L2 (line-fetch floor); 5841–8192 groups (two key subsets, 0.38);
+the join build's two scatters (4.1 TB/s of 3.2 GB each).
+"""
+open("profiles/r06/README.md", "w").write(text)
