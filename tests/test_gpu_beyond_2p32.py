@@ -1,6 +1,6 @@
 """More than 2^32 rows through every operator of the path on one MI355X (288 GB: a 5 x 10^9-row Int64 column is 40 GB) — the sizes at
 which a 32-bit row index, tile count or output offset anywhere in a kernel or its host code would wrap.  Data: id = row number
-(synth kind 0), so every expected value is analytic; nothing here needs the CPU oracle.  Skipped when the device has less than 110 GB
+(synth kind 0), so every expected value is analytic; nothing here needs the CPU oracle.  Skipped when the device has less than 180 GB
 free.  Reference operators: aggregate/mod.rs:113-222, selection.rs:58-107, projection.rs:43-70, hash_join.rs:124-254."""
 import numpy as np
 import pytest
@@ -27,8 +27,8 @@ def free_bytes():
 def big():
     from naive_query_engine_amd import capi
 
-    if free_bytes() < 110 * 2**30:
-        pytest.skip("needs 110 GB of free device memory")
+    if free_bytes() < 180 * 2**30:
+        pytest.skip("needs 180 GB of free device memory")
     c = capi.Context(0)
     p = c.device_alloc(N * 8)
     c.synth_fill(0, 0, 0, N, 1, 0, p)
