@@ -70,8 +70,10 @@ for name, c in rows:
     pvc = pv.get("ms_per_step") if name == "headline" else (pv.get("configs", {}).get(name) or {}).get("ms")
     par = c.get("parity") or {}
     ok = par.get("ok")
-    km, rp = c.get("kernel_ms"), rocprof_ms(name)
-    spread = f" [{f(c.get('kernel_ms_min'), 4)} .. {f(c.get('kernel_ms_max'), 4)}]" if c.get("kernel_ms_min") is not None else ""
+    droof = (det.get(name) or {}).get("roofline") or {}   # (the line sheds kernel_ms* first when it outgrows its limit: the details file keeps them)
+    km, rp = c.get("kernel_ms") or droof.get("kernel_ms_per_step"), rocprof_ms(name)
+    kmin, kmax = c.get("kernel_ms_min") or droof.get("kernel_ms_min"), c.get("kernel_ms_max") or droof.get("kernel_ms_max")
+    spread = f" [{f(kmin, 4)} .. {f(kmax, 4)}]" if kmin is not None else ""
     diff = ""
     if km and rp:
         pct = (rp - km) / km * 100.0
