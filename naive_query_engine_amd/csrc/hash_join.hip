@@ -601,15 +601,15 @@ __global__ void __launch_bounds__(256) part_build_place_kernel(PartBuild pb, con
 // ---- Two-level form of the partitioned build (round 6): what the place pass pays for is one scattered 16-byte store per row —
 // 1.9 ms per 10^8 rows whatever its slice size, workgroup count or cursor chunk (profiles/r05/sweep_build_place.txt), plus a zeroed
 // 16-byte record per key written and read back (memset 0.3 + finish 0.6 ms).  Here every store is coalesced: the count pass takes a
-// FINE histogram (2^PB_FINE_LOG2 bins per partition, each PB_FILL_KEYS keys wide: fine_count), so that after the usual scatter into
+// FINE histogram (up to 64 bins per partition, each PB_FILL_KEYS keys wide: fine_count), so that after the usual scatter into
 // partitions a second one — ONE workgroup per partition, a counting sort of 4096-tuple tiles in LDS, runs of a hundred tuples
 // (part_build_split_kernel) — leaves the tuples grouped by fine bin; a fine bin's keys then fit a workgroup's LDS, where its entries
 // are laid out in key order and leave as whole lines of the FINAL tables (row table, presence words, the packed payload column:
 // part_build_fill_kernel) — no key-ordered records, no finish pass.  Key-only builds and builds with one payload word.
 constexpr int PB_FILL_LOG2 = 13, PB_FILL_KEYS = 1 << PB_FILL_LOG2; // keys of a fine bin: 4 + 8 bytes of LDS each
-constexpr int PB_FINE_LOG2 = 5;                                     // fine bins per partition: partition = key >> (PB_FILL_LOG2 + PB_FINE_LOG2)
+constexpr int PB_FINE_LOG2_MAX = 6;                                 // at most 64 fine bins per partition: partition = key >> (PB_FILL_LOG2 + fine_log2), fine_log2 = pb.shift - PB_FILL_LOG2 (the host picks it: see build_unique_fast)
 constexpr int PB_MAX_FINE = 32768;                                  // bins in all: 128 KB of LDS in the count pass (2.7 x 10^8 keys)
-// count pass: this workgroup's rows per FINE bin in LDS; the partition counts of the scatter's offsets are sums of 2^PB_FINE_LOG2 of them, and the
+// count pass: this workgroup's rows per FINE bin in LDS; the partition counts of the scatter's offsets are sums of 2^fine_log2 of them, and the
 // workgroup's fine histogram goes to finehist[w][bin] (added up by part_build_fine_offsets_kernel)
 __global__ void __launch_bounds__(PB_BLOCK) part_build_count_fine_kernel(PartBuild pb, uint32_t *counts, uint32_t *finehist, int bins) {
     extern __shared__ uint32_t fhist[];
@@ -631,7 +631,8 @@ __global__ void __launch_bounds__(PB_BLOCK) part_build_count_fine_kernel(PartBui
     __syncthreads();
     for (int p = threadIdx.x; p < pb.parts; p += blockDim.x) {
         uint32_t c = 0;
-        for (int f = 0; f < (1 << PB_FINE_LOG2); ++f) c += (p << PB_FINE_LOG2) + f < bins ? fhist[(p << PB_FINE_LOG2) + f] : 0u;
+        const int fl = pb.shift - PB_FILL_LOG2;
+        for (int f = 0; f < (1 << fl); ++f) c += (p << fl) + f < bins ? fhist[(p << fl) + f] : 0u;
         counts[size_t(p) * size_t(pb.W) + blockIdx.x] = c;
     }
     for (int b = threadIdx.x; b < bins; b += blockDim.x) finehist[size_t(blockIdx.x) * size_t(bins) + b] = fhist[b];
@@ -639,20 +640,20 @@ __global__ void __launch_bounds__(PB_BLOCK) part_build_count_fine_kernel(PartBui
 // fine_start[b]: where fine bin b's tuples start in the twice-partitioned stream = its partition's start (offsets[p * W], the scatter's
 // scan) + the bins of the partition before it.  One workgroup per partition (thread = bin x an eighth of the count workgroups);
 // fine_start[bins] = rows.
-__global__ void __launch_bounds__(256) part_build_fine_offsets_kernel(const uint32_t *finehist, int W, int bins, int parts, const uint64_t *offsets, uint64_t *fine_start) {
-    constexpr int F = 1 << PB_FINE_LOG2;
-    __shared__ uint32_t part[256 / F][F];
-    const int p = blockIdx.x, f = threadIdx.x % F, q = threadIdx.x / F, b = (p << PB_FINE_LOG2) + f;
+__global__ void __launch_bounds__(256) part_build_fine_offsets_kernel(const uint32_t *finehist, int W, int bins, int parts, int fine_log2, const uint64_t *offsets, uint64_t *fine_start) {
+    const int F = 1 << fine_log2;
+    __shared__ uint32_t part[256]; // [256 / F][F]
+    const int p = blockIdx.x, f = threadIdx.x % F, q = threadIdx.x / F, b = (p << fine_log2) + f;
     uint32_t c = 0;
     if (b < bins)
         for (int w = q; w < W; w += 256 / F) c += finehist[size_t(w) * size_t(bins) + b];
-    part[q][f] = c;
+    part[q * F + f] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint64_t at = offsets[size_t(p) * size_t(W)];
-        for (int ff = 0; ff < F && (p << PB_FINE_LOG2) + ff < bins; ++ff) {
-            fine_start[(p << PB_FINE_LOG2) + ff] = at;
-            for (int qq = 0; qq < 256 / F; ++qq) at += part[qq][ff];
+        for (int ff = 0; ff < F && (p << fine_log2) + ff < bins; ++ff) {
+            fine_start[(p << fine_log2) + ff] = at;
+            for (int qq = 0; qq < 256 / F; ++qq) at += part[qq * F + ff];
         }
         if (p == parts - 1) fine_start[bins] = at;
     }
@@ -663,16 +664,17 @@ __global__ void __launch_bounds__(256) part_build_fine_offsets_kernel(const uint
 constexpr int PB_SPLIT_TILE = 4096;
 template <int NC>
 __global__ void __launch_bounds__(PB_BLOCK) part_build_split_kernel(PartBuild pb, const uint64_t *offsets, const uint64_t *fine_start, int bins, const uint64_t *tuples, uint64_t *out) {
-    constexpr int F = 1 << PB_FINE_LOG2, RPT = PB_SPLIT_TILE / PB_BLOCK;
+    constexpr int FMAX = 1 << PB_FINE_LOG2_MAX, RPT = PB_SPLIT_TILE / PB_BLOCK;
+    const int fine_log2 = pb.shift - PB_FILL_LOG2, F = 1 << fine_log2;
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
     uint64_t *stage = reinterpret_cast<uint64_t *>(pb_smem); // [PB_SPLIT_TILE][1 + NC]
-    __shared__ uint32_t tcnt[F], tstart[F + 1];
-    __shared__ uint64_t cur[F];
+    __shared__ uint32_t tcnt[FMAX], tstart[FMAX + 1];
+    __shared__ uint64_t cur[FMAX];
     for (int p = blockIdx.x; p < pb.parts; p += gridDim.x) {
         const uint64_t s = offsets[size_t(p) * size_t(pb.W)], e = offsets[size_t(p + 1) * size_t(pb.W)];
         __syncthreads(); // (the previous partition's cursors are done with)
-        if (threadIdx.x < F) {
-            const int b = (p << PB_FINE_LOG2) + int(threadIdx.x);
+        if (int(threadIdx.x) < F) {
+            const int b = (p << fine_log2) + int(threadIdx.x);
             cur[threadIdx.x] = b < bins ? fine_start[b] : e;
             tcnt[threadIdx.x] = 0;
         }
@@ -703,10 +705,10 @@ __global__ void __launch_bounds__(PB_BLOCK) part_build_split_kernel(PartBuild pb
             for (int u = 0; u < RPT; ++u) rank[u] = ok[u] ? atomicAdd(&tcnt[f[u]], 1u) : 0u;
             __syncthreads();
             if (threadIdx.x < 64) { // F <= 64 counters: one wave scans them
-                const uint32_t c = threadIdx.x < F ? tcnt[threadIdx.x] : 0u;
+                const uint32_t c = int(threadIdx.x) < F ? tcnt[threadIdx.x] : 0u;
                 uint32_t tot;
                 const uint32_t ex = wave_exclusive_scan(c, tot);
-                if (threadIdx.x < F) tstart[threadIdx.x] = ex;
+                if (int(threadIdx.x) < F) tstart[threadIdx.x] = ex;
                 if (threadIdx.x == 0) tstart[F] = tot;
             }
             __syncthreads();
@@ -732,7 +734,7 @@ __global__ void __launch_bounds__(PB_BLOCK) part_build_split_kernel(PartBuild pb
                 }
             }
             __syncthreads();
-            if (threadIdx.x < F) {
+            if (int(threadIdx.x) < F) {
                 cur[threadIdx.x] += tcnt[threadIdx.x];
                 tcnt[threadIdx.x] = 0;
             }
@@ -1683,11 +1685,21 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             while (shift < 31 && (uint64_t(2) << shift) * uint64_t(4 + 8 * nc) <= uint64_t(slice_kb) * 1024) ++shift;
             while (((span - 1) >> shift) + 1 > uint64_t(PB_MAX_PARTS)) ++shift;
             // two-level form (part_build_split / part_build_fill above): at most one payload word, a key range of at most PB_MAX_PARTS x
-            // 2^PB_FINE_LOG2 fine bins (2.7 x 10^8 keys).  NQE_JOIN_PART_ONE_LEVEL=1 (read per call): the place pass (A/B)
+            // 2^fine_log2 fine bins (2.7 x 10^8 keys).  NQE_JOIN_PART_ONE_LEVEL=1 (read per call): the place pass (A/B)
             const bool two_level = nc <= 1 && span <= (uint64_t(PB_MAX_FINE) << PB_FILL_LOG2) && getenv("NQE_JOIN_PART_ONE_LEVEL") == nullptr &&
                                    size_t(PB_FILL_KEYS) * size_t(4 + 8 * nc) + 4096 <= ctx->lds_per_block && size_t(PB_MAX_FINE) * 4 <= ctx->lds_per_block;
             const int bins = two_level ? int(((span - 1) >> PB_FILL_LOG2) + 1) : 0;
-            if (two_level) shift = PB_FILL_LOG2 + PB_FINE_LOG2;
+            if (two_level) {
+                // fine bins per partition (at most 64): as few partitions as keep about one workgroup of the second scatter per CU —
+                // the first scatter slows down with its partition count (10^8 rows + a payload: 0.77 ms into 191 partitions, 0.86 into
+                // 382, 1.09 into 763), the second one hardly cares how many bins a partition has (profiles/r06/probe_build_fine_bins.txt:
+                // 10^8 keys 64 bins x 191 partitions 2.49 ms, 32 x 382 2.60; 2^25 keys 16 x 256 0.91 / 0.51, 32 x 128 0.91 / 0.57)
+                int fl = PB_FINE_LOG2_MAX;
+                auto parts_at = [&](int l) { return ((span - 1) >> (PB_FILL_LOG2 + l)) + 1; };
+                while (fl > 0 && parts_at(fl) * 10 < uint64_t(ctx->num_cus) * 7 && parts_at(fl - 1) <= uint64_t(PB_MAX_PARTS)) --fl;
+                while (parts_at(fl) > uint64_t(PB_MAX_PARTS)) ++fl;
+                shift = PB_FILL_LOG2 + fl;
+            }
             pb.keys = kc.words();
             pb.n = n;
             pb.dmin = kmin;
@@ -1736,7 +1748,7 @@ bool build_unique_fast(nqe_ctx *ctx, nqe_join_table *jt, const nqe_table *left, 
             if (nc <= 1 && rpt == 8) sk = nc ? part_build_scatter1_kernel<1> : part_build_scatter1_kernel<0>; // (its tile in registers, the next one prefetched)
             launch(ctx, "join_build_part_scatter", sk, dim3(unsigned(pb.W)), dim3(PB_BLOCK), shmem, pb, (const uint64_t *)offsets->ptr, (uint64_t *)tuples->ptr);
             if (two_level) {
-                launch(ctx, "join_build_part_fine_offsets", part_build_fine_offsets_kernel, dim3(unsigned(pb.parts)), dim3(256), 0, (const uint32_t *)finehist->ptr, pb.W, bins, pb.parts,
+                launch(ctx, "join_build_part_fine_offsets", part_build_fine_offsets_kernel, dim3(unsigned(pb.parts)), dim3(256), 0, (const uint32_t *)finehist->ptr, pb.W, bins, pb.parts, pb.shift - PB_FILL_LOG2,
                        (const uint64_t *)offsets->ptr, (uint64_t *)fine_start->ptr);
                 launch(ctx, "join_build_part_split", nc ? part_build_split_kernel<1> : part_build_split_kernel<0>, dim3(unsigned(std::min(pb.parts, 2 * ctx->num_cus))), dim3(PB_BLOCK),
                        size_t(PB_SPLIT_TILE) * size_t(1 + nc) * 8, pb, (const uint64_t *)offsets->ptr, (const uint64_t *)fine_start->ptr, bins, (const uint64_t *)tuples->ptr, (uint64_t *)tuples2->ptr);
