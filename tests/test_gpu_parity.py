@@ -2539,7 +2539,7 @@ def test_aggregate_first_execution_starts_in_the_tier_its_key_sample_picks(ctx, 
         names = ctx.timing_report()
         assert_rows_multiset_equal(got, exp, RTOL, exact_cols=[0], what=f"{shape} rep {rep} no_hints={no_hints}")
         sampled = "agg_key_sample" in names
-        assert sampled == (rep == 0 or no_hints), (shape, rep, no_hints, sorted(names))
+        assert sampled == (rep == 0 or no_hints or bool(os.environ.get("NQE_NO_PLAN_HINTS"))), (shape, rep, no_hints, sorted(names))
         if rep == 0 and shape == "dense_6000":
             assert names.get("agg_grouped_fast", (0, 0))[1] == 1 and "agg_range_emit" in names and "agg_partition_scatter" not in names, sorted(names)
         if rep == 0 and shape in ("sparse_20000", "groups_300000", "all_distinct", "mod_100000", "spread_6000"):
@@ -2830,7 +2830,7 @@ def test_aggregate_mid_size_table_with_many_groups_takes_the_partitioned_path(ct
         got = ctx.aggregate(t, ALL_AGGS(1), group_nodes=kn)
         ctx.timing_enable(False)
         assert ctx.timing_query("agg_partition_scatter")[1] > 0, f"rep {rep}: the partitioned path was expected"
-        if rep > 0 or sample:
+        if (rep > 0 and not os.environ.get("NQE_NO_PLAN_HINTS")) or sample:   # (the whole suite also runs under NQE_NO_PLAN_HINTS=1: nothing is remembered then)
             assert ctx.timing_query("agg_grouped_fast")[1] == 0, f"rep {rep}: no streaming attempt was expected"
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"mid-size table, rep {rep}")
 
