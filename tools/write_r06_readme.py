@@ -14,6 +14,7 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | File | What |
 |---|---|
 | `bench_default.json`, `bench_details.json` | the default `python bench.py` line (26 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity, `frac_step` beside `frac`), per-kernel details |
+| `bench_default_run1.json`, `bench_details_run1.json`; `bench_default_box2.json`, `bench_details_box2.json` | the same default line on two OTHER boxes of the pool, a few commits earlier (no steady-state kernel differs; the join build's partition count does): headline kernel 2.45 ms = 0.816 and 2.33 ms = 0.859 there against `bench_default.json`'s 2.51 = 0.795 — the boxes differ by up to 8 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
 | `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
 | `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
 | `rocprofv3_kernel_stats_<config>.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --workload … --steps 20 --warmup 3` (its own process: the table below compares its averages with the bench line's HIP-event times) — **C3 and C3 over random keys included** (round 5 had none) |
@@ -22,6 +23,8 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | `ab_wide_direct.txt` | 10⁸ rows over 4096 … 6000 random groups: one directly addressed workgroup table without key words (round 6) against two key subsets (`NQE_NO_WIDE_DIRECT=1`) |
 | `probe_build.txt`, `probe_build_two_level_f32.txt`, `probe_build_two_level_f64.txt` | the join build by size and payload: the two-level form (final: 32 fine bins per partition, scatter with its tile in registers and the next prefetched) against the place pass; the first two-level build (before the scatter's prefetch); 64 fine bins per partition (split slower, scatter unchanged) |
 | `ab_c2tree.txt`, `ab_c2tree_look.txt`, `ab_c2tree_pipe.txt` | the one-pass selection + projection kernel taken apart: without its stores / look-back / both; K statuses per look-back round trip; a software-pipelined loop (experiment builds of the generator, not kept) |
+| `two_kernel_floor.txt` | `tools/probe_two_kernel_floor.py`: the bytes of the two-kernel selection + projection through the best static kernels (no arithmetic) against the one-pass kernel on the tree query: 0.566 vs 0.544 ms |
+| `probe_build_fine_bins.txt` | the two-level join build by fine bins per partition (4 … 64), sweeps and alternating A/B runs on one box |
 | `ab_soa_threads.txt` | the many-group aggregate's scatter at 512 × 2, 256 × 4 and 1024 × 1 threads × workgroups per CU |
 | `../r06_notes.md` | the raw measurement notes the sections of DESIGN.md were written from |
 
