@@ -35,7 +35,7 @@ events time them in the bench process, with min .. max over the blocks; **kernel
 config's own `rocprofv3 --stats` run (another process, often another box); **differ** flags more than 3 % between the two — read
 `frac` with that spread in mind.  `frac` = SURVEY §8d bytes over the HIP-event kernel time as a fraction of 8 TB/s; **`frac_step`** =
 the same bytes over `ms` (the step's wall time — the number a clock outside the library can vouch for).  Parity: rows compared with an
-independent CPU result in the same run (every aggregate config, C2 forms, C4: EVERY row / group).  "previous round ms" is r05's line,
+independent CPU result in the same run — EVERY row / group of EVERY config (the join variants too: the port over chunks of probe rows on threads).  "previous round ms" is r05's line,
 another box and — where the last column says so — another definition.
 
 {table}
