@@ -1686,6 +1686,9 @@ PassStatus AggRun::tier_streaming(int v0) {
         bool tiny = sw.tiny_groups && tiny_ok && !jit_whole && ka.direct == 1 && (fast_key == 1 || fast_key == 2) && tm >= 1 && tm <= 4 && (fp == 0 || fp == 1) && !vnull &&
                     subsets_log2 == 0 && key_col >= 0 && a.nv >= 1 && a.nv <= 3 && in->rows >= (int64_t(1) << 20);
         for (int j = 0; tiny && j < a.nv; ++j) tiny = a.val[j].values != nullptr && (j == a.nv - 1 || !a.need_minmax[j]);
+        // (its tiles are read in 16-byte loads: a column that starts on an odd word — a slice of a borrowed buffer — takes the streaming kernel)
+        tiny = tiny && (reinterpret_cast<uintptr_t>(a.key_src.values) & 15u) == 0;
+        for (int j = 0; tiny && j < a.nv; ++j) tiny = (reinterpret_cast<uintptr_t>(a.val[j].values) & 15u) == 0;
         if (tiny) {
             const size_t cells = size_t(fgrid) * size_t(tm), col_words = (cells * 28 + 7) / 8;
             BufRef partials = dev_alloc(ctx, col_words * 8 * size_t(a.nv) + 64);

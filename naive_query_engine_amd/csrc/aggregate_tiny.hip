@@ -13,8 +13,11 @@
 #include "device_utils.hpp"
 #include "nqe_internal.hpp"
 
+#ifndef NQE_TINY_PAIR
+#define NQE_TINY_PAIR 1 // rows in pairs, one 16-byte load per pair and column (round 6); 0: 8-byte loads, a lane's rows 1024 apart (round 5, A/B)
+#endif
 #ifndef NQE_TINY_U
-#define NQE_TINY_U (NVT == 1 ? 4 : NVT == 2 ? (MM ? 2 : 4) : (TG_K == 3 && SH0) ? (MM ? 3 : 4) : 2) // (beside min / max and several value columns more rows spill inside the loop: checked per instance in the ISA)
+#define NQE_TINY_U (NVT == 1 ? 4 : NVT == 2 ? (MM ? 2 : 4) : (TG_K == 3 && SH0) ? (MM ? (NQE_TINY_PAIR ? 2 : 3) : 4) : 2) // (beside min / max and several value columns more rows spill inside the loop: checked per instance in the ISA)
 #endif
 namespace nqe {
 namespace agg {
@@ -66,8 +69,34 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_tiny_groups_kernel(AggArgs a, F
         uint64_t kw[TG_U], vw[NL > 0 ? NL : 1][TG_U];
     };
     const int64_t n = a.n, last = n - 1, step = int64_t(AGG_BLOCK) * TG_U, stride = int64_t(gridDim.x) * step;
+#if NQE_TINY_PAIR
+    // rows in pairs: lane t takes rows 2 t, 2 t + 1 of every 2048-row half-tile — ONE 16-byte load per pair and column instead of two
+    // 8-byte loads 8 KB apart (three 8 GB streams: 4.19 -> 3.98 ms for the README query, 4.13 -> 3.97 for C1's list, A/B on one box;
+    // the host takes this kernel only for 16-byte aligned columns: AggRun::tier_streaming).  Nothing here depends on which rows a lane
+    // holds: the accumulators are per key, not per run.
+    typedef unsigned long long tiny_u64x2 __attribute__((ext_vector_type(2)));
+    auto row_of = [&](int64_t base, int u) { return base + int64_t(u / 2) * (2 * AGG_BLOCK) + 2 * int64_t(threadIdx.x) + (u & 1); };
+#else
+    auto row_of = [&](int64_t base, int u) { return base + int64_t(u) * AGG_BLOCK + threadIdx.x; };
+#endif
     auto load = [&](Tile &t, int64_t base) {
         if (base + step <= n) { // a whole tile: scalar tile pointer + the lane's 32-bit offsets
+#if NQE_TINY_PAIR
+            static_assert(TG_U % 2 == 0, "pairs");
+#pragma unroll
+            for (int u = 0; u < TG_U; u += 2) {
+                const uint32_t o = uint32_t(u / 2) * (2 * AGG_BLOCK) + 2 * threadIdx.x;
+                const tiny_u64x2 k2 = __builtin_nontemporal_load(reinterpret_cast<const tiny_u64x2 *>(keyp + base + o));
+                t.kw[u] = k2.x;
+                t.kw[u + 1] = k2.y;
+#pragma unroll
+                for (int j = SH0 ? 1 : 0; j < NVT; ++j) {
+                    const tiny_u64x2 v2 = __builtin_nontemporal_load(reinterpret_cast<const tiny_u64x2 *>(valp[j] + base + o));
+                    t.vw[SH0 ? j - 1 : j][u] = v2.x;
+                    t.vw[SH0 ? j - 1 : j][u + 1] = v2.y;
+                }
+            }
+#else
 #pragma unroll
             for (int u = 0; u < TG_U; ++u) {
                 const uint32_t o = uint32_t(u) * AGG_BLOCK + threadIdx.x;
@@ -75,10 +104,11 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_tiny_groups_kernel(AggArgs a, F
 #pragma unroll
                 for (int j = SH0 ? 1 : 0; j < NVT; ++j) t.vw[SH0 ? j - 1 : j][u] = __builtin_nontemporal_load(valp[j] + base + o);
             }
+#endif
         } else {
 #pragma unroll
             for (int u = 0; u < TG_U; ++u) {
-                int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+                int64_t row = row_of(base, u);
                 row = row < last ? row : last;
                 t.kw[u] = __builtin_nontemporal_load(keyp + row);
 #pragma unroll
@@ -102,7 +132,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_tiny_groups_kernel(AggArgs a, F
     auto process = [&](const Tile &t, int64_t base) {
 #pragma unroll
         for (int u = 0; u < TG_U; ++u) {
-            const int64_t row = base + int64_t(u) * AGG_BLOCK + threadIdx.x;
+            const int64_t row = row_of(base, u);
             bool ok = row < n;
             if (PRED == 1) ok = ok && range_pass(fp, t.kw[u]);
             oob = oob || (ok && key_signed && int64_t(t.kw[u]) < 0);

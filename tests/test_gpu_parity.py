@@ -2931,6 +2931,34 @@ def test_aggregate_at_most_four_groups_in_registers(ctx, m, shape):
             np.isin(np.unique(np.fmod(ids, m) if shape != "uint64_key" else (ids.astype(np.uint64) % np.uint64(m)).astype(np.int64)), kk.astype(np.int64))]).all()
 
 
+def test_register_kernel_is_not_taken_for_columns_on_an_odd_word(ctx):
+    """the register kernel reads its tiles in 16-byte loads (round 6): a table whose columns start 8 bytes into a borrowed buffer (a
+    slice: row 1 onwards) must take the streaming kernel instead — same result as the oracle's over those rows, and the aligned table
+    over the same buffers still takes the register kernel"""
+    rng = np.random.default_rng(4321)
+    n = (1 << 20) + 1001
+    ids = rng.integers(0, 1 << 40, n).astype(np.int64)
+    age = rng.integers(18, 78, n).astype(np.int64)
+    score = rng.random(n) * 100.0
+    cols = [Column.from_numpy(ids), Column.from_numpy(age), Column.from_numpy(score)]
+    whole = ctx.table_from_host(cols)
+    ptrs = [int(whole.column_info(i).values) for i in range(3)]
+    odd = ctx.table_from_device([(DType.INT64, n - 1, ptrs[0] + 8, None), (DType.INT64, n - 1, ptrs[1] + 8, None), (DType.FLOAT64, n - 1, ptrs[2] + 8, None)])
+    f3 = fields("id", "age", "score")
+    key = binop(col(0), Operator.Modulos, lit_i64(3)).flatten(f3)
+    A = AggregateFunc
+    aggs = [(A.Count, 0), (A.Sum, 1), (A.Sum, 2), (A.Avg, 2), (A.Max, 2), (A.Min, 2)]
+    for t, sl, expect_tiny in ((odd, slice(1, None), False), (whole, slice(None), True)):
+        exp = orc.aggregate([[Column.from_numpy(ids[sl]), Column.from_numpy(age[sl]), Column.from_numpy(score[sl])]], aggs, group_nodes=key)[0]
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got = ctx.aggregate(t, aggs, group_nodes=key)
+        ctx.timing_enable(False)
+        assert (ctx.timing_query("agg_grouped_tiny")[1] > 0) == expect_tiny
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"README query, register kernel {expect_tiny}")
+    del odd
+
+
 @pytest.mark.parametrize("m", [3, 4])
 def test_register_kernel_unpacks_its_packed_counters_mid_run(m, monkeypatch):
     """aggregate_tiny.hip keeps the per-key row counts of a lane in ONE packed word and unpacks it every 4096 tiles — a branch a workgroup

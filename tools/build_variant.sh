@@ -11,7 +11,7 @@ mkdir -p $D
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 CXX="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -fno-gpu-rdc $FLAGS"
 pids=()
-for f in context exchange arrow_c expr selection sort aggregate aggregate_fast aggregate_partition aggregate_tiny hash_join strings csv; do
+for f in context exchange arrow_c expr selection sort aggregate aggregate_tail aggregate_fast aggregate_partition aggregate_tiny hash_join strings csv; do
   ( $HIPCC $CXX -c $f.hip -o $D/$f.o ) & pids+=($!)
 done
 for p in 0 1 2 3; do for v in 0 1; do
