@@ -14,7 +14,8 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | File | What |
 |---|---|
 | `bench_default.json`, `bench_details.json` | the default `python bench.py` line (26 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity, `frac_step` beside `frac`), per-kernel details |
-| `bench_default_run2.json`, `bench_details_run2.json` | the default line of the profile round itself (same kernels; its C4 variants still compared on 5×10⁶ probe rows — `bench.py` gained their full-size check afterwards): headline kernel 2.51 ms = 0.795 |
+| `bench_default_run3.json`, `bench_details_run3.json` | the default line one revision earlier (before the register kernel's paired loads), another box: headline kernel 2.43 ms = 0.822, `agg_readme_shape` 0.722, `agg_three_value_columns` 0.740 |
+| `bench_default_run2.json`, `bench_details_run2.json` | the default line of an earlier profile round (its C4 variants still compared on 5×10⁶ probe rows — `bench.py` gained their full-size check afterwards): headline kernel 2.51 ms = 0.795 |
 | `bench_default_run1.json`, `bench_details_run1.json`; `bench_default_box2.json`, `bench_details_box2.json` | the same default line on two OTHER boxes of the pool, a few commits earlier (no steady-state kernel differs; the join build's partition count does): headline kernel 2.45 ms = 0.816 and 2.33 ms = 0.859 — the boxes differ by up to 8 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
 | `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
 | `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
@@ -56,6 +57,8 @@ another box and — where the last column says so — another definition.
   rows through aggregate, selection, projection and join probe, > 2³² OUTPUT rows through the selection: green as written — the row
   arithmetic was 64-bit); the register kernel's unpack branch runs under a test hook; ADVICE r05's Utf8-key bug reproduced on
   hardware by the new test, then fixed.
+* **The README query 0.74 → 0.755, C1's list 0.76 → 0.77–0.81**: the register kernel reads its rows in pairs (16-byte loads); the same idea
+  measured on the many-group scatter (no gain) and C4's one-pass probe (17 % slower) and not kept there (`../r06_notes.md`).
 * **Measured, and left as it is** — with the numbers: the many-group aggregate's scatter (5.03 TB/s of its 2.8 GB; the memory pattern
   alone takes as long; 256 × 4 and 1024 × 1 slower, more waves spill: `ab_soa_threads.txt`, DESIGN §3.3); the one-pass selection +
   projection kernel (stores, look-back and loads ADD up to its 0.548 ms; wider look-backs and a pipelined loop both slower:
