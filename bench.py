@@ -64,6 +64,7 @@ def parse(argv=None):
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the BASELINE size of the workload)")
     ap.add_argument("--random-keys", action="store_true", help="c3/headline: group by a random id column instead of the row number")
     ap.add_argument("--groups", type=int, default=65536, help="agg_groups: distinct keys")
+    ap.add_argument("--no-minmax", action="store_true", help="agg_groups: count / sum / avg only")
     ap.add_argument("--dim-rows", type=int, default=10**6, help="c4: build-side rows")
     ap.add_argument("--pass-frac", type=float, default=0.5, help="headline: fraction of rows passing `id < K` (diagnostics; the metric uses 0.5)")
     ap.add_argument("--gather", action="store_true", help="c4 with --gpus N: also all-gather every rank's output batch in rank order (BASELINE config C5)")
@@ -441,6 +442,9 @@ def agg_shape(name, total, random_keys=False, groups=None):
     five = lambda c: [(AGG.Count, c), (AGG.Sum, c), (AGG.Avg, c), (AGG.Min, c), (AGG.Max, c)]
     key_mod = lambda m: binop(col(0), Operator.Modulos, lit_i64(m))
     lt = lambda limit: binop(col(0), Operator.Lt, lit_i64(limit))
+    if groups is not None and name == "no_minmax":   # … without min / max: 12-byte slots, one workgroup table up to 13632 keys (round 6)
+        return dict(cols=[("k", 1, 7, groups, 0, "i64"), ("v", 2, 3, 1, 0, "f64")], aggs=[(AGG.Count, 1), (AGG.Sum, 1), (AGG.Avg, 1)], key=col(0), pred=None, bpr=16.0,
+                    full=(groups, 1), text=f"select count(v),sum(v),avg(v) from t group by k; k random in [0, {groups})")
     if groups is not None:      # many distinct keys: key = a random Int64 column in [0, groups)
         return dict(cols=[("k", 1, 7, groups, 0, "i64"), ("v", 2, 3, 1, 0, "f64")], aggs=five(1), key=col(0), pred=None, bpr=16.0, full=(groups, 1),
                     text=f"select count(v),sum(v),avg(v),min(v),max(v) from t group by k; k random in [0, {groups})")
@@ -1258,9 +1262,9 @@ def main():
         name = {"headline_int64": "headline_int64_values", "headline_single": "headline_single_column", "agg3": "agg_three_value_columns", "agg_readme": "agg_readme_shape",
                 "tree_pred": "agg_tree_predicate"}.get(wl, wl) + ("_random_keys" if args.random_keys else "")
     elif wl == "agg_groups":
-        res, st = wl_aggregate(B, n, False, False, args.steps, args.warmup, groups=args.groups)
+        res, st = wl_aggregate(B, n, False, False, args.steps, args.warmup, groups=args.groups, shape="no_minmax" if args.no_minmax else "v")
         par = parity_aggregate_both(B, st, min(args.cpu_sample_rows, 20_000_000), par_threads) if want_cpu else None
-        name = f"agg_{args.groups}_groups"
+        name = f"agg_{args.groups}_groups" + ("_count_sum_avg" if args.no_minmax else "")
     elif wl == "c2_tree":
         res, st = wl_c2_tree(B, n, args.steps, args.warmup)
         par = parity_c2_tree(B, st, n) if want_cpu else None
@@ -1365,6 +1369,8 @@ def main():
             add("c4_partial_match", lambda: wl_c4(B, 10**8, 10**6, "partial", csteps, cwarm, **kw), pj)
             for G in (4096, 5000, 6000, 65536, 1 << 20):  # 5000: one directly addressed table without key words (round 6); 6000: two key subsets over a direct-mapped table
                 add(f"agg_{G}_groups", lambda G=G: wl_aggregate(B, 10**8, False, False, csteps, cwarm, groups=G, **kw), pa(10_000_000))
+            # count / sum / avg only: no min / max arrays in the workgroup table — 12 bytes per slot, ONE table up to 13632 keys (round 6)
+            add("agg_12000_groups_count_sum_avg", lambda: wl_aggregate(B, 10**8, False, False, csteps, cwarm, groups=12000, shape="no_minmax", **kw), pa(10_000_000))
         else:
             # the headline without its exchange (every rank aggregates its shard only): step time with and without
             add("headline_local_only", lambda: wl_aggregate(B, n, True, False, csteps, cwarm, exchange=False, blocks=cblocks))

@@ -735,6 +735,8 @@ AggResult emit(nqe_ctx *ctx, TableBufs &tb, bool grouped, int key_dtype, const n
 // one workgroup table of the streaming kernel addressed directly (`col % m`, a measured key range), one value column, no validity bitmaps:
 // the table carries no key words (aggregate_fast_kernel.hpp: nokeys) — 28 bytes per slot, 5841 slots in 160 KB
 constexpr uint64_t DIRECT_WIDE_SLOTS = 5840;
+// … and when no aggregate asks for min / max (count / sum / avg: the MM = false instance, 12 bytes per slot): 13633 slots in 160 KB
+constexpr uint64_t DIRECT_WIDE_SLOTS_NOMM = 13632;
 constexpr uint64_t RANGE_TIER_MAX_SLOTS = 5120;             // slots of one LDS table of the range tier (28 bytes each)
 constexpr uint64_t TINY_SALT = 0xC2B2AE3D27D4EB4Full;       // nqe_ctx::agg_key_ranges[hint ^ salt] present: the tiny-groups kernel met a key outside [0, m)
 constexpr uint64_t PART_RANGE_SALT = 0x9E3779B97F4A7C15ull; // nqe_ctx::agg_key_ranges[hint ^ salt]: the key range of the query's groups (range partitions)
@@ -1056,6 +1058,9 @@ void AggRun::load_hints() {
     subsets_ok = V == 1 && !any_val_nullable && !a.key_src.valid && !(a.pred_mode != 0 && a.pred_src.valid);
     range_limit = V <= 1 ? 4096 : 2048; // the smallest workgroup table among the passes
     direct_one_limit = (subsets_ok && getenv("NQE_NO_WIDE_DIRECT") == nullptr) ? DIRECT_WIDE_SLOTS : range_limit; // (subsets_ok: one value column, no validity anywhere; the switch: A/B, read per call)
+    // no predicate, no min / max, a plain key column or `col % m`: the 12-byte slots of the MM = false instance (tier_streaming: nomm1 — the
+    // same conditions, so that a range the planner turns on is one the pass can address)
+    if (direct_one_limit == DIRECT_WIDE_SLOTS && a.pred_mode == 0 && V == 1 && !plan.need_minmax[0] && a.key.nops <= 1) direct_one_limit = DIRECT_WIDE_SLOTS_NOMM;
     key_flip = a.key_src.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
     plain_int_key = key_col >= 0 && !utf8_key && a.key.nops == 0 && !a.key_src.valid && (a.key_src.dtype == NQE_INT64 || a.key_src.dtype == NQE_UINT64);
 }
@@ -1631,8 +1636,11 @@ PassStatus AggRun::tier_streaming(int v0) {
         fshmem = ((size_t(4097) * (8 + 28)) + 15) / 16 * 16;
     }
     // (round 6) a directly addressed table without validity bitmaps has no key words: up to DIRECT_WIDE_SLOTS keys in ONE workgroup table
+    // nomm1: one value column nobody asks min / max of, through the instance without those arrays (12 instead of 28 bytes per slot)
+    const bool nomm1 = a.nv == 1 && !a.need_minmax[0] && !vnull && (fp == 0 || fp == 1) && fast_key != 3 && subsets_log2 == 0;
+    const size_t slot_bytes = nomm1 ? 12 : 28;
     auto widen = [&](uint64_t span) {
-        if (a.nv != 1 || vnull || subsets_log2 != 0 || span > direct_one_limit || span > DIRECT_WIDE_SLOTS) return false;
+        if (a.nv != 1 || vnull || subsets_log2 != 0 || span > direct_one_limit || span > (nomm1 ? DIRECT_WIDE_SLOTS_NOMM : DIRECT_WIDE_SLOTS)) return false;
         ka.lds_cap = int32_t((span + 15) & ~uint64_t(15));
         return true;
     };
@@ -1665,7 +1673,7 @@ PassStatus AggRun::tier_streaming(int v0) {
     }
     if (ka.direct && !vnull) { // no key words in the table (aggregate_fast_kernel.hpp: nokeys); a widened table: its own slot count
         const size_t fslots = size_t(ka.lds_cap) + 1;
-        fshmem = a.nv == 1 ? fslots * 28 : fshmem - fslots * 8;
+        fshmem = a.nv == 1 ? fslots * slot_bytes : fshmem - fslots * 8;
         fshmem = (fshmem + 15) / 16 * 16;
     }
     ka.subset_shift = ka.lds_shift - 3; // the bits below the table's slot bits (subsets_log2 <= 3)
@@ -1675,7 +1683,7 @@ PassStatus AggRun::tier_streaming(int v0) {
                        !vnull && (a.nv == NVMAX || !vf64) && subsets_log2 == 0;
     // no aggregate of the pass asks for min / max: instances without those LDS arrays (two and three columns, and the
     // single-load one — `count(id) … group by id % 3` updates one LDS word per row instead of reading two and updating four)
-    bool nomm = a.nv >= 2 || share;
+    bool nomm = a.nv >= 2 || share || nomm1;
     for (int j = 0; j < a.nv; ++j) nomm = nomm && !a.need_minmax[j];
     // a predicate tree the static kernel would interpret (PRED 5 / 6) over `col % m` keys and one value column: the lean
     // run-time specialised kernel, once it has been compiled — its workgroup tables are folded into the group table here
@@ -1966,7 +1974,7 @@ bool AggRun::react_to_flags(const int *f, const Collected &pre) {
                 range_sampled = false;
             }
             const uint64_t span = rt->second.second;
-            if (span != 0 && span <= direct_one_limit) { // ONE table addressed by key - min takes it after all (the hashed attempt gave up at three quarters of its slots)
+            if (span != 0 && span <= direct_one_limit && attempt < 6) { // ONE table addressed by key - min takes it after all (the hashed attempt gave up at three quarters of its slots)
                 range_on = true;
                 range_min = rt->second.first;
                 range_span = span;

@@ -692,6 +692,12 @@ template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf
             return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 3, true, false, false, true> : agg_grouped_fast_kernel<PRED, KEY, 3, false, false, false, true>;
         }
     }
+    if constexpr (!VNULL && PRED <= 1 && KEY != 3) {
+        // one value column nobody asks min / max of (count / sum / avg): no min / max arrays — 12 bytes per slot of a direct-mapped table,
+        // 13632 keys in one workgroup table (round 6)
+        if (nomm && nv == 1 && !sub && !share)
+            return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, false, false, false> : agg_grouped_fast_kernel<PRED, KEY, 1, false, false, false, false>;
+    }
     if (nv == 3) return nullptr; // (three columns: the instances above only)
     if (sub) {
         // (PRED 4: a query that outgrows one table continues with a materialised predicate; its slice is built without validity only)

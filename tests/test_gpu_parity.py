@@ -2126,21 +2126,25 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
 
 
 @pytest.mark.parametrize("kind", ["range_5000", "range_5840_at_limit", "range_5841_two_subsets", "negative_base", "u64_mod_5000", "predicate", "nan_values", "int_values", "value_is_key",
-                                  "count_and_sum_only"])
+                                  "count_and_sum_only", "count_and_sum_only_13000", "count_and_sum_only_13632_at_limit", "count_and_sum_only_13633_beyond", "count_and_sum_only_u64_mod_12000",
+                                  "count_and_sum_only_predicate_9000"])
 def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
     """4097 .. 5840 values between a key column's min and max (or `col % m`, m <= 5840, UInt64), one value column, no validity bitmaps:
     ONE directly addressed workgroup table (round 6 — the table carries no key words: 28 bytes per slot), where two workgroups per row
     range each read every row before; 5841 values still take two key subsets.  Against the oracle on the first, the remembered and a
     third execution, keys in order, and the same with the switch NQE_NO_WIDE_DIRECT=1 (the two-subset form).  aggregate/mod.rs:113-222"""
     rng = np.random.default_rng(len(kind) + 600)
-    n = 4_000_000 if kind == "predicate" else 1_200_000
-    groups = {"range_5840_at_limit": 5840, "range_5841_two_subsets": 5841}.get(kind, 5000)
+    n = 4_000_000 if "predicate" in kind else 1_200_000
+    # (count / sum / avg only: the instance without min / max arrays — 12 bytes per slot, one table up to 13632 keys; under a predicate the
+    # planner keeps the 28-byte limit, so 9000 keys take the next tier)
+    groups = {"range_5840_at_limit": 5840, "range_5841_two_subsets": 5841, "count_and_sum_only_13000": 13000, "count_and_sum_only_13632_at_limit": 13632,
+              "count_and_sum_only_13633_beyond": 13633, "count_and_sum_only_predicate_9000": 9000}.get(kind, 5000)
     base = {"negative_base": -2500, "range_5840_at_limit": 10**12}.get(kind, 0)
     draw = rng.integers(0, groups, n)
     draw[:2] = [0, groups - 1]
-    if kind == "u64_mod_5000":
+    if kind in ("u64_mod_5000", "count_and_sum_only_u64_mod_12000"):
         kc = Column.from_numpy(rng.integers(0, 1 << 62, n).astype(np.uint64))
-        key = binop(col(0), Operator.Modulos, lit_u64(5000))
+        key = binop(col(0), Operator.Modulos, lit_u64(5000 if kind == "u64_mod_5000" else 12000))
     else:
         kc = Column.from_numpy((draw + base).astype(np.int64))
         key = col(0)
@@ -2150,9 +2154,9 @@ def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
     cols = [kc, Column.from_numpy(v), Column.from_numpy(rng.random(n))]
     f3 = fields("k", "v", "w")
     kn = key.flatten(f3)
-    pn = binop(col(2), Operator.Lt, lit_f64(0.5)).flatten(f3) if kind == "predicate" else None
+    pn = binop(col(2), Operator.Lt, lit_f64(0.5)).flatten(f3) if kind in ("predicate", "count_and_sum_only_predicate_9000") else None
     # (value_is_key: `sum(k) … group by k` — the single-load instance; count_and_sum_only: no aggregate asks for min / max)
-    aggs = ALL_AGGS(0) if kind == "value_is_key" else [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1)] if kind == "count_and_sum_only" else ALL_AGGS(1)
+    aggs = ALL_AGGS(0) if kind == "value_is_key" else [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1)] if kind.startswith("count_and_sum_only") else ALL_AGGS(1)
     exp = orc.aggregate([cols], aggs, group_nodes=kn, pred_nodes=pn)[0]
     t = ctx.table_from_host(cols)
     for rep in range(3):
@@ -2164,7 +2168,7 @@ def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{kind} run {rep}")
         kk = gk.to_host()[0].to_numpy()
         assert len(np.unique(kk)) == len(kk) == got.num_rows
-        if rep >= 1 and not os.environ.get("NQE_NO_PLAN_HINTS"):
+        if rep >= 1 and not os.environ.get("NQE_NO_PLAN_HINTS") and kind not in ("count_and_sum_only_13633_beyond", "count_and_sum_only_predicate_9000"):
             assert "agg_partition_scatter" not in names and names["agg_grouped_fast"][1] == 1, names
     monkeypatch.setenv("NQE_NO_WIDE_DIRECT", "1")
     monkeypatch.setenv("NQE_NO_PLAN_HINTS", "1")

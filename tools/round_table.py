@@ -48,6 +48,7 @@ def rocprof_ms(name):
 # what changed in a row's DEFINITION since the previous round (so that the "previous round" column is not read as a like-for-like A/B)
 NOTES = {
     "agg_5000_groups": "new in round 6 (one directly addressed workgroup table without key words; the two-subset form it replaces: 0.60 ms per step, ab_wide_direct.txt)",
+    "agg_12000_groups_count_sum_avg": "new in round 6 (count / sum / avg only: 12-byte slots, one workgroup table up to 13632 keys; with min / max the same keys take the range tier: 0.84 ms per step, probe_no_minmax.txt)",
     "c2": "kernel time now includes the tile-count scan (scan_single, 13 us)",
     "c2_random_ids": "kernel time now includes the tile-count scan (scan_single, 13 us)",
     "c2_expression_trees": "",

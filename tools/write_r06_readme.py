@@ -22,6 +22,7 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | `rocprofv3_kernel_stats_<config>.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --workload … --steps 20 --warmup 3` (its own process: the table below compares its averages with the bench line's HIP-event times) — **C3 and C3 over random keys included** (round 5 had none) |
 | `pmc_traffic_<config>.json`, `pmc_calibration.json`, `summary.json` | HBM bytes per step from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, calibrated in the same run on `tools/stream_bench` |
 | `probe_*.txt`, `micro_bench.txt` | the diagnostic sweeps of earlier rounds, re-run on this revision (`probe_build.txt`: the join build, two-level against one-level) |
+| `probe_no_minmax.txt` | `tools/probe_no_minmax.py`: count / sum / avg against the five-aggregate list over 4096 … 14000 random groups |
 | `ab_wide_direct.txt` | 10⁸ rows over 4096 … 6000 random groups: one directly addressed workgroup table without key words (round 6) against two key subsets (`NQE_NO_WIDE_DIRECT=1`) |
 | `probe_build.txt`, `probe_build_two_level_f32.txt`, `probe_build_two_level_f64.txt` | the join build by size and payload: the two-level form (final: 32 fine bins per partition, scatter with its tile in registers and the next prefetched) against the place pass; the first two-level build (before the scatter's prefetch); 64 fine bins per partition (split slower, scatter unchanged) |
 | `ab_c2tree.txt`, `ab_c2tree_look.txt`, `ab_c2tree_pipe.txt` | the one-pass selection + projection kernel taken apart: without its stores / look-back / both; K statuses per look-back round trip; a software-pipelined loop (experiment builds of the generator, not kept) |
@@ -47,6 +48,8 @@ another box and — where the last column says so — another definition.
   validity never reads its key words — the array is no longer laid out (28 B per slot, 5841 slots in 160 KB), the planner's one-table
   limit follows, the table folds into the range tier's tail: 4500 / 5000 / 5840 random groups 0.62 / 0.60 / 0.59 → **0.36 / 0.34 / 0.34 ms**
   per 10⁸ rows = 0.37 → **0.71** of 8 TB/s (`ab_wide_direct.txt`).
+* **… and 13632 keys without min / max** (`agg_12000_groups_count_sum_avg`, new): count / sum / avg through the instance without min /
+  max arrays, 12 B per slot: 6000–13632 groups 0.33–0.35 ms per step where the five-aggregate list takes 0.58–0.84 (`probe_no_minmax.txt`).
 * **The 10⁸-row join build 4.27 → 2.54 ms** (key + one payload; key only 2.23 → 1.58; 2²⁵ rows 1.53 → 0.88): a second partition
   level — fine histogram in the count pass, one workgroup per partition sorting its tuples by 8192-key fine bin, LDS fill of the FINAL
   tables in whole lines — replaces the place pass (one scattered 16-byte store per row: 1.9 ms), the zeroed key-ordered records and
