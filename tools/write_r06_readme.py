@@ -69,7 +69,7 @@ another box and — where the last column says so — another definition.
 * **Measurement**: `frac_step` on every config; C2's kernel set includes the scan; C3 profiled like every other config.
 * **Structure**: 32 of round 5's 56 environment switches retired (constants; the forms that lost are deleted: the striped keep pass,
   one-tile-per-wave selection kernels, the 1024-thread scatter instances, eight-rows-per-lane expression instance …); `aggregate.hip`
-  3035 → 2290 lines (`aggregate_tail.hip`); library 29.9 → 28.4 MB, clean build 4 → 3 min.
+  3035 → 2290 lines (`aggregate_tail.hip`); library 29.9 → 28.4 MB, clean build 4 → 3 min (29.3 MB with the twelve no-min/max instances added afterwards).
 
 ## Open
 
