@@ -1164,8 +1164,9 @@ def compact(res):
     """a config's record in the line: numbers only (the text and the per-kernel map go to the details file)"""
     roof = res["roofline"]
     out = {"ms": r4(res["ms_per_step"]), "ms_min": r4(res["spread"]["ms_min"]), "ms_max": r4(res["spread"]["ms_max"]),
-           "kernel_ms": r4(roof["kernel_ms_per_step"]), "frac": r4(roof["frac"]), "frac_physical": r4(roof.get("frac_physical")),
-           "rows": res["rows_per_gpu"]}
+           "kernel_ms": r4(roof["kernel_ms_per_step"]), "frac": r4(roof["frac"]), "rows": res["rows_per_gpu"]}
+    if roof.get("frac_physical") is not None:   # (only where the bytes that move differ from SURVEY 8d's: the line has a size limit)
+        out["frac_physical"] = r4(roof["frac_physical"])
     for k in ("frac_step", "kernel_ms_min", "kernel_ms_max", "frac_8d", "frac_end_to_end", "build_ms", "execute_call_ms", "two_pass_ms", "execute_over_two_pass", "traffic_ratio"):
         if roof.get(k) is not None:
             out[k] = r4(roof[k])
@@ -1196,7 +1197,7 @@ def finish_line(out):
     out.pop("summary", None)
     out["summary"] = summary_of(out)
     line = json.dumps(out, separators=(",", ":"))
-    for k in ("rows", "ms_min", "ms_max", "cpu_rows_per_s", "cold_ms", "kernel_ms_min", "kernel_ms_max", "kernel_ms"):
+    for k in ("rows", "ms_min", "ms_max", "cpu_rows_per_s", "cold_ms", "kernel_ms_min", "kernel_ms_max", "kernel_ms", "traffic_ratio", "execute_call_ms", "two_pass_ms"):
         if len(line) <= LINE_LIMIT:
             break
         for c in out.get("configs", {}).values():
