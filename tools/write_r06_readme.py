@@ -14,9 +14,7 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | File | What |
 |---|---|
 | `bench_default.json`, `bench_details.json` | the default `python bench.py` line (26 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity, `frac_step` beside `frac`), per-kernel details |
-| `bench_default_run3.json`, `bench_details_run3.json` | the default line one revision earlier (before the register kernel's paired loads), another box: headline kernel 2.43 ms = 0.822, `agg_readme_shape` 0.722, `agg_three_value_columns` 0.740 |
-| `bench_default_run2.json`, `bench_details_run2.json` | the default line of an earlier profile round (its C4 variants still compared on 5×10⁶ probe rows — `bench.py` gained their full-size check afterwards): headline kernel 2.51 ms = 0.795 |
-| `bench_default_run1.json`, `bench_details_run1.json`; `bench_default_box2.json`, `bench_details_box2.json` | the same default line on two OTHER boxes of the pool, a few commits earlier (no steady-state kernel differs; the join build's partition count does): headline kernel 2.45 ms = 0.816 and 2.33 ms = 0.859 — the boxes differ by up to 8 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
+| `bench_default_run5.json` … `bench_default_run1.json`, `bench_default_box2.json` (+ `bench_details_*`) | the default line on six OTHER boxes of the pool in the course of the round (run5: the final csrc revision, the run the rocprofv3 / PMC files were made beside; run4: before the no-min/max instances; run3: before the register kernel's paired loads; run2: its C4 variants still compared on a sample; run1, box2: before the join build's partition policy): the headline kernel — the same throughout — 2.53 / 2.49 / 2.43 / 2.51 / 2.45 / 2.33 ms = 0.792 / 0.803 / 0.822 / 0.795 / 0.816 / 0.859 against `bench_default.json`'s 2.47 = 0.809.  The boxes differ by up to 8 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
 | `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
 | `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
 | `rocprofv3_kernel_stats_<config>.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --workload … --steps 20 --warmup 3` (its own process: the table below compares its averages with the bench line's HIP-event times) — **C3 and C3 over random keys included** (round 5 had none) |
