@@ -13,7 +13,7 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 
 | File | What |
 |---|---|
-| `bench_default.json`, `bench_details.json` | the default `python bench.py` line (26 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity, `frac_step` beside `frac`), per-kernel details |
+| `bench_default.json`, `bench_details.json` | the default `python bench.py` line (27 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity, `frac_step` beside `frac`), per-kernel details |
 | `bench_default_run5.json` … `bench_default_run1.json`, `bench_default_box2.json` (+ `bench_details_*`) | the default line on six OTHER boxes of the pool in the course of the round (run5: the final csrc revision, the run the rocprofv3 / PMC files were made beside; run4: before the no-min/max instances; run3: before the register kernel's paired loads; run2: its C4 variants still compared on a sample; run1, box2: before the join build's partition policy): the headline kernel — the same throughout — 2.53 / 2.49 / 2.43 / 2.51 / 2.45 / 2.33 ms = 0.792 / 0.803 / 0.822 / 0.795 / 0.816 / 0.859 against `bench_default.json`'s 2.47 = 0.809.  The boxes differ by up to 8 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
 | `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
 | `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
@@ -22,9 +22,10 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | `probe_*.txt`, `micro_bench.txt` | the diagnostic sweeps of earlier rounds, re-run on this revision (`probe_build.txt`: the join build, two-level against one-level) |
 | `probe_no_minmax.txt` | `tools/probe_no_minmax.py`: count / sum / avg against the five-aggregate list over 4096 … 14000 random groups |
 | `ab_wide_direct.txt` | 10⁸ rows over 4096 … 6000 random groups: one directly addressed workgroup table without key words (round 6) against two key subsets (`NQE_NO_WIDE_DIRECT=1`) |
-| `probe_build.txt`, `probe_build_two_level_f32.txt`, `probe_build_two_level_f64.txt` | the join build by size and payload: the two-level form (final: 32 fine bins per partition, scatter with its tile in registers and the next prefetched) against the place pass; the first two-level build (before the scatter's prefetch); 64 fine bins per partition (split slower, scatter unchanged) |
+| `probe_build.txt`, `probe_build_two_level_f32.txt`, `probe_build_two_level_f64.txt` | the join build by size and payload: the two-level form (final: up to 64 fine bins per partition chosen at run time, scatter with its tile in registers and the next prefetched) against the place pass; the first two-level build (before the scatter's prefetch); 64 fine bins per partition (split slower, scatter unchanged) |
 | `ab_c2tree.txt`, `ab_c2tree_look.txt`, `ab_c2tree_pipe.txt` | the one-pass selection + projection kernel taken apart: without its stores / look-back / both; K statuses per look-back round trip; a software-pipelined loop (experiment builds of the generator, not kept) |
 | `two_kernel_floor.txt` | `tools/probe_two_kernel_floor.py`: the bytes of the two-kernel selection + projection through the best static kernels (no arithmetic) against the one-pass kernel on the tree query: 0.566 vs 0.544 ms |
+| `probe_build_split_stretches.txt` | the second scatter in four stretches per partition (tried, no gain, reverted) |
 | `probe_build_fine_bins.txt` | the two-level join build by fine bins per partition (4 … 64), sweeps and alternating A/B runs on one box |
 | `ab_soa_threads.txt` | the many-group aggregate's scatter at 512 × 2, 256 × 4 and 1024 × 1 threads × workgroups per CU |
 | `../r06_notes.md` | the raw measurement notes the sections of DESIGN.md were written from |
