@@ -2127,7 +2127,7 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
 
 @pytest.mark.parametrize("kind", ["range_5000", "range_5840_at_limit", "range_5841_two_subsets", "negative_base", "u64_mod_5000", "predicate", "nan_values", "int_values", "value_is_key",
                                   "count_and_sum_only", "count_and_sum_only_13000", "count_and_sum_only_13632_at_limit", "count_and_sum_only_13633_beyond", "count_and_sum_only_u64_mod_12000",
-                                  "count_and_sum_only_predicate_9000"])
+                                  "count_and_sum_only_predicate_9000", "count_and_sum_only_value_is_key_9000"])
 def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
     """4097 .. 5840 values between a key column's min and max (or `col % m`, m <= 5840, UInt64), one value column, no validity bitmaps:
     ONE directly addressed workgroup table (round 6 — the table carries no key words: 28 bytes per slot), where two workgroups per row
@@ -2138,7 +2138,7 @@ def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
     # (count / sum / avg only: the instance without min / max arrays — 12 bytes per slot, one table up to 13632 keys; under a predicate the
     # planner keeps the 28-byte limit, so 9000 keys take the next tier)
     groups = {"range_5840_at_limit": 5840, "range_5841_two_subsets": 5841, "count_and_sum_only_13000": 13000, "count_and_sum_only_13632_at_limit": 13632,
-              "count_and_sum_only_13633_beyond": 13633, "count_and_sum_only_predicate_9000": 9000}.get(kind, 5000)
+              "count_and_sum_only_13633_beyond": 13633, "count_and_sum_only_predicate_9000": 9000, "count_and_sum_only_value_is_key_9000": 9000}.get(kind, 5000)
     base = {"negative_base": -2500, "range_5840_at_limit": 10**12}.get(kind, 0)
     draw = rng.integers(0, groups, n)
     draw[:2] = [0, groups - 1]
@@ -2156,7 +2156,8 @@ def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
     kn = key.flatten(f3)
     pn = binop(col(2), Operator.Lt, lit_f64(0.5)).flatten(f3) if kind in ("predicate", "count_and_sum_only_predicate_9000") else None
     # (value_is_key: `sum(k) … group by k` — the single-load instance; count_and_sum_only: no aggregate asks for min / max)
-    aggs = ALL_AGGS(0) if kind == "value_is_key" else [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1)] if kind.startswith("count_and_sum_only") else ALL_AGGS(1)
+    aggs = (ALL_AGGS(0) if kind == "value_is_key" else [(AggregateFunc.Count, 0), (AggregateFunc.Sum, 0), (AggregateFunc.Avg, 0)] if kind == "count_and_sum_only_value_is_key_9000" else
+            [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1)] if kind.startswith("count_and_sum_only") else ALL_AGGS(1))
     exp = orc.aggregate([cols], aggs, group_nodes=kn, pred_nodes=pn)[0]
     t = ctx.table_from_host(cols)
     for rep in range(3):

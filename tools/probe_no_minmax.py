@@ -1,3 +1,7 @@
+#!/usr/bin/env python
+"""10^8 rows over G random groups: `count, sum, avg` (the MM = false instance: 12-byte slots, one workgroup table up to 13632 keys) against the
+five-aggregate list (28-byte slots: one table up to 5840 keys, two key subsets up to 8192, then the partitioned path's range tier), with
+the per-kernel breakdown.  usage: python tools/probe_no_minmax.py"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 from naive_query_engine_amd import AggregateFunc as A, DType, capi
