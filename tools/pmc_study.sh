@@ -17,8 +17,8 @@ for f in glob.glob(out+'/*/x_counter_collection.csv'):
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name']
-        if any(s in k for s in ('agg_grouped_fast','agg_slab_scatter','agg_slab_segments')):
-            acc[([x for x in ('agg_grouped_fast','agg_slab_scatter','agg_slab_segments') if x in k][0], r['Counter_Name'])].append(float(r['Counter_Value']))
+        if any(s in k for s in ('agg_grouped_fast','agg_slab_scatter','agg_slab_segments','agg_range_segments')):
+            acc[([x for x in ('agg_grouped_fast','agg_slab_scatter','agg_slab_segments','agg_range_segments') if x in k][0], r['Counter_Name'])].append(float(r['Counter_Value']))
     for (k,c),v in acc.items():
         res[(name,k)][c]=sum(v)/len(v)
 for k,v in sorted(res.items()): print(k, {a: '%.4g'%b for a,b in sorted(v.items())})

@@ -28,6 +28,7 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | `probe_build_split_stretches.txt` | the second scatter in four stretches per partition (tried, no gain, reverted) |
 | `probe_build_fine_bins.txt` | the two-level join build by fine bins per partition (4 … 64), sweeps and alternating A/B runs on one box |
 | `ab_soa_threads.txt` | the many-group aggregate's scatter at 512 × 2, 256 × 4 and 1024 × 1 threads × workgroups per CU |
+| `pmc_study.txt` | SQ counters (instructions per row, VALU / LDS busy, bank conflicts, waiting share) of the many-group aggregate's scatter and segments kernels and of the headline kernel |
 | `../r06_notes.md` | the raw measurement notes the sections of DESIGN.md were written from |
 
 ## The bench line
