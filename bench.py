@@ -75,6 +75,7 @@ def parse(argv=None):
     ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the communicator self-test that runs before the big allocations")
     ap.add_argument("--preflight-timeout", type=float, default=180.0, help="seconds a preflight stage may take before the rank reports where it is stuck and exits")
     ap.add_argument("--no-configs", action="store_true", help="only the main workload's line (no `configs` block)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure `roofline.traffic` with rocprofv3 --pmc child passes after the timed region (the default run does; quoted figure only)")
     ap.add_argument("--only", default="", help="comma-separated side configs to run (default: all)")
     ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the OPTIONAL second CPU number of the headline — an optimised multi-core form, not the reference's "
                                                                 "single-threaded algorithm (0 = skip, -1 = min(64, host cores))")
@@ -425,6 +426,116 @@ def attach_traffic(roof, config_name):
         roof["traffic_counts"] = "L2 memory-side (fabric) requests; Infinity-Cache hits are included"
     except Exception as e:  # noqa: BLE001 - a missing/odd profile file must not fail the bench
         roof["traffic_quoted_from"] = f"unreadable {path}: {e}"
+
+
+def _pmc_pass(counter, cmd, workdir, timeout_s):
+    """one `rocprofv3 --pmc <counter> --kernel-trace` pass of `cmd` in a child process → {kernel name: (mean per dispatch, dispatches)}"""
+    import csv
+    import subprocess
+
+    env = dict(os.environ, TMPDIR="/tmp")
+    d = os.path.join(workdir, counter.lower())
+    subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "live", "--"] + cmd,
+                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+    acc = {}
+    for root, _, files in os.walk(d):
+        for fn in files:
+            if fn.endswith("counter_collection.csv"):
+                with open(os.path.join(root, fn)) as f:
+                    for r in csv.DictReader(f):
+                        if r.get("Counter_Name") == counter:
+                            a = acc.setdefault(r["Kernel_Name"], [0.0, 0])
+                            a[0] += float(r["Counter_Value"])
+                            a[1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items() if v[1]}
+
+
+class LiveTraffic:
+    """`roofline.traffic` MEASURED by the run that prints it.  After everything timed is done, child processes run a workload (3 steps)
+    under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, --kernel-trace only, as the guide's HBM section
+    prescribes; the counters are reported in KB), and — when tools/stream_bench is built — two more calibrate the counters' factors
+    on known byte counts in the same access pattern, once per run (else this round's committed factors are used:
+    profiles/<tag>/pmc_calibration.json).  The step's kernels and their launches per step: tools/profile_configs.py, the list
+    tools/summarize_profiles.py uses for the quoted files.  The quoted figure of attach_traffic stays beside the live one as
+    `traffic_quoted`.  Any failure (no rocprofv3, a profiler already attached, a time-out) leaves the quoted figure in place and
+    says why."""
+
+    def __init__(self, timeout_s=90.0):
+        import shutil
+        import tempfile
+
+        self.timeout_s, self.why_not, self.factors, self.basis, self.work = timeout_s, None, None, None, None
+        if shutil.which("rocprofv3") is None:
+            self.why_not = "no rocprofv3 on PATH"
+        elif any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+            self.why_not = "this process runs under a profiler"
+        else:
+            self.work = tempfile.mkdtemp(prefix="nqe_live_pmc_")
+
+    def close(self):
+        import shutil
+
+        if self.work:
+            shutil.rmtree(self.work, ignore_errors=True)
+
+    def calibrate(self):
+        if self.factors is not None:
+            return
+        sb = os.path.join(ROOT, "tools", "stream_bench")
+        if os.path.exists(sb):
+            try:
+                cf = _pmc_pass("FETCH_SIZE", [sb, "calib"], os.path.join(self.work, "calib"), self.timeout_s)
+                cw = _pmc_pass("WRITE_SIZE", [sb, "calib"], os.path.join(self.work, "calib"), self.timeout_s)
+                rd = [v for k, v in cf.items() if "read2" in k]
+                wr = [v for k, v in cw.items() if "copy_rw" in k and ("Li0ELi4E" in k or "copy_rw<4,0,4,1>" in k.replace(" ", ""))]
+                if rd and wr:
+                    self.factors = (16e9 / (rd[0][0] * 1024), 6.4e9 / (wr[0][0] * 1024))
+                    self.basis = "calibrated in this run on tools/stream_bench (16e9 B read, 6.4e9 B written, 8-byte non-temporal accesses)"
+                    return
+            except Exception:  # noqa: BLE001 - fall back to the committed factors
+                pass
+        with open(os.path.join(ROOT, "profiles", PROFILE_TAG, "pmc_calibration.json")) as fh:
+            c = json.load(fh)
+        self.factors, self.basis = (c["fetch_factor"], c["write_factor"]), f"factors of profiles/{PROFILE_TAG}/pmc_calibration.json"
+
+    def measure(self, roof, config_name, workload_args):
+        """→ True when roof['traffic'] now holds this run's measurement"""
+        if self.why_not:
+            roof["traffic_live"] = "not measured: " + self.why_not
+            return False
+        t0 = time.time()
+        try:
+            from tools.profile_configs import CONFIGS
+
+            kernels = CONFIGS[config_name][0]
+            self.calibrate()
+            me = [sys.executable, os.path.join(ROOT, "bench.py")] + workload_args + ["--no-configs", "--no-cpu-baseline", "--no-live-traffic", "--steps", "3", "--warmup", "1"]
+            sub = os.path.join(self.work, config_name)
+            fetch = _pmc_pass("FETCH_SIZE", me, sub, self.timeout_s)
+            write = _pmc_pass("WRITE_SIZE", me, sub, self.timeout_s)
+            fb = wb = 0.0
+            disp = 0
+            for name, per_step in kernels.items():
+                f = [v for k, v in fetch.items() if name in k]
+                w = [v for k, v in write.items() if name in k]
+                if not f or not w:
+                    roof["traffic_live"] = f"not measured: no {name} dispatch in the counter files"
+                    return False
+                # (several instances of one kernel template: the dispatch-weighted mean, as tools/summarize_profiles.py takes it)
+                fb += sum(v[0] * v[1] for v in f) / sum(v[1] for v in f) * 1024 * self.factors[0] * per_step
+                wb += sum(v[0] * v[1] for v in w) / sum(v[1] for v in w) * 1024 * self.factors[1] * per_step
+                disp += sum(v[1] for v in f)
+            if roof.get("traffic") is not None:
+                roof["traffic_quoted"] = roof["traffic"]  # (its source: `traffic_quoted_from`)
+            roof["traffic"] = fb + wb
+            roof["traffic_ratio"] = (fb + wb) / roof["algorithmic_bytes_per_step"] if roof.get("algorithmic_bytes_per_step") else None
+            roof["traffic_fetch_write"] = [fb, wb]
+            roof["traffic_live"] = (f"measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this workload after the timed region "
+                                    f"({disp} dispatches per pass; fetch x {self.factors[0]:.4g}, write x {self.factors[1]:.4g}, {self.basis}; {time.time() - t0:.0f} s)")
+            return True
+        except Exception as e:  # noqa: BLE001 - the line must come out whatever the profiler does
+            roof["traffic_live"] = f"not measured: {type(e).__name__}: {str(e)[:120]}"
+            return False
 
 
 AGG = None  # naive_query_engine_amd.AggregateFunc, filled in main (needs the package)
@@ -1432,6 +1543,21 @@ def main():
             up_rec.pop("what", None)
         out["configs"] = cfg
 
+    if rank == 0 and world == 1 and wl == "headline" and not (args.no_configs or args.random_keys or args.no_live_traffic or args.rows) and args.pass_frac == 0.5:
+        # everything timed is done: the counters are collected by child processes (rocprofv3 cannot attach to this one) — the headline and
+        # BASELINE's other single-GPU configs
+        lt = LiveTraffic()
+        if lt.measure(out["roofline"], "headline", ["--workload", "headline"]):
+            # the line keeps the two numbers and the live pass's account; the quoted file's description goes to the details
+            details["main"]["traffic_quoted_from"] = out["roofline"].pop("traffic_quoted_from", None)
+            out["roofline"]["traffic_quoted_from"] = f"profiles/{PROFILE_TAG}/pmc_traffic_headline.json"
+        for cname in ("c2", "c3", "c4"):
+            if cname in out.get("configs", {}) and cname in details["configs"]:
+                roof = details["configs"][cname]["roofline"]
+                if lt.measure(roof, cname, ["--workload", cname]):
+                    out["configs"][cname]["traffic_ratio"] = r4(roof["traffic_ratio"])
+                    out["configs"][cname]["traffic_live"] = 1   # (`traffic_ratio` of this config is this run's measurement; the details file has the bytes)
+        lt.close()
     line = finish_line(out)  # `summary` = the LAST key: what a record that keeps only the tail of the line still holds
     dpath = args.details or (os.path.join(ROOT, "gpurun_out", "bench_details.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "")
     if dpath and rank == 0:

@@ -79,3 +79,50 @@ def test_every_side_config_has_a_parity_check():
 def test_parse_defaults_finish_quickly():
     a = bench.parse([])
     assert a.gpus == 1 and a.steps <= 20 and a.warmup <= 5 and a.workload == "headline"
+
+
+def test_live_traffic_falls_back_to_the_quoted_figure(monkeypatch):
+    """no rocprofv3 (or a profiler already attached): the quoted figure stays, the line says why"""
+    monkeypatch.setenv("PATH", "/nonexistent")
+    lt = bench.LiveTraffic()
+    roof = {"traffic": 16.03e9, "algorithmic_bytes_per_step": 16e9}
+    assert lt.measure(roof, "headline", ["--workload", "headline"]) is False
+    assert roof["traffic"] == 16.03e9 and roof["traffic_live"].startswith("not measured: no rocprofv3")
+    lt.close()
+    monkeypatch.undo()
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    lt = bench.LiveTraffic()
+    assert lt.why_not == "this process runs under a profiler"
+    lt.close()
+
+
+def test_live_traffic_arithmetic(monkeypatch, tmp_path):
+    """counters are KB per dispatch; bytes per step = sum over the step's kernels of mean x 1024 x factor x launches per step"""
+    fake_bin = tmp_path / "rocprofv3"
+    fake_bin.write_text("#!/bin/sh\nexit 0\n")
+    fake_bin.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path))
+    for k in [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_"))]:
+        monkeypatch.delenv(k)
+    calls = []
+
+    def fake_pass(counter, cmd, workdir, timeout_s):
+        calls.append((counter, cmd[-1] if cmd[-1] == "calib" else cmd[3]))
+        if cmd[-1] == "calib":   # stream_bench: 16e9 B read is reported as 8e9 B (factor 2); 6.4e9 B written as 6.4e9 B
+            return {"read2<4,0>": (8e9 / 1024, 3)} if counter == "FETCH_SIZE" else {"void copy_rw<4, 0, 4, 1>(...)": (6.4e9 / 1024, 3)}
+        if counter == "FETCH_SIZE":
+            return {"keep_from_range_tile_kernel<..>": (0.2e9 / 1024, 4), "scan_single_kernel": (1e3 / 1024, 4), "compact_staged_kernel<0>": (0.4e9 / 1024, 4)}
+        return {"keep_from_range_tile_kernel<..>": (0.0125e9 / 1024, 4), "scan_single_kernel": (1e3 / 1024, 4), "compact_staged_kernel<0>": (0.4e9 / 1024, 4)}
+
+    monkeypatch.setattr(bench, "_pmc_pass", fake_pass)
+    lt = bench.LiveTraffic()
+    roof = {"traffic": 1.7e9, "algorithmic_bytes_per_step": 2.0e9}
+    ok = lt.measure(roof, "c2", ["--workload", "c2"])
+    lt.close()
+    assert ok, roof
+    if os.path.exists(os.path.join(ROOT, "tools", "stream_bench")):
+        assert abs(lt.factors[0] - 2.0) < 1e-9 and abs(lt.factors[1] - 1.0) < 1e-9
+        exp = (0.2e9 + 1e3 + 0.4e9) * 2.0 + (0.0125e9 + 1e3 + 0.4e9) * 1.0
+        assert abs(roof["traffic"] - exp) < 1.0, (roof["traffic"], exp)
+    assert roof["traffic_quoted"] == 1.7e9 and roof["traffic_live"].startswith("measured by this run")
+    assert abs(roof["traffic_ratio"] - roof["traffic"] / 2.0e9) < 1e-12
