@@ -1479,7 +1479,7 @@ def main():
             add("c4_sparse_keys", lambda: wl_c4(B, 10**8, 10**6, "sparse", csteps, cwarm, **kw), pj)
             add("c4_dup_keys", lambda: wl_c4(B, 10**8, 10**6, "dup", csteps, cwarm, **kw), pj)
             add("c4_partial_match", lambda: wl_c4(B, 10**8, 10**6, "partial", csteps, cwarm, **kw), pj)
-            for G in (4096, 5000, 6000, 65536, 1 << 20):  # 5000: one directly addressed table without key words (round 6); 6000: two key subsets over a direct-mapped table
+            for G in (4096, 5000, 6000, 11000, 65536, 1 << 20):  # 5000: one directly addressed table without key words (round 6); 6000, 11000: two key subsets, the two halves of the range (up to 2 x 5840 keys)
                 add(f"agg_{G}_groups", lambda G=G: wl_aggregate(B, 10**8, False, False, csteps, cwarm, groups=G, **kw), pa(10_000_000))
             # count / sum / avg only: no min / max arrays in the workgroup table — 12 bytes per slot, ONE table up to 13632 keys (round 6)
             add("agg_12000_groups_count_sum_avg", lambda: wl_aggregate(B, 10**8, False, False, csteps, cwarm, groups=12000, shape="no_minmax", **kw), pa(10_000_000))

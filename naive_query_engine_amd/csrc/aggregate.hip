@@ -801,6 +801,7 @@ struct AggRun {
     uint64_t hint_key = 0;
     bool any_val_nullable = false, subsets_ok = false, plain_int_key = false, no_hints_env = false, range_sampled = false;
     uint64_t range_limit = 4096, key_flip = 0;
+    uint64_t direct_pair_limit = 8192; // values of a key range the direct-mapped tables of TWO key subsets take (AggArgs::direct_sub_width)
     uint64_t direct_one_limit = 4096; // values of a key range ONE direct-mapped workgroup table takes (DIRECT_WIDE_SLOTS where the table has no key words)
     // ---- the attempt
     int attempt = 0;
@@ -844,7 +845,7 @@ struct AggRun {
     bool finish_attempt(AggResult *out);
     void keys_to_strings(AggResult &res);
     // values of a measured key range the streaming tier addresses directly: one table's (direct_one_limit), or 2^subsets_log2 tables of range_limit
-    uint64_t one_table_or_subsets_limit() const { return subsets_log2 ? (range_limit << subsets_log2) : direct_one_limit; }
+    uint64_t one_table_or_subsets_limit() const { return subsets_log2 == 1 ? direct_pair_limit : (subsets_log2 ? (range_limit << subsets_log2) : direct_one_limit); }
     bool react_to_flags(const int *f, const Collected &pre);
     AggResult run();
 };
@@ -1061,6 +1062,7 @@ void AggRun::load_hints() {
     // no predicate, no min / max, a plain key column or `col % m`: the 12-byte slots of the MM = false instance (tier_streaming: nomm1 — the
     // same conditions, so that a range the planner turns on is one the pass can address)
     if (direct_one_limit == DIRECT_WIDE_SLOTS && a.pred_mode == 0 && V == 1 && !plan.need_minmax[0] && a.key.nops <= 1) direct_one_limit = DIRECT_WIDE_SLOTS_NOMM;
+    direct_pair_limit = 2 * direct_one_limit; // two key subsets: the two halves of the range, each in a table like that
     key_flip = a.key_src.dtype == NQE_INT64 ? 0x8000000000000000ull : 0ull;
     plain_int_key = key_col >= 0 && !utf8_key && a.key.nops == 0 && !a.key_src.valid && (a.key_src.dtype == NQE_INT64 || a.key_src.dtype == NQE_UINT64);
 }
@@ -1128,7 +1130,7 @@ void AggRun::sample_keys() {
         const bool one_direct = plain_int_key && !sw.no_key_range && sample_span != 0 && sample_span <= direct_one_limit;
         const uint64_t one_limit = one_direct ? direct_one_limit : (!sw.lds_load_limit ? range_limit : range_limit * 3 / 4);
         const bool sub_direct = plain_int_key && !sw.no_key_range && V == 1 && sw.direct_subsets && subsets_ok && sw.subsets_max >= 1 && sample_span != 0 &&
-                                sample_span <= 2 * range_limit;
+                                sample_span <= direct_pair_limit;
         const bool tier_instead = !sub_direct && sw.direct_subsets && range_part_ok && V == 1 && sw.range_tier && plain_int_key && sample_span != 0 &&
                                   sample_span + sample_span / 128 + 32 < uint64_t(256) * RANGE_TIER_MAX_SLOTS;
         if (!sub_direct && (D > 2 * one_limit || (D > one_limit && (!subsets_ok || sw.subsets_max < 1 || tier_instead)))) {
@@ -1180,7 +1182,7 @@ void AggRun::sample_keys() {
 
 void AggRun::pick_key_range() {
     // (round 5: also under key subsets — two workgroups per row range, each holding one half of a range of up to 2 x 4096 values in a
-    // direct-mapped table (AggArgs::direct_sub_shift): one value column)
+    // direct-mapped table (AggArgs::direct_sub_width): one value column)
     const bool sub_range = subsets_log2 == 1 && subsets_ok && V == 1 && sw.direct_subsets;
     if (hint_key && !sw.no_key_range && !partition_mode && (subsets_log2 == 0 || sub_range) && (!no_hints_env || range_sampled) && plain_int_key) {
         // `group by k`, k a plain integer column (dictionary codes, small ids): a value range that fits a workgroup table makes the
@@ -1637,8 +1639,9 @@ PassStatus AggRun::tier_streaming(int v0) {
     }
     // (round 6) a directly addressed table without validity bitmaps has no key words: up to DIRECT_WIDE_SLOTS keys in ONE workgroup table
     // nomm1: one value column nobody asks min / max of, through the instance without those arrays (12 instead of 28 bytes per slot)
-    const bool nomm1 = a.nv == 1 && !a.need_minmax[0] && !vnull && (fp == 0 || fp == 1) && fast_key != 3 && subsets_log2 == 0;
-    const size_t slot_bytes = nomm1 ? 12 : 28;
+    const bool nomm_ok = a.nv == 1 && !a.need_minmax[0] && !vnull && (fp == 0 || fp == 1) && fast_key != 3;
+    const bool nomm1 = nomm_ok && subsets_log2 == 0;
+    const bool pair_nomm = nomm_ok && subsets_log2 == 1 && fast_key == 0; // … and the two halves of a measured range, each in such a table
     auto widen = [&](uint64_t span) {
         if (a.nv != 1 || vnull || subsets_log2 != 0 || span > direct_one_limit || span > (nomm1 ? DIRECT_WIDE_SLOTS_NOMM : DIRECT_WIDE_SLOTS)) return false;
         ka.lds_cap = int32_t((span + 15) & ~uint64_t(15));
@@ -1659,18 +1662,26 @@ PassStatus AggRun::tier_streaming(int v0) {
             while (ka.direct_rep < 6 && (span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
         }
     }
-    ka.direct_sub_shift = 0;
+    ka.direct_sub_width = 0;
     ka.lds_limit = (ka.allow_partition && sw.lds_load_limit) ? uint32_t(ka.lds_cap) * 3u / 4u : 0u; // (hashed tables only look at it)
-    if (range_on && fast_key == 0 && !ka.direct && (range_span <= (uint64_t(ka.lds_cap) << subsets_log2) || widen(range_span))) {
+    // two subsets over a measured range: its two halves (whole 16-slot units), each a table without key words
+    const uint64_t half_span = ((range_span + 1) / 2 + 15) & ~uint64_t(15);
+    const bool pair_fits = subsets_log2 == 1 && a.nv == 1 && !vnull && range_span <= direct_pair_limit && half_span <= (pair_nomm ? DIRECT_WIDE_SLOTS_NOMM : DIRECT_WIDE_SLOTS);
+    if (range_on && fast_key == 0 && !ka.direct && (subsets_log2 ? pair_fits : (range_span <= uint64_t(ka.lds_cap) || widen(range_span)))) {
         // the key column's measured range fits the table: slot = key - min, every key checked against the range
         ka.direct = 2;
         ka.direct_bias = int64_t(0ull - uint64_t(range_min));
         ka.direct_span = range_span;
         while (ka.direct_rep < 6 && (range_span << (ka.direct_rep + 1)) <= 1024) ++ka.direct_rep;
-        // ... or the tables of 2^subsets_log2 workgroups that share their rows, each holding a consecutive range of lds_cap keys (pick_key_range
-        // turns the range on under subsets for one value column only: lds_cap = 4096, direct_sub_shift = 12)
-        if (subsets_log2) ka.direct_sub_shift = 63 - __builtin_clzll(uint64_t(ka.lds_cap)); // (lds_cap is a power of two)
+        // ... or the tables of the two workgroups that share their rows, each holding one half of the range (pick_key_range turns the range on
+        // under subsets for one value column and two subsets only)
+        if (subsets_log2) {
+            ka.lds_cap = int32_t(half_span);
+            ka.direct_sub_width = int32_t(half_span);
+        }
     }
+    const bool nomm_sub = pair_nomm && ka.direct_sub_width != 0;
+    const size_t slot_bytes = (nomm1 || nomm_sub) ? 12 : 28;
     if (ka.direct && !vnull) { // no key words in the table (aggregate_fast_kernel.hpp: nokeys); a widened table: its own slot count
         const size_t fslots = size_t(ka.lds_cap) + 1;
         fshmem = a.nv == 1 ? fslots * slot_bytes : fshmem - fslots * 8;
@@ -1683,7 +1694,7 @@ PassStatus AggRun::tier_streaming(int v0) {
                        !vnull && (a.nv == NVMAX || !vf64) && subsets_log2 == 0;
     // no aggregate of the pass asks for min / max: instances without those LDS arrays (two and three columns, and the
     // single-load one — `count(id) … group by id % 3` updates one LDS word per row instead of reading two and updating four)
-    bool nomm = a.nv >= 2 || share || nomm1;
+    bool nomm = a.nv >= 2 || share || nomm1 || nomm_sub;
     for (int j = 0; j < a.nv; ++j) nomm = nomm && !a.need_minmax[j];
     // a predicate tree the static kernel would interpret (PRED 5 / 6) over `col % m` keys and one value column: the lean
     // run-time specialised kernel, once it has been compiled — its workgroup tables are folded into the group table here
@@ -1741,8 +1752,8 @@ PassStatus AggRun::tier_streaming(int v0) {
     BufRef direct_partials;
     uint32_t pspan = 0;
     size_t pcol_words = 0;
-    if (ka.direct && !vnull && (subsets_log2 == 0 || ka.direct_sub_shift) && sw.direct_partials) {
-        pspan = ka.direct_sub_shift ? uint32_t(ka.lds_cap) : uint32_t(ka.direct == 2 ? range_span : (a.key.op_dtype[a.key.nops - 1] == NQE_INT64 ? 2 * a.key.aux[a.key.nops - 1].abs_lit - 1 : a.key.aux[a.key.nops - 1].abs_lit));
+    if (ka.direct && !vnull && (subsets_log2 == 0 || ka.direct_sub_width) && sw.direct_partials) {
+        pspan = ka.direct_sub_width ? uint32_t(ka.lds_cap) : uint32_t(ka.direct == 2 ? range_span : (a.key.op_dtype[a.key.nops - 1] == NQE_INT64 ? 2 * a.key.aux[a.key.nops - 1].abs_lit - 1 : a.key.aux[a.key.nops - 1].abs_lit));
         const size_t cells = size_t(fgrid) * pspan;
         pcol_words = (cells * 28 + 7) / 8;
         // ... when the atomics would matter: workgroups x groups x 4 of them at ~2.4 x 10^10 / s against the rows' streaming time.  Measured
@@ -1768,7 +1779,7 @@ PassStatus AggRun::tier_streaming(int v0) {
         for (int j = 0; j < a.nv; ++j) {
             const double *ps = reinterpret_cast<const double *>(direct_partials->ptr) + size_t(j) * pcol_words;
             const bool mmj = a.need_minmax[j] != 0 && !(nomm);
-            const int fsub = ka.direct_sub_shift ? subsets_log2 : 0;
+            const int fsub = ka.direct_sub_width ? subsets_log2 : 0;
             // the subsets' tables cover the key range in order: folded into ONE table of records the range tier's tail ranks and writes (no global
             // hash table of 16384 slots, no collect / sort / finalize behind a host round trip: ~0.12 ms of a 10^8-row step)
             // (round 6: so does ONE table of more than 4096 keys — its groups would crowd the first attempt's 8192-slot group table)
@@ -1983,7 +1994,7 @@ bool AggRun::react_to_flags(const int *f, const Collected &pre) {
                 flags_reset(ctx);
                 return true;
             }
-            if (span != 0 && span <= 2 * range_limit) {
+            if (span != 0 && span <= direct_pair_limit) {
                 range_on = true;
                 range_min = rt->second.first;
                 range_span = span;

@@ -91,10 +91,11 @@ struct AggArgs {
     // [subset_shift, subset_shift + subsets_log2) name it — 2^subsets_log2 LDS tables' worth of groups without partitioning the rows
     int32_t subsets_log2;
     int32_t subset_shift;
-    // … over a direct-mapped table (direct != 0, round 5): the subsets are consecutive RANGES of 2^direct_sub_shift slots — subset of a
-    // key = (key + direct_bias) >> direct_sub_shift, slot = the bits below: a measured key range of up to 2 x 4096 values is aggregated
-    // without hashing, probing or partitioning (0: the subsets are hashed)
-    int32_t direct_sub_shift;
+    // … over a direct-mapped table (direct != 0, round 5): TWO subsets, the two halves of the measured key range — direct_sub_width slots
+    // each; subset of a key = (key + direct_bias >= direct_sub_width), slot = the offset inside the half: a key range of up to 2 x 5840
+    // values (round 6: the halves are equal, whatever the range — equal work keeps the two readers of a tile together — and as wide as a
+    // table without key words gets) is aggregated without hashing, probing or partitioning (0: the subsets are hashed)
+    int32_t direct_sub_width;
     // hashed workgroup table of the streaming kernel: distinct keys it accepts (lds_find_or_insert_counted; 0: as many as find room)
     uint32_t lds_limit;
     ConjPred conj; // pred_mode 3

@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     constexpr int NMM = !MM ? 0 : (ML ? 1 : NVT); // value columns with min / max arrays
     auto mmcol = [](int j) { return MM && (!ML || j == NVT - 1); };
     constexpr int NVL = FK ? NVT - 1 : NVT; // value columns the tile loads
+    // (key subsets: 2 rows per lane 0.59 ms at 6000 groups, 4: 0.49, 8: 0.46-0.47 and 3 MB more code — profiles/r06/ab_sub_plain_loads.txt)
     constexpr int TU = SH1 ? 2 * AGG_U : ((NQE_WIDE_TILES && NVT == 1 && !VNULL && !SUB && PRED <= 1 && KEY != 3) ? NQE_WIDE_TILES : AGG_U); // rows per lane per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t cap = uint32_t(a.lds_cap);
@@ -134,9 +135,9 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     const uint32_t lanes = gridDim.x >> sub_log2;
     // subset of a key: two bits of the slot hash's product below the slot bits, XORed (one bit alone — a rotation sequence for keys
     // in arithmetic progression, like the slot bits — left each half of `5r - 77` clustered: probe sequences of 69 slots at load 0.6)
-    const uint32_t dsub_shift = SUB ? uint32_t(a.direct_sub_shift) : 0u; // direct-mapped table in key-range subsets (wave-uniform)
+    const uint32_t dsub_width = SUB ? uint32_t(a.direct_sub_width) : 0u; // direct-mapped table in two key-range subsets (wave-uniform)
     auto foreign = [&](uint64_t key) {
-        if (SUB && dsub_shift) return (uint32_t(uint64_t(int64_t(key) + a.direct_bias) >> dsub_shift) & sub_mask) != my_subset; // (a key outside the range: some subset's, whose direct_slot rejects it)
+        if (SUB && dsub_width) return uint32_t(uint64_t(int64_t(key) + a.direct_bias) >= uint64_t(dsub_width)) != my_subset; // (a key outside the range: the upper subset's, whose direct_slot rejects it)
         const uint64_t h = key * GOLD;
         return ((uint32_t(h >> a.subset_shift) ^ uint32_t(h >> 23)) & sub_mask) != my_subset;
     };
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     auto direct_slot = [&](uint64_t key) {
         const uint64_t d = uint64_t(int64_t(key) + a.direct_bias);
         if (a.direct == 2 && d >= a.direct_span) return -1; // outside the measured range (wave-uniform test first): the cold path
-        if (SUB && dsub_shift) return int(uint32_t(d) - (my_subset << dsub_shift)); // this subset's range of the table (foreign keys never get here)
+        if (SUB && dsub_width) return int(uint32_t(d) - my_subset * dsub_width); // this subset's half of the range (foreign keys never get here)
         return int((uint32_t(d) << rep_log2) | rep_lane);
     };
     auto flush_run = [&]() {
@@ -218,7 +219,10 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
     const bool key_signed = a.key.op_dtype[0] == NQE_INT64;
     const int64_t n = a.n, last = a.n - 1;
 
-    constexpr bool NT = true; // non-temporal loads: -2..3 % (and the loop below keeps a prefetched second tile in flight: 3.24 -> 2.69 ms with the lean loop)
+    // non-temporal loads — except under key subsets, where 2^k workgroups of one XCD read the same tiles: a plain load leaves the line in
+    // that XCD's L2 for the other readers (tools/pair_bench.hip: a free-running pair 0.436 ms with non-temporal loads, 0.362 with plain
+    // ones, one reader 0.254; the product at 6000 / 8000 groups 0.521 / 0.510 -> 0.483 / 0.488 ms: profiles/r06/ab_sub_plain_loads.txt)
+    constexpr bool NT = !SUB; // non-temporal loads: -2..3 % (and the loop below keeps a prefetched second tile in flight: 3.24 -> 2.69 ms with the lean loop)
     struct Tile {
         uint64_t kw[TU], pw[SH1 ? 1 : TU], vw[SH1 ? 1 : NVL][SH1 ? 1 : TU];
         uint64_t vv[VNULL ? NVT : 1][TU]; // validity word of the wave's 64 rows
@@ -654,7 +658,7 @@ __global__ void __launch_bounds__(AGG_BLOCK) agg_grouped_fast_kernel(AggArgs a, 
         if (a.direct && (s & ((1u << rep_log2) - 1u)) && s != cap) continue; // replicas were folded into replica 0
         if (a.direct && !VNULL) {
             if (lcnt[s] == 0) continue;
-            k = uint64_t(int64_t((s >> rep_log2) + ((SUB && dsub_shift) ? (my_subset << dsub_shift) : 0u)) - a.direct_bias);
+            k = uint64_t(int64_t((s >> rep_log2) + ((SUB && dsub_width) ? my_subset * dsub_width : 0u)) - a.direct_bias);
         } else {
             k = lkeys[s];
             if (k == EMPTY_KEY) continue;
@@ -697,6 +701,11 @@ template <int PRED, int KEY, bool VNULL> FastKernel pick_fast_nv(int nv, bool vf
         // 13632 keys in one workgroup table (round 6)
         if (nomm && nv == 1 && !sub && !share)
             return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, false, false, false> : agg_grouped_fast_kernel<PRED, KEY, 1, false, false, false, false>;
+    }
+    if constexpr (!VNULL && PRED <= 1 && KEY == 0) {
+        // … and the two halves of a measured key range in two such tables (two key subsets): 2 x 13632 keys
+        if (nomm && nv == 1 && sub && !share)
+            return vf64 ? agg_grouped_fast_kernel<PRED, KEY, 1, true, false, true, false> : agg_grouped_fast_kernel<PRED, KEY, 1, false, false, true, false>;
     }
     if (nv == 3) return nullptr; // (three columns: the instances above only)
     if (sub) {

@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(256) agg_merge_partials_kernel(const double *p
 // the same fold for the STATIC streaming kernel's direct-mapped tables (AggArgs::partials), shaped for up to 4096 slots x 256 workgroups:
 // a 256-thread block takes 16 consecutive slots; thread (slot, g) = (tid & 15, tid >> 4) walks the workgroups g, g + 16, ... — 16
 // consecutive lanes read 128 contiguous bytes of one workgroup's table per array — the sixteen partial results of a slot meet in LDS.
-// sub_log2 (a direct-mapped table in 2^sub_log2 key-range subsets, AggArgs::direct_sub_shift): slot S of the whole range is slot S % span of
+// sub_log2 (a direct-mapped table in 2^sub_log2 key-range subsets, AggArgs::direct_sub_width): slot S of the whole range is slot S % span of
 // the tables of subset S / span — the workgroups whose index has that subset in bits [3, 3 + sub_log2)
 __global__ void __launch_bounds__(256) agg_fold_partials_kernel(const double *psum, const double *pmn, const double *pmx, const uint32_t *pcnt, int grid, uint32_t span,
                                                                 int64_t bias, int need_minmax, GroupTable g, int v, int *flags, int sub_log2, RangeRec *tab) {

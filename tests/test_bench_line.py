@@ -27,7 +27,7 @@ def fake_result(i, join=False):
 
 NAMES = ["c3", "headline_random_keys", "c3_random_keys", "headline_int64_values", "headline_single_column", "agg_three_value_columns", "agg_readme_shape", "headline_nullable", "agg_tree_predicate",
          "c2", "c2_random_ids", "c4", "c4_shared_probe_columns", "c4_wide_payload", "c4_dim_1e7", "c4_dim_1e8", "c4_sparse_keys", "c4_dup_keys", "c4_partial_match", "agg_4096_groups",
-         "agg_5000_groups", "agg_6000_groups", "agg_65536_groups", "agg_1048576_groups", "agg_12000_groups_count_sum_avg"]
+         "agg_5000_groups", "agg_6000_groups", "agg_11000_groups", "agg_65536_groups", "agg_1048576_groups", "agg_12000_groups_count_sum_avg"]
 
 
 def make_out():

@@ -2035,22 +2035,25 @@ def test_aggregate_measured_key_range_addresses_the_table_directly(ctx, kind):
         ctx.device_free(p_)
 
 
-@pytest.mark.parametrize("kind", ["i64_0", "i64_negative", "u64_high", "at_limit", "predicate", "int_values", "sparse"])
+@pytest.mark.parametrize("kind", ["i64_0", "i64_negative", "u64_high", "at_limit", "predicate", "int_values", "sparse", "odd_span", "wide_pair", "wide_pair_limit", "wide_pair_predicate"])
 def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
-    """More groups than one workgroup table holds, at most twice as many (4097 .. 8192 values between the column's min and max), one value
-    column: two workgroups share every row range and each keeps ONE HALF OF THE KEY RANGE in a direct-mapped table (AggArgs::direct_sub_shift)
+    """More groups than one workgroup table holds, at most twice as many (5841 .. 11680 values between the column's min and max — 4097 .. 8192
+    where the wide table is not taken), one value
+    column: two workgroups share every row range and each keeps ONE HALF OF THE KEY RANGE in a direct-mapped table (AggArgs::direct_sub_width)
     — no hashing, no probing, no partition pass; the tables leave whole and agg_fold_partials_kernel folds them subset by subset.  The
     range comes from the first execution's key sample and is remembered; "sparse" (every third integer: 15000 values) takes the partitioned
     path's range tier.  Then the column's contents change under the remembered range: the kernel must notice, and the result still equal the oracle's."""
     rng = np.random.default_rng(len(kind) + 50)
     # ("predicate": no key sample under a filter — the first execution overflows its tables and asks for subsets, the second measures the
     # column's range; enough rows per workgroup for that overflow)
-    n = 4_000_000 if kind == "predicate" else 1_000_000
-    groups = {"i64_0": 6000, "i64_negative": 8000, "u64_high": 5000, "at_limit": 8192, "predicate": 7000, "int_values": 4500, "sparse": 5000}[kind]
-    base = {"i64_0": 0, "i64_negative": -5000, "u64_high": (1 << 63) + 999, "at_limit": 10**11, "predicate": 17, "int_values": -1, "sparse": 3}[kind]
+    n = 4_000_000 if kind in ("predicate", "wide_pair_predicate") else 1_000_000
+    groups = {"i64_0": 6000, "i64_negative": 8000, "u64_high": 5000, "at_limit": 8192, "predicate": 7000, "int_values": 4500, "sparse": 5000, "odd_span": 6001, "wide_pair": 11000,
+              "wide_pair_limit": 11680, "wide_pair_predicate": 10001}[kind]
+    base = {"i64_0": 0, "i64_negative": -5000, "u64_high": (1 << 63) + 999, "at_limit": 10**11, "predicate": 17, "int_values": -1, "sparse": 3, "odd_span": -3000, "wide_pair": 12345,
+            "wide_pair_limit": -11679, "wide_pair_predicate": 1}[kind]
     dt = np.uint64 if kind == "u64_high" else np.int64
     draw = rng.integers(0, groups, n)
-    if kind == "at_limit":
+    if kind in ("at_limit", "wide_pair_limit"):
         draw[:2] = [0, groups - 1]  # the whole range is there
     k = (draw.astype(np.uint64) + np.uint64(base)) if kind == "u64_high" else (draw * (3 if kind == "sparse" else 1) + base).astype(dt)
     v = rng.integers(-10**6, 10**6, n).astype(np.int64) if kind == "int_values" else rng.random(n) * 100.0
@@ -2074,7 +2077,7 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
     kdt = DType.UINT64 if kind == "u64_high" else DType.INT64
     t = ctx.table_from_device([(kdt, n, pk, None), (v_dt, n, pv, None), (DType.FLOAT64, n, pw, None)])
     key = col(0).flatten(f3)
-    pred = binop(col(2), Operator.Lt, lit_f64(0.5)).flatten(f3) if kind == "predicate" else None
+    pred = binop(col(2), Operator.Lt, lit_f64(0.5)).flatten(f3) if kind in ("predicate", "wide_pair_predicate") else None
 
     def run():
         ctx.timing_enable(True)
@@ -2092,7 +2095,7 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
             assert "agg_partition_scatter" in names and "agg_grouped_fast" not in names, names
         elif rep >= 1:
             # (NQE_NO_PLAN_HINTS: nothing is remembered — a query under a predicate overflows its single table on every execution first)
-            launches = (1, 2) if os.environ.get("NQE_NO_PLAN_HINTS") and kind == "predicate" else (1,)
+            launches = (1, 2) if os.environ.get("NQE_NO_PLAN_HINTS") and kind in ("predicate", "wide_pair_predicate") else (1,)
             assert "agg_partition_scatter" not in names and names["agg_grouped_fast"][1] in launches, names
         if rep == 2 and kind != "sparse":
             assert "agg_fold_partials" in names and "agg_range_emit" in names, names
@@ -2127,19 +2130,24 @@ def test_aggregate_measured_key_range_over_two_key_subsets(ctx, kind):
 
 @pytest.mark.parametrize("kind", ["range_5000", "range_5840_at_limit", "range_5841_two_subsets", "negative_base", "u64_mod_5000", "predicate", "nan_values", "int_values", "value_is_key",
                                   "count_and_sum_only", "count_and_sum_only_13000", "count_and_sum_only_13632_at_limit", "count_and_sum_only_13633_beyond", "count_and_sum_only_u64_mod_12000",
-                                  "count_and_sum_only_predicate_9000", "count_and_sum_only_value_is_key_9000"])
+                                  "count_and_sum_only_predicate_9000", "count_and_sum_only_value_is_key_9000", "count_and_sum_only_20000_two_subsets",
+                                  "count_and_sum_only_27264_two_subsets_at_limit", "count_and_sum_only_27265_beyond", "count_and_sum_only_int_values_19999_two_subsets"])
 def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
     """4097 .. 5840 values between a key column's min and max (or `col % m`, m <= 5840, UInt64), one value column, no validity bitmaps:
     ONE directly addressed workgroup table (round 6 — the table carries no key words: 28 bytes per slot), where two workgroups per row
     range each read every row before; 5841 values still take two key subsets.  Against the oracle on the first, the remembered and a
-    third execution, keys in order, and the same with the switch NQE_NO_WIDE_DIRECT=1 (the two-subset form).  aggregate/mod.rs:113-222"""
+    third execution, keys in order, and the same with the switch NQE_NO_WIDE_DIRECT=1 (the two-subset form).  count / sum / avg only: 12-byte
+    slots — one table up to 13632 keys, and the two halves of a range of up to 27264 keys in two such tables (two key subsets, one launch).
+    aggregate/mod.rs:113-222"""
     rng = np.random.default_rng(len(kind) + 600)
     n = 4_000_000 if "predicate" in kind else 1_200_000
     # (count / sum / avg only: the instance without min / max arrays — 12 bytes per slot, one table up to 13632 keys; under a predicate the
     # planner keeps the 28-byte limit, so 9000 keys take the next tier)
     groups = {"range_5840_at_limit": 5840, "range_5841_two_subsets": 5841, "count_and_sum_only_13000": 13000, "count_and_sum_only_13632_at_limit": 13632,
-              "count_and_sum_only_13633_beyond": 13633, "count_and_sum_only_predicate_9000": 9000, "count_and_sum_only_value_is_key_9000": 9000}.get(kind, 5000)
-    base = {"negative_base": -2500, "range_5840_at_limit": 10**12}.get(kind, 0)
+              "count_and_sum_only_13633_beyond": 13633, "count_and_sum_only_predicate_9000": 9000, "count_and_sum_only_value_is_key_9000": 9000,
+              "count_and_sum_only_20000_two_subsets": 20000, "count_and_sum_only_27264_two_subsets_at_limit": 27264, "count_and_sum_only_27265_beyond": 27265,
+              "count_and_sum_only_int_values_19999_two_subsets": 19999}.get(kind, 5000)
+    base = {"negative_base": -2500, "range_5840_at_limit": 10**12, "count_and_sum_only_27264_two_subsets_at_limit": -20000}.get(kind, 0)
     draw = rng.integers(0, groups, n)
     draw[:2] = [0, groups - 1]
     if kind in ("u64_mod_5000", "count_and_sum_only_u64_mod_12000"):
@@ -2148,7 +2156,7 @@ def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
     else:
         kc = Column.from_numpy((draw + base).astype(np.int64))
         key = col(0)
-    v = rng.integers(-10**6, 10**6, n).astype(np.int64) if kind == "int_values" else rng.random(n) * 100.0 - 30.0
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64) if "int_values" in kind else rng.random(n) * 100.0 - 30.0
     if kind == "nan_values":
         v[rng.integers(0, n, 50)] = np.nan
     cols = [kc, Column.from_numpy(v), Column.from_numpy(rng.random(n))]
@@ -2169,7 +2177,7 @@ def test_aggregate_one_wide_direct_table(ctx, kind, monkeypatch):
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{kind} run {rep}")
         kk = gk.to_host()[0].to_numpy()
         assert len(np.unique(kk)) == len(kk) == got.num_rows
-        if rep >= 1 and not os.environ.get("NQE_NO_PLAN_HINTS") and kind not in ("count_and_sum_only_13633_beyond", "count_and_sum_only_predicate_9000"):
+        if rep >= 1 and not os.environ.get("NQE_NO_PLAN_HINTS") and kind != "count_and_sum_only_27265_beyond":
             assert "agg_partition_scatter" not in names and names["agg_grouped_fast"][1] == 1, names
     monkeypatch.setenv("NQE_NO_WIDE_DIRECT", "1")
     monkeypatch.setenv("NQE_NO_PLAN_HINTS", "1")

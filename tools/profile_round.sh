@@ -18,13 +18,13 @@ NQE_NO_PLAN_HINTS=1 python bench.py --details $OUT/bench_details_no_plan_hints.j
 NQE_COLD_VARIANTS=NQE_NO_RESERVE,NQE_LAZY_MODULES python tools/probe_cold.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_cold.txt
 fi
 declare -A WL=( [headline]="--workload headline" [headline_random_keys]="--workload headline --random-keys" [c2]="--workload c2" [c3]="--workload c3" [c3_random_keys]="--workload c3 --random-keys" [c4]="--workload c4" \
-                [c4_sparse_keys]="--workload c4_sparse" [agg_65536_groups]="--workload agg_groups --groups 65536" [agg_4096_groups]="--workload agg_groups --groups 4096" [agg_5000_groups]="--workload agg_groups --groups 5000" [agg_6000_groups]="--workload agg_groups --groups 6000" [agg_12000_groups_count_sum_avg]="--workload agg_groups --groups 12000 --no-minmax" [c2_expression_trees]="--workload c2_tree" \
+                [c4_sparse_keys]="--workload c4_sparse" [agg_65536_groups]="--workload agg_groups --groups 65536" [agg_4096_groups]="--workload agg_groups --groups 4096" [agg_5000_groups]="--workload agg_groups --groups 5000" [agg_6000_groups]="--workload agg_groups --groups 6000" [agg_11000_groups]="--workload agg_groups --groups 11000" [agg_12000_groups_count_sum_avg]="--workload agg_groups --groups 12000 --no-minmax" [c2_expression_trees]="--workload c2_tree" \
                 [headline_single_column]="--workload headline_single" [headline_int64_values]="--workload headline_int64" \
                 [agg_tree_predicate]="--workload tree_pred" [agg_three_value_columns]="--workload agg3" [c2_random_ids]="--workload c2_random" \
                 [c4_dup_keys]="--workload c4_dup" [c4_partial_match]="--workload c4_partial" [c4_dim_1e8]="--workload c4 --dim-rows 100000000" \
                 [c4_dim_1e7]="--workload c4 --dim-rows 10000000" [c4_shared_probe_columns]="--workload c4 --immutable" [c4_wide_payload]="--workload c4_wide" \
                 [agg_readme_shape]="--workload agg_readme" [headline_nullable]="--workload headline_nullable" [agg_1048576_groups]="--workload agg_groups --groups 1048576" )
-CONFIGS=${NQE_PROFILE_CONFIGS:-"headline headline_random_keys c3 c3_random_keys headline_single_column headline_int64_values headline_nullable agg_tree_predicate agg_three_value_columns agg_readme_shape c2 c2_random_ids c2_expression_trees c4 c4_shared_probe_columns c4_wide_payload c4_sparse_keys c4_dup_keys c4_partial_match c4_dim_1e7 c4_dim_1e8 agg_4096_groups agg_5000_groups agg_6000_groups agg_12000_groups_count_sum_avg agg_65536_groups agg_1048576_groups"}
+CONFIGS=${NQE_PROFILE_CONFIGS:-"headline headline_random_keys c3 c3_random_keys headline_single_column headline_int64_values headline_nullable agg_tree_predicate agg_three_value_columns agg_readme_shape c2 c2_random_ids c2_expression_trees c4 c4_shared_probe_columns c4_wide_payload c4_sparse_keys c4_dup_keys c4_partial_match c4_dim_1e7 c4_dim_1e8 agg_4096_groups agg_5000_groups agg_6000_groups agg_11000_groups agg_12000_groups_count_sum_avg agg_65536_groups agg_1048576_groups"}
 cd /tmp
 for name in $CONFIGS; do
   args="${WL[$name]} --no-configs --no-cpu-baseline"
