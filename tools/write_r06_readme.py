@@ -13,8 +13,8 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 
 | File | What |
 |---|---|
-| `bench_default.json`, `bench_details.json` | the default `python bench.py` line (27 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity, `frac_step` beside `frac`), per-kernel details |
-| `bench_default_run5.json` … `bench_default_run1.json`, `bench_default_box2.json` (+ `bench_details_*`) | the default line on six OTHER boxes of the pool in the course of the round (run5: the final csrc revision, the run the rocprofv3 / PMC files were made beside; run4: before the no-min/max instances; run3: before the register kernel's paired loads; run2: its C4 variants still compared on a sample; run1, box2: before the join build's partition policy): the headline kernel — the same throughout — 2.53 / 2.49 / 2.43 / 2.51 / 2.45 / 2.33 ms = 0.792 / 0.803 / 0.822 / 0.795 / 0.816 / 0.859 against `bench_default.json`'s 2.47 = 0.809.  The boxes differ by up to 8 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
+| `bench_default.json`, `bench_details.json` | the default `python bench.py` line (28 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity, `frac_step` beside `frac`, `roofline.traffic` measured by the run itself for the headline, C2, C3 and C4), per-kernel details — the LAST thing `tools/profile_round.sh` runs, ten minutes of profiling passes into the box's session: its headline kernel took 2.556 ms where the same box's rocprofv3 pass measured 2.37 and its no-plan-hints line (the FIRST thing run) 2.30 |
+| `bench_default_run6.json` … `bench_default_run1.json`, `bench_default_box2.json` (+ `bench_details_*`) | the default line on seven OTHER boxes of the pool in the course of the round (run6: csrc revision ae0edf8b5bf85f99 — before the two-subset changes and the live traffic passes; run5: the final csrc revision, the run the rocprofv3 / PMC files were made beside; run4: before the no-min/max instances; run3: before the register kernel's paired loads; run2: its C4 variants still compared on a sample; run1, box2: before the join build's partition policy): the headline kernel — the same throughout — 2.53 / 2.49 / 2.43 / 2.51 / 2.45 / 2.33 ms = 0.792 / 0.803 / 0.822 / 0.795 / 0.816 / 0.859 against `bench_default.json`'s 2.47 = 0.809.  The boxes differ by up to 8 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
 | `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
 | `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
 | `rocprofv3_kernel_stats_<config>.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --workload … --steps 20 --warmup 3` (its own process: the table below compares its averages with the bench line's HIP-event times) — **C3 and C3 over random keys included** (round 5 had none) |
@@ -29,6 +29,7 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | `probe_build_fine_bins.txt` | the two-level join build by fine bins per partition (4 … 64), sweeps and alternating A/B runs on one box |
 | `ab_soa_threads.txt` | the many-group aggregate's scatter at 512 × 2, 256 × 4 and 1024 × 1 threads × workgroups per CU |
 | `pmc_study.txt` | SQ counters (instructions per row, VALU / LDS busy, bank conflicts, waiting share) of the many-group aggregate's scatter and segments kernels and of the headline kernel |
+| `ab_sub_plain_loads.txt`, `pair_bench.txt` | two key subsets: plain against non-temporal loads, the wider equal halves, rows per lane; `tools/pair_bench.hip` — two workgroups of one XCD streaming the same tiles (free-running with nt / plain loads, leader throttled on a progress word) |
 | `../r06_notes.md` | the raw measurement notes the sections of DESIGN.md were written from |
 
 ## The bench line
@@ -50,6 +51,14 @@ another box and — where the last column says so — another definition.
   per 10⁸ rows = 0.37 → **0.71** of 8 TB/s (`ab_wide_direct.txt`).
 * **… and 13632 keys without min / max** (`agg_12000_groups_count_sum_avg`, new): count / sum / avg through the instance without min /
   max arrays, 12 B per slot: 6000–13632 groups 0.33–0.35 ms per step where the five-aggregate list takes 0.58–0.84 (`probe_no_minmax.txt`).
+* **Two key subsets: 2 × 5840 keys (2 × 13632 without min / max), plain loads** (`agg_11000_groups`, new; `agg_6000_groups`): the subset
+  instances' loads are plain instead of non-temporal — the XCD's L2 now serves the second reader (PMC traffic 1.73 → **1.03×**), 6000 /
+  8000 groups 0.52 / 0.51 → 0.48 / 0.49 ms of kernel time; the subsets are the two equal halves of the measured range, each as wide as a
+  table without key words gets: **8193–11680 groups 0.80–0.86 → 0.49–0.50 ms**, count / sum / avg over **13633–27264 groups 0.58–0.84 →
+  0.43–0.45** (`ab_sub_plain_loads.txt`, `pair_bench.txt`: one reader / a free-running pair with nt loads / plain loads / a throttled pair;
+  `pmc_study.txt`: the pair is issue-bound now — 78 + 78 vector + scalar instructions per row against 27 + 33).
+* **`roofline.traffic` is measured by the run that prints it** (headline, C2, C3, C4): `rocprofv3 --pmc` child passes after the timed
+  region, calibrated in the same run on `tools/stream_bench`; ≈ 20 s; the quoted figure stays beside it (`traffic_quoted`).
 * **The 10⁸-row join build 4.27 → 2.54 ms** (key + one payload; key only 2.23 → 1.58; 2²⁵ rows 1.53 → 0.88): a second partition
   level — fine histogram in the count pass, one workgroup per partition sorting its tuples by 8192-key fine bin, LDS fill of the FINAL
   tables in whole lines — replaces the place pass (one scattered 16-byte store per row: 1.9 ms), the zeroed key-ordered records and
@@ -69,12 +78,12 @@ another box and — where the last column says so — another definition.
 * **Measurement**: `frac_step` on every config; C2's kernel set includes the scan; C3 profiled like every other config.
 * **Structure**: 32 of round 5's 56 environment switches retired (constants; the forms that lost are deleted: the striped keep pass,
   one-tile-per-wave selection kernels, the 1024-thread scatter instances, eight-rows-per-lane expression instance …); `aggregate.hip`
-  3035 → 2290 lines (`aggregate_tail.hip`); library 29.9 → 28.4 MB, clean build 4 → 3 min (29.3 MB with the twelve no-min/max instances added afterwards).
+  3035 → 2290 lines (`aggregate_tail.hip`); library 29.9 → 28.4 MB, clean build 4 → 3 min (29.3 MB with the 24 no-min/max instances added afterwards; where the 29 MB are, and the one fold that would take 5.7 MB off at +3.5 % on C3 over random keys: `../r06_notes.md`).
 
 ## Open
 
 More than one physical GPU (C5, the xGMI numbers — the preflight is there for the first contact); the three-pass many-group
-aggregate's 40 B/row; `c2_expression_trees` (0.55–0.56); joins beyond L2 (line-fetch floor); 5841–8192 groups (two key subsets, 0.38);
+aggregate's 40 B/row; `c2_expression_trees` (0.55–0.56); joins beyond L2 (line-fetch floor); 5841–11680 groups (two key subsets, 0.40: issue-bound);
 the join build's two scatters (4.1 TB/s of 3.2 GB each).
 """
 open("profiles/r06/README.md", "w").write(text)
