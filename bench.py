@@ -433,10 +433,24 @@ def _pmc_pass(counter, cmd, workdir, timeout_s):
     import csv
     import subprocess
 
+    import signal
+
     env = dict(os.environ, TMPDIR="/tmp")
     d = os.path.join(workdir, counter.lower())
-    subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "live", "--"] + cmd,
-                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+    # its own session: a pass that outlives its time limit is killed with everything it started (rocprofv3 is a launcher around the workload)
+    proc = subprocess.Popen(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "live", "--"] + cmd,
+                            cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+    try:
+        rc = proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.wait()
+        raise
+    if rc != 0:
+        raise RuntimeError(f"rocprofv3 --pmc {counter} exited with {rc}")
     acc = {}
     for root, _, files in os.walk(d):
         for fn in files:
@@ -460,11 +474,12 @@ class LiveTraffic:
     `traffic_quoted`.  Any failure (no rocprofv3, a profiler already attached, a time-out) leaves the quoted figure in place and
     says why."""
 
-    def __init__(self, timeout_s=90.0):
+    def __init__(self, timeout_s=60.0, budget_s=150.0):
         import shutil
         import tempfile
 
-        self.timeout_s, self.why_not, self.factors, self.basis, self.work = timeout_s, None, None, None, None
+        # (a pass takes 2-4 s; `budget_s` bounds all of them together, and the first pass that fails ends the measuring for the run)
+        self.timeout_s, self.why_not, self.factors, self.basis, self.work, self.deadline = timeout_s, None, None, None, None, time.time() + budget_s
         if shutil.which("rocprofv3") is None:
             self.why_not = "no rocprofv3 on PATH"
         elif any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
@@ -500,10 +515,13 @@ class LiveTraffic:
 
     def measure(self, roof, config_name, workload_args):
         """→ True when roof['traffic'] now holds this run's measurement"""
+        if not self.why_not and time.time() + 10.0 > self.deadline:
+            self.why_not = "the run's time budget for the counter passes is spent"
         if self.why_not:
             roof["traffic_live"] = "not measured: " + self.why_not
             return False
         t0 = time.time()
+        self.timeout_s = max(5.0, min(self.timeout_s, self.deadline - time.time()))
         try:
             from tools.profile_configs import CONFIGS
 
@@ -534,7 +552,8 @@ class LiveTraffic:
                                     f"({disp} dispatches per pass; fetch x {self.factors[0]:.4g}, write x {self.factors[1]:.4g}, {self.basis}; {time.time() - t0:.0f} s)")
             return True
         except Exception as e:  # noqa: BLE001 - the line must come out whatever the profiler does
-            roof["traffic_live"] = f"not measured: {type(e).__name__}: {str(e)[:120]}"
+            self.why_not = f"{type(e).__name__}: {str(e)[:120]}"  # … and no later config tries again
+            roof["traffic_live"] = "not measured: " + self.why_not
             return False
 
 

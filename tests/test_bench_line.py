@@ -126,3 +126,31 @@ def test_live_traffic_arithmetic(monkeypatch, tmp_path):
         assert abs(roof["traffic"] - exp) < 1.0, (roof["traffic"], exp)
     assert roof["traffic_quoted"] == 1.7e9 and roof["traffic_live"].startswith("measured by this run")
     assert abs(roof["traffic_ratio"] - roof["traffic"] / 2.0e9) < 1e-12
+
+
+def test_live_traffic_stops_at_its_time_budget_and_after_a_failed_pass(monkeypatch, tmp_path):
+    fake_bin = tmp_path / "rocprofv3"
+    fake_bin.write_text("#!/bin/sh\nexit 0\n")
+    fake_bin.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path))
+    for k in [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_"))]:
+        monkeypatch.delenv(k)
+    lt = bench.LiveTraffic(budget_s=0.0)
+    roof = {"traffic": 1.0, "algorithmic_bytes_per_step": 1.0}
+    assert lt.measure(roof, "c2", ["--workload", "c2"]) is False and "time budget" in roof["traffic_live"]
+    lt.close()
+    calls = []
+
+    def failing_pass(counter, cmd, workdir, timeout_s):
+        calls.append(counter)
+        raise RuntimeError("rocprofv3 --pmc FETCH_SIZE exited with 1")
+
+    monkeypatch.setattr(bench, "_pmc_pass", failing_pass)
+    lt = bench.LiveTraffic()
+    lt.factors, lt.basis = (2.0, 1.0), "test"
+    r1, r2 = dict(roof), dict(roof)
+    assert lt.measure(r1, "headline", ["--workload", "headline"]) is False
+    assert lt.measure(r2, "c2", ["--workload", "c2"]) is False
+    lt.close()
+    assert len(calls) == 1, calls   # the second config did not try again
+    assert r1["traffic"] == 1.0 and r2["traffic"] == 1.0 and "exited with 1" in r2["traffic_live"]
