@@ -3042,3 +3042,25 @@ def test_aggregate_block_scatter_forms(ctx, shape):
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{shape} rep {rep}")
         kk = gk.to_host()[0].to_numpy()
         assert (np.diff(kk) > 0).all(), f"{shape}: keys not in order"
+
+
+@pytest.mark.parametrize("tiles", [1, 4095, 4096, 4097, 8193, 24575, 24576, 24577, 30001])
+def test_selection_tile_offsets_across_the_scan_forms(ctx, tiles):
+    """The tile counts of a selection are scanned by ONE workgroup up to 6 x 4096 tiles (every thread 24 consecutive counts, one wave scan:
+    round 6) and by the chunked recursive scan beyond: row counts around every boundary, ragged last tiles, kept rows checked against numpy
+    (count, every kept value through a checksum, first and last).  selection.rs:58-107"""
+    rng = np.random.default_rng(tiles)
+    n = tiles * 4096 - int(rng.integers(0, 4095)) if tiles > 1 else 1234
+    ids = rng.integers(0, 1000, n).astype(np.int64)
+    v = np.arange(n, dtype=np.int64)
+    t = ctx.table_from_host([Column.from_numpy(ids), Column.from_numpy(v)])
+    f2 = fields("id", "v")
+    for lim in (0, 137, 1000):
+        pred = binop(col(0), Operator.Lt, lit_i64(lim)).flatten(f2)
+        got = ctx.selection(t, pred)
+        keep = ids < lim
+        assert got.num_rows == int(keep.sum()), (tiles, lim)
+        out = got.to_host()
+        gv = out[1].to_numpy()
+        assert (gv == v[keep]).all(), (tiles, lim)
+        assert (out[0].to_numpy() == ids[keep]).all(), (tiles, lim)
