@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../naive_query_engine_amd/csrc"
 D=_var_$NAME
 mkdir -p $D
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-CXX="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -fno-gpu-rdc $FLAGS"
+CXX="-O3 -std=c++17 -fPIC --offload-arch=gfx950 --offload-compress -munsafe-fp-atomics -Wall -Wno-unused-function -fno-gpu-rdc $FLAGS"
 pids=()
 for f in context exchange arrow_c expr selection sort aggregate aggregate_tail aggregate_fast aggregate_partition aggregate_tiny hash_join strings csv; do
   ( $HIPCC $CXX -c $f.hip -o $D/$f.o ) & pids+=($!)
