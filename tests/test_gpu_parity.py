@@ -3064,3 +3064,41 @@ def test_selection_tile_offsets_across_the_scan_forms(ctx, tiles):
         gv = out[1].to_numpy()
         assert (gv == v[keep]).all(), (tiles, lim)
         assert (out[0].to_numpy() == ids[keep]).all(), (tiles, lim)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NQE_SWEEP_SEED_BASE", "0")), int(os.environ.get("NQE_SWEEP_SEED_BASE", "0")) + int(os.environ.get("NQE_SWEEP_SEEDS", "16"))))
+def test_aggregate_direct_tables_random_sweep(ctx, seed):
+    """Random spans around every limit of the directly addressed tables (one table 4096 / 5840 / 13632 keys, two subsets 2 x 5840 / 2 x 13632,
+    the range tier beyond), random bases (negative, beyond 2^40, UInt64 above 2^63), with and without min / max, with and without a
+    predicate, Int64 and Float64 values: three executions each (sampled plan, remembered plan, again) against the oracle, keys in order."""
+    rng = np.random.default_rng(9000 + seed)
+    limits = [4096, 5840, 8192, 11680, 13632, 16384, 27264]
+    span = int(rng.choice(limits)) + int(rng.integers(-3, 4)) if seed % 2 == 0 else int(rng.integers(4097, 30000))
+    span = max(span, 2)
+    n = int(rng.integers(600_000, 1_500_000))
+    unsigned = bool(rng.integers(0, 4) == 0)
+    base = int(rng.choice([0, -span // 2, -10**9, 1 << 41, 7])) if not unsigned else int(rng.choice([0, (1 << 63) + 12345, 1 << 50]))
+    draw = rng.integers(0, span, n)
+    draw[:2] = [0, span - 1]
+    if rng.integers(0, 3) == 0:  # every other value only: a range twice as wide as its keys
+        draw = (draw // 2) * 2
+        draw[:2] = [0, (span - 1) // 2 * 2]
+    k = (draw.astype(np.uint64) + np.uint64(base)) if unsigned else (draw + base).astype(np.int64)
+    int_values = bool(rng.integers(0, 2))
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64) if int_values else rng.random(n) * 200.0 - 100.0
+    w = rng.random(n)
+    nomm = bool(rng.integers(0, 2))
+    with_pred = bool(rng.integers(0, 3) == 0)
+    aggs = [(AggregateFunc.Count, 1), (AggregateFunc.Sum, 1), (AggregateFunc.Avg, 1)] if nomm else ALL_AGGS(1)
+    f3 = fields("k", "v", "w")
+    cols = [Column.from_numpy(k), Column.from_numpy(v), Column.from_numpy(w)]
+    key = col(0).flatten(f3)
+    pred = binop(col(2), Operator.Lt, lit_f64(0.6)).flatten(f3) if with_pred else None
+    exp = orc.aggregate([cols], aggs, group_nodes=key, pred_nodes=pred)[0]
+    t = ctx.table_from_host(cols)
+    what = f"seed {seed}: span {span} base {base} unsigned {unsigned} nomm {nomm} pred {with_pred} int values {int_values}"
+    for rep in range(3):
+        got, gk = ctx.aggregate(t, aggs, group_nodes=key, pred_nodes=pred, with_keys=True)
+        assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{what}, run {rep}")
+        kk = gk.to_host()[0].to_numpy()
+        assert len(np.unique(kk)) == len(kk) == got.num_rows, what
