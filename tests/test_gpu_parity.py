@@ -3102,3 +3102,41 @@ def test_aggregate_direct_tables_random_sweep(ctx, seed):
         assert_rows_multiset_equal(got.to_host(), exp, RTOL, exact_cols=[0], what=f"{what}, run {rep}")
         kk = gk.to_host()[0].to_numpy()
         assert len(np.unique(kk)) == len(kk) == got.num_rows, what
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NQE_SWEEP_SEED_BASE", "0")), int(os.environ.get("NQE_SWEEP_SEED_BASE", "0")) + int(os.environ.get("NQE_SWEEP_SEEDS", "12"))))
+def test_join_two_level_build_random_sweep(ctx, monkeypatch, seed):
+    """The two-level partitioned build over random sizes and key ranges (one partition ... hundreds, 1 ... 64 fine bins per partition, ranges
+    that end inside a bin), key density 1 / 2 / 7 (holes), no payload / a bit-packed / a 32-bit / an 8-byte payload column, a few duplicate
+    keys in some (-> the sort-based build): the join's rows, in order, against the oracle; the table reused for a second probe.
+    hash_join.rs:124-254"""
+    monkeypatch.setenv("NQE_JOIN_PART_BUILD_MIN", "1000")
+    rng = np.random.default_rng(31000 + seed)
+    nb = int(rng.choice([5_000, 70_000, 300_000, 1_100_000, 3_000_000])) + int(rng.integers(0, 999))
+    density = int(rng.choice([1, 1, 2, 7]))
+    base = int(rng.choice([0, 12345, -(10**9), 1 << 40]))
+    dk = (rng.permutation(density * nb)[:nb]).astype(np.int64) + base
+    dup = rng.integers(0, 5) == 0
+    if dup:
+        dk[rng.integers(0, nb, 5)] = dk[rng.integers(0, nb, 5)]
+    left = [Column.from_numpy(dk)]
+    payload = int(rng.integers(0, 4))
+    if payload == 1:
+        left.append(Column.from_numpy(rng.integers(0, 1 << int(rng.integers(2, 25)), nb).astype(np.int64) - 5))
+    elif payload == 2:
+        left.append(Column.from_numpy(rng.integers(0, 1 << 31, nb).astype(np.int64)))
+    elif payload == 3:
+        left.append(Column.from_numpy(rng.random(nb)))
+    n = int(rng.integers(50_000, 300_000))
+    rk = rng.integers(int(dk.min()) - 5, int(dk.max()) + 6, n).astype(np.int64)
+    rk[: min(n, 1000)] = dk[rng.integers(0, nb, min(n, 1000))]
+    right = [Column.from_numpy(rk), Column.from_numpy(rng.random(n))]
+    exp = orc.hash_join([left], [right], 0, 0)[0]
+    lt, rt = ctx.table_from_host(left), ctx.table_from_host(right)
+    what = f"seed {seed}: {nb} build rows, density {density}, base {base}, payload {payload}, dup {bool(dup)}"
+    assert_batches_equal(ctx.hash_join(lt, rt, 0, 0).to_host(), exp, what=what)
+    jt = ctx.hash_join_build(lt, 0)
+    rk2 = rk[::-1].copy()
+    right2 = [Column.from_numpy(rk2), Column.from_numpy(rng.random(n))]
+    exp2 = orc.hash_join([left], [right2], 0, 0)[0]
+    assert_batches_equal(ctx.hash_join_probe(jt, ctx.table_from_host(right2), 0).to_host(), exp2, what=what + ", reused table")
