@@ -798,7 +798,7 @@ def wl_c2(B, rows, steps, warmup, random_ids=False, blocks=1, cold=False):
     step = lambda: B.ctx.selection_projection(table, pred, proj)
     cold_ms = B.cold(step) if cold else None
     ms, kernels, spread = B.timed(step, steps, warmup, blocks)
-    names = ["select_fused", "keep_from_simple", "scan_single", "scan_chunk", "scan_add", "compact_expr"]  # (the scan of the tile counts runs every step: 13 us of ~290)
+    names = ["select_fused", "keep_from_simple", "scan_single", "scan_chunk", "scan_add", "compact_expr"]  # (the scan of the tile counts runs every step: 9.5 us of ~285)
     # 16 B/row read + 8 B per kept row written = 20 B/row at 50 %.  The compaction does not read the source words of
     # 4096-row tiles in which nothing was kept: with ids = row numbers the kept rows are the first half, so only that half of `age`
     # moves (16 B/row) — §8d forbids taking that as skip credit, so for sorted ids `frac` is quoted on the bytes that MOVE and the

@@ -236,9 +236,63 @@ __global__ void __launch_bounds__(1024) scan_single_kernel(const Tin *in, int64_
     }
 }
 
+// the same scan by one workgroup PER CHUNK with no hand-over between them (round 6): workgroup c adds up everything in front of its chunk
+// itself — (c + 1) x 16 KB of reads that hit L2 — and scans its own 4096 entries.  What bounded the one-workgroup form was one CU moving
+// 98 KB in and 195 KB out (13.4-14.4 us for the 24 415 tile counts of a 10^8-row selection, whatever its scans cost:
+// profiles/r06_notes.md); here the stores are spread over the chunks' CUs: 9.5 us.  Up to SCAN_REDUNDANT_MAX chunks (the redundant reads grow with
+// the square: 32 chunks = 8.6 MB); `out` must not alias `in`.
+constexpr int SCAN_REDUNDANT_MAX = 32;
+template <typename Tin, typename Tout>
+__global__ void __launch_bounds__(1024) scan_redundant_kernel(const Tin *__restrict__ in, int64_t n_in, Tout *__restrict__ out, int64_t n_out) {
+    __shared__ Tout wave_tot[2][16];
+    const int wv = threadIdx.x / 64;
+    const int64_t lo = int64_t(blockIdx.x) * SCAN_CHUNK; // (<= n_in: the last chunk starts at or before entry n_in, the total)
+    const int64_t base = lo + int64_t(threadIdx.x) * 4;
+    Tin v[4];
+    Tout s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = base + k < n_in ? in[base + k] : Tin(0);
+        s += Tout(v[k]);
+    }
+    Tout before = 0; // this thread's share of the entries in front of the chunk
+    for (int64_t i = int64_t(threadIdx.x) * 4; i < lo; i += SCAN_CHUNK) { // (requesting four chunks' words at a time measured the same)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) before += Tout(in[i + k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    Tout x = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Tout y = __shfl_up(x, d, 64);
+        if (lane_id() >= d) x += y;
+    }
+    if (lane_id() == 63) {
+        wave_tot[0][wv] = x;
+        wave_tot[1][wv] = before;
+    }
+    __syncthreads();
+    Tout pre = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wv) pre += wave_tot[0][w];
+        pre += wave_tot[1][w];
+    }
+    Tout run = pre + (x - s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n_out) out[base + k] = run;
+        run += Tout(v[k]);
+    }
+}
+
 template <typename Tin, typename Tout> void scan_impl(nqe_ctx *ctx, const Tin *in, int64_t n_in, Tout *out, int64_t n_out) {
     if (n_out <= 0) return;
     int64_t nchunks = (n_out + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (nchunks > 1 && nchunks <= SCAN_REDUNDANT_MAX && static_cast<const void *>(in) != static_cast<const void *>(out)) {
+        launch(ctx, "scan_single", scan_redundant_kernel<Tin, Tout>, dim3(unsigned(nchunks)), dim3(1024), 0, in, n_in, out, n_out);
+        return;
+    }
     if (nchunks > 1 && nchunks <= scan_single_max_chunks<Tin, Tout>()) {
         launch(ctx, "scan_single", scan_single_kernel<Tin, Tout>, dim3(1), dim3(1024), 0, in, n_in, out, n_out);
         return;

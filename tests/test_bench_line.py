@@ -111,8 +111,8 @@ def test_live_traffic_arithmetic(monkeypatch, tmp_path):
         if cmd[-1] == "calib":   # stream_bench: 16e9 B read is reported as 8e9 B (factor 2); 6.4e9 B written as 6.4e9 B
             return {"read2<4,0>": (8e9 / 1024, 3)} if counter == "FETCH_SIZE" else {"void copy_rw<4, 0, 4, 1>(...)": (6.4e9 / 1024, 3)}
         if counter == "FETCH_SIZE":
-            return {"keep_from_range_tile_kernel<..>": (0.2e9 / 1024, 4), "scan_single_kernel": (1e3 / 1024, 4), "compact_staged_kernel<0>": (0.4e9 / 1024, 4)}
-        return {"keep_from_range_tile_kernel<..>": (0.0125e9 / 1024, 4), "scan_single_kernel": (1e3 / 1024, 4), "compact_staged_kernel<0>": (0.4e9 / 1024, 4)}
+            return {"keep_from_range_tile_kernel<..>": (0.2e9 / 1024, 4), "scan_redundant_kernel<unsigned int, unsigned long>": (1e3 / 1024, 4), "compact_staged_kernel<0>": (0.4e9 / 1024, 4)}
+        return {"keep_from_range_tile_kernel<..>": (0.0125e9 / 1024, 4), "scan_redundant_kernel<unsigned int, unsigned long>": (1e3 / 1024, 4), "compact_staged_kernel<0>": (0.4e9 / 1024, 4)}
 
     monkeypatch.setattr(bench, "_pmc_pass", fake_pass)
     lt = bench.LiveTraffic()

@@ -4,7 +4,7 @@
 CONFIGS = {
     "headline": ({"agg_grouped_fast_kernel": 1}, 16e9),
     "headline_random_keys": ({"agg_grouped_fast_kernel": 1}, 16e9),
-    "c2": ({"keep_from_range_tile_kernel": 1, "scan_single_kernel": 1, "compact_staged_kernel": 1}, 2.0e9),
+    "c2": ({"keep_from_range_tile_kernel": 1, "scan_redundant_kernel": 1, "compact_staged_kernel": 1}, 2.0e9),
     "c3": ({"agg_grouped_fast_kernel": 1}, 16e9),
     "c3_random_keys": ({"agg_grouped_fast_kernel": 1}, 16e9),
     "c4": ({"join_sample_range_kernel": 1, "join_fused_write_kernel": 1}, 4.816e9),
@@ -19,7 +19,7 @@ CONFIGS = {
     "agg_12000_groups_count_sum_avg": ({"agg_grouped_fast_kernel": 1, "agg_fold_partials_kernel": 1, "agg_range_emit_kernel": 1}, 1.6e9),
     "agg_6000_groups": ({"agg_grouped_fast_kernel": 1, "agg_fold_partials_kernel": 1, "agg_range_emit_kernel": 1}, 1.6e9),
     "agg_11000_groups": ({"agg_grouped_fast_kernel": 1, "agg_fold_partials_kernel": 1, "agg_range_emit_kernel": 1}, 1.6e9),
-    "c2_random_ids": ({"keep_from_range_tile_kernel": 1, "scan_single_kernel": 1, "compact_staged_kernel": 1}, 2.0e9),
+    "c2_random_ids": ({"keep_from_range_tile_kernel": 1, "scan_redundant_kernel": 1, "compact_staged_kernel": 1}, 2.0e9),
     "c2_expression_trees": ({"nqe_jit_selproj": 1}, 2.4e9),
     "agg_readme_shape": ({"agg_tiny_groups_kernel": 1, "agg_fold_partials_kernel": 3}, 24e9),
     "headline_nullable": ({"agg_grouped_fast_kernel": 1}, 16.125e9),

@@ -51,8 +51,8 @@ NOTES = {
     "agg_12000_groups_count_sum_avg": "new in round 6 (count / sum / avg only: 12-byte slots, one workgroup table up to 13632 keys; with min / max the same keys take the range tier: 0.84 ms per step, probe_no_minmax.txt)",
     "agg_6000_groups": "round 6: plain (not non-temporal) loads in the subset instances, equal halves of the range (ab_sub_plain_loads.txt)",
     "agg_11000_groups": "new in round 6 (two key subsets, each half of the range in a table without key words: up to 2 x 5840 keys; before: the range tier, 0.86 ms per step)",
-    "c2": "kernel time now includes the tile-count scan (scan_single, 13 us)",
-    "c2_random_ids": "kernel time now includes the tile-count scan (scan_single, 13 us)",
+    "c2": "kernel time now includes the tile-count scan (13 us as one workgroup; 9.5 us since the scan runs one workgroup per 4096 counts)",
+    "c2_random_ids": "kernel time now includes the tile-count scan (9.5 us)",
     "c2_expression_trees": "",
     "agg_three_value_columns": "parity now over all 10^9 rows (r05: 2 x 10^7)",
     "agg_readme_shape": "parity now over all 10^9 rows (r05: 2 x 10^7)",
