@@ -14,7 +14,7 @@ file by `tools/write_r06_readme.py`. Every `pmc_traffic_*.json` and `summary.jso
 | File | What |
 |---|---|
 | `bench_default.json`, `bench_details.json` | the default `python bench.py` line (28 configs + 3 drop-in rows, `upload`, `cold_ms`, both CPU numbers, full-size parity, `frac_step` beside `frac`, `roofline.traffic` measured by the run itself for the headline, C2, C3 and C4), per-kernel details — the LAST thing `tools/profile_round.sh` runs, ten minutes of profiling passes into the box's session: its headline kernel 2.536 ms = 0.79 (the same box's rocprofv3 pass: see the table) |
-| `bench_default_run9.json` … `bench_default_run1.json`, `bench_default_box2.json` (+ `bench_details_*`) | the default line on ten OTHER boxes of the pool in the course of the round (run9: csrc revision 9831d19a4b4fc04f — before the one-workgroup-per-chunk scan — at the end of ITS profile round: 2.529 ms; run8: the previous profile round's last line, csrc revision d6027f4aa3c11eaa = the same sources with uncompressed code objects — 2.556 ms where its box's rocprofv3 pass had measured 2.37; run7: the final tree on a FRESH box, the first thing run there — headline kernel 2.584 ms = 0.774, the slowest box of the round; the headline instance's machine code is instruction for instruction the one run6 ran, checked by compiling both revisions to assembly; run6: csrc revision ae0edf8b5bf85f99 — before the two-subset changes and the live traffic passes; run5: the final csrc revision, the run the rocprofv3 / PMC files were made beside; run4: before the no-min/max instances; run3: before the register kernel's paired loads; run2: its C4 variants still compared on a sample; run1, box2: before the join build's partition policy): the headline kernel — the same throughout — 2.53 / 2.49 / 2.43 / 2.51 / 2.45 / 2.33 ms = 0.792 / 0.803 / 0.822 / 0.795 / 0.816 / 0.859 against `bench_default.json`'s 2.47 = 0.809.  The boxes differ by up to 8 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
+| `bench_default_run10.json` … `bench_default_run1.json`, `bench_default_box2.json` (+ `bench_details_*`) | the default line on eleven OTHER boxes of the pool in the course of the round (run10: the FINAL tree on a fresh box, the first thing run there: headline kernel 2.507 ms = 0.798, step 2.559 ms; run9: csrc revision 9831d19a4b4fc04f — before the one-workgroup-per-chunk scan — at the end of ITS profile round: 2.529 ms; run8: the previous profile round's last line, csrc revision d6027f4aa3c11eaa = the same sources with uncompressed code objects — 2.556 ms where its box's rocprofv3 pass had measured 2.37; run7: the final tree on a FRESH box, the first thing run there — headline kernel 2.584 ms = 0.774, the slowest box of the round; the headline instance's machine code is instruction for instruction the one run6 ran, checked by compiling both revisions to assembly; run6: csrc revision ae0edf8b5bf85f99 — before the two-subset changes and the live traffic passes; run5: the final csrc revision, the run the rocprofv3 / PMC files were made beside; run4: before the no-min/max instances; run3: before the register kernel's paired loads; run2: its C4 variants still compared on a sample; run1, box2: before the join build's partition policy): the headline kernel — the same throughout — 2.53 / 2.49 / 2.43 / 2.51 / 2.45 / 2.33 ms = 0.792 / 0.803 / 0.822 / 0.795 / 0.816 / 0.859 against `bench_default.json`'s 2.47 = 0.809.  The boxes differ by up to 8 % on this kernel, which is why the line carries `kernel_ms_min/_max` and this table the rocprofv3 column |
 | `bench_no_plan_hints.json`, `bench_details_no_plan_hints.json` | the same line under `NQE_NO_PLAN_HINTS=1`: nothing remembered between executions |
 | `probe_cold.txt` | first execution / steady state of 12 query shapes, each in a FRESH process |
 | `rocprofv3_kernel_stats_<config>.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --workload … --steps 20 --warmup 3` (its own process: the table below compares its averages with the bench line's HIP-event times) — **C3 and C3 over random keys included** (round 5 had none) |
